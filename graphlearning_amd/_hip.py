@@ -1,0 +1,284 @@
+"""ctypes binding of libglx.so (include/glx.h): the only way the package reaches the GPU.
+
+There is NO CPU fallback: if the library is missing or no MI355X is visible the calls
+raise GlxError.  The library is loaded lazily (first use), so importing the package
+never creates HIP state -- safe for the joblib process pools the reference's
+ssl_trials uses (reference graphlearning/ssl.py:390-396).
+"""
+import os
+import ctypes as C
+import numpy as np
+
+GLX_F32, GLX_F64 = 0, 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libglx.so')
+_lib = None
+
+
+class GlxError(RuntimeError):
+    pass
+
+
+def _dt(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return GLX_F32
+    if dtype == np.float64:
+        return GLX_F64
+    raise GlxError('unsupported dtype %s (float32 or float64)' % dtype)
+
+
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+_f32p = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+# name -> (argtypes); every function returns int status unless listed in _SPECIAL
+_SIGNATURES = {
+    'glx_version': [],
+    'glx_device_count': [C.POINTER(C.c_int)],
+    'glx_set_device': [C.c_int],
+    'glx_device_synchronize': [],
+    'glx_graph_create': [C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)],
+    'glx_graph_destroy': [_vp],
+    'glx_graph_info': [_vp, _i64p],
+    'glx_spmm_bias': [_vp, _vp, _vp, _vp, C.c_int, C.c_int],
+    'glx_poisson_sweep': [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_int)],
+    'glx_sweep_create': [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)],
+    'glx_sweep_set_problem': [_vp, _vp, _vp, _vp, _vp],
+    'glx_sweep_run': [_vp, C.POINTER(C.c_int), C.POINTER(C.c_float)],
+    'glx_sweep_fetch': [_vp, _vp],
+    'glx_sweep_launches': [_vp, _i64p],
+    'glx_sweep_destroy': [_vp],
+    'glx_sweep_set_state': [_vp, _vp, _vp],
+    'glx_sweep_iterate': [_vp, C.c_int],
+    'glx_cg_multi': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), _f64p],
+    'glx_argmax_project': [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
+    'glx_knn_bruteforce': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
+    'glx_knn_stats': [_f64p],
+}
+_SPECIAL = {'glx_last_error': ([], C.c_char_p), 'glx_free': ([_vp], None)}
+
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SPECIAL))
+
+
+def load(required=True):
+    """Load libglx.so (once).  Raises GlxError when it is absent -- build it with
+    `python -m graphlearning_amd._build` or `__graft_entry__.build()`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if required:
+            raise GlxError('libglx.so not found at %s: the HIP extension is not built '
+                           '(python -m graphlearning_amd._build). There is no CPU fallback.' % LIB_PATH)
+        return None
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name, (args, res) in _SPECIAL.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().glx_last_error()
+        raise GlxError('%s failed (%d): %s' % (what or 'libglx call', rc, msg.decode() if msg else '?'))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().glx_device_count(C.byref(n)), 'glx_device_count')
+    return n.value
+
+
+def require_device():
+    try:
+        n = device_count()
+    except GlxError as e:
+        raise GlxError('no usable HIP device: %s' % e)
+    if n < 1:
+        raise GlxError('no HIP device visible; graphlearning_amd has no CPU fallback')
+    return n
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _dense(a, dtype, shape=None, name='array'):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise GlxError('%s has shape %s, expected %s' % (name, a.shape, tuple(shape)))
+    return a
+
+
+class DeviceGraph:
+    """A sparse operator resident in HBM (glx_graph).  `A` is any scipy sparse matrix;
+    the CSR entry order is preserved (see include/glx.h)."""
+
+    def __init__(self, A, dtype=np.float64, device=0, shape=None):
+        from scipy import sparse
+        A = sparse.csr_matrix(A)
+        self.dtype = np.dtype(dtype)
+        self.shape = A.shape if shape is None else shape
+        self.nnz = int(A.nnz)
+        self.device = device
+        rowptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        col = np.ascontiguousarray(A.indices, dtype=np.int32)
+        val = np.ascontiguousarray(A.data, dtype=np.float64)
+        self._h = _vp()
+        lib = load()
+        check(lib.glx_graph_create(self.shape[0], self.shape[1], self.nnz, _ptr(rowptr), _ptr(col), _ptr(val),
+                                   _dt(self.dtype), device, C.byref(self._h)), 'glx_graph_create')
+
+    def info(self):
+        out = (C.c_int64 * 8)()
+        check(load().glx_graph_info(self._h, out), 'glx_graph_info')
+        keys = ['n_rows', 'n_cols', 'nnz', 'stored', 'slices', 'rows_per_slice', 'max_row']
+        return dict(zip(keys, list(out)[:7]))
+
+    def spmm_bias(self, u, Db=None, iters=1):
+        """`iters` applications of u <- Db + A u (host arrays in, host array out)."""
+        u = np.ascontiguousarray(u, dtype=self.dtype)
+        if u.ndim == 1:
+            return self.spmm_bias(u[:, None], None if Db is None else np.asarray(Db)[:, None], iters)[:, 0]
+        if u.shape[0] != self.shape[1]:
+            raise GlxError('operand has %d rows, operator has %d columns' % (u.shape[0], self.shape[1]))
+        Cc = u.shape[1]
+        Dbc = None if Db is None else _dense(Db, self.dtype, (self.shape[0], Cc), 'Db')
+        out = np.empty((self.shape[0], Cc), dtype=self.dtype)
+        check(load().glx_spmm_bias(self._h, _ptr(Dbc), _ptr(u), _ptr(out), Cc, iters), 'glx_spmm_bias')
+        return out
+
+    def poisson_sweep(self, Db, w0, deg, vinf, min_iter=50, max_iter=1000):
+        Db = np.ascontiguousarray(Db, dtype=self.dtype)
+        n, Cc = Db.shape
+        w0 = _dense(w0, np.float64, (n,), 'w0')
+        deg = _dense(deg, np.float64, (n,), 'deg')
+        vinf = _dense(vinf, np.float64, (n,), 'vinf')
+        out = np.empty((n, Cc), dtype=self.dtype)
+        T = C.c_int(0)
+        check(load().glx_poisson_sweep(self._h, _ptr(Db), _ptr(w0), _ptr(deg), _ptr(vinf), Cc, min_iter, max_iter,
+                                       _ptr(out), C.byref(T)), 'glx_poisson_sweep')
+        return out, T.value
+
+    def cg(self, B, tol=1e-10, max_iter=100000):
+        """utils.conjgrad on device: returns (X, iterations, err)."""
+        B = np.ascontiguousarray(B, dtype=self.dtype)
+        squeeze = B.ndim == 1
+        if squeeze:
+            B = B[:, None]
+        X = np.empty_like(B)
+        it = C.c_int(0)
+        err = C.c_double(0)
+        check(load().glx_cg_multi(self._h, _ptr(B), _ptr(X), B.shape[1], float(tol), int(max_iter), C.byref(it),
+                                  C.byref(err)), 'glx_cg_multi')
+        return (X[:, 0] if squeeze else X), it.value, err.value
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            lib = load(required=False)
+            if lib is not None:
+                lib.glx_graph_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Sweep:
+    """Prepared Poisson / heat sweep (glx_sweep): device-resident state, repeated runs."""
+
+    def __init__(self, graph, Cc, min_iter=50, max_iter=1000, use_hipgraph=True):
+        self.graph = graph
+        self.C = Cc
+        self._h = _vp()
+        check(load().glx_sweep_create(graph._h, Cc, min_iter, max_iter, 1 if use_hipgraph else 0, C.byref(self._h)),
+              'glx_sweep_create')
+
+    def set_problem(self, Db, w0, deg, vinf):
+        n = self.graph.shape[0]
+        Db = _dense(Db, self.graph.dtype, (n, self.C), 'Db')
+        check(load().glx_sweep_set_problem(self._h, _ptr(Db), _ptr(_dense(w0, np.float64, (n,))),
+                                           _ptr(_dense(deg, np.float64, (n,))), _ptr(_dense(vinf, np.float64, (n,)))),
+              'glx_sweep_set_problem')
+
+    def run(self):
+        T = C.c_int(0)
+        ms = C.c_float(0)
+        check(load().glx_sweep_run(self._h, C.byref(T), C.byref(ms)), 'glx_sweep_run')
+        return T.value, ms.value
+
+    def set_state(self, u0, Db=None):
+        n = self.graph.shape[0]
+        u0 = None if u0 is None else _dense(u0, self.graph.dtype, (n, self.C), 'u0')
+        Db = None if Db is None else _dense(Db, self.graph.dtype, (n, self.C), 'Db')
+        check(load().glx_sweep_set_state(self._h, _ptr(u0), _ptr(Db)), 'glx_sweep_set_state')
+
+    def iterate(self, iters):
+        check(load().glx_sweep_iterate(self._h, int(iters)), 'glx_sweep_iterate')
+
+    def fetch(self):
+        out = np.empty((self.graph.shape[0], self.C), dtype=self.graph.dtype)
+        check(load().glx_sweep_fetch(self._h, _ptr(out)), 'glx_sweep_fetch')
+        return out
+
+    def launches(self):
+        n = C.c_int64(0)
+        check(load().glx_sweep_launches(self._h, C.byref(n)), 'glx_sweep_launches')
+        return n.value
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            lib = load(required=False)
+            if lib is not None:
+                lib.glx_sweep_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def argmax_project(prob, priors=None, weights=None, max_steps=0, similarity=True, device=0):
+    """ssl.predict / ssl.volume_label_projection on device.
+    Returns (labels int64, weights, err, steps)."""
+    prob = np.ascontiguousarray(prob, dtype=np.float64)
+    n, Cc = prob.shape
+    w = np.ones(Cc) if weights is None else np.array(weights, dtype=np.float64).reshape(Cc).copy()
+    pri = np.zeros(Cc) if priors is None else _dense(priors, np.float64, (Cc,), 'priors')
+    labels = np.empty(n, dtype=np.int64)
+    err = C.c_double(0)
+    steps = C.c_int(0)
+    check(load().glx_argmax_project(_ptr(prob), n, Cc, _ptr(pri), _ptr(w), _ptr(labels), C.byref(err), C.byref(steps),
+                                    int(max_steps), 1 if similarity else 0, device), 'glx_argmax_project')
+    return labels, w, err.value, steps.value
+
+
+def knn_bruteforce(X, k, similarity='euclidean', device=0):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, d = X.shape
+    sim = {'euclidean': 0, 'angular': 1}[similarity]
+    ind = np.empty((n, k), dtype=np.int64)
+    dist = np.empty((n, k), dtype=np.float64)
+    check(load().glx_knn_bruteforce(_ptr(X), n, d, k, sim, _ptr(ind), _ptr(dist), device), 'glx_knn_bruteforce')
+    return ind, dist
+
+
+def knn_stats():
+    out = (C.c_double * 8)()
+    check(load().glx_knn_stats(out), 'glx_knn_stats')
+    return dict(tile_ms=out[0], rerank_ms=out[1], fallback_rows=out[2], total_ms=out[3])

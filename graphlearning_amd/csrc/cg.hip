@@ -1,0 +1,297 @@
+// Multi right-hand-side conjugate gradient on device: utils.conjgrad of the reference
+// (graphlearning/utils.py:483-532) with x0 = 0.  Used by ssl.poisson (default solver,
+// ssl.py:624-629) and ssl.laplace (ssl.py:1249).  Per iteration: one sliced-ELL SpMM with
+// fused column dots, one fused x/r update with fused ||r||^2 partials, one p update, and
+// two single-block fixed-order reductions.  All reductions are deterministic (no float
+// atomics).  The host reads the residual history in chunks; kernels of iterations past
+// convergence exit at once (same trick as the sweep's stop column).
+#include "glx_internal.h"
+#include <string.h>
+#include <algorithm>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct V4Of;
+template <> struct V4Of<float> { typedef f32x4 type; };
+template <> struct V4Of<double> { typedef f64x4 type; };
+
+static const int CG_CHUNK = 8;
+static const int UPD_ROWS_PER_BLOCK = 256;
+
+struct CgScalars {
+  double* rsold;     // [ncols]
+  double* alpha;     // [ncols]
+  double* beta;      // [ncols]
+  double* err_hist;  // [max_hist+1], err_hist[0] = 1 (utils.py:519)
+};
+
+__device__ __forceinline__ bool cg_done(const double* err_hist, int it, double tol) {
+  return !(err_hist[it - 1] > tol);   // `while (err > tol)`, utils.py:521 (NaN stops the loop too)
+}
+
+// x += alpha p ; r -= alpha Ap ; partial[b][c] = sum_rows r^2           (utils.py:525-527)
+// MODE 0: that update.  MODE 1 (init): r = p = b given in r; partial = sum r^2 (utils.py:514-517)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void cg_update_kernel(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
+                                                        const T* __restrict__ Ap, const double* __restrict__ alpha,
+                                                        double* __restrict__ partial, int64_t n, int ld, int nvec,
+                                                        const double* err_hist, int it, double tol) {
+#pragma clang fp contract(off)
+  typedef typename V4Of<T>::type V4;
+  if (MODE == 0 && cg_done(err_hist, it, tol)) return;
+  __shared__ double s_part[256 * 4];
+  const int nvq = ld / 4;
+  const int rows_pass = 256 / nvq;
+  const int cv = threadIdx.x % nvq, rs = threadIdx.x / nvq;
+  const bool on = rs < rows_pass && cv < nvec;
+  double acc[4] = {0, 0, 0, 0};
+  V4 a = {0, 0, 0, 0};
+  if (MODE == 0 && on) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = (T)alpha[cv * 4 + e];
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * UPD_ROWS_PER_BLOCK;
+  const int64_t r1 = min(n, r0 + UPD_ROWS_PER_BLOCK);
+  if (on) {
+    for (int64_t row = r0 + rs; row < r1; row += rows_pass) {
+      const size_t o = (size_t)row * ld + cv * 4;
+      V4 rv = *(const V4*)(r + o);
+      if (MODE == 0) {
+        const V4 pv = *(const V4*)(p + o);
+        const V4 apv = *(const V4*)(Ap + o);
+        V4 xv = *(const V4*)(x + o);
+        const V4 t1 = a * pv;
+        xv = xv + t1;
+        const V4 t2 = a * apv;
+        rv = rv - t2;
+        *(V4*)(x + o) = xv;
+        *(V4*)(r + o) = rv;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double q = (double)rv[e] * (double)rv[e];
+        acc[e] = acc[e] + q;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s_part[threadIdx.x * 4 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < nvec * 4) {
+    const int c = threadIdx.x, ccv = c / 4, ce = c % 4;
+    double s = 0.0;
+    for (int q = 0; q < rows_pass; ++q) s += s_part[(q * nvq + ccv) * 4 + ce];
+    partial[(size_t)blockIdx.x * (nvec * 4) + c] = s;
+  }
+}
+
+// p = r + beta p                                                          (utils.py:529)
+template <typename T>
+__global__ __launch_bounds__(256) void cg_pupdate_kernel(const T* __restrict__ r, T* __restrict__ p,
+                                                         const double* __restrict__ beta, int64_t n, int ld, int nvec,
+                                                         const double* err_hist, int it, double tol, int) {
+#pragma clang fp contract(off)
+  typedef typename V4Of<T>::type V4;
+  // this kernel belongs to iteration `it`: it runs iff the iteration ran
+  if (cg_done(err_hist, it, tol)) return;
+  const int nvq = ld / 4;
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = v / nvq;
+  const int cv = (int)(v % nvq);
+  if (row >= n || cv >= nvec) return;
+  V4 b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b[e] = (T)beta[cv * 4 + e];
+  const size_t o = (size_t)row * ld + cv * 4;
+  const V4 rv = *(const V4*)(r + o);
+  const V4 pv = *(const V4*)(p + o);
+  const V4 t = b * pv;
+  *(V4*)(p + o) = rv + t;
+}
+
+// single-block fixed-order column reduction of partial[nb][ncols]
+// MODE 0: alpha = rsold / sum (utils.py:524)
+// MODE 1: rsnew = sum; err = sqrt(sum_c rsnew); beta = rsnew/rsold; rsold = rsnew (utils.py:527-530)
+// MODE 2: rsold = sum (utils.py:517)
+template <int MODE>
+__global__ __launch_bounds__(256) void cg_reduce_kernel(const double* __restrict__ partial, int64_t nb, int ncols, int C,
+                                                        CgScalars sc, int it, double tol) {
+#pragma clang fp contract(off)
+  if (MODE != 2 && cg_done(sc.err_hist, it, tol)) return;
+  __shared__ double s_sum[256];
+  __shared__ double s_col[256];
+  int cp = 1;
+  while (cp < ncols) cp *= 2;
+  const int nparts = 256 / cp;
+  const int c = threadIdx.x % cp, part = threadIdx.x / cp;
+  double s = 0.0;
+  if (c < ncols && part < nparts) {
+    const int64_t per = (nb + nparts - 1) / nparts;
+    const int64_t b0 = part * per, b1 = min(nb, b0 + per);
+    for (int64_t b = b0; b < b1; ++b) s += partial[(size_t)b * ncols + c];
+  }
+  s_sum[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < ncols) {
+    double tot = 0.0;
+    for (int q = 0; q < nparts; ++q) tot += s_sum[q * cp + threadIdx.x];
+    const int cc = threadIdx.x;
+    if (MODE == 0) {
+      sc.alpha[cc] = cc < C ? sc.rsold[cc] / tot : 0.0;
+    } else if (MODE == 1) {
+      sc.beta[cc] = cc < C ? tot / sc.rsold[cc] : 0.0;
+      sc.rsold[cc] = tot;
+      s_col[cc] = cc < C ? tot : 0.0;
+    } else {
+      sc.rsold[cc] = tot;
+    }
+  }
+  if (MODE == 1) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double e = 0.0;
+      for (int q = 0; q < C; ++q) e += s_col[q];
+      sc.err_hist[it] = sqrt(e);
+    }
+  }
+}
+
+__global__ void cg_set_err0(double* err_hist, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) err_hist[i] = i == 0 ? 1.0 : 0.0;
+}
+
+struct CgBufs {
+  void *x = nullptr, *r = nullptr, *p = nullptr, *ap = nullptr, *dense = nullptr;
+  double *part_dot = nullptr, *part_rs = nullptr, *scal = nullptr, *err_hist = nullptr, *h_err = nullptr;
+  hipStream_t stream = nullptr;
+  ~CgBufs() {
+    hipFree(x); hipFree(r); hipFree(p); hipFree(ap); hipFree(dense); hipFree(part_dot); hipFree(part_rs);
+    hipFree(scal); hipFree(err_hist);
+    if (h_err) hipHostFree(h_err);
+    if (stream) hipStreamDestroy(stream);
+  }
+};
+
+template <typename T>
+static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int* iters_out, double* err_out) {
+  const int64_t n = A->n_rows;
+  const int dtype = A->dtype;
+  RecLayout L;
+  int rc = glx_make_layout(C, dtype, false, &L);
+  if (rc) return rc;
+  SellPlan* plan = nullptr;
+  rc = glx_graph_plan(A, L.G, &plan);
+  if (rc) return rc;
+  const size_t es = L.esize;
+  const int ncols = L.nvec * 4;
+  GLX_CHECK(ncols <= 256, GLX_EUNSUPPORTED, "glx_cg_multi: C=%d too wide for the column reducer", C);
+  GLX_CHECK(256 / (L.ld / 4) >= 1, GLX_EUNSUPPORTED, "glx_cg_multi: record too wide");
+  const int64_t nb_spmm = std::max<int64_t>(glx_spmm_blocks(plan), 1);
+  const int64_t nb_upd = std::max<int64_t>((n + UPD_ROWS_PER_BLOCK - 1) / UPD_ROWS_PER_BLOCK, 1);
+  const int64_t hist_cap = max_iter + 2;
+  GLX_CHECK(max_iter < (1ll << 24), GLX_EUNSUPPORTED, "glx_cg_multi: max_iter %lld exceeds the supported 2^24-1", (long long)max_iter);
+
+  CgBufs b;
+  const size_t recb = std::max<size_t>((size_t)n * L.ld * es, 64);
+  GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+  GLX_HIP(hipMalloc(&b.x, recb));
+  GLX_HIP(hipMalloc(&b.r, recb));
+  GLX_HIP(hipMalloc(&b.p, recb));
+  GLX_HIP(hipMalloc(&b.ap, recb));
+  GLX_HIP(hipMalloc(&b.dense, std::max<size_t>((size_t)n * C * es, 64)));
+  GLX_HIP(hipMalloc(&b.part_dot, nb_spmm * ncols * 8));
+  GLX_HIP(hipMalloc(&b.part_rs, nb_upd * ncols * 8));
+  GLX_HIP(hipMalloc(&b.scal, 3 * ncols * 8));
+  GLX_HIP(hipMalloc(&b.err_hist, hist_cap * 8));
+  GLX_HIP(hipHostMalloc((void**)&b.h_err, (CG_CHUNK + 1) * 8, hipHostMallocDefault));
+  CgScalars sc;
+  sc.rsold = b.scal;
+  sc.alpha = b.scal + ncols;
+  sc.beta = b.scal + 2 * ncols;
+  sc.err_hist = b.err_hist;
+  hipStream_t st = b.stream;
+  const dim3 blk(256);
+  T* x = (T*)b.x;
+  T* r = (T*)b.r;
+  T* p = (T*)b.p;
+  T* ap = (T*)b.ap;
+
+  hipLaunchKernelGGL(cg_set_err0, dim3((unsigned)((hist_cap + 255) / 256)), blk, 0, st, b.err_hist, hist_cap);
+  GLX_HIP(hipGetLastError());
+  GLX_HIP(hipMemsetAsync(b.x, 0, recb, st));
+  GLX_HIP(hipMemsetAsync(b.ap, 0, recb, st));
+  GLX_HIP(hipMemsetAsync(b.part_dot, 0, nb_spmm * ncols * 8, st));
+  GLX_HIP(hipMemcpyAsync(b.dense, B, (size_t)n * C * es, hipMemcpyHostToDevice, st));
+  rc = glx_pack_records(b.dense, b.r, n, L, dtype, nullptr, st);   // r = b - A@0 = b (utils.py:514)
+  if (rc) return rc;
+  GLX_HIP(hipMemcpyAsync(b.p, b.r, recb, hipMemcpyDeviceToDevice, st));   // p = r.copy() (utils.py:516)
+  hipLaunchKernelGGL((cg_update_kernel<T, 1>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
+                     (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, 1, tol);
+  GLX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(cg_reduce_kernel<2>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, 0, tol);
+  GLX_HIP(hipGetLastError());
+
+  SweepArgs a;
+  memset(&a, 0, sizeof(a));
+  a.plan = plan;
+  a.L = L;
+  a.dtype = dtype;
+  a.xin = b.p;
+  a.xout = b.ap;
+  a.dot_partial = b.part_dot;
+  a.n_rows = n;
+  a.exit_tol = tol;
+  const unsigned pgrid = (unsigned)std::max<int64_t>(((int64_t)n * (L.ld / 4) + 255) / 256, 1);
+
+  int64_t it = 0;       // iterations launched
+  int64_t iters = 0;    // iterations that ran (utils.py:522 `i`)
+  double err = 1.0;     // utils.py:519
+  bool stopped = !(err > tol);
+  while (!stopped && it < max_iter) {
+    const int64_t end = std::min<int64_t>(max_iter, it + CG_CHUNK);
+    const int64_t it0 = it;
+    for (; it < end; ++it) {
+      const int i = (int)it + 1;
+      a.exit_err = b.err_hist + (i - 1);
+      rc = glx_launch_spmm(a, st);                                                   // Ap = A@p, p.Ap partials
+      if (rc) return rc;
+      hipLaunchKernelGGL(cg_reduce_kernel<0>, dim3(1), blk, 0, st, (const double*)b.part_dot, nb_spmm, ncols, C, sc, i, tol);
+      GLX_HIP(hipGetLastError());
+      hipLaunchKernelGGL((cg_update_kernel<T, 0>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
+                         (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, i, tol);
+      GLX_HIP(hipGetLastError());
+      hipLaunchKernelGGL(cg_reduce_kernel<1>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, i, tol);
+      GLX_HIP(hipGetLastError());
+      hipLaunchKernelGGL((cg_pupdate_kernel<T>), dim3(pgrid), blk, 0, st, (const T*)r, p, (const double*)sc.beta, n, L.ld, L.nvec,
+                         (const double*)b.err_hist, i, tol, 1);
+      GLX_HIP(hipGetLastError());
+    }
+    const int64_t cnt = end - it0;
+    GLX_HIP(hipMemcpyAsync(b.h_err, b.err_hist + it0 + 1, cnt * 8, hipMemcpyDeviceToHost, st));
+    GLX_HIP(hipStreamSynchronize(st));
+    for (int64_t q = 0; q < cnt; ++q) {
+      // iteration it0+q+1 ran (the previous err was > tol); its err decides the next one
+      iters = it0 + q + 1;
+      err = b.h_err[q];
+      if (!(err > tol)) { stopped = true; break; }
+    }
+  }
+  rc = glx_unpack_records(b.x, b.dense, n, L, dtype, st);
+  if (rc) return rc;
+  GLX_HIP(hipMemcpyAsync(X, b.dense, (size_t)n * C * es, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipStreamSynchronize(st));
+  if (iters_out) *iters_out = (int)iters;
+  if (err_out) *err_out = err;
+  return GLX_OK;
+}
+
+extern "C" int glx_cg_multi(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int* iters_out,
+                            double* err_out) {
+  GLX_CHECK(A && B && X, GLX_EINVAL, "glx_cg_multi: null argument");
+  GLX_CHECK(A->n_rows == A->n_cols, GLX_EINVAL, "glx_cg_multi: operator must be square");
+  GLX_CHECK(max_iter >= 0, GLX_EINVAL, "glx_cg_multi: negative max_iter");
+  GLX_HIP(hipSetDevice(A->device));
+  return A->dtype == GLX_F32 ? cg_run<float>(A, B, X, C, tol, max_iter, iters_out, err_out)
+                             : cg_run<double>(A, B, X, C, tol, max_iter, iters_out, err_out);
+}

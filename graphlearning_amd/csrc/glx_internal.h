@@ -1,0 +1,98 @@
+// Internal declarations shared by the libglx translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/glx.h"
+
+void glx_set_error(const char* fmt, ...);
+
+#define GLX_HIP(call)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      glx_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));  \
+      return GLX_EHIP;                                                                    \
+    }                                                                                     \
+  } while (0)
+
+#define GLX_CHECK(cond, code, ...)   \
+  do {                               \
+    if (!(cond)) {                   \
+      glx_set_error(__VA_ARGS__);    \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+// Record layout of one vertex in a dense operand: `ld` elements of T per vertex,
+// columns 0..C-1 first, zero padding up to nvec*4, then (optionally) one fp64 stop
+// value at byte offset woff.  Rows are 32/64/128-byte aligned so one neighbour
+// gather touches exactly one cache line for C <= 12 (fp64) / 28 (fp32).
+struct RecLayout {
+  int C;      // real columns
+  int nvec;   // column vectors of 4 elements
+  int ld;     // elements of T per vertex record
+  int woff;   // byte offset of the fp64 stop value inside the record (-1: none)
+  int G;      // lanes cooperating on one row (power of two, >= nvec + has_w)
+  int esize;  // sizeof(T)
+};
+int glx_make_layout(int C, int dtype, bool has_w, RecLayout* L);
+
+// Sliced-ELL view of a sparse operator.  A slice is the R = 64/G rows one wavefront
+// processes; entries are stored in chunks of 64: chunk k of a slice holds, for row
+// slot g and t in [0,G), the entry jj = k*G + t of that row at index g*G + t, so a
+// wavefront fetches a whole chunk with one coalesced load and hands entry t to the
+// G lanes of a row with a DPP quad broadcast.
+struct SellPlan {
+  int G = 0, R = 0;
+  int64_t nslices = 0;
+  int64_t stored = 0;          // stored entries incl. padding
+  int32_t* d_slot_row = nullptr;   // [nslices*R] row id or -1
+  int32_t* d_slot_len = nullptr;   // [nslices*R]
+  int64_t* d_slice_ptr = nullptr;  // [nslices+1] entry offset (multiple of 64)
+  int32_t* d_col = nullptr;        // [stored]
+  void* d_val = nullptr;           // [stored] of state dtype
+};
+
+struct glx_graph {
+  int64_t n_rows = 0, n_cols = 0, nnz = 0;
+  int dtype = GLX_F64;
+  int device = 0;
+  int max_row = 0;
+  // host copy of the CSR (entry order preserved), used to build plans lazily
+  std::vector<int32_t> h_rowptr, h_col;
+  std::vector<double> h_val;
+  std::vector<SellPlan> plans;   // one per G in use
+};
+
+int glx_graph_plan(glx_graph* g, int G, SellPlan** out);
+
+// kernels' launch wrappers (sweep.hip)
+struct SweepArgs {
+  const SellPlan* plan;
+  RecLayout L;
+  int dtype;
+  const void* xin;
+  void* xout;
+  const void* bias;              // record layout or nullptr
+  const uint8_t* slot_has_bias;  // per slot flag (nullptr -> dense bias if bias != nullptr)
+  // stop column
+  bool has_w;
+  const double* deg;
+  const double* vinf;
+  unsigned long long* err_prev;  // [64] shards read at kernel start (nullptr: no early exit)
+  unsigned long long* err_next;  // [64] shards written (nullptr: do not compute)
+  double thresh;
+  // fused column dots (CG): dot_out[block][C] partial sums of xin[row,c]*xout[row,c]
+  double* dot_partial;
+  const double* exit_err;        // optional early exit: skip when !(*exit_err > exit_tol)
+  double exit_tol;
+  int64_t n_rows;
+};
+int glx_launch_spmm(const SweepArgs& a, hipStream_t stream);
+int64_t glx_spmm_blocks(const SellPlan* plan);
+
+int glx_pack_records(const void* dense, void* rec, int64_t n, const RecLayout& L, int dtype, const double* w, hipStream_t s);
+int glx_unpack_records(const void* rec, void* dense, int64_t n, const RecLayout& L, int dtype, hipStream_t s);

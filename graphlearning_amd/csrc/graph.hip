@@ -1,0 +1,206 @@
+// Sparse operator residency: CSR (host copy, entry order preserved) -> sliced-ELL plans in HBM.
+// Replaces utils.torch_sparse (reference graphlearning/utils.py:288-317).
+#include "glx_internal.h"
+#include <stdarg.h>
+#include <algorithm>
+#include <numeric>
+
+static thread_local std::string g_err;
+
+void glx_set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+extern "C" const char* glx_last_error(void) { return g_err.c_str(); }
+extern "C" int glx_version(void) { return 100; }
+
+extern "C" int glx_device_count(int* n) {
+  GLX_CHECK(n != nullptr, GLX_EINVAL, "glx_device_count: null output");
+  GLX_HIP(hipGetDeviceCount(n));
+  return GLX_OK;
+}
+
+extern "C" int glx_set_device(int device) {
+  GLX_HIP(hipSetDevice(device));
+  return GLX_OK;
+}
+
+extern "C" int glx_device_synchronize(void) {
+  GLX_HIP(hipDeviceSynchronize());
+  return GLX_OK;
+}
+
+extern "C" void glx_free(void* p) { free(p); }
+
+int glx_make_layout(int C, int dtype, bool has_w, RecLayout* L) {
+  GLX_CHECK(C >= 1, GLX_EINVAL, "layout: C must be >= 1 (got %d)", C);
+  GLX_CHECK(dtype == GLX_F32 || dtype == GLX_F64, GLX_EINVAL, "layout: bad dtype %d", dtype);
+  const int es = dtype == GLX_F32 ? 4 : 8;
+  const int nvec = (C + 3) / 4;
+  const int lanes = nvec + (has_w ? 1 : 0);
+  GLX_CHECK(lanes <= 64, GLX_EUNSUPPORTED, "layout: C=%d needs %d lanes per row (max 64 -> C <= %d)", C, lanes,
+            has_w ? 252 : 256);
+  int G = 4;
+  while (G < lanes) G *= 2;
+  int bytes = lanes * 4 * es;   // the stop value gets a full 4-wide slot so every lane issues the same gather
+  int rb = 32;
+  while (rb < bytes && rb < 128) rb *= 2;      // 32 / 64 / 128-byte records stay line-aligned
+  if (rb < bytes) rb = (bytes + 63) / 64 * 64; // larger records: multiple of 64 bytes
+  L->C = C;
+  L->nvec = nvec;
+  L->ld = rb / es;
+  L->woff = has_w ? nvec * 4 * es : -1;
+  L->G = G;
+  L->esize = es;
+  return GLX_OK;
+}
+
+extern "C" int glx_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr,
+                                const int32_t* col, const double* val, int state_dtype, int device,
+                                glx_graph** out) {
+  GLX_CHECK(out != nullptr, GLX_EINVAL, "glx_graph_create: null output");
+  *out = nullptr;
+  GLX_CHECK(n_rows >= 0 && n_cols >= 0 && nnz >= 0, GLX_EINVAL, "glx_graph_create: negative size");
+  GLX_CHECK(n_rows < (1ll << 31) && n_cols < (1ll << 31), GLX_EINVAL, "glx_graph_create: n must fit int32");
+  GLX_CHECK(rowptr && (nnz == 0 || (col && val)), GLX_EINVAL, "glx_graph_create: null CSR array");
+  GLX_CHECK(state_dtype == GLX_F32 || state_dtype == GLX_F64, GLX_EINVAL, "glx_graph_create: bad dtype %d", state_dtype);
+  GLX_CHECK(rowptr[0] == 0 && rowptr[n_rows] == nnz, GLX_EINVAL, "glx_graph_create: rowptr[0]=%d rowptr[n]=%d nnz=%lld",
+            rowptr[0], rowptr[n_rows], (long long)nnz);
+  int ndev = 0;
+  GLX_HIP(hipGetDeviceCount(&ndev));
+  GLX_CHECK(device >= 0 && device < ndev, GLX_EINVAL, "glx_graph_create: device %d of %d", device, ndev);
+  int max_row = 0;
+  for (int64_t i = 0; i < n_rows; ++i) {
+    const int len = rowptr[i + 1] - rowptr[i];
+    GLX_CHECK(len >= 0, GLX_EINVAL, "glx_graph_create: rowptr not monotone at row %lld", (long long)i);
+    max_row = std::max(max_row, len);
+  }
+  for (int64_t e = 0; e < nnz; ++e)
+    GLX_CHECK(col[e] >= 0 && col[e] < n_cols, GLX_EINVAL, "glx_graph_create: column %d out of range at entry %lld", col[e], (long long)e);
+  glx_graph* g = new glx_graph();
+  g->n_rows = n_rows;
+  g->n_cols = n_cols;
+  g->nnz = nnz;
+  g->dtype = state_dtype;
+  g->device = device;
+  g->max_row = max_row;
+  g->h_rowptr.assign(rowptr, rowptr + n_rows + 1);
+  g->h_col.assign(col, col + nnz);
+  g->h_val.assign(val, val + nnz);
+  g->plans.reserve(8);   // plan pointers handed out stay valid
+  *out = g;
+  return GLX_OK;
+}
+
+static void free_plan(SellPlan& p) {
+  hipFree(p.d_slot_row);
+  hipFree(p.d_slot_len);
+  hipFree(p.d_slice_ptr);
+  hipFree(p.d_col);
+  hipFree(p.d_val);
+  p = SellPlan();
+}
+
+extern "C" int glx_graph_destroy(glx_graph* g) {
+  if (!g) return GLX_OK;
+  hipSetDevice(g->device);
+  for (auto& p : g->plans) free_plan(p);
+  delete g;
+  return GLX_OK;
+}
+
+extern "C" int glx_graph_info(const glx_graph* g, int64_t info[8]) {
+  GLX_CHECK(g && info, GLX_EINVAL, "glx_graph_info: null argument");
+  for (int i = 0; i < 8; ++i) info[i] = 0;
+  info[0] = g->n_rows;
+  info[1] = g->n_cols;
+  info[2] = g->nnz;
+  if (!g->plans.empty()) {
+    info[3] = g->plans[0].stored;
+    info[4] = g->plans[0].nslices;
+    info[5] = g->plans[0].R;
+  }
+  info[6] = g->max_row;
+  return GLX_OK;
+}
+
+// Build (once per G) the sliced-ELL image of the operator.  Rows are handed to
+// wavefront slices in order of decreasing length (longest first: LPT balance, little
+// padding inside a slice); the ENTRY order inside a row is untouched.
+int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
+  for (auto& p : g->plans)
+    if (p.G == G) {
+      *out = &p;
+      return GLX_OK;
+    }
+  GLX_HIP(hipSetDevice(g->device));
+  const int R = 64 / G;
+  const int64_t n = g->n_rows;
+  const int64_t nslices = (n + R - 1) / R;
+  std::vector<int32_t> order(n);
+  {
+    // counting sort by decreasing length, stable in row id
+    std::vector<int64_t> cnt(g->max_row + 2, 0);
+    for (int64_t i = 0; i < n; ++i) cnt[g->max_row - (g->h_rowptr[i + 1] - g->h_rowptr[i]) + 1]++;
+    for (size_t b = 1; b < cnt.size(); ++b) cnt[b] += cnt[b - 1];
+    for (int64_t i = 0; i < n; ++i) order[cnt[g->max_row - (g->h_rowptr[i + 1] - g->h_rowptr[i])]++] = (int32_t)i;
+  }
+  std::vector<int32_t> slot_row(nslices * R, -1), slot_len(nslices * R, 0);
+  std::vector<int64_t> slice_ptr(nslices + 1, 0);
+  for (int64_t s = 0; s < nslices; ++s) {
+    int width = 0;
+    for (int r = 0; r < R; ++r) {
+      const int64_t slot = s * R + r;
+      if (slot < n) {
+        const int32_t row = order[slot];
+        slot_row[slot] = row;
+        slot_len[slot] = g->h_rowptr[row + 1] - g->h_rowptr[row];
+        width = std::max(width, slot_len[slot]);
+      }
+    }
+    const int64_t nchunks = (width + G - 1) / G;
+    slice_ptr[s + 1] = slice_ptr[s] + nchunks * 64;
+  }
+  const int64_t stored = slice_ptr[nslices];
+  std::vector<int32_t> col(stored, 0);
+  std::vector<double> val64;
+  std::vector<float> val32;
+  if (g->dtype == GLX_F64) val64.assign(stored, 0.0); else val32.assign(stored, 0.0f);
+  for (int64_t s = 0; s < nslices; ++s) {
+    for (int r = 0; r < R; ++r) {
+      const int64_t slot = s * R + r;
+      const int32_t row = slot_row[slot];
+      if (row < 0) continue;
+      const int64_t b = g->h_rowptr[row];
+      for (int jj = 0; jj < slot_len[slot]; ++jj) {
+        const int64_t idx = slice_ptr[s] + (int64_t)(jj / G) * 64 + r * G + (jj % G);
+        col[idx] = g->h_col[b + jj];
+        if (g->dtype == GLX_F64) val64[idx] = g->h_val[b + jj]; else val32[idx] = (float)g->h_val[b + jj];
+      }
+    }
+  }
+  SellPlan p;
+  p.G = G;
+  p.R = R;
+  p.nslices = nslices;
+  p.stored = stored;
+  const size_t es = g->dtype == GLX_F64 ? 8 : 4;
+  GLX_HIP(hipMalloc(&p.d_slot_row, std::max<size_t>(4, slot_row.size() * 4)));
+  GLX_HIP(hipMalloc(&p.d_slot_len, std::max<size_t>(4, slot_len.size() * 4)));
+  GLX_HIP(hipMalloc(&p.d_slice_ptr, slice_ptr.size() * 8));
+  GLX_HIP(hipMalloc(&p.d_col, std::max<size_t>(4, stored * 4)));
+  GLX_HIP(hipMalloc(&p.d_val, std::max<size_t>(8, stored * es)));
+  GLX_HIP(hipMemcpy(p.d_slot_row, slot_row.data(), slot_row.size() * 4, hipMemcpyHostToDevice));
+  GLX_HIP(hipMemcpy(p.d_slot_len, slot_len.data(), slot_len.size() * 4, hipMemcpyHostToDevice));
+  GLX_HIP(hipMemcpy(p.d_slice_ptr, slice_ptr.data(), slice_ptr.size() * 8, hipMemcpyHostToDevice));
+  GLX_HIP(hipMemcpy(p.d_col, col.data(), stored * 4, hipMemcpyHostToDevice));
+  GLX_HIP(hipMemcpy(p.d_val, g->dtype == GLX_F64 ? (void*)val64.data() : (void*)val32.data(), stored * es, hipMemcpyHostToDevice));
+  g->plans.push_back(p);
+  *out = &g->plans.back();
+  return GLX_OK;
+}

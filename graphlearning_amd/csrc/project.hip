@@ -1,0 +1,218 @@
+// ssl.predict (reference graphlearning/ssl.py:230-266) and ssl.volume_label_projection
+// (ssl.py:172-209) on device.  All arithmetic is elementwise IEEE fp64 with contraction
+// off and integer class counts, so labels and weights are bit-identical to numpy's.
+#include "glx_internal.h"
+#include <algorithm>
+
+static const int PROJ_CHUNK = 32;
+
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int lo = __shfl_xor(__double2loint(v), off), hi = __shfl_xor(__double2hiint(v), off);
+    const double o = __hiloint2double(hi, lo);
+    v = (o < v || o != o) ? o : v;   // NaN propagates like np.min
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int lo = __shfl_xor(__double2loint(v), off), hi = __shfl_xor(__double2hiint(v), off);
+    const double o = __hiloint2double(hi, lo);
+    v = (o > v || o != o) ? o : v;
+  }
+  return v;
+}
+
+// stage 1: per-block min / max of prob; stage 2 (one block) reduces the block results
+__global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ a, int64_t total, double* __restrict__ bmin,
+                                                     double* __restrict__ bmax) {
+  double mn = __longlong_as_double(0x7ff0000000000000ll), mx = -mn;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const double v = a[i];
+    mn = (v < mn || v != v) ? v : mn;
+    mx = (v > mx || v != v) ? v : mx;
+  }
+  mn = wave_min_d(mn);
+  mx = wave_max_d(mx);
+  __shared__ double s_mn[4], s_mx[4];
+  if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      mn = (s_mn[w] < mn || s_mn[w] != s_mn[w]) ? s_mn[w] : mn;
+      mx = (s_mx[w] > mx || s_mx[w] != s_mx[w]) ? s_mx[w] : mx;
+    }
+    bmin[blockIdx.x] = mn;
+    bmax[blockIdx.x] = mx;
+  }
+}
+
+// scores = (prob - min) / max(prob - min)                                   (ssl.py:256-257)
+__global__ __launch_bounds__(256) void scores_kernel(double* __restrict__ a, int64_t total, const double* __restrict__ mm) {
+#pragma clang fp contract(off)
+  const double mn = mm[0];
+  const double den = mm[1] - mn;   // max(prob - min) == fl(max - min): rounding is monotone
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const double s = a[i] - mn;
+    a[i] = s / den;
+  }
+}
+
+struct ProjState {
+  double* w;        // [C]
+  double* priors;   // [C]
+  long long* counts;  // [C]
+  double* err;      // [1]
+  int* steps;       // [1]
+  int* done;        // [1]
+};
+
+// labels = argmax_c scores[i,c]*w[c] (first index wins, NaN wins like np.argmax); class histogram
+__global__ __launch_bounds__(256) void argmax_hist_kernel(const double* __restrict__ scores, int64_t n, int C, ProjState st,
+                                                          long long* __restrict__ labels, int similarity, int check_done,
+                                                          int do_hist) {
+#pragma clang fp contract(off)
+  if (check_done && *st.done) return;
+  extern __shared__ long long s_cnt[];
+  for (int c = threadIdx.x; c < C; c += 256) s_cnt[c] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double* row = scores + i * C;
+    double best = row[0] * st.w[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+      const double v = row[c] * st.w[c];
+      const bool better = similarity ? (v > best) : (v < best);
+      if ((better || v != v) && !(best != best)) { best = v; bi = c; }
+    }
+    labels[i] = bi;
+    if (do_hist) atomicAdd((unsigned long long*)&s_cnt[bi], 1ull);
+  }
+  if (do_hist) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+      if (s_cnt[c]) atomicAdd((unsigned long long*)&st.counts[c], (unsigned long long)s_cnt[c]);
+  }
+}
+
+// one gradient step on the class weights                                     (ssl.py:198-205)
+__global__ void proj_update_kernel(ProjState st, int64_t n, int C, double dt, int max_steps) {
+#pragma clang fp contract(off)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (*st.done) return;
+  double err = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const double size = (double)st.counts[c] / (double)n;   // np.mean of a 0/1 column
+    const double grad = size - st.priors[c];
+    const double ag = fabs(grad);
+    if (ag > err || ag != ag) err = ag;                      // np.max propagates NaN
+    const double t = dt * grad;
+    st.w[c] = st.w[c] + t;
+    st.counts[c] = 0;
+  }
+  const double w0 = st.w[0];
+  for (int c = 0; c < C; ++c) st.w[c] = st.w[c] / w0;
+  *st.err = err;
+  *st.steps += 1;
+  if (!(err > 1e-3) || *st.steps >= max_steps) *st.done = 1;
+}
+
+__global__ void minmax_final_kernel(const double* bmin, const double* bmax, int nb, double* mm) {
+  if (threadIdx.x != 0) return;
+  double mn = bmin[0], mx = bmax[0];
+  for (int b = 1; b < nb; ++b) {
+    mn = (bmin[b] < mn || bmin[b] != bmin[b]) ? bmin[b] : mn;
+    mx = (bmax[b] > mx || bmax[b] != bmax[b]) ? bmax[b] : mx;
+  }
+  mm[0] = mn;
+  mm[1] = mx;
+}
+
+struct ProjBufs {
+  double *scores = nullptr, *bmin = nullptr, *bmax = nullptr, *mm = nullptr, *w = nullptr, *priors = nullptr, *err = nullptr;
+  long long *counts = nullptr, *labels = nullptr;
+  int *steps = nullptr, *done = nullptr;
+  hipStream_t stream = nullptr;
+  ~ProjBufs() {
+    hipFree(scores); hipFree(bmin); hipFree(bmax); hipFree(mm); hipFree(w); hipFree(priors); hipFree(err);
+    hipFree(counts); hipFree(labels); hipFree(steps); hipFree(done);
+    if (stream) hipStreamDestroy(stream);
+  }
+};
+
+extern "C" int glx_argmax_project(const double* prob, int64_t n, int C, const double* priors, double* weights_inout,
+                                  int64_t* labels_out, double* err_out, int* steps_out, int max_steps, int similarity,
+                                  int device) {
+  GLX_CHECK(prob && weights_inout && labels_out, GLX_EINVAL, "glx_argmax_project: null argument");
+  GLX_CHECK(n >= 1 && C >= 1, GLX_EINVAL, "glx_argmax_project: empty input (n=%lld, C=%d)", (long long)n, C);
+  GLX_CHECK(max_steps == 0 || priors, GLX_EINVAL, "glx_argmax_project: projection needs priors");
+  GLX_CHECK(C <= 4096, GLX_EUNSUPPORTED, "glx_argmax_project: C=%d too large", C);
+  GLX_HIP(hipSetDevice(device));
+  ProjBufs b;
+  const int64_t total = n * C;
+  const int nb = (int)std::min<int64_t>((total + 255) / 256, 1024);
+  const int nbr = (int)std::min<int64_t>((n + 255) / 256, 2048);
+  GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+  hipStream_t st = b.stream;
+  GLX_HIP(hipMalloc(&b.scores, total * 8));
+  GLX_HIP(hipMalloc(&b.bmin, nb * 8));
+  GLX_HIP(hipMalloc(&b.bmax, nb * 8));
+  GLX_HIP(hipMalloc(&b.mm, 16));
+  GLX_HIP(hipMalloc(&b.w, C * 8));
+  GLX_HIP(hipMalloc(&b.priors, C * 8));
+  GLX_HIP(hipMalloc(&b.err, 8));
+  GLX_HIP(hipMalloc(&b.counts, C * 8));
+  GLX_HIP(hipMalloc(&b.labels, n * 8));
+  GLX_HIP(hipMalloc(&b.steps, 4));
+  GLX_HIP(hipMalloc(&b.done, 4));
+  GLX_HIP(hipMemcpyAsync(b.scores, prob, total * 8, hipMemcpyHostToDevice, st));
+  GLX_HIP(hipMemcpyAsync(b.w, weights_inout, C * 8, hipMemcpyHostToDevice, st));
+  if (priors) GLX_HIP(hipMemcpyAsync(b.priors, priors, C * 8, hipMemcpyHostToDevice, st));
+  GLX_HIP(hipMemsetAsync(b.counts, 0, C * 8, st));
+  GLX_HIP(hipMemsetAsync(b.steps, 0, 4, st));
+  GLX_HIP(hipMemsetAsync(b.done, 0, 4, st));
+  GLX_HIP(hipMemsetAsync(b.err, 0, 8, st));
+  hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, st, (const double*)b.scores, total, b.bmin, b.bmax);
+  GLX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, st, (const double*)b.bmin, (const double*)b.bmax, nb, b.mm);
+  GLX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(scores_kernel, dim3(nb), dim3(256), 0, st, b.scores, total, (const double*)b.mm);
+  GLX_HIP(hipGetLastError());
+  ProjState ps;
+  ps.w = b.w;
+  ps.priors = b.priors;
+  ps.counts = b.counts;
+  ps.err = b.err;
+  ps.steps = b.steps;
+  ps.done = b.done;
+  const double dt = similarity ? -0.1 : 0.1;   // ssl.py:195-197
+  const size_t shm = (size_t)C * 8;
+  int steps = 0;
+  double err = 1.0;   // ssl.py:201
+  if (max_steps > 0) {
+    int done = 0;
+    while (!done) {
+      for (int q = 0; q < PROJ_CHUNK; ++q) {
+        hipLaunchKernelGGL(argmax_hist_kernel, dim3(nbr), dim3(256), shm, st, (const double*)b.scores, n, C, ps, b.labels, similarity, 1, 1);
+        GLX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(proj_update_kernel, dim3(1), dim3(64), 0, st, ps, n, C, dt, max_steps);
+        GLX_HIP(hipGetLastError());
+      }
+      GLX_HIP(hipMemcpyAsync(&done, b.done, 4, hipMemcpyDeviceToHost, st));
+      GLX_HIP(hipStreamSynchronize(st));
+    }
+    GLX_HIP(hipMemcpyAsync(&steps, b.steps, 4, hipMemcpyDeviceToHost, st));
+    GLX_HIP(hipMemcpyAsync(&err, b.err, 8, hipMemcpyDeviceToHost, st));
+  }
+  // final predict with the (updated) weights                                 (ssl.py:209)
+  hipLaunchKernelGGL(argmax_hist_kernel, dim3(nbr), dim3(256), shm, st, (const double*)b.scores, n, C, ps, b.labels, similarity, 0, 0);
+  GLX_HIP(hipGetLastError());
+  GLX_HIP(hipMemcpyAsync(labels_out, b.labels, n * 8, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipMemcpyAsync(weights_inout, b.w, C * 8, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipStreamSynchronize(st));
+  if (err_out) *err_out = err;
+  if (steps_out) *steps_out = steps;
+  return GLX_OK;
+}

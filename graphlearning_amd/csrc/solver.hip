@@ -1,0 +1,392 @@
+// Iteration drivers on top of the sliced-ELL SpMM: the Poisson sweep with its fused stop
+// column (reference graphlearning/ssl.py:631-670), the PoissonMBO heat loop (ssl.py:826-827)
+// and the one-shot glx_spmm_bias.  All iterations run on the device; the host only reads
+// back the per-iteration stop-test maxima in small chunks.
+#include "glx_internal.h"
+#include <string.h>
+#include <map>
+#include <math.h>
+
+static const int ERR_SHARDS = 64;
+static const int TAIL_CHUNK = 16;
+
+struct glx_sweep {
+  glx_graph* P = nullptr;
+  int C = 0, min_iter = 0, max_iter = 0;
+  bool has_w = false, use_graph = false;
+  RecLayout L;
+  SellPlan* plan = nullptr;
+  int64_t n_rows = 0, n_cols = 0;
+  void* buf[2] = {nullptr, nullptr};
+  void* bias = nullptr;
+  uint8_t* slot_has_bias = nullptr;
+  bool bias_set = false;
+  double *deg = nullptr, *vinf = nullptr, *w0 = nullptr;
+  unsigned long long* err = nullptr;        // [(max_iter+1) * ERR_SHARDS]
+  unsigned long long* h_err = nullptr;      // pinned mirror
+  void* dense = nullptr;                    // staging (n_cols, C)
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipGraphExec_t head_exec = nullptr;       // captured: reset + min_iter unconditional sweeps
+  std::map<long, hipGraphExec_t> iter_exec; // heat loop graphs keyed by (iters, parity)
+  int cur = 0;
+  int64_t launches = 0;
+  double err0 = 0.0, thresh = 0.0;
+};
+
+static size_t rec_bytes(const glx_sweep* s, int64_t rows) { return (size_t)rows * s->L.ld * s->L.esize; }
+
+extern "C" int glx_sweep_destroy(glx_sweep* s) {
+  if (!s) return GLX_OK;
+  hipSetDevice(s->P->device);
+  if (s->stream) hipStreamSynchronize(s->stream);
+  if (s->head_exec) hipGraphExecDestroy(s->head_exec);
+  for (auto& kv : s->iter_exec) hipGraphExecDestroy(kv.second);
+  hipFree(s->buf[0]);
+  hipFree(s->buf[1]);
+  hipFree(s->bias);
+  hipFree(s->slot_has_bias);
+  hipFree(s->deg);
+  hipFree(s->vinf);
+  hipFree(s->w0);
+  hipFree(s->err);
+  if (s->h_err) hipHostFree(s->h_err);
+  hipFree(s->dense);
+  if (s->ev0) hipEventDestroy(s->ev0);
+  if (s->ev1) hipEventDestroy(s->ev1);
+  if (s->stream) hipStreamDestroy(s->stream);
+  delete s;
+  return GLX_OK;
+}
+
+extern "C" int glx_sweep_create(glx_graph* P, int C, int min_iter, int max_iter, int use_hipgraph, glx_sweep** out) {
+  GLX_CHECK(P && out, GLX_EINVAL, "glx_sweep_create: null argument");
+  *out = nullptr;
+  GLX_CHECK(min_iter >= 0 && max_iter >= 0, GLX_EINVAL, "glx_sweep_create: negative iteration bound");
+  GLX_HIP(hipSetDevice(P->device));
+  glx_sweep* s = new glx_sweep();
+  s->P = P;
+  s->C = C;
+  s->min_iter = min_iter;
+  s->max_iter = max_iter;
+  s->has_w = max_iter > 0;
+  s->use_graph = use_hipgraph != 0;
+  s->n_rows = P->n_rows;
+  s->n_cols = P->n_cols;
+  int rc = glx_make_layout(C, P->dtype, s->has_w, &s->L);
+  if (rc) { delete s; return rc; }
+  rc = glx_graph_plan(P, s->L.G, &s->plan);
+  if (rc) { delete s; return rc; }
+#define SW_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { glx_set_error("%s -> %s", #call, hipGetErrorString(e_)); glx_sweep_destroy(s); return GLX_EHIP; } } while (0)
+  SW_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  SW_HIP(hipEventCreate(&s->ev0));
+  SW_HIP(hipEventCreate(&s->ev1));
+  const size_t rb = std::max<size_t>(rec_bytes(s, s->n_cols), 64);
+  SW_HIP(hipMalloc(&s->buf[0], rb));
+  SW_HIP(hipMalloc(&s->buf[1], rb));
+  SW_HIP(hipMemset(s->buf[0], 0, rb));
+  SW_HIP(hipMemset(s->buf[1], 0, rb));
+  SW_HIP(hipMalloc(&s->bias, std::max<size_t>(rec_bytes(s, s->n_rows), 64)));
+  SW_HIP(hipMemset(s->bias, 0, std::max<size_t>(rec_bytes(s, s->n_rows), 64)));
+  SW_HIP(hipMalloc(&s->slot_has_bias, std::max<size_t>((size_t)s->plan->nslices * s->plan->R, 64)));
+  SW_HIP(hipMalloc(&s->dense, std::max<size_t>((size_t)s->n_cols * C * s->L.esize, 64)));
+  if (s->has_w) {
+    SW_HIP(hipMalloc(&s->deg, std::max<size_t>(s->n_rows * 8, 64)));
+    SW_HIP(hipMalloc(&s->vinf, std::max<size_t>(s->n_rows * 8, 64)));
+    SW_HIP(hipMalloc(&s->w0, std::max<size_t>(s->n_cols * 8, 64)));
+    const size_t eb = (size_t)(max_iter + 1) * ERR_SHARDS * 8;
+    SW_HIP(hipMalloc(&s->err, eb));
+    SW_HIP(hipHostMalloc((void**)&s->h_err, eb, hipHostMallocDefault));
+  }
+#undef SW_HIP
+  *out = s;
+  return GLX_OK;
+}
+
+// per-slot flag: does the row's bias record hold any nonzero?  (Poisson's Db = D^-1 b is
+// nonzero on the m labelled rows only, ssl.py:620-622,636: the sweep then skips reading it.)
+__global__ void bias_flags_kernel(const int32_t* __restrict__ slot_row, uint8_t* __restrict__ flags, int64_t nslots,
+                                  const char* __restrict__ bias, int rec_bytes) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= nslots) return;
+  const int row = slot_row[slot];
+  uint8_t f = 0;
+  if (row >= 0) {
+    const unsigned long long* r = (const unsigned long long*)(bias + (size_t)row * rec_bytes);
+    for (int i = 0; i < rec_bytes / 8; ++i) f |= (r[i] << 1) != 0;   // -0.0 counts as zero
+  }
+  flags[slot] = f;
+}
+
+static int upload_bias(glx_sweep* s, const void* Db) {
+  const int64_t nslots = s->plan->nslices * s->plan->R;
+  if (!Db) {
+    GLX_HIP(hipMemsetAsync(s->bias, 0, rec_bytes(s, s->n_rows), s->stream));
+    GLX_HIP(hipMemsetAsync(s->slot_has_bias, 0, std::max<int64_t>(nslots, 1), s->stream));
+    s->bias_set = false;
+    return GLX_OK;
+  }
+  GLX_HIP(hipMemcpyAsync(s->dense, Db, (size_t)s->n_rows * s->C * s->L.esize, hipMemcpyHostToDevice, s->stream));
+  int rc = glx_pack_records(s->dense, s->bias, s->n_rows, s->L, s->P->dtype, nullptr, s->stream);
+  if (rc) return rc;
+  if (nslots > 0) {
+    hipLaunchKernelGGL(bias_flags_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s->stream,
+                       s->plan->d_slot_row, s->slot_has_bias, nslots, (const char*)s->bias, s->L.ld * s->L.esize);
+    GLX_HIP(hipGetLastError());
+  }
+  s->bias_set = true;
+  return GLX_OK;
+}
+
+extern "C" int glx_sweep_set_problem(glx_sweep* s, const void* Db, const double* w0, const double* deg, const double* vinf) {
+  GLX_CHECK(s, GLX_EINVAL, "glx_sweep_set_problem: null sweep");
+  GLX_CHECK(s->has_w, GLX_EINVAL, "glx_sweep_set_problem: sweep was created without a stop column (max_iter = 0)");
+  GLX_CHECK(w0 && deg && vinf, GLX_EINVAL, "glx_sweep_set_problem: null vector");
+  GLX_CHECK(s->n_rows == s->n_cols, GLX_EINVAL, "glx_sweep_set_problem: operator must be square");
+  GLX_HIP(hipSetDevice(s->P->device));
+  int rc = upload_bias(s, Db);
+  if (rc) return rc;
+  GLX_HIP(hipMemcpyAsync(s->w0, w0, s->n_cols * 8, hipMemcpyHostToDevice, s->stream));
+  GLX_HIP(hipMemcpyAsync(s->deg, deg, s->n_rows * 8, hipMemcpyHostToDevice, s->stream));
+  GLX_HIP(hipMemcpyAsync(s->vinf, vinf, s->n_rows * 8, hipMemcpyHostToDevice, s->stream));
+  double e0 = 0.0;
+  for (int64_t i = 0; i < s->n_rows; ++i) {
+    const double e = fabs(deg[i] * w0[i] - vinf[i]);
+    if (e > e0 || e != e) e0 = e;
+  }
+  s->err0 = e0;
+  s->thresh = 1.0 / (double)s->n_rows;   // `> 1/n`, ssl.py:667
+  GLX_HIP(hipStreamSynchronize(s->stream));
+  return GLX_OK;
+}
+
+static int launch_sweep(glx_sweep* s, int t, bool with_stop) {
+  SweepArgs a;
+  memset(&a, 0, sizeof(a));
+  a.plan = s->plan;
+  a.L = s->L;
+  a.dtype = s->P->dtype;
+  a.xin = s->buf[s->cur];
+  a.xout = s->buf[s->cur ^ 1];
+  a.bias = s->bias_set ? s->bias : nullptr;
+  a.slot_has_bias = s->bias_set ? s->slot_has_bias : nullptr;
+  a.has_w = s->has_w;
+  a.n_rows = s->n_rows;
+  if (with_stop) {
+    a.deg = s->deg;
+    a.vinf = s->vinf;
+    a.thresh = s->thresh;
+    a.err_prev = t >= s->min_iter ? s->err + (size_t)t * ERR_SHARDS : nullptr;
+    a.err_next = t + 1 >= s->min_iter ? s->err + (size_t)(t + 1) * ERR_SHARDS : nullptr;
+  }
+  int rc = glx_launch_spmm(a, s->stream);
+  if (rc) return rc;
+  s->cur ^= 1;
+  s->launches++;
+  return GLX_OK;
+}
+
+// reset state + the min_iter unconditional sweeps; identical every run -> capturable
+static int enqueue_head(glx_sweep* s) {
+  GLX_HIP(hipMemsetAsync(s->err, 0, (size_t)(s->max_iter + 1) * ERR_SHARDS * 8, s->stream));
+  if (s->min_iter == 0) {
+    union { double d; unsigned long long u; } cv;
+    cv.d = s->err0;
+    s->h_err[0] = cv.u;
+    GLX_HIP(hipMemcpyAsync(s->err, s->h_err, 8, hipMemcpyHostToDevice, s->stream));
+  }
+  s->cur = 0;
+  int rc = glx_pack_records(nullptr, s->buf[0], s->n_cols, s->L, s->P->dtype, s->w0, s->stream);   // u = 0 (ssl.py:645), w = w0
+  if (rc) return rc;
+  const int head = std::min(s->min_iter, s->max_iter);
+  for (int t = 0; t < head; ++t) {
+    rc = launch_sweep(s, t, true);
+    if (rc) return rc;
+  }
+  return GLX_OK;
+}
+
+extern "C" int glx_sweep_run(glx_sweep* s, int* T_out, float* device_ms_out) {
+  GLX_CHECK(s && s->has_w, GLX_EINVAL, "glx_sweep_run: sweep has no stop column");
+  GLX_HIP(hipSetDevice(s->P->device));
+  const int head = std::min(s->min_iter, s->max_iter);
+  int rc;
+  GLX_HIP(hipEventRecord(s->ev0, s->stream));
+  if (s->use_graph) {
+    if (!s->head_exec) {
+      hipGraph_t graph;
+      GLX_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+      rc = enqueue_head(s);
+      hipError_t e = hipStreamEndCapture(s->stream, &graph);
+      if (rc) return rc;
+      GLX_HIP(e);
+      GLX_HIP(hipGraphInstantiate(&s->head_exec, graph, nullptr, nullptr, 0));
+      GLX_HIP(hipGraphDestroy(graph));
+    } else {
+      s->launches += head;
+    }
+    if (s->min_iter == 0) {
+      union { double d; unsigned long long u; } cv;
+      cv.d = s->err0;
+      s->h_err[0] = cv.u;
+    }
+    GLX_HIP(hipGraphLaunch(s->head_exec, s->stream));
+    s->cur = head & 1;
+  } else {
+    rc = enqueue_head(s);
+    if (rc) return rc;
+  }
+  // tail: conditional sweeps in chunks; each kernel exits at once when the stop test
+  // (read from the previous kernel's maxima) already holds, so over-launching is harmless.
+  int T = head;
+  int t = head;
+  bool stopped = false;
+  while (!stopped && t < s->max_iter) {
+    // check err[t] first
+    GLX_HIP(hipMemcpyAsync(s->h_err + (size_t)t * ERR_SHARDS, s->err + (size_t)t * ERR_SHARDS, ERR_SHARDS * 8, hipMemcpyDeviceToHost, s->stream));
+    GLX_HIP(hipStreamSynchronize(s->stream));
+    {
+      unsigned long long m = 0;
+      for (int k = 0; k < ERR_SHARDS; ++k) m = std::max(m, s->h_err[(size_t)t * ERR_SHARDS + k]);
+      union { double d; unsigned long long u; } cv;
+      cv.u = m;
+      if (cv.d <= s->thresh) { stopped = true; T = t; break; }
+    }
+    const int end = std::min(s->max_iter, t + TAIL_CHUNK);
+    const int t0 = t;
+    const int cur0 = s->cur;
+    for (; t < end; ++t) {
+      rc = launch_sweep(s, t, true);
+      if (rc) return rc;
+    }
+    // which of the chunk's sweeps really ran?
+    GLX_HIP(hipMemcpyAsync(s->h_err + (size_t)(t0 + 1) * ERR_SHARDS, s->err + (size_t)(t0 + 1) * ERR_SHARDS,
+                           (size_t)(end - t0) * ERR_SHARDS * 8, hipMemcpyDeviceToHost, s->stream));
+    GLX_HIP(hipStreamSynchronize(s->stream));
+    T = end;
+    for (int q = t0 + 1; q < end; ++q) {   // sweep q ran iff err[q] > thresh
+      unsigned long long m = 0;
+      for (int k = 0; k < ERR_SHARDS; ++k) m = std::max(m, s->h_err[(size_t)q * ERR_SHARDS + k]);
+      union { double d; unsigned long long u; } cv;
+      cv.u = m;
+      if (cv.d <= s->thresh) { T = q; stopped = true; break; }
+    }
+    if (stopped) s->cur = cur0 ^ ((T - t0) & 1);
+    t = stopped ? T : end;
+  }
+  if (!stopped) T = t;
+  GLX_HIP(hipEventRecord(s->ev1, s->stream));
+  GLX_HIP(hipStreamSynchronize(s->stream));
+  if (device_ms_out) GLX_HIP(hipEventElapsedTime(device_ms_out, s->ev0, s->ev1));
+  if (T_out) *T_out = T;
+  return GLX_OK;
+}
+
+extern "C" int glx_sweep_fetch(glx_sweep* s, void* u_out) {
+  GLX_CHECK(s && u_out, GLX_EINVAL, "glx_sweep_fetch: null argument");
+  GLX_HIP(hipSetDevice(s->P->device));
+  int rc = glx_unpack_records(s->buf[s->cur], s->dense, s->n_rows, s->L, s->P->dtype, s->stream);
+  if (rc) return rc;
+  GLX_HIP(hipMemcpyAsync(u_out, s->dense, (size_t)s->n_rows * s->C * s->L.esize, hipMemcpyDeviceToHost, s->stream));
+  GLX_HIP(hipStreamSynchronize(s->stream));
+  return GLX_OK;
+}
+
+extern "C" int glx_sweep_launches(const glx_sweep* s, int64_t* n) {
+  GLX_CHECK(s && n, GLX_EINVAL, "glx_sweep_launches: null argument");
+  *n = s->launches;
+  return GLX_OK;
+}
+
+extern "C" int glx_sweep_set_state(glx_sweep* s, const void* u0, const void* Db) {
+  GLX_CHECK(s, GLX_EINVAL, "glx_sweep_set_state: null sweep");
+  GLX_CHECK(!s->has_w, GLX_EINVAL, "glx_sweep_set_state: only for sweeps created with max_iter = 0");
+  GLX_HIP(hipSetDevice(s->P->device));
+  int rc = upload_bias(s, Db);
+  if (rc) return rc;
+  GLX_HIP(hipStreamSynchronize(s->stream));   // `dense` staging is reused below
+  if (u0) {
+    GLX_HIP(hipMemcpyAsync(s->dense, u0, (size_t)s->n_cols * s->C * s->L.esize, hipMemcpyHostToDevice, s->stream));
+    rc = glx_pack_records(s->dense, s->buf[0], s->n_cols, s->L, s->P->dtype, nullptr, s->stream);
+  } else {
+    rc = glx_pack_records(nullptr, s->buf[0], s->n_cols, s->L, s->P->dtype, nullptr, s->stream);
+  }
+  if (rc) return rc;
+  s->cur = 0;
+  GLX_HIP(hipStreamSynchronize(s->stream));
+  return GLX_OK;
+}
+
+extern "C" int glx_sweep_iterate(glx_sweep* s, int iters) {
+  GLX_CHECK(s && iters >= 0, GLX_EINVAL, "glx_sweep_iterate: bad argument");
+  GLX_CHECK(!s->has_w, GLX_EINVAL, "glx_sweep_iterate: only for sweeps created with max_iter = 0");
+  GLX_CHECK(s->n_rows == s->n_cols, GLX_EINVAL, "glx_sweep_iterate: operator must be square");
+  GLX_HIP(hipSetDevice(s->P->device));
+  int rc;
+  if (s->use_graph && iters > 1) {
+    const long key = (long)iters * 4 + s->cur * 2 + (s->bias_set ? 1 : 0);
+    auto it = s->iter_exec.find(key);
+    if (it == s->iter_exec.end()) {
+      hipGraph_t graph;
+      hipGraphExec_t exec;
+      const int cur0 = s->cur;
+      GLX_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+      rc = GLX_OK;
+      for (int t = 0; t < iters && rc == GLX_OK; ++t) rc = launch_sweep(s, t, false);
+      hipError_t e = hipStreamEndCapture(s->stream, &graph);
+      if (rc) return rc;
+      GLX_HIP(e);
+      GLX_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      GLX_HIP(hipGraphDestroy(graph));
+      s->iter_exec[key] = exec;
+      s->cur = cur0;
+      s->launches -= iters;
+      it = s->iter_exec.find(key);
+    }
+    GLX_HIP(hipGraphLaunch(it->second, s->stream));
+    s->cur ^= (iters & 1);
+    s->launches += iters;
+  } else {
+    for (int t = 0; t < iters; ++t) {
+      rc = launch_sweep(s, t, false);
+      if (rc) return rc;
+    }
+  }
+  GLX_HIP(hipStreamSynchronize(s->stream));
+  return GLX_OK;
+}
+
+extern "C" int glx_spmm_bias(glx_graph* A, const void* Db, const void* u_in, void* u_out, int C, int iters) {
+  GLX_CHECK(A && u_in && u_out, GLX_EINVAL, "glx_spmm_bias: null argument");
+  GLX_CHECK(iters >= 0, GLX_EINVAL, "glx_spmm_bias: negative iters");
+  GLX_CHECK(A->n_rows == A->n_cols || iters <= 1, GLX_EINVAL, "glx_spmm_bias: iterating needs a square operator");
+  glx_sweep* s = nullptr;
+  int rc = glx_sweep_create(A, C, 0, 0, 0, &s);
+  if (rc) return rc;
+  rc = glx_sweep_set_state(s, u_in, Db);
+  if (!rc) {
+    for (int t = 0; t < iters && !rc; ++t) rc = launch_sweep(s, t, false);
+    if (!rc && hipStreamSynchronize(s->stream) != hipSuccess) { glx_set_error("glx_spmm_bias: sync failed"); rc = GLX_EHIP; }
+  }
+  if (!rc) rc = glx_sweep_fetch(s, u_out);
+  glx_sweep_destroy(s);
+  return rc;
+}
+
+extern "C" int glx_poisson_sweep(glx_graph* P, const void* Db, const double* w0, const double* deg, const double* vinf,
+                                 int C, int min_iter, int max_iter, void* u_out, int* T_out) {
+  GLX_CHECK(P && u_out, GLX_EINVAL, "glx_poisson_sweep: null argument");
+  if (max_iter == 0) {   // zero sweeps: u = 0
+    memset(u_out, 0, (size_t)P->n_rows * C * (P->dtype == GLX_F32 ? 4 : 8));
+    if (T_out) *T_out = 0;
+    return GLX_OK;
+  }
+  glx_sweep* s = nullptr;
+  int rc = glx_sweep_create(P, C, min_iter, max_iter, 0, &s);
+  if (rc) return rc;
+  rc = glx_sweep_set_problem(s, Db, w0, deg, vinf);
+  if (!rc) rc = glx_sweep_run(s, T_out, nullptr);
+  if (!rc) rc = glx_sweep_fetch(s, u_out);
+  glx_sweep_destroy(s);
+  return rc;
+}

@@ -1,0 +1,367 @@
+// Sliced-ELL SpMM over the n x C label matrix: the D^-1 W^T u sweep of Poisson learning
+// (reference graphlearning/ssl.py:667-670, :826-827) and the A@p product of utils.conjgrad
+// (utils.py:515,523) as one hand-written gfx950 kernel.
+//
+// Mapping: one wavefront = one slice of R = 64/G rows; the G lanes of a row each own one
+// 4-wide column vector of the vertex record (the last used lane owns the fp64 stop value),
+// so a neighbour gather is G adjacent lanes reading one contiguous, line-aligned record.
+// Entries of a row are accumulated sequentially in stored order with separate multiply
+// and add roundings (fp contraction off) -- the order scipy's csr_matvecs uses -- so fp64
+// results are bit-identical to the reference's CPU path.  No cross-lane reduction is
+// needed for the product itself; wavefront shuffles/DPP serve the entry broadcast, the
+// stop-test max and the CG column dots.
+#include "glx_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { typedef f32x4 type; };
+template <> struct VecOf<double> { typedef f64x4 type; };
+
+struct SpmmParams {
+  const int32_t* slot_row;
+  const int32_t* slot_len;
+  const int64_t* slice_ptr;
+  const int32_t* col;
+  const void* val;
+  int64_t nslices;
+  int64_t nblocks;
+  const char* xin;
+  char* xout;
+  const char* bias;
+  const uint8_t* slot_has_bias;
+  int rec_bytes;
+  int nlanes;  // active lanes per row: nvec + has_w
+  int nvec;
+  const double* deg;
+  const double* vinf;
+  const unsigned long long* err_prev;
+  unsigned long long* err_next;
+  unsigned long long thresh_bits;
+  double* dot_partial;
+  int dot_ld;
+  const double* exit_err;   // CG: skip the launch when !(*exit_err > exit_tol)
+  double exit_tol;
+};
+
+// ---- cross-lane helpers -------------------------------------------------------------
+template <int T> __device__ __forceinline__ int quad_bcast_i(int v) {
+  return __builtin_amdgcn_mov_dpp(v, T * 0x55, 0xf, 0xf, true);
+}
+template <int T> __device__ __forceinline__ float quad_bcast(float v) {
+  return __int_as_float(quad_bcast_i<T>(__float_as_int(v)));
+}
+template <int T> __device__ __forceinline__ double quad_bcast(double v) {
+  const int lo = quad_bcast_i<T>(__double2loint(v));
+  const int hi = quad_bcast_i<T>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_d(double v, int src) {
+  const int lo = __shfl(__double2loint(v), src);
+  const int hi = __shfl(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float shfl_t(float v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ double shfl_t(double v, int src) { return shfl_d(v, src); }
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), off);
+    const unsigned hi = __shfl_xor((unsigned)(v >> 32), off);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// XCD-aware block -> slice-group map: the dispatcher places block b on XCD b % 8; hand
+// each XCD a contiguous range of slices so rows that share neighbours share an L2.
+__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nb) {
+  const int64_t q = nb / 8, r = nb % 8;
+  const int64_t xcd = b % 8, i = b / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+template <typename T, bool HAS_W>
+__device__ __forceinline__ void accum4(typename VecOf<T>::type& acc, double& accw, T v, const typename VecOf<T>::type& x,
+                                       bool act, bool is_w) {
+#pragma clang fp contract(off)
+  typename VecOf<T>::type prod = x * v;
+  typename VecOf<T>::type sum = acc + prod;
+  if (act) acc = sum;
+  if constexpr (HAS_W && sizeof(T) == 4) {
+    // fp32 state: the stop value is an fp64 stored in elements 0..1 of the last vector
+    const double xw = __hiloint2double(__float_as_int(x[1]), __float_as_int(x[0]));
+    const double pw = (double)v * xw;
+    const double sw = accw + pw;
+    if (act && is_w) accw = sw;
+  }
+}
+
+template <typename T, int G, bool HAS_W, bool HAS_DOT>
+__global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
+#pragma clang fp contract(off)
+  typedef typename VecOf<T>::type V4;
+  constexpr int R = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  __shared__ double s_red[HAS_DOT ? 4 * 64 * 4 : 4];
+
+  if constexpr (HAS_W) {
+    if (p.err_prev) {   // stop test of ssl.py:667, decided identically by every wavefront
+      const unsigned long long m = wave_max_u64(p.err_prev[lane]);
+      if (m <= p.thresh_bits) return;
+    }
+  }
+  if constexpr (HAS_DOT) {
+    if (p.exit_err && !(*p.exit_err > p.exit_tol)) return;
+  }
+  const int64_t vb = xcd_remap(blockIdx.x, p.nblocks);
+  const int64_t slice = vb * 4 + wave;
+  const int g = lane / G, c = lane % G;
+  const bool lane_on = c < p.nlanes;
+  const bool is_w = HAS_W && (c == p.nvec);
+  int row = -1, len = 0, nchunks = 0;
+  int64_t base = 0;
+  if (slice < p.nslices) {
+    const int64_t slot = slice * R + g;
+    row = p.slot_row[slot];
+    len = p.slot_len[slot];
+    base = p.slice_ptr[slice];
+    nchunks = (int)((p.slice_ptr[slice + 1] - base) >> 6);
+  }
+  const T* __restrict__ valp = (const T*)p.val;
+  const size_t lane_off = (size_t)c * 4 * sizeof(T);
+  V4 acc = {0, 0, 0, 0};
+  double accw = 0.0;
+
+  for (int k = 0; k < nchunks; ++k) {
+    const int colv = p.col[base + (int64_t)k * 64 + lane];
+    const T valv = valp[base + (int64_t)k * 64 + lane];
+    const int j0 = k * G;
+    if constexpr (G == 4) {
+      const int c0 = quad_bcast_i<0>(colv), c1 = quad_bcast_i<1>(colv), c2 = quad_bcast_i<2>(colv), c3 = quad_bcast_i<3>(colv);
+      const T v0 = quad_bcast<0>(valv), v1 = quad_bcast<1>(valv), v2 = quad_bcast<2>(valv), v3 = quad_bcast<3>(valv);
+      const bool a0 = lane_on && j0 + 0 < len, a1 = lane_on && j0 + 1 < len, a2 = lane_on && j0 + 2 < len, a3 = lane_on && j0 + 3 < len;
+      V4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0}, x2 = {0, 0, 0, 0}, x3 = {0, 0, 0, 0};
+      if (a0) x0 = *(const V4*)(p.xin + (size_t)c0 * p.rec_bytes + lane_off);
+      if (a1) x1 = *(const V4*)(p.xin + (size_t)c1 * p.rec_bytes + lane_off);
+      if (a2) x2 = *(const V4*)(p.xin + (size_t)c2 * p.rec_bytes + lane_off);
+      if (a3) x3 = *(const V4*)(p.xin + (size_t)c3 * p.rec_bytes + lane_off);
+      accum4<T, HAS_W>(acc, accw, v0, x0, a0, is_w);
+      accum4<T, HAS_W>(acc, accw, v1, x1, a1, is_w);
+      accum4<T, HAS_W>(acc, accw, v2, x2, a2, is_w);
+      accum4<T, HAS_W>(acc, accw, v3, x3, a3, is_w);
+    } else {
+      const int gbase = lane & ~(G - 1);
+      for (int tb = 0; tb < G; tb += 4) {
+        int cj[4];
+        T vj[4];
+        bool aj[4];
+        V4 xj[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          cj[t] = __shfl(colv, gbase + tb + t);
+          vj[t] = shfl_t(valv, gbase + tb + t);
+          aj[t] = lane_on && (j0 + tb + t < len);
+          xj[t] = V4{0, 0, 0, 0};
+          if (aj[t]) xj[t] = *(const V4*)(p.xin + (size_t)cj[t] * p.rec_bytes + lane_off);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accum4<T, HAS_W>(acc, accw, vj[t], xj[t], aj[t], is_w);
+      }
+    }
+  }
+
+  // epilogue: u_out[row] = Db[row] + acc   (ssl.py:668: `Db + P*u`; addition commutes bitwise)
+  V4 outv = acc;
+  const bool store_on = lane_on && row >= 0;
+  if (store_on) {
+    bool hb = p.bias != nullptr;
+    if (hb && p.slot_has_bias) hb = p.slot_has_bias[slice * R + g] != 0;
+    if (hb) {
+      const V4 b = *(const V4*)(p.bias + (size_t)row * p.rec_bytes + lane_off);
+      outv = b + acc;
+    }
+    if constexpr (HAS_W && sizeof(T) == 4) {
+      if (is_w) {
+        outv[0] = __int_as_float(__double2loint(accw));
+        outv[1] = __int_as_float(__double2hiint(accw));
+        outv[2] = 0;
+        outv[3] = 0;
+      }
+    }
+    *(V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off) = outv;
+  }
+
+  if constexpr (HAS_W) {
+    if (p.err_next) {   // max_i |v_i - vinf_i| with v = deg * w  (ssl.py:667)
+      double e = 0.0;
+      if (store_on && is_w) {
+        double wnew;
+        if constexpr (sizeof(T) == 4) wnew = accw; else wnew = (double)outv[0];
+        e = fabs(p.deg[row] * wnew - p.vinf[row]);
+        if (e != e) e = __longlong_as_double(0x7ff0000000000000ll);   // NaN never satisfies the stop test
+      }
+      unsigned long long m = wave_max_u64((unsigned long long)__double_as_longlong(e));
+      __shared__ unsigned long long s_err[4];
+      if (lane == 0) s_err[wave] = m;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned long long mm = s_err[0];
+        for (int w = 1; w < 4; ++w) mm = s_err[w] > mm ? s_err[w] : mm;
+        if (mm != 0) atomicMax(&p.err_next[blockIdx.x & 63], mm);
+      }
+    }
+  }
+
+  if constexpr (HAS_DOT) {
+    // column dots sum_rows xin[row,c] * xout[row,c] (utils.py:524 `np.sum(p*Ap,axis=0)`):
+    // fixed-order tree inside the block, one partial row per block, reduced by the consumer.
+    double d[4] = {0, 0, 0, 0};
+    if (store_on) {
+      const V4 own = *(const V4*)(p.xin + (size_t)row * p.rec_bytes + lane_off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = (double)own[e] * (double)outv[e];
+    }
+#pragma unroll
+    for (int off = 32; off >= G; off >>= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] += shfl_d(d[e], lane ^ off);
+    }
+    if (lane < G) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s_red[(wave * 64 + lane) * 4 + e] = d[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < G && threadIdx.x < p.nvec) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double s = s_red[(0 * 64 + threadIdx.x) * 4 + e];
+        s += s_red[(1 * 64 + threadIdx.x) * 4 + e];
+        s += s_red[(2 * 64 + threadIdx.x) * 4 + e];
+        s += s_red[(3 * 64 + threadIdx.x) * 4 + e];
+        p.dot_partial[(size_t)vb * p.dot_ld + threadIdx.x * 4 + e] = s;
+      }
+    }
+  }
+}
+
+int64_t glx_spmm_blocks(const SellPlan* plan) { return (plan->nslices + 3) / 4; }
+
+template <typename T, int G>
+static int launch_g(const SweepArgs& a, const SpmmParams& p, hipStream_t stream) {
+  const dim3 grid((unsigned)p.nblocks), block(256);
+  if (a.dot_partial) {
+    hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, true>), grid, block, 0, stream, p);
+  } else if (a.has_w) {
+    hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false>), grid, block, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, false>), grid, block, 0, stream, p);
+  }
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}
+
+template <typename T>
+static int launch_t(const SweepArgs& a, const SpmmParams& p, hipStream_t stream) {
+  switch (a.plan->G) {
+    case 4: return launch_g<T, 4>(a, p, stream);
+    case 8: return launch_g<T, 8>(a, p, stream);
+    case 16: return launch_g<T, 16>(a, p, stream);
+    case 32: return launch_g<T, 32>(a, p, stream);
+    case 64: return launch_g<T, 64>(a, p, stream);
+  }
+  glx_set_error("spmm: unsupported lanes-per-row %d", a.plan->G);
+  return GLX_EUNSUPPORTED;
+}
+
+int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
+  GLX_CHECK(!(a.dot_partial && a.has_w), GLX_EINVAL, "spmm: dot and stop column are exclusive");
+  GLX_CHECK(a.plan->G == a.L.G, GLX_EINVAL, "spmm: plan G=%d but layout G=%d", a.plan->G, a.L.G);
+  if (a.plan->nslices == 0) return GLX_OK;
+  SpmmParams p;
+  p.slot_row = a.plan->d_slot_row;
+  p.slot_len = a.plan->d_slot_len;
+  p.slice_ptr = a.plan->d_slice_ptr;
+  p.col = a.plan->d_col;
+  p.val = a.plan->d_val;
+  p.nslices = a.plan->nslices;
+  p.nblocks = glx_spmm_blocks(a.plan);
+  p.xin = (const char*)a.xin;
+  p.xout = (char*)a.xout;
+  p.bias = (const char*)a.bias;
+  p.slot_has_bias = a.slot_has_bias;
+  p.rec_bytes = a.L.ld * a.L.esize;
+  p.nvec = a.L.nvec;
+  p.nlanes = a.L.nvec + (a.has_w ? 1 : 0);
+  p.deg = a.deg;
+  p.vinf = a.vinf;
+  p.err_prev = a.err_prev;
+  p.err_next = a.err_next;
+  union { double d; unsigned long long u; } cv;
+  cv.d = a.thresh;
+  p.thresh_bits = cv.u;
+  p.dot_partial = a.dot_partial;
+  p.dot_ld = a.L.nvec * 4;
+  p.exit_err = a.exit_err;
+  p.exit_tol = a.exit_tol;
+  return a.dtype == GLX_F32 ? launch_t<float>(a, p, stream) : launch_t<double>(a, p, stream);
+}
+
+// ---- dense (n,C) <-> vertex records ---------------------------------------------------
+template <typename T>
+__global__ void pack_kernel(const T* __restrict__ dense, T* __restrict__ rec, int64_t n, int C, int ld) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * ld) return;
+  const int64_t row = i / ld;
+  const int c = (int)(i % ld);
+  T v = 0;
+  if (c < C && dense) v = dense[row * C + c];
+  rec[i] = v;
+}
+
+template <typename T>
+__global__ void unpack_kernel(const T* __restrict__ rec, T* __restrict__ dense, int64_t n, int C, int ld) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * C) return;
+  const int64_t row = i / C;
+  const int c = (int)(i % C);
+  dense[i] = rec[row * ld + c];
+}
+
+__global__ void write_w_kernel(char* __restrict__ rec, int64_t n, int rec_bytes, int woff, const double* __restrict__ w) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < n) *(double*)(rec + (size_t)row * rec_bytes + woff) = w[row];
+}
+
+// dense (n,C) [or zeros when dense == nullptr] -> records; then the fp64 stop values, if any
+int glx_pack_records(const void* dense, void* rec, int64_t n, const RecLayout& L, int dtype, const double* w, hipStream_t s) {
+  const int64_t total = n * L.ld;
+  if (total == 0) return GLX_OK;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (dtype == GLX_F32)
+    hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dense, (float*)rec, n, L.C, L.ld);
+  else
+    hipLaunchKernelGGL(pack_kernel<double>, dim3(grid), dim3(256), 0, s, (const double*)dense, (double*)rec, n, L.C, L.ld);
+  GLX_HIP(hipGetLastError());
+  if (L.woff >= 0 && w) {
+    hipLaunchKernelGGL(write_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (char*)rec, n, L.ld * L.esize, L.woff, w);
+    GLX_HIP(hipGetLastError());
+  }
+  return GLX_OK;
+}
+
+int glx_unpack_records(const void* rec, void* dense, int64_t n, const RecLayout& L, int dtype, hipStream_t s) {
+  const int64_t total = n * L.C;
+  if (total == 0) return GLX_OK;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (dtype == GLX_F32)
+    hipLaunchKernelGGL(unpack_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)rec, (float*)dense, n, L.C, L.ld);
+  else
+    hipLaunchKernelGGL(unpack_kernel<double>, dim3(grid), dim3(256), 0, s, (const double*)rec, (double*)dense, n, L.C, L.ld);
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}

@@ -1,0 +1,49 @@
+"""Graph object: the part of reference graphlearning/graph.py on the hot path
+(`graph.__init__` :25-67, `degree_vector` :108-122, `degree_matrix` :210-233,
+`laplacian` :469-513).  The reference's `__ccode_init__` (graph.py:69-84, 0.4-0.6 s per
+construction at 70k nodes, never used by this path) is not executed."""
+import sys
+import numpy as np
+from scipy import sparse
+
+
+class graph:
+    def __init__(self, W, labels=None, features=None, label_names=None, node_names=None):
+        self.weight_matrix = sparse.csr_matrix(W)
+        self.labels = labels
+        self.features = features
+        self.num_nodes = W.shape[0]
+        self.label_names = label_names
+        self.node_names = node_names
+
+    def degree_vector(self):
+        """d_i = sum_j w_ij (row sums; reference graph.py:108-122)."""
+        return self.weight_matrix * np.ones(self.num_nodes)
+
+    def degree_matrix(self, p=1):
+        """Sparse diagonal matrix of d^p (reference graph.py:210-233)."""
+        d = self.degree_vector()
+        return sparse.spdiags(d ** p, 0, self.num_nodes, self.num_nodes).tocsr()
+
+    def laplacian(self, normalization='combinatorial'):
+        """D-W, I-D^-1 W or I-D^-1/2 W D^-1/2 (reference graph.py:469-513)."""
+        I = sparse.identity(self.num_nodes)
+        D = self.degree_matrix()
+        if normalization == 'combinatorial':
+            L = D - self.weight_matrix
+        elif normalization == 'randomwalk':
+            L = I - self.degree_matrix(p=-1) * self.weight_matrix
+        elif normalization == 'normalized':
+            Dh = self.degree_matrix(p=-0.5)
+            L = I - Dh * self.weight_matrix * Dh
+        else:
+            sys.exit('Invalid option for graph Laplacian normalization.')
+        return L.tocsr()
+
+    def subgraph(self, ind):
+        W = self.weight_matrix
+        return graph(W[ind, :][:, ind])
+
+    def isconnected(self):
+        from scipy.sparse import csgraph
+        return csgraph.connected_components(self.weight_matrix)[0] == 1

@@ -1,0 +1,350 @@
+"""Graph-based semi-supervised learning on the MI355X: the learners of reference
+graphlearning/ssl.py named by the north star -- `poisson` (:513-693), `poisson_mbo`
+(:695-839), `laplace` (:1106-1261) -- behind the reference's `ssl` contract (:131-510):
+`model = poisson(W, ...)`, `model.fit(train_ind, train_labels) -> (n,C)`,
+`model.predict()`, `model.fit_predict(...)`.
+
+As in the reference's own device seam (`if self.use_cuda:` ssl.py:649-663, :807-823) the
+host prepares the sparse operator and the dense right-hand side with scipy (O(nnz), once
+per fit) and the device runs every iteration; unlike the reference, the stop test, the
+conjugate-gradient solver and the volume-constrained projection run on the device too.
+
+Precision: `use_cuda=False` (default) computes in fp64 -- iterates are bit-identical to the
+reference CPU path for the sweeps, within rounding for CG; `use_cuda=True` computes in
+fp32 like the reference's torch.sparse.addmm branch and returns float32.
+"""
+import sys
+import numpy as np
+from scipy import sparse
+from . import graph as graph_mod
+from . import utils
+from . import _hip
+
+
+class ssl:
+    """Base class, reference ssl.py:131-510."""
+
+    def __init__(self, W, class_priors):
+        if W is None:
+            self.graph = None
+        else:
+            self.set_graph(W)
+        self.prob = None
+        self.fitted = False
+        self.name = ''
+        self.accuracy_filename = ''
+        self.requires_eig = False
+        self.onevsrest = False
+        self.similarity = True
+        self.class_priors = class_priors
+        if self.class_priors is not None:
+            self.class_priors = self.class_priors / np.sum(self.class_priors)
+        self.weights = 1
+        self.class_priors_error = 1
+        self.device = 0
+
+    def set_graph(self, W):
+        if type(W) == graph_mod.graph:
+            self.graph = W
+        else:
+            self.graph = graph_mod.graph(W)
+        self._cache = None      # device-resident operators belong to the previous graph
+
+    def volume_label_projection(self):
+        """Volume-constrained label decision (reference ssl.py:172-209) on the device:
+        at most 1e4 steps of w += -0.1 (class_size - priors); w /= w[0], stop at max error
+        <= 1e-3.  Updates self.weights / self.class_priors_error; returns the labels."""
+        k = self.prob.shape[1]
+        w = np.ones((k,)) if type(self.weights) == int else self.weights
+        labels, w, err, _ = _hip.argmax_project(self.prob, self.class_priors, w, max_steps=10000,
+                                                similarity=self.similarity, device=self.device)
+        self.weights = w
+        self.class_priors_error = err
+        return labels
+
+    def get_accuracy_filename(self):
+        fname = self.accuracy_filename
+        if self.class_priors is not None:
+            fname += '_classpriors'
+        fname += '_accuracy.csv'
+        return fname
+
+    def predict(self, ignore_class_priors=False):
+        """argmax of the globally min/max-normalised scores times the class weights
+        (reference ssl.py:230-266), on the device."""
+        if self.fitted == False:
+            sys.exit('Model has not been fitted yet.')
+        k = self.prob.shape[1]
+        if ignore_class_priors or type(self.weights) == int:
+            w = np.ones((k,))
+        else:
+            w = self.weights
+        labels, _, _, _ = _hip.argmax_project(self.prob, None, w, max_steps=0, similarity=self.similarity,
+                                              device=self.device)
+        return labels
+
+    def fit_predict(self, train_ind, train_labels, all_labels=None):
+        self.fit(train_ind, train_labels, all_labels=all_labels)
+        return self.predict()
+
+    def fit(self, train_ind, train_labels, all_labels=None):
+        """reference ssl.py:439-481."""
+        if self.graph is None:
+            sys.exit('SSL object has no graph. Use graph.set_graph() to provide a graph for SSL.')
+        self.fitted = True
+        train_ind = np.asarray(train_ind)
+        train_labels = np.asarray(train_labels)
+        if self.onevsrest:
+            unique_labels = np.unique(train_labels)
+            self.prob = np.zeros((self.graph.num_nodes, len(unique_labels)))
+            for i, l in enumerate(unique_labels):
+                self.prob[:, i] = self._fit(train_ind, train_labels == l)
+        else:
+            self.prob = self._fit(train_ind, train_labels, all_labels=all_labels)
+        if self.class_priors is not None:
+            self.volume_label_projection()
+        return self.prob
+
+    def _fit(self, train_ind, train_labels, all_labels=None):
+        raise NotImplementedError('Must override _fit')
+
+
+def _poisson_source(n, train_ind, train_labels):
+    """b[train] = onehot - mean(onehot) (reference ssl.py:619-622)."""
+    k = len(np.unique(train_labels))
+    onehot = utils.labels_to_onehot(train_labels, k)
+    source = np.zeros((n, onehot.shape[1]))
+    source[train_ind] = onehot - np.mean(onehot, axis=0)
+    return source, k
+
+
+class poisson(ssl):
+    def __init__(self, W=None, class_priors=None, solver='conjugate_gradient', p=1, use_cuda=False, min_iter=50,
+                 max_iter=1000, tol=1e-3, spectral_cutoff=10):
+        """Poisson learning, reference ssl.py:513-693.  Solvers 'conjugate_gradient'
+        (default) and 'gradient_descent' run on the GPU; 'spectral' (an eigensolver) is out
+        of this package's scope."""
+        super().__init__(W, class_priors)
+        if solver not in ['conjugate_gradient', 'spectral', 'gradient_descent']:
+            sys.exit('Invalid Poisson solver')
+        self.solver = solver
+        self.p = p
+        if p != 1:
+            self.solver = 'spectral'
+        self.use_cuda = use_cuda
+        self.min_iter = min_iter
+        self.max_iter = max_iter
+        self.tol = tol
+        self.spectral_cutoff = spectral_cutoff
+        fname = '_poisson'
+        if self.p != 1:
+            fname += '_p%.2f' % p
+        if self.solver == 'spectral':
+            fname += '_N%d' % self.spectral_cutoff
+            self.requries_eig = True
+        self.accuracy_filename = fname
+        self.name = 'Poisson Learning'
+        self.num_iter = None        # sweeps / CG iterations of the last fit
+
+    def _dtype(self):
+        # the reference's use_cuda switch only touches the gradient-descent branch (ssl.py:649)
+        return np.float32 if (self.use_cuda and self.solver == 'gradient_descent') else np.float64
+
+    def _operators(self):
+        """Host-side setup shared by every fit on this graph (reference ssl.py:615-617,
+        626-627, 634-635, 642-644): zero the diagonal, degrees, P = D^-1 W^T or the
+        normalised Laplacian; uploaded once and kept on the device."""
+        key = (id(self.graph.weight_matrix), self.solver, self._dtype())
+        if self._cache is not None and self._cache[0] == key:
+            return self._cache[1], self._cache[2]
+        n = self.graph.num_nodes
+        W = self.graph.weight_matrix
+        W = W - sparse.spdiags(W.diagonal(), 0, n, n)
+        G = graph_mod.graph(W)
+        aux = {}
+        if self.solver == 'conjugate_gradient':
+            L = G.laplacian(normalization='normalized')
+            aux['D'] = G.degree_matrix(p=-0.5)
+            dev = _hip.DeviceGraph(L, dtype=self._dtype(), device=self.device)
+        else:
+            D = G.degree_matrix(p=-1)
+            P = D * W.transpose()
+            deg = G.degree_vector()
+            aux['D'] = D
+            aux['deg'] = deg
+            aux['vinf'] = deg / np.sum(deg)
+            dev = _hip.DeviceGraph(P, dtype=self._dtype(), device=self.device)
+        if self._cache is not None:
+            self._cache[1].close()
+        self._cache = (key, dev, aux)
+        return dev, aux
+
+    def _fit(self, train_ind, train_labels, all_labels=None):
+        n = self.graph.num_nodes
+        source, k = _poisson_source(n, train_ind, train_labels)
+        if self.solver == 'conjugate_gradient':       # reference ssl.py:624-629
+            dev, aux = self._operators()
+            D = aux['D']
+            x, it, _ = dev.cg(np.ascontiguousarray(D * source, dtype=self._dtype()), tol=self.tol)
+            self.num_iter = it
+            u = D * x
+        elif self.solver == 'gradient_descent':       # reference ssl.py:631-677
+            dev, aux = self._operators()
+            Db = aux['D'] * source
+            v = np.zeros(n)
+            v[train_ind] = 1
+            v = v / np.sum(v)
+            w0 = v / aux['deg']       # w = D^-1 v rides along as the stop column (include/glx.h)
+            u, T = dev.poisson_sweep(Db, w0, aux['deg'], aux['vinf'], self.min_iter, self.max_iter)
+            self.num_iter = T
+            if all_labels is not None:
+                self.prob = u
+                acc = ssl_accuracy(self.predict(), all_labels, train_ind)
+                print('%d,Accuracy = %.2f' % (T, acc))
+        elif self.solver == 'spectral':
+            raise NotImplementedError("poisson(solver='spectral') needs an eigensolver, which is outside the "
+                                      'GPU hot path this package covers (SURVEY.md section 8)')
+        else:
+            sys.exit('Invalid Poisson solver ' + self.solver)
+        return u
+
+
+class poisson_mbo(ssl):
+    def __init__(self, W=None, class_priors=None, solver='conjugate_gradient', use_cuda=False, min_iter=50,
+                 max_iter=1000, tol=1e-3, spectral_cutoff=10, Ns=40, mu=1, T=20):
+        """PoissonMBO, reference ssl.py:695-839.  class_priors must be provided."""
+        super().__init__(W, class_priors)
+        self.poisson_model = poisson(W, solver=solver, use_cuda=use_cuda, min_iter=min_iter, max_iter=max_iter,
+                                     tol=tol, spectral_cutoff=spectral_cutoff)
+        self.Ns = Ns
+        self.mu = mu
+        self.T = T
+        self.use_cuda = use_cuda
+        fname = '_poisson_mbo'
+        if solver == 'spectral':
+            fname += '_N%d' % spectral_cutoff
+            self.requries_eig = True
+        fname += '_Ns_%d_mu_%.2f_T_%d' % (Ns, mu, T)
+        self.accuracy_filename = fname
+        self.name = 'Poisson MBO'
+
+    def _fit(self, train_ind, train_labels, all_labels=None):
+        Ns, mu, T = self.Ns, self.mu, self.T
+        dtype = np.float32 if self.use_cuda else np.float64
+        n = self.graph.num_nodes
+        W = self.graph.weight_matrix
+        W = W - sparse.spdiags(W.diagonal(), 0, n, n)
+        G = graph_mod.graph(W)
+        source, k = _poisson_source(n, train_ind, train_labels)
+        # initialise with Poisson learning (plain argmax: the inner model has no priors)
+        labels = self.poisson_model.fit_predict(train_ind, train_labels, all_labels=all_labels)
+        u = utils.labels_to_onehot(labels, k)
+        dt = 1 / np.max(G.degree_vector())                  # reference ssl.py:801
+        P = sparse.identity(n) - dt * G.laplacian()         # reference ssl.py:804
+        Db = mu * dt * source                               # reference ssl.py:805
+        dev = _hip.DeviceGraph(P, dtype=dtype, device=self.device)
+        heat = _hip.Sweep(dev, k, min_iter=0, max_iter=0, use_hipgraph=True)
+        try:
+            for i in range(T):
+                heat.set_state(u, Db)
+                heat.iterate(Ns)                            # Ns x `u = P*u + Db`, reference ssl.py:826-827
+                u = heat.fetch()
+                self.prob = u
+                labels = self.volume_label_projection()     # reference ssl.py:830-832
+                u = utils.labels_to_onehot(labels, k)
+                if all_labels is not None:
+                    acc = ssl_accuracy(labels, all_labels, train_ind)
+                    print('%d, Accuracy = %.2f' % (i, acc))
+        finally:
+            heat.close()
+            dev.close()
+        return u
+
+
+class laplace(ssl):
+    def __init__(self, W=None, class_priors=None, X=None, reweighting='none', normalization='combinatorial', tau=0,
+                 order=1, mean_shift=False, tol=1e-5, alpha=2, zeta=1e7, r=0.1):
+        """Laplace learning, reference ssl.py:1106-1261: Dirichlet sub-system solved by a
+        Jacobi-scaled multi-RHS conjugate gradient on the GPU.  Reweightings other than
+        'none' (graph.reweight, reference graph.py:368-466) are outside this package's scope."""
+        super().__init__(W, class_priors)
+        self.reweighting = reweighting
+        self.normalization = normalization
+        self.mean_shift = mean_shift
+        self.tol = tol
+        self.order = order
+        self.X = X
+        if type(tau) in [float, int]:
+            self.tau = np.ones(self.graph.num_nodes) * tau
+        elif type(tau) is np.ndarray:
+            self.tau = tau
+        fname = '_laplace'
+        self.name = 'Laplace Learning'
+        if self.reweighting != 'none':
+            fname += '_' + self.reweighting
+            self.name += ': ' + self.reweighting + ' reweighted'
+        if self.normalization != 'combinatorial':
+            fname += '_' + self.normalization
+            self.name += ' ' + self.normalization
+        if self.mean_shift:
+            fname += '_meanshift'
+            self.name += ' with meanshift'
+        if self.order > 1:
+            fname += '_order%d' % int(self.order)
+            self.name += ' order %d' % int(self.order)
+        if np.max(self.tau) > 0:
+            fname += '_tau_%.3f' % np.max(self.tau)
+            self.name += ' tau=%.3f' % np.max(self.tau)
+        self.accuracy_filename = fname
+        self.num_iter = None
+        self.dtype = np.float64
+
+    def _fit(self, train_ind, train_labels, all_labels=None):
+        if self.reweighting != 'none':
+            raise NotImplementedError("laplace(reweighting=%r): only 'none' is on the GPU hot path" % self.reweighting)
+        G = self.graph
+        n = G.num_nodes
+        k = len(np.unique(train_labels))
+        L = sparse.spdiags(self.tau, 0, n, n) + G.laplacian(normalization=self.normalization)
+        if self.order > 1:                                   # host-side SpGEMM, reference ssl.py:1223-1228
+            Lpow = L * L
+            for _ in range(2, self.order):
+                Lpow = L * Lpow
+            L = Lpow
+        F = utils.labels_to_onehot(train_labels, k)
+        idx = np.full((n,), True, dtype=bool)
+        idx[train_ind] = False
+        b = -L[:, train_ind] * F                             # reference ssl.py:1236-1237
+        b = b[idx, :]
+        A = L[idx, :]
+        A = A[:, idx]
+        m = A.shape[0]
+        M = A.diagonal()
+        M = sparse.spdiags(1 / np.sqrt(M + 1e-10), 0, m, m).tocsr()   # reference ssl.py:1244-1246
+        dev = _hip.DeviceGraph(M * A * M, dtype=self.dtype, device=self.device)
+        try:
+            v, it, _ = dev.cg(np.ascontiguousarray(M * b, dtype=self.dtype), tol=self.tol)   # reference ssl.py:1249
+        finally:
+            dev.close()
+        self.num_iter = it
+        v = M * v
+        u = np.zeros((n, k))
+        u[idx, :] = v
+        u[train_ind, :] = F
+        if self.mean_shift:
+            u -= np.mean(u, axis=0)
+        return u
+
+
+def ssl_accuracy(pred_labels, true_labels, train_ind):
+    """Accuracy in percent over nodes outside train_ind with a true label >= 0
+    (reference ssl.py:1795-1834)."""
+    mask = np.ones(len(pred_labels), dtype=bool)
+    if type(train_ind) != np.ndarray:
+        print('Warning: ssl_accuracy requires the indices of the labeled points, not just the number of labels.')
+    else:
+        mask[train_ind] = False
+    pred_labels = np.asarray(pred_labels)[mask]
+    true_labels = np.asarray(true_labels)[mask]
+    keep = true_labels >= 0
+    return 100 * np.mean(pred_labels[keep] == true_labels[keep])

@@ -1,0 +1,118 @@
+/* glx.h -- C-ABI of libglx.so: the MI355X (gfx950) device path for GraphLearning's
+ * kNN-graph + Poisson/Laplace label-propagation hot path.
+ *
+ * The reference (jwcalder/GraphLearning v1.7.5) has no FFI on this path; its only
+ * device seam is the `if self.use_cuda:` blocks of graphlearning/ssl.py:649-663 and
+ * :807-823 (host builds scipy CSR P and dense Db, the device runs the iteration, the
+ * result is copied back as numpy).  Its native calling convention elsewhere
+ * (c_code/cextensions.cpp:19-60, graph.py:69-84) is "caller pre-allocates C-contiguous
+ * numpy buffers with explicit dtypes, callee fills them in place".  libglx keeps that
+ * convention and adds status codes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative GLX_E* code on failure;
+ *     glx_last_error() returns a thread-local message for the last failure.
+ *   - host pointers are borrowed for the duration of the call; outputs are
+ *     caller-allocated unless stated (glx_knn_to_csr allocates, glx_free releases).
+ *   - dense matrices are C-contiguous (n, C); dtype codes: GLX_F32 = 0, GLX_F64 = 1.
+ *   - no global HIP state is created at load time (fork-safe; ssl.py:390-396 forks
+ *     workers through joblib): the device is touched on the first call only.
+ *   - functions ending in _dev take DEVICE pointers (e.g. torch tensors' data_ptr())
+ *     and a hipStream_t passed as void*; they never synchronise.
+ */
+#ifndef GLX_H
+#define GLX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLX_F32 0
+#define GLX_F64 1
+
+#define GLX_OK 0
+#define GLX_EINVAL (-1)   /* bad argument */
+#define GLX_EHIP (-2)     /* HIP runtime error (message has the hipError string) */
+#define GLX_ENOMEM (-3)
+#define GLX_EUNSUPPORTED (-4)
+
+typedef struct glx_graph glx_graph;   /* a sparse operator resident in HBM (sliced-ELL + CSR) */
+typedef struct glx_sweep glx_sweep;   /* a prepared Poisson / heat sweep: device state + launch plan */
+typedef struct glx_cg glx_cg;         /* a prepared multi-RHS conjugate-gradient solve */
+
+const char* glx_last_error(void);
+int glx_version(void);
+int glx_device_count(int* n);
+int glx_set_device(int device);
+int glx_device_synchronize(void);
+void glx_free(void* p);
+
+/* ---- sparse operator -------------------------------------------------------------
+ * Replaces utils.torch_sparse (graphlearning/utils.py:288-317): scipy CSR -> device.
+ * The entry order inside each CSR row is preserved: products accumulate a row's
+ * entries sequentially in stored order with separate multiply and add roundings,
+ * exactly like scipy's csr_matvecs, so fp64 results are bit-identical to `A * X`.
+ * n_cols may exceed n_rows (rank-local operator with halo columns).
+ * state_dtype selects the arithmetic/storage type of the dense operand (values are
+ * converted from the fp64 input once at upload). */
+int glx_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr,
+                     const int32_t* col, const double* val, int state_dtype, int device,
+                     glx_graph** out);
+int glx_graph_destroy(glx_graph* g);
+/* info[0]=n_rows,[1]=n_cols,[2]=nnz,[3]=stored entries incl. padding,[4]=slices,[5]=rows per slice,[6]=max row nnz */
+int glx_graph_info(const glx_graph* g, int64_t info[8]);
+
+/* u_out = Db + A u_in, applied `iters` times (u fed back).  Db may be NULL (no bias).
+ * Replaces `ut = torch.sparse.addmm(Dbt, Pt, ut)` (ssl.py:658, :821) / `u = Db + P*u`
+ * (ssl.py:668) / `u = P*u + Db` (ssl.py:827).  Host pointers, dtype = state_dtype. */
+int glx_spmm_bias(glx_graph* A, const void* Db, const void* u_in, void* u_out, int C, int iters);
+
+/* Poisson learning sweep, ssl.py:631-670: u <- Db + P u from u = 0 for T iterations,
+ * T = first T >= min_iter with max_i |deg_i w_T[i] - vinf_i| <= 1/n (w_t = D^-1 v_t obeys
+ * w_{t+1} = P w_t, so the reference's stop vector v rides along as one extra fp64
+ * column), capped at max_iter.  w0 = D^-1 v0, deg, vinf: (n,) fp64.  u_out (n,C). */
+int glx_poisson_sweep(glx_graph* P, const void* Db, const double* w0, const double* deg,
+                      const double* vinf, int C, int min_iter, int max_iter, void* u_out,
+                      int* T_out);
+
+/* prepared form of the same (used by bench.py and repeated fits on one graph) */
+int glx_sweep_create(glx_graph* P, int C, int min_iter, int max_iter, int use_hipgraph, glx_sweep** out);
+int glx_sweep_set_problem(glx_sweep* s, const void* Db, const double* w0, const double* deg, const double* vinf);
+int glx_sweep_run(glx_sweep* s, int* T_out, float* device_ms_out);   /* all iterations on device; HIP-event time */
+int glx_sweep_fetch(glx_sweep* s, void* u_out);
+int glx_sweep_launches(const glx_sweep* s, int64_t* sweep_kernel_launches);
+int glx_sweep_destroy(glx_sweep* s);
+
+/* Heat/MBO inner loop, ssl.py:826-827: u <- P u + Db, `iters` times, u resident on
+ * device between calls (glx_sweep created with min_iter = max_iter = 0 has no stop column). */
+int glx_sweep_set_state(glx_sweep* s, const void* u0, const void* Db);
+int glx_sweep_iterate(glx_sweep* s, int iters);
+
+/* ---- multi right-hand-side conjugate gradient -------------------------------------
+ * Replaces utils.conjgrad (graphlearning/utils.py:483-532): x0 = 0, per-column
+ * alpha/beta, global stop sqrt(sum over all columns ||r||^2) <= tol, max_iter cap. */
+int glx_cg_multi(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter,
+                 int* iters_out, double* err_out);
+
+/* ---- predict / volume-constrained projection --------------------------------------
+ * ssl.predict (ssl.py:230-266) and ssl.volume_label_projection (ssl.py:172-209) on
+ * device.  prob (n,C) fp64 host.  weights_inout (C,) fp64: all ones for a fresh model.
+ * max_steps = 0 -> plain predict with the given weights.  similarity!=0 -> argmax. */
+int glx_argmax_project(const double* prob, int64_t n, int C, const double* priors,
+                       double* weights_inout, int64_t* labels_out, double* err_out,
+                       int* steps_out, int max_steps, int similarity, int device);
+
+/* ---- kNN graph construction --------------------------------------------------------
+ * weightmatrix.knnsearch (graphlearning/weightmatrix.py:297-429), exact: brute-force
+ * tiled pairwise distances (fp32 MFMA candidate filter + fp64 direct-difference re-rank
+ * with an exactness check and fp64 fallback).  k counts the self point.  X (n,d) fp64
+ * host.  similarity 0 = euclidean, 1 = angular.  ind_out (n,k) int64, dist_out (n,k)
+ * fp64, rows ascending by (distance, index). */
+int glx_knn_bruteforce(const double* X, int64_t n, int d, int k, int similarity,
+                       int64_t* ind_out, double* dist_out, int device);
+int glx_knn_stats(double stats[8]);   /* last call: [0] tile-kernel ms, [1] rerank ms, [2] fallback rows, [3] total ms */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by IMPORTING THE REFERENCE.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    cd /root/repo && PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 \
+        MPLBACKEND=Agg python3 tests/golden/make_golden.py [--large]
+
+Versions the vectors were captured with: Python 3.10.12, numpy 2.2.6,
+scipy 1.15.3, scikit-learn 1.7.2, reference graphlearning 1.7.5.
+
+Every file holds inputs + the reference's outputs (data only; no reference
+source).  Iteration counts (T, CG iterations) are not returned by the
+reference API; they are recorded from the oracle after asserting that the
+oracle's iterates are bit-identical to the reference's for that case.
+"""
+import os
+import sys
+import json
+import hashlib
+import argparse
+import numpy as np
+from scipy import sparse
+import sklearn.datasets as skd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import graphlearning as gl                      # the REFERENCE (PYTHONPATH=/root/reference)
+from oracle import gl_oracle as orc             # our restatement, cross-checked below
+
+assert gl.__file__.startswith('/root/reference'), gl.__file__
+
+
+def csr_parts(W, prefix):
+    W = sparse.csr_matrix(W)
+    return {prefix + '_indptr': W.indptr.astype(np.int32), prefix + '_indices': W.indices.astype(np.int32),
+            prefix + '_data': W.data.astype(np.float64)}
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def blobs(n, d, C, seed, scale, labels=None):
+    rng = np.random.default_rng(seed)
+    centers = rng.normal(size=(C, d)) * scale
+    if labels is None:
+        labels = rng.integers(0, C, size=n)
+    X = centers[labels] + rng.normal(size=(n, d))
+    return X, labels.astype(np.int64)
+
+
+def g1_twomoons():
+    X, labels = skd.make_moons(n_samples=500, noise=0.1, random_state=0)
+    out = {'X': X, 'labels': labels.astype(np.int64)}
+    J, D = gl.weightmatrix.knnsearch(X, 11, method='kdtree')
+    out['knn_ind'], out['knn_dist'] = J.astype(np.int64), D
+    for kernel in ['gaussian', 'uniform', 'symgaussian', 'distance', 'singular']:
+        W = gl.weightmatrix.knn(X, 10, kernel=kernel, knn_data=(J.copy(), D.copy()))
+        out.update(csr_parts(W, 'W_' + kernel))
+    Wd = gl.weightmatrix.knn(X, 10, symmetrize=False, knn_data=(J.copy(), D.copy()))
+    out.update(csr_parts(Wd, 'W_gaussian_nosym'))
+    W = gl.weightmatrix.knn(X, 10, knn_data=(J.copy(), D.copy()))
+    train_ind = gl.trainsets.generate(labels, rate=5, seed=0)
+    train_labels = labels[train_ind]
+    out['train_ind'] = np.asarray(train_ind, dtype=np.int64)
+
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    out['poisson_gd_prob'] = m.fit(train_ind, train_labels)
+    out['poisson_gd_pred'] = m.predict()
+    u, T = orc.poisson_gd(W, train_ind, train_labels, return_T=True)
+    assert np.array_equal(u, out['poisson_gd_prob'])
+    out['poisson_gd_T'] = np.int64(T)
+
+    m = gl.ssl.poisson(W)
+    out['poisson_cg_prob'] = m.fit(train_ind, train_labels)
+    out['poisson_cg_pred'] = m.predict()
+    u, it = orc.poisson_cg(W, train_ind, train_labels, return_iters=True)
+    assert np.array_equal(u, out['poisson_cg_prob'])
+    out['poisson_cg_iters'] = np.int64(it)
+
+    # directed (non-symmetrized) graph through the sweep: exercises P = D^-1 W^T
+    m = gl.ssl.poisson(Wd, solver='gradient_descent')
+    out['poisson_gd_directed_prob'] = m.fit(train_ind, train_labels)
+    u, T = orc.poisson_gd(Wd, train_ind, train_labels, return_T=True)
+    assert np.array_equal(u, out['poisson_gd_directed_prob'])
+    out['poisson_gd_directed_T'] = np.int64(T)
+
+    for norm in ['combinatorial', 'randomwalk', 'normalized']:
+        m = gl.ssl.laplace(W, normalization=norm)
+        out['laplace_%s_prob' % norm] = m.fit(train_ind, train_labels)
+        out['laplace_%s_pred' % norm] = m.predict()
+        u, it = orc.laplace_fit(W, train_ind, train_labels, normalization=norm, return_iters=True)
+        assert np.array_equal(u, out['laplace_%s_prob' % norm])
+        out['laplace_%s_iters' % norm] = np.int64(it)
+    m = gl.ssl.laplace(W, tau=0.01, mean_shift=True)
+    out['laplace_tau_ms_prob'] = m.fit(train_ind, train_labels)
+
+    priors = gl.utils.class_priors(labels)
+    out['class_priors'] = priors
+    for solver in ['gradient_descent', 'conjugate_gradient']:
+        m = gl.ssl.poisson_mbo(W, priors, solver=solver)
+        pred = m.fit_predict(train_ind, train_labels)
+        out['poisson_mbo_%s_prob' % solver] = m.prob
+        out['poisson_mbo_%s_pred' % solver] = pred
+        out['poisson_mbo_%s_weights' % solver] = np.asarray(m.weights, dtype=float)
+    out['accuracy_poisson_gd'] = np.float64(gl.ssl.ssl_accuracy(out['poisson_gd_pred'], labels, train_ind))
+    np.savez_compressed(os.path.join(HERE, 'g1_twomoons.npz'), **out)
+    print('g1: T=%d cg=%d' % (out['poisson_gd_T'], out['poisson_cg_iters']))
+
+
+def g2_knn():
+    out = {}
+    for tag, (n, d, seed) in {'d20': (2000, 20, 10), 'd64': (2000, 64, 11), 'd3': (1500, 3, 12)}.items():
+        X, _ = blobs(n, d, 10, seed, 2.0)
+        J, D = gl.weightmatrix.knnsearch(X, 11, method='kdtree')
+        out['X_' + tag], out['J_' + tag], out['D_' + tag] = X, J.astype(np.int64), D
+    X = out['X_d20'][:400]
+    J, D = gl.weightmatrix.knnsearch(X, 11, method='brute')
+    out['Jb_brute400'], out['Db_brute400'] = J.astype(np.int64), D
+    J, D = gl.weightmatrix.knnsearch(X, 8, method='kdtree', similarity='angular')
+    out['J_angular400'], out['D_angular400'] = J.astype(np.int64), D
+    np.savez_compressed(os.path.join(HERE, 'g2_knn.npz'), **out)
+    print('g2 done')
+
+
+def g3_mid():
+    n, d, C, k = 5000, 20, 10, 10
+    X, labels = blobs(n, d, C, 3, 2.0)
+    out = {'X': X, 'labels': labels}
+    J, D = gl.weightmatrix.knnsearch(X, k + 1, method='kdtree')
+    out['knn_ind'], out['knn_dist'] = J.astype(np.int64), D
+    W = gl.weightmatrix.knn(X, k, knn_data=(J, D))
+    out.update(csr_parts(W, 'W'))
+    train_ind = gl.trainsets.generate(labels, rate=2, seed=1)
+    train_labels = labels[train_ind]
+    out['train_ind'] = np.asarray(train_ind, dtype=np.int64)
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    out['poisson_gd_prob'] = m.fit(train_ind, train_labels)
+    out['poisson_gd_pred'] = m.predict()
+    u, T = orc.poisson_gd(W, train_ind, train_labels, return_T=True)
+    assert np.array_equal(u, out['poisson_gd_prob'])
+    out['poisson_gd_T'] = np.int64(T)
+    m = gl.ssl.poisson(W)
+    out['poisson_cg_prob'] = m.fit(train_ind, train_labels)
+    out['poisson_cg_pred'] = m.predict()
+    u, it = orc.poisson_cg(W, train_ind, train_labels, return_iters=True)
+    assert np.array_equal(u, out['poisson_cg_prob'])
+    out['poisson_cg_iters'] = np.int64(it)
+    m = gl.ssl.laplace(W)
+    out['laplace_prob'] = m.fit(train_ind, train_labels)
+    out['laplace_pred'] = m.predict()
+    u, it = orc.laplace_fit(W, train_ind, train_labels, return_iters=True)
+    assert np.array_equal(u, out['laplace_prob'])
+    out['laplace_iters'] = np.int64(it)
+    priors = gl.utils.class_priors(labels)
+    m = gl.ssl.poisson_mbo(W, priors, solver='gradient_descent')
+    out['poisson_mbo_pred'] = m.fit_predict(train_ind, train_labels)
+    out['poisson_mbo_prob'] = m.prob
+    out['poisson_mbo_weights'] = np.asarray(m.weights, dtype=float)
+    out['class_priors'] = priors
+    np.savez_compressed(os.path.join(HERE, 'g3_blobs5000.npz'), **out)
+    print('g3: T=%d cg=%d lap=%d' % (out['poisson_gd_T'], out['poisson_cg_iters'], out['laplace_iters']))
+
+
+def g5_projection():
+    rng = np.random.default_rng(5)
+    n, C = 2000, 5
+    lab = rng.choice(C, size=n, p=[0.4, 0.25, 0.2, 0.1, 0.05])
+    prob = rng.normal(size=(n, C)) * 0.6
+    prob[np.arange(n), lab] += 1.0
+    prob[:, 0] += 0.4                      # bias so the first call needs several steps
+    priors = gl.utils.class_priors(lab)
+    W = sparse.identity(n, format='csr')
+    m = gl.ssl.poisson(W, class_priors=priors)
+    m.prob = prob.copy()
+    m.fitted = True
+    out = {'prob': prob, 'priors': priors, 'pred_plain': m.predict(ignore_class_priors=True)}
+    out['labels_1'] = m.volume_label_projection()
+    out['weights_1'] = np.array(m.weights, dtype=float)
+    out['err_1'] = np.float64(m.class_priors_error)
+    out['labels_2'] = m.volume_label_projection()          # warm start from weights_1
+    out['weights_2'] = np.array(m.weights, dtype=float)
+    _, w, e, it = orc.volume_label_projection(prob, priors, 1)
+    assert np.array_equal(w, out['weights_1'])
+    out['iters_1'] = np.int64(it)
+    np.savez_compressed(os.path.join(HERE, 'g5_projection.npz'), **out)
+    print('g5: iters=%d err=%g' % (it, e))
+
+
+def g6_helpers():
+    labels = np.load('/root/reference/Data/MNIST_labels.npz')['labels']
+    out = {'gen_rate1_seed0': np.asarray(gl.trainsets.generate(labels, rate=1, seed=0), dtype=np.int64),
+           'gen_rate3_seed7': np.asarray(gl.trainsets.generate(labels, rate=3, seed=7), dtype=np.int64),
+           'priors': gl.utils.class_priors(labels),
+           'onehot_small': gl.utils.labels_to_onehot(np.array([2, 0, 1, 1]), 3)}
+    multi = gl.trainsets.generate(labels[:5000], rate=2, num_trials=3, seed=4)
+    out['gen_multi'] = np.stack([np.asarray(t, dtype=np.int64) for t in multi])
+    out['gen_frac'] = np.asarray(gl.trainsets.generate(labels[:5000], rate=0.01, seed=9), dtype=np.int64)
+    perm = np.load('/root/reference/LabelPermutations/MNIST_permutations.npz', allow_pickle=True)['perm']
+    for i in range(10):
+        out['mnist_perm_%d' % i] = np.asarray(perm[i], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, 'g6_helpers.npz'), **out)
+    print('g6 done')
+
+
+def g4_large():
+    """Config 2 (70k) and config 3 (60k): checksums only; the graphs are
+    regenerated from seeds by the oracle on the GPU box."""
+    meta = {}
+    labels = np.load('/root/reference/Data/MNIST_labels.npz')['labels'].astype(np.int64)
+    rng = np.random.default_rng(0)
+    centers = rng.normal(size=(10, 20)) * 2.0
+    X = centers[labels] + rng.normal(size=(70000, 20))
+    J, D = gl.weightmatrix.knnsearch(X, 11, method='kdtree')
+    W = gl.weightmatrix.knn(X, 10, knn_data=(J, D))
+    train_ind = gl.trainsets.generate(labels, rate=1, seed=0)
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    prob = m.fit(train_ind, labels[train_ind])
+    u, T = orc.poisson_gd(W, train_ind, labels[train_ind], return_T=True)
+    assert np.array_equal(u, prob)
+    mc = gl.ssl.poisson(W)
+    probc = mc.fit(train_ind, labels[train_ind])
+    uc, itc = orc.poisson_cg(W, train_ind, labels[train_ind], return_iters=True)
+    assert np.array_equal(uc, probc)
+    meta['config2'] = dict(n=70000, d=20, k=10, nnz=int(W.nnz), row_nnz_max=int(np.diff(W.indptr).max()),
+                           J_sha=sha(J.astype(np.int64)), D_sum=float(D.sum()),
+                           W_indices_sha=sha(W.indices.astype(np.int32)), W_data_sum=float(W.data.sum()),
+                           train_ind=[int(t) for t in train_ind], T=int(T), prob_abs_sum=float(np.abs(prob).sum()),
+                           pred_sha=sha(m.predict().astype(np.int64)),
+                           accuracy=float(gl.ssl.ssl_accuracy(m.predict(), labels, train_ind)),
+                           cg_iters=int(itc), cg_prob_abs_sum=float(np.abs(probc).sum()),
+                           cg_pred_sha=sha(mc.predict().astype(np.int64)))
+    print('config2', meta['config2'])
+    clabels = np.load('/root/reference/Data/cifar_labels.npz')['labels'].astype(np.int64)
+    rng = np.random.default_rng(1)
+    centers = rng.normal(size=(10, 32)) * 1.2
+    X = centers[clabels] + rng.normal(size=(60000, 32))
+    J, D = gl.weightmatrix.knnsearch(X, 21, method='kdtree')
+    W = gl.weightmatrix.knn(X, 20, knn_data=(J, D))
+    train_ind = gl.trainsets.generate(clabels, rate=10, seed=0)
+    ml = gl.ssl.laplace(W)
+    prob = ml.fit(train_ind, clabels[train_ind])
+    ul, itl = orc.laplace_fit(W, train_ind, clabels[train_ind], return_iters=True)
+    assert np.array_equal(ul, prob)
+    meta['config3'] = dict(n=60000, d=32, k=20, nnz=int(W.nnz), row_nnz_max=int(np.diff(W.indptr).max()),
+                           J_sha=sha(J.astype(np.int64)), W_indices_sha=sha(W.indices.astype(np.int32)),
+                           W_data_sum=float(W.data.sum()), cg_iters=int(itl),
+                           prob_abs_sum=float(np.abs(prob).sum()), pred_sha=sha(ml.predict().astype(np.int64)),
+                           accuracy=float(gl.ssl.ssl_accuracy(ml.predict(), clabels, train_ind)))
+    print('config3', meta['config3'])
+    with open(os.path.join(HERE, 'g4_large_meta.json'), 'w') as f:
+        json.dump(meta, f, indent=1)
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--large', action='store_true', help='also regenerate the 70k/60k checksum file (minutes)')
+    args = ap.parse_args()
+    g1_twomoons()
+    g2_knn()
+    g3_mid()
+    g5_projection()
+    g6_helpers()
+    if args.large:
+        g4_large()

@@ -1,0 +1,213 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via graphlearning_amd) against the
+committed golden vectors of the reference and against the oracle on seeded inputs.
+Bars: bit-exact for labels / iteration counts / fp64 sweep iterates; 1e-5 (north star)
+or tighter, as stated per test, for CG iterates."""
+import numpy as np
+import pytest
+from scipy import sparse
+from conftest import csr_from, blobs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gl():
+    import graphlearning_amd as gl
+    from graphlearning_amd import _hip
+    _hip.require_device()
+    return gl
+
+
+@pytest.fixture(scope='module')
+def orc():
+    from oracle import gl_oracle
+    return gl_oracle
+
+
+def test_spmm_bias_bitexact_vs_scipy(gl, orc):
+    from graphlearning_amd import _hip
+    rng = np.random.default_rng(0)
+    for n, dens, C in [(1, 1.0, 3), (7, 0.5, 1), (300, 0.05, 10), (2000, 0.01, 13), (513, 0.03, 40)]:
+        A = sparse.random(n, n, density=dens, random_state=1, format='csr', dtype=np.float64)
+        u = rng.normal(size=(n, C))
+        Db = rng.normal(size=(n, C))
+        G = _hip.DeviceGraph(A)
+        got = G.spmm_bias(u, Db, iters=1)
+        assert np.array_equal(got, Db + A * u), (n, C)
+        got3 = G.spmm_bias(u, None, iters=3)
+        assert np.array_equal(got3, A * (A * (A * u))), (n, C)
+        G.close()
+
+
+def test_spmm_unsorted_rows_and_hubs(gl):
+    """Entry order inside a row is the accumulation order: unsorted / duplicate-free rows with
+    one hub row of ~n entries must match scipy's sequential sum bit for bit."""
+    from graphlearning_amd import _hip
+    rng = np.random.default_rng(3)
+    n = 700
+    A = sparse.random(n, n, density=0.02, random_state=2, format='lil', dtype=np.float64)
+    A[5, :] = rng.normal(size=n)          # hub
+    A = sparse.csr_matrix(A)
+    # shuffle entries inside each row
+    for i in range(n):
+        s, e = A.indptr[i], A.indptr[i + 1]
+        perm = rng.permutation(e - s)
+        A.indices[s:e] = A.indices[s:e][perm]
+        A.data[s:e] = A.data[s:e][perm]
+    A.has_sorted_indices = False
+    u = rng.normal(size=(n, 10))
+    G = _hip.DeviceGraph(A)
+    assert np.array_equal(G.spmm_bias(u), A * u)
+    G.close()
+
+
+def test_spmm_fp32(gl):
+    from graphlearning_amd import _hip
+    rng = np.random.default_rng(1)
+    A = sparse.random(1000, 1000, density=0.02, random_state=4, format='csr', dtype=np.float64)
+    u = rng.normal(size=(1000, 10)).astype(np.float32)
+    G = _hip.DeviceGraph(A, dtype=np.float32)
+    got = G.spmm_bias(u)
+    A32 = A.astype(np.float32)
+    assert got.dtype == np.float32
+    assert np.array_equal(got, A32 * u)     # scipy fp32 csr_matvecs: same order, same roundings
+    G.close()
+
+
+def test_twomoons_poisson_gd_golden(gl, golden):
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    train_ind = g['train_ind']
+    labels = g['labels']
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    u = m.fit(train_ind, labels[train_ind])
+    assert m.num_iter == int(g['poisson_gd_T']) == 409
+    assert np.array_equal(u, g['poisson_gd_prob'])          # bit-identical fp64 iterates
+    assert np.array_equal(m.predict(), g['poisson_gd_pred'])
+    assert gl.ssl.ssl_accuracy(m.predict(), labels, train_ind) == float(g['accuracy_poisson_gd'])
+
+
+def test_twomoons_poisson_gd_directed_golden(gl, golden):
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian_nosym')
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    u = m.fit(g['train_ind'], g['labels'][g['train_ind']])
+    assert m.num_iter == int(g['poisson_gd_directed_T'])
+    assert np.array_equal(u, g['poisson_gd_directed_prob'])
+
+
+def test_twomoons_poisson_gd_fp32(gl, golden):
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    m = gl.ssl.poisson(W, solver='gradient_descent', use_cuda=True)
+    u = m.fit(g['train_ind'], g['labels'][g['train_ind']])
+    assert u.dtype == np.float32
+    assert m.num_iter == 409
+    assert np.max(np.abs(u - g['poisson_gd_prob'])) < 1e-5   # north-star tolerance
+    assert np.array_equal(m.predict(), g['poisson_gd_pred'])
+
+
+def test_twomoons_poisson_cg_golden(gl, golden):
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    m = gl.ssl.poisson(W)
+    u = m.fit(g['train_ind'], g['labels'][g['train_ind']])
+    assert m.num_iter == int(g['poisson_cg_iters'])
+    assert np.max(np.abs(u - g['poisson_cg_prob'])) < 1e-5 * max(1.0, np.max(np.abs(g['poisson_cg_prob'])))
+    assert np.array_equal(m.predict(), g['poisson_cg_pred'])
+
+
+@pytest.mark.parametrize('norm', ['combinatorial', 'randomwalk', 'normalized'])
+def test_twomoons_laplace_golden(gl, golden, norm):
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    m = gl.ssl.laplace(W, normalization=norm)
+    u = m.fit(g['train_ind'], g['labels'][g['train_ind']])
+    assert m.num_iter == int(g['laplace_%s_iters' % norm])
+    assert np.max(np.abs(u - g['laplace_%s_prob' % norm])) < 1e-5
+    assert np.array_equal(m.predict(), g['laplace_%s_pred' % norm])
+
+
+def test_twomoons_laplace_tau_meanshift(gl, golden):
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    m = gl.ssl.laplace(W, tau=0.01, mean_shift=True)
+    u = m.fit(g['train_ind'], g['labels'][g['train_ind']])
+    assert np.max(np.abs(u - g['laplace_tau_ms_prob'])) < 1e-5
+
+
+@pytest.mark.parametrize('solver', ['gradient_descent', 'conjugate_gradient'])
+def test_twomoons_poisson_mbo_golden(gl, golden, solver):
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    m = gl.ssl.poisson_mbo(W, g['class_priors'], solver=solver)
+    pred = m.fit_predict(g['train_ind'], g['labels'][g['train_ind']])
+    assert np.array_equal(m.prob, g['poisson_mbo_%s_prob' % solver])
+    assert np.array_equal(pred, g['poisson_mbo_%s_pred' % solver])
+    assert np.allclose(m.weights, g['poisson_mbo_%s_weights' % solver], rtol=0, atol=1e-12)
+
+
+def test_projection_golden(gl, golden):
+    from graphlearning_amd import _hip
+    g = golden('g5_projection.npz')
+    lab0, _, _, _ = _hip.argmax_project(g['prob'], None, None, max_steps=0)
+    assert np.array_equal(lab0, g['pred_plain'])
+    lab1, w1, err1, it1 = _hip.argmax_project(g['prob'], g['priors'], None, max_steps=10000)
+    assert it1 == int(g['iters_1'])
+    assert np.array_equal(w1, g['weights_1'])            # bit-identical weights
+    assert np.array_equal(lab1, g['labels_1'])
+    assert err1 == float(g['err_1'])
+    lab2, w2, _, _ = _hip.argmax_project(g['prob'], g['priors'], w1, max_steps=10000)
+    assert np.array_equal(w2, g['weights_2'])
+    assert np.array_equal(lab2, g['labels_2'])
+
+
+def test_blobs5000_golden(gl, golden):
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    ti, lab = g['train_ind'], g['labels']
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    u = m.fit(ti, lab[ti])
+    assert m.num_iter == int(g['poisson_gd_T'])
+    assert np.array_equal(u, g['poisson_gd_prob'])
+    assert np.array_equal(m.predict(), g['poisson_gd_pred'])
+    m = gl.ssl.poisson(W)
+    u = m.fit(ti, lab[ti])
+    assert m.num_iter == int(g['poisson_cg_iters'])
+    scale = np.max(np.abs(g['poisson_cg_prob']))
+    assert np.max(np.abs(u - g['poisson_cg_prob'])) < 1e-5 * max(1.0, scale)
+    assert np.array_equal(m.predict(), g['poisson_cg_pred'])
+    m = gl.ssl.laplace(W)
+    u = m.fit(ti, lab[ti])
+    assert m.num_iter == int(g['laplace_iters'])
+    assert np.max(np.abs(u - g['laplace_prob'])) < 1e-5
+    assert np.array_equal(m.predict(), g['laplace_pred'])
+    m = gl.ssl.poisson_mbo(W, g['class_priors'], solver='gradient_descent')
+    pred = m.fit_predict(ti, lab[ti])
+    assert np.array_equal(pred, g['poisson_mbo_pred'])
+    assert np.array_equal(m.prob, g['poisson_mbo_prob'])
+
+
+def test_conjgrad_vs_oracle(gl, orc):
+    rng = np.random.default_rng(7)
+    n = 3000
+    A = sparse.random(n, n, density=0.003, random_state=5, format='csr')
+    A = A + A.T + sparse.identity(n) * 4.0
+    b = rng.normal(size=(n, 6))
+    x_ref, it_ref, err_ref = orc.conjgrad(sparse.csr_matrix(A), b, tol=1e-8, return_iters=True)
+    x, it, err = gl.utils.conjgrad(A, b, tol=1e-8, return_info=True)
+    assert it == it_ref
+    assert np.max(np.abs(x - x_ref)) < 1e-9
+
+
+def test_errors(gl):
+    from graphlearning_amd import _hip
+    A = sparse.identity(4, format='csr')
+    G = _hip.DeviceGraph(A)
+    with pytest.raises(_hip.GlxError):
+        G.spmm_bias(np.zeros((5, 2)))
+    with pytest.raises(_hip.GlxError):
+        _hip.DeviceGraph(A, dtype=np.int32)
+    G.close()
+    with pytest.raises(SystemExit):
+        gl.ssl.poisson(A, solver='nope')
