@@ -8,6 +8,7 @@
 #include "glx_internal.h"
 #include <string.h>
 #include <algorithm>
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -156,6 +157,75 @@ __global__ __launch_bounds__(256) void cg_reduce_kernel(const double* __restrict
   }
 }
 
+// ---- reference-order reductions ---------------------------------------------------------
+// numpy's `np.sum(a*b, axis=0)` on a C-contiguous (n,k) array accumulates row after row
+// (out[c] += a[i,c]*b[i,c], i ascending), a strictly sequential rounding chain per column.
+// Reproducing it makes the whole CG bit-identical to the reference (iteration count
+// included) -- necessary because the Poisson system is singular and 100+ CG iterations
+// amplify any reordering far beyond 1e-5.  One wavefront, lane c = column c; loads and
+// products are software-pipelined 8 rows deep, only the add chain is serial.
+// MODE 0: tot = sum p*Ap ; alpha = rsold / tot                                (utils.py:524)
+// MODE 1: tot = sum r*r  ; beta = tot / rsold ; rsold = tot ; err = sqrt(np.sum(tot)) (:527-530)
+// MODE 2: rsold = sum r*r                                                     (utils.py:517)
+template <typename T, int MODE>
+__global__ __launch_bounds__(64) void cg_seqdot_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t n, int ld,
+                                                       int ncols, int C, CgScalars sc, int it, double tol) {
+#pragma clang fp contract(off)
+  if (MODE != 2 && cg_done(sc.err_hist, it, tol)) return;
+  __shared__ double s_col[64];
+  const int c = threadIdx.x;
+  double tot = 0.0;
+  if (c < ncols) {
+    const T* pa = a + c;
+    const T* pb = b + c;
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+      T va[8], vb[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { va[q] = pa[(size_t)(i + q) * ld]; vb[q] = pb[(size_t)(i + q) * ld]; }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const T pr = va[q] * vb[q];        // elementwise product in the array dtype, as numpy forms p*Ap
+        tot = tot + (double)pr;
+      }
+    }
+    for (; i < n; ++i) {
+      const T pr = pa[(size_t)i * ld] * pb[(size_t)i * ld];
+      tot = tot + (double)pr;
+    }
+    if (MODE == 0) {
+      sc.alpha[c] = c < C ? sc.rsold[c] / tot : 0.0;
+    } else if (MODE == 1) {
+      sc.beta[c] = c < C ? tot / sc.rsold[c] : 0.0;
+      sc.rsold[c] = tot;
+    } else {
+      sc.rsold[c] = tot;
+    }
+  }
+  if (MODE == 1) {
+    s_col[c] = (c < C) ? tot : 0.0;
+    __syncthreads();
+    if (c == 0) {
+      // np.sum over a contiguous 1-D float64 array: numpy's pairwise_sum (8 accumulators
+      // below 128 elements, then a fixed tree; plain loop below 8 elements)
+      double e;
+      if (C < 8) {
+        e = 0.0;
+        for (int q = 0; q < C; ++q) e = e + s_col[q];
+      } else {
+        double r8[8];
+        for (int q = 0; q < 8; ++q) r8[q] = s_col[q];
+        int i = 8;
+        for (; i < C - (C % 8); i += 8)
+          for (int q = 0; q < 8; ++q) r8[q] = r8[q] + s_col[i + q];
+        e = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+        for (; i < C; ++i) e = e + s_col[i];
+      }
+      sc.err_hist[it] = sqrt(e);
+    }
+  }
+}
+
 __global__ void cg_set_err0(double* err_hist, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) err_hist[i] = i == 0 ? 1.0 : 0.0;
@@ -175,6 +245,9 @@ struct CgBufs {
 
 template <typename T>
 static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int* iters_out, double* err_out) {
+  // GLX_CG_REDUCE=tree selects block-tree reductions (faster, deterministic, not bit-identical to numpy)
+  const char* red_env = getenv("GLX_CG_REDUCE");
+  const bool exact = !(red_env && strcmp(red_env, "tree") == 0);
   const int64_t n = A->n_rows;
   const int dtype = A->dtype;
   RecLayout L;
@@ -185,7 +258,8 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   if (rc) return rc;
   const size_t es = L.esize;
   const int ncols = L.nvec * 4;
-  GLX_CHECK(ncols <= 256, GLX_EUNSUPPORTED, "glx_cg_multi: C=%d too wide for the column reducer", C);
+  GLX_CHECK(ncols <= (exact ? 64 : 256), GLX_EUNSUPPORTED, "glx_cg_multi: C=%d too wide for the column reducer", C);
+  GLX_CHECK(C <= 128 || !exact, GLX_EUNSUPPORTED, "glx_cg_multi: C=%d too wide for the reference-order reducer", C);
   GLX_CHECK(256 / (L.ld / 4) >= 1, GLX_EUNSUPPORTED, "glx_cg_multi: record too wide");
   const int64_t nb_spmm = std::max<int64_t>(glx_spmm_blocks(plan), 1);
   const int64_t nb_upd = std::max<int64_t>((n + UPD_ROWS_PER_BLOCK - 1) / UPD_ROWS_PER_BLOCK, 1);
@@ -229,7 +303,10 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   hipLaunchKernelGGL((cg_update_kernel<T, 1>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
                      (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, 1, tol);
   GLX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(cg_reduce_kernel<2>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, 0, tol);
+  if (exact)
+    hipLaunchKernelGGL((cg_seqdot_kernel<T, 2>), dim3(1), dim3(64), 0, st, (const T*)r, (const T*)r, n, L.ld, ncols, C, sc, 0, tol);
+  else
+    hipLaunchKernelGGL(cg_reduce_kernel<2>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, 0, tol);
   GLX_HIP(hipGetLastError());
 
   SweepArgs a;
@@ -239,7 +316,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   a.dtype = dtype;
   a.xin = b.p;
   a.xout = b.ap;
-  a.dot_partial = b.part_dot;
+  a.dot_partial = b.part_dot;   // the fused dot also carries the kernel's early-exit hook
   a.n_rows = n;
   a.exit_tol = tol;
   const unsigned pgrid = (unsigned)std::max<int64_t>(((int64_t)n * (L.ld / 4) + 255) / 256, 1);
@@ -256,12 +333,18 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
       a.exit_err = b.err_hist + (i - 1);
       rc = glx_launch_spmm(a, st);                                                   // Ap = A@p, p.Ap partials
       if (rc) return rc;
-      hipLaunchKernelGGL(cg_reduce_kernel<0>, dim3(1), blk, 0, st, (const double*)b.part_dot, nb_spmm, ncols, C, sc, i, tol);
+      if (exact)
+        hipLaunchKernelGGL((cg_seqdot_kernel<T, 0>), dim3(1), dim3(64), 0, st, (const T*)p, (const T*)ap, n, L.ld, ncols, C, sc, i, tol);
+      else
+        hipLaunchKernelGGL(cg_reduce_kernel<0>, dim3(1), blk, 0, st, (const double*)b.part_dot, nb_spmm, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
       hipLaunchKernelGGL((cg_update_kernel<T, 0>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
                          (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, i, tol);
       GLX_HIP(hipGetLastError());
-      hipLaunchKernelGGL(cg_reduce_kernel<1>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, i, tol);
+      if (exact)
+        hipLaunchKernelGGL((cg_seqdot_kernel<T, 1>), dim3(1), dim3(64), 0, st, (const T*)r, (const T*)r, n, L.ld, ncols, C, sc, i, tol);
+      else
+        hipLaunchKernelGGL(cg_reduce_kernel<1>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
       hipLaunchKernelGGL((cg_pupdate_kernel<T>), dim3(pgrid), blk, 0, st, (const T*)r, p, (const double*)sc.beta, n, L.ld, L.nvec,
                          (const double*)b.err_hist, i, tol, 1);
