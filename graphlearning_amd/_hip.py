@@ -56,6 +56,7 @@ _SIGNATURES = {
     'glx_cg_multi': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), _f64p],
     'glx_argmax_project': [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
     'glx_knn_bruteforce': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
+    'glx_knn_bruteforce_range': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
     'glx_knn_stats': [_f64p],
 }
 _SPECIAL = {'glx_last_error': ([], C.c_char_p), 'glx_free': ([_vp], None)}
@@ -268,17 +269,26 @@ def argmax_project(prob, priors=None, weights=None, max_steps=0, similarity=True
     return labels, w, err.value, steps.value
 
 
-def knn_bruteforce(X, k, similarity='euclidean', device=0):
-    X = np.ascontiguousarray(X, dtype=np.float64)
+def knn_bruteforce(X, k, similarity='euclidean', device=0, query_range=None):
+    """Exact kNN (incl. self) on the GPU.  'angular' = euclidean on row-normalised data, formed
+    with the reference's own expression (weightmatrix.py:344-345)."""
+    X = np.asarray(X, dtype=np.float64)
+    if similarity == 'angular':
+        X = X / np.linalg.norm(X, axis=1)[:, None]
+    elif similarity != 'euclidean':
+        raise GlxError('similarity %r not supported (euclidean, angular)' % (similarity,))
+    X = np.ascontiguousarray(X)
     n, d = X.shape
-    sim = {'euclidean': 0, 'angular': 1}[similarity]
-    ind = np.empty((n, k), dtype=np.int64)
-    dist = np.empty((n, k), dtype=np.float64)
-    check(load().glx_knn_bruteforce(_ptr(X), n, d, k, sim, _ptr(ind), _ptr(dist), device), 'glx_knn_bruteforce')
+    q0, q1 = (0, n) if query_range is None else query_range
+    ind = np.empty((q1 - q0, k), dtype=np.int64)
+    dist = np.empty((q1 - q0, k), dtype=np.float64)
+    check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, q0, q1, _ptr(ind), _ptr(dist), device),
+          'glx_knn_bruteforce')
     return ind, dist
 
 
 def knn_stats():
     out = (C.c_double * 8)()
     check(load().glx_knn_stats(out), 'glx_knn_stats')
-    return dict(tile_ms=out[0], rerank_ms=out[1], fallback_rows=out[2], total_ms=out[3])
+    return dict(tile_ms=out[0], rerank_ms=out[1], fallback_rows=out[2], total_ms=out[3], fallback_ms=out[4],
+                dpa=out[5], nsplit=out[6], KP=out[7])

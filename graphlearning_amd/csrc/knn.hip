@@ -1,11 +1,457 @@
-// placeholder until the MFMA tile kernel lands (next commit)
+// Exact k-nearest-neighbour search on the MI355X: weightmatrix.knnsearch of the reference
+// (graphlearning/weightmatrix.py:297-429; kdtree branch :349-352 is the exact answer we
+// reproduce).  Three stages:
+//   1. candidate filter -- brute-force tiled pairwise squared distances as an
+//      (n x d) @ (d x n) contraction on the fp32 matrix cores (v_mfma_f32_32x32x2_f32),
+//      refs staged through LDS, the norms folded into the contraction as two extra
+//      features so the accumulator IS |q|^2 + |r|^2 - 2 q.r; every lane owns one query
+//      column and keeps a sorted top-KP list of its half of the refs in LDS;
+//   2. exact re-rank -- fp64 direct-difference distances (the accumulation pattern of
+//      scipy cKDTree's sqeuclidean_distance_double) of the candidates, sorted by
+//      (distance, index); a row is accepted only if every candidate list's threshold
+//      exceeds the exact k-th distance by twice a bound on the fp32 error;
+//   3. fallback -- rows that fail the check are redone by an exact fp64 scan.
 #include "glx_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 static double g_knn_stats[8];
-extern "C" int glx_knn_bruteforce(const double* X, int64_t n, int d, int k, int similarity, int64_t* ind_out, double* dist_out, int device) {
-  glx_set_error("glx_knn_bruteforce: not built yet");
-  return GLX_EUNSUPPORTED;
-}
 extern "C" int glx_knn_stats(double stats[8]) {
+  GLX_CHECK(stats, GLX_EINVAL, "glx_knn_stats: null output");
   for (int i = 0; i < 8; ++i) stats[i] = g_knn_stats[i];
   return GLX_OK;
+}
+
+static const int BQ = 128;   // queries per workgroup (4 waves x 32)
+static const int BR_MAX = 128; // refs per LDS tile: 32 * NSUB
+
+// ---- stage 0: centred fp32 images with the norms folded in ---------------------------------
+// Rf[i] = [x_0..x_{d-1}, 0.., |x|^2, 1]   Qf[i] = [-2x_0..-2x_{d-1}, 0.., 1, |x|^2]   (dpa floats)
+__global__ void knn_prep_kernel(const double* __restrict__ X, const double* __restrict__ mean, int64_t n, int d, int dpa,
+                                float* __restrict__ Rf, float* __restrict__ Qf, float* __restrict__ qnorm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float nrm = 0.f;
+  for (int f = 0; f < d; ++f) {
+    const float x = (float)(X[i * d + f] - mean[f]);
+    Rf[i * dpa + f] = x;
+    Qf[i * dpa + f] = -2.f * x;
+    nrm = fmaf(x, x, nrm);
+  }
+  for (int f = d; f < dpa - 2; ++f) { Rf[i * dpa + f] = 0.f; Qf[i * dpa + f] = 0.f; }
+  Rf[i * dpa + dpa - 2] = nrm;
+  Rf[i * dpa + dpa - 1] = 1.f;
+  Qf[i * dpa + dpa - 2] = 1.f;
+  Qf[i * dpa + dpa - 1] = nrm;
+  qnorm[i] = sqrtf(nrm);
+}
+
+// ---- stage 1: MFMA tile kernel -------------------------------------------------------------
+template <int DH, int KP, int NSUB>
+__global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__ Rf, const float* __restrict__ Qf, int64_t n,
+                                                       int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d,
+                                                       int* __restrict__ cand_i) {
+  constexpr int DPA = 2 * DH;
+  constexpr int BR = 32 * NSUB;
+  constexpr int STRIDE = (DH % 2 == 1) ? DPA : DPA + 2;   // floats; ds_read_b64 of 32 rows hits 64 distinct banks
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tile = smem;                                  // [2][BR][STRIDE]
+  float* ld = smem + 2 * BR * STRIDE;                  // [KP][256] list distances
+  int* li = (int*)(ld + KP * 256);                     // [KP][256] list indices
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int64_t qb = blockIdx.x, sp = blockIdx.y;
+  const int64_t q = q_begin + qb * BQ + wave * 32 + j;   // this lane's query
+  const int64_t qc = q < q_end ? q : q_end - 1;
+  // query fragment: B[k = h][j] for k-step s is feature h*DH + s
+  float bq[DH];
+#pragma unroll
+  for (int s = 0; s < DH; ++s) bq[s] = Qf[qc * DPA + h * DH + s];
+#pragma unroll
+  for (int p = 0; p < KP; ++p) { ld[p * 256 + tid] = INFINITY; li[p * 256 + tid] = -1; }
+  float tau = INFINITY;
+
+  const int64_t ntiles = (n + BR - 1) / BR;
+  const int64_t t0 = ntiles * sp / nsplit, t1 = ntiles * (sp + 1) / nsplit;
+  auto stage = [&](int buf, int64_t t) {
+    // BR rows x DH float2 units; rows beyond n become "infinitely far" refs
+    float* dst = tile + buf * BR * STRIDE;
+    for (int u = tid; u < BR * DH; u += 256) {
+      const int r = u / DH, f2 = u % DH;
+      const int64_t ref = t * BR + r;
+      float2 v;
+      if (ref < n) {
+        v = *(const float2*)(Rf + ref * DPA + 2 * f2);
+      } else {
+        v.x = 0.f;
+        v.y = (f2 == DH - 1) ? 0.f : 0.f;
+        if (f2 == DH - 1) v.x = 1e30f;   // norm slot (feature DPA-2)
+      }
+      *(float2*)(dst + r * STRIDE + 2 * f2) = v;
+    }
+  };
+  if (t0 < t1) stage(0, t0);
+  __syncthreads();
+  for (int64_t t = t0; t < t1; ++t) {
+    const int buf = (int)((t - t0) & 1);
+    if (t + 1 < t1) stage(buf ^ 1, t + 1);
+    const float* tl = tile + buf * BR * STRIDE;
+    f32x16 acc[NSUB];
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[sub][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < DH; s += 2) {
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+        const float2 a = *(const float2*)(tl + (sub * 32 + j) * STRIDE + h * DH + s);
+        acc[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[s], acc[sub], 0, 0, 0);
+        if (s + 1 < DH) acc[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[s + 1], acc[sub], 0, 0, 0);
+      }
+    }
+    // selection: acc[sub][e] = dist^2(query j, ref sub*32 + (e&3) + 8*(e>>2) + 4*h)
+    float m = acc[0][0];
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m = fminf(m, acc[sub][e]);
+    if (m < tau) {
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[sub][e];
+          if (v < tau) {
+            const int ref = (int)(t * BR) + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            int p = KP - 1;
+            while (p > 0) {
+              const float prev = ld[(p - 1) * 256 + tid];
+              if (!(prev > v)) break;
+              ld[p * 256 + tid] = prev;
+              li[p * 256 + tid] = li[(p - 1) * 256 + tid];
+              --p;
+            }
+            ld[p * 256 + tid] = v;
+            li[p * 256 + tid] = ref;
+            tau = ld[(KP - 1) * 256 + tid];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (q < q_end) {
+    const int64_t lists = (int64_t)nsplit * 2;
+    const int64_t base = ((q - q_begin) * lists + sp * 2 + h) * KP;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+      cand_d[base + p] = ld[p * 256 + tid];
+      cand_i[base + p] = li[p * 256 + tid];
+    }
+  }
+}
+
+// ---- stage 2: exact fp64 re-rank + acceptance check ------------------------------------------
+// squared distance with the accumulation pattern of scipy's ckdtree sqeuclidean_distance_double
+// (4 partial sums over blocks of 4 coordinates, combined left to right, then the tail)
+__device__ __forceinline__ double sqdist_exact(const double* __restrict__ u, const double* __restrict__ v, int d) {
+#pragma clang fp contract(off)
+  double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+  int i = 0;
+  for (; i + 4 <= d; i += 4) {
+    const double d0 = u[i] - v[i], d1 = u[i + 1] - v[i + 1], d2 = u[i + 2] - v[i + 2], d3 = u[i + 3] - v[i + 3];
+    a0 = a0 + d0 * d0;
+    a1 = a1 + d1 * d1;
+    a2 = a2 + d2 * d2;
+    a3 = a3 + d3 * d3;
+  }
+  double s = a0 + a1 + a2 + a3;
+  for (; i < d; ++i) {
+    const double dd = u[i] - v[i];
+    s = s + dd * dd;
+  }
+  return s;
+}
+
+__device__ __forceinline__ bool lex_less(double da, int ia, double db, int ib) { return da < db || (da == db && ia < ib); }
+
+// one workgroup of 64 threads per query; M (power of two) candidate slots sorted in LDS
+__global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict__ X, int64_t n, int d, int k, int64_t q_begin,
+                                                        int64_t nq, const float* __restrict__ cand_d, const int* __restrict__ cand_i,
+                                                        int lists, int KP, int M, const float* __restrict__ qnorm, float rmax,
+                                                        double cerr, int64_t* __restrict__ ind_out, double* __restrict__ dist_out,
+                                                        int* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  double* sd = (double*)sm;          // [M]
+  int* si = (int*)(sd + M);          // [M]
+  const int64_t ql = blockIdx.x;
+  if (ql >= nq) return;
+  const int64_t q = q_begin + ql;
+  const int ncand = lists * KP;
+  const double* xq = X + q * d;
+  for (int c = threadIdx.x; c < M; c += 64) {
+    double dd = INFINITY;
+    int idx = 0x7fffffff;
+    if (c < ncand) {
+      const int ci = cand_i[ql * ncand + c];
+      if (ci >= 0 && ci < n) {
+        idx = ci;
+        dd = sqdist_exact(xq, X + (int64_t)ci * d, d);
+      }
+    }
+    sd[c] = dd;
+    si[c] = idx;
+  }
+  __syncthreads();
+  for (int size = 2; size <= M; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < M / 2; t += 64) {
+        const int lo = (t / stride) * stride * 2 + (t % stride);
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const double dl = sd[lo], dh = sd[hi];
+        const int il = si[lo], ih = si[hi];
+        const bool sw = up ? lex_less(dh, ih, dl, il) : lex_less(dl, il, dh, ih);
+        if (sw) { sd[lo] = dh; sd[hi] = dl; si[lo] = ih; si[hi] = il; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int c = threadIdx.x; c < k; c += 64) {
+    ind_out[ql * k + c] = si[c] == 0x7fffffff ? -1 : si[c];
+    dist_out[ql * k + c] = sqrt(sd[c]);
+  }
+  if (threadIdx.x == 0) {
+    // every ref outside a full list has fp32 dist^2 >= that list's threshold; accept the row
+    // only if no such ref can beat the exact k-th neighbour once the fp32 error is allowed for
+    const double dk2 = sd[k - 1];
+    const double rq = (double)qnorm[q] + (double)rmax;
+    const double eps = cerr * rq * rq;
+    int bad = !(dk2 < INFINITY);
+    for (int l = 0; l < lists && !bad; ++l) {
+      const float tau = cand_d[ql * ncand + l * KP + KP - 1];
+      if (tau < INFINITY && !((double)tau >= dk2 + 2.0 * eps)) bad = 1;
+    }
+    flags[ql] = bad;
+  }
+}
+
+// ---- stage 3: exact fp64 fallback for flagged rows --------------------------------------------
+// k rounds of "smallest (dist, idx) lexicographically greater than the last one picked"
+__global__ __launch_bounds__(256) void knn_fallback_kernel(const double* __restrict__ X, int64_t n, int d, int k, int64_t q_begin,
+                                                           const int* __restrict__ rows, int nrows, int64_t* __restrict__ ind_out,
+                                                           double* __restrict__ dist_out) {
+  __shared__ double s_d[256];
+  __shared__ int s_i[256];
+  __shared__ double last_d;
+  __shared__ int last_i;
+  const int64_t ql = rows[blockIdx.x];
+  const double* xq = X + (q_begin + ql) * d;
+  if (threadIdx.x == 0) { last_d = -1.0; last_i = -1; }
+  __syncthreads();
+  for (int r = 0; r < k; ++r) {
+    const double pd = last_d;
+    const int pi = last_i;
+    double bd = INFINITY;
+    int bi = 0x7fffffff;
+    for (int64_t ref = threadIdx.x; ref < n; ref += 256) {
+      const double dd = sqdist_exact(xq, X + ref * d, d);
+      if (lex_less(pd, pi, dd, (int)ref) && lex_less(dd, (int)ref, bd, bi)) { bd = dd; bi = (int)ref; }
+    }
+    s_d[threadIdx.x] = bd;
+    s_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off && lex_less(s_d[threadIdx.x + off], s_i[threadIdx.x + off], s_d[threadIdx.x], s_i[threadIdx.x])) {
+        s_d[threadIdx.x] = s_d[threadIdx.x + off];
+        s_i[threadIdx.x] = s_i[threadIdx.x + off];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      last_d = s_d[0];
+      last_i = s_i[0];
+      ind_out[ql * k + r] = s_i[0] == 0x7fffffff ? -1 : s_i[0];
+      dist_out[ql * k + r] = sqrt(s_d[0]);
+    }
+    __syncthreads();
+  }
+}
+
+// refs per tile = 32*NSUB, as many as fit LDS (160 KiB) beside the candidate lists
+constexpr int tile_nsub(int DH, int KP) {
+  const int stride = 2 * DH + 2;
+  for (int ns = 4; ns >= 1; ns /= 2)
+    if (2 * 32 * ns * stride * 4 + KP * 256 * 8 <= 150 * 1024) return ns;
+  return 1;
+}
+
+struct KnnBufs {
+  double *X = nullptr, *mean = nullptr, *dist = nullptr;
+  float *Rf = nullptr, *Qf = nullptr, *qnorm = nullptr, *cand_d = nullptr;
+  int *cand_i = nullptr, *flags = nullptr, *rows = nullptr;
+  int64_t* ind = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+  ~KnnBufs() {
+    hipFree(X); hipFree(mean); hipFree(dist); hipFree(Rf); hipFree(Qf); hipFree(qnorm); hipFree(cand_d);
+    hipFree(cand_i); hipFree(flags); hipFree(rows); hipFree(ind);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (e2) hipEventDestroy(e2);
+    if (e3) hipEventDestroy(e3);
+    if (stream) hipStreamDestroy(stream);
+  }
+};
+
+template <int DH, int KP>
+static int launch_tile(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st) {
+  constexpr int DPA = 2 * DH;
+  constexpr int STRIDE = (DH % 2 == 1) ? DPA : DPA + 2;
+  constexpr int NSUB = tile_nsub(DH, KP);
+  const size_t shm = (size_t)2 * 32 * NSUB * STRIDE * 4 + (size_t)KP * 256 * 8;
+  GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_kernel<DH, KP, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)nsplit);
+  hipLaunchKernelGGL((knn_tile_kernel<DH, KP, NSUB>), grid, dim3(256), shm, st, (const float*)b.Rf, (const float*)b.Qf, n, q0, q1, nsplit,
+                     b.cand_d, b.cand_i);
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}
+
+template <int KP>
+static int launch_tile_dh(int DH, const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st) {
+  switch (DH) {
+    case 8: return launch_tile<8, KP>(b, n, q0, q1, nsplit, st);
+    case 12: return launch_tile<12, KP>(b, n, q0, q1, nsplit, st);
+    case 18: return launch_tile<18, KP>(b, n, q0, q1, nsplit, st);
+    case 34: return launch_tile<34, KP>(b, n, q0, q1, nsplit, st);
+    case 66: return launch_tile<66, KP>(b, n, q0, q1, nsplit, st);
+  }
+  glx_set_error("knn: no tile kernel for %d features per half", DH);
+  return GLX_EUNSUPPORTED;
+}
+
+static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t q1, int64_t* ind_out, double* dist_out, int device) {
+  GLX_CHECK(X && ind_out && dist_out, GLX_EINVAL, "glx_knn_bruteforce: null argument");
+  GLX_CHECK(n >= 1 && d >= 1 && k >= 1, GLX_EINVAL, "glx_knn_bruteforce: need n, d, k >= 1 (n=%lld d=%d k=%d)", (long long)n, d, k);
+  GLX_CHECK(k <= n, GLX_EINVAL, "glx_knn_bruteforce: k=%d exceeds the number of points %lld", k, (long long)n);
+  GLX_CHECK(n < (1ll << 31) - BR_MAX, GLX_EINVAL, "glx_knn_bruteforce: n must fit int32");
+  GLX_CHECK(0 <= q0 && q0 <= q1 && q1 <= n, GLX_EINVAL, "glx_knn_bruteforce: bad query range");
+  GLX_CHECK(k <= 60, GLX_EUNSUPPORTED, "glx_knn_bruteforce: k=%d (incl. self) above the supported 60", k);
+  GLX_CHECK(d <= 130, GLX_EUNSUPPORTED, "glx_knn_bruteforce: d=%d above the supported 130", d);
+  const int64_t nq = q1 - q0;
+  if (nq == 0) return GLX_OK;
+  GLX_HIP(hipSetDevice(device));
+  int DH = 8;
+  for (int cand : {8, 12, 18, 34, 66})
+    if (2 * cand >= d + 2) { DH = cand; break; }
+  const int dpa = 2 * DH;
+  const int KP = k <= 12 ? 16 : (k <= 28 ? 32 : 64);
+  const int64_t nqb = (nq + BQ - 1) / BQ;
+  const int BR = 32 * tile_nsub(DH, KP);
+  const int64_t ntiles = (n + BR - 1) / BR;
+  int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, ntiles), (1024 + nqb - 1) / nqb));
+  const int lists = nsplit * 2;
+  const int ncand = lists * KP;
+  int M = 64;
+  while (M < ncand) M *= 2;
+
+  // centring in fp64 (distances are translation invariant; small norms keep the fp32 filter sharp)
+  std::vector<double> mean(d, 0.0);
+  for (int64_t i = 0; i < n; ++i)
+    for (int f = 0; f < d; ++f) mean[f] += X[i * d + f];
+  for (int f = 0; f < d; ++f) mean[f] /= (double)n;
+  double rmax2 = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    double s = 0.0;
+    for (int f = 0; f < d; ++f) { const double c = X[i * d + f] - mean[f]; s += c * c; }
+    rmax2 = std::max(rmax2, s);
+  }
+  GLX_CHECK(std::isfinite(rmax2), GLX_EINVAL, "glx_knn_bruteforce: non-finite input");
+  const float rmax = (float)(std::sqrt(rmax2) * (1.0 + 1e-6));
+  // |fp32 filter value - exact dist^2| <= cerr * (|q| + rmax)^2 : input rounding (2^-24 per coordinate),
+  // dpa products and sums at 2^-24 each, norms computed in fp32; generous constant
+  const double cerr = (double)(dpa + 8) * std::ldexp(1.0, -22);
+
+  KnnBufs b;
+  GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+  hipStream_t st = b.stream;
+  GLX_HIP(hipEventCreate(&b.e0));
+  GLX_HIP(hipEventCreate(&b.e1));
+  GLX_HIP(hipEventCreate(&b.e2));
+  GLX_HIP(hipEventCreate(&b.e3));
+  GLX_HIP(hipMalloc(&b.X, (size_t)n * d * 8));
+  GLX_HIP(hipMalloc(&b.mean, d * 8));
+  GLX_HIP(hipMalloc(&b.Rf, (size_t)n * dpa * 4));
+  GLX_HIP(hipMalloc(&b.Qf, (size_t)n * dpa * 4));
+  GLX_HIP(hipMalloc(&b.qnorm, (size_t)n * 4));
+  GLX_HIP(hipMalloc(&b.cand_d, (size_t)nq * ncand * 4));
+  GLX_HIP(hipMalloc(&b.cand_i, (size_t)nq * ncand * 4));
+  GLX_HIP(hipMalloc(&b.flags, (size_t)nq * 4));
+  GLX_HIP(hipMalloc(&b.rows, (size_t)nq * 4));
+  GLX_HIP(hipMalloc(&b.ind, (size_t)nq * k * 8));
+  GLX_HIP(hipMalloc(&b.dist, (size_t)nq * k * 8));
+  GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyHostToDevice, st));
+  GLX_HIP(hipMemcpyAsync(b.mean, mean.data(), d * 8, hipMemcpyHostToDevice, st));
+  GLX_HIP(hipEventRecord(b.e0, st));
+  hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const double*)b.mean,
+                     n, d, dpa, b.Rf, b.Qf, b.qnorm);
+  GLX_HIP(hipGetLastError());
+  int rc;
+  if (KP == 16) rc = launch_tile_dh<16>(DH, b, n, q0, q1, nsplit, st);
+  else if (KP == 32) rc = launch_tile_dh<32>(DH, b, n, q0, q1, nsplit, st);
+  else rc = launch_tile_dh<64>(DH, b, n, q0, q1, nsplit, st);
+  if (rc) return rc;
+  GLX_HIP(hipEventRecord(b.e1, st));
+  hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)nq), dim3(64), (size_t)M * 12, st, (const double*)b.X, n, d, k, q0, nq,
+                     (const float*)b.cand_d, (const int*)b.cand_i, lists, KP, M, (const float*)b.qnorm, rmax, cerr, b.ind, b.dist,
+                     b.flags);
+  GLX_HIP(hipGetLastError());
+  GLX_HIP(hipEventRecord(b.e2, st));
+  std::vector<int> flags(nq);
+  GLX_HIP(hipMemcpyAsync(flags.data(), b.flags, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipStreamSynchronize(st));
+  std::vector<int> rows;
+  for (int64_t i = 0; i < nq; ++i)
+    if (flags[i]) rows.push_back((int)i);
+  if (!rows.empty()) {
+    GLX_HIP(hipMemcpyAsync(b.rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(knn_fallback_kernel, dim3((unsigned)rows.size()), dim3(256), 0, st, (const double*)b.X, n, d, k, q0,
+                       (const int*)b.rows, (int)rows.size(), b.ind, b.dist);
+    GLX_HIP(hipGetLastError());
+  }
+  GLX_HIP(hipEventRecord(b.e3, st));
+  GLX_HIP(hipMemcpyAsync(ind_out, b.ind, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipMemcpyAsync(dist_out, b.dist, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipStreamSynchronize(st));
+  float ms_tile = 0, ms_rr = 0, ms_fb = 0;
+  GLX_HIP(hipEventElapsedTime(&ms_tile, b.e0, b.e1));
+  GLX_HIP(hipEventElapsedTime(&ms_rr, b.e1, b.e2));
+  GLX_HIP(hipEventElapsedTime(&ms_fb, b.e2, b.e3));
+  g_knn_stats[0] = ms_tile;
+  g_knn_stats[1] = ms_rr;
+  g_knn_stats[2] = (double)rows.size();
+  g_knn_stats[3] = ms_tile + ms_rr + ms_fb;
+  g_knn_stats[4] = ms_fb;
+  g_knn_stats[5] = (double)dpa;
+  g_knn_stats[6] = (double)nsplit;
+  g_knn_stats[7] = (double)KP;
+  return GLX_OK;
+}
+
+extern "C" int glx_knn_bruteforce(const double* X, int64_t n, int d, int k, int similarity, int64_t* ind_out, double* dist_out,
+                                  int device) {
+  GLX_CHECK(similarity == 0, GLX_EINVAL,
+            "glx_knn_bruteforce: similarity %d; only euclidean (0) -- normalise rows on the host for angular", similarity);
+  return knn_run(X, n, d, k, 0, n, ind_out, dist_out, device);
+}
+
+extern "C" int glx_knn_bruteforce_range(const double* X, int64_t n, int d, int k, int64_t q_begin, int64_t q_end,
+                                        int64_t* ind_out, double* dist_out, int device) {
+  return knn_run(X, n, d, k, q_begin, q_end, ind_out, dist_out, device);
 }

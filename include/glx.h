@@ -106,10 +106,15 @@ int glx_argmax_project(const double* prob, int64_t n, int C, const double* prior
  * weightmatrix.knnsearch (graphlearning/weightmatrix.py:297-429), exact: brute-force
  * tiled pairwise distances (fp32 MFMA candidate filter + fp64 direct-difference re-rank
  * with an exactness check and fp64 fallback).  k counts the self point.  X (n,d) fp64
- * host.  similarity 0 = euclidean, 1 = angular.  ind_out (n,k) int64, dist_out (n,k)
+ * host.  similarity must be 0 (euclidean); angular = euclidean on rows the caller normalised
+ * (the Python boundary does that with the reference's own expression).  ind_out (n,k) int64, dist_out (n,k)
  * fp64, rows ascending by (distance, index). */
 int glx_knn_bruteforce(const double* X, int64_t n, int d, int k, int similarity,
                        int64_t* ind_out, double* dist_out, int device);
+/* same search restricted to the query rows [q_begin, q_end) (rank-local share when the queries are
+ * sharded across GPUs; every rank holds all of X).  ind_out/dist_out: (q_end - q_begin, k). */
+int glx_knn_bruteforce_range(const double* X, int64_t n, int d, int k, int64_t q_begin, int64_t q_end,
+                             int64_t* ind_out, double* dist_out, int device);
 int glx_knn_stats(double stats[8]);   /* last call: [0] tile-kernel ms, [1] rerank ms, [2] fallback rows, [3] total ms */
 
 #ifdef __cplusplus

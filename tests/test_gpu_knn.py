@@ -1,0 +1,102 @@
+"""GPU parity of the exact kNN search and the kNN weight matrix against the reference's
+golden vectors (cKDTree results captured by tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+from conftest import csr_from, blobs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gl():
+    import graphlearning_amd as gl
+    from graphlearning_amd import _hip
+    _hip.require_device()
+    return gl
+
+
+@pytest.mark.parametrize('tag', ['d20', 'd64', 'd3'])
+def test_knnsearch_golden(gl, golden, tag):
+    g = golden('g2_knn.npz')
+    X, J, D = g['X_' + tag], g['J_' + tag], g['D_' + tag]
+    ind, dist = gl.weightmatrix.knnsearch(X, 11)
+    assert ind.dtype == np.int64 and dist.dtype == np.float64
+    assert np.array_equal(ind, J)                      # identical neighbour sets and order
+    assert np.array_equal(dist[:, 0], np.zeros(len(X)))  # self distance exactly 0
+    assert np.max(np.abs(dist - D)) <= 1e-12           # fp64 direct-difference distances
+    from graphlearning_amd import _hip
+    print(tag, _hip.knn_stats())
+
+
+def test_knnsearch_brute_and_angular_golden(gl, golden):
+    g = golden('g2_knn.npz')
+    X = g['X_d20'][:400]
+    ind, dist = gl.weightmatrix.knnsearch(X, 11, method='brute')
+    assert np.array_equal(ind, g['Jb_brute400'])
+    assert np.max(np.abs(dist - g['Db_brute400'])) <= 1e-12
+    ind, dist = gl.weightmatrix.knnsearch(X, 8, method='kdtree', similarity='angular')
+    assert np.array_equal(ind, g['J_angular400'])
+    assert np.max(np.abs(dist - g['D_angular400'])) <= 1e-12
+
+
+def test_knnsearch_edge_cases(gl):
+    from graphlearning_amd import _hip
+    rng = np.random.default_rng(0)
+    # tiny inputs, k == n, ragged tile (n not a multiple of 128), duplicates
+    for n, d, k in [(1, 3, 1), (5, 2, 5), (129, 7, 4), (300, 33, 30), (200, 130, 3)]:
+        X = rng.normal(size=(n, d))
+        ind, dist = _hip.knn_bruteforce(X, k)
+        D2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
+        ref = np.argsort(D2, axis=1, kind='stable')[:, :k]
+        assert np.array_equal(ind, ref), (n, d, k)
+        assert np.allclose(dist, np.sqrt(np.take_along_axis(D2, ref, 1)), rtol=0, atol=1e-12)
+    X = np.repeat(rng.normal(size=(40, 5)), 3, axis=0)       # every point three times
+    ind, dist = _hip.knn_bruteforce(X, 4)
+    assert np.all(dist[:, :3] == 0)
+    assert np.all(np.sort(ind[:, :3], axis=1) == (np.arange(120) // 3 * 3)[:, None] + np.arange(3))
+    with pytest.raises(_hip.GlxError):
+        _hip.knn_bruteforce(X, 1000)
+    with pytest.raises(SystemExit):
+        gl.weightmatrix.knnsearch(X, 3, similarity='manhattan')
+
+
+def test_knn_range_matches_full(gl):
+    from graphlearning_amd import _hip
+    X, _ = blobs(1000, 16, 5, 3, 2.0)
+    ind, dist = _hip.knn_bruteforce(X, 9)
+    ind2, dist2 = _hip.knn_bruteforce(X, 9, query_range=(300, 811))
+    assert np.array_equal(ind2, ind[300:811]) and np.array_equal(dist2, dist[300:811])
+
+
+@pytest.mark.parametrize('kernel', ['gaussian', 'uniform', 'symgaussian', 'distance', 'singular'])
+def test_knn_weightmatrix_golden(gl, golden, kernel):
+    g = golden('g1_twomoons.npz')
+    W = gl.weightmatrix.knn(g['X'], 10, kernel=kernel)
+    Wg = csr_from(g, 'W_' + kernel)
+    assert W.dtype == np.float64 and W.format == 'csr'
+    assert np.array_equal(W.indptr, Wg.indptr) and np.array_equal(W.indices, Wg.indices)
+    assert np.max(np.abs(W.data - Wg.data)) <= 1e-12
+    assert (abs(W - W.T) > 1e-15).nnz == 0 or kernel == 'symgaussian'
+    assert W.diagonal().sum() == 0
+
+
+def test_knn_weightmatrix_nosym_and_injected(gl, golden):
+    g = golden('g1_twomoons.npz')
+    W = gl.weightmatrix.knn(g['X'], 10, symmetrize=False)
+    Wg = csr_from(g, 'W_gaussian_nosym')
+    assert np.array_equal(W.indices, Wg.indices) and np.max(np.abs(W.data - Wg.data)) <= 1e-12
+    # knn_data injection (reference weightmatrix.py:122-123) needs no GPU search and is bit-identical
+    W2 = gl.weightmatrix.knn(None, 10, knn_data=(g['knn_ind'], g['knn_dist']))
+    Wg = csr_from(g, 'W_gaussian')
+    assert np.array_equal(W2.indices, Wg.indices) and np.array_equal(W2.data, Wg.data)
+
+
+def test_blobs5000_knn_graph_golden(gl, golden):
+    g = golden('g3_blobs5000.npz')
+    ind, dist = gl.weightmatrix.knnsearch(g['X'], 11)
+    assert np.array_equal(ind, g['knn_ind'])
+    assert np.max(np.abs(dist - g['knn_dist'])) <= 1e-12
+    W = gl.weightmatrix.knn(g['X'], 10)
+    Wg = csr_from(g, 'W')
+    assert np.array_equal(W.indptr, Wg.indptr) and np.array_equal(W.indices, Wg.indices)
+    assert np.max(np.abs(W.data - Wg.data)) <= 1e-12
