@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- Poisson-learning sweep rate on the MNIST-shaped k=10 graph (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "Config 2"): n = 70000 vertices,
+real MNIST label vector (tests/golden/MNIST_labels.npz), synthetic d = 20 Gaussian-blob
+features standing in for the absent MNIST-VAE blob, k = 10 Gaussian-kernel kNN graph built by
+the GPU search, one label per class (trainsets.generate(labels, rate=1, seed=0)).  One STEP is
+one Poisson gradient-descent solve: u <- D^-1 b + D^-1 W^T u from u = 0 until the reference's
+stop test fires (T = 50 sweeps on this graph), all on the device, inputs resident in HBM.
+value = sweeps per second (Poisson iters/sec); edges*classes/sec = value * nnz * C is reported
+beside it.  N > 1: every rank owns 70000 vertices of an (N*70000)-vertex graph (weak scaling),
+vertex-partitioned after an RCM reordering, one RCCL halo exchange per sweep.
+"""
+import os
+import sys
+import json
+import time
+import argparse
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_PER_RANK = 70000
+D_FEAT = 20
+K_NN = 10
+N_CLASSES = 10
+
+
+def load_labels(n_total):
+    """MNIST label vector, tiled when the weak-scaling graph is larger than 70000."""
+    path = os.path.join(ROOT, 'tests', 'golden', 'MNIST_labels.npz')
+    labels = np.load(path)['labels'].astype(np.int64)
+    reps = (n_total + len(labels) - 1) // len(labels)
+    return np.tile(labels, reps)[:n_total]
+
+
+def make_features(labels):
+    """SURVEY.md 8d config 2 generator (same as tests/golden/make_golden.py g4_large)."""
+    rng = np.random.default_rng(0)
+    centers = rng.normal(size=(N_CLASSES, D_FEAT)) * 2.0
+    return centers[labels] + rng.normal(size=(len(labels), D_FEAT))
+
+
+def algorithmic_bytes(n, nnz, C, s_v, s_u):
+    """Per-sweep algorithmic HBM bytes: CSR values + 4-byte indices, row pointer,
+    read u + read Db + write u, and the fused fp64 stop column read + write."""
+    return nnz * (s_v + 4) + 4 * (n + 1) + 3 * n * C * s_u + 2 * n * 8
+
+
+def cpu_baseline(W, train_ind, train_labels, u_hip, T_hip, budget_s=12.0):
+    """The oracle (scipy csr_matvecs / csc_matvec, the reference's own arithmetic) timed on this
+    host, single-threaded as scipy is: repeated `u = Db + P*u ; v = RW*v` sweeps for ~budget_s."""
+    from oracle import gl_oracle as orc
+    s = orc.poisson_gd_setup(W, train_ind, train_labels)
+    P, Db, RW = s['P'], s['Db'], s['RW']
+    n = W.shape[0]
+    u_ref, T_ref = orc.poisson_gd(W, train_ind, train_labels, return_T=True)
+    parity = bool(T_ref == T_hip and np.array_equal(u_ref, u_hip))
+    u = np.zeros((n, s['k']))
+    v = s['v0'].copy()
+    sweeps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for _ in range(10):
+            u = Db + P * u
+            v = RW * v
+        sweeps += 10
+    dt = time.perf_counter() - t0
+    return dict(value=sweeps / dt, unit='Poisson iters/sec', cores=1, kind='port',
+                sample='%d scipy sweeps (u=Db+P*u; v=RW*v) of the same 70000-vertex graph in %.1f s' % (sweeps, dt),
+                edges_classes_per_s=sweeps / dt * P.nnz * s['k']), parity, T_ref
+
+
+def run_single(args):
+    import torch
+    import graphlearning_amd as gl
+    from graphlearning_amd import _hip
+    _hip.require_device()
+    labels = load_labels(N_PER_RANK)
+    X = make_features(labels)
+    t0 = time.perf_counter()
+    W = gl.weightmatrix.knn(X, K_NN)
+    t_graph = time.perf_counter() - t0
+    knn_stats = _hip.knn_stats()
+    train_ind = gl.trainsets.generate(labels, rate=1, seed=0)
+    train_labels = labels[train_ind]
+    n, nnz, C = W.shape[0], W.nnz, N_CLASSES
+
+    results = {}
+    for dtype in (np.float64, np.float32):
+        model = gl.ssl.poisson(W, solver='gradient_descent', use_cuda=(dtype == np.float32))
+        dev, aux = model._operators()
+        source, k = gl.ssl._poisson_source(n, train_ind, train_labels)
+        Db = aux['D'] * source
+        v0 = np.zeros(n)
+        v0[train_ind] = 1
+        v0 = v0 / np.sum(v0)
+        sweep = _hip.Sweep(dev, k, min_iter=model.min_iter, max_iter=model.max_iter, use_hipgraph=True)
+        sweep.set_problem(Db, v0 / aux['deg'], aux['deg'], aux['vinf'])
+        for _ in range(args.warmup):
+            sweep.run()
+        torch.cuda.synchronize()
+        dev_ms = 0.0
+        T = 0
+        l0 = sweep.launches()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            T, ms = sweep.run()
+            dev_ms += ms
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        launches = sweep.launches() - l0
+        u = sweep.fetch()
+        results[dtype] = dict(T=T, wall=wall, dev_ms=dev_ms, launches=launches, u=u, info=dev.info())
+        sweep.close()
+
+    r64, r32 = results[np.float64], results[np.float32]
+    T = r64['T']
+    sweeps = args.steps * T
+    value = sweeps / r64['wall']
+    # dominant kernel: spmm_sell_kernel<double,4,true,false>; HIP events bracket the launches on the library's stream
+    abytes = algorithmic_bytes(n, nnz, C, 8, 8)
+    avg_launch_s = r64['dev_ms'] * 1e-3 / max(r64['launches'], 1)
+    achieved = abytes / avg_launch_s / 1e9
+    roof = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
+                traffic=None, kernel='spmm_sell_kernel<double,4,true,false>', algorithmic_bytes_per_launch=abytes,
+                avg_launch_us=avg_launch_s * 1e6)
+    cpu, parity, T_ref = cpu_baseline(W, train_ind, train_labels, r64['u'], T)
+    a32 = algorithmic_bytes(n, nnz, C, 4, 4)
+    line = {
+        'metric': 'Poisson iters/sec', 'value': value, 'unit': 'iters/s', 'n_gpus': 1, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': r64['wall'] / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: MNIST-shaped k=10 kNN graph, n=70000, nnz=%d, C=10, ssl.poisson '
+                               'gradient_descent (T=%d sweeps per step, stop test included)' % (nnz, T),
+                   'n': n, 'nnz': int(nnz), 'classes': C, 'sweeps_per_step': T},
+        'edges_classes_per_sec': value * nnz * C,
+        'roofline': roof,
+        'cpu_baseline': cpu,
+        'speedup_vs_cpu_baseline': value / cpu['value'],
+        'parity': {'bit_identical_to_oracle': parity, 'T': T, 'T_oracle': T_ref,
+                   'fp32_max_abs_diff': float(np.max(np.abs(r32['u'].astype(np.float64) - r64['u'])))},
+        'fp32': {'value': args.steps * r32['T'] / r32['wall'],
+                 'roofline_frac': a32 / (r32['dev_ms'] * 1e-3 / max(r32['launches'], 1)) / 1e9 / HBM_PEAK_GBS},
+        'graph_build': {'knn_plus_weights_s': t_graph, 'knn_tile_ms': knn_stats['tile_ms'],
+                        'knn_total_ms': knn_stats['total_ms'], 'fallback_rows': knn_stats['fallback_rows'],
+                        'sell': r64['info']},
+    }
+    print(json.dumps(line))
+
+
+def run_distributed(args):
+    from graphlearning_amd import dist_bench
+    dist_bench.main(args)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    args = ap.parse_args()
+    if args.gpus > 1 or int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        run_distributed(args)
+    else:
+        run_single(args)
+
+
+if __name__ == '__main__':
+    main()

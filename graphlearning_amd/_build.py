@@ -32,7 +32,7 @@ def build_lib(force=False, verbose=False):
     if not os.path.exists(hipcc):
         hipcc = 'hipcc'
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
-           '-Wno-unused-result', '-o', LIB + '.tmp'] + sources()
+           '-Wno-unused-result'] + os.environ.get('GLX_CXXFLAGS', '').split() + ['-o', LIB + '.tmp'] + sources()
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

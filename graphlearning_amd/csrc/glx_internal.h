@@ -44,14 +44,21 @@ int glx_make_layout(int C, int dtype, bool has_w, RecLayout* L);
 // processes; entries are stored in chunks of 64: chunk k of a slice holds, for row
 // slot g and t in [0,G), the entry jj = k*G + t of that row at index g*G + t, so a
 // wavefront fetches a whole chunk with one coalesced load and hands entry t to the
-// G lanes of a row with a DPP quad broadcast.
+// G lanes of a row with a DPP quad broadcast.  In G = 4 plans a long row occupies S = 4 or
+// 16 consecutive slots (its entries dealt to them 4 at a time, in order), see sweep.hip.
+struct SliceHdr {
+  int64_t ptr;      // entry offset of the slice's first chunk (multiple of 64)
+  int32_t nchunks;  // 64-entry chunks
+  int32_t S;        // segments per row: 1, or 4 / 16 for long rows (G = 4 plans)
+};
+
 struct SellPlan {
   int G = 0, R = 0;
   int64_t nslices = 0;
   int64_t stored = 0;          // stored entries incl. padding
   int32_t* d_slot_row = nullptr;   // [nslices*R] row id or -1
   int32_t* d_slot_len = nullptr;   // [nslices*R]
-  int64_t* d_slice_ptr = nullptr;  // [nslices+1] entry offset (multiple of 64)
+  SliceHdr* d_slice_hdr = nullptr; // [nslices]
   int32_t* d_col = nullptr;        // [stored]
   void* d_val = nullptr;           // [stored] of state dtype
 };

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <algorithm>
 #include <numeric>
+#include <stdlib.h>
 
 static thread_local std::string g_err;
 
@@ -100,7 +101,7 @@ extern "C" int glx_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, con
 static void free_plan(SellPlan& p) {
   hipFree(p.d_slot_row);
   hipFree(p.d_slot_len);
-  hipFree(p.d_slice_ptr);
+  hipFree(p.d_slice_hdr);
   hipFree(p.d_col);
   hipFree(p.d_val);
   p = SellPlan();
@@ -129,9 +130,10 @@ extern "C" int glx_graph_info(const glx_graph* g, int64_t info[8]) {
   return GLX_OK;
 }
 
-// Build (once per G) the sliced-ELL image of the operator.  Rows are handed to
-// wavefront slices in order of decreasing length (longest first: LPT balance, little
-// padding inside a slice); the ENTRY order inside a row is untouched.
+// Build (once per G) the sliced-ELL image of the operator.  Rows are handed to wavefront
+// slices in order of decreasing length (longest first: LPT balance, little padding inside a
+// slice); the ENTRY order inside a row is untouched.  G = 4 plans split rows longer than L1
+// entries over S = 4 slots and rows longer than L4 over S = 16 slots (GLX_SELL_L1/L4).
 int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   for (auto& p : g->plans)
     if (p.G == G) {
@@ -141,7 +143,10 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   GLX_HIP(hipSetDevice(g->device));
   const int R = 64 / G;
   const int64_t n = g->n_rows;
-  const int64_t nslices = (n + R - 1) / R;
+  int L1 = 32, L4 = 128;   // measured on the 70k k=10 graph: 24..32 / 96..128 are within noise
+  if (const char* e = getenv("GLX_SELL_L1")) L1 = std::max(4, atoi(e));
+  if (const char* e = getenv("GLX_SELL_L4")) L4 = std::max(L1, atoi(e));
+  if (G != 4) { L1 = 1 << 30; L4 = 1 << 30; }
   std::vector<int32_t> order(n);
   {
     // counting sort by decreasing length, stable in row id
@@ -150,35 +155,57 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
     for (size_t b = 1; b < cnt.size(); ++b) cnt[b] += cnt[b - 1];
     for (int64_t i = 0; i < n; ++i) order[cnt[g->max_row - (g->h_rowptr[i + 1] - g->h_rowptr[i])]++] = (int32_t)i;
   }
-  std::vector<int32_t> slot_row(nslices * R, -1), slot_len(nslices * R, 0);
-  std::vector<int64_t> slice_ptr(nslices + 1, 0);
-  for (int64_t s = 0; s < nslices; ++s) {
+  auto rowlen = [&](int32_t row) { return g->h_rowptr[row + 1] - g->h_rowptr[row]; };
+  // slices: consecutive runs of the sorted rows with the same S, R/S rows each
+  std::vector<SliceHdr> hdr;
+  std::vector<int32_t> slot_row, slot_len;
+  int64_t pos = 0, stored = 0;
+  while (pos < n) {
+    const int len0 = rowlen(order[pos]);
+    const int S = len0 > L4 ? 16 : (len0 > L1 ? 4 : 1);
+    const int rows_per = R / S;
+    SliceHdr h;
+    h.ptr = stored;
+    h.S = S;
     int width = 0;
-    for (int r = 0; r < R; ++r) {
-      const int64_t slot = s * R + r;
-      if (slot < n) {
-        const int32_t row = order[slot];
-        slot_row[slot] = row;
-        slot_len[slot] = g->h_rowptr[row + 1] - g->h_rowptr[row];
-        width = std::max(width, slot_len[slot]);
+    int filled = 0;
+    for (int r = 0; r < rows_per; ++r) {
+      int32_t row = -1;
+      int len = 0;
+      if (pos < n) {
+        const int l = rowlen(order[pos]);
+        const int Sr = l > L4 ? 16 : (l > L1 ? 4 : 1);
+        if (Sr == S) { row = order[pos]; len = l; ++pos; ++filled; }
       }
+      for (int sgm = 0; sgm < S; ++sgm) { slot_row.push_back(row); slot_len.push_back(len); }
+      width = std::max(width, len);
     }
-    const int64_t nchunks = (width + G - 1) / G;
-    slice_ptr[s + 1] = slice_ptr[s] + nchunks * 64;
+    (void)filled;
+    h.nchunks = (width + 4 * S - 1) / (4 * S) * (G / 4 > 1 ? 1 : 1);
+    if (G != 4) h.nchunks = (width + G - 1) / G;
+    stored += (int64_t)h.nchunks * 64;
+    hdr.push_back(h);
   }
-  const int64_t stored = slice_ptr[nslices];
+  const int64_t nslices = (int64_t)hdr.size();
   std::vector<int32_t> col(stored, 0);
   std::vector<double> val64;
   std::vector<float> val32;
   if (g->dtype == GLX_F64) val64.assign(stored, 0.0); else val32.assign(stored, 0.0f);
   for (int64_t s = 0; s < nslices; ++s) {
-    for (int r = 0; r < R; ++r) {
-      const int64_t slot = s * R + r;
-      const int32_t row = slot_row[slot];
+    const int S = hdr[s].S;
+    for (int slot = 0; slot < R; slot += S) {
+      const int32_t row = slot_row[s * R + slot];
       if (row < 0) continue;
       const int64_t b = g->h_rowptr[row];
-      for (int jj = 0; jj < slot_len[slot]; ++jj) {
-        const int64_t idx = slice_ptr[s] + (int64_t)(jj / G) * 64 + r * G + (jj % G);
+      const int len = slot_len[s * R + slot];
+      for (int jj = 0; jj < len; ++jj) {
+        int64_t idx;
+        if (G == 4) {
+          const int k = jj / (4 * S), sgm = (jj % (4 * S)) / 4, t = jj % 4;
+          idx = hdr[s].ptr + (int64_t)k * 64 + (slot + sgm) * 4 + t;
+        } else {
+          idx = hdr[s].ptr + (int64_t)(jj / G) * 64 + slot * G + (jj % G);
+        }
         col[idx] = g->h_col[b + jj];
         if (g->dtype == GLX_F64) val64[idx] = g->h_val[b + jj]; else val32[idx] = (float)g->h_val[b + jj];
       }
@@ -192,12 +219,12 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   const size_t es = g->dtype == GLX_F64 ? 8 : 4;
   GLX_HIP(hipMalloc(&p.d_slot_row, std::max<size_t>(4, slot_row.size() * 4)));
   GLX_HIP(hipMalloc(&p.d_slot_len, std::max<size_t>(4, slot_len.size() * 4)));
-  GLX_HIP(hipMalloc(&p.d_slice_ptr, slice_ptr.size() * 8));
+  GLX_HIP(hipMalloc(&p.d_slice_hdr, std::max<size_t>(16, hdr.size() * sizeof(SliceHdr))));
   GLX_HIP(hipMalloc(&p.d_col, std::max<size_t>(4, stored * 4)));
   GLX_HIP(hipMalloc(&p.d_val, std::max<size_t>(8, stored * es)));
   GLX_HIP(hipMemcpy(p.d_slot_row, slot_row.data(), slot_row.size() * 4, hipMemcpyHostToDevice));
   GLX_HIP(hipMemcpy(p.d_slot_len, slot_len.data(), slot_len.size() * 4, hipMemcpyHostToDevice));
-  GLX_HIP(hipMemcpy(p.d_slice_ptr, slice_ptr.data(), slice_ptr.size() * 8, hipMemcpyHostToDevice));
+  GLX_HIP(hipMemcpy(p.d_slice_hdr, hdr.data(), hdr.size() * sizeof(SliceHdr), hipMemcpyHostToDevice));
   GLX_HIP(hipMemcpy(p.d_col, col.data(), stored * 4, hipMemcpyHostToDevice));
   GLX_HIP(hipMemcpy(p.d_val, g->dtype == GLX_F64 ? (void*)val64.data() : (void*)val32.data(), stored * es, hipMemcpyHostToDevice));
   g->plans.push_back(p);

@@ -11,6 +11,10 @@
 // needed for the product itself; wavefront shuffles/DPP serve the entry broadcast, the
 // stop-test max and the CG column dots.
 #include "glx_internal.h"
+#include <stdlib.h>
+#ifndef GLX_PIPE_DEPTH
+#define GLX_PIPE_DEPTH 1
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -22,7 +26,7 @@ template <> struct VecOf<double> { typedef f64x4 type; };
 struct SpmmParams {
   const int32_t* slot_row;
   const int32_t* slot_len;
-  const int64_t* slice_ptr;
+  const SliceHdr* slice_hdr;
   const int32_t* col;
   const void* val;
   int64_t nslices;
@@ -43,6 +47,7 @@ struct SpmmParams {
   int dot_ld;
   const double* exit_err;   // CG: skip the launch when !(*exit_err > exit_tol)
   double exit_tol;
+  int ablate;               // developer probe (GLX_ABLATE): 1 no chunk loop, 2 gathers hit one hot record, 4 no stores
 };
 
 // ---- cross-lane helpers -------------------------------------------------------------
@@ -64,6 +69,26 @@ __device__ __forceinline__ double shfl_d(double v, int src) {
 }
 __device__ __forceinline__ float shfl_t(float v, int src) { return __shfl(v, src); }
 __device__ __forceinline__ double shfl_t(double v, int src) { return shfl_d(v, src); }
+
+// move a value 4 lanes to the right: within a 16-lane row (DPP row_ror:4) or around the wave
+__device__ __forceinline__ int row_ror4_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false); }
+template <typename V> __device__ __forceinline__ V row_ror4(V v) {
+  constexpr int NW = sizeof(V) / 4;
+  union { V v; int w[NW]; } a, b;
+  a.v = v;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) b.w[i] = row_ror4_i(a.w[i]);
+  return b.v;
+}
+template <typename V> __device__ __forceinline__ V wave_ror4(V v, int lane) {
+  constexpr int NW = sizeof(V) / 4;
+  union { V v; int w[NW]; } a, b;
+  a.v = v;
+  const int src = (lane - 4) & 63;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) b.w[i] = __shfl(a.w[i], src);
+  return b.v;
+}
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
 #pragma unroll
@@ -100,6 +125,42 @@ __device__ __forceinline__ void accum4(typename VecOf<T>::type& acc, double& acc
   }
 }
 
+// product of one entry, as it will be added: for the fp32 stop lane the fp64 product travels
+// in elements 0..1 of the vector
+template <typename T, bool HAS_W>
+__device__ __forceinline__ typename VecOf<T>::type product4(T v, const typename VecOf<T>::type& x, bool is_w) {
+#pragma clang fp contract(off)
+  typename VecOf<T>::type prod = x * v;
+  if constexpr (HAS_W && sizeof(T) == 4) {
+    if (is_w) {
+      const double xw = __hiloint2double(__float_as_int(x[1]), __float_as_int(x[0]));
+      const double pw = (double)v * xw;
+      prod[0] = __int_as_float(__double2loint(pw));
+      prod[1] = __int_as_float(__double2hiint(pw));
+    }
+  }
+  return prod;
+}
+
+template <typename T, bool HAS_W>
+__device__ __forceinline__ void add_product(typename VecOf<T>::type& acc, double& accw, const typename VecOf<T>::type& pr,
+                                            bool act, bool is_w) {
+#pragma clang fp contract(off)
+  typename VecOf<T>::type sum = acc + pr;
+  if (act) acc = sum;
+  if constexpr (HAS_W && sizeof(T) == 4) {
+    const double pw = __hiloint2double(__float_as_int(pr[1]), __float_as_int(pr[0]));
+    const double sw = accw + pw;
+    if (act && is_w) accw = sw;
+  }
+}
+
+// One wavefront = one slice of 64/G slots.  A slot is a row (S = 1) or one of the S segments
+// a long row is split into (G = 4 only: S = 4 or 16): the segments fetch and multiply their
+// entries in parallel and the running sum hops from segment to segment (DPP row rotate /
+// wave shuffle), each adding its products in entry order -- long rows stop being a latency
+// chain of len/4 dependent memory round trips while the rounding sequence stays that of a
+// sequential row sum.
 template <typename T, int G, bool HAS_W, bool HAS_DOT>
 __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
 #pragma clang fp contract(off)
@@ -123,39 +184,114 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
   const int g = lane / G, c = lane % G;
   const bool lane_on = c < p.nlanes;
   const bool is_w = HAS_W && (c == p.nvec);
-  int row = -1, len = 0, nchunks = 0;
+  int row = -1, len = 0, nchunks = 0, S = 1;
   int64_t base = 0;
   if (slice < p.nslices) {
     const int64_t slot = slice * R + g;
     row = p.slot_row[slot];
     len = p.slot_len[slot];
-    base = p.slice_ptr[slice];
-    nchunks = (int)((p.slice_ptr[slice + 1] - base) >> 6);
+    const SliceHdr hd = p.slice_hdr[slice];
+    base = hd.ptr;
+    nchunks = (p.ablate & 1) ? 0 : hd.nchunks;
+    S = hd.S;
   }
+  const int seg = g & (S - 1);            // S is a power of two
   const T* __restrict__ valp = (const T*)p.val;
   const size_t lane_off = (size_t)c * 4 * sizeof(T);
   V4 acc = {0, 0, 0, 0};
   double accw = 0.0;
 
-  for (int k = 0; k < nchunks; ++k) {
-    const int colv = p.col[base + (int64_t)k * 64 + lane];
-    const T valv = valp[base + (int64_t)k * 64 + lane];
-    const int j0 = k * G;
-    if constexpr (G == 4) {
-      const int c0 = quad_bcast_i<0>(colv), c1 = quad_bcast_i<1>(colv), c2 = quad_bcast_i<2>(colv), c3 = quad_bcast_i<3>(colv);
-      const T v0 = quad_bcast<0>(valv), v1 = quad_bcast<1>(valv), v2 = quad_bcast<2>(valv), v3 = quad_bcast<3>(valv);
+  if constexpr (G == 4) {
+    // Software pipeline: index/value chunks travel 3 chunks ahead of their use, the
+    // neighbour gathers of chunk k+1 are in flight while chunk k is being added up.
+    struct CV { int col; T val; };
+    auto load_cv = [&](int k) -> CV {
+      CV r;
+      r.col = 0;
+      r.val = 0;
+      if (k < nchunks) {
+        r.col = p.col[base + (int64_t)k * 64 + lane];
+        r.val = valp[base + (int64_t)k * 64 + lane];
+      }
+      return r;
+    };
+    auto issue = [&](const CV& cv, int k, V4 (&x)[4], T (&v)[4]) {
+      int c0 = quad_bcast_i<0>(cv.col), c1 = quad_bcast_i<1>(cv.col), c2 = quad_bcast_i<2>(cv.col), c3 = quad_bcast_i<3>(cv.col);
+      if (p.ablate & 2) { c0 &= 15; c1 &= 15; c2 &= 15; c3 &= 15; }
+      v[0] = quad_bcast<0>(cv.val);
+      v[1] = quad_bcast<1>(cv.val);
+      v[2] = quad_bcast<2>(cv.val);
+      v[3] = quad_bcast<3>(cv.val);
+      const int j0 = (k * S + seg) * 4;   // first row entry this slot holds in chunk k
+      x[0] = V4{0, 0, 0, 0};
+      x[1] = V4{0, 0, 0, 0};
+      x[2] = V4{0, 0, 0, 0};
+      x[3] = V4{0, 0, 0, 0};
+      if (lane_on && j0 + 0 < len) x[0] = *(const V4*)(p.xin + (size_t)c0 * p.rec_bytes + lane_off);
+      if (lane_on && j0 + 1 < len) x[1] = *(const V4*)(p.xin + (size_t)c1 * p.rec_bytes + lane_off);
+      if (lane_on && j0 + 2 < len) x[2] = *(const V4*)(p.xin + (size_t)c2 * p.rec_bytes + lane_off);
+      if (lane_on && j0 + 3 < len) x[3] = *(const V4*)(p.xin + (size_t)c3 * p.rec_bytes + lane_off);
+    };
+    auto consume = [&](int k, const V4 (&x)[4], const T (&v)[4]) {
+      const int j0 = (k * S + seg) * 4;
       const bool a0 = lane_on && j0 + 0 < len, a1 = lane_on && j0 + 1 < len, a2 = lane_on && j0 + 2 < len, a3 = lane_on && j0 + 3 < len;
-      V4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0}, x2 = {0, 0, 0, 0}, x3 = {0, 0, 0, 0};
-      if (a0) x0 = *(const V4*)(p.xin + (size_t)c0 * p.rec_bytes + lane_off);
-      if (a1) x1 = *(const V4*)(p.xin + (size_t)c1 * p.rec_bytes + lane_off);
-      if (a2) x2 = *(const V4*)(p.xin + (size_t)c2 * p.rec_bytes + lane_off);
-      if (a3) x3 = *(const V4*)(p.xin + (size_t)c3 * p.rec_bytes + lane_off);
-      accum4<T, HAS_W>(acc, accw, v0, x0, a0, is_w);
-      accum4<T, HAS_W>(acc, accw, v1, x1, a1, is_w);
-      accum4<T, HAS_W>(acc, accw, v2, x2, a2, is_w);
-      accum4<T, HAS_W>(acc, accw, v3, x3, a3, is_w);
-    } else {
-      const int gbase = lane & ~(G - 1);
+      if (S == 1) {
+        accum4<T, HAS_W>(acc, accw, v[0], x[0], a0, is_w);
+        accum4<T, HAS_W>(acc, accw, v[1], x[1], a1, is_w);
+        accum4<T, HAS_W>(acc, accw, v[2], x[2], a2, is_w);
+        accum4<T, HAS_W>(acc, accw, v[3], x[3], a3, is_w);
+      } else {
+        // the running sum visits the row's S segments in order: whoever holds it adds its 4
+        // products, then it moves 4 lanes on (every lane executes the adds; only the holder's
+        // count).  After S hops it is back at segment 0, ready for the next chunk.
+        const V4 q0 = product4<T, HAS_W>(v[0], x[0], is_w), q1 = product4<T, HAS_W>(v[1], x[1], is_w);
+        const V4 q2 = product4<T, HAS_W>(v[2], x[2], is_w), q3 = product4<T, HAS_W>(v[3], x[3], is_w);
+        for (int ph = 0; ph < S; ++ph) {
+          add_product<T, HAS_W>(acc, accw, q0, a0, is_w);
+          add_product<T, HAS_W>(acc, accw, q1, a1, is_w);
+          add_product<T, HAS_W>(acc, accw, q2, a2, is_w);
+          add_product<T, HAS_W>(acc, accw, q3, a3, is_w);
+          if (S == 4) {
+            acc = row_ror4(acc);
+            if constexpr (HAS_W && sizeof(T) == 4) accw = row_ror4(accw);
+          } else {
+            acc = wave_ror4(acc, lane);
+            if constexpr (HAS_W && sizeof(T) == 4) accw = wave_ror4(accw, lane);
+          }
+        }
+      }
+    };
+#if GLX_PIPE_DEPTH >= 2
+    V4 xA[4], xB[4];
+    T vA[4], vB[4];
+    CV q0 = load_cv(0), q1 = load_cv(1), q2 = load_cv(2), q3;
+    q3.col = 0;
+    q3.val = 0;
+    if (nchunks > 0) issue(q0, 0, xA, vA);
+    int k = 0;
+    while (k < nchunks) {
+      q3 = load_cv(k + 3); issue(q1, k + 1, xB, vB); consume(k, xA, vA); if (++k >= nchunks) break;
+      q0 = load_cv(k + 3); issue(q2, k + 1, xA, vA); consume(k, xB, vB); if (++k >= nchunks) break;
+      q1 = load_cv(k + 3); issue(q3, k + 1, xB, vB); consume(k, xA, vA); if (++k >= nchunks) break;
+      q2 = load_cv(k + 3); issue(q0, k + 1, xA, vA); consume(k, xB, vB); ++k;
+    }
+#else
+    V4 xA[4];
+    T vA[4];
+    CV qn = load_cv(0);
+    for (int k = 0; k < nchunks; ++k) {
+      const CV qc = qn;
+      qn = load_cv(k + 1);      // next chunk's indices/values travel while this chunk's gathers do
+      issue(qc, k, xA, vA);
+      consume(k, xA, vA);
+    }
+#endif
+  } else {
+    const int gbase = lane & ~(G - 1);
+    for (int k = 0; k < nchunks; ++k) {
+      const int colv = p.col[base + (int64_t)k * 64 + lane];
+      const T valv = valp[base + (int64_t)k * 64 + lane];
+      const int j0 = k * G;
       for (int tb = 0; tb < G; tb += 4) {
         int cj[4];
         T vj[4];
@@ -177,7 +313,7 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
 
   // epilogue: u_out[row] = Db[row] + acc   (ssl.py:668: `Db + P*u`; addition commutes bitwise)
   V4 outv = acc;
-  const bool store_on = lane_on && row >= 0;
+  const bool store_on = lane_on && row >= 0 && seg == 0;
   if (store_on) {
     bool hb = p.bias != nullptr;
     if (hb && p.slot_has_bias) hb = p.slot_has_bias[slice * R + g] != 0;
@@ -193,7 +329,7 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
         outv[3] = 0;
       }
     }
-    *(V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off) = outv;
+    if (!(p.ablate & 4)) *(V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off) = outv;
   }
 
   if constexpr (HAS_W) {
@@ -285,7 +421,7 @@ int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
   SpmmParams p;
   p.slot_row = a.plan->d_slot_row;
   p.slot_len = a.plan->d_slot_len;
-  p.slice_ptr = a.plan->d_slice_ptr;
+  p.slice_hdr = a.plan->d_slice_hdr;
   p.col = a.plan->d_col;
   p.val = a.plan->d_val;
   p.nslices = a.plan->nslices;
@@ -308,6 +444,8 @@ int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
   p.dot_ld = a.L.nvec * 4;
   p.exit_err = a.exit_err;
   p.exit_tol = a.exit_tol;
+  static const int ablate = getenv("GLX_ABLATE") ? atoi(getenv("GLX_ABLATE")) : 0;
+  p.ablate = ablate;
   return a.dtype == GLX_F32 ? launch_t<float>(a, p, stream) : launch_t<double>(a, p, stream);
 }
 
