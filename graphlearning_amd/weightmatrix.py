@@ -49,7 +49,9 @@ def knn(data, k, kernel='gaussian', eta=None, symmetrize=True, metric='raw', sim
     else:
         D = knn_dist * knn_dist
         eps = D[:, k - 1]
-        weights = eta(D / eps)
+        # the reference divides (n,k) by (n,) here (weightmatrix.py:164), which cannot broadcast;
+        # the documented formula eta(|x_i-x_j|^2 / d_k(x_i)^2) is what is computed
+        weights = eta(D / eps[:, None])
     knn_ind = knn_ind.flatten()
     weights = weights.flatten()
     self_ind = (np.ones((n, k)) * np.arange(n)[:, None]).flatten()

@@ -1,0 +1,134 @@
+"""CPU: the host-side mirror of the reference interface (graphlearning_amd) -- helpers,
+graph calculus, kNN weight assembly, constructor/attribute contract, error behaviour --
+against the golden vectors and the oracle; and the C-ABI library: it loads and exports
+every symbol include/glx.h declares (no compute calls without a GPU)."""
+import os
+import re
+import numpy as np
+import pytest
+from scipy import sparse
+from conftest import csr_from, ROOT
+import graphlearning_amd as gl
+from graphlearning_amd import _hip
+from oracle import gl_oracle as orc
+
+
+def test_package_never_imports_oracle():
+    import ast
+    pkg = os.path.join(ROOT, 'graphlearning_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            tree = ast.parse(open(os.path.join(pkg, fn)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or '']
+                assert not any(n.split('.')[0] == 'oracle' for n in names), fn
+
+
+def test_helpers_match_golden(golden):
+    g = golden('g6_helpers.npz')
+    labels = np.load(os.path.join(ROOT, 'tests', 'golden', 'MNIST_labels.npz'))['labels']
+    assert np.array_equal(gl.trainsets.generate(labels, rate=1, seed=0), g['gen_rate1_seed0'])
+    assert np.array_equal(gl.trainsets.generate(labels, rate=3, seed=7), g['gen_rate3_seed7'])
+    assert np.array_equal(np.stack(gl.trainsets.generate(labels[:5000], rate=2, num_trials=3, seed=4)), g['gen_multi'])
+    assert np.array_equal(gl.trainsets.generate(labels[:5000], rate=0.01, seed=9), g['gen_frac'])
+    assert np.array_equal(gl.utils.class_priors(labels), g['priors'])
+    assert np.array_equal(gl.utils.labels_to_onehot(np.array([2, 0, 1, 1]), 3), g['onehot_small'])
+    assert gl.utils.labels_to_onehot(np.array([0, 5]), 2).shape == (2, 6)      # width grows to max label + 1
+    with pytest.raises(SystemExit):
+        gl.trainsets.generate(labels, rate='x')
+
+
+def test_knn_weights_from_injected_knn_data(golden):
+    g = golden('g1_twomoons.npz')
+    for kernel in ['gaussian', 'uniform', 'symgaussian', 'distance', 'singular']:
+        W = gl.weightmatrix.knn(None, 10, kernel=kernel, knn_data=(g['knn_ind'], g['knn_dist'].copy()))
+        Wg = csr_from(g, 'W_' + kernel)
+        assert W.format == 'csr' and W.dtype == np.float64 and W.indices.dtype == np.int32
+        assert np.array_equal(W.indptr, Wg.indptr) and np.array_equal(W.indices, Wg.indices)
+        assert np.array_equal(W.data, Wg.data), kernel
+    W = gl.weightmatrix.knn(None, 10, symmetrize=False, knn_data=(g['knn_ind'], g['knn_dist']))
+    assert np.array_equal(W.data, csr_from(g, 'W_gaussian_nosym').data)
+    # k is clamped to the columns available (reference weightmatrix.py:135)
+    W5 = gl.weightmatrix.knn(None, 50, knn_data=(g['knn_ind'], g['knn_dist']))
+    assert np.array_equal(W5.data, csr_from(g, 'W_gaussian').data)
+    # user eta overrides the kernel
+    We = gl.weightmatrix.knn(None, 10, eta=lambda t: np.exp(-4 * t), knn_data=(g['knn_ind'], g['knn_dist']))
+    assert np.allclose(We.data, csr_from(g, 'W_gaussian').data, rtol=1e-14, atol=0)
+    with pytest.raises(SystemExit):
+        gl.weightmatrix.knn(None, 10, kernel='nope', knn_data=(g['knn_ind'], g['knn_dist']))
+    with pytest.raises(SystemExit):
+        gl.weightmatrix.knnsearch(g['X'], 3, method='faiss')
+    with pytest.raises(SystemExit):
+        gl.weightmatrix.knnsearch(g['X'], 3, similarity='hamming')
+
+
+def test_graph_calculus_matches_oracle(golden):
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    G = gl.graph.graph(W)
+    assert G.num_nodes == 500
+    assert np.array_equal(G.degree_vector(), orc.degree_vector(W))
+    for p in (1, -1, -0.5):
+        assert (G.degree_matrix(p) != orc.degree_matrix(W, p)).nnz == 0
+    for norm in ['combinatorial', 'randomwalk', 'normalized']:
+        A, B = G.laplacian(norm), orc.laplacian(W, norm)
+        assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices) and np.array_equal(A.data, B.data)
+    with pytest.raises(SystemExit):
+        G.laplacian('bogus')
+    assert gl.graph.graph(np.eye(3)).weight_matrix.format == 'csr'
+
+
+def test_learner_contract():
+    W = sparse.identity(6, format='csr')
+    m = gl.ssl.poisson(W)
+    for attr in ['prob', 'fitted', 'name', 'accuracy_filename', 'graph', 'weights', 'class_priors',
+                 'class_priors_error', 'requires_eig', 'onevsrest', 'similarity']:
+        assert hasattr(m, attr)
+    assert m.name == 'Poisson Learning' and m.get_accuracy_filename() == '_poisson_accuracy.csv'
+    assert m.solver == 'conjugate_gradient' and m.min_iter == 50 and m.max_iter == 1000 and m.tol == 1e-3
+    assert gl.ssl.poisson(W, p=2).solver == 'spectral'
+    mm = gl.ssl.poisson_mbo(W, np.array([1.0, 3.0]))
+    assert np.allclose(mm.class_priors, [0.25, 0.75]) and mm.get_accuracy_filename().endswith('_classpriors_accuracy.csv')
+    assert mm.accuracy_filename == '_poisson_mbo_Ns_40_mu_1.00_T_20'
+    ml = gl.ssl.laplace(W, normalization='normalized', tau=0.5, mean_shift=True)
+    assert ml.accuracy_filename == '_laplace_normalized_meanshift_tau_0.500'
+    assert gl.ssl.laplace(gl.graph.graph(W)).graph.num_nodes == 6         # a graph object is accepted as is
+    with pytest.raises(SystemExit):
+        gl.ssl.poisson(W, solver='bogus')
+    with pytest.raises(SystemExit):
+        m.predict()                                                       # not fitted yet
+    with pytest.raises(SystemExit):
+        gl.ssl.poisson(None).fit(np.array([0]), np.array([0]))
+    assert gl.ssl.ssl_accuracy(np.array([0, 1, 1, 0]), np.array([0, 1, 0, -1]), np.array([0])) == 50.0
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the solvers must fail loudly, never fall back."""
+    try:
+        n = _hip.device_count()
+    except _hip.GlxError:
+        n = 0
+    if n > 0:
+        pytest.skip('GPU present')
+    W = sparse.identity(6, format='csr') + sparse.diags([1.0] * 5, 1) + sparse.diags([1.0] * 5, -1)
+    with pytest.raises(_hip.GlxError):
+        gl.ssl.poisson(W, solver='gradient_descent').fit(np.array([0, 5]), np.array([0, 1]))
+    with pytest.raises(_hip.GlxError):
+        gl.weightmatrix.knnsearch(np.random.rand(10, 3), 3)
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'glx.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(glx_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 20
+    lib = _hip.load()
+    for sym in sorted(declared):
+        assert getattr(lib, sym) is not None, sym
+    # and the Python binding covers exactly the declared surface
+    assert declared == set(_hip.EXPORTED_SYMBOLS), declared ^ set(_hip.EXPORTED_SYMBOLS)
+    assert lib.glx_version() >= 100
