@@ -164,7 +164,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     args = ap.parse_args()
-    if args.gpus > 1 or int(os.environ.get('WORLD_SIZE', '1')) > 1:
+    if args.gpus > 1 or int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('GLX_BENCH_FORCE_DIST') == '1':
         run_distributed(args)
     else:
         run_single(args)

@@ -53,6 +53,12 @@ _SIGNATURES = {
     'glx_sweep_destroy': [_vp],
     'glx_sweep_set_state': [_vp, _vp, _vp],
     'glx_sweep_iterate': [_vp, C.c_int],
+    'glx_record_layout': [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)],
+    'glx_graph_slots': [_vp, C.c_int, C.c_int, _i64p],
+    'glx_bias_flags_dev': [_vp, C.c_int, C.c_int, _vp, _vp, _vp],
+    'glx_sweep_step_dev': [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'glx_pack_records_dev': [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp],
+    'glx_unpack_records_dev': [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp],
     'glx_cg_multi': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), _f64p],
     'glx_argmax_project': [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
     'glx_knn_bruteforce': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
@@ -252,6 +258,13 @@ class Sweep:
             self.close()
         except Exception:
             pass
+
+
+def record_layout(Cc, dtype=np.float64, has_w=True):
+    """Vertex-record layout of the dense operands (pure host call, no GPU needed)."""
+    out = (C.c_int32 * 6)()
+    check(load().glx_record_layout(int(Cc), _dt(dtype), 1 if has_w else 0, out), 'glx_record_layout')
+    return dict(ld=out[0], woff=out[1], rec_bytes=out[2], G=out[3], nvec=out[4], esize=out[5])
 
 
 def argmax_project(prob, priors=None, weights=None, max_steps=0, similarity=True, device=0):

@@ -390,3 +390,92 @@ extern "C" int glx_poisson_sweep(glx_graph* P, const void* Db, const double* w0,
   glx_sweep_destroy(s);
   return rc;
 }
+
+// ---- device-pointer entry points (rank-local sweeps of the vertex-partitioned solver) --------
+// The caller (graphlearning_amd/dist.py) owns the buffers -- torch tensors in the record layout
+// of glx_record_layout -- and the stream; nothing here synchronises.
+
+extern "C" int glx_record_layout(int C, int dtype, int has_w, int32_t out[6]) {
+  GLX_CHECK(out, GLX_EINVAL, "glx_record_layout: null output");
+  RecLayout L;
+  int rc = glx_make_layout(C, dtype, has_w != 0, &L);
+  if (rc) return rc;
+  out[0] = L.ld;
+  out[1] = L.woff;
+  out[2] = L.ld * L.esize;
+  out[3] = L.G;
+  out[4] = L.nvec;
+  out[5] = L.esize;
+  return GLX_OK;
+}
+
+extern "C" int glx_graph_slots(glx_graph* P, int C, int has_w, int64_t* nslots) {
+  GLX_CHECK(P && nslots, GLX_EINVAL, "glx_graph_slots: null argument");
+  RecLayout L;
+  int rc = glx_make_layout(C, P->dtype, has_w != 0, &L);
+  if (rc) return rc;
+  SellPlan* plan = nullptr;
+  rc = glx_graph_plan(P, L.G, &plan);
+  if (rc) return rc;
+  *nslots = plan->nslices * plan->R;
+  return GLX_OK;
+}
+
+extern "C" int glx_bias_flags_dev(glx_graph* P, int C, int has_w, const void* bias_rec, uint8_t* flags, void* stream) {
+  GLX_CHECK(P && bias_rec && flags, GLX_EINVAL, "glx_bias_flags_dev: null argument");
+  RecLayout L;
+  int rc = glx_make_layout(C, P->dtype, has_w != 0, &L);
+  if (rc) return rc;
+  SellPlan* plan = nullptr;
+  rc = glx_graph_plan(P, L.G, &plan);
+  if (rc) return rc;
+  const int64_t nslots = plan->nslices * plan->R;
+  if (nslots == 0) return GLX_OK;
+  hipLaunchKernelGGL(bias_flags_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     plan->d_slot_row, flags, nslots, (const char*)bias_rec, L.ld * L.esize);
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}
+
+extern "C" int glx_sweep_step_dev(glx_graph* P, int C, int has_w, const void* xin, void* xout, const void* bias_rec,
+                                  const uint8_t* slot_flags, const double* deg, const double* vinf, void* err_next,
+                                  void* stream) {
+  GLX_CHECK(P && xin && xout, GLX_EINVAL, "glx_sweep_step_dev: null argument");
+  SweepArgs a;
+  memset(&a, 0, sizeof(a));
+  int rc = glx_make_layout(C, P->dtype, has_w != 0, &a.L);
+  if (rc) return rc;
+  SellPlan* plan = nullptr;
+  rc = glx_graph_plan(P, a.L.G, &plan);
+  if (rc) return rc;
+  a.plan = plan;
+  a.dtype = P->dtype;
+  a.xin = xin;
+  a.xout = xout;
+  a.bias = bias_rec;
+  a.slot_has_bias = bias_rec ? slot_flags : nullptr;
+  a.has_w = has_w != 0;
+  a.n_rows = P->n_rows;
+  a.deg = deg;
+  a.vinf = vinf;
+  a.err_next = (unsigned long long*)err_next;   // 64 fp64-bit-pattern maxima, caller zeroes them
+  GLX_CHECK(!err_next || (has_w && deg && vinf), GLX_EINVAL, "glx_sweep_step_dev: the stop test needs the stop column, deg and vinf");
+  return glx_launch_spmm(a, (hipStream_t)stream);
+}
+
+extern "C" int glx_pack_records_dev(const void* dense, void* rec, int64_t n, int C, int dtype, int has_w, const double* w,
+                                    void* stream) {
+  GLX_CHECK(rec, GLX_EINVAL, "glx_pack_records_dev: null output");
+  RecLayout L;
+  int rc = glx_make_layout(C, dtype, has_w != 0, &L);
+  if (rc) return rc;
+  return glx_pack_records(dense, rec, n, L, dtype, w, (hipStream_t)stream);
+}
+
+extern "C" int glx_unpack_records_dev(const void* rec, void* dense, int64_t n, int C, int dtype, int has_w, void* stream) {
+  GLX_CHECK(rec && dense, GLX_EINVAL, "glx_unpack_records_dev: null argument");
+  RecLayout L;
+  int rc = glx_make_layout(C, dtype, has_w != 0, &L);
+  if (rc) return rc;
+  return glx_unpack_records(rec, dense, n, L, dtype, (hipStream_t)stream);
+}

@@ -1,0 +1,323 @@
+"""Vertex-partitioned Poisson sweep across the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  The reference has
+no distributed code: this is new functionality around the same sweep
+(reference graphlearning/ssl.py:631-670).
+
+  * the vertices are reordered for locality (reverse Cuthill-McKee on the symmetrised pattern)
+    and cut into `world` contiguous row blocks; rank r owns block r of P, Db, u;
+  * rank-local columns are renumbered [owned | halo], the halo being the distinct remote rows
+    its block references, grouped by owner rank;
+  * every sweep: local sliced-ELL SpMM (HIP kernel on the rank's torch stream), then ONE
+    all_to_all_single of the boundary vertex records straight into the peers' halo regions
+    (xGMI is point-to-point: a direct exchange uses all links at once; no ring);
+  * the stop column rides inside the vertex record; the stop test is a scalar all_reduce(MAX),
+    evaluated from sweep min_iter on.
+The ENTRY order inside every row is untouched by the partitioning, so the distributed iterates
+are bit-identical to the single-GPU ones and to the reference's CPU path.
+
+The partition / halo / exchange logic is backend-agnostic (`ops` object): `HipOps` runs the
+rank-local sweep through libglx on torch CUDA tensors; the CPU tests inject a scipy-backed
+`ops` and run the same driver over the gloo backend with world_size 2.
+"""
+import numpy as np
+from scipy import sparse
+
+
+def locality_order(P):
+    """Permutation (new -> old) that keeps graph neighbours close: reverse Cuthill-McKee on
+    the symmetrised sparsity pattern."""
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    A = sparse.csr_matrix(P)
+    pattern = sparse.csr_matrix((np.ones(A.nnz, dtype=np.int8), A.indices, A.indptr), shape=A.shape)
+    pattern = (pattern + pattern.T).tocsr()
+    return np.asarray(reverse_cuthill_mckee(pattern, symmetric_mode=True), dtype=np.int64)
+
+
+def block_bounds(n, world):
+    """`world` contiguous blocks of (nearly) equal size."""
+    return np.array([(n * r) // world for r in range(world + 1)], dtype=np.int64)
+
+
+class RankPlan:
+    """What rank `rank` needs: its rows of P with columns renumbered [owned | halo] and the
+    send / receive lists of the per-sweep exchange."""
+
+    def __init__(self, P, order, bounds, rank):
+        P = sparse.csr_matrix(P)
+        n = P.shape[0]
+        world = len(bounds) - 1
+        self.rank, self.world, self.n_global = rank, world, n
+        pos = np.empty(n, dtype=np.int64)          # old id -> position in the locality order
+        pos[order] = np.arange(n)
+        owner_of_pos = np.searchsorted(bounds, np.arange(n), side='right') - 1
+        self.own = order[bounds[rank]:bounds[rank + 1]]     # global ids this rank owns, in local order
+        self.n_own = len(self.own)
+
+        def halo_of(r):
+            rows = order[bounds[r]:bounds[r + 1]]
+            cols = np.unique(P[rows, :].indices) if len(rows) else np.zeros(0, dtype=np.int64)
+            cpos = pos[cols]
+            remote = cpos[(cpos < bounds[r]) | (cpos >= bounds[r + 1])]
+            remote.sort()                                    # grouped by owner (blocks are contiguous), then by position
+            return remote
+
+        my_halo_pos = halo_of(rank)
+        self.halo = order[my_halo_pos]                       # global ids, in halo order
+        self.n_halo = len(self.halo)
+        halo_owner = owner_of_pos[my_halo_pos]
+        self.recv_counts = [int(np.sum(halo_owner == r)) for r in range(world)]
+        # what every peer needs from me, in the order it expects it
+        send = []
+        self.send_counts = []
+        for dst in range(world):
+            if dst == rank:
+                self.send_counts.append(0)
+                continue
+            hp = halo_of(dst)
+            mine = hp[(hp >= bounds[rank]) & (hp < bounds[rank + 1])]
+            send.append(mine - bounds[rank])                 # local row indices
+            self.send_counts.append(len(mine))
+        self.send_idx = np.concatenate(send) if send else np.zeros(0, dtype=np.int64)
+        # local operator: rows = own, columns -> [0, n_own) owned, n_own + halo index otherwise
+        local_of = np.full(n, -1, dtype=np.int64)
+        local_of[self.own] = np.arange(self.n_own)
+        local_of[self.halo] = self.n_own + np.arange(self.n_halo)
+        sub = P[self.own, :]                                 # row slicing keeps the entry order of each row
+        sub = sparse.csr_matrix(sub)
+        cols = local_of[sub.indices]
+        assert np.all(cols >= 0)
+        self.P_local = sparse.csr_matrix((sub.data, cols.astype(np.int32), sub.indptr),
+                                         shape=(self.n_own, self.n_own + self.n_halo))
+        self.P_local.has_sorted_indices = False              # keep scipy from reordering the entries
+
+
+class HipOps:
+    """Rank-local sweep through libglx on torch CUDA tensors (device-pointer C-ABI)."""
+
+    def __init__(self, plan, C, device, dtype=np.float64):
+        import torch
+        from . import _hip
+        self.torch, self._hip = torch, _hip
+        self.C = C
+        self.dtype = np.dtype(dtype)
+        self.tdtype = torch.float64 if self.dtype == np.float64 else torch.float32
+        self.device = torch.device('cuda', device)
+        self.devidx = device
+        _assert_single_hip_runtime()
+        self.lay = _hip.record_layout(C, self.dtype, True)
+        self.ld = self.lay['ld']
+        self.graph = _hip.DeviceGraph(plan.P_local, dtype=self.dtype, device=device, shape=plan.P_local.shape)
+        n = _hip.C.c_int64(0)
+        _hip.check(_hip.load().glx_graph_slots(self.graph._h, C, 1, _hip.C.byref(n)), 'glx_graph_slots')
+        self.nslots = n.value
+        self.flags = torch.zeros(max(self.nslots, 1), dtype=torch.uint8, device=self.device)
+        self.err = torch.zeros(64, dtype=torch.int64, device=self.device)
+        self.plan = plan
+
+    def _stream(self):
+        return self._hip._vp(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def new_state(self, rows):
+        return self.torch.zeros((rows, self.ld), dtype=self.tdtype, device=self.device)
+
+    def to_device(self, a, dtype=None):
+        t = self.torch.from_numpy(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device)
+
+    def pack(self, dense, w, rows):
+        """(rows, C) dense [or None = zeros] + optional (rows,) fp64 stop values -> records."""
+        rec = self.new_state(rows)
+        lib = self._hip.load()
+        d = None if dense is None else self.to_device(dense, self.tdtype)
+        wt = None if w is None else self.to_device(w, self.torch.float64)
+        self._hip.check(lib.glx_pack_records_dev(None if d is None else d.data_ptr(), rec.data_ptr(), rows, self.C,
+                                                  self._hip._dt(self.dtype), 1, None if wt is None else wt.data_ptr(),
+                                                  self._stream()), 'glx_pack_records_dev')
+        self.torch.cuda.current_stream(self.device).synchronize()   # d / wt die here
+        return rec
+
+    def unpack(self, rec, rows):
+        out = self.torch.empty((rows, self.C), dtype=self.tdtype, device=self.device)
+        self._hip.check(self._hip.load().glx_unpack_records_dev(rec.data_ptr(), out.data_ptr(), rows, self.C,
+                                                                 self._hip._dt(self.dtype), 1, self._stream()),
+                        'glx_unpack_records_dev')
+        return out.cpu().numpy()
+
+    def set_bias(self, bias_rec):
+        self.bias = bias_rec
+        self._hip.check(self._hip.load().glx_bias_flags_dev(self.graph._h, self.C, 1, bias_rec.data_ptr(),
+                                                             self.flags.data_ptr(), self._stream()), 'glx_bias_flags_dev')
+
+    def set_stop_vectors(self, deg, vinf):
+        self.deg = self.to_device(deg, self.torch.float64)
+        self.vinf = self.to_device(vinf, self.torch.float64)
+
+    def sweep(self, xin, xout, want_err):
+        if want_err:
+            self.err.zero_()
+        self._hip.check(self._hip.load().glx_sweep_step_dev(
+            self.graph._h, self.C, 1, xin.data_ptr(), xout.data_ptr(), self.bias.data_ptr(), self.flags.data_ptr(),
+            self.deg.data_ptr(), self.vinf.data_ptr(), self.err.data_ptr() if want_err else None, self._stream()),
+            'glx_sweep_step_dev')
+        if want_err:   # fp64 bit patterns of non-negative values order like the values
+            return self.err.max().view(1).view(self.torch.float64)
+        return None
+
+    def index_rows(self, rec, idx):
+        return rec.index_select(0, idx)
+
+    def close(self):
+        self.graph.close()
+
+
+def _assert_single_hip_runtime():
+    """torch bundles its own libamdhip64; libglx must have bound to THAT copy (it does when
+    torch is imported before libglx is first loaded), otherwise torch's pointers and streams
+    would belong to a different HIP runtime instance."""
+    paths = set()
+    try:
+        with open('/proc/self/maps') as f:
+            for line in f:
+                if 'libamdhip64' in line:
+                    paths.add(line.split()[-1])
+    except OSError:
+        return
+    if len(paths) > 1:
+        raise RuntimeError('two HIP runtimes are loaded (%s): import torch before the first graphlearning_amd GPU call '
+                           'in multi-GPU processes' % sorted(paths))
+
+
+class DistSweep:
+    """The distributed Poisson sweep.  `ops` provides the rank-local kernel, `dist` is
+    torch.distributed (already initialised), tensors live wherever `ops` puts them."""
+
+    def __init__(self, plan, ops, dist, group=None):
+        import torch
+        self.torch = torch
+        self.plan, self.ops, self.dist, self.group = plan, ops, dist, group
+        self.n_loc = plan.n_own + plan.n_halo
+        self.send_idx = ops.to_device(plan.send_idx.astype(np.int64))
+        self.in_splits = list(plan.send_counts)
+        self.out_splits = list(plan.recv_counts)
+        self.exchanges = 0
+
+    def exchange(self, x):
+        """Boundary records of x[0:n_own] -> the peers' halo regions x[n_own:]."""
+        p = self.plan
+        if p.world == 1:
+            return
+        send = self.ops.index_rows(x, self.send_idx)
+        recv = x[p.n_own:]
+        self.dist.all_to_all_single(recv, send, output_split_sizes=self.out_splits, input_split_sizes=self.in_splits,
+                                    group=self.group)
+        self.exchanges += 1
+
+    def setup(self, Db_own, w0_own, deg_own, vinf_own):
+        """Rank-local problem data (rows in this rank's local order)."""
+        ops, p = self.ops, self.plan
+        ops.set_bias(ops.pack(Db_own, None, p.n_own))
+        ops.set_stop_vectors(deg_own, vinf_own)
+        self.w0_own = np.ascontiguousarray(w0_own, dtype=np.float64)
+        self.xa = ops.new_state(self.n_loc)
+        self.xb = ops.new_state(self.n_loc)
+
+    def reset(self):
+        """u = 0 (ssl.py:645), w = w0 on the owned rows; halo filled by one exchange."""
+        p, ops = self.plan, self.ops
+        init = ops.pack(None, self.w0_own, p.n_own)
+        self.xa.zero_()
+        self.xa[:p.n_own].copy_(init)
+        self.exchange(self.xa)
+        self.cur = 0
+
+    def run(self, min_iter, max_iter, err0=None):
+        """All sweeps; returns T.  Stop test (ssl.py:667): T = first T >= min_iter with
+        max over ALL vertices |deg w_T - vinf| <= 1/n_global."""
+        torch, dist, ops, p = self.torch, self.dist, self.ops, self.plan
+        thresh = 1.0 / p.n_global
+        self.reset()
+        bufs = [self.xa, self.xb]
+        T = 0
+        err_T = err0          # error of v_T, known for T >= min_iter (err0: error of v_0 when min_iter == 0)
+        while T < max_iter:
+            if T >= min_iter:
+                if err_T is None:
+                    raise RuntimeError('stop test needs the error of v_%d' % T)
+                if not (err_T > thresh):
+                    break
+            xin, xout = bufs[self.cur], bufs[self.cur ^ 1]
+            want = (T + 1) >= min_iter
+            e = ops.sweep(xin, xout, want)
+            self.exchange(xout)
+            if want:
+                if p.world > 1:
+                    dist.all_reduce(e, op=dist.ReduceOp.MAX, group=self.group)
+                err_T = float(e.item())
+            self.cur ^= 1
+            T += 1
+        return T
+
+    def result_own(self):
+        return self.ops.unpack([self.xa, self.xb][self.cur], self.plan.n_own)
+
+
+def initial_error(w0, deg, vinf, dist=None, group=None, torch=None):
+    """max |deg*w0 - vinf| over all vertices (needed only when min_iter == 0)."""
+    e = float(np.max(np.abs(deg * w0 - vinf))) if len(w0) else 0.0
+    if dist is not None and dist.get_world_size(group) > 1:
+        t = torch.tensor([e], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        e = float(t.item())
+    return e
+
+
+def poisson_problem(W, train_ind, train_labels):
+    """Global host-side setup of the gradient-descent solver (reference ssl.py:615-645):
+    returns P = D^-1 W^T, Db, w0 = D^-1 v0, deg, vinf, number of classes."""
+    from . import graph as graph_mod
+    from . import ssl as ssl_mod
+    n = W.shape[0]
+    W = sparse.csr_matrix(W)
+    W = W - sparse.spdiags(W.diagonal(), 0, n, n)
+    G = graph_mod.graph(W)
+    source, k = ssl_mod._poisson_source(n, np.asarray(train_ind), np.asarray(train_labels))
+    D = G.degree_matrix(p=-1)
+    P = sparse.csr_matrix(D * W.transpose())
+    deg = G.degree_vector()
+    v0 = np.zeros(n)
+    v0[train_ind] = 1
+    v0 = v0 / np.sum(v0)
+    return dict(P=P, Db=D * source, w0=v0 / deg, deg=deg, vinf=deg / np.sum(deg), k=k)
+
+
+def poisson_fit_distributed(W, train_ind, train_labels, dist, ops_factory, min_iter=50, max_iter=1000, order=None,
+                            group=None, gather=True):
+    """ssl.poisson(solver='gradient_descent').fit across the ranks of `dist`.
+    Every rank holds the whole (host) graph and calls this collectively.  Returns (u, T) with
+    u the full (n,C) matrix on every rank (gather=True) or this rank's rows."""
+    import torch
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    prob = poisson_problem(W, train_ind, train_labels)
+    P = prob['P']
+    n = P.shape[0]
+    if order is None:
+        order = locality_order(P)
+    plan = RankPlan(P, order, block_bounds(n, world), rank)
+    ops = ops_factory(plan, prob['k'])
+    sweep = DistSweep(plan, ops, dist, group)
+    own = plan.own
+    sweep.setup(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
+    err0 = initial_error(prob['w0'][own], prob['deg'][own], prob['vinf'][own], dist, group, torch) if min_iter == 0 else None
+    T = sweep.run(min_iter, max_iter, err0)
+    u_own = sweep.result_own()
+    if not gather:
+        return u_own, T, plan
+    parts = [None] * world
+    dist.all_gather_object(parts, (own, u_own), group=group)
+    u = np.zeros((n, prob['k']), dtype=u_own.dtype)
+    for ids, block in parts:
+        u[ids] = block
+    return u, T

@@ -88,6 +88,24 @@ int glx_sweep_destroy(glx_sweep* s);
 int glx_sweep_set_state(glx_sweep* s, const void* u0, const void* Db);
 int glx_sweep_iterate(glx_sweep* s, int iters);
 
+/* ---- device-pointer entry points: rank-local sweeps of the vertex-partitioned solver -------
+ * Buffers are DEVICE memory in the vertex-record layout (torch tensors' data_ptr()); `stream`
+ * is a hipStream_t; nothing synchronises.  Record layout: `ld` elements per vertex, columns
+ * 0..C-1, zero padding to a multiple of 4, then (has_w) the fp64 stop value at byte `woff`.
+ * out = {ld, woff, record bytes, lanes per row, 4-wide column vectors, element size}. */
+int glx_record_layout(int C, int dtype, int has_w, int32_t out[6]);
+int glx_graph_slots(glx_graph* P, int C, int has_w, int64_t* nslots);
+/* flags[slot] = 1 where the slot's row has a nonzero bias record (sparse Db: ssl.py:620-622) */
+int glx_bias_flags_dev(glx_graph* P, int C, int has_w, const void* bias_rec, uint8_t* flags, void* stream);
+/* one sweep xout[0:n_rows] = bias + P xin[0:n_cols]; err_next (64 x uint64, caller-zeroed) receives
+ * max |deg*w - vinf| as fp64 bit patterns when non-NULL (the rank-local part of ssl.py:667) */
+int glx_sweep_step_dev(glx_graph* P, int C, int has_w, const void* xin, void* xout, const void* bias_rec,
+                       const uint8_t* slot_flags, const double* deg, const double* vinf, void* err_next,
+                       void* stream);
+int glx_pack_records_dev(const void* dense, void* rec, int64_t n, int C, int dtype, int has_w, const double* w,
+                         void* stream);
+int glx_unpack_records_dev(const void* rec, void* dense, int64_t n, int C, int dtype, int has_w, void* stream);
+
 /* ---- multi right-hand-side conjugate gradient -------------------------------------
  * Replaces utils.conjgrad (graphlearning/utils.py:483-532): x0 = 0, per-column
  * alpha/beta, global stop sqrt(sum over all columns ||r||^2) <= tol, max_iter cap. */

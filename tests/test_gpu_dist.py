@@ -1,0 +1,61 @@
+"""GPU: the rank-local pieces of the multi-GPU path on ONE MI355X -- HipOps (libglx device-pointer
+API on torch tensors) for every rank of a 2- and 4-way partition, checked against scipy; and
+the distributed bench entry under torchrun with one rank (NCCL/RCCL init, all_reduce, driver)."""
+import json
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+from conftest import ROOT, csr_from
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hipops_rank_local_sweeps_match_scipy(golden):
+    import torch                      # before libglx: one shared HIP runtime
+    from graphlearning_amd import dist as gdist, _hip
+    _hip.require_device()
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    ti = g['train_ind']
+    prob = gdist.poisson_problem(W, ti, g['labels'][ti])
+    P, C = prob['P'], prob['k']
+    n = P.shape[0]
+    order = gdist.locality_order(P)
+    rng = np.random.default_rng(0)
+    u = rng.normal(size=(n, C))
+    w = rng.random(n)
+    ref_u = prob['Db'] + P * u
+    ref_w = P * w
+    for world in (2, 4):
+        for rank in range(world):
+            plan = gdist.RankPlan(P, order, gdist.block_bounds(n, world), rank)
+            ops = gdist.HipOps(plan, C, 0)
+            glob = np.concatenate([plan.own, plan.halo])
+            xin = ops.pack(u[glob], w[glob], len(glob))
+            xout = ops.new_state(len(glob))
+            ops.set_bias(ops.pack(prob['Db'][plan.own], None, plan.n_own))
+            ops.set_stop_vectors(prob['deg'][plan.own], prob['vinf'][plan.own])
+            e = ops.sweep(xin, xout, True)
+            torch.cuda.synchronize()
+            got = ops.unpack(xout, plan.n_own)
+            assert np.array_equal(got, ref_u[plan.own]), (world, rank)
+            wcol = ops.lay['woff'] // 8
+            got_w = xout[:plan.n_own, wcol].cpu().numpy()
+            assert np.array_equal(got_w, ref_w[plan.own])
+            err_ref = np.max(np.abs(prob['deg'][plan.own] * ref_w[plan.own] - prob['vinf'][plan.own]))
+            assert float(e.item()) == err_ref
+            ops.close()
+
+
+def test_distributed_bench_entry_one_rank(tmp_path):
+    env = dict(os.environ, GLX_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    j = json.loads(line)
+    assert j['n_gpus'] == 1 and j['value'] > 0 and j['config']['sweeps_per_step'] == 50
+    print(line[:400])
