@@ -42,6 +42,7 @@ _SIGNATURES = {
     'glx_device_synchronize': [],
     'glx_graph_create': [C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)],
     'glx_graph_destroy': [_vp],
+    'glx_graph_keep_order': [_vp],
     'glx_graph_info': [_vp, _i64p],
     'glx_spmm_bias': [_vp, _vp, _vp, _vp, C.c_int, C.c_int],
     'glx_poisson_sweep': [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_int)],
@@ -131,7 +132,7 @@ class DeviceGraph:
     """A sparse operator resident in HBM (glx_graph).  `A` is any scipy sparse matrix;
     the CSR entry order is preserved (see include/glx.h)."""
 
-    def __init__(self, A, dtype=np.float64, device=0, shape=None):
+    def __init__(self, A, dtype=np.float64, device=0, shape=None, keep_order=False):
         from scipy import sparse
         A = sparse.csr_matrix(A)
         self.dtype = np.dtype(dtype)
@@ -145,12 +146,14 @@ class DeviceGraph:
         lib = load()
         check(lib.glx_graph_create(self.shape[0], self.shape[1], self.nnz, _ptr(rowptr), _ptr(col), _ptr(val),
                                    _dt(self.dtype), device, C.byref(self._h)), 'glx_graph_create')
+        if keep_order:
+            check(lib.glx_graph_keep_order(self._h), 'glx_graph_keep_order')
 
     def info(self):
         out = (C.c_int64 * 8)()
         check(load().glx_graph_info(self._h, out), 'glx_graph_info')
-        keys = ['n_rows', 'n_cols', 'nnz', 'stored', 'slices', 'rows_per_slice', 'max_row']
-        return dict(zip(keys, list(out)[:7]))
+        keys = ['n_rows', 'n_cols', 'nnz', 'stored', 'slices', 'rows_per_slice', 'max_row', 'renumbered']
+        return dict(zip(keys, list(out)[:8]))
 
     def spmm_bias(self, u, Db=None, iters=1):
         """`iters` applications of u <- Db + A u (host arrays in, host array out)."""

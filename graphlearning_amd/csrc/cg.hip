@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void cg_reduce_kernel(const double* __restrict
 // MODE 2: rsold = sum r*r                                                     (utils.py:517)
 template <typename T, int MODE>
 __global__ __launch_bounds__(64) void cg_seqdot_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t n, int ld,
-                                                       int ncols, int C, CgScalars sc, int it, double tol) {
+                                                       int ncols, int C, CgScalars sc, int it, double tol,
+                                                       const int32_t* __restrict__ inv) {
 #pragma clang fp contract(off)
   if (MODE != 2 && cg_done(sc.err_hist, it, tol)) return;
   __shared__ double s_col[64];
@@ -182,7 +183,11 @@ __global__ __launch_bounds__(64) void cg_seqdot_kernel(const T* __restrict__ a, 
     for (; i + 8 <= n; i += 8) {
       T va[8], vb[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { va[q] = pa[(size_t)(i + q) * ld]; vb[q] = pb[(size_t)(i + q) * ld]; }
+      for (int q = 0; q < 8; ++q) {   // caller's row i lives in record inv[i]
+        const size_t r = inv ? (size_t)inv[i + q] : (size_t)(i + q);
+        va[q] = pa[r * ld];
+        vb[q] = pb[r * ld];
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const T pr = va[q] * vb[q];        // elementwise product in the array dtype, as numpy forms p*Ap
@@ -190,7 +195,8 @@ __global__ __launch_bounds__(64) void cg_seqdot_kernel(const T* __restrict__ a, 
       }
     }
     for (; i < n; ++i) {
-      const T pr = pa[(size_t)i * ld] * pb[(size_t)i * ld];
+      const size_t r = inv ? (size_t)inv[i] : (size_t)i;
+      const T pr = pa[r * ld] * pb[r * ld];
       tot = tot + (double)pr;
     }
     if (MODE == 0) {
@@ -297,14 +303,14 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   GLX_HIP(hipMemsetAsync(b.ap, 0, recb, st));
   GLX_HIP(hipMemsetAsync(b.part_dot, 0, nb_spmm * ncols * 8, st));
   GLX_HIP(hipMemcpyAsync(b.dense, B, (size_t)n * C * es, hipMemcpyHostToDevice, st));
-  rc = glx_pack_records(b.dense, b.r, n, L, dtype, nullptr, st);   // r = b - A@0 = b (utils.py:514)
+  rc = glx_pack_records(b.dense, b.r, n, L, dtype, nullptr, st, A->d_perm);   // r = b - A@0 = b (utils.py:514)
   if (rc) return rc;
   GLX_HIP(hipMemcpyAsync(b.p, b.r, recb, hipMemcpyDeviceToDevice, st));   // p = r.copy() (utils.py:516)
   hipLaunchKernelGGL((cg_update_kernel<T, 1>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
                      (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, 1, tol);
   GLX_HIP(hipGetLastError());
   if (exact)
-    hipLaunchKernelGGL((cg_seqdot_kernel<T, 2>), dim3(1), dim3(64), 0, st, (const T*)r, (const T*)r, n, L.ld, ncols, C, sc, 0, tol);
+    hipLaunchKernelGGL((cg_seqdot_kernel<T, 2>), dim3(1), dim3(64), 0, st, (const T*)r, (const T*)r, n, L.ld, ncols, C, sc, 0, tol, (const int32_t*)A->d_inv);
   else
     hipLaunchKernelGGL(cg_reduce_kernel<2>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, 0, tol);
   GLX_HIP(hipGetLastError());
@@ -334,7 +340,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
       rc = glx_launch_spmm(a, st);                                                   // Ap = A@p, p.Ap partials
       if (rc) return rc;
       if (exact)
-        hipLaunchKernelGGL((cg_seqdot_kernel<T, 0>), dim3(1), dim3(64), 0, st, (const T*)p, (const T*)ap, n, L.ld, ncols, C, sc, i, tol);
+        hipLaunchKernelGGL((cg_seqdot_kernel<T, 0>), dim3(1), dim3(64), 0, st, (const T*)p, (const T*)ap, n, L.ld, ncols, C, sc, i, tol, (const int32_t*)A->d_inv);
       else
         hipLaunchKernelGGL(cg_reduce_kernel<0>, dim3(1), blk, 0, st, (const double*)b.part_dot, nb_spmm, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
@@ -342,7 +348,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
                          (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, i, tol);
       GLX_HIP(hipGetLastError());
       if (exact)
-        hipLaunchKernelGGL((cg_seqdot_kernel<T, 1>), dim3(1), dim3(64), 0, st, (const T*)r, (const T*)r, n, L.ld, ncols, C, sc, i, tol);
+        hipLaunchKernelGGL((cg_seqdot_kernel<T, 1>), dim3(1), dim3(64), 0, st, (const T*)r, (const T*)r, n, L.ld, ncols, C, sc, i, tol, (const int32_t*)A->d_inv);
       else
         hipLaunchKernelGGL(cg_reduce_kernel<1>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
@@ -360,7 +366,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
       if (!(err > tol)) { stopped = true; break; }
     }
   }
-  rc = glx_unpack_records(b.x, b.dense, n, L, dtype, st);
+  rc = glx_unpack_records(b.x, b.dense, n, L, dtype, st, A->d_perm);
   if (rc) return rc;
   GLX_HIP(hipMemcpyAsync(X, b.dense, (size_t)n * C * es, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));

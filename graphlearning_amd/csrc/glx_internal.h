@@ -72,9 +72,15 @@ struct glx_graph {
   std::vector<int32_t> h_rowptr, h_col;
   std::vector<double> h_val;
   std::vector<SellPlan> plans;   // one per G in use
+  // locality renumbering (square operators): perm[new] = old, inv[old] = new; empty = identity
+  bool order_ready = false, keep_order = false;
+  std::vector<int32_t> h_perm, h_inv;
+  int32_t* d_perm = nullptr;
+  int32_t* d_inv = nullptr;
 };
 
 int glx_graph_plan(glx_graph* g, int G, SellPlan** out);
+int glx_graph_ensure_order(glx_graph* g);
 
 // kernels' launch wrappers (sweep.hip)
 struct SweepArgs {
@@ -101,5 +107,8 @@ struct SweepArgs {
 int glx_launch_spmm(const SweepArgs& a, hipStream_t stream);
 int64_t glx_spmm_blocks(const SellPlan* plan);
 
-int glx_pack_records(const void* dense, void* rec, int64_t n, const RecLayout& L, int dtype, const double* w, hipStream_t s);
-int glx_unpack_records(const void* rec, void* dense, int64_t n, const RecLayout& L, int dtype, hipStream_t s);
+// perm (device, may be null = identity): record `i` holds vertex perm[i] of the caller's arrays
+int glx_pack_records(const void* dense, void* rec, int64_t n, const RecLayout& L, int dtype, const double* w, hipStream_t s,
+                     const int32_t* perm = nullptr);
+int glx_unpack_records(const void* rec, void* dense, int64_t n, const RecLayout& L, int dtype, hipStream_t s,
+                       const int32_t* perm = nullptr);

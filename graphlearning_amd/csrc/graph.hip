@@ -61,6 +61,13 @@ int glx_make_layout(int C, int dtype, bool has_w, RecLayout* L) {
   return GLX_OK;
 }
 
+extern "C" int glx_graph_keep_order(glx_graph* g) {
+  GLX_CHECK(g, GLX_EINVAL, "glx_graph_keep_order: null graph");
+  GLX_CHECK(g->plans.empty() && !g->order_ready, GLX_EINVAL, "glx_graph_keep_order: call before the operator is first used");
+  g->keep_order = true;
+  return GLX_OK;
+}
+
 extern "C" int glx_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr,
                                 const int32_t* col, const double* val, int state_dtype, int device,
                                 glx_graph** out) {
@@ -111,6 +118,8 @@ extern "C" int glx_graph_destroy(glx_graph* g) {
   if (!g) return GLX_OK;
   hipSetDevice(g->device);
   for (auto& p : g->plans) free_plan(p);
+  hipFree(g->d_perm);
+  hipFree(g->d_inv);
   delete g;
   return GLX_OK;
 }
@@ -127,66 +136,163 @@ extern "C" int glx_graph_info(const glx_graph* g, int64_t info[8]) {
     info[5] = g->plans[0].R;
   }
   info[6] = g->max_row;
+  info[7] = g->h_perm.empty() ? 0 : 1;
   return GLX_OK;
 }
 
-// Build (once per G) the sliced-ELL image of the operator.  Rows are handed to wavefront
-// slices in order of decreasing length (longest first: LPT balance, little padding inside a
-// slice); the ENTRY order inside a row is untouched.  G = 4 plans split rows longer than L1
-// entries over S = 4 slots and rows longer than L4 over S = 16 slots (GLX_SELL_L1/L4).
+// Reverse Cuthill-McKee on the symmetrised pattern: neighbours get nearby ids, so the
+// contiguous id range an XCD works on mostly gathers records of that same range (its own L2).
+static void rcm_order(const glx_graph* g, std::vector<int32_t>& perm) {
+  const int64_t n = g->n_rows;
+  std::vector<int64_t> ptr(n + 1, 0);
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t e = g->h_rowptr[i]; e < g->h_rowptr[i + 1]; ++e) {
+      ptr[i + 1]++;
+      ptr[g->h_col[e] + 1]++;
+    }
+  for (int64_t i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
+  std::vector<int32_t> adj(ptr[n]);
+  std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t e = g->h_rowptr[i]; e < g->h_rowptr[i + 1]; ++e) {
+      const int32_t j = g->h_col[e];
+      adj[fill[i]++] = j;
+      adj[fill[j]++] = (int32_t)i;
+    }
+  auto degree = [&](int32_t v) { return ptr[v + 1] - ptr[v]; };
+  std::vector<int32_t> by_deg(n);
+  std::iota(by_deg.begin(), by_deg.end(), 0);
+  std::stable_sort(by_deg.begin(), by_deg.end(), [&](int32_t a, int32_t b) { return degree(a) < degree(b); });
+  std::vector<char> seen(n, 0);
+  perm.clear();
+  perm.reserve(n);
+  std::vector<int32_t> nb;
+  for (int32_t start : by_deg) {
+    if (seen[start]) continue;
+    seen[start] = 1;
+    size_t head = perm.size();
+    perm.push_back(start);
+    while (head < perm.size()) {
+      const int32_t v = perm[head++];
+      nb.clear();
+      for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e) {
+        const int32_t u = adj[e];
+        if (!seen[u]) { seen[u] = 1; nb.push_back(u); }
+      }
+      std::sort(nb.begin(), nb.end(), [&](int32_t a, int32_t b) { return degree(a) < degree(b) || (degree(a) == degree(b) && a < b); });
+      perm.insert(perm.end(), nb.begin(), nb.end());
+    }
+  }
+  std::reverse(perm.begin(), perm.end());
+}
+
+// Vertex renumbering used by every plan of this operator (square operators only):
+// d_perm[new] = old, d_inv[old] = new.  Dense operands live on the device in the NEW order;
+// pack/unpack translate.  The entry order inside a row never changes.
+int glx_graph_ensure_order(glx_graph* g) {
+  if (g->order_ready) return GLX_OK;
+  g->order_ready = true;
+  const int64_t n = g->n_rows;
+  const char* e = getenv("GLX_REORDER");
+  const bool want = !(e && atoi(e) == 0);
+  if (!want || g->keep_order || g->n_rows != g->n_cols || n < 4096) return GLX_OK;
+  rcm_order(g, g->h_perm);
+  g->h_inv.assign(n, 0);
+  for (int64_t i = 0; i < n; ++i) g->h_inv[g->h_perm[i]] = (int32_t)i;
+  GLX_HIP(hipSetDevice(g->device));
+  GLX_HIP(hipMalloc(&g->d_perm, n * 4));
+  GLX_HIP(hipMalloc(&g->d_inv, n * 4));
+  GLX_HIP(hipMemcpy(g->d_perm, g->h_perm.data(), n * 4, hipMemcpyHostToDevice));
+  GLX_HIP(hipMemcpy(g->d_inv, g->h_inv.data(), n * 4, hipMemcpyHostToDevice));
+  return GLX_OK;
+}
+
+// Build (once per G) the sliced-ELL image of the operator.  The (renumbered) rows are cut
+// into 8 contiguous id ranges, one per XCD; inside a range rows are handed to wavefront slices
+// in order of decreasing length (longest first: LPT balance, little padding inside a slice);
+// the ENTRY order inside a row is untouched.  G = 4 plans split rows longer than L1 entries
+// over S = 4 slots and rows longer than L4 over S = 16 slots (GLX_SELL_L1/L4).  Every range
+// is padded with empty slices to the same number of 4-slice blocks, so block b serves range
+// b % 8 -- the XCD the dispatcher is observed to place it on.
 int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   for (auto& p : g->plans)
     if (p.G == G) {
       *out = &p;
       return GLX_OK;
     }
+  int rc = glx_graph_ensure_order(g);
+  if (rc) return rc;
   GLX_HIP(hipSetDevice(g->device));
   const int R = 64 / G;
   const int64_t n = g->n_rows;
+  const bool renum = !g->h_perm.empty();
   int L1 = 32, L4 = 128;   // measured on the 70k k=10 graph: 24..32 / 96..128 are within noise
   if (const char* e = getenv("GLX_SELL_L1")) L1 = std::max(4, atoi(e));
   if (const char* e = getenv("GLX_SELL_L4")) L4 = std::max(L1, atoi(e));
   if (G != 4) { L1 = 1 << 30; L4 = 1 << 30; }
-  std::vector<int32_t> order(n);
-  {
-    // counting sort by decreasing length, stable in row id
-    std::vector<int64_t> cnt(g->max_row + 2, 0);
-    for (int64_t i = 0; i < n; ++i) cnt[g->max_row - (g->h_rowptr[i + 1] - g->h_rowptr[i]) + 1]++;
-    for (size_t b = 1; b < cnt.size(); ++b) cnt[b] += cnt[b - 1];
-    for (int64_t i = 0; i < n; ++i) order[cnt[g->max_row - (g->h_rowptr[i + 1] - g->h_rowptr[i])]++] = (int32_t)i;
-  }
-  auto rowlen = [&](int32_t row) { return g->h_rowptr[row + 1] - g->h_rowptr[row]; };
-  // slices: consecutive runs of the sorted rows with the same S, R/S rows each
-  std::vector<SliceHdr> hdr;
-  std::vector<int32_t> slot_row, slot_len;
-  int64_t pos = 0, stored = 0;
-  while (pos < n) {
-    const int len0 = rowlen(order[pos]);
-    const int S = len0 > L4 ? 16 : (len0 > L1 ? 4 : 1);
-    const int rows_per = R / S;
-    SliceHdr h;
-    h.ptr = stored;
-    h.S = S;
-    int width = 0;
-    int filled = 0;
-    for (int r = 0; r < rows_per; ++r) {
-      int32_t row = -1;
-      int len = 0;
-      if (pos < n) {
-        const int l = rowlen(order[pos]);
-        const int Sr = l > L4 ? 16 : (l > L1 ? 4 : 1);
-        if (Sr == S) { row = order[pos]; len = l; ++pos; ++filled; }
-      }
-      for (int sgm = 0; sgm < S; ++sgm) { slot_row.push_back(row); slot_len.push_back(len); }
-      width = std::max(width, len);
+  auto old_of = [&](int64_t nid) -> int64_t { return renum ? g->h_perm[nid] : nid; };
+  auto rowlen = [&](int64_t nid) { const int64_t o = old_of(nid); return g->h_rowptr[o + 1] - g->h_rowptr[o]; };
+  auto klass = [&](int len) { return len > L4 ? 16 : (len > L1 ? 4 : 1); };
+
+  const int NX = 8;
+  std::vector<std::vector<SliceHdr>> ghdr(NX);
+  std::vector<std::vector<int32_t>> grow(NX), glen(NX);
+  for (int x = 0; x < NX; ++x) {
+    const int64_t b0 = n * x / NX, b1 = n * (x + 1) / NX;
+    const int64_t m = b1 - b0;
+    std::vector<int32_t> order(m);
+    {
+      std::vector<int64_t> cnt(g->max_row + 2, 0);
+      for (int64_t i = b0; i < b1; ++i) cnt[g->max_row - rowlen(i) + 1]++;
+      for (size_t b = 1; b < cnt.size(); ++b) cnt[b] += cnt[b - 1];
+      for (int64_t i = b0; i < b1; ++i) order[cnt[g->max_row - rowlen(i)]++] = (int32_t)i;
     }
-    (void)filled;
-    h.nchunks = (width + 4 * S - 1) / (4 * S) * (G / 4 > 1 ? 1 : 1);
-    if (G != 4) h.nchunks = (width + G - 1) / G;
-    stored += (int64_t)h.nchunks * 64;
-    hdr.push_back(h);
+    int64_t pos = 0;
+    while (pos < m) {
+      const int S = klass(rowlen(order[pos]));
+      SliceHdr h;
+      h.ptr = 0;
+      h.S = S;
+      int width = 0;
+      for (int r = 0; r < R / S; ++r) {
+        int32_t row = -1;
+        int len = 0;
+        if (pos < m && klass(rowlen(order[pos])) == S) {
+          row = order[pos];
+          len = rowlen(row);
+          ++pos;
+        }
+        for (int sgm = 0; sgm < S; ++sgm) { grow[x].push_back(row); glen[x].push_back(len); }
+        width = std::max(width, len);
+      }
+      h.nchunks = G == 4 ? (width + 4 * S - 1) / (4 * S) : (width + G - 1) / G;
+      ghdr[x].push_back(h);
+    }
   }
-  const int64_t nslices = (int64_t)hdr.size();
+  int64_t bpx = 0;   // blocks (4 slices) per XCD range
+  for (int x = 0; x < NX; ++x) bpx = std::max<int64_t>(bpx, ((int64_t)ghdr[x].size() + 3) / 4);
+  const int64_t spx = bpx * 4;
+  const int64_t nslices = spx * NX;
+  std::vector<SliceHdr> hdr(nslices);
+  std::vector<int32_t> slot_row(nslices * R, -1), slot_len(nslices * R, 0);
+  int64_t stored = 0;
+  for (int x = 0; x < NX; ++x)
+    for (int64_t s = 0; s < spx; ++s) {
+      SliceHdr h;
+      h.ptr = stored;
+      h.nchunks = 0;
+      h.S = 1;
+      if (s < (int64_t)ghdr[x].size()) {
+        h = ghdr[x][s];
+        h.ptr = stored;
+        for (int r = 0; r < R; ++r) {
+          slot_row[(x * spx + s) * R + r] = grow[x][s * R + r];
+          slot_len[(x * spx + s) * R + r] = glen[x][s * R + r];
+        }
+      }
+      stored += (int64_t)h.nchunks * 64;
+      hdr[x * spx + s] = h;
+    }
   std::vector<int32_t> col(stored, 0);
   std::vector<double> val64;
   std::vector<float> val32;
@@ -196,7 +302,7 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
     for (int slot = 0; slot < R; slot += S) {
       const int32_t row = slot_row[s * R + slot];
       if (row < 0) continue;
-      const int64_t b = g->h_rowptr[row];
+      const int64_t b = g->h_rowptr[old_of(row)];
       const int len = slot_len[s * R + slot];
       for (int jj = 0; jj < len; ++jj) {
         int64_t idx;
@@ -206,7 +312,8 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
         } else {
           idx = hdr[s].ptr + (int64_t)(jj / G) * 64 + slot * G + (jj % G);
         }
-        col[idx] = g->h_col[b + jj];
+        const int32_t c = g->h_col[b + jj];
+        col[idx] = renum ? g->h_inv[c] : c;
         if (g->dtype == GLX_F64) val64[idx] = g->h_val[b + jj]; else val32[idx] = (float)g->h_val[b + jj];
       }
     }
@@ -225,8 +332,10 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   GLX_HIP(hipMemcpy(p.d_slot_row, slot_row.data(), slot_row.size() * 4, hipMemcpyHostToDevice));
   GLX_HIP(hipMemcpy(p.d_slot_len, slot_len.data(), slot_len.size() * 4, hipMemcpyHostToDevice));
   GLX_HIP(hipMemcpy(p.d_slice_hdr, hdr.data(), hdr.size() * sizeof(SliceHdr), hipMemcpyHostToDevice));
-  GLX_HIP(hipMemcpy(p.d_col, col.data(), stored * 4, hipMemcpyHostToDevice));
-  GLX_HIP(hipMemcpy(p.d_val, g->dtype == GLX_F64 ? (void*)val64.data() : (void*)val32.data(), stored * es, hipMemcpyHostToDevice));
+  if (stored > 0) {
+    GLX_HIP(hipMemcpy(p.d_col, col.data(), stored * 4, hipMemcpyHostToDevice));
+    GLX_HIP(hipMemcpy(p.d_val, g->dtype == GLX_F64 ? (void*)val64.data() : (void*)val32.data(), stored * es, hipMemcpyHostToDevice));
+  }
   g->plans.push_back(p);
   *out = &g->plans.back();
   return GLX_OK;

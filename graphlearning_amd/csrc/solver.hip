@@ -6,6 +6,7 @@
 #include <string.h>
 #include <map>
 #include <math.h>
+#include <vector>
 
 static const int ERR_SHARDS = 64;
 static const int TAIL_CHUNK = 16;
@@ -127,7 +128,7 @@ static int upload_bias(glx_sweep* s, const void* Db) {
     return GLX_OK;
   }
   GLX_HIP(hipMemcpyAsync(s->dense, Db, (size_t)s->n_rows * s->C * s->L.esize, hipMemcpyHostToDevice, s->stream));
-  int rc = glx_pack_records(s->dense, s->bias, s->n_rows, s->L, s->P->dtype, nullptr, s->stream);
+  int rc = glx_pack_records(s->dense, s->bias, s->n_rows, s->L, s->P->dtype, nullptr, s->stream, s->P->d_perm);
   if (rc) return rc;
   if (nslots > 0) {
     hipLaunchKernelGGL(bias_flags_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s->stream,
@@ -146,9 +147,15 @@ extern "C" int glx_sweep_set_problem(glx_sweep* s, const void* Db, const double*
   GLX_HIP(hipSetDevice(s->P->device));
   int rc = upload_bias(s, Db);
   if (rc) return rc;
-  GLX_HIP(hipMemcpyAsync(s->w0, w0, s->n_cols * 8, hipMemcpyHostToDevice, s->stream));
-  GLX_HIP(hipMemcpyAsync(s->deg, deg, s->n_rows * 8, hipMemcpyHostToDevice, s->stream));
-  GLX_HIP(hipMemcpyAsync(s->vinf, vinf, s->n_rows * 8, hipMemcpyHostToDevice, s->stream));
+  GLX_HIP(hipMemcpyAsync(s->w0, w0, s->n_cols * 8, hipMemcpyHostToDevice, s->stream));   // caller order; packed through perm
+  std::vector<double> degp, vinfp;
+  if (!s->P->h_perm.empty()) {   // the kernel indexes deg / vinf by renumbered row
+    degp.resize(s->n_rows);
+    vinfp.resize(s->n_rows);
+    for (int64_t i = 0; i < s->n_rows; ++i) { degp[i] = deg[s->P->h_perm[i]]; vinfp[i] = vinf[s->P->h_perm[i]]; }
+  }
+  GLX_HIP(hipMemcpyAsync(s->deg, degp.empty() ? deg : degp.data(), s->n_rows * 8, hipMemcpyHostToDevice, s->stream));
+  GLX_HIP(hipMemcpyAsync(s->vinf, vinfp.empty() ? vinf : vinfp.data(), s->n_rows * 8, hipMemcpyHostToDevice, s->stream));
   double e0 = 0.0;
   for (int64_t i = 0; i < s->n_rows; ++i) {
     const double e = fabs(deg[i] * w0[i] - vinf[i]);
@@ -196,7 +203,7 @@ static int enqueue_head(glx_sweep* s) {
     GLX_HIP(hipMemcpyAsync(s->err, s->h_err, 8, hipMemcpyHostToDevice, s->stream));
   }
   s->cur = 0;
-  int rc = glx_pack_records(nullptr, s->buf[0], s->n_cols, s->L, s->P->dtype, s->w0, s->stream);   // u = 0 (ssl.py:645), w = w0
+  int rc = glx_pack_records(nullptr, s->buf[0], s->n_cols, s->L, s->P->dtype, s->w0, s->stream, s->P->d_perm);   // u = 0 (ssl.py:645), w = w0
   if (rc) return rc;
   const int head = std::min(s->min_iter, s->max_iter);
   for (int t = 0; t < head; ++t) {
@@ -285,7 +292,7 @@ extern "C" int glx_sweep_run(glx_sweep* s, int* T_out, float* device_ms_out) {
 extern "C" int glx_sweep_fetch(glx_sweep* s, void* u_out) {
   GLX_CHECK(s && u_out, GLX_EINVAL, "glx_sweep_fetch: null argument");
   GLX_HIP(hipSetDevice(s->P->device));
-  int rc = glx_unpack_records(s->buf[s->cur], s->dense, s->n_rows, s->L, s->P->dtype, s->stream);
+  int rc = glx_unpack_records(s->buf[s->cur], s->dense, s->n_rows, s->L, s->P->dtype, s->stream, s->P->d_perm);
   if (rc) return rc;
   GLX_HIP(hipMemcpyAsync(u_out, s->dense, (size_t)s->n_rows * s->C * s->L.esize, hipMemcpyDeviceToHost, s->stream));
   GLX_HIP(hipStreamSynchronize(s->stream));
@@ -307,7 +314,7 @@ extern "C" int glx_sweep_set_state(glx_sweep* s, const void* u0, const void* Db)
   GLX_HIP(hipStreamSynchronize(s->stream));   // `dense` staging is reused below
   if (u0) {
     GLX_HIP(hipMemcpyAsync(s->dense, u0, (size_t)s->n_cols * s->C * s->L.esize, hipMemcpyHostToDevice, s->stream));
-    rc = glx_pack_records(s->dense, s->buf[0], s->n_cols, s->L, s->P->dtype, nullptr, s->stream);
+    rc = glx_pack_records(s->dense, s->buf[0], s->n_cols, s->L, s->P->dtype, nullptr, s->stream, s->P->d_perm);
   } else {
     rc = glx_pack_records(nullptr, s->buf[0], s->n_cols, s->L, s->P->dtype, nullptr, s->stream);
   }
@@ -409,6 +416,14 @@ extern "C" int glx_record_layout(int C, int dtype, int has_w, int32_t out[6]) {
   return GLX_OK;
 }
 
+static int require_caller_order(glx_graph* P, const char* who) {
+  int rc = glx_graph_ensure_order(P);
+  if (rc) return rc;
+  GLX_CHECK(P->h_perm.empty(), GLX_EINVAL, "%s: the operator was renumbered internally; create it with glx_graph_keep_order() "
+            "to use caller-ordered device records", who);
+  return GLX_OK;
+}
+
 extern "C" int glx_graph_slots(glx_graph* P, int C, int has_w, int64_t* nslots) {
   GLX_CHECK(P && nslots, GLX_EINVAL, "glx_graph_slots: null argument");
   RecLayout L;
@@ -443,7 +458,9 @@ extern "C" int glx_sweep_step_dev(glx_graph* P, int C, int has_w, const void* xi
   GLX_CHECK(P && xin && xout, GLX_EINVAL, "glx_sweep_step_dev: null argument");
   SweepArgs a;
   memset(&a, 0, sizeof(a));
-  int rc = glx_make_layout(C, P->dtype, has_w != 0, &a.L);
+  int rc = require_caller_order(P, "glx_sweep_step_dev");
+  if (rc) return rc;
+  rc = glx_make_layout(C, P->dtype, has_w != 0, &a.L);
   if (rc) return rc;
   SellPlan* plan = nullptr;
   rc = glx_graph_plan(P, a.L.G, &plan);

@@ -103,10 +103,9 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 
 // XCD-aware block -> slice-group map: the dispatcher places block b on XCD b % 8; hand
 // each XCD a contiguous range of slices so rows that share neighbours share an L2.
+// (the plan pads every range to nb/8 blocks, so the map is a plain transpose)
 __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nb) {
-  const int64_t q = nb / 8, r = nb % 8;
-  const int64_t xcd = b % 8, i = b / 8;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  return (b % 8) * (nb / 8) + b / 8;
 }
 
 template <typename T, bool HAS_W>
@@ -451,55 +450,60 @@ int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
 
 // ---- dense (n,C) <-> vertex records ---------------------------------------------------
 template <typename T>
-__global__ void pack_kernel(const T* __restrict__ dense, T* __restrict__ rec, int64_t n, int C, int ld) {
+__global__ void pack_kernel(const T* __restrict__ dense, T* __restrict__ rec, int64_t n, int C, int ld,
+                            const int32_t* __restrict__ perm) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * ld) return;
   const int64_t row = i / ld;
   const int c = (int)(i % ld);
   T v = 0;
-  if (c < C && dense) v = dense[row * C + c];
+  if (c < C && dense) v = dense[(perm ? (int64_t)perm[row] : row) * C + c];
   rec[i] = v;
 }
 
 template <typename T>
-__global__ void unpack_kernel(const T* __restrict__ rec, T* __restrict__ dense, int64_t n, int C, int ld) {
+__global__ void unpack_kernel(const T* __restrict__ rec, T* __restrict__ dense, int64_t n, int C, int ld,
+                              const int32_t* __restrict__ perm) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * C) return;
   const int64_t row = i / C;
   const int c = (int)(i % C);
-  dense[i] = rec[row * ld + c];
+  dense[(perm ? (int64_t)perm[row] : row) * C + c] = rec[row * ld + c];
 }
 
-__global__ void write_w_kernel(char* __restrict__ rec, int64_t n, int rec_bytes, int woff, const double* __restrict__ w) {
+__global__ void write_w_kernel(char* __restrict__ rec, int64_t n, int rec_bytes, int woff, const double* __restrict__ w,
+                               const int32_t* __restrict__ perm) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row < n) *(double*)(rec + (size_t)row * rec_bytes + woff) = w[row];
+  if (row < n) *(double*)(rec + (size_t)row * rec_bytes + woff) = w[perm ? perm[row] : row];
 }
 
 // dense (n,C) [or zeros when dense == nullptr] -> records; then the fp64 stop values, if any
-int glx_pack_records(const void* dense, void* rec, int64_t n, const RecLayout& L, int dtype, const double* w, hipStream_t s) {
+int glx_pack_records(const void* dense, void* rec, int64_t n, const RecLayout& L, int dtype, const double* w, hipStream_t s,
+                     const int32_t* perm) {
   const int64_t total = n * L.ld;
   if (total == 0) return GLX_OK;
   const unsigned grid = (unsigned)((total + 255) / 256);
   if (dtype == GLX_F32)
-    hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dense, (float*)rec, n, L.C, L.ld);
+    hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dense, (float*)rec, n, L.C, L.ld, perm);
   else
-    hipLaunchKernelGGL(pack_kernel<double>, dim3(grid), dim3(256), 0, s, (const double*)dense, (double*)rec, n, L.C, L.ld);
+    hipLaunchKernelGGL(pack_kernel<double>, dim3(grid), dim3(256), 0, s, (const double*)dense, (double*)rec, n, L.C, L.ld, perm);
   GLX_HIP(hipGetLastError());
   if (L.woff >= 0 && w) {
-    hipLaunchKernelGGL(write_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (char*)rec, n, L.ld * L.esize, L.woff, w);
+    hipLaunchKernelGGL(write_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (char*)rec, n, L.ld * L.esize, L.woff, w, perm);
     GLX_HIP(hipGetLastError());
   }
   return GLX_OK;
 }
 
-int glx_unpack_records(const void* rec, void* dense, int64_t n, const RecLayout& L, int dtype, hipStream_t s) {
+int glx_unpack_records(const void* rec, void* dense, int64_t n, const RecLayout& L, int dtype, hipStream_t s,
+                       const int32_t* perm) {
   const int64_t total = n * L.C;
   if (total == 0) return GLX_OK;
   const unsigned grid = (unsigned)((total + 255) / 256);
   if (dtype == GLX_F32)
-    hipLaunchKernelGGL(unpack_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)rec, (float*)dense, n, L.C, L.ld);
+    hipLaunchKernelGGL(unpack_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)rec, (float*)dense, n, L.C, L.ld, perm);
   else
-    hipLaunchKernelGGL(unpack_kernel<double>, dim3(grid), dim3(256), 0, s, (const double*)rec, (double*)dense, n, L.C, L.ld);
+    hipLaunchKernelGGL(unpack_kernel<double>, dim3(grid), dim3(256), 0, s, (const double*)rec, (double*)dense, n, L.C, L.ld, perm);
   GLX_HIP(hipGetLastError());
   return GLX_OK;
 }

@@ -107,7 +107,8 @@ class HipOps:
         _assert_single_hip_runtime()
         self.lay = _hip.record_layout(C, self.dtype, True)
         self.ld = self.lay['ld']
-        self.graph = _hip.DeviceGraph(plan.P_local, dtype=self.dtype, device=device, shape=plan.P_local.shape)
+        self.graph = _hip.DeviceGraph(plan.P_local, dtype=self.dtype, device=device, shape=plan.P_local.shape,
+                                      keep_order=True)   # records stay in the partition's (RCM) order
         n = _hip.C.c_int64(0)
         _hip.check(_hip.load().glx_graph_slots(self.graph._h, C, 1, _hip.C.byref(n)), 'glx_graph_slots')
         self.nslots = n.value

@@ -59,7 +59,12 @@ int glx_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t*
                      const int32_t* col, const double* val, int state_dtype, int device,
                      glx_graph** out);
 int glx_graph_destroy(glx_graph* g);
-/* info[0]=n_rows,[1]=n_cols,[2]=nnz,[3]=stored entries incl. padding,[4]=slices,[5]=rows per slice,[6]=max row nnz */
+/* Square operators are renumbered internally for cache locality (reverse Cuthill-McKee; dense
+ * operands passed as HOST arrays are translated on the way in and out, results do not change).
+ * Call this right after creation to keep the caller's vertex order -- required for the
+ * device-pointer (_dev) entry points, whose records are in the caller's order. */
+int glx_graph_keep_order(glx_graph* g);
+/* info[0]=n_rows,[1]=n_cols,[2]=nnz,[3]=stored entries incl. padding,[4]=slices,[5]=rows per slice,[6]=max row nnz,[7]=1 if renumbered */
 int glx_graph_info(const glx_graph* g, int64_t info[8]);
 
 /* u_out = Db + A u_in, applied `iters` times (u fed back).  Db may be NULL (no bias).
