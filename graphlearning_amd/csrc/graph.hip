@@ -226,7 +226,7 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   const int R = 64 / G;
   const int64_t n = g->n_rows;
   const bool renum = !g->h_perm.empty();
-  int L1 = 32, L4 = 128;   // measured on the 70k k=10 graph: 24..32 / 96..128 are within noise
+  int L1 = 24, L4 = 96;   // measured on the 70k k=10 graph (fp64): 24/96 13.3 us, 32/128 15.2 us, 16/64 15.4 us
   if (const char* e = getenv("GLX_SELL_L1")) L1 = std::max(4, atoi(e));
   if (const char* e = getenv("GLX_SELL_L4")) L4 = std::max(L1, atoi(e));
   if (G != 4) { L1 = 1 << 30; L4 = 1 << 30; }
@@ -241,11 +241,17 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
     const int64_t b0 = n * x / NX, b1 = n * (x + 1) / NX;
     const int64_t m = b1 - b0;
     std::vector<int32_t> order(m);
-    {
+    // sort by decreasing length inside windows of `sigma` consecutive ids (SELL-C-sigma): small
+    // windows keep rows that share neighbours in the same wavefronts/CUs (L1 reuse), large ones
+    // minimise padding.  GLX_SELL_SIGMA, default: the whole XCD range.
+    int64_t sigma = m;
+    if (const char* e = getenv("GLX_SELL_SIGMA")) sigma = std::max<int64_t>(R, atoll(e));
+    for (int64_t w0 = 0; w0 < m; w0 += sigma) {
+      const int64_t w1 = std::min(m, w0 + sigma);
       std::vector<int64_t> cnt(g->max_row + 2, 0);
-      for (int64_t i = b0; i < b1; ++i) cnt[g->max_row - rowlen(i) + 1]++;
+      for (int64_t i = w0; i < w1; ++i) cnt[g->max_row - rowlen(b0 + i) + 1]++;
       for (size_t b = 1; b < cnt.size(); ++b) cnt[b] += cnt[b - 1];
-      for (int64_t i = b0; i < b1; ++i) order[cnt[g->max_row - rowlen(i)]++] = (int32_t)i;
+      for (int64_t i = w0; i < w1; ++i) order[w0 + cnt[g->max_row - rowlen(b0 + i)]++] = (int32_t)(b0 + i);
     }
     int64_t pos = 0;
     while (pos < m) {

@@ -108,19 +108,20 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nb) {
   return (b % 8) * (nb / 8) + b / 8;
 }
 
+// acc += v * x for one entry.  Entries past the end of a row carry val = 0 and an unloaded
+// x = 0, i.e. a product of exactly 0, and acc (which starts at +0 and therefore can never be
+// -0) satisfies acc + 0 == acc bit for bit: no predicate is needed.
 template <typename T, bool HAS_W>
 __device__ __forceinline__ void accum4(typename VecOf<T>::type& acc, double& accw, T v, const typename VecOf<T>::type& x,
-                                       bool act, bool is_w) {
+                                       bool is_w) {
 #pragma clang fp contract(off)
   typename VecOf<T>::type prod = x * v;
-  typename VecOf<T>::type sum = acc + prod;
-  if (act) acc = sum;
+  acc = acc + prod;
   if constexpr (HAS_W && sizeof(T) == 4) {
     // fp32 state: the stop value is an fp64 stored in elements 0..1 of the last vector
     const double xw = __hiloint2double(__float_as_int(x[1]), __float_as_int(x[0]));
     const double pw = (double)v * xw;
-    const double sw = accw + pw;
-    if (act && is_w) accw = sw;
+    accw = accw + pw;
   }
 }
 
@@ -142,15 +143,12 @@ __device__ __forceinline__ typename VecOf<T>::type product4(T v, const typename 
 }
 
 template <typename T, bool HAS_W>
-__device__ __forceinline__ void add_product(typename VecOf<T>::type& acc, double& accw, const typename VecOf<T>::type& pr,
-                                            bool act, bool is_w) {
+__device__ __forceinline__ void add_product(typename VecOf<T>::type& acc, double& accw, const typename VecOf<T>::type& pr) {
 #pragma clang fp contract(off)
-  typename VecOf<T>::type sum = acc + pr;
-  if (act) acc = sum;
+  acc = acc + pr;
   if constexpr (HAS_W && sizeof(T) == 4) {
     const double pw = __hiloint2double(__float_as_int(pr[1]), __float_as_int(pr[0]));
-    const double sw = accw + pw;
-    if (act && is_w) accw = sw;
+    accw = accw + pw;
   }
 }
 
@@ -232,13 +230,11 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
       if (lane_on && j0 + 3 < len) x[3] = *(const V4*)(p.xin + (size_t)c3 * p.rec_bytes + lane_off);
     };
     auto consume = [&](int k, const V4 (&x)[4], const T (&v)[4]) {
-      const int j0 = (k * S + seg) * 4;
-      const bool a0 = lane_on && j0 + 0 < len, a1 = lane_on && j0 + 1 < len, a2 = lane_on && j0 + 2 < len, a3 = lane_on && j0 + 3 < len;
       if (S == 1) {
-        accum4<T, HAS_W>(acc, accw, v[0], x[0], a0, is_w);
-        accum4<T, HAS_W>(acc, accw, v[1], x[1], a1, is_w);
-        accum4<T, HAS_W>(acc, accw, v[2], x[2], a2, is_w);
-        accum4<T, HAS_W>(acc, accw, v[3], x[3], a3, is_w);
+        accum4<T, HAS_W>(acc, accw, v[0], x[0], is_w);
+        accum4<T, HAS_W>(acc, accw, v[1], x[1], is_w);
+        accum4<T, HAS_W>(acc, accw, v[2], x[2], is_w);
+        accum4<T, HAS_W>(acc, accw, v[3], x[3], is_w);
       } else {
         // the running sum visits the row's S segments in order: whoever holds it adds its 4
         // products, then it moves 4 lanes on (every lane executes the adds; only the holder's
@@ -246,10 +242,10 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
         const V4 q0 = product4<T, HAS_W>(v[0], x[0], is_w), q1 = product4<T, HAS_W>(v[1], x[1], is_w);
         const V4 q2 = product4<T, HAS_W>(v[2], x[2], is_w), q3 = product4<T, HAS_W>(v[3], x[3], is_w);
         for (int ph = 0; ph < S; ++ph) {
-          add_product<T, HAS_W>(acc, accw, q0, a0, is_w);
-          add_product<T, HAS_W>(acc, accw, q1, a1, is_w);
-          add_product<T, HAS_W>(acc, accw, q2, a2, is_w);
-          add_product<T, HAS_W>(acc, accw, q3, a3, is_w);
+          add_product<T, HAS_W>(acc, accw, q0);
+          add_product<T, HAS_W>(acc, accw, q1);
+          add_product<T, HAS_W>(acc, accw, q2);
+          add_product<T, HAS_W>(acc, accw, q3);
           if (S == 4) {
             acc = row_ror4(acc);
             if constexpr (HAS_W && sizeof(T) == 4) accw = row_ror4(accw);
@@ -305,7 +301,7 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
           if (aj[t]) xj[t] = *(const V4*)(p.xin + (size_t)cj[t] * p.rec_bytes + lane_off);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) accum4<T, HAS_W>(acc, accw, vj[t], xj[t], aj[t], is_w);
+        for (int t = 0; t < 4; ++t) accum4<T, HAS_W>(acc, accw, vj[t], xj[t], is_w);
       }
     }
   }
