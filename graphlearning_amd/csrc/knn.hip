@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -28,6 +29,7 @@ extern "C" int glx_knn_stats(double stats[8]) {
 
 static const int BQ = 128;   // queries per workgroup (4 waves x 32)
 static const int BR_MAX = 128; // refs per LDS tile: 32 * NSUB
+static const int KBUF = 16;    // per-lane append slots between list compactions
 
 // ---- stage 0: centred fp32 images with the norms folded in ---------------------------------
 // Rf[i] = [x_0..x_{d-1}, 0.., |x|^2, 1]   Qf[i] = [-2x_0..-2x_{d-1}, 0.., 1, |x|^2]   (dpa floats)
@@ -54,14 +56,14 @@ __global__ void knn_prep_kernel(const double* __restrict__ X, const double* __re
 template <int DH, int KP, int NSUB>
 __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__ Rf, const float* __restrict__ Qf, int64_t n,
                                                        int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d,
-                                                       int* __restrict__ cand_i) {
+                                                       int* __restrict__ cand_i, int ablate) {
   constexpr int DPA = 2 * DH;
   constexpr int BR = 32 * NSUB;
   constexpr int STRIDE = (DH % 2 == 1) ? DPA : DPA + 2;   // floats; ds_read_b64 of 32 rows hits 64 distinct banks
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tile = smem;                                  // [2][BR][STRIDE]
-  float* ld = smem + 2 * BR * STRIDE;                  // [KP][256] list distances
-  int* li = (int*)(ld + KP * 256);                     // [KP][256] list indices
+  float* ld = smem + 2 * BR * STRIDE;                  // [KP + KBUF][256]: sorted top-KP list, then append slots
+  int* li = (int*)(ld + (KP + KBUF) * 256);            // [KP + KBUF][256] indices
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
   const int64_t qb = blockIdx.x, sp = blockIdx.y;
@@ -77,28 +79,64 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
 
   const int64_t ntiles = (n + BR - 1) / BR;
   const int64_t t0 = ntiles * sp / nsplit, t1 = ntiles * (sp + 1) / nsplit;
-  auto stage = [&](int buf, int64_t t) {
+  // staging split in two (issue early / write late): the global loads of tile t+1 are issued
+  // before the MFMAs of tile t and land in LDS only after them, so their latency hides
+  // under the matrix work instead of stalling the wavefront in front of it.
+  constexpr int UNITS = (BR * DH + 255) / 256;   // float2 units per thread per tile
+  float2 pre[UNITS];
+  auto stage_load = [&](int64_t t) {
     // BR rows x DH float2 units; rows beyond n become "infinitely far" refs
-    float* dst = tile + buf * BR * STRIDE;
-    for (int u = tid; u < BR * DH; u += 256) {
+#pragma unroll
+    for (int i = 0; i < UNITS; ++i) {
+      const int u = tid + i * 256;
       const int r = u / DH, f2 = u % DH;
       const int64_t ref = t * BR + r;
       float2 v;
-      if (ref < n) {
-        v = *(const float2*)(Rf + ref * DPA + 2 * f2);
-      } else {
-        v.x = 0.f;
-        v.y = (f2 == DH - 1) ? 0.f : 0.f;
-        if (f2 == DH - 1) v.x = 1e30f;   // norm slot (feature DPA-2)
-      }
-      *(float2*)(dst + r * STRIDE + 2 * f2) = v;
+      v.x = (f2 == DH - 1) ? 1e30f : 0.f;   // norm slot (feature DPA-2) of a padding ref
+      v.y = 0.f;
+      if (u < BR * DH && ref < n) v = *(const float2*)(Rf + ref * DPA + 2 * f2);
+      pre[i] = v;
     }
   };
-  if (t0 < t1) stage(0, t0);
+  auto stage_store = [&](int buf) {
+    float* dst = tile + buf * BR * STRIDE;
+#pragma unroll
+    for (int i = 0; i < UNITS; ++i) {
+      const int u = tid + i * 256;
+      if (u < BR * DH) *(float2*)(dst + (u / DH) * STRIDE + 2 * (u % DH)) = pre[i];
+    }
+  };
+  int cnt = 0;
+  auto compact = [&]() {
+    int mx = cnt;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+    for (int a = 0; a < mx; ++a) {
+      if (a < cnt) {
+        const float v = ld[(KP + a) * 256 + tid];
+        if (v < ld[(KP - 1) * 256 + tid]) {
+          const int ref = li[(KP + a) * 256 + tid];
+          int p = KP - 1;
+          while (p > 0) {
+            const float prev = ld[(p - 1) * 256 + tid];
+            if (!(prev > v)) break;
+            ld[p * 256 + tid] = prev;
+            li[p * 256 + tid] = li[(p - 1) * 256 + tid];
+            --p;
+          }
+          ld[p * 256 + tid] = v;
+          li[p * 256 + tid] = ref;
+        }
+      }
+    }
+    cnt = 0;
+    tau = ld[(KP - 1) * 256 + tid];
+  };
+  if (t0 < t1) { stage_load(t0); stage_store(0); }
   __syncthreads();
   for (int64_t t = t0; t < t1; ++t) {
     const int buf = (int)((t - t0) & 1);
-    if (t + 1 < t1) stage(buf ^ 1, t + 1);
+    if (t + 1 < t1) stage_load(t + 1);
     const float* tl = tile + buf * BR * STRIDE;
     f32x16 acc[NSUB];
 #pragma unroll
@@ -114,37 +152,40 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
         if (s + 1 < DH) acc[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[s + 1], acc[sub], 0, 0, 0);
       }
     }
-    // selection: acc[sub][e] = dist^2(query j, ref sub*32 + (e&3) + 8*(e>>2) + 4*h)
+    // selection: acc[sub][e] = dist^2(query j, ref sub*32 + (e&3) + 8*(e>>2) + 4*h).
+    // Candidates below the lane's threshold are APPENDED to the lane's LDS slots (cheap, even
+    // when only a few lanes have one); when any lane's slots run low the whole wavefront
+    // merges its appended candidates into the sorted lists in lockstep, so the insertion
+    // cost is paid once per wavefront, not once per lane.
     float m = acc[0][0];
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
       for (int e = 0; e < 16; ++e) m = fminf(m, acc[sub][e]);
-    if (m < tau) {
+    if (ablate == 1) {   // developer probe: matrix work + staging only
+      if (m == 12345.f) tau = m;
+    } else if (__any(m < tau)) {
 #pragma unroll
       for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[sub][e];
-          if (v < tau) {
-            const int ref = (int)(t * BR) + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            int p = KP - 1;
-            while (p > 0) {
-              const float prev = ld[(p - 1) * 256 + tid];
-              if (!(prev > v)) break;
-              ld[p * 256 + tid] = prev;
-              li[p * 256 + tid] = li[(p - 1) * 256 + tid];
-              --p;
+        for (int eg = 0; eg < 16; eg += 8) {
+#pragma unroll
+          for (int e = eg; e < eg + 8; ++e) {
+            const float v = acc[sub][e];
+            if (v < tau) {
+              ld[(KP + cnt) * 256 + tid] = v;
+              li[(KP + cnt) * 256 + tid] = (int)(t * BR) + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+              ++cnt;
             }
-            ld[p * 256 + tid] = v;
-            li[p * 256 + tid] = ref;
-            tau = ld[(KP - 1) * 256 + tid];
           }
+          if (__any(cnt > KBUF - 8)) compact();
         }
       }
     }
+    if (t + 1 < t1) stage_store(buf ^ 1);
     __syncthreads();
   }
+  compact();
   if (q < q_end) {
     const int64_t lists = (int64_t)nsplit * 2;
     const int64_t base = ((q - q_begin) * lists + sp * 2 + h) * KP;
@@ -286,8 +327,8 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(const double* __restr
 // refs per tile = 32*NSUB, as many as fit LDS (160 KiB) beside the candidate lists
 constexpr int tile_nsub(int DH, int KP) {
   const int stride = 2 * DH + 2;
-  for (int ns = 4; ns >= 1; ns /= 2)
-    if (2 * 32 * ns * stride * 4 + KP * 256 * 8 <= 150 * 1024) return ns;
+  for (int ns = 4; ns >= 2; ns /= 2)
+    if (2 * 32 * ns * stride * 4 + (KP + KBUF) * 256 * 8 <= 78 * 1024) return ns;   // two workgroups per CU
   return 1;
 }
 
@@ -314,11 +355,11 @@ static int launch_tile(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int 
   constexpr int DPA = 2 * DH;
   constexpr int STRIDE = (DH % 2 == 1) ? DPA : DPA + 2;
   constexpr int NSUB = tile_nsub(DH, KP);
-  const size_t shm = (size_t)2 * 32 * NSUB * STRIDE * 4 + (size_t)KP * 256 * 8;
+  const size_t shm = (size_t)2 * 32 * NSUB * STRIDE * 4 + (size_t)(KP + KBUF) * 256 * 8;
   GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_kernel<DH, KP, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)nsplit);
   hipLaunchKernelGGL((knn_tile_kernel<DH, KP, NSUB>), grid, dim3(256), shm, st, (const float*)b.Rf, (const float*)b.Qf, n, q0, q1, nsplit,
-                     b.cand_d, b.cand_i);
+                     b.cand_d, b.cand_i, getenv("GLX_KNN_ABLATE") ? atoi(getenv("GLX_KNN_ABLATE")) : 0);
   GLX_HIP(hipGetLastError());
   return GLX_OK;
 }
@@ -342,7 +383,7 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   GLX_CHECK(k <= n, GLX_EINVAL, "glx_knn_bruteforce: k=%d exceeds the number of points %lld", k, (long long)n);
   GLX_CHECK(n < (1ll << 31) - BR_MAX, GLX_EINVAL, "glx_knn_bruteforce: n must fit int32");
   GLX_CHECK(0 <= q0 && q0 <= q1 && q1 <= n, GLX_EINVAL, "glx_knn_bruteforce: bad query range");
-  GLX_CHECK(k <= 60, GLX_EUNSUPPORTED, "glx_knn_bruteforce: k=%d (incl. self) above the supported 60", k);
+  GLX_CHECK(k <= 28, GLX_EUNSUPPORTED, "glx_knn_bruteforce: k=%d (incl. self) above the supported 28", k);
   GLX_CHECK(d <= 130, GLX_EUNSUPPORTED, "glx_knn_bruteforce: d=%d above the supported 130", d);
   const int64_t nq = q1 - q0;
   if (nq == 0) return GLX_OK;
@@ -351,11 +392,12 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   for (int cand : {8, 12, 18, 34, 66})
     if (2 * cand >= d + 2) { DH = cand; break; }
   const int dpa = 2 * DH;
-  const int KP = k <= 12 ? 16 : (k <= 28 ? 32 : 64);
+  const int KP = k <= 12 ? 16 : 32;
   const int64_t nqb = (nq + BQ - 1) / BQ;
   const int BR = 32 * tile_nsub(DH, KP);
   const int64_t ntiles = (n + BR - 1) / BR;
   int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, ntiles), (1024 + nqb - 1) / nqb));
+  if (const char* e = getenv("GLX_KNN_NSPLIT")) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, ntiles), atoi(e)));
   const int lists = nsplit * 2;
   const int ncand = lists * KP;
   int M = 64;
@@ -404,8 +446,7 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   GLX_HIP(hipGetLastError());
   int rc;
   if (KP == 16) rc = launch_tile_dh<16>(DH, b, n, q0, q1, nsplit, st);
-  else if (KP == 32) rc = launch_tile_dh<32>(DH, b, n, q0, q1, nsplit, st);
-  else rc = launch_tile_dh<64>(DH, b, n, q0, q1, nsplit, st);
+  else rc = launch_tile_dh<32>(DH, b, n, q0, q1, nsplit, st);
   if (rc) return rc;
   GLX_HIP(hipEventRecord(b.e1, st));
   hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)nq), dim3(64), (size_t)M * 12, st, (const double*)b.X, n, d, k, q0, nq,

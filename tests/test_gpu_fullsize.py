@@ -1,0 +1,124 @@
+"""GPU, BASELINE.json's full sizes: config 2 (70000 x 10 classes, k=10) and config 3 (60000,
+k=20, Laplace CG) regenerated from seeds and checked against the checksums the reference
+produced in the build container (tests/golden/g4_large_meta.json), plus size-independent
+properties (symmetry, zero diagonal, row-stochastic P, conservation of sum_i deg_i u_i)."""
+import hashlib
+import json
+import os
+import time
+import numpy as np
+import pytest
+from scipy import sparse
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+@pytest.fixture(scope='module')
+def gl():
+    import graphlearning_amd as gl
+    from graphlearning_amd import _hip
+    _hip.require_device()
+    return gl
+
+
+@pytest.fixture(scope='module')
+def meta():
+    return json.load(open(os.path.join(GOLDEN, 'g4_large_meta.json')))
+
+
+@pytest.fixture(scope='module')
+def config2(gl):
+    labels = np.load(os.path.join(GOLDEN, 'MNIST_labels.npz'))['labels'].astype(np.int64)
+    rng = np.random.default_rng(0)
+    centers = rng.normal(size=(10, 20)) * 2.0
+    X = centers[labels] + rng.normal(size=(70000, 20))
+    J, D = gl.weightmatrix.knnsearch(X, 11)
+    W = gl.weightmatrix.knn(None, 10, knn_data=(J, D))
+    return dict(labels=labels, X=X, J=J, D=D, W=W, train_ind=gl.trainsets.generate(labels, rate=1, seed=0))
+
+
+def test_config2_graph(gl, meta, config2):
+    m = meta['config2']
+    J, D, W = config2['J'], config2['D'], config2['W']
+    assert sha(J.astype(np.int64)) == m['J_sha']                 # identical neighbour lists, 70000 x 11
+    assert abs(D.sum() - m['D_sum']) < 1e-6
+    assert W.nnz == m['nnz'] and np.diff(W.indptr).max() == m['row_nnz_max']
+    assert sha(W.indices.astype(np.int32)) == m['W_indices_sha']
+    assert abs(W.data.sum() - m['W_data_sum']) < 1e-8
+    assert (abs(W - W.T) > 0).nnz == 0 and W.diagonal().sum() == 0 and W.data.min() > 0
+    assert np.all(np.diff(D, axis=1) >= 0) and np.all(D[:, 0] == 0) and np.all(J[:, 0] == np.arange(70000))
+    assert list(config2['train_ind']) == m['train_ind']
+
+
+def test_config2_poisson_gd(gl, meta, config2):
+    m = meta['config2']
+    W, ti, labels = config2['W'], config2['train_ind'], config2['labels']
+    model = gl.ssl.poisson(W, solver='gradient_descent')
+    u = model.fit(ti, labels[ti])
+    pred = model.predict()
+    assert model.num_iter == m['T'] == 50
+    assert sha(pred.astype(np.int64)) == m['pred_sha']            # identical predicted labels, all 70000
+    assert abs(np.abs(u).sum() - m['prob_abs_sum']) < 1e-8 * m['prob_abs_sum']
+    assert gl.ssl.ssl_accuracy(pred, labels, ti) == m['accuracy']
+    # conservation: sum_i deg_i u_i stays 0 (the source has zero column sums)
+    deg = np.asarray(W.sum(axis=1)).ravel()
+    assert np.max(np.abs(deg @ u)) < 1e-9
+    # fp32 device path of the reference (use_cuda=True): within 1e-5, same labels
+    m32 = gl.ssl.poisson(W, solver='gradient_descent', use_cuda=True)
+    u32 = m32.fit(ti, labels[ti])
+    assert u32.dtype == np.float32 and m32.num_iter == 50
+    assert np.max(np.abs(u32 - u)) < 1e-5
+    assert np.array_equal(m32.predict(), pred)
+
+
+def test_config2_poisson_cg(gl, meta, config2):
+    m = meta['config2']
+    W, ti, labels = config2['W'], config2['train_ind'], config2['labels']
+    model = gl.ssl.poisson(W)
+    t0 = time.perf_counter()
+    u = model.fit(ti, labels[ti])
+    print('poisson CG 70k: %d iterations, %.3f s' % (model.num_iter, time.perf_counter() - t0))
+    assert model.num_iter == m['cg_iters'] == 140
+    assert sha(model.predict().astype(np.int64)) == m['cg_pred_sha']
+    assert abs(np.abs(u).sum() - m['cg_prob_abs_sum']) <= 1e-9 * m['cg_prob_abs_sum']
+
+
+def test_config5_poisson_mbo_runs_and_balances(gl, config2):
+    W, ti, labels = config2['W'], config2['train_ind'], config2['labels']
+    pri = gl.utils.class_priors(labels)
+    model = gl.ssl.poisson_mbo(W, pri, solver='gradient_descent')
+    t0 = time.perf_counter()
+    pred = model.fit_predict(ti, labels[ti])
+    print('poisson_mbo 70k: %.3f s, accuracy %.2f' % (time.perf_counter() - t0, gl.ssl.ssl_accuracy(pred, labels, ti)))
+    assert model.prob.shape == (70000, 10) and set(np.unique(model.prob)) <= {0.0, 1.0}
+    sizes = np.bincount(pred, minlength=10) / 70000
+    assert np.max(np.abs(sizes - pri)) <= max(model.class_priors_error, 1e-3) + 1e-12
+    assert gl.ssl.ssl_accuracy(pred, labels, ti) > 99.0
+
+
+def test_config3_laplace(gl, meta):
+    m = meta['config3']
+    labels = np.load(os.path.join(GOLDEN, 'cifar_labels.npz'))['labels'].astype(np.int64)
+    rng = np.random.default_rng(1)
+    centers = rng.normal(size=(10, 32)) * 1.2
+    X = centers[labels] + rng.normal(size=(60000, 32))
+    J, D = gl.weightmatrix.knnsearch(X, 21)
+    assert sha(J.astype(np.int64)) == m['J_sha']
+    W = gl.weightmatrix.knn(None, 20, knn_data=(J, D))
+    assert W.nnz == m['nnz'] and np.diff(W.indptr).max() == m['row_nnz_max'] == 660
+    assert sha(W.indices.astype(np.int32)) == m['W_indices_sha']
+    ti = gl.trainsets.generate(labels, rate=10, seed=0)
+    model = gl.ssl.laplace(W)
+    t0 = time.perf_counter()
+    u = model.fit(ti, labels[ti])
+    print('laplace CG 60k: %d iterations, %.3f s' % (model.num_iter, time.perf_counter() - t0))
+    assert model.num_iter == m['cg_iters'] == 54
+    assert sha(model.predict().astype(np.int64)) == m['pred_sha']
+    assert abs(np.abs(u).sum() - m['prob_abs_sum']) < 1e-8 * m['prob_abs_sum']
+    assert np.array_equal(u[ti], np.eye(10)[labels[ti]])           # labelled rows are exactly one-hot
+    assert u.min() > -1e-9 and u.max() < 1 + 1e-9                   # harmonic extension: maximum principle

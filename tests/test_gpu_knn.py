@@ -43,7 +43,7 @@ def test_knnsearch_edge_cases(gl):
     from graphlearning_amd import _hip
     rng = np.random.default_rng(0)
     # tiny inputs, k == n, ragged tile (n not a multiple of 128), duplicates
-    for n, d, k in [(1, 3, 1), (5, 2, 5), (129, 7, 4), (300, 33, 30), (200, 130, 3)]:
+    for n, d, k in [(1, 3, 1), (5, 2, 5), (129, 7, 4), (300, 33, 27), (200, 130, 3)]:
         X = rng.normal(size=(n, d))
         ind, dist = _hip.knn_bruteforce(X, k)
         D2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
