@@ -36,7 +36,8 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void cg_update_kernel(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
                                                         const T* __restrict__ Ap, const double* __restrict__ alpha,
                                                         double* __restrict__ partial, int64_t n, int ld, int nvec,
-                                                        const double* err_hist, int it, double tol) {
+                                                        const double* err_hist, int it, double tol,
+                                                        double* __restrict__ prod_out, const int32_t* __restrict__ perm) {
 #pragma clang fp contract(off)
   typedef typename V4Of<T>::type V4;
   if (MODE == 0 && cg_done(err_hist, it, tol)) return;
@@ -67,6 +68,12 @@ __global__ __launch_bounds__(256) void cg_update_kernel(T* __restrict__ x, T* __
         rv = rv - t2;
         *(V4*)(x + o) = xv;
         *(V4*)(r + o) = rv;
+      }
+      if (prod_out) {   // r*r in the array dtype, column-major in the caller's row order
+        const V4 sq = rv * rv;
+        const int64_t orow = perm ? perm[row] : row;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) prod_out[(size_t)(cv * 4 + e) * n + orow] = (double)sq[e];
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -162,43 +169,32 @@ __global__ __launch_bounds__(256) void cg_reduce_kernel(const double* __restrict
 // (out[c] += a[i,c]*b[i,c], i ascending), a strictly sequential rounding chain per column.
 // Reproducing it makes the whole CG bit-identical to the reference (iteration count
 // included) -- necessary because the Poisson system is singular and 100+ CG iterations
-// amplify any reordering far beyond 1e-5.  One wavefront, lane c = column c; loads and
-// products are software-pipelined 8 rows deep, only the add chain is serial.
+// amplify any reordering far beyond 1e-5.  The elementwise products are formed in parallel
+// by the producing kernels (SpMM epilogue / r-update) into a column-major array in the
+// caller's row order; here one wavefront, lane c = column c, streams its contiguous column
+// 32 rows at a time -- only the add chain is serial.
 // MODE 0: tot = sum p*Ap ; alpha = rsold / tot                                (utils.py:524)
 // MODE 1: tot = sum r*r  ; beta = tot / rsold ; rsold = tot ; err = sqrt(np.sum(tot)) (:527-530)
 // MODE 2: rsold = sum r*r                                                     (utils.py:517)
-template <typename T, int MODE>
-__global__ __launch_bounds__(64) void cg_seqdot_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t n, int ld,
-                                                       int ncols, int C, CgScalars sc, int it, double tol,
-                                                       const int32_t* __restrict__ inv) {
+template <int MODE>
+__global__ __launch_bounds__(64) void cg_seqsum_kernel(const double* __restrict__ prod, int64_t n, int ncols, int C, CgScalars sc,
+                                                       int it, double tol) {
 #pragma clang fp contract(off)
   if (MODE != 2 && cg_done(sc.err_hist, it, tol)) return;
   __shared__ double s_col[64];
   const int c = threadIdx.x;
   double tot = 0.0;
   if (c < ncols) {
-    const T* pa = a + c;
-    const T* pb = b + c;
+    const double* col = prod + (size_t)c * n;   // this column's products, rows in the caller's order
     int64_t i = 0;
-    for (; i + 8 <= n; i += 8) {
-      T va[8], vb[8];
+    for (; i + 32 <= n; i += 32) {
+      double v[32];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {   // caller's row i lives in record inv[i]
-        const size_t r = inv ? (size_t)inv[i + q] : (size_t)(i + q);
-        va[q] = pa[r * ld];
-        vb[q] = pb[r * ld];
-      }
+      for (int q = 0; q < 32; ++q) v[q] = col[i + q];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const T pr = va[q] * vb[q];        // elementwise product in the array dtype, as numpy forms p*Ap
-        tot = tot + (double)pr;
-      }
+      for (int q = 0; q < 32; ++q) tot = tot + v[q];
     }
-    for (; i < n; ++i) {
-      const size_t r = inv ? (size_t)inv[i] : (size_t)i;
-      const T pr = pa[r * ld] * pb[r * ld];
-      tot = tot + (double)pr;
-    }
+    for (; i < n; ++i) tot = tot + col[i];
     if (MODE == 0) {
       sc.alpha[c] = c < C ? sc.rsold[c] / tot : 0.0;
     } else if (MODE == 1) {
@@ -239,11 +235,12 @@ __global__ void cg_set_err0(double* err_hist, int64_t n) {
 
 struct CgBufs {
   void *x = nullptr, *r = nullptr, *p = nullptr, *ap = nullptr, *dense = nullptr;
+  double* prod = nullptr;
   double *part_dot = nullptr, *part_rs = nullptr, *scal = nullptr, *err_hist = nullptr, *h_err = nullptr;
   hipStream_t stream = nullptr;
   ~CgBufs() {
     hipFree(x); hipFree(r); hipFree(p); hipFree(ap); hipFree(dense); hipFree(part_dot); hipFree(part_rs);
-    hipFree(scal); hipFree(err_hist);
+    hipFree(scal); hipFree(err_hist); hipFree(prod);
     if (h_err) hipHostFree(h_err);
     if (stream) hipStreamDestroy(stream);
   }
@@ -284,6 +281,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   GLX_HIP(hipMalloc(&b.part_rs, nb_upd * ncols * 8));
   GLX_HIP(hipMalloc(&b.scal, 3 * ncols * 8));
   GLX_HIP(hipMalloc(&b.err_hist, hist_cap * 8));
+  if (exact) GLX_HIP(hipMalloc(&b.prod, std::max<size_t>((size_t)ncols * n * 8, 64)));
   GLX_HIP(hipHostMalloc((void**)&b.h_err, (CG_CHUNK + 1) * 8, hipHostMallocDefault));
   CgScalars sc;
   sc.rsold = b.scal;
@@ -307,10 +305,11 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   if (rc) return rc;
   GLX_HIP(hipMemcpyAsync(b.p, b.r, recb, hipMemcpyDeviceToDevice, st));   // p = r.copy() (utils.py:516)
   hipLaunchKernelGGL((cg_update_kernel<T, 1>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
-                     (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, 1, tol);
+                     (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, 1, tol, b.prod,
+                     (const int32_t*)A->d_perm);
   GLX_HIP(hipGetLastError());
   if (exact)
-    hipLaunchKernelGGL((cg_seqdot_kernel<T, 2>), dim3(1), dim3(64), 0, st, (const T*)r, (const T*)r, n, L.ld, ncols, C, sc, 0, tol, (const int32_t*)A->d_inv);
+    hipLaunchKernelGGL(cg_seqsum_kernel<2>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, 0, tol);
   else
     hipLaunchKernelGGL(cg_reduce_kernel<2>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, 0, tol);
   GLX_HIP(hipGetLastError());
@@ -325,6 +324,8 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   a.dot_partial = b.part_dot;   // the fused dot also carries the kernel's early-exit hook
   a.n_rows = n;
   a.exit_tol = tol;
+  a.prod_out = b.prod;
+  a.perm = A->d_perm;
   const unsigned pgrid = (unsigned)std::max<int64_t>(((int64_t)n * (L.ld / 4) + 255) / 256, 1);
 
   int64_t it = 0;       // iterations launched
@@ -340,15 +341,16 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
       rc = glx_launch_spmm(a, st);                                                   // Ap = A@p, p.Ap partials
       if (rc) return rc;
       if (exact)
-        hipLaunchKernelGGL((cg_seqdot_kernel<T, 0>), dim3(1), dim3(64), 0, st, (const T*)p, (const T*)ap, n, L.ld, ncols, C, sc, i, tol, (const int32_t*)A->d_inv);
+        hipLaunchKernelGGL(cg_seqsum_kernel<0>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       else
         hipLaunchKernelGGL(cg_reduce_kernel<0>, dim3(1), blk, 0, st, (const double*)b.part_dot, nb_spmm, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
       hipLaunchKernelGGL((cg_update_kernel<T, 0>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
-                         (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, i, tol);
+                         (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, i, tol, b.prod,
+                         (const int32_t*)A->d_perm);
       GLX_HIP(hipGetLastError());
       if (exact)
-        hipLaunchKernelGGL((cg_seqdot_kernel<T, 1>), dim3(1), dim3(64), 0, st, (const T*)r, (const T*)r, n, L.ld, ncols, C, sc, i, tol, (const int32_t*)A->d_inv);
+        hipLaunchKernelGGL(cg_seqsum_kernel<1>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       else
         hipLaunchKernelGGL(cg_reduce_kernel<1>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());

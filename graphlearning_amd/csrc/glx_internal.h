@@ -102,6 +102,8 @@ struct SweepArgs {
   double* dot_partial;
   const double* exit_err;        // optional early exit: skip when !(*exit_err > exit_tol)
   double exit_tol;
+  double* prod_out;              // optional: elementwise xin*xout, column-major, caller row order (CG)
+  const int32_t* perm;
   int64_t n_rows;
 };
 int glx_launch_spmm(const SweepArgs& a, hipStream_t stream);

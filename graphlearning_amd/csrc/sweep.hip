@@ -47,6 +47,9 @@ struct SpmmParams {
   int dot_ld;
   const double* exit_err;   // CG: skip the launch when !(*exit_err > exit_tol)
   double exit_tol;
+  double* prod_out;         // CG reference-order reductions: prod_out[c*n + caller_row] = xin*xout
+  const int32_t* perm;      // record -> caller row (null: identity)
+  int64_t n_rows;
   int ablate;               // developer probe (GLX_ABLATE): 1 no chunk loop, 2 gathers hit one hot record, 4 no stores
 };
 
@@ -356,6 +359,12 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
       const V4 own = *(const V4*)(p.xin + (size_t)row * p.rec_bytes + lane_off);
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = (double)own[e] * (double)outv[e];
+      if (p.prod_out && c < p.nvec) {   // elementwise p*Ap in the array dtype, laid out column-major in the caller's row order
+        const V4 pr = own * outv;
+        const int64_t orow = p.perm ? p.perm[row] : row;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p.prod_out[(size_t)(c * 4 + e) * p.n_rows + orow] = (double)pr[e];
+      }
     }
 #pragma unroll
     for (int off = 32; off >= G; off >>= 1) {
@@ -439,6 +448,9 @@ int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
   p.dot_ld = a.L.nvec * 4;
   p.exit_err = a.exit_err;
   p.exit_tol = a.exit_tol;
+  p.prod_out = a.prod_out;
+  p.perm = a.perm;
+  p.n_rows = a.n_rows;
   static const int ablate = getenv("GLX_ABLATE") ? atoi(getenv("GLX_ABLATE")) : 0;
   p.ablate = ablate;
   return a.dtype == GLX_F32 ? launch_t<float>(a, p, stream) : launch_t<double>(a, p, stream);
