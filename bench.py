@@ -126,8 +126,12 @@ def run_single(args):
     abytes = algorithmic_bytes(n, nnz, C, 8, 8)
     avg_launch_s = r64['dev_ms'] * 1e-3 / max(r64['launches'], 1)
     achieved = abytes / avg_launch_s / 1e9
+    traffic = None   # HBM-side bytes per launch from the PMC passes of this same command (profiles/), if recorded
+    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get('traffic_bytes_per_launch')
     roof = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
-                traffic=None, kernel='spmm_sell_kernel<double,4,true,false>', algorithmic_bytes_per_launch=abytes,
+                traffic=traffic, kernel='spmm_sell_kernel<double,4,true,false>', algorithmic_bytes_per_launch=abytes,
                 avg_launch_us=avg_launch_s * 1e6)
     cpu, parity, T_ref = cpu_baseline(W, train_ind, train_labels, r64['u'], T)
     a32 = algorithmic_bytes(n, nnz, C, 4, 4)

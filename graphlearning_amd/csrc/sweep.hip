@@ -15,6 +15,12 @@
 #ifndef GLX_PIPE_DEPTH
 #define GLX_PIPE_DEPTH 1
 #endif
+#ifndef GLX_NT_STREAM
+#define GLX_NT_STREAM 0   // measured: nontemporal operator loads 15.5 vs 13.4 us (the image is re-read from the Infinity Cache every sweep)
+#endif
+#ifndef GLX_NT_STORE
+#define GLX_NT_STORE 0
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -210,8 +216,14 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
       r.col = 0;
       r.val = 0;
       if (k < nchunks) {
+#if GLX_NT_STREAM
+        // the operator image is read exactly once per sweep: keep it from evicting vertex records
+        r.col = __builtin_nontemporal_load(p.col + base + (int64_t)k * 64 + lane);
+        r.val = __builtin_nontemporal_load(valp + base + (int64_t)k * 64 + lane);
+#else
         r.col = p.col[base + (int64_t)k * 64 + lane];
         r.val = valp[base + (int64_t)k * 64 + lane];
+#endif
       }
       return r;
     };
@@ -327,7 +339,13 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
         outv[3] = 0;
       }
     }
-    if (!(p.ablate & 4)) *(V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off) = outv;
+    if (!(p.ablate & 4)) {
+#if GLX_NT_STORE
+      __builtin_nontemporal_store(outv, (V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off));
+#else
+      *(V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off) = outv;
+#endif
+    }
   }
 
   if constexpr (HAS_W) {
