@@ -65,6 +65,8 @@ _SIGNATURES = {
     'glx_knn_bruteforce': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
     'glx_knn_bruteforce_range': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
     'glx_knn_stats': [_f64p],
+    'glx_knn_to_csr': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
+                       C.POINTER(_vp), _i64p, C.c_int],
 }
 _SPECIAL = {'glx_last_error': ([], C.c_char_p), 'glx_free': ([_vp], None)}
 
@@ -301,6 +303,36 @@ def knn_bruteforce(X, k, similarity='euclidean', device=0, query_range=None):
     check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, q0, q1, _ptr(ind), _ptr(dist), device),
           'glx_knn_bruteforce')
     return ind, dist
+
+
+_KERNEL_ID = {'given': 0, 'uniform': 1, 'gaussian': 2, 'symgaussian': 3, 'distance': 4, 'singular': 5}
+
+
+def knn_to_csr(knn_ind, knn_dist, k, kernel='gaussian', sym=1, weights=None, device=0):
+    """kNN data -> scipy CSR weight matrix, assembled on the GPU (glx_knn_to_csr)."""
+    from scipy import sparse
+    ind = np.ascontiguousarray(knn_ind, dtype=np.int64)
+    n, kk = ind.shape
+    dist = None if knn_dist is None else _dense(knn_dist, np.float64, (n, kk), 'knn_dist')
+    w = None if weights is None else _dense(weights, np.float64, (n, k), 'weights')
+    rp, ci, va = _vp(), _vp(), _vp()
+    nnz = C.c_int64(0)
+    lib = load()
+    check(lib.glx_knn_to_csr(_ptr(ind), _ptr(dist), _ptr(w), n, kk, int(k), _KERNEL_ID[kernel], int(sym), C.byref(rp),
+                             C.byref(ci), C.byref(va), C.byref(nnz), device), 'glx_knn_to_csr')
+    try:
+        m = nnz.value
+        indptr = np.ctypeslib.as_array(C.cast(rp, _i32p), shape=(n + 1,)).copy()
+        indices = np.ctypeslib.as_array(C.cast(ci, _i32p), shape=(max(m, 1),))[:m].copy()
+        data = np.ctypeslib.as_array(C.cast(va, _f64p), shape=(max(m, 1),))[:m].copy()
+    finally:
+        lib.glx_free(rp)
+        lib.glx_free(ci)
+        lib.glx_free(va)
+    W = sparse.csr_matrix((data, indices, indptr), shape=(n, n))
+    W.has_sorted_indices = True
+    W.has_canonical_format = True
+    return W
 
 
 def knn_stats():

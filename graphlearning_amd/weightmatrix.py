@@ -1,8 +1,10 @@
 """kNN weight-matrix construction (reference graphlearning/weightmatrix.py: `knn` :68-187,
 `knnsearch` :297-429, `load_knn_data` :431-467).  The search is an exact brute-force
-tiled pairwise-distance kernel on the GPU (glx_knn_bruteforce); the kernel weights and
-the sparse symmetrisation follow the reference operation by operation so the returned
-scipy CSR matrix has the identical structure."""
+tiled pairwise-distance kernel on the GPU (glx_knn_bruteforce); the kernel weights, the
+sparse assembly and the symmetrisation run on the GPU too (glx_knn_to_csr) and follow the
+reference operation by operation, so the returned scipy CSR matrix has the identical
+structure and values (the Gaussian kernels take numpy's exp on the host by default so that W
+stays bit-identical to the reference's; see `knn`)."""
 import os
 import sys
 import numpy as np
@@ -13,7 +15,8 @@ from . import _hip
 knn_dir = os.path.abspath(os.path.join(os.getcwd(), 'knn_data'))
 
 
-def knn(data, k, kernel='gaussian', eta=None, symmetrize=True, metric='raw', similarity='euclidean', knn_data=None):
+def knn(data, k, kernel='gaussian', eta=None, symmetrize=True, metric='raw', similarity='euclidean', knn_data=None,
+        device=0):
     """kNN weight matrix, same signature and result as reference weightmatrix.py:68-187.
     Returns a scipy CSR (n,n) float64 matrix: symmetric (unless symmetrize=False), zero
     diagonal, canonical format."""
@@ -25,47 +28,43 @@ def knn(data, k, kernel='gaussian', eta=None, symmetrize=True, metric='raw', sim
     else:
         knn_ind, knn_dist = knnsearch(data, k, similarity=similarity)
     n = knn_ind.shape[0]
-    k = np.minimum(knn_ind.shape[1], k)      # clamp to the columns available (reference :135)
-    knn_ind = knn_ind[:, :k]
-    knn_dist = knn_dist[:, :k]
-    if eta is None:
-        if kernel == 'uniform':
-            weights = np.ones_like(knn_dist)
-        elif kernel == 'gaussian':
-            D = knn_dist * knn_dist
-            eps = D[:, k - 1]
-            weights = np.exp(-4 * D / eps[:, None])
-        elif kernel == 'symgaussian':
-            eps = knn_dist[:, k - 1]
-            weights = np.exp(-4 * knn_dist * knn_dist / eps[:, None] / eps[knn_ind])
-        elif kernel == 'distance':
-            weights = knn_dist
-        elif kernel == 'singular':
-            weights = np.array(knn_dist, dtype=float)
-            weights[knn_dist == 0] = 1
-            weights = 1 / weights
-        else:
-            sys.exit('Invalid choice of kernel: ' + kernel)
+    k = int(np.minimum(knn_ind.shape[1], k))      # clamp to the columns available (reference :135)
+    if eta is None and kernel not in ['uniform', 'gaussian', 'symgaussian', 'distance', 'singular']:
+        sys.exit('Invalid choice of kernel: ' + kernel)
+    # symmetrisation rule (reference :177-183)
+    if not symmetrize:
+        sym = 0
+    elif kernel in ['distance', 'uniform', 'singular']:
+        sym = 2
+    elif kernel == 'symgaussian':
+        sym = 3
     else:
-        D = knn_dist * knn_dist
-        eps = D[:, k - 1]
-        # the reference divides (n,k) by (n,) here (weightmatrix.py:164), which cannot broadcast;
-        # the documented formula eta(|x_i-x_j|^2 / d_k(x_i)^2) is what is computed
-        weights = eta(D / eps[:, None])
-    knn_ind = knn_ind.flatten()
-    weights = weights.flatten()
-    self_ind = (np.ones((n, k)) * np.arange(n)[:, None]).flatten()
-    W = sparse.coo_matrix((weights, (self_ind, knn_ind)), shape=(n, n)).tocsr()   # duplicates are summed
-    if symmetrize:
-        if kernel in ['distance', 'uniform', 'singular']:
-            W = utils.sparse_max(W, W.transpose())
-        elif kernel == 'symgaussian':
-            W = W + W.T.multiply(W.T > W) - W.multiply(W.T > W)
-        else:
-            W = (W + W.transpose()) / 2
-    W.setdiag(0)
-    W.eliminate_zeros()
-    return W
+        sym = 1
+    if eta is None:
+        if kernel in ('gaussian', 'symgaussian') and os.environ.get('GLX_DEVICE_WEIGHTS') != '1':
+            # exp is the one operation on this path whose bits are library-defined.  The Poisson CG
+            # system is singular and amplifies a 1-ulp change of W into a different iteration count,
+            # so the Gaussian kernels evaluate numpy's exp on the host (elementwise over (n,k), the
+            # reference's own expressions, weightmatrix.py:144-150) to keep W bit-identical to the
+            # reference's; assembly and symmetrisation run on the device.  GLX_DEVICE_WEIGHTS=1
+            # moves the exp to the device as well (within an ulp).
+            d = np.asarray(knn_dist)[:, :k]
+            if kernel == 'gaussian':
+                D = d * d
+                eps = D[:, k - 1]
+                weights = np.exp(-4 * D / eps[:, None])
+            else:
+                eps = d[:, k - 1]
+                weights = np.exp(-4 * d * d / eps[:, None] / eps[np.asarray(knn_ind)[:, :k]])
+            return _hip.knn_to_csr(knn_ind, knn_dist, k, kernel='given', sym=sym, weights=weights, device=device)
+        return _hip.knn_to_csr(knn_ind, knn_dist, k, kernel=kernel, sym=sym, device=device)
+    # user kernel: a Python callable, evaluated on the host; assembly on the device.
+    # (the reference divides (n,k) by (n,) here (weightmatrix.py:164), which cannot broadcast;
+    # the documented formula eta(|x_i-x_j|^2 / d_k(x_i)^2) is what is computed)
+    D = knn_dist[:, :k] * knn_dist[:, :k]
+    eps = D[:, k - 1]
+    weights = eta(D / eps[:, None])
+    return _hip.knn_to_csr(knn_ind, knn_dist, k, kernel='given', sym=sym, weights=weights, device=device)
 
 
 def knnsearch(X, k, method=None, similarity='euclidean', dataset=None, metric='raw', device=0):

@@ -138,7 +138,18 @@ int glx_knn_bruteforce(const double* X, int64_t n, int d, int k, int similarity,
  * sharded across GPUs; every rank holds all of X).  ind_out/dist_out: (q_end - q_begin, k). */
 int glx_knn_bruteforce_range(const double* X, int64_t n, int d, int k, int64_t q_begin, int64_t q_end,
                              int64_t* ind_out, double* dist_out, int device);
-int glx_knn_stats(double stats[8]);   /* last call: [0] tile-kernel ms, [1] rerank ms, [2] fallback rows, [3] total ms */
+int glx_knn_stats(double stats[8]);
+
+/* weightmatrix.knn given knn data (graphlearning/weightmatrix.py:134-187) on the device: kernel
+ * weights, COO->CSR with duplicates summed, symmetrisation, zero diagonal, zeros dropped.
+ * ind (n,kk) int64 and dist (n,kk) fp64 host arrays of which the first k columns are used
+ * (k counts the self point).  kernel: 0 = `weights` (n,k) given (user eta), 1 uniform,
+ * 2 gaussian, 3 symgaussian, 4 distance, 5 singular.  sym: 0 none, 1 (W+W^T)/2, 2 element-wise
+ * max (utils.sparse_max), 3 the symgaussian rule.  Outputs are allocated by the library
+ * (release with glx_free): canonical CSR, int32 indices like scipy's. */
+int glx_knn_to_csr(const int64_t* ind, const double* dist, const double* weights, int64_t n, int kk, int k,
+                   int kernel, int sym, int32_t** rowptr_out, int32_t** col_out, double** val_out,
+                   int64_t* nnz_out, int device);   /* last call: [0] tile-kernel ms, [1] rerank ms, [2] fallback rows, [3] total ms */
 
 #ifdef __cplusplus
 }

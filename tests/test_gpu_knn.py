@@ -1,5 +1,6 @@
 """GPU parity of the exact kNN search and the kNN weight matrix against the reference's
 golden vectors (cKDTree results captured by tests/golden/make_golden.py)."""
+import os
 import numpy as np
 import pytest
 from conftest import csr_from, blobs
@@ -85,10 +86,49 @@ def test_knn_weightmatrix_nosym_and_injected(gl, golden):
     W = gl.weightmatrix.knn(g['X'], 10, symmetrize=False)
     Wg = csr_from(g, 'W_gaussian_nosym')
     assert np.array_equal(W.indices, Wg.indices) and np.max(np.abs(W.data - Wg.data)) <= 1e-12
-    # knn_data injection (reference weightmatrix.py:122-123) needs no GPU search and is bit-identical
-    W2 = gl.weightmatrix.knn(None, 10, knn_data=(g['knn_ind'], g['knn_dist']))
-    Wg = csr_from(g, 'W_gaussian')
-    assert np.array_equal(W2.indices, Wg.indices) and np.array_equal(W2.data, Wg.data)
+    # knn_data injection (reference weightmatrix.py:122-123): the golden kNN data through the
+    # device assembly reproduces the golden matrices -- structure exactly, values exactly where no
+    # exp is involved and within 2 ulp of numpy's exp otherwise
+    kd = (g['knn_ind'], g['knn_dist'])
+    for kernel in ['gaussian', 'uniform', 'symgaussian', 'distance', 'singular']:
+        W2 = gl.weightmatrix.knn(None, 10, kernel=kernel, knn_data=(kd[0], kd[1].copy()))
+        Wg = csr_from(g, 'W_' + kernel)
+        assert W2.format == 'csr' and W2.dtype == np.float64 and W2.indices.dtype == np.int32
+        assert np.array_equal(W2.indptr, Wg.indptr) and np.array_equal(W2.indices, Wg.indices), kernel
+        assert np.array_equal(W2.data, Wg.data), kernel            # bit-identical weight matrix
+    W3 = gl.weightmatrix.knn(None, 10, symmetrize=False, knn_data=kd)
+    assert np.array_equal(W3.data, csr_from(g, 'W_gaussian_nosym').data)
+    # exp on the device as well: within 2 ulp of numpy's
+    os.environ['GLX_DEVICE_WEIGHTS'] = '1'
+    try:
+        for kernel in ['gaussian', 'symgaussian']:
+            W4 = gl.weightmatrix.knn(None, 10, kernel=kernel, knn_data=kd)
+            Wg = csr_from(g, 'W_' + kernel)
+            assert np.array_equal(W4.indices, Wg.indices)
+            assert np.max(np.abs(W4.data - Wg.data) / Wg.data) <= 4.5e-16, kernel
+    finally:
+        del os.environ['GLX_DEVICE_WEIGHTS']
+    # k is clamped to the columns available (reference weightmatrix.py:135)
+    W5 = gl.weightmatrix.knn(None, 50, knn_data=kd)
+    assert np.array_equal(W5.indices, csr_from(g, 'W_gaussian').indices)
+    # user eta overrides the kernel (host callable, device assembly)
+    We = gl.weightmatrix.knn(None, 10, eta=lambda t: np.exp(-4 * t), knn_data=kd)
+    assert np.allclose(We.data, csr_from(g, 'W_gaussian').data, rtol=1e-14, atol=0)
+    assert np.array_equal(We.indices, csr_from(g, 'W_gaussian').indices)
+
+
+def test_knn_to_csr_duplicates_and_asymmetry(gl):
+    """Hand-made knn data: duplicate neighbours in a row (summed like COO->CSR), a one-directional
+    edge (carries w/2), self loops (removed), against the oracle's scipy assembly."""
+    from oracle import gl_oracle as orc
+    ind = np.array([[0, 1, 1], [1, 2, 0], [2, 2, 3], [3, 0, 1]], dtype=np.int64)
+    dist = np.array([[0.0, 0.5, 0.7], [0.0, 0.2, 0.9], [0.0, 0.0, 0.4], [0.0, 1.0, 1.5]])
+    for kernel in ['gaussian', 'uniform', 'distance', 'singular', 'symgaussian']:
+        for symmetrize in (True, False):
+            W = gl.weightmatrix.knn(None, 2, kernel=kernel, symmetrize=symmetrize, knn_data=(ind, dist.copy()))
+            Wo = orc.knn_weights(ind, dist.copy(), 2, kernel=kernel, symmetrize=symmetrize)
+            assert np.array_equal(W.indptr, Wo.indptr) and np.array_equal(W.indices, Wo.indices), (kernel, symmetrize)
+            assert np.allclose(W.data, Wo.data, rtol=1e-15, atol=0), (kernel, symmetrize)
 
 
 def test_blobs5000_knn_graph_golden(gl, golden):

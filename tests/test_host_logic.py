@@ -42,22 +42,8 @@ def test_helpers_match_golden(golden):
         gl.trainsets.generate(labels, rate='x')
 
 
-def test_knn_weights_from_injected_knn_data(golden):
+def test_knn_argument_errors_need_no_gpu(golden):
     g = golden('g1_twomoons.npz')
-    for kernel in ['gaussian', 'uniform', 'symgaussian', 'distance', 'singular']:
-        W = gl.weightmatrix.knn(None, 10, kernel=kernel, knn_data=(g['knn_ind'], g['knn_dist'].copy()))
-        Wg = csr_from(g, 'W_' + kernel)
-        assert W.format == 'csr' and W.dtype == np.float64 and W.indices.dtype == np.int32
-        assert np.array_equal(W.indptr, Wg.indptr) and np.array_equal(W.indices, Wg.indices)
-        assert np.array_equal(W.data, Wg.data), kernel
-    W = gl.weightmatrix.knn(None, 10, symmetrize=False, knn_data=(g['knn_ind'], g['knn_dist']))
-    assert np.array_equal(W.data, csr_from(g, 'W_gaussian_nosym').data)
-    # k is clamped to the columns available (reference weightmatrix.py:135)
-    W5 = gl.weightmatrix.knn(None, 50, knn_data=(g['knn_ind'], g['knn_dist']))
-    assert np.array_equal(W5.data, csr_from(g, 'W_gaussian').data)
-    # user eta overrides the kernel
-    We = gl.weightmatrix.knn(None, 10, eta=lambda t: np.exp(-4 * t), knn_data=(g['knn_ind'], g['knn_dist']))
-    assert np.allclose(We.data, csr_from(g, 'W_gaussian').data, rtol=1e-14, atol=0)
     with pytest.raises(SystemExit):
         gl.weightmatrix.knn(None, 10, kernel='nope', knn_data=(g['knn_ind'], g['knn_dist']))
     with pytest.raises(SystemExit):
@@ -119,6 +105,8 @@ def test_no_cpu_fallback_without_gpu():
         gl.ssl.poisson(W, solver='gradient_descent').fit(np.array([0, 5]), np.array([0, 1]))
     with pytest.raises(_hip.GlxError):
         gl.weightmatrix.knnsearch(np.random.rand(10, 3), 3)
+    with pytest.raises(_hip.GlxError):
+        gl.weightmatrix.knn(None, 2, knn_data=(np.zeros((4, 3), dtype=np.int64), np.zeros((4, 3))))
 
 
 def test_cabi_exports_every_declared_symbol():
