@@ -211,3 +211,76 @@ def test_errors(gl):
     G.close()
     with pytest.raises(SystemExit):
         gl.ssl.poisson(A, solver='nope')
+
+
+def test_spmm_shapes_and_edge_cases(gl):
+    """Ragged and degenerate operators: empty rows, empty matrix, rectangular (halo columns),
+    wide label matrices (G = 8 / 16 / 32 lanes per row), fp32 -- all bit-identical to scipy."""
+    from graphlearning_amd import _hip
+    rng = np.random.default_rng(11)
+    # rows without entries and an all-zero operator
+    A = sparse.random(300, 300, density=0.01, random_state=7, format='csr')
+    assert (np.diff(A.indptr) == 0).sum() > 5
+    u = rng.normal(size=(300, 10))
+    G = _hip.DeviceGraph(A)
+    assert np.array_equal(G.spmm_bias(u), A * u)
+    G.close()
+    Z = sparse.csr_matrix((50, 50))
+    G = _hip.DeviceGraph(Z)
+    assert np.array_equal(G.spmm_bias(u[:50], u[:50]), u[:50])     # Db + 0
+    G.close()
+    # rectangular: 200 rows, 500 columns
+    R = sparse.random(200, 500, density=0.03, random_state=8, format='csr')
+    x = rng.normal(size=(500, 7))
+    G = _hip.DeviceGraph(R)
+    assert np.array_equal(G.spmm_bias(x), R * x)
+    G.close()
+    # wide operands
+    B = sparse.random(5000, 5000, density=0.002, random_state=9, format='csr') + sparse.identity(5000, format='csr')
+    for C in (1, 4, 13, 28, 29, 60, 100):
+        x = rng.normal(size=(5000, C))
+        G = _hip.DeviceGraph(B)
+        assert np.array_equal(G.spmm_bias(x), B * x), C
+        G.close()
+        x32 = x.astype(np.float32)
+        G = _hip.DeviceGraph(B, dtype=np.float32)
+        assert np.array_equal(G.spmm_bias(x32), B.astype(np.float32) * x32), C
+        G.close()
+    # a 1-D operand is a single column
+    G = _hip.DeviceGraph(B)
+    v = rng.normal(size=5000)
+    assert np.array_equal(G.spmm_bias(v), B * v)
+    G.close()
+    with pytest.raises(_hip.GlxError):
+        _hip.DeviceGraph(B).spmm_bias(rng.normal(size=(5000, 300)))      # beyond 256 columns
+
+
+def test_poisson_sweep_many_classes_and_long_rows(gl, orc):
+    """C = 30 classes (G = 8 lanes/row path with the stop column) and hub rows (S = 4 / 16 split
+    rows) through the full Poisson sweep, bit-identical to the oracle."""
+    rng = np.random.default_rng(5)
+    n, C = 6000, 30
+    lab = rng.integers(0, C, size=n)
+    X = rng.normal(size=(C, 12))[lab] * 2.0 + rng.normal(size=(n, 12))
+    W = gl.weightmatrix.knn(X, 12)
+    W = W.tolil()
+    hub = rng.choice(n, size=400, replace=False)          # make vertex 7 a hub with ~400 neighbours
+    for j in hub:
+        if j != 7:
+            W[7, j] = 0.3
+            W[j, 7] = 0.3
+    W = sparse.csr_matrix(W)
+    assert np.diff(W.indptr).max() > 300
+    ti = orc.trainsets_generate(lab, rate=2, seed=3)
+    u_ref, T_ref = orc.poisson_gd(W, ti, lab[ti], return_T=True)
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    u = m.fit(ti, lab[ti])
+    assert m.num_iter == T_ref
+    assert np.array_equal(u, u_ref)
+    assert np.array_equal(m.predict(), orc.predict(u_ref))
+    # C = 10 on the same hub graph exercises S = 16 in the G = 4 plan
+    lab10 = lab % 10
+    ti = orc.trainsets_generate(lab10, rate=2, seed=4)
+    u_ref, T_ref = orc.poisson_gd(W, ti, lab10[ti], return_T=True)
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    assert np.array_equal(m.fit(ti, lab10[ti]), u_ref) and m.num_iter == T_ref
