@@ -8,6 +8,7 @@
 #include "glx_internal.h"
 #include <algorithm>
 #include <vector>
+#include <utility>
 
 static const int ROW_CAP = 1024;   // forward + reverse entries one wavefront can merge in LDS
 
@@ -77,19 +78,18 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restri
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned long long* key = (unsigned long long*)sm + (size_t)wave * ROW_CAP;                 // (col << 32) | (tag << 24) | seq... packed below
+  unsigned long long* key = (unsigned long long*)sm + (size_t)wave * ROW_CAP;                 // (col << 32) | (tag << 16) | seq
   double* val = (double*)(sm + (size_t)4 * ROW_CAP * 8) + (size_t)wave * ROW_CAP;
   const int64_t i = (int64_t)blockIdx.x * 4 + wave;
   if (i >= n) return;
   const int rc = sym == SYM_NONE ? 0 : (int)(roff[i + 1] - roff[i]);
   const int M = k + rc;
-  if (M > ROW_CAP) {
-    if (lane == 0) *overflow = 1;
+  if (M > ROW_CAP) {   // hub vertex: merged on the host (rare), see glx_knn_to_csr
+    if (lane == 0 && !mode) { rowcnt[i] = -1; *overflow = 1; }
     return;
   }
   int P = 64;
   while (P < M) P <<= 1;
-  // key = col (31 bits) | tag (1 bit) | seq (31 bits... rows hold <= 1024 entries, 16 bits suffice)
   for (int e = lane; e < P; e += 64) {
     unsigned long long kx = ~0ull;
     double v = 0.0;
@@ -165,6 +165,20 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restri
   }
   if (!mode && lane == 0) rowcnt[i] = kept_before;
 }
+
+// the per-column combination rule, shared by the device kernel (above, inline) and the host path
+static double combine_host(double a, double b, int sym) {
+  if (sym == SYM_NONE) return a;
+  if (sym == SYM_MEAN) return (a + b) / 2.0;
+  if (sym == SYM_MAX) return (b > a) ? b : (((a + b) > 0.0) ? a : 0.0);
+  if (b > a) { const double s = a + b; return s - a; }
+  return a;
+}
+
+struct HostRow {
+  std::vector<int32_t> col;
+  std::vector<double> val;
+};
 
 struct AsmBufs {
   int64_t *ind = nullptr, *roff = nullptr, *rowptr = nullptr;
@@ -243,7 +257,43 @@ extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const doub
   GLX_HIP(hipMemcpyAsync(rowcnt.data(), b.rowcnt, n * 4, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipMemcpyAsync(flags, b.flag, 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
-  GLX_CHECK(!flags[1], GLX_EUNSUPPORTED, "glx_knn_to_csr: a vertex has more than %d forward+reverse neighbours", ROW_CAP);
+  // hub vertices (more than ROW_CAP forward+reverse neighbours; high-dimensional data has them):
+  // merged here on the host with the same rule, written into the CSR after the device pass
+  std::vector<std::pair<int64_t, HostRow>> hubs;
+  if (flags[1]) {
+    std::vector<double> wrow(k);
+    std::vector<int> rs;
+    std::vector<double> rwv;
+    for (int64_t i = 0; i < n; ++i) {
+      if (rowcnt[i] >= 0) continue;
+      const int rc = (int)(roff[i + 1] - roff[i]);
+      rs.resize(rc);
+      rwv.resize(rc);
+      GLX_HIP(hipMemcpy(wrow.data(), b.w + i * k, (size_t)k * 8, hipMemcpyDeviceToHost));
+      GLX_HIP(hipMemcpy(rs.data(), b.rsrc + roff[i], (size_t)rc * 4, hipMemcpyDeviceToHost));
+      GLX_HIP(hipMemcpy(rwv.data(), b.rw + roff[i], (size_t)rc * 8, hipMemcpyDeviceToHost));
+      struct Ent { int32_t col; int tag; int seq; double v; };
+      std::vector<Ent> ents;
+      ents.reserve(k + rc);
+      for (int t = 0; t < k; ++t) ents.push_back({(int32_t)ind[i * kk + t], 0, t, wrow[t]});
+      for (int q = 0; q < rc; ++q) ents.push_back({rs[q], 1, q, rwv[q]});
+      std::sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) {
+        return x.col != y.col ? x.col < y.col : (x.tag != y.tag ? x.tag < y.tag : x.seq < y.seq);
+      });
+      HostRow hr;
+      for (size_t e = 0; e < ents.size();) {
+        const int32_t c = ents[e].col;
+        double a = 0.0, bb = 0.0;
+        for (; e < ents.size() && ents[e].col == c; ++e) {
+          if (ents[e].tag) bb = bb + ents[e].v; else a = a + ents[e].v;
+        }
+        const double v = combine_host(a, bb, sym);
+        if (c != (int32_t)i && v != 0.0) { hr.col.push_back(c); hr.val.push_back(v); }
+      }
+      rowcnt[i] = (int)hr.col.size();
+      hubs.emplace_back(i, std::move(hr));
+    }
+  }
   std::vector<int64_t> rp(n + 1, 0);
   for (int64_t i = 0; i < n; ++i) rp[i + 1] = rp[i] + rowcnt[i];
   const int64_t nnz = rp[n];
@@ -271,6 +321,10 @@ extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const doub
     free(h_rp); free(h_col); free(h_val);
     glx_set_error("glx_knn_to_csr: download failed");
     return GLX_EHIP;
+  }
+  for (auto& hb : hubs) {
+    std::copy(hb.second.col.begin(), hb.second.col.end(), h_col + rp[hb.first]);
+    std::copy(hb.second.val.begin(), hb.second.val.end(), h_val + rp[hb.first]);
   }
   *rowptr_out = h_rp;
   *col_out = h_col;

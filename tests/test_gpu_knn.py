@@ -131,6 +131,28 @@ def test_knn_to_csr_duplicates_and_asymmetry(gl):
             assert np.allclose(W.data, Wo.data, rtol=1e-15, atol=0), (kernel, symmetrize)
 
 
+def test_knn_to_csr_hub_vertex(gl):
+    """A vertex that is everyone's neighbour (3000 reverse neighbours > the 1024 one wavefront merges
+    in LDS) takes the host merge path; result identical to the oracle's scipy assembly."""
+    from oracle import gl_oracle as orc
+    rng = np.random.default_rng(2)
+    n, k = 3000, 4
+    ind = np.empty((n, k), dtype=np.int64)
+    ind[:, 0] = np.arange(n)
+    ind[:, 1] = 0                                   # the hub
+    ind[:, 2] = (np.arange(n) + 1) % n
+    ind[:, 3] = (np.arange(n) + 7) % n
+    ind[0, 1] = 5
+    dist = np.sort(rng.random((n, k)), axis=1)
+    dist[:, 0] = 0
+    for kernel, symmetrize in [('gaussian', True), ('distance', True), ('uniform', False)]:
+        W = gl.weightmatrix.knn(None, 3, kernel=kernel, symmetrize=symmetrize, knn_data=(ind, dist.copy()))
+        Wo = orc.knn_weights(ind, dist.copy(), 3, kernel=kernel, symmetrize=symmetrize)
+        assert np.array_equal(W.indptr, Wo.indptr) and np.array_equal(W.indices, Wo.indices), kernel
+        assert np.array_equal(W.data, Wo.data), kernel
+    assert np.diff(W.indptr).max() <= 4 and np.diff(Wo.indptr).max() <= 4    # unsymmetrised: k entries per row
+
+
 def test_blobs5000_knn_graph_golden(gl, golden):
     g = golden('g3_blobs5000.npz')
     ind, dist = gl.weightmatrix.knnsearch(g['X'], 11)
