@@ -13,12 +13,16 @@ Precision: `use_cuda=False` (default) computes in fp64 -- iterates are bit-ident
 reference CPU path for the sweeps, within rounding for CG; `use_cuda=True` computes in
 fp32 like the reference's torch.sparse.addmm branch and returns float32.
 """
+import os
 import sys
 import numpy as np
 from scipy import sparse
 from . import graph as graph_mod
 from . import utils
 from . import _hip
+
+
+results_dir = os.path.join(os.getcwd(), 'results')
 
 
 class ssl:
@@ -104,6 +108,55 @@ class ssl:
         if self.class_priors is not None:
             self.volume_label_projection()
         return self.prob
+
+    def ssl_trials(self, trainsets, labels, num_cores=1, tag='', save_results=True, overwrite=False, num_trials=-1):
+        """Run the learner on a list of training sets and record `Number of labels,Accuracy[,...]`
+        rows to results/<tag><accuracy filename> (reference ssl.py:292-396, same file format,
+        same abort-if-exists rule).  Trials run one after another on the GPU with the operator
+        resident on the device; `num_cores` is accepted for signature compatibility."""
+        if num_trials > 0:
+            trainsets = trainsets[:num_trials]
+        print('\nModel: ' + self.name)
+        outfile = None
+        with_priors = self.class_priors is not None
+        header = 'Number of labels,Accuracy,Accuracy with class priors,Class priors error' if with_priors else 'Number of labels,Accuracy'
+        if save_results:
+            if not os.path.exists(results_dir):
+                os.makedirs(results_dir)
+            outfile = os.path.join(results_dir, tag + self.get_accuracy_filename())
+            if (not overwrite) and os.path.exists(outfile):
+                print('Aborting: SSL trial (' + self.get_accuracy_filename() + ') already completed , and overwrite is False.')
+                return
+            with open(outfile, 'w') as f:
+                f.write(header + '\n')
+            print('Results File: ' + outfile)
+        print('\n' + header)
+        labels = np.asarray(labels)
+        for train_ind in trainsets:
+            train_ind = np.asarray(train_ind)
+            pred = self.fit_predict(train_ind, labels[train_ind])
+            accuracy = ssl_accuracy(pred, labels, train_ind)
+            if with_priors:
+                plain = ssl_accuracy(self.predict(ignore_class_priors=True), labels, train_ind)
+                row = '%d,%.2f,%.2f,%.5f' % (len(train_ind), plain, accuracy, self.class_priors_error)
+            else:
+                row = '%d' % len(train_ind) + ',%.2f' % accuracy
+            print(row)
+            if save_results:
+                with open(outfile, 'a+') as f:
+                    f.write(row + '\n')
+
+    def trials_statistics(self, tag=''):
+        """Mean / standard deviation of the accuracies recorded by ssl_trials, per label rate
+        (reference ssl.py:398-436)."""
+        X = np.loadtxt(os.path.join(results_dir, tag + self.get_accuracy_filename()), delimiter=',', skiprows=1, ndmin=2)
+        num_train = np.unique(X[:, 0])
+        acc_mean, acc_stddev = [], []
+        for m in num_train:
+            Y = X[X[:, 0] == m, 1:]
+            acc_mean += [np.mean(Y, axis=0)]
+            acc_stddev += [np.std(Y, axis=0)]
+        return num_train, np.array(acc_mean), np.array(acc_stddev), int(len(X[:, 0]) / len(num_train))
 
     def _fit(self, train_ind, train_labels, all_labels=None):
         raise NotImplementedError('Must override _fit')

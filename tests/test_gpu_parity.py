@@ -284,3 +284,28 @@ def test_poisson_sweep_many_classes_and_long_rows(gl, orc):
     u_ref, T_ref = orc.poisson_gd(W, ti, lab10[ti], return_T=True)
     m = gl.ssl.poisson(W, solver='gradient_descent')
     assert np.array_equal(m.fit(ti, lab10[ti]), u_ref) and m.num_iter == T_ref
+
+
+def test_ssl_trials_csv(gl, golden, tmp_path, monkeypatch):
+    """ssl_trials writes the reference's CSV format; accuracies equal the oracle's per trial."""
+    from oracle import gl_oracle as orc
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    labels = g['labels']
+    monkeypatch.setattr(gl.ssl, 'results_dir', str(tmp_path / 'results'))
+    sets = orc.trainsets_generate(labels, rate=np.array([[1], [2]]), num_trials=2, seed=5)
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    m.ssl_trials(sets, labels, tag='t_')
+    lines = open(tmp_path / 'results' / 't__poisson_accuracy.csv').read().strip().split('\n')
+    assert lines[0] == 'Number of labels,Accuracy' and len(lines) == 5
+    for ts, line in zip(sets, lines[1:]):
+        acc = orc.ssl_accuracy(orc.predict(orc.poisson_gd(W, ts, labels[ts])), labels, ts)
+        assert line == '%d' % len(ts) + ',%.2f' % acc
+    num_train, mean, std, nt = m.trials_statistics(tag='t_')
+    assert list(num_train) == [10.0, 20.0] and nt == 2 and mean.shape == (2, 1)
+    m.ssl_trials(sets, labels, tag='t_')          # exists -> aborts without touching the file
+    assert len(open(tmp_path / 'results' / 't__poisson_accuracy.csv').read().strip().split('\n')) == 5
+    mp = gl.ssl.poisson(W, class_priors=g['class_priors'], solver='gradient_descent')
+    mp.ssl_trials(sets[:1], labels, tag='p_')
+    hdr = open(tmp_path / 'results' / 'p__poisson_classpriors_accuracy.csv').readline().strip()
+    assert hdr == 'Number of labels,Accuracy,Accuracy with class priors,Class priors error'
