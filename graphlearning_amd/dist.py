@@ -94,6 +94,7 @@ class RankPlan:
 
 class HipOps:
     """Rank-local sweep through libglx on torch CUDA tensors (device-pointer C-ABI)."""
+    supports_graph = True
 
     def __init__(self, plan, C, device, dtype=np.float64):
         import torch
@@ -204,11 +205,13 @@ class DistSweep:
         self.in_splits = list(plan.send_counts)
         self.out_splits = list(plan.recv_counts)
         self.exchanges = 0
+        import os
+        self._force_coll = os.environ.get('GLX_DIST_FORCE_COLLECTIVES') == '1'   # test hook: collectives at world 1
 
     def exchange(self, x):
         """Boundary records of x[0:n_own] -> the peers' halo regions x[n_own:]."""
         p = self.plan
-        if p.world == 1:
+        if p.world == 1 and not self._force_coll:
             return
         send = self.ops.index_rows(x, self.send_idx)
         recv = x[p.n_own:]
@@ -221,28 +224,73 @@ class DistSweep:
         ops, p = self.ops, self.plan
         ops.set_bias(ops.pack(Db_own, None, p.n_own))
         ops.set_stop_vectors(deg_own, vinf_own)
-        self.w0_own = np.ascontiguousarray(w0_own, dtype=np.float64)
+        self.init_rec = ops.pack(None, np.ascontiguousarray(w0_own, dtype=np.float64), p.n_own)   # u = 0 (ssl.py:645), w = w0
         self.xa = ops.new_state(self.n_loc)
         self.xb = ops.new_state(self.n_loc)
+        self.cur = 0
+        self._graph = None
+        self._graph_err = None
+        self._graph_ok = bool(getattr(ops, 'supports_graph', False))
 
     def reset(self):
-        """u = 0 (ssl.py:645), w = w0 on the owned rows; halo filled by one exchange."""
-        p, ops = self.plan, self.ops
-        init = ops.pack(None, self.w0_own, p.n_own)
+        """Owned rows <- initial records; halo filled by one exchange.  Allocation-free apart from
+        the exchange's send buffer, so it can be stream-captured."""
+        p = self.plan
         self.xa.zero_()
-        self.xa[:p.n_own].copy_(init)
+        self.xa[:p.n_own].copy_(self.init_rec)
         self.exchange(self.xa)
         self.cur = 0
 
+    def _head(self, nsweeps, min_iter):
+        """The first `nsweeps` sweeps, which the stop test cannot cut short; returns the device
+        scalar holding max|v - vinf| after the last one when the stop test will need it."""
+        bufs = [self.xa, self.xb]
+        e = None
+        for T in range(nsweeps):
+            want = (T + 1) >= min_iter
+            e = self.ops.sweep(bufs[self.cur], bufs[self.cur ^ 1], want)
+            self.exchange(bufs[self.cur ^ 1])
+            if want and (self.plan.world > 1 or self._force_coll):
+                self.dist.all_reduce(e, op=self.dist.ReduceOp.MAX, group=self.group)
+            self.cur ^= 1
+        return e
+
     def run(self, min_iter, max_iter, err0=None):
         """All sweeps; returns T.  Stop test (ssl.py:667): T = first T >= min_iter with
-        max over ALL vertices |deg w_T - vinf| <= 1/n_global."""
+        max over ALL vertices |deg w_T - vinf| <= 1/n_global.  The min_iter sweeps that always
+        run are captured once into a device graph (kernels, record gathers and RCCL exchanges)
+        and replayed; if capture is not possible the same sequence runs eagerly."""
         torch, dist, ops, p = self.torch, self.dist, self.ops, self.plan
         thresh = 1.0 / p.n_global
-        self.reset()
+        head = min(min_iter, max_iter)
+        e = None
+        if self._graph_ok and head > 0:
+            if self._graph is None:
+                try:
+                    self.reset()                                   # eager warm-up: communicator, allocator
+                    self._head(1, min_iter + 2)
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self.reset()
+                        self._graph_err = self._head(head, min_iter)
+                    self._graph = g
+                except Exception as exc:                           # e.g. a collective that cannot be captured
+                    self._graph_ok = False
+                    self._graph = None
+                    torch.cuda.synchronize()
+                    import warnings
+                    warnings.warn('DistSweep: device-graph capture unavailable (%s); running eagerly' % (exc,))
+            if self._graph is not None:
+                self._graph.replay()
+                self.cur = head & 1
+                e = self._graph_err
+        if self._graph is None or head == 0:
+            self.reset()
+            e = self._head(head, min_iter)
         bufs = [self.xa, self.xb]
-        T = 0
-        err_T = err0          # error of v_T, known for T >= min_iter (err0: error of v_0 when min_iter == 0)
+        T = head
+        err_T = err0 if head == 0 else (float(e.item()) if e is not None else None)
         while T < max_iter:
             if T >= min_iter:
                 if err_T is None:

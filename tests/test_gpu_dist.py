@@ -49,12 +49,15 @@ def test_hipops_rank_local_sweeps_match_scipy(golden):
             ops.close()
 
 
-def test_distributed_bench_entry_one_rank(tmp_path):
-    env = dict(os.environ, GLX_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+@pytest.mark.parametrize('force_coll', ['0', '1'])
+def test_distributed_bench_entry_one_rank(tmp_path, force_coll):
+    # force_coll=1: the all_to_all / all_reduce calls are issued (and graph-captured) even with one rank
+    env = dict(os.environ, GLX_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', GLX_DIST_FORCE_COLLECTIVES=force_coll)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
            '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'capture unavailable' not in r.stderr, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     j = json.loads(line)
     assert j['n_gpus'] == 1 and j['value'] > 0 and j['config']['sweeps_per_step'] == 50
