@@ -7,6 +7,11 @@
 #include <vector>
 #include "../../include/glx.h"
 
+// wavefronts (= slices) per workgroup of the SpMM kernel
+#ifndef GLX_WPB
+#define GLX_WPB 4
+#endif
+
 void glx_set_error(const char* fmt, ...);
 
 #define GLX_HIP(call)                                                                     \

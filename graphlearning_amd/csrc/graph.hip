@@ -275,9 +275,9 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
       ghdr[x].push_back(h);
     }
   }
-  int64_t bpx = 0;   // blocks (4 slices) per XCD range
-  for (int x = 0; x < NX; ++x) bpx = std::max<int64_t>(bpx, ((int64_t)ghdr[x].size() + 3) / 4);
-  const int64_t spx = bpx * 4;
+  int64_t bpx = 0;   // blocks (GLX_WPB slices) per XCD range
+  for (int x = 0; x < NX; ++x) bpx = std::max<int64_t>(bpx, ((int64_t)ghdr[x].size() + GLX_WPB - 1) / GLX_WPB);
+  const int64_t spx = bpx * GLX_WPB;
   const int64_t nslices = spx * NX;
   std::vector<SliceHdr> hdr(nslices);
   std::vector<int32_t> slot_row(nslices * R, -1), slot_len(nslices * R, 0);

@@ -168,13 +168,13 @@ __device__ __forceinline__ void add_product(typename VecOf<T>::type& acc, double
 // chain of len/4 dependent memory round trips while the rounding sequence stays that of a
 // sequential row sum.
 template <typename T, int G, bool HAS_W, bool HAS_DOT>
-__global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
+__global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParams p) {
 #pragma clang fp contract(off)
   typedef typename VecOf<T>::type V4;
   constexpr int R = 64 / G;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  __shared__ double s_red[HAS_DOT ? 4 * 64 * 4 : 4];
+  __shared__ double s_red[HAS_DOT ? GLX_WPB * 64 * 4 : 4];
 
   if constexpr (HAS_W) {
     if (p.err_prev) {   // stop test of ssl.py:667, decided identically by every wavefront
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
     if (p.exit_err && !(*p.exit_err > p.exit_tol)) return;
   }
   const int64_t vb = xcd_remap(blockIdx.x, p.nblocks);
-  const int64_t slice = vb * 4 + wave;
+  const int64_t slice = vb * GLX_WPB + wave;
   const int g = lane / G, c = lane % G;
   const bool lane_on = c < p.nlanes;
   const bool is_w = HAS_W && (c == p.nvec);
@@ -211,20 +211,13 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
     // Software pipeline: index/value chunks travel 3 chunks ahead of their use, the
     // neighbour gathers of chunk k+1 are in flight while chunk k is being added up.
     struct CV { int col; T val; };
+    // unconditional (index clamped to the slice's last chunk): a conditional load would make the
+    // compiler wait for it at the branch join, i.e. before this chunk's gathers are even issued
     auto load_cv = [&](int k) -> CV {
       CV r;
-      r.col = 0;
-      r.val = 0;
-      if (k < nchunks) {
-#if GLX_NT_STREAM
-        // the operator image is read exactly once per sweep: keep it from evicting vertex records
-        r.col = __builtin_nontemporal_load(p.col + base + (int64_t)k * 64 + lane);
-        r.val = __builtin_nontemporal_load(valp + base + (int64_t)k * 64 + lane);
-#else
-        r.col = p.col[base + (int64_t)k * 64 + lane];
-        r.val = valp[base + (int64_t)k * 64 + lane];
-#endif
-      }
+      const int kc = k < nchunks ? k : nchunks - 1;
+      r.col = p.col[base + (int64_t)kc * 64 + lane];
+      r.val = valp[base + (int64_t)kc * 64 + lane];
       return r;
     };
     auto issue = [&](const CV& cv, int k, V4 (&x)[4], T (&v)[4]) {
@@ -274,10 +267,10 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
 #if GLX_PIPE_DEPTH >= 2
     V4 xA[4], xB[4];
     T vA[4], vB[4];
-    CV q0 = load_cv(0), q1 = load_cv(1), q2 = load_cv(2), q3;
-    q3.col = 0;
-    q3.val = 0;
-    if (nchunks > 0) issue(q0, 0, xA, vA);
+    CV q0, q1, q2, q3;
+    q0.col = q1.col = q2.col = q3.col = 0;
+    q0.val = q1.val = q2.val = q3.val = 0;
+    if (nchunks > 0) { q0 = load_cv(0); q1 = load_cv(1); q2 = load_cv(2); issue(q0, 0, xA, vA); }
     int k = 0;
     while (k < nchunks) {
       q3 = load_cv(k + 3); issue(q1, k + 1, xB, vB); consume(k, xA, vA); if (++k >= nchunks) break;
@@ -288,7 +281,10 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
 #else
     V4 xA[4];
     T vA[4];
-    CV qn = load_cv(0);
+    CV qn;
+    qn.col = 0;
+    qn.val = 0;
+    if (nchunks > 0) qn = load_cv(0);
     for (int k = 0; k < nchunks; ++k) {
       const CV qc = qn;
       qn = load_cv(k + 1);      // next chunk's indices/values travel while this chunk's gathers do
@@ -358,12 +354,12 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
         if (e != e) e = __longlong_as_double(0x7ff0000000000000ll);   // NaN never satisfies the stop test
       }
       unsigned long long m = wave_max_u64((unsigned long long)__double_as_longlong(e));
-      __shared__ unsigned long long s_err[4];
+      __shared__ unsigned long long s_err[GLX_WPB];
       if (lane == 0) s_err[wave] = m;
       __syncthreads();
       if (threadIdx.x == 0) {
         unsigned long long mm = s_err[0];
-        for (int w = 1; w < 4; ++w) mm = s_err[w] > mm ? s_err[w] : mm;
+        for (int w = 1; w < GLX_WPB; ++w) mm = s_err[w] > mm ? s_err[w] : mm;
         if (mm != 0) atomicMax(&p.err_next[blockIdx.x & 63], mm);
       }
     }
@@ -398,20 +394,18 @@ __global__ __launch_bounds__(256) void spmm_sell_kernel(const SpmmParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         double s = s_red[(0 * 64 + threadIdx.x) * 4 + e];
-        s += s_red[(1 * 64 + threadIdx.x) * 4 + e];
-        s += s_red[(2 * 64 + threadIdx.x) * 4 + e];
-        s += s_red[(3 * 64 + threadIdx.x) * 4 + e];
+        for (int w = 1; w < GLX_WPB; ++w) s += s_red[(w * 64 + threadIdx.x) * 4 + e];
         p.dot_partial[(size_t)vb * p.dot_ld + threadIdx.x * 4 + e] = s;
       }
     }
   }
 }
 
-int64_t glx_spmm_blocks(const SellPlan* plan) { return (plan->nslices + 3) / 4; }
+int64_t glx_spmm_blocks(const SellPlan* plan) { return (plan->nslices + GLX_WPB - 1) / GLX_WPB; }
 
 template <typename T, int G>
 static int launch_g(const SweepArgs& a, const SpmmParams& p, hipStream_t stream) {
-  const dim3 grid((unsigned)p.nblocks), block(256);
+  const dim3 grid((unsigned)p.nblocks), block(64 * GLX_WPB);
   if (a.dot_partial) {
     hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, true>), grid, block, 0, stream, p);
   } else if (a.has_w) {
