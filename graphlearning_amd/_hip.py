@@ -61,6 +61,7 @@ _SIGNATURES = {
     'glx_pack_records_dev': [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp],
     'glx_unpack_records_dev': [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp],
     'glx_cg_multi': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), _f64p],
+    'glx_cg_solve': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_argmax_project': [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
     'glx_knn_bruteforce': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
     'glx_knn_bruteforce_range': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
@@ -191,8 +192,8 @@ class DeviceGraph:
         X = np.empty_like(B)
         it = C.c_int(0)
         err = C.c_double(0)
-        check(load().glx_cg_multi(self._h, _ptr(B), _ptr(X), B.shape[1], float(tol), int(max_iter), C.byref(it),
-                                  C.byref(err)), 'glx_cg_multi')
+        check(load().glx_cg_solve(self._h, _ptr(B), _ptr(X), B.shape[1], float(tol), int(max_iter), 1 if squeeze else 0,
+                                  C.byref(it), C.byref(err)), 'glx_cg_solve')
         return (X[:, 0] if squeeze else X), it.value, err.value
 
     def close(self):

@@ -228,6 +228,58 @@ __global__ __launch_bounds__(64) void cg_seqsum_kernel(const double* __restrict_
   }
 }
 
+// numpy reduces a contiguous 1-D float64 array with pairwise summation (umath
+// DOUBLE_pairwise_sum: blocks of <= 128 elements summed with 8 strided accumulators combined as a
+// fixed tree, halves split at a multiple of 8).  utils.conjgrad called with a 1-D right-hand side
+// (graph.reweight, graph.py:429) takes that path, so its device twin reproduces the same tree.
+__device__ __noinline__ double np_pairwise_sum(const double* __restrict__ a, int64_t n) {
+#pragma clang fp contract(off)
+  if (n < 8) {
+    double res = -0.0;
+    for (int64_t i = 0; i < n; ++i) res = res + a[i];
+    return res;
+  }
+  if (n <= 128) {
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int64_t i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res = res + a[i];
+    return res;
+  }
+  int64_t n2 = n / 2;
+  n2 -= n2 % 8;
+  const double lo = np_pairwise_sum(a, n2);
+  const double hi = np_pairwise_sum(a + n2, n - n2);
+  return lo + hi;
+}
+
+template <int MODE>
+__global__ void cg_pairwise1d_kernel(const double* __restrict__ prod, int64_t n, CgScalars sc, int it, double tol) {
+#pragma clang fp contract(off)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (MODE != 2 && cg_done(sc.err_hist, it, tol)) return;
+  const double tot = 0.0 + np_pairwise_sum(prod, n);
+  if (MODE == 0) {
+    sc.alpha[0] = sc.rsold[0] / tot;
+  } else if (MODE == 1) {
+    sc.beta[0] = tot / sc.rsold[0];
+    sc.rsold[0] = tot;
+    sc.err_hist[it] = sqrt(tot);
+  } else {
+    sc.rsold[0] = tot;
+  }
+  for (int c = 1; c < 4; ++c) {   // padded columns of the single 4-wide vector stay inert
+    if (MODE == 0) sc.alpha[c] = 0.0;
+    if (MODE == 1) sc.beta[c] = 0.0;
+  }
+}
+
 __global__ void cg_set_err0(double* err_hist, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) err_hist[i] = i == 0 ? 1.0 : 0.0;
@@ -247,10 +299,12 @@ struct CgBufs {
 };
 
 template <typename T>
-static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int* iters_out, double* err_out) {
+static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int* iters_out, double* err_out,
+                  int flags) {
   // GLX_CG_REDUCE=tree selects block-tree reductions (faster, deterministic, not bit-identical to numpy)
   const char* red_env = getenv("GLX_CG_REDUCE");
   const bool exact = !(red_env && strcmp(red_env, "tree") == 0);
+  const bool np1d = exact && (flags & 1) && C == 1;   // caller passed a 1-D right-hand side: numpy's pairwise reductions
   const int64_t n = A->n_rows;
   const int dtype = A->dtype;
   RecLayout L;
@@ -308,7 +362,9 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
                      (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, 1, tol, b.prod,
                      (const int32_t*)A->d_perm);
   GLX_HIP(hipGetLastError());
-  if (exact)
+  if (np1d)
+    hipLaunchKernelGGL(cg_pairwise1d_kernel<2>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, sc, 0, tol);
+  else if (exact)
     hipLaunchKernelGGL(cg_seqsum_kernel<2>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, 0, tol);
   else
     hipLaunchKernelGGL(cg_reduce_kernel<2>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, 0, tol);
@@ -340,7 +396,9 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
       a.exit_err = b.err_hist + (i - 1);
       rc = glx_launch_spmm(a, st);                                                   // Ap = A@p, p.Ap partials
       if (rc) return rc;
-      if (exact)
+      if (np1d)
+        hipLaunchKernelGGL(cg_pairwise1d_kernel<0>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, sc, i, tol);
+      else if (exact)
         hipLaunchKernelGGL(cg_seqsum_kernel<0>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       else
         hipLaunchKernelGGL(cg_reduce_kernel<0>, dim3(1), blk, 0, st, (const double*)b.part_dot, nb_spmm, ncols, C, sc, i, tol);
@@ -349,7 +407,9 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
                          (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, i, tol, b.prod,
                          (const int32_t*)A->d_perm);
       GLX_HIP(hipGetLastError());
-      if (exact)
+      if (np1d)
+        hipLaunchKernelGGL(cg_pairwise1d_kernel<1>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, sc, i, tol);
+      else if (exact)
         hipLaunchKernelGGL(cg_seqsum_kernel<1>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       else
         hipLaunchKernelGGL(cg_reduce_kernel<1>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, i, tol);
@@ -377,12 +437,17 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   return GLX_OK;
 }
 
-extern "C" int glx_cg_multi(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int* iters_out,
-                            double* err_out) {
+extern "C" int glx_cg_solve(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int flags,
+                            int* iters_out, double* err_out) {
   GLX_CHECK(A && B && X, GLX_EINVAL, "glx_cg_multi: null argument");
   GLX_CHECK(A->n_rows == A->n_cols, GLX_EINVAL, "glx_cg_multi: operator must be square");
   GLX_CHECK(max_iter >= 0, GLX_EINVAL, "glx_cg_multi: negative max_iter");
   GLX_HIP(hipSetDevice(A->device));
-  return A->dtype == GLX_F32 ? cg_run<float>(A, B, X, C, tol, max_iter, iters_out, err_out)
-                             : cg_run<double>(A, B, X, C, tol, max_iter, iters_out, err_out);
+  return A->dtype == GLX_F32 ? cg_run<float>(A, B, X, C, tol, max_iter, iters_out, err_out, flags)
+                             : cg_run<double>(A, B, X, C, tol, max_iter, iters_out, err_out, flags);
+}
+
+extern "C" int glx_cg_multi(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int* iters_out,
+                            double* err_out) {
+  return glx_cg_solve(A, B, X, C, tol, max_iter, 0, iters_out, err_out);
 }

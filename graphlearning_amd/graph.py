@@ -40,6 +40,43 @@ class graph:
             sys.exit('Invalid option for graph Laplacian normalization.')
         return L.tocsr()
 
+    def reweight(self, idx, method='poisson', normalization='combinatorial', tau=0, X=None, alpha=2, zeta=1e7, r=0.1):
+        """Reweight the graph more heavily near the labelled nodes `idx` (reference
+        graph.py:368-466).  'poisson' solves one Poisson problem with the GPU conjugate-gradient
+        solver (1-D right-hand side: numpy's pairwise-summed reductions are reproduced);
+        'wnll' is a diagonal scaling.  'properly' (a kd-tree range query on the features) is
+        outside this package's scope."""
+        from . import utils
+        n = self.num_nodes
+        if method == 'poisson':
+            f = np.zeros(n)
+            f[idx] = 1
+            if normalization == 'combinatorial':
+                f -= np.mean(f)
+                L = self.laplacian()
+            elif normalization == 'normalized':
+                d = self.degree_vector() ** (0.5)
+                c = np.sum(d * f) / np.sum(d)
+                f -= c
+                L = self.laplacian(normalization=normalization)
+            else:
+                sys.exit('Unsupported normalization ' + normalization + ' for graph.reweight.')
+            w = utils.conjgrad(L, f, tol=1e-5)
+            w -= np.min(w)
+            w += 1e-5
+            D = sparse.spdiags(w, 0, n, n).tocsr()
+            return D * self.weight_matrix * D
+        elif method == 'wnll':
+            m = len(idx)
+            a = np.ones((n,))
+            a[idx] = n / m
+            D = sparse.spdiags(a, 0, n, n).tocsr()
+            return D * self.weight_matrix + self.weight_matrix * D
+        elif method == 'properly':
+            raise NotImplementedError("graph.reweight(method='properly') is outside the GPU hot path this package covers")
+        else:
+            sys.exit('Invalid reweighting method ' + method + '.')
+
     def subgraph(self, ind):
         W = self.weight_matrix
         return graph(W[ind, :][:, ind])

@@ -318,8 +318,8 @@ class laplace(ssl):
     def __init__(self, W=None, class_priors=None, X=None, reweighting='none', normalization='combinatorial', tau=0,
                  order=1, mean_shift=False, tol=1e-5, alpha=2, zeta=1e7, r=0.1):
         """Laplace learning, reference ssl.py:1106-1261: Dirichlet sub-system solved by a
-        Jacobi-scaled multi-RHS conjugate gradient on the GPU.  Reweightings other than
-        'none' (graph.reweight, reference graph.py:368-466) are outside this package's scope."""
+        Jacobi-scaled multi-RHS conjugate gradient on the GPU.  Reweightings 'poisson' and 'wnll'
+        (graph.reweight, reference graph.py:368-466) are supported; 'properly' is not."""
         super().__init__(W, class_priors)
         self.reweighting = reweighting
         self.normalization = normalization
@@ -353,9 +353,11 @@ class laplace(ssl):
         self.dtype = np.float64
 
     def _fit(self, train_ind, train_labels, all_labels=None):
-        if self.reweighting != 'none':
-            raise NotImplementedError("laplace(reweighting=%r): only 'none' is on the GPU hot path" % self.reweighting)
-        G = self.graph
+        if self.reweighting == 'none':
+            G = self.graph
+        else:       # reference ssl.py:1211-1213
+            W = self.graph.reweight(train_ind, method=self.reweighting, normalization=self.normalization, X=self.X)
+            G = graph_mod.graph(W)
         n = G.num_nodes
         k = len(np.unique(train_labels))
         L = sparse.spdiags(self.tau, 0, n, n) + G.laplacian(normalization=self.normalization)
@@ -387,6 +389,35 @@ class laplace(ssl):
         if self.mean_shift:
             u -= np.mean(u, axis=0)
         return u
+
+
+class randomwalk(ssl):
+    def __init__(self, W=None, class_priors=None, alpha=0.95):
+        """Lazy random walk classification (reference ssl.py:1731-1793): one Jacobi-scaled
+        multi-RHS conjugate-gradient solve, on the GPU."""
+        super().__init__(W, class_priors)
+        self.alpha = alpha
+        self.accuracy_filename = '_randomwalk'
+        self.name = 'Lazy Random Walks'
+        self.num_iter = None
+
+    def _fit(self, train_ind, train_labels, all_labels=None):
+        alpha = self.alpha
+        n = self.graph.num_nodes
+        W = self.graph.weight_matrix
+        W = W - sparse.spdiags(W.diagonal(), 0, n, n)
+        G = graph_mod.graph(W)
+        L = (1 - alpha) * sparse.identity(n) + alpha * G.laplacian(normalization='normalized')
+        m = L.shape[0]
+        M = L.diagonal()
+        M = sparse.spdiags(1 / np.sqrt(M + 1e-10), 0, m, m).tocsr()
+        k = len(np.unique(train_labels))
+        onehot = utils.labels_to_onehot(train_labels, k)
+        Y = np.zeros((n, onehot.shape[1]))
+        Y[train_ind, :] = onehot
+        u, it, _ = utils.conjgrad(M * L * M, M * Y, tol=1e-6, return_info=True, device=self.device)
+        self.num_iter = it
+        return M * u
 
 
 def ssl_accuracy(pred_labels, true_labels, train_ind):

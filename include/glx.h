@@ -116,6 +116,10 @@ int glx_unpack_records_dev(const void* rec, void* dense, int64_t n, int C, int d
  * alpha/beta, global stop sqrt(sum over all columns ||r||^2) <= tol, max_iter cap. */
 int glx_cg_multi(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter,
                  int* iters_out, double* err_out);
+/* same with flags: bit 0 = the caller's right-hand side is 1-D (C must be 1): numpy then reduces
+ * with pairwise summation (graph.reweight, graphlearning/graph.py:429), reproduced exactly. */
+int glx_cg_solve(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int flags,
+                 int* iters_out, double* err_out);
 
 /* ---- predict / volume-constrained projection --------------------------------------
  * ssl.predict (ssl.py:230-266) and ssl.volume_label_projection (ssl.py:172-209) on

@@ -415,6 +415,62 @@ def laplace_fit(W, train_ind, train_labels, normalization='combinatorial', tau=0
 
 
 # ----------------------------------------------------------------------------
+# "next" rows: graph.reweight, laplace reweightings, ssl.randomwalk
+# ----------------------------------------------------------------------------
+def reweight(W, idx, method='poisson', normalization='combinatorial'):
+    """graph.reweight, graphlearning/graph.py:368-466, methods 'poisson' (:413-434) and 'wnll'
+    (:436-446).  Note the 1-D right-hand side: numpy reduces it with pairwise summation."""
+    W = sparse.csr_matrix(W)
+    n = W.shape[0]
+    if method == 'poisson':
+        f = np.zeros(n)
+        f[idx] = 1
+        if normalization == 'combinatorial':
+            f -= np.mean(f)
+            L = laplacian(W)
+        elif normalization == 'normalized':
+            d = degree_vector(W) ** (0.5)
+            c = np.sum(d * f) / np.sum(d)
+            f -= c
+            L = laplacian(W, normalization)
+        else:
+            raise ValueError('Unsupported normalization ' + normalization + ' for graph.reweight.')
+        w = conjgrad(L, f, tol=1e-5)
+        w -= np.min(w)
+        w += 1e-5
+        D = sparse.spdiags(w, 0, n, n).tocsr()
+        return D * W * D
+    if method == 'wnll':
+        m = len(idx)
+        a = np.ones((n,))
+        a[idx] = n / m
+        D = sparse.spdiags(a, 0, n, n).tocsr()
+        return D * W + W * D
+    raise ValueError('Invalid reweighting method ' + method + '.')
+
+
+def laplace_reweighted_fit(W, train_ind, train_labels, reweighting, normalization='combinatorial', tol=1e-5):
+    """ssl.laplace._fit with reweighting != 'none', graphlearning/ssl.py:1208-1213."""
+    Wr = reweight(W, train_ind, method=reweighting, normalization=normalization)
+    return laplace_fit(Wr, train_ind, train_labels, normalization=normalization, tol=tol)
+
+
+def randomwalk_fit(W, train_ind, train_labels, alpha=0.95, return_iters=False):
+    """ssl.randomwalk._fit, graphlearning/ssl.py:1765-1793."""
+    n = W.shape[0]
+    W = sparse.csr_matrix(W)
+    W = sparse.csr_matrix(W - sparse.spdiags(W.diagonal(), 0, n, n))
+    L = (1 - alpha) * sparse.identity(n) + alpha * laplacian(W, 'normalized')
+    M = sparse.spdiags(1 / np.sqrt(L.diagonal() + 1e-10), 0, n, n).tocsr()
+    k = len(np.unique(train_labels))
+    Y = np.zeros((n, k))
+    Y[train_ind, :] = labels_to_onehot(train_labels, k)
+    u, it, err = conjgrad(M * L * M, M * Y, tol=1e-6, return_iters=True)
+    u = M * u
+    return (u, it) if return_iters else u
+
+
+# ----------------------------------------------------------------------------
 # a-6  PoissonMBO (graphlearning/ssl.py:774-839)
 # ----------------------------------------------------------------------------
 def poisson_mbo_fit(W, train_ind, train_labels, priors, solver='conjugate_gradient',

@@ -205,6 +205,41 @@ def g6_helpers():
     print('g6 done')
 
 
+def g7_next_rows():
+    """SURVEY 8f-3 rows on two-moons: laplace reweightings (graph.reweight) and ssl.randomwalk."""
+    X, labels = skd.make_moons(n_samples=500, noise=0.1, random_state=0)
+    W = gl.weightmatrix.knn(X, 10, knn_data=gl.weightmatrix.knnsearch(X, 11, method='kdtree'))
+    train_ind = gl.trainsets.generate(labels, rate=5, seed=0)
+    tl = labels[train_ind]
+    out = {'train_ind': np.asarray(train_ind, dtype=np.int64), 'labels': labels.astype(np.int64)}
+    out.update(csr_parts(W, 'W'))
+    G = gl.graph(W)
+    for method, norm in [('poisson', 'combinatorial'), ('poisson', 'normalized'), ('wnll', 'combinatorial')]:
+        Wr = G.reweight(train_ind, method=method, normalization=norm)
+        tag = method + '_' + norm
+        out.update(csr_parts(Wr, 'Wr_' + tag))
+        Wo = orc.reweight(W, train_ind, method=method, normalization=norm)
+        assert np.array_equal(sparse.csr_matrix(Wr).data, sparse.csr_matrix(Wo).data)
+        mdl = gl.ssl.laplace(W, reweighting=method, normalization=norm)
+        out['laplace_' + tag + '_prob'] = mdl.fit(train_ind, tl)
+        out['laplace_' + tag + '_pred'] = mdl.predict()
+        assert np.array_equal(orc.laplace_reweighted_fit(W, train_ind, tl, method, norm), out['laplace_' + tag + '_prob'])
+    mdl = gl.ssl.randomwalk(W)
+    out['randomwalk_prob'] = mdl.fit(train_ind, tl)
+    out['randomwalk_pred'] = mdl.predict()
+    u, it = orc.randomwalk_fit(W, train_ind, tl, return_iters=True)
+    assert np.array_equal(u, out['randomwalk_prob'])
+    out['randomwalk_iters'] = np.int64(it)
+    # a 1-D conjgrad solve on its own (numpy's pairwise-summed reductions)
+    L = G.laplacian() + sparse.identity(500) * 0.05
+    f = np.sin(np.arange(500) * 0.1)
+    out['cg1d_rhs'] = f
+    out.update(csr_parts(L, 'cg1d_A'))
+    out['cg1d_x'] = gl.utils.conjgrad(L, f, tol=1e-9)
+    np.savez_compressed(os.path.join(HERE, 'g7_next_rows.npz'), **out)
+    print('g7 done, randomwalk iters', it)
+
+
 def g4_large():
     """Config 2 (70k) and config 3 (60k): checksums only; the graphs are
     regenerated from seeds by the oracle on the GPU box."""
@@ -263,5 +298,6 @@ if __name__ == '__main__':
     g3_mid()
     g5_projection()
     g6_helpers()
+    g7_next_rows()
     if args.large:
         g4_large()

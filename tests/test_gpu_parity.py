@@ -309,3 +309,30 @@ def test_ssl_trials_csv(gl, golden, tmp_path, monkeypatch):
     mp.ssl_trials(sets[:1], labels, tag='p_')
     hdr = open(tmp_path / 'results' / 'p__poisson_classpriors_accuracy.csv').readline().strip()
     assert hdr == 'Number of labels,Accuracy,Accuracy with class priors,Class priors error'
+
+
+def test_next_rows_reweight_randomwalk_golden(gl, golden):
+    """graph.reweight ('poisson' = a 1-D CG with numpy's pairwise reductions, 'wnll'),
+    laplace reweightings and ssl.randomwalk -- bit-identical to the reference goldens."""
+    g = golden('g7_next_rows.npz')
+    W = csr_from(g, 'W')
+    ti, lab = g['train_ind'], g['labels']
+    A = csr_from(g, 'cg1d_A')
+    x = gl.utils.conjgrad(A, g['cg1d_rhs'], tol=1e-9)
+    assert x.shape == (500,) and np.array_equal(x, g['cg1d_x'])
+    G = gl.graph.graph(W)
+    for method, norm in [('poisson', 'combinatorial'), ('poisson', 'normalized'), ('wnll', 'combinatorial')]:
+        tag = method + '_' + norm
+        Wr = sparse.csr_matrix(G.reweight(ti, method=method, normalization=norm))
+        Wg = csr_from(g, 'Wr_' + tag)
+        assert np.array_equal(Wr.indices, Wg.indices) and np.array_equal(Wr.data, Wg.data), tag
+        m = gl.ssl.laplace(W, reweighting=method, normalization=norm)
+        u = m.fit(ti, lab[ti])
+        assert np.array_equal(u, g['laplace_' + tag + '_prob']), tag
+        assert np.array_equal(m.predict(), g['laplace_' + tag + '_pred'])
+    m = gl.ssl.randomwalk(W)
+    u = m.fit(ti, lab[ti])
+    assert m.num_iter == int(g['randomwalk_iters'])
+    assert np.array_equal(u, g['randomwalk_prob']) and np.array_equal(m.predict(), g['randomwalk_pred'])
+    with pytest.raises(NotImplementedError):
+        G.reweight(ti, method='properly', X=np.zeros((500, 2)))

@@ -143,3 +143,17 @@ def test_g4_meta_is_consistent():
     c2, c3 = meta['config2'], meta['config3']
     assert c2['n'] == 70000 and c2['nnz'] == 1136022 and c2['T'] == 50 and c2['row_nnz_max'] == 138
     assert c3['n'] == 60000 and c3['nnz'] == 1992536 and c3['row_nnz_max'] == 660
+
+
+def test_g7_next_rows(golden):
+    g = golden('g7_next_rows.npz')
+    W = csr_from(g, 'W')
+    ti, lab = g['train_ind'], g['labels']
+    for method, norm in [('poisson', 'combinatorial'), ('poisson', 'normalized'), ('wnll', 'combinatorial')]:
+        tag = method + '_' + norm
+        Wr = orc.reweight(W, ti, method=method, normalization=norm)
+        assert np.array_equal(Wr.tocsr().data, g['Wr_' + tag + '_data'])
+        assert np.array_equal(orc.laplace_reweighted_fit(W, ti, lab[ti], method, norm), g['laplace_' + tag + '_prob'])
+    u, it = orc.randomwalk_fit(W, ti, lab[ti], return_iters=True)
+    assert it == int(g['randomwalk_iters']) and np.array_equal(u, g['randomwalk_prob'])
+    assert np.array_equal(orc.conjgrad(csr_from(g, 'cg1d_A'), g['cg1d_rhs'], tol=1e-9), g['cg1d_x'])
