@@ -313,6 +313,34 @@ class DistSweep:
         return self.ops.unpack([self.xa, self.xb][self.cur], self.plan.n_own)
 
 
+def knnsearch_distributed(X, k, dist, device, similarity='euclidean', group=None):
+    """weightmatrix.knnsearch with the QUERY rows sharded over the ranks: every
+    rank holds all of X, searches its contiguous block of queries on its own GPU
+    (glx_knn_bruteforce_range) and the blocks are all_gathered -- the only communication."""
+    import torch
+    from . import _hip
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = X.shape[0]
+    bounds = block_bounds(n, world)
+    ind, dst = _hip.knn_bruteforce(X, k, similarity=similarity, device=device,
+                                   query_range=(int(bounds[rank]), int(bounds[rank + 1])))
+    if world == 1:
+        return ind, dst
+    rows = int(np.max(np.diff(bounds)))               # pad to equal blocks for all_gather
+    dev = torch.device('cuda', device)
+    ti = torch.full((rows, k), -1, dtype=torch.int64, device=dev)
+    td = torch.zeros((rows, k), dtype=torch.float64, device=dev)
+    ti[:len(ind)] = torch.from_numpy(ind).to(dev)
+    td[:len(dst)] = torch.from_numpy(dst).to(dev)
+    gi = [torch.empty_like(ti) for _ in range(world)]
+    gd = [torch.empty_like(td) for _ in range(world)]
+    dist.all_gather(gi, ti, group=group)
+    dist.all_gather(gd, td, group=group)
+    ind_all = np.concatenate([gi[r][:bounds[r + 1] - bounds[r]].cpu().numpy() for r in range(world)])
+    dst_all = np.concatenate([gd[r][:bounds[r + 1] - bounds[r]].cpu().numpy() for r in range(world)])
+    return ind_all, dst_all
+
+
 def initial_error(w0, deg, vinf, dist=None, group=None, torch=None):
     """max |deg*w0 - vinf| over all vertices (needed only when min_iter == 0)."""
     e = float(np.max(np.abs(deg * w0 - vinf))) if len(w0) else 0.0

@@ -3,7 +3,7 @@
 Launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: one
 rank per GPU, torch.distributed backend "nccl" (= RCCL over xGMI).  The global graph has
 N * 70000 vertices (MNIST label vector tiled, same blob generator, k = 10): every rank builds
-it identically (exact kNN on its own GPU, deterministic host assembly), owns one contiguous
+it identically (exact kNN with the queries sharded over the ranks and all_gathered, deterministic assembly), owns one contiguous
 block of the RCM-ordered vertices and exchanges boundary vertex records once per sweep.
 """
 import os
@@ -29,7 +29,7 @@ def main(args):
     labels = bench.load_labels(n)
     X = bench.make_features(labels)
     t0 = time.perf_counter()
-    ind, dst = _hip.knn_bruteforce(X, bench.K_NN + 1, device=local_rank)
+    ind, dst = gdist.knnsearch_distributed(X, bench.K_NN + 1, dist, local_rank)   # queries sharded by rank
     W = gl.weightmatrix.knn(None, bench.K_NN, knn_data=(ind, dst))
     t_graph = time.perf_counter() - t0
     train_ind = gl.trainsets.generate(labels, rate=1, seed=0)
