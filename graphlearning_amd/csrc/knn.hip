@@ -5,7 +5,7 @@
 //      (n x d) @ (d x n) contraction on the fp32 matrix cores (v_mfma_f32_32x32x2_f32),
 //      refs staged through LDS, the norms folded into the contraction as two extra
 //      features so the accumulator IS |q|^2 + |r|^2 - 2 q.r; every lane owns one query
-//      column and keeps a sorted top-KP list of its half of the refs in LDS;
+//      column and keeps the KP best of its half of the refs in an LDS list (unsorted, maximum tracked);
 //   2. exact re-rank -- fp64 direct-difference distances (the accumulation pattern of
 //      scipy cKDTree's sqeuclidean_distance_double) of the candidates, sorted by
 //      (distance, index); a row is accepted only if every candidate list's threshold
@@ -29,7 +29,7 @@ extern "C" int glx_knn_stats(double stats[8]) {
 
 static const int BQ = 128;   // queries per workgroup (4 waves x 32)
 static const int BR_MAX = 128; // refs per LDS tile: 32 * NSUB
-static const int KBUF = 16;    // per-lane append slots between list compactions
+static const int KBUF = 8;     // per-lane append slots between list merges
 
 // ---- stage 0: centred fp32 images with the norms folded in ---------------------------------
 // Rf[i] = [x_0..x_{d-1}, 0.., |x|^2, 1]   Qf[i] = [-2x_0..-2x_{d-1}, 0.., 1, |x|^2]   (dpa floats)
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
   constexpr int STRIDE = (DH % 2 == 1) ? DPA : DPA + 2;   // floats; ds_read_b64 of 32 rows hits 64 distinct banks
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tile = smem;                                  // [2][BR][STRIDE]
-  float* ld = smem + 2 * BR * STRIDE;                  // [KP + KBUF][256]: sorted top-KP list, then append slots
+  float* ld = smem + 2 * BR * STRIDE;                  // [KP + KBUF][256]: the lane's KP best so far, then append slots
   int* li = (int*)(ld + (KP + KBUF) * 256);            // [KP + KBUF][256] indices
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
@@ -107,6 +107,12 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
     }
   };
   int cnt = 0;
+  const bool share_tau = !(ablate & 2);
+  // The per-lane list is kept UNSORTED with its maximum tracked (value tau_own at slot pmax): an
+  // accepted candidate overwrites the maximum and the KP entries are rescanned with independent
+  // LDS reads -- no dependent shift chain.  The re-rank kernel sorts anyway.
+  float tau_own = INFINITY;
+  int pmax = 0;
   auto compact = [&]() {
     int mx = cnt;
 #pragma unroll
@@ -114,23 +120,26 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
     for (int a = 0; a < mx; ++a) {
       if (a < cnt) {
         const float v = ld[(KP + a) * 256 + tid];
-        if (v < ld[(KP - 1) * 256 + tid]) {
-          const int ref = li[(KP + a) * 256 + tid];
-          int p = KP - 1;
-          while (p > 0) {
-            const float prev = ld[(p - 1) * 256 + tid];
-            if (!(prev > v)) break;
-            ld[p * 256 + tid] = prev;
-            li[p * 256 + tid] = li[(p - 1) * 256 + tid];
-            --p;
+        if (v < tau_own) {
+          ld[pmax * 256 + tid] = v;
+          li[pmax * 256 + tid] = li[(KP + a) * 256 + tid];
+          float m2 = ld[tid];
+          int pm = 0;
+#pragma unroll
+          for (int p = 1; p < KP; ++p) {
+            const float x = ld[p * 256 + tid];
+            if (x > m2) { m2 = x; pm = p; }
           }
-          ld[p * 256 + tid] = v;
-          li[p * 256 + tid] = ref;
+          tau_own = m2;
+          pmax = pm;
         }
       }
     }
     cnt = 0;
-    tau = ld[(KP - 1) * 256 + tid];
+    // lanes l and l^32 serve the same query: at least KP refs lie below the smaller of their two
+    // thresholds, so that bound filters both halves (the acceptance check in the re-rank kernel,
+    // min over all lists of the final thresholds, is unaffected)
+    tau = share_tau ? fminf(tau_own, __shfl_xor(tau_own, 32)) : tau_own;
   };
   if (t0 < t1) { stage_load(t0); stage_store(0); }
   __syncthreads();
@@ -168,17 +177,17 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
 #pragma unroll
       for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
-        for (int eg = 0; eg < 16; eg += 8) {
+        for (int eg = 0; eg < 16; eg += 4) {
 #pragma unroll
-          for (int e = eg; e < eg + 8; ++e) {
+          for (int e = eg; e < eg + 4; ++e) {
             const float v = acc[sub][e];
-            if (v < tau) {
+            if (v < tau && !(ablate & 4)) {
               ld[(KP + cnt) * 256 + tid] = v;
               li[(KP + cnt) * 256 + tid] = (int)(t * BR) + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
               ++cnt;
             }
           }
-          if (__any(cnt > KBUF - 8)) compact();
+          if (__any(cnt > KBUF - 4)) compact();
         }
       }
     }
@@ -275,7 +284,8 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
     const double eps = cerr * rq * rq;
     int bad = !(dk2 < INFINITY);
     for (int l = 0; l < lists && !bad; ++l) {
-      const float tau = cand_d[ql * ncand + l * KP + KP - 1];
+      float tau = 0.f;   // the list's threshold = its largest entry (lists arrive unsorted); INFINITY while not full
+      for (int p = 0; p < KP; ++p) tau = fmaxf(tau, cand_d[ql * ncand + l * KP + p]);
       if (tau < INFINITY && !((double)tau >= dk2 + 2.0 * eps)) bad = 1;
     }
     flags[ql] = bad;
