@@ -176,25 +176,67 @@ __global__ __launch_bounds__(256) void cg_reduce_kernel(const double* __restrict
 // MODE 0: tot = sum p*Ap ; alpha = rsold / tot                                (utils.py:524)
 // MODE 1: tot = sum r*r  ; beta = tot / rsold ; rsold = tot ; err = sqrt(np.sum(tot)) (:527-530)
 // MODE 2: rsold = sum r*r                                                     (utils.py:517)
+// One workgroup: all 256 threads stream the next tile of the column-major product array into
+// registers (coalesced) while wavefront 0 -- lane c = column c -- adds up the current tile from
+// LDS in row order; the registers are then written to the other LDS buffer.  Only the add chain
+// is serial, the memory latency hides under it.
 template <int MODE>
-__global__ __launch_bounds__(64) void cg_seqsum_kernel(const double* __restrict__ prod, int64_t n, int ncols, int C, CgScalars sc,
-                                                       int it, double tol) {
+__global__ __launch_bounds__(256) void cg_seqsum_kernel(const double* __restrict__ prod, int64_t n, int ncols, int C, CgScalars sc,
+                                                        int it, double tol, int TR) {
 #pragma clang fp contract(off)
   if (MODE != 2 && cg_done(sc.err_hist, it, tol)) return;
+  extern __shared__ __attribute__((aligned(16))) double s_tile[];   // [2][ncols][TR + 1]
   __shared__ double s_col[64];
-  const int c = threadIdx.x;
-  double tot = 0.0;
-  if (c < ncols) {
-    const double* col = prod + (size_t)c * n;   // this column's products, rows in the caller's order
-    int64_t i = 0;
-    for (; i + 32 <= n; i += 32) {
-      double v[32];
+  const int tid = threadIdx.x;
+  const int LDT = TR + 1;                       // +1: lanes of one read hit different banks
+  const int per = (TR * ncols + 255) / 256;     // elements per thread per tile (<= 24)
+  double reg[24];
+  auto tile_load = [&](int64_t base) {
 #pragma unroll
-      for (int q = 0; q < 32; ++q) v[q] = col[i + q];
-#pragma unroll
-      for (int q = 0; q < 32; ++q) tot = tot + v[q];
+    for (int q = 0; q < 24; ++q) {
+      const int idx = tid + q * 256;
+      double v = 0.0;
+      if (q < per && idx < TR * ncols) {
+        const int cc = idx / TR, r = idx % TR;
+        if (base + r < n) v = prod[(size_t)cc * n + base + r];
+      }
+      reg[q] = v;
     }
-    for (; i < n; ++i) tot = tot + col[i];
+  };
+  auto tile_store = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 24; ++q) {
+      const int idx = tid + q * 256;
+      if (q < per && idx < TR * ncols) s_tile[(size_t)buf * ncols * LDT + (idx / TR) * LDT + (idx % TR)] = reg[q];
+    }
+  };
+  const int c = tid;
+  double tot = 0.0;
+  tile_load(0);
+  tile_store(0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t base = 0; base < n; base += TR) {
+    const bool more = base + TR < n;
+    if (more) tile_load(base + TR);
+    if (tid < ncols) {
+      const double* col = s_tile + (size_t)buf * ncols * LDT + c * LDT;
+      const int rows = (int)min((int64_t)TR, n - base);
+      int r = 0;
+      for (; r + 16 <= rows; r += 16) {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = col[r + q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot = tot + v[q];
+      }
+      for (; r < rows; ++r) tot = tot + col[r];
+    }
+    if (more) tile_store(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (c < ncols) {
     if (MODE == 0) {
       sc.alpha[c] = c < C ? sc.rsold[c] / tot : 0.0;
     } else if (MODE == 1) {
@@ -205,7 +247,7 @@ __global__ __launch_bounds__(64) void cg_seqsum_kernel(const double* __restrict_
     }
   }
   if (MODE == 1) {
-    s_col[c] = (c < C) ? tot : 0.0;
+    if (c < 64) s_col[c] = (c < C && c < ncols) ? tot : 0.0;
     __syncthreads();
     if (c == 0) {
       // np.sum over a contiguous 1-D float64 array: numpy's pairwise_sum (8 accumulators
@@ -323,6 +365,15 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   const int64_t hist_cap = max_iter + 2;
   GLX_CHECK(max_iter < (1ll << 24), GLX_EUNSUPPORTED, "glx_cg_multi: max_iter %lld exceeds the supported 2^24-1", (long long)max_iter);
 
+  // tile of the reference-order reducer: TR rows x ncols columns, 24 elements per thread at most
+  int TR = 512;
+  while (TR > 16 && TR * ncols > 24 * 256) TR /= 2;
+  const size_t seq_shm = (size_t)2 * ncols * (TR + 1) * 8;
+  if (exact) {
+    GLX_HIP(hipFuncSetAttribute((const void*)cg_seqsum_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_shm));
+    GLX_HIP(hipFuncSetAttribute((const void*)cg_seqsum_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_shm));
+    GLX_HIP(hipFuncSetAttribute((const void*)cg_seqsum_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_shm));
+  }
   CgBufs b;
   const size_t recb = std::max<size_t>((size_t)n * L.ld * es, 64);
   GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
@@ -365,7 +416,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   if (np1d)
     hipLaunchKernelGGL(cg_pairwise1d_kernel<2>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, sc, 0, tol);
   else if (exact)
-    hipLaunchKernelGGL(cg_seqsum_kernel<2>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, 0, tol);
+    hipLaunchKernelGGL(cg_seqsum_kernel<2>, dim3(1), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, 0, tol, TR);
   else
     hipLaunchKernelGGL(cg_reduce_kernel<2>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, 0, tol);
   GLX_HIP(hipGetLastError());
@@ -399,7 +450,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
       if (np1d)
         hipLaunchKernelGGL(cg_pairwise1d_kernel<0>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, sc, i, tol);
       else if (exact)
-        hipLaunchKernelGGL(cg_seqsum_kernel<0>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
+        hipLaunchKernelGGL(cg_seqsum_kernel<0>, dim3(1), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, i, tol, TR);
       else
         hipLaunchKernelGGL(cg_reduce_kernel<0>, dim3(1), blk, 0, st, (const double*)b.part_dot, nb_spmm, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
@@ -410,7 +461,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
       if (np1d)
         hipLaunchKernelGGL(cg_pairwise1d_kernel<1>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, sc, i, tol);
       else if (exact)
-        hipLaunchKernelGGL(cg_seqsum_kernel<1>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
+        hipLaunchKernelGGL(cg_seqsum_kernel<1>, dim3(1), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, i, tol, TR);
       else
         hipLaunchKernelGGL(cg_reduce_kernel<1>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
