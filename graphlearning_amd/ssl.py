@@ -218,7 +218,9 @@ class poisson(ssl):
         if self.solver == 'conjugate_gradient':
             L = G.laplacian(normalization='normalized')
             aux['D'] = G.degree_matrix(p=-0.5)
-            dev = _hip.DeviceGraph(L, dtype=self._dtype(), device=self.device)
+            # one-shot CG solves spend their time in the reference-order reductions, not in the SpMM:
+            # the locality renumbering (an O(nnz) host pass) would not pay for itself
+            dev = _hip.DeviceGraph(L, dtype=self._dtype(), device=self.device, keep_order=True)
         else:
             D = G.degree_matrix(p=-1)
             P = D * W.transpose()
@@ -376,7 +378,7 @@ class laplace(ssl):
         m = A.shape[0]
         M = A.diagonal()
         M = sparse.spdiags(1 / np.sqrt(M + 1e-10), 0, m, m).tocsr()   # reference ssl.py:1244-1246
-        dev = _hip.DeviceGraph(M * A * M, dtype=self.dtype, device=self.device)
+        dev = _hip.DeviceGraph(M * A * M, dtype=self.dtype, device=self.device, keep_order=True)
         try:
             v, it, _ = dev.cg(np.ascontiguousarray(M * b, dtype=self.dtype), tol=self.tol)   # reference ssl.py:1249
         finally:

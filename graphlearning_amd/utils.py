@@ -50,7 +50,7 @@ def conjgrad(A, b, x0=None, max_iter=1e5, tol=1e-10, dtype=np.float64, return_in
         d, it, err = conjgrad(A, r0, None, max_iter, tol, dtype, True, device)
         x = x0 + d
         return (x, it, err) if return_info else x
-    G = _hip.DeviceGraph(sparse.csr_matrix(A), dtype=dtype, device=device)
+    G = _hip.DeviceGraph(sparse.csr_matrix(A), dtype=dtype, device=device, keep_order=True)
     try:
         x, it, err = G.cg(np.asarray(b), tol=tol, max_iter=int(max_iter))
     finally:
