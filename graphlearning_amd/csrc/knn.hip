@@ -366,6 +366,7 @@ static int launch_tile(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int 
   constexpr int STRIDE = (DH % 2 == 1) ? DPA : DPA + 2;
   constexpr int NSUB = tile_nsub(DH, KP);
   const size_t shm = (size_t)2 * 32 * NSUB * STRIDE * 4 + (size_t)(KP + KBUF) * 256 * 8;
+  GLX_CHECK(shm <= 160 * 1024, GLX_EUNSUPPORTED, "glx_knn_bruteforce: this (d, k) needs %zu bytes of LDS per workgroup (160 KiB available)", shm);
   GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_kernel<DH, KP, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)nsplit);
   hipLaunchKernelGGL((knn_tile_kernel<DH, KP, NSUB>), grid, dim3(256), shm, st, (const float*)b.Rf, (const float*)b.Qf, n, q0, q1, nsplit,
@@ -393,7 +394,7 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   GLX_CHECK(k <= n, GLX_EINVAL, "glx_knn_bruteforce: k=%d exceeds the number of points %lld", k, (long long)n);
   GLX_CHECK(n < (1ll << 31) - BR_MAX, GLX_EINVAL, "glx_knn_bruteforce: n must fit int32");
   GLX_CHECK(0 <= q0 && q0 <= q1 && q1 <= n, GLX_EINVAL, "glx_knn_bruteforce: bad query range");
-  GLX_CHECK(k <= 28, GLX_EUNSUPPORTED, "glx_knn_bruteforce: k=%d (incl. self) above the supported 28", k);
+  GLX_CHECK(k <= 60, GLX_EUNSUPPORTED, "glx_knn_bruteforce: k=%d (incl. self) above the supported 60", k);
   GLX_CHECK(d <= 130, GLX_EUNSUPPORTED, "glx_knn_bruteforce: d=%d above the supported 130", d);
   const int64_t nq = q1 - q0;
   if (nq == 0) return GLX_OK;
@@ -402,7 +403,7 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   for (int cand : {8, 12, 18, 34, 66})
     if (2 * cand >= d + 2) { DH = cand; break; }
   const int dpa = 2 * DH;
-  const int KP = k <= 12 ? 16 : 32;
+  const int KP = k <= 12 ? 16 : (k <= 28 ? 32 : 64);
   const int64_t nqb = (nq + BQ - 1) / BQ;
   const int BR = 32 * tile_nsub(DH, KP);
   const int64_t ntiles = (n + BR - 1) / BR;
@@ -456,7 +457,8 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   GLX_HIP(hipGetLastError());
   int rc;
   if (KP == 16) rc = launch_tile_dh<16>(DH, b, n, q0, q1, nsplit, st);
-  else rc = launch_tile_dh<32>(DH, b, n, q0, q1, nsplit, st);
+  else if (KP == 32) rc = launch_tile_dh<32>(DH, b, n, q0, q1, nsplit, st);
+  else rc = launch_tile_dh<64>(DH, b, n, q0, q1, nsplit, st);
   if (rc) return rc;
   GLX_HIP(hipEventRecord(b.e1, st));
   hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)nq), dim3(64), (size_t)M * 12, st, (const double*)b.X, n, d, k, q0, nq,

@@ -53,8 +53,13 @@ def test_hipops_rank_local_sweeps_match_scipy(golden):
 def test_distributed_bench_entry_one_rank(tmp_path, force_coll):
     # force_coll=1: the all_to_all / all_reduce calls are issued (and graph-captured) even with one rank
     env = dict(os.environ, GLX_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', GLX_DIST_FORCE_COLLECTIVES=force_coll)
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
-           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1']
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'capture unavailable' not in r.stderr, r.stderr[-2000:]
