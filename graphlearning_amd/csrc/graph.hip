@@ -52,6 +52,7 @@ int glx_make_layout(int C, int dtype, bool has_w, RecLayout* L) {
   int rb = 32;
   while (rb < bytes && rb < 128) rb *= 2;      // 32 / 64 / 128-byte records stay line-aligned
   if (rb < bytes) rb = (bytes + 63) / 64 * 64; // larger records: multiple of 64 bytes
+  if (getenv("GLX_REC_NOPAD") && atoi(getenv("GLX_REC_NOPAD"))) rb = bytes;   // developer probe: unpadded records
   L->C = C;
   L->nvec = nvec;
   L->ld = rb / es;

@@ -205,6 +205,8 @@ class DistSweep:
         self.in_splits = list(plan.send_counts)
         self.out_splits = list(plan.recv_counts)
         self.exchanges = 0
+        # a backend without device collectives (gloo) with device-resident records: stage through the host
+        self._stage_host = bool(getattr(ops, 'supports_graph', False)) and dist.get_backend(group) == 'gloo'
         import os
         self._force_coll = os.environ.get('GLX_DIST_FORCE_COLLECTIVES') == '1'   # test hook: collectives at world 1
 
@@ -215,9 +217,24 @@ class DistSweep:
             return
         send = self.ops.index_rows(x, self.send_idx)
         recv = x[p.n_own:]
-        self.dist.all_to_all_single(recv, send, output_split_sizes=self.out_splits, input_split_sizes=self.in_splits,
-                                    group=self.group)
+        if self._stage_host:
+            send_h = send.cpu()
+            recv_h = self.torch.empty(recv.shape, dtype=recv.dtype)
+            self.dist.all_to_all_single(recv_h, send_h, output_split_sizes=self.out_splits, input_split_sizes=self.in_splits,
+                                        group=self.group)
+            recv.copy_(recv_h)
+        else:
+            self.dist.all_to_all_single(recv, send, output_split_sizes=self.out_splits, input_split_sizes=self.in_splits,
+                                        group=self.group)
         self.exchanges += 1
+
+    def _all_reduce_max(self, e):
+        if self._stage_host:
+            h = e.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX, group=self.group)
+            e.copy_(h)
+        else:
+            self.dist.all_reduce(e, op=self.dist.ReduceOp.MAX, group=self.group)
 
     def setup(self, Db_own, w0_own, deg_own, vinf_own):
         """Rank-local problem data (rows in this rank's local order)."""
@@ -230,7 +247,7 @@ class DistSweep:
         self.cur = 0
         self._graph = None
         self._graph_err = None
-        self._graph_ok = bool(getattr(ops, 'supports_graph', False))
+        self._graph_ok = bool(getattr(ops, 'supports_graph', False)) and not self._stage_host
 
     def reset(self):
         """Owned rows <- initial records; halo filled by one exchange.  Allocation-free apart from
@@ -251,7 +268,7 @@ class DistSweep:
             e = self.ops.sweep(bufs[self.cur], bufs[self.cur ^ 1], want)
             self.exchange(bufs[self.cur ^ 1])
             if want and (self.plan.world > 1 or self._force_coll):
-                self.dist.all_reduce(e, op=self.dist.ReduceOp.MAX, group=self.group)
+                self._all_reduce_max(e)
             self.cur ^= 1
         return e
 
@@ -303,7 +320,7 @@ class DistSweep:
             self.exchange(xout)
             if want:
                 if p.world > 1:
-                    dist.all_reduce(e, op=dist.ReduceOp.MAX, group=self.group)
+                    self._all_reduce_max(e)
                 err_T = float(e.item())
             self.cur ^= 1
             T += 1

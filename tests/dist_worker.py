@@ -70,6 +70,7 @@ class ScipyOps:
 def main():
     case = sys.argv[1]
     out_path = sys.argv[2]
+    use_hip = len(sys.argv) > 3 and sys.argv[3] == 'hip'     # rank-local sweeps on the GPU (all ranks share cuda:0)
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     from conftest import csr_from, blobs
@@ -88,8 +89,8 @@ def main():
         ti = orc.trainsets_generate(lab, rate=3, seed=2); tl = lab[ti]
     else:
         raise SystemExit('unknown case')
-    u, T = gdist.poisson_fit_distributed(W, ti, tl, dist, lambda plan, k: ScipyOps(plan, k), min_iter=min_iter,
-                                         max_iter=max_iter)
+    factory = (lambda plan, k: gdist.HipOps(plan, k, 0)) if use_hip else (lambda plan, k: ScipyOps(plan, k))
+    u, T = gdist.poisson_fit_distributed(W, ti, tl, dist, factory, min_iter=min_iter, max_iter=max_iter)
     u_ref, T_ref = orc.poisson_gd(W, ti, tl, min_iter=min_iter, max_iter=max_iter, return_T=True)
     # partition bookkeeping invariants
     P = gdist.poisson_problem(W, ti, tl)['P']

@@ -67,3 +67,23 @@ def test_distributed_bench_entry_one_rank(tmp_path, force_coll):
     j = json.loads(line)
     assert j['n_gpus'] == 1 and j['value'] > 0 and j['config']['sweeps_per_step'] == 50
     print(line[:400])
+
+
+@pytest.mark.parametrize('case,world', [('twomoons', 2), ('blobs', 3), ('miniter0', 2)])
+def test_multi_rank_hip_sweeps_over_gloo(case, world, tmp_path):
+    """Several ranks, every one running its rank-local sweeps with the HIP kernel (all on cuda:0),
+    exchanging halo records through gloo (host-staged): the full multi-rank GPU path minus RCCL,
+    bit-identical to the single-rank oracle."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / ('res_' + case))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out, 'hip']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS='1'), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for k in range(world):
+        res = json.load(open(out + '.%d' % k))
+        assert res['T'] == res['T_ref'] and res['equal'] and res['ok_counts'], res
