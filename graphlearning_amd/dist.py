@@ -247,7 +247,9 @@ class DistSweep:
         self.cur = 0
         self._graph = None
         self._graph_err = None
-        self._graph_ok = bool(getattr(ops, 'supports_graph', False)) and not self._stage_host
+        import os
+        self._graph_ok = (bool(getattr(ops, 'supports_graph', False)) and not self._stage_host
+                          and os.environ.get('GLX_DIST_GRAPH', '1') != '0')
 
     def reset(self):
         """Owned rows <- initial records; halo filled by one exchange.  Allocation-free apart from

@@ -122,3 +122,20 @@ def test_config3_laplace(gl, meta):
     assert abs(np.abs(u).sum() - m['prob_abs_sum']) < 1e-8 * m['prob_abs_sum']
     assert np.array_equal(u[ti], np.eye(10)[labels[ti]])           # labelled rows are exactly one-hot
     assert u.min() > -1e-9 and u.max() < 1 + 1e-9                   # harmonic extension: maximum principle
+
+
+def test_config2_published_mnist_trainsets(gl, golden, config2):
+    """the first published MNIST train sets (LabelPermutations/MNIST_permutations.npz,
+    label rates 1..5 per class) through the HIP sweep vs the oracle run here on the host: bit-identical
+    iterates, stop iteration and labels at n = 70000."""
+    from oracle import gl_oracle as orc
+    g = golden('g6_helpers.npz')
+    W, labels = config2['W'], config2['labels']
+    model = gl.ssl.poisson(W, solver='gradient_descent')
+    for i in (0, 4, 9):
+        ti = g['mnist_perm_%d' % i]
+        u = model.fit(ti, labels[ti])
+        u_ref, T_ref = orc.poisson_gd(W, ti, labels[ti], return_T=True)
+        assert model.num_iter == T_ref
+        assert np.array_equal(u, u_ref), i
+        assert np.array_equal(model.predict(), orc.predict(u_ref))
