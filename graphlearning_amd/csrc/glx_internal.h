@@ -52,7 +52,7 @@ int glx_make_layout(int C, int dtype, bool has_w, RecLayout* L);
 // G lanes of a row with a DPP quad broadcast.  In G = 4 plans a long row occupies S = 4 or
 // 16 consecutive slots (its entries dealt to them 4 at a time, in order), see sweep.hip.
 struct SliceHdr {
-  int64_t ptr;      // entry offset of the slice's first chunk (multiple of 64)
+  int64_t ptr;      // entry offset (within the tail region) of the slice's chunk 1 (multiple of 64)
   int32_t nchunks;  // 64-entry chunks
   int32_t S;        // segments per row: 1, or 4 / 16 for long rows (G = 4 plans)
 };
@@ -61,6 +61,8 @@ struct SellPlan {
   int G = 0, R = 0;
   int64_t nslices = 0;
   int64_t stored = 0;          // stored entries incl. padding
+  int64_t head = 0;            // first `head` entries: chunk 0 of every slice (slice s at s*64), addressable
+                               // without the slice header; chunks 1.. follow at head + hdr.ptr
   int32_t* d_slot_row = nullptr;   // [nslices*R] row id or -1
   int32_t* d_slot_len = nullptr;   // [nslices*R]
   SliceHdr* d_slice_hdr = nullptr; // [nslices]

@@ -297,13 +297,15 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
           slot_len[(x * spx + s) * R + r] = glen[x][s * R + r];
         }
       }
-      stored += (int64_t)h.nchunks * 64;
+      stored += (int64_t)(h.nchunks > 0 ? h.nchunks - 1 : 0) * 64;   // chunk 0 lives in the dense head arrays
       hdr[x * spx + s] = h;
     }
-  std::vector<int32_t> col(stored, 0);
+  // image = [head: chunk 0 of every slice, nslices*64 entries][tail: chunks 1.. at hdr.ptr]
+  const int64_t head = nslices * 64;
+  std::vector<int32_t> col(head + stored, 0);
   std::vector<double> val64;
   std::vector<float> val32;
-  if (g->dtype == GLX_F64) val64.assign(stored, 0.0); else val32.assign(stored, 0.0f);
+  if (g->dtype == GLX_F64) val64.assign(head + stored, 0.0); else val32.assign(head + stored, 0.0f);
   for (int64_t s = 0; s < nslices; ++s) {
     const int S = hdr[s].S;
     for (int slot = 0; slot < R; slot += S) {
@@ -313,12 +315,15 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
       const int len = slot_len[s * R + slot];
       for (int jj = 0; jj < len; ++jj) {
         int64_t idx;
+        int k, within;
         if (G == 4) {
-          const int k = jj / (4 * S), sgm = (jj % (4 * S)) / 4, t = jj % 4;
-          idx = hdr[s].ptr + (int64_t)k * 64 + (slot + sgm) * 4 + t;
+          k = jj / (4 * S);
+          within = (slot + (jj % (4 * S)) / 4) * 4 + jj % 4;
         } else {
-          idx = hdr[s].ptr + (int64_t)(jj / G) * 64 + slot * G + (jj % G);
+          k = jj / G;
+          within = slot * G + (jj % G);
         }
+        idx = k == 0 ? s * 64 + within : head + hdr[s].ptr + (int64_t)(k - 1) * 64 + within;
         const int32_t c = g->h_col[b + jj];
         col[idx] = renum ? g->h_inv[c] : c;
         if (g->dtype == GLX_F64) val64[idx] = g->h_val[b + jj]; else val32[idx] = (float)g->h_val[b + jj];
@@ -329,19 +334,20 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   p.G = G;
   p.R = R;
   p.nslices = nslices;
-  p.stored = stored;
+  p.stored = head + stored;
+  p.head = head;
   const size_t es = g->dtype == GLX_F64 ? 8 : 4;
   GLX_HIP(hipMalloc(&p.d_slot_row, std::max<size_t>(4, slot_row.size() * 4)));
   GLX_HIP(hipMalloc(&p.d_slot_len, std::max<size_t>(4, slot_len.size() * 4)));
   GLX_HIP(hipMalloc(&p.d_slice_hdr, std::max<size_t>(16, hdr.size() * sizeof(SliceHdr))));
-  GLX_HIP(hipMalloc(&p.d_col, std::max<size_t>(4, stored * 4)));
-  GLX_HIP(hipMalloc(&p.d_val, std::max<size_t>(8, stored * es)));
+  GLX_HIP(hipMalloc(&p.d_col, std::max<size_t>(4, (head + stored) * 4)));
+  GLX_HIP(hipMalloc(&p.d_val, std::max<size_t>(8, (head + stored) * es)));
   GLX_HIP(hipMemcpy(p.d_slot_row, slot_row.data(), slot_row.size() * 4, hipMemcpyHostToDevice));
   GLX_HIP(hipMemcpy(p.d_slot_len, slot_len.data(), slot_len.size() * 4, hipMemcpyHostToDevice));
   GLX_HIP(hipMemcpy(p.d_slice_hdr, hdr.data(), hdr.size() * sizeof(SliceHdr), hipMemcpyHostToDevice));
-  if (stored > 0) {
-    GLX_HIP(hipMemcpy(p.d_col, col.data(), stored * 4, hipMemcpyHostToDevice));
-    GLX_HIP(hipMemcpy(p.d_val, g->dtype == GLX_F64 ? (void*)val64.data() : (void*)val32.data(), stored * es, hipMemcpyHostToDevice));
+  if (head + stored > 0) {
+    GLX_HIP(hipMemcpy(p.d_col, col.data(), (head + stored) * 4, hipMemcpyHostToDevice));
+    GLX_HIP(hipMemcpy(p.d_val, g->dtype == GLX_F64 ? (void*)val64.data() : (void*)val32.data(), (head + stored) * es, hipMemcpyHostToDevice));
   }
   g->plans.push_back(p);
   *out = &g->plans.back();

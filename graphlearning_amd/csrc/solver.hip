@@ -119,8 +119,17 @@ __global__ void bias_flags_kernel(const int32_t* __restrict__ slot_row, uint8_t*
   flags[slot] = f;
 }
 
+// captured launch sequences bake in whether a bias is read: drop them when that changes
+static void drop_graphs_if_bias_changes(glx_sweep* s, bool will_have_bias) {
+  if (s->bias_set == will_have_bias) return;
+  if (s->head_exec) { hipGraphExecDestroy(s->head_exec); s->head_exec = nullptr; }
+  for (auto& kv : s->iter_exec) hipGraphExecDestroy(kv.second);
+  s->iter_exec.clear();
+}
+
 static int upload_bias(glx_sweep* s, const void* Db) {
   const int64_t nslots = s->plan->nslices * s->plan->R;
+  drop_graphs_if_bias_changes(s, Db != nullptr);
   if (!Db) {
     GLX_HIP(hipMemsetAsync(s->bias, 0, rec_bytes(s, s->n_rows), s->stream));
     GLX_HIP(hipMemsetAsync(s->slot_has_bias, 0, std::max<int64_t>(nslots, 1), s->stream));

@@ -35,6 +35,7 @@ struct SpmmParams {
   const SliceHdr* slice_hdr;
   const int32_t* col;
   const void* val;
+  int64_t head;   // entries of the dense chunk-0 region
   int64_t nslices;
   int64_t nblocks;
   const char* xin;
@@ -192,17 +193,24 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
   const bool is_w = HAS_W && (c == p.nvec);
   int row = -1, len = 0, nchunks = 0, S = 1;
   int64_t base = 0;
+  const T* __restrict__ valp = (const T*)p.val;
+  // chunk 0 sits at a slice-indexed address: its load is issued together with the header loads
+  int col0 = 0;
+  T val0 = 0;
+  if (slice < p.nslices) {
+    col0 = p.col[slice * 64 + lane];
+    val0 = valp[slice * 64 + lane];
+  }
   if (slice < p.nslices) {
     const int64_t slot = slice * R + g;
     row = p.slot_row[slot];
     len = p.slot_len[slot];
     const SliceHdr hd = p.slice_hdr[slice];
-    base = hd.ptr;
+    base = p.head + hd.ptr - 64;   // chunk k >= 1 at base + k*64
     nchunks = (p.ablate & 1) ? 0 : hd.nchunks;
     S = hd.S;
   }
   const int seg = g & (S - 1);            // S is a power of two
-  const T* __restrict__ valp = (const T*)p.val;
   const size_t lane_off = (size_t)c * 4 * sizeof(T);
   V4 acc = {0, 0, 0, 0};
   double accw = 0.0;
@@ -216,8 +224,13 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
     auto load_cv = [&](int k) -> CV {
       CV r;
       const int kc = k < nchunks ? k : nchunks - 1;
-      r.col = p.col[base + (int64_t)kc * 64 + lane];
-      r.val = valp[base + (int64_t)kc * 64 + lane];
+      if (kc <= 0) {          // (also the clamp target of a 1-chunk slice)
+        r.col = col0;
+        r.val = val0;
+      } else {
+        r.col = p.col[base + (int64_t)kc * 64 + lane];
+        r.val = valp[base + (int64_t)kc * 64 + lane];
+      }
       return r;
     };
     auto issue = [&](const CV& cv, int k, V4 (&x)[4], T (&v)[4]) {
@@ -295,8 +308,8 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
   } else {
     const int gbase = lane & ~(G - 1);
     for (int k = 0; k < nchunks; ++k) {
-      const int colv = p.col[base + (int64_t)k * 64 + lane];
-      const T valv = valp[base + (int64_t)k * 64 + lane];
+      const int colv = k == 0 ? col0 : p.col[base + (int64_t)k * 64 + lane];
+      const T valv = k == 0 ? val0 : valp[base + (int64_t)k * 64 + lane];
       const int j0 = k * G;
       for (int tb = 0; tb < G; tb += 4) {
         int cj[4];
@@ -440,6 +453,7 @@ int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
   p.slice_hdr = a.plan->d_slice_hdr;
   p.col = a.plan->d_col;
   p.val = a.plan->d_val;
+  p.head = a.plan->head;
   p.nslices = a.plan->nslices;
   p.nblocks = glx_spmm_blocks(a.plan);
   p.xin = (const char*)a.xin;

@@ -336,3 +336,39 @@ def test_next_rows_reweight_randomwalk_golden(gl, golden):
     assert np.array_equal(u, g['randomwalk_prob']) and np.array_equal(m.predict(), g['randomwalk_pred'])
     with pytest.raises(NotImplementedError):
         G.reweight(ti, method='properly', X=np.zeros((500, 2)))
+
+
+def test_prepared_sweep_reuse(gl, golden):
+    """A prepared glx_sweep reused across problems (different train sets, with and without bias):
+    captured launch graphs must not leak state from one problem into the next."""
+    from graphlearning_amd import _hip
+    from oracle import gl_oracle as orc
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    labels = g['labels']
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    dev, aux = m._operators()
+    n = W.shape[0]
+    sw = _hip.Sweep(dev, 10, min_iter=50, max_iter=1000, use_hipgraph=True)
+    for seed in (1, 2, 3):
+        ti = orc.trainsets_generate(labels, rate=2, seed=seed)
+        src, k = gl.ssl._poisson_source(n, ti, labels[ti])
+        v0 = np.zeros(n); v0[ti] = 1; v0 /= v0.sum()
+        sw.set_problem(aux['D'] * src, v0 / aux['deg'], aux['deg'], aux['vinf'])
+        for _ in range(2):                      # replaying the captured graph gives the same answer
+            T, _ = sw.run()
+            u_ref, T_ref = orc.poisson_gd(W, ti, labels[ti], return_T=True)
+            assert T == T_ref and np.array_equal(sw.fetch(), u_ref), seed
+    sw.close()
+    heat = _hip.Sweep(dev, 10, min_iter=0, max_iter=0, use_hipgraph=True)
+    rng = np.random.default_rng(0)
+    u0 = rng.normal(size=(n, 10)); Db = rng.normal(size=(n, 10))
+    P = aux['D'] * W.T
+    for bias in (None, Db, None):
+        heat.set_state(u0, bias)
+        heat.iterate(4)
+        ref = u0
+        for _ in range(4):
+            ref = P * ref if bias is None else P * ref + bias
+        assert np.array_equal(heat.fetch(), ref)
+    heat.close()
