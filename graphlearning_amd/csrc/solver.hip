@@ -13,6 +13,7 @@ static const int TAIL_CHUNK = 16;
 
 struct glx_sweep {
   glx_graph* P = nullptr;
+  int device = 0;   // copied from P: destruction must not touch the operator (it may already be gone)
   int C = 0, min_iter = 0, max_iter = 0;
   bool has_w = false, use_graph = false;
   RecLayout L;
@@ -39,7 +40,7 @@ static size_t rec_bytes(const glx_sweep* s, int64_t rows) { return (size_t)rows 
 
 extern "C" int glx_sweep_destroy(glx_sweep* s) {
   if (!s) return GLX_OK;
-  hipSetDevice(s->P->device);
+  hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->head_exec) hipGraphExecDestroy(s->head_exec);
   for (auto& kv : s->iter_exec) hipGraphExecDestroy(kv.second);
@@ -67,6 +68,7 @@ extern "C" int glx_sweep_create(glx_graph* P, int C, int min_iter, int max_iter,
   GLX_HIP(hipSetDevice(P->device));
   glx_sweep* s = new glx_sweep();
   s->P = P;
+  s->device = P->device;
   s->C = C;
   s->min_iter = min_iter;
   s->max_iter = max_iter;
