@@ -8,9 +8,10 @@ no distributed code: this is new functionality around the same sweep
     and cut into `world` contiguous row blocks; rank r owns block r of P, Db, u;
   * rank-local columns are renumbered [owned | halo], the halo being the distinct remote rows
     its block references, grouped by owner rank;
-  * every sweep: local sliced-ELL SpMM (HIP kernel on the rank's torch stream), then ONE
-    all_to_all_single of the boundary vertex records straight into the peers' halo regions
-    (xGMI is point-to-point: a direct exchange uses all links at once; no ring);
+  * the rank's rows are ordered boundary-first; every sweep: local sliced-ELL SpMM of the
+    boundary rows (HIP kernel on the rank's torch stream), then ONE all_to_all_single of the
+    boundary vertex records straight into the peers' halo regions (xGMI is point-to-point: a
+    direct exchange uses all links at once; no ring) while the SpMM of the interior rows runs;
   * the stop column rides inside the vertex record; the stop test is a scalar all_reduce(MAX),
     evaluated from sweep min_iter on.
 The ENTRY order inside every row is untouched by the partitioning, so the distributed iterates
@@ -43,7 +44,7 @@ class RankPlan:
     """What rank `rank` needs: its rows of P with columns renumbered [owned | halo] and the
     send / receive lists of the per-sweep exchange."""
 
-    def __init__(self, P, order, bounds, rank):
+    def __init__(self, P, order, bounds, rank, boundary_first=True):
         P = sparse.csr_matrix(P)
         n = P.shape[0]
         world = len(bounds) - 1
@@ -79,6 +80,18 @@ class RankPlan:
             send.append(mine - bounds[rank])                 # local row indices
             self.send_counts.append(len(mine))
         self.send_idx = np.concatenate(send) if send else np.zeros(0, dtype=np.int64)
+        # local row order: BOUNDARY rows (needed by some peer) first, interior rows after -- the
+        # boundary part of a sweep runs first, its records leave while the interior part computes
+        is_b = np.zeros(self.n_own, dtype=bool)
+        is_b[self.send_idx] = True
+        if not boundary_first:
+            is_b[:] = True
+        new_of_old = np.empty(self.n_own, dtype=np.int64)
+        perm_local = np.concatenate([np.flatnonzero(is_b), np.flatnonzero(~is_b)])
+        new_of_old[perm_local] = np.arange(self.n_own)
+        self.own = self.own[perm_local]
+        self.send_idx = new_of_old[self.send_idx]
+        self.n_boundary = int(is_b.sum())
         # local operator: rows = own, columns -> [0, n_own) owned, n_own + halo index otherwise
         local_of = np.full(n, -1, dtype=np.int64)
         local_of[self.own] = np.arange(self.n_own)
@@ -108,13 +121,21 @@ class HipOps:
         _assert_single_hip_runtime()
         self.lay = _hip.record_layout(C, self.dtype, True)
         self.ld = self.lay['ld']
-        self.graph = _hip.DeviceGraph(plan.P_local, dtype=self.dtype, device=device, shape=plan.P_local.shape,
-                                      keep_order=True)   # records stay in the partition's (RCM) order
-        n = _hip.C.c_int64(0)
-        _hip.check(_hip.load().glx_graph_slots(self.graph._h, C, 1, _hip.C.byref(n)), 'glx_graph_slots')
-        self.nslots = n.value
-        self.flags = torch.zeros(max(self.nslots, 1), dtype=torch.uint8, device=self.device)
-        self.err = torch.zeros(64, dtype=torch.int64, device=self.device)
+        # two operators over the same local vector: boundary rows [0, nb) and interior rows [nb, n_own)
+        nb = plan.n_boundary
+        self.parts = []
+        for lo, hi in ((0, nb), (nb, plan.n_own)):
+            if hi <= lo:
+                self.parts.append(None)
+                continue
+            sub = plan.P_local[lo:hi, :]
+            g = _hip.DeviceGraph(sub, dtype=self.dtype, device=device, shape=(hi - lo, plan.P_local.shape[1]),
+                                 keep_order=True)   # records stay in the partition's order
+            n = _hip.C.c_int64(0)
+            _hip.check(_hip.load().glx_graph_slots(g._h, C, 1, _hip.C.byref(n)), 'glx_graph_slots')
+            self.parts.append(dict(graph=g, lo=lo, hi=hi, flags=torch.zeros(max(n.value, 1), dtype=torch.uint8, device=self.device),
+                                   err=torch.zeros(64, dtype=torch.int64, device=self.device)))
+        self.rec_bytes = self.lay['rec_bytes']
         self.plan = plan
 
     def _stream(self):
@@ -150,29 +171,52 @@ class HipOps:
 
     def set_bias(self, bias_rec):
         self.bias = bias_rec
-        self._hip.check(self._hip.load().glx_bias_flags_dev(self.graph._h, self.C, 1, bias_rec.data_ptr(),
-                                                             self.flags.data_ptr(), self._stream()), 'glx_bias_flags_dev')
+        for part in self.parts:
+            if part is not None:
+                self._hip.check(self._hip.load().glx_bias_flags_dev(
+                    part['graph']._h, self.C, 1, bias_rec.data_ptr() + part['lo'] * self.rec_bytes, part['flags'].data_ptr(),
+                    self._stream()), 'glx_bias_flags_dev')
 
     def set_stop_vectors(self, deg, vinf):
         self.deg = self.to_device(deg, self.torch.float64)
         self.vinf = self.to_device(vinf, self.torch.float64)
 
-    def sweep(self, xin, xout, want_err):
+    def sweep_part(self, which, xin, xout, want_err):
+        """Rows of part `which` (0 = boundary, 1 = interior): xout[rows] = bias[rows] + P[rows] xin."""
+        part = self.parts[which]
+        if part is None:
+            return None
+        lo = part['lo']
         if want_err:
-            self.err.zero_()
+            part['err'].zero_()
         self._hip.check(self._hip.load().glx_sweep_step_dev(
-            self.graph._h, self.C, 1, xin.data_ptr(), xout.data_ptr(), self.bias.data_ptr(), self.flags.data_ptr(),
-            self.deg.data_ptr(), self.vinf.data_ptr(), self.err.data_ptr() if want_err else None, self._stream()),
-            'glx_sweep_step_dev')
+            part['graph']._h, self.C, 1, xin.data_ptr(), xout.data_ptr() + lo * self.rec_bytes,
+            self.bias.data_ptr() + lo * self.rec_bytes, part['flags'].data_ptr(), self.deg.data_ptr() + lo * 8,
+            self.vinf.data_ptr() + lo * 8, part['err'].data_ptr() if want_err else None, self._stream()), 'glx_sweep_step_dev')
         if want_err:   # fp64 bit patterns of non-negative values order like the values
-            return self.err.max().view(1).view(self.torch.float64)
+            return part['err'].max().view(1).view(self.torch.float64)
         return None
+
+    def sweep(self, xin, xout, want_err):
+        e0 = self.sweep_part(0, xin, xout, want_err)
+        e1 = self.sweep_part(1, xin, xout, want_err)
+        return combine_err(self.torch, e0, e1)
 
     def index_rows(self, rec, idx):
         return rec.index_select(0, idx)
 
     def close(self):
-        self.graph.close()
+        for part in self.parts:
+            if part is not None:
+                part['graph'].close()
+
+
+def combine_err(torch, e0, e1):
+    if e0 is None:
+        return e1
+    if e1 is None:
+        return e0
+    return torch.maximum(e0, e1)
 
 
 def _assert_single_hip_runtime():
@@ -210,23 +254,39 @@ class DistSweep:
         import os
         self._force_coll = os.environ.get('GLX_DIST_FORCE_COLLECTIVES') == '1'   # test hook: collectives at world 1
 
-    def exchange(self, x):
-        """Boundary records of x[0:n_own] -> the peers' halo regions x[n_own:]."""
+    def exchange(self, x, async_op=False):
+        """Boundary records of x[0:n_own] -> the peers' halo regions x[n_own:].  With async_op the
+        collective is only enqueued; the returned handle's wait() orders later work behind it."""
         p = self.plan
         if p.world == 1 and not self._force_coll:
-            return
+            return None
         send = self.ops.index_rows(x, self.send_idx)
         recv = x[p.n_own:]
+        self.exchanges += 1
         if self._stage_host:
             send_h = send.cpu()
             recv_h = self.torch.empty(recv.shape, dtype=recv.dtype)
             self.dist.all_to_all_single(recv_h, send_h, output_split_sizes=self.out_splits, input_split_sizes=self.in_splits,
                                         group=self.group)
             recv.copy_(recv_h)
-        else:
-            self.dist.all_to_all_single(recv, send, output_split_sizes=self.out_splits, input_split_sizes=self.in_splits,
-                                        group=self.group)
-        self.exchanges += 1
+            return None
+        work = self.dist.all_to_all_single(recv, send, output_split_sizes=self.out_splits, input_split_sizes=self.in_splits,
+                                           group=self.group, async_op=async_op)
+        return work if async_op else None
+
+    def step(self, xin, xout, want_err):
+        """One distributed sweep: boundary rows, start their exchange, interior rows meanwhile, join."""
+        ops = self.ops
+        if hasattr(ops, 'sweep_part'):
+            e0 = ops.sweep_part(0, xin, xout, want_err)
+            work = self.exchange(xout, async_op=True)
+            e1 = ops.sweep_part(1, xin, xout, want_err)
+            if work is not None:
+                work.wait()
+            return combine_err(self.torch, e0, e1)
+        e = ops.sweep(xin, xout, want_err)
+        self.exchange(xout)
+        return e
 
     def _all_reduce_max(self, e):
         if self._stage_host:
@@ -267,8 +327,7 @@ class DistSweep:
         e = None
         for T in range(nsweeps):
             want = (T + 1) >= min_iter
-            e = self.ops.sweep(bufs[self.cur], bufs[self.cur ^ 1], want)
-            self.exchange(bufs[self.cur ^ 1])
+            e = self.step(bufs[self.cur], bufs[self.cur ^ 1], want)
             if want and (self.plan.world > 1 or self._force_coll):
                 self._all_reduce_max(e)
             self.cur ^= 1
@@ -318,8 +377,7 @@ class DistSweep:
                     break
             xin, xout = bufs[self.cur], bufs[self.cur ^ 1]
             want = (T + 1) >= min_iter
-            e = ops.sweep(xin, xout, want)
-            self.exchange(xout)
+            e = self.step(xin, xout, want)
             if want:
                 if p.world > 1:
                     self._all_reduce_max(e)

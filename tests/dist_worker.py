@@ -49,6 +49,24 @@ class ScipyOps:
     def set_stop_vectors(self, deg, vinf):
         self.deg, self.vinf = np.asarray(deg), np.asarray(vinf)
 
+    def sweep_part(self, which, xin, xout, want_err):
+        nb = self.plan.n_boundary
+        lo, hi = (0, nb) if which == 0 else (nb, self.plan.n_own)
+        if hi <= lo:
+            return None
+        C = self.C
+        x = xin.numpy()
+        u = np.ascontiguousarray(x[:, :C])
+        w = np.ascontiguousarray(x[:, self.wcol])
+        Ps = self.P[lo:hi, :]
+        out = xout.numpy()
+        out[lo:hi, :C] = self.bias[lo:hi, :C] + Ps * u
+        wn = Ps * w
+        out[lo:hi, self.wcol] = wn
+        if want_err:
+            return torch.tensor([np.max(np.abs(self.deg[lo:hi] * wn - self.vinf[lo:hi]))], dtype=torch.float64)
+        return None
+
     def sweep(self, xin, xout, want_err):
         n_own, C = self.plan.n_own, self.C
         x = xin.numpy()
