@@ -13,6 +13,22 @@ GLX_F32, GLX_F64 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libglx.so')
 _lib = None
+_default_device = int(os.environ.get('GLX_DEVICE', '0'))
+
+
+def set_default_device(device):
+    """GPU used by every call that is not given an explicit `device` (one process per GPU: set it
+    to LOCAL_RANK once).  Initial value: $GLX_DEVICE or 0."""
+    global _default_device
+    _default_device = int(device)
+
+
+def default_device():
+    return _default_device
+
+
+def _dev(device):
+    return _default_device if device is None else int(device)
 
 
 class GlxError(RuntimeError):
@@ -135,13 +151,13 @@ class DeviceGraph:
     """A sparse operator resident in HBM (glx_graph).  `A` is any scipy sparse matrix;
     the CSR entry order is preserved (see include/glx.h)."""
 
-    def __init__(self, A, dtype=np.float64, device=0, shape=None, keep_order=False):
+    def __init__(self, A, dtype=np.float64, device=None, shape=None, keep_order=False):
         from scipy import sparse
         A = sparse.csr_matrix(A)
         self.dtype = np.dtype(dtype)
         self.shape = A.shape if shape is None else shape
         self.nnz = int(A.nnz)
-        self.device = device
+        self.device = device = _dev(device)
         rowptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
         col = np.ascontiguousarray(A.indices, dtype=np.int32)
         val = np.ascontiguousarray(A.data, dtype=np.float64)
@@ -273,7 +289,7 @@ def record_layout(Cc, dtype=np.float64, has_w=True):
     return dict(ld=out[0], woff=out[1], rec_bytes=out[2], G=out[3], nvec=out[4], esize=out[5])
 
 
-def argmax_project(prob, priors=None, weights=None, max_steps=0, similarity=True, device=0):
+def argmax_project(prob, priors=None, weights=None, max_steps=0, similarity=True, device=None):
     """ssl.predict / ssl.volume_label_projection on device.
     Returns (labels int64, weights, err, steps)."""
     prob = np.ascontiguousarray(prob, dtype=np.float64)
@@ -284,11 +300,11 @@ def argmax_project(prob, priors=None, weights=None, max_steps=0, similarity=True
     err = C.c_double(0)
     steps = C.c_int(0)
     check(load().glx_argmax_project(_ptr(prob), n, Cc, _ptr(pri), _ptr(w), _ptr(labels), C.byref(err), C.byref(steps),
-                                    int(max_steps), 1 if similarity else 0, device), 'glx_argmax_project')
+                                    int(max_steps), 1 if similarity else 0, _dev(device)), 'glx_argmax_project')
     return labels, w, err.value, steps.value
 
 
-def knn_bruteforce(X, k, similarity='euclidean', device=0, query_range=None):
+def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None):
     """Exact kNN (incl. self) on the GPU.  'angular' = euclidean on row-normalised data, formed
     with the reference's own expression (weightmatrix.py:344-345)."""
     X = np.asarray(X, dtype=np.float64)
@@ -301,7 +317,7 @@ def knn_bruteforce(X, k, similarity='euclidean', device=0, query_range=None):
     q0, q1 = (0, n) if query_range is None else query_range
     ind = np.empty((q1 - q0, k), dtype=np.int64)
     dist = np.empty((q1 - q0, k), dtype=np.float64)
-    check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, q0, q1, _ptr(ind), _ptr(dist), device),
+    check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
           'glx_knn_bruteforce')
     return ind, dist
 
@@ -309,7 +325,7 @@ def knn_bruteforce(X, k, similarity='euclidean', device=0, query_range=None):
 _KERNEL_ID = {'given': 0, 'uniform': 1, 'gaussian': 2, 'symgaussian': 3, 'distance': 4, 'singular': 5}
 
 
-def knn_to_csr(knn_ind, knn_dist, k, kernel='gaussian', sym=1, weights=None, device=0):
+def knn_to_csr(knn_ind, knn_dist, k, kernel='gaussian', sym=1, weights=None, device=None):
     """kNN data -> scipy CSR weight matrix, assembled on the GPU (glx_knn_to_csr)."""
     from scipy import sparse
     ind = np.ascontiguousarray(knn_ind, dtype=np.int64)
@@ -320,7 +336,7 @@ def knn_to_csr(knn_ind, knn_dist, k, kernel='gaussian', sym=1, weights=None, dev
     nnz = C.c_int64(0)
     lib = load()
     check(lib.glx_knn_to_csr(_ptr(ind), _ptr(dist), _ptr(w), n, kk, int(k), _KERNEL_ID[kernel], int(sym), C.byref(rp),
-                             C.byref(ci), C.byref(va), C.byref(nnz), device), 'glx_knn_to_csr')
+                             C.byref(ci), C.byref(va), C.byref(nnz), _dev(device)), 'glx_knn_to_csr')
     try:
         m = nnz.value
         indptr = np.ctypeslib.as_array(C.cast(rp, _i32p), shape=(n + 1,)).copy()

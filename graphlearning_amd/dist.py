@@ -109,13 +109,14 @@ class HipOps:
     """Rank-local sweep through libglx on torch CUDA tensors (device-pointer C-ABI)."""
     supports_graph = True
 
-    def __init__(self, plan, C, device, dtype=np.float64):
+    def __init__(self, plan, C, device=None, dtype=np.float64):
         import torch
         from . import _hip
         self.torch, self._hip = torch, _hip
         self.C = C
         self.dtype = np.dtype(dtype)
         self.tdtype = torch.float64 if self.dtype == np.float64 else torch.float32
+        device = _hip.default_device() if device is None else int(device)
         self.device = torch.device('cuda', device)
         self.devidx = device
         _assert_single_hip_runtime()
@@ -390,13 +391,14 @@ class DistSweep:
         return self.ops.unpack([self.xa, self.xb][self.cur], self.plan.n_own)
 
 
-def knnsearch_distributed(X, k, dist, device, similarity='euclidean', group=None):
+def knnsearch_distributed(X, k, dist, device=None, similarity='euclidean', group=None):
     """weightmatrix.knnsearch with the QUERY rows sharded over the ranks: every
     rank holds all of X, searches its contiguous block of queries on its own GPU
     (glx_knn_bruteforce_range) and the blocks are all_gathered -- the only communication."""
     import torch
     from . import _hip
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    device = _hip.default_device() if device is None else int(device)
     n = X.shape[0]
     bounds = block_bounds(n, world)
     ind, dst = _hip.knn_bruteforce(X, k, similarity=similarity, device=device,
@@ -422,9 +424,9 @@ def initial_error(w0, deg, vinf, dist=None, group=None, torch=None):
     """max |deg*w0 - vinf| over all vertices (needed only when min_iter == 0)."""
     e = float(np.max(np.abs(deg * w0 - vinf))) if len(w0) else 0.0
     if dist is not None and dist.get_world_size(group) > 1:
-        t = torch.tensor([e], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        e = float(t.item())
+        parts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(parts, e, group=group)     # backend-agnostic (a python float per rank)
+        e = max(parts)
     return e
 
 

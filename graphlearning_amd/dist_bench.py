@@ -24,6 +24,8 @@ def main(args):
     import bench
     import graphlearning_amd as gl
     from graphlearning_amd import _hip, dist as gdist
+    _hip.set_default_device(local_rank)        # every libglx call of this process uses this rank's GPU
+    dev = torch.device('cuda', local_rank)
 
     n = bench.N_PER_RANK * world
     labels = bench.load_labels(n)
@@ -47,17 +49,18 @@ def main(args):
     for _ in range(args.warmup):
         T = sweep.run(min_iter, max_iter)
     dist.barrier()
+    torch.cuda.set_device(local_rank)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         T = sweep.run(min_iter, max_iter)
     torch.cuda.synchronize()
     dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device='cuda')
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     wall = float(dt.item())
 
-    halo = torch.tensor([plan.n_halo, plan.n_own, int(plan.P_local.nnz)], dtype=torch.int64, device='cuda')
+    halo = torch.tensor([plan.n_halo, plan.n_own, int(plan.P_local.nnz)], dtype=torch.int64, device=dev)
     halos = [torch.zeros_like(halo) for _ in range(world)]
     dist.all_gather(halos, halo)
     if rank == 0:

@@ -45,7 +45,7 @@ class ssl:
             self.class_priors = self.class_priors / np.sum(self.class_priors)
         self.weights = 1
         self.class_priors_error = 1
-        self.device = 0
+        self.device = None      # None -> _hip.default_device() (set_default_device(LOCAL_RANK) in multi-GPU processes)
 
     def set_graph(self, W):
         if type(W) == graph_mod.graph:

@@ -40,7 +40,7 @@ def sparse_max(A, B):
     return A.multiply(a_wins) + B.multiply(b_wins)
 
 
-def conjgrad(A, b, x0=None, max_iter=1e5, tol=1e-10, dtype=np.float64, return_info=False, device=0):
+def conjgrad(A, b, x0=None, max_iter=1e5, tol=1e-10, dtype=np.float64, return_info=False, device=None):
     """Multi right-hand-side conjugate gradient, reference utils.py:483-532, on the GPU
     (glx_cg_multi).  Per-column alpha/beta, global stop sqrt(sum_cols ||r||^2) <= tol."""
     if x0 is not None:

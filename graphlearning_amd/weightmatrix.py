@@ -16,7 +16,7 @@ knn_dir = os.path.abspath(os.path.join(os.getcwd(), 'knn_data'))
 
 
 def knn(data, k, kernel='gaussian', eta=None, symmetrize=True, metric='raw', similarity='euclidean', knn_data=None,
-        device=0):
+        device=None):
     """kNN weight matrix, same signature and result as reference weightmatrix.py:68-187.
     Returns a scipy CSR (n,n) float64 matrix: symmetric (unless symmetrize=False), zero
     diagonal, canonical format."""
@@ -67,7 +67,7 @@ def knn(data, k, kernel='gaussian', eta=None, symmetrize=True, metric='raw', sim
     return _hip.knn_to_csr(knn_ind, knn_dist, k, kernel='given', sym=sym, weights=weights, device=device)
 
 
-def knnsearch(X, k, method=None, similarity='euclidean', dataset=None, metric='raw', device=0):
+def knnsearch(X, k, method=None, similarity='euclidean', dataset=None, metric='raw', device=None):
     """k nearest neighbours including the self point (reference weightmatrix.py:297-429).
     Every `method` the reference knows ('kdtree', 'brute', 'annoy', None) is served by the
     exact GPU search ('hip'); 'annoy' is approximate in the reference, exact here.
