@@ -53,13 +53,22 @@ __global__ void knn_prep_kernel(const double* __restrict__ X, const double* __re
 }
 
 // ---- stage 1: MFMA tile kernel -------------------------------------------------------------
-template <int DH, int KP, int NSUB>
+// KBLK = false: the whole (padded) feature vector of a query lives in registers (DH features per
+// half, d + 2 <= 2*DH <= 132).  KBLK = true (any d): the features are processed in nkb blocks of
+// DH per half; each step stages one feature block of the ref tile into LDS, reloads the lane's
+// query fragment for that block (prefetched one step ahead) and accumulates into the same MFMA
+// accumulators; the selection runs after the last block of a tile.
+template <int DH, int KP, int NSUB, bool KBLK>
 __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__ Rf, const float* __restrict__ Qf, int64_t n,
                                                        int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d,
-                                                       int* __restrict__ cand_i, int ablate) {
+                                                       int* __restrict__ cand_i, int ablate, int nkb_arg) {
+  static_assert(!KBLK || DH % 4 == 0, "blocked variant loads the query fragment as float4");
   constexpr int DPA = 2 * DH;
   constexpr int BR = 32 * NSUB;
   constexpr int STRIDE = (DH % 2 == 1) ? DPA : DPA + 2;   // floats; ds_read_b64 of 32 rows hits 64 distinct banks
+  const int nkb = KBLK ? nkb_arg : 1;
+  const int DHT = DH * nkb;                            // features per half over all blocks
+  const int64_t dpa = 2 * (int64_t)DHT;                // row stride of Rf / Qf
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tile = smem;                                  // [2][BR][STRIDE]
   float* ld = smem + 2 * BR * STRIDE;                  // [KP + KBUF][256]: the lane's KP best so far, then append slots
@@ -69,32 +78,48 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
   const int64_t qb = blockIdx.x, sp = blockIdx.y;
   const int64_t q = q_begin + qb * BQ + wave * 32 + j;   // this lane's query
   const int64_t qc = q < q_end ? q : q_end - 1;
-  // query fragment: B[k = h][j] for k-step s is feature h*DH + s
+  // query fragment: B[k = h][j] for k-step s of feature block kb is feature h*DHT + kb*DH + s
   float bq[DH];
+  float bqn[KBLK ? DH : 1];
+  const float* qrow = Qf + qc * dpa + (int64_t)h * DHT;
+  auto load_bq_next = [&](int kb) {
+    if constexpr (KBLK) {
 #pragma unroll
-  for (int s = 0; s < DH; ++s) bq[s] = Qf[qc * DPA + h * DH + s];
+      for (int s = 0; s < DH; s += 4) {
+        const float4 v = *(const float4*)(qrow + kb * DH + s);
+        bqn[s] = v.x; bqn[s + 1] = v.y; bqn[s + 2] = v.z; bqn[s + 3] = v.w;
+      }
+    }
+  };
+  if constexpr (!KBLK) {
+#pragma unroll
+    for (int s = 0; s < DH; ++s) bq[s] = qrow[s];
+  }
 #pragma unroll
   for (int p = 0; p < KP; ++p) { ld[p * 256 + tid] = INFINITY; li[p * 256 + tid] = -1; }
   float tau = INFINITY;
 
   const int64_t ntiles = (n + BR - 1) / BR;
   const int64_t t0 = ntiles * sp / nsplit, t1 = ntiles * (sp + 1) / nsplit;
-  // staging split in two (issue early / write late): the global loads of tile t+1 are issued
-  // before the MFMAs of tile t and land in LDS only after them, so their latency hides
+  // staging split in two (issue early / write late): the global loads of step u+1 are issued
+  // before the MFMAs of step u and land in LDS only after them, so their latency hides
   // under the matrix work instead of stalling the wavefront in front of it.
-  constexpr int UNITS = (BR * DH + 255) / 256;   // float2 units per thread per tile
+  constexpr int UNITS = (BR * DH + 255) / 256;   // float2 units per thread per step
   float2 pre[UNITS];
-  auto stage_load = [&](int64_t t) {
-    // BR rows x DH float2 units; rows beyond n become "infinitely far" refs
+  auto stage_load = [&](int64_t t, int kb) {
+    // BR rows x DH float2 units (DH/2 per half when blocked); rows beyond n become "infinitely far" refs
 #pragma unroll
     for (int i = 0; i < UNITS; ++i) {
       const int u = tid + i * 256;
       const int r = u / DH, f2 = u % DH;
       const int64_t ref = t * BR + r;
       float2 v;
-      v.x = (f2 == DH - 1) ? 1e30f : 0.f;   // norm slot (feature DPA-2) of a padding ref
+      v.x = (f2 == DH - 1 && kb == nkb - 1) ? 1e30f : 0.f;   // norm slot (feature dpa-2) of a padding ref
       v.y = 0.f;
-      if (u < BR * DH && ref < n) v = *(const float2*)(Rf + ref * DPA + 2 * f2);
+      if (u < BR * DH && ref < n) {
+        if constexpr (KBLK) v = *(const float2*)(Rf + ref * dpa + (int64_t)(f2 / (DH / 2)) * DHT + kb * DH + 2 * (f2 % (DH / 2)));
+        else v = *(const float2*)(Rf + ref * DPA + 2 * f2);
+      }
       pre[i] = v;
     }
   };
@@ -141,17 +166,29 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
     // min over all lists of the final thresholds, is unaffected)
     tau = share_tau ? fminf(tau_own, __shfl_xor(tau_own, 32)) : tau_own;
   };
-  if (t0 < t1) { stage_load(t0); stage_store(0); }
+  if (t0 < t1) { stage_load(t0, 0); stage_store(0); load_bq_next(0); }
   __syncthreads();
-  for (int64_t t = t0; t < t1; ++t) {
-    const int buf = (int)((t - t0) & 1);
-    if (t + 1 < t1) stage_load(t + 1);
+  int buf = 0;
+  f32x16 acc[NSUB];
+  for (int64_t t = t0; t < t1; ++t)
+  for (int kb = 0; kb < nkb; ++kb) {
+    const bool last_kb = kb == nkb - 1;
+    const bool has_next = !(last_kb && t + 1 == t1);
+    if constexpr (KBLK) {
+#pragma unroll
+      for (int s = 0; s < DH; ++s) bq[s] = bqn[s];
+    }
+    if (has_next) {
+      stage_load(last_kb ? t + 1 : t, last_kb ? 0 : kb + 1);
+      load_bq_next(last_kb ? 0 : kb + 1);
+    }
     const float* tl = tile + buf * BR * STRIDE;
-    f32x16 acc[NSUB];
+    if (kb == 0) {
 #pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub)
+      for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[sub][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[sub][e] = 0.f;
+    }
 #pragma unroll
     for (int s = 0; s < DH; s += 2) {
 #pragma unroll
@@ -161,6 +198,7 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
         if (s + 1 < DH) acc[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[s + 1], acc[sub], 0, 0, 0);
       }
     }
+    if (last_kb) {
     // selection: acc[sub][e] = dist^2(query j, ref sub*32 + (e&3) + 8*(e>>2) + 4*h).
     // Candidates below the lane's threshold are APPENDED to the lane's LDS slots (cheap, even
     // when only a few lanes have one); when any lane's slots run low the whole wavefront
@@ -191,8 +229,10 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
         }
       }
     }
-    if (t + 1 < t1) stage_store(buf ^ 1);
+    }   // last_kb
+    if (has_next) stage_store(buf ^ 1);
     __syncthreads();
+    buf ^= 1;
   }
   compact();
   if (q < q_end) {
@@ -334,6 +374,9 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(const double* __restr
   }
 }
 
+// features per half per block of the blocked (d > 130) variant; 16 where the KP = 64 lists leave less LDS
+constexpr int knn_kb(int KP) { return KP == 64 ? 16 : 32; }
+
 // refs per tile = 32*NSUB, as many as fit LDS (160 KiB) beside the candidate lists
 constexpr int tile_nsub(int DH, int KP) {
   const int stride = 2 * DH + 2;
@@ -360,23 +403,24 @@ struct KnnBufs {
   }
 };
 
-template <int DH, int KP>
-static int launch_tile(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st) {
+template <int DH, int KP, bool KBLK = false>
+static int launch_tile(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st, int nkb = 1) {
   constexpr int DPA = 2 * DH;
   constexpr int STRIDE = (DH % 2 == 1) ? DPA : DPA + 2;
   constexpr int NSUB = tile_nsub(DH, KP);
   const size_t shm = (size_t)2 * 32 * NSUB * STRIDE * 4 + (size_t)(KP + KBUF) * 256 * 8;
   GLX_CHECK(shm <= 160 * 1024, GLX_EUNSUPPORTED, "glx_knn_bruteforce: this (d, k) needs %zu bytes of LDS per workgroup (160 KiB available)", shm);
-  GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_kernel<DH, KP, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_kernel<DH, KP, NSUB, KBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)nsplit);
-  hipLaunchKernelGGL((knn_tile_kernel<DH, KP, NSUB>), grid, dim3(256), shm, st, (const float*)b.Rf, (const float*)b.Qf, n, q0, q1, nsplit,
-                     b.cand_d, b.cand_i, getenv("GLX_KNN_ABLATE") ? atoi(getenv("GLX_KNN_ABLATE")) : 0);
+  hipLaunchKernelGGL((knn_tile_kernel<DH, KP, NSUB, KBLK>), grid, dim3(256), shm, st, (const float*)b.Rf, (const float*)b.Qf, n, q0, q1,
+                     nsplit, b.cand_d, b.cand_i, getenv("GLX_KNN_ABLATE") ? atoi(getenv("GLX_KNN_ABLATE")) : 0, nkb);
   GLX_HIP(hipGetLastError());
   return GLX_OK;
 }
 
 template <int KP>
-static int launch_tile_dh(int DH, const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st) {
+static int launch_tile_dh(int DH, int nkb, const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st) {
+  if (nkb > 1) return launch_tile<knn_kb(KP), KP, true>(b, n, q0, q1, nsplit, st, nkb);
   switch (DH) {
     case 8: return launch_tile<8, KP>(b, n, q0, q1, nsplit, st);
     case 12: return launch_tile<12, KP>(b, n, q0, q1, nsplit, st);
@@ -395,15 +439,20 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   GLX_CHECK(n < (1ll << 31) - BR_MAX, GLX_EINVAL, "glx_knn_bruteforce: n must fit int32");
   GLX_CHECK(0 <= q0 && q0 <= q1 && q1 <= n, GLX_EINVAL, "glx_knn_bruteforce: bad query range");
   GLX_CHECK(k <= 60, GLX_EUNSUPPORTED, "glx_knn_bruteforce: k=%d (incl. self) above the supported 60", k);
-  GLX_CHECK(d <= 130, GLX_EUNSUPPORTED, "glx_knn_bruteforce: d=%d above the supported 130", d);
+  GLX_CHECK(d <= 16382, GLX_EUNSUPPORTED, "glx_knn_bruteforce: d=%d above the supported 16382", d);
   const int64_t nq = q1 - q0;
   if (nq == 0) return GLX_OK;
   GLX_HIP(hipSetDevice(device));
-  int DH = 8;
-  for (int cand : {8, 12, 18, 34, 66})
-    if (2 * cand >= d + 2) { DH = cand; break; }
-  const int dpa = 2 * DH;
+  // d + 2 <= 132: the query's features stay in registers; above that the feature dimension is blocked
   const int KP = k <= 12 ? 16 : (k <= 28 ? 32 : 64);
+  int DH = knn_kb(KP), nkb = 1;
+  if (d + 2 <= 132 && !(KP == 64 && d + 2 > 36)) {   // (KP = 64 lists + a wide double-buffered tile exceed the LDS)
+    for (int cand : {8, 12, 18, 34, 66})
+      if (2 * cand >= d + 2) { DH = cand; break; }
+  } else {
+    nkb = (d + 2 + 2 * DH - 1) / (2 * DH);
+  }
+  const int dpa = 2 * DH * nkb;
   const int64_t nqb = (nq + BQ - 1) / BQ;
   const int BR = 32 * tile_nsub(DH, KP);
   const int64_t ntiles = (n + BR - 1) / BR;
@@ -456,9 +505,9 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
                      n, d, dpa, b.Rf, b.Qf, b.qnorm);
   GLX_HIP(hipGetLastError());
   int rc;
-  if (KP == 16) rc = launch_tile_dh<16>(DH, b, n, q0, q1, nsplit, st);
-  else if (KP == 32) rc = launch_tile_dh<32>(DH, b, n, q0, q1, nsplit, st);
-  else rc = launch_tile_dh<64>(DH, b, n, q0, q1, nsplit, st);
+  if (KP == 16) rc = launch_tile_dh<16>(DH, nkb, b, n, q0, q1, nsplit, st);
+  else if (KP == 32) rc = launch_tile_dh<32>(DH, nkb, b, n, q0, q1, nsplit, st);
+  else rc = launch_tile_dh<64>(DH, nkb, b, n, q0, q1, nsplit, st);
   if (rc) return rc;
   GLX_HIP(hipEventRecord(b.e1, st));
   hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)nq), dim3(64), (size_t)M * 12, st, (const double*)b.X, n, d, k, q0, nq,

@@ -135,7 +135,8 @@ int glx_argmax_project(const double* prob, int64_t n, int C, const double* prior
  * with an exactness check and fp64 fallback).  k counts the self point.  X (n,d) fp64
  * host.  similarity must be 0 (euclidean); angular = euclidean on rows the caller normalised
  * (the Python boundary does that with the reference's own expression).  ind_out (n,k) int64, dist_out (n,k)
- * fp64, rows ascending by (distance, index).  Limits: d <= 130; k <= 28 (k <= 60 when d <= 34). */
+ * fp64, rows ascending by (distance, index).  Limits: k <= 60 (self included), d <= 16382; for d > 130 (or k > 28 with
+ * d > 34) the candidate filter blocks the feature dimension instead of keeping the query in registers. */
 int glx_knn_bruteforce(const double* X, int64_t n, int d, int k, int similarity,
                        int64_t* ind_out, double* dist_out, int device);
 /* same search restricted to the query rows [q_begin, q_end) (rank-local share when the queries are

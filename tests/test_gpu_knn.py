@@ -44,7 +44,9 @@ def test_knnsearch_edge_cases(gl):
     from graphlearning_amd import _hip
     rng = np.random.default_rng(0)
     # tiny inputs, k == n, ragged tile (n not a multiple of 128), duplicates
-    for n, d, k in [(1, 3, 1), (5, 2, 5), (129, 7, 4), (300, 33, 27), (200, 130, 3), (400, 10, 45), (150, 30, 60)]:
+    for n, d, k in [(1, 3, 1), (5, 2, 5), (129, 7, 4), (300, 33, 27), (200, 130, 3), (400, 10, 45), (150, 30, 60),
+                    # feature-blocked variant (d > 130, or k > 28 with d > 34)
+                    (500, 131, 5), (700, 200, 11), (1000, 784, 11), (300, 300, 40), (150, 64, 60), (257, 1000, 20)]:
         X = rng.normal(size=(n, d))
         ind, dist = _hip.knn_bruteforce(X, k)
         D2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
@@ -57,8 +59,8 @@ def test_knnsearch_edge_cases(gl):
     assert np.all(np.sort(ind[:, :3], axis=1) == (np.arange(120) // 3 * 3)[:, None] + np.arange(3))
     with pytest.raises(_hip.GlxError):
         _hip.knn_bruteforce(X, 1000)
-    with pytest.raises(_hip.GlxError):          # k > 28 with d > 34 does not fit the LDS candidate lists
-        _hip.knn_bruteforce(rng.normal(size=(150, 64)), 60)
+    with pytest.raises(_hip.GlxError):          # k (incl. self) above 60
+        _hip.knn_bruteforce(rng.normal(size=(150, 8)), 61)
     with pytest.raises(SystemExit):
         gl.weightmatrix.knnsearch(X, 3, similarity='manhattan')
 
