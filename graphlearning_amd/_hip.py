@@ -78,6 +78,7 @@ _SIGNATURES = {
     'glx_unpack_records_dev': [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp],
     'glx_cg_multi': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), _f64p],
     'glx_cg_solve': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
+    'glx_cg_groups': [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_argmax_project': [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
     'glx_knn_bruteforce': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
     'glx_knn_bruteforce_range': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
@@ -211,6 +212,18 @@ class DeviceGraph:
         check(load().glx_cg_solve(self._h, _ptr(B), _ptr(X), B.shape[1], float(tol), int(max_iter), 1 if squeeze else 0,
                                   C.byref(it), C.byref(err)), 'glx_cg_solve')
         return (X[:, 0] if squeeze else X), it.value, err.value
+
+    def cg_groups(self, B, group_cols, tol=1e-10, max_iter=100000):
+        """Independent systems side by side (columns in groups of `group_cols`), each with its own
+        stop test: returns (X, iterations per group, err per group)."""
+        B = np.ascontiguousarray(B, dtype=self.dtype)
+        ng = B.shape[1] // group_cols
+        X = np.empty_like(B)
+        its = np.zeros(ng, dtype=np.int32)
+        errs = np.zeros(ng, dtype=np.float64)
+        check(load().glx_cg_groups(self._h, _ptr(B), _ptr(X), B.shape[1], int(group_cols), float(tol), int(max_iter), 0,
+                                   its.ctypes.data_as(C.POINTER(C.c_int)), errs.ctypes.data_as(_f64p)), 'glx_cg_groups')
+        return X, its, errs
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:

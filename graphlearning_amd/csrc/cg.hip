@@ -8,6 +8,7 @@
 #include "glx_internal.h"
 #include <string.h>
 #include <algorithm>
+#include <vector>
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -17,17 +18,31 @@ template <> struct V4Of<float> { typedef f32x4 type; };
 template <> struct V4Of<double> { typedef f64x4 type; };
 
 static const int CG_CHUNK = 8;
+static const int SEQ_COLS = 16;   // columns per workgroup of the reference-order reducer
 static const int UPD_ROWS_PER_BLOCK = 256;
 
+// The C columns may hold several independent systems side by side ("groups" of Cg columns: the
+// trials of ssl.ssl_trials, ssl.py:292-396, stacked on one operator).  Every group has its own
+// residual norm, stop test and iteration count, exactly as if it had been solved alone; a group
+// that has converged is frozen (no further updates of its columns) while the others run on.
 struct CgScalars {
   double* rsold;     // [ncols]
   double* alpha;     // [ncols]
   double* beta;      // [ncols]
-  double* err_hist;  // [max_hist+1], err_hist[0] = 1 (utils.py:519)
+  double* err_hist;  // [max_hist+1][stride]: per group, then the maximum over the groups still running;
+                     // row 0 = 1 (utils.py:519), unwritten rows = 0 (= stopped)
+  int stride;        // ngroups + 1
+  int ngroups;
+  int Cg;            // columns per group
+  int C;             // ngroups * Cg
 };
 
-__device__ __forceinline__ bool cg_done(const double* err_hist, int it, double tol) {
-  return !(err_hist[it - 1] > tol);   // `while (err > tol)`, utils.py:521 (NaN stops the loop too)
+// `while (err > tol)`, utils.py:521 (NaN stops the loop too): does iteration `it` run for ...
+__device__ __forceinline__ bool cg_any_active(const CgScalars& sc, int it, double tol) {   // ... any group
+  return sc.err_hist[(size_t)(it - 1) * sc.stride + sc.ngroups] > tol;
+}
+__device__ __forceinline__ bool cg_col_active(const CgScalars& sc, int it, double tol, int col) {   // ... this column's group
+  return col < sc.C && sc.err_hist[(size_t)(it - 1) * sc.stride + col / sc.Cg] > tol;
 }
 
 // x += alpha p ; r -= alpha Ap ; partial[b][c] = sum_rows r^2           (utils.py:525-527)
@@ -36,11 +51,11 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void cg_update_kernel(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
                                                         const T* __restrict__ Ap, const double* __restrict__ alpha,
                                                         double* __restrict__ partial, int64_t n, int ld, int nvec,
-                                                        const double* err_hist, int it, double tol,
+                                                        const CgScalars sc, int it, double tol,
                                                         double* __restrict__ prod_out, const int32_t* __restrict__ perm) {
 #pragma clang fp contract(off)
   typedef typename V4Of<T>::type V4;
-  if (MODE == 0 && cg_done(err_hist, it, tol)) return;
+  if (MODE == 0 && !cg_any_active(sc, it, tol)) return;
   __shared__ double s_part[256 * 4];
   const int nvq = ld / 4;
   const int rows_pass = 256 / nvq;
@@ -48,13 +63,19 @@ __global__ __launch_bounds__(256) void cg_update_kernel(T* __restrict__ x, T* __
   const bool on = rs < rows_pass && cv < nvec;
   double acc[4] = {0, 0, 0, 0};
   V4 a = {0, 0, 0, 0};
+  bool act[4] = {true, true, true, true};
+  bool on_any = on;
   if (MODE == 0 && on) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) a[e] = (T)alpha[cv * 4 + e];
+    for (int e = 0; e < 4; ++e) {
+      a[e] = (T)alpha[cv * 4 + e];
+      act[e] = cg_col_active(sc, it, tol, cv * 4 + e);
+    }
+    on_any = act[0] || act[1] || act[2] || act[3];   // all four columns converged: nothing to read or write
   }
   const int64_t r0 = (int64_t)blockIdx.x * UPD_ROWS_PER_BLOCK;
   const int64_t r1 = min(n, r0 + UPD_ROWS_PER_BLOCK);
-  if (on) {
+  if (on_any) {
     for (int64_t row = r0 + rs; row < r1; row += rows_pass) {
       const size_t o = (size_t)row * ld + cv * 4;
       V4 rv = *(const V4*)(r + o);
@@ -63,17 +84,24 @@ __global__ __launch_bounds__(256) void cg_update_kernel(T* __restrict__ x, T* __
         const V4 apv = *(const V4*)(Ap + o);
         V4 xv = *(const V4*)(x + o);
         const V4 t1 = a * pv;
-        xv = xv + t1;
+        const V4 xn = xv + t1;
         const V4 t2 = a * apv;
-        rv = rv - t2;
+        const V4 rn = rv - t2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {   // columns of a converged group keep their values
+          xv[e] = act[e] ? xn[e] : xv[e];
+          rv[e] = act[e] ? rn[e] : rv[e];
+        }
         *(V4*)(x + o) = xv;
         *(V4*)(r + o) = rv;
       }
-      if (prod_out) {   // r*r in the array dtype, column-major in the caller's row order
+      if (prod_out) {   // r*r in the array dtype, row-major (nvec*4 columns) in the caller's row order
         const V4 sq = rv * rv;
         const int64_t orow = perm ? perm[row] : row;
+        f64x4 sd;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) prod_out[(size_t)(cv * 4 + e) * n + orow] = (double)sq[e];
+        for (int e = 0; e < 4; ++e) sd[e] = (double)sq[e];
+        *(f64x4*)(prod_out + (size_t)orow * (nvec * 4) + cv * 4) = sd;
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -97,16 +125,20 @@ __global__ __launch_bounds__(256) void cg_update_kernel(T* __restrict__ x, T* __
 template <typename T>
 __global__ __launch_bounds__(256) void cg_pupdate_kernel(const T* __restrict__ r, T* __restrict__ p,
                                                          const double* __restrict__ beta, int64_t n, int ld, int nvec,
-                                                         const double* err_hist, int it, double tol, int) {
+                                                         const CgScalars sc, int it, double tol, int) {
 #pragma clang fp contract(off)
   typedef typename V4Of<T>::type V4;
   // this kernel belongs to iteration `it`: it runs iff the iteration ran
-  if (cg_done(err_hist, it, tol)) return;
+  if (!cg_any_active(sc, it, tol)) return;
   const int nvq = ld / 4;
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t row = v / nvq;
   const int cv = (int)(v % nvq);
   if (row >= n || cv >= nvec) return;
+  bool any = false;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) any = any || cg_col_active(sc, it, tol, cv * 4 + e);
+  if (!any) return;
   V4 b;
 #pragma unroll
   for (int e = 0; e < 4; ++e) b[e] = (T)beta[cv * 4 + e];
@@ -114,20 +146,22 @@ __global__ __launch_bounds__(256) void cg_pupdate_kernel(const T* __restrict__ r
   const V4 rv = *(const V4*)(r + o);
   const V4 pv = *(const V4*)(p + o);
   const V4 t = b * pv;
-  *(V4*)(p + o) = rv + t;
+  V4 pn = rv + t;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) pn[e] = cg_col_active(sc, it, tol, cv * 4 + e) ? pn[e] : pv[e];
+  *(V4*)(p + o) = pn;
 }
 
 // single-block fixed-order column reduction of partial[nb][ncols]
 // MODE 0: alpha = rsold / sum (utils.py:524)
-// MODE 1: rsnew = sum; err = sqrt(sum_c rsnew); beta = rsnew/rsold; rsold = rsnew (utils.py:527-530)
+// MODE 1: rsnew = sum; beta = rsnew/rsold; rsold = rsnew (utils.py:527-530; err: cg_group_err_kernel)
 // MODE 2: rsold = sum (utils.py:517)
 template <int MODE>
 __global__ __launch_bounds__(256) void cg_reduce_kernel(const double* __restrict__ partial, int64_t nb, int ncols, int C,
                                                         CgScalars sc, int it, double tol) {
 #pragma clang fp contract(off)
-  if (MODE != 2 && cg_done(sc.err_hist, it, tol)) return;
+  if (MODE != 2 && !cg_any_active(sc, it, tol)) return;
   __shared__ double s_sum[256];
-  __shared__ double s_col[256];
   int cp = 1;
   while (cp < ncols) cp *= 2;
   const int nparts = 256 / cp;
@@ -144,23 +178,56 @@ __global__ __launch_bounds__(256) void cg_reduce_kernel(const double* __restrict
     double tot = 0.0;
     for (int q = 0; q < nparts; ++q) tot += s_sum[q * cp + threadIdx.x];
     const int cc = threadIdx.x;
-    if (MODE == 0) {
+    const bool live = MODE == 2 || cc >= C || cg_col_active(sc, it, tol, cc);
+    if (!live) {
+    } else if (MODE == 0) {
       sc.alpha[cc] = cc < C ? sc.rsold[cc] / tot : 0.0;
     } else if (MODE == 1) {
       sc.beta[cc] = cc < C ? tot / sc.rsold[cc] : 0.0;
       sc.rsold[cc] = tot;
-      s_col[cc] = cc < C ? tot : 0.0;
     } else {
       sc.rsold[cc] = tot;
     }
   }
-  if (MODE == 1) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double e = 0.0;
-      for (int q = 0; q < C; ++q) e += s_col[q];
-      sc.err_hist[it] = sqrt(e);
+}
+
+// err_g = np.sqrt(np.sum(rsnew_g)) for every group still running (utils.py:528), then the
+// maximum over those groups (what the kernels of the next iteration test).  np.sum over a
+// contiguous 1-D float64 array is numpy's pairwise_sum: 8 accumulators below 128 elements, a plain
+// loop below 8 (Cg <= 128 here).  One thread per group.
+__global__ __launch_bounds__(256) void cg_group_err_kernel(CgScalars sc, int it, double tol) {
+#pragma clang fp contract(off)
+  if (!cg_any_active(sc, it, tol)) return;
+  __shared__ double s_e[256];
+  const int g = threadIdx.x;
+  double mine = 0.0;
+  if (g < sc.ngroups && cg_col_active(sc, it, tol, g * sc.Cg)) {
+    const double* a = sc.rsold + (size_t)g * sc.Cg;
+    const int C = sc.Cg;
+    double e;
+    if (C < 8) {
+      e = 0.0;
+      for (int q = 0; q < C; ++q) e = e + a[q];
+    } else {
+      double r8[8];
+      for (int q = 0; q < 8; ++q) r8[q] = a[q];
+      int i = 8;
+      for (; i < C - (C % 8); i += 8)
+        for (int q = 0; q < 8; ++q) r8[q] = r8[q] + a[i + q];
+      e = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+      for (; i < C; ++i) e = e + a[i];
     }
+    mine = sqrt(e);
+    sc.err_hist[(size_t)it * sc.stride + g] = mine;
+  }
+  s_e[threadIdx.x] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // a NaN error stops its own group (`nan > tol` is false) and must not keep the others alive
+    double m = 0.0;
+    for (int q = 0; q < sc.ngroups; ++q)
+      if (s_e[q] > m) m = s_e[q];
+    sc.err_hist[(size_t)it * sc.stride + sc.ngroups] = m;
   }
 }
 
@@ -170,24 +237,32 @@ __global__ __launch_bounds__(256) void cg_reduce_kernel(const double* __restrict
 // Reproducing it makes the whole CG bit-identical to the reference (iteration count
 // included) -- necessary because the Poisson system is singular and 100+ CG iterations
 // amplify any reordering far beyond 1e-5.  The elementwise products are formed in parallel
-// by the producing kernels (SpMM epilogue / r-update) into a column-major array in the
-// caller's row order; here one wavefront, lane c = column c, streams its contiguous column
-// 32 rows at a time -- only the add chain is serial.
+// by the producing kernels (SpMM epilogue / r-update) into a row-major array in the
+// caller's row order; here one wavefront per 16 columns, lane c = column c, adds up its column
+// row after row -- only the add chain is serial.
 // MODE 0: tot = sum p*Ap ; alpha = rsold / tot                                (utils.py:524)
 // MODE 1: tot = sum r*r  ; beta = tot / rsold ; rsold = tot ; err = sqrt(np.sum(tot)) (:527-530)
 // MODE 2: rsold = sum r*r                                                     (utils.py:517)
-// One workgroup: all 256 threads stream the next tile of the column-major product array into
+// One workgroup: all 256 threads stream the next tile of the row-major product array into
 // registers (coalesced) while wavefront 0 -- lane c = column c -- adds up the current tile from
 // LDS in row order; the registers are then written to the other LDS buffer.  Only the add chain
 // is serial, the memory latency hides under it.
 template <int MODE>
-__global__ __launch_bounds__(256) void cg_seqsum_kernel(const double* __restrict__ prod, int64_t n, int ncols, int C, CgScalars sc,
-                                                        int it, double tol, int TR) {
+__global__ __launch_bounds__(256) void cg_seqsum_kernel(const double* __restrict__ prod_all, int64_t n, int ncols_all, int C,
+                                                        CgScalars sc, int it, double tol, int TR) {
 #pragma clang fp contract(off)
-  if (MODE != 2 && cg_done(sc.err_hist, it, tol)) return;
+  if (MODE != 2 && !cg_any_active(sc, it, tol)) return;
   extern __shared__ __attribute__((aligned(16))) double s_tile[];   // [2][ncols][TR + 1]
-  __shared__ double s_col[64];
   const int tid = threadIdx.x;
+  // workgroup b reduces columns [SEQ_COLS b, SEQ_COLS (b + 1))
+  const int col0 = blockIdx.x * SEQ_COLS;
+  const int ncols = min(SEQ_COLS, ncols_all - col0);
+  const double* __restrict__ prod = prod_all + col0;   // row-major, ncols_all columns
+  if (MODE != 2) {   // nothing to do if every group with a column here has converged
+    bool any = false;
+    for (int cc = col0; cc < col0 + ncols; cc += 1) any = any || cg_col_active(sc, it, tol, cc);
+    if (!any) return;
+  }
   const int LDT = TR + 1;                       // +1: lanes of one read hit different banks
   const int per = (TR * ncols + 255) / 256;     // elements per thread per tile (<= 24)
   double reg[24];
@@ -197,8 +272,8 @@ __global__ __launch_bounds__(256) void cg_seqsum_kernel(const double* __restrict
       const int idx = tid + q * 256;
       double v = 0.0;
       if (q < per && idx < TR * ncols) {
-        const int cc = idx / TR, r = idx % TR;
-        if (base + r < n) v = prod[(size_t)cc * n + base + r];
+        const int r = idx / ncols, cc = idx % ncols;
+        if (base + r < n) v = prod[(size_t)(base + r) * ncols_all + cc];
       }
       reg[q] = v;
     }
@@ -207,7 +282,7 @@ __global__ __launch_bounds__(256) void cg_seqsum_kernel(const double* __restrict
 #pragma unroll
     for (int q = 0; q < 24; ++q) {
       const int idx = tid + q * 256;
-      if (q < per && idx < TR * ncols) s_tile[(size_t)buf * ncols * LDT + (idx / TR) * LDT + (idx % TR)] = reg[q];
+      if (q < per && idx < TR * ncols) s_tile[(size_t)buf * ncols * LDT + (idx % ncols) * LDT + (idx / ncols)] = reg[q];
     }
   };
   const int c = tid;
@@ -237,35 +312,16 @@ __global__ __launch_bounds__(256) void cg_seqsum_kernel(const double* __restrict
     buf ^= 1;
   }
   if (c < ncols) {
-    if (MODE == 0) {
-      sc.alpha[c] = c < C ? sc.rsold[c] / tot : 0.0;
+    const int gc = col0 + c;
+    const bool live = MODE == 2 || gc >= C || cg_col_active(sc, it, tol, gc);
+    if (!live) {
+    } else if (MODE == 0) {
+      sc.alpha[gc] = gc < C ? sc.rsold[gc] / tot : 0.0;
     } else if (MODE == 1) {
-      sc.beta[c] = c < C ? tot / sc.rsold[c] : 0.0;
-      sc.rsold[c] = tot;
+      sc.beta[gc] = gc < C ? tot / sc.rsold[gc] : 0.0;
+      sc.rsold[gc] = tot;
     } else {
-      sc.rsold[c] = tot;
-    }
-  }
-  if (MODE == 1) {
-    if (c < 64) s_col[c] = (c < C && c < ncols) ? tot : 0.0;
-    __syncthreads();
-    if (c == 0) {
-      // np.sum over a contiguous 1-D float64 array: numpy's pairwise_sum (8 accumulators
-      // below 128 elements, then a fixed tree; plain loop below 8 elements)
-      double e;
-      if (C < 8) {
-        e = 0.0;
-        for (int q = 0; q < C; ++q) e = e + s_col[q];
-      } else {
-        double r8[8];
-        for (int q = 0; q < 8; ++q) r8[q] = s_col[q];
-        int i = 8;
-        for (; i < C - (C % 8); i += 8)
-          for (int q = 0; q < 8; ++q) r8[q] = r8[q] + s_col[i + q];
-        e = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-        for (; i < C; ++i) e = e + s_col[i];
-      }
-      sc.err_hist[it] = sqrt(e);
+      sc.rsold[gc] = tot;
     }
   }
 }
@@ -274,45 +330,45 @@ __global__ __launch_bounds__(256) void cg_seqsum_kernel(const double* __restrict
 // DOUBLE_pairwise_sum: blocks of <= 128 elements summed with 8 strided accumulators combined as a
 // fixed tree, halves split at a multiple of 8).  utils.conjgrad called with a 1-D right-hand side
 // (graph.reweight, graph.py:429) takes that path, so its device twin reproduces the same tree.
-__device__ __noinline__ double np_pairwise_sum(const double* __restrict__ a, int64_t n) {
+// (`a` holds the elements `st` doubles apart: column 0 of the row-major product array)
+__device__ __noinline__ double np_pairwise_sum(const double* __restrict__ a, int64_t n, int st) {
 #pragma clang fp contract(off)
   if (n < 8) {
     double res = -0.0;
-    for (int64_t i = 0; i < n; ++i) res = res + a[i];
+    for (int64_t i = 0; i < n; ++i) res = res + a[i * st];
     return res;
   }
   if (n <= 128) {
     double r[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    for (int j = 0; j < 8; ++j) r[j] = a[j * st];
     int64_t i = 8;
     for (; i < n - (n % 8); i += 8) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+      for (int j = 0; j < 8; ++j) r[j] = r[j] + a[(i + j) * st];
     }
     double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; ++i) res = res + a[i];
+    for (; i < n; ++i) res = res + a[i * st];
     return res;
   }
   int64_t n2 = n / 2;
   n2 -= n2 % 8;
-  const double lo = np_pairwise_sum(a, n2);
-  const double hi = np_pairwise_sum(a + n2, n - n2);
+  const double lo = np_pairwise_sum(a, n2, st);
+  const double hi = np_pairwise_sum(a + n2 * st, n - n2, st);
   return lo + hi;
 }
 
 template <int MODE>
-__global__ void cg_pairwise1d_kernel(const double* __restrict__ prod, int64_t n, CgScalars sc, int it, double tol) {
+__global__ void cg_pairwise1d_kernel(const double* __restrict__ prod, int64_t n, int st, CgScalars sc, int it, double tol) {
 #pragma clang fp contract(off)
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (MODE != 2 && cg_done(sc.err_hist, it, tol)) return;
-  const double tot = 0.0 + np_pairwise_sum(prod, n);
+  if (MODE != 2 && !cg_any_active(sc, it, tol)) return;
+  const double tot = 0.0 + np_pairwise_sum(prod, n, st);
   if (MODE == 0) {
     sc.alpha[0] = sc.rsold[0] / tot;
   } else if (MODE == 1) {
     sc.beta[0] = tot / sc.rsold[0];
     sc.rsold[0] = tot;
-    sc.err_hist[it] = sqrt(tot);
   } else {
     sc.rsold[0] = tot;
   }
@@ -322,9 +378,9 @@ __global__ void cg_pairwise1d_kernel(const double* __restrict__ prod, int64_t n,
   }
 }
 
-__global__ void cg_set_err0(double* err_hist, int64_t n) {
+__global__ void cg_set_err0(double* err_hist, int64_t n, int stride) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) err_hist[i] = i == 0 ? 1.0 : 0.0;
+  if (i < n) err_hist[i] = i < stride ? 1.0 : 0.0;
 }
 
 struct CgBufs {
@@ -341,12 +397,14 @@ struct CgBufs {
 };
 
 template <typename T>
-static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int* iters_out, double* err_out,
-                  int flags) {
+static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double tol, int64_t max_iter, int* iters_out,
+                  double* err_out, int flags) {
   // GLX_CG_REDUCE=tree selects block-tree reductions (faster, deterministic, not bit-identical to numpy)
   const char* red_env = getenv("GLX_CG_REDUCE");
   const bool exact = !(red_env && strcmp(red_env, "tree") == 0);
   const bool np1d = exact && (flags & 1) && C == 1;   // caller passed a 1-D right-hand side: numpy's pairwise reductions
+  const int ngroups = C / Cg;
+  const int stride = ngroups + 1;
   const int64_t n = A->n_rows;
   const int dtype = A->dtype;
   RecLayout L;
@@ -357,18 +415,21 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   if (rc) return rc;
   const size_t es = L.esize;
   const int ncols = L.nvec * 4;
-  GLX_CHECK(ncols <= (exact ? 64 : 256), GLX_EUNSUPPORTED, "glx_cg_multi: C=%d too wide for the column reducer", C);
-  GLX_CHECK(C <= 128 || !exact, GLX_EUNSUPPORTED, "glx_cg_multi: C=%d too wide for the reference-order reducer", C);
+  GLX_CHECK(ncols <= 256, GLX_EUNSUPPORTED, "glx_cg_multi: C=%d too wide for the column reducer", C);
+  GLX_CHECK(Cg <= 128 || !exact, GLX_EUNSUPPORTED, "glx_cg_multi: %d columns per system too wide for the reference-order reducer", Cg);
   GLX_CHECK(256 / (L.ld / 4) >= 1, GLX_EUNSUPPORTED, "glx_cg_multi: record too wide");
   const int64_t nb_spmm = std::max<int64_t>(glx_spmm_blocks(plan), 1);
   const int64_t nb_upd = std::max<int64_t>((n + UPD_ROWS_PER_BLOCK - 1) / UPD_ROWS_PER_BLOCK, 1);
   const int64_t hist_cap = max_iter + 2;
   GLX_CHECK(max_iter < (1ll << 24), GLX_EUNSUPPORTED, "glx_cg_multi: max_iter %lld exceeds the supported 2^24-1", (long long)max_iter);
 
-  // tile of the reference-order reducer: TR rows x ncols columns, 24 elements per thread at most
+  // tile of the reference-order reducer (one workgroup per SEQ_COLS columns): TR rows x <= SEQ_COLS columns,
+  // 24 elements per thread at most
+  const int seq_cols = std::min(ncols, SEQ_COLS);
+  const unsigned seq_grid = (unsigned)((ncols + SEQ_COLS - 1) / SEQ_COLS);
   int TR = 512;
-  while (TR > 16 && TR * ncols > 24 * 256) TR /= 2;
-  const size_t seq_shm = (size_t)2 * ncols * (TR + 1) * 8;
+  while (TR > 16 && TR * seq_cols > 24 * 256) TR /= 2;
+  const size_t seq_shm = (size_t)2 * seq_cols * (TR + 1) * 8;
   if (exact) {
     GLX_HIP(hipFuncSetAttribute((const void*)cg_seqsum_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_shm));
     GLX_HIP(hipFuncSetAttribute((const void*)cg_seqsum_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_shm));
@@ -385,14 +446,18 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   GLX_HIP(hipMalloc(&b.part_dot, nb_spmm * ncols * 8));
   GLX_HIP(hipMalloc(&b.part_rs, nb_upd * ncols * 8));
   GLX_HIP(hipMalloc(&b.scal, 3 * ncols * 8));
-  GLX_HIP(hipMalloc(&b.err_hist, hist_cap * 8));
+  GLX_HIP(hipMalloc(&b.err_hist, hist_cap * stride * 8));
   if (exact) GLX_HIP(hipMalloc(&b.prod, std::max<size_t>((size_t)ncols * n * 8, 64)));
-  GLX_HIP(hipHostMalloc((void**)&b.h_err, (CG_CHUNK + 1) * 8, hipHostMallocDefault));
+  GLX_HIP(hipHostMalloc((void**)&b.h_err, (size_t)(CG_CHUNK + 1) * stride * 8, hipHostMallocDefault));
   CgScalars sc;
   sc.rsold = b.scal;
   sc.alpha = b.scal + ncols;
   sc.beta = b.scal + 2 * ncols;
   sc.err_hist = b.err_hist;
+  sc.stride = stride;
+  sc.ngroups = ngroups;
+  sc.Cg = Cg;
+  sc.C = C;
   hipStream_t st = b.stream;
   const dim3 blk(256);
   T* x = (T*)b.x;
@@ -400,23 +465,23 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   T* p = (T*)b.p;
   T* ap = (T*)b.ap;
 
-  hipLaunchKernelGGL(cg_set_err0, dim3((unsigned)((hist_cap + 255) / 256)), blk, 0, st, b.err_hist, hist_cap);
+  hipLaunchKernelGGL(cg_set_err0, dim3((unsigned)((hist_cap * stride + 255) / 256)), blk, 0, st, b.err_hist, hist_cap * stride, stride);
   GLX_HIP(hipGetLastError());
   GLX_HIP(hipMemsetAsync(b.x, 0, recb, st));
   GLX_HIP(hipMemsetAsync(b.ap, 0, recb, st));
   GLX_HIP(hipMemsetAsync(b.part_dot, 0, nb_spmm * ncols * 8, st));
+  GLX_HIP(hipMemsetAsync(b.scal, 0, 3 * ncols * 8, st));
   GLX_HIP(hipMemcpyAsync(b.dense, B, (size_t)n * C * es, hipMemcpyHostToDevice, st));
   rc = glx_pack_records(b.dense, b.r, n, L, dtype, nullptr, st, A->d_perm);   // r = b - A@0 = b (utils.py:514)
   if (rc) return rc;
   GLX_HIP(hipMemcpyAsync(b.p, b.r, recb, hipMemcpyDeviceToDevice, st));   // p = r.copy() (utils.py:516)
   hipLaunchKernelGGL((cg_update_kernel<T, 1>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
-                     (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, 1, tol, b.prod,
-                     (const int32_t*)A->d_perm);
+                     (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, sc, 1, tol, b.prod, (const int32_t*)A->d_perm);
   GLX_HIP(hipGetLastError());
   if (np1d)
-    hipLaunchKernelGGL(cg_pairwise1d_kernel<2>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, sc, 0, tol);
+    hipLaunchKernelGGL(cg_pairwise1d_kernel<2>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, sc, 0, tol);
   else if (exact)
-    hipLaunchKernelGGL(cg_seqsum_kernel<2>, dim3(1), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, 0, tol, TR);
+    hipLaunchKernelGGL(cg_seqsum_kernel<2>, dim3(seq_grid), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, 0, tol, TR);
   else
     hipLaunchKernelGGL(cg_reduce_kernel<2>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, 0, tol);
   GLX_HIP(hipGetLastError());
@@ -433,69 +498,87 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, double tol, int64
   a.exit_tol = tol;
   a.prod_out = b.prod;
   a.perm = A->d_perm;
+  a.act_cg = Cg;
+  a.act_c = C;
   const unsigned pgrid = (unsigned)std::max<int64_t>(((int64_t)n * (L.ld / 4) + 255) / 256, 1);
 
-  int64_t it = 0;       // iterations launched
-  int64_t iters = 0;    // iterations that ran (utils.py:522 `i`)
-  double err = 1.0;     // utils.py:519
-  bool stopped = !(err > tol);
-  while (!stopped && it < max_iter) {
+  int64_t it = 0;                               // iterations launched
+  std::vector<int64_t> iters(ngroups, 0);       // iterations that ran, per group (utils.py:522 `i`)
+  std::vector<double> err(ngroups, 1.0);        // utils.py:519
+  std::vector<char> done(ngroups, !(1.0 > tol));
+  int running = 0;
+  for (int g = 0; g < ngroups; ++g) running += !done[g];
+  while (running > 0 && it < max_iter) {
     const int64_t end = std::min<int64_t>(max_iter, it + CG_CHUNK);
     const int64_t it0 = it;
     for (; it < end; ++it) {
       const int i = (int)it + 1;
-      a.exit_err = b.err_hist + (i - 1);
+      a.exit_err = b.err_hist + (size_t)(i - 1) * stride + ngroups;   // all groups converged: exit at once
+      a.act_row = ngroups > 1 ? b.err_hist + (size_t)(i - 1) * stride : nullptr;
       rc = glx_launch_spmm(a, st);                                                   // Ap = A@p, p.Ap partials
       if (rc) return rc;
       if (np1d)
-        hipLaunchKernelGGL(cg_pairwise1d_kernel<0>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, sc, i, tol);
+        hipLaunchKernelGGL(cg_pairwise1d_kernel<0>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, sc, i, tol);
       else if (exact)
-        hipLaunchKernelGGL(cg_seqsum_kernel<0>, dim3(1), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, i, tol, TR);
+        hipLaunchKernelGGL(cg_seqsum_kernel<0>, dim3(seq_grid), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, i, tol, TR);
       else
         hipLaunchKernelGGL(cg_reduce_kernel<0>, dim3(1), blk, 0, st, (const double*)b.part_dot, nb_spmm, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
       hipLaunchKernelGGL((cg_update_kernel<T, 0>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
-                         (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, (const double*)b.err_hist, i, tol, b.prod,
-                         (const int32_t*)A->d_perm);
+                         (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, sc, i, tol, b.prod, (const int32_t*)A->d_perm);
       GLX_HIP(hipGetLastError());
       if (np1d)
-        hipLaunchKernelGGL(cg_pairwise1d_kernel<1>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, sc, i, tol);
+        hipLaunchKernelGGL(cg_pairwise1d_kernel<1>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, sc, i, tol);
       else if (exact)
-        hipLaunchKernelGGL(cg_seqsum_kernel<1>, dim3(1), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, i, tol, TR);
+        hipLaunchKernelGGL(cg_seqsum_kernel<1>, dim3(seq_grid), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, i, tol, TR);
       else
         hipLaunchKernelGGL(cg_reduce_kernel<1>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
+      hipLaunchKernelGGL(cg_group_err_kernel, dim3(1), blk, 0, st, sc, i, tol);
+      GLX_HIP(hipGetLastError());
       hipLaunchKernelGGL((cg_pupdate_kernel<T>), dim3(pgrid), blk, 0, st, (const T*)r, p, (const double*)sc.beta, n, L.ld, L.nvec,
-                         (const double*)b.err_hist, i, tol, 1);
+                         sc, i, tol, 1);
       GLX_HIP(hipGetLastError());
     }
     const int64_t cnt = end - it0;
-    GLX_HIP(hipMemcpyAsync(b.h_err, b.err_hist + it0 + 1, cnt * 8, hipMemcpyDeviceToHost, st));
+    GLX_HIP(hipMemcpyAsync(b.h_err, b.err_hist + (size_t)(it0 + 1) * stride, (size_t)cnt * stride * 8, hipMemcpyDeviceToHost, st));
     GLX_HIP(hipStreamSynchronize(st));
-    for (int64_t q = 0; q < cnt; ++q) {
-      // iteration it0+q+1 ran (the previous err was > tol); its err decides the next one
-      iters = it0 + q + 1;
-      err = b.h_err[q];
-      if (!(err > tol)) { stopped = true; break; }
+    for (int64_t q = 0; q < cnt && running > 0; ++q) {
+      // iteration it0+q+1 ran for every group whose previous err was > tol; its err decides the next one
+      for (int g = 0; g < ngroups; ++g) {
+        if (done[g]) continue;
+        iters[g] = it0 + q + 1;
+        err[g] = b.h_err[(size_t)q * stride + g];
+        if (!(err[g] > tol)) { done[g] = 1; --running; }
+      }
     }
   }
   rc = glx_unpack_records(b.x, b.dense, n, L, dtype, st, A->d_perm);
   if (rc) return rc;
   GLX_HIP(hipMemcpyAsync(X, b.dense, (size_t)n * C * es, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
-  if (iters_out) *iters_out = (int)iters;
-  if (err_out) *err_out = err;
+  for (int g = 0; g < ngroups; ++g) {
+    if (iters_out) iters_out[g] = (int)iters[g];
+    if (err_out) err_out[g] = err[g];
+  }
   return GLX_OK;
+}
+
+extern "C" int glx_cg_groups(glx_graph* A, const void* B, void* X, int C, int group_cols, double tol, int64_t max_iter, int flags,
+                             int* iters_out, double* err_out) {
+  GLX_CHECK(A && B && X, GLX_EINVAL, "glx_cg_multi: null argument");
+  GLX_CHECK(A->n_rows == A->n_cols, GLX_EINVAL, "glx_cg_multi: operator must be square");
+  GLX_CHECK(max_iter >= 0, GLX_EINVAL, "glx_cg_multi: negative max_iter");
+  GLX_CHECK(C >= 1 && group_cols >= 1 && C % group_cols == 0, GLX_EINVAL,
+            "glx_cg_groups: %d columns do not split into systems of %d columns", C, group_cols);
+  GLX_HIP(hipSetDevice(A->device));
+  return A->dtype == GLX_F32 ? cg_run<float>(A, B, X, C, group_cols, tol, max_iter, iters_out, err_out, flags)
+                             : cg_run<double>(A, B, X, C, group_cols, tol, max_iter, iters_out, err_out, flags);
 }
 
 extern "C" int glx_cg_solve(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int flags,
                             int* iters_out, double* err_out) {
-  GLX_CHECK(A && B && X, GLX_EINVAL, "glx_cg_multi: null argument");
-  GLX_CHECK(A->n_rows == A->n_cols, GLX_EINVAL, "glx_cg_multi: operator must be square");
-  GLX_CHECK(max_iter >= 0, GLX_EINVAL, "glx_cg_multi: negative max_iter");
-  GLX_HIP(hipSetDevice(A->device));
-  return A->dtype == GLX_F32 ? cg_run<float>(A, B, X, C, tol, max_iter, iters_out, err_out, flags)
-                             : cg_run<double>(A, B, X, C, tol, max_iter, iters_out, err_out, flags);
+  return glx_cg_groups(A, B, X, C, C, tol, max_iter, flags, iters_out, err_out);
 }
 
 extern "C" int glx_cg_multi(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int* iters_out,

@@ -109,7 +109,9 @@ struct SweepArgs {
   double* dot_partial;
   const double* exit_err;        // optional early exit: skip when !(*exit_err > exit_tol)
   double exit_tol;
-  double* prod_out;              // optional: elementwise xin*xout, column-major, caller row order (CG)
+  double* prod_out;              // optional: elementwise xin*xout, row-major (nvec*4 columns), caller row order (CG)
+  const double* act_row;         // optional (CG column groups): group g still runs iff act_row[g] > exit_tol
+  int act_cg, act_c;             // columns per group / total columns
   const int32_t* perm;
   int64_t n_rows;
 };

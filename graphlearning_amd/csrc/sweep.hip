@@ -54,7 +54,10 @@ struct SpmmParams {
   int dot_ld;
   const double* exit_err;   // CG: skip the launch when !(*exit_err > exit_tol)
   double exit_tol;
-  double* prod_out;         // CG reference-order reductions: prod_out[c*n + caller_row] = xin*xout
+  double* prod_out;         // CG reference-order reductions: prod_out[caller_row*dot_ld + c] = xin*xout
+  const double* act_row;    // CG column groups: group g still runs iff act_row[g] > exit_tol (null: all)
+  int act_cg;               // columns per group
+  int act_c;                // total columns
   const int32_t* perm;      // record -> caller row (null: identity)
   int64_t n_rows;
   int ablate;               // developer probe (GLX_ABLATE): 1 no chunk loop, 2 gathers hit one hot record, 4 no stores
@@ -189,7 +192,20 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
   const int64_t vb = xcd_remap(blockIdx.x, p.nblocks);
   const int64_t slice = vb * GLX_WPB + wave;
   const int g = lane / G, c = lane % G;
-  const bool lane_on = c < p.nlanes;
+  bool lane_on = c < p.nlanes;
+  if constexpr (HAS_DOT) {
+    // column groups (CG on several systems): lanes whose 4 columns all belong to converged
+    // systems neither gather nor store
+    if (p.act_row && lane_on) {
+      bool any = false;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = c * 4 + e;
+        if (col < p.act_c) any = any || (p.act_row[col / p.act_cg] > p.exit_tol);
+      }
+      lane_on = any;
+    }
+  }
   const bool is_w = HAS_W && (c == p.nvec);
   int row = -1, len = 0, nchunks = 0, S = 1;
   int64_t base = 0;
@@ -386,11 +402,13 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       const V4 own = *(const V4*)(p.xin + (size_t)row * p.rec_bytes + lane_off);
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = (double)own[e] * (double)outv[e];
-      if (p.prod_out && c < p.nvec) {   // elementwise p*Ap in the array dtype, laid out column-major in the caller's row order
+      if (p.prod_out && c < p.nvec) {   // elementwise p*Ap in the array dtype, row-major (dot_ld columns) in the caller's row order
         const V4 pr = own * outv;
         const int64_t orow = p.perm ? p.perm[row] : row;
+        f64x4 pd;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) p.prod_out[(size_t)(c * 4 + e) * p.n_rows + orow] = (double)pr[e];
+        for (int e = 0; e < 4; ++e) pd[e] = (double)pr[e];
+        *(f64x4*)(p.prod_out + (size_t)orow * p.dot_ld + c * 4) = pd;
       }
     }
 #pragma unroll
@@ -475,6 +493,9 @@ int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
   p.exit_err = a.exit_err;
   p.exit_tol = a.exit_tol;
   p.prod_out = a.prod_out;
+  p.act_row = a.act_row;
+  p.act_cg = a.act_cg;
+  p.act_c = a.act_c;
   p.perm = a.perm;
   p.n_rows = a.n_rows;
   static const int ablate = getenv("GLX_ABLATE") ? atoi(getenv("GLX_ABLATE")) : 0;

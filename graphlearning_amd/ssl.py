@@ -132,19 +132,41 @@ class ssl:
             print('Results File: ' + outfile)
         print('\n' + header)
         labels = np.asarray(labels)
-        for train_ind in trainsets:
-            train_ind = np.asarray(train_ind)
-            pred = self.fit_predict(train_ind, labels[train_ind])
-            accuracy = ssl_accuracy(pred, labels, train_ind)
-            if with_priors:
-                plain = ssl_accuracy(self.predict(ignore_class_priors=True), labels, train_ind)
-                row = '%d,%.2f,%.2f,%.5f' % (len(train_ind), plain, accuracy, self.class_priors_error)
-            else:
-                row = '%d' % len(train_ind) + ',%.2f' % accuracy
-            print(row)
-            if save_results:
-                with open(outfile, 'a+') as f:
-                    f.write(row + '\n')
+        trainsets = [np.asarray(t) for t in trainsets]
+        batch = 1 if self.onevsrest else max(1, int(self._trial_batch_size(labels)))
+        for pos in range(0, len(trainsets), batch):
+            group = trainsets[pos:pos + batch]
+            # trials that share the graph are stacked as extra right-hand-side columns of ONE device
+            # solve where the learner supports it (column for column the same result as one by one)
+            probs = self._fit_batch([(t, labels[t]) for t in group]) if len(group) > 1 else None
+            for j, train_ind in enumerate(group):
+                if probs is None:
+                    pred = self.fit_predict(train_ind, labels[train_ind])
+                else:
+                    self.fitted = True
+                    self.prob = probs[j]
+                    if self.class_priors is not None:
+                        self.volume_label_projection()
+                    pred = self.predict()
+                accuracy = ssl_accuracy(pred, labels, train_ind)
+                if with_priors:
+                    plain = ssl_accuracy(self.predict(ignore_class_priors=True), labels, train_ind)
+                    row = '%d,%.2f,%.2f,%.5f' % (len(train_ind), plain, accuracy, self.class_priors_error)
+                else:
+                    row = '%d' % len(train_ind) + ',%.2f' % accuracy
+                print(row)
+                if save_results:
+                    with open(outfile, 'a+') as f:
+                        f.write(row + '\n')
+
+    def _trial_batch_size(self, labels):
+        """How many trials ssl_trials hands to _fit_batch at once (1 = one by one)."""
+        return 1
+
+    def _fit_batch(self, trials):
+        """Fit several (train_ind, train_labels) pairs on the same graph in one device call and
+        return their (n, C) results, or None when the learner has no batched path."""
+        return None
 
     def trials_statistics(self, tag=''):
         """Mean / standard deviation of the accuracies recorded by ssl_trials, per label rate
@@ -279,6 +301,32 @@ class poisson(ssl):
         else:
             sys.exit('Invalid Poisson solver ' + self.solver)
         return u
+
+
+    def _trial_batch_size(self, labels):
+        if self.solver != 'conjugate_gradient':
+            return 1
+        k = max(1, len(np.unique(labels)))
+        return max(1, min(24, 240 // k))
+
+    def _fit_batch(self, trials):
+        """Poisson CG for several training sets at once: the trials' right-hand sides become column
+        groups of one multi-RHS solve (glx_cg_groups), each group with the stop test and iteration
+        count utils.conjgrad would give it alone (reference: one conjgrad call per trial,
+        ssl.py:624-629 under ssl.py:292-396)."""
+        if self.solver != 'conjugate_gradient':
+            return None
+        n = self.graph.num_nodes
+        sources = [_poisson_source(n, np.asarray(ti), np.asarray(tl)) for ti, tl in trials]
+        k = sources[0][1]
+        if any(kk != k for _, kk in sources):
+            return None
+        dev, aux = self._operators()
+        D = aux['D']
+        B = np.ascontiguousarray(np.hstack([D * src for src, _ in sources]), dtype=self._dtype())
+        x, its, _ = dev.cg_groups(B, k, tol=self.tol)
+        self.num_iter = [int(i) for i in its]
+        return [np.ascontiguousarray(D * x[:, b * k:(b + 1) * k]) for b in range(len(trials))]
 
 
 class poisson_mbo(ssl):

@@ -120,6 +120,13 @@ int glx_cg_multi(glx_graph* A, const void* B, void* X, int C, double tol, int64_
  * with pairwise summation (graph.reweight, graphlearning/graph.py:429), reproduced exactly. */
 int glx_cg_solve(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int flags,
                  int* iters_out, double* err_out);
+/* several independent systems on one operator, side by side: the C columns are C/group_cols systems
+ * of group_cols columns each -- the trials of ssl.ssl_trials (graphlearning/ssl.py:292-396, one
+ * utils.conjgrad call per trial there).  Every system keeps its own residual norm, stop test and
+ * iteration count and is frozen once it converges, so column for column the result is identical
+ * to solving it alone.  iters_out / err_out: C/group_cols entries.  C <= 252. */
+int glx_cg_groups(glx_graph* A, const void* B, void* X, int C, int group_cols, double tol, int64_t max_iter,
+                  int flags, int* iters_out, double* err_out);
 
 /* ---- predict / volume-constrained projection --------------------------------------
  * ssl.predict (ssl.py:230-266) and ssl.volume_label_projection (ssl.py:172-209) on
