@@ -18,7 +18,7 @@ template <> struct V4Of<float> { typedef f32x4 type; };
 template <> struct V4Of<double> { typedef f64x4 type; };
 
 static const int CG_CHUNK = 8;
-static const int SEQ_COLS = 16;   // columns per workgroup of the reference-order reducer
+static const int SEQ_COLS_DEFAULT = 8;    // columns per workgroup of the reference-order reducer (4, 8 or 16)
 static const int UPD_ROWS_PER_BLOCK = 256;
 
 // The C columns may hold several independent systems side by side ("groups" of Cg columns: the
@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void cg_update_kernel(T* __restrict__ x, T* __
                                                         const T* __restrict__ Ap, const double* __restrict__ alpha,
                                                         double* __restrict__ partial, int64_t n, int ld, int nvec,
                                                         const CgScalars sc, int it, double tol,
-                                                        double* __restrict__ prod_out, const int32_t* __restrict__ perm) {
+                                                        double* __restrict__ prod_out, int prod_sc,
+                                                        const int32_t* __restrict__ perm) {
 #pragma clang fp contract(off)
   typedef typename V4Of<T>::type V4;
   if (MODE == 0 && !cg_any_active(sc, it, tol)) return;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void cg_update_kernel(T* __restrict__ x, T* __
         f64x4 sd;
 #pragma unroll
         for (int e = 0; e < 4; ++e) sd[e] = (double)sq[e];
-        *(f64x4*)(prod_out + (size_t)orow * (nvec * 4) + cv * 4) = sd;
+        *(f64x4*)(prod_out + ((size_t)((cv * 4) / prod_sc) * n + orow) * prod_sc + (cv * 4) % prod_sc) = sd;
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -237,83 +238,230 @@ __global__ __launch_bounds__(256) void cg_group_err_kernel(CgScalars sc, int it,
 // Reproducing it makes the whole CG bit-identical to the reference (iteration count
 // included) -- necessary because the Poisson system is singular and 100+ CG iterations
 // amplify any reordering far beyond 1e-5.  The elementwise products are formed in parallel
-// by the producing kernels (SpMM epilogue / r-update) into a row-major array in the
-// caller's row order; here one wavefront per 16 columns, lane c = column c, adds up its column
+// by the producing kernels (SpMM epilogue / r-update) into an array in the caller's row order,
+// blocked by 8 columns; here one wavefront per block, lane c = column c, adds up its column
 // row after row -- only the add chain is serial.
 // MODE 0: tot = sum p*Ap ; alpha = rsold / tot                                (utils.py:524)
 // MODE 1: tot = sum r*r  ; beta = tot / rsold ; rsold = tot ; err = sqrt(np.sum(tot)) (:527-530)
 // MODE 2: rsold = sum r*r                                                     (utils.py:517)
-// One workgroup: all 256 threads stream the next tile of the row-major product array into
-// registers (coalesced) while wavefront 0 -- lane c = column c -- adds up the current tile from
-// LDS in row order; the registers are then written to the other LDS buffer.  Only the add chain
-// is serial, the memory latency hides under it.
+// One workgroup: wavefronts 1..3 stream the next tile of the row-major product array into
+// registers (coalesced) while wavefront 0 -- lane c = column c, doing nothing else -- adds up the
+// current tile from LDS in row order (16 rows per step, the next 16 already being read); the
+// registers are then written to the other LDS buffer.  Only the add chain is serial, the memory
+// and LDS latencies hide under it.
 template <int MODE>
 __global__ __launch_bounds__(256) void cg_seqsum_kernel(const double* __restrict__ prod_all, int64_t n, int ncols_all, int C,
-                                                        CgScalars sc, int it, double tol, int TR) {
+                                                        CgScalars sc, int it, double tol, int TR, int SEQ_COLS) {
 #pragma clang fp contract(off)
   if (MODE != 2 && !cg_any_active(sc, it, tol)) return;
-  extern __shared__ __attribute__((aligned(16))) double s_tile[];   // [2][ncols][TR + 1]
+  extern __shared__ __attribute__((aligned(16))) double s_tile[];   // [2][ncols][TR + 2]
   const int tid = threadIdx.x;
   // workgroup b reduces columns [SEQ_COLS b, SEQ_COLS (b + 1))
   const int col0 = blockIdx.x * SEQ_COLS;
   const int ncols = min(SEQ_COLS, ncols_all - col0);
-  const double* __restrict__ prod = prod_all + col0;   // row-major, ncols_all columns
+  // block-major layout: element (row, col) at ((col / SEQ_COLS) * n + row) * SEQ_COLS + col % SEQ_COLS,
+  // i.e. this workgroup streams one contiguous array of n rows x SEQ_COLS columns
+  const double* __restrict__ prod = prod_all + (size_t)blockIdx.x * n * SEQ_COLS;
   if (MODE != 2) {   // nothing to do if every group with a column here has converged
     bool any = false;
     for (int cc = col0; cc < col0 + ncols; cc += 1) any = any || cg_col_active(sc, it, tol, cc);
     if (!any) return;
   }
-  const int LDT = TR + 1;                       // +1: lanes of one read hit different banks
-  const int per = (TR * ncols + 255) / 256;     // elements per thread per tile (<= 24)
-  double reg[24];
-  auto tile_load = [&](int64_t base) {
+  // wavefront 0 only adds; wavefronts 1..3 (192 threads) stage the tiles
+  const int LDT = TR + 2;                       // even: 16-byte LDS reads; lanes of one read spread over the banks
+  const int lt = tid - 64;                      // loader thread id
+  // loader thread -> (column, first row); 192 is a multiple of every ncols in {4, 8, 12, 16}, so a
+  // thread keeps its column and steps 192/ncols rows per element: no divisions in the loop
+  const int lcc = lt >= 0 ? lt % ncols : 0, lr0 = lt >= 0 ? lt / ncols : 0, rstep = 192 / ncols;
+  const int per = (TR + rstep - 1) / rstep;     // elements per loader thread per tile (<= 24)
+  // two register sets: the global loads of tile t+2 are in flight while tile t+1 waits in the
+  // other set to be written to LDS and tile t is being added up
+  double regA[24], regB[24];
+  auto tile_load = [&](double (&reg)[24], int64_t base) {
+    const double* src = prod + (size_t)(base + lr0) * SEQ_COLS + lcc;
 #pragma unroll
     for (int q = 0; q < 24; ++q) {
-      const int idx = tid + q * 256;
+      const int r = lr0 + q * rstep;
       double v = 0.0;
-      if (q < per && idx < TR * ncols) {
-        const int r = idx / ncols, cc = idx % ncols;
-        if (base + r < n) v = prod[(size_t)(base + r) * ncols_all + cc];
-      }
+      if (q < per && r < TR && base + r < n) v = src[(size_t)q * rstep * SEQ_COLS];
       reg[q] = v;
     }
   };
-  auto tile_store = [&](int buf) {
+  auto tile_store = [&](const double (&reg)[24], int buf) {
+    double* dst = s_tile + (size_t)buf * ncols * LDT + lcc * LDT + lr0;
 #pragma unroll
     for (int q = 0; q < 24; ++q) {
-      const int idx = tid + q * 256;
-      if (q < per && idx < TR * ncols) s_tile[(size_t)buf * ncols * LDT + (idx % ncols) * LDT + (idx / ncols)] = reg[q];
+      if (q < per && lr0 + q * rstep < TR) dst[q * rstep] = reg[q];
     }
   };
+  const bool loader = tid >= 64;
   const int c = tid;
   double tot = 0.0;
-  tile_load(0);
-  tile_store(0);
-  __syncthreads();
-  int buf = 0;
-  for (int64_t base = 0; base < n; base += TR) {
-    const bool more = base + TR < n;
-    if (more) tile_load(base + TR);
+  auto chain = [&](int buf, int64_t base) {
     if (tid < ncols) {
       const double* col = s_tile + (size_t)buf * ncols * LDT + c * LDT;
       const int rows = (int)min((int64_t)TR, n - base);
-      int r = 0;
-      for (; r + 16 <= rows; r += 16) {
-        double v[16];
+      // The wavefront can issue one instruction every 4 cycles and a dependent fp64 add every ~6, so
+      // every instruction that is not an add stretches the chain: 32 rows per group (one 16-byte LDS
+      // read per 2 rows, the reads of the next group in flight while this one is added), two groups
+      // per loop iteration, no branch inside.
+      const int ngr = rows / 32;
+      double va[32], vb[32];
+      auto fetch = [&](double (&v)[32], int g) {
+        const double2* src = (const double2*)(col + g * 32);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = col[r + q];
+        for (int q = 0; q < 16; ++q) { const double2 t = src[q]; v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+      };
+      int g = 0;
+      if (ngr > 0) fetch(va, 0);
+      for (; g + 2 <= ngr; g += 2) {
+        // (sched_barrier: keep the reads of the next group IN FRONT of this group's adds -- the
+        // scheduler otherwise sinks them behind the chain and their LDS latency is exposed)
+        fetch(vb, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) tot = tot + v[q];
+        for (int q = 0; q < 32; ++q) tot = tot + va[q];
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(va, g + 2 < ngr ? g + 2 : g + 1);   // (clamped: the last prefetch re-reads a valid group)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tot = tot + vb[q];
+        __builtin_amdgcn_sched_barrier(0);
       }
-      for (; r < rows; ++r) tot = tot + col[r];
+      if (g < ngr) {   // odd group count: one group left, already in va
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tot = tot + va[q];
+        ++g;
+      }
+      for (int r = ngr * 32; r < rows; ++r) tot = tot + col[r];
     }
-    if (more) tile_store(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+  };
+  if (loader) {
+    tile_load(regA, 0);
+    tile_store(regA, 0);
+    if (TR < n) tile_load(regA, TR);
+  }
+  __syncthreads();
+  // invariant at the top of a step: tile t is in LDS buffer (t & 1), tile t+1 in `nxt`
+  auto step = [&](int64_t base, int buf, double (&nxt)[24], double (&nxt2)[24]) {
+    if (loader && base + 2 * (int64_t)TR < n) tile_load(nxt2, base + 2 * (int64_t)TR);
+    chain(buf, base);
+    if (loader && base + TR < n) tile_store(nxt, buf ^ 1);
+    // workgroup barrier that orders LDS only: __syncthreads() would also drain the loaders' global
+    // loads (vmcnt(0)), i.e. wait for the tile that was just requested two steps ahead
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  for (int64_t base = 0; base < n; base += 2 * (int64_t)TR) {
+    step(base, 0, regA, regB);
+    if (base + TR < n) step(base + TR, 1, regB, regA);
   }
   if (c < ncols) {
     const int gc = col0 + c;
     const bool live = MODE == 2 || gc >= C || cg_col_active(sc, it, tol, gc);
+    if (!live) {
+    } else if (MODE == 0) {
+      sc.alpha[gc] = gc < C ? sc.rsold[gc] / tot : 0.0;
+    } else if (MODE == 1) {
+      sc.beta[gc] = gc < C ? tot / sc.rsold[gc] : 0.0;
+      sc.rsold[gc] = tot;
+    } else {
+      sc.rsold[gc] = tot;
+    }
+  }
+}
+
+// ---- the same reduction with the add chain fed through DPP ----------------------------------
+// A wavefront issues one instruction every 4 cycles and a dependent fp64 add every ~6, so in the
+// kernel above every LDS read that feeds the chain stretches it.  Here one wavefront owns 4
+// columns, one per DPP row of 16 lanes: lane k of row r loads element (16 g + k, column r) straight
+// from global memory (the product array is blocked by 4 columns, so a wavefront load is 512
+// contiguous bytes), and `v_fmac_f64_dpp tot, x, 1.0 row_newbcast:k` adds the value held by lane k
+// to the running sum of every lane of its row: ONE load instruction per 16 rows, 16 dependent
+// fused multiply-adds x*1+tot (= the correctly rounded sum, bit for bit the add).  48 loads stay in
+// flight to cover the memory latency; no LDS, no barriers.
+#define GLX_DPP_L(K) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+// (one asm block: the compiler pads separate asm statements with s_nop, each an issue slot of the chain)
+#define GLX_DPP_ADD16()                                                                                                        \
+  asm volatile(GLX_DPP_L(0) GLX_DPP_L(1) GLX_DPP_L(2) GLX_DPP_L(3) GLX_DPP_L(4) GLX_DPP_L(5) GLX_DPP_L(6) GLX_DPP_L(7) GLX_DPP_L(8) \
+                   GLX_DPP_L(9) GLX_DPP_L(10) GLX_DPP_L(11) GLX_DPP_L(12) GLX_DPP_L(13) GLX_DPP_L(14) GLX_DPP_L(15)              \
+               : "+v"(tot)                                                                                                     \
+               : "v"(x), "v"(one))
+
+template <int MODE>
+__global__ __launch_bounds__(64) void cg_seqsum_dpp_kernel(const double* __restrict__ prod_all, int64_t n, int ncols_all, int C,
+                                                           CgScalars sc, int it, double tol) {
+  if (MODE != 2 && !cg_any_active(sc, it, tol)) return;
+  const int lane = threadIdx.x, r = lane >> 4, k = lane & 15;
+  const int col0 = blockIdx.x * 4;
+  if (MODE != 2) {   // nothing to do if every group with a column here has converged
+    bool any = false;
+    for (int cc = col0; cc < col0 + 4; ++cc) any = any || cg_col_active(sc, it, tol, cc);
+    if (!any) return;
+  }
+  // element (row 16 g + k, column r) of this block at src[g * 64]
+  const double* __restrict__ src = prod_all + (size_t)blockIdx.x * n * 4 + (size_t)k * 4 + r;
+  const int64_t ngroups = (n + 15) / 16;   // the last one may be partial
+  const int64_t nfull = n / 16;
+  constexpr int DEPTH = 48;
+  double buf[DEPTH];
+  // rows past n read as +0: tot (which starts at +0 and can never become -0) + 0 == tot bit for bit
+  auto load_checked = [&](int64_t g) -> double { return g * 16 + k < n ? src[g * 64] : 0.0; };
+  double tot = 0.0;
+  const double one = 1.0;
+  int64_t g0 = 0;
+  if (2 * DEPTH <= nfull) {
+    // steady state: group g0+d is added, then the load of group g0+d+DEPTH is issued into the
+    // register it just freed (no bounds check: a full group).  The loads and their waits are
+    // written by hand: loads return in order and exactly DEPTH are outstanding whenever a group is
+    // about to be added, so `s_waitcnt vmcnt(DEPTH-1)` is the exact wait for the oldest -- the
+    // compiler's own counter analysis gives up at the loop back-edge and drains all of them
+    // (vmcnt(0)) at the top of every iteration, exposing a full memory latency each time.
+    static_assert(DEPTH == 48, "the vmcnt immediate below is DEPTH-1");
+    const double* sbase = prod_all + (size_t)blockIdx.x * n * 4;            // uniform: lives in SGPRs
+    unsigned voff = (unsigned)((k * 4 + r) * 8);                            // this lane's byte offset, group 0
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(buf[d]) : "v"(voff), "s"(sbase));
+      voff += 512;
+    }
+    for (; g0 + 2 * DEPTH <= nfull; g0 += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        asm volatile("s_waitcnt vmcnt(47)\n\t" GLX_DPP_L(0) GLX_DPP_L(1) GLX_DPP_L(2) GLX_DPP_L(3) GLX_DPP_L(4) GLX_DPP_L(5) GLX_DPP_L(6)
+                         GLX_DPP_L(7) GLX_DPP_L(8) GLX_DPP_L(9) GLX_DPP_L(10) GLX_DPP_L(11) GLX_DPP_L(12) GLX_DPP_L(13) GLX_DPP_L(14)
+                             GLX_DPP_L(15)
+                     : "+v"(tot)
+                     : "v"(buf[d]), "v"(one));
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(buf[d]) : "v"(voff), "s"(sbase));
+        voff += 512;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // hand the buffers back to compiler-managed code
+  } else {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) buf[d] = load_checked(d);
+  }
+  // last rounds: the same with checked loads
+  for (; g0 + DEPTH <= ngroups; g0 += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const double x = buf[d];
+      GLX_DPP_ADD16();
+      __builtin_amdgcn_sched_barrier(0);
+      buf[d] = load_checked(g0 + d + DEPTH);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    if (g0 + d < ngroups) {
+      const double x = buf[d];
+      GLX_DPP_ADD16();
+    }
+  }
+  if (k == 0) {
+    const int gc = col0 + r;
+    const bool live = gc < ncols_all && (MODE == 2 || gc >= C || cg_col_active(sc, it, tol, gc));
     if (!live) {
     } else if (MODE == 0) {
       sc.alpha[gc] = gc < C ? sc.rsold[gc] / tot : 0.0;
@@ -425,11 +573,21 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
 
   // tile of the reference-order reducer (one workgroup per SEQ_COLS columns): TR rows x <= SEQ_COLS columns,
   // 24 elements per thread at most
-  const int seq_cols = std::min(ncols, SEQ_COLS);
+  int SEQ_COLS = SEQ_COLS_DEFAULT;
+  if (const char* e = getenv("GLX_CG_SEQ_COLS")) {   // developer probe
+    const int v = atoi(e);
+    if (v == 4 || v == 8 || v == 16) SEQ_COLS = v;
+  }
+  const char* seq_env = getenv("GLX_CG_SEQ");
+  const bool seq_dpp = !(seq_env && strcmp(seq_env, "lds") == 0);   // developer probe: the LDS-fed reducer
+  if (seq_dpp) SEQ_COLS = 4;
+  SEQ_COLS = std::min(SEQ_COLS, ncols);
+  const int prod_sc = SEQ_COLS;
+  const int seq_cols = SEQ_COLS;
   const unsigned seq_grid = (unsigned)((ncols + SEQ_COLS - 1) / SEQ_COLS);
   int TR = 512;
-  while (TR > 16 && TR * seq_cols > 24 * 256) TR /= 2;
-  const size_t seq_shm = (size_t)2 * seq_cols * (TR + 1) * 8;
+  while (TR > 16 && TR * seq_cols > 24 * 192) TR -= 32;    // 192 loader threads, <= 24 elements each
+  const size_t seq_shm = (size_t)2 * seq_cols * (TR + 2) * 8;
   if (exact) {
     GLX_HIP(hipFuncSetAttribute((const void*)cg_seqsum_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_shm));
     GLX_HIP(hipFuncSetAttribute((const void*)cg_seqsum_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_shm));
@@ -447,7 +605,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   GLX_HIP(hipMalloc(&b.part_rs, nb_upd * ncols * 8));
   GLX_HIP(hipMalloc(&b.scal, 3 * ncols * 8));
   GLX_HIP(hipMalloc(&b.err_hist, hist_cap * stride * 8));
-  if (exact) GLX_HIP(hipMalloc(&b.prod, std::max<size_t>((size_t)ncols * n * 8, 64)));
+  if (exact) GLX_HIP(hipMalloc(&b.prod, std::max<size_t>((size_t)seq_grid * SEQ_COLS * n * 8, 64)));
   GLX_HIP(hipHostMalloc((void**)&b.h_err, (size_t)(CG_CHUNK + 1) * stride * 8, hipHostMallocDefault));
   CgScalars sc;
   sc.rsold = b.scal;
@@ -476,12 +634,15 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   if (rc) return rc;
   GLX_HIP(hipMemcpyAsync(b.p, b.r, recb, hipMemcpyDeviceToDevice, st));   // p = r.copy() (utils.py:516)
   hipLaunchKernelGGL((cg_update_kernel<T, 1>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
-                     (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, sc, 1, tol, b.prod, (const int32_t*)A->d_perm);
+                     (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, sc, 1, tol, b.prod, prod_sc, (const int32_t*)A->d_perm);
   GLX_HIP(hipGetLastError());
   if (np1d)
-    hipLaunchKernelGGL(cg_pairwise1d_kernel<2>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, sc, 0, tol);
+    hipLaunchKernelGGL(cg_pairwise1d_kernel<2>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, prod_sc, sc, 0, tol);
   else if (exact)
-    hipLaunchKernelGGL(cg_seqsum_kernel<2>, dim3(seq_grid), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, 0, tol, TR);
+    {
+      if (seq_dpp) hipLaunchKernelGGL(cg_seqsum_dpp_kernel<2>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, 0, tol);
+      else hipLaunchKernelGGL(cg_seqsum_kernel<2>, dim3(seq_grid), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, 0, tol, TR, SEQ_COLS);
+    }
   else
     hipLaunchKernelGGL(cg_reduce_kernel<2>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, 0, tol);
   GLX_HIP(hipGetLastError());
@@ -500,6 +661,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   a.perm = A->d_perm;
   a.act_cg = Cg;
   a.act_c = C;
+  a.prod_sc = prod_sc;
   const unsigned pgrid = (unsigned)std::max<int64_t>(((int64_t)n * (L.ld / 4) + 255) / 256, 1);
 
   int64_t it = 0;                               // iterations launched
@@ -518,19 +680,25 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       rc = glx_launch_spmm(a, st);                                                   // Ap = A@p, p.Ap partials
       if (rc) return rc;
       if (np1d)
-        hipLaunchKernelGGL(cg_pairwise1d_kernel<0>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, sc, i, tol);
+        hipLaunchKernelGGL(cg_pairwise1d_kernel<0>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, prod_sc, sc, i, tol);
       else if (exact)
-        hipLaunchKernelGGL(cg_seqsum_kernel<0>, dim3(seq_grid), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, i, tol, TR);
+        {
+      if (seq_dpp) hipLaunchKernelGGL(cg_seqsum_dpp_kernel<0>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
+      else hipLaunchKernelGGL(cg_seqsum_kernel<0>, dim3(seq_grid), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, i, tol, TR, SEQ_COLS);
+    }
       else
         hipLaunchKernelGGL(cg_reduce_kernel<0>, dim3(1), blk, 0, st, (const double*)b.part_dot, nb_spmm, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
       hipLaunchKernelGGL((cg_update_kernel<T, 0>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
-                         (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, sc, i, tol, b.prod, (const int32_t*)A->d_perm);
+                         (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, sc, i, tol, b.prod, prod_sc, (const int32_t*)A->d_perm);
       GLX_HIP(hipGetLastError());
       if (np1d)
-        hipLaunchKernelGGL(cg_pairwise1d_kernel<1>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, ncols, sc, i, tol);
+        hipLaunchKernelGGL(cg_pairwise1d_kernel<1>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, prod_sc, sc, i, tol);
       else if (exact)
-        hipLaunchKernelGGL(cg_seqsum_kernel<1>, dim3(seq_grid), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, i, tol, TR);
+        {
+      if (seq_dpp) hipLaunchKernelGGL(cg_seqsum_dpp_kernel<1>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
+      else hipLaunchKernelGGL(cg_seqsum_kernel<1>, dim3(seq_grid), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, i, tol, TR, SEQ_COLS);
+    }
       else
         hipLaunchKernelGGL(cg_reduce_kernel<1>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());

@@ -112,6 +112,7 @@ struct SweepArgs {
   double* prod_out;              // optional: elementwise xin*xout, row-major (nvec*4 columns), caller row order (CG)
   const double* act_row;         // optional (CG column groups): group g still runs iff act_row[g] > exit_tol
   int act_cg, act_c;             // columns per group / total columns
+  int prod_sc;                   // prod_out column-block width
   const int32_t* perm;
   int64_t n_rows;
 };

@@ -58,6 +58,7 @@ struct SpmmParams {
   const double* act_row;    // CG column groups: group g still runs iff act_row[g] > exit_tol (null: all)
   int act_cg;               // columns per group
   int act_c;                // total columns
+  int prod_sc;              // prod_out is blocked by prod_sc columns: (row, col) at ((col/sc)*n + row)*sc + col%sc
   const int32_t* perm;      // record -> caller row (null: identity)
   int64_t n_rows;
   int ablate;               // developer probe (GLX_ABLATE): 1 no chunk loop, 2 gathers hit one hot record, 4 no stores
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
         f64x4 pd;
 #pragma unroll
         for (int e = 0; e < 4; ++e) pd[e] = (double)pr[e];
-        *(f64x4*)(p.prod_out + (size_t)orow * p.dot_ld + c * 4) = pd;
+        *(f64x4*)(p.prod_out + ((size_t)((c * 4) / p.prod_sc) * p.n_rows + orow) * p.prod_sc + (c * 4) % p.prod_sc) = pd;
       }
     }
 #pragma unroll
@@ -496,6 +497,7 @@ int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
   p.act_row = a.act_row;
   p.act_cg = a.act_cg;
   p.act_c = a.act_c;
+  p.prod_sc = a.prod_sc > 0 ? a.prod_sc : 4;
   p.perm = a.perm;
   p.n_rows = a.n_rows;
   static const int ablate = getenv("GLX_ABLATE") ? atoi(getenv("GLX_ABLATE")) : 0;
