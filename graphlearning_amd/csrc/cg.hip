@@ -18,7 +18,6 @@ template <> struct V4Of<float> { typedef f32x4 type; };
 template <> struct V4Of<double> { typedef f64x4 type; };
 
 static const int CG_CHUNK = 8;
-static const int SEQ_COLS_DEFAULT = 8;    // columns per workgroup of the reference-order reducer (4, 8 or 16)
 static const int UPD_ROWS_PER_BLOCK = 256;
 
 // The C columns may hold several independent systems side by side ("groups" of Cg columns: the
@@ -239,140 +238,14 @@ __global__ __launch_bounds__(256) void cg_group_err_kernel(CgScalars sc, int it,
 // included) -- necessary because the Poisson system is singular and 100+ CG iterations
 // amplify any reordering far beyond 1e-5.  The elementwise products are formed in parallel
 // by the producing kernels (SpMM epilogue / r-update) into an array in the caller's row order,
-// blocked by 8 columns; here one wavefront per block, lane c = column c, adds up its column
-// row after row -- only the add chain is serial.
+// blocked by 4 columns; here one wavefront per block adds up its columns row after row -- only
+// the add chain is serial.
 // MODE 0: tot = sum p*Ap ; alpha = rsold / tot                                (utils.py:524)
 // MODE 1: tot = sum r*r  ; beta = tot / rsold ; rsold = tot ; err = sqrt(np.sum(tot)) (:527-530)
 // MODE 2: rsold = sum r*r                                                     (utils.py:517)
-// One workgroup: wavefronts 1..3 stream the next tile of the row-major product array into
-// registers (coalesced) while wavefront 0 -- lane c = column c, doing nothing else -- adds up the
-// current tile from LDS in row order (16 rows per step, the next 16 already being read); the
-// registers are then written to the other LDS buffer.  Only the add chain is serial, the memory
-// and LDS latencies hide under it.
-template <int MODE>
-__global__ __launch_bounds__(256) void cg_seqsum_kernel(const double* __restrict__ prod_all, int64_t n, int ncols_all, int C,
-                                                        CgScalars sc, int it, double tol, int TR, int SEQ_COLS) {
-#pragma clang fp contract(off)
-  if (MODE != 2 && !cg_any_active(sc, it, tol)) return;
-  extern __shared__ __attribute__((aligned(16))) double s_tile[];   // [2][ncols][TR + 2]
-  const int tid = threadIdx.x;
-  // workgroup b reduces columns [SEQ_COLS b, SEQ_COLS (b + 1))
-  const int col0 = blockIdx.x * SEQ_COLS;
-  const int ncols = min(SEQ_COLS, ncols_all - col0);
-  // block-major layout: element (row, col) at ((col / SEQ_COLS) * n + row) * SEQ_COLS + col % SEQ_COLS,
-  // i.e. this workgroup streams one contiguous array of n rows x SEQ_COLS columns
-  const double* __restrict__ prod = prod_all + (size_t)blockIdx.x * n * SEQ_COLS;
-  if (MODE != 2) {   // nothing to do if every group with a column here has converged
-    bool any = false;
-    for (int cc = col0; cc < col0 + ncols; cc += 1) any = any || cg_col_active(sc, it, tol, cc);
-    if (!any) return;
-  }
-  // wavefront 0 only adds; wavefronts 1..3 (192 threads) stage the tiles
-  const int LDT = TR + 2;                       // even: 16-byte LDS reads; lanes of one read spread over the banks
-  const int lt = tid - 64;                      // loader thread id
-  // loader thread -> (column, first row); 192 is a multiple of every ncols in {4, 8, 12, 16}, so a
-  // thread keeps its column and steps 192/ncols rows per element: no divisions in the loop
-  const int lcc = lt >= 0 ? lt % ncols : 0, lr0 = lt >= 0 ? lt / ncols : 0, rstep = 192 / ncols;
-  const int per = (TR + rstep - 1) / rstep;     // elements per loader thread per tile (<= 24)
-  // two register sets: the global loads of tile t+2 are in flight while tile t+1 waits in the
-  // other set to be written to LDS and tile t is being added up
-  double regA[24], regB[24];
-  auto tile_load = [&](double (&reg)[24], int64_t base) {
-    const double* src = prod + (size_t)(base + lr0) * SEQ_COLS + lcc;
-#pragma unroll
-    for (int q = 0; q < 24; ++q) {
-      const int r = lr0 + q * rstep;
-      double v = 0.0;
-      if (q < per && r < TR && base + r < n) v = src[(size_t)q * rstep * SEQ_COLS];
-      reg[q] = v;
-    }
-  };
-  auto tile_store = [&](const double (&reg)[24], int buf) {
-    double* dst = s_tile + (size_t)buf * ncols * LDT + lcc * LDT + lr0;
-#pragma unroll
-    for (int q = 0; q < 24; ++q) {
-      if (q < per && lr0 + q * rstep < TR) dst[q * rstep] = reg[q];
-    }
-  };
-  const bool loader = tid >= 64;
-  const int c = tid;
-  double tot = 0.0;
-  auto chain = [&](int buf, int64_t base) {
-    if (tid < ncols) {
-      const double* col = s_tile + (size_t)buf * ncols * LDT + c * LDT;
-      const int rows = (int)min((int64_t)TR, n - base);
-      // The wavefront can issue one instruction every 4 cycles and a dependent fp64 add every ~6, so
-      // every instruction that is not an add stretches the chain: 32 rows per group (one 16-byte LDS
-      // read per 2 rows, the reads of the next group in flight while this one is added), two groups
-      // per loop iteration, no branch inside.
-      const int ngr = rows / 32;
-      double va[32], vb[32];
-      auto fetch = [&](double (&v)[32], int g) {
-        const double2* src = (const double2*)(col + g * 32);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { const double2 t = src[q]; v[2 * q] = t.x; v[2 * q + 1] = t.y; }
-      };
-      int g = 0;
-      if (ngr > 0) fetch(va, 0);
-      for (; g + 2 <= ngr; g += 2) {
-        // (sched_barrier: keep the reads of the next group IN FRONT of this group's adds -- the
-        // scheduler otherwise sinks them behind the chain and their LDS latency is exposed)
-        fetch(vb, g + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 32; ++q) tot = tot + va[q];
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(va, g + 2 < ngr ? g + 2 : g + 1);   // (clamped: the last prefetch re-reads a valid group)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 32; ++q) tot = tot + vb[q];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (g < ngr) {   // odd group count: one group left, already in va
-#pragma unroll
-        for (int q = 0; q < 32; ++q) tot = tot + va[q];
-        ++g;
-      }
-      for (int r = ngr * 32; r < rows; ++r) tot = tot + col[r];
-    }
-  };
-  if (loader) {
-    tile_load(regA, 0);
-    tile_store(regA, 0);
-    if (TR < n) tile_load(regA, TR);
-  }
-  __syncthreads();
-  // invariant at the top of a step: tile t is in LDS buffer (t & 1), tile t+1 in `nxt`
-  auto step = [&](int64_t base, int buf, double (&nxt)[24], double (&nxt2)[24]) {
-    if (loader && base + 2 * (int64_t)TR < n) tile_load(nxt2, base + 2 * (int64_t)TR);
-    chain(buf, base);
-    if (loader && base + TR < n) tile_store(nxt, buf ^ 1);
-    // workgroup barrier that orders LDS only: __syncthreads() would also drain the loaders' global
-    // loads (vmcnt(0)), i.e. wait for the tile that was just requested two steps ahead
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  };
-  for (int64_t base = 0; base < n; base += 2 * (int64_t)TR) {
-    step(base, 0, regA, regB);
-    if (base + TR < n) step(base + TR, 1, regB, regA);
-  }
-  if (c < ncols) {
-    const int gc = col0 + c;
-    const bool live = MODE == 2 || gc >= C || cg_col_active(sc, it, tol, gc);
-    if (!live) {
-    } else if (MODE == 0) {
-      sc.alpha[gc] = gc < C ? sc.rsold[gc] / tot : 0.0;
-    } else if (MODE == 1) {
-      sc.beta[gc] = gc < C ? tot / sc.rsold[gc] : 0.0;
-      sc.rsold[gc] = tot;
-    } else {
-      sc.rsold[gc] = tot;
-    }
-  }
-}
-
-// ---- the same reduction with the add chain fed through DPP ----------------------------------
-// A wavefront issues one instruction every 4 cycles and a dependent fp64 add every ~6, so in the
-// kernel above every LDS read that feeds the chain stretches it.  Here one wavefront owns 4
+// A wavefront issues one instruction every 4 cycles and a dependent fp64 add every ~6, so every
+// instruction that is not an add stretches the chain (an LDS-staged version with one 16-byte read
+// per 2 rows ran at 4.1 ns per row; this one at 2.4, the latency of the add).  One wavefront owns 4
 // columns, one per DPP row of 16 lanes: lane k of row r loads element (16 g + k, column r) straight
 // from global memory (the product array is blocked by 4 columns, so a wavefront load is 512
 // contiguous bytes), and `v_fmac_f64_dpp tot, x, 1.0 row_newbcast:k` adds the value held by lane k
@@ -571,28 +444,9 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   const int64_t hist_cap = max_iter + 2;
   GLX_CHECK(max_iter < (1ll << 24), GLX_EUNSUPPORTED, "glx_cg_multi: max_iter %lld exceeds the supported 2^24-1", (long long)max_iter);
 
-  // tile of the reference-order reducer (one workgroup per SEQ_COLS columns): TR rows x <= SEQ_COLS columns,
-  // 24 elements per thread at most
-  int SEQ_COLS = SEQ_COLS_DEFAULT;
-  if (const char* e = getenv("GLX_CG_SEQ_COLS")) {   // developer probe
-    const int v = atoi(e);
-    if (v == 4 || v == 8 || v == 16) SEQ_COLS = v;
-  }
-  const char* seq_env = getenv("GLX_CG_SEQ");
-  const bool seq_dpp = !(seq_env && strcmp(seq_env, "lds") == 0);   // developer probe: the LDS-fed reducer
-  if (seq_dpp) SEQ_COLS = 4;
-  SEQ_COLS = std::min(SEQ_COLS, ncols);
-  const int prod_sc = SEQ_COLS;
-  const int seq_cols = SEQ_COLS;
-  const unsigned seq_grid = (unsigned)((ncols + SEQ_COLS - 1) / SEQ_COLS);
-  int TR = 512;
-  while (TR > 16 && TR * seq_cols > 24 * 192) TR -= 32;    // 192 loader threads, <= 24 elements each
-  const size_t seq_shm = (size_t)2 * seq_cols * (TR + 2) * 8;
-  if (exact) {
-    GLX_HIP(hipFuncSetAttribute((const void*)cg_seqsum_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_shm));
-    GLX_HIP(hipFuncSetAttribute((const void*)cg_seqsum_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_shm));
-    GLX_HIP(hipFuncSetAttribute((const void*)cg_seqsum_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_shm));
-  }
+  // reference-order reducer: one wavefront per 4 columns; the product array is blocked the same way
+  const int prod_sc = 4;
+  const unsigned seq_grid = (unsigned)(ncols / 4);
   CgBufs b;
   const size_t recb = std::max<size_t>((size_t)n * L.ld * es, 64);
   GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
@@ -605,7 +459,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   GLX_HIP(hipMalloc(&b.part_rs, nb_upd * ncols * 8));
   GLX_HIP(hipMalloc(&b.scal, 3 * ncols * 8));
   GLX_HIP(hipMalloc(&b.err_hist, hist_cap * stride * 8));
-  if (exact) GLX_HIP(hipMalloc(&b.prod, std::max<size_t>((size_t)seq_grid * SEQ_COLS * n * 8, 64)));
+  if (exact) GLX_HIP(hipMalloc(&b.prod, std::max<size_t>((size_t)ncols * n * 8, 64)));
   GLX_HIP(hipHostMalloc((void**)&b.h_err, (size_t)(CG_CHUNK + 1) * stride * 8, hipHostMallocDefault));
   CgScalars sc;
   sc.rsold = b.scal;
@@ -639,10 +493,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   if (np1d)
     hipLaunchKernelGGL(cg_pairwise1d_kernel<2>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, prod_sc, sc, 0, tol);
   else if (exact)
-    {
-      if (seq_dpp) hipLaunchKernelGGL(cg_seqsum_dpp_kernel<2>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, 0, tol);
-      else hipLaunchKernelGGL(cg_seqsum_kernel<2>, dim3(seq_grid), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, 0, tol, TR, SEQ_COLS);
-    }
+    hipLaunchKernelGGL(cg_seqsum_dpp_kernel<2>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, 0, tol);
   else
     hipLaunchKernelGGL(cg_reduce_kernel<2>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, 0, tol);
   GLX_HIP(hipGetLastError());
@@ -682,10 +533,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       if (np1d)
         hipLaunchKernelGGL(cg_pairwise1d_kernel<0>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, prod_sc, sc, i, tol);
       else if (exact)
-        {
-      if (seq_dpp) hipLaunchKernelGGL(cg_seqsum_dpp_kernel<0>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
-      else hipLaunchKernelGGL(cg_seqsum_kernel<0>, dim3(seq_grid), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, i, tol, TR, SEQ_COLS);
-    }
+        hipLaunchKernelGGL(cg_seqsum_dpp_kernel<0>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       else
         hipLaunchKernelGGL(cg_reduce_kernel<0>, dim3(1), blk, 0, st, (const double*)b.part_dot, nb_spmm, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
@@ -695,10 +543,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       if (np1d)
         hipLaunchKernelGGL(cg_pairwise1d_kernel<1>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, prod_sc, sc, i, tol);
       else if (exact)
-        {
-      if (seq_dpp) hipLaunchKernelGGL(cg_seqsum_dpp_kernel<1>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
-      else hipLaunchKernelGGL(cg_seqsum_kernel<1>, dim3(seq_grid), dim3(256), seq_shm, st, (const double*)b.prod, n, ncols, C, sc, i, tol, TR, SEQ_COLS);
-    }
+        hipLaunchKernelGGL(cg_seqsum_dpp_kernel<1>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       else
         hipLaunchKernelGGL(cg_reduce_kernel<1>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
