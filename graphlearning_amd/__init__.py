@@ -14,7 +14,7 @@ behind the C-ABI of include/glx.h (libglx.so, loaded with ctypes).  There is no 
 fallback: without the built library and a GPU the solvers raise.
 """
 from . import utils
-from . import graph
+from .graph import graph          # like the reference: gl.graph(W) is the class (gl.graph.graph also works)
 from . import trainsets
 from . import weightmatrix
 from . import ssl

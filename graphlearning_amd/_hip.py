@@ -78,6 +78,7 @@ _SIGNATURES = {
     'glx_unpack_records_dev': [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp],
     'glx_cg_multi': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), _f64p],
     'glx_cg_solve': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
+    'glx_affine_iterate': [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int64), _f64p],
     'glx_cg_groups': [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_argmax_project': [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
     'glx_knn_bruteforce': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
@@ -212,6 +213,22 @@ class DeviceGraph:
         check(load().glx_cg_solve(self._h, _ptr(B), _ptr(X), B.shape[1], float(tol), int(max_iter), 1 if squeeze else 0,
                                   C.byref(it), C.byref(err)), 'glx_cg_solve')
         return (X[:, 0] if squeeze else X), it.value, err.value
+
+    def affine_iterate(self, u0, b=None, tol=1e-10, max_iter=1000000):
+        """u <- A u + b from u0 until max|u_new - u_old| <= tol (graph.page_rank's power iteration):
+        returns (u, sweeps, err)."""
+        u0 = np.ascontiguousarray(u0, dtype=self.dtype)
+        squeeze = u0.ndim == 1
+        if squeeze:
+            u0 = u0[:, None]
+        if b is not None:
+            b = np.ascontiguousarray(b, dtype=self.dtype).reshape(u0.shape)
+        out = np.empty_like(u0)
+        it = C.c_int64(0)
+        err = C.c_double(0)
+        check(load().glx_affine_iterate(self._h, _ptr(b) if b is not None else None, _ptr(u0), _ptr(out), u0.shape[1], float(tol),
+                                        int(max_iter), C.byref(it), C.byref(err)), 'glx_affine_iterate')
+        return (out[:, 0] if squeeze else out), it.value, err.value
 
     def cg_groups(self, B, group_cols, tol=1e-10, max_iter=100000):
         """Independent systems side by side (columns in groups of `group_cols`), each with its own

@@ -7,6 +7,7 @@
 #include <map>
 #include <math.h>
 #include <vector>
+#include <algorithm>
 
 static const int ERR_SHARDS = 64;
 static const int TAIL_CHUNK = 16;
@@ -387,6 +388,74 @@ extern "C" int glx_spmm_bias(glx_graph* A, const void* Db, const void* u_in, voi
     if (!rc && hipStreamSynchronize(s->stream) != hipSuccess) { glx_set_error("glx_spmm_bias: sync failed"); rc = GLX_EHIP; }
   }
   if (!rc) rc = glx_sweep_fetch(s, u_out);
+  glx_sweep_destroy(s);
+  return rc;
+}
+
+// ---- affine fixed-point iteration with a sup-norm stop ---------------------------------------
+// u <- A u + b until max |u_new - u_old| <= tol: the power iteration of graph.page_rank
+// (graphlearning/graph.py:1405-1410: `w = alpha*P@u + (1-alpha)*v ; err = np.max(np.absolute(w-u))`,
+// `while err > tol`).  The records of both iterates are compared element by element (padding is 0
+// in both); NaN bit patterns order above +inf, so a NaN difference ends the loop like `nan > tol`.
+template <typename T>
+__global__ __launch_bounds__(256) void absdiff_max_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t total,
+                                                          unsigned long long* __restrict__ out) {
+  unsigned long long m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const T d = a[i] - b[i];                  // the subtraction in the array dtype, like numpy
+    const double ad = fabs((double)d);
+    const unsigned long long u = (unsigned long long)__double_as_longlong(ad);
+    m = u > m ? u : m;
+  }
+  __shared__ unsigned long long s_m[256];
+  s_m[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off && s_m[threadIdx.x + off] > s_m[threadIdx.x]) s_m[threadIdx.x] = s_m[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && s_m[0] != 0) atomicMax(out, s_m[0]);
+}
+
+extern "C" int glx_affine_iterate(glx_graph* A, const void* b, const void* u0, void* u_out, int C, double tol, int64_t max_iter,
+                                  int64_t* iters_out, double* err_out) {
+  GLX_CHECK(A && u0 && u_out, GLX_EINVAL, "glx_affine_iterate: null argument");
+  GLX_CHECK(A->n_rows == A->n_cols, GLX_EINVAL, "glx_affine_iterate: operator must be square");
+  GLX_CHECK(max_iter >= 0, GLX_EINVAL, "glx_affine_iterate: negative max_iter");
+  glx_sweep* s = nullptr;
+  int rc = glx_sweep_create(A, C, 0, 0, 0, &s);
+  if (rc) return rc;
+  rc = glx_sweep_set_state(s, u0, b);
+  unsigned long long* d_err = nullptr;
+  unsigned long long* h_err = nullptr;
+  int64_t it = 0;
+  double err = tol + 1.0;                      // graph.py:1404
+  if (!rc && hipMalloc(&d_err, 8) != hipSuccess) { glx_set_error("glx_affine_iterate: hipMalloc failed"); rc = GLX_EHIP; }
+  if (!rc && hipHostMalloc((void**)&h_err, 8, hipHostMallocDefault) != hipSuccess) { glx_set_error("glx_affine_iterate: hipHostMalloc failed"); rc = GLX_EHIP; }
+  const int64_t total = s ? (int64_t)s->n_rows * s->L.ld : 0;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, (total + 255) / 256));
+  while (!rc && err > tol && it < max_iter) {
+    hipError_t e = hipMemsetAsync(d_err, 0, 8, s->stream);
+    if (e == hipSuccess) {
+      rc = launch_sweep(s, (int)(it & 1), false);
+      if (rc) break;
+      if (A->dtype == GLX_F32)
+        hipLaunchKernelGGL(absdiff_max_kernel<float>, dim3(grid), dim3(256), 0, s->stream, (const float*)s->buf[0], (const float*)s->buf[1], total, d_err);
+      else
+        hipLaunchKernelGGL(absdiff_max_kernel<double>, dim3(grid), dim3(256), 0, s->stream, (const double*)s->buf[0], (const double*)s->buf[1], total, d_err);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_err, d_err, 8, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess) { glx_set_error("glx_affine_iterate: %s", hipGetErrorString(e)); rc = GLX_EHIP; break; }
+    err = __builtin_bit_cast(double, *h_err);
+    ++it;
+  }
+  if (!rc) rc = glx_sweep_fetch(s, u_out);
+  if (iters_out) *iters_out = it;
+  if (err_out) *err_out = err;
+  hipFree(d_err);
+  if (h_err) hipHostFree(h_err);
   glx_sweep_destroy(s);
   return rc;
 }

@@ -77,6 +77,34 @@ class graph:
         else:
             sys.exit('Invalid reweighting method ' + method + '.')
 
+    def page_rank(self, alpha=0.85, v=None, tol=1e-10, device=None):
+        """PageRank vector by the power iteration u <- alpha P u + (1-alpha) v, P = W^T D^-1, from
+        u = 1/n until max|u_new - u_old| <= tol (reference graph.py:1371-1412).  The host builds
+        alpha*P with the reference's own scipy expressions; every sweep and the stop test run on the
+        GPU (glx_affine_iterate).  Bit-identical to the reference: a row's products are added in
+        the order scipy's matvec of that matrix adds them."""
+        from . import _hip
+        n = self.num_nodes
+        u = np.ones((n,)) / n
+        if v is None:
+            v = np.ones((n,)) / n
+        D = self.degree_matrix(p=-1)
+        P = self.weight_matrix.T @ D
+        aP = alpha * P              # `alpha*P@u` in the reference is (alpha*P)@u
+        # csc_matvec adds a row's products column after column (ascending), which is the row order
+        # csc -> csr conversion produces; a csr operand is used by csr_matvec in stored order
+        A = aP.tocsr()
+        self.page_rank_iters = 0
+        if not (tol + 1 > tol):     # `err = tol+1; while err > tol` never enters the loop
+            return u
+        dev = _hip.DeviceGraph(A, dtype=np.float64, device=device)
+        try:
+            u, it, _ = dev.affine_iterate(u, b=(1 - alpha) * v, tol=tol)
+        finally:
+            dev.close()
+        self.page_rank_iters = it
+        return u
+
     def subgraph(self, ind):
         W = self.weight_matrix
         return graph(W[ind, :][:, ind])
@@ -84,3 +112,8 @@ class graph:
     def isconnected(self):
         from scipy.sparse import csgraph
         return csgraph.connected_components(self.weight_matrix)[0] == 1
+
+
+# the reference exposes the class as `graphlearning.graph` (its __init__ rebinds the name of this
+# module to the class); `gl.graph.graph(W)` -- the module-style spelling -- keeps working too
+graph.graph = graph

@@ -111,6 +111,14 @@ int glx_pack_records_dev(const void* dense, void* rec, int64_t n, int C, int dty
                          void* stream);
 int glx_unpack_records_dev(const void* rec, void* dense, int64_t n, int C, int dtype, int has_w, void* stream);
 
+/* ---- affine fixed-point iteration with a sup-norm stop --------------------------------
+ * u <- A u + b (b may be NULL) from u0 until max|u_new - u_old| <= tol or max_iter sweeps: the power
+ * iteration of graph.page_rank (graphlearning/graph.py:1371-1412) with A = alpha * W^T D^-1 and
+ * b = (1-alpha) v, all iterations on the device.  b, u0, u_out: (n, C) host arrays in the operator's
+ * state dtype.  iters_out: sweeps done; err_out: the last max|u_new - u_old|. */
+int glx_affine_iterate(glx_graph* A, const void* b, const void* u0, void* u_out, int C, double tol,
+                       int64_t max_iter, int64_t* iters_out, double* err_out);
+
 /* ---- multi right-hand-side conjugate gradient -------------------------------------
  * Replaces utils.conjgrad (graphlearning/utils.py:483-532): x0 = 0, per-column
  * alpha/beta, global stop sqrt(sum over all columns ||r||^2) <= tol, max_iter cap. */

@@ -470,6 +470,27 @@ def randomwalk_fit(W, train_ind, train_labels, alpha=0.95, return_iters=False):
     return (u, it) if return_iters else u
 
 
+def page_rank(W, alpha=0.85, v=None, tol=1e-10, return_iters=False):
+    """graph.page_rank, graphlearning/graph.py:1371-1412: power iteration
+    u <- alpha*P@u + (1-alpha)*v with P = W^T D^-1, from u = 1/n, `while err > tol` on
+    err = max|w - u|.  (`alpha*P@u` parses as (alpha*P)@u: the scaled matrix times u.)"""
+    W = sparse.csr_matrix(W)
+    n = W.shape[0]
+    u = np.ones((n,)) / n
+    if v is None:
+        v = np.ones((n,)) / n
+    D = degree_matrix(W, p=-1)
+    P = W.T @ D
+    err = tol + 1
+    it = 0
+    while err > tol:
+        w = alpha * P @ u + (1 - alpha) * v
+        err = np.max(np.absolute(w - u))
+        u = w.copy()
+        it += 1
+    return (u, it) if return_iters else u
+
+
 # ----------------------------------------------------------------------------
 # a-6  PoissonMBO (graphlearning/ssl.py:774-839)
 # ----------------------------------------------------------------------------

@@ -240,6 +240,30 @@ def g7_next_rows():
     print('g7 done, randomwalk iters', it)
 
 
+def g8_pagerank():
+    """graph.page_rank (graph.py:1371-1412) on two-moons and on a directed (unsymmetrised) graph."""
+    X, labels = skd.make_moons(n_samples=500, noise=0.1, random_state=0)
+    knn_data = gl.weightmatrix.knnsearch(X, 11, method='kdtree')
+    out = {}
+    for tag, sym in (('sym', True), ('dir', False)):
+        W = gl.weightmatrix.knn(X, 10, knn_data=knn_data, symmetrize=sym)
+        out.update(csr_parts(W, 'W_' + tag))
+        G = gl.graph(W)
+        out['pr_' + tag] = G.page_rank()
+        u, it = orc.page_rank(W, return_iters=True)
+        assert np.array_equal(u, out['pr_' + tag])
+        out['pr_' + tag + '_iters'] = np.int64(it)
+        v = np.zeros(500)
+        v[[3, 77, 400]] = 1 / 3
+        out['pr_' + tag + '_v'] = v
+        out['pr_' + tag + '_tele'] = G.page_rank(alpha=0.5, v=v, tol=1e-8)
+        u, it = orc.page_rank(W, alpha=0.5, v=v, tol=1e-8, return_iters=True)
+        assert np.array_equal(u, out['pr_' + tag + '_tele'])
+        out['pr_' + tag + '_tele_iters'] = np.int64(it)
+    np.savez_compressed(os.path.join(HERE, 'g8_pagerank.npz'), **out)
+    print('g8 done, iterations', out['pr_sym_iters'], out['pr_dir_iters'], out['pr_sym_tele_iters'])
+
+
 def g4_large():
     """Config 2 (70k) and config 3 (60k): checksums only; the graphs are
     regenerated from seeds by the oracle on the GPU box."""
@@ -292,12 +316,17 @@ def g4_large():
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--large', action='store_true', help='also regenerate the 70k/60k checksum file (minutes)')
+    ap.add_argument('--only', default=None, help='run a single generator, e.g. g8_pagerank')
     args = ap.parse_args()
+    if args.only:
+        globals()[args.only]()
+        sys.exit(0)
     g1_twomoons()
     g2_knn()
     g3_mid()
     g5_projection()
     g6_helpers()
     g7_next_rows()
+    g8_pagerank()
     if args.large:
         g4_large()

@@ -372,3 +372,27 @@ def test_prepared_sweep_reuse(gl, golden):
             ref = P * ref if bias is None else P * ref + bias
         assert np.array_equal(heat.fetch(), ref)
     heat.close()
+
+
+def test_page_rank_golden(gl, golden):
+    """graph.page_rank on the device: vectors and sweep counts bit-identical to the
+    reference, symmetric and directed graph, default and custom teleportation vector."""
+    g = golden('g8_pagerank.npz')
+    for tag in ('sym', 'dir'):
+        G = gl.graph(csr_from(g, 'W_' + tag))
+        u = G.page_rank()
+        assert G.page_rank_iters == int(g['pr_' + tag + '_iters'])
+        assert np.array_equal(u, g['pr_' + tag])
+        u = G.page_rank(alpha=0.5, v=g['pr_' + tag + '_v'], tol=1e-8)
+        assert G.page_rank_iters == int(g['pr_' + tag + '_tele_iters'])
+        assert np.array_equal(u, g['pr_' + tag + '_tele'])
+
+
+def test_page_rank_midsize_vs_oracle(gl, orc):
+    X, labels = blobs(6000, 10, 6, 4, 2.0)
+    W = gl.weightmatrix.knn(X, 12)
+    G = gl.graph(W)
+    u = G.page_rank(alpha=0.9, tol=1e-12)
+    uo, it = orc.page_rank(W, alpha=0.9, tol=1e-12, return_iters=True)
+    assert G.page_rank_iters == it
+    assert np.array_equal(u, uo)

@@ -157,3 +157,15 @@ def test_g7_next_rows(golden):
     u, it = orc.randomwalk_fit(W, ti, lab[ti], return_iters=True)
     assert it == int(g['randomwalk_iters']) and np.array_equal(u, g['randomwalk_prob'])
     assert np.array_equal(orc.conjgrad(csr_from(g, 'cg1d_A'), g['cg1d_rhs'], tol=1e-9), g['cg1d_x'])
+
+
+def test_g8_pagerank(golden):
+    """graph.page_rank (graph.py:1371-1412): the oracle reproduces the reference's vectors and
+    iteration counts bit for bit, symmetric and directed graph, default and custom teleportation."""
+    g = golden('g8_pagerank.npz')
+    for tag in ('sym', 'dir'):
+        W = csr_from(g, 'W_' + tag)
+        u, it = orc.page_rank(W, return_iters=True)
+        assert it == int(g['pr_' + tag + '_iters']) and np.array_equal(u, g['pr_' + tag])
+        u, it = orc.page_rank(W, alpha=0.5, v=g['pr_' + tag + '_v'], tol=1e-8, return_iters=True)
+        assert it == int(g['pr_' + tag + '_tele_iters']) and np.array_equal(u, g['pr_' + tag + '_tele'])
