@@ -124,3 +124,12 @@ int glx_pack_records(const void* dense, void* rec, int64_t n, const RecLayout& L
                      const int32_t* perm = nullptr);
 int glx_unpack_records(const void* rec, void* dense, int64_t n, const RecLayout& L, int dtype, hipStream_t s,
                        const int32_t* perm = nullptr);
+
+// project.hip: ssl.predict / volume_label_projection on a device-resident (n, C) array of the state dtype
+struct glx_projector;
+int glx_project_device(glx_projector** pp, const void* dense_dev, int dtype, int64_t n, int C, const double* priors,
+                       double* weights_inout, double* err_out, int* steps_out, int max_steps, int similarity, hipStream_t st,
+                       const long long** d_labels_out);
+int glx_onehot_device(const long long* d_labels, void* dense_dev, int dtype, int64_t n, int C, hipStream_t st);
+void glx_projector_destroy(glx_projector* p);
+

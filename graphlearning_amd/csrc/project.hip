@@ -134,28 +134,31 @@ struct ProjBufs {
   double *scores = nullptr, *bmin = nullptr, *bmax = nullptr, *mm = nullptr, *w = nullptr, *priors = nullptr, *err = nullptr;
   long long *counts = nullptr, *labels = nullptr;
   int *steps = nullptr, *done = nullptr;
-  hipStream_t stream = nullptr;
-  ~ProjBufs() {
+  hipStream_t stream = nullptr;   // owned only by the one-shot entry point
+  int64_t cap_n = 0;
+  int cap_C = 0;
+  void release() {
     hipFree(scores); hipFree(bmin); hipFree(bmax); hipFree(mm); hipFree(w); hipFree(priors); hipFree(err);
     hipFree(counts); hipFree(labels); hipFree(steps); hipFree(done);
+    scores = bmin = bmax = mm = w = priors = err = nullptr;
+    counts = labels = nullptr;
+    steps = done = nullptr;
+    cap_n = 0;
+    cap_C = 0;
+  }
+  ~ProjBufs() {
+    release();
     if (stream) hipStreamDestroy(stream);
   }
 };
 
-extern "C" int glx_argmax_project(const double* prob, int64_t n, int C, const double* priors, double* weights_inout,
-                                  int64_t* labels_out, double* err_out, int* steps_out, int max_steps, int similarity,
-                                  int device) {
-  GLX_CHECK(prob && weights_inout && labels_out, GLX_EINVAL, "glx_argmax_project: null argument");
-  GLX_CHECK(n >= 1 && C >= 1, GLX_EINVAL, "glx_argmax_project: empty input (n=%lld, C=%d)", (long long)n, C);
-  GLX_CHECK(max_steps == 0 || priors, GLX_EINVAL, "glx_argmax_project: projection needs priors");
-  GLX_CHECK(C <= 4096, GLX_EUNSUPPORTED, "glx_argmax_project: C=%d too large", C);
-  GLX_HIP(hipSetDevice(device));
-  ProjBufs b;
+static int proj_blocks(int64_t total) { return (int)std::min<int64_t>((total + 255) / 256, 1024); }
+
+static int proj_alloc(ProjBufs& b, int64_t n, int C) {
+  if (b.cap_n >= n && b.cap_C >= C && b.scores) return GLX_OK;
+  b.release();
   const int64_t total = n * C;
-  const int nb = (int)std::min<int64_t>((total + 255) / 256, 1024);
-  const int nbr = (int)std::min<int64_t>((n + 255) / 256, 2048);
-  GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
-  hipStream_t st = b.stream;
+  const int nb = proj_blocks(total);
   GLX_HIP(hipMalloc(&b.scores, total * 8));
   GLX_HIP(hipMalloc(&b.bmin, nb * 8));
   GLX_HIP(hipMalloc(&b.bmax, nb * 8));
@@ -167,7 +170,18 @@ extern "C" int glx_argmax_project(const double* prob, int64_t n, int C, const do
   GLX_HIP(hipMalloc(&b.labels, n * 8));
   GLX_HIP(hipMalloc(&b.steps, 4));
   GLX_HIP(hipMalloc(&b.done, 4));
-  GLX_HIP(hipMemcpyAsync(b.scores, prob, total * 8, hipMemcpyHostToDevice, st));
+  b.cap_n = n;
+  b.cap_C = C;
+  return GLX_OK;
+}
+
+// the decision itself: b.scores holds prob (n, C) fp64 on the device (overwritten by the scores);
+// on return b.labels holds the labels and weights_inout the updated class weights
+static int proj_core(ProjBufs& b, hipStream_t st, int64_t n, int C, const double* priors, double* weights_inout, double* err_out,
+                     int* steps_out, int max_steps, int similarity) {
+  const int64_t total = n * C;
+  const int nb = proj_blocks(total);
+  const int nbr = (int)std::min<int64_t>((n + 255) / 256, 2048);
   GLX_HIP(hipMemcpyAsync(b.w, weights_inout, C * 8, hipMemcpyHostToDevice, st));
   if (priors) GLX_HIP(hipMemcpyAsync(b.priors, priors, C * 8, hipMemcpyHostToDevice, st));
   GLX_HIP(hipMemsetAsync(b.counts, 0, C * 8, st));
@@ -209,10 +223,82 @@ extern "C" int glx_argmax_project(const double* prob, int64_t n, int C, const do
   // final predict with the (updated) weights                                 (ssl.py:209)
   hipLaunchKernelGGL(argmax_hist_kernel, dim3(nbr), dim3(256), shm, st, (const double*)b.scores, n, C, ps, b.labels, similarity, 0, 0);
   GLX_HIP(hipGetLastError());
-  GLX_HIP(hipMemcpyAsync(labels_out, b.labels, n * 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipMemcpyAsync(weights_inout, b.w, C * 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
   if (err_out) *err_out = err;
   if (steps_out) *steps_out = steps;
   return GLX_OK;
 }
+
+extern "C" int glx_argmax_project(const double* prob, int64_t n, int C, const double* priors, double* weights_inout,
+                                  int64_t* labels_out, double* err_out, int* steps_out, int max_steps, int similarity,
+                                  int device) {
+  GLX_CHECK(prob && weights_inout && labels_out, GLX_EINVAL, "glx_argmax_project: null argument");
+  GLX_CHECK(n >= 1 && C >= 1, GLX_EINVAL, "glx_argmax_project: empty input (n=%lld, C=%d)", (long long)n, C);
+  GLX_CHECK(max_steps == 0 || priors, GLX_EINVAL, "glx_argmax_project: projection needs priors");
+  GLX_CHECK(C <= 4096, GLX_EUNSUPPORTED, "glx_argmax_project: C=%d too large", C);
+  GLX_HIP(hipSetDevice(device));
+  ProjBufs b;
+  GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+  hipStream_t st = b.stream;
+  int rc = proj_alloc(b, n, C);
+  if (rc) return rc;
+  GLX_HIP(hipMemcpyAsync(b.scores, prob, (size_t)n * C * 8, hipMemcpyHostToDevice, st));
+  rc = proj_core(b, st, n, C, priors, weights_inout, err_out, steps_out, max_steps, similarity);
+  if (rc) return rc;
+  GLX_HIP(hipMemcpyAsync(labels_out, b.labels, n * 8, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipStreamSynchronize(st));
+  return GLX_OK;
+}
+
+// ---- the same decision on a device-resident (n, C) array (glx_sweep_project) --------------------
+struct glx_projector { ProjBufs b; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void to_f64_kernel(const T* __restrict__ src, double* __restrict__ dst, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < total) dst[i] = (double)src[i];
+}
+
+// dense[i, c] = (labels[i] == c), utils.labels_to_onehot (utils.py:536-572) for labels in 0..C-1
+template <typename T>
+__global__ __launch_bounds__(256) void onehot_kernel(const long long* __restrict__ labels, T* __restrict__ dense, int64_t n, int C) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * C) return;
+  dense[i] = (labels[i / C] == (long long)(i % C)) ? (T)1 : (T)0;
+}
+
+int glx_project_device(glx_projector** pp, const void* dense_dev, int dtype, int64_t n, int C, const double* priors,
+                       double* weights_inout, double* err_out, int* steps_out, int max_steps, int similarity, hipStream_t st,
+                       const long long** d_labels_out) {
+  GLX_CHECK(pp && dense_dev && weights_inout, GLX_EINVAL, "glx_project_device: null argument");
+  GLX_CHECK(max_steps == 0 || priors, GLX_EINVAL, "glx_sweep_project: projection needs priors");
+  GLX_CHECK(C <= 4096, GLX_EUNSUPPORTED, "glx_sweep_project: C=%d too large", C);
+  if (!*pp) *pp = new glx_projector();
+  ProjBufs& b = (*pp)->b;
+  int rc = proj_alloc(b, n, C);
+  if (rc) return rc;
+  const int64_t total = n * C;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (dtype == GLX_F32)
+    hipLaunchKernelGGL(to_f64_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dense_dev, b.scores, total);
+  else
+    hipLaunchKernelGGL(to_f64_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)dense_dev, b.scores, total);
+  GLX_HIP(hipGetLastError());
+  rc = proj_core(b, st, n, C, priors, weights_inout, err_out, steps_out, max_steps, similarity);
+  if (rc) return rc;
+  if (d_labels_out) *d_labels_out = b.labels;
+  return GLX_OK;
+}
+
+int glx_onehot_device(const long long* d_labels, void* dense_dev, int dtype, int64_t n, int C, hipStream_t st) {
+  const unsigned grid = (unsigned)((n * C + 255) / 256);
+  if (dtype == GLX_F32)
+    hipLaunchKernelGGL(onehot_kernel<float>, dim3(grid), dim3(256), 0, st, d_labels, (float*)dense_dev, n, C);
+  else
+    hipLaunchKernelGGL(onehot_kernel<double>, dim3(grid), dim3(256), 0, st, d_labels, (double*)dense_dev, n, C);
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}
+
+void glx_projector_destroy(glx_projector* p) { delete p; }

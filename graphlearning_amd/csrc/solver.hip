@@ -30,6 +30,7 @@ struct glx_sweep {
   void* dense = nullptr;                    // staging (n_cols, C)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  glx_projector* proj = nullptr;            // label decision on the device-resident state (glx_sweep_project)
   hipGraphExec_t head_exec = nullptr;       // captured: reset + min_iter unconditional sweeps
   std::map<long, hipGraphExec_t> iter_exec; // heat loop graphs keyed by (iters, parity)
   int cur = 0;
@@ -55,6 +56,7 @@ extern "C" int glx_sweep_destroy(glx_sweep* s) {
   hipFree(s->err);
   if (s->h_err) hipHostFree(s->h_err);
   hipFree(s->dense);
+  glx_projector_destroy(s->proj);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -307,6 +309,32 @@ extern "C" int glx_sweep_fetch(glx_sweep* s, void* u_out) {
   int rc = glx_unpack_records(s->buf[s->cur], s->dense, s->n_rows, s->L, s->P->dtype, s->stream, s->P->d_perm);
   if (rc) return rc;
   GLX_HIP(hipMemcpyAsync(u_out, s->dense, (size_t)s->n_rows * s->C * s->L.esize, hipMemcpyDeviceToHost, s->stream));
+  GLX_HIP(hipStreamSynchronize(s->stream));
+  return GLX_OK;
+}
+
+// ssl.predict / ssl.volume_label_projection (ssl.py:230-266, 172-209) on the sweep's current state
+// without a host round trip; with to_onehot the state is then replaced by onehot(labels), which is
+// the hand-over between the heat sweeps and the thresholding of PoissonMBO (ssl.py:826-832).
+extern "C" int glx_sweep_project(glx_sweep* s, const double* priors, double* weights_inout, int64_t* labels_out, double* err_out,
+                                 int* steps_out, int max_steps, int similarity, int to_onehot) {
+  GLX_CHECK(s && weights_inout, GLX_EINVAL, "glx_sweep_project: null argument");
+  GLX_CHECK(!s->has_w || !to_onehot, GLX_EINVAL, "glx_sweep_project: to_onehot needs a sweep created with max_iter = 0");
+  GLX_HIP(hipSetDevice(s->device));
+  const int dtype = s->P->dtype;
+  int rc = glx_unpack_records(s->buf[s->cur], s->dense, s->n_rows, s->L, dtype, s->stream, s->P->d_perm);
+  if (rc) return rc;
+  const long long* d_labels = nullptr;
+  rc = glx_project_device(&s->proj, s->dense, dtype, s->n_rows, s->C, priors, weights_inout, err_out, steps_out, max_steps,
+                          similarity, s->stream, &d_labels);
+  if (rc) return rc;
+  if (labels_out) GLX_HIP(hipMemcpyAsync(labels_out, d_labels, (size_t)s->n_rows * 8, hipMemcpyDeviceToHost, s->stream));
+  if (to_onehot) {
+    rc = glx_onehot_device(d_labels, s->dense, dtype, s->n_rows, s->C, s->stream);
+    if (rc) return rc;
+    rc = glx_pack_records(s->dense, s->buf[s->cur], s->n_cols, s->L, dtype, nullptr, s->stream, s->P->d_perm);
+    if (rc) return rc;
+  }
   GLX_HIP(hipStreamSynchronize(s->stream));
   return GLX_OK;
 }

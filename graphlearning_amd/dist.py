@@ -312,6 +312,19 @@ class DistSweep:
         self._graph_ok = (bool(getattr(ops, 'supports_graph', False)) and not self._stage_host
                           and os.environ.get('GLX_DIST_GRAPH', '1') != '0')
 
+    def close(self):
+        """Release the captured device graph (it holds RCCL work: drop it while the process group
+        is still alive, not at interpreter exit) and the rank-local state."""
+        if getattr(self, '_graph', None) is not None:
+            try:
+                import torch
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            self._graph = None
+            self._graph_err = None
+        self.xa = self.xb = self.init_rec = None
+
     def reset(self):
         """Owned rows <- initial records; halo filled by one exchange.  Allocation-free apart from
         the exchange's send buffer, so it can be stream-captured."""
@@ -469,6 +482,9 @@ def poisson_fit_distributed(W, train_ind, train_labels, dist, ops_factory, min_i
     err0 = initial_error(prob['w0'][own], prob['deg'][own], prob['vinf'][own], dist, group, torch) if min_iter == 0 else None
     T = sweep.run(min_iter, max_iter, err0)
     u_own = sweep.result_own()
+    sweep.close()                      # captured graph and device state go while the group is alive
+    if hasattr(ops, 'close'):
+        ops.close()
     if not gather:
         return u_own, T, plan
     parts = [None] * world

@@ -87,5 +87,10 @@ def main(args):
             'graph_build_s': t_graph,
         }
         print(json.dumps(line))
+    # orderly teardown: captured graph (RCCL work inside) first, then the operators, then the group
+    torch.cuda.synchronize()
+    sweep.close()
     ops.close()
+    dist.barrier()
     dist.destroy_process_group()
+    sys.stdout.flush()

@@ -372,17 +372,23 @@ class poisson_mbo(ssl):
             self._cache = (key, dev, heat, dt)
         _, dev, heat, dt = self._cache
         Db = mu * dt * source                                   # reference ssl.py:805
+        if self.class_priors is None:   # the reference fails in volume_label_projection (None arithmetic, ssl.py:199)
+            raise TypeError('poisson_mbo needs class_priors for its volume-constrained thresholding')
+        # the state never leaves the device between the heat sweeps and the thresholding: the
+        # volume-constrained decision runs on the sweep's buffer and writes onehot(labels) back
+        # into it (glx_sweep_project); per outer step only the class weights come back
+        heat.set_state(u, Db)
         for i in range(T):
-            heat.set_state(u, Db)
             heat.iterate(Ns)                                # Ns x `u = P*u + Db`, reference ssl.py:826-827
-            u = heat.fetch()
-            self.prob = u
-            labels = self.volume_label_projection()         # reference ssl.py:830-832
-            u = utils.labels_to_onehot(labels, k)
+            w = np.ones((k,)) if type(self.weights) == int else self.weights
+            labels, w, err, _ = heat.project(self.class_priors, w, max_steps=10000, similarity=self.similarity,
+                                             to_onehot=True, want_labels=all_labels is not None)   # reference ssl.py:830-832
+            self.weights = w
+            self.class_priors_error = err
             if all_labels is not None:
                 acc = ssl_accuracy(labels, all_labels, train_ind)
                 print('%d, Accuracy = %.2f' % (i, acc))
-        return u
+        return heat.fetch().astype(np.float64)              # onehot of the last labels (reference ssl.py:832)
 
 
 class laplace(ssl):

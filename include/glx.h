@@ -143,6 +143,12 @@ int glx_cg_groups(glx_graph* A, const void* B, void* X, int C, int group_cols, d
 int glx_argmax_project(const double* prob, int64_t n, int C, const double* priors,
                        double* weights_inout, int64_t* labels_out, double* err_out,
                        int* steps_out, int max_steps, int similarity, int device);
+/* the same decision on a sweep's device-resident state (no host round trip).  labels_out may be NULL.
+ * to_onehot != 0 then replaces the state by onehot(labels): the hand-over between the heat sweeps and
+ * the volume-constrained thresholding of ssl.poisson_mbo._fit (graphlearning/ssl.py:826-832). */
+int glx_sweep_project(glx_sweep* s, const double* priors, double* weights_inout, int64_t* labels_out,
+                      double* err_out, int* steps_out, int max_steps, int similarity, int to_onehot);
+
 
 /* ---- kNN graph construction --------------------------------------------------------
  * weightmatrix.knnsearch (graphlearning/weightmatrix.py:297-429), exact: brute-force

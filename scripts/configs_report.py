@@ -1,0 +1,51 @@
+"""Timing report for the single-GPU configurations of SURVEY.md section 8(d): config 2 (Poisson GD and CG,
+70k MNIST-shaped), config 3 (Laplace CG, 60k CIFAR-shaped, k=20) and config 5 (PoissonMBO on the
+config-2 graph).  Synthetic features, real label vectors (tests/golden); prints one line per case."""
+import numpy as np, sys, os, time, cProfile, pstats, io
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import graphlearning_amd as gl
+from graphlearning_amd import _hip
+
+def timed(f, reps=3):
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter(); out = f(); best = min(best, time.perf_counter() - t0)
+    return best, out
+
+prof = len(sys.argv) > 1 and sys.argv[1] == 'profile'
+labels = bench.load_labels(70000); X = bench.make_features(labels)
+t, W = timed(lambda: gl.weightmatrix.knn(X, 10), 2)
+st = _hip.knn_stats()
+print('config 2 graph: weightmatrix.knn(X, 10) n=70000 d=20 -> nnz=%d in %.1f ms (tile kernel %.2f ms)' % (W.nnz, t * 1e3, st['tile_ms']))
+train_ind = gl.trainsets.generate(labels, rate=1, seed=0)
+for solver in ('gradient_descent', 'conjugate_gradient'):
+    m = gl.ssl.poisson(W, solver=solver)
+    m.fit(train_ind, labels[train_ind])
+    t, _ = timed(lambda: m.fit(train_ind, labels[train_ind]))
+    acc = gl.ssl.ssl_accuracy(m.predict(), labels, train_ind)
+    print('config 2 ssl.poisson(%s).fit: %.2f ms, %d iterations, accuracy %.2f%%' % (solver, t * 1e3, m.num_iter, acc))
+priors = gl.utils.class_priors(labels)
+m = gl.ssl.poisson_mbo(W, priors, solver='gradient_descent', Ns=40, mu=1, T=20)
+m.fit(train_ind, labels[train_ind])
+if prof:
+    pr = cProfile.Profile(); pr.enable(); m.fit(train_ind, labels[train_ind]); pr.disable()
+    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(14); print(s.getvalue()[:3000])
+t, _ = timed(lambda: m.fit(train_ind, labels[train_ind]))
+print('config 5 ssl.poisson_mbo(gradient_descent, Ns=40, T=20).fit: %.1f ms (851 SpMMs + 21 volume projections), accuracy %.2f%%'
+      % (t * 1e3, gl.ssl.ssl_accuracy(m.predict(), labels, train_ind)))
+
+lab3 = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'cifar_labels.npz'))['labels'][:60000].astype(np.int64)
+rng = np.random.default_rng(1)
+centers = rng.normal(size=(10, 32)) * 1.2
+X3 = centers[lab3] + rng.normal(size=(60000, 32))
+t, W3 = timed(lambda: gl.weightmatrix.knn(X3, 20), 2)
+print('config 3 graph: weightmatrix.knn(X, 20) n=60000 d=32 -> nnz=%d in %.1f ms' % (W3.nnz, t * 1e3))
+ti3 = gl.trainsets.generate(lab3, rate=10, seed=0)
+m = gl.ssl.laplace(W3)
+m.fit(ti3, lab3[ti3])
+if prof:
+    pr = cProfile.Profile(); pr.enable(); m.fit(ti3, lab3[ti3]); pr.disable()
+    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(14); print(s.getvalue()[:3000])
+t, _ = timed(lambda: m.fit(ti3, lab3[ti3]))
+print('config 3 ssl.laplace.fit: %.1f ms, %d CG iterations, accuracy %.2f%%' % (t * 1e3, m.num_iter, gl.ssl.ssl_accuracy(m.predict(), lab3, ti3)))
