@@ -3,6 +3,8 @@
 // off and integer class counts, so labels and weights are bit-identical to numpy's.
 #include "glx_internal.h"
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 static const int PROJ_CHUNK = 32;
 
@@ -238,8 +240,18 @@ extern "C" int glx_argmax_project(const double* prob, int64_t n, int C, const do
   GLX_CHECK(max_steps == 0 || priors, GLX_EINVAL, "glx_argmax_project: projection needs priors");
   GLX_CHECK(C <= 4096, GLX_EUNSUPPORTED, "glx_argmax_project: C=%d too large", C);
   GLX_HIP(hipSetDevice(device));
-  ProjBufs b;
-  GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+  // work buffers and stream are kept per device between calls (ssl_trials calls predict once per
+  // trial: a dozen hipMalloc/hipFree pairs cost more than the decision itself); intentionally never
+  // destroyed -- a static destructor would run after the HIP runtime has shut down
+  static std::mutex mu;
+  static std::map<int, ProjBufs*>* cache = new std::map<int, ProjBufs*>();
+  std::lock_guard<std::mutex> lock(mu);
+  ProjBufs*& slot = (*cache)[device];
+  if (!slot) {
+    slot = new ProjBufs();
+    GLX_HIP(hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking));
+  }
+  ProjBufs& b = *slot;
   hipStream_t st = b.stream;
   int rc = proj_alloc(b, n, C);
   if (rc) return rc;
