@@ -363,7 +363,9 @@ class DistSweep:
                     self._head(1, min_iter + 2)
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    # thread_local: the process group's watchdog thread polls events concurrently; in the
+                    # default global mode such a call landing inside the capture window invalidates it
+                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
                         self.reset()
                         self._graph_err = self._head(head, min_iter)
                     self._graph = g
