@@ -396,3 +396,45 @@ def test_page_rank_midsize_vs_oracle(gl, orc):
     uo, it = orc.page_rank(W, alpha=0.9, tol=1e-12, return_iters=True)
     assert G.page_rank_iters == it
     assert np.array_equal(u, uo)
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_sweep_project_equals_host_projection(gl, dtype):
+    """glx_sweep_project (decision on the device-resident sweep state) against glx_argmax_project on the
+    fetched array (which the g5 golden pins to the reference): labels, weights, error, step count; then
+    the state has become onehot(labels)."""
+    from graphlearning_amd import _hip
+    from scipy import sparse
+    rng = np.random.default_rng(11)
+    n, C = 3000, 5
+    prob = (rng.normal(size=(n, C)) + np.array([0.8, 0.0, -0.3, 0.2, 0.1])).astype(dtype)
+    priors = np.array([0.1, 0.3, 0.2, 0.25, 0.15])
+    G = _hip.DeviceGraph(sparse.identity(n, format='csr'), dtype=dtype)
+    S = _hip.Sweep(G, C, min_iter=0, max_iter=0, use_hipgraph=False)
+    S.set_state(prob, None)
+    ref = _hip.argmax_project(prob.astype(np.float64), priors, np.ones(C), max_steps=10000)
+    labels, w, err, steps = S.project(priors, np.ones(C), max_steps=10000, to_onehot=True)
+    assert steps == ref[3] and steps > 1
+    assert np.array_equal(labels, ref[0]) and np.array_equal(w, ref[1]) and err == ref[2]
+    onehot = S.fetch()
+    assert onehot.dtype == dtype and np.array_equal(onehot, np.eye(C, dtype=dtype)[labels])
+    # plain predict with given weights, labels not requested
+    S.set_state(prob, None)
+    none, w2, _, _ = S.project(None, w, max_steps=0, want_labels=False)
+    assert none is None and np.array_equal(w2, w)
+    lab2, _, _, _ = S.project(None, w, max_steps=0)
+    assert np.array_equal(lab2, _hip.argmax_project(prob.astype(np.float64), None, w, max_steps=0)[0])
+    S.close(); G.close()
+
+
+def test_poisson_mbo_fp32_device_path(gl, golden):
+    """use_cuda=True (the reference's fp32 device variant, ssl.py:807-823): same labels as the fp64 fit
+    on two-moons, one-hot result returned as float64 like the reference's labels_to_onehot."""
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    ti = g['train_ind']
+    tl = g['labels'][ti]
+    m = gl.ssl.poisson_mbo(W, g['class_priors'], solver='gradient_descent', use_cuda=True)
+    u = m.fit(ti, tl)
+    assert u.dtype == np.float64 and set(np.unique(u)) <= {0.0, 1.0} and np.all(u.sum(axis=1) == 1)
+    assert np.array_equal(m.predict(), g['poisson_mbo_gradient_descent_pred'])
