@@ -79,6 +79,8 @@ _SIGNATURES = {
     'glx_cg_multi': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), _f64p],
     'glx_cg_solve': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_sweep_project': [_vp, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
+    'glx_lp_iterate': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_int64, C.c_double, C.c_int64, C.c_int64, C.c_int64,
+                       C.POINTER(C.c_int64), C.c_int],
     'glx_affine_iterate': [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int64), _f64p],
     'glx_cg_groups': [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_argmax_project': [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
@@ -347,6 +349,17 @@ def argmax_project(prob, priors=None, weights=None, max_steps=0, similarity=True
     check(load().glx_argmax_project(_ptr(prob), n, Cc, _ptr(pri), _ptr(w), _ptr(labels), C.byref(err), C.byref(steps),
                                     int(max_steps), 1 if similarity else 0, _dev(device)), 'glx_argmax_project')
     return labels, w, err.value, steps.value
+
+
+def lp_iterate(uu, ul, nbr, row, W, ind, val, p, T, tol, device=None):
+    """lp_iterate of the reference's C extension on the GPU (in place on uu, ul); returns the stopping iteration."""
+    for a, dt in ((uu, np.float64), (ul, np.float64), (nbr, np.int32), (row, np.int32), (W, np.float64), (ind, np.int32), (val, np.float64)):
+        if not (isinstance(a, np.ndarray) and a.dtype == dt and a.flags['C_CONTIGUOUS']):
+            raise GlxError('lp_iterate: arrays must be C-contiguous with the dtypes of the reference binding')
+    it = C.c_int64(0)
+    check(load().glx_lp_iterate(_ptr(uu), _ptr(ul), _ptr(nbr), _ptr(row), _ptr(W), _ptr(ind), _ptr(val), float(p), int(T), float(tol),
+                                len(uu), len(W), len(ind), C.byref(it), _dev(device)), 'glx_lp_iterate')
+    return it.value
 
 
 def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None):

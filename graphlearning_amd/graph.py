@@ -105,6 +105,44 @@ class graph:
         self.page_rank_iters = it
         return u
 
+    def __ccode_init__(self):
+        """Stored entries as (vertex, neighbour, weight) arrays sorted by vertex, the form the
+        reference hands to its C extension (reference graph.py:69-84, same expressions: the order
+        inside a vertex's block is whatever np.argsort's default sort leaves)."""
+        I, J, V = sparse.find(self.weight_matrix)
+        ind = np.argsort(I)
+        self.I, self.J, self.V = I[ind], J[ind], V[ind]
+        self.I = np.ascontiguousarray(self.I, dtype=np.int32)
+        self.J = np.ascontiguousarray(self.J, dtype=np.int32)
+        self.V = np.ascontiguousarray(self.V, dtype=np.float64)
+
+    def plaplace(self, bdy_set, bdy_val, p, tol=1e-1, max_num_it=1e6, prog=False, fast=True, device=None):
+        """Game-theoretic p-Laplace equation with Dirichlet data (reference graph.py:1177-1278).
+        `fast=False` -- the Jacobi iteration of upper / lower barriers, lp_iterate_main of the
+        reference's C extension -- runs on the GPU (glx_lp_iterate) and returns (uu+ul)/2 like the
+        reference.  The reference's default `fast=True` is a Gauss-Seidel sweep (lip_iterate_main,
+        c_code/lp_iterate.cpp:127-180): every vertex reads values updated earlier in the same sweep,
+        an inherently sequential recurrence that has no parallel form with the same iterates."""
+        from . import _hip, utils
+        if fast:
+            raise NotImplementedError('graph.plaplace(fast=True) is a sequential Gauss-Seidel sweep in the reference; '
+                                      'pass fast=False for the Jacobi iteration, which runs on the GPU')
+        if getattr(self, 'I', None) is None:
+            self.__ccode_init__()
+        n = self.num_nodes
+        bdy_set, bdy_val = utils._boundary_handling(bdy_set, bdy_val)
+        uu = np.max(bdy_val) * np.ones((n,))
+        ul = np.min(bdy_val) * np.ones((n,))
+        uu[bdy_set] = bdy_val
+        ul[bdy_set] = bdy_val
+        uu = np.ascontiguousarray(uu, dtype=np.float64)
+        ul = np.ascontiguousarray(ul, dtype=np.float64)
+        bdy_set = np.ascontiguousarray(bdy_set, dtype=np.int32)
+        bdy_val = np.ascontiguousarray(bdy_val, dtype=np.float64)
+        self.plaplace_iters = _hip.lp_iterate(uu, ul, self.J, self.I, self.V, bdy_set, bdy_val, p, int(max_num_it), float(tol),
+                                              device=device)
+        return (uu + ul) / 2
+
     def subgraph(self, ind):
         W = self.weight_matrix
         return graph(W[ind, :][:, ind])

@@ -56,3 +56,15 @@ def conjgrad(A, b, x0=None, max_iter=1e5, tol=1e-10, dtype=np.float64, return_in
     finally:
         G.close()
     return (x, it, err) if return_info else x
+
+
+def _boundary_handling(bdy_set, bdy_val):
+    """Boundary data in standard form: index array + value array (reference utils.py:144-174)."""
+    if type(bdy_set) == list:
+        bdy_set = np.array(bdy_set)
+    if bdy_set.dtype == bool:
+        bdy_set = np.where(bdy_set)[0]
+    m = len(bdy_set)
+    if type(bdy_val) != np.ndarray:
+        bdy_val = np.ones((m,)) * bdy_val
+    return bdy_set, bdy_val

@@ -119,6 +119,18 @@ int glx_unpack_records_dev(const void* rec, void* dense, int64_t n, int C, int d
 int glx_affine_iterate(glx_graph* A, const void* b, const void* u0, void* u_out, int C, double tol,
                        int64_t max_iter, int64_t* iters_out, double* err_out);
 
+/* ---- p-Laplace Jacobi iteration (graph.plaplace, fast=False) --------------------------
+ * Replaces lp_iterate_main of the reference's C extension (c_code/lp_iterate.cpp:35-125; bound in
+ * c_code/cextensions.cpp:19-60 as lp_iterate(uu, ul, I, J, W, ind, val, p, T, tol, prog)), same
+ * argument order and the same in-place convention: uu / ul (n,) fp64 are the upper / lower barrier,
+ * overwritten with the iterate the reference leaves in the caller's arrays (its swapped pointers are
+ * local: U_it if it stops at an even iteration `it`, U_it+1 if odd).  nbr / row / W (M,): neighbour,
+ * vertex (ascending) and weight of every stored entry; ind / val (m,): Dirichlet vertices and values.
+ * iters_out: the iteration at which `err < tol && it > 10` held (T if never).  T <= 2^24. */
+int glx_lp_iterate(double* uu, double* ul, const int32_t* nbr, const int32_t* row, const double* W,
+                   const int32_t* ind, const double* val, double p, int64_t T, double tol,
+                   int64_t n, int64_t M, int64_t m, int64_t* iters_out, int device);
+
 /* ---- multi right-hand-side conjugate gradient -------------------------------------
  * Replaces utils.conjgrad (graphlearning/utils.py:483-532): x0 = 0, per-column
  * alpha/beta, global stop sqrt(sum over all columns ||r||^2) <= tol, max_iter cap. */

@@ -15,6 +15,7 @@
  */
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 /* Y (n_row, n_vecs) += A (CSR) * X (n_col, n_vecs); C-contiguous dense operands */
 void ref_csr_matvecs(int64_t n_row, int64_t n_vecs, const int32_t* indptr, const int32_t* indices, const double* data,
@@ -44,4 +45,76 @@ void ref_poisson_sweeps(int64_t n, int64_t C, const int32_t* indptr, const int32
     ref_csr_matvecs(n, C, indptr, indices, data, u, tmp);
     for (int64_t k = 0; k < n * C; ++k) u[k] = Db[k] + tmp[k];
   }
+}
+
+/* ---- p-Laplace Jacobi sweep ---------------------------------------------------
+ * Restates lp_iterate_main, reference c_code/lp_iterate.cpp:35-125, as called by graph.plaplace
+ * with fast=False (graph.py:1262-1276: `cextensions.lp_iterate(uu,ul,self.J,self.I,self.V,...)`,
+ * i.e. nbr = the neighbour of each stored entry, row = its vertex, entries sorted by vertex).
+ * Kept quirks: err is the maximum of uu-ul over the iterate that was READ; the test
+ * `err < tol && it > 10` comes before the pointer swap; the swap exchanges local pointers only, so
+ * on return the caller's arrays hold the iterate that last lived in them (U_it if the loop stopped
+ * at an even `it`, U_it+1 if odd; after T full iterations U_T if T is even, U_T-1 if odd).
+ * Returns the iteration index at which the loop stopped (T if it ran out). */
+#define REF_MIN(a, b) (((a) < (b)) ? (a) : (b))
+#define REF_MAX(a, b) (((a) > (b)) ? (a) : (b))
+int64_t ref_lp_iterate(double* uu_caller, double* ul_caller, const int32_t* nbr, const int32_t* row, const double* W,
+                       const int32_t* ind, const double* val, double p, int64_t T, double tol, int64_t n, int64_t M, int64_t m) {
+  const double alpha = 1 / p;
+  const double delta = 1 - 2 / p;
+  double dt = 0.9 / (alpha + 2 * delta);
+  int64_t* num = (int64_t*)calloc((size_t)n, sizeof(int64_t));
+  int64_t* start = (int64_t*)calloc((size_t)n, sizeof(int64_t));
+  double* invdeg = (double*)calloc((size_t)n, sizeof(double));
+  double* vu = (double*)calloc((size_t)n, sizeof(double));
+  double* vl = (double*)calloc((size_t)n, sizeof(double));
+  double *uu = uu_caller, *ul = ul_caller;
+  int64_t i, j = 0, it;
+  for (i = 0; i < n; i++) {                        /* lp_iterate.cpp:47-58 */
+    start[i] = j;
+    invdeg[i] = 0;
+    while (j < M && row[j] == i) {
+      num[i]++;
+      invdeg[i] += W[j];
+      j++;
+    }
+    invdeg[i] = alpha / invdeg[i];
+  }
+  double maxW = 0;                                  /* :61-64 */
+  for (i = 0; i < M; i++) maxW = REF_MAX(maxW, W[i]);
+  dt = dt / maxW;
+  for (it = 0; it < T; it++) {                      /* :74-124 */
+    double err = 0;
+    for (i = 0; i < n; i++) {
+      double minw = 0, maxw = 0, sumw = 0;
+      for (j = start[i]; j < start[i] + num[i]; j++) {
+        minw = REF_MIN(W[j] * (uu[nbr[j]] - uu[i]), minw);
+        maxw = REF_MAX(W[j] * (uu[nbr[j]] - uu[i]), maxw);
+        sumw += W[j] * (uu[nbr[j]] - uu[i]);
+      }
+      vu[i] = uu[i] + dt * (invdeg[i] * sumw + delta * (minw + maxw));
+      minw = 0; maxw = 0; sumw = 0;
+      for (j = start[i]; j < start[i] + num[i]; j++) {
+        minw = REF_MIN(W[j] * (ul[nbr[j]] - ul[i]), minw);
+        maxw = REF_MAX(W[j] * (ul[nbr[j]] - ul[i]), maxw);
+        sumw += W[j] * (ul[nbr[j]] - ul[i]);
+      }
+      vl[i] = ul[i] + dt * (invdeg[i] * sumw + delta * (minw + maxw));
+      err = REF_MAX(uu[i] - ul[i], err);
+    }
+    for (j = 0; j < m; j++) {
+      i = ind[j];
+      vu[i] = val[j];
+      vl[i] = val[j];
+    }
+    if (err < tol && it > 10) break;
+    double* t;
+    t = uu; uu = vu; vu = t;
+    t = ul; ul = vl; vl = t;
+  }
+  /* the two scratch arrays are whichever pair the caller does not own */
+  free(uu == uu_caller ? vu : uu);
+  free(ul == ul_caller ? vl : ul);
+  free(num); free(start); free(invdeg);
+  return it;
 }

@@ -22,6 +22,7 @@ so its iterates are bit-identical to the reference's on the same inputs.
 
 Reference citations are ``file:line`` relative to /root/reference/.
 """
+import os
 import numpy as np
 from scipy import sparse, spatial
 
@@ -489,6 +490,75 @@ def page_rank(W, alpha=0.85, v=None, tol=1e-10, return_iters=False):
         u = w.copy()
         it += 1
     return (u, it) if return_iters else u
+
+
+# ----------------------------------------------------------------------------
+# f-4  p-Laplace, Jacobi variant (graph.plaplace with fast=False, graphlearning/graph.py:1177-1278)
+# ----------------------------------------------------------------------------
+def ccode_arrays(W):
+    """graph.__ccode_init__, graphlearning/graph.py:69-84: the stored entries of W as
+    (vertex, neighbour, weight) sorted by vertex with np.argsort's default (unstable) sort --
+    the order inside a vertex's block is whatever that sort leaves, and it is the order in which
+    the C code adds a vertex's terms."""
+    I, J, V = sparse.find(sparse.csr_matrix(W))
+    ind = np.argsort(I)
+    I, J, V = I[ind], J[ind], V[ind]
+    return (np.ascontiguousarray(I, dtype=np.int32), np.ascontiguousarray(J, dtype=np.int32),
+            np.ascontiguousarray(V, dtype=np.float64))
+
+
+def boundary_handling(bdy_set, bdy_val):
+    """utils._boundary_handling, graphlearning/utils.py:144-174."""
+    if type(bdy_set) == list:
+        bdy_set = np.array(bdy_set)
+    if bdy_set.dtype == bool:
+        bdy_set = np.where(bdy_set)[0]
+    m = len(bdy_set)
+    if type(bdy_val) != np.ndarray:
+        bdy_val = np.ones((m,)) * bdy_val
+    return bdy_set, bdy_val
+
+
+def _c_lib():
+    import ctypes
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, '_build', 'libcsr_ref.so')
+    if not os.path.exists(path):
+        subprocess.run(['make', '-s', '-C', here], check=True)
+    return ctypes.CDLL(path)
+
+
+def plaplace_jacobi(W, bdy_set, bdy_val, p, tol=1e-1, max_num_it=1e6, return_iters=False, return_bounds=False):
+    """graph.plaplace(..., fast=False), graphlearning/graph.py:1262-1278: upper / lower barriers
+    initialised to max / min of the boundary values, iterated by lp_iterate_main
+    (c_code/lp_iterate.cpp:35-125, restated in oracle/csr_ref.c:ref_lp_iterate), u = (uu+ul)/2."""
+    import ctypes
+    n = W.shape[0]
+    I, J, V = ccode_arrays(W)
+    bdy_set, bdy_val = boundary_handling(bdy_set, bdy_val)
+    uu = np.max(bdy_val) * np.ones((n,))
+    ul = np.min(bdy_val) * np.ones((n,))
+    uu[bdy_set] = bdy_val
+    ul[bdy_set] = bdy_val
+    uu = np.ascontiguousarray(uu, dtype=np.float64)
+    ul = np.ascontiguousarray(ul, dtype=np.float64)
+    bdy_set = np.ascontiguousarray(bdy_set, dtype=np.int32)
+    bdy_val = np.ascontiguousarray(bdy_val, dtype=np.float64)
+    lib = _c_lib()
+    lib.ref_lp_iterate.restype = ctypes.c_int64
+    vp = ctypes.c_void_p
+    it = lib.ref_lp_iterate(uu.ctypes.data_as(vp), ul.ctypes.data_as(vp), J.ctypes.data_as(vp), I.ctypes.data_as(vp),
+                            V.ctypes.data_as(vp), bdy_set.ctypes.data_as(vp), bdy_val.ctypes.data_as(vp), ctypes.c_double(p),
+                            ctypes.c_int64(int(max_num_it)), ctypes.c_double(float(tol)), ctypes.c_int64(n),
+                            ctypes.c_int64(len(V)), ctypes.c_int64(len(bdy_set)))
+    u = (uu + ul) / 2
+    out = (u,)
+    if return_iters:
+        out += (int(it),)
+    if return_bounds:
+        out += (uu, ul)
+    return out if len(out) > 1 else u
 
 
 # ----------------------------------------------------------------------------

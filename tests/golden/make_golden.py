@@ -264,6 +264,50 @@ def g8_pagerank():
     print('g8 done, iterations', out['pr_sym_iters'], out['pr_dir_iters'], out['pr_sym_tele_iters'])
 
 
+def g9_plaplace():
+    """graph.plaplace(fast=False) (graph.py:1262-1278).  The reference's C extension is not
+    built in /root/reference (read-only), so its lp_iterate_main is compiled as is by oracle/Makefile into
+    oracle/_ref/liblp_ref.so and called here on the REFERENCE graph object's own (I, J, V) arrays with the
+    reference's own set-up expressions; outputs = what graph.plaplace would return."""
+    import ctypes
+    ref = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(HERE)), 'oracle', '_ref', 'liblp_ref.so'))
+    f = getattr(ref, '_Z15lp_iterate_mainPdS_PiS0_S_S0_S_didbiii')      # lp_iterate_main(double*,double*,int*,int*,double*,int*,double*,double,int,double,bool,int,int,int)
+    f.restype = None
+    vp = ctypes.c_void_p
+    rng = np.random.default_rng(5)
+    X = rng.random((1500, 2))
+    W = gl.weightmatrix.knn(X, 8, knn_data=gl.weightmatrix.knnsearch(X, 9, method='kdtree'))
+    G = gl.graph(W)
+    x, y = X[:, 0], X[:, 1]
+    bdy = (x < 0.06) | (x > 0.94) | (y < 0.06) | (y > 0.94)
+    g = x ** 2 - y ** 2
+    out = {'X': X, 'bdy': bdy, 'bdy_val': g[bdy]}
+    out.update(csr_parts(W, 'W'))
+    n = G.num_nodes
+    for tag, p, tol, T in [('p10', 10.0, 1e-1, 1e6), ('p3', 3.0, 1e-2, 1e6), ('T57', 2.5, 1e-9, 57), ('T200', 50.0, 1e-3, 200)]:
+        bdy_set, bdy_val = gl.utils._boundary_handling(bdy, g[bdy])
+        uu = np.max(bdy_val) * np.ones((n,))
+        ul = np.min(bdy_val) * np.ones((n,))
+        uu[bdy_set] = bdy_val
+        ul[bdy_set] = bdy_val
+        uu = np.ascontiguousarray(uu, dtype=np.float64)
+        ul = np.ascontiguousarray(ul, dtype=np.float64)
+        bdy_set = np.ascontiguousarray(bdy_set, dtype=np.int32)
+        bdy_val = np.ascontiguousarray(bdy_val, dtype=np.float64)
+        f(uu.ctypes.data_as(vp), ul.ctypes.data_as(vp), G.J.ctypes.data_as(vp), G.I.ctypes.data_as(vp), G.V.ctypes.data_as(vp),
+          bdy_set.ctypes.data_as(vp), bdy_val.ctypes.data_as(vp), ctypes.c_double(p), ctypes.c_int(int(T)), ctypes.c_double(tol),
+          ctypes.c_bool(False), ctypes.c_int(n), ctypes.c_int(len(G.V)), ctypes.c_int(len(bdy_set)))
+        u, it, ouu, oul = orc.plaplace_jacobi(W, bdy, g[bdy], p, tol=tol, max_num_it=T, return_iters=True, return_bounds=True)
+        assert np.array_equal(ouu, uu) and np.array_equal(oul, ul) and np.array_equal(u, (uu + ul) / 2)
+        out[tag + '_u'] = (uu + ul) / 2
+        out[tag + '_uu'] = uu
+        out[tag + '_ul'] = ul
+        out[tag + '_params'] = np.array([p, tol, T, it], dtype=np.float64)
+        print('g9', tag, 'stopped at', it)
+    np.savez_compressed(os.path.join(HERE, 'g9_plaplace.npz'), **out)
+    print('g9 done')
+
+
 def g4_large():
     """Config 2 (70k) and config 3 (60k): checksums only; the graphs are
     regenerated from seeds by the oracle on the GPU box."""
@@ -328,5 +372,6 @@ if __name__ == '__main__':
     g6_helpers()
     g7_next_rows()
     g8_pagerank()
+    g9_plaplace()
     if args.large:
         g4_large()

@@ -438,3 +438,22 @@ def test_poisson_mbo_fp32_device_path(gl, golden):
     u = m.fit(ti, tl)
     assert u.dtype == np.float64 and set(np.unique(u)) <= {0.0, 1.0} and np.all(u.sum(axis=1) == 1)
     assert np.array_equal(m.predict(), g['poisson_mbo_gradient_descent_pred'])
+
+
+def test_plaplace_jacobi_golden(gl, golden, orc):
+    """graph.plaplace(fast=False) on the device against the compiled reference's outputs.
+    The order in which a vertex's terms are summed comes from np.argsort's unstable default sort of
+    the vertex column (reference graph.py:73), which may differ between hosts: bit-exact when this
+    host's order equals the one the golden run saw, 1e-12 otherwise; the stopping iteration is exact."""
+    g = golden('g9_plaplace.npz')
+    W = csr_from(g, 'W')
+    G = gl.graph(W)
+    for tag in ('p10', 'p3', 'T57', 'T200'):
+        p, tol, T, it_ref = g[tag + '_params']
+        u = G.plaplace(g['bdy'], g['bdy_val'], p, tol=tol, max_num_it=T, fast=False)
+        assert abs(G.plaplace_iters - int(it_ref)) <= (0 if tag.startswith('T') else 1)
+        uo = orc.plaplace_jacobi(W, g['bdy'], g['bdy_val'], p, tol=tol, max_num_it=T)
+        assert np.array_equal(u, uo)                      # same host, same entry order: bit-identical to the oracle
+        assert np.max(np.abs(u - g[tag + '_u'])) <= 1e-12
+    with pytest.raises(NotImplementedError):
+        G.plaplace(g['bdy'], g['bdy_val'], 10)            # fast=True: sequential Gauss-Seidel in the reference

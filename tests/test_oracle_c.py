@@ -47,3 +47,29 @@ def test_c_sweeps_reproduce_golden(lib, golden):
     Db = np.ascontiguousarray(s['Db'])
     lib.ref_poisson_sweeps(C.c_int64(n), C.c_int64(k), _p(P.indptr.astype(np.int32)), _p(P.indices.astype(np.int32)), _p(P.data), _p(Db), _p(u), _p(tmp), C.c_int64(409))
     assert np.array_equal(u, g['poisson_gd_prob'])
+
+
+def test_lp_iterate_restatement_equals_compiled_reference():
+    """oracle/_ref/liblp_ref.so is the reference's own lp_iterate.cpp compiled as is (oracle/Makefile,
+    present where /root/reference was available at build time): the restatement must agree bit for bit."""
+    from oracle import gl_oracle as orc
+    path = os.path.join(ROOT, 'oracle', '_ref', 'liblp_ref.so')
+    if not os.path.exists(path):
+        subprocess.run(['make', '-s', '-C', os.path.join(ROOT, 'oracle')], check=True)
+    if not os.path.exists(path):
+        pytest.skip('compiled reference not available (no /root/reference at build time)')
+    f = getattr(C.CDLL(path), '_Z15lp_iterate_mainPdS_PiS0_S_S0_S_didbiii')
+    f.restype = None
+    rng = np.random.default_rng(1)
+    for n, dens, p, tol, T in [(300, 0.03, 4.0, 1e-2, 5000), (800, 0.01, 20.0, 1e-1, 33), (150, 0.08, 2.2, 1e-6, 400)]:
+        A = sparse.random(n, n, density=dens, random_state=7, format='csr')
+        W = sparse.csr_matrix(A + A.T)
+        bdy = rng.permutation(n)[:n // 10]
+        val = rng.normal(size=len(bdy))
+        u, it, uu, ul = orc.plaplace_jacobi(W, bdy, val, p, tol=tol, max_num_it=T, return_iters=True, return_bounds=True)
+        I, J, V = orc.ccode_arrays(W)
+        ru = np.max(val) * np.ones(n); rl = np.min(val) * np.ones(n); ru[bdy] = val; rl[bdy] = val
+        b32 = np.ascontiguousarray(bdy, dtype=np.int32)
+        f(_p(ru), _p(rl), _p(J), _p(I), _p(V), _p(b32), _p(val), C.c_double(p), C.c_int(T), C.c_double(tol), C.c_bool(False),
+          C.c_int(n), C.c_int(len(V)), C.c_int(len(b32)))
+        assert np.array_equal(ru, uu, equal_nan=True) and np.array_equal(rl, ul, equal_nan=True), (n, p)

@@ -169,3 +169,16 @@ def test_g8_pagerank(golden):
         assert it == int(g['pr_' + tag + '_iters']) and np.array_equal(u, g['pr_' + tag])
         u, it = orc.page_rank(W, alpha=0.5, v=g['pr_' + tag + '_v'], tol=1e-8, return_iters=True)
         assert it == int(g['pr_' + tag + '_tele_iters']) and np.array_equal(u, g['pr_' + tag + '_tele'])
+
+
+def test_g9_plaplace(golden):
+    """graph.plaplace(fast=False): the C restatement of lp_iterate_main (oracle/csr_ref.c) reproduces
+    the compiled reference's barriers bit for bit, including which iterate its swapped pointers leave
+    in the caller's arrays (T = 57 odd, T = 200 even) and the stopping iteration."""
+    g = golden('g9_plaplace.npz')
+    W = csr_from(g, 'W')
+    for tag in ('p10', 'p3', 'T57', 'T200'):
+        p, tol, T, it_ref = g[tag + '_params']
+        u, it, uu, ul = orc.plaplace_jacobi(W, g['bdy'], g['bdy_val'], p, tol=tol, max_num_it=T, return_iters=True, return_bounds=True)
+        assert it == int(it_ref)
+        assert np.array_equal(uu, g[tag + '_uu']) and np.array_equal(ul, g[tag + '_ul']) and np.array_equal(u, g[tag + '_u'])
