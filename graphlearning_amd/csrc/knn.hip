@@ -94,6 +94,11 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
   if constexpr (!KBLK) {
 #pragma unroll
     for (int s = 0; s < DH; ++s) bq[s] = qrow[s];
+    // a use in front of the loop: the compiler waits for these loads HERE.  Left pending into the
+    // loop they make its wait-counter pass put a vmcnt(0) before the first MFMA of every tile, which
+    // also drains the next tile's prefetch that was issued just before
+#pragma unroll
+    for (int s = 0; s < DH; ++s) asm volatile("" ::"v"(bq[s]));
   }
 #pragma unroll
   for (int p = 0; p < KP; ++p) { ld[p * 256 + tid] = INFINITY; li[p * 256 + tid] = -1; }
