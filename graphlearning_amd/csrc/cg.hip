@@ -309,7 +309,10 @@ __global__ __launch_bounds__(64) void cg_seqsum_dpp_kernel(const double* __restr
         voff += 512;
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // hand the buffers back to compiler-managed code
+    // hand the buffers back to compiler-managed code: the operand ties every later use of buf[d]
+    // to this wait (a plain copy of the register could otherwise be scheduled in front of it)
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) asm volatile("s_waitcnt vmcnt(0)" : "+v"(buf[d]));
   } else {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) buf[d] = load_checked(d);
