@@ -355,39 +355,59 @@ __global__ __launch_bounds__(64) void cg_seqsum_dpp_kernel(const double* __restr
 // fixed tree, halves split at a multiple of 8).  utils.conjgrad called with a 1-D right-hand side
 // (graph.reweight, graph.py:429) takes that path, so its device twin reproduces the same tree.
 // (`a` holds the elements `st` doubles apart: column 0 of the row-major product array)
-__device__ __noinline__ double np_pairwise_sum(const double* __restrict__ a, int64_t n, int st) {
+// The recursion tree is fixed by n alone, so it is parallel: the host lists the leaves (blocks of
+// at most 128 elements) and the internal nodes by height; one thread sums a leaf exactly as numpy
+// does (8 strided accumulators, fixed combination, tail), then one workgroup adds the nodes level
+// by level -- the same additions in the same association as the recursive routine.
+__device__ __forceinline__ double np_leaf_sum(const double* __restrict__ a, int64_t n, int st) {
 #pragma clang fp contract(off)
   if (n < 8) {
     double res = -0.0;
     for (int64_t i = 0; i < n; ++i) res = res + a[i * st];
     return res;
   }
-  if (n <= 128) {
-    double r[8];
+  double r[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = a[j * st];
-    int64_t i = 8;
-    for (; i < n - (n % 8); i += 8) {
+  for (int j = 0; j < 8; ++j) r[j] = a[j * st];
+  int64_t i = 8;
+  for (; i < n - (n % 8); i += 8) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = r[j] + a[(i + j) * st];
-    }
-    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; ++i) res = res + a[i * st];
-    return res;
+    for (int j = 0; j < 8; ++j) r[j] = r[j] + a[(i + j) * st];
   }
-  int64_t n2 = n / 2;
-  n2 -= n2 % 8;
-  const double lo = np_pairwise_sum(a, n2, st);
-  const double hi = np_pairwise_sum(a + n2 * st, n - n2, st);
-  return lo + hi;
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res = res + a[i * st];
+  return res;
+}
+
+struct PwPlan {          // device arrays; value index space: leaves [0, nleaves), internal nodes after them by height
+  const int64_t* leaf_off;
+  const int32_t* leaf_len;
+  const int32_t* node_l;     // [ninternal] children of internal node q (value indices)
+  const int32_t* node_r;
+  const int32_t* level_start;   // [nlevels + 1] ranges of internal nodes (0-based among internals) per height
+  double* vals;              // [nleaves + ninternal]
+  int nleaves, ninternal, nlevels;
+};
+
+__global__ __launch_bounds__(256) void cg_pw_leaf_kernel(const double* __restrict__ prod, int st, PwPlan pw, CgScalars sc, int it,
+                                                         double tol, int mode) {
+  if (mode != 2 && !cg_any_active(sc, it, tol)) return;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q < pw.nleaves) pw.vals[q] = np_leaf_sum(prod + pw.leaf_off[q] * st, pw.leaf_len[q], st);
 }
 
 template <int MODE>
-__global__ void cg_pairwise1d_kernel(const double* __restrict__ prod, int64_t n, int st, CgScalars sc, int it, double tol) {
+__global__ __launch_bounds__(256) void cg_pw_tree_kernel(PwPlan pw, CgScalars sc, int it, double tol) {
 #pragma clang fp contract(off)
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (MODE != 2 && !cg_any_active(sc, it, tol)) return;
-  const double tot = 0.0 + np_pairwise_sum(prod, n, st);
+  for (int h = 0; h < pw.nlevels; ++h) {
+    for (int q = pw.level_start[h] + threadIdx.x; q < pw.level_start[h + 1]; q += 256)
+      pw.vals[pw.nleaves + q] = pw.vals[pw.node_l[q]] + pw.vals[pw.node_r[q]];
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double tot = 0.0 + pw.vals[pw.nleaves + pw.ninternal - 1];   // the root is the last value (a lone leaf if n <= 128)
   if (MODE == 0) {
     sc.alpha[0] = sc.rsold[0] / tot;
   } else if (MODE == 1) {
@@ -402,6 +422,57 @@ __global__ void cg_pairwise1d_kernel(const double* __restrict__ prod, int64_t n,
   }
 }
 
+// host side of the plan: the recursion of DOUBLE_pairwise_sum on (offset, n)
+struct PwHost {
+  std::vector<int64_t> leaf_off;
+  std::vector<int32_t> leaf_len, node_l, node_r, node_h, level_start;
+  // returns a provisional id: leaves >= 0, internal nodes as -(index + 1)
+  int build(int64_t off, int64_t n, int* height) {
+    if (n <= 128) {
+      leaf_off.push_back(off);
+      leaf_len.push_back((int32_t)n);
+      *height = 0;
+      return (int)leaf_off.size() - 1;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    int hl, hr;
+    const int l = build(off, n2, &hl);
+    const int r = build(off + n2, n - n2, &hr);
+    *height = std::max(hl, hr) + 1;
+    node_l.push_back(l);
+    node_r.push_back(r);
+    node_h.push_back(*height);
+    return -(int)node_l.size();
+  }
+  void finish() {   // order the internal nodes by height (stable: children always precede parents) and renumber
+    const int ni = (int)node_l.size(), nl = (int)leaf_off.size();
+    std::vector<int> order(ni);
+    for (int q = 0; q < ni; ++q) order[q] = q;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return node_h[x] < node_h[y]; });
+    std::vector<int> newpos(ni);
+    for (int q = 0; q < ni; ++q) newpos[order[q]] = q;
+    auto remap = [&](int id) { return id >= 0 ? id : nl + newpos[-id - 1]; };
+    std::vector<int32_t> l2(ni), r2(ni);
+    int maxh = 0;
+    for (int q = 0; q < ni; ++q) {
+      l2[q] = remap(node_l[order[q]]);
+      r2[q] = remap(node_r[order[q]]);
+      maxh = std::max(maxh, (int)node_h[order[q]]);
+    }
+    level_start.assign(maxh + 1, 0);
+    for (int q = 0; q < ni; ++q) level_start[node_h[order[q]]]++;   // counts per height h >= 1 at index h
+    // prefix: level_start[h-1] = first internal node of height h
+    std::vector<int32_t> ls(maxh + 1, 0);
+    int acc = 0;
+    for (int h = 1; h <= maxh; ++h) { ls[h - 1] = acc; acc += level_start[h]; }
+    ls[maxh] = acc;
+    level_start = ls;
+    node_l = l2;
+    node_r = r2;
+  }
+};
+
 __global__ void cg_set_err0(double* err_hist, int64_t n, int stride) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) err_hist[i] = i < stride ? 1.0 : 0.0;
@@ -410,11 +481,15 @@ __global__ void cg_set_err0(double* err_hist, int64_t n, int stride) {
 struct CgBufs {
   void *x = nullptr, *r = nullptr, *p = nullptr, *ap = nullptr, *dense = nullptr;
   double* prod = nullptr;
+  int64_t* pw_off = nullptr;
+  int32_t *pw_len = nullptr, *pw_l = nullptr, *pw_r = nullptr, *pw_ls = nullptr;
+  double* pw_vals = nullptr;
   double *part_dot = nullptr, *part_rs = nullptr, *scal = nullptr, *err_hist = nullptr, *h_err = nullptr;
   hipStream_t stream = nullptr;
   ~CgBufs() {
     hipFree(x); hipFree(r); hipFree(p); hipFree(ap); hipFree(dense); hipFree(part_dot); hipFree(part_rs);
     hipFree(scal); hipFree(err_hist); hipFree(prod);
+    hipFree(pw_off); hipFree(pw_len); hipFree(pw_l); hipFree(pw_r); hipFree(pw_ls); hipFree(pw_vals);
     if (h_err) hipHostFree(h_err);
     if (stream) hipStreamDestroy(stream);
   }
@@ -463,6 +538,39 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   GLX_HIP(hipMalloc(&b.scal, 3 * ncols * 8));
   GLX_HIP(hipMalloc(&b.err_hist, hist_cap * stride * 8));
   if (exact) GLX_HIP(hipMalloc(&b.prod, std::max<size_t>((size_t)ncols * n * 8, 64)));
+  PwPlan pw;
+  memset(&pw, 0, sizeof(pw));
+  unsigned pw_grid = 1;
+  if (np1d) {   // numpy's pairwise-summation tree for n elements
+    PwHost ph;
+    int hroot;
+    ph.build(0, n, &hroot);
+    ph.finish();
+    const size_t nl = ph.leaf_off.size(), ni = ph.node_l.size();
+    GLX_HIP(hipMalloc(&b.pw_off, nl * 8));
+    GLX_HIP(hipMalloc(&b.pw_len, nl * 4));
+    GLX_HIP(hipMalloc(&b.pw_l, std::max<size_t>(ni, 1) * 4));
+    GLX_HIP(hipMalloc(&b.pw_r, std::max<size_t>(ni, 1) * 4));
+    GLX_HIP(hipMalloc(&b.pw_ls, ph.level_start.size() * 4 + 4));
+    GLX_HIP(hipMalloc(&b.pw_vals, (nl + ni) * 8));
+    GLX_HIP(hipMemcpy(b.pw_off, ph.leaf_off.data(), nl * 8, hipMemcpyHostToDevice));
+    GLX_HIP(hipMemcpy(b.pw_len, ph.leaf_len.data(), nl * 4, hipMemcpyHostToDevice));
+    if (ni) {
+      GLX_HIP(hipMemcpy(b.pw_l, ph.node_l.data(), ni * 4, hipMemcpyHostToDevice));
+      GLX_HIP(hipMemcpy(b.pw_r, ph.node_r.data(), ni * 4, hipMemcpyHostToDevice));
+    }
+    if (!ph.level_start.empty()) GLX_HIP(hipMemcpy(b.pw_ls, ph.level_start.data(), ph.level_start.size() * 4, hipMemcpyHostToDevice));
+    pw.leaf_off = b.pw_off;
+    pw.leaf_len = b.pw_len;
+    pw.node_l = b.pw_l;
+    pw.node_r = b.pw_r;
+    pw.level_start = b.pw_ls;
+    pw.vals = b.pw_vals;
+    pw.nleaves = (int)nl;
+    pw.ninternal = (int)ni;
+    pw.nlevels = ph.level_start.empty() ? 0 : (int)ph.level_start.size() - 1;
+    pw_grid = (unsigned)((nl + 255) / 256);
+  }
   GLX_HIP(hipHostMalloc((void**)&b.h_err, (size_t)(CG_CHUNK + 1) * stride * 8, hipHostMallocDefault));
   CgScalars sc;
   sc.rsold = b.scal;
@@ -494,7 +602,10 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
                      (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, sc, 1, tol, b.prod, prod_sc, (const int32_t*)A->d_perm);
   GLX_HIP(hipGetLastError());
   if (np1d)
-    hipLaunchKernelGGL(cg_pairwise1d_kernel<2>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, prod_sc, sc, 0, tol);
+    {
+      hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, 0, tol, 2);
+      hipLaunchKernelGGL(cg_pw_tree_kernel<2>, dim3(1), dim3(256), 0, st, pw, sc, 0, tol);
+    }
   else if (exact)
     hipLaunchKernelGGL(cg_seqsum_dpp_kernel<2>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, 0, tol);
   else
@@ -534,7 +645,10 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       rc = glx_launch_spmm(a, st);                                                   // Ap = A@p, p.Ap partials
       if (rc) return rc;
       if (np1d)
-        hipLaunchKernelGGL(cg_pairwise1d_kernel<0>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, prod_sc, sc, i, tol);
+        {
+      hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, i, tol, 0);
+      hipLaunchKernelGGL(cg_pw_tree_kernel<0>, dim3(1), dim3(256), 0, st, pw, sc, i, tol);
+    }
       else if (exact)
         hipLaunchKernelGGL(cg_seqsum_dpp_kernel<0>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       else
@@ -544,7 +658,10 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
                          (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, sc, i, tol, b.prod, prod_sc, (const int32_t*)A->d_perm);
       GLX_HIP(hipGetLastError());
       if (np1d)
-        hipLaunchKernelGGL(cg_pairwise1d_kernel<1>, dim3(1), dim3(64), 0, st, (const double*)b.prod, n, prod_sc, sc, i, tol);
+        {
+      hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, i, tol, 1);
+      hipLaunchKernelGGL(cg_pw_tree_kernel<1>, dim3(1), dim3(256), 0, st, pw, sc, i, tol);
+    }
       else if (exact)
         hipLaunchKernelGGL(cg_seqsum_dpp_kernel<1>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       else

@@ -457,3 +457,16 @@ def test_plaplace_jacobi_golden(gl, golden, orc):
         assert np.max(np.abs(u - g[tag + '_u'])) <= 1e-12
     with pytest.raises(NotImplementedError):
         G.plaplace(g['bdy'], g['bdy_val'], 10)            # fast=True: sequential Gauss-Seidel in the reference
+
+
+def test_reweight_poisson_midsize_vs_oracle(gl, orc):
+    """1-D conjgrad (numpy's pairwise-summed reductions, parallel on the device) on a graph whose
+    summation tree is several levels deep: the reweighted matrix equals the oracle's bit for bit."""
+    X, labels = blobs(9000, 6, 5, 8, 2.2)
+    W = gl.weightmatrix.knn(X, 9)
+    ti = gl.trainsets.generate(labels, rate=4, seed=1)
+    for norm in ('combinatorial', 'normalized'):
+        Wr = gl.graph(W).reweight(ti, method='poisson', normalization=norm)
+        Wo = orc.reweight(W, ti, method='poisson', normalization=norm)
+        assert (Wr != Wo).nnz == 0
+        assert np.array_equal(sparse.csr_matrix(Wr).data, sparse.csr_matrix(Wo).data)
