@@ -352,7 +352,8 @@ __global__ __launch_bounds__(64) void cg_seqsum_dpp_kernel(const double* __restr
 
 // numpy reduces a contiguous 1-D float64 array with pairwise summation (umath
 // DOUBLE_pairwise_sum: blocks of <= 128 elements summed with 8 strided accumulators combined as a
-// fixed tree, halves split at a multiple of 8).  utils.conjgrad called with a 1-D right-hand side
+// fixed tree, halves split at a multiple of 8), applied to pieces of 8192 elements (its buffer size)
+// whose sums are added one after another.  utils.conjgrad called with a 1-D right-hand side
 // (graph.reweight, graph.py:429) takes that path, so its device twin reproduces the same tree.
 // (`a` holds the elements `st` doubles apart: column 0 of the row-major product array)
 // The recursion tree is fixed by n alone, so it is parallel: the host lists the leaves (blocks of
@@ -444,6 +445,21 @@ struct PwHost {
     node_r.push_back(r);
     node_h.push_back(*height);
     return -(int)node_l.size();
+  }
+  // numpy hands a contiguous 1-D reduction to the pairwise routine in pieces of its buffer size
+  // (8192 elements) and adds the pieces' sums one after another: ((c0 + c1) + c2) + ...
+  void build_chunked(int64_t n) {
+    const int64_t NPY_BUFSIZE = 8192;
+    int h, hacc = 0;
+    int acc = build(0, std::min(n, NPY_BUFSIZE), &hacc);
+    for (int64_t off = NPY_BUFSIZE; off < n; off += NPY_BUFSIZE) {
+      const int c = build(off, std::min(NPY_BUFSIZE, n - off), &h);
+      hacc = std::max(hacc, h) + 1;
+      node_l.push_back(acc);
+      node_r.push_back(c);
+      node_h.push_back(hacc);
+      acc = -(int)node_l.size();
+    }
   }
   void finish() {   // order the internal nodes by height (stable: children always precede parents) and renumber
     const int ni = (int)node_l.size(), nl = (int)leaf_off.size();
@@ -543,8 +559,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   unsigned pw_grid = 1;
   if (np1d) {   // numpy's pairwise-summation tree for n elements
     PwHost ph;
-    int hroot;
-    ph.build(0, n, &hroot);
+    ph.build_chunked(n);
     ph.finish();
     const size_t nl = ph.leaf_off.size(), ni = ph.node_l.size();
     GLX_HIP(hipMalloc(&b.pw_off, nl * 8));
