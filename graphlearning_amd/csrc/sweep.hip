@@ -61,7 +61,7 @@ struct SpmmParams {
   int prod_sc;              // prod_out is blocked by prod_sc columns: (row, col) at ((col/sc)*n + row)*sc + col%sc
   const int32_t* perm;      // record -> caller row (null: identity)
   int64_t n_rows;
-  int ablate;               // developer probe (GLX_ABLATE): 1 no chunk loop, 2 gathers hit one hot record, 4 no stores
+  int ablate;               // developer probe (GLX_ABLATE): 1 no chunk loop, 2 gathers hit one hot record, 4 no stores, 8 no XCD remap
 };
 
 // ---- cross-lane helpers -------------------------------------------------------------
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
   if constexpr (HAS_DOT) {
     if (p.exit_err && !(*p.exit_err > p.exit_tol)) return;
   }
-  const int64_t vb = xcd_remap(blockIdx.x, p.nblocks);
+  const int64_t vb = (p.ablate & 8) ? (int64_t)blockIdx.x : xcd_remap(blockIdx.x, p.nblocks);
   const int64_t slice = vb * GLX_WPB + wave;
   const int g = lane / G, c = lane % G;
   bool lane_on = c < p.nlanes;
