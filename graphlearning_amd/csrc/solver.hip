@@ -90,10 +90,12 @@ extern "C" int glx_sweep_create(glx_graph* P, int C, int min_iter, int max_iter,
   const size_t rb = std::max<size_t>(rec_bytes(s, s->n_cols), 64);
   SW_HIP(hipMalloc(&s->buf[0], rb));
   SW_HIP(hipMalloc(&s->buf[1], rb));
-  SW_HIP(hipMemset(s->buf[0], 0, rb));
-  SW_HIP(hipMemset(s->buf[1], 0, rb));
+  // (on the sweep's own stream: it is non-blocking, so a null-stream memset -- asynchronous to the host --
+  // would not be ordered against the first pack / upload and could land after it)
+  SW_HIP(hipMemsetAsync(s->buf[0], 0, rb, s->stream));
+  SW_HIP(hipMemsetAsync(s->buf[1], 0, rb, s->stream));
   SW_HIP(hipMalloc(&s->bias, std::max<size_t>(rec_bytes(s, s->n_rows), 64)));
-  SW_HIP(hipMemset(s->bias, 0, std::max<size_t>(rec_bytes(s, s->n_rows), 64)));
+  SW_HIP(hipMemsetAsync(s->bias, 0, std::max<size_t>(rec_bytes(s, s->n_rows), 64), s->stream));
   SW_HIP(hipMalloc(&s->slot_has_bias, std::max<size_t>((size_t)s->plan->nslices * s->plan->R, 64)));
   SW_HIP(hipMalloc(&s->dense, std::max<size_t>((size_t)s->n_cols * C * s->L.esize, 64)));
   if (s->has_w) {
