@@ -139,3 +139,22 @@ def test_config2_published_mnist_trainsets(gl, golden, config2):
         assert model.num_iter == T_ref
         assert np.array_equal(u, u_ref), i
         assert np.array_equal(model.predict(), orc.predict(u_ref))
+
+
+def test_config2_batched_cg_trials_equal_single_fits(gl, golden, meta, config2):
+    """SURVEY 8f-1 at n = 70000: five published MNIST train sets (label rates 1..5) plus the config-2
+    train set as column groups of ONE conjugate-gradient solve: every trial's iterate and iteration
+    count equal the fit on its own (which test_config2_poisson_cg pins to the reference: 140 iterations)."""
+    g = golden('g6_helpers.npz')
+    W, labels = config2['W'], config2['labels']
+    model = gl.ssl.poisson(W)
+    trials = [config2['train_ind']] + [g['mnist_perm_%d' % i] for i in (0, 2, 4, 6, 8)]
+    t0 = time.perf_counter()
+    together = model._fit_batch([(ti, labels[ti]) for ti in trials])
+    iters = list(model.num_iter)
+    print('6 stacked Poisson CG trials at 70k: iterations %s, %.3f s' % (iters, time.perf_counter() - t0))
+    assert iters[0] == meta['config2']['cg_iters']
+    for j in (0, 3, 5):
+        alone = model.fit(trials[j], labels[trials[j]])
+        assert model.num_iter == iters[j]
+        assert np.array_equal(alone, together[j]), j
