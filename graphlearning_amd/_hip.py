@@ -83,6 +83,7 @@ _SIGNATURES = {
                        C.POINTER(C.c_int64), C.c_int],
     'glx_affine_iterate': [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int64), _f64p],
     'glx_cg_groups': [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
+    'glx_cg_groups_masked': [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_argmax_project': [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
     'glx_knn_bruteforce': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
     'glx_knn_bruteforce_range': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
@@ -233,16 +234,31 @@ class DeviceGraph:
                                         int(max_iter), C.byref(it), C.byref(err)), 'glx_affine_iterate')
         return (out[:, 0] if squeeze else out), it.value, err.value
 
-    def cg_groups(self, B, group_cols, tol=1e-10, max_iter=100000):
+    def cg_groups(self, B, group_cols, tol=1e-10, max_iter=100000, masks=None):
         """Independent systems side by side (columns in groups of `group_cols`), each with its own
-        stop test: returns (X, iterations per group, err per group)."""
-        B = np.ascontiguousarray(B, dtype=self.dtype)
+        stop test: returns (X, iterations per group, err per group).  masks: per group an array of
+        Dirichlet rows (x held at zero there; B is zeroed on them) -- the sub-matrix solve of
+        ssl.laplace on the full operator."""
+        B = np.array(B, dtype=self.dtype, order='C', copy=masks is not None)
         ng = B.shape[1] // group_cols
         X = np.empty_like(B)
         its = np.zeros(ng, dtype=np.int32)
         errs = np.zeros(ng, dtype=np.float64)
-        check(load().glx_cg_groups(self._h, _ptr(B), _ptr(X), B.shape[1], int(group_cols), float(tol), int(max_iter), 0,
-                                   its.ctypes.data_as(C.POINTER(C.c_int)), errs.ctypes.data_as(_f64p)), 'glx_cg_groups')
+        if masks is None:
+            check(load().glx_cg_groups(self._h, _ptr(B), _ptr(X), B.shape[1], int(group_cols), float(tol), int(max_iter), 0,
+                                       its.ctypes.data_as(C.POINTER(C.c_int)), errs.ctypes.data_as(_f64p)), 'glx_cg_groups')
+            return X, its, errs
+        if len(masks) != ng:
+            raise GlxError('cg_groups: %d masks for %d systems' % (len(masks), ng))
+        rows = [np.ascontiguousarray(m, dtype=np.int32).ravel() for m in masks]
+        ptr = np.zeros(ng + 1, dtype=np.int32)
+        ptr[1:] = np.cumsum([len(r) for r in rows])
+        allrows = np.ascontiguousarray(np.concatenate(rows) if rows else np.zeros(0, np.int32), dtype=np.int32)
+        for g, r in enumerate(rows):
+            B[r, g * group_cols:(g + 1) * group_cols] = 0
+        check(load().glx_cg_groups_masked(self._h, _ptr(B), _ptr(X), B.shape[1], int(group_cols), _ptr(allrows), _ptr(ptr),
+                                          float(tol), int(max_iter), 0, its.ctypes.data_as(C.POINTER(C.c_int)),
+                                          errs.ctypes.data_as(_f64p)), 'glx_cg_groups_masked')
         return X, its, errs
 
     def close(self):

@@ -494,18 +494,37 @@ __global__ void cg_set_err0(double* err_hist, int64_t n, int stride) {
   if (i < n) err_hist[i] = i < stride ? 1.0 : 0.0;
 }
 
+// Dirichlet rows (ssl.laplace._fit, ssl.py:1232-1241, solves on the sub-matrix of the unlabelled
+// vertices): on the FULL operator the same solve is obtained by keeping x, r, p at zero on the
+// labelled rows -- their columns then multiply zeros, which adds exact zeros to every row sum
+// and to every reduction chain -- and that only needs A p forced to zero there after each SpMM.
+// mask_rows holds record indices, group g owns mask_rows[mask_ptr[g] .. mask_ptr[g+1]).
+template <typename T>
+__global__ __launch_bounds__(256) void cg_zero_rows_kernel(T* __restrict__ ap, int ld, const int32_t* __restrict__ mask_rows,
+                                                           const int32_t* __restrict__ mask_ptr, int Cg, CgScalars sc, int it,
+                                                           double tol) {
+  if (!cg_any_active(sc, it, tol)) return;
+  const int g = blockIdx.y;
+  const int cnt = mask_ptr[g + 1] - mask_ptr[g];
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)cnt * Cg) return;
+  const int row = mask_rows[mask_ptr[g] + idx / Cg];
+  ap[(size_t)row * ld + g * Cg + idx % Cg] = (T)0;
+}
+
 struct CgBufs {
   void *x = nullptr, *r = nullptr, *p = nullptr, *ap = nullptr, *dense = nullptr;
   double* prod = nullptr;
   int64_t* pw_off = nullptr;
   int32_t *pw_len = nullptr, *pw_l = nullptr, *pw_r = nullptr, *pw_ls = nullptr;
   double* pw_vals = nullptr;
+  int32_t *mask_rows = nullptr, *mask_ptr = nullptr;
   double *part_dot = nullptr, *part_rs = nullptr, *scal = nullptr, *err_hist = nullptr, *h_err = nullptr;
   hipStream_t stream = nullptr;
   ~CgBufs() {
     hipFree(x); hipFree(r); hipFree(p); hipFree(ap); hipFree(dense); hipFree(part_dot); hipFree(part_rs);
     hipFree(scal); hipFree(err_hist); hipFree(prod);
-    hipFree(pw_off); hipFree(pw_len); hipFree(pw_l); hipFree(pw_r); hipFree(pw_ls); hipFree(pw_vals);
+    hipFree(pw_off); hipFree(pw_len); hipFree(pw_l); hipFree(pw_r); hipFree(pw_ls); hipFree(pw_vals); hipFree(mask_rows); hipFree(mask_ptr);
     if (h_err) hipHostFree(h_err);
     if (stream) hipStreamDestroy(stream);
   }
@@ -513,7 +532,7 @@ struct CgBufs {
 
 template <typename T>
 static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double tol, int64_t max_iter, int* iters_out,
-                  double* err_out, int flags) {
+                  double* err_out, int flags, const int32_t* mask_rows, const int32_t* mask_ptr) {
   // GLX_CG_REDUCE=tree selects block-tree reductions (faster, deterministic, not bit-identical to numpy)
   const char* red_env = getenv("GLX_CG_REDUCE");
   const bool exact = !(red_env && strcmp(red_env, "tree") == 0);
@@ -642,6 +661,23 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   a.act_cg = Cg;
   a.act_c = C;
   a.prod_sc = prod_sc;
+  // Dirichlet rows per group (caller row numbers -> record indices)
+  unsigned mask_grid = 0;
+  if (mask_rows && mask_ptr && mask_ptr[ngroups] > 0) {
+    const int total = mask_ptr[ngroups];
+    std::vector<int32_t> rec(total);
+    int most = 0;
+    for (int g = 0; g < ngroups; ++g) most = std::max(most, mask_ptr[g + 1] - mask_ptr[g]);
+    for (int q = 0; q < total; ++q) {
+      GLX_CHECK(mask_rows[q] >= 0 && mask_rows[q] < n, GLX_EINVAL, "glx_cg_groups_masked: row %d out of range", mask_rows[q]);
+      rec[q] = A->order_ready && !A->h_inv.empty() ? A->h_inv[mask_rows[q]] : mask_rows[q];
+    }
+    GLX_HIP(hipMalloc(&b.mask_rows, (size_t)total * 4));
+    GLX_HIP(hipMalloc(&b.mask_ptr, (size_t)(ngroups + 1) * 4));
+    GLX_HIP(hipMemcpy(b.mask_rows, rec.data(), (size_t)total * 4, hipMemcpyHostToDevice));
+    GLX_HIP(hipMemcpy(b.mask_ptr, mask_ptr, (size_t)(ngroups + 1) * 4, hipMemcpyHostToDevice));
+    mask_grid = (unsigned)(((int64_t)most * Cg + 255) / 256);
+  }
   const unsigned pgrid = (unsigned)std::max<int64_t>(((int64_t)n * (L.ld / 4) + 255) / 256, 1);
 
   int64_t it = 0;                               // iterations launched
@@ -659,6 +695,11 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       a.act_row = ngroups > 1 ? b.err_hist + (size_t)(i - 1) * stride : nullptr;
       rc = glx_launch_spmm(a, st);                                                   // Ap = A@p, p.Ap partials
       if (rc) return rc;
+      if (mask_grid) {
+        hipLaunchKernelGGL((cg_zero_rows_kernel<T>), dim3(mask_grid, (unsigned)ngroups), blk, 0, st, ap, L.ld, (const int32_t*)b.mask_rows,
+                           (const int32_t*)b.mask_ptr, Cg, sc, i, tol);
+        GLX_HIP(hipGetLastError());
+      }
       if (np1d)
         {
       hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, i, tol, 0);
@@ -712,16 +753,24 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   return GLX_OK;
 }
 
-extern "C" int glx_cg_groups(glx_graph* A, const void* B, void* X, int C, int group_cols, double tol, int64_t max_iter, int flags,
-                             int* iters_out, double* err_out) {
+extern "C" int glx_cg_groups_masked(glx_graph* A, const void* B, void* X, int C, int group_cols, const int32_t* mask_rows,
+                                    const int32_t* mask_ptr, double tol, int64_t max_iter, int flags, int* iters_out,
+                                    double* err_out) {
   GLX_CHECK(A && B && X, GLX_EINVAL, "glx_cg_multi: null argument");
   GLX_CHECK(A->n_rows == A->n_cols, GLX_EINVAL, "glx_cg_multi: operator must be square");
   GLX_CHECK(max_iter >= 0, GLX_EINVAL, "glx_cg_multi: negative max_iter");
   GLX_CHECK(C >= 1 && group_cols >= 1 && C % group_cols == 0, GLX_EINVAL,
             "glx_cg_groups: %d columns do not split into systems of %d columns", C, group_cols);
+  GLX_CHECK((mask_rows == nullptr) == (mask_ptr == nullptr) || (mask_ptr && mask_ptr[C / group_cols] == 0), GLX_EINVAL,
+            "glx_cg_groups_masked: mask_rows and mask_ptr go together");
   GLX_HIP(hipSetDevice(A->device));
-  return A->dtype == GLX_F32 ? cg_run<float>(A, B, X, C, group_cols, tol, max_iter, iters_out, err_out, flags)
-                             : cg_run<double>(A, B, X, C, group_cols, tol, max_iter, iters_out, err_out, flags);
+  return A->dtype == GLX_F32 ? cg_run<float>(A, B, X, C, group_cols, tol, max_iter, iters_out, err_out, flags, mask_rows, mask_ptr)
+                             : cg_run<double>(A, B, X, C, group_cols, tol, max_iter, iters_out, err_out, flags, mask_rows, mask_ptr);
+}
+
+extern "C" int glx_cg_groups(glx_graph* A, const void* B, void* X, int C, int group_cols, double tol, int64_t max_iter, int flags,
+                             int* iters_out, double* err_out) {
+  return glx_cg_groups_masked(A, B, X, C, group_cols, nullptr, nullptr, tol, max_iter, flags, iters_out, err_out);
 }
 
 extern "C" int glx_cg_solve(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int flags,

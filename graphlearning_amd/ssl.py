@@ -429,20 +429,66 @@ class laplace(ssl):
         self.num_iter = None
         self.dtype = np.float64
 
-    def _fit(self, train_ind, train_labels, all_labels=None):
-        if self.reweighting == 'none':
-            G = self.graph
-        else:       # reference ssl.py:1211-1213
-            W = self.graph.reweight(train_ind, method=self.reweighting, normalization=self.normalization, X=self.X)
-            G = graph_mod.graph(W)
+    def _laplacian(self, G):
         n = G.num_nodes
-        k = len(np.unique(train_labels))
         L = sparse.spdiags(self.tau, 0, n, n) + G.laplacian(normalization=self.normalization)
         if self.order > 1:                                   # host-side SpGEMM, reference ssl.py:1223-1228
             Lpow = L * L
             for _ in range(2, self.order):
                 Lpow = L * Lpow
             L = Lpow
+        return L
+
+    def _full_system(self):
+        """Without reweighting the operator of every training set is a sub-matrix of ONE matrix:
+        A = L[unl, unl] and M = diag((A_ii + 1e-10)^-1/2) (reference ssl.py:1239-1246) are the rows
+        and columns of L and of M_full = diag((L_ii + 1e-10)^-1/2) at the unlabelled vertices, so
+        M A M is that part of M_full L M_full (same products, same entry order).  Built and
+        uploaded once per graph; the solves then hold the labelled rows at zero (glx_cg_groups_masked)."""
+        key = (id(self.graph.weight_matrix), self.normalization, np.asarray(self.tau, dtype=np.float64).tobytes(), int(self.order))
+        if self._cache is not None and self._cache[0] == key:
+            return self._cache[1:]
+        if self._cache is not None:
+            self._cache[3].close()
+        n = self.graph.num_nodes
+        L = sparse.csr_matrix(self._laplacian(self.graph))
+        Mv = 1 / np.sqrt(L.diagonal() + 1e-10)
+        M = sparse.spdiags(Mv, 0, n, n).tocsr()
+        dev = _hip.DeviceGraph(M * L * M, dtype=self.dtype, device=self.device, keep_order=True)
+        self._cache = (key, L, Mv, dev)
+        return L, Mv, dev
+
+    def _rhs(self, L, Mv, train_ind, train_labels):
+        """F, and M b embedded in an (n, k) array that is zero on the labelled rows (reference ssl.py:1229-1237, 1249)."""
+        n = L.shape[0]
+        k = len(np.unique(train_labels))
+        F = utils.labels_to_onehot(train_labels, k)
+        b = -L[:, train_ind] * F                             # reference ssl.py:1236
+        B = Mv[:, None] * b                                  # row i of M*b is m_i * b_i
+        B[train_ind, :] = 0
+        return F, np.ascontiguousarray(B, dtype=self.dtype), k
+
+    def _assemble(self, x, Mv, train_ind, F):
+        u = Mv[:, None] * x                                  # v = M*v, reference ssl.py:1250
+        u[train_ind, :] = F                                  # reference ssl.py:1253-1255
+        if self.mean_shift:
+            u -= np.mean(u, axis=0)
+        return u
+
+    def _fit(self, train_ind, train_labels, all_labels=None):
+        if self.reweighting == 'none':
+            L, Mv, dev = self._full_system()
+            train_ind = np.asarray(train_ind)
+            F, B, k = self._rhs(L, Mv, train_ind, train_labels)
+            x, its, _ = dev.cg_groups(B, k, tol=self.tol, masks=[train_ind])
+            self.num_iter = int(its[0])
+            return self._assemble(x, Mv, train_ind, F)
+        # reweighted graphs depend on the training set: per-fit sub-matrix, reference ssl.py:1211-1250 line by line
+        W = self.graph.reweight(train_ind, method=self.reweighting, normalization=self.normalization, X=self.X)
+        G = graph_mod.graph(W)
+        n = G.num_nodes
+        k = len(np.unique(train_labels))
+        L = self._laplacian(G)
         F = utils.labels_to_onehot(train_labels, k)
         idx = np.full((n,), True, dtype=bool)
         idx[train_ind] = False
@@ -466,6 +512,27 @@ class laplace(ssl):
         if self.mean_shift:
             u -= np.mean(u, axis=0)
         return u
+
+    def _trial_batch_size(self, labels):
+        if self.reweighting != 'none':
+            return 1
+        k = max(1, len(np.unique(labels)))
+        return max(1, min(24, 240 // k))
+
+    def _fit_batch(self, trials):
+        """Laplace learning for several training sets at once: one operator, the trials as column
+        groups with their own Dirichlet rows, stop tests and iteration counts (glx_cg_groups_masked)."""
+        if self.reweighting != 'none':
+            return None
+        L, Mv, dev = self._full_system()
+        parts = [self._rhs(L, Mv, np.asarray(ti), np.asarray(tl)) for ti, tl in trials]
+        k = parts[0][2]
+        if any(p[2] != k for p in parts):
+            return None
+        x, its, _ = dev.cg_groups(np.hstack([p[1] for p in parts]), k, tol=self.tol, masks=[np.asarray(ti) for ti, _ in trials])
+        self.num_iter = [int(i) for i in its]
+        return [self._assemble(np.ascontiguousarray(x[:, j * k:(j + 1) * k]), Mv, np.asarray(trials[j][0]), parts[j][0])
+                for j in range(len(trials))]
 
 
 class randomwalk(ssl):

@@ -147,6 +147,15 @@ int glx_cg_solve(glx_graph* A, const void* B, void* X, int C, double tol, int64_
  * to solving it alone.  iters_out / err_out: C/group_cols entries.  C <= 252. */
 int glx_cg_groups(glx_graph* A, const void* B, void* X, int C, int group_cols, double tol, int64_t max_iter,
                   int flags, int* iters_out, double* err_out);
+/* the same with Dirichlet rows per system: the solve on the sub-matrix of the unlabelled vertices that
+ * ssl.laplace._fit builds for every training set (graphlearning/ssl.py:1232-1250) is carried out on
+ * the FULL operator by holding x, r, p at zero on the labelled rows (B must be zero there): their
+ * columns then contribute exact zeros to every row sum and reduction, so the unlabelled rows of X and
+ * the iteration counts are those of the sub-matrix solve, while the operator is uploaded once for all
+ * training sets.  mask_rows: concatenated row numbers, system g owns [mask_ptr[g], mask_ptr[g+1]). */
+int glx_cg_groups_masked(glx_graph* A, const void* B, void* X, int C, int group_cols, const int32_t* mask_rows,
+                         const int32_t* mask_ptr, double tol, int64_t max_iter, int flags, int* iters_out,
+                         double* err_out);
 
 /* ---- predict / volume-constrained projection --------------------------------------
  * ssl.predict (ssl.py:230-266) and ssl.volume_label_projection (ssl.py:172-209) on

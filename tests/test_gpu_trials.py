@@ -73,3 +73,51 @@ def test_ssl_trials_batched_file_equals_sequential(gl, tmp_path, monkeypatch):
             assert len(rows[(tag, priors is None)].splitlines()) == len(trainsets) + 1
     assert rows[('b_', True)] == rows[('s_', True)]
     assert rows[('b_', False)] == rows[('s_', False)]
+
+
+@pytest.mark.parametrize('norm', ['combinatorial', 'randomwalk', 'normalized'])
+def test_laplace_trials_on_the_full_operator(gl, golden, norm):
+    """ssl.laplace over several training sets: one uploaded operator, Dirichlet rows held at zero
+    (glx_cg_groups_masked).  The golden trial inside the batch reproduces the reference (iterates
+    and iteration count of the sub-matrix solve), every trial equals its single fit."""
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    labels = g['labels']
+    model = gl.ssl.laplace(W, normalization=norm)
+    trials = [g['train_ind']] + [gl.trainsets.generate(labels, rate=r, seed=s) for r, s in ((2, 1), (7, 2), (3, 3))]
+    together = model._fit_batch([(ti, labels[ti]) for ti in trials])
+    iters = list(model.num_iter)
+    assert iters[0] == int(g['laplace_%s_iters' % norm])
+    assert np.array_equal(together[0], g['laplace_%s_prob' % norm])
+    for j, ti in enumerate(trials):
+        alone = model.fit(ti, labels[ti])
+        assert model.num_iter == iters[j]
+        assert np.array_equal(alone, together[j])
+
+
+def test_laplace_full_operator_equals_submatrix_solve(gl):
+    """The same fits through the reference's literal route (sub-matrix per training set; what the
+    reweighted variants still use) on a 10-class graph: identical iterates and iteration counts."""
+    from graphlearning_amd import _hip
+    from scipy import sparse
+    W, labels = _blob_graph(gl, 4000, 10, 12)
+    model = gl.ssl.laplace(W, tau=0.01)
+    for seed in (0, 1):
+        ti = gl.trainsets.generate(labels, rate=2, seed=seed)
+        u = model.fit(ti, labels[ti])
+        n = W.shape[0]
+        L = sparse.spdiags(model.tau, 0, n, n) + gl.graph(W).laplacian()
+        F = gl.utils.labels_to_onehot(labels[ti], 10)
+        idx = np.full((n,), True)
+        idx[ti] = False
+        b = (-L[:, ti] * F)[idx, :]
+        A = L[idx, :][:, idx]
+        M = sparse.spdiags(1 / np.sqrt(A.diagonal() + 1e-10), 0, A.shape[0], A.shape[0]).tocsr()
+        dev = _hip.DeviceGraph(M * A * M, keep_order=True)
+        v, it, _ = dev.cg(np.ascontiguousarray(M * b), tol=model.tol)
+        dev.close()
+        ref = np.zeros((n, 10))
+        ref[idx, :] = M * v
+        ref[ti, :] = F
+        assert it == model.num_iter
+        assert np.array_equal(u, ref)
