@@ -545,7 +545,14 @@ class randomwalk(ssl):
         self.name = 'Lazy Random Walks'
         self.num_iter = None
 
-    def _fit(self, train_ind, train_labels, all_labels=None):
+    def _operator(self):
+        """M L M of reference ssl.py:1779-1786 depends on the graph and alpha only: built and
+        uploaded once, shared by every fit on this graph."""
+        key = (id(self.graph.weight_matrix), float(self.alpha))
+        if self._cache is not None and self._cache[0] == key:
+            return self._cache[1], self._cache[2]
+        if self._cache is not None:
+            self._cache[2].close()
         alpha = self.alpha
         n = self.graph.num_nodes
         W = self.graph.weight_matrix
@@ -555,13 +562,38 @@ class randomwalk(ssl):
         m = L.shape[0]
         M = L.diagonal()
         M = sparse.spdiags(1 / np.sqrt(M + 1e-10), 0, m, m).tocsr()
+        dev = _hip.DeviceGraph(M * L * M, dtype=np.float64, device=self.device, keep_order=True)
+        self._cache = (key, M, dev)
+        return M, dev
+
+    def _rhs(self, train_ind, train_labels):
+        n = self.graph.num_nodes
         k = len(np.unique(train_labels))
         onehot = utils.labels_to_onehot(train_labels, k)
         Y = np.zeros((n, onehot.shape[1]))
         Y[train_ind, :] = onehot
-        u, it, _ = utils.conjgrad(M * L * M, M * Y, tol=1e-6, return_info=True, device=self.device)
+        return Y
+
+    def _fit(self, train_ind, train_labels, all_labels=None):
+        M, dev = self._operator()
+        u, it, _ = dev.cg(np.ascontiguousarray(M * self._rhs(train_ind, train_labels)), tol=1e-6)   # reference ssl.py:1790
         self.num_iter = it
         return M * u
+
+    def _trial_batch_size(self, labels):
+        k = max(1, len(np.unique(labels)))
+        return max(1, min(24, 240 // k))
+
+    def _fit_batch(self, trials):
+        """Several training sets as column groups of one solve (glx_cg_groups), like ssl.poisson."""
+        M, dev = self._operator()
+        Ys = [M * self._rhs(np.asarray(ti), np.asarray(tl)) for ti, tl in trials]
+        k = Ys[0].shape[1]
+        if any(Y.shape[1] != k for Y in Ys):
+            return None
+        x, its, _ = dev.cg_groups(np.hstack(Ys), k, tol=1e-6)
+        self.num_iter = [int(i) for i in its]
+        return [M * np.ascontiguousarray(x[:, j * k:(j + 1) * k]) for j in range(len(trials))]
 
 
 def ssl_accuracy(pred_labels, true_labels, train_ind):

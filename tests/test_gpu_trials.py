@@ -121,3 +121,17 @@ def test_laplace_full_operator_equals_submatrix_solve(gl):
         ref[ti, :] = F
         assert it == model.num_iter
         assert np.array_equal(u, ref)
+
+
+def test_randomwalk_trials_stacked_equal_single(gl, golden):
+    g = golden('g7_next_rows.npz')
+    W = csr_from(g, 'W')
+    labels = g['labels']
+    model = gl.ssl.randomwalk(W)
+    trials = [g['train_ind']] + [gl.trainsets.generate(labels, rate=r, seed=s) for r, s in ((1, 4), (6, 5))]
+    together = model._fit_batch([(ti, labels[ti]) for ti in trials])
+    iters = list(model.num_iter)
+    assert iters[0] == int(g['randomwalk_iters']) and np.array_equal(together[0], g['randomwalk_prob'])
+    for j, ti in enumerate(trials):
+        alone = model.fit(ti, labels[ti])
+        assert model.num_iter == iters[j] and np.array_equal(alone, together[j])
