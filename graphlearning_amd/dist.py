@@ -40,6 +40,93 @@ def block_bounds(n, world):
     return np.array([(n * r) // world for r in range(world + 1)], dtype=np.int64)
 
 
+def crossing_counts(P, order):
+    """cross[p] = number of stored entries (i, j) of the symmetrised pattern whose endpoints lie on
+    different sides of a cut between positions p-1 and p of `order` (cross[0] = cross[n] = 0)."""
+    A = sparse.csr_matrix(P)
+    n = A.shape[0]
+    pos = np.empty(n, dtype=np.int64)
+    pos[order] = np.arange(n)
+    coo = A.tocoo()
+    a = np.minimum(pos[coo.row], pos[coo.col])
+    b = np.maximum(pos[coo.row], pos[coo.col])
+    diff = np.bincount(a + 1, minlength=n + 2) - np.bincount(b + 1, minlength=n + 2)
+    return np.cumsum(diff)[:n + 1]
+
+
+def _best_cuts(cross, n, world, cap, cand):
+    """world-1 increasing cut positions among `cand` with every block <= cap rows, minimising the
+    total crossing count, ties towards balanced blocks.  Returns (total crossing, cuts) or None."""
+    m = len(cand)
+    INF = (float('inf'), float('inf'))
+    prev = [((int(cross[c]), c * c) if c <= cap else INF) for c in cand]
+    back = []
+    for k in range(2, world):
+        cur, arg = [INF] * m, [-1] * m
+        for j in range(m):
+            cj = cand[j]
+            best, bi = INF, -1
+            for i in range(j):
+                if prev[i] is INF or cj - cand[i] > cap:
+                    continue
+                t = (prev[i][0] + int(cross[cj]), prev[i][1] + (cj - cand[i]) ** 2)
+                if t < best:
+                    best, bi = t, i
+            cur[j], arg[j] = best, bi
+        back.append(arg)
+        prev = cur
+    best, bj = INF, -1
+    for j in range(m):
+        if prev[j] is INF or n - cand[j] > cap:
+            continue
+        t = (prev[j][0], prev[j][1] + (n - cand[j]) ** 2)
+        if t < best:
+            best, bj = t, j
+    if bj < 0:
+        return None
+    cuts = [cand[bj]]
+    for arg in reversed(back):
+        bj = arg[bj]
+        cuts.append(cand[bj])
+    return best[0], cuts[::-1]
+
+
+def cut_bounds(P, order, world, slack_levels=(0.0, 0.1, 0.25, 0.45, 0.65, 0.85)):
+    """Block boundaries along `order` that follow the graph: a kNN graph of clustered data is a set of
+    (nearly) disconnected pieces which the locality order lays out one after another, and a boundary
+    placed in the gap between two pieces costs no halo at all -- a rank that owns whole pieces has
+    nothing to exchange.  For growing allowed imbalance (block size <= (1 + slack) n/world) the cuts
+    of least total crossing are found by dynamic programming over the low-crossing positions; a larger
+    slack is accepted only if it removes the crossings entirely or cuts them at least four-fold, so a
+    graph without such structure keeps equal blocks (slack 0 = block_bounds)."""
+    n = len(order)
+    if world <= 1:
+        return np.array([0, n], dtype=np.int64)
+    cross = crossing_counts(P, order)
+    ideal = [(n * r) // world for r in range(1, world)]
+    # candidate positions: the equal-split points and the least-crossed position of each of 32*world windows
+    cand = set(ideal)
+    edges = np.linspace(1, n, 32 * world + 1).astype(np.int64)
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        if hi > lo:
+            cand.add(int(lo + np.argmin(cross[lo:hi])))
+    cand = sorted(c for c in cand if 0 < c < n)
+    chosen = None
+    for slack in slack_levels:
+        cap = int(np.ceil((1.0 + slack) * n / world))
+        res = _best_cuts(cross, n, world, cap, cand)
+        if res is None:
+            continue
+        if chosen is None or res[0] == 0 or 4 * res[0] <= chosen[0]:
+            if chosen is None or res[0] < chosen[0]:
+                chosen = res
+        if chosen is not None and chosen[0] == 0:
+            break
+    if chosen is None:
+        return block_bounds(n, world)
+    return np.array([0] + list(chosen[1]) + [n], dtype=np.int64)
+
+
 class RankPlan:
     """What rank `rank` needs: its rows of P with columns renumbered [owned | halo] and the
     send / receive lists of the per-sweep exchange."""
@@ -80,6 +167,9 @@ class RankPlan:
             send.append(mine - bounds[rank])                 # local row indices
             self.send_counts.append(len(mine))
         self.send_idx = np.concatenate(send) if send else np.zeros(0, dtype=np.int64)
+        # does ANY rank import anything?  (every rank derives the same answer from the same inputs;
+        # blocks that follow the connected pieces of the graph have no halo and need no exchange)
+        self.global_halo = self.n_halo + sum(len(halo_of(r)) for r in range(world) if r != rank)
         # local row order: BOUNDARY rows (needed by some peer) first, interior rows after -- the
         # boundary part of a sweep runs first, its records leave while the interior part computes
         is_b = np.zeros(self.n_own, dtype=bool)
@@ -259,7 +349,7 @@ class DistSweep:
         """Boundary records of x[0:n_own] -> the peers' halo regions x[n_own:].  With async_op the
         collective is only enqueued; the returned handle's wait() orders later work behind it."""
         p = self.plan
-        if p.world == 1 and not self._force_coll:
+        if (p.world == 1 or p.global_halo == 0) and not self._force_coll:
             return None
         send = self.ops.index_rows(x, self.send_idx)
         recv = x[p.n_own:]
@@ -465,10 +555,11 @@ def poisson_problem(W, train_ind, train_labels):
 
 
 def poisson_fit_distributed(W, train_ind, train_labels, dist, ops_factory, min_iter=50, max_iter=1000, order=None,
-                            group=None, gather=True):
+                            group=None, gather=True, partition='cut'):
     """ssl.poisson(solver='gradient_descent').fit across the ranks of `dist`.
     Every rank holds the whole (host) graph and calls this collectively.  Returns (u, T) with
-    u the full (n,C) matrix on every rank (gather=True) or this rank's rows."""
+    u the full (n,C) matrix on every rank (gather=True) or this rank's rows.  partition: 'cut' =
+    block boundaries that follow the graph's pieces (cut_bounds), 'even' = equal blocks."""
     import torch
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     prob = poisson_problem(W, train_ind, train_labels)
@@ -476,7 +567,8 @@ def poisson_fit_distributed(W, train_ind, train_labels, dist, ops_factory, min_i
     n = P.shape[0]
     if order is None:
         order = locality_order(P)
-    plan = RankPlan(P, order, block_bounds(n, world), rank)
+    bounds = cut_bounds(P, order, world) if partition == 'cut' else block_bounds(n, world)
+    plan = RankPlan(P, order, bounds, rank)
     ops = ops_factory(plan, prob['k'])
     sweep = DistSweep(plan, ops, dist, group)
     own = plan.own

@@ -4,7 +4,8 @@ Launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --g
 rank per GPU, torch.distributed backend "nccl" (= RCCL over xGMI).  The global graph has
 N * 70000 vertices (MNIST label vector tiled, same blob generator, k = 10): every rank builds
 it identically (exact kNN with the queries sharded over the ranks and all_gathered, deterministic assembly), owns one contiguous
-block of the RCM-ordered vertices and exchanges boundary vertex records once per sweep.
+block of the RCM-ordered vertices (boundaries placed in the gaps between the graph's pieces, dist.cut_bounds)
+and exchanges boundary vertex records once per sweep -- or nothing at all when no block has a halo.
 """
 import os
 import sys
@@ -38,7 +39,7 @@ def main(args):
     prob = gdist.poisson_problem(W, train_ind, labels[train_ind])
     P = prob['P']
     order = gdist.locality_order(P)
-    plan = gdist.RankPlan(P, order, gdist.block_bounds(n, world), rank)
+    plan = gdist.RankPlan(P, order, gdist.cut_bounds(P, order, world), rank)
     ops = gdist.HipOps(plan, prob['k'], local_rank)
     sweep = gdist.DistSweep(plan, ops, dist)
     own = plan.own
@@ -73,8 +74,12 @@ def main(args):
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'configs[1] scaled weakly: %d x 70000 = %d vertices, k=10 kNN graph, nnz=%d, C=%d, '
-                                   'vertex-partitioned over %d GPUs (RCM order), one RCCL all_to_all halo exchange per '
-                                   'sweep; value = sweeps/s of the whole graph x %d' % (world, n, nnz, C, world, world),
+                                   'vertex-partitioned over %d GPUs (RCM order, block boundaries in the gaps between the '
+                                   'graph\'s pieces), %s; value = sweeps/s of the whole graph x %d'
+                                   % (world, n, nnz, C, world,
+                                      'one RCCL all_to_all halo exchange per sweep' if plan.global_halo > 0 else
+                                      'no halo (every rank owns whole pieces): no per-sweep exchange, RCCL all_reduce for the stop test only',
+                                      world),
                        'n': n, 'nnz': nnz, 'classes': C, 'sweeps_per_step': T, 'parallelism': 'vertex-partition x%d' % world},
             'global_sweeps_per_sec': iters,
             'edges_classes_per_sec': iters * nnz * C,
@@ -83,7 +88,7 @@ def main(args):
                          'note': 'whole-job algorithmic bytes per sweep / wall time incl. halo exchange'},
             'cpu_baseline': None,
             'halo': {'rows_per_rank': [int(h[0]) for h in halos], 'owned_per_rank': [int(h[1]) for h in halos],
-                     'exchanges_per_sweep': 1},
+                     'exchanges_per_sweep': 1 if plan.global_halo > 0 else 0, 'global_halo_rows': int(plan.global_halo)},
             'graph_build_s': t_graph,
         }
         print(json.dumps(line))

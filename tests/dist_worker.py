@@ -89,6 +89,7 @@ def main():
     case = sys.argv[1]
     out_path = sys.argv[2]
     use_hip = len(sys.argv) > 3 and sys.argv[3] == 'hip'     # rank-local sweeps on the GPU (all ranks share cuda:0)
+    partition = sys.argv[4] if len(sys.argv) > 4 else 'even'  # 'even': equal blocks (halo exchange every sweep); 'cut': graph-following blocks
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     from conftest import csr_from, blobs
@@ -108,17 +109,18 @@ def main():
     else:
         raise SystemExit('unknown case')
     factory = (lambda plan, k: gdist.HipOps(plan, k, 0)) if use_hip else (lambda plan, k: ScipyOps(plan, k))
-    u, T = gdist.poisson_fit_distributed(W, ti, tl, dist, factory, min_iter=min_iter, max_iter=max_iter)
+    u, T = gdist.poisson_fit_distributed(W, ti, tl, dist, factory, min_iter=min_iter, max_iter=max_iter, partition=partition)
     u_ref, T_ref = orc.poisson_gd(W, ti, tl, min_iter=min_iter, max_iter=max_iter, return_T=True)
     # partition bookkeeping invariants
     P = gdist.poisson_problem(W, ti, tl)['P']
     order = gdist.locality_order(P)
-    plan = gdist.RankPlan(P, order, gdist.block_bounds(P.shape[0], world), rank)
+    bounds = gdist.cut_bounds(P, order, world) if partition == 'cut' else gdist.block_bounds(P.shape[0], world)
+    plan = gdist.RankPlan(P, order, bounds, rank)
     counts = [None] * world
     dist.all_gather_object(counts, (plan.send_counts, plan.recv_counts, plan.n_own, plan.n_halo))
     ok_counts = all(counts[a][0][b] == counts[b][1][a] for a in range(world) for b in range(world))
     res = dict(rank=rank, world=world, T=int(T), T_ref=int(T_ref), equal=bool(np.array_equal(u, u_ref)),
-               ok_counts=bool(ok_counts), n_own=int(plan.n_own), n_halo=int(plan.n_halo),
+               ok_counts=bool(ok_counts), n_own=int(plan.n_own), n_halo=int(plan.n_halo), global_halo=int(plan.global_halo),
                sorted_perm=bool(np.array_equal(np.sort(order), np.arange(P.shape[0]))))
     with open(out_path + '.%d' % rank, 'w') as f:
         json.dump(res, f)

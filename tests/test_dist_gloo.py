@@ -19,11 +19,11 @@ def _free_port():
     return p
 
 
-def _run(case, world, tmp_path):
-    out = str(tmp_path / ('res_' + case))
+def _run(case, world, tmp_path, partition='even'):
+    out = str(tmp_path / ('res_' + case + '_' + partition))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
-           os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out]
+           os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out, 'scipy', partition]
     env = dict(os.environ, OMP_NUM_THREADS='1')
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -79,3 +79,46 @@ def test_record_layout_host_call():
     assert _hip.record_layout(2, has_w=False)['woff'] == -1
     with pytest.raises(_hip.GlxError):
         _hip.record_layout(0)
+
+
+@pytest.mark.parametrize('case,world', [('twomoons', 2), ('blobs', 3)])
+def test_distributed_sweep_graph_following_partition(case, world, tmp_path):
+    """partition='cut' (the default of poisson_fit_distributed and of bench.py --gpus N): block
+    boundaries in the gaps between the graph's pieces.  Same bit-identical result; where every rank
+    owns whole pieces nothing is exchanged at all."""
+    res = _run(case, world, tmp_path, partition='cut')
+    for r in res:
+        assert r['T'] == r['T_ref'] and r['equal'] and r['ok_counts'] and r['sorted_perm'], r
+    even = _run(case, world, tmp_path, partition='even')
+    assert sum(r['n_halo'] for r in res) <= sum(r['n_halo'] for r in even)
+    assert len({r['global_halo'] for r in res}) == 1            # every rank derives the same global halo size
+
+
+def test_cut_bounds_follow_the_pieces():
+    """Five disconnected random pieces of unequal size, 2/3/4 ranks: zero crossings, every block within
+    the allowed imbalance; a graph without structure keeps equal blocks."""
+    from scipy import sparse
+    from graphlearning_amd import dist as gdist
+    rng = np.random.default_rng(3)
+    sizes = [700, 900, 650, 1100, 800]
+    blocks = []
+    for m in sizes:
+        B = sparse.random(m, m, density=12.0 / m, random_state=int(rng.integers(1 << 30)), format='csr')
+        blocks.append(B + B.T + sparse.identity(m))
+    A = sparse.block_diag(blocks, format='csr')
+    perm = rng.permutation(A.shape[0])
+    A = A[perm][:, perm].tocsr()                               # hide the structure from the natural order
+    order = gdist.locality_order(A)
+    n = A.shape[0]
+    for world in (2, 3, 4):
+        b = gdist.cut_bounds(A, order, world)
+        cross = gdist.crossing_counts(A, order)
+        assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) > 0)
+        assert int(cross[b[1:-1]].sum()) == 0
+        assert np.diff(b).max() <= 1.85 * n / world + 1
+        plans = [gdist.RankPlan(A, order, b, r) for r in range(world)]
+        assert all(p.n_halo == 0 and p.global_halo == 0 for p in plans)
+    R = sparse.random(6000, 6000, density=8 / 6000, random_state=1, format='csr')
+    R = (R + R.T).tocsr()
+    o = gdist.locality_order(R)
+    assert np.array_equal(gdist.cut_bounds(R, o, 4), gdist.block_bounds(6000, 4))

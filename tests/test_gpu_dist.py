@@ -69,8 +69,9 @@ def test_distributed_bench_entry_one_rank(tmp_path, force_coll):
     print(line[:400])
 
 
-@pytest.mark.parametrize('case,world', [('twomoons', 2), ('blobs', 3), ('miniter0', 2)])
-def test_multi_rank_hip_sweeps_over_gloo(case, world, tmp_path):
+@pytest.mark.parametrize('case,world,partition', [('twomoons', 2, 'even'), ('blobs', 3, 'even'), ('miniter0', 2, 'even'),
+                                                  ('twomoons', 2, 'cut'), ('blobs', 3, 'cut')])
+def test_multi_rank_hip_sweeps_over_gloo(case, world, partition, tmp_path):
     """Several ranks, every one running its rank-local sweeps with the HIP kernel (all on cuda:0),
     exchanging halo records through gloo (host-staged): the full multi-rank GPU path minus RCCL,
     bit-identical to the single-rank oracle."""
@@ -79,9 +80,9 @@ def test_multi_rank_hip_sweeps_over_gloo(case, world, tmp_path):
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    out = str(tmp_path / ('res_' + case))
+    out = str(tmp_path / ('res_' + case + '_' + partition))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out, 'hip']
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out, 'hip', partition]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS='1'), cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for k in range(world):
