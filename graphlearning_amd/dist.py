@@ -432,34 +432,39 @@ class DistSweep:
         for T in range(nsweeps):
             want = (T + 1) >= min_iter
             e = self.step(bufs[self.cur], bufs[self.cur ^ 1], want)
-            if want and (self.plan.world > 1 or self._force_coll):
-                self._all_reduce_max(e)
             self.cur ^= 1
         return e
 
+    def _exchanges(self):
+        """Does a sweep contain a collective (halo exchange)?"""
+        p = self.plan
+        return (p.world > 1 and p.global_halo > 0) or self._force_coll
+
     def run(self, min_iter, max_iter, err0=None):
         """All sweeps; returns T.  Stop test (ssl.py:667): T = first T >= min_iter with
-        max over ALL vertices |deg w_T - vinf| <= 1/n_global.  The min_iter sweeps that always
-        run are captured once into a device graph (kernels, record gathers and RCCL exchanges)
-        and replayed; if capture is not possible the same sequence runs eagerly."""
+        max over ALL vertices |deg w_T - vinf| <= 1/n_global.  When the sweeps are purely local (no
+        halo anywhere, or one rank) the min_iter sweeps that always run are captured once into a
+        device graph and replayed.  Collectives are NEVER captured: the process group's watchdog
+        thread polls the completion events of the work it tracks, and an event recorded inside a
+        capture makes that query fail (hipErrorCapturedEvent) and the watchdog abort the process --
+        seen in about 1 of 20 single-rank runs when the exchanges were part of the graph.  With a
+        halo the sequence [boundary rows | exchange | interior rows] therefore runs eagerly."""
         torch, dist, ops, p = self.torch, self.dist, self.ops, self.plan
         thresh = 1.0 / p.n_global
         head = min(min_iter, max_iter)
         e = None
-        if self._graph_ok and head > 0:
+        if self._graph_ok and head > 0 and not self._exchanges():
             if self._graph is None:
                 try:
-                    self.reset()                                   # eager warm-up: communicator, allocator
+                    self.reset()                                   # eager warm-up
                     self._head(1, min_iter + 2)
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
-                    # thread_local: the process group's watchdog thread polls events concurrently; in the
-                    # default global mode such a call landing inside the capture window invalidates it
                     with torch.cuda.graph(g, capture_error_mode='thread_local'):
                         self.reset()
                         self._graph_err = self._head(head, min_iter)
                     self._graph = g
-                except Exception as exc:                           # e.g. a collective that cannot be captured
+                except Exception as exc:
                     self._graph_ok = False
                     self._graph = None
                     torch.cuda.synchronize()
@@ -472,6 +477,8 @@ class DistSweep:
         if self._graph is None or head == 0:
             self.reset()
             e = self._head(head, min_iter)
+        if e is not None and head >= min_iter and (p.world > 1 or self._force_coll):
+            self._all_reduce_max(e)                                # stop test of the last head sweep, outside any capture
         bufs = [self.xa, self.xb]
         T = head
         err_T = err0 if head == 0 else (float(e.item()) if e is not None else None)
@@ -485,7 +492,7 @@ class DistSweep:
             want = (T + 1) >= min_iter
             e = self.step(xin, xout, want)
             if want:
-                if p.world > 1:
+                if p.world > 1 or self._force_coll:
                     self._all_reduce_max(e)
                 err_T = float(e.item())
             self.cur ^= 1

@@ -51,7 +51,8 @@ def test_hipops_rank_local_sweeps_match_scipy(golden):
 
 @pytest.mark.parametrize('force_coll', ['0', '1'])
 def test_distributed_bench_entry_one_rank(tmp_path, force_coll):
-    # force_coll=1: the all_to_all / all_reduce calls are issued (and graph-captured) even with one rank
+    # force_coll=1: the all_to_all / all_reduce calls are issued even with one rank (eagerly: collectives are never
+    # captured into a device graph, see DistSweep.run)
     env = dict(os.environ, GLX_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', GLX_DIST_FORCE_COLLECTIVES=force_coll)
     import socket
     s = socket.socket()
