@@ -403,8 +403,8 @@ class DistSweep:
                           and os.environ.get('GLX_DIST_GRAPH', '1') != '0')
 
     def close(self):
-        """Release the captured device graph (it holds RCCL work: drop it while the process group
-        is still alive, not at interpreter exit) and the rank-local state."""
+        """Release the captured device graph and the rank-local state while the process group is
+        still alive (not at interpreter exit)."""
         if getattr(self, '_graph', None) is not None:
             try:
                 import torch
@@ -417,7 +417,7 @@ class DistSweep:
 
     def reset(self):
         """Owned rows <- initial records; halo filled by one exchange.  Allocation-free apart from
-        the exchange's send buffer, so it can be stream-captured."""
+        the exchange's send buffer; without an exchange it can be stream-captured."""
         p = self.plan
         self.xa.zero_()
         self.xa[:p.n_own].copy_(self.init_rec)

@@ -92,7 +92,7 @@ def main(args):
             'graph_build_s': t_graph,
         }
         print(json.dumps(line))
-    # orderly teardown: captured graph (RCCL work inside) first, then the operators, then the group
+    # orderly teardown: captured graph first, then the operators, then the group
     torch.cuda.synchronize()
     sweep.close()
     ops.close()
