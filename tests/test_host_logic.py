@@ -107,6 +107,23 @@ def test_no_cpu_fallback_without_gpu():
         gl.weightmatrix.knnsearch(np.random.rand(10, 3), 3)
     with pytest.raises(_hip.GlxError):
         gl.weightmatrix.knn(None, 2, knn_data=(np.zeros((4, 3), dtype=np.int64), np.zeros((4, 3))))
+    for model in (gl.ssl.poisson(W), gl.ssl.laplace(W), gl.ssl.randomwalk(W), gl.ssl.poisson_mbo(W, np.array([0.5, 0.5]))):
+        with pytest.raises(_hip.GlxError):
+            model.fit(np.array([0, 5]), np.array([0, 1]))
+    with pytest.raises(_hip.GlxError):
+        gl.ssl.laplace(W).ssl_trials([np.array([0, 5]), np.array([1, 4])], np.array([0, 0, 0, 1, 1, 1]), save_results=False)
+    with pytest.raises(_hip.GlxError):
+        gl.graph(W).page_rank()
+    with pytest.raises(_hip.GlxError):
+        gl.graph(W).plaplace(np.array([0, 5]), np.array([0.0, 1.0]), 4, fast=False)
+
+
+def test_plaplace_default_is_refused_not_emulated():
+    """The reference's default fast=True is a sequential Gauss-Seidel sweep: no silent substitute."""
+    W = sparse.identity(6, format='csr') + sparse.diags([1.0] * 5, 1) + sparse.diags([1.0] * 5, -1)
+    with pytest.raises(NotImplementedError):
+        gl.graph(W).plaplace(np.array([0, 5]), np.array([0.0, 1.0]), 4)
+    assert gl.graph is gl.graph.graph                       # gl.graph(W) like the reference, gl.graph.graph(W) still works
 
 
 def test_cabi_exports_every_declared_symbol():
