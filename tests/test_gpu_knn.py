@@ -57,6 +57,17 @@ def test_knnsearch_edge_cases(gl):
     ind, dist = _hip.knn_bruteforce(X, 4)
     assert np.all(dist[:, :3] == 0)
     assert np.all(np.sort(ind[:, :3], axis=1) == (np.arange(120) // 3 * 3)[:, None] + np.arange(3))
+    # far from the origin and on very different scales per feature: centring + the fp32 filter's error bound
+    for d in (20, 200):
+        Y = rng.normal(size=(900, d)) * np.logspace(-2, 2, d) + 1e6
+        ind, dist = _hip.knn_bruteforce(Y, 8)
+        Yc = Y - Y.mean(axis=0)
+        D2 = ((Yc[:, None, :] - Yc[None, :, :]) ** 2).sum(-1)
+        ref = np.argsort(D2, axis=1, kind='stable')[:, :8]
+        assert np.array_equal(ind, ref), d
+    Z = np.repeat(rng.normal(size=(50, 300)), 4, axis=0)      # duplicates through the feature-blocked variant
+    ind, dist = _hip.knn_bruteforce(Z, 5)
+    assert np.all(dist[:, :4] == 0) and np.all(np.sort(ind[:, :4], axis=1) == (np.arange(200) // 4 * 4)[:, None] + np.arange(4))
     with pytest.raises(_hip.GlxError):
         _hip.knn_bruteforce(X, 1000)
     with pytest.raises(_hip.GlxError):          # k (incl. self) above 60
