@@ -21,7 +21,9 @@ def main(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
     torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    # a stuck collective ends the job after 5 minutes (watchdog abort) instead of holding the GPUs
+    import datetime
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=datetime.timedelta(minutes=5))
     import bench
     import graphlearning_amd as gl
     from graphlearning_amd import _hip, dist as gdist
