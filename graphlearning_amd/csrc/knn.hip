@@ -338,53 +338,78 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
 }
 
 // ---- stage 3: exact fp64 fallback for flagged rows --------------------------------------------
-// k rounds of "smallest (dist, idx) lexicographically greater than the last one picked"
-__global__ __launch_bounds__(256) void knn_fallback_kernel(const double* __restrict__ X, int64_t n, int d, int k, int64_t q_begin,
-                                                           const int* __restrict__ rows, int nrows, int64_t* __restrict__ ind_out,
-                                                           double* __restrict__ dist_out) {
+// k rounds of "smallest (dist, idx) lexicographically greater than the last one picked".  Every
+// round scans all refs; a flagged row's scan is split over FB_SPLIT workgroups (a single one would
+// read the whole data set k times: 50 ms per row at n = 1e7), a second kernel picks the round's
+// winner among the partial minima, writes it out and makes it the next round's lower bound.
+static const int FB_SPLIT = 64;
+
+__global__ __launch_bounds__(256) void knn_fallback_scan_kernel(const double* __restrict__ X, int64_t n, int d, int64_t q_begin,
+                                                                const int* __restrict__ rows, const double* __restrict__ last_d,
+                                                                const int* __restrict__ last_i, double* __restrict__ part_d,
+                                                                int* __restrict__ part_i) {
   __shared__ double s_d[256];
   __shared__ int s_i[256];
-  __shared__ double last_d;
-  __shared__ int last_i;
-  const int64_t ql = rows[blockIdx.x];
+  const int row = blockIdx.x, piece = blockIdx.y;
+  const int64_t ql = rows[row];
   const double* xq = X + (q_begin + ql) * d;
-  if (threadIdx.x == 0) { last_d = -1.0; last_i = -1; }
+  const double pd = last_d[row];
+  const int pi = last_i[row];
+  const int64_t per = (n + FB_SPLIT - 1) / FB_SPLIT;
+  const int64_t r0 = piece * per, r1 = min(n, r0 + per);
+  double bd = INFINITY;
+  int bi = 0x7fffffff;
+  for (int64_t ref = r0 + threadIdx.x; ref < r1; ref += 256) {
+    const double dd = sqdist_exact(xq, X + ref * d, d);
+    if (lex_less(pd, pi, dd, (int)ref) && lex_less(dd, (int)ref, bd, bi)) { bd = dd; bi = (int)ref; }
+  }
+  s_d[threadIdx.x] = bd;
+  s_i[threadIdx.x] = bi;
   __syncthreads();
-  for (int r = 0; r < k; ++r) {
-    const double pd = last_d;
-    const int pi = last_i;
-    double bd = INFINITY;
-    int bi = 0x7fffffff;
-    for (int64_t ref = threadIdx.x; ref < n; ref += 256) {
-      const double dd = sqdist_exact(xq, X + ref * d, d);
-      if (lex_less(pd, pi, dd, (int)ref) && lex_less(dd, (int)ref, bd, bi)) { bd = dd; bi = (int)ref; }
-    }
-    s_d[threadIdx.x] = bd;
-    s_i[threadIdx.x] = bi;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (threadIdx.x < off && lex_less(s_d[threadIdx.x + off], s_i[threadIdx.x + off], s_d[threadIdx.x], s_i[threadIdx.x])) {
-        s_d[threadIdx.x] = s_d[threadIdx.x + off];
-        s_i[threadIdx.x] = s_i[threadIdx.x + off];
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      last_d = s_d[0];
-      last_i = s_i[0];
-      ind_out[ql * k + r] = s_i[0] == 0x7fffffff ? -1 : s_i[0];
-      dist_out[ql * k + r] = sqrt(s_d[0]);
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off && lex_less(s_d[threadIdx.x + off], s_i[threadIdx.x + off], s_d[threadIdx.x], s_i[threadIdx.x])) {
+      s_d[threadIdx.x] = s_d[threadIdx.x + off];
+      s_i[threadIdx.x] = s_i[threadIdx.x + off];
     }
     __syncthreads();
   }
+  if (threadIdx.x == 0) {
+    part_d[(size_t)row * FB_SPLIT + piece] = s_d[0];
+    part_i[(size_t)row * FB_SPLIT + piece] = s_i[0];
+  }
+}
+
+__global__ __launch_bounds__(64) void knn_fallback_pick_kernel(const double* __restrict__ part_d, const int* __restrict__ part_i,
+                                                               const int* __restrict__ rows, int nrows, int k, int r,
+                                                               double* __restrict__ last_d, int* __restrict__ last_i,
+                                                               int64_t* __restrict__ ind_out, double* __restrict__ dist_out) {
+  const int row = blockIdx.x * 64 + threadIdx.x;
+  if (row >= nrows) return;
+  double bd = INFINITY;
+  int bi = 0x7fffffff;
+  for (int piece = 0; piece < FB_SPLIT; ++piece) {
+    const double dd = part_d[(size_t)row * FB_SPLIT + piece];
+    const int ii = part_i[(size_t)row * FB_SPLIT + piece];
+    if (lex_less(dd, ii, bd, bi)) { bd = dd; bi = ii; }
+  }
+  last_d[row] = bd;
+  last_i[row] = bi;
+  const int64_t ql = rows[row];
+  ind_out[ql * k + r] = bi == 0x7fffffff ? -1 : bi;
+  dist_out[ql * k + r] = sqrt(bd);
 }
 
 // features per half per block of the blocked (d > 130) variant; 16 where the KP = 64 lists leave less LDS
-constexpr int knn_kb(int KP) { return KP == 64 ? 16 : 32; }
+constexpr int knn_kb(int KP) { return KP == 64 ? 16 : 32; }   // (KP = 8 never takes the blocked variant)
 
 // refs per tile = 32*NSUB, as many as fit LDS (160 KiB) beside the candidate lists
 constexpr int tile_nsub(int DH, int KP) {
   const int stride = 2 * DH + 2;
+  if (KP == 8) {   // short lists: aim at three workgroups per CU
+    for (int ns = 4; ns >= 2; ns /= 2)
+      if (2 * 32 * ns * stride * 4 + (KP + KBUF) * 256 * 8 <= 53 * 1024) return ns;
+    return 1;
+  }
   for (int ns = 4; ns >= 2; ns /= 2)
     if (2 * 32 * ns * stride * 4 + (KP + KBUF) * 256 * 8 <= 78 * 1024) return ns;   // two workgroups per CU
   return 1;
@@ -393,13 +418,14 @@ constexpr int tile_nsub(int DH, int KP) {
 struct KnnBufs {
   double *X = nullptr, *mean = nullptr, *dist = nullptr;
   float *Rf = nullptr, *Qf = nullptr, *qnorm = nullptr, *cand_d = nullptr;
-  int *cand_i = nullptr, *flags = nullptr, *rows = nullptr;
+  int *cand_i = nullptr, *flags = nullptr, *rows = nullptr, *fb_li = nullptr, *fb_pi = nullptr;
+  double *fb_ld = nullptr, *fb_pd = nullptr;
   int64_t* ind = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
   ~KnnBufs() {
     hipFree(X); hipFree(mean); hipFree(dist); hipFree(Rf); hipFree(Qf); hipFree(qnorm); hipFree(cand_d);
-    hipFree(cand_i); hipFree(flags); hipFree(rows); hipFree(ind);
+    hipFree(cand_i); hipFree(flags); hipFree(rows); hipFree(ind); hipFree(fb_li); hipFree(fb_pi); hipFree(fb_ld); hipFree(fb_pd);
     if (e0) hipEventDestroy(e0);
     if (e1) hipEventDestroy(e1);
     if (e2) hipEventDestroy(e2);
@@ -449,7 +475,16 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   if (nq == 0) return GLX_OK;
   GLX_HIP(hipSetDevice(device));
   // d + 2 <= 132: the query's features stay in registers; above that the feature dimension is blocked
-  const int KP = k <= 12 ? 16 : (k <= 28 ? 32 : 64);
+  int KP = k <= 12 ? 16 : (k <= 28 ? 32 : 64);
+  // Short lists.  A query's candidates are kept in 2*nsplit separate lists (two half-wavefronts x
+  // nsplit ref ranges); with >= 8 lists, 8 entries per list hold the k <= 12 nearest unless 8 of
+  // them fall into the same list (5e-5 per query for k = 11; the acceptance test of the re-rank
+  // sees a full list whose threshold is too small and sends the row to the exact fallback).  The
+  // shorter lists free LDS for a third workgroup per CU and halve the list rescans: 5.1 -> 3.6 ms
+  // at config 2, 94 -> 108 TFLOP/s at d = 64.  Not for the blocked variant: at large d the fp32
+  // error margin of the acceptance test makes short lists fall back too often.
+  const bool short_lists = k <= 12 && d + 2 <= 132 && !(getenv("GLX_KNN_KP8") && atoi(getenv("GLX_KNN_KP8")) == 0);
+  if (short_lists) KP = 8;
   int DH = knn_kb(KP), nkb = 1;
   if (d + 2 <= 132 && !(KP == 64 && d + 2 > 36)) {   // (KP = 64 lists + a wide double-buffered tile exceed the LDS)
     for (int cand : {8, 12, 18, 34, 66})
@@ -462,6 +497,7 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   const int BR = 32 * tile_nsub(DH, KP);
   const int64_t ntiles = (n + BR - 1) / BR;
   int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, ntiles), (1024 + nqb - 1) / nqb));
+  if (KP == 8) nsplit = (int)std::max<int64_t>(nsplit, std::min<int64_t>(4, ntiles));   // >= 8 lists per query
   if (const char* e = getenv("GLX_KNN_NSPLIT")) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, ntiles), atoi(e)));
   const int lists = nsplit * 2;
   const int ncand = lists * KP;
@@ -510,7 +546,8 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
                      n, d, dpa, b.Rf, b.Qf, b.qnorm);
   GLX_HIP(hipGetLastError());
   int rc;
-  if (KP == 16) rc = launch_tile_dh<16>(DH, nkb, b, n, q0, q1, nsplit, st);
+  if (KP == 8) rc = launch_tile_dh<8>(DH, nkb, b, n, q0, q1, nsplit, st);
+  else if (KP == 16) rc = launch_tile_dh<16>(DH, nkb, b, n, q0, q1, nsplit, st);
   else if (KP == 32) rc = launch_tile_dh<32>(DH, nkb, b, n, q0, q1, nsplit, st);
   else rc = launch_tile_dh<64>(DH, nkb, b, n, q0, q1, nsplit, st);
   if (rc) return rc;
@@ -528,9 +565,23 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
     if (flags[i]) rows.push_back((int)i);
   if (!rows.empty()) {
     GLX_HIP(hipMemcpyAsync(b.rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(knn_fallback_kernel, dim3((unsigned)rows.size()), dim3(256), 0, st, (const double*)b.X, n, d, k, q0,
-                       (const int*)b.rows, (int)rows.size(), b.ind, b.dist);
+    const size_t nr = rows.size();
+    GLX_HIP(hipMalloc(&b.fb_ld, nr * 8));
+    GLX_HIP(hipMalloc(&b.fb_li, nr * 4));
+    GLX_HIP(hipMalloc(&b.fb_pd, nr * FB_SPLIT * 8));
+    GLX_HIP(hipMalloc(&b.fb_pi, nr * FB_SPLIT * 4));
+    std::vector<double> ld0(nr, -1.0);
+    std::vector<int> li0(nr, -1);
+    GLX_HIP(hipMemcpyAsync(b.fb_ld, ld0.data(), nr * 8, hipMemcpyHostToDevice, st));
+    GLX_HIP(hipMemcpyAsync(b.fb_li, li0.data(), nr * 4, hipMemcpyHostToDevice, st));
+    for (int r = 0; r < k; ++r) {
+      hipLaunchKernelGGL(knn_fallback_scan_kernel, dim3((unsigned)nr, FB_SPLIT), dim3(256), 0, st, (const double*)b.X, n, d, q0,
+                         (const int*)b.rows, (const double*)b.fb_ld, (const int*)b.fb_li, b.fb_pd, b.fb_pi);
+      hipLaunchKernelGGL(knn_fallback_pick_kernel, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, st, (const double*)b.fb_pd,
+                         (const int*)b.fb_pi, (const int*)b.rows, (int)nr, k, r, b.fb_ld, b.fb_li, b.ind, b.dist);
+    }
     GLX_HIP(hipGetLastError());
+    GLX_HIP(hipStreamSynchronize(st));   // ld0 / li0 are read by the asynchronous copies above
   }
   GLX_HIP(hipEventRecord(b.e3, st));
   GLX_HIP(hipMemcpyAsync(ind_out, b.ind, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
