@@ -483,8 +483,9 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   // shorter lists free LDS for a third workgroup per CU and halve the list rescans: 5.1 -> 3.6 ms
   // at config 2, 94 -> 108 TFLOP/s at d = 64.  Not for the blocked variant: at large d the fp32
   // error margin of the acceptance test makes short lists fall back too often.
-  const bool short_lists = k <= 12 && d + 2 <= 132 && !(getenv("GLX_KNN_KP8") && atoi(getenv("GLX_KNN_KP8")) == 0);
-  if (short_lists) KP = 8;
+  // The same argument one size up: 16 entries for k <= 28 (3e-7 per query at k = 28), 32 for k <= 60.
+  const bool short_lists = d + 2 <= 132 && !(getenv("GLX_KNN_SHORT") && atoi(getenv("GLX_KNN_SHORT")) == 0);
+  if (short_lists) KP = k <= 12 ? 8 : (k <= 28 ? 16 : 32);
   int DH = knn_kb(KP), nkb = 1;
   if (d + 2 <= 132 && !(KP == 64 && d + 2 > 36)) {   // (KP = 64 lists + a wide double-buffered tile exceed the LDS)
     for (int cand : {8, 12, 18, 34, 66})
@@ -497,7 +498,7 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   const int BR = 32 * tile_nsub(DH, KP);
   const int64_t ntiles = (n + BR - 1) / BR;
   int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, ntiles), (1024 + nqb - 1) / nqb));
-  if (KP == 8) nsplit = (int)std::max<int64_t>(nsplit, std::min<int64_t>(4, ntiles));   // >= 8 lists per query
+  if (short_lists) nsplit = (int)std::max<int64_t>(nsplit, std::min<int64_t>(4, ntiles));   // >= 8 lists per query
   if (const char* e = getenv("GLX_KNN_NSPLIT")) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, ntiles), atoi(e)));
   const int lists = nsplit * 2;
   const int ncand = lists * KP;

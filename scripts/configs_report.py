@@ -40,7 +40,7 @@ rng = np.random.default_rng(1)
 centers = rng.normal(size=(10, 32)) * 1.2
 X3 = centers[lab3] + rng.normal(size=(60000, 32))
 t, W3 = timed(lambda: gl.weightmatrix.knn(X3, 20), 2)
-print('config 3 graph: weightmatrix.knn(X, 20) n=60000 d=32 -> nnz=%d in %.1f ms' % (W3.nnz, t * 1e3))
+print('config 3 graph: weightmatrix.knn(X, 20) n=60000 d=32 -> nnz=%d in %.1f ms (tile kernel %.2f ms, %d fallback rows)' % (W3.nnz, t * 1e3, _hip.knn_stats()['tile_ms'], _hip.knn_stats()['fallback_rows']))
 ti3 = gl.trainsets.generate(lab3, rate=10, seed=0)
 m = gl.ssl.laplace(W3)
 m.fit(ti3, lab3[ti3])
