@@ -498,7 +498,12 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   const int BR = 32 * tile_nsub(DH, KP);
   const int64_t ntiles = (n + BR - 1) / BR;
   int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, ntiles), (1024 + nqb - 1) / nqb));
-  if (short_lists) nsplit = (int)std::max<int64_t>(nsplit, std::min<int64_t>(4, ntiles));   // >= 8 lists per query
+  if (short_lists) {
+    // >= 8 lists per query; 16 for the 8-entry lists once the data no longer sits in cache (an exact
+    // fallback row then streams all of X k times: 329 rows cost 0.6 s at n = 2e6 -- with 16 lists 5 rows are left)
+    const int64_t want = (KP == 8 && (double)n * d * 8.0 > 64.0 * 1024 * 1024) ? 8 : 4;
+    nsplit = (int)std::max<int64_t>(nsplit, std::min<int64_t>(want, ntiles));
+  }
   if (const char* e = getenv("GLX_KNN_NSPLIT")) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, ntiles), atoi(e)));
   const int lists = nsplit * 2;
   const int ncand = lists * KP;
