@@ -73,3 +73,25 @@ def test_lp_iterate_restatement_equals_compiled_reference():
         f(_p(ru), _p(rl), _p(J), _p(I), _p(V), _p(b32), _p(val), C.c_double(p), C.c_int(T), C.c_double(tol), C.c_bool(False),
           C.c_int(n), C.c_int(len(V)), C.c_int(len(b32)))
         assert np.array_equal(ru, uu, equal_nan=True) and np.array_equal(rl, ul, equal_nan=True), (n, p)
+
+
+def test_openmp_sweeps_equal_scipy(lib):
+    """bench.py's all-core CPU baseline (rows of a sweep over OpenMP threads, fused stop column) is the
+    same arithmetic as the scipy sweeps: bit-identical u and w after an even and an odd number of sweeps."""
+    rng = np.random.default_rng(2)
+    n, nc = 3000, 7
+    P = sparse.random(n, n, density=0.004, random_state=5, format='csr')
+    Db = rng.normal(size=(n, nc))
+    w0 = rng.random(n)
+    ip, ix = P.indptr.astype(np.int32), P.indices.astype(np.int32)
+    for T in (4, 5):
+        u, tmp, w, wt = np.zeros((n, nc)), np.zeros((n, nc)), w0.copy(), np.zeros(n)
+        th = lib.ref_poisson_sweeps_omp(C.c_int64(n), C.c_int64(7), _p(ip), _p(ix), _p(P.data), _p(Db), _p(u), _p(tmp), _p(w), _p(wt),
+                                        C.c_int64(T), C.c_int(3))
+        assert th >= 1
+        ur, wr = np.zeros((n, 7)), w0.copy()
+        for _ in range(T):
+            ur = Db + P * ur
+            wr = P * wr
+        assert np.array_equal(u if T % 2 == 0 else tmp, ur)
+        assert np.array_equal(w if T % 2 == 0 else wt, wr)
