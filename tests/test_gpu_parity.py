@@ -470,3 +470,20 @@ def test_reweight_poisson_midsize_vs_oracle(gl, orc):
         Wo = orc.reweight(W, ti, method='poisson', normalization=norm)
         assert (Wr != Wo).nnz == 0
         assert np.array_equal(sparse.csr_matrix(Wr).data, sparse.csr_matrix(Wo).data)
+
+
+def test_plaplace_jacobi_midsize_vs_oracle(gl, orc):
+    """A larger graph (several workgroups, hub-free kNN), odd and even iteration caps and a run to the
+    stop test: bit-identical to the oracle's C restatement of lp_iterate_main."""
+    rng = np.random.default_rng(4)
+    X = rng.random((9000, 2))
+    W = gl.weightmatrix.knn(X, 10)
+    x, y = X[:, 0], X[:, 1]
+    bdy = (x < 0.03) | (x > 0.97) | (y < 0.03) | (y > 0.97)
+    val = np.sin(3 * x) + y ** 2
+    G = gl.graph(W)
+    for p, tol, T in [(6.0, 1e-1, 301), (20.0, 1e-1, 400), (3.0, 0.5, 1e6)]:
+        u = G.plaplace(bdy, val[bdy], p, tol=tol, max_num_it=T, fast=False)
+        uo, it = orc.plaplace_jacobi(W, bdy, val[bdy], p, tol=tol, max_num_it=T, return_iters=True)
+        assert G.plaplace_iters == it
+        assert np.array_equal(u, uo), (p, tol, T)
