@@ -145,21 +145,42 @@ extern "C" int glx_graph_info(const glx_graph* g, int64_t info[8]) {
 // contiguous id range an XCD works on mostly gathers records of that same range (its own L2).
 static void rcm_order(const glx_graph* g, std::vector<int32_t>& perm) {
   const int64_t n = g->n_rows;
-  std::vector<int64_t> ptr(n + 1, 0);
-  for (int64_t i = 0; i < n; ++i)
-    for (int64_t e = g->h_rowptr[i]; e < g->h_rowptr[i + 1]; ++e) {
-      ptr[i + 1]++;
-      ptr[g->h_col[e] + 1]++;
-    }
-  for (int64_t i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
-  std::vector<int32_t> adj(ptr[n]);
-  std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
-  for (int64_t i = 0; i < n; ++i)
-    for (int64_t e = g->h_rowptr[i]; e < g->h_rowptr[i + 1]; ++e) {
-      const int32_t j = g->h_col[e];
-      adj[fill[i]++] = j;
-      adj[fill[j]++] = (int32_t)i;
-    }
+  // The order is a locality heuristic: any permutation is correct.  When every vertex has as many
+  // stored entries in its row as in its column the pattern is (almost certainly) symmetric --
+  // P = D^-1 W^T, Laplacians -- and the rows themselves serve as adjacency lists; otherwise the
+  // pattern is symmetrised first.
+  std::vector<int64_t> indeg(n, 0);
+  for (int64_t e = 0; e < g->h_rowptr[n]; ++e) indeg[g->h_col[e]]++;
+  bool balanced = true;
+  for (int64_t i = 0; i < n && balanced; ++i) balanced = indeg[i] == (int64_t)(g->h_rowptr[i + 1] - g->h_rowptr[i]);
+  std::vector<int64_t> ptr_own;
+  std::vector<int32_t> adj_own;
+  const int32_t* adj;
+  const int64_t* ptr;
+  std::vector<int64_t> ptr64;
+  if (balanced) {
+    ptr64.assign(g->h_rowptr.begin(), g->h_rowptr.end());
+    ptr = ptr64.data();
+    adj = g->h_col.data();
+  } else {
+    ptr_own.assign(n + 1, 0);
+    for (int64_t i = 0; i < n; ++i)
+      for (int64_t e = g->h_rowptr[i]; e < g->h_rowptr[i + 1]; ++e) {
+        ptr_own[i + 1]++;
+        ptr_own[g->h_col[e] + 1]++;
+      }
+    for (int64_t i = 0; i < n; ++i) ptr_own[i + 1] += ptr_own[i];
+    adj_own.resize(ptr_own[n]);
+    std::vector<int64_t> fill(ptr_own.begin(), ptr_own.end() - 1);
+    for (int64_t i = 0; i < n; ++i)
+      for (int64_t e = g->h_rowptr[i]; e < g->h_rowptr[i + 1]; ++e) {
+        const int32_t j = g->h_col[e];
+        adj_own[fill[i]++] = j;
+        adj_own[fill[j]++] = (int32_t)i;
+      }
+    ptr = ptr_own.data();
+    adj = adj_own.data();
+  }
   auto degree = [&](int32_t v) { return ptr[v + 1] - ptr[v]; };
   std::vector<int32_t> by_deg(n);
   std::iota(by_deg.begin(), by_deg.end(), 0);
