@@ -594,3 +594,39 @@ def poisson_fit_distributed(W, train_ind, train_labels, dist, ops_factory, min_i
     for ids, block in parts:
         u[ids] = block
     return u, T
+
+
+def ssl_trials_distributed(model, trainsets, labels, dist, tag='', save_results=True, overwrite=False, num_trials=-1, group=None):
+    """ssl.ssl_trials with the training sets shared out over the ranks of `dist` -- the parallel axis
+    the reference gives to joblib workers (`num_cores`, reference ssl.py:390-396).  Every rank holds
+    its own model on its own GPU and runs a contiguous share of the trials; there is no data-path
+    communication, the result rows are gathered once at the end and rank 0 writes the file in the
+    original order (same format as ssl_trials).  As with the reference's worker processes, a learner
+    with class priors warm-starts its volume weights from the previous trial OF THE SAME RANK.
+    Returns the list of rows on every rank."""
+    import os
+    from . import ssl as ssl_mod
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if num_trials > 0:
+        trainsets = trainsets[:num_trials]
+    bounds = block_bounds(len(trainsets), world)
+    mine = list(model._trial_rows(trainsets[bounds[rank]:bounds[rank + 1]], labels))
+    parts = [None] * world
+    dist.all_gather_object(parts, mine, group=group)
+    rows = [r for part in parts for r in part]
+    if rank == 0:
+        with_priors = model.class_priors is not None
+        header = 'Number of labels,Accuracy,Accuracy with class priors,Class priors error' if with_priors else 'Number of labels,Accuracy'
+        print('\nModel: ' + model.name + '\n\n' + header)
+        for r in rows:
+            print(r)
+        if save_results:
+            os.makedirs(ssl_mod.results_dir, exist_ok=True)
+            outfile = os.path.join(ssl_mod.results_dir, tag + model.get_accuracy_filename())
+            if (not overwrite) and os.path.exists(outfile):
+                print('Aborting: SSL trial (' + model.get_accuracy_filename() + ') already completed , and overwrite is False.')
+            else:
+                with open(outfile, 'w') as f:
+                    f.write(header + '\n' + ''.join(r + '\n' for r in rows))
+                print('Results File: ' + outfile)
+    return rows

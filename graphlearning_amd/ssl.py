@@ -131,6 +131,15 @@ class ssl:
                 f.write(header + '\n')
             print('Results File: ' + outfile)
         print('\n' + header)
+        for row in self._trial_rows(trainsets, labels):
+            print(row)
+            if save_results:
+                with open(outfile, 'a+') as f:
+                    f.write(row + '\n')
+
+    def _trial_rows(self, trainsets, labels):
+        """The result row (reference ssl.py:339-343, 381-388) of every training set, in order."""
+        with_priors = self.class_priors is not None
         labels = np.asarray(labels)
         trainsets = [np.asarray(t) for t in trainsets]
         batch = 1 if self.onevsrest else max(1, int(self._trial_batch_size(labels)))
@@ -151,13 +160,9 @@ class ssl:
                 accuracy = ssl_accuracy(pred, labels, train_ind)
                 if with_priors:
                     plain = ssl_accuracy(self.predict(ignore_class_priors=True), labels, train_ind)
-                    row = '%d,%.2f,%.2f,%.5f' % (len(train_ind), plain, accuracy, self.class_priors_error)
+                    yield '%d,%.2f,%.2f,%.5f' % (len(train_ind), plain, accuracy, self.class_priors_error)
                 else:
-                    row = '%d' % len(train_ind) + ',%.2f' % accuracy
-                print(row)
-                if save_results:
-                    with open(outfile, 'a+') as f:
-                        f.write(row + '\n')
+                    yield '%d' % len(train_ind) + ',%.2f' % accuracy
 
     def _trial_batch_size(self, labels):
         """How many trials ssl_trials hands to _fit_batch at once (1 = one by one)."""

@@ -122,3 +122,19 @@ def test_cut_bounds_follow_the_pieces():
     R = (R + R.T).tocsr()
     o = gdist.locality_order(R)
     assert np.array_equal(gdist.cut_bounds(R, o, 4), gdist.block_bounds(6000, 4))
+
+
+def test_ssl_trials_shared_over_ranks(tmp_path):
+    """dist.ssl_trials_distributed (the reference's joblib axis, ssl.py:390-396): 12 training sets over
+    3 ranks, rows gathered in the original order, file written once in ssl_trials' format."""
+    out = str(tmp_path / 'trials')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=3', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'trials_worker.py'), out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = [json.load(open(out + '.%d' % k)) for k in range(3)]
+    assert len(res[0]['rows']) == 12
+    for k in range(3):
+        assert res[k]['rows'] == res[0]['seq']            # same rows, same order as the one-process loop
+    text = open(os.path.join(out + '_results', 'd__stub_accuracy.csv')).read().splitlines()
+    assert text[0] == 'Number of labels,Accuracy' and text[1:] == res[0]['seq']
