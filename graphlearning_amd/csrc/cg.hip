@@ -254,8 +254,10 @@ __global__ __launch_bounds__(256) void cg_group_err_kernel(CgScalars sc, int it,
 // flight to cover the memory latency; no LDS, no barriers.
 #define GLX_DPP_L(K) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
 // (one asm block: the compiler pads separate asm statements with s_nop, each an issue slot of the chain)
+// (s_nop 1: a VALU write of the DPP source right in front of the block -- a compiler-made copy of
+// `x` -- needs two wait states before a DPP read; the assembler block is opaque to the hazard recogniser)
 #define GLX_DPP_ADD16()                                                                                                        \
-  asm volatile(GLX_DPP_L(0) GLX_DPP_L(1) GLX_DPP_L(2) GLX_DPP_L(3) GLX_DPP_L(4) GLX_DPP_L(5) GLX_DPP_L(6) GLX_DPP_L(7) GLX_DPP_L(8) \
+  asm volatile("s_nop 1\n\t" GLX_DPP_L(0) GLX_DPP_L(1) GLX_DPP_L(2) GLX_DPP_L(3) GLX_DPP_L(4) GLX_DPP_L(5) GLX_DPP_L(6) GLX_DPP_L(7) GLX_DPP_L(8) \
                    GLX_DPP_L(9) GLX_DPP_L(10) GLX_DPP_L(11) GLX_DPP_L(12) GLX_DPP_L(13) GLX_DPP_L(14) GLX_DPP_L(15)              \
                : "+v"(tot)                                                                                                     \
                : "v"(x), "v"(one))
@@ -556,6 +558,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   const int64_t nb_upd = std::max<int64_t>((n + UPD_ROWS_PER_BLOCK - 1) / UPD_ROWS_PER_BLOCK, 1);
   const int64_t hist_cap = max_iter + 2;
   GLX_CHECK(max_iter < (1ll << 24), GLX_EUNSUPPORTED, "glx_cg_multi: max_iter %lld exceeds the supported 2^24-1", (long long)max_iter);
+  GLX_CHECK(n < (1ll << 27) || !exact, GLX_EUNSUPPORTED, "glx_cg_multi: %lld rows exceed the reference-order reducer's 32-bit offsets", (long long)n);
 
   // reference-order reducer: one wavefront per 4 columns; the product array is blocked the same way
   const int prod_sc = 4;
