@@ -396,6 +396,28 @@ class poisson_mbo(ssl):
         return heat.fetch().astype(np.float64)              # onehot of the last labels (reference ssl.py:832)
 
 
+def _neg_columns_times(L, Lcsc, cols, F):
+    """`-L[:, cols] * F` (reference ssl.py:1236) without scipy's column fancy-indexing of a CSR
+    matrix (7 ms at 60 000 vertices, per training set).  scipy forms the CSR matrix -L[:, cols] --
+    row i keeps its selected entries in stored order -- and csr_matvecs adds a row's products one
+    after another starting from 0.  With canonical (column-sorted) rows and distinct `cols` that is:
+    for every row, the terms (-l_ij) * F[pos(j), :] in ascending j.  The same sums are formed here
+    column by column from the CSC image, visiting the selected columns in ascending j (a row occurs
+    at most once per column, so each `+=` is one sequential step of that row's sum).  Falls back to
+    the literal expression whenever the preconditions do not hold."""
+    cols = np.asarray(cols)
+    if not (L.has_sorted_indices and L.has_canonical_format and len(np.unique(cols)) == len(cols)):
+        return -L[:, cols] * F
+    out = np.zeros((L.shape[0], F.shape[1]))
+    indptr, indices, data = Lcsc.indptr, Lcsc.indices, Lcsc.data
+    for pos in np.argsort(cols, kind='stable'):
+        j = cols[pos]
+        lo, hi = indptr[j], indptr[j + 1]
+        rows = indices[lo:hi]
+        out[rows, :] += (-data[lo:hi])[:, None] * F[pos, :][None, :]
+    return out
+
+
 class laplace(ssl):
     def __init__(self, W=None, class_priors=None, X=None, reweighting='none', normalization='combinatorial', tau=0,
                  order=1, mean_shift=False, tol=1e-5, alpha=2, zeta=1e7, r=0.1):
@@ -463,12 +485,17 @@ class laplace(ssl):
         self._cache = (key, L, Mv, dev)
         return L, Mv, dev
 
+    def _full_csc(self, L):
+        if getattr(self, '_csc', None) is None or self._csc[0] is not L:
+            self._csc = (L, L.tocsc())
+        return self._csc[1]
+
     def _rhs(self, L, Mv, train_ind, train_labels):
         """F, and M b embedded in an (n, k) array that is zero on the labelled rows (reference ssl.py:1229-1237, 1249)."""
         n = L.shape[0]
         k = len(np.unique(train_labels))
         F = utils.labels_to_onehot(train_labels, k)
-        b = -L[:, train_ind] * F                             # reference ssl.py:1236
+        b = _neg_columns_times(L, self._full_csc(L), train_ind, F)   # b = -L[:,train_ind]*F, reference ssl.py:1236
         B = Mv[:, None] * b                                  # row i of M*b is m_i * b_i
         B[train_ind, :] = 0
         return F, np.ascontiguousarray(B, dtype=self.dtype), k

@@ -137,3 +137,26 @@ def test_cabi_exports_every_declared_symbol():
     # and the Python binding covers exactly the declared surface
     assert declared == set(_hip.EXPORTED_SYMBOLS), declared ^ set(_hip.EXPORTED_SYMBOLS)
     assert lib.glx_version() >= 100
+
+
+def test_laplace_rhs_fast_path_equals_scipy_expression():
+    """ssl._neg_columns_times == `-L[:, cols] * F` bit for bit (several labelled neighbours of one
+    class in a row, unsorted `cols`, explicit zeros), and falls back on non-canonical input."""
+    from graphlearning_amd import ssl as glssl
+    rng = np.random.default_rng(0)
+    for n, dens, m, k in [(300, 0.08, 60, 3), (1000, 0.02, 200, 10), (50, 0.5, 30, 2)]:
+        A = sparse.random(n, n, density=dens, random_state=int(rng.integers(1 << 30)), format='csr')
+        L = sparse.csr_matrix(sparse.diags(np.asarray(A.sum(axis=1)).ravel()) - A - A.T)
+        L.sum_duplicates()
+        L.sort_indices()
+        cols = rng.permutation(n)[:m]
+        F = np.eye(k)[rng.integers(0, k, m)]
+        ref = -L[:, cols] * F
+        got = glssl._neg_columns_times(L, L.tocsc(), cols, F)
+        assert np.array_equal(got, ref)
+    # unsorted rows: the literal expression is used
+    L2 = L.copy()
+    L2.indices[L2.indptr[0]:L2.indptr[1]] = L2.indices[L2.indptr[0]:L2.indptr[1]][::-1]
+    L2.data[L2.indptr[0]:L2.indptr[1]] = L2.data[L2.indptr[0]:L2.indptr[1]][::-1]
+    L2.has_sorted_indices = False
+    assert np.array_equal(glssl._neg_columns_times(L2, L2.tocsc(), cols, F), -L2[:, cols] * F)
