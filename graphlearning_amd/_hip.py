@@ -10,6 +10,7 @@ import ctypes as C
 import numpy as np
 
 GLX_F32, GLX_F64 = 0, 1
+GLX_CG_NP1D, GLX_CG_TREE, GLX_CG_X0 = 1, 2, 4     # flags of glx_cg_solve / glx_cg_groups (include/glx.h)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libglx.so')
 _lib = None
@@ -60,6 +61,7 @@ _SIGNATURES = {
     'glx_graph_destroy': [_vp],
     'glx_graph_keep_order': [_vp],
     'glx_graph_info': [_vp, _i64p],
+    'glx_graph_order': [_vp, _vp],
     'glx_spmm_bias': [_vp, _vp, _vp, _vp, C.c_int, C.c_int],
     'glx_poisson_sweep': [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_int)],
     'glx_sweep_create': [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)],
@@ -85,6 +87,7 @@ _SIGNATURES = {
     'glx_cg_groups': [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_cg_groups_masked': [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_argmax_project': [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
+    'glx_argmax_project_t': [_vp, C.c_int, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
     'glx_knn_bruteforce': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
     'glx_knn_bruteforce_range': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
     'glx_knn_stats': [_f64p],
@@ -180,6 +183,12 @@ class DeviceGraph:
         keys = ['n_rows', 'n_cols', 'nnz', 'stored', 'slices', 'rows_per_slice', 'max_row', 'renumbered']
         return dict(zip(keys, list(out)[:8]))
 
+    def order(self):
+        """perm[new] = caller's row: the vertex order the library keeps its records in."""
+        perm = np.empty(self.shape[0], dtype=np.int32)
+        check(load().glx_graph_order(self._h, _ptr(perm)), 'glx_graph_order')
+        return perm
+
     def spmm_bias(self, u, Db=None, iters=1):
         """`iters` applications of u <- Db + A u (host arrays in, host array out)."""
         u = np.ascontiguousarray(u, dtype=self.dtype)
@@ -205,16 +214,22 @@ class DeviceGraph:
                                        _ptr(out), C.byref(T)), 'glx_poisson_sweep')
         return out, T.value
 
-    def cg(self, B, tol=1e-10, max_iter=100000):
-        """utils.conjgrad on device: returns (X, iterations, err)."""
+    def cg(self, B, tol=1e-10, max_iter=100000, x0=None, reduce='exact'):
+        """utils.conjgrad on device: returns (X, iterations, err).  x0: initial iterate (B must then
+        be the residual b - A@x0, utils.py:510-514).  reduce='tree': tolerance mode (GLX_CG_TREE)."""
         B = np.ascontiguousarray(B, dtype=self.dtype)
         squeeze = B.ndim == 1
         if squeeze:
             B = B[:, None]
-        X = np.empty_like(B)
+        flags = (GLX_CG_NP1D if squeeze else 0) | _reduce_flag(reduce)
+        if x0 is None:
+            X = np.empty_like(B)
+        else:
+            X = np.array(np.asarray(x0).reshape(B.shape), dtype=self.dtype, order='C', copy=True)
+            flags |= GLX_CG_X0
         it = C.c_int(0)
         err = C.c_double(0)
-        check(load().glx_cg_solve(self._h, _ptr(B), _ptr(X), B.shape[1], float(tol), int(max_iter), 1 if squeeze else 0,
+        check(load().glx_cg_solve(self._h, _ptr(B), _ptr(X), B.shape[1], float(tol), int(max_iter), flags,
                                   C.byref(it), C.byref(err)), 'glx_cg_solve')
         return (X[:, 0] if squeeze else X), it.value, err.value
 
@@ -234,18 +249,21 @@ class DeviceGraph:
                                         int(max_iter), C.byref(it), C.byref(err)), 'glx_affine_iterate')
         return (out[:, 0] if squeeze else out), it.value, err.value
 
-    def cg_groups(self, B, group_cols, tol=1e-10, max_iter=100000, masks=None):
+    def cg_groups(self, B, group_cols, tol=1e-10, max_iter=100000, masks=None, reduce='exact'):
         """Independent systems side by side (columns in groups of `group_cols`), each with its own
         stop test: returns (X, iterations per group, err per group).  masks: per group an array of
         Dirichlet rows (x held at zero there; B is zeroed on them) -- the sub-matrix solve of
         ssl.laplace on the full operator."""
-        B = np.array(B, dtype=self.dtype, order='C', copy=masks is not None)
+        B = np.ascontiguousarray(B, dtype=self.dtype)
+        if masks is not None:
+            B = B.copy()                      # zeroed on the Dirichlet rows below; the caller's array stays as it is
+        flags = _reduce_flag(reduce)
         ng = B.shape[1] // group_cols
         X = np.empty_like(B)
         its = np.zeros(ng, dtype=np.int32)
         errs = np.zeros(ng, dtype=np.float64)
         if masks is None:
-            check(load().glx_cg_groups(self._h, _ptr(B), _ptr(X), B.shape[1], int(group_cols), float(tol), int(max_iter), 0,
+            check(load().glx_cg_groups(self._h, _ptr(B), _ptr(X), B.shape[1], int(group_cols), float(tol), int(max_iter), flags,
                                        its.ctypes.data_as(C.POINTER(C.c_int)), errs.ctypes.data_as(_f64p)), 'glx_cg_groups')
             return X, its, errs
         if len(masks) != ng:
@@ -257,7 +275,7 @@ class DeviceGraph:
         for g, r in enumerate(rows):
             B[r, g * group_cols:(g + 1) * group_cols] = 0
         check(load().glx_cg_groups_masked(self._h, _ptr(B), _ptr(X), B.shape[1], int(group_cols), _ptr(allrows), _ptr(ptr),
-                                          float(tol), int(max_iter), 0, its.ctypes.data_as(C.POINTER(C.c_int)),
+                                          float(tol), int(max_iter), flags, its.ctypes.data_as(C.POINTER(C.c_int)),
                                           errs.ctypes.data_as(_f64p)), 'glx_cg_groups_masked')
         return X, its, errs
 
@@ -273,6 +291,14 @@ class DeviceGraph:
             self.close()
         except Exception:
             pass
+
+
+def _reduce_flag(reduce):
+    if reduce == 'exact':
+        return 0
+    if reduce == 'tree':
+        return GLX_CG_TREE
+    raise GlxError("reduce must be 'exact' (reference-order reductions) or 'tree' (tolerance mode), got %r" % (reduce,))
 
 
 class Sweep:
@@ -355,15 +381,17 @@ def record_layout(Cc, dtype=np.float64, has_w=True):
 def argmax_project(prob, priors=None, weights=None, max_steps=0, similarity=True, device=None):
     """ssl.predict / ssl.volume_label_projection on device.
     Returns (labels int64, weights, err, steps)."""
-    prob = np.ascontiguousarray(prob, dtype=np.float64)
+    prob = np.asarray(prob)
+    # a float32 prob (use_cuda=True) is normalised in float32 like numpy would (ssl.py:256-257)
+    prob = np.ascontiguousarray(prob, dtype=np.float32 if prob.dtype == np.float32 else np.float64)
     n, Cc = prob.shape
     w = np.ones(Cc) if weights is None else np.array(weights, dtype=np.float64).reshape(Cc).copy()
     pri = np.zeros(Cc) if priors is None else _dense(priors, np.float64, (Cc,), 'priors')
     labels = np.empty(n, dtype=np.int64)
     err = C.c_double(0)
     steps = C.c_int(0)
-    check(load().glx_argmax_project(_ptr(prob), n, Cc, _ptr(pri), _ptr(w), _ptr(labels), C.byref(err), C.byref(steps),
-                                    int(max_steps), 1 if similarity else 0, _dev(device)), 'glx_argmax_project')
+    check(load().glx_argmax_project_t(_ptr(prob), _dt(prob.dtype), n, Cc, _ptr(pri), _ptr(w), _ptr(labels), C.byref(err),
+                                      C.byref(steps), int(max_steps), 1 if similarity else 0, _dev(device)), 'glx_argmax_project')
     return labels, w, err.value, steps.value
 
 

@@ -537,7 +537,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
                   double* err_out, int flags, const int32_t* mask_rows, const int32_t* mask_ptr) {
   // GLX_CG_REDUCE=tree selects block-tree reductions (faster, deterministic, not bit-identical to numpy)
   const char* red_env = getenv("GLX_CG_REDUCE");
-  const bool exact = !(red_env && strcmp(red_env, "tree") == 0);
+  const bool exact = !((red_env && strcmp(red_env, "tree") == 0) || (flags & GLX_CG_TREE));
   const bool np1d = exact && (flags & 1) && C == 1;   // caller passed a 1-D right-hand side: numpy's pairwise reductions
   const int ngroups = C / Cg;
   const int stride = ngroups + 1;
@@ -627,7 +627,13 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
 
   hipLaunchKernelGGL(cg_set_err0, dim3((unsigned)((hist_cap * stride + 255) / 256)), blk, 0, st, b.err_hist, hist_cap * stride, stride);
   GLX_HIP(hipGetLastError());
-  GLX_HIP(hipMemsetAsync(b.x, 0, recb, st));
+  if (flags & GLX_CG_X0) {   // X holds x0 on entry; B is the caller's r0 = b - A@x0 (utils.py:510-514)
+    GLX_HIP(hipMemcpyAsync(b.dense, X, (size_t)n * C * es, hipMemcpyHostToDevice, st));
+    rc = glx_pack_records(b.dense, b.x, n, L, dtype, nullptr, st, A->d_perm);
+    if (rc) return rc;
+  } else {
+    GLX_HIP(hipMemsetAsync(b.x, 0, recb, st));
+  }
   GLX_HIP(hipMemsetAsync(b.ap, 0, recb, st));
   GLX_HIP(hipMemsetAsync(b.part_dot, 0, nb_spmm * ncols * 8, st));
   GLX_HIP(hipMemsetAsync(b.scal, 0, 3 * ncols * 8, st));

@@ -229,6 +229,14 @@ int glx_graph_ensure_order(glx_graph* g) {
   return GLX_OK;
 }
 
+extern "C" int glx_graph_order(glx_graph* g, int32_t* perm_out) {
+  GLX_CHECK(g && perm_out, GLX_EINVAL, "glx_graph_order: null argument");
+  int rc = glx_graph_ensure_order(g);
+  if (rc) return rc;
+  for (int64_t i = 0; i < g->n_rows; ++i) perm_out[i] = g->h_perm.empty() ? (int32_t)i : g->h_perm[i];
+  return GLX_OK;
+}
+
 // Build (once per G) the sliced-ELL image of the operator.  The (renumbered) rows are cut
 // into 8 contiguous id ranges, one per XCD; inside a range rows are handed to wavefront slices
 // in order of decreasing length (longest first: LPT balance, little padding inside a slice);

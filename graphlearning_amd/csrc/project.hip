@@ -52,13 +52,26 @@ __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ 
 }
 
 // scores = (prob - min) / max(prob - min)                                   (ssl.py:256-257)
+// F32: prob came from a float32 state (the reference's use_cuda branch keeps self.prob float32, so the
+// subtraction and the division round in float32, ssl.py:256-257; only the product with the fp64 class
+// weights is wider) -- the values in `a` are exact float32 numbers and stay so.
+template <bool F32>
 __global__ __launch_bounds__(256) void scores_kernel(double* __restrict__ a, int64_t total, const double* __restrict__ mm) {
 #pragma clang fp contract(off)
-  const double mn = mm[0];
-  const double den = mm[1] - mn;   // max(prob - min) == fl(max - min): rounding is monotone
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const double s = a[i] - mn;
-    a[i] = s / den;
+  if constexpr (F32) {
+    const float mn = (float)mm[0];
+    const float den = (float)mm[1] - mn;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const float s = (float)a[i] - mn;
+      a[i] = (double)(s / den);
+    }
+  } else {
+    const double mn = mm[0];
+    const double den = mm[1] - mn;   // max(prob - min) == fl(max - min): rounding is monotone
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const double s = a[i] - mn;
+      a[i] = s / den;
+    }
   }
 }
 
@@ -136,6 +149,8 @@ struct ProjBufs {
   double *scores = nullptr, *bmin = nullptr, *bmax = nullptr, *mm = nullptr, *w = nullptr, *priors = nullptr, *err = nullptr;
   long long *counts = nullptr, *labels = nullptr;
   int *steps = nullptr, *done = nullptr;
+  float* stage32 = nullptr;       // float32 input of the one-shot entry point, before widening
+  size_t stage_cap = 0;
   hipStream_t stream = nullptr;   // owned only by the one-shot entry point
   int64_t cap_n = 0;
   int cap_C = 0;
@@ -150,6 +165,7 @@ struct ProjBufs {
   }
   ~ProjBufs() {
     release();
+    hipFree(stage32);
     if (stream) hipStreamDestroy(stream);
   }
 };
@@ -180,7 +196,7 @@ static int proj_alloc(ProjBufs& b, int64_t n, int C) {
 // the decision itself: b.scores holds prob (n, C) fp64 on the device (overwritten by the scores);
 // on return b.labels holds the labels and weights_inout the updated class weights
 static int proj_core(ProjBufs& b, hipStream_t st, int64_t n, int C, const double* priors, double* weights_inout, double* err_out,
-                     int* steps_out, int max_steps, int similarity) {
+                     int* steps_out, int max_steps, int similarity, bool f32 = false) {
   const int64_t total = n * C;
   const int nb = proj_blocks(total);
   const int nbr = (int)std::min<int64_t>((n + 255) / 256, 2048);
@@ -194,7 +210,10 @@ static int proj_core(ProjBufs& b, hipStream_t st, int64_t n, int C, const double
   GLX_HIP(hipGetLastError());
   hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, st, (const double*)b.bmin, (const double*)b.bmax, nb, b.mm);
   GLX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(scores_kernel, dim3(nb), dim3(256), 0, st, b.scores, total, (const double*)b.mm);
+  if (f32)
+    hipLaunchKernelGGL(scores_kernel<true>, dim3(nb), dim3(256), 0, st, b.scores, total, (const double*)b.mm);
+  else
+    hipLaunchKernelGGL(scores_kernel<false>, dim3(nb), dim3(256), 0, st, b.scores, total, (const double*)b.mm);
   GLX_HIP(hipGetLastError());
   ProjState ps;
   ps.w = b.w;
@@ -232,9 +251,27 @@ static int proj_core(ProjBufs& b, hipStream_t st, int64_t n, int C, const double
   return GLX_OK;
 }
 
+static int argmax_project_any(const void* prob, int prob_dtype, int64_t n, int C, const double* priors, double* weights_inout,
+                              int64_t* labels_out, double* err_out, int* steps_out, int max_steps, int similarity, int device);
+
 extern "C" int glx_argmax_project(const double* prob, int64_t n, int C, const double* priors, double* weights_inout,
                                   int64_t* labels_out, double* err_out, int* steps_out, int max_steps, int similarity,
                                   int device) {
+  return argmax_project_any(prob, GLX_F64, n, C, priors, weights_inout, labels_out, err_out, steps_out, max_steps, similarity, device);
+}
+
+extern "C" int glx_argmax_project_t(const void* prob, int prob_dtype, int64_t n, int C, const double* priors, double* weights_inout,
+                                    int64_t* labels_out, double* err_out, int* steps_out, int max_steps, int similarity,
+                                    int device) {
+  GLX_CHECK(prob_dtype == GLX_F32 || prob_dtype == GLX_F64, GLX_EINVAL, "glx_argmax_project_t: bad dtype %d", prob_dtype);
+  return argmax_project_any(prob, prob_dtype, n, C, priors, weights_inout, labels_out, err_out, steps_out, max_steps, similarity, device);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void to_f64_kernel(const T* __restrict__ src, double* __restrict__ dst, int64_t total);
+
+static int argmax_project_any(const void* prob, int prob_dtype, int64_t n, int C, const double* priors, double* weights_inout,
+                              int64_t* labels_out, double* err_out, int* steps_out, int max_steps, int similarity, int device) {
   GLX_CHECK(prob && weights_inout && labels_out, GLX_EINVAL, "glx_argmax_project: null argument");
   GLX_CHECK(n >= 1 && C >= 1, GLX_EINVAL, "glx_argmax_project: empty input (n=%lld, C=%d)", (long long)n, C);
   GLX_CHECK(max_steps == 0 || priors, GLX_EINVAL, "glx_argmax_project: projection needs priors");
@@ -255,8 +292,22 @@ extern "C" int glx_argmax_project(const double* prob, int64_t n, int C, const do
   hipStream_t st = b.stream;
   int rc = proj_alloc(b, n, C);
   if (rc) return rc;
-  GLX_HIP(hipMemcpyAsync(b.scores, prob, (size_t)n * C * 8, hipMemcpyHostToDevice, st));
-  rc = proj_core(b, st, n, C, priors, weights_inout, err_out, steps_out, max_steps, similarity);
+  if (prob_dtype == GLX_F32) {
+    if (b.stage_cap < (size_t)n * C) {
+      hipFree(b.stage32);
+      b.stage32 = nullptr;
+      b.stage_cap = 0;
+      GLX_HIP(hipMalloc(&b.stage32, (size_t)n * C * 4));
+      b.stage_cap = (size_t)n * C;
+    }
+    GLX_HIP(hipMemcpyAsync(b.stage32, prob, (size_t)n * C * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(to_f64_kernel<float>, dim3((unsigned)(((size_t)n * C + 255) / 256)), dim3(256), 0, st, (const float*)b.stage32, b.scores,
+                       (int64_t)n * C);
+    GLX_HIP(hipGetLastError());
+  } else {
+    GLX_HIP(hipMemcpyAsync(b.scores, prob, (size_t)n * C * 8, hipMemcpyHostToDevice, st));
+  }
+  rc = proj_core(b, st, n, C, priors, weights_inout, err_out, steps_out, max_steps, similarity, prob_dtype == GLX_F32);
   if (rc) return rc;
   GLX_HIP(hipMemcpyAsync(labels_out, b.labels, n * 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
@@ -297,7 +348,7 @@ int glx_project_device(glx_projector** pp, const void* dense_dev, int dtype, int
   else
     hipLaunchKernelGGL(to_f64_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)dense_dev, b.scores, total);
   GLX_HIP(hipGetLastError());
-  rc = proj_core(b, st, n, C, priors, weights_inout, err_out, steps_out, max_steps, similarity);
+  rc = proj_core(b, st, n, C, priors, weights_inout, err_out, steps_out, max_steps, similarity, dtype == GLX_F32);
   if (rc) return rc;
   if (d_labels_out) *d_labels_out = b.labels;
   return GLX_OK;

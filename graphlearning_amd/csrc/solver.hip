@@ -176,6 +176,7 @@ extern "C" int glx_sweep_set_problem(glx_sweep* s, const void* Db, const double*
   for (int64_t i = 0; i < s->n_rows; ++i) {
     const double e = fabs(deg[i] * w0[i] - vinf[i]);
     if (e > e0 || e != e) e0 = e;
+    if (e != e) break;   // np.max keeps the NaN
   }
   s->err0 = e0;
   s->thresh = 1.0 / (double)s->n_rows;   // `> 1/n`, ssl.py:667
@@ -234,6 +235,7 @@ extern "C" int glx_sweep_run(glx_sweep* s, int* T_out, float* device_ms_out) {
   GLX_HIP(hipSetDevice(s->P->device));
   const int head = std::min(s->min_iter, s->max_iter);
   int rc;
+  const int64_t launches0 = s->launches;
   GLX_HIP(hipEventRecord(s->ev0, s->stream));
   if (s->use_graph) {
     if (!s->head_exec) {
@@ -273,7 +275,7 @@ extern "C" int glx_sweep_run(glx_sweep* s, int* T_out, float* device_ms_out) {
       for (int k = 0; k < ERR_SHARDS; ++k) m = std::max(m, s->h_err[(size_t)t * ERR_SHARDS + k]);
       union { double d; unsigned long long u; } cv;
       cv.u = m;
-      if (cv.d <= s->thresh) { stopped = true; T = t; break; }
+      if (!(cv.d > s->thresh)) { stopped = true; T = t; break; }   // NaN stops the loop, like `nan > 1/n` (ssl.py:667)
     }
     const int end = std::min(s->max_iter, t + TAIL_CHUNK);
     const int t0 = t;
@@ -292,7 +294,7 @@ extern "C" int glx_sweep_run(glx_sweep* s, int* T_out, float* device_ms_out) {
       for (int k = 0; k < ERR_SHARDS; ++k) m = std::max(m, s->h_err[(size_t)q * ERR_SHARDS + k]);
       union { double d; unsigned long long u; } cv;
       cv.u = m;
-      if (cv.d <= s->thresh) { T = q; stopped = true; break; }
+      if (!(cv.d > s->thresh)) { T = q; stopped = true; break; }
     }
     if (stopped) s->cur = cur0 ^ ((T - t0) & 1);
     t = stopped ? T : end;
@@ -302,6 +304,8 @@ extern "C" int glx_sweep_run(glx_sweep* s, int* T_out, float* device_ms_out) {
   GLX_HIP(hipStreamSynchronize(s->stream));
   if (device_ms_out) GLX_HIP(hipEventElapsedTime(device_ms_out, s->ev0, s->ev1));
   if (T_out) *T_out = T;
+  // count the sweeps that really ran: kernels of a tail chunk launched past the stop test exit at once
+  s->launches = launches0 + T;
   return GLX_OK;
 }
 

@@ -183,8 +183,10 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
 
   if constexpr (HAS_W) {
     if (p.err_prev) {   // stop test of ssl.py:667, decided identically by every wavefront
+      // (`while ... np.max(np.absolute(v-vinf)) > 1/n`: a NaN maximum compares False and ends the loop too;
+      //  NaN errors are recorded as a bit pattern above +inf, so they dominate the max like numpy's)
       const unsigned long long m = wave_max_u64(p.err_prev[lane]);
-      if (m <= p.thresh_bits) return;
+      if (m <= p.thresh_bits || m > 0x7ff0000000000000ull) return;
     }
   }
   if constexpr (HAS_DOT) {
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
         double wnew;
         if constexpr (sizeof(T) == 4) wnew = accw; else wnew = (double)outv[0];
         e = fabs(p.deg[row] * wnew - p.vinf[row]);
-        if (e != e) e = __longlong_as_double(0x7ff0000000000000ll);   // NaN never satisfies the stop test
+        if (e != e) e = __longlong_as_double(0x7ff8000000000000ll);   // canonical NaN: orders above +inf as a bit pattern (np.max propagates NaN)
       }
       unsigned long long m = wave_max_u64((unsigned long long)__double_as_longlong(e));
       __shared__ unsigned long long s_err[GLX_WPB];

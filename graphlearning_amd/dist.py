@@ -603,12 +603,20 @@ def ssl_trials_distributed(model, trainsets, labels, dist, tag='', save_results=
     communication, the result rows are gathered once at the end and rank 0 writes the file in the
     original order (same format as ssl_trials).  As with the reference's worker processes, a learner
     with class priors warm-starts its volume weights from the previous trial OF THE SAME RANK.
-    Returns the list of rows on every rank."""
+    Returns the list of rows on every rank (None when the run is refused because the results file exists)."""
     import os
     from . import ssl as ssl_mod
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if num_trials > 0:
         trainsets = trainsets[:num_trials]
+    # the reference aborts BEFORE any work when the results file exists (ssl.py:330-337): rank 0 decides, everyone follows
+    outfile = os.path.join(ssl_mod.results_dir, tag + model.get_accuracy_filename())
+    go = [bool(not save_results or overwrite or not os.path.exists(outfile))] if rank == 0 else [None]
+    dist.broadcast_object_list(go, src=0, group=group)
+    if not go[0]:
+        if rank == 0:
+            print('Aborting: SSL trial (' + model.get_accuracy_filename() + ') already completed , and overwrite is False.')
+        return None
     bounds = block_bounds(len(trainsets), world)
     mine = list(model._trial_rows(trainsets[bounds[rank]:bounds[rank + 1]], labels))
     parts = [None] * world
@@ -622,11 +630,7 @@ def ssl_trials_distributed(model, trainsets, labels, dist, tag='', save_results=
             print(r)
         if save_results:
             os.makedirs(ssl_mod.results_dir, exist_ok=True)
-            outfile = os.path.join(ssl_mod.results_dir, tag + model.get_accuracy_filename())
-            if (not overwrite) and os.path.exists(outfile):
-                print('Aborting: SSL trial (' + model.get_accuracy_filename() + ') already completed , and overwrite is False.')
-            else:
-                with open(outfile, 'w') as f:
-                    f.write(header + '\n' + ''.join(r + '\n' for r in rows))
-                print('Results File: ' + outfile)
+            with open(outfile, 'w') as f:
+                f.write(header + '\n' + ''.join(r + '\n' for r in rows))
+            print('Results File: ' + outfile)
     return rows

@@ -296,10 +296,20 @@ class poisson(ssl):
                 T, _ = aux['sweep'].run()
                 u = aux['sweep'].fetch()
             self.num_iter = T
-            if all_labels is not None:
-                self.prob = u
-                acc = ssl_accuracy(self.predict(), all_labels, train_ind)
-                print('%d,Accuracy = %.2f' % (T, acc))
+            if all_labels is not None and not self.use_cuda:
+                # verbose contract of the reference's CPU loop (ssl.py:672-677): one '%d,Accuracy = %.2f' line per
+                # sweep.  T is known from the run above; the sweeps are repeated one launch at a time on a sweep
+                # without a stop column (the same kernel, the same iterates) and every iterate is read back.
+                step = _hip.Sweep(dev, k, min_iter=0, max_iter=0, use_hipgraph=False)
+                try:
+                    step.set_state(None, Db)
+                    for t in range(1, T + 1):
+                        step.iterate(1)
+                        self.prob = step.fetch()
+                        acc = ssl_accuracy(self.predict(), all_labels, train_ind)
+                        print('%d,Accuracy = %.2f' % (t, acc))
+                finally:
+                    step.close()
         elif self.solver == 'spectral':
             raise NotImplementedError("poisson(solver='spectral') needs an eigensolver, which is outside the "
                                       'GPU hot path this package covers (SURVEY.md section 8)')
@@ -420,11 +430,17 @@ def _neg_columns_times(L, Lcsc, cols, F):
 
 class laplace(ssl):
     def __init__(self, W=None, class_priors=None, X=None, reweighting='none', normalization='combinatorial', tau=0,
-                 order=1, mean_shift=False, tol=1e-5, alpha=2, zeta=1e7, r=0.1):
+                 order=1, mean_shift=False, tol=1e-5, alpha=2, zeta=1e7, r=0.1, reduce='exact'):
         """Laplace learning, reference ssl.py:1106-1261: Dirichlet sub-system solved by a
         Jacobi-scaled multi-RHS conjugate gradient on the GPU.  Reweightings 'poisson' and 'wnll'
-        (graph.reweight, reference graph.py:368-466) are supported; 'properly' is not."""
+        (graph.reweight, reference graph.py:368-466) are supported; 'properly' is not.
+
+        reduce (not in the reference): 'exact' (default) keeps numpy's reduction order, so iterates and
+        iteration counts are bit-identical to the reference; 'tree' is the tolerance mode for this SPD
+        system -- block-tree reductions, about 3x faster per fit, same labels, iterates within 1e-5
+        (the solve converges to tol=1e-5 either way; include/glx.h GLX_CG_TREE)."""
         super().__init__(W, class_priors)
+        self.reduce = reduce
         self.reweighting = reweighting
         self.normalization = normalization
         self.mean_shift = mean_shift
@@ -512,11 +528,11 @@ class laplace(ssl):
             L, Mv, dev = self._full_system()
             train_ind = np.asarray(train_ind)
             F, B, k = self._rhs(L, Mv, train_ind, train_labels)
-            x, its, _ = dev.cg_groups(B, k, tol=self.tol, masks=[train_ind])
+            x, its, _ = dev.cg_groups(B, k, tol=self.tol, masks=[train_ind], reduce=self.reduce)
             self.num_iter = int(its[0])
             return self._assemble(x, Mv, train_ind, F)
         # reweighted graphs depend on the training set: per-fit sub-matrix, reference ssl.py:1211-1250 line by line
-        W = self.graph.reweight(train_ind, method=self.reweighting, normalization=self.normalization, X=self.X)
+        W = self.graph.reweight(train_ind, method=self.reweighting, normalization=self.normalization, X=self.X, reduce=self.reduce)
         G = graph_mod.graph(W)
         n = G.num_nodes
         k = len(np.unique(train_labels))
@@ -533,7 +549,7 @@ class laplace(ssl):
         M = sparse.spdiags(1 / np.sqrt(M + 1e-10), 0, m, m).tocsr()   # reference ssl.py:1244-1246
         dev = _hip.DeviceGraph(M * A * M, dtype=self.dtype, device=self.device, keep_order=True)
         try:
-            v, it, _ = dev.cg(np.ascontiguousarray(M * b, dtype=self.dtype), tol=self.tol)   # reference ssl.py:1249
+            v, it, _ = dev.cg(np.ascontiguousarray(M * b, dtype=self.dtype), tol=self.tol, reduce=self.reduce)   # reference ssl.py:1249
         finally:
             dev.close()
         self.num_iter = it
@@ -561,18 +577,21 @@ class laplace(ssl):
         k = parts[0][2]
         if any(p[2] != k for p in parts):
             return None
-        x, its, _ = dev.cg_groups(np.hstack([p[1] for p in parts]), k, tol=self.tol, masks=[np.asarray(ti) for ti, _ in trials])
+        x, its, _ = dev.cg_groups(np.hstack([p[1] for p in parts]), k, tol=self.tol, masks=[np.asarray(ti) for ti, _ in trials],
+                                  reduce=self.reduce)
         self.num_iter = [int(i) for i in its]
         return [self._assemble(np.ascontiguousarray(x[:, j * k:(j + 1) * k]), Mv, np.asarray(trials[j][0]), parts[j][0])
                 for j in range(len(trials))]
 
 
 class randomwalk(ssl):
-    def __init__(self, W=None, class_priors=None, alpha=0.95):
+    def __init__(self, W=None, class_priors=None, alpha=0.95, reduce='exact'):
         """Lazy random walk classification (reference ssl.py:1731-1793): one Jacobi-scaled
-        multi-RHS conjugate-gradient solve, on the GPU."""
+        multi-RHS conjugate-gradient solve, on the GPU.  reduce='tree' (not in the reference): tolerance
+        mode of the reductions for this SPD system, see ssl.laplace."""
         super().__init__(W, class_priors)
         self.alpha = alpha
+        self.reduce = reduce
         self.accuracy_filename = '_randomwalk'
         self.name = 'Lazy Random Walks'
         self.num_iter = None
@@ -608,7 +627,7 @@ class randomwalk(ssl):
 
     def _fit(self, train_ind, train_labels, all_labels=None):
         M, dev = self._operator()
-        u, it, _ = dev.cg(np.ascontiguousarray(M * self._rhs(train_ind, train_labels)), tol=1e-6)   # reference ssl.py:1790
+        u, it, _ = dev.cg(np.ascontiguousarray(M * self._rhs(train_ind, train_labels)), tol=1e-6, reduce=self.reduce)   # reference ssl.py:1790
         self.num_iter = it
         return M * u
 
@@ -623,7 +642,7 @@ class randomwalk(ssl):
         k = Ys[0].shape[1]
         if any(Y.shape[1] != k for Y in Ys):
             return None
-        x, its, _ = dev.cg_groups(np.hstack(Ys), k, tol=1e-6)
+        x, its, _ = dev.cg_groups(np.hstack(Ys), k, tol=1e-6, reduce=self.reduce)
         self.num_iter = [int(i) for i in its]
         return [M * np.ascontiguousarray(x[:, j * k:(j + 1) * k]) for j in range(len(trials))]
 

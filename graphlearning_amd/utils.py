@@ -40,19 +40,20 @@ def sparse_max(A, B):
     return A.multiply(a_wins) + B.multiply(b_wins)
 
 
-def conjgrad(A, b, x0=None, max_iter=1e5, tol=1e-10, dtype=np.float64, return_info=False, device=None):
+def conjgrad(A, b, x0=None, max_iter=1e5, tol=1e-10, dtype=np.float64, return_info=False, device=None, reduce='exact'):
     """Multi right-hand-side conjugate gradient, reference utils.py:483-532, on the GPU
-    (glx_cg_multi).  Per-column alpha/beta, global stop sqrt(sum_cols ||r||^2) <= tol."""
-    if x0 is not None:
-        # x0 != 0: solve for the correction (A d = b - A x0), the reference's r0 = b - A@x0
-        b = np.asarray(b, dtype=np.float64)
-        r0 = b - A @ x0
-        d, it, err = conjgrad(A, r0, None, max_iter, tol, dtype, True, device)
-        x = x0 + d
-        return (x, it, err) if return_info else x
+    (glx_cg_solve).  Per-column alpha/beta, global stop sqrt(sum_cols ||r||^2) <= tol.
+    With x0 the iteration starts like the reference's: `x = x0.copy(); r = b - A@x` (utils.py:510-514,
+    the residual formed on the host with the reference's own expression) and x accumulates from x0.
+    reduce='tree' selects the tolerance mode of the reductions (include/glx.h GLX_CG_TREE)."""
     G = _hip.DeviceGraph(sparse.csr_matrix(A), dtype=dtype, device=device, keep_order=True)
     try:
-        x, it, err = G.cg(np.asarray(b), tol=tol, max_iter=int(max_iter))
+        if x0 is None:
+            x, it, err = G.cg(np.asarray(b), tol=tol, max_iter=int(max_iter), reduce=reduce)
+        else:
+            x0 = np.asarray(x0)
+            r0 = b - A @ x0
+            x, it, err = G.cg(r0, tol=tol, max_iter=int(max_iter), x0=x0, reduce=reduce)
     finally:
         G.close()
     return (x, it, err) if return_info else x

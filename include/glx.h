@@ -66,6 +66,9 @@ int glx_graph_destroy(glx_graph* g);
 int glx_graph_keep_order(glx_graph* g);
 /* info[0]=n_rows,[1]=n_cols,[2]=nnz,[3]=stored entries incl. padding,[4]=slices,[5]=rows per slice,[6]=max row nnz,[7]=1 if renumbered */
 int glx_graph_info(const glx_graph* g, int64_t info[8]);
+/* the internal vertex order: perm_out[new] = caller's row (n_rows entries; the identity when the operator
+ * was not renumbered).  Forces the order to be computed if it has not been yet. */
+int glx_graph_order(glx_graph* g, int32_t* perm_out);
 
 /* u_out = Db + A u_in, applied `iters` times (u fed back).  Db may be NULL (no bias).
  * Replaces `ut = torch.sparse.addmm(Dbt, Pt, ut)` (ssl.py:658, :821) / `u = Db + P*u`
@@ -136,8 +139,19 @@ int glx_lp_iterate(double* uu, double* ul, const int32_t* nbr, const int32_t* ro
  * alpha/beta, global stop sqrt(sum over all columns ||r||^2) <= tol, max_iter cap. */
 int glx_cg_multi(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter,
                  int* iters_out, double* err_out);
-/* same with flags: bit 0 = the caller's right-hand side is 1-D (C must be 1): numpy then reduces
- * with pairwise summation (graph.reweight, graphlearning/graph.py:429), reproduced exactly. */
+/* same with flags:
+ *   GLX_CG_NP1D  the caller's right-hand side is 1-D (C must be 1): numpy then reduces with pairwise
+ *                summation (graph.reweight, graphlearning/graph.py:429), reproduced exactly;
+ *   GLX_CG_TREE  tolerance mode: the column reductions are deterministic block trees instead of numpy's
+ *                row-after-row chains (about 4x faster per iteration; iterates agree with the reference to
+ *                rounding, not bit for bit -- meant for the well-conditioned SPD systems of ssl.laplace /
+ *                ssl.randomwalk / graph.reweight, not for the singular Poisson system);
+ *   GLX_CG_X0    X holds the initial iterate x0 on entry and B the caller's r0 = b - A@x0
+ *                (utils.py:510-514: `x = x0.copy(); r = b - A@x`); x then accumulates from x0 like the
+ *                reference's `x += alpha * p`. */
+#define GLX_CG_NP1D 1
+#define GLX_CG_TREE 2
+#define GLX_CG_X0 4
 int glx_cg_solve(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int flags,
                  int* iters_out, double* err_out);
 /* several independent systems on one operator, side by side: the C columns are C/group_cols systems
@@ -164,6 +178,12 @@ int glx_cg_groups_masked(glx_graph* A, const void* B, void* X, int C, int group_
 int glx_argmax_project(const double* prob, int64_t n, int C, const double* priors,
                        double* weights_inout, int64_t* labels_out, double* err_out,
                        int* steps_out, int max_steps, int similarity, int device);
+/* the same for prob of either dtype.  GLX_F32 (the float32 `prob` the reference's use_cuda branch produces):
+ * the subtraction and the division of ssl.py:256-257 round in float32 as numpy's do on a float32 array; only the
+ * product with the fp64 class weights is wider. */
+int glx_argmax_project_t(const void* prob, int prob_dtype, int64_t n, int C, const double* priors,
+                         double* weights_inout, int64_t* labels_out, double* err_out,
+                         int* steps_out, int max_steps, int similarity, int device);
 /* the same decision on a sweep's device-resident state (no host round trip).  labels_out may be NULL.
  * to_onehot != 0 then replaces the state by onehot(labels): the hand-over between the heat sweeps and
  * the volume-constrained thresholding of ssl.poisson_mbo._fit (graphlearning/ssl.py:826-832). */

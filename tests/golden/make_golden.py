@@ -308,6 +308,33 @@ def g9_plaplace():
     print('g9 done')
 
 
+def g10_knn_cache():
+    """f-2: the kNN cache file the reference's knnsearch(dataset=...) writes (weightmatrix.py:414-427) and the weight
+    matrix its string path `knn('name', k)` (weightmatrix.py:126-127, 431-467) builds from it."""
+    import tempfile, shutil
+    rng = np.random.default_rng(10)
+    X = rng.normal(size=(300, 5))
+    tmp = tempfile.mkdtemp()
+    old = gl.weightmatrix.knn_dir
+    gl.weightmatrix.knn_dir = os.path.join(tmp, 'knn_data')
+    try:
+        J, D = gl.weightmatrix.knnsearch(X, 8, method='kdtree', dataset='GlxToy', metric='Raw')
+        path = os.path.join(gl.weightmatrix.knn_dir, 'glxtoy_raw.npz')
+        assert os.path.exists(path)
+        W = gl.weightmatrix.knn('glxtoy', 7)
+        Wu = gl.weightmatrix.knn('GLXTOY', 5, kernel='uniform')      # fewer neighbours than the file holds
+        os.makedirs(os.path.join(HERE, 'knn_data'), exist_ok=True)
+        shutil.copy(path, os.path.join(HERE, 'knn_data', 'glxtoy_raw.npz'))
+    finally:
+        gl.weightmatrix.knn_dir = old
+        shutil.rmtree(tmp)
+    out = {'X': X, 'J': J.astype(np.int64), 'D': D}
+    out.update(csr_parts(W, 'W_k7'))
+    out.update(csr_parts(Wu, 'W_k5_uniform'))
+    np.savez_compressed(os.path.join(HERE, 'g10_knn_cache.npz'), **out)
+    print('g10 done', W.nnz, Wu.nnz)
+
+
 def g4_large():
     """Config 2 (70k) and config 3 (60k): checksums only; the graphs are
     regenerated from seeds by the oracle on the GPU box."""
@@ -336,6 +363,8 @@ def g4_large():
                            cg_iters=int(itc), cg_prob_abs_sum=float(np.abs(probc).sum()),
                            cg_pred_sha=sha(mc.predict().astype(np.int64)))
     print('config2', meta['config2'])
+    meta['config5'] = _config5(W, labels, train_ind)
+    print('config5', meta['config5'])
     clabels = np.load('/root/reference/Data/cifar_labels.npz')['labels'].astype(np.int64)
     rng = np.random.default_rng(1)
     centers = rng.normal(size=(10, 32)) * 1.2
@@ -357,6 +386,52 @@ def g4_large():
         json.dump(meta, f, indent=1)
 
 
+def _config5(W, labels, train_ind):
+    """Config 5: PoissonMBO on the config-2 graph (reference ssl.py:774-839), 851 SpMMs + 21 volume projections."""
+    pri = gl.utils.class_priors(labels)
+    mm = gl.ssl.poisson_mbo(W, pri, solver='gradient_descent', Ns=40, mu=1, T=20)
+    prob = mm.fit(train_ind, labels[train_ind])
+    pred = mm.predict()
+    up, lp, wp = orc.poisson_mbo_fit(W, train_ind, labels[train_ind], pri, solver='gradient_descent')
+    assert np.array_equal(up, prob) and np.array_equal(wp, mm.weights) and np.array_equal(lp, pred)
+    return dict(pred_sha=sha(pred.astype(np.int64)), prob_sha=sha(prob.astype(np.float64)), prob_abs_sum=float(np.abs(prob).sum()),
+                weights=[float(w) for w in mm.weights], class_priors_error=float(mm.class_priors_error),
+                class_sizes=[int(c) for c in np.bincount(pred, minlength=10)],
+                accuracy=float(gl.ssl.ssl_accuracy(pred, labels, train_ind)))
+
+
+def g4_config5():
+    """Adds / refreshes the config-5 entry of g4_large_meta.json without redoing configs 2 and 3."""
+    path = os.path.join(HERE, 'g4_large_meta.json')
+    meta = json.load(open(path))
+    labels = np.load('/root/reference/Data/MNIST_labels.npz')['labels'].astype(np.int64)
+    rng = np.random.default_rng(0)
+    centers = rng.normal(size=(10, 20)) * 2.0
+    X = centers[labels] + rng.normal(size=(70000, 20))
+    J, D = gl.weightmatrix.knnsearch(X, 11, method='kdtree')
+    assert sha(J.astype(np.int64)) == meta['config2']['J_sha']
+    W = gl.weightmatrix.knn(X, 10, knn_data=(J, D))
+    train_ind = gl.trainsets.generate(labels, rate=1, seed=0)
+    meta['config5'] = _config5(W, labels, train_ind)
+    print('config5', meta['config5'])
+    # the same pipeline on overlapping blobs (centers * 0.8): the volume projection has real work to do
+    # (weights move away from 1, several hundred projection steps) -- the synthetic config-2 blobs are separable
+    rng = np.random.default_rng(5)
+    centers = rng.normal(size=(10, 20)) * 0.8
+    X = centers[labels] + rng.normal(size=(70000, 20))
+    J, D = gl.weightmatrix.knnsearch(X, 11, method='kdtree')
+    W = gl.weightmatrix.knn(X, 10, knn_data=(J, D))
+    train_ind = gl.trainsets.generate(labels, rate=2, seed=3)
+    hard = _config5(W, labels, train_ind)
+    hard.update(J_sha=sha(J.astype(np.int64)), W_indices_sha=sha(W.indices.astype(np.int32)), nnz=int(W.nnz),
+                generator='default_rng(5): centers = normal((10,20))*0.8; X = centers[labels] + normal((70000,20)); '
+                          'trainsets.generate(labels, rate=2, seed=3)')
+    meta['config5_hard'] = hard
+    print('config5_hard', hard)
+    with open(path, 'w') as f:
+        json.dump(meta, f, indent=1)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--large', action='store_true', help='also regenerate the 70k/60k checksum file (minutes)')
@@ -373,5 +448,6 @@ if __name__ == '__main__':
     g7_next_rows()
     g8_pagerank()
     g9_plaplace()
+    g10_knn_cache()
     if args.large:
         g4_large()

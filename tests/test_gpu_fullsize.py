@@ -88,17 +88,46 @@ def test_config2_poisson_cg(gl, meta, config2):
     assert abs(np.abs(u).sum() - m['cg_prob_abs_sum']) <= 1e-9 * m['cg_prob_abs_sum']
 
 
-def test_config5_poisson_mbo_runs_and_balances(gl, config2):
-    W, ti, labels = config2['W'], config2['train_ind'], config2['labels']
+def _check_config5(gl, m, W, labels, ti):
     pri = gl.utils.class_priors(labels)
-    model = gl.ssl.poisson_mbo(W, pri, solver='gradient_descent')
+    model = gl.ssl.poisson_mbo(W, pri, solver='gradient_descent', Ns=40, mu=1, T=20)
     t0 = time.perf_counter()
-    pred = model.fit_predict(ti, labels[ti])
+    prob = model.fit(ti, labels[ti])
+    pred = model.predict()
     print('poisson_mbo 70k: %.3f s, accuracy %.2f' % (time.perf_counter() - t0, gl.ssl.ssl_accuracy(pred, labels, ti)))
-    assert model.prob.shape == (70000, 10) and set(np.unique(model.prob)) <= {0.0, 1.0}
-    sizes = np.bincount(pred, minlength=10) / 70000
-    assert np.max(np.abs(sizes - pri)) <= max(model.class_priors_error, 1e-3) + 1e-12
-    assert gl.ssl.ssl_accuracy(pred, labels, ti) > 99.0
+    # pinned to the reference's run in the build container (tests/golden/make_golden.py g4_config5)
+    assert sha(pred.astype(np.int64)) == m['pred_sha']
+    assert sha(np.ascontiguousarray(prob, dtype=np.float64)) == m['prob_sha'] and np.abs(prob).sum() == m['prob_abs_sum']
+    assert [float(w) for w in model.weights] == m['weights']
+    assert float(model.class_priors_error) == m['class_priors_error']
+    assert [int(c) for c in np.bincount(pred, minlength=10)] == m['class_sizes']
+    assert gl.ssl.ssl_accuracy(pred, labels, ti) == m['accuracy']
+    # properties: one-hot state, class sizes within the projection's tolerance of the priors
+    assert prob.shape == (70000, 10) and set(np.unique(prob)) <= {0.0, 1.0}
+    assert np.max(np.abs(np.bincount(pred, minlength=10) / 70000 - pri)) <= max(model.class_priors_error, 1e-3) + 1e-12
+
+
+def test_config5_poisson_mbo_pinned(gl, meta, config2):
+    """Config 5 (ssl.poisson_mbo on the config-2 graph, reference ssl.py:774-839): labels, one-hot state, volume
+    weights and class-priors error equal the reference's."""
+    _check_config5(gl, meta['config5'], config2['W'], config2['labels'], config2['train_ind'])
+
+
+def test_config5_hard_overlapping_blobs_pinned(gl, meta):
+    """The same pipeline on overlapping blobs (accuracy 92 %): the volume-constrained projection moves the class
+    weights away from 1 over many steps inside every one of the 21 projections -- all pinned to the reference."""
+    m = meta['config5_hard']
+    labels = np.load(os.path.join(GOLDEN, 'MNIST_labels.npz'))['labels'].astype(np.int64)
+    rng = np.random.default_rng(5)
+    centers = rng.normal(size=(10, 20)) * 0.8
+    X = centers[labels] + rng.normal(size=(70000, 20))
+    J, D = gl.weightmatrix.knnsearch(X, 11)
+    assert sha(J.astype(np.int64)) == m['J_sha']
+    W = gl.weightmatrix.knn(None, 10, knn_data=(J, D))
+    assert W.nnz == m['nnz'] and sha(W.indices.astype(np.int32)) == m['W_indices_sha']
+    ti = gl.trainsets.generate(labels, rate=2, seed=3)
+    assert any(abs(w - 1.0) > 1e-3 for w in m['weights'])
+    _check_config5(gl, m, W, labels, ti)
 
 
 def test_config3_laplace(gl, meta):
@@ -122,6 +151,14 @@ def test_config3_laplace(gl, meta):
     assert abs(np.abs(u).sum() - m['prob_abs_sum']) < 1e-8 * m['prob_abs_sum']
     assert np.array_equal(u[ti], np.eye(10)[labels[ti]])           # labelled rows are exactly one-hot
     assert u.min() > -1e-9 and u.max() < 1 + 1e-9                   # harmonic extension: maximum principle
+    # tolerance mode (reduce='tree'): same labels, iterates within the north star's 1e-5
+    fast = gl.ssl.laplace(W, reduce='tree')
+    fast.fit(ti, labels[ti])
+    t0 = time.perf_counter()
+    ut = fast.fit(ti, labels[ti])
+    print('laplace CG 60k, tree reductions: %d iterations, %.3f s' % (fast.num_iter, time.perf_counter() - t0))
+    assert np.max(np.abs(ut - u)) <= 1e-5 and sha(fast.predict().astype(np.int64)) == m['pred_sha']
+    assert abs(fast.num_iter - m['cg_iters']) <= 2
 
 
 def test_config2_published_mnist_trainsets(gl, golden, config2):

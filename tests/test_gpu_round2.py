@@ -1,0 +1,225 @@
+"""GPU parity tests added in round 2 (through the C-ABI): the kNN cache format, conjgrad with an
+initial iterate, the NaN rule of the stop test, the float32 label decision of the use_cuda branch, the tolerance
+mode of the SPD solves, the verbose per-sweep contract, launch accounting."""
+import os
+import numpy as np
+import pytest
+from scipy import sparse
+from conftest import csr_from, blobs, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gl():
+    import graphlearning_amd as gl
+    from graphlearning_amd import _hip
+    _hip.require_device()
+    return gl
+
+
+@pytest.fixture(scope='module')
+def orc():
+    from oracle import gl_oracle
+    return gl_oracle
+
+
+# ---- f-2: kNN cache ./knn_data/<name>_<metric>.npz (reference weightmatrix.py:414-427, 431-467, :126-127) --------
+def test_knn_cache_roundtrip_and_reference_file(gl, golden, tmp_path, monkeypatch):
+    g = golden('g10_knn_cache.npz')
+    X = g['X']
+    monkeypatch.setattr(gl.weightmatrix, 'knn_dir', str(tmp_path / 'knn_data'))
+    J, D = gl.weightmatrix.knnsearch(X, 8, dataset='GlxToy', metric='Raw')       # names are lower-cased (:418)
+    path = tmp_path / 'knn_data' / 'glxtoy_raw.npz'
+    assert path.exists()
+    ours = np.load(path)
+    ref = np.load(os.path.join(GOLDEN, 'knn_data', 'glxtoy_raw.npz'))            # written by the REFERENCE's knnsearch
+    assert sorted(ours.files) == sorted(ref.files) == ['D', 'J']
+    assert ours['J'].shape == ref['J'].shape == (300, 8) and ours['D'].dtype == ref['D'].dtype == np.float64
+    assert ours['J'].dtype.kind == ref['J'].dtype.kind == 'i'
+    assert np.array_equal(ours['J'], ref['J'])
+    assert np.max(np.abs(ours['D'] - ref['D'])) <= 1e-12
+    # what knnsearch returned is what it stored, and load_knn_data returns it
+    assert np.array_equal(J, ours['J']) and np.array_equal(D, ours['D'])
+    J2, D2 = gl.weightmatrix.load_knn_data('GLXTOY')
+    assert np.array_equal(J2, J) and np.array_equal(D2, D)
+    # string path of knn(): the weight matrix from our file == the reference's from its file
+    W = gl.weightmatrix.knn('glxtoy', 7)
+    Wr = csr_from(g, 'W_k7')
+    assert np.array_equal(W.indptr, Wr.indptr) and np.array_equal(W.indices, Wr.indices)
+    assert np.max(np.abs(W.data - Wr.data)) <= 1e-12
+    # and from the REFERENCE's file, through our loader: bit-identical weights, fewer neighbours than stored
+    monkeypatch.setattr(gl.weightmatrix, 'knn_dir', os.path.join(GOLDEN, 'knn_data'))
+    for name, k, kern, key in (('glxtoy', 7, 'gaussian', 'W_k7'), ('GlxToy', 5, 'uniform', 'W_k5_uniform')):
+        W = gl.weightmatrix.knn(name, k, kernel=kern)
+        Wr = csr_from(g, key)
+        assert np.array_equal(W.indptr, Wr.indptr) and np.array_equal(W.indices, Wr.indices)
+        assert np.array_equal(W.data, Wr.data), name
+
+
+# ---- utils.conjgrad with x0 (reference utils.py:510-530) ---------------------------------------------------------
+def test_conjgrad_with_initial_iterate_vs_oracle(gl, orc):
+    rng = np.random.default_rng(11)
+    n = 2500
+    A = sparse.random(n, n, density=0.004, random_state=6, format='csr')
+    A = sparse.csr_matrix(A + A.T + sparse.identity(n) * 5.0)
+    b = rng.normal(size=(n, 5))
+    x0 = rng.normal(size=(n, 5))
+    x_ref, it_ref, err_ref = orc.conjgrad(A, b, x0=x0, tol=1e-9, return_iters=True)
+    x0_copy = x0.copy()
+    x, it, err = gl.utils.conjgrad(A, b, x0=x0, tol=1e-9, return_info=True)
+    assert np.array_equal(x0, x0_copy)                      # `x = x0.copy()`: the caller's array is untouched
+    assert it == it_ref and err == err_ref
+    assert np.array_equal(x, x_ref)                         # x accumulates from x0 with the reference's roundings
+    # 1-D right-hand side with x0 (numpy's pairwise reductions)
+    x1_ref, it1_ref, _ = orc.conjgrad(A, b[:, 0].copy(), x0=x0[:, 0].copy(), tol=1e-9, return_iters=True)
+    x1, it1, _ = gl.utils.conjgrad(A, b[:, 0].copy(), x0=x0[:, 0].copy(), tol=1e-9, return_info=True)
+    assert it1 == it1_ref and np.array_equal(x1, x1_ref)
+    # x0 = exact solution: r0 = 0 ... the loop still runs once in the reference (err starts at 1)
+    xs = x_ref.copy()
+    a_ref, ita_ref, _ = orc.conjgrad(A, A @ xs, x0=xs, tol=1e-3, return_iters=True)
+    a, ita, _ = gl.utils.conjgrad(A, A @ xs, x0=xs, tol=1e-3, return_info=True)
+    assert ita == ita_ref and np.array_equal(a, a_ref, equal_nan=True)
+
+
+# ---- stop test with NaN / an isolated vertex (ssl.py:667: `np.max(|v - vinf|) > 1/n` is False on NaN) -----------
+def test_isolated_vertex_and_nan_stop_rule(gl, golden, orc):
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian').tolil()
+    iso = 17
+    W[iso, :] = 0
+    W[:, iso] = 0
+    W = sparse.csr_matrix(W)
+    W.eliminate_zeros()
+    ti = g['train_ind']
+    assert iso not in set(ti.tolist())
+    lab = g['labels']
+    with np.errstate(all='ignore'):
+        u_ref, T_ref = orc.poisson_gd(W, ti, lab[ti], return_T=True)
+        m = gl.ssl.poisson(W, solver='gradient_descent')
+        u = m.fit(ti, lab[ti])
+    assert m.num_iter == T_ref
+    assert np.array_equal(u, u_ref, equal_nan=True)
+    assert np.all(np.isnan(u_ref[iso]))                     # D^-1 is inf there: 0 * inf
+    # a NaN in the stop vector itself ends the loop at min_iter in the reference (nan > 1/n is False): same here
+    from graphlearning_amd import _hip
+    n = W.shape[0]
+    P = sparse.csr_matrix(sparse.identity(n) * 0.5)
+    dev = _hip.DeviceGraph(P)
+    w0 = np.full(n, 1.0 / n)
+    w0[3] = np.nan
+    deg = np.ones(n)
+    vinf = np.full(n, 1.0 / n)
+    _, T = dev.poisson_sweep(np.zeros((n, 2)), w0, deg, vinf, min_iter=7, max_iter=200)
+    assert T == 7
+    dev.close()
+
+
+# ---- label decision on a float32 state (reference use_cuda branch: self.prob stays float32, ssl.py:256-257) -----
+def test_fp32_predict_rounds_like_numpy_float32(gl, golden, orc):
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    ti, lab = g['train_ind'], g['labels']
+    m = gl.ssl.poisson(W, solver='gradient_descent', use_cuda=True)
+    u32 = m.fit(ti, lab[ti])
+    assert u32.dtype == np.float32
+    assert np.array_equal(m.predict(), orc.predict(u32))            # numpy on the float32 array
+    # near-ties: float32 rounding of (p - min)/max decides; class weights are fp64
+    rng = np.random.default_rng(2)
+    prob = rng.normal(size=(20000, 6)).astype(np.float32)
+    prob[:, 1] = prob[:, 0] + rng.integers(-1, 2, size=20000).astype(np.float32) * np.float32(1e-7)
+    from graphlearning_amd import _hip
+    w = np.array([1.0, 1.0 + 1e-9, 0.97, 1.02, 1.0, 0.99])
+    lab32, _, _, _ = _hip.argmax_project(prob, None, w, max_steps=0)
+    assert np.array_equal(lab32, orc.predict(prob, w))
+    lab64, _, _, _ = _hip.argmax_project(prob.astype(np.float64), None, w, max_steps=0)
+    assert np.array_equal(lab64, orc.predict(prob.astype(np.float64), w))
+    # the volume projection on a float32 prob follows numpy's float32 scores too
+    pri = np.array([0.3, 0.1, 0.2, 0.15, 0.15, 0.1])
+    l_ref, w_ref, e_ref, it_ref = orc.volume_label_projection(prob, pri, 1)
+    l, wq, e, it = _hip.argmax_project(prob, pri, None, max_steps=10000)
+    assert it == it_ref and np.array_equal(wq, w_ref) and e == e_ref and np.array_equal(l, l_ref)
+
+
+# ---- tolerance mode of the SPD solves (reduce='tree') ------------------------------------------------------------
+@pytest.mark.parametrize('norm', ['combinatorial', 'normalized'])
+def test_tree_reductions_laplace_twomoons(gl, golden, norm):
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    m = gl.ssl.laplace(W, normalization=norm, reduce='tree')
+    u = m.fit(g['train_ind'], g['labels'][g['train_ind']])
+    assert np.max(np.abs(u - g['laplace_%s_prob' % norm])) <= 1e-5        # north-star tolerance on the iterates
+    assert np.array_equal(m.predict(), g['laplace_%s_pred' % norm])      # identical labels
+    assert abs(m.num_iter - int(g['laplace_%s_iters' % norm])) <= 2
+
+
+def test_tree_reductions_blobs5000_and_randomwalk(gl, golden, orc):
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    ti, lab = g['train_ind'], g['labels']
+    exact = gl.ssl.laplace(W)
+    ue = exact.fit(ti, lab[ti])
+    tree = gl.ssl.laplace(W, reduce='tree')
+    ut = tree.fit(ti, lab[ti])
+    assert np.array_equal(ue, orc.laplace_fit(W, ti, lab[ti]))
+    assert np.max(np.abs(ut - ue)) <= 1e-5 and np.array_equal(tree.predict(), exact.predict())
+    assert np.array_equal(ut[ti], ue[ti])                                 # labelled rows are exactly one-hot either way
+    # stacked trials in tolerance mode: each trial within 1e-5 of its exact fit
+    sets = [gl.trainsets.generate(lab, rate=r, seed=s) for r, s in ((2, 1), (3, 2), (5, 3))]
+    outs = tree._fit_batch([(t, lab[t]) for t in sets])
+    for t, o in zip(sets, outs):
+        assert np.max(np.abs(o - exact.fit(t, lab[t]))) <= 1e-5
+    rw_e = gl.ssl.randomwalk(W)
+    rw_t = gl.ssl.randomwalk(W, reduce='tree')
+    a, b = rw_e.fit(ti, lab[ti]), rw_t.fit(ti, lab[ti])
+    assert np.max(np.abs(a - b)) <= 1e-5 and np.array_equal(rw_e.predict(), rw_t.predict())
+    # graph.reweight('poisson'): weights within rounding
+    G = gl.graph(W)
+    We, Wt = G.reweight(ti, method='poisson'), G.reweight(ti, method='poisson', reduce='tree')
+    assert np.array_equal(We.indices, Wt.indices) and np.max(np.abs(We.data - Wt.data) / np.abs(We.data)) <= 1e-6
+    with pytest.raises(Exception):
+        gl.ssl.laplace(W, reduce='fastest').fit(ti, lab[ti])
+
+
+# ---- verbose contract: one '%d,Accuracy = %.2f' line per sweep of the CPU loop (ssl.py:672-677) ------------------
+def test_all_labels_prints_every_sweep(gl, golden, orc, capsys):
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    ti, lab = g['train_ind'], g['labels']
+    s = orc.poisson_gd_setup(W, ti, lab[ti])
+    n = W.shape[0]
+    u = np.zeros((n, s['k']))
+    v = s['v0']
+    T = 0
+    want = []
+    while (T < 50 or np.max(np.absolute(v - s['vinf'])) > 1 / n) and T < 1000:
+        u = s['Db'] + s['P'] * u
+        v = s['RW'] * v
+        T += 1
+        want.append('%d,Accuracy = %.2f' % (T, orc.ssl_accuracy(orc.predict(u), lab, ti)))
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    capsys.readouterr()
+    got_u = m.fit(ti, lab[ti], all_labels=lab)
+    lines = [l for l in capsys.readouterr().out.splitlines() if 'Accuracy' in l]
+    assert lines == want and len(lines) == T == int(g['poisson_gd_T'])
+    assert np.array_equal(got_u, g['poisson_gd_prob'])
+
+
+def test_sweep_launch_count_is_sweeps_run(gl, golden):
+    """glx_sweep_launches counts the sweeps that ran, not the kernels of a tail chunk that exit at once."""
+    from graphlearning_amd import _hip
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    ti, lab = g['train_ind'], g['labels']
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    dev, aux = m._operators()
+    src, k = gl.ssl._poisson_source(W.shape[0], ti, lab[ti])
+    v0 = np.zeros(W.shape[0]); v0[ti] = 1; v0 /= v0.sum()
+    sw = _hip.Sweep(dev, k, 50, 1000, True)
+    sw.set_problem(aux['D'] * src, v0 / aux['deg'], aux['deg'], aux['vinf'])
+    l0 = sw.launches()
+    T, _ = sw.run()
+    assert T == int(g['poisson_gd_T']) == 409 and sw.launches() - l0 == T
+    T2, _ = sw.run()
+    assert T2 == T and sw.launches() - l0 == 2 * T
+    sw.close()
