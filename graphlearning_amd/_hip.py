@@ -57,6 +57,8 @@ _SIGNATURES = {
     'glx_device_count': [C.POINTER(C.c_int)],
     'glx_set_device': [C.c_int],
     'glx_device_synchronize': [],
+    'glx_host_alloc': [C.c_size_t, C.POINTER(_vp)],
+    'glx_host_free': [_vp],
     'glx_graph_create': [C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)],
     'glx_graph_destroy': [_vp],
     'glx_graph_keep_order': [_vp],
@@ -66,6 +68,8 @@ _SIGNATURES = {
     'glx_poisson_sweep': [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_int)],
     'glx_sweep_create': [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)],
     'glx_sweep_set_problem': [_vp, _vp, _vp, _vp, _vp],
+    'glx_sweep_set_vectors': [_vp, _vp, _vp],
+    'glx_sweep_set_problem_rows': [_vp, C.c_int64, _vp, _vp, _vp, C.c_double],
     'glx_sweep_run': [_vp, C.POINTER(C.c_int), C.POINTER(C.c_float)],
     'glx_sweep_fetch': [_vp, _vp],
     'glx_sweep_launches': [_vp, _i64p],
@@ -154,6 +158,59 @@ def _dense(a, dtype, shape=None, name='array'):
     if shape is not None and tuple(a.shape) != tuple(shape):
         raise GlxError('%s has shape %s, expected %s' % (name, a.shape, tuple(shape)))
     return a
+
+
+class _PinnedBlock:
+    """A page-locked host block serving as the memory of one numpy array (its `base`); returned to the pool
+    when the array and every view of it are gone."""
+
+    def __init__(self, pool, ptr, nbytes, shape, dtype):
+        self._pool, self._ptr, self._nbytes = pool, ptr, nbytes
+        self.__array_interface__ = {'data': (ptr, False), 'shape': tuple(shape), 'typestr': np.dtype(dtype).str, 'version': 3}
+
+    def __del__(self):
+        try:
+            self._pool._release(self._ptr, self._nbytes)
+        except Exception:
+            pass
+
+
+class _PinnedPool:
+    """Result arrays (prob, labels) are handed out as numpy arrays backed by page-locked memory: the device-to-host
+    copy then runs at PCIe speed and a fresh array costs no page faults (a 5.6 MB np.empty + first write is ~1 ms).
+    Blocks are recycled by size; at most `keep` idle blocks per size are retained."""
+
+    def __init__(self, keep=4):
+        self.keep = keep
+        self.idle = {}
+
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        nbytes = max(int(np.prod(shape)) * dtype.itemsize, 1)
+        if nbytes < (1 << 16):
+            return np.empty(shape, dtype=dtype)
+        lst = self.idle.get(nbytes)
+        if lst:
+            ptr = lst.pop()
+        else:
+            p = _vp()
+            check(load().glx_host_alloc(nbytes, C.byref(p)), 'glx_host_alloc')
+            ptr = p.value
+        return np.asarray(_PinnedBlock(self, ptr, nbytes, shape, dtype))
+
+    def _release(self, ptr, nbytes):
+        lst = self.idle.setdefault(nbytes, [])
+        if len(lst) < self.keep:
+            lst.append(ptr)
+        elif _lib is not None:
+            _lib.glx_host_free(_vp(ptr))
+
+
+_pinned = _PinnedPool()
+
+
+def pinned_empty(shape, dtype):
+    return _pinned.empty(shape, dtype)
 
 
 class DeviceGraph:
@@ -318,10 +375,27 @@ class Sweep:
                                            _ptr(_dense(deg, np.float64, (n,))), _ptr(_dense(vinf, np.float64, (n,)))),
               'glx_sweep_set_problem')
 
+    def set_vectors(self, deg, vinf):
+        """The graph's own vectors of the stop test (ssl.py:642-643), uploaded once per prepared sweep."""
+        n = self.graph.shape[0]
+        check(load().glx_sweep_set_vectors(self._h, _ptr(_dense(deg, np.float64, (n,))), _ptr(_dense(vinf, np.float64, (n,)))),
+              'glx_sweep_set_vectors')
+
+    def set_problem_rows(self, rows, Db_rows, w0_rows, err0):
+        """A new training set: the labelled rows, their rows of Db = D^-1 b and of w0 = v0/deg, and
+        err0 = max|v0 - vinf| (ssl.py:620-622, 636, 639-641, 667)."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64).ravel()
+        m = len(rows)
+        Db_rows = _dense(Db_rows, self.graph.dtype, (m, self.C), 'Db_rows')
+        w0_rows = _dense(w0_rows, np.float64, (m,), 'w0_rows')
+        check(load().glx_sweep_set_problem_rows(self._h, m, _ptr(rows), _ptr(Db_rows), _ptr(w0_rows), float(err0)),
+              'glx_sweep_set_problem_rows')
+
     def run(self):
         T = C.c_int(0)
         ms = C.c_float(0)
         check(load().glx_sweep_run(self._h, C.byref(T), C.byref(ms)), 'glx_sweep_run')
+        self.generation = getattr(self, 'generation', 0) + 1
         return T.value, ms.value
 
     def set_state(self, u0, Db=None):
@@ -329,12 +403,14 @@ class Sweep:
         u0 = None if u0 is None else _dense(u0, self.graph.dtype, (n, self.C), 'u0')
         Db = None if Db is None else _dense(Db, self.graph.dtype, (n, self.C), 'Db')
         check(load().glx_sweep_set_state(self._h, _ptr(u0), _ptr(Db)), 'glx_sweep_set_state')
+        self.generation = getattr(self, 'generation', 0) + 1
 
     def iterate(self, iters):
         check(load().glx_sweep_iterate(self._h, int(iters)), 'glx_sweep_iterate')
+        self.generation = getattr(self, 'generation', 0) + 1
 
     def fetch(self):
-        out = np.empty((self.graph.shape[0], self.C), dtype=self.graph.dtype)
+        out = pinned_empty((self.graph.shape[0], self.C), self.graph.dtype)
         check(load().glx_sweep_fetch(self._h, _ptr(out)), 'glx_sweep_fetch')
         return out
 
@@ -344,7 +420,7 @@ class Sweep:
         n = self.graph.shape[0]
         w = np.ones(self.C) if weights is None else np.array(weights, dtype=np.float64).reshape(self.C).copy()
         pri = np.zeros(self.C) if priors is None else _dense(priors, np.float64, (self.C,), 'priors')
-        labels = np.empty(n, dtype=np.int64) if want_labels else None
+        labels = pinned_empty((n,), np.int64) if want_labels else None
         err = C.c_double(0)
         steps = C.c_int(0)
         check(load().glx_sweep_project(self._h, _ptr(pri), _ptr(w), _ptr(labels) if want_labels else None, C.byref(err),

@@ -38,6 +38,18 @@ extern "C" int glx_device_synchronize(void) {
 
 extern "C" void glx_free(void* p) { free(p); }
 
+extern "C" int glx_host_alloc(size_t bytes, void** out) {
+  GLX_CHECK(out, GLX_EINVAL, "glx_host_alloc: null output");
+  *out = nullptr;
+  GLX_HIP(hipHostMalloc(out, bytes > 0 ? bytes : 1, hipHostMallocDefault));
+  return GLX_OK;
+}
+
+extern "C" int glx_host_free(void* p) {
+  if (p) GLX_HIP(hipHostFree(p));
+  return GLX_OK;
+}
+
 int glx_make_layout(int C, int dtype, bool has_w, RecLayout* L) {
   GLX_CHECK(C >= 1, GLX_EINVAL, "layout: C must be >= 1 (got %d)", C);
   GLX_CHECK(dtype == GLX_F32 || dtype == GLX_F64, GLX_EINVAL, "layout: bad dtype %d", dtype);

@@ -36,6 +36,14 @@ struct glx_sweep {
   int cur = 0;
   int64_t launches = 0;
   double err0 = 0.0, thresh = 0.0;
+  // sparse right-hand side (glx_sweep_set_problem_rows): record indices of the rows set by the previous call
+  int32_t* row_slot = nullptr;              // [n_rows] record index -> its (first) slot in the plan
+  int32_t* prev_rec = nullptr;              // [prev_cap] records whose bias / flag / w0 the previous problem set
+  int64_t* prev_row = nullptr;              // [prev_cap] the same rows in the caller's numbering (for w0)
+  int64_t prev_m = 0, prev_cap = 0;
+  void* rows_stage = nullptr;               // device staging for (rows, Db_rows, w0_rows)
+  size_t rows_stage_cap = 0;
+  bool vectors_set = false;
 };
 
 static size_t rec_bytes(const glx_sweep* s, int64_t rows) { return (size_t)rows * s->L.ld * s->L.esize; }
@@ -56,6 +64,10 @@ extern "C" int glx_sweep_destroy(glx_sweep* s) {
   hipFree(s->err);
   if (s->h_err) hipHostFree(s->h_err);
   hipFree(s->dense);
+  hipFree(s->row_slot);
+  hipFree(s->prev_rec);
+  hipFree(s->prev_row);
+  hipFree(s->rows_stage);
   glx_projector_destroy(s->proj);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
@@ -163,6 +175,8 @@ extern "C" int glx_sweep_set_problem(glx_sweep* s, const void* Db, const double*
   GLX_HIP(hipSetDevice(s->P->device));
   int rc = upload_bias(s, Db);
   if (rc) return rc;
+  if (s->row_slot) { hipFree(s->row_slot); s->row_slot = nullptr; s->prev_m = 0; }   // a later sparse problem starts from scratch
+  s->vectors_set = true;
   GLX_HIP(hipMemcpyAsync(s->w0, w0, s->n_cols * 8, hipMemcpyHostToDevice, s->stream));   // caller order; packed through perm
   std::vector<double> degp, vinfp;
   if (!s->P->h_perm.empty()) {   // the kernel indexes deg / vinf by renumbered row
@@ -181,6 +195,168 @@ extern "C" int glx_sweep_set_problem(glx_sweep* s, const void* Db, const double*
   s->err0 = e0;
   s->thresh = 1.0 / (double)s->n_rows;   // `> 1/n`, ssl.py:667
   GLX_HIP(hipStreamSynchronize(s->stream));
+  return GLX_OK;
+}
+
+// ---- sparse problem upload -------------------------------------------------------------------------
+// Poisson's right-hand side Db = D^-1 b and the initial stop vector v0 are nonzero on the m labelled rows only
+// (ssl.py:620-622, 639-641): a new training set on a resident graph then costs a few KB of upload instead of a
+// dense (n, C) array, and the graph's own vectors (deg, vinf) are uploaded once.
+__global__ void permute_f64_kernel(const double* __restrict__ src, double* __restrict__ dst, const int32_t* __restrict__ perm, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[perm ? perm[i] : i];
+}
+
+extern "C" int glx_sweep_set_vectors(glx_sweep* s, const double* deg, const double* vinf) {
+  GLX_CHECK(s && deg && vinf, GLX_EINVAL, "glx_sweep_set_vectors: null argument");
+  GLX_CHECK(s->has_w, GLX_EINVAL, "glx_sweep_set_vectors: sweep was created without a stop column (max_iter = 0)");
+  GLX_CHECK(s->n_rows == s->n_cols, GLX_EINVAL, "glx_sweep_set_vectors: operator must be square");
+  GLX_HIP(hipSetDevice(s->device));
+  double* tmp = (double*)s->dense;   // staging (n, C) of the state dtype: C*esize >= 4 bytes per row is not enough for 2 x fp64
+  void* own = nullptr;
+  if ((size_t)s->C * s->L.esize < 16) { GLX_HIP(hipMalloc(&own, (size_t)s->n_rows * 16)); tmp = (double*)own; }
+  const unsigned grid = (unsigned)((s->n_rows + 255) / 256);
+  hipError_t e = hipMemcpyAsync(tmp, deg, s->n_rows * 8, hipMemcpyHostToDevice, s->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(tmp + s->n_rows, vinf, s->n_rows * 8, hipMemcpyHostToDevice, s->stream);
+  if (e == hipSuccess && s->n_rows > 0) {
+    hipLaunchKernelGGL(permute_f64_kernel, dim3(grid), dim3(256), 0, s->stream, (const double*)tmp, s->deg, (const int32_t*)s->P->d_perm, s->n_rows);
+    hipLaunchKernelGGL(permute_f64_kernel, dim3(grid), dim3(256), 0, s->stream, (const double*)(tmp + s->n_rows), s->vinf,
+                       (const int32_t*)s->P->d_perm, s->n_rows);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  hipFree(own);
+  GLX_HIP(e);
+  s->thresh = 1.0 / (double)s->n_rows;   // `> 1/n`, ssl.py:667
+  s->vectors_set = true;
+  return GLX_OK;
+}
+
+__global__ void row_slot_kernel(const int32_t* __restrict__ slot_row, int32_t* __restrict__ row_slot, int64_t nslots) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= nslots) return;
+  const int row = slot_row[slot];
+  // the first of a long row's S consecutive slots is the one whose lanes store (and read the bias flag)
+  if (row >= 0 && (slot == 0 || slot_row[slot - 1] != row)) row_slot[row] = (int32_t)slot;
+}
+
+template <typename T>
+__global__ void clear_rows_kernel(char* __restrict__ bias, int rec_bytes, uint8_t* __restrict__ flags, const int32_t* __restrict__ row_slot,
+                                  double* __restrict__ w0, const int32_t* __restrict__ prev_rec, const int64_t* __restrict__ prev_row,
+                                  int64_t m, int ld) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * ld) return;
+  const int64_t q = i / ld;
+  const int c = (int)(i % ld);
+  const int32_t rec = prev_rec[q];
+  ((T*)(bias + (size_t)rec * rec_bytes))[c] = 0;
+  if (c == 0) {
+    flags[row_slot[rec]] = 0;
+    w0[prev_row[q]] = 0.0;
+  }
+}
+
+template <typename T>
+__global__ void set_rows_kernel(char* __restrict__ bias, int rec_bytes, uint8_t* __restrict__ flags, const int32_t* __restrict__ row_slot,
+                                double* __restrict__ w0, const int64_t* __restrict__ rows, const int32_t* __restrict__ inv,
+                                const T* __restrict__ Db_rows, const double* __restrict__ w0_rows, int64_t m, int C,
+                                int32_t* __restrict__ prev_rec, int64_t* __restrict__ prev_row) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * C) return;
+  const int64_t q = i / C;
+  const int c = (int)(i % C);
+  const int64_t row = rows[q];
+  const int32_t rec = inv ? inv[row] : (int32_t)row;
+  const T v = Db_rows[i];
+  ((T*)(bias + (size_t)rec * rec_bytes))[c] = v;
+  // flag: any nonzero in the record (-0.0 counts as zero, like bias_flags_kernel); benign race: every writer stores 1
+  bool nz;
+  if constexpr (sizeof(T) == 8) nz = ((unsigned long long)__double_as_longlong((double)v) << 1) != 0;
+  else nz = ((unsigned)__float_as_int((float)v) << 1) != 0;
+  if (nz) flags[row_slot[rec]] = 1;
+  if (c == 0) {
+    w0[row] = w0_rows[q];
+    prev_rec[q] = rec;
+    prev_row[q] = row;
+  }
+}
+
+extern "C" int glx_sweep_set_problem_rows(glx_sweep* s, int64_t m, const int64_t* rows, const void* Db_rows, const double* w0_rows,
+                                          double err0) {
+  GLX_CHECK(s, GLX_EINVAL, "glx_sweep_set_problem_rows: null sweep");
+  GLX_CHECK(s->has_w, GLX_EINVAL, "glx_sweep_set_problem_rows: sweep was created without a stop column (max_iter = 0)");
+  GLX_CHECK(s->vectors_set, GLX_EINVAL, "glx_sweep_set_problem_rows: call glx_sweep_set_vectors first");
+  GLX_CHECK(m >= 0 && (m == 0 || (rows && Db_rows && w0_rows)), GLX_EINVAL, "glx_sweep_set_problem_rows: null array");
+  for (int64_t q = 0; q < m; ++q)
+    GLX_CHECK(rows[q] >= 0 && rows[q] < s->n_rows, GLX_EINVAL, "glx_sweep_set_problem_rows: row %lld out of range", (long long)rows[q]);
+  GLX_HIP(hipSetDevice(s->device));
+  const int64_t nslots = s->plan->nslices * s->plan->R;
+  const int rb = s->L.ld * s->L.esize;
+  if (!s->row_slot) {
+    GLX_HIP(hipMalloc(&s->row_slot, std::max<size_t>((size_t)s->n_rows * 4, 64)));
+    if (nslots > 0) {
+      hipLaunchKernelGGL(row_slot_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s->stream, (const int32_t*)s->plan->d_slot_row,
+                         s->row_slot, nslots);
+      GLX_HIP(hipGetLastError());
+    }
+    // from a dense problem to sparse ones: start from an all-zero bias
+    GLX_HIP(hipMemsetAsync(s->bias, 0, rec_bytes(s, s->n_rows), s->stream));
+    GLX_HIP(hipMemsetAsync(s->slot_has_bias, 0, std::max<int64_t>(nslots, 1), s->stream));
+    GLX_HIP(hipMemsetAsync(s->w0, 0, std::max<size_t>(s->n_cols * 8, 8), s->stream));
+    s->prev_m = 0;
+  }
+  drop_graphs_if_bias_changes(s, true);
+  if (s->prev_m > 0) {
+    const int64_t tot = s->prev_m * s->L.ld;
+    if (s->P->dtype == GLX_F32)
+      hipLaunchKernelGGL(clear_rows_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (char*)s->bias, rb, s->slot_has_bias,
+                         (const int32_t*)s->row_slot, s->w0, (const int32_t*)s->prev_rec, (const int64_t*)s->prev_row, s->prev_m, s->L.ld);
+    else
+      hipLaunchKernelGGL(clear_rows_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (char*)s->bias, rb, s->slot_has_bias,
+                         (const int32_t*)s->row_slot, s->w0, (const int32_t*)s->prev_rec, (const int64_t*)s->prev_row, s->prev_m, s->L.ld);
+    GLX_HIP(hipGetLastError());
+    s->prev_m = 0;
+  }
+  if (m > 0) {
+    if (s->prev_cap < m) {
+      hipFree(s->prev_rec);
+      hipFree(s->prev_row);
+      s->prev_rec = nullptr;
+      s->prev_row = nullptr;
+      s->prev_cap = 0;
+      const int64_t cap = std::max<int64_t>(m * 2, 256);
+      GLX_HIP(hipMalloc(&s->prev_rec, cap * 4));
+      GLX_HIP(hipMalloc(&s->prev_row, cap * 8));
+      s->prev_cap = cap;
+    }
+    const size_t es = s->L.esize;
+    const size_t b_rows = (size_t)m * 8, b_db = ((size_t)m * s->C * es + 7) / 8 * 8, b_w = (size_t)m * 8;
+    if (s->rows_stage_cap < b_rows + b_db + b_w) {
+      hipFree(s->rows_stage);
+      s->rows_stage = nullptr;
+      s->rows_stage_cap = 0;
+      GLX_HIP(hipMalloc(&s->rows_stage, 2 * (b_rows + b_db + b_w)));
+      s->rows_stage_cap = 2 * (b_rows + b_db + b_w);
+    }
+    char* st = (char*)s->rows_stage;
+    GLX_HIP(hipMemcpyAsync(st, rows, b_rows, hipMemcpyHostToDevice, s->stream));
+    GLX_HIP(hipMemcpyAsync(st + b_rows, Db_rows, (size_t)m * s->C * es, hipMemcpyHostToDevice, s->stream));
+    GLX_HIP(hipMemcpyAsync(st + b_rows + b_db, w0_rows, b_w, hipMemcpyHostToDevice, s->stream));
+    const int64_t tot = m * s->C;
+    if (s->P->dtype == GLX_F32)
+      hipLaunchKernelGGL(set_rows_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (char*)s->bias, rb, s->slot_has_bias,
+                         (const int32_t*)s->row_slot, s->w0, (const int64_t*)st, (const int32_t*)s->P->d_inv, (const float*)(st + b_rows),
+                         (const double*)(st + b_rows + b_db), m, s->C, s->prev_rec, s->prev_row);
+    else
+      hipLaunchKernelGGL(set_rows_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (char*)s->bias, rb, s->slot_has_bias,
+                         (const int32_t*)s->row_slot, s->w0, (const int64_t*)st, (const int32_t*)s->P->d_inv, (const double*)(st + b_rows),
+                         (const double*)(st + b_rows + b_db), m, s->C, s->prev_rec, s->prev_row);
+    GLX_HIP(hipGetLastError());
+    s->prev_m = m;
+  }
+  s->bias_set = true;
+  s->err0 = err0;
+  GLX_HIP(hipStreamSynchronize(s->stream));   // the host arrays may go; the staging is reused by the next call
   return GLX_OK;
 }
 

@@ -61,6 +61,7 @@ struct SpmmParams {
   int prod_sc;              // prod_out is blocked by prod_sc columns: (row, col) at ((col/sc)*n + row)*sc + col%sc
   const int32_t* perm;      // record -> caller row (null: identity)
   int64_t n_rows;
+  int nt;                   // bit 0: nontemporal operator-stream loads, bit 1: nontemporal stores (GLX_NT / large operators)
   int ablate;               // developer probe (GLX_ABLATE): 1 no chunk loop, 2 gathers hit one hot record, 4 no stores, 8 no XCD remap
 };
 
@@ -217,8 +218,13 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
   int col0 = 0;
   T val0 = 0;
   if (slice < p.nslices) {
-    col0 = p.col[slice * 64 + lane];
-    val0 = valp[slice * 64 + lane];
+    if (p.nt & 1) {
+      col0 = __builtin_nontemporal_load(&p.col[slice * 64 + lane]);
+      val0 = __builtin_nontemporal_load(&valp[slice * 64 + lane]);
+    } else {
+      col0 = p.col[slice * 64 + lane];
+      val0 = valp[slice * 64 + lane];
+    }
   }
   if (slice < p.nslices) {
     const int64_t slot = slice * R + g;
@@ -246,6 +252,9 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       if (kc <= 0) {          // (also the clamp target of a 1-chunk slice)
         r.col = col0;
         r.val = val0;
+      } else if (p.nt & 1) {
+        r.col = __builtin_nontemporal_load(&p.col[base + (int64_t)kc * 64 + lane]);
+        r.val = __builtin_nontemporal_load(&valp[base + (int64_t)kc * 64 + lane]);
       } else {
         r.col = p.col[base + (int64_t)kc * 64 + lane];
         r.val = valp[base + (int64_t)kc * 64 + lane];
@@ -368,11 +377,10 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       }
     }
     if (!(p.ablate & 4)) {
-#if GLX_NT_STORE
-      __builtin_nontemporal_store(outv, (V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off));
-#else
-      *(V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off) = outv;
-#endif
+      if (p.nt & 2)
+        __builtin_nontemporal_store(outv, (V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off));
+      else
+        *(V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off) = outv;
     }
   }
 
@@ -504,6 +512,8 @@ int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
   p.n_rows = a.n_rows;
   static const int ablate = getenv("GLX_ABLATE") ? atoi(getenv("GLX_ABLATE")) : 0;
   p.ablate = ablate;
+  static const int nt_env = getenv("GLX_NT") ? atoi(getenv("GLX_NT")) : -1;
+  p.nt = nt_env >= 0 ? nt_env : 0;
   return a.dtype == GLX_F32 ? launch_t<float>(a, p, stream) : launch_t<double>(a, p, stream);
 }
 

@@ -40,14 +40,14 @@ class graph:
             sys.exit('Invalid option for graph Laplacian normalization.')
         return L.tocsr()
 
-    def reweight(self, idx, method='poisson', normalization='combinatorial', tau=0, X=None, alpha=2, zeta=1e7, r=0.1,
-                 reduce='exact'):
+    def reweight(self, idx, method='poisson', normalization='combinatorial', tau=0, X=None, alpha=2, zeta=1e7, r=0.1):
         """Reweight the graph more heavily near the labelled nodes `idx` (reference
         graph.py:368-466).  'poisson' solves one Poisson problem with the GPU conjugate-gradient
         solver (1-D right-hand side: numpy's pairwise-summed reductions are reproduced);
         'wnll' is a diagonal scaling.  'properly' (a kd-tree range query on the features) is
-        outside this package's scope.  reduce='tree' (not in the reference): tolerance mode of the
-        solver's reductions (include/glx.h GLX_CG_TREE) -- weights within rounding of the reference's."""
+        outside this package's scope.  (The 'poisson' system is the singular graph Laplacian: its
+        conjugate-gradient iterates amplify rounding, so the solve always uses the reference-order
+        reductions -- the tolerance mode of ssl.laplace / ssl.randomwalk does not apply here.)"""
         from . import utils
         n = self.num_nodes
         if method == 'poisson':
@@ -63,7 +63,7 @@ class graph:
                 L = self.laplacian(normalization=normalization)
             else:
                 sys.exit('Unsupported normalization ' + normalization + ' for graph.reweight.')
-            w = utils.conjgrad(L, f, tol=1e-5, reduce=reduce)
+            w = utils.conjgrad(L, f, tol=1e-5)
             w -= np.min(w)
             w += 1e-5
             D = sparse.spdiags(w, 0, n, n).tocsr()

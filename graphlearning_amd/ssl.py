@@ -25,10 +25,54 @@ from . import _hip
 results_dir = os.path.join(os.getcwd(), 'results')
 
 
+class _DeviceState:
+    """Result of a fit that still lives in a prepared sweep's device buffer: `prob` is read back only when somebody
+    looks at it, label decisions (predict / volume_label_projection) run on the device state directly."""
+
+    def __init__(self, sweep):
+        self.sweep = sweep
+        self.generation = getattr(sweep, 'generation', 0)
+
+    def valid(self):
+        return self.sweep._h.value and getattr(self.sweep, 'generation', 0) == self.generation
+
+    def fetch(self):
+        if not self.valid():
+            raise RuntimeError('the device state of this fit has been overwritten by a later solve')
+        return self.sweep.fetch()
+
+
 class ssl:
     """Base class, reference ssl.py:131-510."""
 
+    # `prob` (the (n, C) result of the last fit, reference ssl.py:146) is an ordinary attribute for callers; when a fit
+    # leaves its result on the device it is read back on first access
+    @property
+    def prob(self):
+        if self._prob is None and self._dev_state is not None:
+            self._prob = self._dev_state.fetch()
+        return self._prob
+
+    @prob.setter
+    def prob(self, value):
+        self._prob = value
+        self._dev_state = None
+
+    def _set_result(self, res):
+        if isinstance(res, _DeviceState):
+            self._prob = None
+            self._dev_state = res
+        else:
+            self.prob = res
+
+    def _device_state(self):
+        """The sweep holding the current `prob` on the device, if it is still there."""
+        st = self._dev_state
+        return st if (st is not None and st.valid()) else None
+
     def __init__(self, W, class_priors):
+        self._prob = None
+        self._dev_state = None
         if W is None:
             self.graph = None
         else:
@@ -58,10 +102,14 @@ class ssl:
         """Volume-constrained label decision (reference ssl.py:172-209) on the device:
         at most 1e4 steps of w += -0.1 (class_size - priors); w /= w[0], stop at max error
         <= 1e-3.  Updates self.weights / self.class_priors_error; returns the labels."""
-        k = self.prob.shape[1]
+        st = self._device_state()
+        k = st.sweep.C if st is not None else self.prob.shape[1]
         w = np.ones((k,)) if type(self.weights) == int else self.weights
-        labels, w, err, _ = _hip.argmax_project(self.prob, self.class_priors, w, max_steps=10000,
-                                                similarity=self.similarity, device=self.device)
+        if st is not None:
+            labels, w, err, _ = st.sweep.project(self.class_priors, w, max_steps=10000, similarity=self.similarity)
+        else:
+            labels, w, err, _ = _hip.argmax_project(self.prob, self.class_priors, w, max_steps=10000,
+                                                    similarity=self.similarity, device=self.device)
         self.weights = w
         self.class_priors_error = err
         return labels
@@ -78,21 +126,30 @@ class ssl:
         (reference ssl.py:230-266), on the device."""
         if self.fitted == False:
             sys.exit('Model has not been fitted yet.')
-        k = self.prob.shape[1]
+        st = self._device_state()
+        k = st.sweep.C if st is not None else self.prob.shape[1]
         if ignore_class_priors or type(self.weights) == int:
             w = np.ones((k,))
         else:
             w = self.weights
+        if st is not None:      # the fit's result is still on the device: decide there, only the labels come back
+            labels, _, _, _ = st.sweep.project(None, w, max_steps=0, similarity=self.similarity)
+            return labels
         labels, _, _, _ = _hip.argmax_project(self.prob, None, w, max_steps=0, similarity=self.similarity,
                                               device=self.device)
         return labels
 
     def fit_predict(self, train_ind, train_labels, all_labels=None):
-        self.fit(train_ind, train_labels, all_labels=all_labels)
+        self._fit_only(train_ind, train_labels, all_labels=all_labels)
         return self.predict()
 
     def fit(self, train_ind, train_labels, all_labels=None):
         """reference ssl.py:439-481."""
+        self._fit_only(train_ind, train_labels, all_labels=all_labels)
+        return self.prob
+
+    def _fit_only(self, train_ind, train_labels, all_labels=None):
+        """`fit` without reading the result back: `prob` stays on the device until it is looked at."""
         if self.graph is None:
             sys.exit('SSL object has no graph. Use graph.set_graph() to provide a graph for SSL.')
         self.fitted = True
@@ -104,10 +161,9 @@ class ssl:
             for i, l in enumerate(unique_labels):
                 self.prob[:, i] = self._fit(train_ind, train_labels == l)
         else:
-            self.prob = self._fit(train_ind, train_labels, all_labels=all_labels)
+            self._set_result(self._fit(train_ind, train_labels, all_labels=all_labels))
         if self.class_priors is not None:
             self.volume_label_projection()
-        return self.prob
 
     def ssl_trials(self, trainsets, labels, num_cores=1, tag='', save_results=True, overwrite=False, num_trials=-1):
         """Run the learner on a list of training sets and record `Number of labels,Accuracy[,...]`
@@ -253,6 +309,7 @@ class poisson(ssl):
             P = D * W.transpose()
             deg = G.degree_vector()
             aux['D'] = D
+            aux['dinv'] = D.diagonal()
             aux['deg'] = deg
             aux['vinf'] = deg / np.sum(deg)
             dev = _hip.DeviceGraph(P, dtype=self._dtype(), device=self.device)
@@ -265,8 +322,8 @@ class poisson(ssl):
 
     def _fit(self, train_ind, train_labels, all_labels=None):
         n = self.graph.num_nodes
-        source, k = _poisson_source(n, train_ind, train_labels)
         if self.solver == 'conjugate_gradient':       # reference ssl.py:624-629
+            source, k = _poisson_source(n, train_ind, train_labels)
             dev, aux = self._operators()
             D = aux['D']
             x, it, _ = dev.cg(np.ascontiguousarray(D * source, dtype=self._dtype()), tol=self.tol)
@@ -274,11 +331,8 @@ class poisson(ssl):
             u = D * x
         elif self.solver == 'gradient_descent':       # reference ssl.py:631-677
             dev, aux = self._operators()
-            Db = aux['D'] * source
-            v = np.zeros(n)
-            v[train_ind] = 1
-            v = v / np.sum(v)
-            w0 = v / aux['deg']       # w = D^-1 v rides along as the stop column (include/glx.h)
+            train_ind = np.asarray(train_ind)
+            k = len(np.unique(train_labels))
             # prepared sweep (device buffers + captured launch graph) kept with the operator: repeated
             # fits on one graph (ssl_trials) only upload the new right-hand side
             key = (k, self.min_iter, self.max_iter)
@@ -288,19 +342,43 @@ class poisson(ssl):
                 aux['sweep'] = None
                 if self.max_iter > 0:
                     aux['sweep'] = _hip.Sweep(dev, k, min_iter=self.min_iter, max_iter=self.max_iter, use_hipgraph=True)
+                    aux['sweep'].set_vectors(aux['deg'], aux['vinf'])
                 aux['sweep_key'] = key
+            Db = None
             if aux['sweep'] is None:
                 u, T = np.zeros((n, k), dtype=self._dtype()), 0
-            else:
-                aux['sweep'].set_problem(Db, w0, aux['deg'], aux['vinf'])
+            elif len(np.unique(train_ind)) == len(train_ind):
+                # Db = D*source and v = 1_train/m are nonzero on the labelled rows only (ssl.py:620-622, 636, 639-641):
+                # those m rows are all a new training set uploads; deg and vinf went up with the prepared sweep
+                onehot = utils.labels_to_onehot(train_labels, k)
+                Db_rows = aux['dinv'][train_ind, None] * (onehot - np.mean(onehot, axis=0))   # rows of D*source: one product per entry
+                vval = 1.0 / float(len(train_ind))                        # v[train] = 1; v = v/np.sum(v)
+                w0_rows = vval / aux['deg'][train_ind]                    # w = D^-1 v rides along as the stop column
+                err0 = 0.0
+                if self.min_iter == 0:                                    # the stop test before the first sweep (ssl.py:667)
+                    v = np.zeros(n)
+                    v[train_ind] = vval
+                    err0 = np.max(np.absolute(v - aux['vinf']))
+                aux['sweep'].set_problem_rows(train_ind, Db_rows, w0_rows, err0)
                 T, _ = aux['sweep'].run()
-                u = aux['sweep'].fetch()
+                u = _DeviceState(aux['sweep'])
+            else:                                                         # repeated labelled rows: the dense expressions, literally
+                source, k = _poisson_source(n, train_ind, train_labels)
+                Db = aux['D'] * source
+                v = np.zeros(n)
+                v[train_ind] = 1
+                v = v / np.sum(v)
+                aux['sweep'].set_problem(Db, v / aux['deg'], aux['deg'], aux['vinf'])
+                T, _ = aux['sweep'].run()
+                u = _DeviceState(aux['sweep'])
             self.num_iter = T
             if all_labels is not None and not self.use_cuda:
                 # verbose contract of the reference's CPU loop (ssl.py:672-677): one '%d,Accuracy = %.2f' line per
                 # sweep.  T is known from the run above; the sweeps are repeated one launch at a time on a sweep
                 # without a stop column (the same kernel, the same iterates) and every iterate is read back.
                 step = _hip.Sweep(dev, k, min_iter=0, max_iter=0, use_hipgraph=False)
+                if Db is None:
+                    Db = aux['D'] * _poisson_source(n, train_ind, train_labels)[0]
                 try:
                     step.set_state(None, Db)
                     for t in range(1, T + 1):
@@ -310,6 +388,7 @@ class poisson(ssl):
                         print('%d,Accuracy = %.2f' % (t, acc))
                 finally:
                     step.close()
+                u = self.prob
         elif self.solver == 'spectral':
             raise NotImplementedError("poisson(solver='spectral') needs an eigensolver, which is outside the "
                                       'GPU hot path this package covers (SURVEY.md section 8)')
@@ -532,7 +611,7 @@ class laplace(ssl):
             self.num_iter = int(its[0])
             return self._assemble(x, Mv, train_ind, F)
         # reweighted graphs depend on the training set: per-fit sub-matrix, reference ssl.py:1211-1250 line by line
-        W = self.graph.reweight(train_ind, method=self.reweighting, normalization=self.normalization, X=self.X, reduce=self.reduce)
+        W = self.graph.reweight(train_ind, method=self.reweighting, normalization=self.normalization, X=self.X)
         G = graph_mod.graph(W)
         n = G.num_nodes
         k = len(np.unique(train_labels))

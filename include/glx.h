@@ -23,6 +23,7 @@
 #ifndef GLX_H
 #define GLX_H
 #include <stdint.h>
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -46,6 +47,10 @@ int glx_device_count(int* n);
 int glx_set_device(int device);
 int glx_device_synchronize(void);
 void glx_free(void* p);
+/* page-locked host memory for result arrays (a D2H copy into pageable memory is staged and several times slower;
+ * the Python boundary recycles these blocks as the backing store of the numpy arrays it returns) */
+int glx_host_alloc(size_t bytes, void** out);
+int glx_host_free(void* p);
 
 /* ---- sparse operator -------------------------------------------------------------
  * Replaces utils.torch_sparse (graphlearning/utils.py:288-317): scipy CSR -> device.
@@ -86,6 +91,15 @@ int glx_poisson_sweep(glx_graph* P, const void* Db, const double* w0, const doub
 /* prepared form of the same (used by bench.py and repeated fits on one graph) */
 int glx_sweep_create(glx_graph* P, int C, int min_iter, int max_iter, int use_hipgraph, glx_sweep** out);
 int glx_sweep_set_problem(glx_sweep* s, const void* Db, const double* w0, const double* deg, const double* vinf);
+/* the same problem with what a NEW TRAINING SET on a resident graph really changes: Db = D^-1 b and the initial
+ * stop vector v0 are nonzero on the m labelled rows only (ssl.py:620-622, 639-641).  glx_sweep_set_vectors uploads
+ * the graph's own vectors once (deg, vinf; (n,) fp64, caller's row order); glx_sweep_set_problem_rows then takes the
+ * labelled rows (caller's numbering), their rows of Db ((m, C), state dtype) and of w0 = v0/deg ((m,) fp64), and
+ * err0 = max|v0 - vinf| (the stop test before the first sweep; only read when min_iter = 0).  Rows set by the
+ * previous call are cleared first. */
+int glx_sweep_set_vectors(glx_sweep* s, const double* deg, const double* vinf);
+int glx_sweep_set_problem_rows(glx_sweep* s, int64_t m, const int64_t* rows, const void* Db_rows,
+                               const double* w0_rows, double err0);
 int glx_sweep_run(glx_sweep* s, int* T_out, float* device_ms_out);   /* all iterations on device; HIP-event time */
 int glx_sweep_fetch(glx_sweep* s, void* u_out);
 int glx_sweep_launches(const glx_sweep* s, int64_t* sweep_kernel_launches);

@@ -15,9 +15,10 @@ ap.add_argument('tag')
 ap.add_argument('--match', default='spmm')
 ap.add_argument('--pmc', action='append', default=[])
 ap.add_argument('--no-stats', action='store_true')
-ap.add_argument('cmd', nargs=argparse.REMAINDER)
-a = ap.parse_args()
-cmd = a.cmd[1:] if a.cmd and a.cmd[0] == '--' else a.cmd
+argv = sys.argv[1:]
+split = argv.index('--') if '--' in argv else len(argv)
+a = ap.parse_args(argv[:split])
+cmd = argv[split + 1:]
 root = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out = os.path.join(root, 'gpurun_out', a.tag)
 os.makedirs(out, exist_ok=True)

@@ -1,0 +1,108 @@
+"""GPU, config 4's shape at an HBM-resident single-GPU size (BASELINE.json configs[3]: isotropic Gaussian blobs,
+d = 64, k = 10, C = 10; SURVEY.md 8d "Config 4" generator, default_rng(2), centers * 4) -- n = 10^6 is what one GPU of
+the 8-GPU run owns per 8 x 10^6 vertices.  Against host fp64 checks and the oracle (scipy) on the same inputs:
+  * exact kNN on 2048 sampled query rows (counting argument on fp64 distances to ALL 10^6 points),
+  * the device-assembled weight matrix == oracle.knn_weights on the same lists (structure bit-exact, values bit-exact),
+  * 50 Poisson sweeps bit-identical to oracle.poisson_gd, fp32 within 1e-5, the stop iteration T of a full run."""
+import time
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 1000000
+
+
+@pytest.fixture(scope='module')
+def gl():
+    import graphlearning_amd as gl
+    from graphlearning_amd import _hip
+    _hip.require_device()
+    return gl
+
+
+@pytest.fixture(scope='module')
+def orc():
+    from oracle import gl_oracle
+    return gl_oracle
+
+
+@pytest.fixture(scope='module')
+def data(gl):
+    rng = np.random.default_rng(2)
+    labels = rng.integers(0, 10, size=N)
+    centers = rng.normal(size=(10, 64)) * 4
+    X = centers[labels] + rng.normal(size=(N, 64))
+    t0 = time.perf_counter()
+    J, D = gl.weightmatrix.knnsearch(X, 11)
+    print('kNN n=%d d=64: %.2f s' % (N, time.perf_counter() - t0))
+    return dict(X=X, labels=labels.astype(np.int64), J=J, D=D)
+
+
+def test_scale_knn_exact_on_sampled_rows(gl, data):
+    X, J, D = data['X'], data['J'], data['D']
+    assert J.shape == (N, 11) and np.all(J[:, 0] == np.arange(N)) and np.all(D[:, 0] == 0)
+    assert np.all(np.diff(D, axis=1) >= 0)
+    q = np.random.default_rng(0).choice(N, size=2048, replace=False)
+    # (1) the listed neighbours carry their exact fp64 direct-difference distances, in ascending (distance, index) order
+    diff = X[q][:, None, :] - X[J[q]]
+    exact = np.sqrt(np.sum(diff * diff, axis=2))
+    assert np.max(np.abs(exact - D[q])) <= 1e-12
+    for r in range(len(q)):
+        assert len(set(J[q[r]].tolist())) == 11
+    # (2) nothing else is closer: at most k-1 = 10 points lie strictly inside the k-th distance (self included)
+    sq = np.einsum('ij,ij->i', X, X)
+    rk2 = D[q, 10] ** 2
+    for lo in range(0, len(q), 256):
+        qq = q[lo:lo + 256]
+        d2 = sq[qq][:, None] + sq[None, :] - 2.0 * (X[qq] @ X.T)
+        inside = np.sum(d2 < (rk2[lo:lo + 256] * (1 - 1e-9))[:, None], axis=1)
+        assert np.all(inside <= 10), int(inside.max())
+        # and every listed neighbour is inside-or-on the k-th distance
+        assert np.all(inside >= np.sum(D[qq] < (D[qq, 10] * (1 - 1e-9))[:, None], axis=1))
+
+
+def test_scale_weight_matrix_equals_oracle(gl, orc, data):
+    J, D = data['J'], data['D']
+    t0 = time.perf_counter()
+    W = gl.weightmatrix.knn(None, 10, knn_data=(J, D))
+    t1 = time.perf_counter()
+    Wr = orc.knn_weights(J, D, 10)
+    print('weight matrix n=%d: nnz=%d max row %d, device %.2f s, oracle %.2f s' % (N, W.nnz, np.diff(W.indptr).max(), t1 - t0,
+                                                                                 time.perf_counter() - t1))
+    Wr.sort_indices()
+    assert W.nnz == Wr.nnz and np.array_equal(W.indptr, Wr.indptr) and np.array_equal(W.indices, Wr.indices)
+    assert np.array_equal(W.data, Wr.data)
+    data['W'] = W
+
+
+def test_scale_poisson_sweeps_equal_oracle(gl, orc, data):
+    W = data.get('W')
+    if W is None:
+        W = gl.weightmatrix.knn(None, 10, knn_data=(data['J'], data['D']))
+    labels = data['labels']
+    ti = gl.trainsets.generate(labels, rate=5, seed=0)
+    t0 = time.perf_counter()
+    u_ref, T_ref = orc.poisson_gd(W, ti, labels[ti], min_iter=50, max_iter=50, return_T=True)
+    t1 = time.perf_counter()
+    m = gl.ssl.poisson(W, solver='gradient_descent', min_iter=50, max_iter=50)
+    u = m.fit(ti, labels[ti])
+    t2 = time.perf_counter()
+    u = m.fit(ti, labels[ti])
+    t3 = time.perf_counter()
+    print('50 sweeps n=%d nnz=%d: oracle %.1f s, first fit %.2f s (operator set-up + upload), second fit %.3f s' % (
+        N, W.nnz, t1 - t0, t2 - t1, t3 - t2))
+    assert m.num_iter == T_ref == 50
+    assert np.array_equal(u, u_ref)                              # bit-identical at 18 M stored entries
+    assert np.array_equal(m.predict(), orc.predict(u_ref))
+    # fp32 device path of the reference (use_cuda=True): north-star tolerance, same labels
+    m32 = gl.ssl.poisson(W, solver='gradient_descent', min_iter=50, max_iter=50, use_cuda=True)
+    u32 = m32.fit(ti, labels[ti])
+    assert u32.dtype == np.float32 and np.max(np.abs(u32 - u_ref)) <= 1e-5
+    assert np.array_equal(m32.predict(), orc.predict(u_ref))
+    # the stop test at this size: T of a full run == the oracle's (a host loop over the stop vector only)
+    T_full = orc.poisson_gd_iterations(W, ti, min_iter=50, max_iter=300)
+    mf = gl.ssl.poisson(W, solver='gradient_descent', min_iter=50, max_iter=300)
+    mf.fit(ti, labels[ti])
+    print('stop test n=%d: T = %d' % (N, T_full))
+    assert mf.num_iter == T_full

@@ -160,3 +160,16 @@ def test_laplace_rhs_fast_path_equals_scipy_expression():
     L2.data[L2.indptr[0]:L2.indptr[1]] = L2.data[L2.indptr[0]:L2.indptr[1]][::-1]
     L2.has_sorted_indices = False
     assert np.array_equal(glssl._neg_columns_times(L2, L2.tocsc(), cols, F), -L2[:, cols] * F)
+
+
+def test_load_knn_data_reads_the_reference_cache_file(golden, monkeypatch):
+    """./knn_data/<dataset>_<metric>.npz with keys J, D (reference weightmatrix.py:416-427, 451-465).
+    tests/golden/knn_data/glxtoy_raw.npz was written by the reference's own knnsearch(dataset='GlxToy')."""
+    from graphlearning_amd import weightmatrix as wm
+    g = golden('g10_knn_cache.npz')
+    monkeypatch.setattr(wm, 'knn_dir', os.path.join(ROOT, 'tests', 'golden', 'knn_data'))
+    for name, metric in (('glxtoy', 'raw'), ('GLXtoy', 'RAW')):       # not case-sensitive (:418, :452)
+        J, D = wm.load_knn_data(name, metric=metric)
+        assert J.shape == (300, 8) and np.array_equal(J, g['J']) and np.array_equal(D, g['D'])
+    with pytest.raises(SystemExit):
+        wm.load_knn_data('no_such_dataset')
