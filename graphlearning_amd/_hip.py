@@ -82,6 +82,23 @@ _SIGNATURES = {
     'glx_sweep_step_dev': [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'glx_pack_records_dev': [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp],
     'glx_unpack_records_dev': [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp],
+    'glx_dist_unique_id': [_vp],
+    'glx_dist_init_rank': [C.c_int, C.c_int, _vp, C.c_int, C.POINTER(_vp)],
+    'glx_dist_init': [C.c_int, _vp, C.POINTER(_vp)],
+    'glx_dist_comm_info': [_vp, C.POINTER(C.c_int32)],
+    'glx_dist_destroy': [_vp],
+    'glx_dist_sweep_create': [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int64,
+                              C.c_int, C.c_int, C.POINTER(_vp)],
+    'glx_dist_sweep_set_problem': [_vp, _vp, _vp, _vp, _vp],
+    'glx_poisson_sweep_dist': [_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_float)],
+    'glx_dist_sweep_fetch': [_vp, _vp],
+    'glx_dist_sweep_stats': [_vp, _i64p],
+    'glx_dist_sweep_destroy': [_vp],
+    'glx_dist_sweep_begin': [_vp],
+    'glx_dist_sweep_boundary': [_vp, C.c_int],
+    'glx_dist_sweep_get_send': [_vp, _vp],
+    'glx_dist_sweep_put_halo': [_vp, _vp, C.c_int],
+    'glx_dist_sweep_interior': [_vp, C.c_int, _f64p],
     'glx_cg_multi': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), _f64p],
     'glx_cg_solve': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_sweep_project': [_vp, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
@@ -438,6 +455,127 @@ class Sweep:
             lib = load(required=False)
             if lib is not None:
                 lib.glx_sweep_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """One rank's libglx-owned RCCL communicator (glx_comm).  `uid`: the 128 bytes of Comm.unique_id() made on rank 0
+    and shipped to every rank; uid=None with nranks == 1 gives a transport-free single rank."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(load().glx_dist_unique_id(buf), 'glx_dist_unique_id')
+        return buf.raw
+
+    def __init__(self, nranks=1, rank=0, uid=None, device=None):
+        self.nranks, self.rank, self.device = int(nranks), int(rank), _dev(device)
+        self._h = _vp()
+        idbuf = None if uid is None else C.create_string_buffer(bytes(uid), 128)
+        check(load().glx_dist_init_rank(self.nranks, self.rank, idbuf, self.device, C.byref(self._h)), 'glx_dist_init_rank')
+
+    def has_transport(self):
+        info = (C.c_int32 * 4)()
+        check(load().glx_dist_comm_info(self._h, info), 'glx_dist_comm_info')
+        return bool(info[3])
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            lib = load(required=False)
+            if lib is not None:
+                lib.glx_dist_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DistSweep:
+    """One rank's share of the vertex-partitioned Poisson sweep (glx_dist_sweep): local operator (boundary rows first,
+    columns [owned | halo]), exchange lists, device state; every sweep and every collective is enqueued by libglx."""
+
+    def __init__(self, comm, P_local, n_boundary, send_counts, send_idx, recv_counts, n_global, Cc, dtype=np.float64,
+                 force_exchange=False, use_hipgraph=True):
+        from scipy import sparse
+        A = sparse.csr_matrix(P_local)
+        self.comm = comm
+        self.n_own, n_loc = A.shape
+        self.n_halo = n_loc - self.n_own
+        self.C = int(Cc)
+        self.dtype = np.dtype(dtype)
+        self.lay = record_layout(Cc, dtype, True)
+        rowptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        col = np.ascontiguousarray(A.indices, dtype=np.int32)
+        val = np.ascontiguousarray(A.data, dtype=np.float64)
+        sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+        rcnt = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        si = np.ascontiguousarray(send_idx, dtype=np.int32)
+        self.n_send = int(sc.sum())
+        self._h = _vp()
+        check(load().glx_dist_sweep_create(comm._h, self.n_own, self.n_halo, int(n_boundary), _ptr(rowptr), _ptr(col), _ptr(val),
+                                           _dt(self.dtype), self.C, _ptr(sc), _ptr(si), _ptr(rcnt), int(n_global),
+                                           1 if force_exchange else 0, 1 if use_hipgraph else 0, C.byref(self._h)),
+              'glx_dist_sweep_create')
+
+    def set_problem(self, Db_own, w0_own, deg_own, vinf_own):
+        n = self.n_own
+        Db = None if Db_own is None else _dense(Db_own, self.dtype, (n, self.C), 'Db_own')
+        check(load().glx_dist_sweep_set_problem(self._h, _ptr(Db), _ptr(_dense(w0_own, np.float64, (n,))),
+                                                _ptr(_dense(deg_own, np.float64, (n,))), _ptr(_dense(vinf_own, np.float64, (n,)))),
+              'glx_dist_sweep_set_problem')
+
+    def run(self, min_iter=50, max_iter=1000, check_every=8, err0=0.0):
+        T = C.c_int(0)
+        ms = C.c_float(0)
+        check(load().glx_poisson_sweep_dist(self._h, int(min_iter), int(max_iter), int(check_every), float(err0), C.byref(T),
+                                            C.byref(ms)), 'glx_poisson_sweep_dist')
+        return T.value, ms.value
+
+    def fetch(self):
+        out = np.empty((self.n_own, self.C), dtype=self.dtype)
+        check(load().glx_dist_sweep_fetch(self._h, _ptr(out)), 'glx_dist_sweep_fetch')
+        return out
+
+    def stats(self):
+        out = (C.c_int64 * 4)()
+        check(load().glx_dist_sweep_stats(self._h, out), 'glx_dist_sweep_stats')
+        return dict(sweeps=out[0], exchanges=out[1], graphs=out[2], exchanging=bool(out[3]))
+
+    # stepwise form (transport left to the caller)
+    def begin(self):
+        check(load().glx_dist_sweep_begin(self._h), 'glx_dist_sweep_begin')
+
+    def boundary(self, want_err):
+        check(load().glx_dist_sweep_boundary(self._h, 1 if want_err else 0), 'glx_dist_sweep_boundary')
+
+    def get_send(self):
+        out = np.empty((self.n_send, self.lay['ld']), dtype=self.dtype)
+        check(load().glx_dist_sweep_get_send(self._h, _ptr(out)), 'glx_dist_sweep_get_send')
+        return out
+
+    def put_halo(self, rec, next_iterate):
+        rec = _dense(rec, self.dtype, (self.n_halo, self.lay['ld']), 'halo records')
+        check(load().glx_dist_sweep_put_halo(self._h, _ptr(rec), 1 if next_iterate else 0), 'glx_dist_sweep_put_halo')
+
+    def interior(self, want_err):
+        e = C.c_double(0)
+        check(load().glx_dist_sweep_interior(self._h, 1 if want_err else 0, C.byref(e)), 'glx_dist_sweep_interior')
+        return e.value if want_err else None
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            lib = load(required=False)
+            if lib is not None:
+                lib.glx_dist_sweep_destroy(self._h)
             self._h = _vp()
 
     def __del__(self):

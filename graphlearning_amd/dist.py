@@ -503,6 +503,110 @@ class DistSweep:
         return self.ops.unpack([self.xa, self.xb][self.cur], self.plan.n_own)
 
 
+# ---- libglx-owned communicator and sweep (include/glx.h: glx_dist_*) ----------------------------------------------
+def init_comm(dist, device=None, group=None):
+    """A libglx RCCL communicator over the ranks of `dist` (any initialised torch.distributed backend serves as the
+    bootstrap channel: rank 0's 128-byte unique id is broadcast as a Python object).  One rank: no transport."""
+    from . import _hip
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world == 1 and not _force_collectives():
+        return _hip.Comm(1, 0, None, device)
+    uid = [_hip.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0, group=group)
+    return _hip.Comm(world, rank, uid[0], device)
+
+
+def _force_collectives():
+    import os
+    return os.environ.get('GLX_DIST_FORCE_COLLECTIVES') == '1'
+
+
+def glx_dist_sweep(comm, plan, C, dtype=np.float64, force_exchange=False, use_hipgraph=True):
+    """The rank's glx_dist_sweep for a RankPlan."""
+    from . import _hip
+    return _hip.DistSweep(comm, plan.P_local, plan.n_boundary, plan.send_counts, plan.send_idx, plan.recv_counts, plan.n_global, C,
+                          dtype=dtype, force_exchange=force_exchange, use_hipgraph=use_hipgraph)
+
+
+def run_stepwise(ds, plan, dist, min_iter, max_iter, err0=None, group=None):
+    """The distributed sweep with libglx doing every rank-local piece (boundary rows, pack, interior rows, local
+    maxima) and `dist` -- any backend, host tensors -- moving the packed records: how several ranks sharing ONE GPU
+    (tests) or a machine without RCCL run the glx_dist_sweep object.  Returns T."""
+    import torch
+    world = dist.get_world_size(group)
+
+    def exchange(next_iterate):
+        if plan.global_halo == 0:
+            return
+        send = torch.from_numpy(np.ascontiguousarray(ds.get_send()))
+        recv = torch.empty((plan.n_halo, ds.lay['ld']), dtype=send.dtype)
+        dist.all_to_all_single(recv, send, output_split_sizes=list(plan.recv_counts), input_split_sizes=list(plan.send_counts),
+                               group=group)
+        ds.put_halo(recv.numpy(), next_iterate)
+
+    ds.begin()
+    exchange(False)
+    thresh = 1.0 / plan.n_global
+    T, err_T = 0, err0
+    while T < max_iter:
+        if T >= min_iter and not (err_T > thresh):
+            break
+        want = (T + 1) >= min_iter
+        ds.boundary(want)
+        exchange(True)
+        e = ds.interior(want)
+        if want:
+            t = torch.tensor([e], dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            err_T = float(t.item())
+        T += 1
+    return T
+
+
+def poisson_fit_glx(W, train_ind, train_labels, dist, comm=None, device=None, min_iter=50, max_iter=1000, order=None, group=None,
+                    gather=True, partition='cut', dtype=np.float64, check_every=8, stepwise=False, force_exchange=False):
+    """ssl.poisson(solver='gradient_descent').fit across the ranks of `dist` with the library-owned sweep: planner on
+    the host, then ONE collective call (glx_poisson_sweep_dist) runs every sweep, exchange and stop test on the
+    device (stepwise=True: the same object with `dist` as the transport, see run_stepwise).  Returns (u, T) as
+    poisson_fit_distributed does."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    prob = poisson_problem(W, train_ind, train_labels)
+    P = prob['P']
+    n = P.shape[0]
+    if order is None:
+        order = locality_order(P)
+    bounds = cut_bounds(P, order, world) if partition == 'cut' else block_bounds(n, world)
+    plan = RankPlan(P, order, bounds, rank)
+    own_comm = comm is None and not stepwise
+    if stepwise and comm is None:
+        from . import _hip
+        comm = _hip.Comm(world, rank, None, device)      # rank identity only: `dist` is the transport
+    elif comm is None:
+        comm = init_comm(dist, device, group)
+    ds = glx_dist_sweep(comm, plan, prob['k'], dtype=dtype, force_exchange=force_exchange or _force_collectives())
+    own = plan.own
+    ds.set_problem(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
+    err0 = initial_error(prob['w0'][own], prob['deg'][own], prob['vinf'][own], dist, group) if min_iter == 0 else 0.0
+    if stepwise:
+        T = run_stepwise(ds, plan, dist, min_iter, max_iter, err0, group)
+    else:
+        T, _ = ds.run(min_iter, max_iter, check_every, err0)
+    u_own = ds.fetch()
+    stats = ds.stats()
+    ds.close()
+    if own_comm or stepwise:
+        comm.close()
+    if not gather:
+        return u_own, T, plan, stats
+    parts = [None] * world
+    dist.all_gather_object(parts, (own, u_own), group=group)
+    u = np.zeros((n, prob['k']), dtype=u_own.dtype)
+    for ids, block in parts:
+        u[ids] = block
+    return u, T
+
+
 def knnsearch_distributed(X, k, dist, device=None, similarity='euclidean', group=None):
     """weightmatrix.knnsearch with the QUERY rows sharded over the ranks: every
     rank holds all of X, searches its contiguous block of queries on its own GPU

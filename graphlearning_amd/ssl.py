@@ -310,6 +310,7 @@ class poisson(ssl):
             deg = G.degree_vector()
             aux['D'] = D
             aux['dinv'] = D.diagonal()
+            aux['zero_degree'] = bool(np.any(~np.isfinite(aux['dinv'])))
             aux['deg'] = deg
             aux['vinf'] = deg / np.sum(deg)
             dev = _hip.DeviceGraph(P, dtype=self._dtype(), device=self.device)
@@ -347,7 +348,7 @@ class poisson(ssl):
             Db = None
             if aux['sweep'] is None:
                 u, T = np.zeros((n, k), dtype=self._dtype()), 0
-            elif len(np.unique(train_ind)) == len(train_ind):
+            elif len(np.unique(train_ind)) == len(train_ind) and not aux['zero_degree']:
                 # Db = D*source and v = 1_train/m are nonzero on the labelled rows only (ssl.py:620-622, 636, 639-641):
                 # those m rows are all a new training set uploads; deg and vinf went up with the prepared sweep
                 onehot = utils.labels_to_onehot(train_labels, k)
@@ -362,7 +363,7 @@ class poisson(ssl):
                 aux['sweep'].set_problem_rows(train_ind, Db_rows, w0_rows, err0)
                 T, _ = aux['sweep'].run()
                 u = _DeviceState(aux['sweep'])
-            else:                                                         # repeated labelled rows: the dense expressions, literally
+            else:   # repeated labelled rows, or vertices of degree 0 (D^-1 = inf turns their rows of Db into NaN): the dense expressions, literally
                 source, k = _poisson_source(n, train_ind, train_labels)
                 Db = aux['D'] * source
                 v = np.zeros(n)

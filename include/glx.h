@@ -36,10 +36,13 @@ extern "C" {
 #define GLX_EHIP (-2)     /* HIP runtime error (message has the hipError string) */
 #define GLX_ENOMEM (-3)
 #define GLX_EUNSUPPORTED (-4)
+#define GLX_ERCCL (-5)    /* RCCL could not be loaded / a collective call failed */
 
 typedef struct glx_graph glx_graph;   /* a sparse operator resident in HBM (sliced-ELL + CSR) */
 typedef struct glx_sweep glx_sweep;   /* a prepared Poisson / heat sweep: device state + launch plan */
 typedef struct glx_cg glx_cg;         /* a prepared multi-RHS conjugate-gradient solve */
+typedef struct glx_comm glx_comm;     /* one rank's RCCL communicator, owned by the library */
+typedef struct glx_dist_sweep glx_dist_sweep;   /* one rank's share of the vertex-partitioned Poisson sweep */
 
 const char* glx_last_error(void);
 int glx_version(void);
@@ -127,6 +130,49 @@ int glx_sweep_step_dev(glx_graph* P, int C, int has_w, const void* xin, void* xo
 int glx_pack_records_dev(const void* dense, void* rec, int64_t n, int C, int dtype, int has_w, const double* w,
                          void* stream);
 int glx_unpack_records_dev(const void* rec, void* dense, int64_t n, int C, int dtype, int has_w, void* stream);
+
+/* ---- vertex-partitioned sweep over RCCL (the reference has no distributed code) -------------
+ * One process per GPU: rank 0 calls glx_dist_unique_id, ships the 128 bytes to the other ranks by any means (the
+ * launcher's store, torch.distributed, MPI ...), every rank calls glx_dist_init_rank.  glx_dist_init is the
+ * one-process form (all GPUs of the node, ncclCommInitAll; out[nranks]).  id = NULL gives a rank identity without a
+ * transport: enough for one rank, and for the stepwise form below where the caller moves the records.  RCCL is bound with dlopen on first use (librccl.so.1: the copy a host framework
+ * already mapped, else /opt/rocm's). */
+int glx_dist_unique_id(char id_out[128]);
+int glx_dist_init_rank(int nranks, int rank, const char id[128], int device, glx_comm** out);
+int glx_dist_init(int nranks, const int* devices, glx_comm** out);
+int glx_dist_comm_info(const glx_comm* c, int32_t info[4]);   /* rank, nranks, device, 1 if it has an RCCL communicator */
+int glx_dist_destroy(glx_comm* c);
+/* This rank's share.  rowptr / col / val: its n_own rows of P in local order -- the n_boundary rows some peer
+ * gathers FIRST -- with columns renumbered [0, n_own) owned and [n_own, n_own + n_halo) halo, the halo ordered as
+ * the peers' records arrive (by owner rank ascending, each peer's in the order of that peer's send list).  Entry
+ * order inside a row is kept, so iterates are bit-identical to the single-GPU sweep.  send_counts / recv_counts
+ * [nranks]: records exchanged with every peer per sweep; send_idx: local (boundary) row of every record sent,
+ * grouped by destination rank.  n_global: vertices of the whole graph (the stop threshold is 1/n_global).
+ * force_exchange: issue the exchange even when this rank has nothing to send or receive (1-rank tests). */
+int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_halo, int64_t n_boundary, const int32_t* rowptr,
+                          const int32_t* col, const double* val, int state_dtype, int C, const int64_t* send_counts,
+                          const int32_t* send_idx, const int64_t* recv_counts, int64_t n_global, int force_exchange,
+                          int use_hipgraph, glx_dist_sweep** out);
+/* rank-local rows (local order) of Db (n_own, C; may be NULL), w0 = v0/deg, deg, vinf */
+int glx_dist_sweep_set_problem(glx_dist_sweep* s, const void* Db_own, const double* w0_own, const double* deg_own,
+                               const double* vinf_own);
+/* ssl.py:631-670 across the ranks (collective call): every sweep is [boundary rows | pack | grouped
+ * ncclSend/ncclRecv all-to-all-v on a second stream | interior rows], the first min_iter sweeps one captured device
+ * graph, later sweeps in chunks of check_every on a ring of state buffers with ONE ncclAllReduce(MAX) of the chunk's
+ * per-sweep maxima -- no host round trip per sweep, and T and u_T are exactly the reference's.  err0 = max|v0 - vinf|
+ * over all vertices (read when min_iter = 0). */
+int glx_poisson_sweep_dist(glx_dist_sweep* s, int min_iter, int max_iter, int check_every, double err0, int* T_out,
+                           float* device_ms_out);
+int glx_dist_sweep_fetch(glx_dist_sweep* s, void* u_own_out);           /* (n_own, C) host, local row order */
+int glx_dist_sweep_stats(const glx_dist_sweep* s, int64_t out[4]);      /* sweeps run, exchanges enqueued, graphs, 1 if it exchanges */
+int glx_dist_sweep_destroy(glx_dist_sweep* s);
+/* the same pieces one at a time with the transport left to the caller (eager, synchronous): multi-rank tests on one
+ * GPU move the packed records between ranks through a host-side backend */
+int glx_dist_sweep_begin(glx_dist_sweep* s);                                    /* state <- initial records; packs them */
+int glx_dist_sweep_boundary(glx_dist_sweep* s, int want_err);                   /* boundary rows of the next iterate; packs them */
+int glx_dist_sweep_get_send(glx_dist_sweep* s, void* host_out);                 /* the packed records (sum of send_counts) */
+int glx_dist_sweep_put_halo(glx_dist_sweep* s, const void* host_in, int next);  /* received records -> halo of the current / next iterate */
+int glx_dist_sweep_interior(glx_dist_sweep* s, int want_err, double* err_local_out);   /* interior rows; next becomes current */
 
 /* ---- affine fixed-point iteration with a sup-norm stop --------------------------------
  * u <- A u + b (b may be NULL) from u0 until max|u_new - u_old| <= tol or max_iter sweeps: the power

@@ -89,6 +89,7 @@ def main():
     case = sys.argv[1]
     out_path = sys.argv[2]
     use_hip = len(sys.argv) > 3 and sys.argv[3] == 'hip'     # rank-local sweeps on the GPU (all ranks share cuda:0)
+    glxstep = len(sys.argv) > 3 and sys.argv[3] == 'glxstep'  # the C-ABI sweep object (glx_dist_sweep), gloo as the transport
     partition = sys.argv[4] if len(sys.argv) > 4 else 'even'  # 'even': equal blocks (halo exchange every sweep); 'cut': graph-following blocks
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -109,7 +110,10 @@ def main():
     else:
         raise SystemExit('unknown case')
     factory = (lambda plan, k: gdist.HipOps(plan, k, 0)) if use_hip else (lambda plan, k: ScipyOps(plan, k))
-    u, T = gdist.poisson_fit_distributed(W, ti, tl, dist, factory, min_iter=min_iter, max_iter=max_iter, partition=partition)
+    if glxstep:
+        u, T = gdist.poisson_fit_glx(W, ti, tl, dist, device=0, min_iter=min_iter, max_iter=max_iter, partition=partition, stepwise=True)
+    else:
+        u, T = gdist.poisson_fit_distributed(W, ti, tl, dist, factory, min_iter=min_iter, max_iter=max_iter, partition=partition)
     u_ref, T_ref = orc.poisson_gd(W, ti, tl, min_iter=min_iter, max_iter=max_iter, return_T=True)
     # partition bookkeeping invariants
     P = gdist.poisson_problem(W, ti, tl)['P']

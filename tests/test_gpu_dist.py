@@ -70,12 +70,14 @@ def test_distributed_bench_entry_one_rank(tmp_path, force_coll):
     print(line[:400])
 
 
+@pytest.mark.parametrize('engine', ['hip', 'glxstep'])
 @pytest.mark.parametrize('case,world,partition', [('twomoons', 2, 'even'), ('blobs', 3, 'even'), ('miniter0', 2, 'even'),
                                                   ('twomoons', 2, 'cut'), ('blobs', 3, 'cut')])
-def test_multi_rank_hip_sweeps_over_gloo(case, world, partition, tmp_path):
+def test_multi_rank_hip_sweeps_over_gloo(case, world, partition, engine, tmp_path):
     """Several ranks, every one running its rank-local sweeps with the HIP kernel (all on cuda:0),
     exchanging halo records through gloo (host-staged): the full multi-rank GPU path minus RCCL,
-    bit-identical to the single-rank oracle."""
+    bit-identical to the single-rank oracle.  engine 'hip': torch-tensor plumbing (dist.HipOps); 'glxstep': the
+    C-ABI sweep object glx_dist_sweep (boundary rows / pack / interior rows in libglx) with gloo as the transport."""
     import socket
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -83,9 +85,108 @@ def test_multi_rank_hip_sweeps_over_gloo(case, world, partition, tmp_path):
     s.close()
     out = str(tmp_path / ('res_' + case + '_' + partition))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out, 'hip', partition]
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out, engine, partition]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS='1'), cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for k in range(world):
         res = json.load(open(out + '.%d' % k))
         assert res['T'] == res['T_ref'] and res['equal'] and res['ok_counts'], res
+
+
+class _Solo:
+    """torch.distributed's interface for one rank, without a process group."""
+
+    def get_rank(self, group=None):
+        return 0
+
+    def get_world_size(self, group=None):
+        return 1
+
+    def all_gather_object(self, out, obj, group=None):
+        out[0] = obj
+
+    def broadcast_object_list(self, lst, src=0, group=None):
+        pass
+
+
+@pytest.mark.parametrize('check_every', [1, 8, 5])
+def test_glx_dist_one_rank_tail_chunks_match_golden(golden, check_every):
+    """glx_poisson_sweep_dist on one rank (no transport): the min_iter head graph, then 359 more sweeps in chunks of
+    check_every on the ring of state buffers; the stop test fires inside a chunk (T = 409 = 50 + 44*8 + 7) and the
+    iterate handed back is exactly u_409, bit-identical to the reference."""
+    from graphlearning_amd import dist as gdist, _hip
+    _hip.require_device()
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    ti, lab = g['train_ind'], g['labels']
+    u, T, plan, stats = gdist.poisson_fit_glx(W, ti, lab[ti], _Solo(), device=0, gather=False, check_every=check_every)
+    assert T == int(g['poisson_gd_T']) == 409
+    full = np.zeros_like(g['poisson_gd_prob'])
+    full[plan.own] = u
+    assert np.array_equal(full, g['poisson_gd_prob'])
+    assert stats['exchanges'] == 0 and stats['graphs'] >= 2
+    # max_iter below the stop iteration, and below min_iter
+    for mi, ma in ((50, 60), (50, 30), (0, 25)):
+        from oracle import gl_oracle as orc
+        u_ref, T_ref = orc.poisson_gd(W, ti, lab[ti], min_iter=mi, max_iter=ma, return_T=True)
+        u2, T2, plan2, _ = gdist.poisson_fit_glx(W, ti, lab[ti], _Solo(), device=0, gather=False, min_iter=mi, max_iter=ma,
+                                                 check_every=check_every)
+        assert T2 == T_ref, (mi, ma)
+        full[plan2.own] = u2
+        assert np.array_equal(full, u_ref), (mi, ma)
+
+
+def _self_halo_plan(P, frac=7):
+    """A one-rank partition with a halo of its own: every `frac`-th row is a boundary row whose record is also kept
+    in the halo region, and all other rows read those records from the halo -- so every sweep needs the exchange
+    (the rank sends its boundary records to itself)."""
+    from scipy import sparse
+    from types import SimpleNamespace
+    P = sparse.csr_matrix(P)
+    n = P.shape[0]
+    is_b = (np.arange(n) % frac) == 0
+    own = np.concatenate([np.flatnonzero(is_b), np.flatnonzero(~is_b)])     # boundary rows first
+    nb = int(is_b.sum())
+    local_of = np.empty(n, dtype=np.int64)
+    local_of[own] = np.arange(n)
+    sub = sparse.csr_matrix(P[own, :])
+    cols = local_of[sub.indices]
+    rows = np.repeat(np.arange(n), np.diff(sub.indptr))
+    redirect = (cols < nb) & (rows >= nb)                                    # interior rows read boundary records from the halo
+    cols = np.where(redirect, n + cols, cols)
+    P_local = sparse.csr_matrix((sub.data, cols.astype(np.int32), sub.indptr), shape=(n, n + nb))
+    P_local.has_sorted_indices = False
+    return SimpleNamespace(P_local=P_local, n_boundary=nb, send_counts=[nb], send_idx=np.arange(nb), recv_counts=[nb], n_global=n,
+                           own=own, n_own=n, n_halo=nb, global_halo=nb)
+
+
+@pytest.mark.parametrize('transport', ['none', 'rccl'])
+def test_glx_dist_one_rank_forced_halo(golden, transport):
+    """The exchange path on ONE rank: boundary records packed, sent to itself (plain copy without a communicator;
+    grouped ncclSend / ncclRecv on a 1-rank RCCL communicator, captured inside the device graphs, with 'rccl'),
+    landing in the halo that the interior rows read.  Results bit-identical to the golden iterates."""
+    from graphlearning_amd import dist as gdist, _hip
+    _hip.require_device()
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    ti, lab = g['train_ind'], g['labels']
+    prob = gdist.poisson_problem(W, ti, lab[ti])
+    plan = _self_halo_plan(prob['P'])
+    comm = _hip.Comm(1, 0, _hip.Comm.unique_id() if transport == 'rccl' else None, 0)
+    assert comm.has_transport() == (transport == 'rccl')
+    ds = gdist.glx_dist_sweep(comm, plan, prob['k'], force_exchange=True)
+    own = plan.own
+    ds.set_problem(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
+    T, ms = ds.run(50, 1000, 8, 0.0)
+    u = ds.fetch()
+    assert T == int(g['poisson_gd_T'])
+    full = np.zeros_like(g['poisson_gd_prob'])
+    full[own] = u
+    assert np.array_equal(full, g['poisson_gd_prob'])
+    st = ds.stats()
+    assert st['exchanging'] and st['exchanges'] >= min(T, 50)
+    T2, ms2 = ds.run(50, 1000, 8, 0.0)          # replay of the captured graphs
+    assert T2 == T and np.array_equal(ds.fetch(), u)
+    print('one-rank forced exchange (%s): T=%d, %.1f us per sweep incl. exchange' % (transport, T, ms2 * 1e3 / max(T, 1)))
+    ds.close()
+    comm.close()
