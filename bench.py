@@ -323,7 +323,10 @@ def run_single(args):
 
 def run_distributed(args):
     from graphlearning_amd import dist_bench
-    dist_bench.main(args)
+    if args.config == 4:
+        dist_bench.main_config4(args)
+    else:
+        dist_bench.main(args)
 
 
 def main():
@@ -331,6 +334,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--config', type=int, default=2, choices=[2, 4],
+                    help='2 (default): BASELINE configs[1], weak scaling over --gpus; 4: configs[3] (blobs d=64), strong scaling of --n vertices')
+    ap.add_argument('--n', type=float, default=1e7, help='vertices of --config 4 (default 10^7; kNN alone is ~110 s on one GPU at that size)')
     ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 counter passes (roofline.traffic = null)')
     ap.add_argument('--no-scale', action='store_true', help='skip the n = 10^6 shard-size line')
     ap.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)
@@ -338,7 +344,7 @@ def main():
     if args.traffic_child:
         traffic_child()
         return
-    if args.gpus > 1 or int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('GLX_BENCH_FORCE_DIST') == '1':
+    if args.gpus > 1 or args.config == 4 or int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('GLX_BENCH_FORCE_DIST') == '1':
         run_distributed(args)
     else:
         run_single(args)

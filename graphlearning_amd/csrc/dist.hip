@@ -19,6 +19,7 @@
 #include "glx_internal.h"
 #include <dlfcn.h>
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -175,6 +176,7 @@ struct glx_dist_sweep {
   hipEvent_t ev_pack = nullptr, ev_x = nullptr, ev0 = nullptr, ev1 = nullptr;
   std::map<long, hipGraphExec_t> graphs;
   bool use_graph = true;
+  bool overlap = true;                       // exchange on its own stream beside the interior rows (else in line on the sweep's stream)
   bool problem_set = false;
   int cur = 0;                               // ring index of the current iterate
   int64_t sweeps_run = 0, exchanges = 0;
@@ -247,6 +249,15 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
   s->n_loc = n_own + n_halo;
   s->n_global = n_global;
   s->use_graph = use_hipgraph != 0;
+  {
+    // HIP runtimes before 7.2 (e.g. the 7.0 copy bundled with torch, which wins when torch is imported first) recurse
+    // without end in hipStreamEndCapture when a second stream forks from and joins back into the capturing stream:
+    // captured sweeps then keep the exchange in line on the one stream; eager sweeps overlap on any runtime.
+    int rt = 0;
+    hipRuntimeGetVersion(&rt);
+    s->overlap = !(s->use_graph && rt < 70200000);
+    if (const char* e = getenv("GLX_DIST_OVERLAP")) s->overlap = atoi(e) != 0;
+  }
   s->thresh = 1.0 / (double)n_global;   // `> 1/n`, ssl.py:667, n = ALL vertices
   int rc = glx_make_layout(C, state_dtype, true, &s->L);
   if (rc) { delete s; return rc; }
@@ -389,29 +400,32 @@ static int enqueue_exchange(glx_dist_sweep* s, void* x) {
   if (!s->exchange) return GLX_OK;
   int rc = enqueue_pack(s, x);
   if (rc) return rc;
-  GLX_HIP(hipEventRecord(s->ev_pack, s->stream));
-  GLX_HIP(hipStreamWaitEvent(s->xstream, s->ev_pack, 0));
+  hipStream_t xs = s->overlap ? s->xstream : s->stream;
+  if (s->overlap) {
+    GLX_HIP(hipEventRecord(s->ev_pack, s->stream));
+    GLX_HIP(hipStreamWaitEvent(s->xstream, s->ev_pack, 0));
+  }
   const size_t rb = (size_t)s->L.ld * s->L.esize;
   if (s->comm->comm) {
     RcclApi* a = rccl_api();
     GLX_NCCL(a->GroupStart());
     for (int r = 0; r < s->comm->nranks; ++r) {
       if (s->send_cnt[r] > 0)
-        GLX_NCCL(a->Send((const char*)s->sendbuf + s->send_off[r] * rb, (size_t)s->send_cnt[r] * rb, ncclUint8, r, s->comm->comm, s->xstream));
+        GLX_NCCL(a->Send((const char*)s->sendbuf + s->send_off[r] * rb, (size_t)s->send_cnt[r] * rb, ncclUint8, r, s->comm->comm, xs));
       if (s->recv_cnt[r] > 0)
-        GLX_NCCL(a->Recv(rec_at(x, s, s->n_own + s->recv_off[r]), (size_t)s->recv_cnt[r] * rb, ncclUint8, r, s->comm->comm, s->xstream));
+        GLX_NCCL(a->Recv(rec_at(x, s, s->n_own + s->recv_off[r]), (size_t)s->recv_cnt[r] * rb, ncclUint8, r, s->comm->comm, xs));
     }
     GLX_NCCL(a->GroupEnd());
   } else if (s->n_send > 0) {   // one rank without a communicator: what it "sends" to itself lands in its own halo
-    GLX_HIP(hipMemcpyAsync(rec_at(x, s, s->n_own), s->sendbuf, (size_t)std::min(s->n_send, s->n_halo) * rb, hipMemcpyDeviceToDevice, s->xstream));
+    GLX_HIP(hipMemcpyAsync(rec_at(x, s, s->n_own), s->sendbuf, (size_t)std::min(s->n_send, s->n_halo) * rb, hipMemcpyDeviceToDevice, xs));
   }
-  GLX_HIP(hipEventRecord(s->ev_x, s->xstream));
+  if (s->overlap) GLX_HIP(hipEventRecord(s->ev_x, s->xstream));
   s->exchanges++;
   return GLX_OK;
 }
 
 static int wait_exchange(glx_dist_sweep* s) {
-  if (!s->exchange) return GLX_OK;
+  if (!s->exchange || !s->overlap) return GLX_OK;
   GLX_HIP(hipStreamWaitEvent(s->stream, s->ev_x, 0));
   return GLX_OK;
 }

@@ -140,3 +140,117 @@ def main(args):
     dist.barrier()
     dist.destroy_process_group()
     sys.stdout.flush()
+
+
+def config4_features(n, world_shards=64, seed=2, d=64, C=10):
+    """Config-4-shaped data (isotropic Gaussian blobs, d = 64, C = 10, centers * 4) from SHARD-LOCAL random
+    streams: shard q of `world_shards` equal blocks uses default_rng([seed, q]), so any rank can produce any block and
+    the data do not depend on the number of GPUs.  Returns (X (n, d) float64, labels (n,) int64)."""
+    centers = np.random.default_rng(seed).normal(size=(C, d)) * 4
+    bounds = [(n * q) // world_shards for q in range(world_shards + 1)]
+    X = np.empty((n, d))
+    labels = np.empty(n, dtype=np.int64)
+    for q in range(world_shards):
+        lo, hi = bounds[q], bounds[q + 1]
+        g = np.random.default_rng([seed, q])
+        labels[lo:hi] = g.integers(0, C, size=hi - lo)
+        X[lo:hi] = centers[labels[lo:hi]] + g.normal(size=(hi - lo, d))
+    return X, labels
+
+
+def main_config4(args):
+    """bench.py --gpus N --config 4: STRONG scaling of config 4 (BASELINE.json configs[3]): n vertices in total (default
+    10^7), d = 64, k = 10, C = 10, Poisson gradient descent with a fixed T = 200 sweeps per step, the graph built sharded
+    (dist_build: every rank searches, symmetrises and plans only its own block of rows) and swept by the library-owned
+    distributed sweep (glx_dist_sweep: RCCL halo exchange captured with the SpMMs)."""
+    import torch
+    import torch.distributed as dist
+    import datetime
+    if 'RANK' not in os.environ:            # plain `python bench.py --config 4`: a one-rank job without a launcher
+        import socket
+        sk = socket.socket()
+        sk.bind(('127.0.0.1', 0))
+        os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(sk.getsockname()[1]))
+        sk.close()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=datetime.timedelta(minutes=20))
+    import bench
+    import graphlearning_amd as gl
+    from graphlearning_amd import _hip, dist as gdist, dist_build
+    _hip.set_default_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    n, K, T = int(args.n), 10, 200
+    t0 = time.perf_counter()
+    X, labels = config4_features(n)
+    t_feat = time.perf_counter() - t0
+    bounds = gdist.block_bounds(n, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    t0 = time.perf_counter()
+    J, D = _hip.knn_bruteforce(X, K + 1, device=local_rank, query_range=(lo, hi))
+    st = _hip.knn_stats()
+    t_knn = time.perf_counter() - t0
+    del X
+    t0 = time.perf_counter()
+    sg = dist_build.ShardedGraph(dist, n, J, D, K, device=dev)
+    del J, D
+    train_ind = gl.trainsets.generate(labels, rate=5, seed=0)
+    prob = sg.poisson_problem_rows(train_ind, labels[train_ind])
+    t_build = time.perf_counter() - t0
+    comm = gdist.init_comm(dist, local_rank)
+    ds = gdist.glx_dist_sweep(comm, sg.plan, prob['k'], force_exchange=gdist._force_collectives())
+    ds.set_problem(prob['Db'], prob['w0'], prob['deg'], prob['vinf'])
+    for _ in range(max(args.warmup, 1)):
+        ds.run(T, T, 8, 0.0)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms_dev = 0.0
+    for _ in range(args.steps):
+        _, ms = ds.run(T, T, 8, 0.0)
+        ms_dev += ms
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    stats = torch.tensor([sg.plan.n_halo, sg.plan.n_own, int(sg.W_own.nnz), sg.plan.n_boundary], dtype=torch.int64, device=dev)
+    allst = [torch.zeros_like(stats) for _ in range(world)]
+    dist.all_gather(allst, stats)
+    u_own = ds.fetch()
+    pred = np.argmax(u_own, axis=1)
+    hit = torch.tensor([int(np.sum(pred == labels[sg.plan.own])), len(pred)], dtype=torch.int64, device=dev)
+    dist.all_reduce(hit)
+    if rank == 0:
+        nnz = int(sum(int(a[2]) for a in allst))
+        wall = float(dt.item())
+        iters = args.steps * T / wall
+        abytes = bench.algorithmic_bytes(n, nnz, 10, 8, 8)
+        line = {
+            'metric': 'Poisson iters/sec', 'value': iters, 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': 'configs[3]: Gaussian blobs n=%d d=64 k=10 C=10, ssl.poisson gradient_descent with T=%d fixed sweeps per '
+                                   'step, vertex-sharded over %d GPUs (contiguous id blocks; sharded kNN search, symmetrisation by owner '
+                                   'rank, request-based halo plan), RCCL all-to-all-v halo exchange per sweep' % (n, T, world),
+                       'n': n, 'nnz': nnz, 'classes': 10, 'sweeps_per_step': T, 'parallelism': 'vertex-partition x%d' % world},
+            'edges_classes_per_sec': iters * nnz * 10,
+            'roofline': {'bound': 'hbm', 'achieved': abytes * iters / 1e9, 'peak': bench.HBM_PEAK_GBS * world, 'unit': 'GB/s',
+                         'frac': abytes * iters / 1e9 / (bench.HBM_PEAK_GBS * world), 'traffic': None,
+                         'note': 'whole-job algorithmic bytes per sweep / wall time incl. halo exchange; the kernel is bound by random '
+                                 '128-byte line gathers (one per stored edge), see DESIGN.md 4.1'},
+            'cpu_baseline': None,
+            'halo': {'rows_per_rank': [int(a[0]) for a in allst], 'owned_per_rank': [int(a[1]) for a in allst],
+                     'boundary_rows_per_rank': [int(a[3]) for a in allst]},
+            'build': {'features_s': t_feat, 'knn_own_rows_s': t_knn, 'knn_tile_tflops_rank0': 2.0 * (hi - lo) * n * st['dpa'] / st['tile_ms'] / 1e9,
+                      'symmetrise_plan_s': t_build},
+            'accuracy_percent': 100.0 * int(hit[0]) / max(int(hit[1]), 1),
+        }
+        print(json.dumps(line))
+    ds.close()
+    comm.close()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.stdout.flush()

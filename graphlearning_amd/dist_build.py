@@ -1,0 +1,290 @@
+"""Sharded graph build and planning for the vertex-partitioned sweep: O(n/N) graph data per rank.
+
+`dist.py`'s first planner has every rank hold the whole weight matrix and derive every rank's halo.  That is fine at
+N x 70 000 vertices and hopeless at config 4 (n = 10^7: 183 M stored entries per rank on the host).  Here every rank
+only ever touches its own block of rows [lo, hi) of the ORIGINAL vertex numbering:
+
+  1. kNN lists of its own query rows (glx_knn_bruteforce_range; every rank holds the features -- the one O(n d)
+     array the brute-force search needs everywhere);
+  2. symmetrisation by owner rank: each list entry (i -> j, w) is also needed by the owner of row j, so the
+     entries are routed to their owners with one all-to-all-v of (j, i, w) triples, and every rank assembles ITS
+     rows of W = (A + A^T)/2 from its own lists and the triples it received -- with the reference's own scipy
+     expressions (weightmatrix.py:170-186) applied to the row block, so the rows are bit-identical to the rows of
+     the reference's W;
+  3. degrees, D^-1 and its rows of P = D^-1 W^T locally (W is symmetric bit for bit, so row i of W^T is row i of
+     W; the product is formed by scipy on the block, which yields the same entry order as the reference's global
+     product: the accumulation order of the sweep);
+  4. halo planning with a request exchange: the rank lists the remote columns its rows reference (grouped by
+     owner = ascending id), sends each owner its request list, and builds its send lists from the requests it
+     receives.  No rank computes another rank's halo.
+
+The only O(n) arrays a rank holds are 8-byte-per-vertex vectors (labels, degrees -- `vinf = deg / np.sum(deg)`
+needs the global sum in numpy's own summation order to stay bit-identical) and the features.
+Functions taking `msgs` work on plain numpy data (unit-testable without processes); `ShardedGraph.build` drives them
+through torch.distributed.
+"""
+import numpy as np
+from scipy import sparse
+
+from .dist import block_bounds
+
+
+# ---- step 2: symmetrisation by owner -------------------------------------------------------------------------------
+def knn_weights_rows(J, D, k, kernel='gaussian'):
+    """Kernel weights of a block of kNN lists (reference weightmatrix.py:134-156; every kernel here needs only the
+    row's own distances).  k counts the self point."""
+    k = int(min(J.shape[1], k))
+    J, D = J[:, :k], D[:, :k]
+    if kernel == 'uniform':
+        w = np.ones_like(D)
+    elif kernel == 'gaussian':
+        sq = D * D
+        eps = sq[:, k - 1]
+        w = np.exp(-4 * sq / eps[:, None])
+    elif kernel == 'distance':
+        w = D
+    elif kernel == 'singular':
+        w = D.copy()
+        w[D == 0] = 1
+        w = 1 / w
+    else:
+        raise ValueError("kernel %r needs remote rows' bandwidths; the sharded build supports uniform, gaussian, distance, singular" % (kernel,))
+    return J, w
+
+
+def reverse_messages(J, w, lo, bounds):
+    """For the list entries (i -> j, w_ij) of the rows [lo, lo+len(J)): the triples (j, i, w_ij) the owner of row j
+    needs, per destination rank, in list order (row after row, neighbour after neighbour)."""
+    n_rows, k = J.shape
+    rows_i = np.repeat(np.arange(lo, lo + n_rows, dtype=np.int64), k)
+    cols_j = J.reshape(-1).astype(np.int64)
+    vals = np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
+    dest = np.searchsorted(bounds, cols_j, side='right') - 1
+    order = np.argsort(dest, kind='stable')                     # stable: list order survives inside a destination
+    counts = np.bincount(dest, minlength=len(bounds) - 1)
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    out = []
+    for r in range(len(bounds) - 1):
+        sel = order[offs[r]:offs[r + 1]]
+        out.append((cols_j[sel], rows_i[sel], vals[sel]))
+    return out
+
+
+def assemble_rows(lo, hi, n, J, w, received, symmetrize=True, sym_rule='mean'):
+    """Rows [lo, hi) of the weight matrix of weightmatrix.knn from the block's own lists (J, w) and the reverse triples
+    `received` (list over source ranks, in rank order, of (j, i, w_ij) with j in [lo, hi)).  The reference's expressions
+    (weightmatrix.py:170-186) on the row block: COO -> CSR sums duplicates, (W + W^T)/2 or the element-wise max,
+    zero diagonal, explicit zeros dropped."""
+    m = hi - lo
+    k = J.shape[1]
+    rows = (np.ones((m, k)) * np.arange(m)[:, None]).flatten()           # float row ids like weightmatrix.py:171
+    A = sparse.coo_matrix((np.asarray(w).flatten(), (rows, J.flatten())), shape=(m, n)).tocsr()
+    if symmetrize:
+        if received:
+            rj = np.concatenate([t[0] for t in received]) - lo
+            ri = np.concatenate([t[1] for t in received])
+            rv = np.concatenate([t[2] for t in received])
+        else:
+            rj, ri, rv = np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0)
+        # row j of A^T = the entries (i -> j): ordered by source row i like the transpose of a canonical CSR
+        AT = sparse.coo_matrix((rv, (rj, ri)), shape=(m, n)).tocsr()
+        if sym_rule == 'mean':
+            W = (A + AT) / 2
+        elif sym_rule == 'max':                                           # utils.sparse_max (utils.py:263-286)
+            nz = (A + AT) > 0
+            b_wins = AT > A
+            a_wins = nz - b_wins
+            W = A.multiply(a_wins) + AT.multiply(b_wins)
+        else:
+            raise ValueError(sym_rule)
+    else:
+        W = A
+    W = sparse.csr_matrix(W)
+    # setdiag(0) + eliminate_zeros on the block: the diagonal of row r is column lo + r
+    rr = np.repeat(np.arange(m), np.diff(W.indptr))
+    W.data[W.indices == rr + lo] = 0
+    W.eliminate_zeros()
+    W.sort_indices()
+    return W
+
+
+# ---- step 3: rows of the Poisson operator --------------------------------------------------------------------------
+def poisson_rows(W_own):
+    """deg, D^-1 and the rows of P = D^-1 W^T for a block of rows of a SYMMETRIC W (ssl.py:615-617, 634-635): row i of
+    W^T is row i of W bit for bit, and `D * rows` through scipy's csr product leaves every row's entries in the order
+    the reference's global product leaves them (the accumulation order of `P*u`)."""
+    m, n = W_own.shape
+    deg = W_own * np.ones(n)                                               # graph.degree_vector: csr row sums in stored order
+    D = sparse.spdiags(deg ** (-1), 0, m, m).tocsr()                      # graph.degree_matrix(p=-1): d**p
+    P = D * W_own
+    return sparse.csr_matrix(P), deg, D
+
+
+# ---- step 4: halo planning with a request exchange -----------------------------------------------------------------
+def halo_requests(P_own, lo, hi, bounds):
+    """The remote columns the block's rows reference: (needed ids ascending = grouped by owner, per-owner request lists)."""
+    cols = np.unique(P_own.indices)
+    needed = cols[(cols < lo) | (cols >= hi)].astype(np.int64)
+    owner = np.searchsorted(bounds, needed, side='right') - 1
+    reqs = [needed[owner == r] for r in range(len(bounds) - 1)]
+    return needed, reqs
+
+
+class ShardPlan:
+    """The fields dist.RankPlan has, built from the rank's own rows and the requests its peers sent (no global matrix)."""
+
+    def __init__(self, P_own, lo, hi, n, rank, bounds, needed, requests_from_peers, global_halo):
+        world = len(bounds) - 1
+        self.rank, self.world, self.n_global = rank, world, n
+        m = hi - lo
+        self.n_own = m
+        self.halo = needed
+        self.n_halo = len(needed)
+        owner = np.searchsorted(bounds, needed, side='right') - 1
+        self.recv_counts = [int(np.sum(owner == r)) for r in range(world)]
+        send = [np.asarray(requests_from_peers[r], dtype=np.int64) - lo if r != rank else np.zeros(0, np.int64) for r in range(world)]
+        self.send_counts = [len(x) for x in send]
+        send_idx = np.concatenate(send) if send else np.zeros(0, np.int64)
+        self.global_halo = int(global_halo)
+        is_b = np.zeros(m, dtype=bool)
+        is_b[send_idx] = True
+        perm_local = np.concatenate([np.flatnonzero(is_b), np.flatnonzero(~is_b)])      # boundary rows first
+        new_of_old = np.empty(m, dtype=np.int64)
+        new_of_old[perm_local] = np.arange(m)
+        self.own = lo + perm_local                                                       # global ids in local order
+        self.send_idx = new_of_old[send_idx]
+        self.n_boundary = int(is_b.sum())
+        sub = sparse.csr_matrix(P_own[perm_local, :])                                    # row slicing keeps each row's entry order
+        cols = sub.indices.astype(np.int64)
+        local = np.where((cols >= lo) & (cols < hi), new_of_old[np.clip(cols - lo, 0, max(m - 1, 0))],
+                         m + np.searchsorted(needed, cols))
+        self.P_local = sparse.csr_matrix((sub.data, local.astype(np.int32), sub.indptr), shape=(m, m + self.n_halo))
+        self.P_local.has_sorted_indices = False
+
+
+# ---- driver over torch.distributed ---------------------------------------------------------------------------------
+def _alltoallv(dist, arrays, dtype, group=None, device=None):
+    """Variable all-to-all of 1-D numpy arrays (one per destination) -> list per source."""
+    import torch
+    world = dist.get_world_size(group)
+    tdt = {np.int64: torch.int64, np.float64: torch.float64}[dtype]
+    counts = torch.tensor([len(a) for a in arrays], dtype=torch.int64)
+    rcounts = torch.empty(world, dtype=torch.int64)
+    dev = device if dist.get_backend(group) == 'nccl' else None
+    if dev is not None:
+        counts, rcounts = counts.to(dev), rcounts.to(dev)
+    dist.all_to_all_single(rcounts, counts, group=group)
+    rc = [int(x) for x in rcounts.cpu()]
+    send = torch.from_numpy(np.ascontiguousarray(np.concatenate(arrays) if arrays else np.zeros(0), dtype=dtype))
+    recv = torch.empty(sum(rc), dtype=tdt)
+    if dev is not None:
+        send, recv = send.to(dev), recv.to(dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=[len(a) for a in arrays], group=group)
+    out = recv.cpu().numpy()
+    offs = np.concatenate([[0], np.cumsum(rc)])
+    return [out[offs[r]:offs[r + 1]] for r in range(world)]
+
+
+class ShardedGraph:
+    """One rank's rows of the kNN weight matrix and of the Poisson operator plus its exchange plan, built collectively."""
+
+    def __init__(self, dist, n, J_own, D_own, k, kernel='gaussian', symmetrize=True, group=None, device=None):
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        self.dist, self.group, self.rank, self.world, self.n = dist, group, rank, world, n
+        self.bounds = bounds = block_bounds(n, world)
+        self.lo, self.hi = lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        assert J_own.shape[0] == hi - lo
+        J, w = knn_weights_rows(np.asarray(J_own), np.asarray(D_own), k + 1, kernel)
+        sym_rule = 'max' if kernel in ('distance', 'uniform', 'singular') else 'mean'
+        received = None
+        if symmetrize:
+            msgs = reverse_messages(J, w, lo, bounds)
+            rj = _alltoallv(dist, [m[0] for m in msgs], np.int64, group, device)
+            ri = _alltoallv(dist, [m[1] for m in msgs], np.int64, group, device)
+            rv = _alltoallv(dist, [m[2] for m in msgs], np.float64, group, device)
+            received = list(zip(rj, ri, rv))
+        self.W_own = assemble_rows(lo, hi, n, J, w, received, symmetrize, sym_rule)
+        self.P_own, self.deg_own, self.D_own = poisson_rows(self.W_own)
+        needed, reqs = halo_requests(self.P_own, lo, hi, bounds)
+        got = _alltoallv(dist, reqs, np.int64, group, device)
+        import torch
+        tot = torch.tensor([len(needed)], dtype=torch.int64)
+        if dist.get_backend(group) == 'nccl' and device is not None:
+            tot = tot.to(device)
+        dist.all_reduce(tot, group=group)
+        self.plan = ShardPlan(self.P_own, lo, hi, n, rank, bounds, needed, got, int(tot.item()))
+
+    def all_degrees(self):
+        """deg of every vertex on every rank (8 bytes per vertex): `vinf = deg / np.sum(deg)` needs numpy's own sum."""
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, self.deg_own, group=self.group)
+        return np.concatenate(parts)
+
+    def poisson_problem_rows(self, train_ind, train_labels):
+        """This rank's rows (local order) of Db, w0, deg, vinf for ssl.poisson(gradient_descent) (ssl.py:619-622, 636-644)."""
+        from . import utils
+        train_ind = np.asarray(train_ind)
+        k = len(np.unique(train_labels))
+        onehot = utils.labels_to_onehot(np.asarray(train_labels), k)
+        rows_src = onehot - np.mean(onehot, axis=0)
+        deg_all = self.all_degrees()
+        vinf_all = deg_all / np.sum(deg_all)
+        own = self.plan.own
+        Db = np.zeros((len(own), k))
+        w0 = np.zeros(len(own))
+        pos_of = {int(g): p for p, g in enumerate(own)} if len(train_ind) < 4096 else None
+        vval = 1.0 / float(len(train_ind))
+        for q, t in enumerate(train_ind):
+            t = int(t)
+            if self.lo <= t < self.hi:
+                p = pos_of[t] if pos_of is not None else int(np.flatnonzero(own == t)[0])
+                Db[p] = (deg_all[t] ** (-1)) * rows_src[q]      # row of D*source: one product per entry
+                w0[p] = vval / deg_all[t]
+        return dict(Db=Db, w0=w0, deg=deg_all[own], vinf=vinf_all[own], k=k, deg_all=deg_all, vinf_all=vinf_all)
+
+
+def poisson_fit_sharded(dist, n, J_own, D_own, k, train_ind, train_labels, engine='glx', ops_factory=None, comm=None, device=None,
+                        min_iter=50, max_iter=1000, kernel='gaussian', group=None, check_every=8, gather=True, dtype=np.float64):
+    """weightmatrix.knn + ssl.poisson(solver='gradient_descent').fit with every rank holding only its block of rows:
+    (J_own, D_own) are the kNN lists (self included, k+1 columns) of the rank's rows [lo, hi) of block_bounds(n, world).
+    engine 'glx': the library-owned sweep (glx_dist_sweep over a libglx RCCL communicator); 'ops': dist.DistSweep with
+    the rank-local kernel from ops_factory(plan, classes) (CPU tests).  Returns (u, T, sharded graph); u is the full
+    (n, C) matrix (gather=True) or this rank's rows in plan.own order."""
+    from . import dist as gdist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    sg = ShardedGraph(dist, n, J_own, D_own, k, kernel=kernel, group=group, device=device)
+    prob = sg.poisson_problem_rows(train_ind, train_labels)
+    plan = sg.plan
+    err0 = 0.0
+    if min_iter == 0:
+        v = np.zeros(n)
+        v[np.asarray(train_ind)] = 1.0 / float(len(train_ind))
+        err0 = float(np.max(np.absolute(v - prob['vinf_all'])))
+    if engine == 'glx':
+        own_comm = comm is None
+        if comm is None:
+            comm = gdist.init_comm(dist, device, group)
+        ds = gdist.glx_dist_sweep(comm, plan, prob['k'], dtype=dtype, force_exchange=gdist._force_collectives())
+        ds.set_problem(prob['Db'], prob['w0'], prob['deg'], prob['vinf'])
+        T, _ = ds.run(min_iter, max_iter, check_every, err0)
+        u_own = ds.fetch()
+        ds.close()
+        if own_comm:
+            comm.close()
+    else:
+        ops = ops_factory(plan, prob['k'])
+        sweep = gdist.DistSweep(plan, ops, dist, group)
+        sweep.setup(prob['Db'], prob['w0'], prob['deg'], prob['vinf'])
+        T = sweep.run(min_iter, max_iter, err0 if min_iter == 0 else None)
+        u_own = sweep.result_own()
+        sweep.close()
+        if hasattr(ops, 'close'):
+            ops.close()
+    if not gather:
+        return u_own, T, sg
+    parts = [None] * world
+    dist.all_gather_object(parts, (plan.own, u_own), group=group)
+    u = np.zeros((n, prob['k']), dtype=u_own.dtype)
+    for ids, block in parts:
+        u[ids] = block
+    return u, T, sg

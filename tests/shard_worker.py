@@ -1,0 +1,77 @@
+"""Worker of tests/test_dist_gloo.py::test_sharded_build_*: one rank of a gloo job building ITS rows of the kNN weight
+matrix / Poisson operator / exchange plan with graphlearning_amd.dist_build (no rank holds the whole matrix) and
+running the distributed sweep with a scipy stand-in for the rank-local kernel; everything is compared with the
+single-process oracle."""
+import os
+import sys
+import json
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch.distributed as dist
+from scipy import sparse
+from graphlearning_amd import dist as gdist, dist_build
+from dist_worker import ScipyOps
+
+
+def main():
+    case, out_path = sys.argv[1], sys.argv[2]
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from conftest import blobs
+    from oracle import gl_oracle as orc
+    kernel = 'gaussian'
+    min_iter, max_iter = 50, 400
+    if case == 'blobs':
+        X, lab = blobs(1500, 8, 4, 21, 2.5)
+        k = 8
+    elif case == 'uniform':
+        X, lab = blobs(900, 5, 3, 4, 2.0)
+        k = 6
+        kernel = 'uniform'
+    elif case == 'miniter0':
+        X, lab = blobs(700, 6, 3, 9, 3.0)
+        k = 7
+        min_iter, max_iter = 0, 40
+    else:
+        raise SystemExit('unknown case')
+    n = X.shape[0]
+    J, D = orc.knnsearch(X, k + 1)                       # every rank could search its own rows; the lists are the input here
+    ti = orc.trainsets_generate(lab, rate=3, seed=2)
+    tl = lab[ti]
+    bounds = gdist.block_bounds(n, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    u, T, sg = dist_build.poisson_fit_sharded(dist, n, J[lo:hi], D[lo:hi], k, ti, tl, engine='ops', ops_factory=lambda plan, C: ScipyOps(plan, C),
+                                             min_iter=min_iter, max_iter=max_iter, kernel=kernel)
+    # oracle: the whole pipeline in one process
+    W = orc.knn_weights(J, D, k, kernel=kernel)
+    W.sort_indices()
+    s = orc.poisson_gd_setup(W, ti, tl)
+    u_ref, T_ref = orc.poisson_gd(W, ti, tl, min_iter=min_iter, max_iter=max_iter, return_T=True)
+    Wb = sparse.csr_matrix(W[lo:hi, :])
+    Pb = sparse.csr_matrix(s['P'])[lo:hi, :]
+    w_ok = (np.array_equal(sg.W_own.indptr, Wb.indptr) and np.array_equal(sg.W_own.indices, Wb.indices)
+            and np.array_equal(sg.W_own.data, Wb.data))
+    p_ok = (np.array_equal(sg.P_own.indptr, Pb.indptr) and np.array_equal(sg.P_own.indices, Pb.indices)      # entry ORDER included
+            and np.array_equal(sg.P_own.data, Pb.data))
+    deg_ok = np.array_equal(sg.deg_own, s['deg'][lo:hi])
+    # the plan equals the one the global planner derives for the same blocks
+    ref_plan = gdist.RankPlan(s['P'], np.arange(n), bounds, rank)
+    pl = sg.plan
+    plan_ok = (np.array_equal(pl.own, ref_plan.own) and np.array_equal(pl.halo, ref_plan.halo) and pl.send_counts == ref_plan.send_counts
+               and pl.recv_counts == ref_plan.recv_counts and np.array_equal(pl.send_idx, ref_plan.send_idx)
+               and pl.n_boundary == ref_plan.n_boundary and pl.global_halo == ref_plan.global_halo
+               and np.array_equal(pl.P_local.indices, ref_plan.P_local.indices) and np.array_equal(pl.P_local.data, ref_plan.P_local.data)
+               and np.array_equal(pl.P_local.indptr, ref_plan.P_local.indptr))
+    res = dict(rank=rank, world=world, T=int(T), T_ref=int(T_ref), equal=bool(np.array_equal(u, u_ref)), w_ok=bool(w_ok), p_ok=bool(p_ok),
+               deg_ok=bool(deg_ok), plan_ok=bool(plan_ok), n_halo=int(pl.n_halo), nnz_own=int(sg.W_own.nnz))
+    with open(out_path + '.%d' % rank, 'w') as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -108,6 +108,15 @@ class _Solo:
     def broadcast_object_list(self, lst, src=0, group=None):
         pass
 
+    def get_backend(self, group=None):
+        return 'gloo'
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+        out.copy_(inp)
+
+    def all_reduce(self, t, op=None, group=None):
+        pass
+
 
 @pytest.mark.parametrize('check_every', [1, 8, 5])
 def test_glx_dist_one_rank_tail_chunks_match_golden(golden, check_every):
@@ -190,3 +199,29 @@ def test_glx_dist_one_rank_forced_halo(golden, transport):
     print('one-rank forced exchange (%s): T=%d, %.1f us per sweep incl. exchange' % (transport, T, ms2 * 1e3 / max(T, 1)))
     ds.close()
     comm.close()
+
+
+def test_sharded_build_and_glx_sweep_one_rank(golden):
+    """dist_build (rows of W, P and the plan from the rank's own kNN lists) + the library-owned sweep on one rank: the
+    pipeline the multi-GPU config-4 run uses, against the golden n = 5000 case (W from the reference, iterates, T)."""
+    from graphlearning_amd import dist_build, _hip
+    _hip.require_device()
+    g = golden('g3_blobs5000.npz')
+    J, D = g['knn_ind'], g['knn_dist']
+    ti, lab = g['train_ind'], g['labels']
+    u, T, sg = dist_build.poisson_fit_sharded(_Solo(), 5000, J, D, 10, ti, lab[ti], engine='glx', device=0)
+    Wr = csr_from(g, 'W')
+    assert np.array_equal(sg.W_own.indptr, Wr.indptr) and np.array_equal(sg.W_own.indices, Wr.indices)
+    assert np.array_equal(sg.W_own.data, Wr.data)
+    assert T == int(g['poisson_gd_T']) and np.array_equal(u, g['poisson_gd_prob'])
+
+
+def test_config4_bench_entry_one_rank():
+    """bench.py --config 4 (strong-scaling harness of BASELINE configs[3]) end to end on one GPU at n = 300 000."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', '4', '--n', '300000', '--steps', '1', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert j['scaling'] == 'strong' and j['config']['n'] == 300000 and j['config']['sweeps_per_step'] == 200
+    assert j['accuracy_percent'] > 99.0 and j['value'] > 0
+    print(json.dumps(j)[:600])
