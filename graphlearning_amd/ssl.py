@@ -729,13 +729,19 @@ class randomwalk(ssl):
 
 def ssl_accuracy(pred_labels, true_labels, train_ind):
     """Accuracy in percent over nodes outside train_ind with a true label >= 0
-    (reference ssl.py:1795-1834)."""
-    mask = np.ones(len(pred_labels), dtype=bool)
+    (reference ssl.py:1795-1834: `100*np.mean(pred[mask] == true[mask])` over the masked arrays).  The same number from
+    counts instead of boolean-indexed copies: np.mean of a 0/1 array is (exact count)/(length) in float64."""
+    pred_labels = np.asarray(pred_labels)
+    true_labels = np.asarray(true_labels)
     if type(train_ind) != np.ndarray:
         print('Warning: ssl_accuracy requires the indices of the labeled points, not just the number of labels.')
+        t = np.zeros(0, dtype=np.int64)
     else:
-        mask[train_ind] = False
-    pred_labels = np.asarray(pred_labels)[mask]
-    true_labels = np.asarray(true_labels)[mask]
-    keep = true_labels >= 0
-    return 100 * np.mean(pred_labels[keep] == true_labels[keep])
+        t = np.unique(train_ind)
+    valid = true_labels >= 0
+    hit = (pred_labels == true_labels) & valid
+    total = int(np.count_nonzero(valid)) - int(np.count_nonzero(valid[t]))
+    hits = int(np.count_nonzero(hit)) - int(np.count_nonzero(hit[t]))
+    if total == 0:
+        return 100 * np.mean(np.zeros(0, dtype=bool))          # nan (+ numpy's warning), like the reference
+    return 100 * (np.float64(hits) / np.float64(total))

@@ -49,3 +49,12 @@ if prof:
     s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(14); print(s.getvalue()[:3000])
 t, _ = timed(lambda: m.fit(ti3, lab3[ti3]))
 print('config 3 ssl.laplace.fit: %.1f ms, %d CG iterations, accuracy %.2f%%' % (t * 1e3, m.num_iter, gl.ssl.ssl_accuracy(m.predict(), lab3, ti3)))
+mt = gl.ssl.laplace(W3, reduce='tree')
+mt.fit(ti3, lab3[ti3])
+t, _ = timed(lambda: mt.fit(ti3, lab3[ti3]))
+print('config 3 ssl.laplace(reduce=tree).fit: %.1f ms, %d CG iterations, labels identical to exact: %s' % (
+    t * 1e3, mt.num_iter, bool(np.array_equal(mt.predict(), m.predict()))))
+# one-shot cost (fresh model: operator set-up + upload + first fit) and fit_predict on a resident model
+t0 = time.perf_counter(); m1 = gl.ssl.poisson(W, solver='gradient_descent'); p1 = m1.fit_predict(train_ind, labels[train_ind]); t1 = time.perf_counter() - t0
+t, _ = timed(lambda: m1.fit_predict(train_ind, labels[train_ind]), 5)
+print('config 2 ssl.poisson(gradient_descent): fresh model fit_predict %.1f ms; resident fit_predict %.2f ms (labels only come back)' % (t1 * 1e3, t * 1e3))

@@ -136,6 +136,7 @@ def test_ssl_trials_shared_over_ranks(tmp_path):
     assert len(res[0]['rows']) == 12
     for k in range(3):
         assert res[k]['rows'] == res[0]['seq']            # same rows, same order as the one-process loop
+        assert res[k]['refused'] and res[k]['fits_after_refusal'] == 0     # existing file, overwrite=False: no work is done, on any rank
     text = open(os.path.join(out + '_results', 'd__stub_accuracy.csv')).read().splitlines()
     assert text[0] == 'Number of labels,Accuracy' and text[1:] == res[0]['seq']
 

@@ -43,8 +43,18 @@ def main():
     glssl.results_dir = out + '_results'
     rows = gdist.ssl_trials_distributed(nearest_label(W), trainsets, labels, dist, tag='d_', overwrite=True)
     seq = list(nearest_label(W)._trial_rows(trainsets, labels))
+    # the results file exists now: without overwrite every rank must refuse BEFORE running a single trial
+    # (reference ssl.py:330-337), consistently across the ranks
+    class counting(nearest_label):
+        fits = 0
+
+        def _fit(self, *a, **k):
+            counting.fits += 1
+            return super()._fit(*a, **k)
+    dist.barrier()
+    again = gdist.ssl_trials_distributed(counting(W), trainsets, labels, dist, tag='d_', overwrite=False)
     with open(out + '.%d' % rank, 'w') as f:
-        json.dump(dict(rows=rows, seq=seq), f)
+        json.dump(dict(rows=rows, seq=seq, refused=again is None, fits_after_refusal=counting.fits), f)
     dist.barrier()
     dist.destroy_process_group()
 
