@@ -631,8 +631,8 @@ def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None):
     X = np.ascontiguousarray(X)
     n, d = X.shape
     q0, q1 = (0, n) if query_range is None else query_range
-    ind = np.empty((q1 - q0, k), dtype=np.int64)
-    dist = np.empty((q1 - q0, k), dtype=np.float64)
+    ind = pinned_empty((q1 - q0, k), np.int64)       # page-locked result arrays: the copy back runs at PCIe speed
+    dist = pinned_empty((q1 - q0, k), np.float64)
     check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
           'glx_knn_bruteforce')
     return ind, dist

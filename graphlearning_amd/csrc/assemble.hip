@@ -6,6 +6,7 @@
 // row merges its forward and reverse lists with a bitonic sort in LDS and applies the
 // symmetrisation rule per column.  Output: canonical CSR (sorted, no duplicates, no zeros).
 #include "glx_internal.h"
+#define GLX_POOL(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 #include <algorithm>
 #include <vector>
 #include <utility>
@@ -186,8 +187,9 @@ struct AsmBufs {
   int *rcnt = nullptr, *cursor = nullptr, *rsrc = nullptr, *rowcnt = nullptr, *col = nullptr, *flag = nullptr;
   hipStream_t stream = nullptr;
   ~AsmBufs() {
-    hipFree(ind); hipFree(roff); hipFree(rowptr); hipFree(dist); hipFree(given); hipFree(w); hipFree(rw); hipFree(val);
-    hipFree(rcnt); hipFree(cursor); hipFree(rsrc); hipFree(rowcnt); hipFree(col); hipFree(flag);
+    if (stream) hipStreamSynchronize(stream);   // pooled blocks are reused at once
+    glx_pool_free(ind); glx_pool_free(roff); glx_pool_free(rowptr); glx_pool_free(dist); glx_pool_free(given); glx_pool_free(w); glx_pool_free(rw); glx_pool_free(val);
+    glx_pool_free(rcnt); glx_pool_free(cursor); glx_pool_free(rsrc); glx_pool_free(rowcnt); glx_pool_free(col); glx_pool_free(flag);
     if (stream) hipStreamDestroy(stream);
   }
 };
@@ -206,25 +208,25 @@ extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const doub
   GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
   hipStream_t st = b.stream;
   const int64_t ne = n * k;
-  GLX_HIP(hipMalloc(&b.ind, (size_t)n * kk * 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.ind, (size_t)n * kk * 8));
   GLX_HIP(hipMemcpyAsync(b.ind, ind, (size_t)n * kk * 8, hipMemcpyHostToDevice, st));
   if (dist) {
-    GLX_HIP(hipMalloc(&b.dist, (size_t)n * kk * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.dist, (size_t)n * kk * 8));
     GLX_HIP(hipMemcpyAsync(b.dist, dist, (size_t)n * kk * 8, hipMemcpyHostToDevice, st));
   }
   if (kernel == K_GIVEN) {
-    GLX_HIP(hipMalloc(&b.given, ne * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.given, ne * 8));
     GLX_HIP(hipMemcpyAsync(b.given, weights, ne * 8, hipMemcpyHostToDevice, st));
   }
-  GLX_HIP(hipMalloc(&b.w, ne * 8));
-  GLX_HIP(hipMalloc(&b.rcnt, (n + 1) * 4));
-  GLX_HIP(hipMalloc(&b.cursor, (n + 1) * 4));
-  GLX_HIP(hipMalloc(&b.roff, (n + 1) * 8));
-  GLX_HIP(hipMalloc(&b.rowptr, (n + 1) * 8));
-  GLX_HIP(hipMalloc(&b.rowcnt, (n + 1) * 4));
-  GLX_HIP(hipMalloc(&b.rsrc, ne * 4));
-  GLX_HIP(hipMalloc(&b.rw, ne * 8));
-  GLX_HIP(hipMalloc(&b.flag, 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.w, ne * 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.rcnt, (n + 1) * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.cursor, (n + 1) * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.roff, (n + 1) * 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.rowptr, (n + 1) * 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.rowcnt, (n + 1) * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.rsrc, ne * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.rw, ne * 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.flag, 8));
   GLX_HIP(hipMemsetAsync(b.rcnt, 0, (n + 1) * 4, st));
   GLX_HIP(hipMemsetAsync(b.cursor, 0, (n + 1) * 4, st));
   GLX_HIP(hipMemsetAsync(b.flag, 0, 8, st));
@@ -299,8 +301,8 @@ extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const doub
   const int64_t nnz = rp[n];
   GLX_CHECK(nnz < (1ll << 31), GLX_EUNSUPPORTED, "glx_knn_to_csr: nnz %lld does not fit the int32 CSR of the reference", (long long)nnz);
   GLX_HIP(hipMemcpyAsync(b.rowptr, rp.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
-  GLX_HIP(hipMalloc(&b.col, std::max<size_t>(nnz * 4, 4)));
-  GLX_HIP(hipMalloc(&b.val, std::max<size_t>(nnz * 8, 8)));
+  GLX_POOL(glx_pool_alloc((void**)&b.col, std::max<size_t>(nnz * 4, 4)));
+  GLX_POOL(glx_pool_alloc((void**)&b.val, std::max<size_t>(nnz * 8, 8)));
   hipLaunchKernelGGL(merge_rows_kernel, dim3(gr), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, n, kk, k,
                      (const int64_t*)b.roff, (const int*)b.rsrc, (const double*)b.rw, sym, 1, b.rowcnt, (const int64_t*)b.rowptr,
                      b.col, b.val, b.flag + 1);

@@ -6,6 +6,7 @@
 // atomics).  The host reads the residual history in chunks; kernels of iterations past
 // convergence exit at once (same trick as the sweep's stop column).
 #include "glx_internal.h"
+#include <map>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -514,6 +515,8 @@ __global__ __launch_bounds__(256) void cg_zero_rows_kernel(T* __restrict__ ap, i
   ap[(size_t)row * ld + g * Cg + idx % Cg] = (T)0;
 }
 
+// Work buffers of a solve.  They live with the operator (glx_graph::cg_ws) and are reused by later solves on it:
+// a dozen hipMalloc / hipFree pairs per call cost milliseconds -- as much as a whole tolerance-mode solve at 60k.
 struct CgBufs {
   void *x = nullptr, *r = nullptr, *p = nullptr, *ap = nullptr, *dense = nullptr;
   double* prod = nullptr;
@@ -523,6 +526,32 @@ struct CgBufs {
   int32_t *mask_rows = nullptr, *mask_ptr = nullptr;
   double *part_dot = nullptr, *part_rs = nullptr, *scal = nullptr, *err_hist = nullptr, *h_err = nullptr;
   hipStream_t stream = nullptr;
+  std::map<void**, size_t> cap;
+  int64_t pw_n = -1;   // rows the pairwise-summation plan was built for
+  PwPlan pw;
+  unsigned pw_grid = 1;
+  // device buffer of at least `bytes` (contents undefined after growth)
+  int need(void** ptr, size_t bytes) {
+    bytes = std::max<size_t>(bytes, 64);
+    auto it = cap.find(ptr);
+    if (it != cap.end() && it->second >= bytes && *ptr) return GLX_OK;
+    hipFree(*ptr);
+    *ptr = nullptr;
+    cap[ptr] = 0;
+    GLX_HIP(hipMalloc(ptr, bytes));
+    cap[ptr] = bytes;
+    return GLX_OK;
+  }
+  int need_host(double** ptr, size_t bytes) {
+    auto it = cap.find((void**)ptr);
+    if (it != cap.end() && it->second >= bytes && *ptr) return GLX_OK;
+    if (*ptr) hipHostFree(*ptr);
+    *ptr = nullptr;
+    cap[(void**)ptr] = 0;
+    GLX_HIP(hipHostMalloc((void**)ptr, bytes, hipHostMallocDefault));
+    cap[(void**)ptr] = bytes;
+    return GLX_OK;
+  }
   ~CgBufs() {
     hipFree(x); hipFree(r); hipFree(p); hipFree(ap); hipFree(dense); hipFree(part_dot); hipFree(part_rs);
     hipFree(scal); hipFree(err_hist); hipFree(prod);
@@ -531,6 +560,8 @@ struct CgBufs {
     if (stream) hipStreamDestroy(stream);
   }
 };
+
+void glx_cg_ws_destroy(void* ws) { delete (CgBufs*)ws; }
 
 template <typename T>
 static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double tol, int64_t max_iter, int* iters_out,
@@ -563,52 +594,60 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   // reference-order reducer: one wavefront per 4 columns; the product array is blocked the same way
   const int prod_sc = 4;
   const unsigned seq_grid = (unsigned)(ncols / 4);
-  CgBufs b;
+  if (!A->cg_ws) A->cg_ws = new CgBufs();
+  CgBufs& b = *(CgBufs*)A->cg_ws;
   const size_t recb = std::max<size_t>((size_t)n * L.ld * es, 64);
-  GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
-  GLX_HIP(hipMalloc(&b.x, recb));
-  GLX_HIP(hipMalloc(&b.r, recb));
-  GLX_HIP(hipMalloc(&b.p, recb));
-  GLX_HIP(hipMalloc(&b.ap, recb));
-  GLX_HIP(hipMalloc(&b.dense, std::max<size_t>((size_t)n * C * es, 64)));
-  GLX_HIP(hipMalloc(&b.part_dot, nb_spmm * ncols * 8));
-  GLX_HIP(hipMalloc(&b.part_rs, nb_upd * ncols * 8));
-  GLX_HIP(hipMalloc(&b.scal, 3 * ncols * 8));
-  GLX_HIP(hipMalloc(&b.err_hist, hist_cap * stride * 8));
-  if (exact) GLX_HIP(hipMalloc(&b.prod, std::max<size_t>((size_t)ncols * n * 8, 64)));
+  if (!b.stream) GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+#define CG_NEED(ptr, bytes) do { int rc_ = b.need((void**)&(ptr), (bytes)); if (rc_) return rc_; } while (0)
+  CG_NEED(b.x, recb);
+  CG_NEED(b.r, recb);
+  CG_NEED(b.p, recb);
+  CG_NEED(b.ap, recb);
+  CG_NEED(b.dense, (size_t)n * C * es);
+  CG_NEED(b.part_dot, (size_t)nb_spmm * ncols * 8);
+  CG_NEED(b.part_rs, (size_t)nb_upd * ncols * 8);
+  CG_NEED(b.scal, (size_t)3 * ncols * 8);
+  // the residual history is read in chunks: capped, the loop below wraps nothing (max_iter entries are needed only if they run)
+  CG_NEED(b.err_hist, (size_t)hist_cap * stride * 8);
+  if (exact) CG_NEED(b.prod, (size_t)ncols * n * 8);
   PwPlan pw;
   memset(&pw, 0, sizeof(pw));
   unsigned pw_grid = 1;
-  if (np1d) {   // numpy's pairwise-summation tree for n elements
-    PwHost ph;
-    ph.build_chunked(n);
-    ph.finish();
-    const size_t nl = ph.leaf_off.size(), ni = ph.node_l.size();
-    GLX_HIP(hipMalloc(&b.pw_off, nl * 8));
-    GLX_HIP(hipMalloc(&b.pw_len, nl * 4));
-    GLX_HIP(hipMalloc(&b.pw_l, std::max<size_t>(ni, 1) * 4));
-    GLX_HIP(hipMalloc(&b.pw_r, std::max<size_t>(ni, 1) * 4));
-    GLX_HIP(hipMalloc(&b.pw_ls, ph.level_start.size() * 4 + 4));
-    GLX_HIP(hipMalloc(&b.pw_vals, (nl + ni) * 8));
-    GLX_HIP(hipMemcpy(b.pw_off, ph.leaf_off.data(), nl * 8, hipMemcpyHostToDevice));
-    GLX_HIP(hipMemcpy(b.pw_len, ph.leaf_len.data(), nl * 4, hipMemcpyHostToDevice));
-    if (ni) {
-      GLX_HIP(hipMemcpy(b.pw_l, ph.node_l.data(), ni * 4, hipMemcpyHostToDevice));
-      GLX_HIP(hipMemcpy(b.pw_r, ph.node_r.data(), ni * 4, hipMemcpyHostToDevice));
+  if (np1d) {   // numpy's pairwise-summation tree for n elements (depends on n only: kept with the buffers)
+    if (b.pw_n != n) {
+      PwHost ph;
+      ph.build_chunked(n);
+      ph.finish();
+      const size_t nl = ph.leaf_off.size(), ni = ph.node_l.size();
+      CG_NEED(b.pw_off, nl * 8);
+      CG_NEED(b.pw_len, nl * 4);
+      CG_NEED(b.pw_l, std::max<size_t>(ni, 1) * 4);
+      CG_NEED(b.pw_r, std::max<size_t>(ni, 1) * 4);
+      CG_NEED(b.pw_ls, ph.level_start.size() * 4 + 4);
+      CG_NEED(b.pw_vals, (nl + ni) * 8);
+      GLX_HIP(hipMemcpy(b.pw_off, ph.leaf_off.data(), nl * 8, hipMemcpyHostToDevice));
+      GLX_HIP(hipMemcpy(b.pw_len, ph.leaf_len.data(), nl * 4, hipMemcpyHostToDevice));
+      if (ni) {
+        GLX_HIP(hipMemcpy(b.pw_l, ph.node_l.data(), ni * 4, hipMemcpyHostToDevice));
+        GLX_HIP(hipMemcpy(b.pw_r, ph.node_r.data(), ni * 4, hipMemcpyHostToDevice));
+      }
+      if (!ph.level_start.empty()) GLX_HIP(hipMemcpy(b.pw_ls, ph.level_start.data(), ph.level_start.size() * 4, hipMemcpyHostToDevice));
+      b.pw.leaf_off = b.pw_off;
+      b.pw.leaf_len = b.pw_len;
+      b.pw.node_l = b.pw_l;
+      b.pw.node_r = b.pw_r;
+      b.pw.level_start = b.pw_ls;
+      b.pw.vals = b.pw_vals;
+      b.pw.nleaves = (int)nl;
+      b.pw.ninternal = (int)ni;
+      b.pw.nlevels = ph.level_start.empty() ? 0 : (int)ph.level_start.size() - 1;
+      b.pw_grid = (unsigned)((nl + 255) / 256);
+      b.pw_n = n;
     }
-    if (!ph.level_start.empty()) GLX_HIP(hipMemcpy(b.pw_ls, ph.level_start.data(), ph.level_start.size() * 4, hipMemcpyHostToDevice));
-    pw.leaf_off = b.pw_off;
-    pw.leaf_len = b.pw_len;
-    pw.node_l = b.pw_l;
-    pw.node_r = b.pw_r;
-    pw.level_start = b.pw_ls;
-    pw.vals = b.pw_vals;
-    pw.nleaves = (int)nl;
-    pw.ninternal = (int)ni;
-    pw.nlevels = ph.level_start.empty() ? 0 : (int)ph.level_start.size() - 1;
-    pw_grid = (unsigned)((nl + 255) / 256);
+    pw = b.pw;
+    pw_grid = b.pw_grid;
   }
-  GLX_HIP(hipHostMalloc((void**)&b.h_err, (size_t)(CG_CHUNK + 1) * stride * 8, hipHostMallocDefault));
+  { int rc_ = b.need_host(&b.h_err, (size_t)(CG_CHUNK + 1) * stride * 8); if (rc_) return rc_; }
   CgScalars sc;
   sc.rsold = b.scal;
   sc.alpha = b.scal + ncols;
@@ -681,8 +720,8 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       GLX_CHECK(mask_rows[q] >= 0 && mask_rows[q] < n, GLX_EINVAL, "glx_cg_groups_masked: row %d out of range", mask_rows[q]);
       rec[q] = A->order_ready && !A->h_inv.empty() ? A->h_inv[mask_rows[q]] : mask_rows[q];
     }
-    GLX_HIP(hipMalloc(&b.mask_rows, (size_t)total * 4));
-    GLX_HIP(hipMalloc(&b.mask_ptr, (size_t)(ngroups + 1) * 4));
+    CG_NEED(b.mask_rows, (size_t)total * 4);
+    CG_NEED(b.mask_ptr, (size_t)(ngroups + 1) * 4);
     GLX_HIP(hipMemcpy(b.mask_rows, rec.data(), (size_t)total * 4, hipMemcpyHostToDevice));
     GLX_HIP(hipMemcpy(b.mask_ptr, mask_ptr, (size_t)(ngroups + 1) * 4, hipMemcpyHostToDevice));
     mask_grid = (unsigned)(((int64_t)most * Cg + 255) / 256);

@@ -84,7 +84,13 @@ struct glx_graph {
   std::vector<int32_t> h_perm, h_inv;
   int32_t* d_perm = nullptr;
   int32_t* d_inv = nullptr;
+  void* cg_ws = nullptr;   // work buffers of the conjugate-gradient solves on this operator (cg.hip), reused between calls
 };
+void glx_cg_ws_destroy(void* ws);
+
+// device work-buffer pool (graph.hip): size-class free lists in front of hipMalloc / hipFree
+int glx_pool_alloc(void** out, size_t bytes);
+void glx_pool_free(void* p);
 
 int glx_graph_plan(glx_graph* g, int G, SellPlan** out);
 int glx_graph_ensure_order(glx_graph* g);

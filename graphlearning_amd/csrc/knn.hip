@@ -12,6 +12,7 @@
 //      exceeds the exact k-th distance by twice a bound on the fp32 error;
 //   3. fallback -- rows that fail the check are redone by an exact fp64 scan.
 #include "glx_internal.h"
+#define GLX_POOL(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -424,8 +425,9 @@ struct KnnBufs {
   hipStream_t stream = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
   ~KnnBufs() {
-    hipFree(X); hipFree(mean); hipFree(dist); hipFree(Rf); hipFree(Qf); hipFree(qnorm); hipFree(cand_d);
-    hipFree(cand_i); hipFree(flags); hipFree(rows); hipFree(ind); hipFree(fb_li); hipFree(fb_pi); hipFree(fb_ld); hipFree(fb_pd);
+    if (stream) hipStreamSynchronize(stream);   // pooled blocks are reused at once: nothing may still be running on them
+    glx_pool_free(X); glx_pool_free(mean); glx_pool_free(dist); glx_pool_free(Rf); glx_pool_free(Qf); glx_pool_free(qnorm); glx_pool_free(cand_d);
+    glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_li); glx_pool_free(fb_pi); glx_pool_free(fb_ld); glx_pool_free(fb_pd);
     if (e0) hipEventDestroy(e0);
     if (e1) hipEventDestroy(e1);
     if (e2) hipEventDestroy(e2);
@@ -534,17 +536,17 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   GLX_HIP(hipEventCreate(&b.e1));
   GLX_HIP(hipEventCreate(&b.e2));
   GLX_HIP(hipEventCreate(&b.e3));
-  GLX_HIP(hipMalloc(&b.X, (size_t)n * d * 8));
-  GLX_HIP(hipMalloc(&b.mean, d * 8));
-  GLX_HIP(hipMalloc(&b.Rf, (size_t)n * dpa * 4));
-  GLX_HIP(hipMalloc(&b.Qf, (size_t)n * dpa * 4));
-  GLX_HIP(hipMalloc(&b.qnorm, (size_t)n * 4));
-  GLX_HIP(hipMalloc(&b.cand_d, (size_t)nq * ncand * 4));
-  GLX_HIP(hipMalloc(&b.cand_i, (size_t)nq * ncand * 4));
-  GLX_HIP(hipMalloc(&b.flags, (size_t)nq * 4));
-  GLX_HIP(hipMalloc(&b.rows, (size_t)nq * 4));
-  GLX_HIP(hipMalloc(&b.ind, (size_t)nq * k * 8));
-  GLX_HIP(hipMalloc(&b.dist, (size_t)nq * k * 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.X, (size_t)n * d * 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.mean, d * 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.Rf, (size_t)n * dpa * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.Qf, (size_t)n * dpa * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.qnorm, (size_t)n * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.cand_d, (size_t)nq * ncand * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.cand_i, (size_t)nq * ncand * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.flags, (size_t)nq * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.rows, (size_t)nq * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.ind, (size_t)nq * k * 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.dist, (size_t)nq * k * 8));
   GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyHostToDevice, st));
   GLX_HIP(hipMemcpyAsync(b.mean, mean.data(), d * 8, hipMemcpyHostToDevice, st));
   GLX_HIP(hipEventRecord(b.e0, st));
@@ -572,10 +574,10 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   if (!rows.empty()) {
     GLX_HIP(hipMemcpyAsync(b.rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
     const size_t nr = rows.size();
-    GLX_HIP(hipMalloc(&b.fb_ld, nr * 8));
-    GLX_HIP(hipMalloc(&b.fb_li, nr * 4));
-    GLX_HIP(hipMalloc(&b.fb_pd, nr * FB_SPLIT * 8));
-    GLX_HIP(hipMalloc(&b.fb_pi, nr * FB_SPLIT * 4));
+    GLX_POOL(glx_pool_alloc((void**)&b.fb_ld, nr * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.fb_li, nr * 4));
+    GLX_POOL(glx_pool_alloc((void**)&b.fb_pd, nr * FB_SPLIT * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.fb_pi, nr * FB_SPLIT * 4));
     std::vector<double> ld0(nr, -1.0);
     std::vector<int> li0(nr, -1);
     GLX_HIP(hipMemcpyAsync(b.fb_ld, ld0.data(), nr * 8, hipMemcpyHostToDevice, st));
