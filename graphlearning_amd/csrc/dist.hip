@@ -177,6 +177,7 @@ struct glx_dist_sweep {
   std::map<long, hipGraphExec_t> graphs;
   bool use_graph = true;
   bool overlap = true;                       // exchange on its own stream beside the interior rows (else in line on the sweep's stream)
+  bool capture_exchange = true;              // sweeps that carry an RCCL exchange may be captured into device graphs
   bool problem_set = false;
   int cur = 0;                               // ring index of the current iterate
   int64_t sweeps_run = 0, exchanges = 0;
@@ -257,6 +258,12 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
     hipRuntimeGetVersion(&rt);
     s->overlap = !(s->use_graph && rt < 70200000);
     if (const char* e = getenv("GLX_DIST_OVERLAP")) s->overlap = atoi(e) != 0;
+    // Grouped ncclSend/ncclRecv inside a stream capture has been exercised on ONE rank only (self exchange, RCCL 2.26.6 and
+    // 2.27.7); with real peers the exchanging sweeps are enqueued eagerly -- plain RCCL usage -- unless asked otherwise.
+    // Sweeps without an exchange (no halo anywhere) are captured either way.
+    s->capture_exchange = comm->nranks == 1;
+    if (const char* e = getenv("GLX_DIST_CAPTURE_EXCHANGE")) s->capture_exchange = atoi(e) != 0;
+    if (!s->capture_exchange && !getenv("GLX_DIST_OVERLAP")) s->overlap = true;   // eager: two streams are safe on every runtime
   }
   s->thresh = 1.0 / (double)n_global;   // `> 1/n`, ssl.py:667, n = ALL vertices
   int rc = glx_make_layout(C, state_dtype, true, &s->L);
@@ -462,7 +469,7 @@ static int ensure_ring(glx_dist_sweep* s, int nbuf) {
 // run `fn` (a sequence of enqueues on s->stream / s->xstream) through a captured device graph keyed by `key`
 template <typename F>
 static int run_captured(glx_dist_sweep* s, long key, F fn) {
-  if (!s->use_graph) return fn();
+  if (!s->use_graph || (s->exchange && !s->capture_exchange)) return fn();
   auto it = s->graphs.find(key);
   if (it == s->graphs.end()) {
     hipGraph_t graph;

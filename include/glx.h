@@ -159,7 +159,8 @@ int glx_dist_sweep_set_problem(glx_dist_sweep* s, const void* Db_own, const doub
 /* ssl.py:631-670 across the ranks (collective call): every sweep is [boundary rows | pack | grouped
  * ncclSend/ncclRecv all-to-all-v on a second stream | interior rows], the first min_iter sweeps one captured device
  * graph, later sweeps in chunks of check_every on a ring of state buffers with ONE ncclAllReduce(MAX) of the chunk's
- * per-sweep maxima -- no host round trip per sweep, and T and u_T are exactly the reference's.  err0 = max|v0 - vinf|
+ * per-sweep maxima -- no host round trip per sweep, and T and u_T are exactly the reference's.  (Sweeps that carry an
+ * exchange with real peers are enqueued eagerly unless GLX_DIST_CAPTURE_EXCHANGE=1: their capture is verified on one rank only.)  err0 = max|v0 - vinf|
  * over all vertices (read when min_iter = 0). */
 int glx_poisson_sweep_dist(glx_dist_sweep* s, int min_iter, int max_iter, int check_every, double err0, int* T_out,
                            float* device_ms_out);
