@@ -225,3 +225,30 @@ def test_config4_bench_entry_one_rank():
     assert j['scaling'] == 'strong' and j['config']['n'] == 300000 and j['config']['sweeps_per_step'] == 200
     assert j['accuracy_percent'] > 99.0 and j['value'] > 0
     print(json.dumps(j)[:600])
+
+
+def test_glx_dist_fp32_matches_single_gpu_fp32(golden):
+    """The distributed sweep object in float32 (the reference's use_cuda precision) with a forced self-halo equals the
+    single-GPU float32 fit bit for bit: the partition never changes a row's arithmetic."""
+    import graphlearning_amd as gl
+    from graphlearning_amd import dist as gdist, _hip
+    _hip.require_device()
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    ti, lab = g['train_ind'], g['labels']
+    m32 = gl.ssl.poisson(W, solver='gradient_descent', use_cuda=True)
+    u32 = np.array(m32.fit(ti, lab[ti]))
+    prob = gdist.poisson_problem(W, ti, lab[ti])
+    plan = _self_halo_plan(prob['P'], frac=5)
+    comm = _hip.Comm(1, 0, None, 0)
+    ds = gdist.glx_dist_sweep(comm, plan, prob['k'], dtype=np.float32, force_exchange=True)
+    own = plan.own
+    ds.set_problem(prob['Db'][own].astype(np.float32), prob['w0'][own], prob['deg'][own], prob['vinf'][own])
+    T, _ = ds.run(50, 1000, 8, 0.0)
+    u = ds.fetch()
+    assert u.dtype == np.float32 and T == m32.num_iter
+    full = np.zeros_like(u32)
+    full[own] = u
+    assert np.array_equal(full, u32)
+    ds.close()
+    comm.close()

@@ -225,3 +225,54 @@ def test_sweep_launch_count_is_sweeps_run(gl, golden):
     T2, _ = sw.run()
     assert T2 == T and sw.launches() - l0 == 2 * T
     sw.close()
+
+
+def test_new_entry_points_reject_bad_arguments(gl, golden):
+    """Status codes instead of crashes (include/glx.h conventions) for the entry points added in round 2."""
+    from graphlearning_amd import _hip
+    g = golden('g1_twomoons.npz')
+    W = csr_from(g, 'W_gaussian')
+    n = W.shape[0]
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    dev, aux = m._operators()
+    sw = _hip.Sweep(dev, 2, 50, 1000, True)
+    with pytest.raises(_hip.GlxError):                       # graph vectors first
+        sw.set_problem_rows(np.array([1, 2]), np.zeros((2, 2)), np.zeros(2), 0.0)
+    sw.set_vectors(aux['deg'], aux['vinf'])
+    with pytest.raises(_hip.GlxError):                       # row out of range
+        sw.set_problem_rows(np.array([1, n]), np.zeros((2, 2)), np.zeros(2), 0.0)
+    with pytest.raises(_hip.GlxError):                       # shape mismatch caught at the boundary
+        sw.set_problem_rows(np.array([1, 2]), np.zeros((3, 2)), np.zeros(2), 0.0)
+    sw.set_problem_rows(np.zeros(0, dtype=np.int64), np.zeros((0, 2)), np.zeros(0), 1.0)   # an empty training set is legal: u stays 0
+    T, _ = sw.run()
+    assert T >= 50 and not np.any(sw.fetch())
+    sw.close()
+    # distributed sweep object
+    comm = _hip.Comm(1, 0, None, 0)
+    P = sparse.csr_matrix(sparse.identity(8) * 0.5)
+    with pytest.raises(_hip.GlxError):                       # receive counts must add up to the halo
+        _hip.DistSweep(comm, sparse.csr_matrix((8, 10)), 0, [0], np.zeros(0, np.int32), [1], 8, 2)
+    with pytest.raises(_hip.GlxError):                       # a send row must be a boundary row
+        _hip.DistSweep(comm, P, 2, [1], np.array([5], np.int32), [0], 8, 2)
+    ds = _hip.DistSweep(comm, P, 0, [0], np.zeros(0, np.int32), [0], 8, 2)
+    with pytest.raises(_hip.GlxError):                       # run before the problem is set
+        ds.run(5, 10, 8, 0.0)
+    ds.set_problem(None, np.full(8, 0.125), np.ones(8), np.full(8, 0.125))
+    with pytest.raises(_hip.GlxError):
+        ds.run(5, 10, 0, 0.0)                                # check_every >= 1
+    T, _ = ds.run(5, 10, 3, 0.0)
+    assert T == 5 and not np.any(ds.fetch())                 # w halves every sweep: |deg*w - vinf| = 0.125 - ... > 1/8? no: stops at min_iter
+    ds.close()
+    comm.close()
+    # label decision: dtype code
+    with pytest.raises(_hip.GlxError):
+        _hip.check(_hip.load().glx_argmax_project_t(None, 7, 4, 2, None, None, None, None, None, 0, 1, 0), 'glx_argmax_project_t')
+    # cg flags: x0 with the wrong shape is caught in Python, unknown reduce mode too
+    A = _hip.DeviceGraph(sparse.identity(16, format='csr') * 2.0)
+    with pytest.raises(Exception):
+        A.cg(np.ones((16, 2)), x0=np.ones((16, 3)))
+    with pytest.raises(_hip.GlxError):
+        A.cg(np.ones((16, 2)), reduce='approximately')
+    x, it, err = A.cg(np.ones((16, 2)), x0=np.full((16, 2), 0.5), tol=1e-12)    # B is the residual r0 = b - A@x0: x = x0 + A^-1 r0
+    assert np.allclose(x, 1.0) and it >= 1
+    A.close()
