@@ -252,6 +252,209 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
   }
 }
 
+
+// ---- stage 1b: candidate filter on the bf16 matrix cores, split operands ----------------------------
+// The filter only has to be accurate to a KNOWN bound (the re-rank is exact fp64 and its acceptance test allows for the
+// bound), so the contraction does not need fp32 operands: every centred coordinate x is split into two bfloat16 numbers,
+// x = hi + lo + e with |e| <= 2^-18 |x|, and q.r is formed as hi.hi + hi.lo + lo.hi -- three v_mfma_f32_32x32x16_bf16
+// per 16 features, accumulated in fp32 -- at 16x the rate of the f32-input MFMA: 96 matrix-pipe cycles per 16 features of
+// a 32 x 32 tile instead of 512.  bf16 products are exact in fp32; what is dropped (lo.lo and the e terms) is below
+// 3.1 * 2^-18 |q||r|, which the acceptance bound `cerr` carries.  The squared norms stay fp32 and are added after the
+// contraction (two extra features would lose them to bf16): value = |r|^2 - 2 q.r, compared with tau - |q|^2.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rn(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// Xb[i] = [hi_0 .. hi_{kpad-1} | lo_0 .. lo_{kpad-1}] (bf16), nrm[i] = |x32|^2 (fp32), qnorm[i] = |x32|
+__global__ void knn_prep_bf16_kernel(const double* __restrict__ X, const double* __restrict__ mean, int64_t n, int d, int kpad,
+                                     unsigned short* __restrict__ Xb, float* __restrict__ nrm, float* __restrict__ qnorm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  unsigned short* row = Xb + i * 2 * kpad;
+  for (int f = 0; f < d; ++f) {
+    const float x = (float)(X[i * d + f] - mean[f]);
+    const unsigned short hi = f32_to_bf16_rn(x);
+    const unsigned short lo = f32_to_bf16_rn(x - bf16_to_f32(hi));
+    row[f] = hi;
+    row[kpad + f] = lo;
+    s = fmaf(x, x, s);
+  }
+  for (int f = d; f < kpad; ++f) { row[f] = 0; row[kpad + f] = 0; }
+  nrm[i] = s;
+  qnorm[i] = sqrtf(s);
+}
+
+// NKB blocks of 16 features (kpad = 16 NKB <= 128); refs are the A operand (LDS), queries the B operand (registers: lane =
+// query column j, k-half h); list handling as in knn_tile_kernel.
+template <int NKB, int KP, int NSUB>
+__global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const float* __restrict__ nrm, int64_t n,
+                                                            int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d,
+                                                            int* __restrict__ cand_i) {
+  constexpr int KPAD = 16 * NKB;
+  constexpr int BR = 32 * NSUB;
+  constexpr int ROWB = 4 * KPAD + 16;                  // bytes per ref row in LDS: hi | lo, +16 so that 16 rows cover all 64 banks
+  constexpr int U_ROW = 4 * KPAD / 16;                 // 16-byte units per row
+  constexpr int UNITS = (BR * U_ROW + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem_b[];
+  char* tile = smem_b;                                  // [2][BR][ROWB]
+  float* rn = (float*)(smem_b + 2 * BR * ROWB);         // [2][BR]
+  float* ld = rn + 2 * BR;                              // [KP + KBUF][256]
+  int* li = (int*)(ld + (KP + KBUF) * 256);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int64_t qb = blockIdx.x, sp = blockIdx.y;
+  const int64_t q = q_begin + qb * BQ + wave * 32 + j;
+  const int64_t qc = q < q_end ? q : q_end - 1;
+  // query fragments: B[k][j], lane holds k = 8h .. 8h+7 of every block, hi and lo
+  bf16x8 bh[NKB], bl[NKB];
+  {
+    const uint4* qrow = (const uint4*)(Xb + qc * 2 * KPAD);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      bh[kb] = __builtin_bit_cast(bf16x8, qrow[kb * 2 + h]);
+      bl[kb] = __builtin_bit_cast(bf16x8, qrow[KPAD / 8 + kb * 2 + h]);
+    }
+  }
+  const float qn = nrm[qc];
+#pragma unroll
+  for (int p = 0; p < KP; ++p) { ld[p * 256 + tid] = INFINITY; li[p * 256 + tid] = -1; }
+  float tau = INFINITY;          // thresholds are kept WITHOUT the query's norm: values are |r|^2 - 2 q.r
+
+  const int64_t ntiles = (n + BR - 1) / BR;
+  const int64_t t0 = ntiles * sp / nsplit, t1 = ntiles * (sp + 1) / nsplit;
+  uint4 pre[UNITS];
+  float pre_rn = 0.f;
+  auto stage_load = [&](int64_t t) {
+#pragma unroll
+    for (int i = 0; i < UNITS; ++i) {
+      const int u = tid + i * 256;
+      const int r = u / U_ROW, c = u % U_ROW;
+      const int64_t ref = t * BR + r;
+      uint4 v = {0u, 0u, 0u, 0u};
+      if (u < BR * U_ROW && ref < n) v = *(const uint4*)(Xb + ref * 2 * KPAD + c * 8);
+      pre[i] = v;
+    }
+    if (tid < BR) {
+      const int64_t ref = t * BR + tid;
+      pre_rn = ref < n ? nrm[ref] : 1e30f;      // rows beyond n are infinitely far
+    }
+  };
+  auto stage_store = [&](int buf) {
+    char* dst = tile + buf * BR * ROWB;
+#pragma unroll
+    for (int i = 0; i < UNITS; ++i) {
+      const int u = tid + i * 256;
+      if (u < BR * U_ROW) *(uint4*)(dst + (u / U_ROW) * ROWB + (u % U_ROW) * 16) = pre[i];
+    }
+    if (tid < BR) rn[buf * BR + tid] = pre_rn;
+  };
+  int cnt = 0;
+  float tau_own = INFINITY;
+  int pmax = 0;
+  auto compact = [&]() {
+    int mx = cnt;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+    for (int a = 0; a < mx; ++a) {
+      if (a < cnt) {
+        const float v = ld[(KP + a) * 256 + tid];
+        if (v < tau_own) {
+          ld[pmax * 256 + tid] = v;
+          li[pmax * 256 + tid] = li[(KP + a) * 256 + tid];
+          float m2 = ld[tid];
+          int pm = 0;
+#pragma unroll
+          for (int p = 1; p < KP; ++p) {
+            const float x = ld[p * 256 + tid];
+            if (x > m2) { m2 = x; pm = p; }
+          }
+          tau_own = m2;
+          pmax = pm;
+        }
+      }
+    }
+    cnt = 0;
+    tau = fminf(tau_own, __shfl_xor(tau_own, 32));   // lanes l and l^32 serve the same query (same |q|^2 offset)
+  };
+  if (t0 < t1) { stage_load(t0); stage_store(0); }
+  __syncthreads();
+  int buf = 0;
+  for (int64_t t = t0; t < t1; ++t) {
+    const bool has_next = t + 1 < t1;
+    if (has_next) stage_load(t + 1);
+    const char* tl = tile + buf * BR * ROWB;
+    const float* rnb = rn + buf * BR;
+    f32x16 acc[NSUB];
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[sub][e] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+        // A[i][k]: lane holds row i = j of the sub-tile, k = 8h .. 8h+7 of block kb
+        const char* rowp = tl + (sub * 32 + j) * ROWB + (kb * 16 + 8 * h) * 2;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)rowp);
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(rowp + 2 * KPAD));
+        acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kb], acc[sub], 0, 0, 0);
+        acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kb], acc[sub], 0, 0, 0);
+        acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kb], acc[sub], 0, 0, 0);
+      }
+    }
+    // selection: element e of sub-tile `sub` is ref sub*32 + (e&3) + 8*(e>>2) + 4h, query j; value = |r|^2 - 2 q.r
+    float m = INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+#pragma unroll
+      for (int eg = 0; eg < 4; ++eg) {
+        const float4 r4 = *(const float4*)(rnb + sub * 32 + 8 * eg + 4 * h);
+        acc[sub][eg * 4 + 0] = fmaf(-2.f, acc[sub][eg * 4 + 0], r4.x);
+        acc[sub][eg * 4 + 1] = fmaf(-2.f, acc[sub][eg * 4 + 1], r4.y);
+        acc[sub][eg * 4 + 2] = fmaf(-2.f, acc[sub][eg * 4 + 2], r4.z);
+        acc[sub][eg * 4 + 3] = fmaf(-2.f, acc[sub][eg * 4 + 3], r4.w);
+        m = fminf(fminf(m, fminf(acc[sub][eg * 4 + 0], acc[sub][eg * 4 + 1])), fminf(acc[sub][eg * 4 + 2], acc[sub][eg * 4 + 3]));
+      }
+    }
+    if (__any(m < tau)) {
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+#pragma unroll
+        for (int eg = 0; eg < 16; eg += 4) {
+#pragma unroll
+          for (int e = eg; e < eg + 4; ++e) {
+            const float v = acc[sub][e];
+            if (v < tau) {
+              ld[(KP + cnt) * 256 + tid] = v;
+              li[(KP + cnt) * 256 + tid] = (int)(t * BR) + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+              ++cnt;
+            }
+          }
+          if (__any(cnt > KBUF - 4)) compact();
+        }
+      }
+    }
+    if (has_next) stage_store(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  compact();
+  if (q < q_end) {
+    const int64_t lists = (int64_t)nsplit * 2;
+    const int64_t base = ((q - q_begin) * lists + sp * 2 + h) * KP;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+      cand_d[base + p] = ld[p * 256 + tid] + qn;       // back to squared distances (inf stays inf)
+      cand_i[base + p] = li[p * 256 + tid];
+    }
+  }
+}
+
 // ---- stage 2: exact fp64 re-rank + acceptance check ------------------------------------------
 // squared distance with the accumulation pattern of scipy's ckdtree sqeuclidean_distance_double
 // (4 partial sums over blocks of 4 coordinates, combined left to right, then the tail)
@@ -417,6 +620,9 @@ constexpr int tile_nsub(int DH, int KP) {
 }
 
 struct KnnBufs {
+  unsigned short* Xb = nullptr;      // bf16 hi | lo image (bf16 filter)
+  float* nrm = nullptr;              // fp32 squared norms (bf16 filter)
+  double* part = nullptr;            // per-block partial column sums / maxima of the centring pass
   double *X = nullptr, *mean = nullptr, *dist = nullptr;
   float *Rf = nullptr, *Qf = nullptr, *qnorm = nullptr, *cand_d = nullptr;
   int *cand_i = nullptr, *flags = nullptr, *rows = nullptr, *fb_li = nullptr, *fb_pi = nullptr;
@@ -426,6 +632,7 @@ struct KnnBufs {
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
   ~KnnBufs() {
     if (stream) hipStreamSynchronize(stream);   // pooled blocks are reused at once: nothing may still be running on them
+    glx_pool_free(Xb); glx_pool_free(nrm); glx_pool_free(part);
     glx_pool_free(X); glx_pool_free(mean); glx_pool_free(dist); glx_pool_free(Rf); glx_pool_free(Qf); glx_pool_free(qnorm); glx_pool_free(cand_d);
     glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_li); glx_pool_free(fb_pi); glx_pool_free(fb_ld); glx_pool_free(fb_pd);
     if (e0) hipEventDestroy(e0);
@@ -435,6 +642,65 @@ struct KnnBufs {
     if (stream) hipStreamDestroy(stream);
   }
 };
+
+
+// ---- centring on the device: column sums and the largest centred norm, as per-block partials reduced by the host
+// in a fixed order (the n x d passes cost milliseconds on one host core: as much as the search itself at 70 000 x 20)
+static const int CENTRE_ROWS = 1024;
+__global__ __launch_bounds__(256) void knn_colsum_kernel(const double* __restrict__ X, int64_t n, int d, double* __restrict__ part) {
+  const int64_t r0 = (int64_t)blockIdx.x * CENTRE_ROWS, r1 = min(n, r0 + CENTRE_ROWS);
+  for (int f = threadIdx.x; f < d; f += 256) {
+    double s = 0.0;
+    for (int64_t i = r0; i < r1; ++i) s += X[i * d + f];
+    part[(size_t)blockIdx.x * d + f] = s;
+  }
+}
+__global__ __launch_bounds__(256) void knn_maxnorm_kernel(const double* __restrict__ X, const double* __restrict__ mean, int64_t n, int d,
+                                                          double* __restrict__ part) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double s = 0.0;
+  if (i < n)
+    for (int f = 0; f < d; ++f) { const double c = X[i * d + f] - mean[f]; s += c * c; }
+  if (!(s == s)) s = INFINITY;     // NaN input: reported as non-finite
+  __shared__ double sm[256];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off && sm[threadIdx.x + off] > sm[threadIdx.x]) sm[threadIdx.x] = sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+
+constexpr int bf16_nsub(int NKB, int KP) { return (NKB >= 6 || KP >= 32) ? 1 : 2; }
+
+template <int NKB, int KP>
+static int launch_tile_bf16(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st) {
+  constexpr int NSUB = bf16_nsub(NKB, KP);
+  constexpr int BR = 32 * NSUB;
+  constexpr int ROWB = 4 * 16 * NKB + 16;
+  const size_t shm = (size_t)2 * BR * ROWB + (size_t)2 * BR * 4 + (size_t)(KP + KBUF) * 256 * 8;
+  GLX_CHECK(shm <= 160 * 1024, GLX_EUNSUPPORTED, "glx_knn_bruteforce: bf16 filter needs %zu bytes of LDS", shm);
+  GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_bf16_kernel<NKB, KP, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)nsplit);
+  hipLaunchKernelGGL((knn_tile_bf16_kernel<NKB, KP, NSUB>), grid, dim3(256), shm, st, (const unsigned short*)b.Xb, (const float*)b.nrm, n, q0, q1,
+                     nsplit, b.cand_d, b.cand_i);
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}
+
+template <int KP>
+static int launch_tile_bf16_nkb(int NKB, const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st) {
+  switch (NKB) {
+    case 1: return launch_tile_bf16<1, KP>(b, n, q0, q1, nsplit, st);
+    case 2: return launch_tile_bf16<2, KP>(b, n, q0, q1, nsplit, st);
+    case 4: return launch_tile_bf16<4, KP>(b, n, q0, q1, nsplit, st);
+    case 6: return launch_tile_bf16<6, KP>(b, n, q0, q1, nsplit, st);
+    case 8: return launch_tile_bf16<8, KP>(b, n, q0, q1, nsplit, st);
+  }
+  glx_set_error("knn: no bf16 tile kernel for %d feature blocks", NKB);
+  return GLX_EUNSUPPORTED;
+}
 
 template <int DH, int KP, bool KBLK = false>
 static int launch_tile(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st, int nkb = 1) {
@@ -495,9 +761,18 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   } else {
     nkb = (d + 2 + 2 * DH - 1) / (2 * DH);
   }
-  const int dpa = 2 * DH * nkb;
+  // Filter arithmetic.  Default: split-bf16 operands on the bf16 matrix cores (d <= 128 with the short lists); the fp32-input
+  // MFMA kernel serves everything else and GLX_KNN_FILTER=f32.
+  const char* fenv = getenv("GLX_KNN_FILTER");
+  const bool use_bf16 = short_lists && d <= 128 && KP <= 32 && !(fenv && strcmp(fenv, "f32") == 0);
+  int NKB = 0;
+  if (use_bf16) {
+    for (int cand : {1, 2, 4, 6, 8})
+      if (16 * cand >= d) { NKB = cand; break; }
+  }
+  const int dpa = use_bf16 ? 16 * NKB : 2 * DH * nkb;
   const int64_t nqb = (nq + BQ - 1) / BQ;
-  const int BR = 32 * tile_nsub(DH, KP);
+  const int BR = use_bf16 ? 32 * bf16_nsub(NKB, KP) : 32 * tile_nsub(DH, KP);
   const int64_t ntiles = (n + BR - 1) / BR;
   int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, ntiles), (1024 + nqb - 1) / nqb));
   if (short_lists) {
@@ -512,23 +787,6 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   int M = 64;
   while (M < ncand) M *= 2;
 
-  // centring in fp64 (distances are translation invariant; small norms keep the fp32 filter sharp)
-  std::vector<double> mean(d, 0.0);
-  for (int64_t i = 0; i < n; ++i)
-    for (int f = 0; f < d; ++f) mean[f] += X[i * d + f];
-  for (int f = 0; f < d; ++f) mean[f] /= (double)n;
-  double rmax2 = 0.0;
-  for (int64_t i = 0; i < n; ++i) {
-    double s = 0.0;
-    for (int f = 0; f < d; ++f) { const double c = X[i * d + f] - mean[f]; s += c * c; }
-    rmax2 = std::max(rmax2, s);
-  }
-  GLX_CHECK(std::isfinite(rmax2), GLX_EINVAL, "glx_knn_bruteforce: non-finite input");
-  const float rmax = (float)(std::sqrt(rmax2) * (1.0 + 1e-6));
-  // |fp32 filter value - exact dist^2| <= cerr * (|q| + rmax)^2 : input rounding (2^-24 per coordinate),
-  // dpa products and sums at 2^-24 each, norms computed in fp32; generous constant
-  const double cerr = (double)(dpa + 8) * std::ldexp(1.0, -22);
-
   KnnBufs b;
   GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
   hipStream_t st = b.stream;
@@ -538,8 +796,34 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   GLX_HIP(hipEventCreate(&b.e3));
   GLX_POOL(glx_pool_alloc((void**)&b.X, (size_t)n * d * 8));
   GLX_POOL(glx_pool_alloc((void**)&b.mean, d * 8));
-  GLX_POOL(glx_pool_alloc((void**)&b.Rf, (size_t)n * dpa * 4));
-  GLX_POOL(glx_pool_alloc((void**)&b.Qf, (size_t)n * dpa * 4));
+  GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyHostToDevice, st));
+  // centring in fp64 (distances are translation invariant; small norms keep the filter sharp): per-block partials, fixed-order host sums
+  const int64_t nb_sum = (n + CENTRE_ROWS - 1) / CENTRE_ROWS, nb_max = (n + 255) / 256;
+  GLX_POOL(glx_pool_alloc((void**)&b.part, (size_t)std::max<int64_t>(nb_sum * d, nb_max) * 8));
+  std::vector<double> mean(d, 0.0), hpart((size_t)std::max<int64_t>(nb_sum * d, nb_max));
+  hipLaunchKernelGGL(knn_colsum_kernel, dim3((unsigned)nb_sum), dim3(256), 0, st, (const double*)b.X, n, d, b.part);
+  GLX_HIP(hipGetLastError());
+  GLX_HIP(hipMemcpyAsync(hpart.data(), b.part, (size_t)nb_sum * d * 8, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipStreamSynchronize(st));
+  for (int64_t blk = 0; blk < nb_sum; ++blk)
+    for (int f = 0; f < d; ++f) mean[f] += hpart[(size_t)blk * d + f];
+  for (int f = 0; f < d; ++f) mean[f] /= (double)n;
+  GLX_HIP(hipMemcpyAsync(b.mean, mean.data(), d * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(knn_maxnorm_kernel, dim3((unsigned)nb_max), dim3(256), 0, st, (const double*)b.X, (const double*)b.mean, n, d, b.part);
+  GLX_HIP(hipGetLastError());
+  GLX_HIP(hipMemcpyAsync(hpart.data(), b.part, (size_t)nb_max * 8, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipStreamSynchronize(st));
+  double rmax2 = 0.0;
+  for (int64_t blk = 0; blk < nb_max; ++blk) rmax2 = std::max(rmax2, hpart[blk]);
+  GLX_CHECK(std::isfinite(rmax2), GLX_EINVAL, "glx_knn_bruteforce: non-finite input");
+  const float rmax = (float)(std::sqrt(rmax2) * (1.0 + 1e-6));
+  // |filter value - exact dist^2| <= cerr * (|q| + rmax)^2.
+  // fp32 filter: input rounding (2^-24 per coordinate), dpa products and sums at 2^-24 each, norms computed in fp32; generous constant.
+  // bf16 filter: the dropped parts of the split products (lo.lo and the residuals, <= 3.1 * 2^-18 |q||r| in q.r, twice that in the
+  // distance, |q||r| <= (|q|+rmax)^2 / 4), 3*kpad fp32 accumulations, fp32 norms and input rounding -- all of it doubled
+  // (the matrix pipe's internal rounding mode is not documented).
+  const double cerr = use_bf16 ? 2.0 * (std::ldexp(1.0, -17) + (1.5 * (3.0 * dpa + 4.0) + d + 16.0) * std::ldexp(1.0, -24))
+                               : (double)(dpa + 8) * std::ldexp(1.0, -22);
   GLX_POOL(glx_pool_alloc((void**)&b.qnorm, (size_t)n * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.cand_d, (size_t)nq * ncand * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.cand_i, (size_t)nq * ncand * 4));
@@ -547,17 +831,28 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   GLX_POOL(glx_pool_alloc((void**)&b.rows, (size_t)nq * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.ind, (size_t)nq * k * 8));
   GLX_POOL(glx_pool_alloc((void**)&b.dist, (size_t)nq * k * 8));
-  GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyHostToDevice, st));
-  GLX_HIP(hipMemcpyAsync(b.mean, mean.data(), d * 8, hipMemcpyHostToDevice, st));
   GLX_HIP(hipEventRecord(b.e0, st));
-  hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const double*)b.mean,
-                     n, d, dpa, b.Rf, b.Qf, b.qnorm);
-  GLX_HIP(hipGetLastError());
   int rc;
-  if (KP == 8) rc = launch_tile_dh<8>(DH, nkb, b, n, q0, q1, nsplit, st);
-  else if (KP == 16) rc = launch_tile_dh<16>(DH, nkb, b, n, q0, q1, nsplit, st);
-  else if (KP == 32) rc = launch_tile_dh<32>(DH, nkb, b, n, q0, q1, nsplit, st);
-  else rc = launch_tile_dh<64>(DH, nkb, b, n, q0, q1, nsplit, st);
+  if (use_bf16) {
+    GLX_POOL(glx_pool_alloc((void**)&b.Xb, (size_t)n * 2 * dpa * 2));
+    GLX_POOL(glx_pool_alloc((void**)&b.nrm, (size_t)n * 4));
+    hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const double*)b.mean,
+                       n, d, dpa, b.Xb, b.nrm, b.qnorm);
+    GLX_HIP(hipGetLastError());
+    if (KP == 8) rc = launch_tile_bf16_nkb<8>(NKB, b, n, q0, q1, nsplit, st);
+    else if (KP == 16) rc = launch_tile_bf16_nkb<16>(NKB, b, n, q0, q1, nsplit, st);
+    else rc = launch_tile_bf16_nkb<32>(NKB, b, n, q0, q1, nsplit, st);
+  } else {
+    GLX_POOL(glx_pool_alloc((void**)&b.Rf, (size_t)n * dpa * 4));
+    GLX_POOL(glx_pool_alloc((void**)&b.Qf, (size_t)n * dpa * 4));
+    hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const double*)b.mean,
+                       n, d, dpa, b.Rf, b.Qf, b.qnorm);
+    GLX_HIP(hipGetLastError());
+    if (KP == 8) rc = launch_tile_dh<8>(DH, nkb, b, n, q0, q1, nsplit, st);
+    else if (KP == 16) rc = launch_tile_dh<16>(DH, nkb, b, n, q0, q1, nsplit, st);
+    else if (KP == 32) rc = launch_tile_dh<32>(DH, nkb, b, n, q0, q1, nsplit, st);
+    else rc = launch_tile_dh<64>(DH, nkb, b, n, q0, q1, nsplit, st);
+  }
   if (rc) return rc;
   GLX_HIP(hipEventRecord(b.e1, st));
   hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)nq), dim3(64), (size_t)M * 12, st, (const double*)b.X, n, d, k, q0, nq,
@@ -606,7 +901,7 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   g_knn_stats[4] = ms_fb;
   g_knn_stats[5] = (double)dpa;
   g_knn_stats[6] = (double)nsplit;
-  g_knn_stats[7] = (double)KP;
+  g_knn_stats[7] = use_bf16 ? -(double)KP : (double)KP;   // negative: the bf16 filter ran
   return GLX_OK;
 }
 
