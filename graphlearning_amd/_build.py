@@ -47,8 +47,16 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def _flag_tag():
+    return hashlib.sha256(' '.join(_flags()).encode()).hexdigest()[:8]
+
+
 def needs_build():
     if not os.path.exists(LIB):
+        return True
+    stamp = os.path.join(HERE, 'libglx.hash')
+    built_with = open(stamp).read().split() if os.path.exists(stamp) else []
+    if len(built_with) < 2 or built_with[1] != _flag_tag():        # other compile flags (GLX_CXXFLAGS) than the library was built with
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(d) > t for d in sources() + headers() if os.path.exists(d))
@@ -60,7 +68,7 @@ def build_lib(force=False, verbose=False):
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     hdr_t = max(os.path.getmtime(h) for h in headers() if os.path.exists(h))
-    flag_tag = hashlib.sha256(' '.join(_flags()).encode()).hexdigest()[:8]
+    flag_tag = _flag_tag()
     jobs = []
     objs = []
     for src in sources():
@@ -80,7 +88,7 @@ def build_lib(force=False, verbose=False):
     run([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB + '.tmp'] + objs + LINK_LIBS)
     os.replace(LIB + '.tmp', LIB)
     with open(os.path.join(HERE, 'libglx.hash'), 'w') as f:
-        f.write(source_hash() + '\n')
+        f.write(source_hash() + ' ' + _flag_tag() + '\n')
     return LIB
 
 

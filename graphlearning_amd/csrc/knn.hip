@@ -262,6 +262,12 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
 // 3.1 * 2^-18 |q||r|, which the acceptance bound `cerr` carries.  The squared norms stay fp32 and are added after the
 // contraction (two extra features would lose them to bf16): value = |r|^2 - 2 q.r, compared with tau - |q|^2.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef KNN_GROUP_GUARD
+#define KNN_GROUP_GUARD 1          // measured: 438 -> 394 ms
+#endif
+#ifndef KNN_BRANCHFREE_STAGE
+#define KNN_BRANCHFREE_STAGE 0   // measured (one box, n = 1e6, d = 64): clamped unconditional loads 593 ms vs 438 ms with the predicated ones
+#endif
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rn(float x) {
   const unsigned u = __float_as_uint(x);
@@ -300,6 +306,7 @@ __global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short
   constexpr int ROWB = 4 * KPAD + 16;                  // bytes per ref row in LDS: hi | lo, +16 so that 16 rows cover all 64 banks
   constexpr int U_ROW = 4 * KPAD / 16;                 // 16-byte units per row
   constexpr int UNITS = (BR * U_ROW + 255) / 256;
+  constexpr bool EXACT_UNITS = (BR * U_ROW) % 256 == 0;
   extern __shared__ __attribute__((aligned(16))) char smem_b[];
   char* tile = smem_b;                                  // [2][BR][ROWB]
   float* rn = (float*)(smem_b + 2 * BR * ROWB);         // [2][BR]
@@ -330,18 +337,24 @@ __global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short
   uint4 pre[UNITS];
   float pre_rn = 0.f;
   auto stage_load = [&](int64_t t) {
+    // branch-free: rows beyond n are read from the last row and made infinitely far through their norm
 #pragma unroll
     for (int i = 0; i < UNITS; ++i) {
       const int u = tid + i * 256;
       const int r = u / U_ROW, c = u % U_ROW;
+#if KNN_BRANCHFREE_STAGE
+      const int64_t ref = min(t * BR + r, n - 1);
+      if (EXACT_UNITS || u < BR * U_ROW) pre[i] = *(const uint4*)(Xb + ref * 2 * KPAD + c * 8);
+#else
       const int64_t ref = t * BR + r;
       uint4 v = {0u, 0u, 0u, 0u};
       if (u < BR * U_ROW && ref < n) v = *(const uint4*)(Xb + ref * 2 * KPAD + c * 8);
       pre[i] = v;
+#endif
     }
     if (tid < BR) {
       const int64_t ref = t * BR + tid;
-      pre_rn = ref < n ? nrm[ref] : 1e30f;      // rows beyond n are infinitely far
+      pre_rn = ref < n ? nrm[ref] : 1e30f;
     }
   };
   auto stage_store = [&](int buf) {
@@ -349,7 +362,7 @@ __global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short
 #pragma unroll
     for (int i = 0; i < UNITS; ++i) {
       const int u = tid + i * 256;
-      if (u < BR * U_ROW) *(uint4*)(dst + (u / U_ROW) * ROWB + (u % U_ROW) * 16) = pre[i];
+      if (EXACT_UNITS || u < BR * U_ROW) *(uint4*)(dst + (u / U_ROW) * ROWB + (u % U_ROW) * 16) = pre[i];
     }
     if (tid < BR) rn[buf * BR + tid] = pre_rn;
   };
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[sub][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[sub][e] = 0.f;     // (the first MFMA of a chain takes the constant 0 as its C operand)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
@@ -407,10 +420,13 @@ __global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short
         acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kb], acc[sub], 0, 0, 0);
       }
     }
-    // selection: element e of sub-tile `sub` is ref sub*32 + (e&3) + 8*(e>>2) + 4h, query j; value = |r|^2 - 2 q.r
+    // selection on value = |r|^2 - 2 q.r (element e of sub-tile `sub` is ref sub*32 + (e&3) + 8*(e>>2) + 4h, query j): per group
+    // of 4 elements a minimum first, so that groups without a candidate in any lane cost one compare (with 64 lanes per
+    // wavefront SOME lane has a candidate in almost every tile)
+    float m4[NSUB][4];
     float m = INFINITY;
 #pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub) {
+    for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
       for (int eg = 0; eg < 4; ++eg) {
         const float4 r4 = *(const float4*)(rnb + sub * 32 + 8 * eg + 4 * h);
@@ -418,24 +434,26 @@ __global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short
         acc[sub][eg * 4 + 1] = fmaf(-2.f, acc[sub][eg * 4 + 1], r4.y);
         acc[sub][eg * 4 + 2] = fmaf(-2.f, acc[sub][eg * 4 + 2], r4.z);
         acc[sub][eg * 4 + 3] = fmaf(-2.f, acc[sub][eg * 4 + 3], r4.w);
-        m = fminf(fminf(m, fminf(acc[sub][eg * 4 + 0], acc[sub][eg * 4 + 1])), fminf(acc[sub][eg * 4 + 2], acc[sub][eg * 4 + 3]));
+        m4[sub][eg] = fminf(fminf(acc[sub][eg * 4 + 0], acc[sub][eg * 4 + 1]), fminf(acc[sub][eg * 4 + 2], acc[sub][eg * 4 + 3]));
+        m = fminf(m, m4[sub][eg]);
       }
-    }
     if (__any(m < tau)) {
 #pragma unroll
       for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
-        for (int eg = 0; eg < 16; eg += 4) {
+        for (int eg = 0; eg < 4; ++eg) {
+          if (!KNN_GROUP_GUARD || __any(m4[sub][eg] < tau)) {
 #pragma unroll
-          for (int e = eg; e < eg + 4; ++e) {
-            const float v = acc[sub][e];
-            if (v < tau) {
-              ld[(KP + cnt) * 256 + tid] = v;
-              li[(KP + cnt) * 256 + tid] = (int)(t * BR) + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-              ++cnt;
+            for (int e = eg * 4; e < eg * 4 + 4; ++e) {
+              const float v = acc[sub][e];
+              if (v < tau) {
+                ld[(KP + cnt) * 256 + tid] = v;
+                li[(KP + cnt) * 256 + tid] = (int)(t * BR) + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                ++cnt;
+              }
             }
+            if (__any(cnt > KBUF - 4)) compact();
           }
-          if (__any(cnt > KBUF - 4)) compact();
         }
       }
     }
@@ -672,7 +690,13 @@ __global__ __launch_bounds__(256) void knn_maxnorm_kernel(const double* __restri
   if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
 }
 
-constexpr int bf16_nsub(int NKB, int KP) { return (NKB >= 6 || KP >= 32) ? 1 : 2; }
+#ifdef KNN_BF16_NSUB
+constexpr int bf16_nsub(int NKB, int KP) { return (NKB >= 6 || KP >= 32) ? 1 : KNN_BF16_NSUB; }
+#else
+// refs per tile = 32 * NSUB.  Measured (one box): 16-32 features: NSUB 2 (config 2: 1.88 vs 2.12 ms, config 3: 2.74 vs 3.09 ms);
+// 64 features: NSUB 1 -- a 17 KB tile lets three workgroups share a CU (n = 1e6: 376 vs 401 ms)
+constexpr int bf16_nsub(int NKB, int KP) { return (NKB >= 4 || KP >= 32) ? 1 : 2; }
+#endif
 
 template <int NKB, int KP>
 static int launch_tile_bf16(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st) {
