@@ -136,7 +136,12 @@ def scale_shard_line(steps=4, T=50):
     del X
     train_ind = gl.trainsets.generate(labels, rate=5, seed=0)
     out = {'n': n, 'nnz': int(W.nnz), 'd': 64, 'sweeps_per_step': T, 'graph_build_s': t_graph,
-           'knn_tile_tflops': 2.0 * n * n * st['dpa'] / st['tile_ms'] / 1e9}
+           'knn_tile_ms': st['tile_ms'], 'knn_filter': st['filter'],
+           # useful work 2 n^2 d_padded per second; the bf16x3 filter issues three bf16 MFMAs per product term, so its matrix-pipe
+           # utilisation is 3 x this against the 2500 TFLOP/s dense bf16 peak (the f32 filter: this against 157.3)
+           'knn_tile_tflops': 2.0 * n * n * st['dpa'] / st['tile_ms'] / 1e9,
+           'knn_mfma_util': (3.0 * 2.0 * n * n * st['dpa'] / st['tile_ms'] / 1e9 / 2500.0) if st['filter'] == 'bf16x3'
+           else (2.0 * n * n * st['dpa'] / st['tile_ms'] / 1e9 / 157.3)}
     for dt, dtype, es in (('f64', np.float64, 8), ('f32', np.float32, 4)):
         model = gl.ssl.poisson(W, solver='gradient_descent', use_cuda=(dtype == np.float32), min_iter=T, max_iter=T)
         dev, aux = model._operators()
@@ -312,7 +317,7 @@ def run_single(args):
                    'fp32_max_abs_diff': float(np.max(np.abs(r32['u'].astype(np.float64) - r64['u'])))},
         'fp32': {'value': args.steps * r32['T'] / r32['wall'],
                  'roofline_frac': a32 / (r32['dev_ms'] * 1e-3 / max(r32['launches'], 1)) / 1e9 / HBM_PEAK_GBS},
-        'graph_build': {'knn_plus_weights_s': t_graph, 'knn_tile_ms': knn_stats['tile_ms'],
+        'graph_build': {'knn_plus_weights_s': t_graph, 'knn_tile_ms': knn_stats['tile_ms'], 'knn_filter': knn_stats['filter'],
                         'knn_total_ms': knn_stats['total_ms'], 'fallback_rows': knn_stats['fallback_rows'],
                         'sell': r64['info']},
     }
