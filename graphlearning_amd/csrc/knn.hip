@@ -326,8 +326,17 @@ __global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short
       bh[kb] = __builtin_bit_cast(bf16x8, qrow[kb * 2 + h]);
       bl[kb] = __builtin_bit_cast(bf16x8, qrow[KPAD / 8 + kb * 2 + h]);
     }
+    // a use in front of the loop: the compiler waits for these loads HERE.  Left pending into the loop they make its
+    // wait-counter pass put decreasing vmcnt waits in front of the MFMAs of EVERY tile, which drain the tile's own staging
+    // loads (issued just before) instead of letting them travel under the matrix work
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const uint4 a = __builtin_bit_cast(uint4, bh[kb]), c = __builtin_bit_cast(uint4, bl[kb]);
+      asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w));
+    }
   }
   const float qn = nrm[qc];
+  asm volatile("" ::"v"(qn));
 #pragma unroll
   for (int p = 0; p < KP; ++p) { ld[p * 256 + tid] = INFINITY; li[p * 256 + tid] = -1; }
   float tau = INFINITY;          // thresholds are kept WITHOUT the query's norm: values are |r|^2 - 2 q.r

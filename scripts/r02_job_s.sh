@@ -1,0 +1,8 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+for fl in "-DKNN_PIPE=0" "-DKNN_PIPE=1"; do
+  export GLX_CXXFLAGS="$fl"
+  python -m graphlearning_amd._build > /dev/null 2>&1
+  echo "== $fl  ($(cat graphlearning_amd/libglx.hash))"; python scripts/knn_filter_probe.py big 2>&1 | grep "bf16:" | cut -c1-150
+done
