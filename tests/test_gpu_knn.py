@@ -183,3 +183,31 @@ def test_blobs5000_knn_graph_golden(gl, golden):
     Wg = csr_from(g, 'W')
     assert np.array_equal(W.indptr, Wg.indptr) and np.array_equal(W.indices, Wg.indices)
     assert np.max(np.abs(W.data - Wg.data)) <= 1e-12
+
+
+def test_knn_filter_soundness_on_near_duplicates_and_offsets(gl):
+    """The split-bf16 filter is only as good as its error bound: clusters of near-duplicate points (spread 1e-6 around
+    centres of norm ~10, on top of a common offset of 1e3) are far below what the filter can resolve, so the acceptance test
+    must hand those rows to the exact fp64 fallback -- and the answer must still be the exact one (cKDTree order)."""
+    from oracle import gl_oracle as orc
+    from graphlearning_amd import _hip
+    rng = np.random.default_rng(12)
+    centres = rng.normal(size=(300, 24)) * 2.0
+    X = np.repeat(centres, 10, axis=0) + rng.normal(size=(3000, 24)) * 1e-6 + 1e3
+    J_ref, D_ref = orc.knnsearch(X, 11)
+    for flt in ('bf16', 'f32'):
+        os.environ['GLX_KNN_FILTER'] = flt
+        try:
+            J, D = gl.weightmatrix.knnsearch(X, 11)
+        finally:
+            del os.environ['GLX_KNN_FILTER']
+        st = _hip.knn_stats()
+        # the 10 members of a cluster are each other's nearest neighbours; ties are broken by index like cKDTree's sort
+        assert np.array_equal(np.sort(J[:, :10], axis=1), np.sort(J_ref[:, :10], axis=1)), flt
+        assert np.max(np.abs(D - D_ref)) <= 1e-9 * 1e3                 # distances of order 1e-6 computed at offset 1e3: cancellation in fp64 itself
+        assert np.array_equal(J[:, 10], J_ref[:, 10]) or np.max(np.abs(D[:, 10] - D_ref[:, 10])) <= 1e-9
+        print(flt, 'fallback rows', st['fallback_rows'])
+    # exact duplicates: distance 0 ties resolved by index, self first
+    Y = np.repeat(rng.normal(size=(50, 7)), 4, axis=0)
+    J, D = gl.weightmatrix.knnsearch(Y, 4)
+    assert np.all(D == 0) and np.array_equal(np.sort(J, axis=1), (np.arange(200) // 4 * 4)[:, None] + np.arange(4)[None, :])
