@@ -29,7 +29,11 @@ def default_device():
 
 
 def _dev(device):
-    return _default_device if device is None else int(device)
+    if device is None:
+        return _default_device
+    if hasattr(device, 'index') and not isinstance(device, int):     # a torch.device
+        return int(device.index or 0)
+    return int(device)
 
 
 class GlxError(RuntimeError):

@@ -170,7 +170,9 @@ def _alltoallv(dist, arrays, dtype, group=None, device=None):
     tdt = {np.int64: torch.int64, np.float64: torch.float64}[dtype]
     counts = torch.tensor([len(a) for a in arrays], dtype=torch.int64)
     rcounts = torch.empty(world, dtype=torch.int64)
-    dev = device if dist.get_backend(group) == 'nccl' else None
+    dev = None
+    if dist.get_backend(group) == 'nccl':          # device collectives: tensors live on this rank's GPU
+        dev = torch.device('cuda', device) if isinstance(device, int) else (device if device is not None else torch.device('cuda', torch.cuda.current_device()))
     if dev is not None:
         counts, rcounts = counts.to(dev), rcounts.to(dev)
     dist.all_to_all_single(rcounts, counts, group=group)
@@ -209,8 +211,8 @@ class ShardedGraph:
         got = _alltoallv(dist, reqs, np.int64, group, device)
         import torch
         tot = torch.tensor([len(needed)], dtype=torch.int64)
-        if dist.get_backend(group) == 'nccl' and device is not None:
-            tot = tot.to(device)
+        if dist.get_backend(group) == 'nccl':
+            tot = tot.to(torch.device('cuda', device) if isinstance(device, int) else (device if device is not None else torch.device('cuda', torch.cuda.current_device())))
         dist.all_reduce(tot, group=group)
         self.plan = ShardPlan(self.P_own, lo, hi, n, rank, bounds, needed, got, int(tot.item()))
 

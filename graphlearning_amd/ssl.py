@@ -92,6 +92,10 @@ class ssl:
         self.device = None      # None -> _hip.default_device() (set_default_device(LOCAL_RANK) in multi-GPU processes)
 
     def set_graph(self, W):
+        st = getattr(self, '_dev_state', None)
+        if st is not None and getattr(self, '_prob', None) is None and st.valid():
+            self._prob = st.fetch()          # a result still on the device belongs to the old graph's sweep: read it back first
+            self._dev_state = None
         if type(W) == graph_mod.graph:
             self.graph = W
         else:
