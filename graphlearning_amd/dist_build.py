@@ -29,6 +29,39 @@ from scipy import sparse
 from .dist import block_bounds
 
 
+# ---- step 0: a cheap locality order before sharding ------------------------------------------------------------------
+def coarse_locality_order(X, ncells=64, seed=0, chunk=262144):
+    """Permutation (new -> old) that makes contiguous blocks of vertices geometrically compact BEFORE the graph exists
+    ("blobs/clusters first"): every point goes to the nearest of `ncells` sample points, the cells are
+    chained greedily by nearest unvisited cell (cells of one cluster end up next to each other), and points are
+    sorted by their cell's place in the chain (stable: original order inside a cell).  O(n * ncells * d) on the host,
+    the same on every rank.  Ranks that own contiguous blocks of this order import only the neighbours across their
+    block boundaries instead of (for data in arbitrary order) nearly every vertex of the graph."""
+    X = np.asarray(X)
+    n = X.shape[0]
+    ncells = int(min(ncells, n))
+    rng = np.random.default_rng(seed)
+    cent = X[np.sort(rng.choice(n, size=ncells, replace=False))].astype(np.float64)
+    cn = np.einsum('ij,ij->i', cent, cent)
+    cell = np.empty(n, dtype=np.int32)
+    for lo in range(0, n, chunk):
+        blk = X[lo:lo + chunk]
+        d2 = cn[None, :] - 2.0 * (blk @ cent.T)            # + |x|^2, constant per row
+        cell[lo:lo + chunk] = np.argmin(d2, axis=1)
+    # chain of cells: start at the cell farthest from the centroid mean, always go to the nearest unvisited one
+    dc = cn[:, None] + cn[None, :] - 2.0 * (cent @ cent.T)
+    start = int(np.argmax(np.sum((cent - cent.mean(axis=0)) ** 2, axis=1)))
+    place = np.full(ncells, -1, dtype=np.int64)
+    cur, seen = start, np.zeros(ncells, dtype=bool)
+    for pos in range(ncells):
+        place[cur] = pos
+        seen[cur] = True
+        if pos + 1 < ncells:
+            cand = np.where(seen, np.inf, dc[cur])
+            cur = int(np.argmin(cand))
+    return np.argsort(place[cell], kind='stable').astype(np.int64)
+
+
 # ---- step 2: symmetrisation by owner -------------------------------------------------------------------------------
 def knn_weights_rows(J, D, k, kernel='gaussian'):
     """Kernel weights of a block of kNN lists (reference weightmatrix.py:134-156; every kernel here needs only the

@@ -209,3 +209,30 @@ def test_sharded_planner_scales_per_rank():
     assert sum(plan.send_counts) == len(plan.send_idx) and max(plan.send_idx) < plan.n_boundary
     print('one rank of 8 at n=1e6: %.1f s, peak traced memory %.0f MB, own nnz %d, halo %d' % (t_build, peak / 1e6, W_own.nnz, len(needed)))
     assert t_build < 120 and peak < 2.5e9
+
+
+def test_coarse_locality_order_shrinks_the_halo():
+    """Sharding points in arbitrary order makes nearly every neighbour remote; after dist_build.coarse_locality_order the
+    contiguous blocks are geometrically compact and import only the neighbours across their boundaries."""
+    from graphlearning_amd import dist_build, dist as gdist
+    from oracle import gl_oracle as orc
+    from conftest import blobs
+    X, lab = blobs(16000, 16, 10, 3, 4.0)
+    world, k = 8, 10
+
+    def halo_rows(Xo):
+        J, D = orc.knnsearch(Xo, k + 1)
+        W = orc.knn_weights(J, D, k)
+        n = W.shape[0]
+        bounds = gdist.block_bounds(n, world)
+        tot = 0
+        for r in range(world):
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            cols = np.unique(W[lo:hi].indices)
+            tot += int(np.sum((cols < lo) | (cols >= hi)))
+        return tot
+    perm = dist_build.coarse_locality_order(X, ncells=64, seed=0)
+    assert np.array_equal(np.sort(perm), np.arange(len(X)))
+    before, after = halo_rows(X), halo_rows(X[perm])
+    print('halo rows over 8 ranks: %d in data order, %d after the coarse order (n = %d)' % (before, after, len(X)))
+    assert after * 3 < before
