@@ -358,7 +358,6 @@ extern "C" int glx_dist_sweep_set_problem(glx_dist_sweep* s, const void* Db_own,
 }
 
 // ---- pieces of one sweep ----------------------------------------------------------------------------------
-template <int VW>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src, char* __restrict__ dst, const int32_t* __restrict__ idx,
                                                           int64_t nrec, int rec_bytes) {
   // 16 bytes per thread, rec_bytes / 16 threads per record
@@ -395,7 +394,7 @@ static int enqueue_pack(glx_dist_sweep* s, const void* x) {
   if (s->n_send == 0) return GLX_OK;
   const int rb = s->L.ld * s->L.esize;
   const int64_t tot = s->n_send * (rb / 16);
-  hipLaunchKernelGGL(gather_rows_kernel<16>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (const char*)x, (char*)s->sendbuf,
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (const char*)x, (char*)s->sendbuf,
                      (const int32_t*)s->send_idx, s->n_send, rb);
   GLX_HIP(hipGetLastError());
   return GLX_OK;
