@@ -650,7 +650,8 @@ def knn_to_csr(knn_ind, knn_dist, k, kernel='gaussian', sym=1, weights=None, dev
     from scipy import sparse
     ind = np.ascontiguousarray(knn_ind, dtype=np.int64)
     n, kk = ind.shape
-    dist = None if knn_dist is None else _dense(knn_dist, np.float64, (n, kk), 'knn_dist')
+    # distances are only read by the kernels that compute weights from them: with given weights they need not travel
+    dist = None if (knn_dist is None or kernel == 'given') else _dense(knn_dist, np.float64, (n, kk), 'knn_dist')
     w = None if weights is None else _dense(weights, np.float64, (n, k), 'weights')
     rp, ci, va = _vp(), _vp(), _vp()
     nnz = C.c_int64(0)
