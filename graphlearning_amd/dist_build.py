@@ -282,8 +282,9 @@ def poisson_fit_sharded(dist, n, J_own, D_own, k, train_ind, train_labels, engin
                         min_iter=50, max_iter=1000, kernel='gaussian', group=None, check_every=8, gather=True, dtype=np.float64):
     """weightmatrix.knn + ssl.poisson(solver='gradient_descent').fit with every rank holding only its block of rows:
     (J_own, D_own) are the kNN lists (self included, k+1 columns) of the rank's rows [lo, hi) of block_bounds(n, world).
-    engine 'glx': the library-owned sweep (glx_dist_sweep over a libglx RCCL communicator); 'ops': dist.DistSweep with
-    the rank-local kernel from ops_factory(plan, classes) (CPU tests).  Returns (u, T, sharded graph); u is the full
+    engine 'glx': the library-owned sweep (glx_dist_sweep over a libglx RCCL communicator); 'glxstep': the same object with
+    `dist` moving the packed records (ranks sharing one GPU); 'ops': dist.DistSweep with the rank-local kernel from
+    ops_factory(plan, classes) (CPU tests).  Returns (u, T, sharded graph); u is the full
     (n, C) matrix (gather=True) or this rank's rows in plan.own order."""
     from . import dist as gdist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -295,7 +296,16 @@ def poisson_fit_sharded(dist, n, J_own, D_own, k, train_ind, train_labels, engin
         v = np.zeros(n)
         v[np.asarray(train_ind)] = 1.0 / float(len(train_ind))
         err0 = float(np.max(np.absolute(v - prob['vinf_all'])))
-    if engine == 'glx':
+    if engine == 'glxstep':          # the C-ABI sweep object with `dist` as the transport (several ranks on ONE GPU, or no RCCL)
+        from . import _hip
+        comm_s = _hip.Comm(world, rank, None, device)
+        ds = gdist.glx_dist_sweep(comm_s, plan, prob['k'], dtype=dtype)
+        ds.set_problem(prob['Db'], prob['w0'], prob['deg'], prob['vinf'])
+        T = gdist.run_stepwise(ds, plan, dist, min_iter, max_iter, err0, group)
+        u_own = ds.fetch()
+        ds.close()
+        comm_s.close()
+    elif engine == 'glx':
         own_comm = comm is None
         if comm is None:
             comm = gdist.init_comm(dist, device, group)

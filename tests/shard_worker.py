@@ -18,6 +18,7 @@ from dist_worker import ScipyOps
 
 def main():
     case, out_path = sys.argv[1], sys.argv[2]
+    engine = sys.argv[3] if len(sys.argv) > 3 else 'ops'      # 'glxstep': rank-local pieces by libglx on cuda:0, gloo as the transport
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     from conftest import blobs
@@ -43,8 +44,8 @@ def main():
     tl = lab[ti]
     bounds = gdist.block_bounds(n, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    u, T, sg = dist_build.poisson_fit_sharded(dist, n, J[lo:hi], D[lo:hi], k, ti, tl, engine='ops', ops_factory=lambda plan, C: ScipyOps(plan, C),
-                                             min_iter=min_iter, max_iter=max_iter, kernel=kernel)
+    u, T, sg = dist_build.poisson_fit_sharded(dist, n, J[lo:hi], D[lo:hi], k, ti, tl, engine=engine, ops_factory=lambda plan, C: ScipyOps(plan, C),
+                                             min_iter=min_iter, max_iter=max_iter, kernel=kernel, device=0)
     # oracle: the whole pipeline in one process
     W = orc.knn_weights(J, D, k, kernel=kernel)
     W.sort_indices()

@@ -252,3 +252,23 @@ def test_glx_dist_fp32_matches_single_gpu_fp32(golden):
     assert np.array_equal(full, u32)
     ds.close()
     comm.close()
+
+
+@pytest.mark.parametrize('case,world', [('blobs', 3), ('miniter0', 2)])
+def test_sharded_build_multi_rank_hip_over_gloo(case, world, tmp_path):
+    """The config-4 pipeline with several ranks on the one GPU: every rank builds only its rows (dist_build over gloo), the
+    rank-local sweeps run in libglx (glx_dist_sweep, stepwise form), gloo moves the packed records: bit-identical to the
+    single-process oracle, as in the CPU version of this test."""
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    out = str(tmp_path / ('shard_gpu_' + case))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'shard_worker.py'), case, out, 'glxstep']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS='1'), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for k in range(world):
+        q = json.load(open(out + '.%d' % k))
+        assert q['w_ok'] and q['p_ok'] and q['deg_ok'] and q['plan_ok'] and q['T'] == q['T_ref'] and q['equal'], q
