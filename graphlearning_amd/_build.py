@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'libglx.so')
 # RCCL (csrc/dist.hip) is bound at run time with dlopen, so the library loads without it
-LINK_LIBS = ['-ldl']
+LINK_LIBS = ['-ldl', '-lpthread']
 
 
 def sources():
