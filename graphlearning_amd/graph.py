@@ -10,6 +10,8 @@ from scipy import sparse
 class graph:
     def __init__(self, W, labels=None, features=None, label_names=None, node_names=None):
         self.weight_matrix = sparse.csr_matrix(W)
+        if getattr(W, '_glx_sym', None) is not None:
+            self.weight_matrix._glx_sym = W._glx_sym      # valid only while the wrapper shares W's arrays: utils.known_symmetric compares addresses
         self.labels = labels
         self.features = features
         self.num_nodes = W.shape[0]

@@ -249,6 +249,23 @@ class ssl:
         raise NotImplementedError('Must override _fit')
 
 
+def _poisson_operator_symmetric(W):
+    """deg, D^-1 and P = D^-1 W^T (reference ssl.py:615-617, 634-635, 642) for a W known to be symmetric bit for bit with an
+    empty diagonal (weightmatrix.knn's output): row i of W^T is row i of W, so nothing is transposed.  scipy's `D * W.transpose()`
+    turns W^T into a sorted CSR and multiplies with csr_matmat, which emits every row's entries in REVERSE order (the linked list
+    it builds is walked from the last insertion); the same arrays are written down directly: row i = (dinv_i * w_ij) for j
+    descending.  Identical to the scipy expressions entry for entry (tests/test_host_logic.py)."""
+    n = W.shape[0]
+    deg = W * np.ones(n)                                   # graph.degree_vector (W - spdiags(diag) == W: no diagonal entries)
+    dinv = deg ** (-1)                                     # graph.degree_matrix(p=-1): d ** p
+    indptr = W.indptr
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
+    rev = indptr[rows].astype(np.int64) + indptr[rows + 1] - 1 - np.arange(W.nnz, dtype=np.int64)    # mirror inside the row
+    P = sparse.csr_matrix(((dinv[rows] * W.data)[rev], W.indices[rev], indptr.copy()), shape=(n, n))
+    P.has_sorted_indices = False
+    return P, deg, dinv
+
+
 def _poisson_source(n, train_ind, train_labels):
     """b[train] = onehot - mean(onehot) (reference ssl.py:619-622)."""
     k = len(np.unique(train_labels))
@@ -299,8 +316,10 @@ class poisson(ssl):
             return self._cache[1], self._cache[2]
         n = self.graph.num_nodes
         W = self.graph.weight_matrix
-        W = W - sparse.spdiags(W.diagonal(), 0, n, n)
-        G = graph_mod.graph(W)
+        fast = (self.solver != 'conjugate_gradient' and utils.known_symmetric(W) and not W.diagonal().any())
+        if not fast:
+            W = W - sparse.spdiags(W.diagonal(), 0, n, n)
+            G = graph_mod.graph(W)
         aux = {}
         if self.solver == 'conjugate_gradient':
             L = G.laplacian(normalization='normalized')
@@ -308,6 +327,14 @@ class poisson(ssl):
             # one-shot CG solves spend their time in the reference-order reductions, not in the SpMM:
             # the locality renumbering (an O(nnz) host pass) would not pay for itself
             dev = _hip.DeviceGraph(L, dtype=self._dtype(), device=self.device, keep_order=True)
+        elif fast:
+            P, deg, dinv = _poisson_operator_symmetric(W)
+            aux['D'] = sparse.spdiags(dinv, 0, n, n).tocsr()
+            aux['dinv'] = dinv
+            aux['zero_degree'] = bool(np.any(~np.isfinite(aux['dinv'])))
+            aux['deg'] = deg
+            aux['vinf'] = deg / np.sum(deg)
+            dev = _hip.DeviceGraph(P, dtype=self._dtype(), device=self.device)
         else:
             D = G.degree_matrix(p=-1)
             P = D * W.transpose()

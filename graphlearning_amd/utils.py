@@ -69,3 +69,16 @@ def _boundary_handling(bdy_set, bdy_val):
     if type(bdy_val) != np.ndarray:
         bdy_val = np.ones((m,)) * bdy_val
     return bdy_set, bdy_val
+
+
+def symmetric_fingerprint(W):
+    """What weightmatrix.knn stamps on a matrix it has just symmetrised (attribute `_glx_sym`), so that later consumers may
+    skip forming W^T: addresses of the three CSR arrays plus two sums of the data.  A matrix whose structure was edited has
+    new arrays, one whose values were edited in place has other sums; anything that does not match is treated as unknown."""
+    addr = lambda a: a.__array_interface__['data'][0]
+    return (addr(W.data), addr(W.indices), addr(W.indptr), int(W.nnz), float(W.data.sum()), float(W.data[::97].sum()))
+
+
+def known_symmetric(W):
+    tag = getattr(W, '_glx_sym', None)
+    return tag is not None and tag == symmetric_fingerprint(W)

@@ -17,6 +17,15 @@ knn_dir = os.path.abspath(os.path.join(os.getcwd(), 'knn_data'))
 
 def knn(data, k, kernel='gaussian', eta=None, symmetrize=True, metric='raw', similarity='euclidean', knn_data=None,
         device=None):
+    W = _knn(data, k, kernel, eta, symmetrize, metric, similarity, knn_data, device)
+    if symmetrize:
+        # symmetric bit for bit ((a+b)/2 = (b+a)/2, max and the symgaussian rule likewise) with an empty diagonal: stamped so
+        # that ssl.poisson can write down D^-1 W^T without transposing (utils.known_symmetric re-checks the stamp)
+        W._glx_sym = utils.symmetric_fingerprint(W)
+    return W
+
+
+def _knn(data, k, kernel, eta, symmetrize, metric, similarity, knn_data, device):
     """kNN weight matrix, same signature and result as reference weightmatrix.py:68-187.
     Returns a scipy CSR (n,n) float64 matrix: symmetric (unless symmetrize=False), zero
     diagonal, canonical format."""

@@ -173,3 +173,37 @@ def test_load_knn_data_reads_the_reference_cache_file(golden, monkeypatch):
         assert J.shape == (300, 8) and np.array_equal(J, g['J']) and np.array_equal(D, g['D'])
     with pytest.raises(SystemExit):
         wm.load_knn_data('no_such_dataset')
+
+
+def test_symmetric_poisson_operator_equals_scipy_expressions(golden):
+    """ssl._poisson_operator_symmetric writes down D^-1 W^T of a symmetric W without transposing: indptr, indices (descending
+    inside a row, the order scipy's csr product leaves) and data must equal the reference's own expressions
+    (ssl.py:615-617, 634-635) entry for entry; the stamp weightmatrix.knn puts on its output is invalidated by edits."""
+    from graphlearning_amd import ssl as glssl, utils as glutils, graph as glgraph
+    from oracle import gl_oracle as orc
+    from conftest import csr_from
+    cases = [csr_from(golden('g1_twomoons.npz'), 'W_gaussian'), csr_from(golden('g1_twomoons.npz'), 'W_uniform'), csr_from(golden('g3_blobs5000.npz'), 'W')]
+    R = sparse.random(300, 300, density=0.03, random_state=3, format='csr')
+    R = (R + R.T).tocsr()
+    R.setdiag(0)
+    R.eliminate_zeros()
+    cases.append(R)
+    for W in cases:
+        n = W.shape[0]
+        Wz = W - sparse.spdiags(W.diagonal(), 0, n, n)
+        D = sparse.spdiags(orc.degree_vector(Wz) ** (-1), 0, n, n).tocsr()
+        P_ref = sparse.csr_matrix(D * Wz.transpose())
+        P, deg, dinv = glssl._poisson_operator_symmetric(sparse.csr_matrix(W))
+        assert np.array_equal(P.indptr, P_ref.indptr) and np.array_equal(P.indices, P_ref.indices)
+        assert np.array_equal(P.data, P_ref.data)
+        assert np.array_equal(deg, orc.degree_vector(Wz)) and np.array_equal(dinv, D.diagonal())
+    # the stamp: valid on the stamped arrays and through graph(), gone after an in-place edit or a structural one
+    W = sparse.csr_matrix(cases[0])
+    W._glx_sym = glutils.symmetric_fingerprint(W)
+    assert glutils.known_symmetric(W) and glutils.known_symmetric(glgraph.graph(W).weight_matrix)
+    W.data[3] *= 1.5
+    assert not glutils.known_symmetric(W)
+    W2 = sparse.csr_matrix(cases[0])
+    W2._glx_sym = glutils.symmetric_fingerprint(W2)
+    W3 = W2 + sparse.identity(W2.shape[0])
+    assert not glutils.known_symmetric(W3) and not glutils.known_symmetric(sparse.csr_matrix(cases[0]))
