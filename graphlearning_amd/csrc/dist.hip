@@ -553,7 +553,7 @@ extern "C" int glx_poisson_sweep_dist(glx_dist_sweep* s, int min_iter, int max_i
       if (rc) return rc;
       const int cnt = std::min(check_every, max_iter - T);
       const int cur0 = s->cur;
-      rc = run_captured(s, (long)cur0 * 128 + cnt, [&]() -> int {
+      rc = run_captured(s, (long)R * 100000L + (long)cur0 * 128 + cnt, [&]() -> int {   // the ring size is part of the buffers a chunk touches
         GLX_HIP(hipMemsetAsync(s->err + ERR_SHARDS, 0, (size_t)cnt * ERR_SHARDS * 8, s->stream));
         int r2 = GLX_OK;
         for (int j = 0; j < cnt && !r2; ++j)

@@ -134,6 +134,20 @@ def test_glx_dist_one_rank_tail_chunks_match_golden(golden, check_every):
     full[plan.own] = u
     assert np.array_equal(full, g['poisson_gd_prob'])
     assert stats['exchanges'] == 0 and stats['graphs'] >= 2
+    # the same sweep object run with different chunk lengths one after another (captured chunks are keyed by the ring they use)
+    prob = gdist.poisson_problem(W, ti, lab[ti])
+    order = gdist.locality_order(prob['P'])
+    pl = gdist.RankPlan(prob['P'], order, gdist.block_bounds(W.shape[0], 1), 0)
+    comm = _hip.Comm(1, 0, None, 0)
+    ds = gdist.glx_dist_sweep(comm, pl, prob['k'])
+    ds.set_problem(prob['Db'][pl.own], prob['w0'][pl.own], prob['deg'][pl.own], prob['vinf'][pl.own])
+    for ce in (8, 3, 8, 1, 5):
+        Tq, _ = ds.run(50, 1000, ce, 0.0)
+        fq = np.zeros_like(g['poisson_gd_prob'])
+        fq[pl.own] = ds.fetch()
+        assert Tq == 409 and np.array_equal(fq, g['poisson_gd_prob']), ce
+    ds.close()
+    comm.close()
     # max_iter below the stop iteration, and below min_iter
     for mi, ma in ((50, 60), (50, 30), (0, 25)):
         from oracle import gl_oracle as orc
