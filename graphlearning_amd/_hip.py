@@ -77,6 +77,7 @@ _SIGNATURES = {
     'glx_sweep_run': [_vp, C.POINTER(C.c_int), C.POINTER(C.c_float)],
     'glx_sweep_fetch': [_vp, _vp],
     'glx_sweep_launches': [_vp, _i64p],
+    'glx_sweep_stop_values': [_vp, C.c_int64, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     'glx_sweep_destroy': [_vp],
     'glx_sweep_set_state': [_vp, _vp, _vp],
     'glx_sweep_iterate': [_vp, C.c_int],
@@ -418,6 +419,14 @@ class Sweep:
         check(load().glx_sweep_run(self._h, C.byref(T), C.byref(ms)), 'glx_sweep_run')
         self.generation = getattr(self, 'generation', 0) + 1
         return T.value, ms.value
+
+    def stop_values(self):
+        """(first, values): the stop values max|v_t - v_inf| the last run() compared with 1/n, t = first, first+1, ..."""
+        first, count = C.c_int(0), C.c_int(0)
+        check(load().glx_sweep_stop_values(self._h, 0, None, C.byref(first), C.byref(count)), 'glx_sweep_stop_values')
+        vals = np.empty(count.value, dtype=np.float64)
+        check(load().glx_sweep_stop_values(self._h, len(vals), _ptr(vals), C.byref(first), C.byref(count)), 'glx_sweep_stop_values')
+        return first.value, vals
 
     def set_state(self, u0, Db=None):
         n = self.graph.shape[0]

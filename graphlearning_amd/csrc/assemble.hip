@@ -4,7 +4,8 @@
 // (:185-186).  No global sort: every row of A has exactly k entries, so A^T is built by
 // counting reverse neighbours (atomics) + a host scan of n counters, then one wavefront per
 // row merges its forward and reverse lists with a bitonic sort in LDS and applies the
-// symmetrisation rule per column.  Output: canonical CSR (sorted, no duplicates, no zeros).
+// symmetrisation rule per column; a hub vertex (more entries than one wavefront's LDS share holds)
+// gets a whole workgroup that sorts in a global scratch.  Output: canonical CSR (sorted, no duplicates, no zeros).
 #include "glx_internal.h"
 #define GLX_POOL(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 #include <algorithm>
@@ -59,21 +60,32 @@ __global__ void count_reverse_kernel(const int64_t* __restrict__ ind, int64_t n,
 
 __global__ void fill_reverse_kernel(const int64_t* __restrict__ ind, const double* __restrict__ w, int64_t n, int kk, int k,
                                     const int64_t* __restrict__ roff, int* __restrict__ cursor, int* __restrict__ rsrc,
-                                    double* __restrict__ rw) {
+                                    unsigned short* __restrict__ rpos, double* __restrict__ rw) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n * k) return;
   const int64_t i = e / k;
   const int64_t j = ind[i * kk + (e % k)];
   const int64_t pos = roff[j] + atomicAdd(&cursor[j], 1);
   rsrc[pos] = (int)i;
+  rpos[pos] = (unsigned short)(e % k);   // duplicates of one source row are summed in the order the row lists them
   rw[pos] = w[e];
+}
+
+__device__ __forceinline__ double combine_entry(double a, double b, int sym) {
+#pragma clang fp contract(off)
+  if (sym == SYM_NONE) return a;
+  if (sym == SYM_MEAN) return (a + b) / 2.0;                                // (W + W^T)/2, weightmatrix.py:183
+  if (sym == SYM_MAX) return (b > a) ? b : (((a + b) > 0.0) ? a : 0.0);     // utils.sparse_max(W, W^T), utils.py:263-286
+  if (b > a) { const double s = a + b; return s - a; }                      // W + W^T*(W^T>W) - W*(W^T>W), weightmatrix.py:181
+  return a;
 }
 
 // one wavefront per row: merge forward (tag 0) and reverse (tag 1) entries, combine per column
 // mode 0: count kept entries -> rowcnt[i];  mode 1: write them at rowptr[i]
 __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restrict__ ind, const double* __restrict__ w, int64_t n, int kk,
                                                          int k, const int64_t* __restrict__ roff, const int* __restrict__ rsrc,
-                                                         const double* __restrict__ rw, int sym, int mode, int* __restrict__ rowcnt,
+                                                         const unsigned short* __restrict__ rpos, const double* __restrict__ rw, int sym,
+                                                         int mode, int* __restrict__ rowcnt,
                                                          const int64_t* __restrict__ rowptr, int* __restrict__ col_out,
                                                          double* __restrict__ val_out, int* __restrict__ overflow) {
 #pragma clang fp contract(off)
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restri
   if (i >= n) return;
   const int rc = sym == SYM_NONE ? 0 : (int)(roff[i + 1] - roff[i]);
   const int M = k + rc;
-  if (M > ROW_CAP) {   // hub vertex: merged on the host (rare), see glx_knn_to_csr
+  if (M > ROW_CAP) {   // hub vertex: merge_hub_kernel's
     if (lane == 0 && !mode) { rowcnt[i] = -1; *overflow = 1; }
     return;
   }
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restri
       v = w[i * k + e];
     } else if (e < M) {
       const int64_t p = roff[i] + (e - k);
-      kx = ((unsigned long long)(unsigned)rsrc[p] << 32) | (1ull << 16) | (unsigned)(e - k);
+      kx = ((unsigned long long)(unsigned)rsrc[p] << 32) | (1ull << 16) | (unsigned)rpos[p];
       v = rw[p];
     }
     key[e] = kx;
@@ -144,15 +156,7 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restri
         for (int q = e; q < M && (int)(key[q] >> 32) == c; ++q) {
           if ((key[q] >> 16) & 1) b = b + val[q]; else a = a + val[q];
         }
-        if (sym == SYM_NONE) {
-          v = a;
-        } else if (sym == SYM_MEAN) {            // (W + W^T)/2, weightmatrix.py:183
-          v = (a + b) / 2.0;
-        } else if (sym == SYM_MAX) {             // utils.sparse_max(W, W^T), utils.py:263-286
-          v = (b > a) ? b : (((a + b) > 0.0) ? a : 0.0);
-        } else {                                 // W + W^T*(W^T>W) - W*(W^T>W), weightmatrix.py:181
-          if (b > a) { const double s = a + b; v = s - a; } else v = a;
-        }
+        v = combine_entry(a, b, sym);
         keep = (c != (int)i) && (v != 0.0);      // setdiag(0); eliminate_zeros(), weightmatrix.py:185-186
       }
     }
@@ -167,29 +171,109 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restri
   if (!mode && lane == 0) rowcnt[i] = kept_before;
 }
 
-// the per-column combination rule, shared by the device kernel (above, inline) and the host path
-static double combine_host(double a, double b, int sym) {
-  if (sym == SYM_NONE) return a;
-  if (sym == SYM_MEAN) return (a + b) / 2.0;
-  if (sym == SYM_MAX) return (b > a) ? b : (((a + b) > 0.0) ? a : 0.0);
-  if (b > a) { const double s = a + b; return s - a; }
-  return a;
+// hub vertices (more than ROW_CAP forward + reverse entries; high-dimensional data has them): one workgroup per hub,
+// the same keys sorted by the same bitonic network in a global scratch of P entries (P = power of two >= M), then the
+// same segment rule.  mode 0 sorts and counts, mode 1 writes from the scratch mode 0 left sorted.
+__global__ __launch_bounds__(1024) void merge_hub_kernel(const int64_t* __restrict__ ind, const double* __restrict__ w, int kk, int k,
+                                                         const int64_t* __restrict__ roff, const int* __restrict__ rsrc,
+                                                         const unsigned short* __restrict__ rpos, const double* __restrict__ rw, int sym,
+                                                         int mode, const int64_t* __restrict__ hub_row, const int64_t* __restrict__ hub_off,
+                                                         unsigned long long* __restrict__ skey, double* __restrict__ sval,
+                                                         int* __restrict__ hub_cnt, const int64_t* __restrict__ rowptr,
+                                                         int* __restrict__ col_out, double* __restrict__ val_out) {
+#pragma clang fp contract(off)
+  __shared__ int wcnt[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t i = hub_row[blockIdx.x];
+  const int64_t P = hub_off[blockIdx.x + 1] - hub_off[blockIdx.x];
+  unsigned long long* key = skey + hub_off[blockIdx.x];      // (col << 32) | (tag << 31) | seq
+  double* val = sval + hub_off[blockIdx.x];
+  const int64_t rc = roff[i + 1] - roff[i];
+  const int64_t M = k + rc;
+  if (!mode) {
+    for (int64_t e = tid; e < P; e += 1024) {
+      unsigned long long kx = ~0ull;
+      double v = 0.0;
+      if (e < k) {
+        kx = ((unsigned long long)(unsigned)ind[i * kk + e] << 32) | (unsigned)e;
+        v = w[i * k + e];
+      } else if (e < M) {
+        const int64_t p = roff[i] + (e - k);
+        kx = ((unsigned long long)(unsigned)rsrc[p] << 32) | (1ull << 31) | (unsigned)rpos[p];
+        v = rw[p];
+      }
+      key[e] = kx;
+      val[e] = v;
+    }
+    __syncthreads();
+    for (int64_t size = 2; size <= P; size <<= 1) {
+      for (int64_t stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int64_t t = tid; t < P / 2; t += 1024) {
+          const int64_t lo = (t / stride) * stride * 2 + (t % stride);
+          const int64_t hi = lo + stride;
+          const bool up = ((lo & size) == 0);
+          const unsigned long long kl = key[lo], kh = key[hi];
+          if (up ? (kh < kl) : (kl < kh)) {
+            key[lo] = kh;
+            key[hi] = kl;
+            const double vl = val[lo];
+            val[lo] = val[hi];
+            val[hi] = vl;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  int kept_before = 0;   // uniform across the workgroup
+  const int64_t obase = mode ? rowptr[i] : 0;
+  for (int64_t e0 = 0; e0 < M; e0 += 1024) {
+    const int64_t e = e0 + tid;
+    bool keep = false;
+    int c = 0;
+    double v = 0.0;
+    if (e < M) {
+      c = (int)(key[e] >> 32);
+      if (e == 0 || (int)(key[e - 1] >> 32) != c) {          // first entry of a column
+        double a = 0.0, b = 0.0;   // a = A[i,c] (forward, duplicates summed), b = A[c,i] (reverse)
+        for (int64_t q = e; q < M && (int)(key[q] >> 32) == c; ++q) {
+          if ((key[q] >> 31) & 1) b = b + val[q]; else a = a + val[q];
+        }
+        v = combine_entry(a, b, sym);
+        keep = (c != (int)i) && (v != 0.0);                   // setdiag(0); eliminate_zeros(), weightmatrix.py:185-186
+      }
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) wcnt[wave] = __popcll(mask);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int q = 0; q < 16; ++q) {
+      if (q < wave) before += wcnt[q];
+      total += wcnt[q];
+    }
+    if (keep && mode) {
+      const int64_t pos = obase + kept_before + before + __popcll(mask & ((1ull << lane) - 1ull));
+      col_out[pos] = c;
+      val_out[pos] = v;
+    }
+    kept_before += total;
+    __syncthreads();
+  }
+  if (!mode && tid == 0) hub_cnt[blockIdx.x] = kept_before;
 }
 
-struct HostRow {
-  std::vector<int32_t> col;
-  std::vector<double> val;
-};
-
 struct AsmBufs {
-  int64_t *ind = nullptr, *roff = nullptr, *rowptr = nullptr;
-  double *dist = nullptr, *given = nullptr, *w = nullptr, *rw = nullptr, *val = nullptr;
-  int *rcnt = nullptr, *cursor = nullptr, *rsrc = nullptr, *rowcnt = nullptr, *col = nullptr, *flag = nullptr;
+  int64_t *ind = nullptr, *roff = nullptr, *rowptr = nullptr, *hub_row = nullptr, *hub_off = nullptr;
+  unsigned long long* skey = nullptr;
+  unsigned short* rpos = nullptr;
+  double *dist = nullptr, *given = nullptr, *w = nullptr, *rw = nullptr, *val = nullptr, *sval = nullptr;
+  int *rcnt = nullptr, *cursor = nullptr, *rsrc = nullptr, *rowcnt = nullptr, *col = nullptr, *flag = nullptr, *hub_cnt = nullptr;
   hipStream_t stream = nullptr;
   ~AsmBufs() {
     if (stream) hipStreamSynchronize(stream);   // pooled blocks are reused at once
     glx_pool_free(ind); glx_pool_free(roff); glx_pool_free(rowptr); glx_pool_free(dist); glx_pool_free(given); glx_pool_free(w); glx_pool_free(rw); glx_pool_free(val);
     glx_pool_free(rcnt); glx_pool_free(cursor); glx_pool_free(rsrc); glx_pool_free(rowcnt); glx_pool_free(col); glx_pool_free(flag);
+    glx_pool_free(hub_row); glx_pool_free(hub_off); glx_pool_free(skey); glx_pool_free(sval); glx_pool_free(hub_cnt); glx_pool_free(rpos);
     if (stream) hipStreamDestroy(stream);
   }
 };
@@ -202,6 +286,7 @@ extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const doub
   GLX_CHECK(sym >= SYM_NONE && sym <= SYM_SYMGAUSS, GLX_EINVAL, "glx_knn_to_csr: bad symmetrisation id %d", sym);
   GLX_CHECK(kernel == K_GIVEN ? weights != nullptr : (kernel == K_UNIFORM || dist != nullptr), GLX_EINVAL, "glx_knn_to_csr: missing weights / distances");
   GLX_CHECK(n < (1ll << 31) && n * k < (1ll << 31), GLX_EUNSUPPORTED, "glx_knn_to_csr: n*k must fit int32");
+  GLX_CHECK(k <= 65535, GLX_EUNSUPPORTED, "glx_knn_to_csr: at most 65535 neighbours per row (k=%d)", k);
   *rowptr_out = nullptr; *col_out = nullptr; *val_out = nullptr; *nnz_out = 0;
   GLX_HIP(hipSetDevice(device));
   AsmBufs b;
@@ -226,6 +311,7 @@ extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const doub
   GLX_POOL(glx_pool_alloc((void**)&b.rowcnt, (n + 1) * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.rsrc, ne * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.rw, ne * 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.rpos, ne * 2));
   GLX_POOL(glx_pool_alloc((void**)&b.flag, 8));
   GLX_HIP(hipMemsetAsync(b.rcnt, 0, (n + 1) * 4, st));
   GLX_HIP(hipMemsetAsync(b.cursor, 0, (n + 1) * 4, st));
@@ -246,55 +332,48 @@ extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const doub
   for (int64_t i = 0; i < n; ++i) roff[i + 1] = roff[i] + rcnt[i];
   GLX_HIP(hipMemcpyAsync(b.roff, roff.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(fill_reverse_kernel, dim3(ge), dim3(256), 0, st, (const int64_t*)b.ind, (const double*)b.w, n, kk, k,
-                     (const int64_t*)b.roff, b.cursor, b.rsrc, b.rw);
+                     (const int64_t*)b.roff, b.cursor, b.rsrc, b.rpos, b.rw);
   GLX_HIP(hipGetLastError());
   const size_t shm = (size_t)4 * ROW_CAP * 16;
   GLX_HIP(hipFuncSetAttribute((const void*)merge_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const unsigned gr = (unsigned)((n + 3) / 4);
   hipLaunchKernelGGL(merge_rows_kernel, dim3(gr), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, n, kk, k,
-                     (const int64_t*)b.roff, (const int*)b.rsrc, (const double*)b.rw, sym, 0, b.rowcnt, (const int64_t*)nullptr,
+                     (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 0, b.rowcnt, (const int64_t*)nullptr,
                      (int*)nullptr, (double*)nullptr, b.flag + 1);
   GLX_HIP(hipGetLastError());
   std::vector<int> rowcnt(n);
   GLX_HIP(hipMemcpyAsync(rowcnt.data(), b.rowcnt, n * 4, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipMemcpyAsync(flags, b.flag, 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
-  // hub vertices (more than ROW_CAP forward+reverse neighbours; high-dimensional data has them):
-  // merged here on the host with the same rule, written into the CSR after the device pass
-  std::vector<std::pair<int64_t, HostRow>> hubs;
+  // hub vertices: a workgroup each, sorted in a global scratch (merge_hub_kernel)
+  int64_t nh = 0;
   if (flags[1]) {
-    std::vector<double> wrow(k);
-    std::vector<int> rs;
-    std::vector<double> rwv;
+    std::vector<int64_t> hrow, hoff(1, 0);
     for (int64_t i = 0; i < n; ++i) {
       if (rowcnt[i] >= 0) continue;
-      const int rc = (int)(roff[i + 1] - roff[i]);
-      rs.resize(rc);
-      rwv.resize(rc);
-      GLX_HIP(hipMemcpy(wrow.data(), b.w + i * k, (size_t)k * 8, hipMemcpyDeviceToHost));
-      GLX_HIP(hipMemcpy(rs.data(), b.rsrc + roff[i], (size_t)rc * 4, hipMemcpyDeviceToHost));
-      GLX_HIP(hipMemcpy(rwv.data(), b.rw + roff[i], (size_t)rc * 8, hipMemcpyDeviceToHost));
-      struct Ent { int32_t col; int tag; int seq; double v; };
-      std::vector<Ent> ents;
-      ents.reserve(k + rc);
-      for (int t = 0; t < k; ++t) ents.push_back({(int32_t)ind[i * kk + t], 0, t, wrow[t]});
-      for (int q = 0; q < rc; ++q) ents.push_back({rs[q], 1, q, rwv[q]});
-      std::sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) {
-        return x.col != y.col ? x.col < y.col : (x.tag != y.tag ? x.tag < y.tag : x.seq < y.seq);
-      });
-      HostRow hr;
-      for (size_t e = 0; e < ents.size();) {
-        const int32_t c = ents[e].col;
-        double a = 0.0, bb = 0.0;
-        for (; e < ents.size() && ents[e].col == c; ++e) {
-          if (ents[e].tag) bb = bb + ents[e].v; else a = a + ents[e].v;
-        }
-        const double v = combine_host(a, bb, sym);
-        if (c != (int32_t)i && v != 0.0) { hr.col.push_back(c); hr.val.push_back(v); }
-      }
-      rowcnt[i] = (int)hr.col.size();
-      hubs.emplace_back(i, std::move(hr));
+      const int64_t M = k + (roff[i + 1] - roff[i]);
+      int64_t P = 2048;
+      while (P < M) P <<= 1;
+      hrow.push_back(i);
+      hoff.push_back(hoff.back() + P);
     }
+    nh = (int64_t)hrow.size();
+    GLX_POOL(glx_pool_alloc((void**)&b.hub_row, nh * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.hub_off, (nh + 1) * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.hub_cnt, nh * 4));
+    GLX_POOL(glx_pool_alloc((void**)&b.skey, (size_t)hoff.back() * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.sval, (size_t)hoff.back() * 8));
+    GLX_HIP(hipMemcpyAsync(b.hub_row, hrow.data(), nh * 8, hipMemcpyHostToDevice, st));
+    GLX_HIP(hipMemcpyAsync(b.hub_off, hoff.data(), (nh + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(merge_hub_kernel, dim3((unsigned)nh), dim3(1024), 0, st, (const int64_t*)b.ind, (const double*)b.w, kk, k,
+                       (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 0,
+                       (const int64_t*)b.hub_row, (const int64_t*)b.hub_off, b.skey, b.sval, b.hub_cnt, (const int64_t*)nullptr,
+                       (int*)nullptr, (double*)nullptr);
+    GLX_HIP(hipGetLastError());
+    std::vector<int> hcnt(nh);
+    GLX_HIP(hipMemcpyAsync(hcnt.data(), b.hub_cnt, nh * 4, hipMemcpyDeviceToHost, st));
+    GLX_HIP(hipStreamSynchronize(st));
+    for (int64_t h = 0; h < nh; ++h) rowcnt[hrow[h]] = hcnt[h];
   }
   std::vector<int64_t> rp(n + 1, 0);
   for (int64_t i = 0; i < n; ++i) rp[i + 1] = rp[i] + rowcnt[i];
@@ -304,9 +383,16 @@ extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const doub
   GLX_POOL(glx_pool_alloc((void**)&b.col, std::max<size_t>(nnz * 4, 4)));
   GLX_POOL(glx_pool_alloc((void**)&b.val, std::max<size_t>(nnz * 8, 8)));
   hipLaunchKernelGGL(merge_rows_kernel, dim3(gr), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, n, kk, k,
-                     (const int64_t*)b.roff, (const int*)b.rsrc, (const double*)b.rw, sym, 1, b.rowcnt, (const int64_t*)b.rowptr,
+                     (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 1, b.rowcnt, (const int64_t*)b.rowptr,
                      b.col, b.val, b.flag + 1);
   GLX_HIP(hipGetLastError());
+  if (nh) {
+    hipLaunchKernelGGL(merge_hub_kernel, dim3((unsigned)nh), dim3(1024), 0, st, (const int64_t*)b.ind, (const double*)b.w, kk, k,
+                       (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 1,
+                       (const int64_t*)b.hub_row, (const int64_t*)b.hub_off, b.skey, b.sval, b.hub_cnt, (const int64_t*)b.rowptr,
+                       b.col, b.val);
+    GLX_HIP(hipGetLastError());
+  }
   int32_t* h_rp = (int32_t*)malloc((n + 1) * 4);
   int32_t* h_col = (int32_t*)malloc(std::max<size_t>(nnz * 4, 4));
   double* h_val = (double*)malloc(std::max<size_t>(nnz * 8, 8));
@@ -323,10 +409,6 @@ extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const doub
     free(h_rp); free(h_col); free(h_val);
     glx_set_error("glx_knn_to_csr: download failed");
     return GLX_EHIP;
-  }
-  for (auto& hb : hubs) {
-    std::copy(hb.second.col.begin(), hb.second.col.end(), h_col + rp[hb.first]);
-    std::copy(hb.second.val.begin(), hb.second.val.end(), h_val + rp[hb.first]);
   }
   *rowptr_out = h_rp;
   *col_out = h_col;

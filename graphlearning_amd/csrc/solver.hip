@@ -36,6 +36,7 @@ struct glx_sweep {
   int cur = 0;
   int64_t launches = 0;
   double err0 = 0.0, thresh = 0.0;
+  int tested_first = 0, tested_count = 0;   // stop values err[t], t = tested_first .. +tested_count-1, of the last glx_sweep_run (in h_err)
   // sparse right-hand side (glx_sweep_set_problem_rows): record indices of the rows set by the previous call
   int32_t* row_slot = nullptr;              // [n_rows] record index -> its (first) slot in the plan
   int32_t* prev_rec = nullptr;              // [prev_cap] records whose bias / flag / w0 the previous problem set
@@ -482,6 +483,30 @@ extern "C" int glx_sweep_run(glx_sweep* s, int* T_out, float* device_ms_out) {
   if (T_out) *T_out = T;
   // count the sweeps that really ran: kernels of a tail chunk launched past the stop test exit at once
   s->launches = launches0 + T;
+  s->tested_first = head;
+  s->tested_count = T - head + (stopped ? 1 : 0);   // err[head..T]; the value at T = max_iter is never compared (ssl.py:667)
+  return GLX_OK;
+}
+
+// The stop values the last glx_sweep_run compared with 1/n: vals[i] = max|v_t - v_inf| at t = *first + i, the last one
+// being the value at t = T.  They are computed as deg*(P w) (the fused column), not as the reference's separate
+// product RW*v (ssl.py:669): equal up to rounding.  The caller (ssl.poisson) uses them to recognise the one case in
+// which the two roundings could decide differently -- a value within a few ulps of 1/n -- and settles that case with
+// the reference's own recurrence.
+extern "C" int glx_sweep_stop_values(const glx_sweep* s, int64_t cap, double* vals, int* first, int* count) {
+  GLX_CHECK(s && first && count, GLX_EINVAL, "glx_sweep_stop_values: null argument");
+  *first = s->tested_first;
+  *count = s->tested_count;
+  if (!vals) return GLX_OK;
+  GLX_CHECK(cap >= s->tested_count, GLX_EINVAL, "glx_sweep_stop_values: %lld values, room for %lld", (long long)s->tested_count, (long long)cap);
+  for (int i = 0; i < s->tested_count; ++i) {
+    const size_t t = (size_t)(s->tested_first + i);
+    unsigned long long m = 0;
+    for (int k = 0; k < ERR_SHARDS; ++k) m = std::max(m, s->h_err[t * ERR_SHARDS + k]);
+    union { double d; unsigned long long u; } cv;
+    cv.u = m;
+    vals[i] = cv.d;
+  }
   return GLX_OK;
 }
 

@@ -104,6 +104,12 @@ int glx_sweep_set_vectors(glx_sweep* s, const double* deg, const double* vinf);
 int glx_sweep_set_problem_rows(glx_sweep* s, int64_t m, const int64_t* rows, const void* Db_rows,
                                const double* w0_rows, double err0);
 int glx_sweep_run(glx_sweep* s, int* T_out, float* device_ms_out);   /* all iterations on device; HIP-event time */
+/* The stop values the last glx_sweep_run compared with 1/n (ssl.py:667): vals[i] = max|v_t - v_inf| for t = *first + i,
+ * i < *count, the last one being the value that ended the loop (absent when max_iter did).  vals may be NULL to query
+ * the counts.  The fused column computes them as deg*(P w), the reference as RW*v (ssl.py:669): equal up to rounding, so
+ * a value within a few ulps of 1/n could decide differently; ssl.poisson re-derives T with the reference's recurrence
+ * in that case (graphlearning_amd/ssl.py: _exact_stop_iteration). */
+int glx_sweep_stop_values(const glx_sweep* s, int64_t cap, double* vals, int* first, int* count);
 int glx_sweep_fetch(glx_sweep* s, void* u_out);
 int glx_sweep_launches(const glx_sweep* s, int64_t* sweep_kernel_launches);
 int glx_sweep_destroy(glx_sweep* s);

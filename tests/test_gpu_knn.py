@@ -153,25 +153,36 @@ def test_knn_to_csr_duplicates_and_asymmetry(gl):
 
 
 def test_knn_to_csr_hub_vertex(gl):
-    """A vertex that is everyone's neighbour (3000 reverse neighbours > the 1024 one wavefront merges
-    in LDS) takes the host merge path; result identical to the oracle's scipy assembly."""
+    """Vertices that are many rows' neighbour (more forward + reverse entries than the 1024 one wavefront merges in
+    LDS) are merged by a workgroup each in a global scratch (merge_hub_kernel); hubs of 1030, 2100 and 5990 reverse
+    neighbours, with duplicate entries in and towards the hubs: identical to the oracle's scipy assembly."""
     from oracle import gl_oracle as orc
     rng = np.random.default_rng(2)
-    n, k = 3000, 4
+    n, k = 6000, 5
     ind = np.empty((n, k), dtype=np.int64)
     ind[:, 0] = np.arange(n)
-    ind[:, 1] = 0                                   # the hub
+    ind[:, 1] = 0                                   # hub 0: everyone's neighbour
     ind[:, 2] = (np.arange(n) + 1) % n
     ind[:, 3] = (np.arange(n) + 7) % n
+    ind[:, 4] = (np.arange(n) + 13) % n
+    ind[:2100, 3] = 11                              # hub 11: 2100 reverse neighbours
+    ind[3000:4030, 4] = 4000                        # hub 4000: 1030
     ind[0, 1] = 5
+    ind[100:140, 2] = 0                             # rows that list hub 0 twice
+    ind[0, 2:5] = [11, 11, 4000]                    # a hub that lists another hub twice
     dist = np.sort(rng.random((n, k)), axis=1)
     dist[:, 0] = 0
-    for kernel, symmetrize in [('gaussian', True), ('distance', True), ('uniform', False)]:
-        W = gl.weightmatrix.knn(None, 3, kernel=kernel, symmetrize=symmetrize, knn_data=(ind, dist.copy()))
-        Wo = orc.knn_weights(ind, dist.copy(), 3, kernel=kernel, symmetrize=symmetrize)
+    for kernel, symmetrize in [('gaussian', True), ('distance', True), ('symgaussian', True), ('singular', True), ('uniform', False)]:
+        W = gl.weightmatrix.knn(None, 4, kernel=kernel, symmetrize=symmetrize, knn_data=(ind, dist.copy()))
+        Wo = orc.knn_weights(ind, dist.copy(), 4, kernel=kernel, symmetrize=symmetrize)
         assert np.array_equal(W.indptr, Wo.indptr) and np.array_equal(W.indices, Wo.indices), kernel
-        assert np.array_equal(W.data, Wo.data), kernel
-    assert np.diff(W.indptr).max() <= 4 and np.diff(Wo.indptr).max() <= 4    # unsymmetrised: k entries per row
+        if kernel == 'symgaussian':
+            assert np.allclose(W.data, Wo.data, rtol=1e-15, atol=0), kernel     # exp on the device: as in the test above
+        else:
+            assert np.array_equal(W.data, Wo.data), kernel
+        if symmetrize:
+            assert np.diff(W.indptr)[[0, 11, 4000]].min() > 1024
+    assert np.diff(W.indptr).max() <= 5 and np.diff(Wo.indptr).max() <= 5    # unsymmetrised: k entries per row
 
 
 def test_blobs5000_knn_graph_golden(gl, golden):

@@ -276,3 +276,92 @@ def test_new_entry_points_reject_bad_arguments(gl, golden):
     x, it, err = A.cg(np.ones((16, 2)), x0=np.full((16, 2), 0.5), tol=1e-12)    # B is the residual r0 = b - A@x0: x = x0 + A^-1 r0
     assert np.allclose(x, 1.0) and it >= 1
     A.close()
+
+
+# ---- the stop test: fused column deg*(P w) vs the reference's own recurrence v <- RW v (ssl.py:644, 667-669) -----
+def _reference_stop_values(orc, W, ti, lab, count):
+    s = orc.poisson_gd_setup(W, ti, lab[ti])
+    v, out = s['v0'], []
+    for _ in range(count):
+        out.append(np.max(np.absolute(v - s['vinf'])))
+        v = s['RW'] * v
+    return np.array(out)
+
+
+def _stop_cases(golden):
+    g = golden('g1_twomoons.npz')
+    yield 'twomoons', csr_from(g, 'W_gaussian'), g['train_ind'], g['labels']
+    yield 'twomoons_directed', csr_from(g, 'W_gaussian_nosym'), g['train_ind'], g['labels']
+    X, lab = blobs(3000, 12, 6, 5, 2.0)
+    import graphlearning_amd as gl
+    W = gl.weightmatrix.knn(X, 8)
+    ti = gl.trainsets.generate(lab, rate=2, seed=3)
+    yield 'blobs3000', W, ti, lab
+
+
+def test_fused_stop_values_track_the_reference_recurrence(gl, golden, orc):
+    worst = 0.0
+    for name, W, ti, lab in _stop_cases(golden):
+        m = gl.ssl.poisson(W, solver='gradient_descent')
+        m.fit(ti, lab[ti])
+        _, aux = m._operators()
+        first, vals = aux['sweep'].stop_values()
+        assert first == 50 and len(vals) == m.num_iter - 50 + 1, name
+        ref = _reference_stop_values(orc, W, ti, lab, m.num_iter + 1)[first:]
+        rel = np.max(np.abs(vals - ref) / ref)
+        worst = max(worst, rel)
+        n = W.shape[0]
+        assert np.all(vals[:-1] > 1 / n) and vals[-1] <= 1 / n, name
+        assert m.stop_settled is None, name              # nothing within STOP_BAND of 1/n: the usual case
+    assert worst <= 1e-12, worst                         # STOP_BAND (1e-9) is >= 1000x the rounding difference
+    print('fused vs reference stop values: max relative difference %.2e' % worst)
+
+
+def test_stop_value_inside_the_band_is_settled_by_the_reference_recurrence(gl, golden, orc, monkeypatch):
+    from graphlearning_amd import ssl as ssl_mod
+    monkeypatch.setattr(ssl_mod, 'STOP_BAND', 1e30)      # every fit takes the settling path
+    for name, W, ti, lab in _stop_cases(golden):
+        for kw in ({}, {'min_iter': 0}, {'min_iter': 0, 'max_iter': 37}, {'min_iter': 60, 'max_iter': 60}):
+            u_ref, T_ref = orc.poisson_gd(W, ti, lab[ti], return_T=True, **kw)
+            m = gl.ssl.poisson(W, solver='gradient_descent', **kw)
+            u = m.fit(ti, lab[ti])
+            assert m.num_iter == T_ref, (name, kw)
+            assert np.array_equal(u, u_ref), (name, kw)
+            if kw.get('min_iter', 50) < kw.get('max_iter', 1000):
+                assert m.stop_settled == (T_ref, T_ref), (name, kw, m.stop_settled)
+                assert m._exact_stop_iteration(ti) == orc.poisson_gd_iterations(W, ti, **kw)
+            else:
+                assert m.stop_settled is None            # min_iter >= max_iter: the test decides nothing
+    # the device SpMV of the recurrence adds in csc_matvec's order: every iterate bit for bit
+    name, W, ti, lab = next(_stop_cases(golden))
+    s = orc.poisson_gd_setup(W, ti, lab[ti])
+    from graphlearning_amd import _hip
+    RW = sparse.csr_matrix(s['RW'])
+    RW.sort_indices()
+    rw = _hip.DeviceGraph(RW, keep_order=True)
+    v = s['v0']
+    vd = s['v0']
+    for _ in range(30):
+        v = s['RW'] * v
+        vd = rw.spmm_bias(vd)
+        assert np.array_equal(v, vd)
+    rw.close()
+
+
+def test_disagreeing_stop_iteration_reruns_exactly_that_many_sweeps(gl, golden, orc, monkeypatch):
+    from graphlearning_amd import ssl as ssl_mod
+    monkeypatch.setattr(ssl_mod, 'STOP_BAND', 1e30)
+    g = golden('g1_twomoons.npz')
+    W, ti, lab = csr_from(g, 'W_gaussian'), g['train_ind'], g['labels']
+    for use_cuda in (False, True):
+        m = gl.ssl.poisson(W, solver='gradient_descent', use_cuda=use_cuda)
+        T_true = orc.poisson_gd_iterations(W, ti)
+        monkeypatch.setattr(m, '_exact_stop_iteration', lambda train_ind: T_true - 3)   # pretend the roundings disagreed
+        u = m.fit(ti, lab[ti])
+        assert m.num_iter == T_true - 3 and m.stop_settled == (T_true, T_true - 3)
+        u_ref = orc.poisson_gd(W, ti, lab[ti], min_iter=T_true - 3, max_iter=T_true - 3)
+        if use_cuda:
+            assert u.dtype == np.float32 and np.allclose(u, u_ref, atol=1e-5)
+        else:
+            assert np.array_equal(u, u_ref)
+        assert np.array_equal(m.predict(), np.argmax(u_ref, axis=1))
