@@ -306,12 +306,16 @@ def test_fused_stop_values_track_the_reference_recurrence(gl, golden, orc):
         m.fit(ti, lab[ti])
         _, aux = m._operators()
         first, vals = aux['sweep'].stop_values()
-        assert first == 50 and len(vals) == m.num_iter - 50 + 1, name
-        ref = _reference_stop_values(orc, W, ti, lab, m.num_iter + 1)[first:]
+        n = W.shape[0]
+        capped = m.num_iter == 1000                      # the directed graph never meets the test: max_iter ends the loop,
+        assert first == 50 and len(vals) == m.num_iter - 50 + (0 if capped else 1), name   # its value is never compared
+        ref = _reference_stop_values(orc, W, ti, lab, m.num_iter + 1)[first:first + len(vals)]
         rel = np.max(np.abs(vals - ref) / ref)
         worst = max(worst, rel)
-        n = W.shape[0]
-        assert np.all(vals[:-1] > 1 / n) and vals[-1] <= 1 / n, name
+        if capped:
+            assert np.all(vals > 1 / n), name
+        else:
+            assert np.all(vals[:-1] > 1 / n) and vals[-1] <= 1 / n, name
         assert m.stop_settled is None, name              # nothing within STOP_BAND of 1/n: the usual case
     assert worst <= 1e-12, worst                         # STOP_BAND (1e-9) is >= 1000x the rounding difference
     print('fused vs reference stop values: max relative difference %.2e' % worst)
