@@ -33,9 +33,14 @@ def _hipcc():
     return hipcc if os.path.exists(hipcc) else 'hipcc'
 
 
+# -amdgpu-mfma-vgpr-form: the kNN tile kernels read every accumulator right after the MFMA chain; with the accumulators in
+# AGPRs that is 16 v_accvgpr_read per 32x32 tile and 120 registers (3 waves per SIMD) instead of 108 (4)
+BASE_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result',
+              '-mllvm', '-amdgpu-mfma-vgpr-form']
+
+
 def _flags():
-    return ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result'] + \
-        os.environ.get('GLX_CXXFLAGS', '').split()
+    return BASE_FLAGS + os.environ.get('GLX_CXXFLAGS', '').split()
 
 
 def source_hash():

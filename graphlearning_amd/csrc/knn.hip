@@ -265,8 +265,26 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef KNN_GROUP_GUARD
 #define KNN_GROUP_GUARD 1          // measured: 438 -> 394 ms
 #endif
-#ifndef KNN_BRANCHFREE_STAGE
-#define KNN_BRANCHFREE_STAGE 0   // measured (one box, n = 1e6, d = 64): clamped unconditional loads 593 ms vs 438 ms with the predicated ones
+static const int KNN_PAD_ROWS = 64;   // spare rows behind Xb / nrm (>= the widest ref tile): the staging loads of the last tile need no predicates
+#ifndef KNN_COUNT
+#define KNN_COUNT 0               // developer probe: event counters of the list maintenance (printed to stderr)
+#endif
+#if KNN_COUNT
+__device__ unsigned long long g_knn_cnt[8];
+#define KNN_CNT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_knn_cnt[i], (unsigned long long)(v)); } while (0)
+#else
+#define KNN_CNT(i, v) do { } while (0)
+#endif
+#ifndef KNN_ABLATE
+#define KNN_ABLATE 0              // developer probes (wrong results): 1 no list maintenance, 2 no barrier per tile, 4 no staging loads
+#endif
+#ifndef KNN_WAVES
+#define KNN_WAVES 0
+#endif
+#if KNN_WAVES
+#define KNN_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(KNN_WAVES, 4)))   // register budget 512 / KNN_WAVES: the prefetched tile must not spill
+#else
+#define KNN_WAVES_ATTR
 #endif
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rn(float x) {
@@ -279,9 +297,14 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_a
 __global__ void knn_prep_bf16_kernel(const double* __restrict__ X, const double* __restrict__ mean, int64_t n, int d, int kpad,
                                      unsigned short* __restrict__ Xb, float* __restrict__ nrm, float* __restrict__ qnorm) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
+  if (i >= n + KNN_PAD_ROWS) return;
   unsigned short* row = Xb + i * 2 * kpad;
+  if (i >= n) {                       // spare rows behind the data: zero features, infinitely far
+    for (int f = 0; f < 2 * kpad; ++f) row[f] = 0;
+    nrm[i] = 1e30f;
+    return;
+  }
+  float s = 0.f;
   for (int f = 0; f < d; ++f) {
     const float x = (float)(X[i * d + f] - mean[f]);
     const unsigned short hi = f32_to_bf16_rn(x);
@@ -298,7 +321,7 @@ __global__ void knn_prep_bf16_kernel(const double* __restrict__ X, const double*
 // NKB blocks of 16 features (kpad = 16 NKB <= 128); refs are the A operand (LDS), queries the B operand (registers: lane =
 // query column j, k-half h); list handling as in knn_tile_kernel.
 template <int NKB, int KP, int NSUB>
-__global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const float* __restrict__ nrm, int64_t n,
+__global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const float* __restrict__ nrm, int64_t n,
                                                             int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d,
                                                             int* __restrict__ cand_i) {
   constexpr int KPAD = 16 * NKB;
@@ -346,24 +369,18 @@ __global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short
   uint4 pre[UNITS];
   float pre_rn = 0.f;
   auto stage_load = [&](int64_t t) {
-    // branch-free: rows beyond n are read from the last row and made infinitely far through their norm
+    // no bounds predicates: Xb / nrm carry KNN_PAD_ROWS spare rows (zero features, norm 1e30) behind the data
 #pragma unroll
     for (int i = 0; i < UNITS; ++i) {
       const int u = tid + i * 256;
       const int r = u / U_ROW, c = u % U_ROW;
-#if KNN_BRANCHFREE_STAGE
-      const int64_t ref = min(t * BR + r, n - 1);
-      if (EXACT_UNITS || u < BR * U_ROW) pre[i] = *(const uint4*)(Xb + ref * 2 * KPAD + c * 8);
-#else
-      const int64_t ref = t * BR + r;
       uint4 v = {0u, 0u, 0u, 0u};
-      if (u < BR * U_ROW && ref < n) v = *(const uint4*)(Xb + ref * 2 * KPAD + c * 8);
+      if (EXACT_UNITS || u < BR * U_ROW) v = *(const uint4*)(Xb + (t * BR + r) * 2 * KPAD + c * 8);
       pre[i] = v;
-#endif
     }
     if (tid < BR) {
       const int64_t ref = t * BR + tid;
-      pre_rn = ref < n ? nrm[ref] : 1e30f;
+      pre_rn = nrm[ref];
     }
   };
   auto stage_store = [&](int buf) {
@@ -382,6 +399,15 @@ __global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short
     int mx = cnt;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+#if KNN_COUNT
+    {
+      int tot = cnt;
+      for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off);
+      KNN_CNT(3, tot);
+      KNN_CNT(4, 1);
+      KNN_CNT(5, mx);
+    }
+#endif
     for (int a = 0; a < mx; ++a) {
       if (a < cnt) {
         const float v = ld[(KP + a) * 256 + tid];
@@ -408,7 +434,9 @@ __global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short
   int buf = 0;
   for (int64_t t = t0; t < t1; ++t) {
     const bool has_next = t + 1 < t1;
+#if !(KNN_ABLATE & 4)
     if (has_next) stage_load(t + 1);
+#endif
     const char* tl = tile + buf * BR * ROWB;
     const float* rnb = rn + buf * BR;
     f32x16 acc[NSUB];
@@ -430,7 +458,7 @@ __global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short
       }
     }
     // selection on value = |r|^2 - 2 q.r (element e of sub-tile `sub` is ref sub*32 + (e&3) + 8*(e>>2) + 4h, query j): per group
-    // of 4 elements a minimum first, so that groups without a candidate in any lane cost one compare (with 64 lanes per
+    // of 4 elements an extremum first, so that groups without a candidate in any lane cost one compare (with 64 lanes per
     // wavefront SOME lane has a candidate in almost every tile)
     float m4[NSUB][4];
     float m = INFINITY;
@@ -446,12 +474,20 @@ __global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short
         m4[sub][eg] = fminf(fminf(acc[sub][eg * 4 + 0], acc[sub][eg * 4 + 1]), fminf(acc[sub][eg * 4 + 2], acc[sub][eg * 4 + 3]));
         m = fminf(m, m4[sub][eg]);
       }
+#if KNN_ABLATE & 1
+    if (m == 12345.f) tau = m;      // developer probe: no list maintenance
+    if (false) {
+#else
+    KNN_CNT(0, 1);
     if (__any(m < tau)) {
+#endif
+      KNN_CNT(1, 1);
 #pragma unroll
       for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
         for (int eg = 0; eg < 4; ++eg) {
           if (!KNN_GROUP_GUARD || __any(m4[sub][eg] < tau)) {
+            KNN_CNT(2, 1);
 #pragma unroll
             for (int e = eg * 4; e < eg * 4 + 4; ++e) {
               const float v = acc[sub][e];
@@ -467,7 +503,9 @@ __global__ __launch_bounds__(256) void knn_tile_bf16_kernel(const unsigned short
       }
     }
     if (has_next) stage_store(buf ^ 1);
+#if !(KNN_ABLATE & 2)
     __syncthreads();
+#endif
     buf ^= 1;
   }
   compact();
@@ -867,9 +905,9 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   GLX_HIP(hipEventRecord(b.e0, st));
   int rc;
   if (use_bf16) {
-    GLX_POOL(glx_pool_alloc((void**)&b.Xb, (size_t)n * 2 * dpa * 2));
-    GLX_POOL(glx_pool_alloc((void**)&b.nrm, (size_t)n * 4));
-    hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const double*)b.mean,
+    GLX_POOL(glx_pool_alloc((void**)&b.Xb, (size_t)(n + KNN_PAD_ROWS) * 2 * dpa * 2));
+    GLX_POOL(glx_pool_alloc((void**)&b.nrm, (size_t)(n + KNN_PAD_ROWS) * 4));
+    hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3((unsigned)((n + KNN_PAD_ROWS + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const double*)b.mean,
                        n, d, dpa, b.Xb, b.nrm, b.qnorm);
     GLX_HIP(hipGetLastError());
     if (KP == 8) rc = launch_tile_bf16_nkb<8>(NKB, b, n, q0, q1, nsplit, st);
@@ -888,6 +926,17 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   }
   if (rc) return rc;
   GLX_HIP(hipEventRecord(b.e1, st));
+#if KNN_COUNT
+  if (use_bf16) {
+    unsigned long long c[8];
+    GLX_HIP(hipStreamSynchronize(st));
+    GLX_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_knn_cnt), sizeof(c)));
+    fprintf(stderr, "knn counters: wave-tiles %llu, with a candidate %llu (%.1f %%), active groups %llu, appended %llu, compactions %llu, compaction steps %llu; nsplit %d\n",
+            c[0], c[1], 100.0 * c[1] / (double)std::max(1ull, c[0]), c[2], c[3], c[4], c[5], nsplit);
+    memset(c, 0, sizeof(c));
+    GLX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_cnt), c, sizeof(c)));
+  }
+#endif
   hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)nq), dim3(64), (size_t)M * 12, st, (const double*)b.X, n, d, k, q0, nq,
                      (const float*)b.cand_d, (const int*)b.cand_i, lists, KP, M, (const float*)b.qnorm, rmax, cerr, b.ind, b.dist,
                      b.flags);
@@ -899,6 +948,7 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   std::vector<int> rows;
   for (int64_t i = 0; i < nq; ++i)
     if (flags[i]) rows.push_back((int)i);
+  if (KNN_ABLATE) rows.clear();   // developer probes produce wrong candidate lists: do not repair them
   if (!rows.empty()) {
     GLX_HIP(hipMemcpyAsync(b.rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
     const size_t nr = rows.size();
