@@ -270,10 +270,17 @@ static const int KNN_PAD_ROWS = 64;   // spare rows behind Xb / nrm (>= the wide
 #define KNN_COUNT 0               // developer probe: event counters of the list maintenance (printed to stderr)
 #endif
 #if KNN_COUNT
-__device__ unsigned long long g_knn_cnt[8];
-#define KNN_CNT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_knn_cnt[i], (unsigned long long)(v)); } while (0)
+__device__ unsigned long long g_knn_cnt[16];
+#define KNN_CNT(i, v) do { knn_ev[i] += (unsigned long long)(v); } while (0)   // per-wave totals in registers, flushed once at the end
 #else
 #define KNN_CNT(i, v) do { } while (0)
+#endif
+#if KNN_COUNT == 2   // cycle attribution (s_memtime) per code region, summed over the waves
+#define KNN_TIC(var) const unsigned long long var = __builtin_readcyclecounter()
+#define KNN_TOC(acc, var) acc += __builtin_readcyclecounter() - var
+#else
+#define KNN_TIC(var) do { } while (0)
+#define KNN_TOC(acc, var) do { } while (0)
 #endif
 #ifndef KNN_ABLATE
 #define KNN_ABLATE 0              // developer probes (wrong results): 1 no list maintenance, 2 no barrier per tile, 4 no staging loads
@@ -395,7 +402,13 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
   int cnt = 0;
   float tau_own = INFINITY;
   int pmax = 0;
+#if KNN_COUNT
+  unsigned long long knn_ev[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  unsigned long long cy_slow = 0, cy_comp = 0, cy_bar = 0, cy_all = 0;
+  (void)cy_slow; (void)cy_comp; (void)cy_bar; (void)cy_all;
   auto compact = [&]() {
+    KNN_TIC(tc);
     int mx = cnt;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
@@ -428,10 +441,12 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
     }
     cnt = 0;
     tau = fminf(tau_own, __shfl_xor(tau_own, 32));   // lanes l and l^32 serve the same query (same |q|^2 offset)
+    KNN_TOC(cy_comp, tc);
   };
   if (t0 < t1) { stage_load(t0); stage_store(0); }
   __syncthreads();
   int buf = 0;
+  KNN_TIC(ta);
   for (int64_t t = t0; t < t1; ++t) {
     const bool has_next = t + 1 < t1;
 #if !(KNN_ABLATE & 4)
@@ -479,6 +494,7 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
     if (false) {
 #else
     KNN_CNT(0, 1);
+    KNN_TIC(ts);
     if (__any(m < tau)) {
 #endif
       KNN_CNT(1, 1);
@@ -502,12 +518,22 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
         }
       }
     }
+    KNN_TOC(cy_slow, ts);
+    KNN_TIC(tb);
     if (has_next) stage_store(buf ^ 1);
 #if !(KNN_ABLATE & 2)
     __syncthreads();
 #endif
+    KNN_TOC(cy_bar, tb);
     buf ^= 1;
   }
+  KNN_TOC(cy_all, ta);
+#if KNN_COUNT
+  if (lane == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_knn_cnt[i], knn_ev[i]);
+    atomicAdd(&g_knn_cnt[8], cy_all); atomicAdd(&g_knn_cnt[9], cy_slow); atomicAdd(&g_knn_cnt[10], cy_comp); atomicAdd(&g_knn_cnt[11], cy_bar);
+  }
+#endif
   compact();
   if (q < q_end) {
     const int64_t lists = (int64_t)nsplit * 2;
@@ -928,11 +954,14 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   GLX_HIP(hipEventRecord(b.e1, st));
 #if KNN_COUNT
   if (use_bf16) {
-    unsigned long long c[8];
+    unsigned long long c[16];
     GLX_HIP(hipStreamSynchronize(st));
     GLX_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_knn_cnt), sizeof(c)));
     fprintf(stderr, "knn counters: wave-tiles %llu, with a candidate %llu (%.1f %%), active groups %llu, appended %llu, compactions %llu, compaction steps %llu; nsplit %d\n",
             c[0], c[1], 100.0 * c[1] / (double)std::max(1ull, c[0]), c[2], c[3], c[4], c[5], nsplit);
+    if (c[8])
+      fprintf(stderr, "knn cycles (sum over waves): tile loop %.3g = 100 %%, threshold test + appends + merges %.1f %% (merges alone %.1f %%), staging store + barrier %.1f %%; per wave-tile %.0f cycles\n",
+              (double)c[8], 100.0 * c[9] / (double)c[8], 100.0 * c[10] / (double)c[8], 100.0 * c[11] / (double)c[8], (double)c[8] / (double)std::max(1ull, c[0]));
     memset(c, 0, sizeof(c));
     GLX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_cnt), c, sizeof(c)));
   }
