@@ -145,10 +145,7 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
   float tau_own = INFINITY;
   int pmax = 0;
   auto compact = [&]() {
-    int mx = cnt;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
-    for (int a = 0; a < mx; ++a) {
+    for (int a = 0; __any(a < cnt); ++a) {
       if (a < cnt) {
         const float v = ld[(KP + a) * 256 + tid];
         if (v < tau_own) {
@@ -405,13 +402,15 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
 #if KNN_COUNT
   unsigned long long knn_ev[6] = {0, 0, 0, 0, 0, 0};
 #endif
-  unsigned long long cy_slow = 0, cy_comp = 0, cy_bar = 0, cy_all = 0;
-  (void)cy_slow; (void)cy_comp; (void)cy_bar; (void)cy_all;
+  unsigned long long cy_slow = 0, cy_comp = 0, cy_bar = 0, cy_all = 0, cy_store = 0;
+  (void)cy_slow; (void)cy_comp; (void)cy_bar; (void)cy_all; (void)cy_store;
   auto compact = [&]() {
     KNN_TIC(tc);
+#if KNN_COUNT
     int mx = cnt;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+#endif
 #if KNN_COUNT
     {
       int tot = cnt;
@@ -421,7 +420,7 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
       KNN_CNT(5, mx);
     }
 #endif
-    for (int a = 0; a < mx; ++a) {
+    for (int a = 0; __any(a < cnt); ++a) {      // (a ballot per step instead of a cross-lane maximum up front: 6 ds_bpermute round trips)
       if (a < cnt) {
         const float v = ld[(KP + a) * 256 + tid];
         if (v < tau_own) {
@@ -521,6 +520,10 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
     KNN_TOC(cy_slow, ts);
     KNN_TIC(tb);
     if (has_next) stage_store(buf ^ 1);
+#if KNN_COUNT == 2
+    __builtin_amdgcn_s_waitcnt(0);      // (probe only) the store's own waits end here, the rest is the barrier
+    KNN_TOC(cy_store, tb);
+#endif
 #if !(KNN_ABLATE & 2)
     __syncthreads();
 #endif
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
 #if KNN_COUNT
   if (lane == 0) {
     for (int i = 0; i < 6; ++i) atomicAdd(&g_knn_cnt[i], knn_ev[i]);
-    atomicAdd(&g_knn_cnt[8], cy_all); atomicAdd(&g_knn_cnt[9], cy_slow); atomicAdd(&g_knn_cnt[10], cy_comp); atomicAdd(&g_knn_cnt[11], cy_bar);
+    atomicAdd(&g_knn_cnt[8], cy_all); atomicAdd(&g_knn_cnt[9], cy_slow); atomicAdd(&g_knn_cnt[10], cy_comp); atomicAdd(&g_knn_cnt[11], cy_bar); atomicAdd(&g_knn_cnt[12], cy_store);
   }
 #endif
   compact();
@@ -960,8 +963,8 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
     fprintf(stderr, "knn counters: wave-tiles %llu, with a candidate %llu (%.1f %%), active groups %llu, appended %llu, compactions %llu, compaction steps %llu; nsplit %d\n",
             c[0], c[1], 100.0 * c[1] / (double)std::max(1ull, c[0]), c[2], c[3], c[4], c[5], nsplit);
     if (c[8])
-      fprintf(stderr, "knn cycles (sum over waves): tile loop %.3g = 100 %%, threshold test + appends + merges %.1f %% (merges alone %.1f %%), staging store + barrier %.1f %%; per wave-tile %.0f cycles\n",
-              (double)c[8], 100.0 * c[9] / (double)c[8], 100.0 * c[10] / (double)c[8], 100.0 * c[11] / (double)c[8], (double)c[8] / (double)std::max(1ull, c[0]));
+      fprintf(stderr, "knn cycles (sum over waves): tile loop %.3g = 100 %%, threshold test + appends + merges %.1f %% (merges alone %.1f %%), staging store + barrier %.1f %% (store and its waits %.1f %%); per wave-tile %.0f cycles\n",
+              (double)c[8], 100.0 * c[9] / (double)c[8], 100.0 * c[10] / (double)c[8], 100.0 * c[11] / (double)c[8], 100.0 * c[12] / (double)c[8], (double)c[8] / (double)std::max(1ull, c[0]));
     memset(c, 0, sizeof(c));
     GLX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_cnt), c, sizeof(c)));
   }
