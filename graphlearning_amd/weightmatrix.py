@@ -18,9 +18,10 @@ knn_dir = os.path.abspath(os.path.join(os.getcwd(), 'knn_data'))
 def knn(data, k, kernel='gaussian', eta=None, symmetrize=True, metric='raw', similarity='euclidean', knn_data=None,
         device=None):
     W = _knn(data, k, kernel, eta, symmetrize, metric, similarity, knn_data, device)
-    if symmetrize:
-        # symmetric bit for bit ((a+b)/2 = (b+a)/2, max and the symgaussian rule likewise) with an empty diagonal: stamped so
-        # that ssl.poisson can write down D^-1 W^T without transposing (utils.known_symmetric re-checks the stamp)
+    if symmetrize and kernel != 'symgaussian':
+        # symmetric bit for bit ((a+b)/2 = (b+a)/2, and the element-wise max) with an empty diagonal: stamped so that ssl.poisson
+        # can write down D^-1 W^T without transposing (utils.known_symmetric re-checks the stamp).  NOT the symgaussian rule:
+        # W + W^T*(W^T>W) - W*(W^T>W) leaves fl(fl(a+b)-a) on one side of an edge and b on the other
         W._glx_sym = utils.symmetric_fingerprint(W)
     return W
 

@@ -1,0 +1,149 @@
+"""Randomised end-to-end parity (through the C-ABI): random point clouds, graph parameters and training sets; every
+stage of the path -- search, weight matrix, Poisson (both solvers), Laplace, PoissonMBO, the label decision -- is held
+against the oracle bit for bit.  The goldens pin a few shapes; this walks many (sizes 40 .. 1500, 2 .. 6 classes,
+3 .. 15 neighbours, all kernels, directed and symmetrised graphs, every normalisation)."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gl():
+    import graphlearning_amd as gl
+    from graphlearning_amd import _hip
+    _hip.require_device()
+    return gl
+
+
+@pytest.fixture(scope='module')
+def orc():
+    from oracle import gl_oracle
+    return gl_oracle
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(40, 1500))
+    d = int(rng.choice([2, 3, 5, 8, 20, 40]))
+    C = int(rng.integers(2, 7))
+    k = int(rng.integers(3, 16))
+    lab = rng.integers(0, C, size=n)
+    lab[:C] = np.arange(C)                                  # every class occurs
+    centres = rng.normal(size=(C, d)) * rng.uniform(0.5, 3.0)
+    X = centres[lab] + rng.normal(size=(n, d))
+    kernel = str(rng.choice(['gaussian', 'gaussian', 'uniform', 'distance', 'singular', 'symgaussian']))
+    symmetrize = bool(rng.random() < 0.8)
+    per_class = int(rng.integers(1, 4))
+    ti = np.concatenate([rng.choice(np.flatnonzero(lab == c), size=min(per_class, int(np.sum(lab == c))), replace=False)
+                         for c in range(C)])
+    return dict(n=n, d=d, C=C, k=k, X=X, lab=lab.astype(np.int64), kernel=kernel, symmetrize=symmetrize, ti=ti, rng=rng)
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_random_pipeline_matches_the_oracle(gl, orc, seed):
+    c = _case(seed)
+    X, lab, ti, k = c['X'], c['lab'], c['ti'], c['k']
+    tag = 'seed %d: n=%d d=%d C=%d k=%d %s sym=%s' % (seed, c['n'], c['d'], c['C'], k, c['kernel'], c['symmetrize'])
+    # a-1: the search (k + 1 columns incl. self), cKDTree's lists
+    J, D = gl.weightmatrix.knnsearch(X, k + 1)
+    Jo, Do = orc.knnsearch(X, k + 1)
+    assert np.array_equal(J, Jo), tag
+    assert np.max(np.abs(D - Do)) <= 1e-12, tag
+    # a-2: the weight matrix from the SAME kNN data
+    W = gl.weightmatrix.knn(None, k, kernel=c['kernel'], symmetrize=c['symmetrize'], knn_data=(Jo, Do.copy()))
+    Wo = orc.knn_weights(Jo, Do.copy(), k, kernel=c['kernel'], symmetrize=c['symmetrize'])
+    assert np.array_equal(W.indptr, Wo.indptr) and np.array_equal(W.indices, Wo.indices) and np.array_equal(W.data, Wo.data), tag
+    if not c['symmetrize'] or c['kernel'] in ('distance', 'singular'):
+        # directed graphs / unbounded weights: the sweep is the part of the path defined for them
+        W = Wo
+    with np.errstate(all='ignore'):
+        # a-3: gradient descent incl. the stop test
+        u_ref, T_ref = orc.poisson_gd(Wo, ti, lab[ti], return_T=True)
+        m = gl.ssl.poisson(W, solver='gradient_descent')
+        u = m.fit(ti, lab[ti])
+        assert m.num_iter == T_ref, tag
+        assert np.array_equal(u, u_ref, equal_nan=True), tag
+        assert np.array_equal(m.predict(), orc.predict(u_ref)), tag
+        if not c['symmetrize'] or c['kernel'] in ('distance', 'singular'):
+            return
+        # a-4: conjugate gradient on the singular system
+        u_ref, it_ref = orc.poisson_cg(Wo, ti, lab[ti], return_iters=True)
+        m = gl.ssl.poisson(W)
+        u = m.fit(ti, lab[ti])
+        assert m.num_iter == it_ref, tag
+        assert np.array_equal(u, u_ref, equal_nan=True), tag
+        # a-5: Laplace, a random normalisation / tau / mean shift
+        norm = str(c['rng'].choice(['combinatorial', 'randomwalk', 'normalized']))
+        tau = float(c['rng'].choice([0.0, 0.0, 0.01]))
+        shift = bool(c['rng'].random() < 0.3)
+        u_ref, it_ref = orc.laplace_fit(Wo, ti, lab[ti], normalization=norm, tau=tau, mean_shift=shift, return_iters=True)
+        m = gl.ssl.laplace(W, normalization=norm, tau=tau, mean_shift=shift)
+        u = m.fit(ti, lab[ti])
+        assert m.num_iter == it_ref, (tag, norm, tau, shift)
+        assert np.array_equal(u, u_ref, equal_nan=True), (tag, norm, tau, shift)
+        # a-6 / a-7: PoissonMBO with the volume constraint (short schedule)
+        priors = orc.class_priors(lab)
+        u_ref, lab_ref, w_ref = orc.poisson_mbo_fit(Wo, ti, lab[ti], priors, solver='gradient_descent', Ns=12, T=4)
+        m = gl.ssl.poisson_mbo(W, priors, solver='gradient_descent', Ns=12, T=4)
+        pred = m.fit_predict(ti, lab[ti])
+        assert np.array_equal(m.prob, u_ref), tag
+        assert np.array_equal(pred, lab_ref), tag
+        assert np.array_equal(np.asarray(m.weights), np.asarray(w_ref)), tag
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_trials_and_comparison_methods_match_the_oracle(gl, orc, seed):
+    """Stacked trials (several training sets as column groups of one solve), the float32 branch, and the comparison
+    methods of SURVEY 8 f-3 on random symmetric graphs."""
+    c = _case(100 + seed)
+    X, lab, k, rng = c['X'], c['lab'], c['k'], c['rng']
+    C = c['C']
+    Jo, Do = orc.knnsearch(X, k + 1)
+    Wo = orc.knn_weights(Jo, Do.copy(), k)
+    W = gl.weightmatrix.knn(X, k)
+    assert np.array_equal(W.indices, Wo.indices) and np.max(np.abs(W.data - Wo.data)) <= 1e-12
+    W = gl.weightmatrix.knn(None, k, knn_data=(Jo, Do.copy()))
+    assert np.array_equal(W.data, Wo.data)
+    tag = 'seed %d: n=%d d=%d C=%d k=%d' % (seed, c['n'], c['d'], C, k)
+    sets = []
+    for _ in range(int(rng.integers(2, 6))):
+        per_class = int(rng.integers(1, 4))
+        sets.append(np.concatenate([rng.choice(np.flatnonzero(lab == cc), size=min(per_class, int(np.sum(lab == cc))), replace=False)
+                                    for cc in range(C)]))
+    with np.errstate(all='ignore'):
+        # f-1: each stacked trial equals its own solve (iterates and iteration count)
+        m = gl.ssl.poisson(W)
+        probs = m._fit_batch([(t, lab[t]) for t in sets])
+        for j, t in enumerate(sets):
+            u_ref, it_ref = orc.poisson_cg(Wo, t, lab[t], return_iters=True)
+            assert m.num_iter[j] == it_ref, (tag, j)
+            assert np.array_equal(probs[j], u_ref, equal_nan=True), (tag, j)
+        same_size = [t for t in sets if len(t) == len(sets[0])]
+        if len(same_size) > 1:
+            m = gl.ssl.laplace(W)
+            probs = m._fit_batch([(t, lab[t]) for t in same_size])
+            if probs is not None:
+                for j, t in enumerate(same_size):
+                    assert np.array_equal(probs[j], orc.laplace_fit(Wo, t, lab[t]), equal_nan=True), (tag, j)
+        ti = sets[0]
+        # the use_cuda branch: float32 state, same T, iterates within the north star's 1e-5, same labels
+        u_ref, T_ref = orc.poisson_gd(Wo, ti, lab[ti], return_T=True)
+        m = gl.ssl.poisson(W, solver='gradient_descent', use_cuda=True)
+        u = m.fit(ti, lab[ti])
+        assert u.dtype == np.float32 and m.num_iter == T_ref, tag
+        assert np.max(np.abs(u - u_ref)) <= 1e-5 * max(1.0, np.max(np.abs(u_ref))), tag     # T sweeps of float32 rounding scale with |u|
+        # f-3: random walk, reweighted Laplace, page rank
+        u_ref, it_ref = orc.randomwalk_fit(Wo, ti, lab[ti], return_iters=True)
+        m = gl.ssl.randomwalk(W)
+        u = m.fit(ti, lab[ti])
+        assert m.num_iter == it_ref and np.array_equal(u, u_ref), tag
+        for rw in ('poisson', 'wnll'):
+            u_ref = orc.laplace_reweighted_fit(Wo, ti, lab[ti], rw)
+            u = gl.ssl.laplace(W, reweighting=rw).fit(ti, lab[ti])
+            assert np.array_equal(u, u_ref, equal_nan=True), (tag, rw)
+        G = gl.graph(W)
+        pr_ref, it_ref = orc.page_rank(Wo, return_iters=True)
+        pr = G.page_rank()
+        assert G.page_rank_iters == it_ref and np.array_equal(pr, pr_ref), tag

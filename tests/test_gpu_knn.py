@@ -222,3 +222,23 @@ def test_knn_filter_soundness_on_near_duplicates_and_offsets(gl):
     Y = np.repeat(rng.normal(size=(50, 7)), 4, axis=0)
     J, D = gl.weightmatrix.knnsearch(Y, 4)
     assert np.all(D == 0) and np.array_equal(np.sort(J, axis=1), (np.arange(200) // 4 * 4)[:, None] + np.arange(4)[None, :])
+
+
+def test_symmetric_stamp_only_on_bitwise_symmetric_graphs(gl):
+    """weightmatrix.knn stamps its output as symmetric (ssl.poisson then builds D^-1 W^T without a transpose) only where the
+    symmetrisation rule is symmetric bit for bit: (a+b)/2 and the element-wise max are, the symgaussian rule is not."""
+    from graphlearning_amd import utils as glutils
+    rng = np.random.default_rng(21)
+    X = rng.normal(size=(3000, 2))
+    asym = 0
+    for kernel in ['gaussian', 'uniform', 'distance', 'singular', 'symgaussian']:
+        W = gl.weightmatrix.knn(X, 7, kernel=kernel)
+        diff = (W != W.T).nnz
+        if kernel == 'symgaussian':
+            assert not glutils.known_symmetric(W)
+            asym = diff
+        else:
+            assert glutils.known_symmetric(W), kernel
+            assert diff == 0, kernel
+    assert asym > 0          # fl(fl(a+b)-a) != b somewhere: the reason symgaussian graphs are not stamped
+    assert not glutils.known_symmetric(gl.weightmatrix.knn(X, 7, symmetrize=False))
