@@ -36,6 +36,19 @@ def main():
         X, lab = blobs(700, 6, 3, 9, 3.0)
         k = 7
         min_iter, max_iter = 0, 40
+    elif case.startswith('random'):
+        # random size / dimension / neighbours / kernel / iteration bounds; clouds with a dense core so that some vertices are
+        # many rows' neighbour and the blocks the ranks own differ widely in their halos
+        rng = np.random.default_rng(500 + int(case[6:]))
+        n_pts = int(rng.integers(150, 1400))
+        dd = int(rng.choice([2, 3, 6, 12]))
+        CC = int(rng.integers(2, 5))
+        lab = rng.integers(0, CC, size=n_pts).astype(np.int64)
+        lab[:CC] = np.arange(CC)
+        X = rng.normal(size=(CC, dd))[lab] * 2.0 + rng.normal(size=(n_pts, dd)) * rng.choice([0.2, 1.0], size=(n_pts, 1))
+        k = int(rng.integers(3, 12))
+        kernel = str(rng.choice(['gaussian', 'gaussian', 'uniform', 'distance', 'singular']))
+        min_iter, max_iter = [(50, 300), (0, 60), (20, 20), (5, 500)][int(rng.integers(0, 4))]
     else:
         raise SystemExit('unknown case')
     n = X.shape[0]

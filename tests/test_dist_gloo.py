@@ -141,7 +141,8 @@ def test_ssl_trials_shared_over_ranks(tmp_path):
     assert text[0] == 'Number of labels,Accuracy' and text[1:] == res[0]['seq']
 
 
-@pytest.mark.parametrize('case,world', [('blobs', 2), ('blobs', 3), ('uniform', 2), ('miniter0', 3)])
+@pytest.mark.parametrize('case,world', [('blobs', 2), ('blobs', 3), ('uniform', 2), ('miniter0', 3),
+                                        ('random0', 2), ('random1', 3), ('random2', 4), ('random3', 3), ('random4', 2), ('random5', 5)])
 def test_sharded_build_matches_oracle(case, world, tmp_path):
     """dist_build: every rank assembles only ITS rows of W (symmetrisation by owner rank: one all-to-all-v of reverse
     edges), of P and its exchange plan (request exchange), then the distributed sweep runs on those plans: W rows, P rows

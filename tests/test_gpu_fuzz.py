@@ -147,3 +147,24 @@ def test_random_trials_and_comparison_methods_match_the_oracle(gl, orc, seed):
         pr_ref, it_ref = orc.page_rank(Wo, return_iters=True)
         pr = G.page_rank()
         assert G.page_rank_iters == it_ref and np.array_equal(pr, pr_ref), tag
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_plaplace_jacobi_matches_the_oracle(gl, orc, seed):
+    """graph.plaplace(fast=False) on random graphs, boundary sets, exponents and iteration caps: iterates and the
+    stopping iteration equal to the C restatement of lp_iterate_main."""
+    c = _case(200 + seed)
+    rng = c['rng']
+    W = gl.weightmatrix.knn(c['X'], c['k'], kernel=str(rng.choice(['gaussian', 'uniform'])))
+    n = c['n']
+    m = int(rng.integers(2, max(3, n // 20)))
+    bdy = rng.choice(n, size=m, replace=False)
+    val = rng.normal(size=m)
+    p = float(rng.choice([2.5, 3.0, 6.0, 10.0, 40.0]))
+    tol = float(rng.choice([1e-1, 1e-2, 1e-4]))
+    T = int(rng.choice([1, 7, 150, 100000]))
+    G = gl.graph(W)
+    u = G.plaplace(bdy, val, p, tol=tol, max_num_it=T, fast=False)
+    uo, it = orc.plaplace_jacobi(W, bdy, val, p, tol=tol, max_num_it=T, return_iters=True)
+    assert G.plaplace_iters == it, (seed, n, p, tol, T)
+    assert np.array_equal(u, uo, equal_nan=True), (seed, n, p, tol, T)      # (p < 3 can send the reference iteration to NaN: same NaNs)
