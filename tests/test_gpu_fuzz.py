@@ -168,3 +168,86 @@ def test_random_plaplace_jacobi_matches_the_oracle(gl, orc, seed):
     uo, it = orc.plaplace_jacobi(W, bdy, val, p, tol=tol, max_num_it=T, return_iters=True)
     assert G.plaplace_iters == it, (seed, n, p, tol, T)
     assert np.array_equal(u, uo, equal_nan=True), (seed, n, p, tol, T)      # (p < 3 can send the reference iteration to NaN: same NaNs)
+
+
+def _virtual_ranks_sweep(gdist, _hip, prob, order, bounds, min_iter, max_iter, dtype=np.float64):
+    """Every rank's glx_dist_sweep object in ONE process, the packed boundary records moved between them by numpy (the
+    all-to-all-v of the real transport): the stepwise protocol of graphlearning_amd.dist.run_stepwise."""
+    P, C = prob['P'], prob['k']
+    n = P.shape[0]
+    world = len(bounds) - 1
+    plans = [gdist.RankPlan(P, order, bounds, r) for r in range(world)]
+    comms = [_hip.Comm(world, r, None) for r in range(world)]
+    dss = [gdist.glx_dist_sweep(comms[r], plans[r], C, dtype=dtype) for r in range(world)]
+    try:
+        for r, ds in enumerate(dss):
+            own = plans[r].own
+            ds.set_problem(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
+
+        def exchange(next_iterate):
+            if plans[0].global_halo == 0:
+                return
+            sends = [ds.get_send() for ds in dss]
+            offs = [np.concatenate([[0], np.cumsum(plans[s].send_counts)]) for s in range(world)]
+            for r, ds in enumerate(dss):
+                parts = [sends[s][offs[s][r]:offs[s][r + 1]] for s in range(world)]
+                assert [len(p) for p in parts] == list(plans[r].recv_counts)
+                ds.put_halo(np.concatenate(parts, axis=0) if plans[r].n_halo else np.zeros((0, ds.lay['ld']), dtype=dtype), next_iterate)
+
+        for ds in dss:
+            ds.begin()
+        exchange(False)
+        thresh = 1.0 / n
+        err_T = float(np.max(np.abs(prob['deg'] * prob['w0'] - prob['vinf'])))
+        T = 0
+        while T < max_iter:
+            if T >= min_iter and not (err_T > thresh):
+                break
+            want = (T + 1) >= min_iter
+            for ds in dss:
+                ds.boundary(want)
+            exchange(True)
+            errs = [ds.interior(want) for ds in dss]
+            if want:
+                err_T = max(errs)
+            T += 1
+        u = np.zeros((n, C), dtype=dtype)
+        for r, ds in enumerate(dss):
+            u[plans[r].own] = ds.fetch()
+        halo = sum(p.n_halo for p in plans)
+    finally:
+        for ds in dss:
+            ds.close()
+        for cm in comms:
+            cm.close()
+    return u, T, halo
+
+
+@pytest.mark.parametrize('seed', range(14))
+def test_random_vertex_partitions_match_the_oracle(gl, orc, seed):
+    """The rank-local pieces of the sharded sweep (boundary rows | pack | halo | interior rows, per-rank maxima of the stop
+    column) on random graphs -- symmetric and directed -- cut into 2..6 vertex blocks in three ways (the library's locality
+    order with cuts in the gaps, the same order in equal blocks, the caller's order in equal blocks): iterates and T equal
+    to the single-process reference for every partition."""
+    from graphlearning_amd import dist as gdist, _hip
+    c = _case(300 + seed)
+    rng, lab, ti, k = c['rng'], c['lab'], c['ti'], c['k']
+    Jo, Do = orc.knnsearch(c['X'], k + 1)
+    sym = bool(rng.random() < 0.7)
+    Wo = orc.knn_weights(Jo, Do.copy(), k, symmetrize=sym)
+    min_iter, max_iter = [(50, 1000), (0, 80), (10, 10), (3, 300)][int(rng.integers(0, 4))]
+    world = int(rng.integers(2, 7))
+    how = ['cut', 'even', 'natural'][int(rng.integers(0, 3))]
+    with np.errstate(all='ignore'):
+        u_ref, T_ref = orc.poisson_gd(Wo, ti, lab[ti], min_iter=min_iter, max_iter=max_iter, return_T=True)
+        prob = gdist.poisson_problem(Wo, ti, lab[ti])
+        n = c['n']
+        order = np.arange(n) if how == 'natural' else gdist.locality_order(prob['P'])
+        bounds = gdist.cut_bounds(prob['P'], order, world) if how == 'cut' else gdist.block_bounds(n, world)
+        u, T, halo = _virtual_ranks_sweep(gdist, _hip, prob, order, bounds, min_iter, max_iter)
+        tag = 'seed %d: n=%d k=%d sym=%s world=%d %s iters=(%d,%d) halo rows %d' % (seed, n, k, sym, world, how, min_iter, max_iter, halo)
+        assert T == T_ref, tag
+        assert np.array_equal(u, u_ref, equal_nan=True), tag
+        u32, T32, _ = _virtual_ranks_sweep(gdist, _hip, prob, order, bounds, min_iter, max_iter, dtype=np.float32)
+        assert T32 == T_ref and u32.dtype == np.float32, tag
+        assert np.nanmax(np.abs(u32 - u_ref)) <= 1e-5 * max(1.0, np.nanmax(np.abs(u_ref))), tag
