@@ -251,3 +251,40 @@ def test_random_vertex_partitions_match_the_oracle(gl, orc, seed):
         u32, T32, _ = _virtual_ranks_sweep(gdist, _hip, prob, order, bounds, min_iter, max_iter, dtype=np.float32)
         assert T32 == T_ref and u32.dtype == np.float32, tag
         assert np.nanmax(np.abs(u32 - u_ref)) <= 1e-5 * max(1.0, np.nanmax(np.abs(u_ref))), tag
+
+
+@pytest.mark.parametrize('seed', range(30))
+def test_random_knn_searches_match_ckdtree(gl, orc, seed):
+    """The exact search over a wide range of shapes -- n = 2 .. 6000, d = 1 .. 300 (every feature-block count of the bf16
+    filter and the blocked fp32 kernel beyond d = 128), k = 1 .. 60 (every list length), clustered / isotropic / offset /
+    badly scaled data, euclidean and angular -- against cKDTree's lists."""
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.choice([2, 3, 17, 64, 65, 129, 500, 1500, 3000, 6000]))
+    d = int(rng.choice([1, 2, 3, 7, 16, 17, 32, 33, 50, 64, 65, 96, 97, 128, 129, 200, 300]))
+    k = int(min(n, rng.choice([1, 2, 5, 11, 12, 13, 21, 28, 29, 40, 60])))
+    style = int(rng.integers(0, 4))
+    if style == 0:
+        X = rng.normal(size=(n, d))
+    elif style == 1:
+        C = int(rng.integers(2, 12))
+        X = rng.normal(size=(C, d))[rng.integers(0, C, size=n)] * 3.0 + rng.normal(size=(n, d))
+    elif style == 2:
+        X = rng.normal(size=(n, d)) + 50.0                                    # far from the origin: the filter must centre
+    else:
+        X = rng.normal(size=(n, d)) * np.exp(rng.normal(size=(1, d)) * 2.0)   # features of very different scale
+    sim = 'angular' if rng.random() < 0.2 and d > 1 else 'euclidean'
+    J, D = gl.weightmatrix.knnsearch(X, k, similarity=sim)
+    Jo, Do = orc.knnsearch(X, k, similarity=sim)
+    Jo, Do = Jo.reshape(n, -1), Do.reshape(n, -1)          # (cKDTree drops the axis for k = 1)
+    tag = 'seed %d: n=%d d=%d k=%d style=%d %s' % (seed, n, d, k, style, sim)
+    assert J.dtype == np.int64 and D.dtype == np.float64 and J.shape == (n, k), tag
+    scale = max(1.0, float(np.max(Do)))
+    assert np.max(np.abs(D - Do)) <= 1e-12 * scale, tag
+    if not np.array_equal(J, Jo):
+        # the only admissible difference: two refs at the same distance (to the last bit) in the other order
+        bad = np.flatnonzero(np.any(J != Jo, axis=1))
+        for i in bad:
+            assert np.array_equal(np.sort(J[i]), np.sort(Jo[i])) or np.abs(D[i, -1] - Do[i, -1]) <= 1e-12 * scale, (tag, i)
+            cols = np.flatnonzero(J[i] != Jo[i])
+            assert np.all(np.abs(Do[i, cols] - D[i, cols]) <= 1e-12 * scale), (tag, i)
+        assert len(bad) <= max(1, n // 1000), (tag, len(bad))
