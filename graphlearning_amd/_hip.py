@@ -119,6 +119,7 @@ _SIGNATURES = {
     'glx_knn_stats': [_f64p],
     'glx_knn_to_csr': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                        C.POINTER(_vp), _i64p, C.c_int],
+    'glx_knn_to_csr_into': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, _i64p, C.c_int],
 }
 _SPECIAL = {'glx_last_error': ([], C.c_char_p), 'glx_free': ([_vp], None)}
 
@@ -651,6 +652,7 @@ def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None):
     return ind, dist
 
 
+_PINNED_CSR_MAX = 512 << 20      # above this the weight matrix comes back through ordinary memory
 _KERNEL_ID = {'given': 0, 'uniform': 1, 'gaussian': 2, 'symgaussian': 3, 'distance': 4, 'singular': 5}
 
 
@@ -662,20 +664,31 @@ def knn_to_csr(knn_ind, knn_dist, k, kernel='gaussian', sym=1, weights=None, dev
     # distances are only read by the kernels that compute weights from them: with given weights they need not travel
     dist = None if (knn_dist is None or kernel == 'given') else _dense(knn_dist, np.float64, (n, kk), 'knn_dist')
     w = None if weights is None else _dense(weights, np.float64, (n, k), 'weights')
-    rp, ci, va = _vp(), _vp(), _vp()
     nnz = C.c_int64(0)
     lib = load()
-    check(lib.glx_knn_to_csr(_ptr(ind), _ptr(dist), _ptr(w), n, kk, int(k), _KERNEL_ID[kernel], int(sym), C.byref(rp),
-                             C.byref(ci), C.byref(va), C.byref(nnz), _dev(device)), 'glx_knn_to_csr')
-    try:
-        m = nnz.value
-        indptr = np.ctypeslib.as_array(C.cast(rp, _i32p), shape=(n + 1,)).copy()
-        indices = np.ctypeslib.as_array(C.cast(ci, _i32p), shape=(max(m, 1),))[:m].copy()
-        data = np.ctypeslib.as_array(C.cast(va, _f64p), shape=(max(m, 1),))[:m].copy()
-    finally:
-        lib.glx_free(rp)
-        lib.glx_free(ci)
-        lib.glx_free(va)
+    cap = n * int(k) * (2 if sym else 1)                   # every list entry appears at most twice (as i->j and as j->i)
+    if cap * 12 <= _PINNED_CSR_MAX:
+        # the CSR lands in page-locked arrays of the pool (recycled by size: the next graph of the same (n, k) reuses them);
+        # indices / data are views of the first nnz entries
+        indptr = pinned_empty((n + 1,), np.int32)
+        col_buf = pinned_empty((cap,), np.int32)
+        val_buf = pinned_empty((cap,), np.float64)
+        check(lib.glx_knn_to_csr_into(_ptr(ind), _ptr(dist), _ptr(w), n, kk, int(k), _KERNEL_ID[kernel], int(sym), cap, _ptr(indptr),
+                                      _ptr(col_buf), _ptr(val_buf), C.byref(nnz), _dev(device)), 'glx_knn_to_csr_into')
+        indices, data = col_buf[:nnz.value], val_buf[:nnz.value]
+    else:
+        rp, ci, va = _vp(), _vp(), _vp()
+        check(lib.glx_knn_to_csr(_ptr(ind), _ptr(dist), _ptr(w), n, kk, int(k), _KERNEL_ID[kernel], int(sym), C.byref(rp),
+                                 C.byref(ci), C.byref(va), C.byref(nnz), _dev(device)), 'glx_knn_to_csr')
+        try:
+            m = nnz.value
+            indptr = np.ctypeslib.as_array(C.cast(rp, _i32p), shape=(n + 1,)).copy()
+            indices = np.ctypeslib.as_array(C.cast(ci, _i32p), shape=(max(m, 1),))[:m].copy()
+            data = np.ctypeslib.as_array(C.cast(va, _f64p), shape=(max(m, 1),))[:m].copy()
+        finally:
+            lib.glx_free(rp)
+            lib.glx_free(ci)
+            lib.glx_free(va)
     W = sparse.csr_matrix((data, indices, indptr), shape=(n, n))
     W.has_sorted_indices = True
     W.has_canonical_format = True

@@ -278,8 +278,10 @@ struct AsmBufs {
   }
 };
 
-extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const double* weights, int64_t n, int kk, int k, int kernel,
-                              int sym, int32_t** rowptr_out, int32_t** col_out, double** val_out, int64_t* nnz_out, int device) {
+// cap < 0: the CSR arrays are allocated here (malloc; glx_free releases them); cap >= 0: *rowptr_out / *col_out / *val_out
+// are the caller's buffers with room for n + 1 row pointers and cap entries
+static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double* weights, int64_t n, int kk, int k, int kernel,
+                           int sym, int64_t cap, int32_t** rowptr_out, int32_t** col_out, double** val_out, int64_t* nnz_out, int device) {
   GLX_CHECK(ind && rowptr_out && col_out && val_out && nnz_out, GLX_EINVAL, "glx_knn_to_csr: null argument");
   GLX_CHECK(n >= 1 && k >= 1 && kk >= k, GLX_EINVAL, "glx_knn_to_csr: need n >= 1 and 1 <= k <= columns (n=%lld k=%d columns=%d)", (long long)n, k, kk);
   GLX_CHECK(kernel >= K_GIVEN && kernel <= K_SINGULAR, GLX_EINVAL, "glx_knn_to_csr: bad kernel id %d", kernel);
@@ -287,7 +289,8 @@ extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const doub
   GLX_CHECK(kernel == K_GIVEN ? weights != nullptr : (kernel == K_UNIFORM || dist != nullptr), GLX_EINVAL, "glx_knn_to_csr: missing weights / distances");
   GLX_CHECK(n < (1ll << 31) && n * k < (1ll << 31), GLX_EUNSUPPORTED, "glx_knn_to_csr: n*k must fit int32");
   GLX_CHECK(k <= 65535, GLX_EUNSUPPORTED, "glx_knn_to_csr: at most 65535 neighbours per row (k=%d)", k);
-  *rowptr_out = nullptr; *col_out = nullptr; *val_out = nullptr; *nnz_out = 0;
+  if (cap < 0) { *rowptr_out = nullptr; *col_out = nullptr; *val_out = nullptr; }
+  *nnz_out = 0;
   GLX_HIP(hipSetDevice(device));
   AsmBufs b;
   GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
@@ -393,11 +396,13 @@ extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const doub
                        b.col, b.val);
     GLX_HIP(hipGetLastError());
   }
-  int32_t* h_rp = (int32_t*)malloc((n + 1) * 4);
-  int32_t* h_col = (int32_t*)malloc(std::max<size_t>(nnz * 4, 4));
-  double* h_val = (double*)malloc(std::max<size_t>(nnz * 8, 8));
+  const bool own = cap < 0;
+  GLX_CHECK(own || nnz <= cap, GLX_EINVAL, "glx_knn_to_csr_into: %lld entries, room for %lld", (long long)nnz, (long long)cap);
+  int32_t* h_rp = own ? (int32_t*)malloc((n + 1) * 4) : *rowptr_out;
+  int32_t* h_col = own ? (int32_t*)malloc(std::max<size_t>(nnz * 4, 4)) : *col_out;
+  double* h_val = own ? (double*)malloc(std::max<size_t>(nnz * 8, 8)) : *val_out;
   if (!h_rp || !h_col || !h_val) {
-    free(h_rp); free(h_col); free(h_val);
+    if (own) { free(h_rp); free(h_col); free(h_val); }
     glx_set_error("glx_knn_to_csr: host allocation failed");
     return GLX_ENOMEM;
   }
@@ -406,7 +411,7 @@ extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const doub
   hipError_t e2 = hipMemcpyAsync(h_val, b.val, nnz * 8, hipMemcpyDeviceToHost, st);
   hipError_t e3 = hipStreamSynchronize(st);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-    free(h_rp); free(h_col); free(h_val);
+    if (own) { free(h_rp); free(h_col); free(h_val); }
     glx_set_error("glx_knn_to_csr: download failed");
     return GLX_EHIP;
   }
@@ -415,4 +420,18 @@ extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const doub
   *val_out = h_val;
   *nnz_out = nnz;
   return GLX_OK;
+}
+
+extern "C" int glx_knn_to_csr(const int64_t* ind, const double* dist, const double* weights, int64_t n, int kk, int k, int kernel,
+                              int sym, int32_t** rowptr_out, int32_t** col_out, double** val_out, int64_t* nnz_out, int device) {
+  return knn_to_csr_impl(ind, dist, weights, n, kk, k, kernel, sym, -1, rowptr_out, col_out, val_out, nnz_out, device);
+}
+
+// the same with the CSR written into the caller's arrays (rowptr: n + 1, col / val: cap entries; 2 n k always suffices,
+// n k without symmetrisation): page-locked ones make the copy back run at PCIe speed and save the copy out of
+// library-owned memory
+extern "C" int glx_knn_to_csr_into(const int64_t* ind, const double* dist, const double* weights, int64_t n, int kk, int k, int kernel,
+                                   int sym, int64_t cap, int32_t* rowptr, int32_t* col, double* val, int64_t* nnz_out, int device) {
+  GLX_CHECK(cap >= 0 && rowptr && col && val, GLX_EINVAL, "glx_knn_to_csr_into: null buffer or negative capacity");
+  return knn_to_csr_impl(ind, dist, weights, n, kk, k, kernel, sym, cap, &rowptr, &col, &val, nnz_out, device);
 }

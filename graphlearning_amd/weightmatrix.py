@@ -59,13 +59,14 @@ def _knn(data, k, kernel, eta, symmetrize, metric, similarity, knn_data, device)
             # reference's; assembly and symmetrisation run on the device.  GLX_DEVICE_WEIGHTS=1
             # moves the exp to the device as well (within an ulp).
             d = np.asarray(knn_dist)[:, :k]
+            weights = _hip.pinned_empty((n, k), np.float64)          # page-locked: the upload to the assembly runs at PCIe speed
             if kernel == 'gaussian':
                 D = d * d
                 eps = D[:, k - 1]
-                weights = np.exp(-4 * D / eps[:, None])
+                np.exp(-4 * D / eps[:, None], out=weights)
             else:
                 eps = d[:, k - 1]
-                weights = np.exp(-4 * d * d / eps[:, None] / eps[np.asarray(knn_ind)[:, :k]])
+                np.exp(-4 * d * d / eps[:, None] / eps[np.asarray(knn_ind)[:, :k]], out=weights)
             return _hip.knn_to_csr(knn_ind, knn_dist, k, kernel='given', sym=sym, weights=weights, device=device)
         return _hip.knn_to_csr(knn_ind, knn_dist, k, kernel=kernel, sym=sym, device=device)
     # user kernel: a Python callable, evaluated on the host; assembly on the device.

@@ -272,7 +272,8 @@ int glx_knn_bruteforce(const double* X, int64_t n, int d, int k, int similarity,
  * sharded across GPUs; every rank holds all of X).  ind_out/dist_out: (q_end - q_begin, k). */
 int glx_knn_bruteforce_range(const double* X, int64_t n, int d, int k, int64_t q_begin, int64_t q_end,
                              int64_t* ind_out, double* dist_out, int device);
-int glx_knn_stats(double stats[8]);
+int glx_knn_stats(double stats[8]);   /* of the last search: [0] tile-kernel ms, [1] re-rank ms, [2] fallback rows, [3] total device ms,
+                                        [4] fallback ms, [5] padded feature count, [6] ref ranges, [7] list length (negative: bf16 filter) */
 
 /* weightmatrix.knn given knn data (graphlearning/weightmatrix.py:134-187) on the device: kernel
  * weights, COO->CSR with duplicates summed, symmetrisation, zero diagonal, zeros dropped.
@@ -283,7 +284,12 @@ int glx_knn_stats(double stats[8]);
  * (release with glx_free): canonical CSR, int32 indices like scipy's. */
 int glx_knn_to_csr(const int64_t* ind, const double* dist, const double* weights, int64_t n, int kk, int k,
                    int kernel, int sym, int32_t** rowptr_out, int32_t** col_out, double** val_out,
-                   int64_t* nnz_out, int device);   /* last call: [0] tile-kernel ms, [1] rerank ms, [2] fallback rows, [3] total ms */
+                   int64_t* nnz_out, int device);
+/* the same with the CSR written into the caller's arrays: rowptr (n + 1), col and val with room for `cap` entries
+ * (2 n k always suffices, n k without symmetrisation); GLX_EINVAL if the result does not fit. */
+int glx_knn_to_csr_into(const int64_t* ind, const double* dist, const double* weights, int64_t n, int kk, int k,
+                        int kernel, int sym, int64_t cap, int32_t* rowptr, int32_t* col, double* val,
+                        int64_t* nnz_out, int device);
 
 #ifdef __cplusplus
 }
