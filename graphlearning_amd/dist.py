@@ -56,39 +56,44 @@ def crossing_counts(P, order):
 
 def _best_cuts(cross, n, world, cap, cand):
     """world-1 increasing cut positions among `cand` with every block <= cap rows, minimising the
-    total crossing count, ties towards balanced blocks.  Returns (total crossing, cuts) or None."""
-    m = len(cand)
-    INF = (float('inf'), float('inf'))
-    prev = [((int(cross[c]), c * c) if c <= cap else INF) for c in cand]
-    back = []
-    for k in range(2, world):
-        cur, arg = [INF] * m, [-1] * m
-        for j in range(m):
-            cj = cand[j]
-            best, bi = INF, -1
-            for i in range(j):
-                if prev[i] is INF or cj - cand[i] > cap:
-                    continue
-                t = (prev[i][0] + int(cross[cj]), prev[i][1] + (cj - cand[i]) ** 2)
-                if t < best:
-                    best, bi = t, i
-            cur[j], arg[j] = best, bi
-        back.append(arg)
-        prev = cur
-    best, bj = INF, -1
-    for j in range(m):
-        if prev[j] is INF or n - cand[j] > cap:
-            continue
-        t = (prev[j][0], prev[j][1] + (n - cand[j]) ** 2)
-        if t < best:
-            best, bj = t, j
-    if bj < 0:
+    total crossing count, ties towards balanced blocks (least sum of squared block sizes, then the
+    earliest predecessor).  Returns (total crossing, cuts) or None.  Dynamic programme over (number of
+    cuts placed, last cut), one numpy pass per cut: O(world * len(cand)^2) array work."""
+    c = np.asarray(cand, dtype=np.int64)
+    m = len(c)
+    if m == 0:
         return None
-    cuts = [cand[bj]]
+    BIG = np.iinfo(np.int64).max // 4
+    xc = cross[c].astype(np.int64)
+    ok0 = c <= cap
+    cost = np.where(ok0, xc, BIG)                         # crossings of the cuts placed so far, last cut at c[j]
+    bal = np.where(ok0, c * c, BIG)                       # sum of squared sizes of the blocks closed so far
+    gap = c[None, :] - c[:, None]                         # gap[i, j] = c[j] - c[i]
+    allowed = (gap > 0) & (gap <= cap)
+    back = []
+    for _ in range(2, world):
+        feas = allowed & (cost < BIG)[:, None]
+        t0 = np.where(feas, cost[:, None] + xc[None, :], BIG)
+        best0 = t0.min(axis=0)
+        t1 = np.where(feas & (t0 == best0[None, :]), bal[:, None] + gap * gap, BIG)
+        arg = t1.argmin(axis=0)                           # first minimiser = earliest predecessor, like the scalar loop
+        best1 = t1[arg, np.arange(m)]
+        none = best0 >= BIG
+        cost = np.where(none, BIG, best0)
+        bal = np.where(none, BIG, best1)
+        back.append(np.where(none, -1, arg))
+    last = n - c
+    feas = (cost < BIG) & (last <= cap)
+    if not np.any(feas):
+        return None
+    best0 = np.where(feas, cost, BIG).min()
+    t1 = np.where(feas & (cost == best0), bal + last * last, BIG)
+    bj = int(t1.argmin())
+    cuts = [int(c[bj])]
     for arg in reversed(back):
-        bj = arg[bj]
-        cuts.append(cand[bj])
-    return best[0], cuts[::-1]
+        bj = int(arg[bj])
+        cuts.append(int(c[bj]))
+    return int(best0), cuts[::-1]
 
 
 def cut_bounds(P, order, world, slack_levels=(0.0, 0.1, 0.25, 0.45, 0.65, 0.85)):
