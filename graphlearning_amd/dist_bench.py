@@ -45,16 +45,29 @@ def main(args):
     engine = os.environ.get('GLX_DIST_ENGINE', 'glx')     # 'glx': library-owned RCCL communicator + captured sweeps; 'torch': round-1 path
     comm = None
     if engine == 'glx':
-        try:
-            comm = gdist.init_comm(dist, local_rank)
-        except Exception as exc:                            # noqa: BLE001 -- fall back rather than lose the measurement
-            if rank == 0:
-                print('glx communicator unavailable (%s); using the torch.distributed engine' % (exc,), file=sys.stderr)
+        # the library's own RCCL communicator; an error OR a rendezvous that does not come back within two minutes must not
+        # cost the measurement: the ranks then agree (below) on the torch.distributed engine
+        import threading
+        box = {}
+
+        def _init():
+            try:
+                box['comm'] = gdist.init_comm(dist, local_rank)
+            except Exception as exc:                        # noqa: BLE001
+                box['err'] = exc
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(120.0)
+        comm = box.get('comm')
+        if comm is None:
+            print('rank %d: glx communicator unavailable (%s); using the torch.distributed engine'
+                  % (rank, box.get('err', 'no answer from ncclCommInitRank after 120 s')), file=sys.stderr)
             engine = 'torch'
     flag = torch.tensor([1 if engine == 'glx' else 0], dtype=torch.int64, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
         engine = 'torch'
+        comm = None                                         # (a communicator some ranks did get is left alone)
 
     def measure(partition):
         bounds = gdist.cut_bounds(P, order, world) if partition == 'cut' else gdist.block_bounds(P.shape[0], world)
