@@ -8,6 +8,9 @@ from scipy import sparse
 
 pytestmark = pytest.mark.gpu
 
+# GLX_FUZZ_SCALE=10 runs ten times as many random cases of every kind (a soak run; the default is what CI runs)
+_SCALE = int(__import__('os').environ.get('GLX_FUZZ_SCALE', '1'))
+
 
 @pytest.fixture(scope='module')
 def gl():
@@ -41,7 +44,7 @@ def _case(seed):
     return dict(n=n, d=d, C=C, k=k, X=X, lab=lab.astype(np.int64), kernel=kernel, symmetrize=symmetrize, ti=ti, rng=rng)
 
 
-@pytest.mark.parametrize('seed', range(24))
+@pytest.mark.parametrize('seed', range(24 * _SCALE))
 def test_random_pipeline_matches_the_oracle(gl, orc, seed):
     c = _case(seed)
     X, lab, ti, k = c['X'], c['lab'], c['ti'], c['k']
@@ -93,7 +96,7 @@ def test_random_pipeline_matches_the_oracle(gl, orc, seed):
         assert np.array_equal(np.asarray(m.weights), np.asarray(w_ref)), tag
 
 
-@pytest.mark.parametrize('seed', range(12))
+@pytest.mark.parametrize('seed', range(12 * _SCALE))
 def test_random_trials_and_comparison_methods_match_the_oracle(gl, orc, seed):
     """Stacked trials (several training sets as column groups of one solve), the float32 branch, and the comparison
     methods of SURVEY 8 f-3 on random symmetric graphs."""
@@ -149,7 +152,7 @@ def test_random_trials_and_comparison_methods_match_the_oracle(gl, orc, seed):
         assert G.page_rank_iters == it_ref and np.array_equal(pr, pr_ref), tag
 
 
-@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('seed', range(8 * _SCALE))
 def test_random_plaplace_jacobi_matches_the_oracle(gl, orc, seed):
     """graph.plaplace(fast=False) on random graphs, boundary sets, exponents and iteration caps: iterates and the
     stopping iteration equal to the C restatement of lp_iterate_main."""
@@ -223,7 +226,7 @@ def _virtual_ranks_sweep(gdist, _hip, prob, order, bounds, min_iter, max_iter, d
     return u, T, halo
 
 
-@pytest.mark.parametrize('seed', range(14))
+@pytest.mark.parametrize('seed', range(14 * _SCALE))
 def test_random_vertex_partitions_match_the_oracle(gl, orc, seed):
     """The rank-local pieces of the sharded sweep (boundary rows | pack | halo | interior rows, per-rank maxima of the stop
     column) on random graphs -- symmetric and directed -- cut into 2..6 vertex blocks in three ways (the library's locality
@@ -253,7 +256,7 @@ def test_random_vertex_partitions_match_the_oracle(gl, orc, seed):
         assert np.nanmax(np.abs(u32 - u_ref)) <= 1e-5 * max(1.0, np.nanmax(np.abs(u_ref))), tag
 
 
-@pytest.mark.parametrize('seed', range(30))
+@pytest.mark.parametrize('seed', range(30 * _SCALE))
 def test_random_knn_searches_match_ckdtree(gl, orc, seed):
     """The exact search over a wide range of shapes -- n = 2 .. 6000, d = 1 .. 300 (every feature-block count of the bf16
     filter and the blocked fp32 kernel beyond d = 128), k = 1 .. 60 (every list length), clustered / isotropic / offset /
