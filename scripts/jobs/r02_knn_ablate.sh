@@ -1,4 +1,6 @@
 #!/bin/bash
+# (record of a job of round 2: some of the compile-time switches it sets were experiments and no longer exist in knn.hip -- the
+#  results are in profiles/r02_knn_ablation.txt; KNN_ABLATE, KNN_COUNT and KNN_BF16_NSUB are the ones that remain)
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/r02x
 B="-mllvm -amdgpu-mfma-vgpr-form -DKNN_PADDED_STAGE=1"

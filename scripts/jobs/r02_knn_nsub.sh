@@ -3,8 +3,8 @@
 #  results are in profiles/r02_knn_ablation.txt; KNN_ABLATE, KNN_COUNT and KNN_BF16_NSUB are the ones that remain)
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/r02x
-for v in "-DKNN_PRIO=0" "-DKNN_PRIO=1" "-DKNN_PRIO=2"; do
+for v in "" "-DKNN_BF16_NSUB=1" "-DKNN_BF16_NSUB=2"; do
   export GLX_CXXFLAGS="$v"
   timeout 600 python -c "from graphlearning_amd import _build; _build.build_lib()" || echo build failed
-  timeout 120 python scripts/knn_variant_probe.py big 2>&1 | tee -a gpurun_out/r02x/knn_prio.txt
+  timeout 120 python scripts/knn_variant_probe.py big 2>&1 | tee -a gpurun_out/r02x/knn_nsub.txt
 done
