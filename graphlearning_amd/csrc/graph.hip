@@ -262,9 +262,16 @@ static void rcm_order(const glx_graph* g, std::vector<int32_t>& perm, bool sort_
     adj = adj_own.data();
   }
   auto degree = [&](int32_t v) { return ptr[v + 1] - ptr[v]; };
+  // vertices by ascending degree, ties by index (a counting sort: degrees are small integers)
   std::vector<int32_t> by_deg(n);
-  std::iota(by_deg.begin(), by_deg.end(), 0);
-  std::stable_sort(by_deg.begin(), by_deg.end(), [&](int32_t a, int32_t b) { return degree(a) < degree(b); });
+  {
+    int64_t dmax = 0;
+    for (int64_t v = 0; v < n; ++v) dmax = std::max<int64_t>(dmax, degree((int32_t)v));
+    std::vector<int64_t> first(dmax + 2, 0);
+    for (int64_t v = 0; v < n; ++v) first[degree((int32_t)v) + 1]++;
+    for (int64_t q = 0; q <= dmax; ++q) first[q + 1] += first[q];
+    for (int64_t v = 0; v < n; ++v) by_deg[first[degree((int32_t)v)]++] = (int32_t)v;
+  }
   std::vector<char> seen(n, 0);
   perm.clear();
   perm.reserve(n);
