@@ -696,7 +696,7 @@ def knn_to_csr(knn_ind, knn_dist, k, kernel='gaussian', sym=1, weights=None, dev
 
 
 def knn_stats():
-    out = (C.c_double * 8)()
+    out = (C.c_double * 16)()
     check(load().glx_knn_stats(out), 'glx_knn_stats')
     return dict(tile_ms=out[0], rerank_ms=out[1], fallback_rows=out[2], total_ms=out[3], fallback_ms=out[4],
-                dpa=out[5], nsplit=out[6], KP=abs(out[7]), filter='bf16x3' if out[7] < 0 else 'f32')
+                dpa=out[5], nsplit=out[6], KP=abs(out[7]), filter='bf16x3' if out[7] < 0 else 'f32', escalated_rows=out[8])

@@ -21,10 +21,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static double g_knn_stats[8];
-extern "C" int glx_knn_stats(double stats[8]) {
+static double g_knn_stats[16];
+extern "C" int glx_knn_stats(double stats[16]) {
   GLX_CHECK(stats, GLX_EINVAL, "glx_knn_stats: null output");
-  for (int i = 0; i < 8; ++i) stats[i] = g_knn_stats[i];
+  for (int i = 0; i < 16; ++i) stats[i] = g_knn_stats[i];
   return GLX_OK;
 }
 
@@ -106,7 +106,11 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
   float tau = INFINITY;
 
   const int64_t ntiles = (n + BR - 1) / BR;
-  const int64_t t0 = ntiles * sp / nsplit, t1 = ntiles * (sp + 1) / nsplit;
+  // ref range `sp` = the tiles sp, sp + nsplit, sp + 2 nsplit, ...: INTERLEAVED, not a contiguous block of refs.  Data often comes
+  // sorted (by class, along a curve, by a locality order): a query's neighbours are then neighbours in index too, a contiguous
+  // range would put all of them into the two lists of one range and overflow them (29 % of the rows of locality-ordered
+  // config-4 data took the exact fallback); interleaved, any 32 * nsplit consecutive refs are spread over all the lists
+  const int64_t t0 = sp, t1 = ntiles;
   // staging split in two (issue early / write late): the global loads of step u+1 are issued
   // before the MFMAs of step u and land in LDS only after them, so their latency hides
   // under the matrix work instead of stalling the wavefront in front of it.
@@ -173,16 +177,16 @@ __global__ __launch_bounds__(256) void knn_tile_kernel(const float* __restrict__
   __syncthreads();
   int buf = 0;
   f32x16 acc[NSUB];
-  for (int64_t t = t0; t < t1; ++t)
+  for (int64_t t = t0; t < t1; t += nsplit)
   for (int kb = 0; kb < nkb; ++kb) {
     const bool last_kb = kb == nkb - 1;
-    const bool has_next = !(last_kb && t + 1 == t1);
+    const bool has_next = !(last_kb && t + nsplit >= t1);
     if constexpr (KBLK) {
 #pragma unroll
       for (int s = 0; s < DH; ++s) bq[s] = bqn[s];
     }
     if (has_next) {
-      stage_load(last_kb ? t + 1 : t, last_kb ? 0 : kb + 1);
+      stage_load(last_kb ? t + nsplit : t, last_kb ? 0 : kb + 1);
       load_bq_next(last_kb ? 0 : kb + 1);
     }
     const float* tl = tile + buf * BR * STRIDE;
@@ -369,7 +373,11 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
   float tau = INFINITY;          // thresholds are kept WITHOUT the query's norm: values are |r|^2 - 2 q.r
 
   const int64_t ntiles = (n + BR - 1) / BR;
-  const int64_t t0 = ntiles * sp / nsplit, t1 = ntiles * (sp + 1) / nsplit;
+  // ref range `sp` = the tiles sp, sp + nsplit, sp + 2 nsplit, ...: INTERLEAVED, not a contiguous block of refs.  Data often comes
+  // sorted (by class, along a curve, by a locality order): a query's neighbours are then neighbours in index too, a contiguous
+  // range would put all of them into the two lists of one range and overflow them (29 % of the rows of locality-ordered
+  // config-4 data took the exact fallback); interleaved, any 32 * nsplit consecutive refs are spread over all the lists
+  const int64_t t0 = sp, t1 = ntiles;
   uint4 pre[UNITS];
   float pre_rn = 0.f;
   auto stage_load = [&](int64_t t) {
@@ -446,10 +454,10 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
   __syncthreads();
   int buf = 0;
   KNN_TIC(ta);
-  for (int64_t t = t0; t < t1; ++t) {
-    const bool has_next = t + 1 < t1;
+  for (int64_t t = t0; t < t1; t += nsplit) {
+    const bool has_next = t + nsplit < t1;
 #if !(KNN_ABLATE & 4)
-    if (has_next) stage_load(t + 1);
+    if (has_next) stage_load(t + nsplit);
 #endif
     const char* tl = tile + buf * BR * ROWB;
     const float* rnb = rn + buf * BR;
@@ -831,7 +839,16 @@ static int launch_tile_dh(int DH, int nkb, const KnnBufs& b, int64_t n, int64_t 
   return GLX_EUNSUPPORTED;
 }
 
-static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t q1, int64_t* ind_out, double* dist_out, int device) {
+static const int KNN_ESCALATE = 1;    // knn_pass: too many rows failed the acceptance test of the short lists -- search again with long ones
+
+// One pass of the search.  long_lists = false: the default (short lists where they apply); if then more than 0.5 % of the
+// query rows (and more than 64) fail the acceptance test, nothing is repaired row by row -- every such row would stream
+// the whole data set k times -- and KNN_ESCALATE is returned: the caller repeats the search with the long lists (one list
+// holds all k neighbours of a query, whatever their arrangement in the data).  It takes data whose k nearest neighbours
+// sit in the same 16 of 32 consecutive points to get there (a curve sampled in order, say); interleaving the ref tiles
+// over the ranges already spreads anything coarser.
+static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_t q1, int64_t* ind_out, double* dist_out, int device,
+                    bool long_lists) {
   GLX_CHECK(X && ind_out && dist_out, GLX_EINVAL, "glx_knn_bruteforce: null argument");
   GLX_CHECK(n >= 1 && d >= 1 && k >= 1, GLX_EINVAL, "glx_knn_bruteforce: need n, d, k >= 1 (n=%lld d=%d k=%d)", (long long)n, d, k);
   GLX_CHECK(k <= n, GLX_EINVAL, "glx_knn_bruteforce: k=%d exceeds the number of points %lld", k, (long long)n);
@@ -852,7 +869,7 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   // at config 2, 94 -> 108 TFLOP/s at d = 64.  Not for the blocked variant: at large d the fp32
   // error margin of the acceptance test makes short lists fall back too often.
   // The same argument one size up: 16 entries for k <= 28 (3e-7 per query at k = 28), 32 for k <= 60.
-  const bool short_lists = d + 2 <= 132 && !(getenv("GLX_KNN_SHORT") && atoi(getenv("GLX_KNN_SHORT")) == 0);
+  const bool short_lists = !long_lists && d + 2 <= 132 && !(getenv("GLX_KNN_SHORT") && atoi(getenv("GLX_KNN_SHORT")) == 0);
   if (short_lists) KP = k <= 12 ? 8 : (k <= 28 ? 16 : 32);
   int DH = knn_kb(KP), nkb = 1;
   if (d + 2 <= 132 && !(KP == 64 && d + 2 > 36)) {   // (KP = 64 lists + a wide double-buffered tile exceed the LDS)
@@ -981,6 +998,10 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   for (int64_t i = 0; i < nq; ++i)
     if (flags[i]) rows.push_back((int)i);
   if (KNN_ABLATE) rows.clear();   // developer probes produce wrong candidate lists: do not repair them
+  if (short_lists && (int64_t)rows.size() > std::max<int64_t>(64, nq / 200)) {
+    g_knn_stats[2] = (double)rows.size();
+    return KNN_ESCALATE;
+  }
   if (!rows.empty()) {
     GLX_HIP(hipMemcpyAsync(b.rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
     const size_t nr = rows.size();
@@ -1018,6 +1039,16 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   g_knn_stats[6] = (double)nsplit;
   g_knn_stats[7] = use_bf16 ? -(double)KP : (double)KP;   // negative: the bf16 filter ran
   return GLX_OK;
+}
+
+static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t q1, int64_t* ind_out, double* dist_out, int device) {
+  g_knn_stats[8] = 0.0;
+  int rc = knn_pass(X, n, d, k, q0, q1, ind_out, dist_out, device, false);
+  if (rc != KNN_ESCALATE) return rc;
+  const double flagged = g_knn_stats[2];
+  rc = knn_pass(X, n, d, k, q0, q1, ind_out, dist_out, device, true);
+  g_knn_stats[8] = flagged;            // rows the first (short-list) pass could not accept
+  return rc;
 }
 
 extern "C" int glx_knn_bruteforce(const double* X, int64_t n, int d, int k, int similarity, int64_t* ind_out, double* dist_out,

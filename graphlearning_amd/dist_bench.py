@@ -217,9 +217,15 @@ def main_config4(args):
     _hip.set_default_device(local_rank)
     dev = torch.device('cuda', local_rank)
     n, K, T = int(args.n), 10, 200
+    t_start = time.perf_counter()
+
+    def progress(what):
+        if rank == 0:
+            print('[config 4] %7.1f s  %s' % (time.perf_counter() - t_start, what), file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     X, labels = config4_features(n)
     t_feat = time.perf_counter() - t0
+    progress('features generated (n = %d)' % n)
     # points arrive in arbitrary order: a contiguous block of them would reference nearly every other vertex.  A coarse
     # geometric order first (64 cells, chained), identical on every rank; the block a rank owns is then compact and its
     # halo is what crosses the block boundaries
@@ -227,12 +233,14 @@ def main_config4(args):
     perm = dist_build.coarse_locality_order(X, ncells=64, seed=0)
     X, labels = np.ascontiguousarray(X[perm]), labels[perm]
     t_order = time.perf_counter() - t0
+    progress('coarse locality order applied')
     bounds = gdist.block_bounds(n, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     t0 = time.perf_counter()
     J, D = _hip.knn_bruteforce(X, K + 1, device=local_rank, query_range=(lo, hi))
     st = _hip.knn_stats()
     t_knn = time.perf_counter() - t0
+    progress('kNN lists of the own rows (tile kernel %.1f s, %d fallback rows)' % (st['tile_ms'] / 1e3, st['fallback_rows']))
     del X
     t0 = time.perf_counter()
     sg = dist_build.ShardedGraph(dist, n, J, D, K, device=dev)
@@ -240,11 +248,14 @@ def main_config4(args):
     train_ind = gl.trainsets.generate(labels, rate=5, seed=0)
     prob = sg.poisson_problem_rows(train_ind, labels[train_ind])
     t_build = time.perf_counter() - t0
+    progress('own rows of W / P symmetrised, halo plan built')
     comm = gdist.init_comm(dist, local_rank)
     ds = gdist.glx_dist_sweep(comm, sg.plan, prob['k'], force_exchange=gdist._force_collectives())
     ds.set_problem(prob['Db'], prob['w0'], prob['deg'], prob['vinf'])
+    progress('sweep object on the device')
     for _ in range(max(args.warmup, 1)):
         ds.run(T, T, 8, 0.0)
+    progress('warm-up done')
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -272,8 +272,10 @@ int glx_knn_bruteforce(const double* X, int64_t n, int d, int k, int similarity,
  * sharded across GPUs; every rank holds all of X).  ind_out/dist_out: (q_end - q_begin, k). */
 int glx_knn_bruteforce_range(const double* X, int64_t n, int d, int k, int64_t q_begin, int64_t q_end,
                              int64_t* ind_out, double* dist_out, int device);
-int glx_knn_stats(double stats[8]);   /* of the last search: [0] tile-kernel ms, [1] re-rank ms, [2] fallback rows, [3] total device ms,
-                                        [4] fallback ms, [5] padded feature count, [6] ref ranges, [7] list length (negative: bf16 filter) */
+int glx_knn_stats(double stats[16]);  /* of the last search: [0] tile-kernel ms, [1] re-rank ms, [2] fallback rows, [3] total device ms,
+                                        [4] fallback ms, [5] padded feature count, [6] ref ranges, [7] list length (negative: bf16 filter),
+                                        [8] rows the short lists could not accept when the search was repeated with long ones (else 0);
+                                        [9..15] reserved */
 
 /* weightmatrix.knn given knn data (graphlearning/weightmatrix.py:134-187) on the device: kernel
  * weights, COO->CSR with duplicates summed, symmetrisation, zero diagonal, zeros dropped.

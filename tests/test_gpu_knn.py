@@ -242,3 +242,35 @@ def test_symmetric_stamp_only_on_bitwise_symmetric_graphs(gl):
             assert diff == 0, kernel
     assert asym > 0          # fl(fl(a+b)-a) != b somewhere: the reason symgaussian graphs are not stamped
     assert not glutils.known_symmetric(gl.weightmatrix.knn(X, 7, symmetrize=False))
+
+
+def test_search_on_data_sorted_by_locality(gl):
+    """Data whose index order follows its geometry.  (1) Sorted by class / by a coarse locality order: a query's neighbours
+    are neighbours in index; the ref ranges of the candidate lists are interleaved tiles, so they still spread over all the
+    lists (a contiguous range per list sent 29 % of such rows to the exact fallback).  (2) Tight groups stored one after another: all k neighbours
+    lie among the 12 rows around the query, 8 of them in the same short list -- the search notices (acceptance test of the
+    re-rank) and repeats itself with the long lists instead of scanning row by row.
+    Exact answer (cKDTree's) in both cases."""
+    from oracle import gl_oracle as orc
+    from graphlearning_amd import _hip, dist_build
+    rng = np.random.default_rng(33)
+    lab = np.sort(rng.integers(0, 10, size=20000))
+    X = rng.normal(size=(10, 24))[lab] * 3.0 + rng.normal(size=(20000, 24))
+    X = np.ascontiguousarray(X[dist_build.coarse_locality_order(X, ncells=32, seed=1)])
+    J, D = gl.weightmatrix.knnsearch(X, 11)
+    st = _hip.knn_stats()
+    Jo, Do = orc.knnsearch(X, 11)
+    assert np.array_equal(J, Jo) and np.max(np.abs(D - Do)) <= 1e-12
+    assert st['escalated_rows'] == 0 and st['fallback_rows'] <= 20, st
+    # (2) 2000 tight groups of 12 points, stored group after group: the 12 nearest of every point (itself included) are 12
+    # consecutive rows, 8 of which share one half-wavefront list of 8 entries
+    centres = rng.normal(size=(2000, 8)) * 3.0
+    G = np.repeat(centres, 12, axis=0) + rng.normal(size=(24000, 8)) * 0.2
+    for k in (12, 8, 5):
+        J, D = gl.weightmatrix.knnsearch(G, k)
+        st = _hip.knn_stats()
+        Jo, Do = orc.knnsearch(G, k)
+        assert np.array_equal(J, Jo) and np.max(np.abs(D - Do)) <= 1e-12, k
+        print('groups of 12, k=%d: %d rows escalated, %d fallback rows, lists of %d' % (k, st['escalated_rows'], st['fallback_rows'], st['KP']))
+        if k == 12:
+            assert st['escalated_rows'] > 120 and st['KP'] == 16 and st['fallback_rows'] <= 24, st   # the repeat ran with the long lists and needed no row scans
