@@ -841,11 +841,11 @@ static int launch_tile_dh(int DH, int nkb, const KnnBufs& b, int64_t n, int64_t 
 
 static const int KNN_ESCALATE = 1;    // knn_pass: too many rows failed the acceptance test of the short lists -- search again with long ones
 
-// One pass of the search.  long_lists = false: the default (short lists where they apply); if then more than 0.5 % of the
-// query rows (and more than 64) fail the acceptance test, nothing is repaired row by row -- every such row would stream
-// the whole data set k times -- and KNN_ESCALATE is returned: the caller repeats the search with the long lists (one list
+// One pass of the search.  long_lists = false: the default (short lists where they apply); if then so many query rows fail
+// the acceptance test that repairing them row by row -- each streams the whole data set k times -- would take longer than
+// searching again, KNN_ESCALATE is returned: the caller repeats the search with the long lists (one list
 // holds all k neighbours of a query, whatever their arrangement in the data).  It takes data whose k nearest neighbours
-// sit in the same 16 of 32 consecutive points to get there (a curve sampled in order, say); interleaving the ref tiles
+// sit in the same 16 of 32 consecutive points to get there (tight groups stored one after another); interleaving the ref tiles
 // over the ranges already spreads anything coarser.
 static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_t q1, int64_t* ind_out, double* dist_out, int device,
                     bool long_lists) {
@@ -998,9 +998,16 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   for (int64_t i = 0; i < nq; ++i)
     if (flags[i]) rows.push_back((int)i);
   if (KNN_ABLATE) rows.clear();   // developer probes produce wrong candidate lists: do not repair them
-  if (short_lists && (int64_t)rows.size() > std::max<int64_t>(64, nq / 200)) {
-    g_knn_stats[2] = (double)rows.size();
-    return KNN_ESCALATE;
+  if (short_lists && rows.size() > 64) {
+    // repair row by row, or search again with the long lists?  A fallback row streams the data k times (measured: ~5 TB/s);
+    // the repeat costs about four tile-kernel times (fp32-input filter, longer lists)
+    float ms_first = 0;
+    GLX_HIP(hipEventElapsedTime(&ms_first, b.e0, b.e1));
+    const double ms_rows = (double)rows.size() * k * ((double)n * d * 8.0 / 5e9);
+    if (ms_rows > 4.0 * ms_first) {
+      g_knn_stats[2] = (double)rows.size();
+      return KNN_ESCALATE;
+    }
   }
   if (!rows.empty()) {
     GLX_HIP(hipMemcpyAsync(b.rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
