@@ -268,13 +268,14 @@ struct AsmBufs {
   unsigned short* rpos = nullptr;
   double *dist = nullptr, *given = nullptr, *w = nullptr, *rw = nullptr, *val = nullptr, *sval = nullptr;
   int *rcnt = nullptr, *cursor = nullptr, *rsrc = nullptr, *rowcnt = nullptr, *col = nullptr, *flag = nullptr, *hub_cnt = nullptr;
+  glx_work* work = nullptr;      // the device's cached stream
   hipStream_t stream = nullptr;
   ~AsmBufs() {
     if (stream) hipStreamSynchronize(stream);   // pooled blocks are reused at once
     glx_pool_free(ind); glx_pool_free(roff); glx_pool_free(rowptr); glx_pool_free(dist); glx_pool_free(given); glx_pool_free(w); glx_pool_free(rw); glx_pool_free(val);
     glx_pool_free(rcnt); glx_pool_free(cursor); glx_pool_free(rsrc); glx_pool_free(rowcnt); glx_pool_free(col); glx_pool_free(flag);
     glx_pool_free(hub_row); glx_pool_free(hub_off); glx_pool_free(skey); glx_pool_free(sval); glx_pool_free(hub_cnt); glx_pool_free(rpos);
-    if (stream) hipStreamDestroy(stream);
+    glx_work_release(work);
   }
 };
 
@@ -293,7 +294,11 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
   *nnz_out = 0;
   GLX_HIP(hipSetDevice(device));
   AsmBufs b;
-  GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+  {
+    int rcw = glx_work_acquire(device, &b.work);
+    if (rcw) return rcw;
+  }
+  b.stream = b.work->stream;
   hipStream_t st = b.stream;
   const int64_t ne = n * k;
   GLX_POOL(glx_pool_alloc((void**)&b.ind, (size_t)n * kk * 8));

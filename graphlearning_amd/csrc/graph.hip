@@ -63,6 +63,73 @@ static size_t pool_class(size_t bytes) {
   return c;
 }
 
+namespace {
+struct WorkCache {
+  std::mutex mu;
+  std::map<int, glx_work*> sets;     // device -> cached set
+  std::map<int, bool> busy;
+};
+WorkCache& work_cache() {
+  static WorkCache* w = new WorkCache;   // never destroyed: HIP objects must not be torn down after the runtime at exit
+  return *w;
+}
+int work_create(int device, glx_work** out) {
+  glx_work* w = new glx_work;
+  w->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+  for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&w->ev[i]);
+  if (e != hipSuccess) {
+    glx_set_error("glx_work_acquire: %s", hipGetErrorString(e));
+    for (int i = 0; i < 4; ++i)
+      if (w->ev[i]) hipEventDestroy(w->ev[i]);
+    if (w->stream) hipStreamDestroy(w->stream);
+    delete w;
+    return GLX_EHIP;
+  }
+  *out = w;
+  return GLX_OK;
+}
+}  // namespace
+
+int glx_work_acquire(int device, glx_work** out) {
+  WorkCache& wc = work_cache();
+  {
+    std::lock_guard<std::mutex> lk(wc.mu);
+    auto it = wc.sets.find(device);
+    if (it != wc.sets.end() && !wc.busy[device]) {
+      wc.busy[device] = true;
+      *out = it->second;
+      return GLX_OK;
+    }
+    if (it != wc.sets.end()) {          // the cached set is in use: a temporary one for this caller
+      return work_create(device, out);
+    }
+  }
+  int rc = work_create(device, out);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(wc.mu);
+  if (wc.sets.find(device) == wc.sets.end()) {
+    (*out)->cached = true;
+    wc.sets[device] = *out;
+    wc.busy[device] = true;
+  }
+  return GLX_OK;
+}
+
+void glx_work_release(glx_work* w) {
+  if (!w) return;
+  if (w->cached) {
+    WorkCache& wc = work_cache();
+    std::lock_guard<std::mutex> lk(wc.mu);
+    wc.busy[w->device] = false;
+    return;
+  }
+  for (int i = 0; i < 4; ++i)
+    if (w->ev[i]) hipEventDestroy(w->ev[i]);
+  if (w->stream) hipStreamDestroy(w->stream);
+  delete w;
+}
+
 int glx_pool_alloc(void** out, size_t bytes) {
   int dev = 0;
   GLX_HIP(hipGetDevice(&dev));

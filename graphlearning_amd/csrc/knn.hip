@@ -12,6 +12,7 @@
 //      exceeds the exact k-th distance by twice a bound on the fp32 error;
 //   3. fallback -- rows that fail the check are redone by an exact fp64 scan.
 #include "glx_internal.h"
+#include <chrono>
 #define GLX_POOL(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 #include <algorithm>
 #include <cmath>
@@ -730,6 +731,7 @@ struct KnnBufs {
   int *cand_i = nullptr, *flags = nullptr, *rows = nullptr, *fb_li = nullptr, *fb_pi = nullptr;
   double *fb_ld = nullptr, *fb_pd = nullptr;
   int64_t* ind = nullptr;
+  glx_work* work = nullptr;           // the device's cached stream + events
   hipStream_t stream = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
   ~KnnBufs() {
@@ -737,11 +739,7 @@ struct KnnBufs {
     glx_pool_free(Xb); glx_pool_free(nrm); glx_pool_free(part);
     glx_pool_free(X); glx_pool_free(mean); glx_pool_free(dist); glx_pool_free(Rf); glx_pool_free(Qf); glx_pool_free(qnorm); glx_pool_free(cand_d);
     glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_li); glx_pool_free(fb_pi); glx_pool_free(fb_ld); glx_pool_free(fb_pd);
-    if (e0) hipEventDestroy(e0);
-    if (e1) hipEventDestroy(e1);
-    if (e2) hipEventDestroy(e2);
-    if (e3) hipEventDestroy(e3);
-    if (stream) hipStreamDestroy(stream);
+    glx_work_release(work);
   }
 };
 
@@ -858,6 +856,11 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   GLX_CHECK(d <= 16382, GLX_EUNSUPPORTED, "glx_knn_bruteforce: d=%d above the supported 16382", d);
   const int64_t nq = q1 - q0;
   if (nq == 0) return GLX_OK;
+  const bool timing = getenv("GLX_TIMING") != nullptr;
+  const auto t_host0 = std::chrono::steady_clock::now();
+  auto stamp = [&](const char* what) {
+    if (timing) fprintf(stderr, "[glx] knn: %-28s %.2f ms since the call\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count());
+  };
   GLX_HIP(hipSetDevice(device));
   // d + 2 <= 132: the query's features stay in registers; above that the feature dimension is blocked
   int KP = k <= 12 ? 16 : (k <= 28 ? 32 : 64);
@@ -905,15 +908,18 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   while (M < ncand) M *= 2;
 
   KnnBufs b;
-  GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+  {
+    int rcw = glx_work_acquire(device, &b.work);
+    if (rcw) return rcw;
+  }
+  b.stream = b.work->stream;
+  b.e0 = b.work->ev[0]; b.e1 = b.work->ev[1]; b.e2 = b.work->ev[2]; b.e3 = b.work->ev[3];
   hipStream_t st = b.stream;
-  GLX_HIP(hipEventCreate(&b.e0));
-  GLX_HIP(hipEventCreate(&b.e1));
-  GLX_HIP(hipEventCreate(&b.e2));
-  GLX_HIP(hipEventCreate(&b.e3));
   GLX_POOL(glx_pool_alloc((void**)&b.X, (size_t)n * d * 8));
   GLX_POOL(glx_pool_alloc((void**)&b.mean, d * 8));
+  stamp("stream, events, buffers");
   GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyHostToDevice, st));
+  stamp("X enqueued");
   // centring in fp64 (distances are translation invariant; small norms keep the filter sharp): per-block partials, fixed-order host sums
   const int64_t nb_sum = (n + CENTRE_ROWS - 1) / CENTRE_ROWS, nb_max = (n + 255) / 256;
   GLX_POOL(glx_pool_alloc((void**)&b.part, (size_t)std::max<int64_t>(nb_sum * d, nb_max) * 8));
@@ -948,6 +954,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   GLX_POOL(glx_pool_alloc((void**)&b.rows, (size_t)nq * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.ind, (size_t)nq * k * 8));
   GLX_POOL(glx_pool_alloc((void**)&b.dist, (size_t)nq * k * 8));
+  stamp("centred, norms bounded");
   GLX_HIP(hipEventRecord(b.e0, st));
   int rc;
   if (use_bf16) {
@@ -994,6 +1001,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   std::vector<int> flags(nq);
   GLX_HIP(hipMemcpyAsync(flags.data(), b.flags, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
+  stamp("tile + re-rank done, flags on the host");
   std::vector<int> rows;
   for (int64_t i = 0; i < nq; ++i)
     if (flags[i]) rows.push_back((int)i);
@@ -1033,6 +1041,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   GLX_HIP(hipMemcpyAsync(ind_out, b.ind, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipMemcpyAsync(dist_out, b.dist, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
+  stamp("results on the host");
   float ms_tile = 0, ms_rr = 0, ms_fb = 0;
   GLX_HIP(hipEventElapsedTime(&ms_tile, b.e0, b.e1));
   GLX_HIP(hipEventElapsedTime(&ms_rr, b.e1, b.e2));
