@@ -119,6 +119,8 @@ _SIGNATURES = {
     'glx_knn_stats': [_f64p],
     'glx_knn_to_csr': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                        C.POINTER(_vp), _i64p, C.c_int],
+    'glx_host_row_sums': [C.c_int64, _vp, _vp, _vp],
+    'glx_host_reverse_scale_rows': [C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp],
     'glx_knn_to_csr_into': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, _i64p, C.c_int],
 }
 _SPECIAL = {'glx_last_error': ([], C.c_char_p), 'glx_free': ([_vp], None)}
@@ -632,6 +634,22 @@ def lp_iterate(uu, ul, nbr, row, W, ind, val, p, T, tol, device=None):
     check(load().glx_lp_iterate(_ptr(uu), _ptr(ul), _ptr(nbr), _ptr(row), _ptr(W), _ptr(ind), _ptr(val), float(p), int(T), float(tol),
                                 len(uu), len(W), len(ind), C.byref(it), _dev(device)), 'glx_lp_iterate')
     return it.value
+
+
+def host_row_sums(W):
+    """W * ones for a CSR matrix with int32 indices (scipy's csr_matvec order), by the library's host loop."""
+    out = np.empty(W.shape[0], dtype=np.float64)
+    check(load().glx_host_row_sums(W.shape[0], _ptr(W.indptr), _ptr(W.data), _ptr(out)), 'glx_host_row_sums')
+    return out
+
+
+def host_reverse_scale_rows(W, scale):
+    """(indices, data) of the matrix whose row i is row i of W times scale[i] with the entries in reverse order."""
+    col = np.empty(W.nnz, dtype=np.int32)
+    val = np.empty(W.nnz, dtype=np.float64)
+    check(load().glx_host_reverse_scale_rows(W.shape[0], _ptr(W.indptr), _ptr(W.indices), _ptr(W.data), _ptr(scale), _ptr(col), _ptr(val)),
+          'glx_host_reverse_scale_rows')
+    return col, val
 
 
 def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None):

@@ -92,14 +92,12 @@ void glx_cg_ws_destroy(void* ws);
 int glx_pool_alloc(void** out, size_t bytes);
 void glx_pool_free(void* p);
 
-// a non-blocking stream and four events per device, kept between calls (graph.hip): creating them costs more than a
-// millisecond, as much as the kNN search of 70 000 points itself.  One caller at a time holds the cached set; a second
-// concurrent caller on the same device gets a temporary one.
+// a non-blocking stream and four events, handed out from a per-device list of idle sets and returned to it (graph.hip):
+// creating and destroying them costs milliseconds -- as much as the kNN search of 70 000 points itself
 struct glx_work {
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int device = 0;
-  bool cached = false;
 };
 int glx_work_acquire(int device, glx_work** out);
 void glx_work_release(glx_work* w);

@@ -66,28 +66,17 @@ static size_t pool_class(size_t bytes) {
 namespace {
 struct WorkCache {
   std::mutex mu;
-  std::map<int, glx_work*> sets;     // device -> cached set
-  std::map<int, bool> busy;
+  std::map<int, std::vector<glx_work*>> idle;     // device -> sets nobody holds
 };
 WorkCache& work_cache() {
   static WorkCache* w = new WorkCache;   // never destroyed: HIP objects must not be torn down after the runtime at exit
   return *w;
 }
-int work_create(int device, glx_work** out) {
-  glx_work* w = new glx_work;
-  w->device = device;
-  hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
-  for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&w->ev[i]);
-  if (e != hipSuccess) {
-    glx_set_error("glx_work_acquire: %s", hipGetErrorString(e));
-    for (int i = 0; i < 4; ++i)
-      if (w->ev[i]) hipEventDestroy(w->ev[i]);
-    if (w->stream) hipStreamDestroy(w->stream);
-    delete w;
-    return GLX_EHIP;
-  }
-  *out = w;
-  return GLX_OK;
+void work_destroy(glx_work* w) {
+  for (int i = 0; i < 4; ++i)
+    if (w->ev[i]) hipEventDestroy(w->ev[i]);
+  if (w->stream) hipStreamDestroy(w->stream);
+  delete w;
 }
 }  // namespace
 
@@ -95,39 +84,39 @@ int glx_work_acquire(int device, glx_work** out) {
   WorkCache& wc = work_cache();
   {
     std::lock_guard<std::mutex> lk(wc.mu);
-    auto it = wc.sets.find(device);
-    if (it != wc.sets.end() && !wc.busy[device]) {
-      wc.busy[device] = true;
-      *out = it->second;
+    auto& v = wc.idle[device];
+    if (!v.empty()) {
+      *out = v.back();
+      v.pop_back();
       return GLX_OK;
     }
-    if (it != wc.sets.end()) {          // the cached set is in use: a temporary one for this caller
-      return work_create(device, out);
-    }
   }
-  int rc = work_create(device, out);
-  if (rc) return rc;
-  std::lock_guard<std::mutex> lk(wc.mu);
-  if (wc.sets.find(device) == wc.sets.end()) {
-    (*out)->cached = true;
-    wc.sets[device] = *out;
-    wc.busy[device] = true;
+  glx_work* w = new glx_work;
+  w->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+  for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&w->ev[i]);
+  if (e != hipSuccess) {
+    glx_set_error("glx_work_acquire: %s", hipGetErrorString(e));
+    work_destroy(w);
+    return GLX_EHIP;
   }
+  *out = w;
   return GLX_OK;
 }
 
+// the holder has synchronised the stream (nothing of its work is left on it)
 void glx_work_release(glx_work* w) {
   if (!w) return;
-  if (w->cached) {
-    WorkCache& wc = work_cache();
+  WorkCache& wc = work_cache();
+  {
     std::lock_guard<std::mutex> lk(wc.mu);
-    wc.busy[w->device] = false;
-    return;
+    auto& v = wc.idle[w->device];
+    if (v.size() < 8) {
+      v.push_back(w);
+      return;
+    }
   }
-  for (int i = 0; i < 4; ++i)
-    if (w->ev[i]) hipEventDestroy(w->ev[i]);
-  if (w->stream) hipStreamDestroy(w->stream);
-  delete w;
+  work_destroy(w);
 }
 
 int glx_pool_alloc(void** out, size_t bytes) {
@@ -383,6 +372,47 @@ int glx_graph_ensure_order(glx_graph* g) {
   GLX_HIP(hipMalloc(&g->d_inv, n * 4));
   GLX_HIP(hipMemcpy(g->d_perm, g->h_perm.data(), n * 4, hipMemcpyHostToDevice));
   GLX_HIP(hipMemcpy(g->d_inv, g->h_inv.data(), n * 4, hipMemcpyHostToDevice));
+  return GLX_OK;
+}
+
+// Host helper of ssl.poisson's operator set-up for a symmetric W: row i of P = D^-1 W^T is row i of W scaled by
+// scale[i] = 1/deg_i, with the entries in REVERSE order (the order scipy's csr_matmat leaves them in, which the sweep's
+// bit-exactness depends on); deg_out[i] = the row sum in stored order from 0.0 (scipy's csr_matvec with a vector of ones).
+// Plain loops over the CSR arrays: the numpy formulation of the same thing cost 8 ms at 70 000 vertices.
+extern "C" int glx_host_row_sums(int64_t n, const int32_t* rowptr, const double* val, double* sum_out) {
+#pragma clang fp contract(off)
+  GLX_CHECK(rowptr && val && sum_out, GLX_EINVAL, "glx_host_row_sums: null argument");
+  for (int64_t i = 0; i < n; ++i) {
+    double s = 0.0;
+    for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) s = s + val[e] * 1.0;
+    sum_out[i] = s;
+  }
+  return GLX_OK;
+}
+
+extern "C" int glx_host_reverse_scale_rows(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val, const double* scale,
+                                           int32_t* col_out, double* val_out) {
+#pragma clang fp contract(off)
+  GLX_CHECK(rowptr && col && val && scale && col_out && val_out, GLX_EINVAL, "glx_host_reverse_scale_rows: null argument");
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(8, n / 16384));
+  auto work = [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; ++i) {
+      const int64_t a = rowptr[i], b = rowptr[i + 1];
+      const double sc = scale[i];
+      for (int64_t e = a; e < b; ++e) {
+        const int64_t src = a + (b - 1 - e);
+        col_out[e] = col[src];
+        val_out[e] = sc * val[src];
+      }
+    }
+  };
+  if (nt == 1) {
+    work(0, n);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+    for (auto& x : th) x.join();
+  }
   return GLX_OK;
 }
 

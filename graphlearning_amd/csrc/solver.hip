@@ -28,6 +28,7 @@ struct glx_sweep {
   unsigned long long* err = nullptr;        // [(max_iter+1) * ERR_SHARDS]
   unsigned long long* h_err = nullptr;      // pinned mirror
   void* dense = nullptr;                    // staging (n_cols, C)
+  glx_work* work = nullptr;                // stream + events of this sweep, from the per-device list of idle sets
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   glx_projector* proj = nullptr;            // label decision on the device-resident state (glx_sweep_project)
@@ -70,9 +71,7 @@ extern "C" int glx_sweep_destroy(glx_sweep* s) {
   hipFree(s->prev_row);
   hipFree(s->rows_stage);
   glx_projector_destroy(s->proj);
-  if (s->ev0) hipEventDestroy(s->ev0);
-  if (s->ev1) hipEventDestroy(s->ev1);
-  if (s->stream) hipStreamDestroy(s->stream);
+  glx_work_release(s->work);      // (the stream was synchronised at the top)
   delete s;
   return GLX_OK;
 }
@@ -97,9 +96,11 @@ extern "C" int glx_sweep_create(glx_graph* P, int C, int min_iter, int max_iter,
   rc = glx_graph_plan(P, s->L.G, &s->plan);
   if (rc) { delete s; return rc; }
 #define SW_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { glx_set_error("%s -> %s", #call, hipGetErrorString(e_)); glx_sweep_destroy(s); return GLX_EHIP; } } while (0)
-  SW_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  SW_HIP(hipEventCreate(&s->ev0));
-  SW_HIP(hipEventCreate(&s->ev1));
+  rc = glx_work_acquire(P->device, &s->work);
+  if (rc) { glx_sweep_destroy(s); return rc; }
+  s->stream = s->work->stream;
+  s->ev0 = s->work->ev[0];
+  s->ev1 = s->work->ev[1];
   const size_t rb = std::max<size_t>(rec_bytes(s, s->n_cols), 64);
   SW_HIP(hipMalloc(&s->buf[0], rb));
   SW_HIP(hipMalloc(&s->buf[1], rb));

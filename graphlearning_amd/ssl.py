@@ -261,6 +261,16 @@ def _poisson_operator_symmetric(W):
     it builds is walked from the last insertion); the same arrays are written down directly: row i = (dinv_i * w_ij) for j
     descending.  Identical to the scipy expressions entry for entry (tests/test_host_logic.py)."""
     n = W.shape[0]
+    plain = (W.indptr.dtype == np.int32 and W.indices.dtype == np.int32 and W.data.dtype == np.float64
+             and W.data.flags.c_contiguous and W.indices.flags.c_contiguous and W.indptr.flags.c_contiguous)
+    if plain and _hip.load(required=False) is not None:
+        # the same arrays by plain loops in the library (host code): the numpy formulation below costs 8 ms at 70 000 vertices
+        deg = _hip.host_row_sums(W)
+        dinv = deg ** (-1)
+        indices, data = _hip.host_reverse_scale_rows(W, dinv)
+        P = sparse.csr_matrix((data, indices, W.indptr.copy()), shape=(n, n))
+        P.has_sorted_indices = False
+        return P, deg, dinv
     deg = W * np.ones(n)                                   # graph.degree_vector (W - spdiags(diag) == W: no diagonal entries)
     dinv = deg ** (-1)                                     # graph.degree_matrix(p=-1): d ** p
     indptr = W.indptr

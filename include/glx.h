@@ -50,6 +50,13 @@ int glx_device_count(int* n);
 int glx_set_device(int device);
 int glx_device_synchronize(void);
 void glx_free(void* p);
+/* Host helpers of ssl.poisson's operator set-up (graphlearning/ssl.py:634-635, 642) for a W that is symmetric bit for bit:
+ * row sums in stored order (= scipy's W * ones), and the rows of P = D^-1 W^T written down without a transpose -- row i of W
+ * scaled by scale[i] with its entries in reverse order, the arrays scipy's `D * W.transpose()` yields.  No device involved. */
+int glx_host_row_sums(int64_t n, const int32_t* rowptr, const double* val, double* sum_out);
+int glx_host_reverse_scale_rows(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val,
+                                const double* scale, int32_t* col_out, double* val_out);
+
 /* page-locked host memory for result arrays (a D2H copy into pageable memory is staged and several times slower;
  * the Python boundary recycles these blocks as the backing store of the numpy arrays it returns) */
 int glx_host_alloc(size_t bytes, void** out);
