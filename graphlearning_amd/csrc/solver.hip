@@ -56,16 +56,16 @@ extern "C" int glx_sweep_destroy(glx_sweep* s) {
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->head_exec) hipGraphExecDestroy(s->head_exec);
   for (auto& kv : s->iter_exec) hipGraphExecDestroy(kv.second);
-  hipFree(s->buf[0]);
-  hipFree(s->buf[1]);
-  hipFree(s->bias);
-  hipFree(s->slot_has_bias);
-  hipFree(s->deg);
-  hipFree(s->vinf);
-  hipFree(s->w0);
-  hipFree(s->err);
+  glx_pool_free(s->buf[0]);
+  glx_pool_free(s->buf[1]);
+  glx_pool_free(s->bias);
+  glx_pool_free(s->slot_has_bias);
+  glx_pool_free(s->deg);
+  glx_pool_free(s->vinf);
+  glx_pool_free(s->w0);
+  glx_pool_free(s->err);
   if (s->h_err) hipHostFree(s->h_err);
-  hipFree(s->dense);
+  glx_pool_free(s->dense);
   hipFree(s->row_slot);
   hipFree(s->prev_rec);
   hipFree(s->prev_row);
@@ -95,6 +95,8 @@ extern "C" int glx_sweep_create(glx_graph* P, int C, int min_iter, int max_iter,
   if (rc) { delete s; return rc; }
   rc = glx_graph_plan(P, s->L.G, &s->plan);
   if (rc) { delete s; return rc; }
+// (work buffers from the size-class pool of graph.hip: a dozen hipMalloc / hipFree pairs per sweep object cost milliseconds)
+#define SW_POOL(call) do { int rc_ = (call); if (rc_) { glx_sweep_destroy(s); return rc_; } } while (0)
 #define SW_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { glx_set_error("%s -> %s", #call, hipGetErrorString(e_)); glx_sweep_destroy(s); return GLX_EHIP; } } while (0)
   rc = glx_work_acquire(P->device, &s->work);
   if (rc) { glx_sweep_destroy(s); return rc; }
@@ -102,22 +104,22 @@ extern "C" int glx_sweep_create(glx_graph* P, int C, int min_iter, int max_iter,
   s->ev0 = s->work->ev[0];
   s->ev1 = s->work->ev[1];
   const size_t rb = std::max<size_t>(rec_bytes(s, s->n_cols), 64);
-  SW_HIP(hipMalloc(&s->buf[0], rb));
-  SW_HIP(hipMalloc(&s->buf[1], rb));
+  SW_POOL(glx_pool_alloc((void**)&s->buf[0], rb));
+  SW_POOL(glx_pool_alloc((void**)&s->buf[1], rb));
   // (on the sweep's own stream: it is non-blocking, so a null-stream memset -- asynchronous to the host --
   // would not be ordered against the first pack / upload and could land after it)
   SW_HIP(hipMemsetAsync(s->buf[0], 0, rb, s->stream));
   SW_HIP(hipMemsetAsync(s->buf[1], 0, rb, s->stream));
-  SW_HIP(hipMalloc(&s->bias, std::max<size_t>(rec_bytes(s, s->n_rows), 64)));
+  SW_POOL(glx_pool_alloc((void**)&s->bias, std::max<size_t>(rec_bytes(s, s->n_rows), 64)));
   SW_HIP(hipMemsetAsync(s->bias, 0, std::max<size_t>(rec_bytes(s, s->n_rows), 64), s->stream));
-  SW_HIP(hipMalloc(&s->slot_has_bias, std::max<size_t>((size_t)s->plan->nslices * s->plan->R, 64)));
-  SW_HIP(hipMalloc(&s->dense, std::max<size_t>((size_t)s->n_cols * C * s->L.esize, 64)));
+  SW_POOL(glx_pool_alloc((void**)&s->slot_has_bias, std::max<size_t>((size_t)s->plan->nslices * s->plan->R, 64)));
+  SW_POOL(glx_pool_alloc((void**)&s->dense, std::max<size_t>((size_t)s->n_cols * C * s->L.esize, 64)));
   if (s->has_w) {
-    SW_HIP(hipMalloc(&s->deg, std::max<size_t>(s->n_rows * 8, 64)));
-    SW_HIP(hipMalloc(&s->vinf, std::max<size_t>(s->n_rows * 8, 64)));
-    SW_HIP(hipMalloc(&s->w0, std::max<size_t>(s->n_cols * 8, 64)));
+    SW_POOL(glx_pool_alloc((void**)&s->deg, std::max<size_t>(s->n_rows * 8, 64)));
+    SW_POOL(glx_pool_alloc((void**)&s->vinf, std::max<size_t>(s->n_rows * 8, 64)));
+    SW_POOL(glx_pool_alloc((void**)&s->w0, std::max<size_t>(s->n_cols * 8, 64)));
     const size_t eb = (size_t)(max_iter + 1) * ERR_SHARDS * 8;
-    SW_HIP(hipMalloc(&s->err, eb));
+    SW_POOL(glx_pool_alloc((void**)&s->err, eb));
     SW_HIP(hipHostMalloc((void**)&s->h_err, eb, hipHostMallocDefault));
   }
 #undef SW_HIP
