@@ -1,24 +1,26 @@
-"""Developer probe: device-memory growth over repeated fits / graph builds (should be flat after warm-up)."""
-import numpy as np, sys, os, gc
-import torch                     # first: one HIP runtime for torch's mem_get_info and libglx
+"""Developer probe: device and host memory over repeated graph builds and fits (new graph, new models every round)."""
+import os, sys, gc, resource
+import numpy as np
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import graphlearning_amd as gl
 rng = np.random.default_rng(0)
-labels = rng.integers(0, 6, 8000)
-X = (rng.normal(size=(6, 12)) * 2.0)[labels] + rng.normal(size=(8000, 12))
+lab = rng.integers(0, 10, size=40000)
+C = rng.normal(size=(10, 16)) * 2.5
+
+
 def used():
-    torch.cuda.synchronize(); free, total = torch.cuda.mem_get_info(); return (total - free) / 2**20
-base = None
-for rep in range(6):
-    for _ in range(10):
-        W = gl.weightmatrix.knn(X, 10)
-        ti = gl.trainsets.generate(labels, rate=2, seed=rep)
-        for m in (gl.ssl.poisson(W), gl.ssl.poisson(W, solver='gradient_descent'), gl.ssl.laplace(W), gl.ssl.laplace(W, reweighting='poisson'),
-                  gl.ssl.randomwalk(W), gl.ssl.poisson_mbo(W, gl.utils.class_priors(labels), solver='gradient_descent')):
-            m.fit_predict(ti, labels[ti])
-        G = gl.graph(W); G.page_rank(); G.plaplace(ti, labels[ti].astype(float), 4, fast=False, max_num_it=200)
-        del W, G, m
+    free, total = torch.cuda.mem_get_info()
+    return (total - free) / 2**20, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024
+
+
+for r in range(41):
+    X = C[lab] + rng.normal(size=(40000, 16))
+    W = gl.weightmatrix.knn(X, 10)
+    ti = gl.trainsets.generate(lab, rate=2, seed=r)
+    for model in (gl.ssl.poisson(W, solver='gradient_descent'), gl.ssl.poisson(W), gl.ssl.laplace(W), gl.ssl.poisson_mbo(W, gl.utils.class_priors(lab), solver='gradient_descent', T=3)):
+        model.fit_predict(ti, lab[ti])
+    del model, W
     gc.collect()
-    u = used()
-    base = u if base is None else base
-    print('round %d: %.1f MiB in use (+%.1f since round 0)' % (rep, u, u - base), flush=True)
+    if r % 10 == 0:
+        print('round %2d: device memory in use %.0f MiB, host peak RSS %.0f MiB' % ((r,) + used()), flush=True)

@@ -369,3 +369,32 @@ def test_disagreeing_stop_iteration_reruns_exactly_that_many_sweeps(gl, golden, 
         else:
             assert np.array_equal(u, u_ref)
         assert np.array_equal(m.predict(), np.argmax(u_ref, axis=1))
+
+
+# ---- repeated builds and fits release what they take -----------------------------------------------------------------
+def test_no_device_memory_growth_over_repeated_builds_and_fits(gl):
+    """New graph, new models, every learner, a dozen rounds: what the pools cache after the first rounds is all that stays
+    on the device (work-buffer pool, page-locked result pool, the per-device list of idle streams)."""
+    import gc
+    import torch
+    rng = np.random.default_rng(0)
+    lab = rng.integers(0, 6, size=8000)
+    lab[:6] = np.arange(6)
+    centres = rng.normal(size=(6, 12)) * 2.5
+
+    def in_use():
+        free, total = torch.cuda.mem_get_info()
+        return total - free
+
+    marks = []
+    for r in range(12):
+        X = centres[lab] + rng.normal(size=(8000, 12))
+        W = gl.weightmatrix.knn(X, 9)
+        ti = gl.trainsets.generate(lab, rate=2, seed=r)
+        for model in (gl.ssl.poisson(W, solver='gradient_descent'), gl.ssl.poisson(W), gl.ssl.laplace(W),
+                      gl.ssl.poisson_mbo(W, gl.utils.class_priors(lab), solver='gradient_descent', T=2), gl.ssl.randomwalk(W)):
+            model.fit_predict(ti, lab[ti])
+        del model, W
+        gc.collect()
+        marks.append(in_use())
+    assert max(marks[4:]) - marks[3] <= 8 << 20, [m >> 20 for m in marks]
