@@ -376,15 +376,17 @@ def test_no_device_memory_growth_over_repeated_builds_and_fits(gl):
     """New graph, new models, every learner, a dozen rounds: what the pools cache after the first rounds is all that stays
     on the device (work-buffer pool, page-locked result pool, the per-device list of idle streams)."""
     import gc
-    import torch
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')                     # the runtime libglx is linked against (already loaded)
     rng = np.random.default_rng(0)
     lab = rng.integers(0, 6, size=8000)
     lab[:6] = np.arange(6)
     centres = rng.normal(size=(6, 12)) * 2.5
 
     def in_use():
-        free, total = torch.cuda.mem_get_info()
-        return total - free
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return total.value - free.value
 
     marks = []
     for r in range(12):
