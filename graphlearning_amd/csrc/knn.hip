@@ -267,6 +267,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef KNN_GROUP_GUARD
 #define KNN_GROUP_GUARD 1          // measured: 438 -> 394 ms
 #endif
+#ifndef KNN_REGLISTS
+#define KNN_REGLISTS 1              // 8-entry lists live in registers (LDS then holds tile + append slots only: a fourth workgroup per CU)
+#endif
 static const int KNN_PAD_ROWS = 64;   // spare rows behind Xb / nrm (>= the widest ref tile): the staging loads of the last tile need no predicates
 #ifndef KNN_COUNT
 #define KNN_COUNT 0               // developer probe: event counters of the list maintenance (printed to stderr)
@@ -286,14 +289,6 @@ __device__ unsigned long long g_knn_cnt[16];
 #endif
 #ifndef KNN_ABLATE
 #define KNN_ABLATE 0              // developer probes (wrong results): 1 no list maintenance, 2 no barrier per tile, 4 no staging loads
-#endif
-#ifndef KNN_WAVES
-#define KNN_WAVES 0
-#endif
-#if KNN_WAVES
-#define KNN_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(KNN_WAVES, 4)))   // register budget 512 / KNN_WAVES: the prefetched tile must not spill
-#else
-#define KNN_WAVES_ATTR
 #endif
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rn(float x) {
@@ -330,7 +325,7 @@ __global__ void knn_prep_bf16_kernel(const double* __restrict__ X, const double*
 // NKB blocks of 16 features (kpad = 16 NKB <= 128); refs are the A operand (LDS), queries the B operand (registers: lane =
 // query column j, k-half h); list handling as in knn_tile_kernel.
 template <int NKB, int KP, int NSUB>
-__global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const float* __restrict__ nrm, int64_t n,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLISTS && KP == 8 && NKB == 4) ? 4 : 1, 4))) void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const float* __restrict__ nrm, int64_t n,
                                                             int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d,
                                                             int* __restrict__ cand_i) {
   constexpr int KPAD = 16 * NKB;
@@ -342,8 +337,14 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
   extern __shared__ __attribute__((aligned(16))) char smem_b[];
   char* tile = smem_b;                                  // [2][BR][ROWB]
   float* rn = (float*)(smem_b + 2 * BR * ROWB);         // [2][BR]
-  float* ld = rn + 2 * BR;                              // [KP + KBUF][256]
-  int* li = (int*)(ld + (KP + KBUF) * 256);
+  // 8-entry lists in registers where that buys a fourth workgroup per CU (d = 49 .. 64: 122 registers, 34 KB of LDS; measured
+  // +4 % at n = 3e5 .. 1e6; at fewer feature blocks the registers spill, at more the kernel is register-bound anyway)
+  constexpr bool REGL = KNN_REGLISTS && KP == 8 && NKB == 4;   // LDS rows [KP, KP + KBUF) are the append slots either way
+  constexpr int LROWS = REGL ? KBUF : KP + KBUF;
+  float* ld = rn + 2 * BR - (REGL ? KP * 256 : 0);      // [KP + KBUF][256] (rows [0, KP) do not exist with register lists)
+  int* li = (int*)(rn + 2 * BR + LROWS * 256) - (REGL ? KP * 256 : 0);
+  float lv[REGL ? 8 : 1];
+  int lx[REGL ? 8 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
   const int64_t qb = blockIdx.x, sp = blockIdx.y;
@@ -370,7 +371,10 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
   const float qn = nrm[qc];
   asm volatile("" ::"v"(qn));
 #pragma unroll
-  for (int p = 0; p < KP; ++p) { ld[p * 256 + tid] = INFINITY; li[p * 256 + tid] = -1; }
+  for (int p = 0; p < KP; ++p) {
+    if constexpr (REGL) { lv[p] = INFINITY; lx[p] = -1; }
+    else { ld[p * 256 + tid] = INFINITY; li[p * 256 + tid] = -1; }
+  }
   float tau = INFINITY;          // thresholds are kept WITHOUT the query's norm: values are |r|^2 - 2 q.r
 
   const int64_t ntiles = (n + BR - 1) / BR;
@@ -433,17 +437,33 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
       if (a < cnt) {
         const float v = ld[(KP + a) * 256 + tid];
         if (v < tau_own) {
-          ld[pmax * 256 + tid] = v;
-          li[pmax * 256 + tid] = li[(KP + a) * 256 + tid];
-          float m2 = ld[tid];
-          int pm = 0;
+          if constexpr (REGL) {
+            // the candidate replaces the (first) largest entry; select chains instead of indexed LDS accesses
+            const int vi = li[(KP + a) * 256 + tid];
+            bool placed = false;
+            float m2 = -INFINITY;
 #pragma unroll
-          for (int p = 1; p < KP; ++p) {
-            const float x = ld[p * 256 + tid];
-            if (x > m2) { m2 = x; pm = p; }
+            for (int p = 0; p < 8; ++p) {
+              const bool hit = !placed && lv[p] == tau_own;
+              lv[p] = hit ? v : lv[p];
+              lx[p] = hit ? vi : lx[p];
+              placed = placed || hit;
+              m2 = fmaxf(m2, lv[p]);
+            }
+            tau_own = m2;
+          } else {
+            ld[pmax * 256 + tid] = v;
+            li[pmax * 256 + tid] = li[(KP + a) * 256 + tid];
+            float m2 = ld[tid];
+            int pm = 0;
+#pragma unroll
+            for (int p = 1; p < KP; ++p) {
+              const float x = ld[p * 256 + tid];
+              if (x > m2) { m2 = x; pm = p; }
+            }
+            tau_own = m2;
+            pmax = pm;
           }
-          tau_own = m2;
-          pmax = pm;
         }
       }
     }
@@ -552,8 +572,13 @@ __global__ __launch_bounds__(256) KNN_WAVES_ATTR void knn_tile_bf16_kernel(const
     const int64_t base = ((q - q_begin) * lists + sp * 2 + h) * KP;
 #pragma unroll
     for (int p = 0; p < KP; ++p) {
-      cand_d[base + p] = ld[p * 256 + tid] + qn;       // back to squared distances (inf stays inf)
-      cand_i[base + p] = li[p * 256 + tid];
+      if constexpr (REGL) {
+        cand_d[base + p] = lv[p] + qn;                 // back to squared distances (inf stays inf)
+        cand_i[base + p] = lx[p];
+      } else {
+        cand_d[base + p] = ld[p * 256 + tid] + qn;
+        cand_i[base + p] = li[p * 256 + tid];
+      }
     }
   }
 }
@@ -785,7 +810,7 @@ static int launch_tile_bf16(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1,
   constexpr int NSUB = bf16_nsub(NKB, KP);
   constexpr int BR = 32 * NSUB;
   constexpr int ROWB = 4 * 16 * NKB + 16;
-  const size_t shm = (size_t)2 * BR * ROWB + (size_t)2 * BR * 4 + (size_t)(KP + KBUF) * 256 * 8;
+  const size_t shm = (size_t)2 * BR * ROWB + (size_t)2 * BR * 4 + (size_t)((KNN_REGLISTS && KP == 8 && NKB == 4) ? KBUF : KP + KBUF) * 256 * 8;
   GLX_CHECK(shm <= 160 * 1024, GLX_EUNSUPPORTED, "glx_knn_bruteforce: bf16 filter needs %zu bytes of LDS", shm);
   GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_bf16_kernel<NKB, KP, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)nsplit);
