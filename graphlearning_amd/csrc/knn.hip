@@ -270,6 +270,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef KNN_REGLISTS
 #define KNN_REGLISTS 1              // 8-entry lists live in registers (LDS then holds tile + append slots only: a fourth workgroup per CU)
 #endif
+#ifndef KNN_GTAU
+#define KNN_GTAU 1
+#endif
 static const int KNN_PAD_ROWS = 64;   // spare rows behind Xb / nrm (>= the widest ref tile): the staging loads of the last tile need no predicates
 #ifndef KNN_COUNT
 #define KNN_COUNT 0               // developer probe: event counters of the list maintenance (printed to stderr)
@@ -327,7 +330,7 @@ __global__ void knn_prep_bf16_kernel(const double* __restrict__ X, const double*
 template <int NKB, int KP, int NSUB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLISTS && KP == 8 && NKB == 4) ? 4 : 1, 4))) void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const float* __restrict__ nrm, int64_t n,
                                                             int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d,
-                                                            int* __restrict__ cand_i) {
+                                                            int* __restrict__ cand_i, int* __restrict__ gtau) {
   constexpr int KPAD = 16 * NKB;
   constexpr int BR = 32 * NSUB;
   constexpr int ROWB = 4 * KPAD + 16;                  // bytes per ref row in LDS: hi | lo, +16 so that 16 rows cover all 64 banks
@@ -469,6 +472,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
     }
     cnt = 0;
     tau = fminf(tau_own, __shfl_xor(tau_own, 32));   // lanes l and l^32 serve the same query (same |q|^2 offset)
+#if KNN_GTAU
+    // the query's lists of the OTHER ref ranges run in other workgroups: the smallest threshold any of them has reached is
+    // published per query (an ordered-int image of the float, atomicMin) and adopted here.  Sound for the same reason the pair's
+    // minimum is: whatever a list rejects lies above the smallest FINAL threshold of the query's lists, which is what the
+    // acceptance test of the re-rank compares with the exact k-th distance.
+    if (tau < INFINITY && q < q_end) {
+      int key = __float_as_int(tau);
+      key ^= (key >> 31) & 0x7fffffff;
+      const int old = atomicMin(&gtau[q - q_begin], key);
+      int best = min(old, key);
+      best ^= (best >> 31) & 0x7fffffff;
+      tau = fminf(tau, __int_as_float(best));
+    }
+#endif
     KNN_TOC(cy_comp, tc);
   };
   if (t0 < t1) { stage_load(t0); stage_store(0); }
@@ -477,6 +494,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
   KNN_TIC(ta);
   for (int64_t t = t0; t < t1; t += nsplit) {
     const bool has_next = t + nsplit < t1;
+#if KNN_GTAU
+    if ((((t - t0) / nsplit) & 15) == 15 && q < q_end) {
+      int best = gtau[q - q_begin];
+      best ^= (best >> 31) & 0x7fffffff;
+      tau = fminf(tau, __int_as_float(best));
+    }
+#endif
 #if !(KNN_ABLATE & 4)
     if (has_next) stage_load(t + nsplit);
 #endif
@@ -753,7 +777,7 @@ struct KnnBufs {
   double* part = nullptr;            // per-block partial column sums / maxima of the centring pass
   double *X = nullptr, *mean = nullptr, *dist = nullptr;
   float *Rf = nullptr, *Qf = nullptr, *qnorm = nullptr, *cand_d = nullptr;
-  int *cand_i = nullptr, *flags = nullptr, *rows = nullptr, *fb_li = nullptr, *fb_pi = nullptr;
+  int *cand_i = nullptr, *flags = nullptr, *rows = nullptr, *fb_li = nullptr, *fb_pi = nullptr, *gtau = nullptr;
   double *fb_ld = nullptr, *fb_pd = nullptr;
   int64_t* ind = nullptr;
   glx_work* work = nullptr;           // the device's cached stream + events
@@ -763,7 +787,7 @@ struct KnnBufs {
     if (stream) hipStreamSynchronize(stream);   // pooled blocks are reused at once: nothing may still be running on them
     glx_pool_free(Xb); glx_pool_free(nrm); glx_pool_free(part);
     glx_pool_free(X); glx_pool_free(mean); glx_pool_free(dist); glx_pool_free(Rf); glx_pool_free(Qf); glx_pool_free(qnorm); glx_pool_free(cand_d);
-    glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_li); glx_pool_free(fb_pi); glx_pool_free(fb_ld); glx_pool_free(fb_pd);
+    glx_pool_free(gtau); glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_li); glx_pool_free(fb_pi); glx_pool_free(fb_ld); glx_pool_free(fb_pd);
     glx_work_release(work);
   }
 };
@@ -815,7 +839,7 @@ static int launch_tile_bf16(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1,
   GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_bf16_kernel<NKB, KP, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)nsplit);
   hipLaunchKernelGGL((knn_tile_bf16_kernel<NKB, KP, NSUB>), grid, dim3(256), shm, st, (const unsigned short*)b.Xb, (const float*)b.nrm, n, q0, q1,
-                     nsplit, b.cand_d, b.cand_i);
+                     nsplit, b.cand_d, b.cand_i, b.gtau);
   GLX_HIP(hipGetLastError());
   return GLX_OK;
 }
@@ -976,6 +1000,8 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   GLX_POOL(glx_pool_alloc((void**)&b.cand_d, (size_t)nq * ncand * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.cand_i, (size_t)nq * ncand * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.flags, (size_t)nq * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.gtau, (size_t)nq * 4));
+  GLX_HIP(hipMemsetD32Async((hipDeviceptr_t)b.gtau, 0x7f800000, (size_t)nq, st));   // +inf: nothing published yet
   GLX_POOL(glx_pool_alloc((void**)&b.rows, (size_t)nq * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.ind, (size_t)nq * k * 8));
   GLX_POOL(glx_pool_alloc((void**)&b.dist, (size_t)nq * k * 8));
