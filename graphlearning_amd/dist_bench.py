@@ -14,7 +14,21 @@ import time
 import numpy as np
 
 
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner with C stdio when its first communicator comes up
+    (torch's and the library's alike), flushed whenever: file descriptor 1 is pointed at stderr for the life of the process and
+    the returned function writes the line to the real stdout."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(real, (line + '\n').encode())
+    return emit
+
+
 def main(args):
+    emit = _claim_stdout()
     import torch                       # first: libglx must bind to torch's HIP runtime (see dist.py)
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
@@ -166,7 +180,7 @@ def main(args):
                                       'halo_rows_per_rank': even['halo_rows'], 'owned_per_rank': even['owned'],
                                       'note': 'equal blocks of the same order: every rank imports a halo, so every sweep carries the '
                                               'RCCL exchange (the headline partition above places the cuts between the graph\'s pieces)'}
-        print(json.dumps(line))
+        emit(json.dumps(line))
     if comm is not None:
         comm.close()
     # orderly teardown: sweeps and communicator are closed above, then the group
@@ -197,6 +211,7 @@ def main_config4(args):
     10^7), d = 64, k = 10, C = 10, Poisson gradient descent with a fixed T = 200 sweeps per step, the graph built sharded
     (dist_build: every rank searches, symmetrises and plans only its own block of rows) and swept by the library-owned
     distributed sweep (glx_dist_sweep: RCCL halo exchange captured with the SpMMs)."""
+    emit = _claim_stdout()
     import torch
     import torch.distributed as dist
     import datetime
@@ -299,7 +314,7 @@ def main_config4(args):
                       'symmetrise_plan_s': t_build},
             'accuracy_percent': 100.0 * int(hit[0]) / max(int(hit[1]), 1),
         }
-        print(json.dumps(line))
+        emit(json.dumps(line))
     ds.close()
     comm.close()
     torch.cuda.synchronize()

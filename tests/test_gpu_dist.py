@@ -64,6 +64,7 @@ def test_distributed_bench_entry_one_rank(tmp_path, force_coll):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'capture unavailable' not in r.stderr, r.stderr[-2000:]
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1, r.stdout[-1500:]     # ONE JSON line on stdout (RCCL's banner goes to stderr)
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     j = json.loads(line)
     assert j['n_gpus'] == 1 and j['value'] > 0 and j['config']['sweeps_per_step'] == 50
@@ -235,6 +236,7 @@ def test_config4_bench_entry_one_rank():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', '4', '--n', '300000', '--steps', '1', '--warmup', '1'],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1, r.stdout[-1500:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert j['scaling'] == 'strong' and j['config']['n'] == 300000 and j['config']['sweeps_per_step'] == 200
     assert j['accuracy_percent'] > 99.0 and j['value'] > 0
