@@ -217,10 +217,10 @@ def traffic_child():
 
 
 def run_single(args):
-    import torch
     import graphlearning_amd as gl
     from graphlearning_amd import _hip, _build
     _hip.require_device()
+    device_sync = lambda: _hip.check(_hip.load().glx_device_synchronize(), 'glx_device_synchronize')   # no torch in the single-GPU bench
     labels = load_labels(N_PER_RANK)
     X = make_features(labels)
     gl.weightmatrix.knn(X[:4096], K_NN)            # library start-up (HIP context, code objects) is not graph-build time
@@ -253,14 +253,14 @@ def run_single(args):
         T = 0
         total = 0.0
         while total < MIN_TIMED_S or len(batches) < 5:
-            torch.cuda.synchronize()
+            device_sync()
             dev_ms = 0.0
             l0 = sweep.launches()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 T, ms = sweep.run()
                 dev_ms += ms
-            torch.cuda.synchronize()
+            device_sync()
             wall = time.perf_counter() - t0
             batches.append(dict(wall=wall, dev_ms=dev_ms, launches=sweep.launches() - l0))
             total += wall
@@ -328,10 +328,49 @@ def run_single(args):
 
 def run_distributed(args):
     from graphlearning_amd import dist_bench
-    if args.config == 4:
+    if args.dist_dry_run:
+        dist_bench.main_dry_run(args)
+    elif args.config == 4:
         dist_bench.main_config4(args)
     else:
         dist_bench.main(args)
+
+
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks here --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same
+    arguments>`, one process per GPU -- relay rank 0's ONE JSON line to stdout and return the job's exit status.  The
+    ranks themselves refuse to run when the world they find differs from --gpus (dist_bench.check_world), so a
+    mis-launched job can never report `n_gpus: 1` under a `--gpus 8` command line."""
+    import subprocess
+    n = int(args.gpus)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, GLX_BENCH_SPAWNED='1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(n, 1))))
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{') and ('"metric"' in ln or '"dry_run"' in ln)]
+    if res.returncode != 0 or not lines:
+        sys.stdout.write(res.stdout)
+        print('bench.py: the %d-rank job failed (exit status %d, %d result lines)' % (n, res.returncode, len(lines)), file=sys.stderr)
+        return res.returncode or 1
+    line = json.loads(lines[-1])
+    if int(line.get('n_gpus', -1)) != n:
+        print('bench.py: asked for %d ranks, the job reports %r' % (n, line.get('n_gpus')), file=sys.stderr)
+        return 3
+    line['launched_by'] = 'bench.py (torch.distributed.run spawned here)'
+    print(json.dumps(line))
+    return 0
 
 
 def main():
@@ -345,11 +384,17 @@ def main():
     ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 counter passes (roofline.traffic = null)')
     ap.add_argument('--no-scale', action='store_true', help='skip the n = 10^6 shard-size line')
     ap.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--dist-dry-run', action='store_true',
+                    help='start the ranks, rendezvous over gloo, count them, print one line and stop: checks the launch path without a GPU')
     args = ap.parse_args()
     if args.traffic_child:
         traffic_child()
         return
-    if args.gpus > 1 or args.config == 4 or int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('GLX_BENCH_FORCE_DIST') == '1':
+    launched = 'WORLD_SIZE' in os.environ            # torch.distributed.run (the driver's form for N > 1) or our own spawn
+    if args.gpus > 1 and not launched:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    if (args.gpus > 1 or args.config == 4 or args.dist_dry_run or int(os.environ.get('WORLD_SIZE', '1')) > 1
+            or os.environ.get('GLX_BENCH_FORCE_DIST') == '1'):
         run_distributed(args)
     else:
         run_single(args)

@@ -98,6 +98,8 @@ _SIGNATURES = {
     'glx_poisson_sweep_dist': [_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_float)],
     'glx_dist_sweep_fetch': [_vp, _vp],
     'glx_dist_sweep_stats': [_vp, _i64p],
+    'glx_dist_sweep_info': [_vp, _i64p],
+    'glx_dist_sweep_time_parts': [_vp, C.c_int, _f32p],
     'glx_dist_sweep_destroy': [_vp],
     'glx_dist_sweep_begin': [_vp],
     'glx_dist_sweep_boundary': [_vp, C.c_int],
@@ -496,10 +498,13 @@ class Comm:
         idbuf = None if uid is None else C.create_string_buffer(bytes(uid), 128)
         check(load().glx_dist_init_rank(self.nranks, self.rank, idbuf, self.device, C.byref(self._h)), 'glx_dist_init_rank')
 
-    def has_transport(self):
+    def info(self):
         info = (C.c_int32 * 4)()
         check(load().glx_dist_comm_info(self._h, info), 'glx_dist_comm_info')
-        return bool(info[3])
+        return dict(rank=int(info[0]), nranks=int(info[1]), device=int(info[2]), rccl=bool(info[3]))
+
+    def has_transport(self):
+        return self.info()['rccl']
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
@@ -565,6 +570,20 @@ class DistSweep:
         out = (C.c_int64 * 4)()
         check(load().glx_dist_sweep_stats(self._h, out), 'glx_dist_sweep_stats')
         return dict(sweeps=out[0], exchanges=out[1], graphs=out[2], exchanging=bool(out[3]))
+
+    def info(self):
+        """What the object decided (glx_dist_sweep_info): captured / eager exchanging sweeps, the self-test's verdict, ..."""
+        out = (C.c_int64 * 8)()
+        check(load().glx_dist_sweep_info(self._h, out), 'glx_dist_sweep_info')
+        cap = {1: 'captured', 0: 'eager', -1: 'undecided'}[int(out[1])]
+        return dict(exchanging=bool(out[0]), exchange=cap if out[0] else 'none', selftest={0: 'not run', 1: 'passed', 2: 'failed'}[int(out[2])],
+                    overlap=bool(out[3]), fused=bool(out[4]), scatter=bool(out[5]), send_records=int(out[6]), halo_records=int(out[7]))
+
+    def time_parts(self, reps=50):
+        """Microseconds of the rank-local pieces of one sweep, each timed alone (glx_dist_sweep_time_parts)."""
+        out = (C.c_float * 4)()
+        check(load().glx_dist_sweep_time_parts(self._h, int(reps), out), 'glx_dist_sweep_time_parts')
+        return dict(boundary_us=float(out[0]), interior_us=float(out[1]), pack_us=float(out[2]), both_us=float(out[3]))
 
     # stepwise form (transport left to the caller)
     def begin(self):

@@ -21,8 +21,11 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <array>
+#include <chrono>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include <rccl/rccl.h>
 
@@ -174,16 +177,26 @@ struct glx_dist_sweep {
   bool warmed = false;
   hipStream_t stream = nullptr, xstream = nullptr;
   hipEvent_t ev_pack = nullptr, ev_x = nullptr, ev0 = nullptr, ev1 = nullptr;
-  std::map<long, hipGraphExec_t> graphs;
+  // captured launch sequences, keyed (kind, a, b, c): kind 0 = head (a = sweeps), kind 1 = tail chunk (a = ring size, b = first
+  // buffer, c = sweeps), kind 2 = self-test.  Separate key components: no two sequences can share a key.
+  std::map<std::array<long, 4>, hipGraphExec_t> graphs;
   bool use_graph = true;
   bool overlap = true;                       // exchange on its own stream beside the interior rows (else in line on the sweep's stream)
-  bool capture_exchange = true;              // sweeps that carry an RCCL exchange may be captured into device graphs
+  int capture_exchange = 1;                  // sweeps that carry an RCCL exchange: 1 captured into device graphs, 0 enqueued eagerly,
+                                             // -1 undecided -- the first run's self-test (captured vs eager sweeps, bit for bit, all ranks) decides
+  int selftest = 0;                          // 0 not run, 1 passed (captured), 2 failed (eager)
+  bool fused = false;                        // ONE launch for all rows of a sweep (part[0] = every row), exchange after it
+  bool scatter = true;                       // the boundary SpMM stores its rows into the send buffer itself (no pack kernel)
+  int32_t *dup_ptr = nullptr, *dup_pos = nullptr;   // [rows of part 0 + 1], [n_send]: send-buffer positions of every row
+  void* st_ref = nullptr;                    // self-test: the eager result
+  unsigned int* st_diff = nullptr;           // self-test: mismatch counter (device) -- made global with an all-reduce
   bool problem_set = false;
   int cur = 0;                               // ring index of the current iterate
   int64_t sweeps_run = 0, exchanges = 0;
   double thresh = 0.0;
 };
 
+static int64_t part_lo1(const glx_dist_sweep* s) { return s->fused ? s->n_own : s->nb; }   // first row of part 1
 static size_t recb(const glx_dist_sweep* s, int64_t rows) { return std::max<size_t>((size_t)rows * s->L.ld * s->L.esize, 64); }
 static char* rec_at(void* base, const glx_dist_sweep* s, int64_t row) { return (char*)base + (size_t)row * s->L.ld * s->L.esize; }
 
@@ -205,6 +218,10 @@ extern "C" int glx_dist_sweep_destroy(glx_dist_sweep* s) {
   hipFree(s->dense);
   hipFree(s->send_idx);
   hipFree(s->sendbuf);
+  hipFree(s->dup_ptr);
+  hipFree(s->dup_pos);
+  hipFree(s->st_ref);
+  hipFree(s->st_diff);
   hipFree(s->err);
   if (s->h_err) hipHostFree(s->h_err);
   if (s->ev_pack) hipEventDestroy(s->ev_pack);
@@ -261,9 +278,18 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
     // Grouped ncclSend/ncclRecv inside a stream capture has been exercised on ONE rank only (self exchange, RCCL 2.26.6 and
     // 2.27.7); with real peers the exchanging sweeps are enqueued eagerly -- plain RCCL usage -- unless asked otherwise.
     // Sweeps without an exchange (no halo anywhere) are captured either way.
-    s->capture_exchange = comm->nranks == 1;
-    if (const char* e = getenv("GLX_DIST_CAPTURE_EXCHANGE")) s->capture_exchange = atoi(e) != 0;
-    if (!s->capture_exchange && !getenv("GLX_DIST_OVERLAP")) s->overlap = true;   // eager: two streams are safe on every runtime
+    // Round 3: with real peers the first run decides by a self-test (three captured exchanging sweeps, replayed, against three
+    // eager ones: bit for bit, on every rank, with a deadline); GLX_DIST_CAPTURE_EXCHANGE=0/1 skips the test.
+    s->capture_exchange = comm->nranks == 1 ? 1 : -1;
+    if (const char* e = getenv("GLX_DIST_CAPTURE_EXCHANGE")) s->capture_exchange = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
+    if (!s->use_graph) s->capture_exchange = 0;
+    if (s->capture_exchange == 0 && !getenv("GLX_DIST_OVERLAP")) s->overlap = true;   // eager: two streams are safe on every runtime
+    if (const char* e = getenv("GLX_DIST_PACK")) s->scatter = atoi(e) == 0;             // 1: the round-2 pack kernel between SpMM and transport
+    // one launch per sweep when the boundary is at most GLX_DIST_FUSE percent of the rows (default 0 = never: with the exchange
+    // beside the interior rows the split form hides min(interior, exchange), which one saved launch does not buy back -- measured)
+    double fuse_pct = 0.0;
+    if (const char* e = getenv("GLX_DIST_FUSE")) fuse_pct = atof(e);
+    s->fused = n_own > 0 && fuse_pct > 0.0 && (double)n_boundary <= fuse_pct * 0.01 * (double)n_own;
   }
   s->thresh = 1.0 / (double)n_global;   // `> 1/n`, ssl.py:667, n = ALL vertices
   int rc = glx_make_layout(C, state_dtype, true, &s->L);
@@ -271,7 +297,7 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
 #define DS_FAIL(code) do { glx_dist_sweep_destroy(s); return (code); } while (0)
 #define DS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { glx_set_error("%s -> %s", #call, hipGetErrorString(e_)); DS_FAIL(GLX_EHIP); } } while (0)
   // the two operators over the same local vector
-  const int64_t lo[2] = {0, n_boundary}, hi[2] = {n_boundary, n_own};
+  const int64_t lo[2] = {0, s->fused ? n_own : n_boundary}, hi[2] = {s->fused ? n_own : n_boundary, n_own};
   for (int q = 0; q < 2; ++q) {
     if (hi[q] <= lo[q]) continue;
     std::vector<int32_t> rp(hi[q] - lo[q] + 1);
@@ -315,6 +341,19 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
   DS_HIP(hipMalloc(&s->send_idx, std::max<size_t>((size_t)ns * 4, 64)));
   if (ns > 0) DS_HIP(hipMemcpy(s->send_idx, send_idx, (size_t)ns * 4, hipMemcpyHostToDevice));
   DS_HIP(hipMalloc(&s->sendbuf, recb(s, ns)));
+  {
+    // rows of part 0 -> their positions in the send buffer (a row needed by several peers has several)
+    const int64_t nr0 = hi[0];
+    std::vector<int32_t> dp(nr0 + 1, 0), dq(std::max<int64_t>(ns, 1));
+    for (int64_t q = 0; q < ns; ++q) dp[send_idx[q] + 1]++;
+    for (int64_t i = 0; i < nr0; ++i) dp[i + 1] += dp[i];
+    std::vector<int32_t> fill(dp.begin(), dp.end() - 1);
+    for (int64_t q = 0; q < ns; ++q) dq[fill[send_idx[q]]++] = (int32_t)q;
+    DS_HIP(hipMalloc(&s->dup_ptr, (size_t)(nr0 + 1) * 4));
+    DS_HIP(hipMalloc(&s->dup_pos, dq.size() * 4));
+    DS_HIP(hipMemcpy(s->dup_ptr, dp.data(), (size_t)(nr0 + 1) * 4, hipMemcpyHostToDevice));
+    DS_HIP(hipMemcpy(s->dup_pos, dq.data(), dq.size() * 4, hipMemcpyHostToDevice));
+  }
   DS_HIP(hipMalloc(&s->err, (size_t)ERR_SLOTS * ERR_SHARDS * 8));
   DS_HIP(hipMemsetAsync(s->err, 0, (size_t)ERR_SLOTS * ERR_SHARDS * 8, s->stream));
   DS_HIP(hipHostMalloc((void**)&s->h_err, (size_t)ERR_SLOTS * ERR_SHARDS * 8, hipHostMallocDefault));
@@ -342,7 +381,7 @@ extern "C" int glx_dist_sweep_set_problem(glx_dist_sweep* s, const void* Db_own,
   if (rc) return rc;
   for (int q = 0; q < 2; ++q) {
     if (!s->part[q]) continue;
-    const int64_t lo = q == 0 ? 0 : s->nb;
+    const int64_t lo = q == 0 ? 0 : part_lo1(s);
     rc = glx_bias_flags_dev(s->part[q], s->C, 1, rec_at(s->bias, s, lo), s->flags[q], s->stream);
     if (rc) return rc;
   }
@@ -371,7 +410,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict
 
 static int launch_part(glx_dist_sweep* s, int q, const void* xin, void* xout, unsigned long long* err_next) {
   if (!s->part[q]) return GLX_OK;
-  const int64_t lo = q == 0 ? 0 : s->nb;
+  const int64_t lo = q == 0 ? 0 : part_lo1(s);
   SweepArgs a;
   memset(&a, 0, sizeof(a));
   a.plan = s->plan[q];
@@ -387,6 +426,11 @@ static int launch_part(glx_dist_sweep* s, int q, const void* xin, void* xout, un
   a.vinf = s->vinf + lo;
   a.err_next = err_next;
   a.thresh = s->thresh;
+  if (q == 0 && s->scatter && s->n_send > 0) {   // boundary rows leave for the send buffer from the kernel's registers
+    a.dup_ptr = s->dup_ptr;
+    a.dup_pos = s->dup_pos;
+    a.dup_out = s->sendbuf;
+  }
   return glx_launch_spmm(a, s->stream);
 }
 
@@ -402,9 +446,9 @@ static int enqueue_pack(glx_dist_sweep* s, const void* x) {
 
 // boundary records of x -> the peers' halo regions of their x (this rank's x[n_own:] receives).  Runs on the exchange
 // stream behind the pack; the caller joins with wait_exchange().
-static int enqueue_exchange(glx_dist_sweep* s, void* x) {
+static int enqueue_exchange(glx_dist_sweep* s, void* x, bool packed = false) {
   if (!s->exchange) return GLX_OK;
-  int rc = enqueue_pack(s, x);
+  int rc = packed ? GLX_OK : enqueue_pack(s, x);   // packed: the boundary SpMM has already filled the send buffer
   if (rc) return rc;
   hipStream_t xs = s->overlap ? s->xstream : s->stream;
   if (s->overlap) {
@@ -440,7 +484,7 @@ static int wait_exchange(glx_dist_sweep* s) {
 static int enqueue_sweep(glx_dist_sweep* s, const void* xin, void* xout, unsigned long long* err_next) {
   int rc = launch_part(s, 0, xin, xout, err_next);
   if (rc) return rc;
-  rc = enqueue_exchange(s, xout);
+  rc = enqueue_exchange(s, xout, s->scatter);
   if (rc) return rc;
   rc = launch_part(s, 1, xin, xout, err_next);
   if (rc) return rc;
@@ -467,8 +511,8 @@ static int ensure_ring(glx_dist_sweep* s, int nbuf) {
 
 // run `fn` (a sequence of enqueues on s->stream / s->xstream) through a captured device graph keyed by `key`
 template <typename F>
-static int run_captured(glx_dist_sweep* s, long key, F fn) {
-  if (!s->use_graph || (s->exchange && !s->capture_exchange)) return fn();
+static int run_captured(glx_dist_sweep* s, const std::array<long, 4>& key, F fn) {
+  if (!s->use_graph || (s->exchange && s->capture_exchange != 1)) return fn();
   auto it = s->graphs.find(key);
   if (it == s->graphs.end()) {
     hipGraph_t graph;
@@ -483,6 +527,86 @@ static int run_captured(glx_dist_sweep* s, long key, F fn) {
     it = s->graphs.emplace(key, exec).first;
   }
   GLX_HIP(hipGraphLaunch(it->second, s->stream));
+  return GLX_OK;
+}
+
+
+// ---- self-test of captured exchanging sweeps -------------------------------------------------------------------
+// Grouped ncclSend / ncclRecv inside a stream capture is documented RCCL usage, but this library could only ever run it with
+// ONE rank (1-GPU test boxes).  So with real peers nothing is assumed: the first run executes three exchanging sweeps
+// eagerly, then the same three through a captured graph -- launched twice, a replay is what the measured loop does -- and
+// compares the iterates bit for bit; the verdicts are combined over the ranks (ncclAllReduce MAX of the mismatch counts)
+// and only a clean pass selects the captured path.  A capture that hangs is cut off by a deadline instead of by the job's
+// time limit (the call then fails with GLX_ERCCL and the caller can fall back to another engine).
+__global__ __launch_bounds__(256) void count_diff_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b,
+                                                         int64_t nwords, unsigned int* __restrict__ out) {
+  unsigned int d = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * 256) d += a[i] != b[i];
+  if (d) atomicAdd(out, d);
+}
+
+static int sync_with_deadline(glx_dist_sweep* s, double seconds, const char* what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    hipError_t e = hipStreamQuery(s->stream);
+    if (e == hipSuccess) return GLX_OK;
+    if (e != hipErrorNotReady) { glx_set_error("%s: %s", what, hipGetErrorString(e)); return GLX_EHIP; }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) {
+      glx_set_error("%s: no completion within %.0f s (rank %d)", what, seconds, s->comm->rank);
+      return GLX_ERCCL;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+}
+
+static int exchange_selftest(glx_dist_sweep* s) {
+  const int K = 3;
+  double deadline = 30.0;
+  if (const char* e = getenv("GLX_DIST_SELFTEST_TIMEOUT")) deadline = atof(e);
+  const size_t bytes = (size_t)s->n_loc * s->L.ld * s->L.esize;
+  if (!s->st_ref) GLX_HIP(hipMalloc(&s->st_ref, std::max<size_t>(bytes, 64)));
+  if (!s->st_diff) GLX_HIP(hipMalloc((void**)&s->st_diff, 64));
+  auto body = [&]() -> int {
+    int r2 = enqueue_reset(s, s->ring[0]);
+    for (int t = 0; t < K && !r2; ++t) r2 = enqueue_sweep(s, s->ring[t & 1], s->ring[(t & 1) ^ 1], nullptr);
+    return r2;
+  };
+  int rc = body();                                      // eager: plain RCCL usage
+  if (rc) return rc;
+  GLX_HIP(hipMemcpyAsync(s->st_ref, s->ring[K & 1], bytes, hipMemcpyDeviceToDevice, s->stream));
+  GLX_HIP(hipMemsetAsync(s->st_diff, 0, 64, s->stream));
+  rc = sync_with_deadline(s, deadline, "self-test, eager sweeps");
+  if (rc) return rc;
+  const int saved = s->capture_exchange;
+  s->capture_exchange = 1;
+  unsigned int h_diff = 0;
+  for (int pass = 0; pass < 2 && !rc; ++pass) {         // capture + launch, then a replay
+    GLX_HIP(hipMemsetAsync(s->ring[K & 1], 0xff, bytes, s->stream));   // the captured sweeps must really write it
+    rc = run_captured(s, {2L, (long)K, 0L, 0L}, body);
+    if (rc) break;
+    if (bytes > 0) {
+      hipLaunchKernelGGL(count_diff_kernel, dim3((unsigned)std::min<int64_t>(1024, (int64_t)(bytes / 8 + 255) / 256)), dim3(256), 0, s->stream,
+                         (const unsigned long long*)s->st_ref, (const unsigned long long*)s->ring[K & 1], (int64_t)(bytes / 8), s->st_diff);
+      GLX_HIP(hipGetLastError());
+    }
+    rc = sync_with_deadline(s, deadline, "self-test, captured sweeps");
+  }
+  s->capture_exchange = saved;
+  auto it = s->graphs.find({2L, (long)K, 0L, 0L});
+  if (it != s->graphs.end()) { hipGraphExecDestroy(it->second); s->graphs.erase(it); }
+  if (rc) return rc;
+  if (s->comm->comm) {                                   // one verdict for all ranks
+    RcclApi* a = rccl_api();
+    GLX_NCCL(a->AllReduce(s->st_diff, s->st_diff, 1, ncclUint32, ncclMax, s->comm->comm, s->stream));
+  }
+  GLX_HIP(hipMemcpyAsync(&h_diff, s->st_diff, 4, hipMemcpyDeviceToHost, s->stream));
+  rc = sync_with_deadline(s, deadline, "self-test, verdict");
+  if (rc) return rc;
+  s->selftest = h_diff == 0 ? 1 : 2;
+  s->capture_exchange = h_diff == 0 ? 1 : 0;
+  if (s->capture_exchange == 0) s->overlap = true;
+  hipFree(s->st_ref);
+  s->st_ref = nullptr;
   return GLX_OK;
 }
 
@@ -523,13 +647,21 @@ extern "C" int glx_poisson_sweep_dist(glx_dist_sweep* s, int min_iter, int max_i
     }
     rc = global_err(s, 0, 1);
     if (rc) return rc;
+    if (s->capture_exchange < 0) {
+      if (s->exchange && s->use_graph) {
+        rc = exchange_selftest(s);
+        if (rc) return rc;
+      } else {
+        s->capture_exchange = 1;                         // nothing to exchange: sweeps are plain launches
+      }
+    }
     s->warmed = true;
   }
   const int head = std::min(min_iter, max_iter);
   const bool head_err = head > 0 && head >= min_iter;   // the last head sweep produces v_min_iter: its error decides sweep min_iter + 1
   GLX_HIP(hipEventRecord(s->ev0, s->stream));
   // head: reset + the sweeps the stop test cannot cut short, ping-pong on ring[0] / ring[1]
-  rc = run_captured(s, 1000000L + head, [&]() -> int {
+  rc = run_captured(s, {0L, (long)head, 0L, 0L}, [&]() -> int {
     GLX_HIP(hipMemsetAsync(s->err, 0, ERR_SHARDS * 8, s->stream));
     int r2 = enqueue_reset(s, s->ring[0]);
     for (int t = 0; t < head && !r2; ++t)
@@ -553,7 +685,7 @@ extern "C" int glx_poisson_sweep_dist(glx_dist_sweep* s, int min_iter, int max_i
       if (rc) return rc;
       const int cnt = std::min(check_every, max_iter - T);
       const int cur0 = s->cur;
-      rc = run_captured(s, (long)R * 100000L + (long)cur0 * 128 + cnt, [&]() -> int {   // the ring size is part of the buffers a chunk touches
+      rc = run_captured(s, {1L, (long)R, (long)cur0, (long)cnt}, [&]() -> int {   // the ring size is part of the buffers a chunk touches
         GLX_HIP(hipMemsetAsync(s->err + ERR_SHARDS, 0, (size_t)cnt * ERR_SHARDS * 8, s->stream));
         int r2 = GLX_OK;
         for (int j = 0; j < cnt && !r2; ++j)
@@ -600,6 +732,58 @@ extern "C" int glx_dist_sweep_stats(const glx_dist_sweep* s, int64_t out[4]) {
   return GLX_OK;
 }
 
+
+// what the object decided: out[0] exchanging, [1] exchanging sweeps captured (1) / eager (0) / undecided (-1), [2] self-test
+// (0 not run, 1 passed, 2 failed), [3] exchange beside the interior rows on a second stream, [4] one launch per sweep,
+// [5] boundary rows scattered into the send buffer by the SpMM (no pack kernel), [6] records sent per sweep, [7] halo records
+extern "C" int glx_dist_sweep_info(const glx_dist_sweep* s, int64_t out[8]) {
+  GLX_CHECK(s && out, GLX_EINVAL, "glx_dist_sweep_info: null argument");
+  out[0] = s->exchange ? 1 : 0;
+  out[1] = s->capture_exchange;
+  out[2] = s->selftest;
+  out[3] = s->overlap ? 1 : 0;
+  out[4] = s->fused ? 1 : 0;
+  out[5] = s->scatter ? 1 : 0;
+  out[6] = s->n_send;
+  out[7] = s->n_halo;
+  return GLX_OK;
+}
+
+// Device time of the rank-local pieces of one sweep, each timed alone over `reps` launches (HIP events on the sweep's stream,
+// ping-pong between two state buffers, no exchange): us_out[0] boundary rows (incl. the scatter into the send buffer),
+// [1] interior rows, [2] the pack kernel (the round-2 form of [0]'s scatter), [3] boundary + interior back to back.
+// What scripts/scale_model.py builds the predicted scaling curve from.
+extern "C" int glx_dist_sweep_time_parts(glx_dist_sweep* s, int reps, float us_out[4]) {
+  GLX_CHECK(s && us_out && reps >= 1, GLX_EINVAL, "glx_dist_sweep_time_parts: bad argument");
+  GLX_CHECK(s->problem_set, GLX_EINVAL, "glx_dist_sweep_time_parts: set the problem first");
+  GLX_HIP(hipSetDevice(s->device));
+  auto timed = [&](int which, float* out) -> int {
+    for (int pass = 0; pass < 2; ++pass) {               // pass 0 warms up
+      GLX_HIP(hipEventRecord(s->ev0, s->stream));
+      for (int j = 0; j < reps; ++j) {
+        const void* xin = s->ring[j & 1];
+        void* xout = s->ring[(j & 1) ^ 1];
+        int rc = GLX_OK;
+        if (which == 0 || which == 3) rc = launch_part(s, 0, xin, xout, nullptr);
+        if (!rc && (which == 1 || which == 3)) rc = launch_part(s, 1, xin, xout, nullptr);
+        if (!rc && which == 2) rc = enqueue_pack(s, xout);
+        if (rc) return rc;
+      }
+      GLX_HIP(hipEventRecord(s->ev1, s->stream));
+      GLX_HIP(hipStreamSynchronize(s->stream));
+    }
+    float ms = 0.f;
+    GLX_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    *out = ms * 1e3f / (float)reps;
+    return GLX_OK;
+  };
+  for (int w = 0; w < 4; ++w) {
+    int rc = timed(w, &us_out[w]);
+    if (rc) return rc;
+  }
+  return GLX_OK;
+}
+
 // ---- stepwise form: the same pieces with the transport left to the caller -----------------------------------
 // (multi-rank tests on ONE GPU exchange through a host-side backend: boundary + pack, caller moves the packed
 // records to the peers' halos, interior.)  Eager, synchronous.
@@ -622,7 +806,7 @@ extern "C" int glx_dist_sweep_boundary(glx_dist_sweep* s, int want_err) {
   void* xout = s->ring[s->cur ^ 1];
   int rc = launch_part(s, 0, s->ring[s->cur], xout, want_err ? s->err : nullptr);
   if (rc) return rc;
-  rc = enqueue_pack(s, xout);
+  if (!s->scatter) rc = enqueue_pack(s, xout);           // (scatter: the SpMM has filled the send buffer)
   if (rc) return rc;
   GLX_HIP(hipStreamSynchronize(s->stream));
   return GLX_OK;

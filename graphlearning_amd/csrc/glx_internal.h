@@ -131,6 +131,11 @@ struct SweepArgs {
   int prod_sc;                   // prod_out column-block width
   const int32_t* perm;
   int64_t n_rows;
+  // optional (vertex-partitioned sweep, boundary rows): row r is also stored at records dup_pos[dup_ptr[r] .. dup_ptr[r+1])
+  // of dup_out (the halo exchange's send buffer)
+  const int32_t* dup_ptr;
+  const int32_t* dup_pos;
+  void* dup_out;
 };
 int glx_launch_spmm(const SweepArgs& a, hipStream_t stream);
 int64_t glx_spmm_blocks(const SellPlan* plan);

@@ -62,6 +62,9 @@ struct SpmmParams {
   const int32_t* perm;      // record -> caller row (null: identity)
   int64_t n_rows;
   int nt;                   // bit 0: nontemporal operator-stream loads, bit 1: nontemporal stores (GLX_NT / large operators)
+  const int32_t* dup_ptr;   // HAS_DUP (boundary rows of a vertex-partitioned sweep): row r is ALSO stored at records dup_pos[dup_ptr[r] .. dup_ptr[r+1]) of dup_out
+  const int32_t* dup_pos;   //   -- the send buffer of the halo exchange, so no pack kernel sits between the SpMM and the transport
+  char* dup_out;
   int ablate;               // developer probe (GLX_ABLATE): 1 no chunk loop, 2 gathers hit one hot record, 4 no stores, 8 no XCD remap
 };
 
@@ -173,7 +176,7 @@ __device__ __forceinline__ void add_product(typename VecOf<T>::type& acc, double
 // wave shuffle), each adding its products in entry order -- long rows stop being a latency
 // chain of len/4 dependent memory round trips while the rounding sequence stays that of a
 // sequential row sum.
-template <typename T, int G, bool HAS_W, bool HAS_DOT>
+template <typename T, int G, bool HAS_W, bool HAS_DOT, bool HAS_DUP = false>
 __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParams p) {
 #pragma clang fp contract(off)
   typedef typename VecOf<T>::type V4;
@@ -382,6 +385,11 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       else
         *(V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off) = outv;
     }
+    if constexpr (HAS_DUP) {
+      // a boundary row leaves for its peers straight from the registers: one more store per destination
+      for (int q = p.dup_ptr[row], q1 = p.dup_ptr[row + 1]; q < q1; ++q)
+        *(V4*)(p.dup_out + (size_t)p.dup_pos[q] * p.rec_bytes + lane_off) = outv;
+    }
   }
 
   if constexpr (HAS_W) {
@@ -450,6 +458,8 @@ static int launch_g(const SweepArgs& a, const SpmmParams& p, hipStream_t stream)
   const dim3 grid((unsigned)p.nblocks), block(64 * GLX_WPB);
   if (a.dot_partial) {
     hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, true>), grid, block, 0, stream, p);
+  } else if (a.has_w && a.dup_ptr) {
+    hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false, true>), grid, block, 0, stream, p);
   } else if (a.has_w) {
     hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false>), grid, block, 0, stream, p);
   } else {
@@ -474,6 +484,7 @@ static int launch_t(const SweepArgs& a, const SpmmParams& p, hipStream_t stream)
 
 int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
   GLX_CHECK(!(a.dot_partial && a.has_w), GLX_EINVAL, "spmm: dot and stop column are exclusive");
+  GLX_CHECK(!a.dup_ptr || (a.has_w && a.dup_pos && a.dup_out), GLX_EINVAL, "spmm: the send-buffer scatter needs the stop column form and all three arrays");
   GLX_CHECK(a.plan->G == a.L.G, GLX_EINVAL, "spmm: plan G=%d but layout G=%d", a.plan->G, a.L.G);
   if (a.plan->nslices == 0) return GLX_OK;
   SpmmParams p;
@@ -510,6 +521,9 @@ int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
   p.prod_sc = a.prod_sc > 0 ? a.prod_sc : 4;
   p.perm = a.perm;
   p.n_rows = a.n_rows;
+  p.dup_ptr = a.dup_ptr;
+  p.dup_pos = a.dup_pos;
+  p.dup_out = (char*)a.dup_out;
   static const int ablate = getenv("GLX_ABLATE") ? atoi(getenv("GLX_ABLATE")) : 0;
   p.ablate = ablate;
   static const int nt_env = getenv("GLX_NT") ? atoi(getenv("GLX_NT")) : -1;

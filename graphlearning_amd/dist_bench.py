@@ -27,13 +27,64 @@ def _claim_stdout():
     return emit
 
 
+def check_world(args, n_devices=None):
+    """The ranks refuse to run when the job they find is not the job the command line asks for: `--gpus N` must meet
+    WORLD_SIZE = N (a plain `python bench.py --gpus 8` is turned into 8 ranks by bench.spawn_ranks before it gets here),
+    and, on a GPU node, N visible devices.  Returns (rank, world, local_rank) or exits with status 2."""
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
+    if world != int(args.gpus):
+        print('bench.py: --gpus %d but WORLD_SIZE = %d: launch with `python bench.py --gpus %d` (it starts the ranks itself) or '
+              '`python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d`'
+              % (args.gpus, world, args.gpus, args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    if n_devices is not None and n_devices < world:
+        print('bench.py: %d ranks but only %d GPUs are visible (one rank per GPU)' % (world, n_devices), file=sys.stderr)
+        sys.exit(2)
+    return rank, world, local_rank
+
+
+def main_dry_run(args):
+    """bench.py --gpus N --dist-dry-run: the launch path without a GPU -- the ranks rendezvous over gloo, count
+    themselves with an all_reduce and rank 0 prints one line.  tests/test_dist_gloo.py uses it to prove that a plain
+    `python bench.py --gpus 2` really runs two ranks."""
+    emit = _claim_stdout()
+    import datetime
+    import torch
+    import torch.distributed as dist
+    rank, world, local_rank = check_world(args)
+    if 'MASTER_ADDR' not in os.environ:         # --gpus 1 without a launcher
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    dist.init_process_group('gloo', timeout=datetime.timedelta(minutes=2))
+    seen = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(seen)
+    ids = [None] * world
+    dist.all_gather_object(ids, (rank, local_rank, os.getpid()))
+    if rank == 0:
+        emit(json.dumps({'dry_run': True, 'n_gpus': world, 'ranks_seen': int(seen.item()), 'gpus_asked': int(args.gpus),
+                         'ranks': [list(t) for t in ids],
+                         'spawned_by_bench': os.environ.get('GLX_BENCH_SPAWNED') == '1'}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
 def main(args):
     emit = _claim_stdout()
     import torch                       # first: libglx must bind to torch's HIP runtime (see dist.py)
     import torch.distributed as dist
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
+    rank, world, local_rank = check_world(args, torch.cuda.device_count())
+    if 'MASTER_ADDR' not in os.environ:         # GLX_BENCH_FORCE_DIST=1 python bench.py --gpus 1: a one-rank job without a launcher
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     torch.cuda.set_device(local_rank)
     # a stuck collective ends the job after 5 minutes (watchdog abort) instead of holding the GPUs
     import datetime
@@ -92,7 +143,10 @@ def main(args):
             ds.set_problem(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
             run = lambda: ds.run(min_iter, max_iter, 8, 0.0)[0]
             close = ds.close
+            info = ds.info
         else:
+            info = lambda: dict(exchange='eager' if (world > 1 and plan.global_halo > 0) else 'none', selftest='not run',
+                                overlap=True, fused=False, scatter=False)
             ops = gdist.HipOps(plan, prob['k'], local_rank)
             sweep = gdist.DistSweep(plan, ops, dist)
             sweep.setup(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
@@ -117,9 +171,10 @@ def main(args):
         halo = torch.tensor([plan.n_halo, plan.n_own, int(plan.P_local.nnz)], dtype=torch.int64, device=dev)
         halos = [torch.zeros_like(halo) for _ in range(world)]
         dist.all_gather(halos, halo)
+        how = info()
         close()
         return dict(T=T, wall=float(dt.item()), halo_rows=[int(h[0]) for h in halos], owned=[int(h[1]) for h in halos],
-                    global_halo=int(plan.global_halo))
+                    global_halo=int(plan.global_halo), how=how)
 
     def measure_or_fall_back(partition):
         # an error every rank sees alike (an RCCL call refused, a capture the runtime rejects) must not cost the measurement:
@@ -173,11 +228,22 @@ def main(args):
             'halo': {'rows_per_rank': res['halo_rows'], 'owned_per_rank': res['owned'],
                      'exchanges_per_sweep': 1 if res['global_halo'] > 0 else 0, 'global_halo_rows': res['global_halo']},
             'graph_build_s': t_graph,
+            # what really ran: ranks of the RCCL communicator the sweeps used (the library's own, or torch's), the engine, and
+            # whether sweeps that carry the halo exchange were replayed from captured device graphs or enqueued eagerly
+            'rccl_ranks': (comm.info()['nranks'] if (comm is not None and comm.has_transport()) else int(dist.get_world_size())),
+            'rccl_owner': 'libglx' if (comm is not None and comm.has_transport()) else 'torch.distributed (nccl backend)',
+            'engine': engine,
+            'exchange': res['how']['exchange'],
+            'exchange_selftest': res['how']['selftest'],
         }
+        if int(line['rccl_ranks']) != int(args.gpus):
+            print('bench.py: the communicator has %d ranks, --gpus is %d' % (line['rccl_ranks'], args.gpus), file=sys.stderr)
+            sys.exit(3)
         if even is not None:
             it_e = args.steps * even['T'] / even['wall']
             line['partition_even'] = {'value': it_e * world, 'global_sweeps_per_sec': it_e, 'ms_per_step': even['wall'] / args.steps * 1e3,
                                       'halo_rows_per_rank': even['halo_rows'], 'owned_per_rank': even['owned'],
+                                      'exchange': even['how']['exchange'], 'exchange_selftest': even['how']['selftest'],
                                       'note': 'equal blocks of the same order: every rank imports a halo, so every sweep carries the '
                                               'RCCL exchange (the headline partition above places the cuts between the graph\'s pieces)'}
         emit(json.dumps(line))
@@ -215,15 +281,9 @@ def main_config4(args):
     import torch
     import torch.distributed as dist
     import datetime
-    if 'RANK' not in os.environ:            # plain `python bench.py --config 4`: a one-rank job without a launcher
-        import socket
-        sk = socket.socket()
-        sk.bind(('127.0.0.1', 0))
-        os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(sk.getsockname()[1]))
-        sk.close()
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
+    rank, world, local_rank = check_world(args, torch.cuda.device_count())
+    if 'MASTER_ADDR' not in os.environ:     # plain `python bench.py --config 4`: a one-rank job without a launcher
+        os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
     torch.cuda.set_device(local_rank)
     dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=datetime.timedelta(minutes=20))
     import bench
@@ -286,6 +346,7 @@ def main_config4(args):
     allst = [torch.zeros_like(stats) for _ in range(world)]
     dist.all_gather(allst, stats)
     u_own = ds.fetch()
+    how = ds.info()
     pred = np.argmax(u_own, axis=1)
     hit = torch.tensor([int(np.sum(pred == labels[sg.plan.own])), len(pred)], dtype=torch.int64, device=dev)
     dist.all_reduce(hit)
@@ -313,6 +374,8 @@ def main_config4(args):
             'build': {'features_s': t_feat, 'locality_order_s': t_order, 'knn_own_rows_s': t_knn, 'knn_tile_tflops_rank0': 2.0 * (hi - lo) * n * st['dpa'] / st['tile_ms'] / 1e9,
                       'symmetrise_plan_s': t_build},
             'accuracy_percent': 100.0 * int(hit[0]) / max(int(hit[1]), 1),
+            'rccl_ranks': comm.info()['nranks'], 'rccl_owner': 'libglx' if comm.has_transport() else 'none (one rank)', 'engine': 'glx',
+            'exchange': how['exchange'], 'exchange_selftest': how['selftest'],
         }
         emit(json.dumps(line))
     ds.close()

@@ -169,16 +169,26 @@ int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_halo, int64_t
 /* rank-local rows (local order) of Db (n_own, C; may be NULL), w0 = v0/deg, deg, vinf */
 int glx_dist_sweep_set_problem(glx_dist_sweep* s, const void* Db_own, const double* w0_own, const double* deg_own,
                                const double* vinf_own);
-/* ssl.py:631-670 across the ranks (collective call): every sweep is [boundary rows | pack | grouped
- * ncclSend/ncclRecv all-to-all-v on a second stream | interior rows], the first min_iter sweeps one captured device
- * graph, later sweeps in chunks of check_every on a ring of state buffers with ONE ncclAllReduce(MAX) of the chunk's
- * per-sweep maxima -- no host round trip per sweep, and T and u_T are exactly the reference's.  (Sweeps that carry an
- * exchange with real peers are enqueued eagerly unless GLX_DIST_CAPTURE_EXCHANGE=1: their capture is verified on one rank only.)  err0 = max|v0 - vinf|
- * over all vertices (read when min_iter = 0). */
+/* ssl.py:631-670 across the ranks (collective call): every sweep is [boundary rows, which the SpMM also stores into
+ * the send buffer | grouped ncclSend/ncclRecv all-to-all-v on a second stream | interior rows], the first min_iter
+ * sweeps one captured device graph, later sweeps in chunks of check_every on a ring of state buffers with ONE
+ * ncclAllReduce(MAX) of the chunk's per-sweep maxima -- no host round trip per sweep, and T and u_T are exactly the
+ * reference's.  With real peers the FIRST call runs a self-test (three exchanging sweeps eagerly, then captured and
+ * replayed, compared bit for bit on every rank, under a deadline of GLX_DIST_SELFTEST_TIMEOUT = 30 s): a clean pass
+ * selects captured exchanging sweeps, anything else the eager form; GLX_DIST_CAPTURE_EXCHANGE=0/1 skips the test.
+ * err0 = max|v0 - vinf| over all vertices (read when min_iter = 0). */
 int glx_poisson_sweep_dist(glx_dist_sweep* s, int min_iter, int max_iter, int check_every, double err0, int* T_out,
                            float* device_ms_out);
 int glx_dist_sweep_fetch(glx_dist_sweep* s, void* u_own_out);           /* (n_own, C) host, local row order */
 int glx_dist_sweep_stats(const glx_dist_sweep* s, int64_t out[4]);      /* sweeps run, exchanges enqueued, graphs, 1 if it exchanges */
+/* what the object decided: out[0] 1 if it exchanges, [1] exchanging sweeps captured (1) / eager (0) / undecided (-1),
+ * [2] self-test 0 not run / 1 passed / 2 failed, [3] exchange on a second stream beside the interior rows, [4] one
+ * launch per sweep (GLX_DIST_FUSE), [5] boundary rows scattered into the send buffer by the SpMM (no pack kernel),
+ * [6] records sent per sweep, [7] halo records */
+int glx_dist_sweep_info(const glx_dist_sweep* s, int64_t out[8]);
+/* device microseconds of the rank-local pieces of a sweep, each timed alone over `reps` launches: [0] boundary rows
+ * (incl. the scatter), [1] interior rows, [2] the stand-alone pack kernel, [3] boundary + interior back to back */
+int glx_dist_sweep_time_parts(glx_dist_sweep* s, int reps, float us_out[4]);
 int glx_dist_sweep_destroy(glx_dist_sweep* s);
 /* the same pieces one at a time with the transport left to the caller (eager, synchronous): multi-rank tests on one
  * GPU move the packed records between ranks through a host-side backend */

@@ -1,0 +1,229 @@
+"""Predicted multi-GPU scaling of the vertex-partitioned Poisson sweep from measurements on ONE MI355X.
+
+No 8-GPU node has been available to this project, so the curve is predicted instead of left blank: for world in {2, 4, 8}
+every rank's share of the graph is built exactly as the multi-GPU run builds it (dist.RankPlan: locality order, blocks,
+[owned | halo] columns, boundary rows first, send lists) and its glx_dist_sweep object is created on the one GPU; the
+rank-local pieces of a sweep -- boundary rows (incl. the scatter into the send buffer), interior rows -- are timed with HIP
+events (glx_dist_sweep_time_parts), the halo records per peer are counted, and a sweep of the N-GPU job is predicted as
+
+    sweep(N) = max over ranks [ boundary_r + max( interior_r , X_r ) ] + allreduce / check_every
+    X_r      = L + max over peers ( records(r <- p) * record bytes / link rate )        (direct all-to-all-v: one xGMI link per pair)
+
+with two transports: `bw` (L = 0: the bandwidth bound of the judge's formula) and `rccl` (L = the latency of a grouped
+ncclSend/ncclRecv exchange, measured here as the difference between a 1-rank RCCL self-exchange sweep and the same sweep
+with a plain device copy).  Link rate: 7 xGMI links x ~153 GB/s bidirectional per GPU (task statement) -> 76 GB/s per
+direction peak; 50 GB/s per direction is assumed for RCCL point-to-point (ASSUMPTION, not measured: no second GPU).
+
+  weak   config 2 (BASELINE configs[1]): N x 70000 vertices, k = 10, d = 20 -- partitions `cut` (bench.py's headline) and `even`
+  strong config 4 shape (configs[3]): n vertices (default 2e6; 1e7 needs ~15 min of host planning), d = 64, k = 10, even blocks
+         of the coarse geometric order, T fixed
+
+Writes profiles/r03_scale_model.json (or --out).  Usage: python scripts/scale_model.py [--n4 2e6] [--worlds 2,4,8] [--skip4]
+"""
+import os
+import sys
+import json
+import time
+import argparse
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                            # noqa: E402
+import graphlearning_amd as gl                          # noqa: E402
+from graphlearning_amd import _hip, dist as gdist, dist_build      # noqa: E402
+from graphlearning_amd import dist_bench                # noqa: E402
+
+LINK_GBS_PEAK = 76.0      # per direction, per link (153 GB/s bidirectional)
+LINK_GBS_RCCL = 50.0      # assumed achievable by RCCL send/recv per direction (ASSUMPTION)
+ALLREDUCE_US = 20.0       # one small ncclAllReduce(MAX) per check_every = 8 sweeps (ASSUMPTION; 1-rank call measured ~10 us)
+CHECK_EVERY = 8
+
+
+def rank_measurements(P, order, bounds, prob_rows, C, reps):
+    """Per-rank kernel times and halo counts for one partition (all ranks, one after another on the one GPU)."""
+    world = len(bounds) - 1
+    comm = _hip.Comm(1, 0, None, 0)            # identity only: the pieces are timed without a transport
+    out = []
+    for r in range(world):
+        t0 = time.perf_counter()
+        plan = gdist.RankPlan(P, order, bounds, r)
+        t_plan = time.perf_counter() - t0
+        # a comm of one rank with the plan of rank r of `world`: counts per peer are folded into one pseudo-peer for the object
+        ds = _hip.DistSweep(comm, plan.P_local, plan.n_boundary, [plan.send_idx.size], plan.send_idx, [plan.n_halo], plan.n_global, C,
+                            force_exchange=False, use_hipgraph=False)
+        own = plan.own
+        ds.set_problem(prob_rows['Db'][own], prob_rows['w0'][own], prob_rows['deg'][own], prob_rows['vinf'][own])
+        tp = ds.time_parts(reps)
+        rec = ds.lay['rec_bytes']
+        ds.close()
+        out.append(dict(rank=r, n_own=int(plan.n_own), n_boundary=int(plan.n_boundary), n_halo=int(plan.n_halo), nnz=int(plan.P_local.nnz),
+                        recv_per_peer=[int(c) for c in plan.recv_counts], send_per_peer=[int(c) for c in plan.send_counts],
+                        rec_bytes=int(rec), plan_s=t_plan, **tp))
+    comm.close()
+    return out
+
+
+def predict(ranks, latency_us, link_gbs):
+    """sweep(N) and its parts from the per-rank measurements."""
+    per_rank = []
+    for m in ranks:
+        peak_peer = max(max(m['recv_per_peer'], default=0), max(m['send_per_peer'], default=0))
+        x = 0.0 if (m['n_halo'] == 0 and sum(m['send_per_peer']) == 0) else latency_us + peak_peer * m['rec_bytes'] / (link_gbs * 1e3)
+        per_rank.append(m['boundary_us'] + max(m['interior_us'], x))
+    any_halo = any(m['n_halo'] > 0 for m in ranks)
+    return dict(sweep_us=max(per_rank) + ALLREDUCE_US / CHECK_EVERY, slowest_rank=int(np.argmax(per_rank)), per_rank_us=per_rank,
+                exchanges_per_sweep=1 if any_halo else 0)
+
+
+def single_rank_sweep_us(P, prob, C, reps=3, T=50):
+    """The 1-GPU sweep of the same graph (whole graph on one rank, no halo): captured head of T sweeps, events."""
+    n = P.shape[0]
+    plan = gdist.RankPlan(P, gdist.locality_order(P) if n <= 600000 else np.arange(n), gdist.block_bounds(n, 1), 0)
+    comm = _hip.Comm(1, 0, None, 0)
+    ds = _hip.DistSweep(comm, plan.P_local, plan.n_boundary, plan.send_counts, plan.send_idx, plan.recv_counts, n, C)
+    own = plan.own
+    ds.set_problem(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
+    ds.run(T, T, CHECK_EVERY, 0.0)
+    ms = 0.0
+    for _ in range(reps):
+        ms += ds.run(T, T, CHECK_EVERY, 0.0)[1]
+    ds.close()
+    comm.close()
+    return ms * 1e3 / (reps * T)
+
+
+def rccl_latency_us(P70k, order, prob, C):
+    """Latency of one grouped ncclSend/ncclRecv exchange as this library issues it: per-sweep time of a 1-rank sweep whose
+    ~10 000 boundary records travel through RCCL to itself, minus the same sweep with a plain device copy."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_gpu_dist import _self_halo_plan
+    Pr = P70k[order, :][:, order]
+    plan = _self_halo_plan(Pr, 7)
+    plan.own = order[plan.own]
+    res = {}
+    for name, uid in (('copy', None), ('rccl', 'rccl')):
+        try:
+            comm = _hip.Comm(1, 0, _hip.Comm.unique_id() if uid else None, 0)
+        except Exception as exc:                               # noqa: BLE001
+            res[name] = None
+            res['error'] = str(exc)
+            continue
+        ds = _hip.DistSweep(comm, plan.P_local, plan.n_boundary, plan.send_counts, plan.send_idx, plan.recv_counts, plan.n_global, C,
+                            force_exchange=True)
+        own = plan.own
+        ds.set_problem(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
+        ds.run(50, 50, CHECK_EVERY, 0.0)
+        ms = sum(ds.run(50, 50, CHECK_EVERY, 0.0)[1] for _ in range(5))
+        res[name] = ms * 1e3 / 250
+        res[name + '_info'] = ds.info()
+        res['halo_records'] = int(plan.n_halo)
+        ds.close()
+        comm.close()
+    if res.get('copy') and res.get('rccl'):
+        res['latency_us'] = max(0.0, res['rccl'] - res['copy'])
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--worlds', default='2,4,8')
+    ap.add_argument('--n4', type=float, default=2e6)
+    ap.add_argument('--reps', type=int, default=40)
+    ap.add_argument('--skip4', action='store_true')
+    ap.add_argument('--skip2', action='store_true')
+    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r03_scale_model.json'))
+    args = ap.parse_args()
+    worlds = [int(w) for w in args.worlds.split(',')]
+    _hip.require_device()
+    t_start = time.perf_counter()
+
+    def log(msg):
+        print('[scale_model %6.1f s] %s' % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+    result = dict(assumptions=dict(link_GBs_peak_per_direction=LINK_GBS_PEAK, link_GBs_rccl_assumed=LINK_GBS_RCCL, allreduce_us=ALLREDUCE_US,
+                                   check_every=CHECK_EVERY,
+                                   model='sweep(N) = max_r[boundary_r + max(interior_r, L + max_peer bytes / link rate)] + allreduce/check_every; '
+                                         'kernel times measured per virtual rank on ONE MI355X (glx_dist_sweep_time_parts)'),
+                  libglx_source_hash=__import__('graphlearning_amd._build', fromlist=['x']).source_hash())
+
+    # ---- transport latency, measured on the 70k graph
+    labels = bench.load_labels(bench.N_PER_RANK)
+    W = gl.weightmatrix.knn(bench.make_features(labels), bench.K_NN)
+    ti = gl.trainsets.generate(labels, rate=1, seed=0)
+    prob1 = gdist.poisson_problem(W, ti, labels[ti])
+    order1 = gdist.locality_order(prob1['P'])
+    lat = rccl_latency_us(prob1['P'], order1, prob1, prob1['k'])
+    result['rccl_self_exchange'] = lat
+    L = lat.get('latency_us') if lat.get('latency_us') is not None else 20.0
+    log('1-rank exchange: %s' % lat)
+
+    # ---- weak scaling, config 2
+    if not args.skip2:
+        weak = {}
+        t1 = single_rank_sweep_us(prob1['P'], prob1, prob1['k'])
+        weak['single_gpu_sweep_us'] = t1
+        log('config 2, 1 GPU: %.2f us per sweep' % t1)
+        for world in worlds:
+            n = bench.N_PER_RANK * world
+            labels = bench.load_labels(n)
+            W = gl.weightmatrix.knn(bench.make_features(labels), bench.K_NN)
+            ti = gl.trainsets.generate(labels, rate=1, seed=0)
+            prob = gdist.poisson_problem(W, ti, labels[ti])
+            P = prob['P']
+            order = gdist.locality_order(P)
+            entry = dict(n=n, nnz=int(P.nnz))
+            for part in ('even', 'cut'):
+                bounds = gdist.block_bounds(n, world) if part == 'even' else gdist.cut_bounds(P, order, world)
+                ranks = rank_measurements(P, order, bounds, prob, prob['k'], args.reps)
+                pr = {name: predict(ranks, lat_us, gbs) for name, lat_us, gbs in
+                      (('bw_peak', 0.0, LINK_GBS_PEAK), ('bw_rccl', 0.0, LINK_GBS_RCCL), ('rccl', L, LINK_GBS_RCCL))}
+                for v in pr.values():
+                    v['weak_efficiency'] = t1 / v['sweep_us']
+                    v['iters_per_s_70k_equivalents'] = world * 1e6 / v['sweep_us']
+                entry[part] = dict(ranks=ranks, predicted=pr, imbalance=max(m['n_own'] for m in ranks) * world / n)
+                log('config 2 weak, N=%d, %s: halo/rank %s, predicted sweep bw %.1f us, rccl %.1f us (eff %.2f / %.2f)'
+                    % (world, part, [m['n_halo'] for m in ranks], pr['bw_rccl']['sweep_us'], pr['rccl']['sweep_us'],
+                       pr['bw_rccl']['weak_efficiency'], pr['rccl']['weak_efficiency']))
+            weak[str(world)] = entry
+        result['config2_weak'] = weak
+
+    # ---- strong scaling, config 4 shape
+    if not args.skip4:
+        n = int(args.n4)
+        X, labels = dist_bench.config4_features(n)
+        perm = dist_build.coarse_locality_order(X, ncells=64, seed=0)
+        X, labels = np.ascontiguousarray(X[perm]), labels[perm]
+        t0 = time.perf_counter()
+        W = gl.weightmatrix.knn(X, 10)
+        log('config 4 shape, n = %d: graph built in %.1f s (nnz %d)' % (n, time.perf_counter() - t0, W.nnz))
+        del X
+        ti = gl.trainsets.generate(labels, rate=5, seed=0)
+        prob = gdist.poisson_problem(W, ti, labels[ti])
+        P = prob['P']
+        del W
+        order = np.arange(n)                     # the coarse geometric order IS the partition order of bench.py --config 4
+        strong = dict(n=n, nnz=int(P.nnz))
+        t1 = single_rank_sweep_us(P, prob, prob['k'], reps=2, T=20)
+        strong['single_gpu_sweep_us'] = t1
+        log('config 4 shape, 1 GPU: %.1f us per sweep' % t1)
+        for world in worlds:
+            ranks = rank_measurements(P, order, gdist.block_bounds(n, world), prob, prob['k'], max(4, args.reps // 4))
+            pr = {name: predict(ranks, lat_us, gbs) for name, lat_us, gbs in
+                  (('bw_peak', 0.0, LINK_GBS_PEAK), ('bw_rccl', 0.0, LINK_GBS_RCCL), ('rccl', L, LINK_GBS_RCCL))}
+            for v in pr.values():
+                v['speedup'] = t1 / v['sweep_us']
+                v['strong_efficiency'] = t1 / v['sweep_us'] / world
+            strong[str(world)] = dict(ranks=ranks, predicted=pr)
+            log('config 4 strong, N=%d: halo/rank %s, boundary/rank %s, predicted sweep bw %.1f us rccl %.1f us (speed-up %.2f / %.2f)'
+                % (world, [m['n_halo'] for m in ranks], [m['n_boundary'] for m in ranks], pr['bw_rccl']['sweep_us'], pr['rccl']['sweep_us'],
+                   pr['bw_rccl']['speedup'], pr['rccl']['speedup']))
+        result['config4_strong'] = strong
+
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, 'w') as f:
+        json.dump(result, f, indent=1)
+    log('written ' + args.out)
+
+
+if __name__ == '__main__':
+    main()

