@@ -68,6 +68,7 @@ _SIGNATURES = {
     'glx_graph_keep_order': [_vp],
     'glx_graph_info': [_vp, _i64p],
     'glx_graph_order': [_vp, _vp],
+    'glx_graph_set_order': [_vp, _vp],
     'glx_spmm_bias': [_vp, _vp, _vp, _vp, C.c_int, C.c_int],
     'glx_poisson_sweep': [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_int)],
     'glx_sweep_create': [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)],
@@ -205,11 +206,23 @@ class _PinnedBlock:
 class _PinnedPool:
     """Result arrays (prob, labels) are handed out as numpy arrays backed by page-locked memory: the device-to-host
     copy then runs at PCIe speed and a fresh array costs no page faults (a 5.6 MB np.empty + first write is ~1 ms).
-    Blocks are recycled by size; at most `keep` idle blocks per size are retained."""
+    Blocks are recycled by size; at most `keep` idle blocks per size are retained.  Page-locked memory cannot be swapped:
+    the pool never holds more than `budget` bytes (live arrays + idle blocks; $GLX_PINNED_MAX_MB, default 4096 MiB) --
+    beyond it arrays come from ordinary memory, and idle blocks are released first when a request would not fit."""
 
     def __init__(self, keep=4):
         self.keep = keep
         self.idle = {}
+        self.total = 0                                   # bytes of page-locked memory this pool currently owns
+        self.budget = int(float(os.environ.get('GLX_PINNED_MAX_MB', '4096')) * (1 << 20))
+
+    def _trim(self):
+        for nbytes, lst in list(self.idle.items()):
+            while lst:
+                ptr = lst.pop()
+                self.total -= nbytes
+                if _lib is not None:
+                    _lib.glx_host_free(_vp(ptr))
 
     def empty(self, shape, dtype):
         dtype = np.dtype(dtype)
@@ -220,17 +233,24 @@ class _PinnedPool:
         if lst:
             ptr = lst.pop()
         else:
+            if self.total + nbytes > self.budget:
+                self._trim()
+            if self.total + nbytes > self.budget:
+                return np.empty(shape, dtype=dtype)      # over the budget: ordinary (pageable) memory
             p = _vp()
             check(load().glx_host_alloc(nbytes, C.byref(p)), 'glx_host_alloc')
             ptr = p.value
+            self.total += nbytes
         return np.asarray(_PinnedBlock(self, ptr, nbytes, shape, dtype))
 
     def _release(self, ptr, nbytes):
         lst = self.idle.setdefault(nbytes, [])
         if len(lst) < self.keep:
             lst.append(ptr)
-        elif _lib is not None:
-            _lib.glx_host_free(_vp(ptr))
+        else:
+            self.total -= nbytes
+            if _lib is not None:
+                _lib.glx_host_free(_vp(ptr))
 
 
 _pinned = _PinnedPool()
@@ -244,7 +264,7 @@ class DeviceGraph:
     """A sparse operator resident in HBM (glx_graph).  `A` is any scipy sparse matrix;
     the CSR entry order is preserved (see include/glx.h)."""
 
-    def __init__(self, A, dtype=np.float64, device=None, shape=None, keep_order=False):
+    def __init__(self, A, dtype=np.float64, device=None, shape=None, keep_order=False, order=None):
         from scipy import sparse
         A = sparse.csr_matrix(A)
         self.dtype = np.dtype(dtype)
@@ -258,7 +278,12 @@ class DeviceGraph:
         lib = load()
         check(lib.glx_graph_create(self.shape[0], self.shape[1], self.nnz, _ptr(rowptr), _ptr(col), _ptr(val),
                                    _dt(self.dtype), device, C.byref(self._h)), 'glx_graph_create')
-        if keep_order:
+        if order is not None:       # the caller's locality order (perm[new] = old) instead of the library's pass over the graph
+            perm = np.ascontiguousarray(order, dtype=np.int32)
+            if perm.shape != (self.shape[0],):
+                raise GlxError('order must be a permutation of the %d rows' % self.shape[0])
+            check(lib.glx_graph_set_order(self._h, _ptr(perm)), 'glx_graph_set_order')
+        elif keep_order:
             check(lib.glx_graph_keep_order(self._h), 'glx_graph_keep_order')
 
     def info(self):

@@ -811,6 +811,7 @@ extern "C" int glx_cg_groups_masked(glx_graph* A, const void* B, void* X, int C,
             "glx_cg_groups: %d columns do not split into systems of %d columns", C, group_cols);
   GLX_CHECK((mask_rows == nullptr) == (mask_ptr == nullptr) || (mask_ptr && mask_ptr[C / group_cols] == 0), GLX_EINVAL,
             "glx_cg_groups_masked: mask_rows and mask_ptr go together");
+  std::lock_guard<std::mutex> one_solve(A->solve_mu);   // the operator's work buffers are shared by its solves (include/glx.h: threading)
   GLX_HIP(hipSetDevice(A->device));
   return A->dtype == GLX_F32 ? cg_run<float>(A, B, X, C, group_cols, tol, max_iter, iters_out, err_out, flags, mask_rows, mask_ptr)
                              : cg_run<double>(A, B, X, C, group_cols, tol, max_iter, iters_out, err_out, flags, mask_rows, mask_ptr);

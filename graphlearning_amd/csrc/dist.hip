@@ -285,11 +285,26 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
     if (!s->use_graph) s->capture_exchange = 0;
     if (s->capture_exchange == 0 && !getenv("GLX_DIST_OVERLAP")) s->overlap = true;   // eager: two streams are safe on every runtime
     if (const char* e = getenv("GLX_DIST_PACK")) s->scatter = atoi(e) == 0;             // 1: the round-2 pack kernel between SpMM and transport
-    // one launch per sweep when the boundary is at most GLX_DIST_FUSE percent of the rows (default 0 = never: with the exchange
-    // beside the interior rows the split form hides min(interior, exchange), which one saved launch does not buy back -- measured)
-    double fuse_pct = 0.0;
-    if (const char* e = getenv("GLX_DIST_FUSE")) fuse_pct = atof(e);
-    s->fused = n_own > 0 && fuse_pct > 0.0 && (double)n_boundary <= fuse_pct * 0.01 * (double)n_own;
+    // Form of a sweep.  SPLIT: [boundary rows | exchange on a second stream beside the interior rows] hides min(interior, exchange)
+    // but pays for a second launch (~9 us at 70 000 rows: a short launch is a chain of dependent memory round trips) and for the
+    // cross-stream edges of the captured graph (~14 us measured: 35.0 vs 29.4 us per sweep with the exchange in line).  FUSED: ONE
+    // launch for all rows, the exchange in line behind it: 22.9 us per sweep for the same 10 000-record halo (profiles/r03_dist_probe.txt).
+    // The split form wins only when BOTH the interior rows and the exchange take longer than those fixed costs (~23 us): estimated
+    // from the interior's stored entries (13 ps per entry) and the largest per-peer message (8 us + bytes / 50 GB/s).
+    // GLX_DIST_FUSE=0/1 forces a form.
+    double interior_us = 0.0, exchange_us = 0.0;
+    {
+      const double nnz_int = (double)(rowptr[n_own] - rowptr[n_boundary]);
+      interior_us = nnz_int * 13e-6;
+      int64_t peer_max = 0;
+      for (int r = 0; r < nr; ++r) peer_max = std::max(peer_max, std::max(send_counts[r], recv_counts[r]));
+      RecLayout L0;
+      if (glx_make_layout(C, state_dtype, true, &L0) == GLX_OK)
+        exchange_us = peer_max > 0 ? 8.0 + (double)peer_max * L0.ld * L0.esize / 50e3 : 0.0;
+    }
+    s->fused = n_own > 0 && std::min(interior_us, exchange_us) < 23.0;
+    if (const char* e = getenv("GLX_DIST_FUSE")) s->fused = n_own > 0 && atoi(e) != 0;
+    if (s->fused && !getenv("GLX_DIST_OVERLAP")) s->overlap = false;   // nothing to run beside the exchange
   }
   s->thresh = 1.0 / (double)n_global;   // `> 1/n`, ssl.py:667, n = ALL vertices
   int rc = glx_make_layout(C, state_dtype, true, &s->L);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/glx.h"
@@ -85,6 +86,8 @@ struct glx_graph {
   int32_t* d_perm = nullptr;
   int32_t* d_inv = nullptr;
   void* cg_ws = nullptr;   // work buffers of the conjugate-gradient solves on this operator (cg.hip), reused between calls
+  std::mutex solve_mu;     // one solve at a time per operator: the work buffers, their stream and the plans are shared (ctypes
+                           // releases the GIL, so two Python threads can reach the same operator)
 };
 void glx_cg_ws_destroy(void* ws);
 

@@ -136,7 +136,21 @@ int glx_pool_alloc(void** out, size_t bytes) {
     }
   }
   *out = nullptr;
-  GLX_HIP(hipMalloc(out, c));
+  hipError_t e = hipMalloc(out, c);
+  if (e == hipErrorOutOfMemory) {
+    // the idle blocks of the pool (up to POOL_CAP) are memory the runtime could hand out: give them back and try once more
+    (void)hipGetLastError();
+    std::vector<void*> idle;
+    {
+      std::lock_guard<std::mutex> lk(ps.mu);
+      for (auto& kv : ps.idle) idle.push_back(kv.second);
+      ps.idle.clear();
+      ps.cached = 0;
+    }
+    for (void* p : idle) hipFree(p);
+    e = hipMalloc(out, c);
+  }
+  GLX_HIP(e);
   std::lock_guard<std::mutex> lk(ps.mu);
   ps.live[*out] = {dev, c};
   return GLX_OK;
@@ -413,6 +427,30 @@ extern "C" int glx_host_reverse_scale_rows(int64_t n, const int32_t* rowptr, con
     for (int t = 0; t < nt; ++t) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
     for (auto& x : th) x.join();
   }
+  return GLX_OK;
+}
+
+// The caller's own vertex order (perm[new] = old) instead of the library's reverse Cuthill-McKee pass: whoever built the graph
+// may know a better one -- weightmatrix.knn has the FEATURES in hand, and an order by a tree over feature space keeps
+// neighbours close without looking at the graph at all.  Before the operator is first used.
+extern "C" int glx_graph_set_order(glx_graph* g, const int32_t* perm) {
+  GLX_CHECK(g && perm, GLX_EINVAL, "glx_graph_set_order: null argument");
+  GLX_CHECK(g->plans.empty() && !g->order_ready, GLX_EINVAL, "glx_graph_set_order: call before the operator is first used");
+  GLX_CHECK(g->n_rows == g->n_cols, GLX_EINVAL, "glx_graph_set_order: operator must be square");
+  const int64_t n = g->n_rows;
+  std::vector<int32_t> inv(n, -1);
+  for (int64_t i = 0; i < n; ++i) {
+    GLX_CHECK(perm[i] >= 0 && perm[i] < n && inv[perm[i]] < 0, GLX_EINVAL, "glx_graph_set_order: not a permutation at position %lld", (long long)i);
+    inv[perm[i]] = (int32_t)i;
+  }
+  g->h_perm.assign(perm, perm + n);
+  g->h_inv.swap(inv);
+  g->order_ready = true;
+  GLX_HIP(hipSetDevice(g->device));
+  GLX_HIP(hipMalloc(&g->d_perm, std::max<size_t>(n * 4, 4)));
+  GLX_HIP(hipMalloc(&g->d_inv, std::max<size_t>(n * 4, 4)));
+  GLX_HIP(hipMemcpy(g->d_perm, g->h_perm.data(), n * 4, hipMemcpyHostToDevice));
+  GLX_HIP(hipMemcpy(g->d_inv, g->h_inv.data(), n * 4, hipMemcpyHostToDevice));
   return GLX_OK;
 }
 

@@ -21,6 +21,9 @@
 #ifndef GLX_NT_STORE
 #define GLX_NT_STORE 0
 #endif
+#ifndef GLX_PERSIST_DEFAULT
+#define GLX_PERSIST_DEFAULT 1   // blocks per workgroup of the sweep kernel (see the persistent form in spmm_sell_kernel)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -176,7 +179,7 @@ __device__ __forceinline__ void add_product(typename VecOf<T>::type& acc, double
 // wave shuffle), each adding its products in entry order -- long rows stop being a latency
 // chain of len/4 dependent memory round trips while the rounding sequence stays that of a
 // sequential row sum.
-template <typename T, int G, bool HAS_W, bool HAS_DOT, bool HAS_DUP = false>
+template <typename T, int G, bool HAS_W, bool HAS_DOT, bool HAS_DUP = false, bool PERSIST = false>
 __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParams p) {
 #pragma clang fp contract(off)
   typedef typename VecOf<T>::type V4;
@@ -196,8 +199,12 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
   if constexpr (HAS_DOT) {
     if (p.exit_err && !(*p.exit_err > p.exit_tol)) return;
   }
-  const int64_t vb = (p.ablate & 8) ? (int64_t)blockIdx.x : xcd_remap(blockIdx.x, p.nblocks);
-  const int64_t slice = vb * GLX_WPB + wave;
+  // Persistent form (GLX_PERSIST = k: grid = nblocks / k workgroups): a workgroup walks the blocks j, j + gridDim/8, ... of ITS
+  // XCD's range, so the header / first-chunk loads of its next block travel while the current one gathers, and the waves of a
+  // CU are in different phases (one stores while another gathers) instead of all starting and all finishing together.
+  // gridDim.x == nblocks is the one-block-per-workgroup form.
+  const int64_t bpx = p.nblocks / 8, gpx = gridDim.x / 8;
+  const bool flat = (p.ablate & 8) != 0;
   const int g = lane / G, c = lane % G;
   bool lane_on = c < p.nlanes;
   if constexpr (HAS_DOT) {
@@ -214,32 +221,57 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
     }
   }
   const bool is_w = HAS_W && (c == p.nvec);
-  int row = -1, len = 0, nchunks = 0, S = 1;
-  int64_t base = 0;
   const T* __restrict__ valp = (const T*)p.val;
-  // chunk 0 sits at a slice-indexed address: its load is issued together with the header loads
-  int col0 = 0;
-  T val0 = 0;
-  if (slice < p.nslices) {
-    if (p.nt & 1) {
-      col0 = __builtin_nontemporal_load(&p.col[slice * 64 + lane]);
-      val0 = __builtin_nontemporal_load(&valp[slice * 64 + lane]);
-    } else {
-      col0 = p.col[slice * 64 + lane];
-      val0 = valp[slice * 64 + lane];
-    }
-  }
-  if (slice < p.nslices) {
-    const int64_t slot = slice * R + g;
-    row = p.slot_row[slot];
-    len = p.slot_len[slot];
-    const SliceHdr hd = p.slice_hdr[slice];
-    base = p.head + hd.ptr - 64;   // chunk k >= 1 at base + k*64
-    nchunks = (p.ablate & 1) ? 0 : hd.nchunks;
-    S = hd.S;
-  }
-  const int seg = g & (S - 1);            // S is a power of two
   const size_t lane_off = (size_t)c * 4 * sizeof(T);
+  unsigned long long err_run = 0;     // running max of this lane's stop values over the blocks it serves (bit patterns)
+
+  // header + chunk 0 of one slice (chunk 0 sits at a slice-indexed address: its load is issued together with the header loads)
+  struct SliceIn { int col0; T val0; int row, len, nchunks, S; int64_t base; };
+  auto load_slice = [&](int64_t slice) -> SliceIn {
+    SliceIn in;
+    in.col0 = 0; in.val0 = 0; in.row = -1; in.len = 0; in.nchunks = 0; in.S = 1; in.base = 0;
+    if (slice < p.nslices) {
+      if (p.nt & 1) {
+        in.col0 = __builtin_nontemporal_load(&p.col[slice * 64 + lane]);
+        in.val0 = __builtin_nontemporal_load(&valp[slice * 64 + lane]);
+      } else {
+        in.col0 = p.col[slice * 64 + lane];
+        in.val0 = valp[slice * 64 + lane];
+      }
+      const int64_t slot = slice * R + g;
+      in.row = p.slot_row[slot];
+      in.len = p.slot_len[slot];
+      const SliceHdr hd = p.slice_hdr[slice];
+      in.base = p.head + hd.ptr - 64;   // chunk k >= 1 at base + k*64
+      in.nchunks = (p.ablate & 1) ? 0 : hd.nchunks;
+      in.S = hd.S;
+    }
+    return in;
+  };
+  auto vb_of = [&](int64_t it) -> int64_t {     // it-th block of this workgroup, or -1
+    if (flat) { const int64_t v = (int64_t)blockIdx.x + it * gridDim.x; return v < p.nblocks ? v : -1; }
+    const int64_t j = (int64_t)(blockIdx.x / 8) + it * gpx;
+    return j < bpx ? (int64_t)(blockIdx.x % 8) * bpx + j : -1;
+  };
+  int64_t vb = vb_of(0);
+  SliceIn nxt;
+  if constexpr (PERSIST) nxt = load_slice(vb >= 0 ? vb * GLX_WPB + wave : p.nslices);
+  for (int64_t it = 0; vb >= 0; ++it) {
+  const int64_t slice = vb * GLX_WPB + wave;
+  SliceIn cur;
+  int64_t vb_next = -1;
+  if constexpr (PERSIST) {
+    cur = nxt;
+    vb_next = vb_of(it + 1);
+    if (vb_next >= 0) nxt = load_slice(vb_next * GLX_WPB + wave);    // in flight during this block's chunk loop
+  } else {
+    cur = load_slice(slice);                                           // one block per workgroup: nothing to look ahead to
+  }
+  const int col0 = cur.col0;
+  const T val0 = cur.val0;
+  const int row = cur.row, len = cur.len, nchunks = cur.nchunks, S = cur.S;
+  const int64_t base = cur.base;
+  const int seg = g & (S - 1);            // S is a power of two
   V4 acc = {0, 0, 0, 0};
   double accw = 0.0;
 
@@ -401,15 +433,8 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
         e = fabs(p.deg[row] * wnew - p.vinf[row]);
         if (e != e) e = __longlong_as_double(0x7ff8000000000000ll);   // canonical NaN: orders above +inf as a bit pattern (np.max propagates NaN)
       }
-      unsigned long long m = wave_max_u64((unsigned long long)__double_as_longlong(e));
-      __shared__ unsigned long long s_err[GLX_WPB];
-      if (lane == 0) s_err[wave] = m;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        unsigned long long mm = s_err[0];
-        for (int w = 1; w < GLX_WPB; ++w) mm = s_err[w] > mm ? s_err[w] : mm;
-        if (mm != 0) atomicMax(&p.err_next[blockIdx.x & 63], mm);
-      }
+      const unsigned long long eb = (unsigned long long)__double_as_longlong(e);
+      err_run = eb > err_run ? eb : err_run;
     }
   }
 
@@ -448,6 +473,23 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
         p.dot_partial[(size_t)vb * p.dot_ld + threadIdx.x * 4 + e] = s;
       }
     }
+    __syncthreads();   // s_red is reused by the workgroup's next block
+  }
+  vb = vb_next;
+  }   // blocks of this workgroup
+
+  if constexpr (HAS_W) {
+    if (p.err_next) {
+      const unsigned long long m = wave_max_u64(err_run);
+      __shared__ unsigned long long s_err[GLX_WPB];
+      if (lane == 0) s_err[wave] = m;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned long long mm = s_err[0];
+        for (int w = 1; w < GLX_WPB; ++w) mm = s_err[w] > mm ? s_err[w] : mm;
+        if (mm != 0) atomicMax(&p.err_next[blockIdx.x & 63], mm);
+      }
+    }
   }
 }
 
@@ -455,15 +497,23 @@ int64_t glx_spmm_blocks(const SellPlan* plan) { return (plan->nslices + GLX_WPB 
 
 template <typename T, int G>
 static int launch_g(const SweepArgs& a, const SpmmParams& p, hipStream_t stream) {
-  const dim3 grid((unsigned)p.nblocks), block(64 * GLX_WPB);
+  // GLX_PERSIST = k > 1: k blocks per workgroup (persistent form, sweeps only: the CG form writes per-block partials)
+  static const int persist = getenv("GLX_PERSIST") ? atoi(getenv("GLX_PERSIST")) : GLX_PERSIST_DEFAULT;
+  int64_t nwg = p.nblocks;
+  if (persist > 1 && !a.dot_partial && p.nblocks >= 8 * (int64_t)persist) nwg = ((p.nblocks / 8 + persist - 1) / persist) * 8;
+  const dim3 grid((unsigned)nwg), block(64 * GLX_WPB);
+  const bool persistent = nwg != p.nblocks;
   if (a.dot_partial) {
     hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, true>), grid, block, 0, stream, p);
   } else if (a.has_w && a.dup_ptr) {
-    hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false, true>), grid, block, 0, stream, p);
+    if (persistent) hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false, true, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false, true>), grid, block, 0, stream, p);
   } else if (a.has_w) {
-    hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false>), grid, block, 0, stream, p);
+    if (persistent) hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false, false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false>), grid, block, 0, stream, p);
   } else {
-    hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, false>), grid, block, 0, stream, p);
+    if (persistent) hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, false, false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, false>), grid, block, 0, stream, p);
   }
   GLX_HIP(hipGetLastError());
   return GLX_OK;

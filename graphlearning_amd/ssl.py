@@ -102,6 +102,20 @@ class ssl:
             self.graph = graph_mod.graph(W)
         self._cache = None      # device-resident operators belong to the previous graph
 
+    def _graph_key(self):
+        """Identity of the graph the cached device operators were built from: the CONTENT fingerprint of the weight matrix
+        (utils.matrix_fingerprint), not its address -- a matrix edited in place between two fits is a new graph, as it is for
+        the reference, which rebuilds its operators in every fit (ssl.py:615-644).  Inside one ssl_trials loop the matrix cannot
+        change under us, so the fingerprint of the loop's first fit is reused (`_trusted_key`)."""
+        W = self.graph.weight_matrix
+        trusted = getattr(self, '_trusted_key', None)
+        if trusted is not None and trusted[0] is W:
+            return trusted[1]
+        key = utils.matrix_fingerprint(W)
+        if trusted is not None:
+            self._trusted_key = (W, key)
+        return key
+
     def volume_label_projection(self):
         """Volume-constrained label decision (reference ssl.py:172-209) on the device:
         at most 1e4 steps of w += -0.1 (class_size - priors); w /= w[0], stop at max error
@@ -173,7 +187,22 @@ class ssl:
         """Run the learner on a list of training sets and record `Number of labels,Accuracy[,...]`
         rows to results/<tag><accuracy filename> (reference ssl.py:292-396, same file format,
         same abort-if-exists rule).  Trials run one after another on the GPU with the operator
-        resident on the device; `num_cores` is accepted for signature compatibility."""
+        resident on the device (stacked as column groups of one solve where the learner supports it).
+        `num_cores` is the reference's number of joblib worker PROCESSES (ssl.py:390-396); here the parallel axis is
+        one process per GPU: with num_cores > 1 inside an initialised torch.distributed job of more than one rank the
+        trials are shared out over the ranks (dist.ssl_trials_distributed: every rank its own GPU, rank 0 writes the file);
+        in a single process the argument changes nothing -- one GPU runs the trials faster than the reference's workers."""
+        if num_cores > 1:
+            try:
+                import torch.distributed as tdist
+                multi = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
+            except ImportError:
+                multi = False
+            if multi:
+                from . import dist as gdist
+                gdist.ssl_trials_distributed(self, trainsets, labels, tdist, tag=tag, save_results=save_results, overwrite=overwrite,
+                                             num_trials=num_trials)
+                return
         if num_trials > 0:
             trainsets = trainsets[:num_trials]
         print('\nModel: ' + self.name)
@@ -203,6 +232,18 @@ class ssl:
         labels = np.asarray(labels)
         trainsets = [np.asarray(t) for t in trainsets]
         batch = 1 if self.onevsrest else max(1, int(self._trial_batch_size(labels)))
+        self._trusted_key = (None, None)         # the graph is fingerprinted once for the whole loop (_graph_key)
+        inner = getattr(self, 'poisson_model', None)
+        if inner is not None:
+            inner._trusted_key = (None, None)
+        try:
+            yield from self._trial_rows_loop(trainsets, labels, batch, with_priors)
+        finally:
+            self._trusted_key = None
+            if inner is not None:
+                inner._trusted_key = None
+
+    def _trial_rows_loop(self, trainsets, labels, batch, with_priors):
         for pos in range(0, len(trainsets), batch):
             group = trainsets[pos:pos + batch]
             # trials that share the graph are stacked as extra right-hand-side columns of ONE device
@@ -327,12 +368,14 @@ class poisson(ssl):
         """Host-side setup shared by every fit on this graph (reference ssl.py:615-617,
         626-627, 634-635, 642-644): zero the diagonal, degrees, P = D^-1 W^T or the
         normalised Laplacian; uploaded once and kept on the device."""
-        key = (id(self.graph.weight_matrix), self.solver, self._dtype())
+        fp = self._graph_key()
+        key = (fp, self.solver, self._dtype())
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1], self._cache[2]
         n = self.graph.num_nodes
         W = self.graph.weight_matrix
-        fast = (self.solver != 'conjugate_gradient' and utils.known_symmetric(W) and not W.diagonal().any())
+        # (a stamped matrix is weightmatrix.knn's output, unchanged: symmetric bit for bit, no diagonal, no stored zeros)
+        fast = self.solver != 'conjugate_gradient' and utils.known_symmetric(W, fp)
         if not fast:
             W = W - sparse.spdiags(W.diagonal(), 0, n, n)
             G = graph_mod.graph(W)
@@ -395,7 +438,9 @@ class poisson(ssl):
             Db = None
             if aux['sweep'] is None:
                 u, T = np.zeros((n, k), dtype=self._dtype()), 0
-            elif len(np.unique(train_ind)) == len(train_ind) and not aux['zero_degree']:
+            elif (len(np.unique(train_ind)) == len(train_ind) and not aux['zero_degree']
+                  and (len(train_ind) == 0 or (train_ind.min() >= 0 and train_ind.max() < n))):
+                # (numpy-style negative indices, which `source[train_ind] = ...` of the reference accepts, take the dense branch below)
                 # Db = D*source and v = 1_train/m are nonzero on the labelled rows only (ssl.py:620-622, 636, 639-641):
                 # those m rows are all a new training set uploads; deg and vinf went up with the prepared sweep
                 onehot = utils.labels_to_onehot(train_labels, k)
@@ -438,7 +483,10 @@ class poisson(ssl):
                         print('%d,Accuracy = %.2f' % (t, acc))
                 finally:
                     step.close()
-                u = self.prob
+                if T > 0:
+                    u = self.prob
+                elif isinstance(u, _DeviceState):      # no sweep ran: u = 0 (ssl.py:645), not whatever a previous fit left in `prob`
+                    u = np.zeros((n, k), dtype=self._dtype())
         elif self.solver == 'spectral':
             raise NotImplementedError("poisson(solver='spectral') needs an eigensolver, which is outside the "
                                       'GPU hot path this package covers (SURVEY.md section 8)')
@@ -559,7 +607,7 @@ class poisson_mbo(ssl):
         labels = self.poisson_model.fit_predict(train_ind, train_labels, all_labels=all_labels)
         u = utils.labels_to_onehot(labels, k)
         # heat operator P = I - dt L and its device image depend on the graph only: kept across fits
-        key = (id(self.graph.weight_matrix), dtype, k)
+        key = (self._graph_key(), dtype, k)
         if self._cache is None or self._cache[0] != key:
             if self._cache is not None:
                 self._cache[2].close()
@@ -674,7 +722,7 @@ class laplace(ssl):
         and columns of L and of M_full = diag((L_ii + 1e-10)^-1/2) at the unlabelled vertices, so
         M A M is that part of M_full L M_full (same products, same entry order).  Built and
         uploaded once per graph; the solves then hold the labelled rows at zero (glx_cg_groups_masked)."""
-        key = (id(self.graph.weight_matrix), self.normalization, np.asarray(self.tau, dtype=np.float64).tobytes(), int(self.order))
+        key = (self._graph_key(), self.normalization, np.asarray(self.tau, dtype=np.float64).tobytes(), int(self.order))
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1:]
         if self._cache is not None:
@@ -785,7 +833,7 @@ class randomwalk(ssl):
     def _operator(self):
         """M L M of reference ssl.py:1779-1786 depends on the graph and alpha only: built and
         uploaded once, shared by every fit on this graph."""
-        key = (id(self.graph.weight_matrix), float(self.alpha))
+        key = (self._graph_key(), float(self.alpha))
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1], self._cache[2]
         if self._cache is not None:

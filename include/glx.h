@@ -19,6 +19,11 @@
  *     workers through joblib): the device is touched on the first call only.
  *   - functions ending in _dev take DEVICE pointers (e.g. torch tensors' data_ptr())
  *     and a hipStream_t passed as void*; they never synchronise.
+ *   - threading: different handles (glx_graph, glx_sweep, glx_dist_sweep) may be used from different
+ *     threads at the same time.  The conjugate-gradient solves of ONE glx_graph share its work buffers:
+ *     the glx_cg_* entry points serialise on the operator (a second thread waits).  A glx_sweep /
+ *     glx_dist_sweep object is owned by one thread at a time -- concurrent calls on the same object are
+ *     the caller's to exclude.
  */
 #ifndef GLX_H
 #define GLX_H
@@ -84,6 +89,10 @@ int glx_graph_info(const glx_graph* g, int64_t info[8]);
 /* the internal vertex order: perm_out[new] = caller's row (n_rows entries; the identity when the operator
  * was not renumbered).  Forces the order to be computed if it has not been yet. */
 int glx_graph_order(glx_graph* g, int32_t* perm_out);
+/* the caller's own locality order instead of the library's pass over the graph: perm[new] = caller's row, a permutation of
+ * 0..n-1 (square operators, before first use).  weightmatrix.knn has the features in hand: an order by a tree over
+ * feature space needs no look at the graph.  Results do not depend on the order (a row's entries keep their order). */
+int glx_graph_set_order(glx_graph* g, const int32_t* perm);
 
 /* u_out = Db + A u_in, applied `iters` times (u fed back).  Db may be NULL (no bias).
  * Replaces `ut = torch.sparse.addmm(Dbt, Pt, ut)` (ssl.py:658, :821) / `u = Db + P*u`

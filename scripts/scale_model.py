@@ -36,12 +36,14 @@ from graphlearning_amd import dist_bench                # noqa: E402
 
 LINK_GBS_PEAK = 76.0      # per direction, per link (153 GB/s bidirectional)
 LINK_GBS_RCCL = 50.0      # assumed achievable by RCCL send/recv per direction (ASSUMPTION)
-ALLREDUCE_US = 20.0       # one small ncclAllReduce(MAX) per check_every = 8 sweeps (ASSUMPTION; 1-rank call measured ~10 us)
+ALLREDUCE_US = 20.0       # one small ncclAllReduce(MAX) + host read per stop-test chunk (ASSUMPTION for real peers; the 1-rank call: ~16 us)
 CHECK_EVERY = 8
+FORK_JOIN_US = 14.0       # cross-stream edges of the captured split form (measured on one rank: 35.0 vs 29.4 us per sweep, profiles/r03_dist_probe.txt)
 
 
 def rank_measurements(P, order, bounds, prob_rows, C, reps):
-    """Per-rank kernel times and halo counts for one partition (all ranks, one after another on the one GPU)."""
+    """Per-rank kernel times and halo counts for one partition (all ranks, one after another on the one GPU): the split
+    form's pieces (boundary rows incl. the scatter, interior rows) and the fused form's one launch."""
     world = len(bounds) - 1
     comm = _hip.Comm(1, 0, None, 0)            # identity only: the pieces are timed without a transport
     out = []
@@ -49,14 +51,22 @@ def rank_measurements(P, order, bounds, prob_rows, C, reps):
         t0 = time.perf_counter()
         plan = gdist.RankPlan(P, order, bounds, r)
         t_plan = time.perf_counter() - t0
-        # a comm of one rank with the plan of rank r of `world`: counts per peer are folded into one pseudo-peer for the object
-        ds = _hip.DistSweep(comm, plan.P_local, plan.n_boundary, [plan.send_idx.size], plan.send_idx, [plan.n_halo], plan.n_global, C,
-                            force_exchange=False, use_hipgraph=False)
         own = plan.own
-        ds.set_problem(prob_rows['Db'][own], prob_rows['w0'][own], prob_rows['deg'][own], prob_rows['vinf'][own])
-        tp = ds.time_parts(reps)
-        rec = ds.lay['rec_bytes']
-        ds.close()
+        tp = {}
+        for form, env in (('split', '0'), ('fused', '1')):
+            os.environ['GLX_DIST_FUSE'] = env
+            # a comm of one rank with the plan of rank r of `world`: counts per peer are folded into one pseudo-peer for the object
+            ds = _hip.DistSweep(comm, plan.P_local, plan.n_boundary, [plan.send_idx.size], plan.send_idx, [plan.n_halo], plan.n_global, C,
+                                force_exchange=False, use_hipgraph=False)
+            ds.set_problem(prob_rows['Db'][own], prob_rows['w0'][own], prob_rows['deg'][own], prob_rows['vinf'][own])
+            t = ds.time_parts(reps)
+            if form == 'split':
+                tp.update(t)
+            else:
+                tp['fused_us'] = t['boundary_us']
+            rec = ds.lay['rec_bytes']
+            ds.close()
+        os.environ.pop('GLX_DIST_FUSE', None)
         out.append(dict(rank=r, n_own=int(plan.n_own), n_boundary=int(plan.n_boundary), n_halo=int(plan.n_halo), nnz=int(plan.P_local.nnz),
                         recv_per_peer=[int(c) for c in plan.recv_counts], send_per_peer=[int(c) for c in plan.send_counts],
                         rec_bytes=int(rec), plan_s=t_plan, **tp))
@@ -64,16 +74,24 @@ def rank_measurements(P, order, bounds, prob_rows, C, reps):
     return out
 
 
-def predict(ranks, latency_us, link_gbs):
-    """sweep(N) and its parts from the per-rank measurements."""
-    per_rank = []
+def predict(ranks, latency_us, link_gbs, T=50, min_iter=50):
+    """sweep(N) and its parts from the per-rank measurements.  Every rank runs the cheaper of its two forms:
+    fused  = one launch for all rows, exchange in line:           fused_r + X_r
+    split  = boundary rows, exchange beside the interior rows:    boundary_r + max(interior_r, X_r) + fork/join
+    (the library picks by the same estimate, glx_dist_sweep_create); stop test: one all-reduce after min_iter sweeps and one per
+    check_every sweeps beyond -- T = min_iter = 50 on the bench graph, i.e. one per 50 sweeps."""
+    per_rank, forms = [], []
     for m in ranks:
         peak_peer = max(max(m['recv_per_peer'], default=0), max(m['send_per_peer'], default=0))
         x = 0.0 if (m['n_halo'] == 0 and sum(m['send_per_peer']) == 0) else latency_us + peak_peer * m['rec_bytes'] / (link_gbs * 1e3)
-        per_rank.append(m['boundary_us'] + max(m['interior_us'], x))
+        fused = m['fused_us'] + x
+        split = m['boundary_us'] + max(m['interior_us'], x) + (FORK_JOIN_US if x > 0 else 0.0)
+        per_rank.append(min(fused, split))
+        forms.append('fused' if fused <= split else 'split')
     any_halo = any(m['n_halo'] > 0 for m in ranks)
-    return dict(sweep_us=max(per_rank) + ALLREDUCE_US / CHECK_EVERY, slowest_rank=int(np.argmax(per_rank)), per_rank_us=per_rank,
-                exchanges_per_sweep=1 if any_halo else 0)
+    n_allreduce = 1 + max(0, -(-(T - min_iter) // CHECK_EVERY))
+    return dict(sweep_us=max(per_rank) + ALLREDUCE_US * n_allreduce / max(T, 1), slowest_rank=int(np.argmax(per_rank)), per_rank_us=per_rank,
+                forms=forms, exchanges_per_sweep=1 if any_halo else 0)
 
 
 def single_rank_sweep_us(P, prob, C, reps=3, T=50):
@@ -102,6 +120,7 @@ def rccl_latency_us(P70k, order, prob, C):
     plan = _self_halo_plan(Pr, 7)
     plan.own = order[plan.own]
     res = {}
+    os.environ['GLX_DIST_FUSE'] = '1'           # one launch + the exchange in line: sweep - launch = the exchange itself
     for name, uid in (('copy', None), ('rccl', 'rccl')):
         try:
             comm = _hip.Comm(1, 0, _hip.Comm.unique_id() if uid else None, 0)
@@ -117,11 +136,16 @@ def rccl_latency_us(P70k, order, prob, C):
         ms = sum(ds.run(50, 50, CHECK_EVERY, 0.0)[1] for _ in range(5))
         res[name] = ms * 1e3 / 250
         res[name + '_info'] = ds.info()
+        res[name + '_launch_alone_us'] = ds.time_parts(50)['boundary_us']
         res['halo_records'] = int(plan.n_halo)
+        res['halo_bytes'] = int(plan.n_halo) * ds.lay['rec_bytes']
         ds.close()
         comm.close()
-    if res.get('copy') and res.get('rccl'):
-        res['latency_us'] = max(0.0, res['rccl'] - res['copy'])
+    os.environ.pop('GLX_DIST_FUSE', None)
+    if res.get('rccl'):
+        # what one grouped ncclSend/ncclRecv exchange of `halo_bytes` costs in line; the part that is not bandwidth is the latency
+        res['exchange_us'] = max(0.0, res['rccl'] - res['rccl_launch_alone_us'])
+        res['latency_us'] = max(0.0, res['exchange_us'] - res['halo_bytes'] / (LINK_GBS_RCCL * 1e3))
     return res
 
 
@@ -141,9 +165,10 @@ def main():
     def log(msg):
         print('[scale_model %6.1f s] %s' % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
     result = dict(assumptions=dict(link_GBs_peak_per_direction=LINK_GBS_PEAK, link_GBs_rccl_assumed=LINK_GBS_RCCL, allreduce_us=ALLREDUCE_US,
-                                   check_every=CHECK_EVERY,
-                                   model='sweep(N) = max_r[boundary_r + max(interior_r, L + max_peer bytes / link rate)] + allreduce/check_every; '
-                                         'kernel times measured per virtual rank on ONE MI355X (glx_dist_sweep_time_parts)'),
+                                   check_every=CHECK_EVERY, fork_join_us=FORK_JOIN_US,
+                                   model='sweep(N) = max_r min(fused_r + X_r, boundary_r + max(interior_r, X_r) + fork_join) + allreduces/T; '
+                                         'X_r = L + max_peer bytes / link rate; kernel times measured per virtual rank on ONE MI355X '
+                                         '(glx_dist_sweep_time_parts)'),
                   libglx_source_hash=__import__('graphlearning_amd._build', fromlist=['x']).source_hash())
 
     # ---- transport latency, measured on the 70k graph

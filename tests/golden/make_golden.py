@@ -386,6 +386,49 @@ def g4_large():
         json.dump(meta, f, indent=1)
 
 
+def g4_samples():
+    """Adds `u_samples` to the config-2 and config-3 entries of g4_large_meta.json: 1000 sampled entries (row, column, value)
+    of the REFERENCE's iterates at full size -- Poisson gradient descent and Poisson CG at 70k, Laplace at 60k -- so that
+    the GPU tests bound the end-to-end iterates element-wise (north star: within 1e-5), not only by checksums."""
+    path = os.path.join(HERE, 'g4_large_meta.json')
+    meta = json.load(open(path))
+    pick = np.random.default_rng(12345)
+
+    def sample(prob):
+        rows = pick.integers(0, prob.shape[0], size=1000)
+        cols = pick.integers(0, prob.shape[1], size=1000)
+        return dict(rows=[int(r) for r in rows], cols=[int(c) for c in cols], values=[float(v) for v in prob[rows, cols]])
+    labels = np.load('/root/reference/Data/MNIST_labels.npz')['labels'].astype(np.int64)
+    rng = np.random.default_rng(0)
+    centers = rng.normal(size=(10, 20)) * 2.0
+    X = centers[labels] + rng.normal(size=(70000, 20))
+    J, D = gl.weightmatrix.knnsearch(X, 11, method='kdtree')
+    assert sha(J.astype(np.int64)) == meta['config2']['J_sha']
+    W = gl.weightmatrix.knn(X, 10, knn_data=(J, D))
+    train_ind = gl.trainsets.generate(labels, rate=1, seed=0)
+    prob = gl.ssl.poisson(W, solver='gradient_descent').fit(train_ind, labels[train_ind])
+    assert abs(float(np.abs(prob).sum()) - meta['config2']['prob_abs_sum']) == 0.0
+    meta['config2']['u_samples'] = sample(prob)
+    probc = gl.ssl.poisson(W).fit(train_ind, labels[train_ind])
+    assert float(np.abs(probc).sum()) == meta['config2']['cg_prob_abs_sum']
+    meta['config2']['cg_u_samples'] = sample(probc)
+    print('config2 samples recorded; max |u| of the sample %.3e' % np.max(np.abs(meta['config2']['u_samples']['values'])))
+    clabels = np.load('/root/reference/Data/cifar_labels.npz')['labels'].astype(np.int64)
+    rng = np.random.default_rng(1)
+    centers = rng.normal(size=(10, 32)) * 1.2
+    X = centers[clabels] + rng.normal(size=(60000, 32))
+    J, D = gl.weightmatrix.knnsearch(X, 21, method='kdtree')
+    assert sha(J.astype(np.int64)) == meta['config3']['J_sha']
+    W = gl.weightmatrix.knn(X, 20, knn_data=(J, D))
+    train_ind = gl.trainsets.generate(clabels, rate=10, seed=0)
+    prob = gl.ssl.laplace(W).fit(train_ind, clabels[train_ind])
+    assert float(np.abs(prob).sum()) == meta['config3']['prob_abs_sum']
+    meta['config3']['u_samples'] = sample(prob)
+    print('config3 samples recorded')
+    with open(path, 'w') as f:
+        json.dump(meta, f, indent=1)
+
+
 def _config5(W, labels, train_ind):
     """Config 5: PoissonMBO on the config-2 graph (reference ssl.py:774-839), 851 SpMMs + 21 volume projections."""
     pri = gl.utils.class_priors(labels)

@@ -216,20 +216,26 @@ def test_glx_dist_one_rank_forced_halo(golden, transport):
     comm.close()
 
 
-@pytest.mark.parametrize('mode', ['scatter', 'pack', 'fused', 'selftest', 'eager'])
+@pytest.mark.parametrize('mode', ['auto', 'split', 'split_pack', 'split_inline', 'fused', 'selftest', 'eager'])
 def test_glx_dist_exchange_forms(golden, mode, monkeypatch):
     """Round-3 forms of the exchanging sweep on ONE rank with a forced self-halo through a 1-rank RCCL communicator, all
-    bit-identical to the golden iterates: the boundary SpMM scattering its rows into the send buffer (default), the
-    round-2 pack kernel (GLX_DIST_PACK=1), one launch per sweep (GLX_DIST_FUSE), the capture decided by the self-test
-    (GLX_DIST_CAPTURE_EXCHANGE=-1: three eager sweeps against three captured + replayed ones), and eager sweeps."""
+    bit-identical to the golden iterates: the form the library picks by itself (a halo this small: ONE launch per sweep, the
+    exchange in line), the split form [boundary rows | exchange beside the interior rows] with the boundary SpMM scattering
+    its rows into the send buffer, with the round-2 pack kernel (GLX_DIST_PACK=1) and with the exchange in line, the fused
+    form forced, the capture decided by the self-test (GLX_DIST_CAPTURE_EXCHANGE=-1: three eager sweeps against three
+    captured + replayed ones), and eager sweeps."""
     from graphlearning_amd import dist as gdist, _hip
     _hip.require_device()
-    for k in ('GLX_DIST_PACK', 'GLX_DIST_FUSE', 'GLX_DIST_CAPTURE_EXCHANGE'):
+    for k in ('GLX_DIST_PACK', 'GLX_DIST_FUSE', 'GLX_DIST_CAPTURE_EXCHANGE', 'GLX_DIST_OVERLAP'):
         monkeypatch.delenv(k, raising=False)
-    if mode == 'pack':
+    if mode.startswith('split'):
+        monkeypatch.setenv('GLX_DIST_FUSE', '0')
+    if mode == 'split_pack':
         monkeypatch.setenv('GLX_DIST_PACK', '1')
+    elif mode == 'split_inline':
+        monkeypatch.setenv('GLX_DIST_OVERLAP', '0')
     elif mode == 'fused':
-        monkeypatch.setenv('GLX_DIST_FUSE', '100')
+        monkeypatch.setenv('GLX_DIST_FUSE', '1')
     elif mode == 'selftest':
         monkeypatch.setenv('GLX_DIST_CAPTURE_EXCHANGE', '-1')
     elif mode == 'eager':
@@ -252,7 +258,8 @@ def test_glx_dist_exchange_forms(golden, mode, monkeypatch):
         assert np.array_equal(full, g['poisson_gd_prob'])
     info = ds.info()
     assert info['exchanging'] and info['send_records'] == plan.n_halo and info['halo_records'] == plan.n_halo
-    assert info['scatter'] == (mode != 'pack') and info['fused'] == (mode == 'fused')
+    assert info['scatter'] == (mode != 'split_pack') and info['fused'] == (not mode.startswith('split'))
+    assert info['overlap'] == (mode in ('split', 'split_pack'))
     if mode == 'selftest':
         assert info['selftest'] == 'passed' and info['exchange'] == 'captured'
     elif mode == 'eager':
@@ -260,7 +267,7 @@ def test_glx_dist_exchange_forms(golden, mode, monkeypatch):
     else:
         assert info['selftest'] == 'not run' and info['exchange'] == 'captured'
     tp = ds.time_parts(5)
-    assert tp['boundary_us'] > 0 and tp['both_us'] > 0 and (mode == 'fused' or tp['interior_us'] > 0)
+    assert tp['boundary_us'] > 0 and tp['both_us'] > 0 and (info['fused'] or tp['interior_us'] > 0)
     print('exchange form %-8s: %.1f us per sweep; parts %s' % (mode, ms * 1e3 / max(T, 1), tp))
     ds.close()
     comm.close()
