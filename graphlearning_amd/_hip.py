@@ -88,6 +88,9 @@ _SIGNATURES = {
     'glx_sweep_step_dev': [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'glx_pack_records_dev': [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp],
     'glx_unpack_records_dev': [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp],
+    'glx_rec_dots_dev': [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp],
+    'glx_rec_axpy2_dev': [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp],
+    'glx_rec_xpby_dev': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp],
     'glx_dist_unique_id': [_vp],
     'glx_dist_init_rank': [C.c_int, C.c_int, _vp, C.c_int, C.POINTER(_vp)],
     'glx_dist_init': [C.c_int, _vp, C.POINTER(_vp)],
@@ -126,7 +129,7 @@ _SIGNATURES = {
     'glx_host_reverse_scale_rows': [C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp],
     'glx_knn_to_csr_into': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, _i64p, C.c_int],
 }
-_SPECIAL = {'glx_last_error': ([], C.c_char_p), 'glx_free': ([_vp], None)}
+_SPECIAL = {'glx_last_error': ([], C.c_char_p), 'glx_free': ([_vp], None), 'glx_rec_dots_scratch': ([C.c_int64, C.c_int], C.c_int64)}
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SPECIAL))
 

@@ -54,9 +54,9 @@ def crossing_counts(P, order):
     return np.cumsum(diff)[:n + 1]
 
 
-def _best_cuts(cross, n, world, cap, cand):
-    """world-1 increasing cut positions among `cand` with every block <= cap rows, minimising the
-    total crossing count, ties towards balanced blocks (least sum of squared block sizes, then the
+def _best_cuts(xc, n, world, cap, cand):
+    """world-1 increasing cut positions among `cand` (xc[i] = entries crossing a cut at cand[i]) with every block <= cap
+    rows, minimising the total crossing count, ties towards balanced blocks (least sum of squared block sizes, then the
     earliest predecessor).  Returns (total crossing, cuts) or None.  Dynamic programme over (number of
     cuts placed, last cut), one numpy pass per cut: O(world * len(cand)^2) array work."""
     c = np.asarray(cand, dtype=np.int64)
@@ -64,7 +64,7 @@ def _best_cuts(cross, n, world, cap, cand):
     if m == 0:
         return None
     BIG = np.iinfo(np.int64).max // 4
-    xc = cross[c].astype(np.int64)
+    xc = np.asarray(xc).astype(np.int64)
     ok0 = c <= cap
     cost = np.where(ok0, xc, BIG)                         # crossings of the cuts placed so far, last cut at c[j]
     bal = np.where(ok0, c * c, BIG)                       # sum of squared sizes of the blocks closed so far
@@ -116,10 +116,17 @@ def cut_bounds(P, order, world, slack_levels=(0.0, 0.1, 0.25, 0.45, 0.65, 0.85))
         if hi > lo:
             cand.add(int(lo + np.argmin(cross[lo:hi])))
     cand = sorted(c for c in cand if 0 < c < n)
+    return choose_cuts(cross[np.asarray(cand, dtype=np.int64)] if cand else np.zeros(0, np.int64), cand, n, world, slack_levels)
+
+
+def choose_cuts(xc, cand, n, world, slack_levels=(0.0, 0.1, 0.25, 0.45, 0.65, 0.85)):
+    """Block boundaries among the candidate positions `cand` (xc[i] = entries crossing a cut at cand[i]): for growing allowed
+    imbalance the cuts of least total crossing; a larger slack is accepted only if it removes the crossings entirely or
+    cuts them at least four-fold (cut_bounds).  Falls back to equal blocks."""
     chosen = None
     for slack in slack_levels:
         cap = int(np.ceil((1.0 + slack) * n / world))
-        res = _best_cuts(cross, n, world, cap, cand)
+        res = _best_cuts(xc, n, world, cap, cand)
         if res is None:
             continue
         if chosen is None or res[0] == 0 or 4 * res[0] <= chosen[0]:
@@ -703,6 +710,246 @@ def poisson_fit_distributed(W, train_ind, train_labels, dist, ops_factory, min_i
     for ids, block in parts:
         u[ids] = block
     return u, T
+
+
+# ---- vertex-partitioned conjugate gradient (tolerance mode) ----------------------------------------------------------
+# ssl.laplace / ssl.randomwalk solve SPD systems with utils.conjgrad (reference utils.py:483-532).  Across ranks: every
+# iteration exchanges the boundary rows of p (the same all-to-all-v as the sweep), multiplies the rank's rows, and adds the
+# ranks' column sums of p*Ap and r*r with one all-reduce each.  The summation order then depends on the
+# partition, so this is the tolerance mode (iterates within 1e-5 of the reference, identical labels: `reduce='tree'` on one
+# GPU makes the same trade).  Poisson's default CG solve stays on one GPU: its system is singular, and its 140+ iterations
+# amplify a reordered reduction into another iteration count and iterates that differ by far more than 1e-5.
+class CgScipyOps:
+    """Rank-local pieces of the distributed CG on numpy arrays (CPU tests over gloo)."""
+    supports_graph = False
+
+    def __init__(self, plan, C):
+        self.plan, self.C = plan, C
+
+    def to_device(self, a, dtype=None):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    def index_rows(self, x, idx):
+        return x.index_select(0, idx)
+
+    def state(self, dense_own, rows):
+        import torch
+        t = torch.zeros((rows, self.C), dtype=torch.float64)
+        if dense_own is not None:
+            t[:dense_own.shape[0]] = torch.from_numpy(np.ascontiguousarray(dense_own, dtype=np.float64))
+        return t
+
+    def spmm(self, p_loc, Ap):
+        Ap.copy_(self.to_device(self.plan.P_local * p_loc.numpy()))
+
+    def dots(self, a, b):
+        n = self.plan.n_own
+        return np.sum(a[:n].numpy() * b[:n].numpy(), axis=0)
+
+    def axpy2(self, x, r, p_loc, Ap, alpha):
+        n = self.plan.n_own
+        x.numpy()[...] += alpha * p_loc[:n].numpy()
+        r.numpy()[...] -= alpha * Ap.numpy()
+
+    def xpby(self, p_loc, r, beta):
+        n = self.plan.n_own
+        p_loc.numpy()[:n] = r.numpy() + beta * p_loc[:n].numpy()
+
+    def to_host(self, x):
+        return np.array(x.numpy())
+
+    def close(self):
+        pass
+
+
+class CgHipOps:
+    """Rank-local pieces of the distributed CG on torch CUDA tensors in libglx's record layout: the sliced-ELL SpMM
+    (glx_sweep_step_dev) and the dense vector kernels of csrc/vecops.hip (glx_rec_*_dev)."""
+    supports_graph = True
+
+    def __init__(self, plan, C, device=None, dtype=np.float64):
+        import torch
+        from . import _hip
+        self.torch, self._hip, self.plan, self.C = torch, _hip, plan, C
+        self.dtype = np.dtype(dtype)
+        self.tdtype = torch.float64 if self.dtype == np.float64 else torch.float32
+        device = _hip.default_device() if device is None else int(device)
+        self.device = torch.device('cuda', device)
+        _assert_single_hip_runtime()
+        self.lay = _hip.record_layout(C, self.dtype, False)
+        self.ld = self.lay['ld']
+        self.graph = _hip.DeviceGraph(plan.P_local, dtype=self.dtype, device=device, shape=plan.P_local.shape, keep_order=True)
+        nscr = int(_hip.load().glx_rec_dots_scratch(max(plan.n_own, 1), C))
+        self.scratch = torch.zeros(nscr, dtype=torch.float64, device=self.device)
+        self.dot_out = torch.zeros(max(C, 1), dtype=torch.float64, device=self.device)
+
+    def _stream(self):
+        return self._hip._vp(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def to_device(self, a, dtype=None):
+        t = self.torch.from_numpy(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device)
+
+    def index_rows(self, x, idx):
+        return x.index_select(0, idx)
+
+    def state(self, dense_own, rows):
+        rec = self.torch.zeros((rows, self.ld), dtype=self.tdtype, device=self.device)
+        if dense_own is not None:
+            d = self.to_device(dense_own, self.tdtype)
+            self._hip.check(self._hip.load().glx_pack_records_dev(d.data_ptr(), rec.data_ptr(), dense_own.shape[0], self.C,
+                                                                  self._hip._dt(self.dtype), 0, None, self._stream()), 'glx_pack_records_dev')
+            self.torch.cuda.current_stream(self.device).synchronize()
+        return rec
+
+    def spmm(self, p_loc, Ap):
+        self._hip.check(self._hip.load().glx_sweep_step_dev(self.graph._h, self.C, 0, p_loc.data_ptr(), Ap.data_ptr(), None, None, None, None,
+                                                            None, self._stream()), 'glx_sweep_step_dev')
+
+    def dots(self, a, b):
+        self._hip.check(self._hip.load().glx_rec_dots_dev(a.data_ptr(), b.data_ptr(), self.plan.n_own, self.C, self._hip._dt(self.dtype), 0,
+                                                          self.scratch.data_ptr(), self.dot_out.data_ptr(), self._stream()), 'glx_rec_dots_dev')
+        return self.dot_out[:self.C].cpu().numpy().copy()
+
+    def axpy2(self, x, r, p_loc, Ap, alpha):
+        al = self.to_device(np.ascontiguousarray(alpha, dtype=np.float64))
+        self._hip.check(self._hip.load().glx_rec_axpy2_dev(x.data_ptr(), r.data_ptr(), p_loc.data_ptr(), Ap.data_ptr(), al.data_ptr(),
+                                                           self.plan.n_own, self.C, self._hip._dt(self.dtype), 0, self._stream()), 'glx_rec_axpy2_dev')
+        self.torch.cuda.current_stream(self.device).synchronize()      # `al` dies here
+
+    def xpby(self, p_loc, r, beta):
+        be = self.to_device(np.ascontiguousarray(beta, dtype=np.float64))
+        self._hip.check(self._hip.load().glx_rec_xpby_dev(p_loc.data_ptr(), r.data_ptr(), be.data_ptr(), self.plan.n_own, self.C,
+                                                          self._hip._dt(self.dtype), 0, self._stream()), 'glx_rec_xpby_dev')
+        self.torch.cuda.current_stream(self.device).synchronize()
+
+    def to_host(self, x):
+        out = self.torch.empty((self.plan.n_own, self.C), dtype=self.tdtype, device=self.device)
+        self._hip.check(self._hip.load().glx_unpack_records_dev(x.data_ptr(), out.data_ptr(), self.plan.n_own, self.C, self._hip._dt(self.dtype), 0,
+                                                                self._stream()), 'glx_unpack_records_dev')
+        return out.cpu().numpy()
+
+    def close(self):
+        self.graph.close()
+
+
+def cg_distributed(A, B, dist, ops_factory, tol=1e-10, max_iter=100000, order=None, partition='even', group=None, gather=True):
+    """utils.conjgrad (reference utils.py:483-532: multi right-hand-side CG from x = 0, per-column alpha / beta, global stop
+    sqrt(sum over all columns of |r|^2) <= tol) for a symmetric positive definite A whose rows are partitioned over the
+    ranks of `dist`; every rank holds the host matrix and calls this collectively.  Per iteration: one halo exchange of the
+    boundary rows of p, the rank's rows of A p, two all-reduces of C column sums.  Returns (x, iterations, err) with x the full
+    (n, C) solution (gather=True) or (x_own, iterations, err, plan)."""
+    import torch
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    A = sparse.csr_matrix(A)
+    n = A.shape[0]
+    B = np.asarray(B, dtype=np.float64)
+    C = B.shape[1]
+    if order is None:
+        order = locality_order(A)
+    bounds = cut_bounds(A, order, world) if partition == 'cut' else block_bounds(n, world)
+    plan = RankPlan(A, order, bounds, rank)
+    ops = ops_factory(plan, C)
+    xch = DistSweep(plan, ops, dist, group)          # its exchange(): boundary records of p[0:n_own] -> the peers' halo regions p[n_own:]
+    n_own, n_loc = plan.n_own, plan.n_own + plan.n_halo
+    own = plan.own
+
+    def allsum(v):
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64))
+        if world > 1:
+            if dist.get_backend(group) == 'nccl':
+                t = t.to(ops.device)
+            dist.all_reduce(t, group=group)
+        return t.cpu().numpy()
+
+    x = ops.state(None, n_own)
+    r = ops.state(B[own], n_own)
+    p = ops.state(B[own], n_loc)                      # p = r; the halo rows arrive with the first exchange
+    Ap = ops.state(None, n_own)
+    rsold = allsum(ops.dots(r, r))
+    err, it = 1.0, 0
+    while err > tol and it < max_iter:                # utils.py:519
+        it += 1
+        xch.exchange(p)
+        ops.spmm(p, Ap)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            alpha = rsold / allsum(ops.dots(p, Ap))
+        ops.axpy2(x, r, p, Ap, alpha)
+        rsnew = allsum(ops.dots(r, r))
+        err = float(np.sqrt(np.sum(rsnew)))
+        with np.errstate(divide='ignore', invalid='ignore'):
+            ops.xpby(p, r, rsnew / rsold)
+        rsold = rsnew
+    x_own = ops.to_host(x)
+    ops.close()
+    if not gather:
+        return x_own, it, err, plan
+    parts = [None] * world
+    dist.all_gather_object(parts, (own, x_own), group=group)
+    xf = np.zeros((n, C), dtype=x_own.dtype)
+    for ids, block in parts:
+        xf[ids] = block
+    return xf, it, err
+
+
+def laplace_fit_distributed(W, train_ind, train_labels, dist, ops_factory, normalization='combinatorial', tau=0, mean_shift=False, tol=1e-5,
+                            order=None, partition='even', group=None):
+    """ssl.laplace(W, ...).fit across the ranks of `dist` (reference ssl.py:1206-1261; reweighting 'none', order 1): the
+    Jacobi-scaled Dirichlet system M A M, A = L[unl, unl], embedded in the full vertex set -- rows and columns of the labelled
+    vertices replaced by the identity, zero right-hand side there -- so that the rank partition is one of ALL vertices and x
+    stays zero on the labelled rows; solved by cg_distributed.  Tolerance mode: labels identical, iterates within 1e-5 of the
+    reference.  Returns (u (n, C), CG iterations)."""
+    from . import graph as graph_mod
+    from . import utils
+    n = W.shape[0]
+    G = graph_mod.graph(W)
+    tau_v = np.ones(n) * tau if np.isscalar(tau) else np.asarray(tau, dtype=np.float64)
+    L = sparse.csr_matrix(sparse.spdiags(tau_v, 0, n, n) + G.laplacian(normalization=normalization))
+    train_ind = np.asarray(train_ind)
+    k = len(np.unique(train_labels))
+    F = utils.labels_to_onehot(np.asarray(train_labels), k)
+    unl = np.ones(n, dtype=bool)
+    unl[train_ind] = False
+    b = -L[:, train_ind] * F                                    # ssl.py:1236
+    Mv = 1 / np.sqrt(L.diagonal() + 1e-10)                      # ssl.py:1244-1246 (A_ii = L_ii)
+    Z = sparse.spdiags(unl.astype(np.float64), 0, n, n).tocsr()
+    M = sparse.spdiags(Mv, 0, n, n).tocsr()
+    Afull = sparse.csr_matrix(Z * (M * L * M) * Z + sparse.spdiags((~unl).astype(np.float64), 0, n, n))
+    Afull.eliminate_zeros()
+    rhs = (Mv[:, None] * b) * unl[:, None]
+    if order is None:
+        order = locality_order(L)
+    x, it, _ = cg_distributed(Afull, rhs, dist, ops_factory, tol=tol, order=order, partition=partition, group=group)
+    u = Mv[:, None] * x                                         # ssl.py:1250
+    u[train_ind, :] = F                                         # ssl.py:1253-1255
+    if mean_shift:
+        u -= np.mean(u, axis=0)
+    return u, it
+
+
+def randomwalk_fit_distributed(W, train_ind, train_labels, dist, ops_factory, alpha=0.95, order=None, partition='even', group=None):
+    """ssl.randomwalk(W, alpha).fit across the ranks of `dist` (reference ssl.py:1765-1793): the Jacobi-scaled system
+    M L M with L = (1-alpha) I + alpha L_normalized, tol 1e-6, by cg_distributed.  Returns (u, CG iterations)."""
+    from . import graph as graph_mod
+    from . import utils
+    n = W.shape[0]
+    W = sparse.csr_matrix(W)
+    W = W - sparse.spdiags(W.diagonal(), 0, n, n)
+    G = graph_mod.graph(W)
+    L = (1 - alpha) * sparse.identity(n) + alpha * G.laplacian(normalization='normalized')
+    Md = sparse.spdiags(1 / np.sqrt(L.diagonal() + 1e-10), 0, n, n).tocsr()
+    k = len(np.unique(train_labels))
+    onehot = utils.labels_to_onehot(np.asarray(train_labels), k)
+    Y = np.zeros((n, onehot.shape[1]))
+    Y[np.asarray(train_ind), :] = onehot
+    A = sparse.csr_matrix(Md * L * Md)
+    if order is None:
+        order = locality_order(A)
+    x, it, _ = cg_distributed(A, Md * Y, dist, ops_factory, tol=1e-6, order=order, partition=partition, group=group)
+    return Md * x, it
 
 
 def ssl_trials_distributed(model, trainsets, labels, dist, tag='', save_results=True, overwrite=False, num_trials=-1, group=None):

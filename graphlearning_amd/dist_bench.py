@@ -272,6 +272,35 @@ def config4_features(n, world_shards=64, seed=2, d=64, C=10):
     return X, labels
 
 
+def config4_features_sharded(n, dist, dev, rank, world, world_shards=64, seed=2, d=64, C=10):
+    """The same data with every rank generating only ITS share of the 64 shard-local streams (shards rank*64/N ..
+    (rank+1)*64/N) -- host work proportional to n/N -- and the ranks all-gathering the blocks over RCCL.  Returns
+    (X as a float64 tensor on `dev` -- the coarse order is computed there --, labels as a host array)."""
+    import torch
+    centers = np.random.default_rng(seed).normal(size=(C, d)) * 4
+    sb = [(n * q) // world_shards for q in range(world_shards + 1)]
+    q0, q1 = (world_shards * rank) // world, (world_shards * (rank + 1)) // world
+    rows = [sb[(world_shards * r) // world] for r in range(world + 1)]          # row ranges of the ranks' shares
+    Xp = np.empty((rows[rank + 1] - rows[rank], d))
+    lp = np.empty(rows[rank + 1] - rows[rank], dtype=np.int64)
+    for q in range(q0, q1):
+        lo, hi = sb[q] - rows[rank], sb[q + 1] - rows[rank]
+        g = np.random.default_rng([seed, q])
+        lp[lo:hi] = g.integers(0, C, size=hi - lo)
+        Xp[lo:hi] = centers[lp[lo:hi]] + g.normal(size=(hi - lo, d))
+    if world == 1:
+        return torch.from_numpy(Xp).to(dev), lp
+    width = max(rows[r + 1] - rows[r] for r in range(world))
+    mine = torch.zeros((width, d + 1), dtype=torch.float64, device=dev)           # last column: the label
+    mine[:len(Xp), :d] = torch.from_numpy(Xp).to(dev)
+    mine[:len(Xp), d] = torch.from_numpy(lp.astype(np.float64)).to(dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    X = torch.cat([parts[r][:rows[r + 1] - rows[r], :d] for r in range(world)])
+    labels = torch.cat([parts[r][:rows[r + 1] - rows[r], d] for r in range(world)]).to(torch.int64).cpu().numpy()
+    return X, labels
+
+
 def main_config4(args):
     """bench.py --gpus N --config 4: STRONG scaling of config 4 (BASELINE.json configs[3]): n vertices in total (default
     10^7), d = 64, k = 10, C = 10, Poisson gradient descent with a fixed T = 200 sweeps per step, the graph built sharded
@@ -298,27 +327,41 @@ def main_config4(args):
         if rank == 0:
             print('[config 4] %7.1f s  %s' % (time.perf_counter() - t_start, what), file=sys.stderr, flush=True)
     t0 = time.perf_counter()
-    X, labels = config4_features(n)
+    Xt, labels = config4_features_sharded(n, dist, dev, rank, world)       # every rank generates 1/N of the rows
     t_feat = time.perf_counter() - t0
-    progress('features generated (n = %d)' % n)
+    progress('features generated (n = %d; this rank: %d rows) and all-gathered' % (n, n // world))
     # points arrive in arbitrary order: a contiguous block of them would reference nearly every other vertex.  A coarse
-    # geometric order first (64 cells, chained), identical on every rank; the block a rank owns is then compact and its
-    # halo is what crosses the block boundaries
+    # geometric order first (64 cells, chained), identical on every rank and computed on the GPU; the block a rank owns
+    # is then compact, and the cell starts are where block boundaries may fall between clusters
     t0 = time.perf_counter()
-    perm = dist_build.coarse_locality_order(X, ncells=64, seed=0)
-    X, labels = np.ascontiguousarray(X[perm]), labels[perm]
+    perm_t, cell_starts = dist_build.coarse_locality_order_torch(Xt, ncells=64, seed=0)
+    X = Xt[perm_t].cpu().numpy()
+    labels = labels[perm_t.cpu().numpy()]
+    del Xt, perm_t
+    torch.cuda.empty_cache()
     t_order = time.perf_counter() - t0
-    progress('coarse locality order applied')
-    bounds = gdist.block_bounds(n, world)
-    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    progress('coarse locality order applied (on the device)')
+    even = gdist.block_bounds(n, world)                                     # the search is balanced by rows: equal blocks
+    lo, hi = int(even[rank]), int(even[rank + 1])
     t0 = time.perf_counter()
     J, D = _hip.knn_bruteforce(X, K + 1, device=local_rank, query_range=(lo, hi))
     st = _hip.knn_stats()
     t_knn = time.perf_counter() - t0
-    progress('kNN lists of the own rows (tile kernel %.1f s, %d fallback rows)' % (st['tile_ms'] / 1e3, st['fallback_rows']))
+    progress('kNN lists of %d query rows (tile kernel %.1f s, %d fallback rows)' % (hi - lo, st['tile_ms'] / 1e3, st['fallback_rows']))
     del X
+    # the sweep's blocks follow the graph: boundaries at the cell starts that cross the fewest list entries (between clusters: none),
+    # the lists move to their new owners (GLX_CONFIG4_PARTITION=even keeps the equal blocks)
     t0 = time.perf_counter()
-    sg = dist_build.ShardedGraph(dist, n, J, D, K, device=dev)
+    partition = os.environ.get('GLX_CONFIG4_PARTITION', 'cut')
+    bounds = even
+    if partition == 'cut' and world > 1:
+        bounds = dist_build.graph_cut_bounds(dist, n, np.asarray(J), lo, cell_starts, device=dev)
+        J, D = dist_build.redistribute_rows(dist, [np.ascontiguousarray(J, dtype=np.int64), np.ascontiguousarray(D, dtype=np.float64)], even, bounds,
+                                            device=dev)
+    t_cut = time.perf_counter() - t0
+    progress('block boundaries %s' % [int(b) for b in bounds])
+    t0 = time.perf_counter()
+    sg = dist_build.ShardedGraph(dist, n, J, D, K, device=dev, bounds=bounds)
     del J, D
     train_ind = gl.trainsets.generate(labels, rate=5, seed=0)
     prob = sg.poisson_problem_rows(train_ind, labels[train_ind])
@@ -360,8 +403,8 @@ def main_config4(args):
             'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic',
             'config': {'workload': 'configs[3]: Gaussian blobs n=%d d=64 k=10 C=10, ssl.poisson gradient_descent with T=%d fixed sweeps per '
-                                   'step, vertex-sharded over %d GPUs (coarse geometric order, then contiguous blocks; sharded kNN search, symmetrisation '
-                                   'by owner rank, request-based halo plan), RCCL all-to-all-v halo exchange per sweep' % (n, T, world),
+                                   'step, vertex-sharded over %d GPUs (coarse geometric order, sharded kNN search, block boundaries placed where the fewest '
+                                   'list entries cross, symmetrisation by owner rank, request-based halo plan), RCCL all-to-all-v halo exchange per sweep' % (n, T, world),
                        'n': n, 'nnz': nnz, 'classes': 10, 'sweeps_per_step': T, 'parallelism': 'vertex-partition x%d' % world},
             'edges_classes_per_sec': iters * nnz * 10,
             'roofline': {'bound': 'hbm', 'achieved': abytes * iters / 1e9, 'peak': bench.HBM_PEAK_GBS * world, 'unit': 'GB/s',
@@ -371,7 +414,9 @@ def main_config4(args):
             'cpu_baseline': None,
             'halo': {'rows_per_rank': [int(a[0]) for a in allst], 'owned_per_rank': [int(a[1]) for a in allst],
                      'boundary_rows_per_rank': [int(a[3]) for a in allst]},
-            'build': {'features_s': t_feat, 'locality_order_s': t_order, 'knn_own_rows_s': t_knn, 'knn_tile_tflops_rank0': 2.0 * (hi - lo) * n * st['dpa'] / st['tile_ms'] / 1e9,
+            'partition': {'kind': partition if world > 1 else 'one block', 'bounds': [int(b) for b in bounds]},
+            'build': {'features_s': t_feat, 'locality_order_s': t_order, 'knn_own_rows_s': t_knn, 'cut_and_redistribute_s': t_cut,
+                      'host_work_note': 'features: every rank generates n/N rows; order: on the device; search: n/N query rows; symmetrisation and plan: the rank\'s own rows', 'knn_tile_tflops_rank0': 2.0 * (hi - lo) * n * st['dpa'] / st['tile_ms'] / 1e9,
                       'symmetrise_plan_s': t_build},
             'accuracy_percent': 100.0 * int(hit[0]) / max(int(hit[1]), 1),
             'rccl_ranks': comm.info()['nranks'], 'rccl_owner': 'libglx' if comm.has_transport() else 'none (one rank)', 'engine': 'glx',

@@ -30,13 +30,15 @@ from .dist import block_bounds
 
 
 # ---- step 0: a cheap locality order before sharding ------------------------------------------------------------------
-def coarse_locality_order(X, ncells=64, seed=0, chunk=262144):
+def coarse_locality_order(X, ncells=64, seed=0, chunk=262144, return_cells=False):
     """Permutation (new -> old) that makes contiguous blocks of vertices geometrically compact BEFORE the graph exists
     ("blobs/clusters first"): every point goes to the nearest of `ncells` sample points, the cells are
     chained greedily by nearest unvisited cell (cells of one cluster end up next to each other), and points are
     sorted by their cell's place in the chain (stable: original order inside a cell).  O(n * ncells * d) on the host,
     the same on every rank.  Ranks that own contiguous blocks of this order import only the neighbours across their
-    block boundaries instead of (for data in arbitrary order) nearly every vertex of the graph."""
+    block boundaries instead of (for data in arbitrary order) nearly every vertex of the graph.
+    return_cells: also the positions (in the new order) at which a new cell starts -- the natural candidates for block
+    boundaries (graph_cut_bounds): a cut between two cells of different clusters crosses no edge at all."""
     X = np.asarray(X)
     n = X.shape[0]
     ncells = int(min(ncells, n))
@@ -59,7 +61,104 @@ def coarse_locality_order(X, ncells=64, seed=0, chunk=262144):
         if pos + 1 < ncells:
             cand = np.where(seen, np.inf, dc[cur])
             cur = int(np.argmin(cand))
-    return np.argsort(place[cell], kind='stable').astype(np.int64)
+    key = place[cell]
+    perm = np.argsort(key, kind='stable').astype(np.int64)
+    if not return_cells:
+        return perm
+    starts = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=ncells))[:-1]]).astype(np.int64)
+    return perm, starts
+
+
+def coarse_locality_order_torch(Xt, ncells=64, seed=0, chunk=1 << 20):
+    """coarse_locality_order with the O(n * ncells * d) part on the device: Xt is an (n, d) float64 tensor on the GPU.  The same
+    sample points, the same chain, the same stable sort; returns (perm tensor new -> old on Xt's device, cell starts as a host
+    array).  (A point whose two nearest sample points are equidistant to the last bit may land in the other cell than on the
+    host: any assignment is a valid locality order as long as every rank computes the same one, which identical GPUs do.)"""
+    import torch
+    n = Xt.shape[0]
+    ncells = int(min(ncells, n))
+    rng = np.random.default_rng(seed)
+    pick = np.sort(rng.choice(n, size=ncells, replace=False))
+    cent_t = Xt[torch.from_numpy(pick).to(Xt.device)]
+    cent = cent_t.cpu().numpy().astype(np.float64)
+    cn = np.einsum('ij,ij->i', cent, cent)
+    cn_t = torch.from_numpy(cn).to(Xt.device)
+    cell = torch.empty(n, dtype=torch.int64, device=Xt.device)
+    for lo in range(0, n, chunk):
+        blk = Xt[lo:lo + chunk]
+        cell[lo:lo + chunk] = torch.argmin(cn_t[None, :] - 2.0 * (blk @ cent_t.T), dim=1)
+    dc = cn[:, None] + cn[None, :] - 2.0 * (cent @ cent.T)
+    start = int(np.argmax(np.sum((cent - cent.mean(axis=0)) ** 2, axis=1)))
+    place = np.full(ncells, -1, dtype=np.int64)
+    cur, seen = start, np.zeros(ncells, dtype=bool)
+    for pos in range(ncells):
+        place[cur] = pos
+        seen[cur] = True
+        if pos + 1 < ncells:
+            cur = int(np.argmin(np.where(seen, np.inf, dc[cur])))
+    key = torch.from_numpy(place).to(Xt.device)[cell]
+    perm = torch.sort(key, stable=True).indices
+    counts = torch.bincount(key, minlength=ncells).cpu().numpy()
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+    return perm, starts
+
+
+# ---- step 1b: block boundaries that follow the graph ---------------------------------------------------------------
+def crossing_counts_at(J_own, lo, cand):
+    """How many kNN list entries (i -> j) of the rows [lo, lo + len(J_own)) cross a cut placed at each candidate position
+    (a cut at p separates vertices < p from vertices >= p): the local part of the count, to be summed over the ranks."""
+    cand = np.asarray(cand, dtype=np.int64)
+    J = np.asarray(J_own, dtype=np.int64)
+    i = np.repeat(np.arange(lo, lo + J.shape[0], dtype=np.int64), J.shape[1])
+    j = J.reshape(-1)
+    a, b = np.minimum(i, j), np.maximum(i, j)
+    first = np.searchsorted(cand, a, side='right')          # candidates p with a < p ...
+    last = np.searchsorted(cand, b, side='right')           # ... and p <= b
+    diff = np.bincount(first, minlength=len(cand) + 1) - np.bincount(last, minlength=len(cand) + 1)
+    return np.cumsum(diff)[:len(cand)].astype(np.int64)
+
+
+def graph_cut_bounds(dist, n, J_own, lo, cell_starts, group=None, device=None, slack_levels=(0.0, 0.1, 0.25, 0.45, 0.65)):
+    """Block boundaries for the sharded pipeline that follow the graph (what dist.cut_bounds does with the global matrix,
+    here from the ranks' own kNN lists): candidates are the equal-split points and the cell starts of the coarse geometric
+    order; the entries crossing each are counted locally and summed over the ranks (one small all-reduce); the cuts of least
+    crossing within a growing imbalance allowance are chosen by the same dynamic programme.  For clustered data the cuts land
+    between clusters -- a rank that owns whole clusters has NO halo -- where equal blocks cut through a cluster and, the kNN
+    graph of an isotropic cluster being expander-like, import about as many rows as they own (profiles/r03_scale_model.json:
+    n = 2e6, 8 equal blocks: 140 000 halo rows per 250 000 owned, one xGMI link carrying 18 MB per sweep).
+    Every rank returns the same bounds."""
+    import torch
+    from . import dist as gdist
+    world = dist.get_world_size(group)
+    if world <= 1:
+        return np.array([0, n], dtype=np.int64)
+    cand = sorted({int(c) for c in list(cell_starts) + [(n * r) // world for r in range(1, world)] if 0 < int(c) < n})
+    xc = torch.from_numpy(crossing_counts_at(J_own, lo, cand))
+    if dist.get_backend(group) == 'nccl':
+        dev = torch.device('cuda', device) if isinstance(device, int) else (device if device is not None else torch.device('cuda', torch.cuda.current_device()))
+        xc = xc.to(dev)
+    dist.all_reduce(xc, group=group)
+    return gdist.choose_cuts(xc.cpu().numpy(), cand, n, world, slack_levels)
+
+
+def redistribute_rows(dist, arrays, old_bounds, new_bounds, group=None, device=None):
+    """Rows of 2-D arrays (kNN lists: J int64, D float64) that the ranks hold for the contiguous blocks `old_bounds` are moved
+    to the owners under `new_bounds` (one all-to-all-v per array).  Returns the arrays of this rank's new block."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo = int(old_bounds[rank])
+    out = []
+    for A in arrays:
+        A = np.ascontiguousarray(A)
+        ncol = A.shape[1]
+        parts = []
+        for r in range(world):
+            a = min(max(int(new_bounds[r]) - lo, 0), A.shape[0])
+            b = min(max(int(new_bounds[r + 1]) - lo, 0), A.shape[0])
+            parts.append(A[a:b].reshape(-1))
+        dtype = np.int64 if A.dtype == np.int64 else np.float64
+        got = _alltoallv(dist, parts, dtype, group, device)
+        out.append(np.concatenate(got).reshape(-1, ncol))        # sources arrive in rank order = ascending row
+    return out
 
 
 # ---- step 2: symmetrisation by owner -------------------------------------------------------------------------------
@@ -223,10 +322,10 @@ def _alltoallv(dist, arrays, dtype, group=None, device=None):
 class ShardedGraph:
     """One rank's rows of the kNN weight matrix and of the Poisson operator plus its exchange plan, built collectively."""
 
-    def __init__(self, dist, n, J_own, D_own, k, kernel='gaussian', symmetrize=True, group=None, device=None):
+    def __init__(self, dist, n, J_own, D_own, k, kernel='gaussian', symmetrize=True, group=None, device=None, bounds=None):
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         self.dist, self.group, self.rank, self.world, self.n = dist, group, rank, world, n
-        self.bounds = bounds = block_bounds(n, world)
+        self.bounds = bounds = block_bounds(n, world) if bounds is None else np.asarray(bounds, dtype=np.int64)   # any contiguous blocks
         self.lo, self.hi = lo, hi = int(bounds[rank]), int(bounds[rank + 1])
         assert J_own.shape[0] == hi - lo
         J, w = knn_weights_rows(np.asarray(J_own), np.asarray(D_own), k + 1, kernel)
@@ -279,16 +378,16 @@ class ShardedGraph:
 
 
 def poisson_fit_sharded(dist, n, J_own, D_own, k, train_ind, train_labels, engine='glx', ops_factory=None, comm=None, device=None,
-                        min_iter=50, max_iter=1000, kernel='gaussian', group=None, check_every=8, gather=True, dtype=np.float64):
+                        min_iter=50, max_iter=1000, kernel='gaussian', group=None, check_every=8, gather=True, dtype=np.float64, bounds=None):
     """weightmatrix.knn + ssl.poisson(solver='gradient_descent').fit with every rank holding only its block of rows:
-    (J_own, D_own) are the kNN lists (self included, k+1 columns) of the rank's rows [lo, hi) of block_bounds(n, world).
+    (J_own, D_own) are the kNN lists (self included, k+1 columns) of the rank's rows [lo, hi) of `bounds` (default block_bounds(n, world)).
     engine 'glx': the library-owned sweep (glx_dist_sweep over a libglx RCCL communicator); 'glxstep': the same object with
     `dist` moving the packed records (ranks sharing one GPU); 'ops': dist.DistSweep with the rank-local kernel from
     ops_factory(plan, classes) (CPU tests).  Returns (u, T, sharded graph); u is the full
     (n, C) matrix (gather=True) or this rank's rows in plan.own order."""
     from . import dist as gdist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    sg = ShardedGraph(dist, n, J_own, D_own, k, kernel=kernel, group=group, device=device)
+    sg = ShardedGraph(dist, n, J_own, D_own, k, kernel=kernel, group=group, device=device, bounds=bounds)
     prob = sg.poisson_problem_rows(train_ind, train_labels)
     plan = sg.plan
     err0 = 0.0

@@ -153,6 +153,16 @@ int glx_pack_records_dev(const void* dense, void* rec, int64_t n, int C, int dty
                          void* stream);
 int glx_unpack_records_dev(const void* rec, void* dense, int64_t n, int C, int dtype, int has_w, void* stream);
 
+/* Dense vector kernels of utils.conjgrad (graphlearning/utils.py:483-532) on device records, for the vertex-partitioned
+ * conjugate-gradient solve (dist.py: cg_distributed): out[c] = sum_i a[i,c] b[i,c] in fp64 with a fixed order inside the
+ * rank (partial: device scratch of glx_rec_dots_scratch(n, C) doubles); x += alpha p, r -= alpha Ap; p = r + beta p --
+ * alpha, beta: device fp64[C].  The ranks add their column sums with one all-reduce each (tolerance mode). */
+int64_t glx_rec_dots_scratch(int64_t n, int C);
+int glx_rec_dots_dev(const void* a, const void* b, int64_t n, int C, int dtype, int has_w, double* partial, double* out, void* stream);
+int glx_rec_axpy2_dev(void* x, void* r, const void* p, const void* Ap, const double* alpha, int64_t n, int C, int dtype, int has_w,
+                      void* stream);
+int glx_rec_xpby_dev(void* p, const void* r, const double* beta, int64_t n, int C, int dtype, int has_w, void* stream);
+
 /* ---- vertex-partitioned sweep over RCCL (the reference has no distributed code) -------------
  * One process per GPU: rank 0 calls glx_dist_unique_id, ships the 128 bytes to the other ranks by any means (the
  * launcher's store, torch.distributed, MPI ...), every rank calls glx_dist_init_rank.  glx_dist_init is the

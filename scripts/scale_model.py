@@ -232,16 +232,20 @@ def main():
         strong['single_gpu_sweep_us'] = t1
         log('config 4 shape, 1 GPU: %.1f us per sweep' % t1)
         for world in worlds:
-            ranks = rank_measurements(P, order, gdist.block_bounds(n, world), prob, prob['k'], max(4, args.reps // 4))
-            pr = {name: predict(ranks, lat_us, gbs) for name, lat_us, gbs in
-                  (('bw_peak', 0.0, LINK_GBS_PEAK), ('bw_rccl', 0.0, LINK_GBS_RCCL), ('rccl', L, LINK_GBS_RCCL))}
-            for v in pr.values():
-                v['speedup'] = t1 / v['sweep_us']
-                v['strong_efficiency'] = t1 / v['sweep_us'] / world
-            strong[str(world)] = dict(ranks=ranks, predicted=pr)
-            log('config 4 strong, N=%d: halo/rank %s, boundary/rank %s, predicted sweep bw %.1f us rccl %.1f us (speed-up %.2f / %.2f)'
-                % (world, [m['n_halo'] for m in ranks], [m['n_boundary'] for m in ranks], pr['bw_rccl']['sweep_us'], pr['rccl']['sweep_us'],
-                   pr['bw_rccl']['speedup'], pr['rccl']['speedup']))
+            entry = {}
+            for part in ('cut', 'even'):       # cut: boundaries where the fewest entries cross (bench.py --config 4's default), even: equal blocks
+                bounds = gdist.cut_bounds(P, order, world) if part == 'cut' else gdist.block_bounds(n, world)
+                ranks = rank_measurements(P, order, bounds, prob, prob['k'], max(4, args.reps // 4))
+                pr = {name: predict(ranks, lat_us, gbs, T=200, min_iter=200) for name, lat_us, gbs in
+                      (('bw_peak', 0.0, LINK_GBS_PEAK), ('bw_rccl', 0.0, LINK_GBS_RCCL), ('rccl', L, LINK_GBS_RCCL))}
+                for v in pr.values():
+                    v['speedup'] = t1 / v['sweep_us']
+                    v['strong_efficiency'] = t1 / v['sweep_us'] / world
+                entry[part] = dict(ranks=ranks, predicted=pr, bounds=[int(b) for b in bounds], imbalance=max(m['n_own'] for m in ranks) * world / n)
+                log('config 4 strong, N=%d, %s: own/rank %s, halo/rank %s, predicted sweep bw %.1f us rccl %.1f us (speed-up %.2f / %.2f) forms %s'
+                    % (world, part, [m['n_own'] for m in ranks], [m['n_halo'] for m in ranks], pr['bw_rccl']['sweep_us'], pr['rccl']['sweep_us'],
+                       pr['bw_rccl']['speedup'], pr['rccl']['speedup'], pr['rccl']['forms']))
+            strong[str(world)] = entry
         result['config4_strong'] = strong
 
     os.makedirs(os.path.dirname(args.out), exist_ok=True)

