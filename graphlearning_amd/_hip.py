@@ -510,6 +510,28 @@ class Sweep:
             pass
 
 
+# Communicators and distributed sweeps that are still open when the interpreter shuts down are ABANDONED, not destroyed:
+# tearing an RCCL communicator (or the streams and captured graphs that carry its kernels) down from a garbage-collection
+# pass during interpreter finalisation was seen to hang the process (a failed test that never reached close(), round 3);
+# the operating system reclaims everything at exit anyway.  close() during normal operation destroys as before.
+import atexit
+import weakref
+_live_dist_objects = weakref.WeakSet()
+
+
+def _abandon_dist_objects():
+    if os.environ.get('GLX_NO_ATEXIT_ABANDON') == '1':
+        return
+    for obj in list(_live_dist_objects):
+        try:
+            obj._h = _vp()
+        except Exception:
+            pass
+
+
+atexit.register(_abandon_dist_objects)
+
+
 class Comm:
     """One rank's libglx-owned RCCL communicator (glx_comm).  `uid`: the 128 bytes of Comm.unique_id() made on rank 0
     and shipped to every rank; uid=None with nranks == 1 gives a transport-free single rank."""
@@ -525,6 +547,7 @@ class Comm:
         self._h = _vp()
         idbuf = None if uid is None else C.create_string_buffer(bytes(uid), 128)
         check(load().glx_dist_init_rank(self.nranks, self.rank, idbuf, self.device, C.byref(self._h)), 'glx_dist_init_rank')
+        _live_dist_objects.add(self)
 
     def info(self):
         info = (C.c_int32 * 4)()
@@ -574,6 +597,7 @@ class DistSweep:
                                            _dt(self.dtype), self.C, _ptr(sc), _ptr(si), _ptr(rcnt), int(n_global),
                                            1 if force_exchange else 0, 1 if use_hipgraph else 0, C.byref(self._h)),
               'glx_dist_sweep_create')
+        _live_dist_objects.add(self)
 
     def set_problem(self, Db_own, w0_own, deg_own, vinf_own):
         n = self.n_own

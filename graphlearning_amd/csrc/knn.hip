@@ -640,7 +640,7 @@ __device__ __forceinline__ bool lex_less(double da, int ia, double db, int ib) {
 // one workgroup of 64 threads per query; M (power of two) candidate slots sorted in LDS
 __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict__ X, int64_t n, int d, int k, int64_t q_begin,
                                                         int64_t nq, const float* __restrict__ cand_d, const int* __restrict__ cand_i,
-                                                        int lists, int KP, int M, const float* __restrict__ qnorm, float rmax,
+                                                        int lists, int KP, int M, const float* __restrict__ qnorm, const float* __restrict__ rmax_p,
                                                         double cerr, int64_t* __restrict__ ind_out, double* __restrict__ dist_out,
                                                         int* __restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
     // every ref outside a full list has fp32 dist^2 >= that list's threshold; accept the row
     // only if no such ref can beat the exact k-th neighbour once the fp32 error is allowed for
     const double dk2 = sd[k - 1];
-    const double rq = (double)qnorm[q] + (double)rmax;
+    const double rq = (double)qnorm[q] + (double)rmax_p[0];   // largest centred norm, reduced on the device (knn_rmax_kernel)
     const double eps = cerr * rq * rq;
     int bad = !(dk2 < INFINITY);
     for (int l = 0; l < lists && !bad; ++l) {
@@ -781,6 +781,7 @@ struct KnnBufs {
   unsigned short* Xb = nullptr;      // bf16 hi | lo image (bf16 filter)
   float* nrm = nullptr;              // fp32 squared norms (bf16 filter)
   double* part = nullptr;            // per-block partial column sums / maxima of the centring pass
+  float* rmax = nullptr;             // [0] largest centred norm (1 + 1e-6), [1] 1 if the input is finite: written by knn_rmax_kernel
   double *X = nullptr, *mean = nullptr, *dist = nullptr;
   float *Rf = nullptr, *Qf = nullptr, *qnorm = nullptr, *cand_d = nullptr;
   int *cand_i = nullptr, *flags = nullptr, *rows = nullptr, *fb_li = nullptr, *fb_pi = nullptr, *gtau = nullptr;
@@ -791,7 +792,7 @@ struct KnnBufs {
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
   ~KnnBufs() {
     if (stream) hipStreamSynchronize(stream);   // pooled blocks are reused at once: nothing may still be running on them
-    glx_pool_free(Xb); glx_pool_free(nrm); glx_pool_free(part);
+    glx_pool_free(Xb); glx_pool_free(nrm); glx_pool_free(part); glx_pool_free(rmax);
     glx_pool_free(X); glx_pool_free(mean); glx_pool_free(dist); glx_pool_free(Rf); glx_pool_free(Qf); glx_pool_free(qnorm); glx_pool_free(cand_d);
     glx_pool_free(gtau); glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_li); glx_pool_free(fb_pi); glx_pool_free(fb_ld); glx_pool_free(fb_pd);
     glx_work_release(work);
@@ -799,15 +800,41 @@ struct KnnBufs {
 };
 
 
-// ---- centring on the device: column sums and the largest centred norm, as per-block partials reduced by the host
-// in a fixed order (the n x d passes cost milliseconds on one host core: as much as the search itself at 70 000 x 20)
-static const int CENTRE_ROWS = 1024;
-__global__ __launch_bounds__(256) void knn_colsum_kernel(const double* __restrict__ X, int64_t n, int d, double* __restrict__ part) {
+// ---- centring on the device: column means and the largest centred norm without a host round trip.
+// Round 2's column-sum kernel gave each of d threads a 1024-long strided chain (20 of 256 threads active at d = 20: 0.39 ms
+// for 11 MB at config 2, a quarter of the tile kernel); now the 256 threads of a workgroup tile its CENTRE_ROWS x d slab as
+// (rows in flight) x (columns side by side), every thread sums its column over its rows in a register, LDS combines the row
+// lanes in a fixed order, and one more small kernel folds the block partials -- in block order -- into the mean.  The largest centred norm is
+// reduced on the device too; the re-rank kernel reads it from memory, the host looks at it (is the input finite?) together
+// with the acceptance flags at the end.  Any FIXED summation order serves: the mean only centres the filter's operands,
+// distances come from the uncentred fp64 data.
+static const int CENTRE_ROWS = 512;
+__global__ __launch_bounds__(256) void knn_colsum_kernel(const double* __restrict__ X, int64_t n, int d, int dt, double* __restrict__ part) {
+  // thread = (row lane, column): dt = power of two >= min(d, 256) columns side by side, 256 / dt rows in flight; the lanes of a
+  // row read consecutive elements, consecutive row lanes the next rows of the contiguous slab
+  const int f0 = threadIdx.x % dt, rl = threadIdx.x / dt, rt = 256 / dt;
   const int64_t r0 = (int64_t)blockIdx.x * CENTRE_ROWS, r1 = min(n, r0 + CENTRE_ROWS);
-  for (int f = threadIdx.x; f < d; f += 256) {
+  __shared__ double sm[256];
+  for (int fb = 0; fb < d; fb += dt) {             // (one pass unless d > 256)
+    const int f = fb + f0;
     double s = 0.0;
-    for (int64_t i = r0; i < r1; ++i) s += X[i * d + f];
-    part[(size_t)blockIdx.x * d + f] = s;
+    if (f < d)
+      for (int64_t i = r0 + rl; i < r1; i += rt) s += X[i * d + f];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && f < d) {
+      double t = sm[f0];
+      for (int q = 1; q < rt; ++q) t += sm[q * dt + f0];     // fixed order
+      part[(size_t)blockIdx.x * d + f] = t;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void knn_mean_kernel(const double* __restrict__ part, int64_t nblk, int d, int64_t n, double* __restrict__ mean) {
+  for (int f = threadIdx.x; f < d; f += 256) {
+    double t = 0.0;
+    for (int64_t b = 0; b < nblk; ++b) t += part[(size_t)b * d + f];
+    mean[f] = t / (double)n;
   }
 }
 __global__ __launch_bounds__(256) void knn_maxnorm_kernel(const double* __restrict__ X, const double* __restrict__ mean, int64_t n, int d,
@@ -825,6 +852,23 @@ __global__ __launch_bounds__(256) void knn_maxnorm_kernel(const double* __restri
     __syncthreads();
   }
   if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+// rmax_out[0] = sqrt(max) * (1 + 1e-6) as a float (what the re-rank's acceptance bound uses), [1] = 1 if the input is finite
+__global__ __launch_bounds__(256) void knn_rmax_kernel(const double* __restrict__ part, int64_t nblk, float* __restrict__ rmax_out) {
+  double m = 0.0;
+  for (int64_t b = threadIdx.x; b < nblk; b += 256) m = part[b] > m ? part[b] : m;
+  __shared__ double sm[256];
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off && sm[threadIdx.x + off] > sm[threadIdx.x]) sm[threadIdx.x] = sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double r2 = sm[0];
+    rmax_out[0] = (float)(sqrt(r2) * (1.0 + 1e-6));
+    rmax_out[1] = (r2 == r2 && r2 < INFINITY) ? 1.0f : 0.0f;
+  }
 }
 
 #ifdef KNN_BF16_NSUB
@@ -975,26 +1019,20 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   stamp("stream, events, buffers");
   GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyHostToDevice, st));
   stamp("X enqueued");
-  // centring in fp64 (distances are translation invariant; small norms keep the filter sharp): per-block partials, fixed-order host sums
+  // centring in fp64 (distances are translation invariant; small norms keep the filter sharp), all of it on the device
   const int64_t nb_sum = (n + CENTRE_ROWS - 1) / CENTRE_ROWS, nb_max = (n + 255) / 256;
   GLX_POOL(glx_pool_alloc((void**)&b.part, (size_t)std::max<int64_t>(nb_sum * d, nb_max) * 8));
-  std::vector<double> mean(d, 0.0), hpart((size_t)std::max<int64_t>(nb_sum * d, nb_max));
-  hipLaunchKernelGGL(knn_colsum_kernel, dim3((unsigned)nb_sum), dim3(256), 0, st, (const double*)b.X, n, d, b.part);
-  GLX_HIP(hipGetLastError());
-  GLX_HIP(hipMemcpyAsync(hpart.data(), b.part, (size_t)nb_sum * d * 8, hipMemcpyDeviceToHost, st));
-  GLX_HIP(hipStreamSynchronize(st));
-  for (int64_t blk = 0; blk < nb_sum; ++blk)
-    for (int f = 0; f < d; ++f) mean[f] += hpart[(size_t)blk * d + f];
-  for (int f = 0; f < d; ++f) mean[f] /= (double)n;
-  GLX_HIP(hipMemcpyAsync(b.mean, mean.data(), d * 8, hipMemcpyHostToDevice, st));
+  GLX_POOL(glx_pool_alloc((void**)&b.rmax, 64));
+  {
+    int dt = 1;
+    while (dt < d && dt < 256) dt *= 2;
+    hipLaunchKernelGGL(knn_colsum_kernel, dim3((unsigned)nb_sum), dim3(256), 0, st, (const double*)b.X, n, d, dt, b.part);
+    GLX_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(knn_mean_kernel, dim3(1), dim3(256), 0, st, (const double*)b.part, nb_sum, d, n, b.mean);
   hipLaunchKernelGGL(knn_maxnorm_kernel, dim3((unsigned)nb_max), dim3(256), 0, st, (const double*)b.X, (const double*)b.mean, n, d, b.part);
+  hipLaunchKernelGGL(knn_rmax_kernel, dim3(1), dim3(256), 0, st, (const double*)b.part, nb_max, b.rmax);
   GLX_HIP(hipGetLastError());
-  GLX_HIP(hipMemcpyAsync(hpart.data(), b.part, (size_t)nb_max * 8, hipMemcpyDeviceToHost, st));
-  GLX_HIP(hipStreamSynchronize(st));
-  double rmax2 = 0.0;
-  for (int64_t blk = 0; blk < nb_max; ++blk) rmax2 = std::max(rmax2, hpart[blk]);
-  GLX_CHECK(std::isfinite(rmax2), GLX_EINVAL, "glx_knn_bruteforce: non-finite input");
-  const float rmax = (float)(std::sqrt(rmax2) * (1.0 + 1e-6));
   // |filter value - exact dist^2| <= cerr * (|q| + rmax)^2.
   // fp32 filter: input rounding (2^-24 per coordinate), dpa products and sums at 2^-24 each, norms computed in fp32; generous constant.
   // bf16 filter: the dropped parts of the split products (lo.lo and the residuals, <= 3.1 * 2^-18 |q||r| in q.r, twice that in the
@@ -1051,14 +1089,17 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   }
 #endif
   hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)nq), dim3(64), (size_t)M * 12, st, (const double*)b.X, n, d, k, q0, nq,
-                     (const float*)b.cand_d, (const int*)b.cand_i, lists, KP, M, (const float*)b.qnorm, rmax, cerr, b.ind, b.dist,
+                     (const float*)b.cand_d, (const int*)b.cand_i, lists, KP, M, (const float*)b.qnorm, (const float*)b.rmax, cerr, b.ind, b.dist,
                      b.flags);
   GLX_HIP(hipGetLastError());
   GLX_HIP(hipEventRecord(b.e2, st));
   std::vector<int> flags(nq);
+  float h_rmax[2] = {0.f, 0.f};
   GLX_HIP(hipMemcpyAsync(flags.data(), b.flags, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipMemcpyAsync(h_rmax, b.rmax, 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
   stamp("tile + re-rank done, flags on the host");
+  GLX_CHECK(h_rmax[1] == 1.0f, GLX_EINVAL, "glx_knn_bruteforce: non-finite input");   // (the first host look at the centring pass)
   std::vector<int> rows;
   for (int64_t i = 0; i < nq; ++i)
     if (flags[i]) rows.push_back((int)i);
