@@ -125,6 +125,8 @@ _SIGNATURES = {
     'glx_knn_stats': [_f64p],
     'glx_knn_to_csr': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                        C.POINTER(_vp), _i64p, C.c_int],
+    'glx_knn_rows_to_csr': [_vp, _vp, C.c_int64, C.c_int, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp, _vp, _vp,
+                            _i64p, C.c_int],
     'glx_host_row_sums': [C.c_int64, _vp, _vp, _vp],
     'glx_host_reverse_scale_rows': [C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp],
     'glx_knn_to_csr_into': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, _i64p, C.c_int],
@@ -784,8 +786,33 @@ def knn_to_csr(knn_ind, knn_dist, k, kernel='gaussian', sym=1, weights=None, dev
     return W
 
 
+def knn_rows_to_csr(J_own, w_own, n_cols, row_base, rev_row, rev_src, rev_pos, rev_w, sym=1, device=None):
+    """Rows [row_base, row_base + m) of weightmatrix.knn's matrix from the block's own lists and the reverse entries sent by the
+    owners of the other rows, merged on the GPU (glx_knn_rows_to_csr).  Returns a scipy CSR of shape (m, n_cols)."""
+    from scipy import sparse
+    J = np.ascontiguousarray(J_own, dtype=np.int64)
+    m, k = J.shape
+    w = _dense(w_own, np.float64, (m, k), 'w_own')
+    rr = np.ascontiguousarray(rev_row, dtype=np.int64)
+    rs = np.ascontiguousarray(rev_src, dtype=np.int64)
+    rp = np.ascontiguousarray(rev_pos, dtype=np.int64)
+    rw = np.ascontiguousarray(rev_w, dtype=np.float64)
+    cap = m * k + len(rr)
+    indptr = np.empty(m + 1, dtype=np.int32)
+    col = np.empty(max(cap, 1), dtype=np.int32)
+    val = np.empty(max(cap, 1), dtype=np.float64)
+    nnz = C.c_int64(0)
+    check(load().glx_knn_rows_to_csr(_ptr(J), _ptr(w), m, k, int(n_cols), int(row_base), _ptr(rr), _ptr(rs), _ptr(rp), _ptr(rw), len(rr), int(sym),
+                                     cap, _ptr(indptr), _ptr(col), _ptr(val), C.byref(nnz), _dev(device)), 'glx_knn_rows_to_csr')
+    W = sparse.csr_matrix((val[:nnz.value].copy(), col[:nnz.value].copy(), indptr), shape=(m, int(n_cols)))
+    W.has_sorted_indices = True
+    W.has_canonical_format = True
+    return W
+
+
 def knn_stats():
     out = (C.c_double * 16)()
     check(load().glx_knn_stats(out), 'glx_knn_stats')
     return dict(tile_ms=out[0], rerank_ms=out[1], fallback_rows=out[2], total_ms=out[3], fallback_ms=out[4],
-                dpa=out[5], nsplit=out[6], KP=abs(out[7]), filter='bf16x3' if out[7] < 0 else 'f32', escalated_rows=out[8])
+                dpa=out[5], nsplit=out[6], KP=abs(out[7]), filter='bf16x3' if out[7] < 0 else 'f32', escalated_rows=out[8],
+                concatenated=bool(out[9]))

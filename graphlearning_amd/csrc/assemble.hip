@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restri
                                                          const unsigned short* __restrict__ rpos, const double* __restrict__ rw, int sym,
                                                          int mode, int* __restrict__ rowcnt,
                                                          const int64_t* __restrict__ rowptr, int* __restrict__ col_out,
-                                                         double* __restrict__ val_out, int* __restrict__ overflow) {
+                                                         double* __restrict__ val_out, int* __restrict__ overflow, int64_t row_base = 0) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restri
           if ((key[q] >> 16) & 1) b = b + val[q]; else a = a + val[q];
         }
         v = combine_entry(a, b, sym);
-        keep = (c != (int)i) && (v != 0.0);      // setdiag(0); eliminate_zeros(), weightmatrix.py:185-186
+        keep = (c != (int)(i + row_base)) && (v != 0.0);      // setdiag(0); eliminate_zeros(), weightmatrix.py:185-186
       }
     }
     const unsigned long long mask = __ballot(keep);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(1024) void merge_hub_kernel(const int64_t* __restri
                                                          int mode, const int64_t* __restrict__ hub_row, const int64_t* __restrict__ hub_off,
                                                          unsigned long long* __restrict__ skey, double* __restrict__ sval,
                                                          int* __restrict__ hub_cnt, const int64_t* __restrict__ rowptr,
-                                                         int* __restrict__ col_out, double* __restrict__ val_out) {
+                                                         int* __restrict__ col_out, double* __restrict__ val_out, int64_t row_base = 0) {
 #pragma clang fp contract(off)
   __shared__ int wcnt[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(1024) void merge_hub_kernel(const int64_t* __restri
           if ((key[q] >> 31) & 1) b = b + val[q]; else a = a + val[q];
         }
         v = combine_entry(a, b, sym);
-        keep = (c != (int)i) && (v != 0.0);                   // setdiag(0); eliminate_zeros(), weightmatrix.py:185-186
+        keep = (c != (int)(i + row_base)) && (v != 0.0);      // setdiag(0); eliminate_zeros(), weightmatrix.py:185-186
       }
     }
     const unsigned long long mask = __ballot(keep);
@@ -423,6 +423,174 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
   *rowptr_out = h_rp;
   *col_out = h_col;
   *val_out = h_val;
+  *nnz_out = nnz;
+  return GLX_OK;
+}
+
+// ---- a BLOCK of rows of the weight matrix (sharded build, SURVEY.md 8e "symmetrisation by owner rank") ----------------------
+// Rows [row_base, row_base + m) of weightmatrix.knn's result from the block's own lists (ind_own / w_own: m x k, weights given)
+// and the reverse entries the other rows' owners sent: (rev_row = j in the block, rev_src = i, rev_pos = position of j in row
+// i's list, rev_w = w_ij).  The same merge as glx_knn_to_csr -- forward and reverse entries of a row sorted by (column, kind,
+// position), duplicates summed in list order, the symmetrisation rule per column, diagonal and zeros dropped -- so the rows are
+// bit-identical to the rows of the whole matrix.  Columns are global ids (< n_cols).
+__global__ void count_rev_rows_kernel(const int64_t* __restrict__ rev_row, int64_t n_rev, int64_t row_base, int64_t m, int* __restrict__ rcnt,
+                                      int* __restrict__ bad) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_rev) return;
+  const int64_t j = rev_row[e] - row_base;
+  if (j < 0 || j >= m) { *bad = 1; return; }
+  atomicAdd(&rcnt[j], 1);
+}
+
+__global__ void fill_rev_rows_kernel(const int64_t* __restrict__ rev_row, const int64_t* __restrict__ rev_src, const int64_t* __restrict__ rev_pos,
+                                     const double* __restrict__ rev_w, int64_t n_rev, int64_t row_base, const int64_t* __restrict__ roff,
+                                     int* __restrict__ cursor, int* __restrict__ rsrc, unsigned short* __restrict__ rpos, double* __restrict__ rw) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_rev) return;
+  const int64_t j = rev_row[e] - row_base;
+  const int64_t pos = roff[j] + atomicAdd(&cursor[j], 1);
+  rsrc[pos] = (int)rev_src[e];
+  rpos[pos] = (unsigned short)rev_pos[e];
+  rw[pos] = rev_w[e];
+}
+
+__global__ void check_cols_kernel(const int64_t* __restrict__ ind, int64_t total, int64_t n_cols, int* __restrict__ bad) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < total && (ind[e] < 0 || ind[e] >= n_cols)) *bad = 1;
+}
+
+extern "C" int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, int64_t m, int k, int64_t n_cols, int64_t row_base,
+                                   const int64_t* rev_row, const int64_t* rev_src, const int64_t* rev_pos, const double* rev_w, int64_t n_rev,
+                                   int sym, int64_t cap, int32_t* rowptr_out, int32_t* col_out, double* val_out, int64_t* nnz_out, int device) {
+  GLX_CHECK(ind_own && w_own && rowptr_out && col_out && val_out && nnz_out, GLX_EINVAL, "glx_knn_rows_to_csr: null argument");
+  GLX_CHECK(m >= 0 && k >= 1 && n_cols >= 1 && row_base >= 0 && row_base + m <= n_cols, GLX_EINVAL, "glx_knn_rows_to_csr: bad sizes");
+  GLX_CHECK(n_rev >= 0 && (n_rev == 0 || (rev_row && rev_src && rev_pos && rev_w)), GLX_EINVAL, "glx_knn_rows_to_csr: null reverse arrays");
+  GLX_CHECK(sym == SYM_NONE || sym == SYM_MEAN || sym == SYM_MAX, GLX_EINVAL, "glx_knn_rows_to_csr: symmetrisation %d needs other rows' data", sym);
+  GLX_CHECK(n_cols < (1ll << 31) && m * k < (1ll << 31) && n_rev < (1ll << 31), GLX_EUNSUPPORTED, "glx_knn_rows_to_csr: sizes must fit int32");
+  GLX_CHECK(k <= 65535, GLX_EUNSUPPORTED, "glx_knn_rows_to_csr: at most 65535 neighbours per row (k=%d)", k);
+  *nnz_out = 0;
+  rowptr_out[0] = 0;
+  if (m == 0) return GLX_OK;
+  GLX_HIP(hipSetDevice(device));
+  AsmBufs b;
+  {
+    int rcw = glx_work_acquire(device, &b.work);
+    if (rcw) return rcw;
+  }
+  b.stream = b.work->stream;
+  hipStream_t st = b.stream;
+  const int64_t ne = m * k, nr = sym == SYM_NONE ? 0 : n_rev;
+  // (AsmBufs' generic slots: dist <- rev_w staging, given <- rev_pos staging, hub_row / hub_off reused below)
+  int64_t *d_rrow = nullptr, *d_rsrc64 = nullptr, *d_rpos64 = nullptr;
+  struct Extra { int64_t *a = nullptr, *b = nullptr, *c = nullptr; ~Extra() { glx_pool_free(a); glx_pool_free(b); glx_pool_free(c); } } ex;
+  GLX_POOL(glx_pool_alloc((void**)&b.ind, (size_t)ne * 8));
+  GLX_HIP(hipMemcpyAsync(b.ind, ind_own, (size_t)ne * 8, hipMemcpyHostToDevice, st));
+  GLX_POOL(glx_pool_alloc((void**)&b.w, (size_t)ne * 8));
+  GLX_HIP(hipMemcpyAsync(b.w, w_own, (size_t)ne * 8, hipMemcpyHostToDevice, st));
+  GLX_POOL(glx_pool_alloc((void**)&b.rcnt, (m + 1) * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.cursor, (m + 1) * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.roff, (m + 1) * 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.rowptr, (m + 1) * 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.rowcnt, (m + 1) * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.rsrc, std::max<size_t>(nr * 4, 4)));
+  GLX_POOL(glx_pool_alloc((void**)&b.rw, std::max<size_t>(nr * 8, 8)));
+  GLX_POOL(glx_pool_alloc((void**)&b.rpos, std::max<size_t>(nr * 2, 2)));
+  GLX_POOL(glx_pool_alloc((void**)&b.flag, 8));
+  GLX_HIP(hipMemsetAsync(b.rcnt, 0, (m + 1) * 4, st));
+  GLX_HIP(hipMemsetAsync(b.cursor, 0, (m + 1) * 4, st));
+  GLX_HIP(hipMemsetAsync(b.flag, 0, 8, st));
+  hipLaunchKernelGGL(check_cols_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, (const int64_t*)b.ind, ne, n_cols, b.flag);
+  if (nr > 0) {
+    GLX_POOL(glx_pool_alloc((void**)&ex.a, (size_t)nr * 8));
+    GLX_POOL(glx_pool_alloc((void**)&ex.b, (size_t)nr * 8));
+    GLX_POOL(glx_pool_alloc((void**)&ex.c, (size_t)nr * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.dist, (size_t)nr * 8));
+    d_rrow = ex.a; d_rsrc64 = ex.b; d_rpos64 = ex.c;
+    GLX_HIP(hipMemcpyAsync(d_rrow, rev_row, (size_t)nr * 8, hipMemcpyHostToDevice, st));
+    GLX_HIP(hipMemcpyAsync(d_rsrc64, rev_src, (size_t)nr * 8, hipMemcpyHostToDevice, st));
+    GLX_HIP(hipMemcpyAsync(d_rpos64, rev_pos, (size_t)nr * 8, hipMemcpyHostToDevice, st));
+    GLX_HIP(hipMemcpyAsync(b.dist, rev_w, (size_t)nr * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(count_rev_rows_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, (const int64_t*)d_rrow, nr, row_base, m, b.rcnt, b.flag);
+    hipLaunchKernelGGL(check_cols_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, (const int64_t*)d_rsrc64, nr, n_cols, b.flag);
+  }
+  GLX_HIP(hipGetLastError());
+  std::vector<int> rcnt(m);
+  int flags[2] = {0, 0};
+  GLX_HIP(hipMemcpyAsync(rcnt.data(), b.rcnt, m * 4, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipMemcpyAsync(flags, b.flag, 8, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipStreamSynchronize(st));
+  GLX_CHECK(!flags[0], GLX_EINVAL, "glx_knn_rows_to_csr: index out of range (a neighbour id, or a reverse entry outside the block)");
+  std::vector<int64_t> roff(m + 1, 0);
+  for (int64_t i = 0; i < m; ++i) roff[i + 1] = roff[i] + rcnt[i];
+  GLX_HIP(hipMemcpyAsync(b.roff, roff.data(), (m + 1) * 8, hipMemcpyHostToDevice, st));
+  if (nr > 0) {
+    hipLaunchKernelGGL(fill_rev_rows_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, (const int64_t*)d_rrow, (const int64_t*)d_rsrc64,
+                       (const int64_t*)d_rpos64, (const double*)b.dist, nr, row_base, (const int64_t*)b.roff, b.cursor, b.rsrc, b.rpos, b.rw);
+    GLX_HIP(hipGetLastError());
+  }
+  const size_t shm = (size_t)4 * ROW_CAP * 16;
+  GLX_HIP(hipFuncSetAttribute((const void*)merge_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  const unsigned gr = (unsigned)((m + 3) / 4);
+  hipLaunchKernelGGL(merge_rows_kernel, dim3(gr), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, m, k, k,
+                     (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 0, b.rowcnt, (const int64_t*)nullptr,
+                     (int*)nullptr, (double*)nullptr, b.flag + 1, row_base);
+  GLX_HIP(hipGetLastError());
+  std::vector<int> rowcnt(m);
+  GLX_HIP(hipMemcpyAsync(rowcnt.data(), b.rowcnt, m * 4, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipMemcpyAsync(flags, b.flag, 8, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipStreamSynchronize(st));
+  int64_t nh = 0;
+  if (flags[1]) {      // hub rows: a workgroup each (merge_hub_kernel)
+    std::vector<int64_t> hrow, hoff(1, 0);
+    for (int64_t i = 0; i < m; ++i) {
+      if (rowcnt[i] >= 0) continue;
+      const int64_t M = k + (roff[i + 1] - roff[i]);
+      int64_t P = 2048;
+      while (P < M) P <<= 1;
+      hrow.push_back(i);
+      hoff.push_back(hoff.back() + P);
+    }
+    nh = (int64_t)hrow.size();
+    GLX_POOL(glx_pool_alloc((void**)&b.hub_row, nh * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.hub_off, (nh + 1) * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.hub_cnt, nh * 4));
+    GLX_POOL(glx_pool_alloc((void**)&b.skey, (size_t)hoff.back() * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.sval, (size_t)hoff.back() * 8));
+    GLX_HIP(hipMemcpyAsync(b.hub_row, hrow.data(), nh * 8, hipMemcpyHostToDevice, st));
+    GLX_HIP(hipMemcpyAsync(b.hub_off, hoff.data(), (nh + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(merge_hub_kernel, dim3((unsigned)nh), dim3(1024), 0, st, (const int64_t*)b.ind, (const double*)b.w, k, k,
+                       (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 0,
+                       (const int64_t*)b.hub_row, (const int64_t*)b.hub_off, b.skey, b.sval, b.hub_cnt, (const int64_t*)nullptr,
+                       (int*)nullptr, (double*)nullptr, row_base);
+    GLX_HIP(hipGetLastError());
+    std::vector<int> hcnt(nh);
+    GLX_HIP(hipMemcpyAsync(hcnt.data(), b.hub_cnt, nh * 4, hipMemcpyDeviceToHost, st));
+    GLX_HIP(hipStreamSynchronize(st));
+    for (int64_t h = 0; h < nh; ++h) rowcnt[hrow[h]] = hcnt[h];
+  }
+  std::vector<int64_t> rp(m + 1, 0);
+  for (int64_t i = 0; i < m; ++i) rp[i + 1] = rp[i] + rowcnt[i];
+  const int64_t nnz = rp[m];
+  GLX_CHECK(nnz < (1ll << 31), GLX_EUNSUPPORTED, "glx_knn_rows_to_csr: nnz %lld does not fit an int32 CSR", (long long)nnz);
+  GLX_CHECK(nnz <= cap, GLX_EINVAL, "glx_knn_rows_to_csr: %lld entries, room for %lld", (long long)nnz, (long long)cap);
+  GLX_HIP(hipMemcpyAsync(b.rowptr, rp.data(), (m + 1) * 8, hipMemcpyHostToDevice, st));
+  GLX_POOL(glx_pool_alloc((void**)&b.col, std::max<size_t>(nnz * 4, 4)));
+  GLX_POOL(glx_pool_alloc((void**)&b.val, std::max<size_t>(nnz * 8, 8)));
+  hipLaunchKernelGGL(merge_rows_kernel, dim3(gr), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, m, k, k,
+                     (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 1, b.rowcnt, (const int64_t*)b.rowptr,
+                     b.col, b.val, b.flag + 1, row_base);
+  GLX_HIP(hipGetLastError());
+  if (nh) {
+    hipLaunchKernelGGL(merge_hub_kernel, dim3((unsigned)nh), dim3(1024), 0, st, (const int64_t*)b.ind, (const double*)b.w, k, k,
+                       (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 1,
+                       (const int64_t*)b.hub_row, (const int64_t*)b.hub_off, b.skey, b.sval, b.hub_cnt, (const int64_t*)b.rowptr,
+                       b.col, b.val, row_base);
+    GLX_HIP(hipGetLastError());
+  }
+  for (int64_t i = 0; i <= m; ++i) rowptr_out[i] = (int32_t)rp[i];
+  GLX_HIP(hipMemcpyAsync(col_out, b.col, nnz * 4, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipMemcpyAsync(val_out, b.val, nnz * 8, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipStreamSynchronize(st));
   *nnz_out = nnz;
   return GLX_OK;
 }

@@ -325,10 +325,40 @@ __global__ void knn_prep_bf16_kernel(const double* __restrict__ X, const double*
   qnorm[i] = sqrtf(s);
 }
 
+// Concatenated split operands for d <= 21 (round 3): hi.hi + hi.lo + lo.hi is ONE contraction of length 3 d <= 63 when the
+// ref image is [rh | rh | rl] and the query image [qh | ql | qh] -- 64 bf16 per row, the size of the [hi(32) | lo(32)] rows the
+// NKB = 2 kernel stages, so four MFMAs of K = 16 do the work of the six the block form needs (hi and lo blocks padded to 32).
+static const int KNN_CAT_SEG = 21;
+__global__ void knn_prep_bf16_cat_kernel(const double* __restrict__ X, const double* __restrict__ mean, int64_t n, int d,
+                                         unsigned short* __restrict__ Xa, unsigned short* __restrict__ Xq, float* __restrict__ nrm,
+                                         float* __restrict__ qnorm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n + KNN_PAD_ROWS) return;
+  unsigned short* ra = Xa + i * 64;
+  unsigned short* rq = Xq + i * 64;
+  for (int f = 0; f < 64; ++f) { ra[f] = 0; rq[f] = 0; }
+  if (i >= n) {                       // spare rows behind the data: zero features, infinitely far
+    nrm[i] = 1e30f;
+    return;
+  }
+  float s = 0.f;
+  for (int f = 0; f < d; ++f) {
+    const float x = (float)(X[i * d + f] - mean[f]);
+    const unsigned short hi = f32_to_bf16_rn(x);
+    const unsigned short lo = f32_to_bf16_rn(x - bf16_to_f32(hi));
+    ra[f] = hi; ra[KNN_CAT_SEG + f] = hi; ra[2 * KNN_CAT_SEG + f] = lo;
+    rq[f] = hi; rq[KNN_CAT_SEG + f] = lo; rq[2 * KNN_CAT_SEG + f] = hi;
+    s = fmaf(x, x, s);
+  }
+  nrm[i] = s;
+  qnorm[i] = sqrtf(s);
+}
+
 // NKB blocks of 16 features (kpad = 16 NKB <= 128); refs are the A operand (LDS), queries the B operand (registers: lane =
 // query column j, k-half h); list handling as in knn_tile_kernel.
-template <int NKB, int KP, int NSUB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLISTS && KP == 8 && NKB == 4) ? 4 : 1, 4))) void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const float* __restrict__ nrm, int64_t n,
+// CAT (NKB = 2 only): the rows are the concatenated operands above, refs from Xb, queries from Xq.
+template <int NKB, int KP, int NSUB, bool CAT = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLISTS && KP == 8 && NKB == 4) ? 4 : 1, 4))) void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned short* __restrict__ Xq, const float* __restrict__ nrm, int64_t n,
                                                             int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d,
                                                             int* __restrict__ cand_i, int* __restrict__ gtau) {
   constexpr int KPAD = 16 * NKB;
@@ -356,7 +386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
   // query fragments: B[k][j], lane holds k = 8h .. 8h+7 of every block, hi and lo
   bf16x8 bh[NKB], bl[NKB];
   {
-    const uint4* qrow = (const uint4*)(Xb + qc * 2 * KPAD);
+    const uint4* qrow = (const uint4*)((CAT ? Xq : Xb) + qc * 2 * KPAD);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       bh[kb] = __builtin_bit_cast(bf16x8, qrow[kb * 2 + h]);
@@ -522,9 +552,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
         const char* rowp = tl + (sub * 32 + j) * ROWB + (kb * 16 + 8 * h) * 2;
         const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)rowp);
         const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(rowp + 2 * KPAD));
-        acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kb], acc[sub], 0, 0, 0);
-        acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kb], acc[sub], 0, 0, 0);
-        acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kb], acc[sub], 0, 0, 0);
+        if constexpr (CAT) {     // fragments kb and 2 + kb of the one concatenated contraction
+          acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kb], acc[sub], 0, 0, 0);
+          acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl[kb], acc[sub], 0, 0, 0);
+        } else {
+          acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kb], acc[sub], 0, 0, 0);
+          acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kb], acc[sub], 0, 0, 0);
+          acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kb], acc[sub], 0, 0, 0);
+        }
       }
     }
     // selection on value = |r|^2 - 2 q.r (element e of sub-tile `sub` is ref sub*32 + (e&3) + 8*(e>>2) + 4h, query j): per group
@@ -778,7 +813,8 @@ constexpr int tile_nsub(int DH, int KP) {
 }
 
 struct KnnBufs {
-  unsigned short* Xb = nullptr;      // bf16 hi | lo image (bf16 filter)
+  unsigned short* Xb = nullptr;      // bf16 hi | lo image (bf16 filter); concatenated form: the ref image [hi | hi | lo]
+  unsigned short* Xq = nullptr;      // concatenated form only: the query image [hi | lo | hi]
   float* nrm = nullptr;              // fp32 squared norms (bf16 filter)
   double* part = nullptr;            // per-block partial column sums / maxima of the centring pass
   float* rmax = nullptr;             // [0] largest centred norm (1 + 1e-6), [1] 1 if the input is finite: written by knn_rmax_kernel
@@ -792,7 +828,7 @@ struct KnnBufs {
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
   ~KnnBufs() {
     if (stream) hipStreamSynchronize(stream);   // pooled blocks are reused at once: nothing may still be running on them
-    glx_pool_free(Xb); glx_pool_free(nrm); glx_pool_free(part); glx_pool_free(rmax);
+    glx_pool_free(Xb); glx_pool_free(Xq); glx_pool_free(nrm); glx_pool_free(part); glx_pool_free(rmax);
     glx_pool_free(X); glx_pool_free(mean); glx_pool_free(dist); glx_pool_free(Rf); glx_pool_free(Qf); glx_pool_free(qnorm); glx_pool_free(cand_d);
     glx_pool_free(gtau); glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_li); glx_pool_free(fb_pi); glx_pool_free(fb_ld); glx_pool_free(fb_pd);
     glx_work_release(work);
@@ -879,23 +915,24 @@ constexpr int bf16_nsub(int NKB, int KP) { return (NKB >= 6 || KP >= 32) ? 1 : K
 constexpr int bf16_nsub(int NKB, int KP) { return (NKB >= 4 || KP >= 32) ? 1 : 2; }
 #endif
 
-template <int NKB, int KP>
+template <int NKB, int KP, bool CAT = false>
 static int launch_tile_bf16(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st) {
   constexpr int NSUB = bf16_nsub(NKB, KP);
   constexpr int BR = 32 * NSUB;
   constexpr int ROWB = 4 * 16 * NKB + 16;
   const size_t shm = (size_t)2 * BR * ROWB + (size_t)2 * BR * 4 + (size_t)((KNN_REGLISTS && KP == 8 && NKB == 4) ? KBUF : KP + KBUF) * 256 * 8;
   GLX_CHECK(shm <= 160 * 1024, GLX_EUNSUPPORTED, "glx_knn_bruteforce: bf16 filter needs %zu bytes of LDS", shm);
-  GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_bf16_kernel<NKB, KP, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_bf16_kernel<NKB, KP, NSUB, CAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)nsplit);
-  hipLaunchKernelGGL((knn_tile_bf16_kernel<NKB, KP, NSUB>), grid, dim3(256), shm, st, (const unsigned short*)b.Xb, (const float*)b.nrm, n, q0, q1,
-                     nsplit, b.cand_d, b.cand_i, b.gtau);
+  hipLaunchKernelGGL((knn_tile_bf16_kernel<NKB, KP, NSUB, CAT>), grid, dim3(256), shm, st, (const unsigned short*)b.Xb, (const unsigned short*)(CAT ? b.Xq : b.Xb),
+                     (const float*)b.nrm, n, q0, q1, nsplit, b.cand_d, b.cand_i, b.gtau);
   GLX_HIP(hipGetLastError());
   return GLX_OK;
 }
 
 template <int KP>
-static int launch_tile_bf16_nkb(int NKB, const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st) {
+static int launch_tile_bf16_nkb(int NKB, const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st, bool cat = false) {
+  if (cat) return launch_tile_bf16<2, KP, true>(b, n, q0, q1, nsplit, st);
   switch (NKB) {
     case 1: return launch_tile_bf16<1, KP>(b, n, q0, q1, nsplit, st);
     case 2: return launch_tile_bf16<2, KP>(b, n, q0, q1, nsplit, st);
@@ -1053,14 +1090,23 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   GLX_HIP(hipEventRecord(b.e0, st));
   int rc;
   if (use_bf16) {
+    // d <= 21: the three split products as ONE contraction over concatenated operands (4 MFMAs per 32 x 32 tile instead of 6)
+    const bool cat = d <= KNN_CAT_SEG && NKB == 2 && !(getenv("GLX_KNN_CAT") && atoi(getenv("GLX_KNN_CAT")) == 0);
     GLX_POOL(glx_pool_alloc((void**)&b.Xb, (size_t)(n + KNN_PAD_ROWS) * 2 * dpa * 2));
     GLX_POOL(glx_pool_alloc((void**)&b.nrm, (size_t)(n + KNN_PAD_ROWS) * 4));
-    hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3((unsigned)((n + KNN_PAD_ROWS + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const double*)b.mean,
-                       n, d, dpa, b.Xb, b.nrm, b.qnorm);
+    if (cat) {
+      GLX_POOL(glx_pool_alloc((void**)&b.Xq, (size_t)(n + KNN_PAD_ROWS) * 64 * 2));
+      hipLaunchKernelGGL(knn_prep_bf16_cat_kernel, dim3((unsigned)((n + KNN_PAD_ROWS + 255) / 256)), dim3(256), 0, st, (const double*)b.X,
+                         (const double*)b.mean, n, d, b.Xb, b.Xq, b.nrm, b.qnorm);
+    } else {
+      hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3((unsigned)((n + KNN_PAD_ROWS + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const double*)b.mean,
+                         n, d, dpa, b.Xb, b.nrm, b.qnorm);
+    }
     GLX_HIP(hipGetLastError());
-    if (KP == 8) rc = launch_tile_bf16_nkb<8>(NKB, b, n, q0, q1, nsplit, st);
-    else if (KP == 16) rc = launch_tile_bf16_nkb<16>(NKB, b, n, q0, q1, nsplit, st);
-    else rc = launch_tile_bf16_nkb<32>(NKB, b, n, q0, q1, nsplit, st);
+    g_knn_stats[9] = cat ? 1.0 : 0.0;
+    if (KP == 8) rc = launch_tile_bf16_nkb<8>(NKB, b, n, q0, q1, nsplit, st, cat);
+    else if (KP == 16) rc = launch_tile_bf16_nkb<16>(NKB, b, n, q0, q1, nsplit, st, cat);
+    else rc = launch_tile_bf16_nkb<32>(NKB, b, n, q0, q1, nsplit, st, cat);
   } else {
     GLX_POOL(glx_pool_alloc((void**)&b.Rf, (size_t)n * dpa * 4));
     GLX_POOL(glx_pool_alloc((void**)&b.Qf, (size_t)n * dpa * 4));

@@ -185,12 +185,13 @@ def knn_weights_rows(J, D, k, kernel='gaussian'):
 
 
 def reverse_messages(J, w, lo, bounds):
-    """For the list entries (i -> j, w_ij) of the rows [lo, lo+len(J)): the triples (j, i, w_ij) the owner of row j
-    needs, per destination rank, in list order (row after row, neighbour after neighbour)."""
+    """For the list entries (i -> j, w_ij) of the rows [lo, lo+len(J)): the tuples (j, i, w_ij, position of j in row i's list)
+    the owner of row j needs, per destination rank, in list order (row after row, neighbour after neighbour)."""
     n_rows, k = J.shape
     rows_i = np.repeat(np.arange(lo, lo + n_rows, dtype=np.int64), k)
     cols_j = J.reshape(-1).astype(np.int64)
     vals = np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
+    pos = np.tile(np.arange(k, dtype=np.int64), n_rows)
     dest = np.searchsorted(bounds, cols_j, side='right') - 1
     order = np.argsort(dest, kind='stable')                     # stable: list order survives inside a destination
     counts = np.bincount(dest, minlength=len(bounds) - 1)
@@ -198,13 +199,39 @@ def reverse_messages(J, w, lo, bounds):
     out = []
     for r in range(len(bounds) - 1):
         sel = order[offs[r]:offs[r + 1]]
-        out.append((cols_j[sel], rows_i[sel], vals[sel]))
+        out.append((cols_j[sel], rows_i[sel], vals[sel], pos[sel]))
     return out
 
 
+def assemble_rows_device(lo, hi, n, J, w, received, symmetrize=True, sym_rule='mean', device=None):
+    """assemble_rows on the GPU (glx_knn_rows_to_csr: the merge kernels of the single-GPU assembly applied to the block):
+    bit-identical rows, without the scipy COO / CSR passes over the block (14.7 s at one rank of n = 1e7).  `received`: tuples
+    (j, i, w_ij, pos) per source rank."""
+    from . import _hip
+    if symmetrize and received:
+        rj = np.concatenate([t[0] for t in received])
+        ri = np.concatenate([t[1] for t in received])
+        rv = np.concatenate([t[2] for t in received])
+        rp = np.concatenate([t[3] for t in received])
+    else:
+        rj = ri = rp = np.zeros(0, np.int64)
+        rv = np.zeros(0)
+    sym = 0 if not symmetrize else (1 if sym_rule == 'mean' else 2)
+    return _hip.knn_rows_to_csr(J, w, n, lo, rj, ri, rp, rv, sym=sym, device=device)
+
+
+def device_assembly_available():
+    """Is there a GPU (and the library) to assemble on?  The CPU tests run the scipy expressions."""
+    from . import _hip
+    try:
+        return _hip.load(required=False) is not None and _hip.device_count() > 0
+    except Exception:
+        return False
+
+
 def assemble_rows(lo, hi, n, J, w, received, symmetrize=True, sym_rule='mean'):
-    """Rows [lo, hi) of the weight matrix of weightmatrix.knn from the block's own lists (J, w) and the reverse triples
-    `received` (list over source ranks, in rank order, of (j, i, w_ij) with j in [lo, hi)).  The reference's expressions
+    """Rows [lo, hi) of the weight matrix of weightmatrix.knn from the block's own lists (J, w) and the reverse tuples
+    `received` (list over source ranks, in rank order, of (j, i, w_ij[, pos]) with j in [lo, hi)).  The reference's expressions
     (weightmatrix.py:170-186) on the row block: COO -> CSR sums duplicates, (W + W^T)/2 or the element-wise max,
     zero diagonal, explicit zeros dropped."""
     m = hi - lo
@@ -322,7 +349,7 @@ def _alltoallv(dist, arrays, dtype, group=None, device=None):
 class ShardedGraph:
     """One rank's rows of the kNN weight matrix and of the Poisson operator plus its exchange plan, built collectively."""
 
-    def __init__(self, dist, n, J_own, D_own, k, kernel='gaussian', symmetrize=True, group=None, device=None, bounds=None):
+    def __init__(self, dist, n, J_own, D_own, k, kernel='gaussian', symmetrize=True, group=None, device=None, bounds=None, assemble='auto'):
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         self.dist, self.group, self.rank, self.world, self.n = dist, group, rank, world, n
         self.bounds = bounds = block_bounds(n, world) if bounds is None else np.asarray(bounds, dtype=np.int64)   # any contiguous blocks
@@ -336,8 +363,16 @@ class ShardedGraph:
             rj = _alltoallv(dist, [m[0] for m in msgs], np.int64, group, device)
             ri = _alltoallv(dist, [m[1] for m in msgs], np.int64, group, device)
             rv = _alltoallv(dist, [m[2] for m in msgs], np.float64, group, device)
-            received = list(zip(rj, ri, rv))
-        self.W_own = assemble_rows(lo, hi, n, J, w, received, symmetrize, sym_rule)
+            rp = _alltoallv(dist, [m[3] for m in msgs], np.int64, group, device)
+            received = list(zip(rj, ri, rv, rp))
+        # the merge of the block's rows: on the GPU when there is one (assemble='device' / 'host' force a path)
+        on_device = assemble == 'device' or (assemble == 'auto' and device_assembly_available())
+        self.assembled_on = 'device' if on_device else 'host'
+        if on_device:
+            dev_idx = device.index if hasattr(device, 'index') and not isinstance(device, int) else device
+            self.W_own = assemble_rows_device(lo, hi, n, J, w, received, symmetrize, sym_rule, device=dev_idx)
+        else:
+            self.W_own = assemble_rows(lo, hi, n, J, w, received, symmetrize, sym_rule)
         self.P_own, self.deg_own, self.D_own = poisson_rows(self.W_own)
         needed, reqs = halo_requests(self.P_own, lo, hi, bounds)
         got = _alltoallv(dist, reqs, np.int64, group, device)

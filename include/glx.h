@@ -328,6 +328,15 @@ int glx_knn_to_csr(const int64_t* ind, const double* dist, const double* weights
 int glx_knn_to_csr_into(const int64_t* ind, const double* dist, const double* weights, int64_t n, int kk, int k,
                         int kernel, int sym, int64_t cap, int32_t* rowptr, int32_t* col, double* val,
                         int64_t* nnz_out, int device);
+/* A BLOCK of rows [row_base, row_base + m) of the same matrix, for the sharded build (one rank's rows, SURVEY.md 8e
+ * "symmetrisation by owner rank"): the block's own lists (ind_own, w_own: (m, k), weights given, column ids global < n_cols)
+ * plus the reverse entries the owners of the other rows sent -- rev_row[e] = j (a row of the block), rev_src[e] = i,
+ * rev_pos[e] = position of j in row i's list, rev_w[e] = w_ij.  Same merge as glx_knn_to_csr, so the rows are bit-identical
+ * to the rows of the whole matrix.  sym: 0 none, 1 (W+W^T)/2, 2 element-wise max.  rowptr (m + 1), col / val (cap entries)
+ * are the caller's; GLX_EINVAL if the result does not fit. */
+int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, int64_t m, int k, int64_t n_cols, int64_t row_base,
+                        const int64_t* rev_row, const int64_t* rev_src, const int64_t* rev_pos, const double* rev_w, int64_t n_rev,
+                        int sym, int64_t cap, int32_t* rowptr, int32_t* col, double* val, int64_t* nnz_out, int device);
 
 #ifdef __cplusplus
 }

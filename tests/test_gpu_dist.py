@@ -401,3 +401,40 @@ def test_distributed_cg_multi_rank_hip_over_gloo(case, world, tmp_path):
     for k in range(world):
         q = json.load(open(out + '.%d' % k))
         assert q['labels_equal'] and q['max_abs_diff'] <= 1e-5 * max(1.0, q['scale']) and abs(q['it'] - q['it_ref']) <= 1, q
+
+
+@pytest.mark.parametrize('kernel', ['gaussian', 'uniform', 'singular'])
+def test_block_assembly_on_device_matches_scipy(golden, kernel):
+    """dist_build's symmetrisation of ONE rank's rows on the GPU (glx_knn_rows_to_csr: own lists + the reverse entries the other
+    owners send) against the reference's scipy expressions on the same block (dist_build.assemble_rows): identical CSR arrays,
+    for unequal blocks, both symmetrisation rules, hub rows (more than 1024 forward + reverse entries) and duplicate list entries."""
+    from graphlearning_amd import dist_build, _hip
+    _hip.require_device()
+    g = golden('g3_blobs5000.npz')
+    cases = [(g['knn_ind'].astype(np.int64), g['knn_dist'], 10)]
+    rng = np.random.default_rng(3)
+    n2 = 3000
+    J2 = rng.integers(0, n2, size=(n2, 9))
+    J2[:, 0] = np.arange(n2)
+    J2[:, 1] = 7                       # a hub: every vertex lists vertex 7
+    J2[::5, 3] = J2[::5, 2]            # duplicate list entries
+    D2 = np.sort(rng.random((n2, 9)), axis=1)
+    D2[:, 0] = 0
+    cases.append((J2, D2, 8))
+    for J, D, k in cases:
+        n = J.shape[0]
+        Jk, w = dist_build.knn_weights_rows(J, D, k + 1, kernel)
+        sym_rule = 'max' if kernel in ('distance', 'uniform', 'singular') else 'mean'
+        bounds = np.array([0, n // 5, n // 2, n], dtype=np.int64)
+        msgs = [dist_build.reverse_messages(Jk[bounds[r]:bounds[r + 1]], w[bounds[r]:bounds[r + 1]], int(bounds[r]), bounds) for r in range(3)]
+        for me in range(3):
+            lo, hi = int(bounds[me]), int(bounds[me + 1])
+            received = [msgs[r][me] for r in range(3)]
+            ref = dist_build.assemble_rows(lo, hi, n, Jk[lo:hi], w[lo:hi], received, True, sym_rule)
+            got = dist_build.assemble_rows_device(lo, hi, n, Jk[lo:hi], w[lo:hi], received, True, sym_rule, device=0)
+            assert got.shape == ref.shape and np.array_equal(got.indptr, ref.indptr), (kernel, me)
+            assert np.array_equal(got.indices, ref.indices) and np.array_equal(got.data, ref.data), (kernel, me)
+        # without symmetrisation
+        ref = dist_build.assemble_rows(0, n // 5, n, Jk[:n // 5], w[:n // 5], None, False, sym_rule)
+        got = dist_build.assemble_rows_device(0, n // 5, n, Jk[:n // 5], w[:n // 5], None, False, sym_rule, device=0)
+        assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices) and np.array_equal(got.data, ref.data)
