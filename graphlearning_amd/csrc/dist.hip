@@ -75,10 +75,17 @@ static RcclApi* rccl_api() {
     }                                                                                                      \
   } while (0)
 
+struct glx_dist_sweep;
 struct glx_comm {
   ncclComm_t comm = nullptr;   // null: single rank, no transport needed
   int rank = 0, nranks = 1, device = 0;
+  // sweeps created on this communicator and still alive.  Their captured device graphs hold RCCL kernels: ncclCommDestroy
+  // waits for every such graph to be released (seen as a hang when a communicator was closed before its sweep, round 3), so
+  // glx_dist_destroy releases them first and detaches the sweeps.
+  std::vector<glx_dist_sweep*> sweeps;
+  std::mutex mu;
 };
+static void detach_sweep(glx_dist_sweep* s);
 
 extern "C" int glx_dist_unique_id(char id_out[128]) {
   GLX_CHECK(id_out, GLX_EINVAL, "glx_dist_unique_id: null output");
@@ -141,6 +148,14 @@ extern "C" int glx_dist_comm_info(const glx_comm* c, int32_t info[4]) {
 
 extern "C" int glx_dist_destroy(glx_comm* c) {
   if (!c) return GLX_OK;
+  {
+    std::vector<glx_dist_sweep*> live;
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      live.swap(c->sweeps);
+    }
+    for (glx_dist_sweep* s : live) detach_sweep(s);      // graphs with RCCL kernels go before the communicator does
+  }
   if (c->comm) {
     hipSetDevice(c->device);
     RcclApi* a = rccl_api();
@@ -200,8 +215,24 @@ static int64_t part_lo1(const glx_dist_sweep* s) { return s->fused ? s->n_own : 
 static size_t recb(const glx_dist_sweep* s, int64_t rows) { return std::max<size_t>((size_t)rows * s->L.ld * s->L.esize, 64); }
 static char* rec_at(void* base, const glx_dist_sweep* s, int64_t row) { return (char*)base + (size_t)row * s->L.ld * s->L.esize; }
 
+// the communicator is going away: finish the sweep's work, release its captured graphs, forget the communicator (later
+// collective calls on the sweep fail with an error; fetch / destroy still work)
+static void detach_sweep(glx_dist_sweep* s) {
+  hipSetDevice(s->device);
+  if (s->stream) hipStreamSynchronize(s->stream);
+  if (s->xstream) hipStreamSynchronize(s->xstream);
+  for (auto& kv : s->graphs) hipGraphExecDestroy(kv.second);
+  s->graphs.clear();
+  s->comm = nullptr;
+}
+
 extern "C" int glx_dist_sweep_destroy(glx_dist_sweep* s) {
   if (!s) return GLX_OK;
+  if (s->comm) {
+    std::lock_guard<std::mutex> lk(s->comm->mu);
+    auto& v = s->comm->sweeps;
+    v.erase(std::remove(v.begin(), v.end(), s), v.end());
+  }
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->xstream) hipStreamSynchronize(s->xstream);
@@ -375,6 +406,10 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
   DS_HIP(hipStreamSynchronize(s->stream));
 #undef DS_HIP
 #undef DS_FAIL
+  {
+    std::lock_guard<std::mutex> lk(comm->mu);
+    comm->sweeps.push_back(s);
+  }
   *out = s;
   return GLX_OK;
 }
@@ -649,6 +684,7 @@ static int global_err(glx_dist_sweep* s, int64_t t0, int64_t cnt) {
 extern "C" int glx_poisson_sweep_dist(glx_dist_sweep* s, int min_iter, int max_iter, int check_every, double err0, int* T_out,
                                       float* device_ms_out) {
   GLX_CHECK(s && s->problem_set, GLX_EINVAL, "glx_poisson_sweep_dist: set the problem first");
+  GLX_CHECK(s->comm, GLX_EINVAL, "glx_poisson_sweep_dist: the communicator of this sweep has been destroyed");
   GLX_CHECK(min_iter >= 0 && max_iter >= 0 && check_every >= 1 && check_every < ERR_SLOTS, GLX_EINVAL,
             "glx_poisson_sweep_dist: bad iteration bounds");
   GLX_CHECK(s->comm->comm || s->comm->nranks == 1, GLX_EINVAL, "glx_poisson_sweep_dist: this communicator has no transport (use the stepwise form)");

@@ -4,8 +4,8 @@ O=gpurun_out/r03c
 mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 for m in leak exc gc_comm_first; do for t in notorch torch; do
-  timeout 90 python scripts/exit_hang_probe.py $m $t > $O/exit_$m_$t.log 2>&1; echo "exit probe $m $t: rc $?"
-  GLX_NO_ATEXIT_ABANDON=1 timeout 90 python scripts/exit_hang_probe.py $m $t > $O/exit_noabandon_$m_$t.log 2>&1; echo "exit probe (no abandon) $m $t: rc $?"
+  timeout 90 python scripts/exit_hang_probe.py $m $t > $O/exit_${m}_${t}.log 2>&1; echo "exit probe $m $t: rc $?"
+  GLX_NO_ATEXIT_ABANDON=1 timeout 90 python scripts/exit_hang_probe.py $m $t > $O/exit_noabandon_${m}_${t}.log 2>&1; echo "exit probe (no abandon) $m $t: rc $?"
 done; done 2>&1 | tee $O/exit_probe.log
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest exit $?" >> $O/pytest.log
 grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" $O/pytest.log | tail -15

@@ -145,7 +145,8 @@ def rccl_latency_us(P70k, order, prob, C):
     if res.get('rccl'):
         # what one grouped ncclSend/ncclRecv exchange of `halo_bytes` costs in line; the part that is not bandwidth is the latency
         res['exchange_us'] = max(0.0, res['rccl'] - res['rccl_launch_alone_us'])
-        res['latency_us'] = max(0.0, res['exchange_us'] - res['halo_bytes'] / (LINK_GBS_RCCL * 1e3))
+        # the data of a self-exchange move inside one GPU (~1 TB/s): the rest of the exchange's time is its fixed cost
+        res['latency_us'] = max(0.0, res['exchange_us'] - res['halo_bytes'] / 1e6)
     return res
 
 

@@ -400,3 +400,44 @@ def test_no_device_memory_growth_over_repeated_builds_and_fits(gl):
         gc.collect()
         marks.append(in_use())
     assert max(marks[4:]) - marks[3] <= 8 << 20, [m >> 20 for m in marks]
+
+
+def test_operator_cache_follows_in_place_edits_of_W(golden):
+    """mutating W.data in place between two fits must not reuse the device operator of the old values (the
+    reference rebuilds P in every fit, ssl.py:615-644): the second fit equals a fresh model's fit on the edited matrix -- for the
+    gradient-descent and the CG solver of ssl.poisson, ssl.laplace and ssl.randomwalk -- while ssl_trials, inside which W cannot
+    change, fingerprints the graph once."""
+    import graphlearning_amd as gl
+    from graphlearning_amd import _hip, utils as glutils
+    from conftest import csr_from
+    _hip.require_device()
+    g = golden('g1_twomoons.npz')
+    ti, lab = g['train_ind'], g['labels']
+    makers = [lambda W: gl.ssl.poisson(W, solver='gradient_descent'), lambda W: gl.ssl.poisson(W), lambda W: gl.ssl.laplace(W),
+              lambda W: gl.ssl.randomwalk(W)]
+    for mk in makers:
+        W = sparse_csr(csr_from(g, 'W_gaussian'))
+        model = mk(W)
+        u0 = np.array(model.fit(ti, lab[ti]))
+        # a symmetric in-place edit: scale the weights of vertex 0's edges (both directions)
+        idx = np.flatnonzero((np.repeat(np.arange(W.shape[0]), np.diff(W.indptr)) == 0) | (W.indices == 0))
+        W.data[idx] *= 0.25
+        u1 = np.array(model.fit(ti, lab[ti]))
+        fresh = np.array(mk(sparse_csr(W.copy())).fit(ti, lab[ti]))
+        assert np.array_equal(u1, fresh), model.name
+        assert not np.array_equal(u1, u0), model.name
+    # ssl_trials fingerprints once per loop (the per-trial rate does not pay for the hash)
+    calls = []
+    real = glutils.matrix_fingerprint
+    try:
+        glutils.matrix_fingerprint = lambda M: (calls.append(1), real(M))[1]
+        m = gl.ssl.poisson(sparse_csr(csr_from(g, 'W_gaussian')), solver='gradient_descent')
+        m.ssl_trials([ti, ti[::-1].copy(), ti], lab, save_results=False)
+    finally:
+        glutils.matrix_fingerprint = real
+    assert len(calls) == 1, calls
+
+
+def sparse_csr(W):
+    from scipy import sparse
+    return sparse.csr_matrix(W)

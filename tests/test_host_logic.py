@@ -207,3 +207,31 @@ def test_symmetric_poisson_operator_equals_scipy_expressions(golden):
     W2._glx_sym = glutils.symmetric_fingerprint(W2)
     W3 = W2 + sparse.identity(W2.shape[0])
     assert not glutils.known_symmetric(W3) and not glutils.known_symmetric(sparse.csr_matrix(cases[0]))
+
+
+def test_matrix_fingerprint_sees_in_place_edits(golden):
+    """The device-resident operators of the learners are keyed by utils.matrix_fingerprint (ADVICE / VERDICT r02: an id(W) key
+    reused a stale operator after an in-place edit of W.data; the reference rebuilds its operator in every fit, ssl.py:615-644):
+    equal content -> equal key (also for a copy); ANY in-place edit -- one value by one ulp, two values swapped (which leaves every
+    sum unchanged), an index -- gives another key."""
+    from graphlearning_amd import utils as glutils
+    from conftest import csr_from
+    W = sparse.csr_matrix(csr_from(golden('g1_twomoons.npz'), 'W_gaussian'))
+    f0 = glutils.matrix_fingerprint(W)
+    assert f0 == glutils.matrix_fingerprint(W.copy()) and f0[0] == W.shape and f0[1] == W.nnz
+    W.data[17] = np.nextafter(W.data[17], 1.0)
+    f1 = glutils.matrix_fingerprint(W)
+    assert f1 != f0
+    a, b = W.data[5], W.data[9]
+    assert a != b
+    W.data[5], W.data[9] = b, a                      # sums of the data are unchanged
+    f2 = glutils.matrix_fingerprint(W)
+    assert f2 != f1
+    W.indices[0], W.indices[1] = W.indices[1], W.indices[0]
+    assert glutils.matrix_fingerprint(W) != f2
+    # W[i, j] = v on an existing entry is an in-place edit of W.data
+    W2 = sparse.csr_matrix(csr_from(golden('g1_twomoons.npz'), 'W_gaussian'))
+    g0 = glutils.matrix_fingerprint(W2)
+    i, j = 0, int(W2.indices[0])
+    W2[i, j] = 0.123
+    assert glutils.matrix_fingerprint(W2) != g0
