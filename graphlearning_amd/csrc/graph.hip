@@ -497,8 +497,27 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   const int NX = 8;
   std::vector<std::vector<SliceHdr>> ghdr(NX);
   std::vector<std::vector<int32_t>> grow(NX), glen(NX);
+  // the eight id ranges carry equal WORK, not equal row counts (GLX_XCD_BALANCE=0: equal rows, the round-2 rule): the launch ends
+  // when the slowest XCD does, and under a locality order the rows' lengths drift along the order (a cluster's dense core
+  // first, its fringe last).  Work of a row = its entries + XCD_ROW_COST (header, epilogue, store).
+  std::vector<int64_t> xb(NX + 1, 0);
+  {
+    const char* e = getenv("GLX_XCD_BALANCE");
+    const bool by_work = !(e && atoi(e) == 0) && n >= NX;
+    const int64_t row_cost = 3;
+    int64_t total = 0;
+    if (by_work) for (int64_t i = 0; i < n; ++i) total += rowlen(i) + row_cost;
+    int64_t acc = 0, i = 0;
+    for (int x = 1; x < NX; ++x) {
+      if (!by_work) { xb[x] = n * x / NX; continue; }
+      const int64_t want = total * x / NX;
+      while (i < n && acc < want) { acc += rowlen(i) + row_cost; ++i; }
+      xb[x] = i;
+    }
+    xb[NX] = n;
+  }
   for (int x = 0; x < NX; ++x) {
-    const int64_t b0 = n * x / NX, b1 = n * (x + 1) / NX;
+    const int64_t b0 = xb[x], b1 = xb[x + 1];
     const int64_t m = b1 - b0;
     std::vector<int32_t> order(m);
     // sort by decreasing length inside windows of `sigma` consecutive ids (SELL-C-sigma): small

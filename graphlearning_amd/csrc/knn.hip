@@ -1090,7 +1090,8 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   GLX_HIP(hipEventRecord(b.e0, st));
   int rc;
   if (use_bf16) {
-    // d <= 21: the three split products as ONE contraction over concatenated operands (4 MFMAs per 32 x 32 tile instead of 6)
+    // 17 <= d <= 21 (two blocks of 16 per half): the three split products as ONE contraction over concatenated operands,
+    // 4 MFMAs per 32 x 32 tile instead of 6 (d <= 16 needs 3 either way)
     const bool cat = d <= KNN_CAT_SEG && NKB == 2 && !(getenv("GLX_KNN_CAT") && atoi(getenv("GLX_KNN_CAT")) == 0);
     GLX_POOL(glx_pool_alloc((void**)&b.Xb, (size_t)(n + KNN_PAD_ROWS) * 2 * dpa * 2));
     GLX_POOL(glx_pool_alloc((void**)&b.nrm, (size_t)(n + KNN_PAD_ROWS) * 4));

@@ -192,13 +192,13 @@ def reverse_messages(J, w, lo, bounds):
     cols_j = J.reshape(-1).astype(np.int64)
     vals = np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
     pos = np.tile(np.arange(k, dtype=np.int64), n_rows)
-    dest = np.searchsorted(bounds, cols_j, side='right') - 1
-    order = np.argsort(dest, kind='stable')                     # stable: list order survives inside a destination
-    counts = np.bincount(dest, minlength=len(bounds) - 1)
-    offs = np.concatenate([[0], np.cumsum(counts)])
+    world = len(bounds) - 1
+    if world == 1:
+        return [(cols_j, rows_i, vals, pos)]
+    dest = (np.searchsorted(bounds, cols_j, side='right') - 1).astype(np.int8 if world < 128 else np.int32)
     out = []
-    for r in range(len(bounds) - 1):
-        sel = order[offs[r]:offs[r + 1]]
+    for r in range(world):                                       # one pass per destination (few): list order survives, no sort of n k keys
+        sel = np.flatnonzero(dest == r)
         out.append((cols_j[sel], rows_i[sel], vals[sel], pos[sel]))
     return out
 
@@ -282,8 +282,10 @@ def poisson_rows(W_own):
 # ---- step 4: halo planning with a request exchange -----------------------------------------------------------------
 def halo_requests(P_own, lo, hi, bounds):
     """The remote columns the block's rows reference: (needed ids ascending = grouped by owner, per-owner request lists)."""
-    cols = np.unique(P_own.indices)
-    needed = cols[(cols < lo) | (cols >= hi)].astype(np.int64)
+    seen = np.zeros(P_own.shape[1], dtype=bool)                 # distinct columns by a mark pass, not by sorting nnz keys
+    seen[P_own.indices] = True
+    seen[lo:hi] = False
+    needed = np.flatnonzero(seen).astype(np.int64)
     owner = np.searchsorted(bounds, needed, side='right') - 1
     reqs = [needed[owner == r] for r in range(len(bounds) - 1)]
     return needed, reqs
@@ -314,9 +316,11 @@ class ShardPlan:
         self.send_idx = new_of_old[send_idx]
         self.n_boundary = int(is_b.sum())
         sub = sparse.csr_matrix(P_own[perm_local, :])                                    # row slicing keeps each row's entry order
-        cols = sub.indices.astype(np.int64)
-        local = np.where((cols >= lo) & (cols < hi), new_of_old[np.clip(cols - lo, 0, max(m - 1, 0))],
-                         m + np.searchsorted(needed, cols))
+        cols = sub.indices
+        local_of = np.full(n, -1, dtype=np.int64)                       # global id -> local column: a table, not a binary search per entry
+        local_of[lo:hi] = new_of_old
+        local_of[needed] = m + np.arange(len(needed), dtype=np.int64)
+        local = local_of[cols]
         self.P_local = sparse.csr_matrix((sub.data, local.astype(np.int32), sub.indptr), shape=(m, m + self.n_halo))
         self.P_local.has_sorted_indices = False
 

@@ -19,7 +19,8 @@ Db = sparse.spdiags(dinv, 0, n, n).tocsr() * src
 orders = {'library rcm': None, 'scipy rcm': gdist.locality_order(P).astype(np.int32)}
 rng = np.random.default_rng(0)
 orders['scipy rcm reversed'] = orders['scipy rcm'][::-1].copy()
-for rep in range(2):
+for rep, balance in ((0, '0'), (1, '1'), (2, '0'), (3, '1')):
+    os.environ['GLX_XCD_BALANCE'] = balance
     for name, order in orders.items():
         dev = _hip.DeviceGraph(P, dtype=np.float64, order=order)
         sw = _hip.Sweep(dev, k, min_iter=50, max_iter=50, use_hipgraph=True)
@@ -32,10 +33,14 @@ for rep in range(2):
         perm = dev.order()
         pos = np.empty(n, dtype=np.int64); pos[perm] = np.arange(n)
         rows = np.repeat(np.arange(n), np.diff(P.indptr))
-        xcd = pos[rows] * 8 // n
-        distinct = sum(len(np.unique(P.indices[xcd == x])) for x in range(8)) / n
-        bw = np.mean(np.abs(pos[rows] - pos[P.indices]))
-        print('%-20s: %.2f us/launch; %.2f distinct records per vertex over the 8 XCD ranges; mean |pos_i - pos_j| %.0f; %s'
-              % (name, tot * 1e3 / (40 * 50), distinct, bw, dev.info()), flush=True)
+        lens = np.diff(P.indptr)[perm]                      # row lengths along the order
+        if balance == '1':
+            work = np.cumsum(lens + 3)
+            cuts = [0] + [int(np.searchsorted(work, work[-1] * x // 8, side='left')) + 0 for x in range(1, 8)] + [n]
+        else:
+            cuts = [n * x // 8 for x in range(9)]
+        per = [int(lens[cuts[x]:cuts[x + 1]].sum()) for x in range(8)]
+        print('%-20s balance=%s: %.2f us/launch; entries per XCD range max/mean %.3f (rows %d..%d); %s'
+              % (name, balance, tot * 1e3 / (40 * 50), max(per) * 8 / sum(per), min(np.diff(cuts)), max(np.diff(cuts)), dev.info()), flush=True)
         sw.close()
         dev.close()

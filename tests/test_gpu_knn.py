@@ -30,7 +30,7 @@ def test_knnsearch_golden(gl, golden, tag, flt, monkeypatch):
     ind, dist = gl.weightmatrix.knnsearch(X, 11)
     st = _hip.knn_stats()
     assert st['filter'] == flt.split('_')[0] and st['fallback_rows'] <= 20
-    assert st['concatenated'] == (flt == 'bf16x3' and tag in ('d20', 'd3'))
+    assert st['concatenated'] == (flt == 'bf16x3' and tag == 'd20')      # 17 <= d <= 21: two blocks of 16 per split half, 3 d <= 63 concatenated
     assert ind.dtype == np.int64 and dist.dtype == np.float64
     assert np.array_equal(ind, J)                      # identical neighbour sets and order
     assert np.array_equal(dist[:, 0], np.zeros(len(X)))  # self distance exactly 0
