@@ -492,7 +492,21 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   if (G != 4) { L1 = 1 << 30; L4 = 1 << 30; }
   auto old_of = [&](int64_t nid) -> int64_t { return renum ? g->h_perm[nid] : nid; };
   auto rowlen = [&](int64_t nid) { const int64_t o = old_of(nid); return g->h_rowptr[o + 1] - g->h_rowptr[o]; };
-  auto klass = [&](int len) { return len > L4 ? 16 : (len > L1 ? 4 : 1); };
+  // GLX_SELL_CAP = c (round 3): every slot holds at most c entries of its row -- a row of len entries takes the smallest
+  // S in {1, 2, 4, 8, 16} with S * c >= len slots (longer rows: S = 16 and more chunks) -- so that every slice needs the same
+  // c / 4 chunks: the launch ends when its LAST slice does, and a slice's chunks are dependent memory round trips.
+  // Unset: the round-1 classes (S = 1 up to L1 entries, 4 up to L4, else 16).
+  int cap = 0;
+  if (const char* e = getenv("GLX_SELL_CAP")) cap = atoi(e) / 4 * 4;
+  if (G != 4) cap = 0;
+  auto klass = [&](int len) {
+    if (cap > 0) {
+      int S = 1;
+      while (S < 16 && S * cap < len) S *= 2;
+      return S;
+    }
+    return len > L4 ? 16 : (len > L1 ? 4 : 1);
+  };
 
   const int NX = 8;
   std::vector<std::vector<SliceHdr>> ghdr(NX);

@@ -273,6 +273,18 @@ def poisson_rows(W_own):
     W^T is row i of W bit for bit, and `D * rows` through scipy's csr product leaves every row's entries in the order
     the reference's global product leaves them (the accumulation order of `P*u`)."""
     m, n = W_own.shape
+    from . import _hip
+    plain = (W_own.indptr.dtype == np.int32 and W_own.indices.dtype == np.int32 and W_own.data.dtype == np.float64
+             and W_own.data.flags.c_contiguous and W_own.indices.flags.c_contiguous and W_own.indptr.flags.c_contiguous)
+    if plain and _hip.load(required=False) is not None:
+        # the same arrays by the library's host loops (ssl._poisson_operator_symmetric: row sums in stored order, row i of W scaled
+        # by 1/deg_i with its entries reversed -- what scipy's csr product emits), without scipy's passes over 10^8 entries
+        deg = _hip.host_row_sums(W_own)
+        dinv = deg ** (-1)
+        indices, data = _hip.host_reverse_scale_rows(W_own, dinv)
+        P = sparse.csr_matrix((data, indices, W_own.indptr.copy()), shape=(m, n))
+        P.has_sorted_indices = False
+        return P, deg, sparse.spdiags(dinv, 0, m, m).tocsr()
     deg = W_own * np.ones(n)                                               # graph.degree_vector: csr row sums in stored order
     D = sparse.spdiags(deg ** (-1), 0, m, m).tocsr()                      # graph.degree_matrix(p=-1): d**p
     P = D * W_own
@@ -315,7 +327,10 @@ class ShardPlan:
         self.own = lo + perm_local                                                       # global ids in local order
         self.send_idx = new_of_old[send_idx]
         self.n_boundary = int(is_b.sum())
-        sub = sparse.csr_matrix(P_own[perm_local, :])                                    # row slicing keeps each row's entry order
+        if self.n_boundary == 0 or self.n_boundary == m:                                 # the local order is the block's order: no row shuffle
+            sub = P_own
+        else:
+            sub = sparse.csr_matrix(P_own[perm_local, :])                                # row slicing keeps each row's entry order
         cols = sub.indices
         local_of = np.full(n, -1, dtype=np.int64)                       # global id -> local column: a table, not a binary search per entry
         local_of[lo:hi] = new_of_old
@@ -330,6 +345,8 @@ def _alltoallv(dist, arrays, dtype, group=None, device=None):
     """Variable all-to-all of 1-D numpy arrays (one per destination) -> list per source."""
     import torch
     world = dist.get_world_size(group)
+    if world == 1:                                   # nothing to move
+        return [np.ascontiguousarray(arrays[0], dtype=dtype)]
     tdt = {np.int64: torch.int64, np.float64: torch.float64}[dtype]
     counts = torch.tensor([len(a) for a in arrays], dtype=torch.int64)
     rcounts = torch.empty(world, dtype=torch.int64)

@@ -13,7 +13,8 @@ ap.add_argument('--big', type=int, default=0)
 ap.add_argument('--cache', default='/tmp/knn_big.npz')
 ap.add_argument('--reps', type=int, default=40)
 args = ap.parse_args()
-tag = 'GLX_PERSIST=%s GLX_WPB-build' % os.environ.get('GLX_PERSIST', '(default)')
+tag = 'GLX_PERSIST=%s GLX_SELL_CAP=%s GLX_XCD_BALANCE=%s' % (os.environ.get('GLX_PERSIST', '(default)'), os.environ.get('GLX_SELL_CAP', '(classes 24/96)'),
+                                                          os.environ.get('GLX_XCD_BALANCE', '(default)'))
 
 
 def probe(W, labels, train_ind, name, dtype, reps, T=50):
@@ -31,8 +32,8 @@ def probe(W, labels, train_ind, name, dtype, reps, T=50):
         ms = sw.run()[1]
         tot += ms
         best = min(best, ms)
-    print('%s  %-18s %s: %.2f us/launch mean, %.2f best (HIP events over %d x %d launches)' % (
-        tag, name, np.dtype(dtype).name, tot * 1e3 / (reps * T), best * 1e3 / T, reps, T), flush=True)
+    print('%s  %-18s %s: %.2f us/launch mean, %.2f best (HIP events over %d x %d launches); slices %d, stored %d' % (
+        tag, name, np.dtype(dtype).name, tot * 1e3 / (reps * T), best * 1e3 / T, reps, T, dev.info()['slices'], dev.info()['stored']), flush=True)
     u = sw.fetch()
     sw.close()
     m._cache[1].close()
