@@ -487,26 +487,18 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   const int64_t n = g->n_rows;
   const bool renum = !g->h_perm.empty();
   int L1 = 24, L4 = 96;   // measured on the 70k k=10 graph (fp64): 24/96 13.3 us, 32/128 15.2 us, 16/64 15.4 us
+  // Round 3: once the vertex records no longer fit the L2s (8 x 4 MB) the balance tips the other way -- every gather is a trip to
+  // the Infinity Cache / HBM whatever the slice shape, and what counts is fewer, longer slices (a row of 25 entries should not take
+  // four quarter-filled slots) and less padding: n = 1e6 (d = 64): 277.1 us with 24/96, 258.5 with 40/160, 248.6 with 64/256
+  // (-10 %), 250.9 with 96/384; n = 1e7: 4020 -> 3887 us; at 70 000 vertices 64/256 costs 18.1 us against 13.1
+  // (profiles/r03_slot_thresholds.txt).
+  if ((double)g->n_cols * G * 4.0 * (g->dtype == GLX_F64 ? 8.0 : 4.0) >= 64.0 * 1024 * 1024) { L1 = 64; L4 = 256; }
   if (const char* e = getenv("GLX_SELL_L1")) L1 = std::max(4, atoi(e));
   if (const char* e = getenv("GLX_SELL_L4")) L4 = std::max(L1, atoi(e));
   if (G != 4) { L1 = 1 << 30; L4 = 1 << 30; }
   auto old_of = [&](int64_t nid) -> int64_t { return renum ? g->h_perm[nid] : nid; };
   auto rowlen = [&](int64_t nid) { const int64_t o = old_of(nid); return g->h_rowptr[o + 1] - g->h_rowptr[o]; };
-  // GLX_SELL_CAP = c (round 3): every slot holds at most c entries of its row -- a row of len entries takes the smallest
-  // S in {1, 2, 4, 8, 16} with S * c >= len slots (longer rows: S = 16 and more chunks) -- so that every slice needs the same
-  // c / 4 chunks: the launch ends when its LAST slice does, and a slice's chunks are dependent memory round trips.
-  // Unset: the round-1 classes (S = 1 up to L1 entries, 4 up to L4, else 16).
-  int cap = 0;
-  if (const char* e = getenv("GLX_SELL_CAP")) cap = atoi(e) / 4 * 4;
-  if (G != 4) cap = 0;
-  auto klass = [&](int len) {
-    if (cap > 0) {
-      int S = 1;
-      while (S < 16 && S * cap < len) S *= 2;
-      return S;
-    }
-    return len > L4 ? 16 : (len > L1 ? 4 : 1);
-  };
+  auto klass = [&](int len) { return len > L4 ? 16 : (len > L1 ? 4 : 1); };
 
   const int NX = 8;
   std::vector<std::vector<SliceHdr>> ghdr(NX);

@@ -101,30 +101,6 @@ template <typename V> __device__ __forceinline__ V row_ror4(V v) {
   for (int i = 0; i < NW; ++i) b.w[i] = row_ror4_i(a.w[i]);
   return b.v;
 }
-// ... within a group of 8 lanes (S = 2): lanes 4..7 take from 4 lanes to their left (row_shr:4 on banks 1 and 3), lanes 0..3
-// from 4 lanes to their right (row_shl:4 on banks 0 and 2) -- two DPP moves, no LDS
-__device__ __forceinline__ int oct_ror4_i(int v) {
-  int t = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xa, false);   // row_shr:4, bank_mask 0b1010
-  return __builtin_amdgcn_update_dpp(t, v, 0x104, 0xf, 0x5, false);    // row_shl:4, bank_mask 0b0101
-}
-template <typename V> __device__ __forceinline__ V oct_ror4(V v) {
-  constexpr int NW = sizeof(V) / 4;
-  union { V v; int w[NW]; } a, b;
-  a.v = v;
-#pragma unroll
-  for (int i = 0; i < NW; ++i) b.w[i] = oct_ror4_i(a.w[i]);
-  return b.v;
-}
-// ... within a group of 32 lanes (S = 8)
-template <typename V> __device__ __forceinline__ V half_ror4(V v, int lane) {
-  constexpr int NW = sizeof(V) / 4;
-  union { V v; int w[NW]; } a, b;
-  a.v = v;
-  const int src = (lane & 32) | ((lane - 4) & 31);
-#pragma unroll
-  for (int i = 0; i < NW; ++i) b.w[i] = __shfl(a.w[i], src);
-  return b.v;
-}
 template <typename V> __device__ __forceinline__ V wave_ror4(V v, int lane) {
   constexpr int NW = sizeof(V) / 4;
   union { V v; int w[NW]; } a, b;
@@ -204,7 +180,7 @@ __device__ __forceinline__ void add_product(typename VecOf<T>::type& acc, double
 // chain of len/4 dependent memory round trips while the rounding sequence stays that of a
 // sequential row sum.
 template <typename T, int G, bool HAS_W, bool HAS_DOT, bool HAS_DUP = false, bool PERSIST = false>
-__global__ __launch_bounds__(64 * GLX_WPB) __attribute__((amdgpu_waves_per_eu((G == 4 && !PERSIST && !HAS_DOT) ? 6 : 1))) void spmm_sell_kernel(const SpmmParams p) {
+__global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParams p) {
 #pragma clang fp contract(off)
   typedef typename VecOf<T>::type V4;
   constexpr int R = 64 / G;
@@ -357,12 +333,6 @@ __global__ __launch_bounds__(64 * GLX_WPB) __attribute__((amdgpu_waves_per_eu((G
           if (S == 4) {
             acc = row_ror4(acc);
             if constexpr (HAS_W && sizeof(T) == 4) accw = row_ror4(accw);
-          } else if (S == 2) {
-            acc = oct_ror4(acc);
-            if constexpr (HAS_W && sizeof(T) == 4) accw = oct_ror4(accw);
-          } else if (S == 8) {
-            acc = half_ror4(acc, lane);
-            if constexpr (HAS_W && sizeof(T) == 4) accw = half_ror4(accw, lane);
           } else {
             acc = wave_ror4(acc, lane);
             if constexpr (HAS_W && sizeof(T) == 4) accw = wave_ror4(accw, lane);

@@ -13,7 +13,7 @@ ap.add_argument('--big', type=int, default=0)
 ap.add_argument('--cache', default='/tmp/knn_big.npz')
 ap.add_argument('--reps', type=int, default=40)
 args = ap.parse_args()
-tag = 'GLX_PERSIST=%s GLX_SELL_CAP=%s GLX_XCD_BALANCE=%s' % (os.environ.get('GLX_PERSIST', '(default)'), os.environ.get('GLX_SELL_CAP', '(classes 24/96)'),
+tag = 'GLX_PERSIST=%s GLX_SELL_L1/L4=%s GLX_XCD_BALANCE=%s' % (os.environ.get('GLX_PERSIST', '(default)'), '%s/%s' % (os.environ.get('GLX_SELL_L1', 'default'), os.environ.get('GLX_SELL_L4', 'default')),
                                                           os.environ.get('GLX_XCD_BALANCE', '(default)'))
 
 
