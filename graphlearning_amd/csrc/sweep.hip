@@ -21,6 +21,9 @@
 #ifndef GLX_NT_STORE
 #define GLX_NT_STORE 0
 #endif
+#ifndef GLX_LOOP_FORM
+#define GLX_LOOP_FORM 1   // 1: branch-free chunk prefetch issued BEHIND the chunk's gathers (see the chunk loop); 0: the round-1 order
+#endif
 #ifndef GLX_PERSIST_DEFAULT
 #define GLX_PERSIST_DEFAULT 1   // blocks per workgroup of the sweep kernel (see the persistent form in spmm_sell_kernel)
 #endif
@@ -31,6 +34,10 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { typedef f32x4 type; };
 template <> struct VecOf<double> { typedef f64x4 type; };
+
+// 256 bytes of zeros: what the lanes of an entry past the end of its row gather in the branch-free loop forms (0 * 0 = 0 exactly,
+// whatever the state holds -- a product with a real record could be 0 * inf)
+__device__ double g_zero_rec[32];
 
 struct SpmmParams {
   const int32_t* slot_row;
@@ -298,7 +305,9 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
     };
     auto issue = [&](const CV& cv, int k, V4 (&x)[4], T (&v)[4]) {
       int c0 = quad_bcast_i<0>(cv.col), c1 = quad_bcast_i<1>(cv.col), c2 = quad_bcast_i<2>(cv.col), c3 = quad_bcast_i<3>(cv.col);
+#ifdef GLX_ABLATE_BUILD      // developer probe (gathers hit 16 hot records): compile-time only, a branch here splits the chunk loop's blocks
       if (p.ablate & 2) { c0 &= 15; c1 &= 15; c2 &= 15; c3 &= 15; }
+#endif
       v[0] = quad_bcast<0>(cv.val);
       v[1] = quad_bcast<1>(cv.val);
       v[2] = quad_bcast<2>(cv.val);
@@ -357,6 +366,98 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
 #else
     V4 xA[4];
     T vA[4];
+#if GLX_LOOP_FORM == 2 || GLX_LOOP_FORM == 3
+    // Experimental (2: two chunks of gathers in flight; 3: one, like form 1, but without exec-mask branches).  Every load of the loop is unconditional -- lanes whose entry lies past the end
+    // of the row gather the zero record instead of being masked off -- so that the compiler's wait-counter pass can count the
+    // loads behind the ones it waits for (a load under an exec-mask branch makes it fall back to "all but the unconditional ones").
+    auto load_cv2 = [&](int k) -> CV {
+      const int kc = k < nchunks ? k : nchunks - 1;
+      const int64_t off = (kc <= 0 ? slice * 64 : base + (int64_t)kc * 64) + lane;
+      CV r;
+      r.col = p.col[off];
+      r.val = valp[off];
+      return r;
+    };
+    const char* zrec = (const char*)g_zero_rec + lane_off;
+    auto issue_u = [&](const CV& cv, int k, V4 (&x)[4], T (&v)[4]) {
+      const int c0 = quad_bcast_i<0>(cv.col), c1 = quad_bcast_i<1>(cv.col), c2 = quad_bcast_i<2>(cv.col), c3 = quad_bcast_i<3>(cv.col);
+      v[0] = quad_bcast<0>(cv.val);
+      v[1] = quad_bcast<1>(cv.val);
+      v[2] = quad_bcast<2>(cv.val);
+      v[3] = quad_bcast<3>(cv.val);
+      const int j0 = (k * S + seg) * 4;
+      const char* a0 = (lane_on && j0 + 0 < len) ? p.xin + (size_t)c0 * p.rec_bytes + lane_off : zrec;
+      const char* a1 = (lane_on && j0 + 1 < len) ? p.xin + (size_t)c1 * p.rec_bytes + lane_off : zrec;
+      const char* a2 = (lane_on && j0 + 2 < len) ? p.xin + (size_t)c2 * p.rec_bytes + lane_off : zrec;
+      const char* a3 = (lane_on && j0 + 3 < len) ? p.xin + (size_t)c3 * p.rec_bytes + lane_off : zrec;
+      x[0] = *(const V4*)a0;
+      x[1] = *(const V4*)a1;
+      x[2] = *(const V4*)a2;
+      x[3] = *(const V4*)a3;
+    };
+#if GLX_LOOP_FORM == 3
+    {
+      CV qn;
+      qn.col = col0;
+      qn.val = val0;
+      for (int k = 0; k < nchunks; ++k) {
+        const CV qc = qn;
+        issue_u(qc, k, xA, vA);
+        qn = load_cv2(k + 1);
+        consume(k, xA, vA);
+      }
+    }
+#else
+    V4 xB[4];
+    T vB[4];
+    if (nchunks > 0) {
+      CV c0v;
+      c0v.col = col0;
+      c0v.val = val0;
+      CV c1v = load_cv2(1);            // older than the gathers of chunk 0: it arrives first
+      CV c2v;
+      issue_u(c0v, 0, xA, vA);
+      int k = 0;
+      while (true) {
+        if (k + 1 >= nchunks) { consume(k, xA, vA); break; }
+        c2v = load_cv2(k + 2);
+        issue_u(c1v, k + 1, xB, vB);
+        consume(k, xA, vA);
+        ++k;
+        if (k + 1 >= nchunks) { consume(k, xB, vB); break; }
+        c1v = load_cv2(k + 2);
+        issue_u(c2v, k + 1, xA, vA);
+        consume(k, xB, vB);
+        ++k;
+      }
+    }
+#endif
+#elif GLX_LOOP_FORM
+    // Round 3.  The round-1 order issued the next chunk's index / value load FIRST and the gathers behind it; the load sat in a
+    // branch (chunk 0 comes from registers, later chunks from memory), and the compiler's wait-counter pass answers a load in a
+    // branch with `s_waitcnt vmcnt(0)` at the join -- so every chunk waited for the NEXT chunk's indices before its own gathers
+    // were even issued: two memory round trips per chunk instead of one (read off the ISA).  Now the address is selected, not the
+    // value (chunk 0 is re-read from its slice-indexed place), the load is unconditional and it is issued BEHIND the gathers: the
+    // wait in front of the adds is `vmcnt(2)` -- the gathers, not the two youngest loads -- and the next chunk's indices have the
+    // whole gather round trip to arrive.
+    auto load_cv2 = [&](int k) -> CV {
+      const int kc = k < nchunks ? k : nchunks - 1;
+      const int64_t off = (kc <= 0 ? slice * 64 : base + (int64_t)kc * 64) + lane;
+      CV r;
+      r.col = p.col[off];
+      r.val = valp[off];
+      return r;
+    };
+    CV qn;
+    qn.col = col0;
+    qn.val = val0;
+    for (int k = 0; k < nchunks; ++k) {
+      const CV qc = qn;
+      issue(qc, k, xA, vA);
+      qn = load_cv2(k + 1);
+      consume(k, xA, vA);
+    }
+#else
     CV qn;
     qn.col = 0;
     qn.val = 0;
@@ -367,6 +468,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       issue(qc, k, xA, vA);
       consume(k, xA, vA);
     }
+#endif
 #endif
   } else {
     const int gbase = lane & ~(G - 1);
