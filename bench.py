@@ -241,7 +241,7 @@ def run_single(args):
     # the timed region: batches of EXACTLY --steps steps, each bracketed by synchronisation; batches are repeated until
     # >= MIN_TIMED_S of sweeps have been timed (a 20-step batch is 13 ms: one noisy batch must not move the headline);
     # the reported batch is the MEDIAN one, min / max beside it
-    MIN_TIMED_S = 0.5
+    MIN_TIMED_S = float(args.min_timed_s)
     results = {}
     for dtype in (np.float64, np.float32):
         model = gl.ssl.poisson(W, solver='gradient_descent', use_cuda=(dtype == np.float32))
@@ -390,6 +390,9 @@ def main():
     ap.add_argument('--n', type=float, default=1e7, help='vertices of --config 4 (default 10^7; kNN alone is ~110 s on one GPU at that size)')
     ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 counter passes (roofline.traffic = null)')
     ap.add_argument('--no-scale', action='store_true', help='skip the n = 10^6 shard-size line')
+    ap.add_argument('--min-timed-s', type=float, default=0.5,
+                    help='batches of --steps steps are repeated until this many seconds have been timed (at least 5 batches).  Profiling runs '
+                         'pass 0: rocprofv3 of ROCm 7.2 segfaults after 16 384 dispatches launched from device graphs (profiles/README.md)')
     ap.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--dist-dry-run', action='store_true',
                     help='start the ranks, rendezvous over gloo, count them, print one line and stop: checks the launch path without a GPU')
