@@ -55,7 +55,7 @@ int glx_make_layout(int C, int dtype, bool has_w, RecLayout* L);
 struct SliceHdr {
   int64_t ptr;      // entry offset (within the tail region) of the slice's chunk 1 (multiple of 64)
   int32_t nchunks;  // 64-entry chunks
-  int32_t S;        // segments per row: 1, or 4 / 16 for long rows (G = 4 plans)
+  int32_t S;        // bits 0..7: segments per row: 1, or 4 / 16 for long rows (G = 4 plans); bits 8..: chunks without a short slot ("full")
 };
 
 struct SellPlan {

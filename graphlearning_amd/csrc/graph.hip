@@ -544,7 +544,7 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
       SliceHdr h;
       h.ptr = 0;
       h.S = S;
-      int width = 0;
+      int width = 0, narrow = 1 << 30;
       for (int r = 0; r < R / S; ++r) {
         int32_t row = -1;
         int len = 0;
@@ -555,8 +555,12 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
         }
         for (int sgm = 0; sgm < S; ++sgm) { grow[x].push_back(row); glen[x].push_back(len); }
         width = std::max(width, len);
+        narrow = std::min(narrow, len);      // (an empty slot has len 0)
       }
       h.nchunks = G == 4 ? (width + 4 * S - 1) / (4 * S) : (width + G - 1) / G;
+      // G = 4: chunks k < full hold four real entries in EVERY slot of the slice -- the kernel gathers them without predicates
+      // (rows are sorted by length, so a slice's rows are nearly equally long and most chunks are full); bits 8.. of S
+      if (G == 4) h.S = S | ((narrow / (4 * S)) << 8);
       ghdr[x].push_back(h);
     }
   }
@@ -595,7 +599,7 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   // 16 ns per entry on one core, 300 ms at 18 M entries) is spread over host threads
   auto fill_range = [&](int64_t s_begin, int64_t s_end) {
   for (int64_t s = s_begin; s < s_end; ++s) {
-    const int S = hdr[s].S;
+    const int S = hdr[s].S & 0xff;
     for (int slot = 0; slot < R; slot += S) {
       const int32_t row = slot_row[s * R + slot];
       if (row < 0) continue;

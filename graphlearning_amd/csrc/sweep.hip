@@ -24,6 +24,12 @@
 #ifndef GLX_LOOP_FORM
 #define GLX_LOOP_FORM 1   // 1: branch-free chunk prefetch issued BEHIND the chunk's gathers (see the chunk loop); 0: the round-1 order
 #endif
+#ifndef GLX_FULL_CHUNKS
+#define GLX_FULL_CHUNKS 1   // chunks in which every slot of the slice has four real entries are gathered without predicates
+#endif
+#ifndef GLX_OFF32
+#define GLX_OFF32 0   // experiment: 32-bit record offsets from a uniform base (state < 4 GB) instead of 64-bit address arithmetic
+#endif
 #ifndef GLX_PERSIST_DEFAULT
 #define GLX_PERSIST_DEFAULT 1   // blocks per workgroup of the sweep kernel (see the persistent form in spmm_sell_kernel)
 #endif
@@ -186,8 +192,16 @@ __device__ __forceinline__ void add_product(typename VecOf<T>::type& acc, double
 // wave shuffle), each adding its products in entry order -- long rows stop being a latency
 // chain of len/4 dependent memory round trips while the rounding sequence stays that of a
 // sequential row sum.
+#ifndef GLX_FORCE_OCC6
+#define GLX_FORCE_OCC6 0
+#endif
+#if GLX_FORCE_OCC6
+#define GLX_SPMM_OCC __attribute__((amdgpu_waves_per_eu((G == 4 && !PERSIST && !HAS_DOT && sizeof(T) == 8) ? 6 : 1)))
+#else
+#define GLX_SPMM_OCC
+#endif
 template <typename T, int G, bool HAS_W, bool HAS_DOT, bool HAS_DUP = false, bool PERSIST = false>
-__global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParams p) {
+__global__ __launch_bounds__(64 * GLX_WPB) GLX_SPMM_OCC void spmm_sell_kernel(const SpmmParams p) {
 #pragma clang fp contract(off)
   typedef typename VecOf<T>::type V4;
   constexpr int R = 64 / G;
@@ -233,10 +247,10 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
   unsigned long long err_run = 0;     // running max of this lane's stop values over the blocks it serves (bit patterns)
 
   // header + chunk 0 of one slice (chunk 0 sits at a slice-indexed address: its load is issued together with the header loads)
-  struct SliceIn { int col0; T val0; int row, len, nchunks, S; int64_t base; };
+  struct SliceIn { int col0; T val0; int row, len, nchunks, S, full; int64_t base; };
   auto load_slice = [&](int64_t slice) -> SliceIn {
     SliceIn in;
-    in.col0 = 0; in.val0 = 0; in.row = -1; in.len = 0; in.nchunks = 0; in.S = 1; in.base = 0;
+    in.col0 = 0; in.val0 = 0; in.row = -1; in.len = 0; in.nchunks = 0; in.S = 1; in.full = 0; in.base = 0;
     if (slice < p.nslices) {
       if (p.nt & 1) {
         in.col0 = __builtin_nontemporal_load(&p.col[slice * 64 + lane]);
@@ -251,7 +265,8 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       const SliceHdr hd = p.slice_hdr[slice];
       in.base = p.head + hd.ptr - 64;   // chunk k >= 1 at base + k*64
       in.nchunks = (p.ablate & 1) ? 0 : hd.nchunks;
-      in.S = hd.S;
+      in.S = hd.S & 0xff;
+      in.full = hd.S >> 8;
     }
     return in;
   };
@@ -277,6 +292,8 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
   const int col0 = cur.col0;
   const T val0 = cur.val0;
   const int row = cur.row, len = cur.len, nchunks = cur.nchunks, S = cur.S;
+  // chunks [0, full): every lane of every slot has a real entry (plan) and every lane of a row is in use -> no predicates
+  const int full = (p.nlanes == G && !(HAS_DOT && p.act_row)) ? (cur.full < nchunks ? cur.full : nchunks) : 0;
   const int64_t base = cur.base;
   const int seg = g & (S - 1);            // S is a power of two
   V4 acc = {0, 0, 0, 0};
@@ -317,10 +334,18 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       x[1] = V4{0, 0, 0, 0};
       x[2] = V4{0, 0, 0, 0};
       x[3] = V4{0, 0, 0, 0};
+#if GLX_OFF32
+      const unsigned lo32 = (unsigned)lane_off, rb = (unsigned)p.rec_bytes;
+      if (lane_on && j0 + 0 < len) x[0] = *(const V4*)(p.xin + ((unsigned)c0 * rb + lo32));
+      if (lane_on && j0 + 1 < len) x[1] = *(const V4*)(p.xin + ((unsigned)c1 * rb + lo32));
+      if (lane_on && j0 + 2 < len) x[2] = *(const V4*)(p.xin + ((unsigned)c2 * rb + lo32));
+      if (lane_on && j0 + 3 < len) x[3] = *(const V4*)(p.xin + ((unsigned)c3 * rb + lo32));
+#else
       if (lane_on && j0 + 0 < len) x[0] = *(const V4*)(p.xin + (size_t)c0 * p.rec_bytes + lane_off);
       if (lane_on && j0 + 1 < len) x[1] = *(const V4*)(p.xin + (size_t)c1 * p.rec_bytes + lane_off);
       if (lane_on && j0 + 2 < len) x[2] = *(const V4*)(p.xin + (size_t)c2 * p.rec_bytes + lane_off);
       if (lane_on && j0 + 3 < len) x[3] = *(const V4*)(p.xin + (size_t)c3 * p.rec_bytes + lane_off);
+#endif
     };
     auto consume = [&](int k, const V4 (&x)[4], const T (&v)[4]) {
       if (S == 1) {
@@ -448,15 +473,54 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       r.val = valp[off];
       return r;
     };
+    // gathers of a full chunk: straight-line, no zero fills, no exec-mask branches (a third of the loop's vector instructions)
+    auto issue_full = [&](const CV& cv, V4 (&x)[4], T (&v)[4]) {
+      const int c0 = quad_bcast_i<0>(cv.col), c1 = quad_bcast_i<1>(cv.col), c2 = quad_bcast_i<2>(cv.col), c3 = quad_bcast_i<3>(cv.col);
+      v[0] = quad_bcast<0>(cv.val);
+      v[1] = quad_bcast<1>(cv.val);
+      v[2] = quad_bcast<2>(cv.val);
+      v[3] = quad_bcast<3>(cv.val);
+#if GLX_OFF32
+      const unsigned lo32 = (unsigned)lane_off, rb = (unsigned)p.rec_bytes;
+      x[0] = *(const V4*)(p.xin + ((unsigned)c0 * rb + lo32));
+      x[1] = *(const V4*)(p.xin + ((unsigned)c1 * rb + lo32));
+      x[2] = *(const V4*)(p.xin + ((unsigned)c2 * rb + lo32));
+      x[3] = *(const V4*)(p.xin + ((unsigned)c3 * rb + lo32));
+#else
+      x[0] = *(const V4*)(p.xin + (size_t)c0 * p.rec_bytes + lane_off);
+      x[1] = *(const V4*)(p.xin + (size_t)c1 * p.rec_bytes + lane_off);
+      x[2] = *(const V4*)(p.xin + (size_t)c2 * p.rec_bytes + lane_off);
+      x[3] = *(const V4*)(p.xin + (size_t)c3 * p.rec_bytes + lane_off);
+#endif
+    };
     CV qn;
     qn.col = col0;
     qn.val = val0;
-    for (int k = 0; k < nchunks; ++k) {
+    int k = 0;
+#if GLX_FULL_CHUNKS == 2
+    for (; k < nchunks; ++k) {          // one loop, the gather form picked per chunk (uniform branch)
+      const CV qc = qn;
+      if (k < full) issue_full(qc, xA, vA); else issue(qc, k, xA, vA);
+      qn = load_cv2(k + 1);
+      consume(k, xA, vA);
+    }
+#else
+#if GLX_FULL_CHUNKS
+    if (sizeof(T) == 4 || GLX_FULL_CHUNKS == 3)     // fp64: the second loop costs 4 registers and with them a wavefront per SIMD (measured: slower)
+      for (; k < full; ++k) {
+        const CV qc = qn;
+        issue_full(qc, xA, vA);
+        qn = load_cv2(k + 1);
+        consume(k, xA, vA);
+      }
+#endif
+    for (; k < nchunks; ++k) {
       const CV qc = qn;
       issue(qc, k, xA, vA);
       qn = load_cv2(k + 1);
       consume(k, xA, vA);
     }
+#endif
 #else
     CV qn;
     qn.col = 0;
