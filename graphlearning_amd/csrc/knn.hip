@@ -328,6 +328,9 @@ __global__ void knn_prep_bf16_kernel(const double* __restrict__ X, const double*
 // Concatenated split operands for d <= 21 (round 3): hi.hi + hi.lo + lo.hi is ONE contraction of length 3 d <= 63 when the
 // ref image is [rh | rh | rl] and the query image [qh | ql | qh] -- 64 bf16 per row, the size of the [hi(32) | lo(32)] rows the
 // NKB = 2 kernel stages, so four MFMAs of K = 16 do the work of the six the block form needs (hi and lo blocks padded to 32).
+#ifndef KNN_PACKED_SELECT
+#define KNN_PACKED_SELECT 0   // measured (profiles/r03_knn_host.txt): v_pk_fma_f32 + nested minima change nothing at config 2 (1.46 ms either way) and cost 3-4 % at d >= 64
+#endif
 static const int KNN_CAT_SEG = 21;
 __global__ void knn_prep_bf16_cat_kernel(const double* __restrict__ X, const double* __restrict__ mean, int64_t n, int d,
                                          unsigned short* __restrict__ Xa, unsigned short* __restrict__ Xq, float* __restrict__ nrm,
@@ -572,11 +575,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
 #pragma unroll
       for (int eg = 0; eg < 4; ++eg) {
         const float4 r4 = *(const float4*)(rnb + sub * 32 + 8 * eg + 4 * h);
+#if KNN_PACKED_SELECT
+        // two fp32 fmas per instruction (v_pk_fma_f32 on adjacent accumulator registers) and three-input minima (v_min3_f32):
+        // the same values, half the vector instructions of the per-element form -- at K <= 64 the selection, not the
+        // contraction, is what the tile kernel waits for
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 m2 = {-2.f, -2.f};
+        f32x2 a01 = {acc[sub][eg * 4 + 0], acc[sub][eg * 4 + 1]}, a23 = {acc[sub][eg * 4 + 2], acc[sub][eg * 4 + 3]};
+        a01 = __builtin_elementwise_fma(m2, a01, f32x2{r4.x, r4.y});
+        a23 = __builtin_elementwise_fma(m2, a23, f32x2{r4.z, r4.w});
+        acc[sub][eg * 4 + 0] = a01.x;
+        acc[sub][eg * 4 + 1] = a01.y;
+        acc[sub][eg * 4 + 2] = a23.x;
+        acc[sub][eg * 4 + 3] = a23.y;
+        m4[sub][eg] = fminf(fminf(fminf(a01.x, a01.y), a23.x), a23.y);
+#else
         acc[sub][eg * 4 + 0] = fmaf(-2.f, acc[sub][eg * 4 + 0], r4.x);
         acc[sub][eg * 4 + 1] = fmaf(-2.f, acc[sub][eg * 4 + 1], r4.y);
         acc[sub][eg * 4 + 2] = fmaf(-2.f, acc[sub][eg * 4 + 2], r4.z);
         acc[sub][eg * 4 + 3] = fmaf(-2.f, acc[sub][eg * 4 + 3], r4.w);
         m4[sub][eg] = fminf(fminf(acc[sub][eg * 4 + 0], acc[sub][eg * 4 + 1]), fminf(acc[sub][eg * 4 + 2], acc[sub][eg * 4 + 3]));
+#endif
         m = fminf(m, m4[sub][eg]);
       }
 #if KNN_ABLATE & 1
