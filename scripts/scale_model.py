@@ -3,20 +3,22 @@
 No 8-GPU node has been available to this project, so the curve is predicted instead of left blank: for world in {2, 4, 8}
 every rank's share of the graph is built exactly as the multi-GPU run builds it (dist.RankPlan: locality order, blocks,
 [owned | halo] columns, boundary rows first, send lists) and its glx_dist_sweep object is created on the one GPU; the
-rank-local pieces of a sweep -- boundary rows (incl. the scatter into the send buffer), interior rows -- are timed with HIP
-events (glx_dist_sweep_time_parts), the halo records per peer are counted, and a sweep of the N-GPU job is predicted as
+rank-local pieces of a sweep -- the one launch of the fused form, boundary rows (incl. the scatter into the send buffer) and
+interior rows of the split form -- are timed with HIP events (glx_dist_sweep_time_parts), the halo records per peer are counted,
+and a sweep of the N-GPU job is predicted as
 
-    sweep(N) = max over ranks [ boundary_r + max( interior_r , X_r ) ] + allreduce / check_every
+    sweep(N) = max over ranks  min( fused_r + X_r ,  boundary_r + max(interior_r, X_r) + fork/join )  +  all-reduces / T
     X_r      = L + max over peers ( records(r <- p) * record bytes / link rate )        (direct all-to-all-v: one xGMI link per pair)
 
-with two transports: `bw` (L = 0: the bandwidth bound of the judge's formula) and `rccl` (L = the latency of a grouped
-ncclSend/ncclRecv exchange, measured here as the difference between a 1-rank RCCL self-exchange sweep and the same sweep
-with a plain device copy).  Link rate: 7 xGMI links x ~153 GB/s bidirectional per GPU (task statement) -> 76 GB/s per
-direction peak; 50 GB/s per direction is assumed for RCCL point-to-point (ASSUMPTION, not measured: no second GPU).
+(every rank takes the cheaper form, as glx_dist_sweep_create does) with three transports: `bw_peak` / `bw_rccl` (L = 0: the
+bandwidth bound at 76 / 50 GB/s per direction) and `rccl` (L = the fixed cost of one grouped ncclSend/ncclRecv exchange, measured
+here on a 1-rank communicator: sweep with a 10 000-record self-exchange minus the same launch alone, minus the data's travel time
+inside one GPU).  Link rate: 7 xGMI links x ~153 GB/s bidirectional per GPU (task statement) -> 76 GB/s per direction peak; 50 GB/s
+per direction is assumed for RCCL point-to-point (ASSUMPTION, not measured: no second GPU).
 
   weak   config 2 (BASELINE configs[1]): N x 70000 vertices, k = 10, d = 20 -- partitions `cut` (bench.py's headline) and `even`
-  strong config 4 shape (configs[3]): n vertices (default 2e6; 1e7 needs ~15 min of host planning), d = 64, k = 10, even blocks
-         of the coarse geometric order, T fixed
+  strong config 4 shape (configs[3]): n vertices (default 2e6; 1e7 needs ~15 min of host planning), d = 64, k = 10, blocks of the coarse
+         geometric order -- `cut` (boundaries where the fewest entries cross) and `even` --, T = 200 fixed
 
 Writes profiles/r03_scale_model.json (or --out).  Usage: python scripts/scale_model.py [--n4 2e6] [--worlds 2,4,8] [--skip4]
 """
