@@ -180,7 +180,9 @@ int glx_dist_destroy(glx_comm* c);
  * order inside a row is kept, so iterates are bit-identical to the single-GPU sweep.  send_counts / recv_counts
  * [nranks]: records exchanged with every peer per sweep; send_idx: local (boundary) row of every record sent,
  * grouped by destination rank.  n_global: vertices of the whole graph (the stop threshold is 1/n_global).
- * force_exchange: issue the exchange even when this rank has nothing to send or receive (1-rank tests). */
+ * force_exchange: issue the exchange even when this rank has nothing to send or receive.  Set it on EVERY rank as soon as ANY
+ * rank has a halo: the collective calls around the exchange (the capture self-test's verdict, the stop test's all-reduce) must be
+ * issued by all ranks alike (dist.glx_dist_sweep does; also used by 1-rank tests). */
 int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_halo, int64_t n_boundary, const int32_t* rowptr,
                           const int32_t* col, const double* val, int state_dtype, int C, const int64_t* send_counts,
                           const int32_t* send_idx, const int64_t* recv_counts, int64_t n_global, int force_exchange,
