@@ -462,6 +462,43 @@ extern "C" int glx_graph_order(glx_graph* g, int32_t* perm_out) {
   return GLX_OK;
 }
 
+
+// The sliced-ELL image is assembled ON THE DEVICE (round 3): the CSR arrays go up as they are and one wavefront per slice
+// writes the slice's chunks -- image position (chunk k, lane w) holds entry jj = (k S + seg) 4 + t of the row in slot w / 4
+// (G = 4: seg = slot within the row's S slots, t = w % 4; wider rows: jj = k G + w % G), or a zero for positions past the end
+// of the row -- so nothing needs a memset and the host never touches the 1.3 M (... 2 x 10^8) entries: the host fill took 6 ms at
+// 70 000 vertices with 16 threads (300 ms at 18 M entries), more than everything else of the plan together.
+template <typename T>
+__global__ __launch_bounds__(256) void sell_fill_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ccol,
+                                                        const double* __restrict__ cval, const int32_t* __restrict__ perm,
+                                                        const int32_t* __restrict__ inv, const int32_t* __restrict__ slot_row,
+                                                        const int32_t* __restrict__ slot_len, const SliceHdr* __restrict__ hdr,
+                                                        int64_t nslices, int64_t head, int G, int32_t* __restrict__ col, T* __restrict__ val) {
+  const int lane = threadIdx.x & 63;
+  const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= nslices) return;
+  const SliceHdr h = hdr[s];
+  const int S = h.S & 0xff, R = 64 / G;
+  const int slot = lane / G, t = lane % G;
+  const int32_t row = slot_row[s * R + slot];
+  const int len = slot_len[s * R + slot];
+  const int seg = slot & (S - 1);
+  const int64_t b = row >= 0 ? rowptr[perm ? perm[row] : row] : 0;
+  for (int k = 0; k < h.nchunks || k == 0; ++k) {          // chunk 0 always exists (the dense head region)
+    const int jj = G == 4 ? (k * S + seg) * 4 + t : k * G + t;
+    int32_t c = 0;
+    double v = 0.0;
+    if (row >= 0 && jj < len) {
+      c = ccol[b + jj];
+      if (inv) c = inv[c];
+      v = cval[b + jj];
+    }
+    const int64_t idx = k == 0 ? s * 64 + lane : head + h.ptr + (int64_t)(k - 1) * 64 + lane;
+    col[idx] = c;
+    val[idx] = (T)v;
+  }
+}
+
 // Build (once per G) the sliced-ELL image of the operator.  The (renumbered) rows are cut
 // into 8 contiguous id ranges, one per XCD; inside a range rows are handed to wavefront slices
 // in order of decreasing length (longest first: LPT balance, little padding inside a slice);
@@ -589,54 +626,8 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
       stored += (int64_t)(h.nchunks > 0 ? h.nchunks - 1 : 0) * 64;   // chunk 0 lives in the dense head arrays
       hdr[x * spx + s] = h;
     }
-  // image = [head: chunk 0 of every slice, nslices*64 entries][tail: chunks 1.. at hdr.ptr]
+  // image = [head: chunk 0 of every slice, nslices*64 entries][tail: chunks 1.. at hdr.ptr], filled by sell_fill_kernel
   const int64_t head = nslices * 64;
-  std::vector<int32_t> col(head + stored, 0);
-  std::vector<double> val64;
-  std::vector<float> val32;
-  if (g->dtype == GLX_F64) val64.assign(head + stored, 0.0); else val32.assign(head + stored, 0.0f);
-  // every slice writes its own part of the image: the fill (random reads through the renumbering, scattered writes --
-  // 16 ns per entry on one core, 300 ms at 18 M entries) is spread over host threads
-  auto fill_range = [&](int64_t s_begin, int64_t s_end) {
-  for (int64_t s = s_begin; s < s_end; ++s) {
-    const int S = hdr[s].S & 0xff;
-    for (int slot = 0; slot < R; slot += S) {
-      const int32_t row = slot_row[s * R + slot];
-      if (row < 0) continue;
-      const int64_t b = g->h_rowptr[old_of(row)];
-      const int len = slot_len[s * R + slot];
-      for (int jj = 0; jj < len; ++jj) {
-        int64_t idx;
-        int k, within;
-        if (G == 4) {
-          k = jj / (4 * S);
-          within = (slot + (jj % (4 * S)) / 4) * 4 + jj % 4;
-        } else {
-          k = jj / G;
-          within = slot * G + (jj % G);
-        }
-        idx = k == 0 ? s * 64 + within : head + hdr[s].ptr + (int64_t)(k - 1) * 64 + within;
-        const int32_t c = g->h_col[b + jj];
-        col[idx] = renum ? g->h_inv[c] : c;
-        if (g->dtype == GLX_F64) val64[idx] = g->h_val[b + jj]; else val32[idx] = (float)g->h_val[b + jj];
-      }
-    }
-  }
-  };
-  {
-    int nthreads = (int)std::min<int64_t>(16, std::max<int64_t>(1, (int64_t)std::thread::hardware_concurrency()));
-    if (g->nnz < (1 << 20)) nthreads = 1;
-    if (const char* e = getenv("GLX_HOST_THREADS")) nthreads = std::max(1, atoi(e));
-    if (nthreads == 1) {
-      fill_range(0, nslices);
-    } else {
-      std::vector<std::thread> pool;
-      for (int t = 0; t < nthreads; ++t)
-        pool.emplace_back(fill_range, nslices * t / nthreads, nslices * (t + 1) / nthreads);
-      for (auto& th : pool) th.join();
-    }
-  }
-  lap("image filled");
   SellPlan p;
   p.G = G;
   p.R = R;
@@ -652,9 +643,32 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   GLX_HIP(hipMemcpy(p.d_slot_row, slot_row.data(), slot_row.size() * 4, hipMemcpyHostToDevice));
   GLX_HIP(hipMemcpy(p.d_slot_len, slot_len.data(), slot_len.size() * 4, hipMemcpyHostToDevice));
   GLX_HIP(hipMemcpy(p.d_slice_hdr, hdr.data(), hdr.size() * sizeof(SliceHdr), hipMemcpyHostToDevice));
-  if (head + stored > 0) {
-    GLX_HIP(hipMemcpy(p.d_col, col.data(), (head + stored) * 4, hipMemcpyHostToDevice));
-    GLX_HIP(hipMemcpy(p.d_val, g->dtype == GLX_F64 ? (void*)val64.data() : (void*)val32.data(), (head + stored) * es, hipMemcpyHostToDevice));
+  if (nslices > 0) {
+    // the CSR arrays as they are (work buffers from the pool, released after the fill)
+    int32_t *d_rp = nullptr, *d_cc = nullptr;
+    double* d_cv = nullptr;
+    struct Tmp { void *a = nullptr, *b = nullptr, *c = nullptr; ~Tmp() { glx_pool_free(a); glx_pool_free(b); glx_pool_free(c); } } tmp;
+    int rc2 = glx_pool_alloc(&tmp.a, (size_t)(n + 1) * 4);
+    if (!rc2) rc2 = glx_pool_alloc(&tmp.b, std::max<size_t>((size_t)g->nnz * 4, 4));
+    if (!rc2) rc2 = glx_pool_alloc(&tmp.c, std::max<size_t>((size_t)g->nnz * 8, 8));
+    if (rc2) return rc2;
+    d_rp = (int32_t*)tmp.a; d_cc = (int32_t*)tmp.b; d_cv = (double*)tmp.c;
+    GLX_HIP(hipMemcpy(d_rp, g->h_rowptr.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    if (g->nnz > 0) {
+      GLX_HIP(hipMemcpy(d_cc, g->h_col.data(), (size_t)g->nnz * 4, hipMemcpyHostToDevice));
+      GLX_HIP(hipMemcpy(d_cv, g->h_val.data(), (size_t)g->nnz * 8, hipMemcpyHostToDevice));
+    }
+    const unsigned grid = (unsigned)((nslices + 3) / 4);
+    if (g->dtype == GLX_F64)
+      hipLaunchKernelGGL(sell_fill_kernel<double>, dim3(grid), dim3(256), 0, 0, (const int32_t*)d_rp, (const int32_t*)d_cc, (const double*)d_cv,
+                         (const int32_t*)(renum ? g->d_perm : nullptr), (const int32_t*)(renum ? g->d_inv : nullptr), (const int32_t*)p.d_slot_row,
+                         (const int32_t*)p.d_slot_len, (const SliceHdr*)p.d_slice_hdr, nslices, head, G, p.d_col, (double*)p.d_val);
+    else
+      hipLaunchKernelGGL(sell_fill_kernel<float>, dim3(grid), dim3(256), 0, 0, (const int32_t*)d_rp, (const int32_t*)d_cc, (const double*)d_cv,
+                         (const int32_t*)(renum ? g->d_perm : nullptr), (const int32_t*)(renum ? g->d_inv : nullptr), (const int32_t*)p.d_slot_row,
+                         (const int32_t*)p.d_slot_len, (const SliceHdr*)p.d_slice_hdr, nslices, head, G, p.d_col, (float*)p.d_val);
+    GLX_HIP(hipGetLastError());
+    GLX_HIP(hipDeviceSynchronize());          // the pooled CSR copies go back before anybody else may draw them
   }
   lap("uploaded");
   g->plans.push_back(p);
