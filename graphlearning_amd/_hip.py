@@ -122,6 +122,7 @@ _SIGNATURES = {
     'glx_argmax_project_t': [_vp, C.c_int, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
     'glx_knn_bruteforce': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
     'glx_knn_bruteforce_range': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
+    'glx_knn_cells_range': [_vp, C.c_int64, C.c_int, C.c_int, _vp, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
     'glx_knn_stats': [_f64p],
     'glx_knn_to_csr': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                        C.POINTER(_vp), _i64p, C.c_int],
@@ -725,9 +726,11 @@ def host_reverse_scale_rows(W, scale):
     return col, val
 
 
-def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None):
+def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, cell_starts=None):
     """Exact kNN (incl. self) on the GPU.  'angular' = euclidean on row-normalised data, formed
-    with the reference's own expression (weightmatrix.py:344-345)."""
+    with the reference's own expression (weightmatrix.py:344-345).  cell_starts: the rows come in a coarse geometric
+    order with cell c = rows [cell_starts[c], cell_starts[c+1]); the search skips the cells that cannot hold a
+    neighbour (glx_knn_cells_range: the same lists, a fraction of the tiles on clustered data)."""
     X = np.asarray(X, dtype=np.float64)
     if similarity == 'angular':
         X = X / np.linalg.norm(X, axis=1)[:, None]
@@ -738,6 +741,11 @@ def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None):
     q0, q1 = (0, n) if query_range is None else query_range
     ind = pinned_empty((q1 - q0, k), np.int64)       # page-locked result arrays: the copy back runs at PCIe speed
     dist = pinned_empty((q1 - q0, k), np.float64)
+    if cell_starts is not None:
+        cs = np.ascontiguousarray(cell_starts, dtype=np.int64)
+        check(load().glx_knn_cells_range(_ptr(X), n, d, k, _ptr(cs), len(cs), q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
+              'glx_knn_cells_range')
+        return ind, dist
     check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
           'glx_knn_bruteforce')
     return ind, dist
@@ -815,4 +823,4 @@ def knn_stats():
     check(load().glx_knn_stats(out), 'glx_knn_stats')
     return dict(tile_ms=out[0], rerank_ms=out[1], fallback_rows=out[2], total_ms=out[3], fallback_ms=out[4],
                 dpa=out[5], nsplit=out[6], KP=abs(out[7]), filter='bf16x3' if out[7] < 0 else 'f32', escalated_rows=out[8],
-                concatenated=bool(out[9]))
+                concatenated=bool(out[9]), seed_sample=int(out[10]), visited_share=out[11], cells=int(out[12]))

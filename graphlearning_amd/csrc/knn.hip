@@ -332,6 +332,9 @@ __global__ void knn_prep_bf16_kernel(const double* __restrict__ X, const double*
 #define KNN_PACKED_SELECT 0   // measured (profiles/r03_knn_host.txt): v_pk_fma_f32 + nested minima change nothing at config 2 (1.46 ms either way) and cost 3-4 % at d >= 64
 #endif
 static const int KNN_CAT_SEG = 21;
+#ifndef KNN_SEED_SUB
+#define KNN_SEED_SUB 8    // the seeding pre-pass looks at every 8th ref tile (0 / 1: no pre-pass); run time: GLX_KNN_SEED
+#endif
 __global__ void knn_prep_bf16_cat_kernel(const double* __restrict__ X, const double* __restrict__ mean, int64_t n, int d,
                                          unsigned short* __restrict__ Xa, unsigned short* __restrict__ Xq, float* __restrict__ nrm,
                                          float* __restrict__ qnorm) {
@@ -360,10 +363,15 @@ __global__ void knn_prep_bf16_cat_kernel(const double* __restrict__ X, const dou
 // NKB blocks of 16 features (kpad = 16 NKB <= 128); refs are the A operand (LDS), queries the B operand (registers: lane =
 // query column j, k-half h); list handling as in knn_tile_kernel.
 // CAT (NKB = 2 only): the rows are the concatenated operands above, refs from Xb, queries from Xq.
-template <int NKB, int KP, int NSUB, bool CAT = false>
+template <int NKB, int KP, int NSUB, bool CAT = false, bool RUNS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLISTS && KP == 8 && NKB == 4) ? 4 : 1, 4))) void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned short* __restrict__ Xq, const float* __restrict__ nrm, int64_t n,
                                                             int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d,
-                                                            int* __restrict__ cand_i, int* __restrict__ gtau) {
+                                                            int* __restrict__ cand_i, int* __restrict__ gtau, const int* __restrict__ runs,
+                                                            const int* __restrict__ nruns, int maxruns) {
+  // RUNS (the cell-pruned search, glx_knn_cells_range): this query block visits only the ref tiles of its runs
+  // [runs[2 r], runs[2 r + 1]), r < nruns[block] (ascending, disjoint; knn_runs_kernel), not all of them
+  // nsplit = the tile stride of a ref range; the number of ranges is the grid's y extent (equal in the search proper; the
+  // seeding pre-pass runs ONE range with a stride of KNN_SEED_SUB: every KNN_SEED_SUB-th tile, a sample of the refs)
   constexpr int KPAD = 16 * NKB;
   constexpr int BR = 32 * NSUB;
   constexpr int ROWB = 4 * KPAD + 16;                  // bytes per ref row in LDS: hi | lo, +16 so that 16 rows cover all 64 banks
@@ -412,13 +420,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
     else { ld[p * 256 + tid] = INFINITY; li[p * 256 + tid] = -1; }
   }
   float tau = INFINITY;          // thresholds are kept WITHOUT the query's norm: values are |r|^2 - 2 q.r
+#if KNN_GTAU
+  if (q < q_end) {               // the seed of the pre-pass (knn_seed_kernel), +inf without one
+    int best = gtau[q - q_begin];
+    best ^= (best >> 31) & 0x7fffffff;
+    tau = __int_as_float(best);
+  }
+#endif
 
   const int64_t ntiles = (n + BR - 1) / BR;
   // ref range `sp` = the tiles sp, sp + nsplit, sp + 2 nsplit, ...: INTERLEAVED, not a contiguous block of refs.  Data often comes
   // sorted (by class, along a curve, by a locality order): a query's neighbours are then neighbours in index too, a contiguous
   // range would put all of them into the two lists of one range and overflow them (29 % of the rows of locality-ordered
   // config-4 data took the exact fallback); interleaved, any 32 * nsplit consecutive refs are spread over all the lists
-  const int64_t t0 = sp, t1 = ntiles;
+  const int64_t t1 = ntiles;
+  // the tile iterator: tiles congruent to sp modulo nsplit, of all tiles or of the block's runs (wave-uniform arithmetic)
+  int run = -1, nrun = 0;
+  int64_t run_b = 0;
+  const int* myruns = nullptr;
+  if constexpr (RUNS) {
+    myruns = runs + qb * 2 * (int64_t)maxruns;
+    nrun = nruns[qb];
+  }
+  auto next_tile = [&](int64_t tc) -> int64_t {
+    int64_t tn = tc + nsplit;
+    if constexpr (RUNS) {
+      while (tn >= run_b) {
+        if (++run >= nrun) return -1;
+        const int64_t a = myruns[2 * run];
+        run_b = myruns[2 * run + 1];
+        tn = a + (sp - a % nsplit + nsplit) % nsplit;
+      }
+      return tn;
+    } else {
+      return tn < t1 ? tn : -1;
+    }
+  };
+  const int64_t t0 = RUNS ? next_tile(-(int64_t)nsplit) : (sp < t1 ? (int64_t)sp : -1);
   uint4 pre[UNITS];
   float pre_rn = 0.f;
   auto stage_load = [&](int64_t t) {
@@ -504,7 +542,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
       }
     }
     cnt = 0;
-    tau = fminf(tau_own, __shfl_xor(tau_own, 32));   // lanes l and l^32 serve the same query (same |q|^2 offset)
+    // lanes l and l^32 serve the same query (same |q|^2 offset); never above what is already known (the seed, published thresholds)
+    tau = fminf(tau, fminf(tau_own, __shfl_xor(tau_own, 32)));
 #if KNN_GTAU
     // the query's lists of the OTHER ref ranges run in other workgroups: the smallest threshold any of them has reached is
     // published per query (an ordered-int image of the float, atomicMin) and adopted here.  Sound for the same reason the pair's
@@ -521,24 +560,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
 #endif
     KNN_TOC(cy_comp, tc);
   };
-  if (t0 < t1) { stage_load(t0); stage_store(0); }
+  if (t0 >= 0) { stage_load(t0); stage_store(0); }
   __syncthreads();
   int buf = 0;
 #if KNN_ABLATE & 1
   float abl_sink = INFINITY;
 #endif
   KNN_TIC(ta);
-  for (int64_t t = t0; t < t1; t += nsplit) {
-    const bool has_next = t + nsplit < t1;
+  int it = 0;
+  for (int64_t t = t0, tn; t >= 0; t = tn, ++it) {
+    tn = next_tile(t);
+    const bool has_next = tn >= 0;
 #if KNN_GTAU
-    if ((((t - t0) / nsplit) & 15) == 15 && q < q_end) {
+    if ((it & 15) == 15 && q < q_end) {
       int best = gtau[q - q_begin];
       best ^= (best >> 31) & 0x7fffffff;
       tau = fminf(tau, __int_as_float(best));
     }
 #endif
 #if !(KNN_ABLATE & 4)
-    if (has_next) stage_load(t + nsplit);
+    if (has_next) stage_load(tn);
 #endif
     const char* tl = tile + buf * BR * ROWB;
     const float* rnb = rn + buf * BR;
@@ -652,7 +693,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
 #endif
   compact();
   if (q < q_end) {
-    const int64_t lists = (int64_t)nsplit * 2;
+    const int64_t lists = (int64_t)gridDim.y * 2;
     const int64_t base = ((q - q_begin) * lists + sp * 2 + h) * KP;
 #pragma unroll
     for (int p = 0; p < KP; ++p) {
@@ -665,6 +706,216 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
       }
     }
   }
+}
+
+// ---- seeding: a threshold for every query BEFORE the search proper -----------------------------
+// The pre-pass ran the tile kernel over a sample of the refs (every KNN_SEED_SUB-th tile, one range: two lists per query).  Any k
+// distinct refs bound the k-th neighbour from above: with v_k = the k-th smallest filter value among the sample's candidates,
+// true dist^2 of those k refs <= v_k + eps, hence the exact k-th distance^2 dk2 <= v_k + eps.  The search proper starts every
+// list's threshold at seed = v_k + 4 eps (instead of +inf): a ref it rejects has filter value >= seed, i.e. true dist^2 >=
+// v_k + 3 eps > dk2 -- never one of the k nearest (nor tied with the k-th).  What it buys: the lists only ever see refs within a few
+// percent of the k-th distance (in d dimensions a sample of 1/8 is (8)^(1/d) further out), a tenth of the appends and merges of
+// lists that start empty; list maintenance was 41-62 % of the tile kernel.  Values here carry the query's norm (cand_d does).
+__global__ __launch_bounds__(256) void knn_seed_kernel(const float* __restrict__ pre_d, const int* __restrict__ pre_i, int64_t nq, int64_t q_begin,
+                                                       int m, int k, const float* __restrict__ qnorm, const float* __restrict__ nrm,
+                                                       const float* __restrict__ rmax_p, double cerr, int* __restrict__ gtau,
+                                                       double* __restrict__ ub2) {
+  const int64_t ql = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ql >= nq) return;
+  const float* v = pre_d + ql * m;
+  const int* vi = pre_i + ql * m;
+  float vk = INFINITY;
+  for (int a = 0; a < m; ++a) {                 // the k-th smallest of m <= 64 values: the one with exactly k - 1 in front of it
+    const float x = v[a];
+    if (!(x < INFINITY) || vi[a] < 0) continue;
+    int before = 0;
+    for (int c = 0; c < m; ++c) {
+      const float y = v[c];
+      before += (vi[c] >= 0 && (y < x || (y == x && c < a))) ? 1 : 0;
+    }
+    if (before == k - 1) vk = x;
+  }
+  int key = 0x7f800000;                          // +inf: fewer than k candidates in the sample
+  if (vk < INFINITY) {
+    const double rq = (double)qnorm[q_begin + ql] + (double)rmax_p[0];
+    const double eps = cerr * rq * rq;
+    // back to the kernel's form (without the query's norm: nrm holds |q|^2 as the tile kernel adds it), rounded up
+    double x = (double)vk + 4.0 * eps;
+    x += 1e-6 * fabs(x);
+    float seed = (float)(x - (double)nrm[q_begin + ql]);
+    seed = nextafterf(seed, INFINITY);
+    key = __float_as_int(seed);
+    key ^= (key >> 31) & 0x7fffffff;
+    if (ub2) ub2[ql] = (double)vk + eps;        // exact k-th distance^2 <= this
+  } else if (ub2) {
+    ub2[ql] = INFINITY;
+  }
+  gtau[ql] = key;
+}
+
+// ---- cell pruning (glx_knn_cells_range) --------------------------------------------------------
+// The rows come in an order in which `cells` are contiguous (a coarse geometric order: nearest of a few dozen sample points, a
+// k-means leaf, a tree leaf -- whatever the caller has).  Per cell a centre (the mean) and a radius (the farthest member); a query
+// whose k-th neighbour is known to lie within sqrt(ub2) needs no ref of a cell with |q - centre| - radius > sqrt(ub2).  The bound
+// ub2 comes from the seeding pre-pass over a sample of the query block's OWN cells; the search proper then visits, per block of
+// 128 queries, the tiles of the cells any of its queries still needs.  Exact: a skipped ref is strictly farther than the k-th
+// neighbour.  On clustered data (config 4: ten Gaussian blobs in 64 dimensions) nine tenths of the tiles go.
+static const int CELL_SPLIT = 64;      // workgroups per cell in the centre / radius passes (a cell of config 4 at n = 1e7 is 80 MB)
+
+// partial column sums of piece s of cell c (fixed order inside a piece; the pieces are added in order by knn_cell_centre_kernel)
+__global__ __launch_bounds__(256) void knn_cell_sum_kernel(const double* __restrict__ X, int d, const int64_t* __restrict__ cell_starts,
+                                                           int64_t n, int ncells, double* __restrict__ part) {
+  __shared__ double red[256];
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const int64_t a0 = cell_starts[c], b0 = c + 1 < ncells ? cell_starts[c + 1] : n;
+  const int64_t len = b0 > a0 ? b0 - a0 : 0;
+  const int64_t a = a0 + len * sp / CELL_SPLIT, b = a0 + len * (sp + 1) / CELL_SPLIT;
+  int dt = 1;
+  while (dt < d && dt < 256) dt *= 2;
+  const int col = threadIdx.x % dt, rl = threadIdx.x / dt, rstep = 256 / dt;
+  for (int f0 = 0; f0 < d; f0 += dt) {
+    double sum = 0.0;
+    if (f0 + col < d)
+      for (int64_t r = a + rl; r < b; r += rstep) sum += X[r * d + f0 + col];
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    if (rl == 0 && f0 + col < d) {
+      double t = 0.0;
+      for (int q = 0; q < rstep; ++q) t += red[q * dt + col];
+      part[((int64_t)c * CELL_SPLIT + sp) * d + f0 + col] = t;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void knn_cell_centre_kernel(const double* __restrict__ part, int d, const int64_t* __restrict__ cell_starts,
+                                                              int64_t n, int ncells, double* __restrict__ cen) {
+  const int c = blockIdx.x;
+  const int64_t a0 = cell_starts[c], b0 = c + 1 < ncells ? cell_starts[c + 1] : n;
+  for (int f = threadIdx.x; f < d; f += 256) {
+    double t = 0.0;
+    for (int sp = 0; sp < CELL_SPLIT; ++sp) t += part[((int64_t)c * CELL_SPLIT + sp) * d + f];
+    cen[(int64_t)c * d + f] = b0 > a0 ? t / (double)(b0 - a0) : 0.0;
+  }
+}
+
+// largest squared distance of a member of piece s of cell c from the cell's centre
+__global__ __launch_bounds__(256) void knn_cell_rad_kernel(const double* __restrict__ X, int d, const int64_t* __restrict__ cell_starts, int64_t n,
+                                                           int ncells, const double* __restrict__ cen, double* __restrict__ prad) {
+  extern __shared__ double cs[];                 // [d] centre, [256] scratch
+  double* red = cs + d;
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const int64_t a0 = cell_starts[c], b0 = c + 1 < ncells ? cell_starts[c + 1] : n;
+  const int64_t len = b0 > a0 ? b0 - a0 : 0;
+  const int64_t a = a0 + len * sp / CELL_SPLIT, b = a0 + len * (sp + 1) / CELL_SPLIT;
+  for (int f = threadIdx.x; f < d; f += 256) cs[f] = cen[(int64_t)c * d + f];
+  __syncthreads();
+  double m = 0.0;
+  for (int64_t r = a + threadIdx.x; r < b; r += 256) {
+    double s2 = 0.0;
+    for (int f = 0; f < d; ++f) {
+      const double df = X[r * d + f] - cs[f];
+      s2 += df * df;
+    }
+    m = fmax(m, s2);
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) prad[c * CELL_SPLIT + sp] = red[0];
+}
+
+__global__ __launch_bounds__(256) void knn_cell_radfin_kernel(const double* __restrict__ prad, const int64_t* __restrict__ cell_starts, int64_t n,
+                                                              int ncells, double* __restrict__ rad) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells) return;
+  const int64_t a0 = cell_starts[c], b0 = c + 1 < ncells ? cell_starts[c + 1] : n;
+  double m = 0.0;
+  for (int sp = 0; sp < CELL_SPLIT; ++sp) m = fmax(m, prad[c * CELL_SPLIT + sp]);
+  rad[c] = b0 > a0 ? sqrt(m) * (1.0 + 1e-9) + 1e-300 : -1.0;        // -1: empty cell
+}
+
+// one workgroup per query block (BQ = 128 queries): mask[block][c] = some query of the block may have one of its k nearest in cell c.
+// Cells in batches of 16 (centres in LDS); a thread keeps the squared distances of its query to 8 of them while it walks the
+// query's features once per batch (direct differences: no cancellation whatever the data's offset).
+__global__ __launch_bounds__(256) void knn_cellmask_kernel(const double* __restrict__ X, int d, int64_t q_begin, int64_t q_end,
+                                                           const double* __restrict__ cen, const double* __restrict__ rad, int ncells,
+                                                           const double* __restrict__ ub2, unsigned char* __restrict__ mask) {
+  extern __shared__ double cc[];                 // centres of a batch of cells [CB][d]
+  __shared__ int need[4096];
+  constexpr int CB = 16, PER = CB / (256 / BQ);
+  const int64_t qb = blockIdx.x;
+  const int j = threadIdx.x & (BQ - 1), g = threadIdx.x / BQ;       // two thread groups share the cells of a batch
+  const int64_t q = q_begin + qb * BQ + j;
+  const bool live = q < q_end;
+  const double* xq = X + (live ? q : q_end - 1) * d;
+  const double u2 = live ? ub2[q - q_begin] : -1.0;
+  for (int c = threadIdx.x; c < ncells; c += 256) need[c] = 0;
+  for (int c0 = 0; c0 < ncells; c0 += CB) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < CB * d; i += 256) {
+      const int c = c0 + i / d;
+      cc[i] = c < ncells ? cen[(int64_t)c * d + i % d] : 0.0;
+    }
+    __syncthreads();
+    double s2[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) s2[e] = 0.0;
+    const double* cp = cc + g * PER * d;
+    for (int f = 0; f < d; ++f) {
+      const double xf = xq[f];
+#pragma unroll
+      for (int e = 0; e < PER; ++e) {
+        const double df = xf - cp[e * d + f];
+        s2[e] += df * df;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const int c = c0 + g * PER + e;
+      if (c >= ncells || !live) continue;
+      const double r = rad[c];
+      if (r < 0.0) continue;
+      const double gap = sqrt(s2[e]) - r;          // every member of the cell is at least this far from the query
+      if (!(gap > 0.0) || !(gap * gap > u2 * (1.0 + 1e-9))) need[c] = 1;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ncells; c += 256) mask[qb * ncells + c] = (unsigned char)need[c];
+}
+
+// one thread per query block: the ascending, disjoint runs of ref tiles the block visits.  mask == nullptr: the block's OWN cells
+// (those its 128 rows lie in) -- the sample the seeding pre-pass looks at.
+__global__ __launch_bounds__(256) void knn_runs_kernel(const unsigned char* __restrict__ mask, const int64_t* __restrict__ cell_starts, int64_t n,
+                                                       int ncells, int BR, int64_t q_begin, int64_t q_end, int64_t nqb, int maxruns,
+                                                       int* __restrict__ runs, int* __restrict__ nruns) {
+  const int64_t qb = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (qb >= nqb) return;
+  const int64_t r0 = q_begin + qb * BQ, r1 = min(q_end, r0 + BQ);
+  int* out = runs + qb * 2 * (int64_t)maxruns;
+  int nr = 0;
+  int64_t last_b = 0;
+  for (int c = 0; c < ncells; ++c) {
+    const int64_t a = cell_starts[c], b = c + 1 < ncells ? cell_starts[c + 1] : n;
+    if (b <= a) continue;
+    const bool want = mask ? mask[qb * ncells + c] != 0 : (a < r1 && b > r0);
+    if (!want) continue;
+    int64_t ta = a / BR, tb = (b + BR - 1) / BR;
+    if (ta < last_b) ta = last_b;                  // the tile a cell shares with its predecessor is visited once
+    if (tb <= ta) continue;
+    if (nr > 0 && out[2 * nr - 1] == ta) {
+      out[2 * nr - 1] = (int)tb;
+    } else {
+      out[2 * nr] = (int)ta;
+      out[2 * nr + 1] = (int)tb;
+      ++nr;
+    }
+    last_b = tb;
+  }
+  nruns[qb] = nr;
 }
 
 // ---- stage 2: exact fp64 re-rank + acceptance check ------------------------------------------
@@ -839,6 +1090,14 @@ struct KnnBufs {
   float* rmax = nullptr;             // [0] largest centred norm (1 + 1e-6), [1] 1 if the input is finite: written by knn_rmax_kernel
   double *X = nullptr, *mean = nullptr, *dist = nullptr;
   float *Rf = nullptr, *Qf = nullptr, *qnorm = nullptr, *cand_d = nullptr;
+  float* pre_d = nullptr;
+  int* pre_i = nullptr;
+  // cell pruning: tile runs of the query blocks (current launch), cell geometry, the per-query bound of the pre-pass
+  int *runs = nullptr, *nruns = nullptr;
+  int maxruns = 0;
+  int64_t* cell_starts = nullptr;
+  double *cen = nullptr, *rad = nullptr, *ub2 = nullptr, *cpart = nullptr;
+  unsigned char* mask = nullptr;
   int *cand_i = nullptr, *flags = nullptr, *rows = nullptr, *fb_li = nullptr, *fb_pi = nullptr, *gtau = nullptr;
   double *fb_ld = nullptr, *fb_pd = nullptr;
   int64_t* ind = nullptr;
@@ -849,7 +1108,8 @@ struct KnnBufs {
     if (stream) hipStreamSynchronize(stream);   // pooled blocks are reused at once: nothing may still be running on them
     glx_pool_free(Xb); glx_pool_free(Xq); glx_pool_free(nrm); glx_pool_free(part); glx_pool_free(rmax);
     glx_pool_free(X); glx_pool_free(mean); glx_pool_free(dist); glx_pool_free(Rf); glx_pool_free(Qf); glx_pool_free(qnorm); glx_pool_free(cand_d);
-    glx_pool_free(gtau); glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_li); glx_pool_free(fb_pi); glx_pool_free(fb_ld); glx_pool_free(fb_pd);
+    glx_pool_free(runs); glx_pool_free(nruns); glx_pool_free(cell_starts); glx_pool_free(cen); glx_pool_free(rad); glx_pool_free(ub2); glx_pool_free(cpart); glx_pool_free(mask);
+    glx_pool_free(pre_d); glx_pool_free(pre_i); glx_pool_free(gtau); glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_li); glx_pool_free(fb_pi); glx_pool_free(fb_ld); glx_pool_free(fb_pd);
     glx_work_release(work);
   }
 };
@@ -934,30 +1194,41 @@ constexpr int bf16_nsub(int NKB, int KP) { return (NKB >= 6 || KP >= 32) ? 1 : K
 constexpr int bf16_nsub(int NKB, int KP) { return (NKB >= 4 || KP >= 32) ? 1 : 2; }
 #endif
 
+// nsplit ref ranges with a tile stride of nsplit (the search proper), or -- seed = true -- ONE range with a stride of nsplit
+// writing the pre-pass's own two lists per query (KnnBufs::pre_d / pre_i)
 template <int NKB, int KP, bool CAT = false>
-static int launch_tile_bf16(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st) {
+static int launch_tile_bf16(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st, bool seed = false) {
   constexpr int NSUB = bf16_nsub(NKB, KP);
   constexpr int BR = 32 * NSUB;
   constexpr int ROWB = 4 * 16 * NKB + 16;
   const size_t shm = (size_t)2 * BR * ROWB + (size_t)2 * BR * 4 + (size_t)((KNN_REGLISTS && KP == 8 && NKB == 4) ? KBUF : KP + KBUF) * 256 * 8;
   GLX_CHECK(shm <= 160 * 1024, GLX_EUNSUPPORTED, "glx_knn_bruteforce: bf16 filter needs %zu bytes of LDS", shm);
-  GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_bf16_kernel<NKB, KP, NSUB, CAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)nsplit);
-  hipLaunchKernelGGL((knn_tile_bf16_kernel<NKB, KP, NSUB, CAT>), grid, dim3(256), shm, st, (const unsigned short*)b.Xb, (const unsigned short*)(CAT ? b.Xq : b.Xb),
-                     (const float*)b.nrm, n, q0, q1, nsplit, b.cand_d, b.cand_i, b.gtau);
+  const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)(seed ? 1 : nsplit));
+  if (b.runs) {
+    GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, true>), grid, dim3(256), shm, st, (const unsigned short*)b.Xb, (const unsigned short*)(CAT ? b.Xq : b.Xb),
+                       (const float*)b.nrm, n, q0, q1, nsplit, seed ? b.pre_d : b.cand_d, seed ? b.pre_i : b.cand_i, b.gtau, (const int*)b.runs,
+                       (const int*)b.nruns, b.maxruns);
+  } else {
+    GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, false>), grid, dim3(256), shm, st, (const unsigned short*)b.Xb, (const unsigned short*)(CAT ? b.Xq : b.Xb),
+                       (const float*)b.nrm, n, q0, q1, nsplit, seed ? b.pre_d : b.cand_d, seed ? b.pre_i : b.cand_i, b.gtau, (const int*)nullptr,
+                       (const int*)nullptr, 0);
+  }
   GLX_HIP(hipGetLastError());
   return GLX_OK;
 }
 
 template <int KP>
-static int launch_tile_bf16_nkb(int NKB, const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st, bool cat = false) {
-  if (cat) return launch_tile_bf16<2, KP, true>(b, n, q0, q1, nsplit, st);
+static int launch_tile_bf16_nkb(int NKB, const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st, bool cat = false,
+                                bool seed = false) {
+  if (cat) return launch_tile_bf16<2, KP, true>(b, n, q0, q1, nsplit, st, seed);
   switch (NKB) {
-    case 1: return launch_tile_bf16<1, KP>(b, n, q0, q1, nsplit, st);
-    case 2: return launch_tile_bf16<2, KP>(b, n, q0, q1, nsplit, st);
-    case 4: return launch_tile_bf16<4, KP>(b, n, q0, q1, nsplit, st);
-    case 6: return launch_tile_bf16<6, KP>(b, n, q0, q1, nsplit, st);
-    case 8: return launch_tile_bf16<8, KP>(b, n, q0, q1, nsplit, st);
+    case 1: return launch_tile_bf16<1, KP>(b, n, q0, q1, nsplit, st, seed);
+    case 2: return launch_tile_bf16<2, KP>(b, n, q0, q1, nsplit, st, seed);
+    case 4: return launch_tile_bf16<4, KP>(b, n, q0, q1, nsplit, st, seed);
+    case 6: return launch_tile_bf16<6, KP>(b, n, q0, q1, nsplit, st, seed);
+    case 8: return launch_tile_bf16<8, KP>(b, n, q0, q1, nsplit, st, seed);
   }
   glx_set_error("knn: no bf16 tile kernel for %d feature blocks", NKB);
   return GLX_EUNSUPPORTED;
@@ -1001,7 +1272,7 @@ static const int KNN_ESCALATE = 1;    // knn_pass: too many rows failed the acce
 // sit in the same 16 of 32 consecutive points to get there (tight groups stored one after another); interleaving the ref tiles
 // over the ranges already spreads anything coarser.
 static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_t q1, int64_t* ind_out, double* dist_out, int device,
-                    bool long_lists) {
+                    bool long_lists, const int64_t* cell_starts = nullptr, int ncells = 0) {
   GLX_CHECK(X && ind_out && dist_out, GLX_EINVAL, "glx_knn_bruteforce: null argument");
   GLX_CHECK(n >= 1 && d >= 1 && k >= 1, GLX_EINVAL, "glx_knn_bruteforce: need n, d, k >= 1 (n=%lld d=%d k=%d)", (long long)n, d, k);
   GLX_CHECK(k <= n, GLX_EINVAL, "glx_knn_bruteforce: k=%d exceeds the number of points %lld", k, (long long)n);
@@ -1124,6 +1395,78 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     }
     GLX_HIP(hipGetLastError());
     g_knn_stats[9] = cat ? 1.0 : 0.0;
+    // The seeding pre-pass (knn_seed_kernel).  Over all refs it does not pay (measured, profiles/r03_knn_seed.txt: the k-th of a
+    // 1/8 sample is the 8k-th of the whole set, 79 % of the wave-tiles still hold a candidate and the pre-pass costs its eighth):
+    // GLX_KNN_SEED=<sample stride> turns it on for experiments.  The cell-pruned search needs it: its bound ub2 decides which
+    // cells a query block visits.
+    const bool cells = cell_starts != nullptr && ncells > 1;
+    int seed_sub = 0;
+    if (const char* e = getenv("GLX_KNN_SEED")) seed_sub = atoi(e);
+    if (cells) {
+      // sample the block's own cells: every tile of small cells, every 8th of cells of >= 128 tiles
+      const int64_t avg_tiles = std::max<int64_t>(1, ntiles / ncells);
+      seed_sub = (int)std::max<int64_t>(1, std::min<int64_t>(8, avg_tiles / 16));
+    }
+    const bool seeded = (cells || (seed_sub > 1 && ntiles >= (int64_t)64 * seed_sub)) && 2 * KP >= k;
+    g_knn_stats[10] = seeded ? (double)seed_sub : 0.0;
+    g_knn_stats[11] = 0.0;
+    g_knn_stats[12] = 0.0;
+    if (cells && seeded) {
+      GLX_POOL(glx_pool_alloc((void**)&b.cell_starts, (size_t)ncells * 8));
+      GLX_POOL(glx_pool_alloc((void**)&b.cen, (size_t)ncells * d * 8));
+      GLX_POOL(glx_pool_alloc((void**)&b.rad, (size_t)ncells * 8));
+      GLX_POOL(glx_pool_alloc((void**)&b.ub2, (size_t)nq * 8));
+      GLX_POOL(glx_pool_alloc((void**)&b.mask, (size_t)nqb * ncells));
+      GLX_POOL(glx_pool_alloc((void**)&b.nruns, (size_t)nqb * 4));
+      b.maxruns = ncells;
+      GLX_POOL(glx_pool_alloc((void**)&b.runs, (size_t)nqb * 2 * ncells * 4));   // (from here on the tile launches follow the runs)
+      GLX_HIP(hipMemcpyAsync(b.cell_starts, cell_starts, (size_t)ncells * 8, hipMemcpyHostToDevice, st));
+      // centres and radii of the cells
+      GLX_POOL(glx_pool_alloc((void**)&b.cpart, (size_t)ncells * CELL_SPLIT * (d + 1) * 8));
+      double* prad = b.cpart + (size_t)ncells * CELL_SPLIT * d;
+      hipLaunchKernelGGL(knn_cell_sum_kernel, dim3((unsigned)ncells, CELL_SPLIT), dim3(256), 0, st, (const double*)b.X, d, (const int64_t*)b.cell_starts, n,
+                         ncells, b.cpart);
+      hipLaunchKernelGGL(knn_cell_centre_kernel, dim3((unsigned)ncells), dim3(256), 0, st, (const double*)b.cpart, d, (const int64_t*)b.cell_starts, n, ncells,
+                         b.cen);
+      hipLaunchKernelGGL(knn_cell_rad_kernel, dim3((unsigned)ncells, CELL_SPLIT), dim3(256), (size_t)(d + 256) * 8, st, (const double*)b.X, d,
+                         (const int64_t*)b.cell_starts, n, ncells, (const double*)b.cen, prad);
+      hipLaunchKernelGGL(knn_cell_radfin_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st, (const double*)prad,
+                         (const int64_t*)b.cell_starts, n, ncells, b.rad);
+      hipLaunchKernelGGL(knn_runs_kernel, dim3((unsigned)((nqb + 255) / 256)), dim3(256), 0, st, (const unsigned char*)nullptr,
+                         (const int64_t*)b.cell_starts, n, ncells, BR, q0, q1, nqb, b.maxruns, b.runs, b.nruns);
+      GLX_HIP(hipGetLastError());
+    }
+    if (seeded) {
+      GLX_POOL(glx_pool_alloc((void**)&b.pre_d, (size_t)nq * 2 * KP * 4));
+      GLX_POOL(glx_pool_alloc((void**)&b.pre_i, (size_t)nq * 2 * KP * 4));
+      if (KP == 8) rc = launch_tile_bf16_nkb<8>(NKB, b, n, q0, q1, seed_sub, st, cat, true);
+      else if (KP == 16) rc = launch_tile_bf16_nkb<16>(NKB, b, n, q0, q1, seed_sub, st, cat, true);
+      else rc = launch_tile_bf16_nkb<32>(NKB, b, n, q0, q1, seed_sub, st, cat, true);
+      if (rc) return rc;
+      hipLaunchKernelGGL(knn_seed_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const float*)b.pre_d, (const int*)b.pre_i, nq, q0,
+                         2 * KP, k, (const float*)b.qnorm, (const float*)b.nrm, (const float*)b.rmax, cerr, b.gtau, b.ub2);
+      GLX_HIP(hipGetLastError());
+    }
+    if (cells && seeded) {
+      hipLaunchKernelGGL(knn_cellmask_kernel, dim3((unsigned)nqb), dim3(256), (size_t)16 * d * 8, st, (const double*)b.X, d, q0, q1, (const double*)b.cen,
+                         (const double*)b.rad, ncells, (const double*)b.ub2, b.mask);
+      hipLaunchKernelGGL(knn_runs_kernel, dim3((unsigned)((nqb + 255) / 256)), dim3(256), 0, st, (const unsigned char*)b.mask,
+                         (const int64_t*)b.cell_starts, n, ncells, BR, q0, q1, nqb, b.maxruns, b.runs, b.nruns);
+      GLX_HIP(hipGetLastError());
+      if (getenv("GLX_TIMING") || getenv("GLX_KNN_CELL_STATS")) {      // share of (query block, cell) pairs still visited
+        std::vector<unsigned char> hm((size_t)nqb * ncells);
+        GLX_HIP(hipMemcpyAsync(hm.data(), b.mask, hm.size(), hipMemcpyDeviceToHost, st));
+        GLX_HIP(hipStreamSynchronize(st));
+        double rows_v = 0.0;
+        for (int64_t qb2 = 0; qb2 < nqb; ++qb2)
+          for (int c = 0; c < ncells; ++c)
+            if (hm[qb2 * ncells + c]) rows_v += (double)((c + 1 < ncells ? cell_starts[c + 1] : n) - cell_starts[c]);
+        g_knn_stats[11] = rows_v / ((double)nqb * (double)n);
+        fprintf(stderr, "[glx] knn: cell pruning, %d cells, sample stride %d: %.1f %% of the (query block, ref) pairs are visited\n", ncells, seed_sub,
+                100.0 * g_knn_stats[11]);
+      }
+      g_knn_stats[12] = (double)ncells;
+    }
     if (KP == 8) rc = launch_tile_bf16_nkb<8>(NKB, b, n, q0, q1, nsplit, st, cat);
     else if (KP == 16) rc = launch_tile_bf16_nkb<16>(NKB, b, n, q0, q1, nsplit, st, cat);
     else rc = launch_tile_bf16_nkb<32>(NKB, b, n, q0, q1, nsplit, st, cat);
@@ -1221,12 +1564,15 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   return GLX_OK;
 }
 
-static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t q1, int64_t* ind_out, double* dist_out, int device) {
+static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t q1, int64_t* ind_out, double* dist_out, int device,
+                   const int64_t* cell_starts = nullptr, int ncells = 0) {
   g_knn_stats[8] = 0.0;
-  int rc = knn_pass(X, n, d, k, q0, q1, ind_out, dist_out, device, false);
+  g_knn_stats[10] = g_knn_stats[11] = g_knn_stats[12] = 0.0;
+  int rc = knn_pass(X, n, d, k, q0, q1, ind_out, dist_out, device, false, cell_starts, ncells);
   if (rc != KNN_ESCALATE) return rc;
   const double flagged = g_knn_stats[2];
-  rc = knn_pass(X, n, d, k, q0, q1, ind_out, dist_out, device, true);
+  g_knn_stats[10] = g_knn_stats[11] = g_knn_stats[12] = 0.0;
+  rc = knn_pass(X, n, d, k, q0, q1, ind_out, dist_out, device, true);     // (long lists: the fp32-input kernel, all refs)
   g_knn_stats[8] = flagged;            // rows the first (short-list) pass could not accept
   return rc;
 }
@@ -1241,4 +1587,19 @@ extern "C" int glx_knn_bruteforce(const double* X, int64_t n, int d, int k, int 
 extern "C" int glx_knn_bruteforce_range(const double* X, int64_t n, int d, int k, int64_t q_begin, int64_t q_end,
                                         int64_t* ind_out, double* dist_out, int device) {
   return knn_run(X, n, d, k, q_begin, q_end, ind_out, dist_out, device);
+}
+
+// The same search -- the same lists, bit for bit -- for rows that come in a coarse geometric order: cell c = the rows
+// [cell_starts[c], cell_starts[c + 1]) (the last cell ends at n; empty cells allowed).  Per query block only the cells that can hold
+// one of its k nearest are visited (bounds from the cells' centres and radii against the k-th distance within a sample of the
+// block's own cells); everything skipped is strictly farther than the k-th neighbour.  Takes the place of the tree the reference
+// searches with (scipy cKDTree / annoy, graphlearning/weightmatrix.py:297-429) at sizes where all pairs are too many.
+extern "C" int glx_knn_cells_range(const double* X, int64_t n, int d, int k, const int64_t* cell_starts, int ncells, int64_t q_begin,
+                                   int64_t q_end, int64_t* ind_out, double* dist_out, int device) {
+  GLX_CHECK(cell_starts && ncells >= 1, GLX_EINVAL, "glx_knn_cells_range: null argument");
+  GLX_CHECK(ncells <= 4096, GLX_EUNSUPPORTED, "glx_knn_cells_range: %d cells above the supported 4096", ncells);
+  GLX_CHECK(cell_starts[0] == 0, GLX_EINVAL, "glx_knn_cells_range: the first cell must start at row 0");
+  for (int c = 1; c < ncells; ++c)
+    GLX_CHECK(cell_starts[c] >= cell_starts[c - 1] && cell_starts[c] <= n, GLX_EINVAL, "glx_knn_cells_range: cell starts must ascend within [0, n]");
+  return knn_run(X, n, d, k, q_begin, q_end, ind_out, dist_out, device, cell_starts, ncells);
 }

@@ -344,10 +344,15 @@ def main_config4(args):
     even = gdist.block_bounds(n, world)                                     # the search is balanced by rows: equal blocks
     lo, hi = int(even[rank]), int(even[rank + 1])
     t0 = time.perf_counter()
-    J, D = _hip.knn_bruteforce(X, K + 1, device=local_rank, query_range=(lo, hi))
+    # the cells of the coarse order double as the search's pruning structure (glx_knn_cells_range: the same lists as the all-pairs
+    # search, only the cells that can hold a neighbour are visited; GLX_CONFIG4_KNN=allpairs for the search over every tile)
+    knn_cells = None if os.environ.get('GLX_CONFIG4_KNN', 'cells') == 'allpairs' else cell_starts
+    J, D = _hip.knn_bruteforce(X, K + 1, device=local_rank, query_range=(lo, hi), cell_starts=knn_cells)
     st = _hip.knn_stats()
     t_knn = time.perf_counter() - t0
-    progress('kNN lists of %d query rows (tile kernel %.1f s, %d fallback rows)' % (hi - lo, st['tile_ms'] / 1e3, st['fallback_rows']))
+    progress('kNN lists of %d query rows (tile kernel %.1f s, %d fallback rows, %s)' % (
+        hi - lo, st['tile_ms'] / 1e3, st['fallback_rows'],
+        'all pairs' if knn_cells is None else '%d cells, sample stride %d' % (st['cells'], st['seed_sample'])))
     del X
     # the sweep's blocks follow the graph: boundaries at the cell starts that cross the fewest list entries (between clusters: none),
     # the lists move to their new owners (GLX_CONFIG4_PARTITION=even keeps the equal blocks)
@@ -417,6 +422,7 @@ def main_config4(args):
             'partition': {'kind': partition if world > 1 else 'one block', 'bounds': [int(b) for b in bounds]},
             'build': {'features_s': t_feat, 'locality_order_s': t_order, 'knn_own_rows_s': t_knn, 'cut_and_redistribute_s': t_cut,
                       'host_work_note': 'features: every rank generates n/N rows; order: on the device; search: n/N query rows; symmetrisation and plan: the rank\'s own rows', 'knn_tile_tflops_rank0': 2.0 * (hi - lo) * n * st['dpa'] / st['tile_ms'] / 1e9,
+                      'knn_search': 'all pairs' if knn_cells is None else 'cell-pruned (%d cells)' % st['cells'], 'knn_tile_s': st['tile_ms'] / 1e3,
                       'symmetrise_plan_s': t_build},
             'accuracy_percent': 100.0 * int(hit[0]) / max(int(hit[1]), 1),
             'rccl_ranks': comm.info()['nranks'], 'rccl_owner': 'libglx' if comm.has_transport() else 'none (one rank)', 'engine': 'glx',

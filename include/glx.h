@@ -310,6 +310,13 @@ int glx_knn_bruteforce(const double* X, int64_t n, int d, int k, int similarity,
  * sharded across GPUs; every rank holds all of X).  ind_out/dist_out: (q_end - q_begin, k). */
 int glx_knn_bruteforce_range(const double* X, int64_t n, int d, int k, int64_t q_begin, int64_t q_end,
                              int64_t* ind_out, double* dist_out, int device);
+/* the same search -- the same lists, bit for bit -- for rows that come in a coarse geometric order: cell c = the rows
+ * [cell_starts[c], cell_starts[c+1]) (host array of ncells <= 4096 ascending starts, cell_starts[0] = 0, the last cell ends at n).
+ * Per block of 128 queries only the cells that can hold one of its k nearest neighbours are visited (centre / radius bounds
+ * against the k-th distance within a sample of the block's own cells); what is skipped is strictly farther than the k-th
+ * neighbour.  The role of the tree in the reference's search (cKDTree / annoy, graphlearning/weightmatrix.py:297-429). */
+int glx_knn_cells_range(const double* X, int64_t n, int d, int k, const int64_t* cell_starts, int ncells, int64_t q_begin,
+                        int64_t q_end, int64_t* ind_out, double* dist_out, int device);
 int glx_knn_stats(double stats[16]);  /* of the last search: [0] tile-kernel ms, [1] re-rank ms, [2] fallback rows, [3] total device ms,
                                         [4] fallback ms, [5] padded feature count, [6] ref ranges, [7] list length (negative: bf16 filter),
                                         [8] rows the short lists could not accept when the search was repeated with long ones (else 0);

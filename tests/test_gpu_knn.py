@@ -278,3 +278,55 @@ def test_search_on_data_sorted_by_locality(gl):
         print('groups of 12, k=%d: %d rows escalated, %d fallback rows, lists of %d' % (k, st['escalated_rows'], st['fallback_rows'], st['KP']))
         if k == 12:
             assert st['escalated_rows'] > 1000 and st['KP'] == 16 and st['fallback_rows'] <= 24, st   # the repeat ran with the long lists and needed no row scans
+
+
+def _cell_order(X, ncells, seed=0):
+    from graphlearning_amd import dist_build
+    perm, starts = dist_build.coarse_locality_order(X, ncells=ncells, seed=seed, return_cells=True)
+    return np.ascontiguousarray(X[perm]), np.asarray(starts, dtype=np.int64)
+
+
+@pytest.mark.parametrize('case', ['blobs64', 'blobs20', 'uniform8', 'tiny_cells', 'one_cell', 'empty_cells', 'k26', 'subrange'])
+def test_knn_cells_identical_to_all_pairs(gl, case, monkeypatch):
+    """glx_knn_cells_range (per query block only the cells that can hold a neighbour) returns the lists of the all-pairs search
+    bit for bit -- clustered data (most cells skipped), uniform data (few skipped), cells smaller than a tile, one cell, empty
+    cells, longer lists, a query sub-range (the rank-local share of a sharded search)."""
+    from graphlearning_amd import _hip
+    monkeypatch.setenv('GLX_KNN_CELL_STATS', '1')
+    rng = np.random.default_rng(11)
+    k, qr = 11, None
+    if case == 'blobs64':
+        X, _ = blobs(60000, 64, 10, 3, 4.0)
+        X, starts = _cell_order(X, 64)
+    elif case == 'blobs20':
+        X, _ = blobs(50000, 20, 6, 5, 6.0)
+        X, starts = _cell_order(X, 48)
+    elif case == 'uniform8':
+        X, starts = _cell_order(rng.random((40000, 8)), 32)
+    elif case == 'tiny_cells':
+        X, _ = blobs(20000, 16, 5, 7, 5.0)
+        X, starts = _cell_order(X, 1500)
+    elif case == 'one_cell':
+        X, _ = blobs(20000, 32, 4, 9, 4.0)
+        starts = np.zeros(1, dtype=np.int64)
+    elif case == 'empty_cells':
+        X, _ = blobs(30000, 24, 6, 2, 5.0)
+        X, st = _cell_order(X, 24)
+        starts = np.sort(np.concatenate([st, st[5:9], [len(X), len(X)]])).astype(np.int64)     # repeated starts = empty cells
+    elif case == 'k26':
+        X, _ = blobs(40000, 32, 8, 4, 5.0)
+        X, starts = _cell_order(X, 40)
+        k = 26
+    else:
+        X, _ = blobs(50000, 48, 7, 6, 5.0)
+        X, starts = _cell_order(X, 56)
+        qr = (12345, 31000)
+    J0, D0 = _hip.knn_bruteforce(X, k, query_range=qr)
+    J0, D0 = np.array(J0), np.array(D0)
+    J1, D1 = _hip.knn_bruteforce(X, k, query_range=qr, cell_starts=starts)
+    st = _hip.knn_stats()
+    assert np.array_equal(J0, J1) and np.array_equal(D0, D1)
+    if case not in ('one_cell',):
+        assert st['cells'] == len(starts)
+    if case in ('blobs64', 'blobs20', 'k26', 'subrange'):
+        assert st['visited_share'] < 0.5, st          # well-separated clusters: most (block, cell) pairs are skipped
