@@ -823,4 +823,4 @@ def knn_stats():
     check(load().glx_knn_stats(out), 'glx_knn_stats')
     return dict(tile_ms=out[0], rerank_ms=out[1], fallback_rows=out[2], total_ms=out[3], fallback_ms=out[4],
                 dpa=out[5], nsplit=out[6], KP=abs(out[7]), filter='bf16x3' if out[7] < 0 else 'f32', escalated_rows=out[8],
-                concatenated=bool(out[9]), seed_sample=int(out[10]), visited_share=out[11], cells=int(out[12]))
+                concatenated=int(out[9]), seed_sample=int(out[10]), visited_share=out[11], cells=int(out[12]))

@@ -335,9 +335,12 @@ static const int KNN_CAT_SEG = 21;
 #ifndef KNN_SEED_SUB
 #define KNN_SEED_SUB 8    // the seeding pre-pass looks at every 8th ref tile (0 / 1: no pre-pass); run time: GLX_KNN_SEED
 #endif
+// fold (d <= 20: the slots 20, 41, 62 of the three segments are free): the ref image holds -2 x (exact) and, in the free slots,
+// |x|^2 as three bf16 pieces against ones in the query image -- the contraction then IS the selection value |r|^2 - 2 q.r and the
+// tile kernel needs neither the norms of the tile nor an fma per pair (measured by ablation: 11 % of the config-2 tile kernel)
 __global__ void knn_prep_bf16_cat_kernel(const double* __restrict__ X, const double* __restrict__ mean, int64_t n, int d,
                                          unsigned short* __restrict__ Xa, unsigned short* __restrict__ Xq, float* __restrict__ nrm,
-                                         float* __restrict__ qnorm) {
+                                         float* __restrict__ qnorm, int fold) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n + KNN_PAD_ROWS) return;
   unsigned short* ra = Xa + i * 64;
@@ -345,25 +348,36 @@ __global__ void knn_prep_bf16_cat_kernel(const double* __restrict__ X, const dou
   for (int f = 0; f < 64; ++f) { ra[f] = 0; rq[f] = 0; }
   if (i >= n) {                       // spare rows behind the data: zero features, infinitely far
     nrm[i] = 1e30f;
+    if (fold) { ra[KNN_CAT_SEG - 1] = f32_to_bf16_rn(1e30f); rq[KNN_CAT_SEG - 1] = 0x3f80; }
     return;
   }
   float s = 0.f;
+  const float sc = fold ? -2.f : 1.f;
   for (int f = 0; f < d; ++f) {
     const float x = (float)(X[i * d + f] - mean[f]);
     const unsigned short hi = f32_to_bf16_rn(x);
     const unsigned short lo = f32_to_bf16_rn(x - bf16_to_f32(hi));
-    ra[f] = hi; ra[KNN_CAT_SEG + f] = hi; ra[2 * KNN_CAT_SEG + f] = lo;
+    const unsigned short shi = f32_to_bf16_rn(sc * bf16_to_f32(hi)), slo = f32_to_bf16_rn(sc * bf16_to_f32(lo));   // (exact: a power of two)
+    ra[f] = shi; ra[KNN_CAT_SEG + f] = shi; ra[2 * KNN_CAT_SEG + f] = slo;
     rq[f] = hi; rq[KNN_CAT_SEG + f] = lo; rq[2 * KNN_CAT_SEG + f] = hi;
     s = fmaf(x, x, s);
   }
   nrm[i] = s;
   qnorm[i] = sqrtf(s);
+  if (fold) {
+    const unsigned short n1 = f32_to_bf16_rn(s);
+    const float r1 = s - bf16_to_f32(n1);
+    const unsigned short n2 = f32_to_bf16_rn(r1);
+    const unsigned short n3 = f32_to_bf16_rn(r1 - bf16_to_f32(n2));
+    ra[KNN_CAT_SEG - 1] = n1; ra[2 * KNN_CAT_SEG - 1] = n2; ra[3 * KNN_CAT_SEG - 1] = n3;
+    rq[KNN_CAT_SEG - 1] = 0x3f80; rq[2 * KNN_CAT_SEG - 1] = 0x3f80; rq[3 * KNN_CAT_SEG - 1] = 0x3f80;
+  }
 }
 
 // NKB blocks of 16 features (kpad = 16 NKB <= 128); refs are the A operand (LDS), queries the B operand (registers: lane =
 // query column j, k-half h); list handling as in knn_tile_kernel.
 // CAT (NKB = 2 only): the rows are the concatenated operands above, refs from Xb, queries from Xq.
-template <int NKB, int KP, int NSUB, bool CAT = false, bool RUNS = false>
+template <int NKB, int KP, int NSUB, int CAT = 0, bool RUNS = false>   // CAT: 1 concatenated operands, 2 also the norm folded into them
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLISTS && KP == 8 && NKB == 4) ? 4 : 1, 4))) void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned short* __restrict__ Xq, const float* __restrict__ nrm, int64_t n,
                                                             int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d,
                                                             int* __restrict__ cand_i, int* __restrict__ gtau, const int* __restrict__ runs,
@@ -615,6 +629,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
     for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
       for (int eg = 0; eg < 4; ++eg) {
+        if constexpr (CAT == 2) {     // the accumulator already is |r|^2 - 2 q.r
+          m4[sub][eg] = fminf(fminf(acc[sub][eg * 4 + 0], acc[sub][eg * 4 + 1]), fminf(acc[sub][eg * 4 + 2], acc[sub][eg * 4 + 3]));
+          m = fminf(m, m4[sub][eg]);
+          continue;
+        }
         const float4 r4 = *(const float4*)(rnb + sub * 32 + 8 * eg + 4 * h);
 #if KNN_PACKED_SELECT
         // two fp32 fmas per instruction (v_pk_fma_f32 on adjacent accumulator registers) and three-input minima (v_min3_f32):
@@ -1196,7 +1215,7 @@ constexpr int bf16_nsub(int NKB, int KP) { return (NKB >= 4 || KP >= 32) ? 1 : 2
 
 // nsplit ref ranges with a tile stride of nsplit (the search proper), or -- seed = true -- ONE range with a stride of nsplit
 // writing the pre-pass's own two lists per query (KnnBufs::pre_d / pre_i)
-template <int NKB, int KP, bool CAT = false>
+template <int NKB, int KP, int CAT = 0>
 static int launch_tile_bf16(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st, bool seed = false) {
   constexpr int NSUB = bf16_nsub(NKB, KP);
   constexpr int BR = 32 * NSUB;
@@ -1220,9 +1239,10 @@ static int launch_tile_bf16(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1,
 }
 
 template <int KP>
-static int launch_tile_bf16_nkb(int NKB, const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st, bool cat = false,
+static int launch_tile_bf16_nkb(int NKB, const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st, int cat = 0,
                                 bool seed = false) {
-  if (cat) return launch_tile_bf16<2, KP, true>(b, n, q0, q1, nsplit, st, seed);
+  if (cat == 2) return launch_tile_bf16<2, KP, 2>(b, n, q0, q1, nsplit, st, seed);
+  if (cat) return launch_tile_bf16<2, KP, 1>(b, n, q0, q1, nsplit, st, seed);
   switch (NKB) {
     case 1: return launch_tile_bf16<1, KP>(b, n, q0, q1, nsplit, st, seed);
     case 2: return launch_tile_bf16<2, KP>(b, n, q0, q1, nsplit, st, seed);
@@ -1382,19 +1402,21 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   if (use_bf16) {
     // 17 <= d <= 21 (two blocks of 16 per half): the three split products as ONE contraction over concatenated operands,
     // 4 MFMAs per 32 x 32 tile instead of 6 (d <= 16 needs 3 either way)
-    const bool cat = d <= KNN_CAT_SEG && NKB == 2 && !(getenv("GLX_KNN_CAT") && atoi(getenv("GLX_KNN_CAT")) == 0);
+    // ... and for d <= 20 with the norm folded in (GLX_KNN_CAT=1: without the fold, =0: blocks of 16 features)
+    int cat = (d <= KNN_CAT_SEG && NKB == 2) ? (d < KNN_CAT_SEG ? 2 : 1) : 0;
+    if (const char* e = getenv("GLX_KNN_CAT")) cat = std::min(cat, atoi(e));
     GLX_POOL(glx_pool_alloc((void**)&b.Xb, (size_t)(n + KNN_PAD_ROWS) * 2 * dpa * 2));
     GLX_POOL(glx_pool_alloc((void**)&b.nrm, (size_t)(n + KNN_PAD_ROWS) * 4));
     if (cat) {
       GLX_POOL(glx_pool_alloc((void**)&b.Xq, (size_t)(n + KNN_PAD_ROWS) * 64 * 2));
       hipLaunchKernelGGL(knn_prep_bf16_cat_kernel, dim3((unsigned)((n + KNN_PAD_ROWS + 255) / 256)), dim3(256), 0, st, (const double*)b.X,
-                         (const double*)b.mean, n, d, b.Xb, b.Xq, b.nrm, b.qnorm);
+                         (const double*)b.mean, n, d, b.Xb, b.Xq, b.nrm, b.qnorm, cat == 2 ? 1 : 0);
     } else {
       hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3((unsigned)((n + KNN_PAD_ROWS + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const double*)b.mean,
                          n, d, dpa, b.Xb, b.nrm, b.qnorm);
     }
     GLX_HIP(hipGetLastError());
-    g_knn_stats[9] = cat ? 1.0 : 0.0;
+    g_knn_stats[9] = (double)cat;
     // The seeding pre-pass (knn_seed_kernel).  Over all refs it does not pay (measured, profiles/r03_knn_seed.txt: the k-th of a
     // 1/8 sample is the 8k-th of the whole set, 79 % of the wave-tiles still hold a candidate and the pre-pass costs its eighth):
     // GLX_KNN_SEED=<sample stride> turns it on for experiments.  The cell-pruned search needs it: its bound ub2 decides which

@@ -16,21 +16,25 @@ def gl():
     return gl
 
 
-@pytest.mark.parametrize('flt', ['bf16x3', 'bf16x3_blocks', 'f32'])
+@pytest.mark.parametrize('flt', ['bf16x3', 'bf16x3_cat', 'bf16x3_blocks', 'f32'])
 @pytest.mark.parametrize('tag', ['d20', 'd64', 'd3'])
 def test_knnsearch_golden(gl, golden, tag, flt, monkeypatch):
-    """The candidate filters -- split-bf16 operands on the bf16 matrix cores (default for d <= 128; for d <= 21 as ONE contraction
-    over concatenated operands [rh|rh|rl].[qh|ql|qh], else and with GLX_KNN_CAT=0 in blocks of 16 features) and the fp32-input
-    MFMA kernel -- end in the same exact answer: the cKDTree lists of the reference."""
+    """The candidate filters -- split-bf16 operands on the bf16 matrix cores (default for d <= 128; for 17 <= d <= 21 as ONE
+    contraction over concatenated operands [rh|rh|rl].[qh|ql|qh], for d <= 20 with |r|^2 folded into it as well; GLX_KNN_CAT=1
+    without the fold, =0 in blocks of 16 features) and the fp32-input MFMA kernel -- end in the same exact answer: the cKDTree
+    lists of the reference."""
     from graphlearning_amd import _hip
     monkeypatch.setenv('GLX_KNN_FILTER', 'f32' if flt == 'f32' else 'bf16')
-    monkeypatch.setenv('GLX_KNN_CAT', '0' if flt == 'bf16x3_blocks' else '1')
+    if flt == 'bf16x3':
+        monkeypatch.delenv('GLX_KNN_CAT', raising=False)
+    else:
+        monkeypatch.setenv('GLX_KNN_CAT', '0' if flt == 'bf16x3_blocks' else '1')
     g = golden('g2_knn.npz')
     X, J, D = g['X_' + tag], g['J_' + tag], g['D_' + tag]
     ind, dist = gl.weightmatrix.knnsearch(X, 11)
     st = _hip.knn_stats()
     assert st['filter'] == flt.split('_')[0] and st['fallback_rows'] <= 20
-    assert st['concatenated'] == (flt == 'bf16x3' and tag == 'd20')      # 17 <= d <= 21: two blocks of 16 per split half, 3 d <= 63 concatenated
+    assert st['concatenated'] == (2 if flt == 'bf16x3' else 1 if flt == 'bf16x3_cat' else 0) * (tag == 'd20')
     assert ind.dtype == np.int64 and dist.dtype == np.float64
     assert np.array_equal(ind, J)                      # identical neighbour sets and order
     assert np.array_equal(dist[:, 0], np.zeros(len(X)))  # self distance exactly 0
