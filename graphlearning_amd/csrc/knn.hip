@@ -273,7 +273,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef KNN_GTAU
 #define KNN_GTAU 1
 #endif
-static const int KNN_PAD_ROWS = 64;   // spare rows behind Xb / nrm (>= the widest ref tile): the staging loads of the last tile need no predicates
+static const int KNN_PAD_ROWS = 256;   // spare rows behind Xb / nrm (>= the widest ref tile): the staging loads of the last tile need no predicates
 #ifndef KNN_COUNT
 #define KNN_COUNT 0               // developer probe: event counters of the list maintenance (printed to stderr)
 #endif
@@ -377,7 +377,8 @@ __global__ void knn_prep_bf16_cat_kernel(const double* __restrict__ X, const dou
 // NKB blocks of 16 features (kpad = 16 NKB <= 128); refs are the A operand (LDS), queries the B operand (registers: lane =
 // query column j, k-half h); list handling as in knn_tile_kernel.
 // CAT (NKB = 2 only): the rows are the concatenated operands above, refs from Xb, queries from Xq.
-template <int NKB, int KP, int NSUB, int CAT = 0, bool RUNS = false>   // CAT: 1 concatenated operands, 2 also the norm folded into them
+// NSTG: sub-tiles of 32 NSUB refs staged (and synchronised) together (an experiment that did not pay, see bf16_nstg)
+template <int NKB, int KP, int NSUB, int CAT = 0, bool RUNS = false, int NSTG = 1>   // CAT: 1 concatenated operands, 2 also the norm folded into them
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLISTS && KP == 8 && NKB == 4) ? 4 : 1, 4))) void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned short* __restrict__ Xq, const float* __restrict__ nrm, int64_t n,
                                                             int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d,
                                                             int* __restrict__ cand_i, int* __restrict__ gtau, const int* __restrict__ runs,
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
   // nsplit = the tile stride of a ref range; the number of ranges is the grid's y extent (equal in the search proper; the
   // seeding pre-pass runs ONE range with a stride of KNN_SEED_SUB: every KNN_SEED_SUB-th tile, a sample of the refs)
   constexpr int KPAD = 16 * NKB;
-  constexpr int BR = 32 * NSUB;
+  constexpr int BR = 32 * NSUB * NSTG;
   constexpr int ROWB = 4 * KPAD + 16;                  // bytes per ref row in LDS: hi | lo, +16 so that 16 rows cover all 64 banks
   constexpr int U_ROW = 4 * KPAD / 16;                 // 16-byte units per row
   constexpr int UNITS = (BR * U_ROW + 255) / 256;
@@ -595,8 +596,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
 #if !(KNN_ABLATE & 4)
     if (has_next) stage_load(tn);
 #endif
-    const char* tl = tile + buf * BR * ROWB;
-    const float* rnb = rn + buf * BR;
+#pragma unroll 1
+    for (int stg = 0; stg < NSTG; ++stg) {
+    const char* tl = tile + (buf * BR + stg * 32 * NSUB) * ROWB;
+    const float* rnb = rn + buf * BR + stg * 32 * NSUB;
     f32x16 acc[NSUB];
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub)
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
               const float v = acc[sub][e];
               if (v < tau) {
                 ld[(KP + cnt) * 256 + tid] = v;
-                li[(KP + cnt) * 256 + tid] = (int)(t * BR) + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                li[(KP + cnt) * 256 + tid] = (int)(t * BR) + (stg * NSUB + sub) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 ++cnt;
               }
             }
@@ -688,6 +691,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
       }
     }
     KNN_TOC(cy_slow, ts);
+    }   // stg
     KNN_TIC(tb);
     if (has_next) stage_store(buf ^ 1);
 #if KNN_COUNT == 2
@@ -1215,22 +1219,30 @@ constexpr int bf16_nsub(int NKB, int KP) { return (NKB >= 4 || KP >= 32) ? 1 : 2
 
 // nsplit ref ranges with a tile stride of nsplit (the search proper), or -- seed = true -- ONE range with a stride of nsplit
 // writing the pre-pass's own two lists per query (KnnBufs::pre_d / pre_i)
+#ifndef KNN_BF16_NSTG
+#define KNN_BF16_NSTG 1
+#endif
+// sub-tiles per barrier (knn_tile_bf16_kernel).  Measured (round 3, gpurun_out/r03af): 2 -> config 2 1.32 -> 1.58 ms, config 3
+// 1.88 -> 3.20 ms, 4 -> 2.45 ms: the doubled tile buffers cost the third workgroup per CU, which matters more than the barrier
+constexpr int bf16_nstg(int NKB, int KP) { return (NKB <= 2 && KP <= 16) ? KNN_BF16_NSTG : 1; }
+
 template <int NKB, int KP, int CAT = 0>
 static int launch_tile_bf16(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st, bool seed = false) {
   constexpr int NSUB = bf16_nsub(NKB, KP);
-  constexpr int BR = 32 * NSUB;
+  constexpr int NSTG = bf16_nstg(NKB, KP);
+  constexpr int BR = 32 * NSUB * NSTG;
   constexpr int ROWB = 4 * 16 * NKB + 16;
   const size_t shm = (size_t)2 * BR * ROWB + (size_t)2 * BR * 4 + (size_t)((KNN_REGLISTS && KP == 8 && NKB == 4) ? KBUF : KP + KBUF) * 256 * 8;
   GLX_CHECK(shm <= 160 * 1024, GLX_EUNSUPPORTED, "glx_knn_bruteforce: bf16 filter needs %zu bytes of LDS", shm);
   const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)(seed ? 1 : nsplit));
   if (b.runs) {
-    GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL((knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, true>), grid, dim3(256), shm, st, (const unsigned short*)b.Xb, (const unsigned short*)(CAT ? b.Xq : b.Xb),
+    GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, true, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, true, NSTG>), grid, dim3(256), shm, st, (const unsigned short*)b.Xb, (const unsigned short*)(CAT ? b.Xq : b.Xb),
                        (const float*)b.nrm, n, q0, q1, nsplit, seed ? b.pre_d : b.cand_d, seed ? b.pre_i : b.cand_i, b.gtau, (const int*)b.runs,
                        (const int*)b.nruns, b.maxruns);
   } else {
-    GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL((knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, false>), grid, dim3(256), shm, st, (const unsigned short*)b.Xb, (const unsigned short*)(CAT ? b.Xq : b.Xb),
+    GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, false, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, false, NSTG>), grid, dim3(256), shm, st, (const unsigned short*)b.Xb, (const unsigned short*)(CAT ? b.Xq : b.Xb),
                        (const float*)b.nrm, n, q0, q1, nsplit, seed ? b.pre_d : b.cand_d, seed ? b.pre_i : b.cand_i, b.gtau, (const int*)nullptr,
                        (const int*)nullptr, 0);
   }
@@ -1338,7 +1350,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   }
   const int dpa = use_bf16 ? 16 * NKB : 2 * DH * nkb;
   const int64_t nqb = (nq + BQ - 1) / BQ;
-  const int BR = use_bf16 ? 32 * bf16_nsub(NKB, KP) : 32 * tile_nsub(DH, KP);
+  const int BR = use_bf16 ? 32 * bf16_nsub(NKB, KP) * bf16_nstg(NKB, KP) : 32 * tile_nsub(DH, KP);
   const int64_t ntiles = (n + BR - 1) / BR;
   int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, ntiles), (1024 + nqb - 1) / nqb));
   if (short_lists) {
