@@ -139,9 +139,14 @@ def scale_shard_line(steps=4, T=50):
            'knn_tile_ms': st['tile_ms'], 'knn_filter': st['filter'],
            # useful work 2 n^2 d_padded per second; the bf16x3 filter issues three bf16 MFMAs per product term, so its matrix-pipe
            # utilisation is 3 x this against the 2500 TFLOP/s dense bf16 peak (the f32 filter: this against 157.3)
-           'knn_tile_tflops': 2.0 * n * n * st['dpa'] / st['tile_ms'] / 1e9,
-           'knn_mfma_util': (3.0 * 2.0 * n * n * st['dpa'] / st['tile_ms'] / 1e9 / 2500.0) if st['filter'] == 'bf16x3'
-           else (2.0 * n * n * st['dpa'] / st['tile_ms'] / 1e9 / 157.3)}
+           # from 2^17 rows on weightmatrix.knn lets the library form cells and skip those that cannot hold a neighbour
+           # (glx_knn_clustered: the same lists): only the visited share of the n^2 pairs is contracted, and the tile time
+           # includes the cell passes (centres, bounds, sample pre-pass)
+           'knn_search': ('cell-pruned, %d cells' % st['cells']) if st['cells'] else 'all pairs',
+           'knn_visited_share': st['visited_share'] if st['cells'] else 1.0}
+    pairs = float(n) * n * out['knn_visited_share']
+    out['knn_tile_tflops'] = 2.0 * pairs * st['dpa'] / st['tile_ms'] / 1e9
+    out['knn_mfma_util'] = (3.0 * out['knn_tile_tflops'] / 2500.0) if st['filter'] == 'bf16x3' else out['knn_tile_tflops'] / 157.3
     for dt, dtype, es in (('f64', np.float64, 8), ('f32', np.float32, 4)):
         model = gl.ssl.poisson(W, solver='gradient_descent', use_cuda=(dtype == np.float32), min_iter=T, max_iter=T)
         dev, aux = model._operators()

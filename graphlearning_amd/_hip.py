@@ -123,6 +123,7 @@ _SIGNATURES = {
     'glx_knn_bruteforce': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
     'glx_knn_bruteforce_range': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
     'glx_knn_cells_range': [_vp, C.c_int64, C.c_int, C.c_int, _vp, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
+    'glx_knn_clustered': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
     'glx_knn_stats': [_f64p],
     'glx_knn_to_csr': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                        C.POINTER(_vp), _i64p, C.c_int],
@@ -726,11 +727,24 @@ def host_reverse_scale_rows(W, scale):
     return col, val
 
 
-def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, cell_starts=None):
+def auto_cells(n, d):
+    """How many cells glx_knn_clustered forms when the caller leaves it to the library: none below 2^17 rows (the all-pairs
+    search takes a few ms there) or above 128 features (the cell pruning rides on the split-bf16 filter), else one per 8192
+    rows within [16, 256].  GLX_KNN_CLUSTERED=0 turns it off, =<m> forces m cells."""
+    e = os.environ.get('GLX_KNN_CLUSTERED')
+    if e is not None:
+        return max(0, int(e))
+    if n < (1 << 17) or d > 128:
+        return 0
+    return int(min(256, max(16, n // 8192)))
+
+
+def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, cell_starts=None, clustered=None):
     """Exact kNN (incl. self) on the GPU.  'angular' = euclidean on row-normalised data, formed
     with the reference's own expression (weightmatrix.py:344-345).  cell_starts: the rows come in a coarse geometric
     order with cell c = rows [cell_starts[c], cell_starts[c+1]); the search skips the cells that cannot hold a
-    neighbour (glx_knn_cells_range: the same lists, a fraction of the tiles on clustered data)."""
+    neighbour (glx_knn_cells_range: the same lists, a fraction of the tiles on clustered data).  clustered: number of cells
+    the library forms itself (glx_knn_clustered; None = auto_cells(n, d), 0 = all pairs)."""
     X = np.asarray(X, dtype=np.float64)
     if similarity == 'angular':
         X = X / np.linalg.norm(X, axis=1)[:, None]
@@ -745,6 +759,10 @@ def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, 
         cs = np.ascontiguousarray(cell_starts, dtype=np.int64)
         check(load().glx_knn_cells_range(_ptr(X), n, d, k, _ptr(cs), len(cs), q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
               'glx_knn_cells_range')
+        return ind, dist
+    m = (auto_cells(n, d) if clustered is None else int(clustered)) if query_range is None else 0
+    if m > 1:       # cells formed by the library (same lists; a fraction of the tiles when the data has clusters)
+        check(load().glx_knn_clustered(_ptr(X), n, d, k, m, _ptr(ind), _ptr(dist), _dev(device)), 'glx_knn_clustered')
         return ind, dist
     check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
           'glx_knn_bruteforce')

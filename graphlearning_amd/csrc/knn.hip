@@ -783,6 +783,50 @@ __global__ __launch_bounds__(256) void knn_seed_kernel(const float* __restrict__
 // ub2 comes from the seeding pre-pass over a sample of the query block's OWN cells; the search proper then visits, per block of
 // 128 queries, the tiles of the cells any of its queries still needs.  Exact: a skipped ref is strictly farther than the k-th
 // neighbour.  On clustered data (config 4: ten Gaussian blobs in 64 dimensions) nine tenths of the tiles go.
+// ---- glx_knn_clustered: cells formed by the library ---------------------------------------------
+// out[i] = X[rows[i]] (rows of d doubles)
+__global__ __launch_bounds__(256) void knn_gather_rows_kernel(const double* __restrict__ X, const int* __restrict__ rows, int64_t m, int d,
+                                                              double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m * d) return;
+  out[i] = X[(int64_t)rows[i / d] * d + i % d];
+}
+
+// cell[i] = the nearest of m centres (lowest index on ties); centres in batches of 8 through LDS, one walk over a point's
+// features per batch
+__global__ __launch_bounds__(256) void knn_assign_kernel(const double* __restrict__ X, int d, int64_t n, const double* __restrict__ cen, int m,
+                                                         int* __restrict__ cell) {
+  extern __shared__ double cc[];
+  constexpr int CB = 8;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const double* x = X + (i < n ? i : n - 1) * d;
+  double best = INFINITY;
+  int bc = 0;
+  for (int c0 = 0; c0 < m; c0 += CB) {
+    __syncthreads();
+    for (int u = threadIdx.x; u < CB * d; u += 256) {
+      const int c = c0 + u / d;
+      cc[u] = c < m ? cen[(int64_t)c * d + u % d] : 0.0;
+    }
+    __syncthreads();
+    double s2[CB];
+#pragma unroll
+    for (int e = 0; e < CB; ++e) s2[e] = 0.0;
+    for (int f = 0; f < d; ++f) {
+      const double xf = x[f];
+#pragma unroll
+      for (int e = 0; e < CB; ++e) {
+        const double df = xf - cc[e * d + f];
+        s2[e] += df * df;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < CB; ++e)
+      if (c0 + e < m && s2[e] < best) { best = s2[e]; bc = c0 + e; }
+  }
+  if (i < n) cell[i] = bc;
+}
+
 static const int CELL_SPLIT = 64;      // workgroups per cell in the centre / radius passes (a cell of config 4 at n = 1e7 is 80 MB)
 
 // partial column sums of piece s of cell c (fixed order inside a piece; the pieces are added in order by knn_cell_centre_kernel)
@@ -914,7 +958,7 @@ __global__ __launch_bounds__(256) void knn_cellmask_kernel(const double* __restr
 // (those its 128 rows lie in) -- the sample the seeding pre-pass looks at.
 __global__ __launch_bounds__(256) void knn_runs_kernel(const unsigned char* __restrict__ mask, const int64_t* __restrict__ cell_starts, int64_t n,
                                                        int ncells, int BR, int64_t q_begin, int64_t q_end, int64_t nqb, int maxruns,
-                                                       int* __restrict__ runs, int* __restrict__ nruns) {
+                                                       int* __restrict__ runs, int* __restrict__ nruns, unsigned long long* __restrict__ visited) {
   const int64_t qb = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (qb >= nqb) return;
   const int64_t r0 = q_begin + qb * BQ, r1 = min(q_end, r0 + BQ);
@@ -939,6 +983,11 @@ __global__ __launch_bounds__(256) void knn_runs_kernel(const unsigned char* __re
     last_b = tb;
   }
   nruns[qb] = nr;
+  if (visited) {                                    // tiles this block visits (statistics: glx_knn_stats [11])
+    unsigned long long tot = 0;
+    for (int r = 0; r < nr; ++r) tot += (unsigned long long)(out[2 * r + 1] - out[2 * r]);
+    atomicAdd(visited, tot);
+  }
 }
 
 // ---- stage 2: exact fp64 re-rank + acceptance check ------------------------------------------
@@ -970,7 +1019,10 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
                                                         int64_t nq, const float* __restrict__ cand_d, const int* __restrict__ cand_i,
                                                         int lists, int KP, int M, const float* __restrict__ qnorm, const float* __restrict__ rmax_p,
                                                         double cerr, int64_t* __restrict__ ind_out, double* __restrict__ dist_out,
-                                                        int* __restrict__ flags) {
+                                                        int* __restrict__ flags, const int* __restrict__ orig) {
+  // orig (glx_knn_clustered: the rows were reordered by cell, orig[position] = the caller's row): candidates are ranked by
+  // (distance, the CALLER's index) and the caller's indices go out, into the caller's row -- the lists of the search in the
+  // caller's order, ties included
   extern __shared__ __attribute__((aligned(16))) char sm[];
   double* sd = (double*)sm;          // [M]
   int* si = (int*)(sd + M);          // [M]
@@ -985,7 +1037,7 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
     if (c < ncand) {
       const int ci = cand_i[ql * ncand + c];
       if (ci >= 0 && ci < n) {
-        idx = ci;
+        idx = orig ? orig[ci] : ci;
         dd = sqdist_exact(xq, X + (int64_t)ci * d, d);
       }
     }
@@ -1007,9 +1059,10 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
       __syncthreads();
     }
   }
+  const int64_t orow = orig ? (int64_t)orig[q] - q_begin : ql;
   for (int c = threadIdx.x; c < k; c += 64) {
-    ind_out[ql * k + c] = si[c] == 0x7fffffff ? -1 : si[c];
-    dist_out[ql * k + c] = sqrt(sd[c]);
+    ind_out[orow * k + c] = si[c] == 0x7fffffff ? -1 : si[c];
+    dist_out[orow * k + c] = sqrt(sd[c]);
   }
   if (threadIdx.x == 0) {
     // every ref outside a full list has fp32 dist^2 >= that list's threshold; accept the row
@@ -1037,7 +1090,7 @@ static const int FB_SPLIT = 64;
 __global__ __launch_bounds__(256) void knn_fallback_scan_kernel(const double* __restrict__ X, int64_t n, int d, int64_t q_begin,
                                                                 const int* __restrict__ rows, const double* __restrict__ last_d,
                                                                 const int* __restrict__ last_i, double* __restrict__ part_d,
-                                                                int* __restrict__ part_i) {
+                                                                int* __restrict__ part_i, const int* __restrict__ orig) {
   __shared__ double s_d[256];
   __shared__ int s_i[256];
   const int row = blockIdx.x, piece = blockIdx.y;
@@ -1051,7 +1104,8 @@ __global__ __launch_bounds__(256) void knn_fallback_scan_kernel(const double* __
   int bi = 0x7fffffff;
   for (int64_t ref = r0 + threadIdx.x; ref < r1; ref += 256) {
     const double dd = sqdist_exact(xq, X + ref * d, d);
-    if (lex_less(pd, pi, dd, (int)ref) && lex_less(dd, (int)ref, bd, bi)) { bd = dd; bi = (int)ref; }
+    const int id = orig ? orig[ref] : (int)ref;
+    if (lex_less(pd, pi, dd, id) && lex_less(dd, id, bd, bi)) { bd = dd; bi = id; }
   }
   s_d[threadIdx.x] = bd;
   s_i[threadIdx.x] = bi;
@@ -1072,7 +1126,8 @@ __global__ __launch_bounds__(256) void knn_fallback_scan_kernel(const double* __
 __global__ __launch_bounds__(64) void knn_fallback_pick_kernel(const double* __restrict__ part_d, const int* __restrict__ part_i,
                                                                const int* __restrict__ rows, int nrows, int k, int r,
                                                                double* __restrict__ last_d, int* __restrict__ last_i,
-                                                               int64_t* __restrict__ ind_out, double* __restrict__ dist_out) {
+                                                               int64_t* __restrict__ ind_out, double* __restrict__ dist_out,
+                                                               const int* __restrict__ orig, int64_t q_begin) {
   const int row = blockIdx.x * 64 + threadIdx.x;
   if (row >= nrows) return;
   double bd = INFINITY;
@@ -1084,7 +1139,7 @@ __global__ __launch_bounds__(64) void knn_fallback_pick_kernel(const double* __r
   }
   last_d[row] = bd;
   last_i[row] = bi;
-  const int64_t ql = rows[row];
+  const int64_t ql = orig ? (int64_t)orig[q_begin + rows[row]] - q_begin : rows[row];
   ind_out[ql * k + r] = bi == 0x7fffffff ? -1 : bi;
   dist_out[ql * k + r] = sqrt(bd);
 }
@@ -1121,6 +1176,10 @@ struct KnnBufs {
   int64_t* cell_starts = nullptr;
   double *cen = nullptr, *rad = nullptr, *ub2 = nullptr, *cpart = nullptr;
   unsigned char* mask = nullptr;
+  unsigned long long* visited = nullptr;      // ref tiles the query blocks visit, summed (statistics)
+  // glx_knn_clustered: the rows reordered by cell (X points at the reordered copy), orig[position] = the caller's row
+  double* Xraw = nullptr;
+  int *orig = nullptr, *cell_id = nullptr;
   int *cand_i = nullptr, *flags = nullptr, *rows = nullptr, *fb_li = nullptr, *fb_pi = nullptr, *gtau = nullptr;
   double *fb_ld = nullptr, *fb_pd = nullptr;
   int64_t* ind = nullptr;
@@ -1131,7 +1190,7 @@ struct KnnBufs {
     if (stream) hipStreamSynchronize(stream);   // pooled blocks are reused at once: nothing may still be running on them
     glx_pool_free(Xb); glx_pool_free(Xq); glx_pool_free(nrm); glx_pool_free(part); glx_pool_free(rmax);
     glx_pool_free(X); glx_pool_free(mean); glx_pool_free(dist); glx_pool_free(Rf); glx_pool_free(Qf); glx_pool_free(qnorm); glx_pool_free(cand_d);
-    glx_pool_free(runs); glx_pool_free(nruns); glx_pool_free(cell_starts); glx_pool_free(cen); glx_pool_free(rad); glx_pool_free(ub2); glx_pool_free(cpart); glx_pool_free(mask);
+    glx_pool_free(runs); glx_pool_free(nruns); glx_pool_free(cell_starts); glx_pool_free(cen); glx_pool_free(rad); glx_pool_free(ub2); glx_pool_free(cpart); glx_pool_free(mask); glx_pool_free(visited); glx_pool_free(Xraw); glx_pool_free(orig); glx_pool_free(cell_id);
     glx_pool_free(pre_d); glx_pool_free(pre_i); glx_pool_free(gtau); glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_li); glx_pool_free(fb_pi); glx_pool_free(fb_ld); glx_pool_free(fb_pd);
     glx_work_release(work);
   }
@@ -1304,7 +1363,7 @@ static const int KNN_ESCALATE = 1;    // knn_pass: too many rows failed the acce
 // sit in the same 16 of 32 consecutive points to get there (tight groups stored one after another); interleaving the ref tiles
 // over the ranges already spreads anything coarser.
 static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_t q1, int64_t* ind_out, double* dist_out, int device,
-                    bool long_lists, const int64_t* cell_starts = nullptr, int ncells = 0) {
+                    bool long_lists, const int64_t* cell_starts = nullptr, int ncells = 0, int auto_cells = 0) {
   GLX_CHECK(X && ind_out && dist_out, GLX_EINVAL, "glx_knn_bruteforce: null argument");
   GLX_CHECK(n >= 1 && d >= 1 && k >= 1, GLX_EINVAL, "glx_knn_bruteforce: need n, d, k >= 1 (n=%lld d=%d k=%d)", (long long)n, d, k);
   GLX_CHECK(k <= n, GLX_EINVAL, "glx_knn_bruteforce: k=%d exceeds the number of points %lld", k, (long long)n);
@@ -1378,6 +1437,45 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   stamp("stream, events, buffers");
   GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyHostToDevice, st));
   stamp("X enqueued");
+  // glx_knn_clustered: form auto_cells cells (nearest of that many sample rows), reorder the rows by cell ON THE DEVICE and
+  // search with the cell pruning of glx_knn_cells_range; the re-rank ranks by and returns the caller's indices
+  std::vector<int64_t> own_starts;
+  if (auto_cells > 1 && q0 == 0 && q1 == n && !long_lists && d <= 128 && n >= 4 * (int64_t)auto_cells) {
+    const int m = auto_cells;
+    std::vector<int> sample(m);
+    for (int c = 0; c < m; ++c) sample[c] = (int)(((2 * (int64_t)c + 1) * n) / (2 * (int64_t)m));     // evenly spaced rows
+    GLX_POOL(glx_pool_alloc((void**)&b.cen, (size_t)m * d * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.cell_id, (size_t)std::max<int64_t>(n, m) * 4));
+    GLX_POOL(glx_pool_alloc((void**)&b.orig, (size_t)n * 4));
+    GLX_HIP(hipMemcpyAsync(b.cell_id, sample.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(knn_gather_rows_kernel, dim3((unsigned)(((int64_t)m * d + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const int*)b.cell_id,
+                       (int64_t)m, d, b.cen);
+    GLX_HIP(hipStreamSynchronize(st));            // (`sample` is read by the copy above)
+    hipLaunchKernelGGL(knn_assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)8 * d * 8, st, (const double*)b.X, d, n, (const double*)b.cen, m,
+                       b.cell_id);
+    GLX_HIP(hipGetLastError());
+    std::vector<int> cid(n), perm(n);
+    GLX_HIP(hipMemcpyAsync(cid.data(), b.cell_id, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    GLX_HIP(hipStreamSynchronize(st));
+    own_starts.assign(m, 0);
+    std::vector<int64_t> fill(m + 1, 0);
+    for (int64_t i = 0; i < n; ++i) ++fill[cid[i] + 1];
+    for (int c = 0; c < m; ++c) fill[c + 1] += fill[c];
+    for (int c = 0; c < m; ++c) own_starts[c] = fill[c];
+    for (int64_t i = 0; i < n; ++i) perm[fill[cid[i]]++] = (int)i;       // stable: ascending caller index inside a cell
+    GLX_HIP(hipMemcpyAsync(b.orig, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    b.Xraw = b.X;
+    b.X = nullptr;
+    GLX_POOL(glx_pool_alloc((void**)&b.X, (size_t)n * d * 8));
+    hipLaunchKernelGGL(knn_gather_rows_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, st, (const double*)b.Xraw, (const int*)b.orig, n, d, b.X);
+    GLX_HIP(hipGetLastError());
+    GLX_HIP(hipStreamSynchronize(st));            // (`perm` is read by the copy above)
+    glx_pool_free(b.cen);                          // the cell pass allocates its own
+    b.cen = nullptr;
+    cell_starts = own_starts.data();
+    ncells = m;
+    stamp("rows reordered by cell");
+  }
   // centring in fp64 (distances are translation invariant; small norms keep the filter sharp), all of it on the device
   const int64_t nb_sum = (n + CENTRE_ROWS - 1) / CENTRE_ROWS, nb_max = (n + 255) / 256;
   GLX_POOL(glx_pool_alloc((void**)&b.part, (size_t)std::max<int64_t>(nb_sum * d, nb_max) * 8));
@@ -1467,7 +1565,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
       hipLaunchKernelGGL(knn_cell_radfin_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st, (const double*)prad,
                          (const int64_t*)b.cell_starts, n, ncells, b.rad);
       hipLaunchKernelGGL(knn_runs_kernel, dim3((unsigned)((nqb + 255) / 256)), dim3(256), 0, st, (const unsigned char*)nullptr,
-                         (const int64_t*)b.cell_starts, n, ncells, BR, q0, q1, nqb, b.maxruns, b.runs, b.nruns);
+                         (const int64_t*)b.cell_starts, n, ncells, BR, q0, q1, nqb, b.maxruns, b.runs, b.nruns, (unsigned long long*)nullptr);
       GLX_HIP(hipGetLastError());
     }
     if (seeded) {
@@ -1484,21 +1582,11 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     if (cells && seeded) {
       hipLaunchKernelGGL(knn_cellmask_kernel, dim3((unsigned)nqb), dim3(256), (size_t)16 * d * 8, st, (const double*)b.X, d, q0, q1, (const double*)b.cen,
                          (const double*)b.rad, ncells, (const double*)b.ub2, b.mask);
+      GLX_POOL(glx_pool_alloc((void**)&b.visited, 8));
+      GLX_HIP(hipMemsetAsync(b.visited, 0, 8, st));
       hipLaunchKernelGGL(knn_runs_kernel, dim3((unsigned)((nqb + 255) / 256)), dim3(256), 0, st, (const unsigned char*)b.mask,
-                         (const int64_t*)b.cell_starts, n, ncells, BR, q0, q1, nqb, b.maxruns, b.runs, b.nruns);
+                         (const int64_t*)b.cell_starts, n, ncells, BR, q0, q1, nqb, b.maxruns, b.runs, b.nruns, b.visited);
       GLX_HIP(hipGetLastError());
-      if (getenv("GLX_TIMING") || getenv("GLX_KNN_CELL_STATS")) {      // share of (query block, cell) pairs still visited
-        std::vector<unsigned char> hm((size_t)nqb * ncells);
-        GLX_HIP(hipMemcpyAsync(hm.data(), b.mask, hm.size(), hipMemcpyDeviceToHost, st));
-        GLX_HIP(hipStreamSynchronize(st));
-        double rows_v = 0.0;
-        for (int64_t qb2 = 0; qb2 < nqb; ++qb2)
-          for (int c = 0; c < ncells; ++c)
-            if (hm[qb2 * ncells + c]) rows_v += (double)((c + 1 < ncells ? cell_starts[c + 1] : n) - cell_starts[c]);
-        g_knn_stats[11] = rows_v / ((double)nqb * (double)n);
-        fprintf(stderr, "[glx] knn: cell pruning, %d cells, sample stride %d: %.1f %% of the (query block, ref) pairs are visited\n", ncells, seed_sub,
-                100.0 * g_knn_stats[11]);
-      }
       g_knn_stats[12] = (double)ncells;
     }
     if (KP == 8) rc = launch_tile_bf16_nkb<8>(NKB, b, n, q0, q1, nsplit, st, cat);
@@ -1533,14 +1621,20 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
 #endif
   hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)nq), dim3(64), (size_t)M * 12, st, (const double*)b.X, n, d, k, q0, nq,
                      (const float*)b.cand_d, (const int*)b.cand_i, lists, KP, M, (const float*)b.qnorm, (const float*)b.rmax, cerr, b.ind, b.dist,
-                     b.flags);
+                     b.flags, (const int*)b.orig);
   GLX_HIP(hipGetLastError());
   GLX_HIP(hipEventRecord(b.e2, st));
   std::vector<int> flags(nq);
   float h_rmax[2] = {0.f, 0.f};
   GLX_HIP(hipMemcpyAsync(flags.data(), b.flags, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipMemcpyAsync(h_rmax, b.rmax, 8, hipMemcpyDeviceToHost, st));
+  unsigned long long h_visited = 0;
+  if (b.visited) GLX_HIP(hipMemcpyAsync(&h_visited, b.visited, 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
+  if (b.visited) {
+    g_knn_stats[11] = (double)h_visited / ((double)nqb * (double)ntiles);
+    if (timing) fprintf(stderr, "[glx] knn: cell pruning, %d cells: %.1f %% of the (query block, ref tile) pairs visited\n", ncells, 100.0 * g_knn_stats[11]);
+  }
   stamp("tile + re-rank done, flags on the host");
   GLX_CHECK(h_rmax[1] == 1.0f, GLX_EINVAL, "glx_knn_bruteforce: non-finite input");   // (the first host look at the centring pass)
   std::vector<int> rows;
@@ -1571,9 +1665,9 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     GLX_HIP(hipMemcpyAsync(b.fb_li, li0.data(), nr * 4, hipMemcpyHostToDevice, st));
     for (int r = 0; r < k; ++r) {
       hipLaunchKernelGGL(knn_fallback_scan_kernel, dim3((unsigned)nr, FB_SPLIT), dim3(256), 0, st, (const double*)b.X, n, d, q0,
-                         (const int*)b.rows, (const double*)b.fb_ld, (const int*)b.fb_li, b.fb_pd, b.fb_pi);
+                         (const int*)b.rows, (const double*)b.fb_ld, (const int*)b.fb_li, b.fb_pd, b.fb_pi, (const int*)b.orig);
       hipLaunchKernelGGL(knn_fallback_pick_kernel, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, st, (const double*)b.fb_pd,
-                         (const int*)b.fb_pi, (const int*)b.rows, (int)nr, k, r, b.fb_ld, b.fb_li, b.ind, b.dist);
+                         (const int*)b.fb_pi, (const int*)b.rows, (int)nr, k, r, b.fb_ld, b.fb_li, b.ind, b.dist, (const int*)b.orig, q0);
     }
     GLX_HIP(hipGetLastError());
     GLX_HIP(hipStreamSynchronize(st));   // ld0 / li0 are read by the asynchronous copies above
@@ -1599,10 +1693,10 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
 }
 
 static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t q1, int64_t* ind_out, double* dist_out, int device,
-                   const int64_t* cell_starts = nullptr, int ncells = 0) {
+                   const int64_t* cell_starts = nullptr, int ncells = 0, int auto_cells = 0) {
   g_knn_stats[8] = 0.0;
   g_knn_stats[10] = g_knn_stats[11] = g_knn_stats[12] = 0.0;
-  int rc = knn_pass(X, n, d, k, q0, q1, ind_out, dist_out, device, false, cell_starts, ncells);
+  int rc = knn_pass(X, n, d, k, q0, q1, ind_out, dist_out, device, false, cell_starts, ncells, auto_cells);
   if (rc != KNN_ESCALATE) return rc;
   const double flagged = g_knn_stats[2];
   g_knn_stats[10] = g_knn_stats[11] = g_knn_stats[12] = 0.0;
@@ -1636,4 +1730,13 @@ extern "C" int glx_knn_cells_range(const double* X, int64_t n, int d, int k, con
   for (int c = 1; c < ncells; ++c)
     GLX_CHECK(cell_starts[c] >= cell_starts[c - 1] && cell_starts[c] <= n, GLX_EINVAL, "glx_knn_cells_range: cell starts must ascend within [0, n]");
   return knn_run(X, n, d, k, q_begin, q_end, ind_out, dist_out, device, cell_starts, ncells);
+}
+
+// All n rows in the caller's order, the cells formed here: ncells evenly spaced rows serve as centres, every row joins the
+// nearest one, the rows are reordered by cell on the device and searched with the pruning of glx_knn_cells_range; indices and
+// output rows are the caller's, ties between equal distances go to the lower caller index -- the lists of glx_knn_bruteforce,
+// bit for bit.  On data without cluster structure every cell stays in play and the extra passes cost a few per cent.
+extern "C" int glx_knn_clustered(const double* X, int64_t n, int d, int k, int ncells, int64_t* ind_out, double* dist_out, int device) {
+  GLX_CHECK(ncells >= 0 && ncells <= 4096, GLX_EINVAL, "glx_knn_clustered: ncells=%d outside [0, 4096]", ncells);
+  return knn_run(X, n, d, k, 0, n, ind_out, dist_out, device, nullptr, 0, ncells);
 }

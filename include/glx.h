@@ -317,6 +317,11 @@ int glx_knn_bruteforce_range(const double* X, int64_t n, int d, int k, int64_t q
  * neighbour.  The role of the tree in the reference's search (cKDTree / annoy, graphlearning/weightmatrix.py:297-429). */
 int glx_knn_cells_range(const double* X, int64_t n, int d, int k, const int64_t* cell_starts, int ncells, int64_t q_begin,
                         int64_t q_end, int64_t* ind_out, double* dist_out, int device);
+/* all n rows in the caller's order, the cells formed by the library: ncells (<= 4096; 0 / 1 = plain all-pairs search) evenly
+ * spaced rows serve as centres, every row joins the nearest, the rows are reordered by cell on the device and searched with the
+ * pruning of glx_knn_cells_range.  Indices and output rows are the caller's, equal distances go to the lower caller index: the
+ * lists of glx_knn_bruteforce bit for bit. */
+int glx_knn_clustered(const double* X, int64_t n, int d, int k, int ncells, int64_t* ind_out, double* dist_out, int device);
 int glx_knn_stats(double stats[16]);  /* of the last search: [0] tile-kernel ms, [1] re-rank ms, [2] fallback rows, [3] total device ms,
                                         [4] fallback ms, [5] padded feature count, [6] ref ranges, [7] list length (negative: bf16 filter),
                                         [8] rows the short lists could not accept when the search was repeated with long ones (else 0);

@@ -296,7 +296,6 @@ def test_knn_cells_identical_to_all_pairs(gl, case, monkeypatch):
     bit for bit -- clustered data (most cells skipped), uniform data (few skipped), cells smaller than a tile, one cell, empty
     cells, longer lists, a query sub-range (the rank-local share of a sharded search)."""
     from graphlearning_amd import _hip
-    monkeypatch.setenv('GLX_KNN_CELL_STATS', '1')
     rng = np.random.default_rng(11)
     k, qr = 11, None
     if case == 'blobs64':
@@ -334,3 +333,36 @@ def test_knn_cells_identical_to_all_pairs(gl, case, monkeypatch):
         assert st['cells'] == len(starts)
     if case in ('blobs64', 'blobs20', 'k26', 'subrange'):
         assert st['visited_share'] < 0.5, st          # well-separated clusters: most (block, cell) pairs are skipped
+
+
+@pytest.mark.parametrize('case', ['blobs64', 'dup_ties', 'uniform', 'small_forced', 'k26_d32'])
+def test_knn_clustered_identical_to_all_pairs(gl, case, monkeypatch):
+    """glx_knn_clustered (cells formed by the library, rows reordered on the device, caller's indices and rows out) returns the
+    lists of the all-pairs search bit for bit -- including which of several equidistant points makes the list (duplicated points:
+    the lower caller index wins in both)."""
+    from graphlearning_amd import _hip
+    rng = np.random.default_rng(3)
+    k, m = 11, 32
+    if case == 'blobs64':
+        X, _ = blobs(70000, 64, 10, 3, 4.0)
+    elif case == 'dup_ties':
+        base, _ = blobs(9000, 12, 6, 5, 5.0)
+        X = base[rng.integers(0, len(base), size=40000)]          # every point about 4 times: ties at distance 0 and beyond
+    elif case == 'uniform':
+        X = rng.random((50000, 10))
+    elif case == 'small_forced':
+        X, _ = blobs(3000, 8, 3, 1, 4.0)
+        m = 7
+    else:
+        X, _ = blobs(45000, 32, 9, 8, 5.0)
+        k = 26
+    J0, D0 = _hip.knn_bruteforce(X, k, clustered=0)
+    assert _hip.knn_stats()['cells'] == 0
+    J0, D0 = np.array(J0), np.array(D0)
+    J1, D1 = _hip.knn_bruteforce(X, k, clustered=m)
+    st = _hip.knn_stats()
+    assert st['cells'] == m
+    assert np.array_equal(J0, J1) and np.array_equal(D0, D1)
+    if case in ('blobs64', 'k26_d32'):
+        assert st['visited_share'] < 0.5, st
+    assert _hip.auto_cells(70000, 20) == 0 and _hip.auto_cells(1000000, 64) == 122 and _hip.auto_cells(10 ** 7, 64) == 256
