@@ -325,7 +325,10 @@ int glx_knn_clustered(const double* X, int64_t n, int d, int k, int ncells, int6
 int glx_knn_stats(double stats[16]);  /* of the last search: [0] tile-kernel ms, [1] re-rank ms, [2] fallback rows, [3] total device ms,
                                         [4] fallback ms, [5] padded feature count, [6] ref ranges, [7] list length (negative: bf16 filter),
                                         [8] rows the short lists could not accept when the search was repeated with long ones (else 0);
-                                        [9..15] reserved */
+                                        [9] concatenated operands (d <= 21): 0 no, 1 yes, 2 with the norm folded in (d <= 20),
+                                        [10] tile stride of the sample the seeding pre-pass looked at (0: no pre-pass; tile-kernel ms
+                                        include it and the cell passes), [11] share of the (query block, ref tile) pairs visited and
+                                        [12] number of cells of a cell-pruned search (0: all pairs); [13..15] reserved */
 
 /* weightmatrix.knn given knn data (graphlearning/weightmatrix.py:134-187) on the device: kernel
  * weights, COO->CSR with duplicates summed, symmetrisation, zero diagonal, zeros dropped.
