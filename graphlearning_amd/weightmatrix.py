@@ -60,13 +60,17 @@ def _knn(data, k, kernel, eta, symmetrize, metric, similarity, knn_data, device)
             # moves the exp to the device as well (within an ulp).
             d = np.asarray(knn_dist)[:, :k]
             weights = _hip.pinned_empty((n, k), np.float64)          # page-locked: the upload to the assembly runs at PCIe speed
-            if kernel == 'gaussian':
-                D = d * d
-                eps = D[:, k - 1]
-                np.exp(-4 * D / eps[:, None], out=weights)
-            else:
-                eps = d[:, k - 1]
-                np.exp(-4 * d * d / eps[:, None] / eps[np.asarray(knn_ind)[:, :k]], out=weights)
+            J = np.asarray(knn_ind)[:, :k]
+            eps_all = d[:, k - 1] if kernel == 'symgaussian' else None
+
+            def rows(lo, hi):           # elementwise: any split into row blocks gives the same bits
+                if kernel == 'gaussian':
+                    D = d[lo:hi] * d[lo:hi]
+                    eps = D[:, k - 1]
+                    np.exp(-4 * D / eps[:, None], out=weights[lo:hi])
+                else:
+                    np.exp(-4 * d[lo:hi] * d[lo:hi] / eps_all[lo:hi, None] / eps_all[J[lo:hi]], out=weights[lo:hi])
+            _row_blocks(rows, n)
             return _hip.knn_to_csr(knn_ind, knn_dist, k, kernel='given', sym=sym, weights=weights, device=device)
         return _hip.knn_to_csr(knn_ind, knn_dist, k, kernel=kernel, sym=sym, device=device)
     # user kernel: a Python callable, evaluated on the host; assembly on the device.
@@ -76,6 +80,25 @@ def _knn(data, k, kernel, eta, symmetrize, metric, similarity, knn_data, device)
     eps = D[:, k - 1]
     weights = eta(D / eps[:, None])
     return _hip.knn_to_csr(knn_ind, knn_dist, k, kernel='given', sym=sym, weights=weights, device=device)
+
+
+_pool = None
+
+
+def _row_blocks(fn, n, min_rows=16384):
+    """fn(lo, hi) over row blocks on a few host threads (numpy releases the GIL inside its loops): the exp of the Gaussian
+    weights was 1 ms of weightmatrix.knn's 5.7 at config 2 on one thread."""
+    global _pool
+    nt = int(min(8, os.cpu_count() or 1, n // min_rows))
+    if nt <= 1 or os.environ.get('GLX_HOST_THREADS') == '1':
+        fn(0, n)
+        return
+    if _pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max_workers=8)
+    cuts = [n * t // nt for t in range(nt + 1)]
+    for f in [_pool.submit(fn, cuts[t], cuts[t + 1]) for t in range(nt)]:
+        f.result()
 
 
 def knnsearch(X, k, method=None, similarity='euclidean', dataset=None, metric='raw', device=None):
