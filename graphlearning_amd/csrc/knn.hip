@@ -1081,67 +1081,99 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
 }
 
 // ---- stage 3: exact fp64 fallback for flagged rows --------------------------------------------
-// k rounds of "smallest (dist, idx) lexicographically greater than the last one picked".  Every
-// round scans all refs; a flagged row's scan is split over FB_SPLIT workgroups (a single one would
-// read the whole data set k times: 50 ms per row at n = 1e7), a second kernel picks the round's
-// winner among the partial minima, writes it out and makes it the next round's lower bound.
+// A flagged row's refs are split over FB_SPLIT workgroups (a single one would read the whole data set k times: 50 ms per
+// row at n = 1e7); each finds the k smallest (dist, idx) of its piece by k rounds of "smallest pair lexicographically greater
+// than the last one picked", a second kernel merges the pieces' ascending lists.
 static const int FB_SPLIT = 64;
+static const int FB_CACHE = 2048;     // a piece of at most this many refs keeps its distances in LDS between the rounds
 
-__global__ __launch_bounds__(256) void knn_fallback_scan_kernel(const double* __restrict__ X, int64_t n, int d, int64_t q_begin,
-                                                                const int* __restrict__ rows, const double* __restrict__ last_d,
-                                                                const int* __restrict__ last_i, double* __restrict__ part_d,
-                                                                int* __restrict__ part_i, const int* __restrict__ orig) {
+// Piece `piece` of the refs, flagged row `row`: the k smallest (distance, index) of the piece in ascending order -- k rounds of
+// "smallest pair above the last one picked" INSIDE the kernel (round 2 launched a scan and a pick kernel per round: 2 k launches,
+// 0.3 ms for three rows at config 2, more than their arithmetic by two orders of magnitude).
+__global__ __launch_bounds__(256) void knn_fallback_piece_kernel(const double* __restrict__ X, int64_t n, int d, int k, int64_t q_begin,
+                                                                 const int* __restrict__ rows, double* __restrict__ part_d,
+                                                                 int* __restrict__ part_i, const int* __restrict__ orig) {
   __shared__ double s_d[256];
   __shared__ int s_i[256];
+  __shared__ double cache[FB_CACHE];
   const int row = blockIdx.x, piece = blockIdx.y;
   const int64_t ql = rows[row];
   const double* xq = X + (q_begin + ql) * d;
-  const double pd = last_d[row];
-  const int pi = last_i[row];
   const int64_t per = (n + FB_SPLIT - 1) / FB_SPLIT;
   const int64_t r0 = piece * per, r1 = min(n, r0 + per);
-  double bd = INFINITY;
-  int bi = 0x7fffffff;
-  for (int64_t ref = r0 + threadIdx.x; ref < r1; ref += 256) {
-    const double dd = sqdist_exact(xq, X + ref * d, d);
-    const int id = orig ? orig[ref] : (int)ref;
-    if (lex_less(pd, pi, dd, id) && lex_less(dd, id, bd, bi)) { bd = dd; bi = id; }
-  }
-  s_d[threadIdx.x] = bd;
-  s_i[threadIdx.x] = bi;
+  const bool cached = r1 - r0 <= FB_CACHE;
+  if (cached)
+    for (int64_t ref = r0 + threadIdx.x; ref < r1; ref += 256) cache[ref - r0] = sqdist_exact(xq, X + ref * d, d);
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off && lex_less(s_d[threadIdx.x + off], s_i[threadIdx.x + off], s_d[threadIdx.x], s_i[threadIdx.x])) {
-      s_d[threadIdx.x] = s_d[threadIdx.x + off];
-      s_i[threadIdx.x] = s_i[threadIdx.x + off];
+  double pd = -1.0;
+  int pi = -1;
+  for (int r = 0; r < k; ++r) {
+    double bd = INFINITY;
+    int bi = 0x7fffffff;
+    for (int64_t ref = r0 + threadIdx.x; ref < r1; ref += 256) {
+      const double dd = cached ? cache[ref - r0] : sqdist_exact(xq, X + ref * d, d);
+      const int id = orig ? orig[ref] : (int)ref;
+      if (lex_less(pd, pi, dd, id) && lex_less(dd, id, bd, bi)) { bd = dd; bi = id; }
     }
+    s_d[threadIdx.x] = bd;
+    s_i[threadIdx.x] = bi;
     __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    part_d[(size_t)row * FB_SPLIT + piece] = s_d[0];
-    part_i[(size_t)row * FB_SPLIT + piece] = s_i[0];
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off && lex_less(s_d[threadIdx.x + off], s_i[threadIdx.x + off], s_d[threadIdx.x], s_i[threadIdx.x])) {
+        s_d[threadIdx.x] = s_d[threadIdx.x + off];
+        s_i[threadIdx.x] = s_i[threadIdx.x + off];
+      }
+      __syncthreads();
+    }
+    pd = s_d[0];
+    pi = s_i[0];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      part_d[((size_t)row * FB_SPLIT + piece) * k + r] = pd;
+      part_i[((size_t)row * FB_SPLIT + piece) * k + r] = pi;
+    }
+    if (pi == 0x7fffffff) {               // the piece is exhausted: the remaining slots stay empty
+      for (int r2 = r + 1 + threadIdx.x; r2 < k; r2 += 256) {
+        part_d[((size_t)row * FB_SPLIT + piece) * k + r2] = INFINITY;
+        part_i[((size_t)row * FB_SPLIT + piece) * k + r2] = 0x7fffffff;
+      }
+      break;
+    }
   }
 }
 
-__global__ __launch_bounds__(64) void knn_fallback_pick_kernel(const double* __restrict__ part_d, const int* __restrict__ part_i,
-                                                               const int* __restrict__ rows, int nrows, int k, int r,
-                                                               double* __restrict__ last_d, int* __restrict__ last_i,
-                                                               int64_t* __restrict__ ind_out, double* __restrict__ dist_out,
-                                                               const int* __restrict__ orig, int64_t q_begin) {
-  const int row = blockIdx.x * 64 + threadIdx.x;
+// one wavefront per flagged row, lane p at the head of piece p's ascending list: k rounds of a lexicographic minimum over the lanes
+__global__ __launch_bounds__(64) void knn_fallback_merge_kernel(const double* __restrict__ part_d, const int* __restrict__ part_i,
+                                                                const int* __restrict__ rows, int nrows, int k,
+                                                                int64_t* __restrict__ ind_out, double* __restrict__ dist_out,
+                                                                const int* __restrict__ orig, int64_t q_begin) {
+  static_assert(FB_SPLIT == 64, "one lane per piece");
+  const int row = blockIdx.x, p = threadIdx.x;
   if (row >= nrows) return;
-  double bd = INFINITY;
-  int bi = 0x7fffffff;
-  for (int piece = 0; piece < FB_SPLIT; ++piece) {
-    const double dd = part_d[(size_t)row * FB_SPLIT + piece];
-    const int ii = part_i[(size_t)row * FB_SPLIT + piece];
-    if (lex_less(dd, ii, bd, bi)) { bd = dd; bi = ii; }
-  }
-  last_d[row] = bd;
-  last_i[row] = bi;
   const int64_t ql = orig ? (int64_t)orig[q_begin + rows[row]] - q_begin : rows[row];
-  ind_out[ql * k + r] = bi == 0x7fffffff ? -1 : bi;
-  dist_out[ql * k + r] = sqrt(bd);
+  int head = 0;
+  const size_t base = ((size_t)row * FB_SPLIT + p) * k;
+  double dd = part_d[base];
+  int ii = part_i[base];
+  for (int r = 0; r < k; ++r) {
+    double bd = dd;
+    int bi = ii;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double od = __shfl_xor(bd, off);
+      const int oi = __shfl_xor(bi, off);
+      if (lex_less(od, oi, bd, bi)) { bd = od; bi = oi; }
+    }
+    if (p == 0) {
+      ind_out[ql * k + r] = bi == 0x7fffffff ? -1 : bi;
+      dist_out[ql * k + r] = sqrt(bd);
+    }
+    if (bi != 0x7fffffff && dd == bd && ii == bi) {       // (indices are unique: exactly one lane holds the winner)
+      ++head;
+      dd = head < k ? part_d[base + head] : INFINITY;
+      ii = head < k ? part_i[base + head] : 0x7fffffff;
+    }
+  }
 }
 
 // features per half per block of the blocked (d > 130) variant; 16 where the KP = 64 lists leave less LDS
@@ -1180,8 +1212,8 @@ struct KnnBufs {
   // glx_knn_clustered: the rows reordered by cell (X points at the reordered copy), orig[position] = the caller's row
   double* Xraw = nullptr;
   int *orig = nullptr, *cell_id = nullptr;
-  int *cand_i = nullptr, *flags = nullptr, *rows = nullptr, *fb_li = nullptr, *fb_pi = nullptr, *gtau = nullptr;
-  double *fb_ld = nullptr, *fb_pd = nullptr;
+  int *cand_i = nullptr, *flags = nullptr, *rows = nullptr, *fb_pi = nullptr, *gtau = nullptr;
+  double* fb_pd = nullptr;
   int64_t* ind = nullptr;
   glx_work* work = nullptr;           // the device's cached stream + events
   hipStream_t stream = nullptr;
@@ -1191,7 +1223,7 @@ struct KnnBufs {
     glx_pool_free(Xb); glx_pool_free(Xq); glx_pool_free(nrm); glx_pool_free(part); glx_pool_free(rmax);
     glx_pool_free(X); glx_pool_free(mean); glx_pool_free(dist); glx_pool_free(Rf); glx_pool_free(Qf); glx_pool_free(qnorm); glx_pool_free(cand_d);
     glx_pool_free(runs); glx_pool_free(nruns); glx_pool_free(cell_starts); glx_pool_free(cen); glx_pool_free(rad); glx_pool_free(ub2); glx_pool_free(cpart); glx_pool_free(mask); glx_pool_free(visited); glx_pool_free(Xraw); glx_pool_free(orig); glx_pool_free(cell_id);
-    glx_pool_free(pre_d); glx_pool_free(pre_i); glx_pool_free(gtau); glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_li); glx_pool_free(fb_pi); glx_pool_free(fb_ld); glx_pool_free(fb_pd);
+    glx_pool_free(pre_d); glx_pool_free(pre_i); glx_pool_free(gtau); glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_pi); glx_pool_free(fb_pd);
     glx_work_release(work);
   }
 };
@@ -1655,22 +1687,14 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   if (!rows.empty()) {
     GLX_HIP(hipMemcpyAsync(b.rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
     const size_t nr = rows.size();
-    GLX_POOL(glx_pool_alloc((void**)&b.fb_ld, nr * 8));
-    GLX_POOL(glx_pool_alloc((void**)&b.fb_li, nr * 4));
-    GLX_POOL(glx_pool_alloc((void**)&b.fb_pd, nr * FB_SPLIT * 8));
-    GLX_POOL(glx_pool_alloc((void**)&b.fb_pi, nr * FB_SPLIT * 4));
-    std::vector<double> ld0(nr, -1.0);
-    std::vector<int> li0(nr, -1);
-    GLX_HIP(hipMemcpyAsync(b.fb_ld, ld0.data(), nr * 8, hipMemcpyHostToDevice, st));
-    GLX_HIP(hipMemcpyAsync(b.fb_li, li0.data(), nr * 4, hipMemcpyHostToDevice, st));
-    for (int r = 0; r < k; ++r) {
-      hipLaunchKernelGGL(knn_fallback_scan_kernel, dim3((unsigned)nr, FB_SPLIT), dim3(256), 0, st, (const double*)b.X, n, d, q0,
-                         (const int*)b.rows, (const double*)b.fb_ld, (const int*)b.fb_li, b.fb_pd, b.fb_pi, (const int*)b.orig);
-      hipLaunchKernelGGL(knn_fallback_pick_kernel, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, st, (const double*)b.fb_pd,
-                         (const int*)b.fb_pi, (const int*)b.rows, (int)nr, k, r, b.fb_ld, b.fb_li, b.ind, b.dist, (const int*)b.orig, q0);
-    }
+    GLX_POOL(glx_pool_alloc((void**)&b.fb_pd, nr * FB_SPLIT * k * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.fb_pi, nr * FB_SPLIT * k * 4));
+    hipLaunchKernelGGL(knn_fallback_piece_kernel, dim3((unsigned)nr, FB_SPLIT), dim3(256), 0, st, (const double*)b.X, n, d, k, q0, (const int*)b.rows,
+                       b.fb_pd, b.fb_pi, (const int*)b.orig);
+    hipLaunchKernelGGL(knn_fallback_merge_kernel, dim3((unsigned)nr), dim3(64), 0, st, (const double*)b.fb_pd, (const int*)b.fb_pi,
+                       (const int*)b.rows, (int)nr, k, b.ind, b.dist, (const int*)b.orig, q0);
     GLX_HIP(hipGetLastError());
-    GLX_HIP(hipStreamSynchronize(st));   // ld0 / li0 are read by the asynchronous copies above
+    GLX_HIP(hipStreamSynchronize(st));   // (`rows` is read by the asynchronous copy above)
   }
   GLX_HIP(hipEventRecord(b.e3, st));
   GLX_HIP(hipMemcpyAsync(ind_out, b.ind, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
