@@ -22,3 +22,14 @@ for mode in ('exact', 'tree'):
     t0 = time.perf_counter(); x, it, err = dev.cg(rhs, tol=1e-3); dt = time.perf_counter() - t0
     print('poisson CG 70k [%s reductions]: %d iterations in %.1f ms = %.0f it/s  (nnz*C*it/s = %.2e)' % (mode, it, dt * 1e3, it / dt, L.nnz * k * it / dt))
 os.environ.pop('GLX_CG_REDUCE', None)
+
+# ssl.laplace at config-3 shape (60 000 vertices, k = 20): the positive definite system, both reference-order sums per iteration
+rng = np.random.default_rng(3)
+lab3 = rng.integers(0, 10, size=60000)
+X3 = (rng.normal(size=(10, 32)) * 2.5)[lab3] + rng.normal(size=(60000, 32))
+W3 = gl.weightmatrix.knn(X3, 20)
+ti3 = gl.trainsets.generate(lab3, rate=10, seed=0)
+model = gl.ssl.laplace(W3)
+model.fit(ti3, lab3[ti3])
+t0 = time.perf_counter(); u = model.fit(ti3, lab3[ti3]); dt = time.perf_counter() - t0
+print('laplace 60k k=20 [exact reductions]: fit %.1f ms' % (dt * 1e3))
