@@ -235,3 +235,40 @@ def test_matrix_fingerprint_sees_in_place_edits(golden):
     i, j = 0, int(W2.indices[0])
     W2[i, j] = 0.123
     assert glutils.matrix_fingerprint(W2) != g0
+
+
+def test_gaussian_weight_blocks_and_auto_cells(monkeypatch):
+    """Host pieces of weightmatrix.knn added in round 3: numpy's exp over row blocks on host threads gives the bits of the one-call
+    expression (reference weightmatrix.py:144-150), and the policy that decides when the library forms cells for the search."""
+    from graphlearning_amd import weightmatrix as wm, _hip
+    rng = np.random.default_rng(5)
+    n, k = 50000, 11
+    d = np.sort(rng.random((n, k)), axis=1)
+    d[:, 0] = 0.0
+    J = rng.integers(0, n, size=(n, k))
+    D = d * d
+    ref_g = np.exp(-4 * D / D[:, k - 1][:, None])
+    eps = d[:, k - 1]
+    ref_s = np.exp(-4 * d * d / eps[:, None] / eps[J])
+    out_g, out_s = np.empty((n, k)), np.empty((n, k))
+
+    def rows_g(lo, hi):
+        Db = d[lo:hi] * d[lo:hi]
+        np.exp(-4 * Db / Db[:, k - 1][:, None], out=out_g[lo:hi])
+
+    def rows_s(lo, hi):
+        np.exp(-4 * d[lo:hi] * d[lo:hi] / eps[lo:hi, None] / eps[J[lo:hi]], out=out_s[lo:hi])
+    wm._row_blocks(rows_g, n)
+    wm._row_blocks(rows_s, n)
+    assert np.array_equal(out_g, ref_g) and np.array_equal(out_s, ref_s)
+    monkeypatch.setenv('GLX_HOST_THREADS', '1')
+    out_g[:] = 0
+    wm._row_blocks(rows_g, n)
+    assert np.array_equal(out_g, ref_g)
+    monkeypatch.delenv('GLX_KNN_CLUSTERED', raising=False)
+    assert _hip.auto_cells(70000, 20) == 0 and _hip.auto_cells(131072, 64) == 16 and _hip.auto_cells(10 ** 6, 64) == 122
+    assert _hip.auto_cells(10 ** 7, 64) == 256 and _hip.auto_cells(10 ** 6, 200) == 0
+    monkeypatch.setenv('GLX_KNN_CLUSTERED', '0')
+    assert _hip.auto_cells(10 ** 6, 64) == 0
+    monkeypatch.setenv('GLX_KNN_CLUSTERED', '48')
+    assert _hip.auto_cells(1000, 3) == 48
