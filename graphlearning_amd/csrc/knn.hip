@@ -1125,7 +1125,10 @@ static const int FB_CACHE = 2048;     // a piece of at most this many refs keeps
 // 0.3 ms for three rows at config 2, more than their arithmetic by two orders of magnitude).
 __global__ __launch_bounds__(256) void knn_fallback_piece_kernel(const double* __restrict__ X, int64_t n, int d, int k, int64_t q_begin,
                                                                  const int* __restrict__ rows, double* __restrict__ part_d,
-                                                                 int* __restrict__ part_i, const int* __restrict__ orig) {
+                                                                 int* __restrict__ part_i, const int* __restrict__ orig,
+                                                                 const int* __restrict__ runs, const int* __restrict__ nruns, int maxruns, int BR) {
+  // runs (the cell-pruned search): the refs are those of the tile runs of the row's query block -- everything else is strictly
+  // farther than the row's k-th neighbour (knn_cellmask_kernel) -- cut into FB_SPLIT pieces of equally many tiles
   __shared__ double s_d[256];
   __shared__ int s_i[256];
   __shared__ double cache[FB_CACHE];
@@ -1133,7 +1136,21 @@ __global__ __launch_bounds__(256) void knn_fallback_piece_kernel(const double* _
   const int64_t ql = rows[row];
   const double* xq = X + (q_begin + ql) * d;
   const int64_t per = (n + FB_SPLIT - 1) / FB_SPLIT;
-  const int64_t r0 = piece * per, r1 = min(n, r0 + per);
+  int64_t r0 = piece * per, r1 = min(n, r0 + per);
+  const int* rr = nullptr;
+  int nr = 0;
+  int64_t t_lo = 0, t_hi = 0;
+  if (runs) {
+    const int64_t qb = ql / BQ;
+    rr = runs + qb * 2 * (int64_t)maxruns;
+    nr = nruns[qb];
+    int64_t tv = 0;
+    for (int r = 0; r < nr; ++r) tv += rr[2 * r + 1] - rr[2 * r];
+    t_lo = tv * piece / FB_SPLIT;
+    t_hi = tv * (piece + 1) / FB_SPLIT;
+    r0 = 0;
+    r1 = (int64_t)FB_CACHE + 1;                       // (no distance cache on this path)
+  }
   const bool cached = r1 - r0 <= FB_CACHE;
   if (cached)
     for (int64_t ref = r0 + threadIdx.x; ref < r1; ref += 256) cache[ref - r0] = sqdist_exact(xq, X + ref * d, d);
@@ -1143,10 +1160,22 @@ __global__ __launch_bounds__(256) void knn_fallback_piece_kernel(const double* _
   for (int r = 0; r < k; ++r) {
     double bd = INFINITY;
     int bi = 0x7fffffff;
-    for (int64_t ref = r0 + threadIdx.x; ref < r1; ref += 256) {
-      const double dd = cached ? cache[ref - r0] : sqdist_exact(xq, X + ref * d, d);
+    auto look = [&](int64_t ref, double dd) {
       const int id = orig ? orig[ref] : (int)ref;
       if (lex_less(pd, pi, dd, id) && lex_less(dd, id, bd, bi)) { bd = dd; bi = id; }
+    };
+    if (runs) {
+      int64_t off = 0;                                // tiles of the runs in front of run q
+      for (int q = 0; q < nr; ++q) {
+        const int64_t a = rr[2 * q], b = rr[2 * q + 1];
+        const int64_t lo = max(a, a + (t_lo - off)), hi = min(b, a + (t_hi - off));
+        off += b - a;
+        if (lo >= hi) continue;
+        const int64_t s0 = lo * BR, s1 = min(n, hi * BR);
+        for (int64_t ref = s0 + threadIdx.x; ref < s1; ref += 256) look(ref, sqdist_exact(xq, X + ref * d, d));
+      }
+    } else {
+      for (int64_t ref = r0 + threadIdx.x; ref < r1; ref += 256) look(ref, cached ? cache[ref - r0] : sqdist_exact(xq, X + ref * d, d));
     }
     s_d[threadIdx.x] = bd;
     s_i[threadIdx.x] = bi;
@@ -1722,8 +1751,9 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     const size_t nr = rows.size();
     GLX_POOL(glx_pool_alloc((void**)&b.fb_pd, nr * FB_SPLIT * k * 8));
     GLX_POOL(glx_pool_alloc((void**)&b.fb_pi, nr * FB_SPLIT * k * 4));
+    // (b.runs: the main pass's runs when the search was cell-pruned -- the pre-pass's were overwritten by them)
     hipLaunchKernelGGL(knn_fallback_piece_kernel, dim3((unsigned)nr, FB_SPLIT), dim3(256), 0, st, (const double*)b.X, n, d, k, q0, (const int*)b.rows,
-                       b.fb_pd, b.fb_pi, (const int*)b.orig);
+                       b.fb_pd, b.fb_pi, (const int*)b.orig, (const int*)(b.visited ? b.runs : nullptr), (const int*)b.nruns, b.maxruns, BR);
     hipLaunchKernelGGL(knn_fallback_merge_kernel, dim3((unsigned)nr), dim3(64), 0, st, (const double*)b.fb_pd, (const int*)b.fb_pi,
                        (const int*)b.rows, (int)nr, k, b.ind, b.dist, (const int*)b.orig, q0);
     GLX_HIP(hipGetLastError());
