@@ -291,3 +291,42 @@ def test_random_knn_searches_match_ckdtree(gl, orc, seed):
             cols = np.flatnonzero(J[i] != Jo[i])
             assert np.all(np.abs(Do[i, cols] - D[i, cols]) <= 1e-12 * scale), (tag, i)
         assert len(bad) <= max(1, n // 1000), (tag, len(bad))
+
+
+@pytest.mark.parametrize('seed', range(16 * _SCALE))
+def test_random_clustered_searches_match_all_pairs(gl, seed):
+    """glx_knn_clustered / glx_knn_cells_range over random shapes -- n = 300 .. 40 000, d = 1 .. 128, k = 1 .. 60, 2 .. 300 cells,
+    clustered / isotropic / offset / duplicated data, whole set or a query sub-range with the caller's cells -- against the all-pairs
+    search: identical lists and distances, bit for bit."""
+    from graphlearning_amd import _hip, dist_build
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([300, 1000, 4097, 12000, 40000]))
+    d = int(rng.choice([1, 2, 3, 8, 16, 17, 20, 21, 32, 48, 64, 100, 128]))
+    k = int(rng.choice([1, 2, 11, 12, 13, 28, 29, 60]))
+    m = int(min(n // 4, rng.choice([2, 3, 16, 64, 300])))
+    style = int(rng.integers(0, 4))
+    if style == 0:
+        X = rng.normal(size=(n, d))
+    elif style == 1:
+        C = int(rng.integers(2, 12))
+        X = rng.normal(size=(C, d))[rng.integers(0, C, size=n)] * 5.0 + rng.normal(size=(n, d))
+    elif style == 2:
+        X = rng.normal(size=(n, d)) * 0.01 + 1000.0                           # far from the origin, tiny distances
+    else:
+        base = rng.normal(size=(max(n // 5, k + 1), d))
+        X = base[rng.integers(0, len(base), size=n)]                          # every point several times: ties everywhere
+    tag = 'seed %d: n=%d d=%d k=%d cells=%d style=%d' % (seed, n, d, k, m, style)
+    J0, D0 = _hip.knn_bruteforce(X, k, clustered=0)
+    J0, D0 = np.array(J0), np.array(D0)
+    J1, D1 = _hip.knn_bruteforce(X, k, clustered=m)
+    assert np.array_equal(J0, J1) and np.array_equal(D0, D1), tag
+    if seed % 2 == 0:        # the caller's own cells and a query sub-range
+        perm, starts = dist_build.coarse_locality_order(X, ncells=m, seed=seed, return_cells=True)
+        Xp = np.ascontiguousarray(X[perm])
+        q0, q1 = sorted(int(v) for v in rng.integers(0, n + 1, size=2))
+        if q0 == q1:
+            q0, q1 = 0, n
+        Ja, Da = _hip.knn_bruteforce(Xp, k, query_range=(q0, q1))
+        Ja, Da = np.array(Ja), np.array(Da)
+        Jb, Db = _hip.knn_bruteforce(Xp, k, query_range=(q0, q1), cell_starts=starts)
+        assert np.array_equal(Ja, Jb) and np.array_equal(Da, Db), tag + ' range %d:%d' % (q0, q1)
