@@ -267,6 +267,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef KNN_GROUP_GUARD
 #define KNN_GROUP_GUARD 1          // measured: 438 -> 394 ms
 #endif
+#ifndef KNN_REGL2
+#define KNN_REGL2 0                 // the same for two feature blocks (d = 17 .. 32): see the note at bf16_nstg
+#endif
 #ifndef KNN_REGLISTS
 #define KNN_REGLISTS 1              // 8-entry lists live in registers (LDS then holds tile + append slots only: a fourth workgroup per CU)
 #endif
@@ -379,7 +382,7 @@ __global__ void knn_prep_bf16_cat_kernel(const double* __restrict__ X, const dou
 // CAT (NKB = 2 only): the rows are the concatenated operands above, refs from Xb, queries from Xq.
 // NSTG: sub-tiles of 32 NSUB refs staged (and synchronised) together (an experiment that did not pay, see bf16_nstg)
 template <int NKB, int KP, int NSUB, int CAT = 0, bool RUNS = false, int NSTG = 1>   // CAT: 1 concatenated operands, 2 also the norm folded into them
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLISTS && KP == 8 && NKB == 4) ? 4 : 1, 4))) void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned short* __restrict__ Xq, const float* __restrict__ nrm, int64_t n,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLISTS && KP == 8 && (NKB == 4 || (KNN_REGL2 && NKB == 2))) ? 4 : 1, 4))) void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned short* __restrict__ Xq, const float* __restrict__ nrm, int64_t n,
                                                             int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d,
                                                             int* __restrict__ cand_i, int* __restrict__ gtau, const int* __restrict__ runs,
                                                             const int* __restrict__ nruns, int maxruns) {
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
   float* rn = (float*)(smem_b + 2 * BR * ROWB);         // [2][BR]
   // 8-entry lists in registers where that buys a fourth workgroup per CU (d = 49 .. 64: 122 registers, 34 KB of LDS; measured
   // +4 % at n = 3e5 .. 1e6; at fewer feature blocks the registers spill, at more the kernel is register-bound anyway)
-  constexpr bool REGL = KNN_REGLISTS && KP == 8 && NKB == 4;   // LDS rows [KP, KP + KBUF) are the append slots either way
+  constexpr bool REGL = KNN_REGLISTS && KP == 8 && (NKB == 4 || (KNN_REGL2 && NKB == 2));   // LDS rows [KP, KP + KBUF) are the append slots either way
   constexpr int LROWS = REGL ? KBUF : KP + KBUF;
   float* ld = rn + 2 * BR - (REGL ? KP * 256 : 0);      // [KP + KBUF][256] (rows [0, KP) do not exist with register lists)
   int* li = (int*)(rn + 2 * BR + LROWS * 256) - (REGL ? KP * 256 : 0);
@@ -1385,7 +1388,7 @@ static int launch_tile_bf16(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1,
   constexpr int NSTG = bf16_nstg(NKB, KP);
   constexpr int BR = 32 * NSUB * NSTG;
   constexpr int ROWB = 4 * 16 * NKB + 16;
-  const size_t shm = (size_t)2 * BR * ROWB + (size_t)2 * BR * 4 + (size_t)((KNN_REGLISTS && KP == 8 && NKB == 4) ? KBUF : KP + KBUF) * 256 * 8;
+  const size_t shm = (size_t)2 * BR * ROWB + (size_t)2 * BR * 4 + (size_t)((KNN_REGLISTS && KP == 8 && (NKB == 4 || (KNN_REGL2 && NKB == 2))) ? KBUF : KP + KBUF) * 256 * 8;
   GLX_CHECK(shm <= 160 * 1024, GLX_EUNSUPPORTED, "glx_knn_bruteforce: bf16 filter needs %zu bytes of LDS", shm);
   const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)(seed ? 1 : nsplit));
   if (b.runs) {
