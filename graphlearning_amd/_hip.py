@@ -129,6 +129,8 @@ _SIGNATURES = {
                        C.POINTER(_vp), _i64p, C.c_int],
     'glx_knn_rows_to_csr': [_vp, _vp, C.c_int64, C.c_int, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp, _vp, _vp,
                             _i64p, C.c_int],
+    'glx_host_locality_order': [C.c_int64, _vp, _vp, C.c_int64, _vp],
+    'glx_host_permute_rows': [C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'glx_host_row_sums': [C.c_int64, _vp, _vp, _vp],
     'glx_host_reverse_scale_rows': [C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp],
     'glx_knn_to_csr_into': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, _i64p, C.c_int],
@@ -834,6 +836,31 @@ def knn_rows_to_csr(J_own, w_own, n_cols, row_base, rev_row, rev_src, rev_pos, r
     W.has_sorted_indices = True
     W.has_canonical_format = True
     return W
+
+
+def host_locality_order(indptr, indices, col_lo=0):
+    """perm[new] = old: the library's breadth-first locality order of an n-row pattern restricted to columns [col_lo, col_lo + n)."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    n = len(indptr) - 1
+    perm = np.empty(n, dtype=np.int32)
+    check(load().glx_host_locality_order(n, _ptr(indptr), _ptr(indices), int(col_lo), _ptr(perm)), 'glx_host_locality_order')
+    return perm
+
+
+def host_permute_rows(A, perm):
+    """csr_matrix with row i = row perm[i] of A (entry order inside the rows kept), on host threads."""
+    from scipy import sparse
+    indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+    data = np.ascontiguousarray(A.data, dtype=np.float64)
+    perm = np.ascontiguousarray(perm, dtype=np.int64)
+    n = len(indptr) - 1
+    ip, ix, dv = np.empty(n + 1, dtype=np.int32), np.empty(len(indices), dtype=np.int32), np.empty(len(data), dtype=np.float64)
+    check(load().glx_host_permute_rows(n, _ptr(indptr), _ptr(indices), _ptr(data), _ptr(perm), _ptr(ip), _ptr(ix), _ptr(dv)), 'glx_host_permute_rows')
+    out = sparse.csr_matrix((dv, ix, ip), shape=A.shape)
+    out.has_sorted_indices = A.has_sorted_indices
+    return out
 
 
 def knn_stats():

@@ -366,7 +366,10 @@ def main_config4(args):
     t_cut = time.perf_counter() - t0
     progress('block boundaries %s' % [int(b) for b in bounds])
     t0 = time.perf_counter()
-    sg = dist_build.ShardedGraph(dist, n, J, D, K, device=dev, bounds=bounds)
+    # (GLX_CONFIG4_LOCAL_ORDER=rcm: a rank's rows in the library's breadth-first order of their links among themselves.  Measured: no
+    # gain over the chained cells of the coarse order -- 253 us per sweep at 10^6 rows either way -- for 3 s more set-up at 10^7)
+    local_order = os.environ.get('GLX_CONFIG4_LOCAL_ORDER', 'block')
+    sg = dist_build.ShardedGraph(dist, n, J, D, K, device=dev, bounds=bounds, local_order=local_order)
     del J, D
     train_ind = gl.trainsets.generate(labels, rate=5, seed=0)
     prob = sg.poisson_problem_rows(train_ind, labels[train_ind])
@@ -422,7 +425,7 @@ def main_config4(args):
             'partition': {'kind': partition if world > 1 else 'one block', 'bounds': [int(b) for b in bounds]},
             'build': {'features_s': t_feat, 'locality_order_s': t_order, 'knn_own_rows_s': t_knn, 'cut_and_redistribute_s': t_cut,
                       'host_work_note': 'features: every rank generates n/N rows; order: on the device; search: n/N query rows; symmetrisation and plan: the rank\'s own rows', 'knn_tile_tflops_rank0': 2.0 * (hi - lo) * n * st['dpa'] / st['tile_ms'] / 1e9,
-                      'knn_search': 'all pairs' if knn_cells is None else 'cell-pruned (%d cells)' % st['cells'], 'knn_tile_s': st['tile_ms'] / 1e3,
+                      'local_order': local_order, 'knn_search': 'all pairs' if knn_cells is None else 'cell-pruned (%d cells)' % st['cells'], 'knn_tile_s': st['tile_ms'] / 1e3,
                       'symmetrise_plan_s': t_build},
             'accuracy_percent': 100.0 * int(hit[0]) / max(int(hit[1]), 1),
             'rccl_ranks': comm.info()['nranks'], 'rccl_owner': 'libglx' if comm.has_transport() else 'none (one rank)', 'engine': 'glx',

@@ -62,6 +62,13 @@ int glx_host_row_sums(int64_t n, const int32_t* rowptr, const double* val, doubl
 int glx_host_reverse_scale_rows(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val,
                                 const double* scale, int32_t* col_out, double* val_out);
 
+/* host helpers of the sharded build: the library's locality order (perm_out[new] = old, the breadth-first pass glx_graph uses for
+ * square operators) of an n-row pattern restricted to the columns [col_lo, col_lo + n) -- a rank orders its own rows by their links
+ * among themselves --, and the rows of a CSR matrix in another order (row i of the result = row perm[i], entry order kept). */
+int glx_host_locality_order(int64_t n, const int32_t* rowptr, const int32_t* col, int64_t col_lo, int32_t* perm_out);
+int glx_host_permute_rows(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val, const int64_t* perm,
+                          int32_t* rowptr_out, int32_t* col_out, double* val_out);
+
 /* page-locked host memory for result arrays (a D2H copy into pageable memory is staged and several times slower;
  * the Python boundary recycles these blocks as the backing store of the numpy arrays it returns) */
 int glx_host_alloc(size_t bytes, void** out);

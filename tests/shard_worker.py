@@ -20,6 +20,7 @@ def main():
     case, out_path = sys.argv[1], sys.argv[2]
     engine = sys.argv[3] if len(sys.argv) > 3 else 'ops'      # 'glxstep': rank-local pieces by libglx on cuda:0, gloo as the transport
     partition = sys.argv[4] if len(sys.argv) > 4 else 'even'   # 'cut': blocks that follow the graph (dist_build.graph_cut_bounds) + redistributed lists
+    local_order = sys.argv[5] if len(sys.argv) > 5 else 'block'  # 'rcm': a rank's rows in the library's breadth-first order (ShardPlan)
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     from conftest import blobs
@@ -74,7 +75,7 @@ def main():
         cut_info = dict(moved_ok=bool(np.array_equal(J_own, J[lo:hi]) and np.array_equal(D_own, D[lo:hi])), bounds=[int(b) for b in bounds],
                         crossing=cross, crossing_even=cross_even)
     u, T, sg = dist_build.poisson_fit_sharded(dist, n, J_own, D_own, k, ti, tl, engine=engine, ops_factory=lambda plan, C: ScipyOps(plan, C),
-                                             min_iter=min_iter, max_iter=max_iter, kernel=kernel, device=0, bounds=bounds)
+                                             min_iter=min_iter, max_iter=max_iter, kernel=kernel, device=0, bounds=bounds, local_order=local_order)
     # oracle: the whole pipeline in one process
     W = orc.knn_weights(J, D, k, kernel=kernel)
     W.sort_indices()
@@ -90,7 +91,23 @@ def main():
     # the plan equals the one the global planner derives for the same blocks
     ref_plan = gdist.RankPlan(s['P'], np.arange(n), bounds, rank)
     pl = sg.plan
-    plan_ok = (np.array_equal(pl.own, ref_plan.own) and np.array_equal(pl.halo, ref_plan.halo) and pl.send_counts == ref_plan.send_counts
+    if local_order != 'block':      # another order of the rank's rows: the same SETS of boundary / interior rows, every row intact
+        nb = pl.n_boundary
+        inv = np.empty(hi - lo, dtype=np.int64)
+        inv[pl.own - lo] = np.arange(hi - lo)
+        rows_ok = True
+        Pl = sparse.csr_matrix(pl.P_local)
+        glob = np.concatenate([pl.own, pl.halo])
+        for g_row in np.random.default_rng(1).integers(lo, hi, size=min(200, hi - lo)):
+            r = inv[g_row - lo]
+            a, b = Pl.indptr[r], Pl.indptr[r + 1]
+            a0, b0 = Pb.indptr[g_row - lo], Pb.indptr[g_row - lo + 1]
+            rows_ok = rows_ok and np.array_equal(glob[Pl.indices[a:b]], Pb.indices[a0:b0]) and np.array_equal(Pl.data[a:b], Pb.data[a0:b0])
+        plan_ok = (set(pl.own[:nb]) == set(ref_plan.own[:nb]) and set(pl.own) == set(ref_plan.own) and np.array_equal(pl.halo, ref_plan.halo)
+                   and pl.send_counts == ref_plan.send_counts and pl.recv_counts == ref_plan.recv_counts and pl.n_boundary == ref_plan.n_boundary
+                   and np.array_equal(np.sort(pl.own[pl.send_idx]), np.sort(ref_plan.own[ref_plan.send_idx])) and rows_ok)
+    else:
+      plan_ok = (np.array_equal(pl.own, ref_plan.own) and np.array_equal(pl.halo, ref_plan.halo) and pl.send_counts == ref_plan.send_counts
                and pl.recv_counts == ref_plan.recv_counts and np.array_equal(pl.send_idx, ref_plan.send_idx)
                and pl.n_boundary == ref_plan.n_boundary and pl.global_halo == ref_plan.global_halo
                and np.array_equal(pl.P_local.indices, ref_plan.P_local.indices) and np.array_equal(pl.P_local.data, ref_plan.P_local.data)

@@ -183,6 +183,47 @@ def test_sharded_build_with_graph_cuts(case, world, tmp_path):
         assert 20 * sum(res[0]['crossing']) <= sum(res[0]['crossing_even']), res
 
 
+@pytest.mark.parametrize('case,world,partition', [('blobs', 3, 'even'), ('random3', 2, 'even'), ('blobs', 2, 'cut')])
+def test_sharded_build_with_local_row_order(case, world, partition, tmp_path):
+    """ShardPlan(local_order='rcm'): every rank puts its boundary rows and its interior rows in the library's breadth-first order
+    of the block (glx_host_locality_order + glx_host_permute_rows -- host code of libglx, no GPU).  The SETS of boundary and
+    interior rows, the halo, the counts and every row of P are those of the reference plan, and the iterates of the distributed
+    sweep stay bit-identical to the single-process pipeline."""
+    out = str(tmp_path / ('shardrcm_' + case))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'shard_worker.py'), case, out, 'ops', partition, 'rcm']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = [json.load(open(out + '.%d' % k)) for k in range(world)]
+    for q in res:
+        assert q['w_ok'] and q['p_ok'] and q['deg_ok'] and q['plan_ok'], q
+        assert q['T'] == q['T_ref'] and q['equal'], q
+
+
+def test_host_locality_order_and_row_permutation():
+    """The two host helpers alone: the order is a permutation that keeps linked rows close (a path graph comes out as a path), rows
+    are moved whole with their entry order."""
+    from scipy import sparse
+    from graphlearning_amd import _hip
+    n = 5000
+    rng = np.random.default_rng(0)
+    shuffle = rng.permutation(n)                       # a path 0-1-2-...-(n-1) under a random relabelling
+    i = np.concatenate([shuffle[:-1], shuffle[1:]])
+    j = np.concatenate([shuffle[1:], shuffle[:-1]])
+    A = sparse.csr_matrix((rng.random(len(i)) + 0.1, (i, j)), shape=(n, n))
+    perm = _hip.host_locality_order(A.indptr, A.indices)
+    assert sorted(perm.tolist()) == list(range(n))
+    pos = np.empty(n, dtype=np.int64)
+    pos[perm] = np.arange(n)
+    assert np.max(np.abs(pos[i] - pos[j])) <= 2        # linked rows end up next to each other (breadth-first from an end of the path)
+    B = _hip.host_permute_rows(A, perm)
+    C2 = sparse.csr_matrix(A[perm, :])
+    assert np.array_equal(B.indptr, C2.indptr) and np.array_equal(B.indices, C2.indices) and np.array_equal(B.data, C2.data)
+    # columns outside [col_lo, col_lo + n) are ignored: the same pattern shifted by 100 columns plus halo columns
+    R = sparse.csr_matrix((A.data, A.indices + 100, A.indptr), shape=(n, n + 300))
+    assert np.array_equal(_hip.host_locality_order(R.indptr, R.indices, col_lo=100), perm)
+
+
 def test_sharded_planner_scales_per_rank():
     """n = 10^6, 8 ranks, k = 10 (random lists): building ONE rank's rows, operator and plan touches O(n/N) graph data --
     bounded time and memory -- and the pieces are consistent (what rank a requests from b is what b sends to a)."""
