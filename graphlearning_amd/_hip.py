@@ -124,6 +124,7 @@ _SIGNATURES = {
     'glx_knn_bruteforce_range': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
     'glx_knn_cells_range': [_vp, C.c_int64, C.c_int, C.c_int, _vp, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
     'glx_knn_clustered': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
+    'glx_knn_last_order': [C.c_int64, _vp],
     'glx_knn_stats': [_f64p],
     'glx_knn_to_csr': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                        C.POINTER(_vp), _i64p, C.c_int],
@@ -861,6 +862,14 @@ def host_permute_rows(A, perm):
     out = sparse.csr_matrix((dv, ix, ip), shape=A.shape)
     out.has_sorted_indices = A.has_sorted_indices
     return out
+
+
+def knn_last_order(n):
+    """perm[position] = row in the cell order of the last clustered search over n rows, or None."""
+    perm = np.empty(int(n), dtype=np.int32)
+    if load().glx_knn_last_order(int(n), _ptr(perm)) != 0:
+        return None
+    return perm
 
 
 def knn_stats():

@@ -18,11 +18,17 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static double g_knn_stats[16];
+// the row order of the last glx_knn_clustered search (perm[position] = caller's row; cells contiguous, neighbouring cells chained): a
+// locality order of the vertices that whoever builds an operator on the graph can hand to glx_graph_set_order instead of the
+// library's pass over the graph
+static std::vector<int32_t> g_knn_last_order;
+static std::mutex g_knn_order_mu;
 extern "C" int glx_knn_stats(double stats[16]) {
   GLX_CHECK(stats, GLX_EINVAL, "glx_knn_stats: null output");
   for (int i = 0; i < 16; ++i) stats[i] = g_knn_stats[i];
@@ -1554,6 +1560,32 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     std::vector<int> cid(n), perm(n);
     GLX_HIP(hipMemcpyAsync(cid.data(), b.cell_id, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     GLX_HIP(hipStreamSynchronize(st));
+    // the cells in a chain of nearest centres (greedy, from the centre farthest from the centres' mean): neighbouring cells of
+    // feature space end up next to each other in the row order, which then serves as a locality order for the graph's operators
+    // too (one XCD's share of the rows = a few whole clusters; with the cells in arbitrary order the sweep at 10^6 rows ran 20 % slower)
+    {
+      std::vector<double> cen((size_t)m * d);
+      GLX_HIP(hipMemcpyAsync(cen.data(), b.cen, (size_t)m * d * 8, hipMemcpyDeviceToHost, st));
+      GLX_HIP(hipStreamSynchronize(st));
+      std::vector<double> mean(d, 0.0);
+      for (int c = 0; c < m; ++c)
+        for (int f = 0; f < d; ++f) mean[f] += cen[(size_t)c * d + f] / m;
+      auto dist2 = [&](const double* a, const double* bb) { double t = 0; for (int f = 0; f < d; ++f) { const double q = a[f] - bb[f]; t += q * q; } return t; };
+      int cur = 0;
+      double far = -1.0;
+      for (int c = 0; c < m; ++c) { const double t = dist2(&cen[(size_t)c * d], mean.data()); if (t > far) { far = t; cur = c; } }
+      std::vector<int> place(m, -1);
+      for (int pos = 0; pos < m; ++pos) {
+        place[cur] = pos;
+        int nxt = -1;
+        double best = INFINITY;
+        for (int c = 0; c < m; ++c)
+          if (place[c] < 0) { const double t = dist2(&cen[(size_t)c * d], &cen[(size_t)cur * d]); if (t < best) { best = t; nxt = c; } }
+        if (nxt < 0) break;
+        cur = nxt;
+      }
+      for (int64_t i = 0; i < n; ++i) cid[i] = place[cid[i]];
+    }
     own_starts.assign(m, 0);
     std::vector<int64_t> fill(m + 1, 0);
     for (int64_t i = 0; i < n; ++i) ++fill[cid[i] + 1];
@@ -1561,6 +1593,10 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     for (int c = 0; c < m; ++c) own_starts[c] = fill[c];
     for (int64_t i = 0; i < n; ++i) perm[fill[cid[i]]++] = (int)i;       // stable: ascending caller index inside a cell
     GLX_HIP(hipMemcpyAsync(b.orig, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    {
+      std::lock_guard<std::mutex> lk(g_knn_order_mu);
+      g_knn_last_order.assign(perm.begin(), perm.end());
+    }
     b.Xraw = b.X;
     b.X = nullptr;
     GLX_POOL(glx_pool_alloc((void**)&b.X, (size_t)n * d * 8));
@@ -1829,4 +1865,15 @@ extern "C" int glx_knn_cells_range(const double* X, int64_t n, int d, int k, con
 extern "C" int glx_knn_clustered(const double* X, int64_t n, int d, int k, int ncells, int64_t* ind_out, double* dist_out, int device) {
   GLX_CHECK(ncells >= 0 && ncells <= 4096, GLX_EINVAL, "glx_knn_clustered: ncells=%d outside [0, 4096]", ncells);
   return knn_run(X, n, d, k, 0, n, ind_out, dist_out, device, nullptr, 0, ncells);
+}
+
+// perm_out[position] = caller's row in the cell order of the last glx_knn_clustered search over n rows (GLX_EINVAL if there is none
+// of that size): contiguous, chained cells of feature space -- on clustered data as good a locality order for the graph's operators
+// as the library's own pass over the graph (glx_graph_set_order), and free.
+extern "C" int glx_knn_last_order(int64_t n, int32_t* perm_out) {
+  GLX_CHECK(perm_out, GLX_EINVAL, "glx_knn_last_order: null output");
+  std::lock_guard<std::mutex> lk(g_knn_order_mu);
+  GLX_CHECK((int64_t)g_knn_last_order.size() == n && n > 0, GLX_EINVAL, "glx_knn_last_order: no clustered search over %lld rows on record", (long long)n);
+  memcpy(perm_out, g_knn_last_order.data(), (size_t)n * 4);
+  return GLX_OK;
 }

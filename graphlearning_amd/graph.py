@@ -12,6 +12,8 @@ class graph:
         self.weight_matrix = sparse.csr_matrix(W)
         if getattr(W, '_glx_sym', None) is not None:
             self.weight_matrix._glx_sym = W._glx_sym      # valid only while the wrapper shares W's arrays: utils.known_symmetric compares addresses
+        if getattr(W, '_glx_order', None) is not None:
+            self.weight_matrix._glx_order = W._glx_order    # (a vertex order stays valid whatever happens to the values)
         self.labels = labels
         self.features = features
         self.num_nodes = W.shape[0]

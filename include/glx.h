@@ -329,6 +329,10 @@ int glx_knn_cells_range(const double* X, int64_t n, int d, int k, const int64_t*
  * pruning of glx_knn_cells_range.  Indices and output rows are the caller's, equal distances go to the lower caller index: the
  * lists of glx_knn_bruteforce bit for bit. */
 int glx_knn_clustered(const double* X, int64_t n, int d, int k, int ncells, int64_t* ind_out, double* dist_out, int device);
+/* perm_out[position] = caller's row in the cell order of the last glx_knn_clustered search over n rows (GLX_EINVAL: none of that
+ * size on record): contiguous cells of feature space, neighbouring cells chained -- a locality order of the vertices for
+ * glx_graph_set_order that costs nothing. */
+int glx_knn_last_order(int64_t n, int32_t* perm_out);
 int glx_knn_stats(double stats[16]);  /* of the last search: [0] tile-kernel ms, [1] re-rank ms, [2] fallback rows, [3] total device ms,
                                         [4] fallback ms, [5] padded feature count, [6] ref ranges, [7] list length (negative: bf16 filter),
                                         [8] rows the short lists could not accept when the search was repeated with long ones (else 0);

@@ -366,3 +366,25 @@ def test_knn_clustered_identical_to_all_pairs(gl, case, monkeypatch):
     if case in ('blobs64', 'k26_d32'):
         assert st['visited_share'] < 0.5, st
     assert _hip.auto_cells(70000, 20) == 0 and _hip.auto_cells(1000000, 64) == 122 and _hip.auto_cells(10 ** 7, 64) == 256
+
+
+def test_clustered_search_hands_its_cell_order_to_the_operator(gl, monkeypatch):
+    """From 2^17 rows on weightmatrix.knn searches with cells it forms itself and leaves their (chained) order on the matrix; ssl.poisson
+    gives it to the device operator instead of the library's own pass over the graph.  The order is a permutation, and nothing
+    about the results depends on it: the fit equals the one on a matrix without the order, bit for bit."""
+    X, lab = blobs(140000, 16, 6, 11, 5.0)
+    W = gl.weightmatrix.knn(X, 10)
+    order = getattr(W, '_glx_order', None)
+    assert order is not None and sorted(order.tolist()) == list(range(len(X)))
+    ti = gl.trainsets.generate(lab, rate=3, seed=1)
+    m1 = gl.ssl.poisson(W, solver='gradient_descent')
+    u1 = m1.fit(ti, lab[ti])
+    assert m1._operators()[0].info()['renumbered'] == 1
+    monkeypatch.setenv('GLX_KNN_ORDER', '0')
+    W2 = gl.weightmatrix.knn(X, 10)
+    assert getattr(W2, '_glx_order', None) is None
+    assert np.array_equal(W.indptr, W2.indptr) and np.array_equal(W.indices, W2.indices) and np.array_equal(W.data, W2.data)
+    m2 = gl.ssl.poisson(W2, solver='gradient_descent')
+    u2 = m2.fit(ti, lab[ti])
+    assert m1.num_iter == m2.num_iter and np.array_equal(u1, u2)
+    assert not np.array_equal(m1._operators()[0].order(), m2._operators()[0].order())     # (two different vertex orders were in use)
