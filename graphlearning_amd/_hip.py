@@ -739,7 +739,16 @@ def auto_cells(n, d):
         return max(0, int(e))
     if n < (1 << 17) or d > 128:
         return 0
-    return int(min(256, max(16, n // 8192)))
+    return int(min(256, max(64, n // 8192)))      # (>= 64: the cells' order also serves as the vertex order of the graph's operators)
+
+
+def auto_order_cells(n, d):
+    """Below the size of the clustered search: how many cells the all-pairs search works out an ORDER for on the side (the
+    operators on the graph take it instead of their own pass over the graph: 3.7 ms at 70 000 vertices, and the sweep is a
+    per cent faster on it).  GLX_KNN_ORDER=0 turns it off."""
+    if os.environ.get('GLX_KNN_ORDER', '1') == '0' or n < 4096 or n >= (1 << 17) or d > 128:
+        return 0
+    return int(min(128, n // 64))     # (measured at 70 000 x 20: 128 cells = the library's order to 0.5 %, 64 and 32 cells 0.5-1 % behind)
 
 
 def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, cell_starts=None, clustered=None):
@@ -764,7 +773,9 @@ def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, 
               'glx_knn_cells_range')
         return ind, dist
     m = (auto_cells(n, d) if clustered is None else int(clustered)) if query_range is None else 0
-    if m > 1:       # cells formed by the library (same lists; a fraction of the tiles when the data has clusters)
+    if m <= 1 and clustered is None and query_range is None and cell_starts is None and auto_order_cells(n, d) > 1:
+        m = -auto_order_cells(n, d)     # all pairs; the order of that many chained cells is left for knn_last_order
+    if m > 1 or m < -1:       # cells formed by the library (same lists; a fraction of the tiles when the data has clusters)
         check(load().glx_knn_clustered(_ptr(X), n, d, k, m, _ptr(ind), _ptr(dist), _dev(device)), 'glx_knn_clustered')
         return ind, dist
     check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, q0, q1, _ptr(ind), _ptr(dist), _dev(device)),

@@ -1527,6 +1527,9 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   int M = 64;
   while (M < ncand) M *= 2;
 
+  // (host buffers of the cell-order by-product: declared in front of `b`, whose destructor drains the stream they are filled through)
+  std::vector<int> oc_sample, oc_cid, oc_perm;
+  std::vector<double> oc_cen;
   KnnBufs b;
   {
     int rcw = glx_work_acquire(device, &b.work);
@@ -1543,60 +1546,73 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   // glx_knn_clustered: form auto_cells cells (nearest of that many sample rows), reorder the rows by cell ON THE DEVICE and
   // search with the cell pruning of glx_knn_cells_range; the re-rank ranks by and returns the caller's indices
   std::vector<int64_t> own_starts;
-  if (auto_cells > 1 && q0 == 0 && q1 == n && !long_lists && d <= 128 && n >= 4 * (int64_t)auto_cells) {
-    const int m = auto_cells;
-    std::vector<int> sample(m);
-    for (int c = 0; c < m; ++c) sample[c] = (int)(((2 * (int64_t)c + 1) * n) / (2 * (int64_t)m));     // evenly spaced rows
-    GLX_POOL(glx_pool_alloc((void**)&b.cen, (size_t)m * d * 8));
-    GLX_POOL(glx_pool_alloc((void**)&b.cell_id, (size_t)std::max<int64_t>(n, m) * 4));
-    GLX_POOL(glx_pool_alloc((void**)&b.orig, (size_t)n * 4));
-    GLX_HIP(hipMemcpyAsync(b.cell_id, sample.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(knn_gather_rows_kernel, dim3((unsigned)(((int64_t)m * d + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const int*)b.cell_id,
-                       (int64_t)m, d, b.cen);
-    GLX_HIP(hipStreamSynchronize(st));            // (`sample` is read by the copy above)
-    hipLaunchKernelGGL(knn_assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)8 * d * 8, st, (const double*)b.X, d, n, (const double*)b.cen, m,
-                       b.cell_id);
-    GLX_HIP(hipGetLastError());
-    std::vector<int> cid(n), perm(n);
-    GLX_HIP(hipMemcpyAsync(cid.data(), b.cell_id, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    GLX_HIP(hipStreamSynchronize(st));
-    // the cells in a chain of nearest centres (greedy, from the centre farthest from the centres' mean): neighbouring cells of
-    // feature space end up next to each other in the row order, which then serves as a locality order for the graph's operators
-    // too (one XCD's share of the rows = a few whole clusters; with the cells in arbitrary order the sweep at 10^6 rows ran 20 % slower)
-    {
-      std::vector<double> cen((size_t)m * d);
-      GLX_HIP(hipMemcpyAsync(cen.data(), b.cen, (size_t)m * d * 8, hipMemcpyDeviceToHost, st));
-      GLX_HIP(hipStreamSynchronize(st));
-      std::vector<double> mean(d, 0.0);
+  // (auto_cells < 0: only the ORDER of -auto_cells chained cells is worked out and left for glx_knn_last_order -- below 2^17 rows the
+  // all-pairs search is the faster one, but the cell order still saves the operators on the graph their pass over it.  Nothing
+  // of that waits for the device: the cell ids travel back behind the search and the host part runs after its last synchronisation.)
+  const bool order_only = auto_cells < -1;
+  if (order_only) auto_cells = -auto_cells;
+  int oc_m = 0;
+  // the cells in a chain of nearest centres (greedy, from the centre farthest from the centres' mean): neighbouring cells of
+  // feature space end up next to each other in the row order, which then serves as a locality order for the graph's operators
+  // too (one XCD's share of the rows = a few whole clusters; with the cells in arbitrary order the sweep at 10^6 rows ran 20 % slower);
+  // then the rows by cell (counting sort, ascending caller index inside a cell).  Host work on oc_cid / oc_cen.
+  auto finish_order = [&]() {
+    const int m = oc_m;
+    std::vector<double>& cen = oc_cen;
+    std::vector<int>& cid = oc_cid;
+    std::vector<double> mean(d, 0.0);
+    for (int c = 0; c < m; ++c)
+      for (int f = 0; f < d; ++f) mean[f] += cen[(size_t)c * d + f] / m;
+    auto dist2 = [&](const double* a, const double* bb) { double t = 0; for (int f = 0; f < d; ++f) { const double q = a[f] - bb[f]; t += q * q; } return t; };
+    int cur = 0;
+    double far = -1.0;
+    for (int c = 0; c < m; ++c) { const double t = dist2(&cen[(size_t)c * d], mean.data()); if (t > far) { far = t; cur = c; } }
+    std::vector<int> place(m, -1);
+    for (int pos = 0; pos < m; ++pos) {
+      place[cur] = pos;
+      int nxt = -1;
+      double best = INFINITY;
       for (int c = 0; c < m; ++c)
-        for (int f = 0; f < d; ++f) mean[f] += cen[(size_t)c * d + f] / m;
-      auto dist2 = [&](const double* a, const double* bb) { double t = 0; for (int f = 0; f < d; ++f) { const double q = a[f] - bb[f]; t += q * q; } return t; };
-      int cur = 0;
-      double far = -1.0;
-      for (int c = 0; c < m; ++c) { const double t = dist2(&cen[(size_t)c * d], mean.data()); if (t > far) { far = t; cur = c; } }
-      std::vector<int> place(m, -1);
-      for (int pos = 0; pos < m; ++pos) {
-        place[cur] = pos;
-        int nxt = -1;
-        double best = INFINITY;
-        for (int c = 0; c < m; ++c)
-          if (place[c] < 0) { const double t = dist2(&cen[(size_t)c * d], &cen[(size_t)cur * d]); if (t < best) { best = t; nxt = c; } }
-        if (nxt < 0) break;
-        cur = nxt;
-      }
-      for (int64_t i = 0; i < n; ++i) cid[i] = place[cid[i]];
+        if (place[c] < 0) { const double t = dist2(&cen[(size_t)c * d], &cen[(size_t)cur * d]); if (t < best) { best = t; nxt = c; } }
+      if (nxt < 0) break;
+      cur = nxt;
     }
+    for (int64_t i = 0; i < n; ++i) cid[i] = place[cid[i]];
     own_starts.assign(m, 0);
     std::vector<int64_t> fill(m + 1, 0);
     for (int64_t i = 0; i < n; ++i) ++fill[cid[i] + 1];
     for (int c = 0; c < m; ++c) fill[c + 1] += fill[c];
     for (int c = 0; c < m; ++c) own_starts[c] = fill[c];
-    for (int64_t i = 0; i < n; ++i) perm[fill[cid[i]]++] = (int)i;       // stable: ascending caller index inside a cell
+    oc_perm.resize(n);
+    for (int64_t i = 0; i < n; ++i) oc_perm[fill[cid[i]]++] = (int)i;
+    std::lock_guard<std::mutex> lk(g_knn_order_mu);
+    g_knn_last_order.assign(oc_perm.begin(), oc_perm.end());
+  };
+  bool order_pending = false;
+  if (auto_cells > 1 && q0 == 0 && q1 == n && !long_lists && d <= 128 && n >= 4 * (int64_t)auto_cells) {
+    const int m = oc_m = auto_cells;
+    oc_sample.resize(m);
+    for (int c = 0; c < m; ++c) oc_sample[c] = (int)(((2 * (int64_t)c + 1) * n) / (2 * (int64_t)m));     // evenly spaced rows
+    GLX_POOL(glx_pool_alloc((void**)&b.cen, (size_t)m * d * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.cell_id, (size_t)std::max<int64_t>(n, m) * 4));
+    GLX_HIP(hipMemcpyAsync(b.cell_id, oc_sample.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(knn_gather_rows_kernel, dim3((unsigned)(((int64_t)m * d + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const int*)b.cell_id,
+                       (int64_t)m, d, b.cen);
+    hipLaunchKernelGGL(knn_assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)8 * d * 8, st, (const double*)b.X, d, n, (const double*)b.cen, m,
+                       b.cell_id);
+    GLX_HIP(hipGetLastError());
+    oc_cid.resize(n);
+    oc_cen.resize((size_t)m * d);
+    GLX_HIP(hipMemcpyAsync(oc_cid.data(), b.cell_id, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    GLX_HIP(hipMemcpyAsync(oc_cen.data(), b.cen, (size_t)m * d * 8, hipMemcpyDeviceToHost, st));
+    if (order_only) {
+      order_pending = true;                          // finished behind the search (finish_order at the end of the pass)
+    } else {
+    GLX_HIP(hipStreamSynchronize(st));
+    finish_order();
+    std::vector<int>& perm = oc_perm;
+    GLX_POOL(glx_pool_alloc((void**)&b.orig, (size_t)n * 4));
     GLX_HIP(hipMemcpyAsync(b.orig, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-    {
-      std::lock_guard<std::mutex> lk(g_knn_order_mu);
-      g_knn_last_order.assign(perm.begin(), perm.end());
-    }
     b.Xraw = b.X;
     b.X = nullptr;
     GLX_POOL(glx_pool_alloc((void**)&b.X, (size_t)n * d * 8));
@@ -1608,6 +1624,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     cell_starts = own_starts.data();
     ncells = m;
     stamp("rows reordered by cell");
+    }
   }
   // centring in fp64 (distances are translation invariant; small norms keep the filter sharp), all of it on the device
   const int64_t nb_sum = (n + CENTRE_ROWS - 1) / CENTRE_ROWS, nb_max = (n + 255) / 256;
@@ -1803,6 +1820,10 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   GLX_HIP(hipMemcpyAsync(dist_out, b.dist, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
   stamp("results on the host");
+  if (order_pending) {
+    finish_order();
+    stamp("cell order worked out");
+  }
   float ms_tile = 0, ms_rr = 0, ms_fb = 0;
   GLX_HIP(hipEventElapsedTime(&ms_tile, b.e0, b.e1));
   GLX_HIP(hipEventElapsedTime(&ms_rr, b.e1, b.e2));
@@ -1822,6 +1843,10 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
                    const int64_t* cell_starts = nullptr, int ncells = 0, int auto_cells = 0) {
   g_knn_stats[8] = 0.0;
   g_knn_stats[10] = g_knn_stats[11] = g_knn_stats[12] = 0.0;
+  {
+    std::lock_guard<std::mutex> lk(g_knn_order_mu);
+    g_knn_last_order.clear();            // (an order on record always belongs to the search that ran last)
+  }
   int rc = knn_pass(X, n, d, k, q0, q1, ind_out, dist_out, device, false, cell_starts, ncells, auto_cells);
   if (rc != KNN_ESCALATE) return rc;
   const double flagged = g_knn_stats[2];
@@ -1863,7 +1888,8 @@ extern "C" int glx_knn_cells_range(const double* X, int64_t n, int d, int k, con
 // output rows are the caller's, ties between equal distances go to the lower caller index -- the lists of glx_knn_bruteforce,
 // bit for bit.  On data without cluster structure every cell stays in play and the extra passes cost a few per cent.
 extern "C" int glx_knn_clustered(const double* X, int64_t n, int d, int k, int ncells, int64_t* ind_out, double* dist_out, int device) {
-  GLX_CHECK(ncells >= 0 && ncells <= 4096, GLX_EINVAL, "glx_knn_clustered: ncells=%d outside [0, 4096]", ncells);
+  // ncells < -1: the all-pairs search, with the order of -ncells chained cells left for glx_knn_last_order as a by-product
+  GLX_CHECK(ncells >= -4096 && ncells <= 4096, GLX_EINVAL, "glx_knn_clustered: ncells=%d outside [-4096, 4096]", ncells);
   return knn_run(X, n, d, k, 0, n, ind_out, dist_out, device, nullptr, 0, ncells);
 }
 

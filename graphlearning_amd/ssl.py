@@ -394,9 +394,9 @@ class poisson(ssl):
             aux['deg'] = deg
             aux['vinf'] = deg / np.sum(deg)
             # the cell order of the search that built W, if it was a clustered one: for the fp64 sweep as good as the library's own
-            # pass over the graph (251 vs 250 us at 10^6 vertices) and free (0.13 s there); the fp32 sweep is 4 % faster on the
-            # library's order (201 vs 209 us), so that mode keeps paying for it
-            order = getattr(W, '_glx_order', None) if self._dtype() == np.float64 else None
+            # pass over the graph (251 vs 250 us at 10^6 vertices; 12.45 vs 12.59 us at 70 000) and free (0.13 s / 3.7 ms); the fp32
+            # sweep at 10^6 vertices is 4 % faster on the library's order (201 vs 209 us), so that mode keeps paying for it there
+            order = getattr(W, '_glx_order', None) if (self._dtype() == np.float64 or n < (1 << 17)) else None
             if order is not None and len(order) != n:
                 order = None
             dev = _hip.DeviceGraph(P, dtype=self._dtype(), device=self.device, order=order)

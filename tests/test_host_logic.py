@@ -266,9 +266,18 @@ def test_gaussian_weight_blocks_and_auto_cells(monkeypatch):
     wm._row_blocks(rows_g, n)
     assert np.array_equal(out_g, ref_g)
     monkeypatch.delenv('GLX_KNN_CLUSTERED', raising=False)
-    assert _hip.auto_cells(70000, 20) == 0 and _hip.auto_cells(131072, 64) == 16 and _hip.auto_cells(10 ** 6, 64) == 122
+    assert _hip.auto_cells(70000, 20) == 0 and _hip.auto_cells(131072, 64) == 64 and _hip.auto_cells(10 ** 6, 64) == 122
     assert _hip.auto_cells(10 ** 7, 64) == 256 and _hip.auto_cells(10 ** 6, 200) == 0
     monkeypatch.setenv('GLX_KNN_CLUSTERED', '0')
     assert _hip.auto_cells(10 ** 6, 64) == 0
     monkeypatch.setenv('GLX_KNN_CLUSTERED', '48')
     assert _hip.auto_cells(1000, 3) == 48
+
+
+def test_order_cells_policy(monkeypatch):
+    from graphlearning_amd import _hip
+    monkeypatch.delenv('GLX_KNN_ORDER', raising=False)
+    assert _hip.auto_order_cells(70000, 20) == 128 and _hip.auto_order_cells(5000, 8) == 78 and _hip.auto_order_cells(4000, 8) == 0
+    assert _hip.auto_order_cells(1 << 17, 20) == 0 and _hip.auto_order_cells(70000, 200) == 0
+    monkeypatch.setenv('GLX_KNN_ORDER', '0')
+    assert _hip.auto_order_cells(70000, 20) == 0
