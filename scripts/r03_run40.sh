@@ -1,5 +1,5 @@
 #!/bin/bash
-O=/root/repo/gpurun_out/r03am
+O=/root/repo/gpurun_out/r03ay
 mkdir -p $O
 export TMPDIR=/tmp
 export HSA_ENABLE_IPC_MODE_LEGACY=0
