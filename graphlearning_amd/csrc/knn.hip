@@ -273,6 +273,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef KNN_GROUP_GUARD
 #define KNN_GROUP_GUARD 1          // measured: 438 -> 394 ms
 #endif
+#ifndef KNN_DIRECT
+#define KNN_DIRECT 0                // experiment: A fragments straight from global memory into registers (no LDS tiles, no barrier per tile)
+#endif
 #ifndef KNN_REGL2
 #define KNN_REGL2 0                 // the same for two feature blocks (d = 17 .. 32): see the note at bf16_nstg
 #endif
@@ -381,6 +384,26 @@ __global__ void knn_prep_bf16_cat_kernel(const double* __restrict__ X, const dou
     ra[KNN_CAT_SEG - 1] = n1; ra[2 * KNN_CAT_SEG - 1] = n2; ra[3 * KNN_CAT_SEG - 1] = n3;
     rq[KNN_CAT_SEG - 1] = 0x3f80; rq[2 * KNN_CAT_SEG - 1] = 0x3f80; rq[3 * KNN_CAT_SEG - 1] = 0x3f80;
   }
+}
+
+// (KNN_DIRECT experiment) the ref image in the order the wavefronts fetch it: per tile of BR rows, per sub-tile of 32, per block of 16
+// features, per half (first / second 16 KPAD-slots region), the 16 bytes of lane (h, j) side by side
+__global__ void knn_frag_layout_kernel(const unsigned short* __restrict__ Xrow, int64_t nrows, int KPAD, int NSUB, int NKB,
+                                       unsigned short* __restrict__ Xf, int64_t ntiles) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte unit
+  const int64_t total = ntiles * NSUB * NKB * 2 * 64;
+  if (u >= total) return;
+  const int lane = (int)(u % 64);
+  int64_t f = u / 64;
+  const int part = (int)(f % 2); f /= 2;
+  const int kb = (int)(f % NKB); f /= NKB;
+  const int sub = (int)(f % NSUB); f /= NSUB;
+  const int64_t tt = f;
+  const int h = lane >> 5, j = lane & 31;
+  const int64_t row = tt * 32 * NSUB + sub * 32 + j;
+  uint4 v = {0u, 0u, 0u, 0u};
+  if (row < nrows) v = *(const uint4*)(Xrow + row * 2 * KPAD + part * KPAD + kb * 16 + 8 * h);
+  ((uint4*)Xf)[u] = v;
 }
 
 // NKB blocks of 16 features (kpad = 16 NKB <= 128); refs are the A operand (LDS), queries the B operand (registers: lane =
@@ -584,15 +607,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
 #endif
     KNN_TOC(cy_comp, tc);
   };
-  if (t0 >= 0) { stage_load(t0); stage_store(0); }
-  __syncthreads();
+  if (!(KNN_DIRECT && CAT == 2 && NSTG == 1)) {
+    if (t0 >= 0) { stage_load(t0); stage_store(0); }
+    __syncthreads();
+  }
   int buf = 0;
 #if KNN_ABLATE & 1
   float abl_sink = INFINITY;
 #endif
   KNN_TIC(ta);
   int it = 0;
-  for (int64_t t = t0, tn; t >= 0; t = tn, ++it) {
+  // DIRECT (build option, norm-folded concatenated form only): no LDS tiles and no barrier -- every wavefront fetches the A fragments of
+  // the next tile from global memory (L1 / L2: the four wavefronts of a workgroup walk the same tiles) into registers while it
+  // contracts the current one
+  constexpr bool DIRECT = KNN_DIRECT && CAT == 2 && NSTG == 1;
+  constexpr int NF = NSUB * NKB * 2;
+  uint4 fa[DIRECT ? NF : 1], fb[DIRECT ? NF : 1];
+  auto direct_load = [&](int64_t tt, uint4 (&dst)[DIRECT ? NF : 1]) {
+    if constexpr (DIRECT) {
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          // (Xb here is the FRAGMENT image written by knn_frag_layout_kernel: 64 lanes x 16 bytes contiguous per fragment)
+          const uint4* fp = (const uint4*)Xb + (((tt * NSUB + sub) * NKB + kb) * 2) * 64 + lane;
+          dst[(sub * NKB + kb) * 2 + 0] = fp[0];
+          dst[(sub * NKB + kb) * 2 + 1] = fp[64];
+        }
+    }
+  };
+  int64_t t = t0, tn = -1;
+  if constexpr (DIRECT) { if (t0 >= 0) direct_load(t0, fa); }
+  auto tile_body = [&](uint4 (&cur)[DIRECT ? NF : 1], uint4 (&nxt)[DIRECT ? NF : 1]) {
     tn = next_tile(t);
     const bool has_next = tn >= 0;
 #if KNN_GTAU
@@ -603,7 +649,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
     }
 #endif
 #if !(KNN_ABLATE & 4)
-    if (has_next) stage_load(tn);
+    if constexpr (DIRECT) { if (has_next) direct_load(tn, nxt); }
+    else { if (has_next) stage_load(tn); }
 #endif
 #pragma unroll 1
     for (int stg = 0; stg < NSTG; ++stg) {
@@ -620,8 +667,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
       for (int sub = 0; sub < NSUB; ++sub) {
         // A[i][k]: lane holds row i = j of the sub-tile, k = 8h .. 8h+7 of block kb
         const char* rowp = tl + (sub * 32 + j) * ROWB + (kb * 16 + 8 * h) * 2;
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)rowp);
-        const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(rowp + 2 * KPAD));
+        bf16x8 ah, al;
+        if constexpr (DIRECT) {
+          ah = __builtin_bit_cast(bf16x8, cur[(sub * NKB + kb) * 2 + 0]);
+          al = __builtin_bit_cast(bf16x8, cur[(sub * NKB + kb) * 2 + 1]);
+        } else {
+          ah = __builtin_bit_cast(bf16x8, *(const uint4*)rowp);
+          al = __builtin_bit_cast(bf16x8, *(const uint4*)(rowp + 2 * KPAD));
+        }
         if constexpr (CAT) {     // fragments kb and 2 + kb of the one concatenated contraction
           acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kb], acc[sub], 0, 0, 0);
           acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl[kb], acc[sub], 0, 0, 0);
@@ -702,6 +755,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
     KNN_TOC(cy_slow, ts);
     }   // stg
     KNN_TIC(tb);
+    if constexpr (!DIRECT) {
     if (has_next) stage_store(buf ^ 1);
 #if KNN_COUNT == 2
     __builtin_amdgcn_s_waitcnt(0);      // (probe only) the store's own waits end here, the rest is the barrier
@@ -710,8 +764,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
 #if !(KNN_ABLATE & 2)
     __syncthreads();
 #endif
+    }
     KNN_TOC(cy_bar, tb);
     buf ^= 1;
+    t = tn;
+    ++it;
+  };
+  while (t >= 0) {
+    tile_body(fa, fb);
+    if constexpr (DIRECT) {
+      if (t < 0) break;
+      tile_body(fb, fa);
+    }
   }
   KNN_TOC(cy_all, ta);
 #if KNN_ABLATE & 1
@@ -1266,6 +1330,7 @@ constexpr int tile_nsub(int DH, int KP) {
 struct KnnBufs {
   unsigned short* Xb = nullptr;      // bf16 hi | lo image (bf16 filter); concatenated form: the ref image [hi | hi | lo]
   unsigned short* Xq = nullptr;      // concatenated form only: the query image [hi | lo | hi]
+  unsigned short* Xf = nullptr;      // (KNN_DIRECT experiment) second ref image
   float* nrm = nullptr;              // fp32 squared norms (bf16 filter)
   double* part = nullptr;            // per-block partial column sums / maxima of the centring pass
   float* rmax = nullptr;             // [0] largest centred norm (1 + 1e-6), [1] 1 if the input is finite: written by knn_rmax_kernel
@@ -1291,7 +1356,7 @@ struct KnnBufs {
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
   ~KnnBufs() {
     if (stream) hipStreamSynchronize(stream);   // pooled blocks are reused at once: nothing may still be running on them
-    glx_pool_free(Xb); glx_pool_free(Xq); glx_pool_free(nrm); glx_pool_free(part); glx_pool_free(rmax);
+    glx_pool_free(Xb); glx_pool_free(Xq); glx_pool_free(Xf); glx_pool_free(nrm); glx_pool_free(part); glx_pool_free(rmax);
     glx_pool_free(X); glx_pool_free(mean); glx_pool_free(dist); glx_pool_free(Rf); glx_pool_free(Qf); glx_pool_free(qnorm); glx_pool_free(cand_d);
     glx_pool_free(runs); glx_pool_free(nruns); glx_pool_free(cell_starts); glx_pool_free(cen); glx_pool_free(rad); glx_pool_free(ub2); glx_pool_free(cpart); glx_pool_free(mask); glx_pool_free(visited); glx_pool_free(Xraw); glx_pool_free(orig); glx_pool_free(cell_id);
     glx_pool_free(pre_d); glx_pool_free(pre_i); glx_pool_free(gtau); glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_pi); glx_pool_free(fb_pd);
@@ -1676,6 +1741,18 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
                          n, d, dpa, b.Xb, b.nrm, b.qnorm);
     }
     GLX_HIP(hipGetLastError());
+#if KNN_DIRECT
+    if (cat == 2) {          // (experiment) the tile kernel of this form reads the fragment image
+      const int nsub = bf16_nsub(NKB, KP);
+      const int64_t nt = (n + KNN_PAD_ROWS) / (32 * nsub);
+      GLX_POOL(glx_pool_alloc((void**)&b.Xf, (size_t)nt * 32 * nsub * 2 * dpa * 2));
+      const int64_t units = nt * nsub * NKB * 2 * 64;
+      hipLaunchKernelGGL(knn_frag_layout_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, (const unsigned short*)b.Xb, n + KNN_PAD_ROWS, dpa, nsub, NKB,
+                         b.Xf, nt);
+      GLX_HIP(hipGetLastError());
+      std::swap(b.Xb, b.Xf);   // (Xq keeps the row layout for the queries)
+    }
+#endif
     g_knn_stats[9] = (double)cat;
     // The seeding pre-pass (knn_seed_kernel).  Over all refs it does not pay (measured, profiles/r03_knn_seed.txt: the k-th of a
     // 1/8 sample is the 8k-th of the whole set, 79 % of the wave-tiles still hold a candidate and the pre-pass costs its eighth):
