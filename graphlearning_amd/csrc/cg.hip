@@ -169,9 +169,18 @@ __global__ __launch_bounds__(256) void cg_reduce_kernel(const double* __restrict
   const int c = threadIdx.x % cp, part = threadIdx.x / cp;
   double s = 0.0;
   if (c < ncols && part < nparts) {
+    // eight partial sums per thread, combined in a fixed order: the loads of a run of eight do not wait for one another (one
+    // dependent load + add per block result was 30 us for 1528 blocks -- a third of a tolerance-mode iteration at 70 000 rows)
     const int64_t per = (nb + nparts - 1) / nparts;
     const int64_t b0 = part * per, b1 = min(nb, b0 + per);
-    for (int64_t b = b0; b < b1; ++b) s += partial[(size_t)b * ncols + c];
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t b = b0;
+    for (; b + 8 <= b1; b += 8) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a[q] += partial[(size_t)(b + q) * ncols + c];
+    }
+    for (int q = 0; b < b1; ++b, ++q) a[q] += partial[(size_t)b * ncols + c];
+    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   s_sum[threadIdx.x] = s;
   __syncthreads();
