@@ -99,7 +99,9 @@ void glx_pool_free(void* p);
 // creating and destroying them costs milliseconds -- as much as the kNN search of 70 000 points itself
 struct glx_work {
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;     // a second stream for work beside the main one (the cell-order by-product of the kNN search)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_side = nullptr;
   int device = 0;
 };
 int glx_work_acquire(int device, glx_work** out);

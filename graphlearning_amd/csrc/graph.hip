@@ -76,6 +76,8 @@ WorkCache& work_cache() {
 void work_destroy(glx_work* w) {
   for (int i = 0; i < 4; ++i)
     if (w->ev[i]) hipEventDestroy(w->ev[i]);
+  if (w->ev_side) hipEventDestroy(w->ev_side);
+  if (w->side) hipStreamDestroy(w->side);
   if (w->stream) hipStreamDestroy(w->stream);
   delete w;
 }
@@ -95,6 +97,8 @@ int glx_work_acquire(int device, glx_work** out) {
   glx_work* w = new glx_work;
   w->device = device;
   hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_side, hipEventDisableTiming);
   for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&w->ev[i]);
   if (e != hipSuccess) {
     glx_set_error("glx_work_acquire: %s", hipGetErrorString(e));

@@ -353,36 +353,53 @@ static const int KNN_CAT_SEG = 21;
 __global__ void knn_prep_bf16_cat_kernel(const double* __restrict__ X, const double* __restrict__ mean, int64_t n, int d,
                                          unsigned short* __restrict__ Xa, unsigned short* __restrict__ Xq, float* __restrict__ nrm,
                                          float* __restrict__ qnorm, int fold) {
+  // (a row of each image is put together in registers and leaves in eight 16-byte stores: 128 two-byte stores per row and image
+  // took 78 us at 70 000 rows)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n + KNN_PAD_ROWS) return;
-  unsigned short* ra = Xa + i * 64;
-  unsigned short* rq = Xq + i * 64;
+  unsigned short ra[64], rq[64];
+#pragma unroll
   for (int f = 0; f < 64; ++f) { ra[f] = 0; rq[f] = 0; }
   if (i >= n) {                       // spare rows behind the data: zero features, infinitely far
     nrm[i] = 1e30f;
     if (fold) { ra[KNN_CAT_SEG - 1] = f32_to_bf16_rn(1e30f); rq[KNN_CAT_SEG - 1] = 0x3f80; }
-    return;
+  } else {
+    float s = 0.f;
+    const float sc = fold ? -2.f : 1.f;
+#pragma unroll
+    for (int f = 0; f < KNN_CAT_SEG; ++f) {
+      if (f < d) {
+        const float x = (float)(X[i * d + f] - mean[f]);
+        const unsigned short hi = f32_to_bf16_rn(x);
+        const unsigned short lo = f32_to_bf16_rn(x - bf16_to_f32(hi));
+        const unsigned short shi = f32_to_bf16_rn(sc * bf16_to_f32(hi)), slo = f32_to_bf16_rn(sc * bf16_to_f32(lo));   // (exact: a power of two)
+        ra[f] = shi; ra[KNN_CAT_SEG + f] = shi; ra[2 * KNN_CAT_SEG + f] = slo;
+        rq[f] = hi; rq[KNN_CAT_SEG + f] = lo; rq[2 * KNN_CAT_SEG + f] = hi;
+        s = fmaf(x, x, s);
+      }
+    }
+    nrm[i] = s;
+    qnorm[i] = sqrtf(s);
+    if (fold) {
+      const unsigned short n1 = f32_to_bf16_rn(s);
+      const float r1 = s - bf16_to_f32(n1);
+      const unsigned short n2 = f32_to_bf16_rn(r1);
+      const unsigned short n3 = f32_to_bf16_rn(r1 - bf16_to_f32(n2));
+      ra[KNN_CAT_SEG - 1] = n1; ra[2 * KNN_CAT_SEG - 1] = n2; ra[3 * KNN_CAT_SEG - 1] = n3;
+      rq[KNN_CAT_SEG - 1] = 0x3f80; rq[2 * KNN_CAT_SEG - 1] = 0x3f80; rq[3 * KNN_CAT_SEG - 1] = 0x3f80;
+    }
   }
-  float s = 0.f;
-  const float sc = fold ? -2.f : 1.f;
-  for (int f = 0; f < d; ++f) {
-    const float x = (float)(X[i * d + f] - mean[f]);
-    const unsigned short hi = f32_to_bf16_rn(x);
-    const unsigned short lo = f32_to_bf16_rn(x - bf16_to_f32(hi));
-    const unsigned short shi = f32_to_bf16_rn(sc * bf16_to_f32(hi)), slo = f32_to_bf16_rn(sc * bf16_to_f32(lo));   // (exact: a power of two)
-    ra[f] = shi; ra[KNN_CAT_SEG + f] = shi; ra[2 * KNN_CAT_SEG + f] = slo;
-    rq[f] = hi; rq[KNN_CAT_SEG + f] = lo; rq[2 * KNN_CAT_SEG + f] = hi;
-    s = fmaf(x, x, s);
-  }
-  nrm[i] = s;
-  qnorm[i] = sqrtf(s);
-  if (fold) {
-    const unsigned short n1 = f32_to_bf16_rn(s);
-    const float r1 = s - bf16_to_f32(n1);
-    const unsigned short n2 = f32_to_bf16_rn(r1);
-    const unsigned short n3 = f32_to_bf16_rn(r1 - bf16_to_f32(n2));
-    ra[KNN_CAT_SEG - 1] = n1; ra[2 * KNN_CAT_SEG - 1] = n2; ra[3 * KNN_CAT_SEG - 1] = n3;
-    rq[KNN_CAT_SEG - 1] = 0x3f80; rq[2 * KNN_CAT_SEG - 1] = 0x3f80; rq[3 * KNN_CAT_SEG - 1] = 0x3f80;
+  uint4* oa = (uint4*)(Xa + i * 64);
+  uint4* oq = (uint4*)(Xq + i * 64);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    uint4 va, vq;
+    va.x = ra[8 * u + 0] | ((unsigned)ra[8 * u + 1] << 16); va.y = ra[8 * u + 2] | ((unsigned)ra[8 * u + 3] << 16);
+    va.z = ra[8 * u + 4] | ((unsigned)ra[8 * u + 5] << 16); va.w = ra[8 * u + 6] | ((unsigned)ra[8 * u + 7] << 16);
+    vq.x = rq[8 * u + 0] | ((unsigned)rq[8 * u + 1] << 16); vq.y = rq[8 * u + 2] | ((unsigned)rq[8 * u + 3] << 16);
+    vq.z = rq[8 * u + 4] | ((unsigned)rq[8 * u + 5] << 16); vq.w = rq[8 * u + 6] | ((unsigned)rq[8 * u + 7] << 16);
+    oa[u] = va;
+    oq[u] = vq;
   }
 }
 
@@ -1356,6 +1373,7 @@ struct KnnBufs {
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
   ~KnnBufs() {
     if (stream) hipStreamSynchronize(stream);   // pooled blocks are reused at once: nothing may still be running on them
+    if (work && work->side) hipStreamSynchronize(work->side);
     glx_pool_free(Xb); glx_pool_free(Xq); glx_pool_free(Xf); glx_pool_free(nrm); glx_pool_free(part); glx_pool_free(rmax);
     glx_pool_free(X); glx_pool_free(mean); glx_pool_free(dist); glx_pool_free(Rf); glx_pool_free(Qf); glx_pool_free(qnorm); glx_pool_free(cand_d);
     glx_pool_free(runs); glx_pool_free(nruns); glx_pool_free(cell_starts); glx_pool_free(cen); glx_pool_free(rad); glx_pool_free(ub2); glx_pool_free(cpart); glx_pool_free(mask); glx_pool_free(visited); glx_pool_free(Xraw); glx_pool_free(orig); glx_pool_free(cell_id);
@@ -1396,10 +1414,35 @@ __global__ __launch_bounds__(256) void knn_colsum_kernel(const double* __restric
   }
 }
 __global__ __launch_bounds__(256) void knn_mean_kernel(const double* __restrict__ part, int64_t nblk, int d, int64_t n, double* __restrict__ mean) {
-  for (int f = threadIdx.x; f < d; f += 256) {
-    double t = 0.0;
-    for (int64_t b = 0; b < nblk; ++b) t += part[(size_t)b * d + f];
-    mean[f] = t / (double)n;
+  // thread = (column, one of 256 / dt runs of blocks), eight partial sums per thread whose loads do not wait for one another, the
+  // runs combined in order: a fixed summation order (one dependent load + add per block was 35 us at 70 000 x 20)
+  __shared__ double sm[256];
+  int dt = 1;
+  while (dt < d && dt < 256) dt *= 2;
+  const int c = threadIdx.x % dt, part_id = threadIdx.x / dt, nparts = 256 / dt;
+  for (int f0 = 0; f0 < d; f0 += dt) {
+    const int f = f0 + c;
+    double s = 0.0;
+    if (f < d) {
+      const int64_t per = (nblk + nparts - 1) / nparts;
+      const int64_t b0 = part_id * per, b1 = min(nblk, b0 + per);
+      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int64_t b = b0;
+      for (; b + 8 <= b1; b += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += part[(size_t)(b + q) * d + f];
+      }
+      for (int q = 0; b < b1; ++b, ++q) a[q] += part[(size_t)b * d + f];
+      s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (part_id == 0 && f < d) {
+      double t = 0.0;
+      for (int q = 0; q < nparts; ++q) t += sm[q * dt + c];
+      mean[f] = t / (double)n;
+    }
+    __syncthreads();
   }
 }
 __global__ __launch_bounds__(256) void knn_maxnorm_kernel(const double* __restrict__ X, const double* __restrict__ mean, int64_t n, int d,
@@ -1660,16 +1703,22 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     for (int c = 0; c < m; ++c) oc_sample[c] = (int)(((2 * (int64_t)c + 1) * n) / (2 * (int64_t)m));     // evenly spaced rows
     GLX_POOL(glx_pool_alloc((void**)&b.cen, (size_t)m * d * 8));
     GLX_POOL(glx_pool_alloc((void**)&b.cell_id, (size_t)std::max<int64_t>(n, m) * 4));
-    GLX_HIP(hipMemcpyAsync(b.cell_id, oc_sample.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(knn_gather_rows_kernel, dim3((unsigned)(((int64_t)m * d + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const int*)b.cell_id,
+    // order only: beside the search, on the work set's second stream (it needs the uploaded rows and nothing else)
+    hipStream_t so = order_only ? b.work->side : st;
+    if (order_only) {
+      GLX_HIP(hipEventRecord(b.work->ev_side, st));
+      GLX_HIP(hipStreamWaitEvent(so, b.work->ev_side, 0));
+    }
+    GLX_HIP(hipMemcpyAsync(b.cell_id, oc_sample.data(), (size_t)m * 4, hipMemcpyHostToDevice, so));
+    hipLaunchKernelGGL(knn_gather_rows_kernel, dim3((unsigned)(((int64_t)m * d + 255) / 256)), dim3(256), 0, so, (const double*)b.X, (const int*)b.cell_id,
                        (int64_t)m, d, b.cen);
-    hipLaunchKernelGGL(knn_assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)8 * d * 8, st, (const double*)b.X, d, n, (const double*)b.cen, m,
+    hipLaunchKernelGGL(knn_assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)8 * d * 8, so, (const double*)b.X, d, n, (const double*)b.cen, m,
                        b.cell_id);
     GLX_HIP(hipGetLastError());
     oc_cid.resize(n);
     oc_cen.resize((size_t)m * d);
-    GLX_HIP(hipMemcpyAsync(oc_cid.data(), b.cell_id, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    GLX_HIP(hipMemcpyAsync(oc_cen.data(), b.cen, (size_t)m * d * 8, hipMemcpyDeviceToHost, st));
+    GLX_HIP(hipMemcpyAsync(oc_cid.data(), b.cell_id, (size_t)n * 4, hipMemcpyDeviceToHost, so));
+    GLX_HIP(hipMemcpyAsync(oc_cen.data(), b.cen, (size_t)m * d * 8, hipMemcpyDeviceToHost, so));
     if (order_only) {
       order_pending = true;                          // finished behind the search (finish_order at the end of the pass)
     } else {
@@ -1898,6 +1947,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   GLX_HIP(hipStreamSynchronize(st));
   stamp("results on the host");
   if (order_pending) {
+    GLX_HIP(hipStreamSynchronize(b.work->side));
     finish_order();
     stamp("cell order worked out");
   }
