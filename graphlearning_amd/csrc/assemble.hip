@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restri
   const int rc = sym == SYM_NONE ? 0 : (int)(roff[i + 1] - roff[i]);
   const int M = k + rc;
   if (M > ROW_CAP) {   // hub vertex: merge_hub_kernel's
-    if (lane == 0 && !mode) { rowcnt[i] = -1; *overflow = 1; }
+    if (lane == 0 && mode != 1) { rowcnt[i] = -1; *overflow = 1; }
     return;
   }
   int P = 64;
@@ -142,7 +142,10 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restri
   }
   // segment heads: first entry of each distinct column
   int kept_before = 0;   // running count of kept entries (uniform across the wave)
-  const int64_t obase = mode ? rowptr[i] : 0;
+  // mode 2: ONE pass -- the kept entries go to the row's slot in a scratch image (room for all M candidates: offset i k + roff[i],
+  // known without a scan) and compact_rows_kernel moves them to their place once the row pointers exist; the second sort of
+  // every row that modes 0 + 1 cost was a fifth of weightmatrix.knn's assembly
+  const int64_t obase = mode == 1 ? rowptr[i] : (mode == 2 ? i * (int64_t)k + (sym == SYM_NONE ? 0 : roff[i]) : 0);
   for (int e0 = 0; e0 < M; e0 += 64) {
     const int e = e0 + lane;
     bool keep = false;
@@ -168,7 +171,24 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restri
     }
     kept_before += __popcll(mask);
   }
-  if (!mode && lane == 0) rowcnt[i] = kept_before;
+  if (mode != 1 && lane == 0) rowcnt[i] = kept_before;
+}
+
+// rows of the scratch image of merge_rows_kernel's mode 2 to their place in the CSR arrays (hub rows, rowcnt < 0, are written by
+// merge_hub_kernel); four rows per workgroup
+__global__ __launch_bounds__(256) void compact_rows_kernel(const int* __restrict__ rowcnt, const int64_t* __restrict__ roff, int64_t n, int k, int sym,
+                                                           const int64_t* __restrict__ rowptr, const int* __restrict__ tcol,
+                                                           const double* __restrict__ tval, int* __restrict__ col_out, double* __restrict__ val_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int cnt = rowcnt[i];
+  if (cnt <= 0) return;
+  const int64_t src = i * (int64_t)k + (sym == SYM_NONE ? 0 : roff[i]), dst = rowptr[i];
+  for (int e = lane; e < cnt; e += 64) {
+    col_out[dst + e] = tcol[src + e];
+    val_out[dst + e] = tval[src + e];
+  }
 }
 
 // hub vertices (more than ROW_CAP forward + reverse entries; high-dimensional data has them): one workgroup per hub,
@@ -268,6 +288,8 @@ struct AsmBufs {
   unsigned short* rpos = nullptr;
   double *dist = nullptr, *given = nullptr, *w = nullptr, *rw = nullptr, *val = nullptr, *sval = nullptr;
   int *rcnt = nullptr, *cursor = nullptr, *rsrc = nullptr, *rowcnt = nullptr, *col = nullptr, *flag = nullptr, *hub_cnt = nullptr;
+  int* tcol = nullptr;           // scratch image of the one-pass merge (merge_rows_kernel mode 2)
+  double* tval = nullptr;
   glx_work* work = nullptr;      // the device's cached stream
   hipStream_t stream = nullptr;
   ~AsmBufs() {
@@ -275,6 +297,7 @@ struct AsmBufs {
     glx_pool_free(ind); glx_pool_free(roff); glx_pool_free(rowptr); glx_pool_free(dist); glx_pool_free(given); glx_pool_free(w); glx_pool_free(rw); glx_pool_free(val);
     glx_pool_free(rcnt); glx_pool_free(cursor); glx_pool_free(rsrc); glx_pool_free(rowcnt); glx_pool_free(col); glx_pool_free(flag);
     glx_pool_free(hub_row); glx_pool_free(hub_off); glx_pool_free(skey); glx_pool_free(sval); glx_pool_free(hub_cnt); glx_pool_free(rpos);
+    glx_pool_free(tcol); glx_pool_free(tval);
     glx_work_release(work);
   }
 };
@@ -345,9 +368,11 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
   const size_t shm = (size_t)4 * ROW_CAP * 16;
   GLX_HIP(hipFuncSetAttribute((const void*)merge_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const unsigned gr = (unsigned)((n + 3) / 4);
+  GLX_POOL(glx_pool_alloc((void**)&b.tcol, (size_t)(2 * ne) * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.tval, (size_t)(2 * ne) * 8));
   hipLaunchKernelGGL(merge_rows_kernel, dim3(gr), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, n, kk, k,
-                     (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 0, b.rowcnt, (const int64_t*)nullptr,
-                     (int*)nullptr, (double*)nullptr, b.flag + 1);
+                     (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 2, b.rowcnt, (const int64_t*)nullptr,
+                     b.tcol, b.tval, b.flag + 1);
   GLX_HIP(hipGetLastError());
   std::vector<int> rowcnt(n);
   GLX_HIP(hipMemcpyAsync(rowcnt.data(), b.rowcnt, n * 4, hipMemcpyDeviceToHost, st));
@@ -390,9 +415,8 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
   GLX_HIP(hipMemcpyAsync(b.rowptr, rp.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
   GLX_POOL(glx_pool_alloc((void**)&b.col, std::max<size_t>(nnz * 4, 4)));
   GLX_POOL(glx_pool_alloc((void**)&b.val, std::max<size_t>(nnz * 8, 8)));
-  hipLaunchKernelGGL(merge_rows_kernel, dim3(gr), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, n, kk, k,
-                     (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 1, b.rowcnt, (const int64_t*)b.rowptr,
-                     b.col, b.val, b.flag + 1);
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(gr), dim3(256), 0, st, (const int*)b.rowcnt, (const int64_t*)b.roff, n, k, sym, (const int64_t*)b.rowptr,
+                     (const int*)b.tcol, (const double*)b.tval, b.col, b.val);
   GLX_HIP(hipGetLastError());
   if (nh) {
     hipLaunchKernelGGL(merge_hub_kernel, dim3((unsigned)nh), dim3(1024), 0, st, (const int64_t*)b.ind, (const double*)b.w, kk, k,
