@@ -317,22 +317,36 @@ __global__ void knn_prep_bf16_kernel(const double* __restrict__ X, const double*
                                      unsigned short* __restrict__ Xb, float* __restrict__ nrm, float* __restrict__ qnorm) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n + KNN_PAD_ROWS) return;
-  unsigned short* row = Xb + i * 2 * kpad;
+  // (eight features at a time: their hi and lo halves leave in one 16-byte store each -- two-byte stores made this kernel 2.3 ms at
+  // 10^6 x 64)
+  uint4* row_hi = (uint4*)(Xb + i * 2 * kpad);
+  uint4* row_lo = (uint4*)(Xb + i * 2 * kpad + kpad);
   if (i >= n) {                       // spare rows behind the data: zero features, infinitely far
-    for (int f = 0; f < 2 * kpad; ++f) row[f] = 0;
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (int u = 0; u < kpad / 8; ++u) { row_hi[u] = z; row_lo[u] = z; }
     nrm[i] = 1e30f;
     return;
   }
   float s = 0.f;
-  for (int f = 0; f < d; ++f) {
-    const float x = (float)(X[i * d + f] - mean[f]);
-    const unsigned short hi = f32_to_bf16_rn(x);
-    const unsigned short lo = f32_to_bf16_rn(x - bf16_to_f32(hi));
-    row[f] = hi;
-    row[kpad + f] = lo;
-    s = fmaf(x, x, s);
+  for (int u = 0; u < kpad / 8; ++u) {
+    unsigned short hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int f = u * 8 + e;
+      hi[e] = 0; lo[e] = 0;
+      if (f < d) {
+        const float x = (float)(X[i * d + f] - mean[f]);
+        hi[e] = f32_to_bf16_rn(x);
+        lo[e] = f32_to_bf16_rn(x - bf16_to_f32(hi[e]));
+        s = fmaf(x, x, s);
+      }
+    }
+    uint4 vh, vl;
+    vh.x = hi[0] | ((unsigned)hi[1] << 16); vh.y = hi[2] | ((unsigned)hi[3] << 16); vh.z = hi[4] | ((unsigned)hi[5] << 16); vh.w = hi[6] | ((unsigned)hi[7] << 16);
+    vl.x = lo[0] | ((unsigned)lo[1] << 16); vl.y = lo[2] | ((unsigned)lo[3] << 16); vl.z = lo[4] | ((unsigned)lo[5] << 16); vl.w = lo[6] | ((unsigned)lo[7] << 16);
+    row_hi[u] = vh;
+    row_lo[u] = vl;
   }
-  for (int f = d; f < kpad; ++f) { row[f] = 0; row[kpad + f] = 0; }
   nrm[i] = s;
   qnorm[i] = sqrtf(s);
 }
@@ -829,24 +843,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
 // v_k + 3 eps > dk2 -- never one of the k nearest (nor tied with the k-th).  What it buys: the lists only ever see refs within a few
 // percent of the k-th distance (in d dimensions a sample of 1/8 is (8)^(1/d) further out), a tenth of the appends and merges of
 // lists that start empty; list maintenance was 41-62 % of the tile kernel.  Values here carry the query's norm (cand_d does).
+template <int M>       // M = 2 KP candidates per query (16 / 32 / 64): they wait in registers (read from memory inside the double loop the
+                       // kernel took 4.8 ms at 10^6 queries)
 __global__ __launch_bounds__(256) void knn_seed_kernel(const float* __restrict__ pre_d, const int* __restrict__ pre_i, int64_t nq, int64_t q_begin,
-                                                       int m, int k, const float* __restrict__ qnorm, const float* __restrict__ nrm,
+                                                       int k, const float* __restrict__ qnorm, const float* __restrict__ nrm,
                                                        const float* __restrict__ rmax_p, double cerr, int* __restrict__ gtau,
                                                        double* __restrict__ ub2) {
   const int64_t ql = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (ql >= nq) return;
-  const float* v = pre_d + ql * m;
-  const int* vi = pre_i + ql * m;
-  float vk = INFINITY;
-  for (int a = 0; a < m; ++a) {                 // the k-th smallest of m <= 64 values: the one with exactly k - 1 in front of it
-    const float x = v[a];
-    if (!(x < INFINITY) || vi[a] < 0) continue;
-    int before = 0;
-    for (int c = 0; c < m; ++c) {
-      const float y = v[c];
-      before += (vi[c] >= 0 && (y < x || (y == x && c < a))) ? 1 : 0;
+  float v[M];
+  {
+    const float4* pv = (const float4*)(pre_d + ql * M);
+    const int4* pi = (const int4*)(pre_i + ql * M);
+#pragma unroll
+    for (int u = 0; u < M / 4; ++u) {
+      const float4 a = pv[u];
+      const int4 b = pi[u];
+      v[4 * u + 0] = b.x >= 0 ? a.x : INFINITY;    // (an empty slot counts as +inf: never among the k smallest)
+      v[4 * u + 1] = b.y >= 0 ? a.y : INFINITY;
+      v[4 * u + 2] = b.z >= 0 ? a.z : INFINITY;
+      v[4 * u + 3] = b.w >= 0 ? a.w : INFINITY;
     }
-    if (before == k - 1) vk = x;
+  }
+  float vk = INFINITY;
+#pragma unroll
+  for (int a = 0; a < M; ++a) {                 // the k-th smallest of M values: the one with exactly k - 1 in front of it
+    const float x = v[a];
+    int before = 0;
+#pragma unroll
+    for (int c = 0; c < M; ++c) before += (v[c] < x || (v[c] == x && c < a)) ? 1 : 0;
+    if (x < INFINITY && before == k - 1) vk = x;
   }
   int key = 0x7f800000;                          // +inf: fewer than k candidates in the sample
   if (vk < INFINITY) {
@@ -1447,11 +1473,22 @@ __global__ __launch_bounds__(256) void knn_mean_kernel(const double* __restrict_
 }
 __global__ __launch_bounds__(256) void knn_maxnorm_kernel(const double* __restrict__ X, const double* __restrict__ mean, int64_t n, int d,
                                                           double* __restrict__ part) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // 256 rows per workgroup, sixteen lanes on a row (consecutive lanes on consecutive features: a thread walking its own row reads
+  // one value per 64 cache lines and made this pass 0.94 ms at 10^6 x 64); the lanes' partial sums meet in lane 0 of the sixteen
+  const int l16 = threadIdx.x & 15;
   double s = 0.0;
-  if (i < n)
-    for (int f = 0; f < d; ++f) { const double c = X[i * d + f] - mean[f]; s += c * c; }
-  if (!(s == s)) s = INFINITY;     // NaN input: reported as non-finite
+  for (int r = threadIdx.x >> 4; r < 256; r += 16) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + r;
+    double t = 0.0;
+    if (i < n)
+      for (int f = l16; f < d; f += 16) { const double c = X[i * d + f] - mean[f]; t += c * c; }
+    t += __shfl_xor(t, 1, 16);
+    t += __shfl_xor(t, 2, 16);
+    t += __shfl_xor(t, 4, 16);
+    t += __shfl_xor(t, 8, 16);
+    if (!(t == t)) t = INFINITY;   // NaN input: reported as non-finite
+    s = t > s ? t : s;
+  }
   __shared__ double sm[256];
   sm[threadIdx.x] = s;
   __syncthreads();
@@ -1851,8 +1888,16 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
       else if (KP == 16) rc = launch_tile_bf16_nkb<16>(NKB, b, n, q0, q1, seed_sub, st, cat, true);
       else rc = launch_tile_bf16_nkb<32>(NKB, b, n, q0, q1, seed_sub, st, cat, true);
       if (rc) return rc;
-      hipLaunchKernelGGL(knn_seed_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const float*)b.pre_d, (const int*)b.pre_i, nq, q0,
-                         2 * KP, k, (const float*)b.qnorm, (const float*)b.nrm, (const float*)b.rmax, cerr, b.gtau, b.ub2);
+      const dim3 sg((unsigned)((nq + 255) / 256));
+      if (KP == 8)
+        hipLaunchKernelGGL(knn_seed_kernel<16>, sg, dim3(256), 0, st, (const float*)b.pre_d, (const int*)b.pre_i, nq, q0, k, (const float*)b.qnorm,
+                           (const float*)b.nrm, (const float*)b.rmax, cerr, b.gtau, b.ub2);
+      else if (KP == 16)
+        hipLaunchKernelGGL(knn_seed_kernel<32>, sg, dim3(256), 0, st, (const float*)b.pre_d, (const int*)b.pre_i, nq, q0, k, (const float*)b.qnorm,
+                           (const float*)b.nrm, (const float*)b.rmax, cerr, b.gtau, b.ub2);
+      else
+        hipLaunchKernelGGL(knn_seed_kernel<64>, sg, dim3(256), 0, st, (const float*)b.pre_d, (const int*)b.pre_i, nq, q0, k, (const float*)b.qnorm,
+                           (const float*)b.nrm, (const float*)b.rmax, cerr, b.gtau, b.ub2);
       GLX_HIP(hipGetLastError());
     }
     if (cells && seeded) {
