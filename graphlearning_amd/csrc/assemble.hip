@@ -555,9 +555,12 @@ extern "C" int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, 
   const size_t shm = (size_t)4 * ROW_CAP * 16;
   GLX_HIP(hipFuncSetAttribute((const void*)merge_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const unsigned gr = (unsigned)((m + 3) / 4);
+  // (one pass into a scratch image, compacted below: see merge_rows_kernel mode 2)
+  GLX_POOL(glx_pool_alloc((void**)&b.tcol, std::max<size_t>((size_t)(m * k + n_rev) * 4, 4)));
+  GLX_POOL(glx_pool_alloc((void**)&b.tval, std::max<size_t>((size_t)(m * k + n_rev) * 8, 8)));
   hipLaunchKernelGGL(merge_rows_kernel, dim3(gr), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, m, k, k,
-                     (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 0, b.rowcnt, (const int64_t*)nullptr,
-                     (int*)nullptr, (double*)nullptr, b.flag + 1, row_base);
+                     (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 2, b.rowcnt, (const int64_t*)nullptr,
+                     b.tcol, b.tval, b.flag + 1, row_base);
   GLX_HIP(hipGetLastError());
   std::vector<int> rowcnt(m);
   GLX_HIP(hipMemcpyAsync(rowcnt.data(), b.rowcnt, m * 4, hipMemcpyDeviceToHost, st));
@@ -600,9 +603,8 @@ extern "C" int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, 
   GLX_HIP(hipMemcpyAsync(b.rowptr, rp.data(), (m + 1) * 8, hipMemcpyHostToDevice, st));
   GLX_POOL(glx_pool_alloc((void**)&b.col, std::max<size_t>(nnz * 4, 4)));
   GLX_POOL(glx_pool_alloc((void**)&b.val, std::max<size_t>(nnz * 8, 8)));
-  hipLaunchKernelGGL(merge_rows_kernel, dim3(gr), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, m, k, k,
-                     (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 1, b.rowcnt, (const int64_t*)b.rowptr,
-                     b.col, b.val, b.flag + 1, row_base);
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(gr), dim3(256), 0, st, (const int*)b.rowcnt, (const int64_t*)b.roff, m, k, sym, (const int64_t*)b.rowptr,
+                     (const int*)b.tcol, (const double*)b.tval, b.col, b.val);
   GLX_HIP(hipGetLastError());
   if (nh) {
     hipLaunchKernelGGL(merge_hub_kernel, dim3((unsigned)nh), dim3(1024), 0, st, (const int64_t*)b.ind, (const double*)b.w, k, k,
