@@ -1,5 +1,5 @@
 #!/bin/bash
-O=/root/repo/gpurun_out/r03ay
+O=/root/repo/gpurun_out/r03bj
 mkdir -p $O
 export TMPDIR=/tmp
 export HSA_ENABLE_IPC_MODE_LEGACY=0
