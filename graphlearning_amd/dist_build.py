@@ -170,9 +170,13 @@ def knn_weights_rows(J, D, k, kernel='gaussian'):
     if kernel == 'uniform':
         w = np.ones_like(D)
     elif kernel == 'gaussian':
-        sq = D * D
-        eps = sq[:, k - 1]
-        w = np.exp(-4 * sq / eps[:, None])
+        from .weightmatrix import _row_blocks
+        w = np.empty(D.shape, dtype=np.float64)
+
+        def rows(lo, hi):           # elementwise, so any split into row blocks gives the same bits (host threads: numpy frees the GIL)
+            sq = D[lo:hi] * D[lo:hi]
+            np.exp(-4 * sq / sq[:, k - 1][:, None], out=w[lo:hi])
+        _row_blocks(rows, D.shape[0])
     elif kernel == 'distance':
         w = D
     elif kernel == 'singular':
