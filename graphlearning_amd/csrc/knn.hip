@@ -358,9 +358,6 @@ __global__ void knn_prep_bf16_kernel(const double* __restrict__ X, const double*
 #define KNN_PACKED_SELECT 0   // measured (profiles/r03_knn_host.txt): v_pk_fma_f32 + nested minima change nothing at config 2 (1.46 ms either way) and cost 3-4 % at d >= 64
 #endif
 static const int KNN_CAT_SEG = 21;
-#ifndef KNN_SEED_SUB
-#define KNN_SEED_SUB 8    // the seeding pre-pass looks at every 8th ref tile (0 / 1: no pre-pass); run time: GLX_KNN_SEED
-#endif
 // fold (d <= 20: the slots 20, 41, 62 of the three segments are free): the ref image holds -2 x (exact) and, in the free slots,
 // |x|^2 as three bf16 pieces against ones in the query image -- the contraction then IS the selection value |r|^2 - 2 q.r and the
 // tile kernel needs neither the norms of the tile nor an fma per pair (measured by ablation: 11 % of the config-2 tile kernel)
@@ -449,7 +446,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
   // RUNS (the cell-pruned search, glx_knn_cells_range): this query block visits only the ref tiles of its runs
   // [runs[2 r], runs[2 r + 1]), r < nruns[block] (ascending, disjoint; knn_runs_kernel), not all of them
   // nsplit = the tile stride of a ref range; the number of ranges is the grid's y extent (equal in the search proper; the
-  // seeding pre-pass runs ONE range with a stride of KNN_SEED_SUB: every KNN_SEED_SUB-th tile, a sample of the refs)
+  // seeding pre-pass runs ONE range with a larger stride: every 8th tile, say -- a sample of the refs)
   constexpr int KPAD = 16 * NKB;
   constexpr int BR = 32 * NSUB * NSTG;
   constexpr int ROWB = 4 * KPAD + 16;                  // bytes per ref row in LDS: hi | lo, +16 so that 16 rows cover all 64 banks
@@ -836,7 +833,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
 }
 
 // ---- seeding: a threshold for every query BEFORE the search proper -----------------------------
-// The pre-pass ran the tile kernel over a sample of the refs (every KNN_SEED_SUB-th tile, one range: two lists per query).  Any k
+// The pre-pass ran the tile kernel over a sample of the refs (every 8th tile, say; one range: two lists per query).  Any k
 // distinct refs bound the k-th neighbour from above: with v_k = the k-th smallest filter value among the sample's candidates,
 // true dist^2 of those k refs <= v_k + eps, hence the exact k-th distance^2 dk2 <= v_k + eps.  The search proper starts every
 // list's threshold at seed = v_k + 4 eps (instead of +inf): a ref it rejects has filter value >= seed, i.e. true dist^2 >=
