@@ -1128,6 +1128,10 @@ __device__ __forceinline__ double sqdist_exact(const double* __restrict__ u, con
 __device__ __forceinline__ bool lex_less(double da, int ia, double db, int ib) { return da < db || (da == db && ia < ib); }
 
 // one workgroup of 64 threads per query; M (power of two) candidate slots sorted in LDS
+// R = candidate slots per lane (M = 64 R <= 512): the candidates stay in registers and are ranked by a bitonic network over the
+// wavefront -- partners 64 or more slots apart sit in the same lane, nearer ones are a lane exchange away -- without LDS arrays or
+// barriers; R = 0: the LDS network (longer lists).  The acceptance test takes one lane per list.
+template <int R>
 __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict__ X, int64_t n, int d, int k, int64_t q_begin,
                                                         int64_t nq, const float* __restrict__ cand_d, const int* __restrict__ cand_i,
                                                         int lists, int KP, int M, const float* __restrict__ qnorm, const float* __restrict__ rmax_p,
@@ -1141,6 +1145,7 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
   int* si = (int*)(sd + M);          // [M]
   const int64_t ql = blockIdx.x;
   if (ql >= nq) return;
+  const int lane = threadIdx.x;
   const int64_t q = q_begin + ql;
   const int ncand = lists * KP;
   const double* xq = X + q * d;
@@ -1177,9 +1182,9 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
   }
   __syncthreads();
   const double keep = prefilter ? (double)s_vk + 2.0 * eps0 + 1e-6 * fabs((double)s_vk) : INFINITY;
-  for (int c = threadIdx.x; c < M; c += 64) {
-    double dd = INFINITY;
-    int idx = 0x7fffffff;
+  auto exact_of = [&](int c, double& dd, int& idx) {
+    dd = INFINITY;
+    idx = 0x7fffffff;
     if (c < ncand && (!prefilter || (double)sv[c] <= keep)) {    // (an invalid slot holds +inf and is skipped unless nothing can be excluded)
       const int ci = cand_i[ql * ncand + c];
       if (ci >= 0 && ci < n) {
@@ -1187,43 +1192,96 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
         dd = sqdist_exact(xq, X + (int64_t)ci * d, d);
       }
     }
-    sd[c] = dd;
-    si[c] = idx;
-  }
-  __syncthreads();
-  for (int size = 2; size <= M; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = threadIdx.x; t < M / 2; t += 64) {
-        const int lo = (t / stride) * stride * 2 + (t % stride);
-        const int hi = lo + stride;
-        const bool up = ((lo & size) == 0);
-        const double dl = sd[lo], dh = sd[hi];
-        const int il = si[lo], ih = si[hi];
-        const bool sw = up ? lex_less(dh, ih, dl, il) : lex_less(dl, il, dh, ih);
-        if (sw) { sd[lo] = dh; sd[hi] = dl; si[lo] = ih; si[hi] = il; }
-      }
-      __syncthreads();
-    }
-  }
+  };
   const int64_t orow = orig ? (int64_t)orig[q] - q_begin : ql;
-  for (int c = threadIdx.x; c < k; c += 64) {
-    ind_out[orow * k + c] = si[c] == 0x7fffffff ? -1 : si[c];
-    dist_out[orow * k + c] = sqrt(sd[c]);
-  }
-  if (threadIdx.x == 0) {
-    // every ref outside a full list has fp32 dist^2 >= that list's threshold; accept the row
-    // only if no such ref can beat the exact k-th neighbour once the fp32 error is allowed for
-    const double dk2 = sd[k - 1];
-    const double rq = (double)qnorm[q] + (double)rmax_p[0];   // largest centred norm, reduced on the device (knn_rmax_kernel)
-    const double eps = cerr * rq * rq;
-    int bad = !(dk2 < INFINITY);
-    for (int l = 0; l < lists && !bad; ++l) {
-      float tau = 0.f;   // the list's threshold = its largest entry (lists arrive unsorted); INFINITY while not full
-      for (int p = 0; p < KP; ++p) tau = fmaxf(tau, cand_d[ql * ncand + l * KP + p]);
-      if (tau < INFINITY && !((double)tau >= dk2 + 2.0 * eps)) bad = 1;
+  double dk2;
+  if constexpr (R > 0) {
+    double rd[R];
+    int ri[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) exact_of(lane + 64 * r, rd[r], ri[r]);      // slot e = lane + 64 r
+#pragma unroll
+    for (int size = 2; size <= 64 * R; size <<= 1) {
+#pragma unroll
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        if (stride >= 64) {                       // partners in the same lane
+          const int rs = stride / 64;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            if ((r & rs) == 0) {
+              const int r2 = r | rs;
+              const bool up = (((lane + 64 * r) & size) == 0);
+              const bool sw = up ? lex_less(rd[r2], ri[r2], rd[r], ri[r]) : lex_less(rd[r], ri[r], rd[r2], ri[r2]);
+              const double td = sw ? rd[r2] : rd[r], ud = sw ? rd[r] : rd[r2];
+              const int ti = sw ? ri[r2] : ri[r], ui = sw ? ri[r] : ri[r2];
+              rd[r] = td; ri[r] = ti; rd[r2] = ud; ri[r2] = ui;
+            }
+          }
+        } else {                                  // partners a lane exchange away
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int lo = __shfl_xor(__double2loint(rd[r]), stride), hi = __shfl_xor(__double2hiint(rd[r]), stride);
+            const double od = __hiloint2double(hi, lo);
+            const int oi = __shfl_xor(ri[r], stride);
+            const bool up = (((lane + 64 * r) & size) == 0), lower = (lane & stride) == 0;
+            const bool mine_first = lex_less(rd[r], ri[r], od, oi);
+            const bool take_min = lower == up;
+            const bool keep_mine = take_min ? mine_first : !mine_first;
+            rd[r] = keep_mine ? rd[r] : od;
+            ri[r] = keep_mine ? ri[r] : oi;
+          }
+        }
+      }
     }
-    flags[ql] = bad;
+    // slots 0 .. k - 1 (k <= 60 < 64) are lanes 0 .. k - 1 of register 0
+    if (lane < k) {
+      ind_out[orow * k + lane] = ri[0] == 0x7fffffff ? -1 : ri[0];
+      dist_out[orow * k + lane] = sqrt(rd[0]);
+    }
+    {
+      const int lo = __shfl(__double2loint(rd[0]), k - 1), hi = __shfl(__double2hiint(rd[0]), k - 1);
+      dk2 = __hiloint2double(hi, lo);
+    }
+  } else {
+    for (int c = threadIdx.x; c < M; c += 64) {
+      double dd;
+      int idx;
+      exact_of(c, dd, idx);
+      sd[c] = dd;
+      si[c] = idx;
+    }
+    __syncthreads();
+    for (int size = 2; size <= M; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = threadIdx.x; t < M / 2; t += 64) {
+          const int lo = (t / stride) * stride * 2 + (t % stride);
+          const int hi = lo + stride;
+          const bool up = ((lo & size) == 0);
+          const double dl = sd[lo], dh = sd[hi];
+          const int il = si[lo], ih = si[hi];
+          const bool sw = up ? lex_less(dh, ih, dl, il) : lex_less(dl, il, dh, ih);
+          if (sw) { sd[lo] = dh; sd[hi] = dl; si[lo] = ih; si[hi] = il; }
+        }
+        __syncthreads();
+      }
+    }
+    for (int c = threadIdx.x; c < k; c += 64) {
+      ind_out[orow * k + c] = si[c] == 0x7fffffff ? -1 : si[c];
+      dist_out[orow * k + c] = sqrt(sd[c]);
+    }
+    dk2 = sd[k - 1];
   }
+  // every ref outside a full list has fp32 dist^2 >= that list's threshold; accept the row only if no such ref can beat the exact
+  // k-th neighbour once the fp32 error is allowed for.  One lane per list (the lists' thresholds = their largest entries: they
+  // arrive unsorted; INFINITY while a list is not full)
+  int bad = 0;
+  for (int l = lane; l < lists; l += 64) {
+    float tau = 0.f;
+    for (int p = 0; p < KP; ++p) tau = fmaxf(tau, cand_d[ql * ncand + l * KP + p]);
+    if (tau < INFINITY && !((double)tau >= dk2 + 2.0 * eps0)) bad = 1;
+  }
+  bad = __any(bad) || !(dk2 < INFINITY);
+  if (lane == 0) flags[ql] = bad;
 }
 
 // ---- stage 3: exact fp64 fallback for flagged rows --------------------------------------------
@@ -1937,9 +1995,16 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     GLX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_cnt), c, sizeof(c)));
   }
 #endif
-  hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)nq), dim3(64), (size_t)M * 16, st, (const double*)b.X, n, d, k, q0, nq,
-                     (const float*)b.cand_d, (const int*)b.cand_i, lists, KP, M, (const float*)b.qnorm, (const float*)b.rmax, cerr, b.ind, b.dist,
-                     b.flags, (const int*)b.orig, d >= 48 ? 1 : 0);
+#define GLX_RERANK(RR)                                                                                                                    \
+  hipLaunchKernelGGL(knn_rerank_kernel<RR>, dim3((unsigned)nq), dim3(64), (size_t)M * 16, st, (const double*)b.X, n, d, k, q0, nq,          \
+                     (const float*)b.cand_d, (const int*)b.cand_i, lists, KP, M, (const float*)b.qnorm, (const float*)b.rmax, cerr, b.ind, b.dist, \
+                     b.flags, (const int*)b.orig, d >= 48 ? 1 : 0)
+  if (M == 64) GLX_RERANK(1);
+  else if (M == 128) GLX_RERANK(2);
+  else if (M == 256) GLX_RERANK(4);
+  else if (M == 512) GLX_RERANK(8);
+  else GLX_RERANK(0);
+#undef GLX_RERANK
   GLX_HIP(hipGetLastError());
   GLX_HIP(hipEventRecord(b.e2, st));
   std::vector<int> flags(nq);
