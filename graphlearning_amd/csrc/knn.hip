@@ -508,30 +508,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
   // sorted (by class, along a curve, by a locality order): a query's neighbours are then neighbours in index too, a contiguous
   // range would put all of them into the two lists of one range and overflow them (29 % of the rows of locality-ordered
   // config-4 data took the exact fallback); interleaved, any 32 * nsplit consecutive refs are spread over all the lists
-  const int64_t t1 = ntiles;
+  const int t1 = (int)ntiles;         // (tile numbers fit 32 bits -- ref indices do, cand_i is int --: scalar compares instead of 64-bit vector ones)
   // the tile iterator: tiles congruent to sp modulo nsplit, of all tiles or of the block's runs (wave-uniform arithmetic)
   int run = -1, nrun = 0;
-  int64_t run_b = 0;
+  int run_b = 0;
   const int* myruns = nullptr;
   if constexpr (RUNS) {
     myruns = runs + qb * 2 * (int64_t)maxruns;
     nrun = nruns[qb];
   }
-  auto next_tile = [&](int64_t tc) -> int64_t {
-    int64_t tn = tc + nsplit;
+  auto next_tile = [&](int tc) -> int {
+    int tn = tc + nsplit;
     if constexpr (RUNS) {
       while (tn >= run_b) {
         if (++run >= nrun) return -1;
-        const int64_t a = myruns[2 * run];
+        const int a = myruns[2 * run];
         run_b = myruns[2 * run + 1];
-        tn = a + (sp - a % nsplit + nsplit) % nsplit;
+        tn = a + ((int)sp - a % nsplit + nsplit) % nsplit;
       }
       return tn;
     } else {
       return tn < t1 ? tn : -1;
     }
   };
-  const int64_t t0 = RUNS ? next_tile(-(int64_t)nsplit) : (sp < t1 ? (int64_t)sp : -1);
+  const int t0 = RUNS ? next_tile(-nsplit) : ((int)sp < t1 ? (int)sp : -1);
   uint4 pre[UNITS];
   float pre_rn = 0.f;
   auto stage_load = [&](int64_t t) {
@@ -541,10 +541,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
       const int u = tid + i * 256;
       const int r = u / U_ROW, c = u % U_ROW;
       uint4 v = {0u, 0u, 0u, 0u};
-      if (EXACT_UNITS || u < BR * U_ROW) v = *(const uint4*)(Xb + (t * BR + r) * 2 * KPAD + c * 8);
+      (void)r; (void)c;
+      // (the rows of a tile are contiguous: a wave-uniform tile base + a 32-bit lane offset, no 64-bit vector address arithmetic)
+      if (EXACT_UNITS || u < BR * U_ROW) v = *(const uint4*)((const char*)Xb + t * (int64_t)(BR * 4 * KPAD) + (unsigned)(u * 16));
       pre[i] = v;
     }
-    if (tid < BR) {
+    if (CAT != 2 && tid < BR) {       // (CAT == 2: the norm is part of the contraction)
       const int64_t ref = t * BR + tid;
       pre_rn = nrm[ref];
     }
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
       const int u = tid + i * 256;
       if (EXACT_UNITS || u < BR * U_ROW) *(uint4*)(dst + (u / U_ROW) * ROWB + (u % U_ROW) * 16) = pre[i];
     }
-    if (tid < BR) rn[buf * BR + tid] = pre_rn;
+    if (CAT != 2 && tid < BR) rn[buf * BR + tid] = pre_rn;
   };
   int cnt = 0;
   float tau_own = INFINITY;
@@ -618,13 +620,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
     }
     cnt = 0;
     // lanes l and l^32 serve the same query (same |q|^2 offset); never above what is already known (the seed, published thresholds)
+    const float tau_was = tau;
     tau = fminf(tau, fminf(tau_own, __shfl_xor(tau_own, 32)));
 #if KNN_GTAU
     // the query's lists of the OTHER ref ranges run in other workgroups: the smallest threshold any of them has reached is
     // published per query (an ordered-int image of the float, atomicMin) and adopted here.  Sound for the same reason the pair's
     // minimum is: whatever a list rejects lies above the smallest FINAL threshold of the query's lists, which is what the
     // acceptance test of the re-rank compares with the exact k-th distance.
-    if (tau < INFINITY && q < q_end) {
+    if (tau < tau_was && q < q_end) {       // (only a threshold that moved: the atomic's round trip is a stall of the whole wavefront)
       int key = __float_as_int(tau);
       key ^= (key >> 31) & 0x7fffffff;
       const int old = atomicMin(&gtau[q - q_begin], key);
@@ -664,13 +667,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
         }
     }
   };
-  int64_t t = t0, tn = -1;
+  int t = t0, tn = -1;
   if constexpr (DIRECT) { if (t0 >= 0) direct_load(t0, fa); }
   auto tile_body = [&](uint4 (&cur)[DIRECT ? NF : 1], uint4 (&nxt)[DIRECT ? NF : 1]) {
     tn = next_tile(t);
     const bool has_next = tn >= 0;
 #if KNN_GTAU
-    if ((it & 15) == 15 && q < q_end) {
+    if ((it & 15) == 15) if (q < q_end) {
       int best = gtau[q - q_begin];
       best ^= (best >> 31) & 0x7fffffff;
       tau = fminf(tau, __int_as_float(best));
@@ -723,8 +726,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
 #pragma unroll
       for (int eg = 0; eg < 4; ++eg) {
         if constexpr (CAT == 2) {     // the accumulator already is |r|^2 - 2 q.r
-          m4[sub][eg] = fminf(fminf(acc[sub][eg * 4 + 0], acc[sub][eg * 4 + 1]), fminf(acc[sub][eg * 4 + 2], acc[sub][eg * 4 + 3]));
-          m = fminf(m, m4[sub][eg]);
+          // (written as ONE chain ending in +inf: two v_min3_f32 on the raw accumulators.  A two-input minimum of raw MFMA results
+          // costs a v_max_f32 x, x per input first -- the compiler quiets possible signalling NaNs for v_min_f32, not for
+          // v_min3_f32: 37 -> 20 vector instructions per wave-tile for this reduction)
+          m4[sub][eg] = fminf(fminf(fminf(fminf(acc[sub][eg * 4 + 0], acc[sub][eg * 4 + 1]), acc[sub][eg * 4 + 2]), acc[sub][eg * 4 + 3]), INFINITY);
           continue;
         }
         const float4 r4 = *(const float4*)(rnb + sub * 32 + 8 * eg + 4 * h);
@@ -751,6 +756,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
 #endif
         m = fminf(m, m4[sub][eg]);
       }
+    if constexpr (CAT == 2) {
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) m = fminf(fminf(fminf(fminf(m, m4[sub][0]), m4[sub][1]), m4[sub][2]), m4[sub][3]);
+    }
 #if KNN_ABLATE & 1
     abl_sink = fminf(abl_sink, m);  // developer probe: no list maintenance (the minimum is kept alive: without a use the
     if (false) {                    // compiler removes the whole contraction, as the first version of this probe found out)
