@@ -517,23 +517,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
     myruns = runs + qb * 2 * (int64_t)maxruns;
     nrun = nruns[qb];
   }
-  auto next_tile = [&](int tc) -> int {
+  auto next_tile = [&](int tc) -> int {       // t1 (or beyond) = no further tile
     int tn = tc + nsplit;
     if constexpr (RUNS) {
       while (tn >= run_b) {
-        if (++run >= nrun) return -1;
+        if (++run >= nrun) return t1;
         const int a = myruns[2 * run];
         run_b = myruns[2 * run + 1];
         tn = a + ((int)sp - a % nsplit + nsplit) % nsplit;
       }
-      return tn;
-    } else {
-      return tn < t1 ? tn : -1;
     }
+    return tn;
   };
-  const int t0 = RUNS ? next_tile(-nsplit) : ((int)sp < t1 ? (int)sp : -1);
+  const int t0 = RUNS ? next_tile(-nsplit) : (int)sp;
   uint4 pre[UNITS];
   float pre_rn = 0.f;
+  // the lane's first 16-byte unit of tile 0, +2048: with -2048 in the instruction the 13-bit signed offset field reaches the unit
+  // at +4096 as well (one 64-bit address computation per tile instead of two; opaque to the compiler, which would fold it back)
+  const char* lane_base = (const char*)Xb + (unsigned)(tid * 16 + 2048);
+  asm volatile("" : "+v"(lane_base));
   auto stage_load = [&](int64_t t) {
     // no bounds predicates: Xb / nrm carry KNN_PAD_ROWS spare rows (zero features, norm 1e30) behind the data
 #pragma unroll
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
       uint4 v = {0u, 0u, 0u, 0u};
       (void)r; (void)c;
       // (the rows of a tile are contiguous: a wave-uniform tile base + a 32-bit lane offset, no 64-bit vector address arithmetic)
-      if (EXACT_UNITS || u < BR * U_ROW) v = *(const uint4*)((const char*)Xb + t * (int64_t)(BR * 4 * KPAD) + (unsigned)(u * 16));
+      if (EXACT_UNITS || u < BR * U_ROW) v = *(const uint4*)(lane_base + t * (int64_t)(BR * 4 * KPAD) + (i * 4096 - 2048));
       pre[i] = v;
     }
     if (CAT != 2 && tid < BR) {       // (CAT == 2: the norm is part of the contraction)
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
     KNN_TOC(cy_comp, tc);
   };
   if (!(KNN_DIRECT && CAT == 2 && NSTG == 1)) {
-    if (t0 >= 0) { stage_load(t0); stage_store(0); }
+    if (t0 < t1) { stage_load(t0); stage_store(0); }
     __syncthreads();
   }
   int buf = 0;
@@ -668,13 +670,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
     }
   };
   int t = t0, tn = -1;
-  if constexpr (DIRECT) { if (t0 >= 0) direct_load(t0, fa); }
+  if constexpr (DIRECT) { if (t0 < t1) direct_load(t0, fa); }
   auto tile_body = [&](uint4 (&cur)[DIRECT ? NF : 1], uint4 (&nxt)[DIRECT ? NF : 1]) {
     tn = next_tile(t);
-    const bool has_next = tn >= 0;
+    const bool has_next = tn < t1;
 #if KNN_GTAU
-    if ((it & 15) == 15) if (q < q_end) {
-      int best = gtau[q - q_begin];
+    if ((it & 15) == 15) {        // (every lane reads -- rows past q_end their clamped query's --: a scalar branch, no exec-mask bookkeeping per tile)
+      int best = gtau[qc - q_begin];
       best ^= (best >> 31) & 0x7fffffff;
       tau = fminf(tau, __int_as_float(best));
     }
@@ -807,10 +809,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
     t = tn;
     ++it;
   };
-  while (t >= 0) {
+  while (t < t1) {
     tile_body(fa, fb);
     if constexpr (DIRECT) {
-      if (t < 0) break;
+      if (t >= t1) break;
       tile_body(fb, fa);
     }
   }
