@@ -1176,8 +1176,8 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
     sv[c] = v;
   }
   if (prefilter) __syncthreads();
-  // (prefilter: from 48 features on -- below that the rank count costs more than the gathers it saves: measured 0.22 -> 0.29 ms at
-  // d = 20, 2.13 -> 1.04 ms at d = 128)
+  // (prefilter: from 32 features on -- measured with the LDS sort of round 2: 0.22 -> 0.29 ms at d = 20, 2.13 -> 1.04 ms at
+  // d = 128; with the register sort: d = 20 0.12 ms either way, d = 32 (config 3) 0.31 -> 0.26 ms.  GLX_KNN_PREFILTER_D moves it)
   __shared__ float s_vk;
   if (threadIdx.x == 0) s_vk = INFINITY;
   if (prefilter) __syncthreads();
@@ -2006,10 +2006,11 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     GLX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_cnt), c, sizeof(c)));
   }
 #endif
+  static const int prefilter_from = getenv("GLX_KNN_PREFILTER_D") ? atoi(getenv("GLX_KNN_PREFILTER_D")) : 32;
 #define GLX_RERANK(RR)                                                                                                                    \
   hipLaunchKernelGGL(knn_rerank_kernel<RR>, dim3((unsigned)nq), dim3(64), (size_t)M * 16, st, (const double*)b.X, n, d, k, q0, nq,          \
                      (const float*)b.cand_d, (const int*)b.cand_i, lists, KP, M, (const float*)b.qnorm, (const float*)b.rmax, cerr, b.ind, b.dist, \
-                     b.flags, (const int*)b.orig, d >= 48 ? 1 : 0)
+                     b.flags, (const int*)b.orig, d >= prefilter_from ? 1 : 0)
   if (M == 64) GLX_RERANK(1);
   else if (M == 128) GLX_RERANK(2);
   else if (M == 256) GLX_RERANK(4);
