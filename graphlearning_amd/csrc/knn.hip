@@ -354,6 +354,9 @@ __global__ void knn_prep_bf16_kernel(const double* __restrict__ X, const double*
 // Concatenated split operands for d <= 21 (round 3): hi.hi + hi.lo + lo.hi is ONE contraction of length 3 d <= 63 when the
 // ref image is [rh | rh | rl] and the query image [qh | ql | qh] -- 64 bf16 per row, the size of the [hi(32) | lo(32)] rows the
 // NKB = 2 kernel stages, so four MFMAs of K = 16 do the work of the six the block form needs (hi and lo blocks padded to 32).
+#ifndef KNN_NORMS_FIRST
+#define KNN_NORMS_FIRST 1
+#endif
 #ifndef KNN_PACKED_SELECT
 #define KNN_PACKED_SELECT 0   // measured (profiles/r03_knn_host.txt): v_pk_fma_f32 + nested minima change nothing at config 2 (1.46 ms either way) and cost 3-4 % at d >= 64
 #endif
@@ -532,10 +535,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
   const int t0 = RUNS ? next_tile(-nsplit) : (int)sp;
   uint4 pre[UNITS];
   float pre_rn = 0.f;
-  // the lane's first 16-byte unit of tile 0, +2048: with -2048 in the instruction the 13-bit signed offset field reaches the unit
-  // at +4096 as well (one 64-bit address computation per tile instead of two; opaque to the compiler, which would fold it back)
-  const char* lane_base = (const char*)Xb + (unsigned)(tid * 16 + 2048);
-  asm volatile("" : "+v"(lane_base));
+  // the lane's first 16-byte unit within a tile, +2048: with -2048 in the instruction the 13-bit signed offset field reaches the unit
+  // at +4096 as well (a scalar tile base + this 32-bit lane offset + an immediate; opaque to the compiler, which would fold it back)
+  unsigned lane_off = (unsigned)(tid * 16 + 2048);       // (the OFFSET is made opaque, not the pointer: a laundered pointer loses its
+  asm volatile("" : "+v"(lane_off));                     //  address space and the loads become flat_load, which LDS waits then wait for)
   auto stage_load = [&](int64_t t) {
     // no bounds predicates: Xb / nrm carry KNN_PAD_ROWS spare rows (zero features, norm 1e30) behind the data
 #pragma unroll
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
       uint4 v = {0u, 0u, 0u, 0u};
       (void)r; (void)c;
       // (the rows of a tile are contiguous: a wave-uniform tile base + a 32-bit lane offset, no 64-bit vector address arithmetic)
-      if (EXACT_UNITS || u < BR * U_ROW) v = *(const uint4*)(lane_base + t * (int64_t)(BR * 4 * KPAD) + (i * 4096 - 2048));
+      if (EXACT_UNITS || u < BR * U_ROW) v = *(const uint4*)((const char*)Xb + t * (int64_t)(BR * 4 * KPAD) + (size_t)lane_off + (i * 4096 - 2048));
       pre[i] = v;
     }
     if (CAT != 2 && tid < BR) {       // (CAT == 2: the norm is part of the contraction)
@@ -694,6 +697,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
     for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[sub][e] = 0.f;     // (the first MFMA of a chain takes the constant 0 as its C operand)
+    // the tile's norms, read IN FRONT of the contraction: behind it (where they are used) every one of the 4 NSUB reads was a
+    // round trip of its own -- ds_read_b128, s_waitcnt lgkmcnt(0), four fmas, next read -- with the matrix pipe idle
+    float4 r4s[(CAT != 2 && KNN_NORMS_FIRST) ? NSUB : 1][4];
+    if constexpr (CAT != 2 && KNN_NORMS_FIRST) {
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+        for (int eg = 0; eg < 4; ++eg) r4s[sub][eg] = *(const float4*)(rnb + sub * 32 + 8 * eg + 4 * h);
+    }
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
@@ -734,7 +746,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KNN_REGLIS
           m4[sub][eg] = fminf(fminf(fminf(fminf(acc[sub][eg * 4 + 0], acc[sub][eg * 4 + 1]), acc[sub][eg * 4 + 2]), acc[sub][eg * 4 + 3]), INFINITY);
           continue;
         }
-        const float4 r4 = *(const float4*)(rnb + sub * 32 + 8 * eg + 4 * h);
+        const float4 r4 = KNN_NORMS_FIRST ? r4s[KNN_NORMS_FIRST ? sub : 0][eg] : *(const float4*)(rnb + sub * 32 + 8 * eg + 4 * h);
 #if KNN_PACKED_SELECT
         // two fp32 fmas per instruction (v_pk_fma_f32 on adjacent accumulator registers) and three-input minima (v_min3_f32):
         // the same values, half the vector instructions of the per-element form -- at K <= 64 the selection, not the
