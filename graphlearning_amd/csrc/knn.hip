@@ -358,7 +358,8 @@ __global__ void knn_prep_bf16_kernel(const double* __restrict__ X, const double*
 #define KNN_NORMS_FIRST 1
 #endif
 #ifndef KNN_PACKED_SELECT
-#define KNN_PACKED_SELECT 0   // measured (profiles/r03_knn_host.txt): v_pk_fma_f32 + nested minima change nothing at config 2 (1.46 ms either way) and cost 3-4 % at d >= 64
+#define KNN_PACKED_SELECT 0   // measured (profiles/r03_knn_host.txt): v_pk_fma_f32 + nested minima change nothing at config 2 (1.46 ms either way) and cost 3-4 % at d >= 64;
+                              // again with the norms read in front of the contraction (scripts/r03_run69.sh): config 3 1.72 vs 1.71 ms, n = 1e6 39.9 vs 38.3 ms
 #endif
 static const int KNN_CAT_SEG = 21;
 // fold (d <= 20: the slots 20, 41, 62 of the three segments are free): the ref image holds -2 x (exact) and, in the free slots,
