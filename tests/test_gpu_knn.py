@@ -388,3 +388,34 @@ def test_clustered_search_hands_its_cell_order_to_the_operator(gl, monkeypatch):
     u2 = m2.fit(ti, lab[ti])
     assert m1.num_iter == m2.num_iter and np.array_equal(u1, u2)
     assert not np.array_equal(m1._operators()[0].order(), m2._operators()[0].order())     # (two different vertex orders were in use)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k,nsplit,short', [(8, 4, '1'), (11, 8, '1'), (21, 8, '1'), (40, 8, '1'), (11, 2, '0'), (28, 4, '0'), (60, 8, '0')])
+def test_rerank_every_candidate_width(gl, monkeypatch, k, nsplit, short):
+    """The re-rank ranks a query's candidates in registers (one to eight per lane: 64 .. 512 candidates) or, beyond that, in LDS
+    (1024: 16 lists of 64): every width against cKDTree's lists -- ties by (distance, index) included, the data has duplicates.
+    GLX_KNN_NSPLIT / GLX_KNN_SHORT pick the number and the length of the lists (reference weightmatrix.py:297-429)."""
+    from graphlearning_amd import _hip
+    from oracle import gl_oracle as orc
+    monkeypatch.setenv('GLX_KNN_NSPLIT', str(nsplit))
+    monkeypatch.setenv('GLX_KNN_SHORT', short)
+    rng = np.random.default_rng(900 + k)
+    n, d = 5000, 24
+    X = rng.normal(size=(8, d))[rng.integers(0, 8, size=n)] * 2.0 + rng.normal(size=(n, d))
+    X[n - 200:] = X[:200]                                     # exact duplicates: ties at distance 0 and beyond
+    J, D = gl.weightmatrix.knnsearch(X, k)
+    st = _hip.knn_stats()
+    Jo, Do = orc.knnsearch(X, k)
+    Jo, Do = Jo.reshape(n, -1), Do.reshape(n, -1)
+    assert np.max(np.abs(D - Do)) <= 1e-12 * max(1.0, float(np.max(Do)))
+    # duplicates make cKDTree's order among equal distances arbitrary: the lists agree as sets wherever the k-th distance is not tied
+    for i in np.flatnonzero(np.any(J != Jo, axis=1)):
+        assert np.array_equal(np.sort(D[i]), np.sort(Do[i]))
+        untied = D[i] < D[i, -1]
+        assert set(J[i][untied]) == set(Jo[i][Do[i] < Do[i, -1]]), i
+    # ours: ties in ascending index order
+    same = (D[:, 1:] == D[:, :-1])
+    assert np.all(J[:, 1:][same] > J[:, :-1][same])
+    ncand = int(abs(st['KP'])) * 2 * int(st['nsplit'])
+    assert ncand in (64, 128, 256, 512, 1024), (st['KP'], st['nsplit'])
