@@ -87,16 +87,23 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restri
                                                          const unsigned short* __restrict__ rpos, const double* __restrict__ rw, int sym,
                                                          int mode, int* __restrict__ rowcnt,
                                                          const int64_t* __restrict__ rowptr, int* __restrict__ col_out,
-                                                         double* __restrict__ val_out, int* __restrict__ overflow, int64_t row_base = 0) {
+                                                         double* __restrict__ val_out, int* __restrict__ overflow, int64_t row_base = 0,
+                                                         int m_lo = 0, const int* __restrict__ rowlist = nullptr, int nlist = 0) {
+  // m_lo: rows of at most m_lo entries are merge_rows_small_kernel's (mode 2 only); rowlist: only these rows (the others are)
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long* key = (unsigned long long*)sm + (size_t)wave * ROW_CAP;                 // (col << 32) | (tag << 16) | seq
   double* val = (double*)(sm + (size_t)4 * ROW_CAP * 8) + (size_t)wave * ROW_CAP;
-  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (rowlist) {
+    if (i >= nlist) return;
+    i = rowlist[i];
+  }
   if (i >= n) return;
   const int rc = sym == SYM_NONE ? 0 : (int)(roff[i + 1] - roff[i]);
   const int M = k + rc;
+  if (M <= m_lo) return;
   if (M > ROW_CAP) {   // hub vertex: merge_hub_kernel's
     if (lane == 0 && mode != 1) { rowcnt[i] = -1; *overflow = 1; }
     return;
@@ -172,6 +179,84 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(const int64_t* __restri
     kept_before += __popcll(mask);
   }
   if (mode != 1 && lane == 0) rowcnt[i] = kept_before;
+}
+
+// The same merge for rows of at most 64 entries (forward + reverse) -- all of them unless the graph has popular vertices --, mode 2
+// only: one entry per lane, sorted by a bitonic network over the wavefront in REGISTERS (keys only: the source lane rides in the
+// key's low bits and the value is fetched from it afterwards), 4 KB of LDS per workgroup for the segment pass instead of the 64 KB
+// the general kernel sizes for ROW_CAP entries (two workgroups per CU, 21 LDS passes with a barrier each: 0.24 ms of the 1.2 ms
+// assembly at config 2).  Rows above 64 entries are left to merge_rows_kernel (m_lo = 64).
+__global__ __launch_bounds__(256) void merge_rows_small_kernel(const int64_t* __restrict__ ind, const double* __restrict__ w, int64_t n, int kk,
+                                                               int k, const int64_t* __restrict__ roff, const int* __restrict__ rsrc,
+                                                               const unsigned short* __restrict__ rpos, const double* __restrict__ rw, int sym,
+                                                               int* __restrict__ rowcnt, int* __restrict__ col_out,
+                                                               double* __restrict__ val_out, int64_t row_base) {
+#pragma clang fp contract(off)
+  __shared__ unsigned long long s_key[4][64];
+  __shared__ double s_val[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  const int rc = sym == SYM_NONE ? 0 : (int)(roff[i + 1] - roff[i]);
+  const int M = k + rc;
+  if (M > 64) return;
+  // key: column | tag (0 forward, 1 reverse) | position in the source row | lane -- (column, tag, position) is unique, so the
+  // order is that of merge_rows_kernel's (col << 32) | (tag << 16) | seq
+  unsigned long long kx = ~0ull;
+  double v = 0.0;
+  if (lane < k) {
+    kx = ((unsigned long long)(unsigned)ind[i * kk + lane] << 32) | (0ull << 22) | ((unsigned long long)(unsigned)lane << 6) | (unsigned)lane;
+    v = w[i * k + lane];
+  } else if (lane < M) {
+    const int64_t p = roff[i] + (lane - k);
+    kx = ((unsigned long long)(unsigned)rsrc[p] << 32) | (1ull << 22) | ((unsigned long long)rpos[p] << 6) | (unsigned)lane;
+    v = rw[p];
+  }
+#pragma unroll
+  for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const unsigned lo = __shfl_xor((unsigned)(kx & 0xffffffffull), stride), hi = __shfl_xor((unsigned)(kx >> 32), stride);
+      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+      const bool up = (lane & size) == 0, lower = (lane & stride) == 0;
+      const bool take_min = lower == up;
+      kx = (take_min == (o < kx)) ? o : kx;
+    }
+  }
+  {
+    const int src = (int)(kx & 63);                   // (padding keys point at lane 63: its value is 0 and never read)
+    const int vlo = __shfl(__double2loint(v), src), vhi = __shfl(__double2hiint(v), src);
+    s_key[wave][lane] = kx;
+    s_val[wave][lane] = __hiloint2double(vhi, vlo);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const unsigned long long* key = s_key[wave];
+  const double* val = s_val[wave];
+  const int64_t obase = i * (int64_t)k + (sym == SYM_NONE ? 0 : roff[i]);
+  bool keep = false;
+  int c = 0;
+  double vv = 0.0;
+  if (lane < M) {
+    c = (int)(key[lane] >> 32);
+    const bool head = lane == 0 || (int)(key[lane - 1] >> 32) != c;
+    if (head) {
+      double a = 0.0, b = 0.0;   // a = A[i,c] (forward, duplicates summed), b = A[c,i] (reverse)
+      for (int q = lane; q < M && (int)(key[q] >> 32) == c; ++q) {
+        if ((key[q] >> 22) & 1) b = b + val[q]; else a = a + val[q];
+      }
+      vv = combine_entry(a, b, sym);
+      keep = (c != (int)(i + row_base)) && (vv != 0.0);      // setdiag(0); eliminate_zeros(), weightmatrix.py:185-186
+    }
+  }
+  const unsigned long long mask = __ballot(keep);
+  if (keep) {
+    const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+    col_out[obase + pos] = c;
+    val_out[obase + pos] = vv;
+  }
+  if (lane == 0) rowcnt[i] = __popcll(mask);
 }
 
 // rows of the scratch image of merge_rows_kernel's mode 2 to their place in the CSR arrays (hub rows, rowcnt < 0, are written by
@@ -288,6 +373,7 @@ struct AsmBufs {
   unsigned short* rpos = nullptr;
   double *dist = nullptr, *given = nullptr, *w = nullptr, *rw = nullptr, *val = nullptr, *sval = nullptr;
   int *rcnt = nullptr, *cursor = nullptr, *rsrc = nullptr, *rowcnt = nullptr, *col = nullptr, *flag = nullptr, *hub_cnt = nullptr;
+  int* biglist = nullptr;        // rows above 64 entries (merge_rows_kernel's share when merge_rows_small_kernel runs)
   int* tcol = nullptr;           // scratch image of the one-pass merge (merge_rows_kernel mode 2)
   double* tval = nullptr;
   glx_work* work = nullptr;      // the device's cached stream
@@ -297,7 +383,7 @@ struct AsmBufs {
     glx_pool_free(ind); glx_pool_free(roff); glx_pool_free(rowptr); glx_pool_free(dist); glx_pool_free(given); glx_pool_free(w); glx_pool_free(rw); glx_pool_free(val);
     glx_pool_free(rcnt); glx_pool_free(cursor); glx_pool_free(rsrc); glx_pool_free(rowcnt); glx_pool_free(col); glx_pool_free(flag);
     glx_pool_free(hub_row); glx_pool_free(hub_off); glx_pool_free(skey); glx_pool_free(sval); glx_pool_free(hub_cnt); glx_pool_free(rpos);
-    glx_pool_free(tcol); glx_pool_free(tval);
+    glx_pool_free(tcol); glx_pool_free(tval); glx_pool_free(biglist);
     glx_work_release(work);
   }
 };
@@ -370,9 +456,29 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
   const unsigned gr = (unsigned)((n + 3) / 4);
   GLX_POOL(glx_pool_alloc((void**)&b.tcol, (size_t)(2 * ne) * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.tval, (size_t)(2 * ne) * 8));
-  hipLaunchKernelGGL(merge_rows_kernel, dim3(gr), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, n, kk, k,
-                     (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 2, b.rowcnt, (const int64_t*)nullptr,
-                     b.tcol, b.tval, b.flag + 1);
+  {
+    // rows of at most 64 entries: the register kernel; the general one only when some row has more (the host has the counts)
+    const bool small_rows = k <= 64;
+    std::vector<int> big;          // rows above 64 entries (popular vertices): the general kernel's, one wavefront each
+    if (small_rows && sym != SYM_NONE)
+      for (int64_t i = 0; i < n; ++i)
+        if (k + rcnt[i] > 64) big.push_back((int)i);
+    if (small_rows)
+      hipLaunchKernelGGL(merge_rows_small_kernel, dim3(gr), dim3(256), 0, st, (const int64_t*)b.ind, (const double*)b.w, n, kk, k,
+                         (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, b.rowcnt,
+                         b.tcol, b.tval, (int64_t)0);
+    if (!small_rows) {
+      hipLaunchKernelGGL(merge_rows_kernel, dim3(gr), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, n, kk, k,
+                         (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 2, b.rowcnt, (const int64_t*)nullptr,
+                         b.tcol, b.tval, b.flag + 1, (int64_t)0);
+    } else if (!big.empty()) {
+      GLX_POOL(glx_pool_alloc((void**)&b.biglist, big.size() * 4));
+      GLX_HIP(hipMemcpyAsync(b.biglist, big.data(), big.size() * 4, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(merge_rows_kernel, dim3((unsigned)((big.size() + 3) / 4)), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, n, kk, k,
+                         (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 2, b.rowcnt, (const int64_t*)nullptr,
+                         b.tcol, b.tval, b.flag + 1, (int64_t)0, 64, (const int*)b.biglist, (int)big.size());
+    }
+  }
   GLX_HIP(hipGetLastError());
   std::vector<int> rowcnt(n);
   GLX_HIP(hipMemcpyAsync(rowcnt.data(), b.rowcnt, n * 4, hipMemcpyDeviceToHost, st));
@@ -558,9 +664,28 @@ extern "C" int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, 
   // (one pass into a scratch image, compacted below: see merge_rows_kernel mode 2)
   GLX_POOL(glx_pool_alloc((void**)&b.tcol, std::max<size_t>((size_t)(m * k + n_rev) * 4, 4)));
   GLX_POOL(glx_pool_alloc((void**)&b.tval, std::max<size_t>((size_t)(m * k + n_rev) * 8, 8)));
-  hipLaunchKernelGGL(merge_rows_kernel, dim3(gr), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, m, k, k,
-                     (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 2, b.rowcnt, (const int64_t*)nullptr,
-                     b.tcol, b.tval, b.flag + 1, row_base);
+  std::vector<int> big;          // rows above 64 entries (popular vertices): the general kernel's, one wavefront each (outlives the asynchronous copy)
+  {
+    const bool small_rows = k <= 64;
+    if (small_rows && sym != SYM_NONE)
+      for (int64_t i = 0; i < m; ++i)
+        if (k + rcnt[i] > 64) big.push_back((int)i);
+    if (small_rows)
+      hipLaunchKernelGGL(merge_rows_small_kernel, dim3(gr), dim3(256), 0, st, (const int64_t*)b.ind, (const double*)b.w, m, k, k,
+                         (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, b.rowcnt,
+                         b.tcol, b.tval, row_base);
+    if (!small_rows) {
+      hipLaunchKernelGGL(merge_rows_kernel, dim3(gr), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, m, k, k,
+                         (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 2, b.rowcnt, (const int64_t*)nullptr,
+                         b.tcol, b.tval, b.flag + 1, row_base);
+    } else if (!big.empty()) {
+      GLX_POOL(glx_pool_alloc((void**)&b.biglist, big.size() * 4));
+      GLX_HIP(hipMemcpyAsync(b.biglist, big.data(), big.size() * 4, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(merge_rows_kernel, dim3((unsigned)((big.size() + 3) / 4)), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, m, k, k,
+                         (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 2, b.rowcnt, (const int64_t*)nullptr,
+                         b.tcol, b.tval, b.flag + 1, row_base, 64, (const int*)b.biglist, (int)big.size());
+    }
+  }
   GLX_HIP(hipGetLastError());
   std::vector<int> rowcnt(m);
   GLX_HIP(hipMemcpyAsync(rowcnt.data(), b.rowcnt, m * 4, hipMemcpyDeviceToHost, st));
