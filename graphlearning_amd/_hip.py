@@ -125,6 +125,7 @@ _SIGNATURES = {
     'glx_knn_cells_range': [_vp, C.c_int64, C.c_int, C.c_int, _vp, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
     'glx_knn_clustered': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
     'glx_knn_last_order': [C.c_int64, _vp],
+    'glx_knn_retain_next': [C.c_int],
     'glx_knn_stats': [_f64p],
     'glx_knn_to_csr': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                        C.POINTER(_vp), _i64p, C.c_int],
@@ -751,12 +752,14 @@ def auto_order_cells(n, d):
     return int(min(128, n // 64))     # (measured at 70 000 x 20: 128 cells = the library's order to 0.5 %, 64 and 32 cells 0.5-1 % behind)
 
 
-def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, cell_starts=None, clustered=None):
+def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, cell_starts=None, clustered=None, retain=False):
     """Exact kNN (incl. self) on the GPU.  'angular' = euclidean on row-normalised data, formed
     with the reference's own expression (weightmatrix.py:344-345).  cell_starts: the rows come in a coarse geometric
     order with cell c = rows [cell_starts[c], cell_starts[c+1]); the search skips the cells that cannot hold a
     neighbour (glx_knn_cells_range: the same lists, a fraction of the tiles on clustered data).  clustered: number of cells
-    the library forms itself (glx_knn_clustered; None = auto_cells(n, d), 0 = all pairs)."""
+    the library forms itself (glx_knn_clustered; None = auto_cells(n, d), 0 = all pairs).
+    retain (full searches only): the indices stay on the device for the knn_to_csr(None, ...) that follows and None is returned in
+    their place (glx_knn_retain_next: weightmatrix.knn's own flow)."""
     X = np.asarray(X, dtype=np.float64)
     if similarity == 'angular':
         X = X / np.linalg.norm(X, axis=1)[:, None]
@@ -765,20 +768,36 @@ def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, 
     X = np.ascontiguousarray(X)
     n, d = X.shape
     q0, q1 = (0, n) if query_range is None else query_range
-    ind = pinned_empty((q1 - q0, k), np.int64)       # page-locked result arrays: the copy back runs at PCIe speed
+    retain = bool(retain) and query_range is None and cell_starts is None
+    ind = None if retain else pinned_empty((q1 - q0, k), np.int64)       # page-locked result arrays: the copy back runs at PCIe speed
     dist = pinned_empty((q1 - q0, k), np.float64)
+    if retain:
+        load().glx_knn_retain_next(1)
+        try:
+            return _knn_search_full(X, n, d, k, clustered, ind, dist, device)
+        except BaseException:
+            load().glx_knn_retain_next(0)
+            raise
     if cell_starts is not None:
         cs = np.ascontiguousarray(cell_starts, dtype=np.int64)
         check(load().glx_knn_cells_range(_ptr(X), n, d, k, _ptr(cs), len(cs), q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
               'glx_knn_cells_range')
         return ind, dist
-    m = (auto_cells(n, d) if clustered is None else int(clustered)) if query_range is None else 0
-    if m <= 1 and clustered is None and query_range is None and cell_starts is None and auto_order_cells(n, d) > 1:
+    if query_range is None:
+        return _knn_search_full(X, n, d, k, clustered, ind, dist, device)
+    check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
+          'glx_knn_bruteforce')
+    return ind, dist
+
+
+def _knn_search_full(X, n, d, k, clustered, ind, dist, device):
+    m = auto_cells(n, d) if clustered is None else int(clustered)
+    if m <= 1 and clustered is None and auto_order_cells(n, d) > 1:
         m = -auto_order_cells(n, d)     # all pairs; the order of that many chained cells is left for knn_last_order
     if m > 1 or m < -1:       # cells formed by the library (same lists; a fraction of the tiles when the data has clusters)
         check(load().glx_knn_clustered(_ptr(X), n, d, k, m, _ptr(ind), _ptr(dist), _dev(device)), 'glx_knn_clustered')
         return ind, dist
-    check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
+    check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, 0, n, _ptr(ind), _ptr(dist), _dev(device)),
           'glx_knn_bruteforce')
     return ind, dist
 
@@ -790,8 +809,14 @@ _KERNEL_ID = {'given': 0, 'uniform': 1, 'gaussian': 2, 'symgaussian': 3, 'distan
 def knn_to_csr(knn_ind, knn_dist, k, kernel='gaussian', sym=1, weights=None, device=None):
     """kNN data -> scipy CSR weight matrix, assembled on the GPU (glx_knn_to_csr)."""
     from scipy import sparse
-    ind = np.ascontiguousarray(knn_ind, dtype=np.int64)
-    n, kk = ind.shape
+    if knn_ind is None:      # the indices the search left on the device (knn_bruteforce(retain=True))
+        ind = None
+        n, kk = np.shape(knn_dist if weights is None else weights)
+        if kk != int(k):
+            raise GlxError('knn_to_csr: retained indices need k = the number of columns')
+    else:
+        ind = np.ascontiguousarray(knn_ind, dtype=np.int64)
+        n, kk = ind.shape
     # distances are only read by the kernels that compute weights from them: with given weights they need not travel
     dist = None if (knn_dist is None or kernel == 'given') else _dense(knn_dist, np.float64, (n, kk), 'knn_dist')
     w = None if weights is None else _dense(weights, np.float64, (n, k), 'weights')

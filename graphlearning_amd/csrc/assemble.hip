@@ -392,7 +392,9 @@ struct AsmBufs {
 // are the caller's buffers with room for n + 1 row pointers and cap entries
 static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double* weights, int64_t n, int kk, int k, int kernel,
                            int sym, int64_t cap, int32_t** rowptr_out, int32_t** col_out, double** val_out, int64_t* nnz_out, int device) {
-  GLX_CHECK(ind && rowptr_out && col_out && val_out && nnz_out, GLX_EINVAL, "glx_knn_to_csr: null argument");
+  // ind = NULL: the indices the last search retained on the device (glx_knn_retain_next) -- they never visited the host
+  GLX_CHECK(rowptr_out && col_out && val_out && nnz_out, GLX_EINVAL, "glx_knn_to_csr: null argument");
+  GLX_CHECK(ind || kk == k, GLX_EINVAL, "glx_knn_to_csr: retained indices have exactly k columns (columns=%d k=%d)", kk, k);
   GLX_CHECK(n >= 1 && k >= 1 && kk >= k, GLX_EINVAL, "glx_knn_to_csr: need n >= 1 and 1 <= k <= columns (n=%lld k=%d columns=%d)", (long long)n, k, kk);
   GLX_CHECK(kernel >= K_GIVEN && kernel <= K_SINGULAR, GLX_EINVAL, "glx_knn_to_csr: bad kernel id %d", kernel);
   GLX_CHECK(sym >= SYM_NONE && sym <= SYM_SYMGAUSS, GLX_EINVAL, "glx_knn_to_csr: bad symmetrisation id %d", sym);
@@ -410,8 +412,13 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
   b.stream = b.work->stream;
   hipStream_t st = b.stream;
   const int64_t ne = n * k;
-  GLX_POOL(glx_pool_alloc((void**)&b.ind, (size_t)n * kk * 8));
-  GLX_HIP(hipMemcpyAsync(b.ind, ind, (size_t)n * kk * 8, hipMemcpyHostToDevice, st));
+  if (ind) {
+    GLX_POOL(glx_pool_alloc((void**)&b.ind, (size_t)n * kk * 8));
+    GLX_HIP(hipMemcpyAsync(b.ind, ind, (size_t)n * kk * 8, hipMemcpyHostToDevice, st));
+  } else {
+    int rct = glx_knn_take_retained(n, k, device, &b.ind);
+    if (rct) return rct;
+  }
   if (dist) {
     GLX_POOL(glx_pool_alloc((void**)&b.dist, (size_t)n * kk * 8));
     GLX_HIP(hipMemcpyAsync(b.dist, dist, (size_t)n * kk * 8, hipMemcpyHostToDevice, st));

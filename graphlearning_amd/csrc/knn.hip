@@ -1689,9 +1689,43 @@ static const int KNN_ESCALATE = 1;    // knn_pass: too many rows failed the acce
 // holds all k neighbours of a query, whatever their arrangement in the data).  It takes data whose k nearest neighbours
 // sit in the same 16 of 32 consecutive points to get there (tight groups stored one after another); interleaving the ref tiles
 // over the ranges already spreads anything coarser.
+// glx_knn_retain_next: the next FULL search (all rows as queries) keeps its neighbour indices on the device for the assembly that
+// follows it (glx_knn_to_csr with ind = NULL adopts them), and may be called with ind_out = NULL -- weightmatrix.knn's own flow,
+// where the lists never need to visit the host (2 x 6 MB over PCIe at config 2)
+static std::mutex g_knn_keep_mu;
+static int g_knn_keep_next = 0;
+static struct { int64_t* ind; int64_t n; int k; int device; } g_knn_kept = {nullptr, 0, 0, 0};
+
+extern "C" int glx_knn_retain_next(int on) {
+  std::lock_guard<std::mutex> lk(g_knn_keep_mu);
+  g_knn_keep_next = on ? 1 : 0;
+  if (!on && g_knn_kept.ind) {
+    glx_pool_free(g_knn_kept.ind);
+    g_knn_kept.ind = nullptr;
+  }
+  return GLX_OK;
+}
+
+int glx_knn_take_retained(int64_t n, int k, int device, int64_t** ind_dev) {
+  std::lock_guard<std::mutex> lk(g_knn_keep_mu);
+  if (!g_knn_kept.ind || g_knn_kept.n != n || g_knn_kept.k != k || g_knn_kept.device != device) {
+    glx_set_error("glx_knn_to_csr: ind = NULL, but no search result of %lld x %d indices is retained on device %d (glx_knn_retain_next)",
+                  (long long)n, k, device);
+    return GLX_EINVAL;
+  }
+  *ind_dev = g_knn_kept.ind;
+  g_knn_kept.ind = nullptr;
+  return GLX_OK;
+}
+
 static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_t q1, int64_t* ind_out, double* dist_out, int device,
                     bool long_lists, const int64_t* cell_starts = nullptr, int ncells = 0, int auto_cells = 0) {
-  GLX_CHECK(X && ind_out && dist_out, GLX_EINVAL, "glx_knn_bruteforce: null argument");
+  bool keep_ind = false;
+  {
+    std::lock_guard<std::mutex> lk(g_knn_keep_mu);
+    keep_ind = g_knn_keep_next && q0 == 0 && q1 == n;
+  }
+  GLX_CHECK(X && (ind_out || keep_ind) && dist_out, GLX_EINVAL, "glx_knn_bruteforce: null argument");
   GLX_CHECK(n >= 1 && d >= 1 && k >= 1, GLX_EINVAL, "glx_knn_bruteforce: need n, d, k >= 1 (n=%lld d=%d k=%d)", (long long)n, d, k);
   GLX_CHECK(k <= n, GLX_EINVAL, "glx_knn_bruteforce: k=%d exceeds the number of points %lld", k, (long long)n);
   GLX_CHECK(n < (1ll << 31) - BR_MAX, GLX_EINVAL, "glx_knn_bruteforce: n must fit int32");
@@ -2074,7 +2108,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     GLX_HIP(hipStreamSynchronize(st));   // (`rows` is read by the asynchronous copy above)
   }
   GLX_HIP(hipEventRecord(b.e3, st));
-  GLX_HIP(hipMemcpyAsync(ind_out, b.ind, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+  if (ind_out) GLX_HIP(hipMemcpyAsync(ind_out, b.ind, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipMemcpyAsync(dist_out, b.dist, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
   stamp("results on the host");
@@ -2082,6 +2116,16 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     GLX_HIP(hipStreamSynchronize(b.work->side));
     finish_order();
     stamp("cell order worked out");
+  }
+  if (keep_ind) {        // (everything that writes b.ind has finished: the stream was synchronised above)
+    std::lock_guard<std::mutex> lk(g_knn_keep_mu);
+    if (g_knn_kept.ind) glx_pool_free(g_knn_kept.ind);
+    g_knn_kept.ind = b.ind;
+    g_knn_kept.n = n;
+    g_knn_kept.k = k;
+    g_knn_kept.device = device;
+    b.ind = nullptr;
+    g_knn_keep_next = 0;                       // one search
   }
   float ms_tile = 0, ms_rr = 0, ms_fb = 0;
   GLX_HIP(hipEventElapsedTime(&ms_tile, b.e0, b.e1));

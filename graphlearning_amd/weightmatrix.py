@@ -42,10 +42,17 @@ def _knn(data, k, kernel, eta, symmetrize, metric, similarity, knn_data, device)
         knn_ind, knn_dist = knn_data
     elif type(data) is str:
         knn_ind, knn_dist = load_knn_data(data, metric=metric)
+    elif kernel != 'symgaussian' and os.environ.get('GLX_KNN_RETAIN', '1') != '0':
+        # the lists are only consumed by the assembly below: they stay on the device (knn_ind is None here; knn_to_csr adopts
+        # them) instead of coming back and going out again -- 2 x 6 MB over PCIe at config 2.  symgaussian reads them on the host
+        X = np.asarray(data, dtype=np.float64)
+        if similarity not in ['angular', 'euclidean']:
+            sys.exit('Invalid choice of similarity ' + similarity)
+        knn_ind, knn_dist = _hip.knn_bruteforce(X, int(k), similarity=similarity, device=device, retain=True)
     else:
         knn_ind, knn_dist = knnsearch(data, k, similarity=similarity)
-    n = knn_ind.shape[0]
-    k = int(np.minimum(knn_ind.shape[1], k))      # clamp to the columns available (reference :135)
+    n = knn_dist.shape[0]
+    k = int(np.minimum(knn_dist.shape[1], k))      # clamp to the columns available (reference :135)
     if eta is None and kernel not in ['uniform', 'gaussian', 'symgaussian', 'distance', 'singular']:
         sys.exit('Invalid choice of kernel: ' + kernel)
     # symmetrisation rule (reference :177-183)
@@ -67,7 +74,7 @@ def _knn(data, k, kernel, eta, symmetrize, metric, similarity, knn_data, device)
             # moves the exp to the device as well (within an ulp).
             d = np.asarray(knn_dist)[:, :k]
             weights = _hip.pinned_empty((n, k), np.float64)          # page-locked: the upload to the assembly runs at PCIe speed
-            J = np.asarray(knn_ind)[:, :k]
+            J = np.asarray(knn_ind)[:, :k] if kernel == 'symgaussian' else None
             eps_all = d[:, k - 1] if kernel == 'symgaussian' else None
 
             def rows(lo, hi):           # elementwise: any split into row blocks gives the same bits

@@ -334,6 +334,11 @@ int glx_knn_clustered(const double* X, int64_t n, int d, int k, int ncells, int6
  * size on record): contiguous cells of feature space, neighbouring cells chained -- a locality order of the vertices for
  * glx_graph_set_order that costs nothing. */
 int glx_knn_last_order(int64_t n, int32_t* perm_out);
+/* on != 0: the NEXT full search (glx_knn_bruteforce / glx_knn_clustered: all rows as queries) keeps its (n,k) neighbour indices
+ * on the device for the assembly that follows it -- glx_knn_to_csr[_into] with ind = NULL and kk = k adopts them -- and may be
+ * called with ind_out = NULL: inside weightmatrix.knn (graphlearning/weightmatrix.py:119-187) the lists are only ever consumed by
+ * the assembly and need not cross PCIe twice.  One search; on = 0 withdraws the request and drops what is retained. */
+int glx_knn_retain_next(int on);
 int glx_knn_stats(double stats[16]);  /* of the last search: [0] tile-kernel ms, [1] re-rank ms, [2] fallback rows, [3] total device ms,
                                         [4] fallback ms, [5] padded feature count, [6] ref ranges, [7] list length (negative: bf16 filter),
                                         [8] rows the short lists could not accept when the search was repeated with long ones (else 0);
@@ -345,7 +350,7 @@ int glx_knn_stats(double stats[16]);  /* of the last search: [0] tile-kernel ms,
 /* weightmatrix.knn given knn data (graphlearning/weightmatrix.py:134-187) on the device: kernel
  * weights, COO->CSR with duplicates summed, symmetrisation, zero diagonal, zeros dropped.
  * ind (n,kk) int64 and dist (n,kk) fp64 host arrays of which the first k columns are used
- * (k counts the self point).  kernel: 0 = `weights` (n,k) given (user eta), 1 uniform,
+ * (k counts the self point); ind = NULL (kk = k): the indices retained by the last search, see glx_knn_retain_next.  kernel: 0 = `weights` (n,k) given (user eta), 1 uniform,
  * 2 gaussian, 3 symgaussian, 4 distance, 5 singular.  sym: 0 none, 1 (W+W^T)/2, 2 element-wise
  * max (utils.sparse_max), 3 the symgaussian rule.  Outputs are allocated by the library
  * (release with glx_free): canonical CSR, int32 indices like scipy's. */

@@ -419,3 +419,26 @@ def test_rerank_every_candidate_width(gl, monkeypatch, k, nsplit, short):
     assert np.all(J[:, 1:][same] > J[:, :-1][same])
     ncand = int(abs(st['KP'])) * 2 * int(st['nsplit'])
     assert ncand in (64, 128, 256, 512, 1024), (st['KP'], st['nsplit'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kernel', ['gaussian', 'uniform', 'distance'])
+def test_retained_indices_give_the_same_matrix(gl, monkeypatch, kernel):
+    """weightmatrix.knn keeps the neighbour lists of its own search on the device for the assembly (glx_knn_retain_next; the
+    indices never visit the host): the matrix equals the one built from the lists that did (reference weightmatrix.py:119-187)."""
+    from graphlearning_amd import _hip
+    rng = np.random.default_rng(77)
+    X = rng.normal(size=(6, 12))[rng.integers(0, 6, size=9000)] * 2.0 + rng.normal(size=(9000, 12))
+    W1 = gl.weightmatrix.knn(X, 12, kernel=kernel)
+    monkeypatch.setenv('GLX_KNN_RETAIN', '0')
+    W0 = gl.weightmatrix.knn(X, 12, kernel=kernel)
+    assert np.array_equal(W1.indptr, W0.indptr) and np.array_equal(W1.indices, W0.indices) and np.array_equal(W1.data, W0.data)
+    # nothing is left behind, and an assembly without indices and without a retained search is refused
+    with pytest.raises(_hip.GlxError):
+        _hip.knn_to_csr(None, np.ones((9000, 13)), 13, kernel='uniform', sym=2)
+    # a retained result is dropped by a withdrawn request
+    J, D = _hip.knn_bruteforce(X, 13, retain=True)
+    assert J is None and D.shape == (9000, 13)
+    _hip.load().glx_knn_retain_next(0)
+    with pytest.raises(_hip.GlxError):
+        _hip.knn_to_csr(None, D, 13, kernel='uniform', sym=2)
