@@ -1692,12 +1692,12 @@ static const int KNN_ESCALATE = 1;    // knn_pass: too many rows failed the acce
 // glx_knn_retain_next: the next FULL search (all rows as queries) keeps its neighbour indices on the device for the assembly that
 // follows it (glx_knn_to_csr with ind = NULL adopts them), and may be called with ind_out = NULL -- weightmatrix.knn's own flow,
 // where the lists never need to visit the host (2 x 6 MB over PCIe at config 2)
-static std::mutex g_knn_keep_mu;
-static int g_knn_keep_next = 0;
-static struct { int64_t* ind; int64_t n; int k; int device; } g_knn_kept = {nullptr, 0, 0, 0};
+// (per calling thread: request, search and assembly are three calls of ONE thread -- another thread's search must neither take the
+// request nor replace what is retained)
+static thread_local int g_knn_keep_next = 0;
+static thread_local struct { int64_t* ind; int64_t n; int k; int device; } g_knn_kept = {nullptr, 0, 0, 0};
 
 extern "C" int glx_knn_retain_next(int on) {
-  std::lock_guard<std::mutex> lk(g_knn_keep_mu);
   g_knn_keep_next = on ? 1 : 0;
   if (!on && g_knn_kept.ind) {
     glx_pool_free(g_knn_kept.ind);
@@ -1707,7 +1707,6 @@ extern "C" int glx_knn_retain_next(int on) {
 }
 
 int glx_knn_take_retained(int64_t n, int k, int device, int64_t** ind_dev) {
-  std::lock_guard<std::mutex> lk(g_knn_keep_mu);
   if (!g_knn_kept.ind || g_knn_kept.n != n || g_knn_kept.k != k || g_knn_kept.device != device) {
     glx_set_error("glx_knn_to_csr: ind = NULL, but no search result of %lld x %d indices is retained on device %d (glx_knn_retain_next)",
                   (long long)n, k, device);
@@ -1720,11 +1719,7 @@ int glx_knn_take_retained(int64_t n, int k, int device, int64_t** ind_dev) {
 
 static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_t q1, int64_t* ind_out, double* dist_out, int device,
                     bool long_lists, const int64_t* cell_starts = nullptr, int ncells = 0, int auto_cells = 0) {
-  bool keep_ind = false;
-  {
-    std::lock_guard<std::mutex> lk(g_knn_keep_mu);
-    keep_ind = g_knn_keep_next && q0 == 0 && q1 == n;
-  }
+  const bool keep_ind = g_knn_keep_next && q0 == 0 && q1 == n;
   GLX_CHECK(X && (ind_out || keep_ind) && dist_out, GLX_EINVAL, "glx_knn_bruteforce: null argument");
   GLX_CHECK(n >= 1 && d >= 1 && k >= 1, GLX_EINVAL, "glx_knn_bruteforce: need n, d, k >= 1 (n=%lld d=%d k=%d)", (long long)n, d, k);
   GLX_CHECK(k <= n, GLX_EINVAL, "glx_knn_bruteforce: k=%d exceeds the number of points %lld", k, (long long)n);
@@ -2118,7 +2113,6 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     stamp("cell order worked out");
   }
   if (keep_ind) {        // (everything that writes b.ind has finished: the stream was synchronised above)
-    std::lock_guard<std::mutex> lk(g_knn_keep_mu);
     if (g_knn_kept.ind) glx_pool_free(g_knn_kept.ind);
     g_knn_kept.ind = b.ind;
     g_knn_kept.n = n;

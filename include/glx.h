@@ -337,7 +337,8 @@ int glx_knn_last_order(int64_t n, int32_t* perm_out);
 /* on != 0: the NEXT full search (glx_knn_bruteforce / glx_knn_clustered: all rows as queries) keeps its (n,k) neighbour indices
  * on the device for the assembly that follows it -- glx_knn_to_csr[_into] with ind = NULL and kk = k adopts them -- and may be
  * called with ind_out = NULL: inside weightmatrix.knn (graphlearning/weightmatrix.py:119-187) the lists are only ever consumed by
- * the assembly and need not cross PCIe twice.  One search; on = 0 withdraws the request and drops what is retained. */
+ * the assembly and need not cross PCIe twice.  One search; on = 0 withdraws the request and drops what is retained.  Request,
+ * search and assembly belong to the calling thread: other threads' searches neither see the request nor touch what is retained. */
 int glx_knn_retain_next(int on);
 int glx_knn_stats(double stats[16]);  /* of the last search: [0] tile-kernel ms, [1] re-rank ms, [2] fallback rows, [3] total device ms,
                                         [4] fallback ms, [5] padded feature count, [6] ref ranges, [7] list length (negative: bf16 filter),

@@ -442,3 +442,31 @@ def test_retained_indices_give_the_same_matrix(gl, monkeypatch, kernel):
     _hip.load().glx_knn_retain_next(0)
     with pytest.raises(_hip.GlxError):
         _hip.knn_to_csr(None, D, 13, kernel='uniform', sym=2)
+
+
+@pytest.mark.gpu
+def test_retained_indices_are_per_thread(gl):
+    """Two threads building different graphs at once: each assembly adopts the lists of ITS thread's search (the request and what
+    is retained are thread-local in the library), the matrices equal the ones built one after the other."""
+    import threading
+    rng = np.random.default_rng(78)
+    Xs = [rng.normal(size=(5, 10))[rng.integers(0, 5, size=n)] * 2.0 + rng.normal(size=(n, 10)) for n in (8000, 8000, 9000)]
+    serial = [gl.weightmatrix.knn(X, 10) for X in Xs]
+    out, errs = {}, []
+
+    def work(t):
+        try:
+            for rep in range(4):
+                for j, X in enumerate(Xs):
+                    out[(t, rep, j)] = gl.weightmatrix.knn(X, 10)
+        except BaseException as exc:      # noqa: BLE001
+            errs.append(exc)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for (t, rep, j), W in out.items():
+        S = serial[j]
+        assert np.array_equal(W.indptr, S.indptr) and np.array_equal(W.indices, S.indices) and np.array_equal(W.data, S.data), (t, rep, j)
