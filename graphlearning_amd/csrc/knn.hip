@@ -1160,7 +1160,12 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
                                                         int64_t nq, const float* __restrict__ cand_d, const int* __restrict__ cand_i,
                                                         int lists, int KP, int M, const float* __restrict__ qnorm, const float* __restrict__ rmax_p,
                                                         double cerr, int64_t* __restrict__ ind_out, double* __restrict__ dist_out,
-                                                        int* __restrict__ flags, const int* __restrict__ orig, int prefilter) {
+                                                        int* __restrict__ flags, const int* __restrict__ orig, int prefilter,
+                                                        double* __restrict__ dk2_out, int* __restrict__ nbad, int* __restrict__ badrows) {
+  // nbad / badrows: the flagged rows as a list, appended here (in no particular order: nothing depends on it), so that the host
+  // reads one count instead of nq flags
+  // dk2_out[query]: the exact k-th smallest distance^2 among the candidates -- an upper bound of the true k-th -- for the rows the
+  // acceptance test flags (the fallback looks for the refs within it)
   // orig (glx_knn_clustered: the rows were reordered by cell, orig[position] = the caller's row): candidates are ranked by
   // (distance, the CALLER's index) and the caller's indices go out, into the caller's row -- the lists of the search in the
   // caller's order, ties included
@@ -1305,7 +1310,13 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
     if (tau < INFINITY && !((double)tau >= dk2 + 2.0 * eps0)) bad = 1;
   }
   bad = __any(bad) || !(dk2 < INFINITY);
-  if (lane == 0) flags[ql] = bad;
+  if (lane == 0) {
+    flags[ql] = bad;
+    if (bad) {
+      dk2_out[ql] = dk2;
+      badrows[atomicAdd(nbad, 1)] = (int)ql;          // (room for every query)
+    }
+  }
 }
 
 // ---- stage 3: exact fp64 fallback for flagged rows --------------------------------------------
@@ -1321,13 +1332,15 @@ static const int FB_CACHE = 2048;     // a piece of at most this many refs keeps
 __global__ __launch_bounds__(256) void knn_fallback_piece_kernel(const double* __restrict__ X, int64_t n, int d, int k, int64_t q_begin,
                                                                  const int* __restrict__ rows, double* __restrict__ part_d,
                                                                  int* __restrict__ part_i, const int* __restrict__ orig,
-                                                                 const int* __restrict__ runs, const int* __restrict__ nruns, int maxruns, int BR) {
+                                                                 const int* __restrict__ runs, const int* __restrict__ nruns, int maxruns, int BR,
+                                                                 const int* __restrict__ redo) {
   // runs (the cell-pruned search): the refs are those of the tile runs of the row's query block -- everything else is strictly
   // farther than the row's k-th neighbour (knn_cellmask_kernel) -- cut into FB_SPLIT pieces of equally many tiles
   __shared__ double s_d[256];
   __shared__ int s_i[256];
   __shared__ double cache[FB_CACHE];
   const int row = blockIdx.x, piece = blockIdx.y;
+  if (redo && !redo[row]) return;                      // the one-pass fallback (knn_fallback_collect / _select) has done this row
   const int64_t ql = rows[row];
   const double* xq = X + (q_begin + ql) * d;
   const int64_t per = (n + FB_SPLIT - 1) / FB_SPLIT;
@@ -1400,13 +1413,126 @@ __global__ __launch_bounds__(256) void knn_fallback_piece_kernel(const double* _
 }
 
 // one wavefront per flagged row, lane p at the head of piece p's ascending list: k rounds of a lexicographic minimum over the lanes
+// The one-pass form of the fallback.  The re-rank leaves dk2 = the exact k-th smallest distance^2 among the row's candidates: k
+// distinct refs lie within it, so the true k nearest do too.  ONE pass over the refs (the same FB_SPLIT pieces, the same runs)
+// appends every ref with exact distance^2 <= dk2 to the row's buffer -- k of them plus the few the lists missed --, a wavefront per
+// row ranks them by (distance, index) and writes the first k.  Rows whose buffer overflows (FB_CAP: masses of ties) or whose
+// bound is not finite are left to the k-round kernels above (redo[row] = 1).
+static const int FB_CAP = 128;
+__global__ __launch_bounds__(256) void knn_fallback_collect_kernel(const double* __restrict__ X, int64_t n, int d, int64_t q_begin,
+                                                                   const int* __restrict__ rows, const double* __restrict__ dk2,
+                                                                   int* __restrict__ cnt, double* __restrict__ buf_d, int* __restrict__ buf_i,
+                                                                   const int* __restrict__ orig, const int* __restrict__ runs,
+                                                                   const int* __restrict__ nruns, int maxruns, int BR) {
+  const int row = blockIdx.x, piece = blockIdx.y;
+  const int64_t ql = rows[row];
+  const double bound = dk2[ql];
+  if (!(bound < INFINITY)) {
+    if (piece == 0 && threadIdx.x == 0) cnt[row] = FB_CAP + 1;
+    return;
+  }
+  const double* xq = X + (q_begin + ql) * d;
+  auto look = [&](int64_t ref) {
+    const double dd = sqdist_exact(xq, X + ref * d, d);
+    if (dd <= bound) {
+      const int slot = atomicAdd(&cnt[row], 1);
+      if (slot < FB_CAP) {
+        buf_d[(size_t)row * FB_CAP + slot] = dd;
+        buf_i[(size_t)row * FB_CAP + slot] = orig ? orig[ref] : (int)ref;
+      }
+    }
+  };
+  if (runs) {
+    const int64_t qb = ql / BQ;
+    const int* rr = runs + qb * 2 * (int64_t)maxruns;
+    const int nr = nruns[qb];
+    int64_t tv = 0;
+    for (int r = 0; r < nr; ++r) tv += rr[2 * r + 1] - rr[2 * r];
+    const int64_t t_lo = tv * piece / FB_SPLIT, t_hi = tv * (piece + 1) / FB_SPLIT;
+    int64_t off = 0;                                // tiles of the runs in front of run q
+    for (int q = 0; q < nr; ++q) {
+      const int64_t a = rr[2 * q], b = rr[2 * q + 1];
+      const int64_t lo = max(a, a + (t_lo - off)), hi = min(b, a + (t_hi - off));
+      off += b - a;
+      if (lo >= hi) continue;
+      const int64_t s0 = lo * BR, s1 = min(n, hi * BR);
+      for (int64_t ref = s0 + threadIdx.x; ref < s1; ref += 256) look(ref);
+    }
+  } else {
+    const int64_t per = (n + FB_SPLIT - 1) / FB_SPLIT;
+    const int64_t r0 = piece * per, r1 = min(n, r0 + per);
+    for (int64_t ref = r0 + threadIdx.x; ref < r1; ref += 256) look(ref);
+  }
+}
+
+__global__ __launch_bounds__(64) void knn_fallback_select_kernel(const int* __restrict__ cnt, const double* __restrict__ buf_d,
+                                                                 const int* __restrict__ buf_i, const int* __restrict__ rows, int nrows, int k,
+                                                                 int64_t* __restrict__ ind_out, double* __restrict__ dist_out,
+                                                                 const int* __restrict__ orig, int64_t q_begin, int* __restrict__ redo) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  if (row >= nrows) return;
+  const int c = cnt[row];
+  if (c > FB_CAP || c < k) {            // (c < k cannot happen with a sound bound: left to the k-round kernels all the same)
+    if (lane == 0) redo[row] = 1;
+    return;
+  }
+  if (lane == 0) redo[row] = 0;
+  const int64_t ql = orig ? (int64_t)orig[q_begin + rows[row]] - q_begin : rows[row];
+  constexpr int R = FB_CAP / 64;
+  double rd[R];
+  int ri[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = lane + 64 * r;
+    rd[r] = e < c ? buf_d[(size_t)row * FB_CAP + e] : INFINITY;
+    ri[r] = e < c ? buf_i[(size_t)row * FB_CAP + e] : 0x7fffffff;
+  }
+#pragma unroll
+  for (int size = 2; size <= 64 * R; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (stride >= 64) {
+        const int rs = stride / 64;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if ((r & rs) == 0) {
+            const int r2 = r | rs;
+            const bool up = (((lane + 64 * r) & size) == 0);
+            const bool sw = up ? lex_less(rd[r2], ri[r2], rd[r], ri[r]) : lex_less(rd[r], ri[r], rd[r2], ri[r2]);
+            const double td = sw ? rd[r2] : rd[r], ud = sw ? rd[r] : rd[r2];
+            const int ti = sw ? ri[r2] : ri[r], ui = sw ? ri[r] : ri[r2];
+            rd[r] = td; ri[r] = ti; rd[r2] = ud; ri[r2] = ui;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int lo = __shfl_xor(__double2loint(rd[r]), stride), hi = __shfl_xor(__double2hiint(rd[r]), stride);
+          const double od = __hiloint2double(hi, lo);
+          const int oi = __shfl_xor(ri[r], stride);
+          const bool up = (((lane + 64 * r) & size) == 0), lower = (lane & stride) == 0;
+          const bool mine_first = lex_less(rd[r], ri[r], od, oi);
+          const bool keep_mine = (lower == up) ? mine_first : !mine_first;
+          rd[r] = keep_mine ? rd[r] : od;
+          ri[r] = keep_mine ? ri[r] : oi;
+        }
+      }
+    }
+  }
+  if (lane < k) {                       // (k <= 60: the first k slots are lanes 0 .. k - 1 of register 0)
+    ind_out[ql * k + lane] = ri[0];
+    dist_out[ql * k + lane] = sqrt(rd[0]);
+  }
+}
+
 __global__ __launch_bounds__(64) void knn_fallback_merge_kernel(const double* __restrict__ part_d, const int* __restrict__ part_i,
                                                                 const int* __restrict__ rows, int nrows, int k,
                                                                 int64_t* __restrict__ ind_out, double* __restrict__ dist_out,
-                                                                const int* __restrict__ orig, int64_t q_begin) {
+                                                                const int* __restrict__ orig, int64_t q_begin, const int* __restrict__ redo) {
   static_assert(FB_SPLIT == 64, "one lane per piece");
   const int row = blockIdx.x, p = threadIdx.x;
   if (row >= nrows) return;
+  if (redo && !redo[row]) return;
   const int64_t ql = orig ? (int64_t)orig[q_begin + rows[row]] - q_begin : rows[row];
   int head = 0;
   const size_t base = ((size_t)row * FB_SPLIT + p) * k;
@@ -1472,6 +1598,8 @@ struct KnnBufs {
   int *orig = nullptr, *cell_id = nullptr;
   int *cand_i = nullptr, *flags = nullptr, *rows = nullptr, *fb_pi = nullptr, *gtau = nullptr;
   double* fb_pd = nullptr;
+  double *dk2 = nullptr, *fb_bd = nullptr;   // exact k-th candidate distance^2 of flagged rows; the one-pass fallback's buffers
+  int *fb_cnt = nullptr, *fb_bi = nullptr, *nbad = nullptr;
   int64_t* ind = nullptr;
   glx_work* work = nullptr;           // the device's cached stream + events
   hipStream_t stream = nullptr;
@@ -1482,7 +1610,7 @@ struct KnnBufs {
     glx_pool_free(Xb); glx_pool_free(Xq); glx_pool_free(Xf); glx_pool_free(nrm); glx_pool_free(part); glx_pool_free(rmax);
     glx_pool_free(X); glx_pool_free(mean); glx_pool_free(dist); glx_pool_free(Rf); glx_pool_free(Qf); glx_pool_free(qnorm); glx_pool_free(cand_d);
     glx_pool_free(runs); glx_pool_free(nruns); glx_pool_free(cell_starts); glx_pool_free(cen); glx_pool_free(rad); glx_pool_free(ub2); glx_pool_free(cpart); glx_pool_free(mask); glx_pool_free(visited); glx_pool_free(Xraw); glx_pool_free(orig); glx_pool_free(cell_id);
-    glx_pool_free(pre_d); glx_pool_free(pre_i); glx_pool_free(gtau); glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_pi); glx_pool_free(fb_pd);
+    glx_pool_free(pre_d); glx_pool_free(pre_i); glx_pool_free(gtau); glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_pi); glx_pool_free(fb_pd); glx_pool_free(dk2); glx_pool_free(fb_bd); glx_pool_free(fb_cnt); glx_pool_free(fb_bi); glx_pool_free(nbad);
     glx_work_release(work);
   }
 };
@@ -1910,6 +2038,9 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   GLX_POOL(glx_pool_alloc((void**)&b.cand_d, (size_t)nq * ncand * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.cand_i, (size_t)nq * ncand * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.flags, (size_t)nq * 4));
+  GLX_POOL(glx_pool_alloc((void**)&b.dk2, (size_t)nq * 8));
+  GLX_POOL(glx_pool_alloc((void**)&b.nbad, 4));
+  GLX_HIP(hipMemsetAsync(b.nbad, 0, 4, st));
   GLX_POOL(glx_pool_alloc((void**)&b.gtau, (size_t)nq * 4));
   GLX_HIP(hipMemsetD32Async((hipDeviceptr_t)b.gtau, 0x7f800000, (size_t)nq, st));   // +inf: nothing published yet
   GLX_POOL(glx_pool_alloc((void**)&b.rows, (size_t)nq * 4));
@@ -2052,7 +2183,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
 #define GLX_RERANK(RR)                                                                                                                    \
   hipLaunchKernelGGL(knn_rerank_kernel<RR>, dim3((unsigned)nq), dim3(64), (size_t)M * 16, st, (const double*)b.X, n, d, k, q0, nq,          \
                      (const float*)b.cand_d, (const int*)b.cand_i, lists, KP, M, (const float*)b.qnorm, (const float*)b.rmax, cerr, b.ind, b.dist, \
-                     b.flags, (const int*)b.orig, d >= prefilter_from ? 1 : 0)
+                     b.flags, (const int*)b.orig, d >= prefilter_from ? 1 : 0, b.dk2, b.nbad, b.rows)
   if (M == 64) GLX_RERANK(1);
   else if (M == 128) GLX_RERANK(2);
   else if (M == 256) GLX_RERANK(4);
@@ -2061,9 +2192,9 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
 #undef GLX_RERANK
   GLX_HIP(hipGetLastError());
   GLX_HIP(hipEventRecord(b.e2, st));
-  std::vector<int> flags(nq);
   float h_rmax[2] = {0.f, 0.f};
-  GLX_HIP(hipMemcpyAsync(flags.data(), b.flags, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+  int h_nbad = 0;
+  GLX_HIP(hipMemcpyAsync(&h_nbad, b.nbad, 4, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipMemcpyAsync(h_rmax, b.rmax, 8, hipMemcpyDeviceToHost, st));
   unsigned long long h_visited = 0;
   if (b.visited) GLX_HIP(hipMemcpyAsync(&h_visited, b.visited, 8, hipMemcpyDeviceToHost, st));
@@ -2074,10 +2205,8 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   }
   stamp("tile + re-rank done, flags on the host");
   GLX_CHECK(h_rmax[1] == 1.0f, GLX_EINVAL, "glx_knn_bruteforce: non-finite input");   // (the first host look at the centring pass)
-  std::vector<int> rows;
-  for (int64_t i = 0; i < nq; ++i)
-    if (flags[i]) rows.push_back((int)i);
-  if (KNN_ABLATE) rows.clear();   // developer probes produce wrong candidate lists: do not repair them
+  struct { size_t n; size_t size() const { return n; } bool empty() const { return n == 0; } } rows = {(size_t)h_nbad};   // (the list itself is on the device: b.rows)
+  if (KNN_ABLATE) rows.n = 0;     // developer probes produce wrong candidate lists: do not repair them
   if (short_lists && rows.size() > 64) {
     // repair row by row, or search again with the long lists?  A fallback row streams the data k times (measured: ~5 TB/s);
     // the repeat costs about four tile-kernel times (fp32-input filter, longer lists)
@@ -2090,17 +2219,28 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     }
   }
   if (!rows.empty()) {
-    GLX_HIP(hipMemcpyAsync(b.rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
     const size_t nr = rows.size();
     GLX_POOL(glx_pool_alloc((void**)&b.fb_pd, nr * FB_SPLIT * k * 8));
     GLX_POOL(glx_pool_alloc((void**)&b.fb_pi, nr * FB_SPLIT * k * 4));
-    // (b.runs: the main pass's runs when the search was cell-pruned -- the pre-pass's were overwritten by them)
+    GLX_POOL(glx_pool_alloc((void**)&b.fb_cnt, nr * 2 * 4));            // [nr] counts, [nr] redo marks
+    GLX_POOL(glx_pool_alloc((void**)&b.fb_bd, nr * FB_CAP * 8));
+    GLX_POOL(glx_pool_alloc((void**)&b.fb_bi, nr * FB_CAP * 4));
+    GLX_HIP(hipMemsetAsync(b.fb_cnt, 0, nr * 2 * 4, st));
+    const int* fb_runs = (const int*)(b.visited ? b.runs : nullptr);   // (b.runs: the main pass's runs when the search was cell-pruned -- the pre-pass's were overwritten by them)
+    int* redo = getenv("GLX_KNN_FALLBACK_ROUNDS") ? nullptr : b.fb_cnt + nr;       // (the k-round kernels alone: a developer switch)
+    if (redo) {
+      // one pass: every ref within the bound the re-rank left, ranked by a wavefront per row
+      hipLaunchKernelGGL(knn_fallback_collect_kernel, dim3((unsigned)nr, FB_SPLIT), dim3(256), 0, st, (const double*)b.X, n, d, q0, (const int*)b.rows,
+                         (const double*)b.dk2, b.fb_cnt, b.fb_bd, b.fb_bi, (const int*)b.orig, fb_runs, (const int*)b.nruns, b.maxruns, BR);
+      hipLaunchKernelGGL(knn_fallback_select_kernel, dim3((unsigned)nr), dim3(64), 0, st, (const int*)b.fb_cnt, (const double*)b.fb_bd, (const int*)b.fb_bi,
+                         (const int*)b.rows, (int)nr, k, b.ind, b.dist, (const int*)b.orig, q0, redo);
+    }
+    // the k-round kernels: only the rows the one pass could not finish (their workgroups return at once otherwise)
     hipLaunchKernelGGL(knn_fallback_piece_kernel, dim3((unsigned)nr, FB_SPLIT), dim3(256), 0, st, (const double*)b.X, n, d, k, q0, (const int*)b.rows,
-                       b.fb_pd, b.fb_pi, (const int*)b.orig, (const int*)(b.visited ? b.runs : nullptr), (const int*)b.nruns, b.maxruns, BR);
+                       b.fb_pd, b.fb_pi, (const int*)b.orig, fb_runs, (const int*)b.nruns, b.maxruns, BR, (const int*)redo);
     hipLaunchKernelGGL(knn_fallback_merge_kernel, dim3((unsigned)nr), dim3(64), 0, st, (const double*)b.fb_pd, (const int*)b.fb_pi,
-                       (const int*)b.rows, (int)nr, k, b.ind, b.dist, (const int*)b.orig, q0);
+                       (const int*)b.rows, (int)nr, k, b.ind, b.dist, (const int*)b.orig, q0, (const int*)redo);
     GLX_HIP(hipGetLastError());
-    GLX_HIP(hipStreamSynchronize(st));   // (`rows` is read by the asynchronous copy above)
   }
   GLX_HIP(hipEventRecord(b.e3, st));
   if (ind_out) GLX_HIP(hipMemcpyAsync(ind_out, b.ind, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
