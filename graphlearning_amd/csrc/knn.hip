@@ -2208,11 +2208,11 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   struct { size_t n; size_t size() const { return n; } bool empty() const { return n == 0; } } rows = {(size_t)h_nbad};   // (the list itself is on the device: b.rows)
   if (KNN_ABLATE) rows.n = 0;     // developer probes produce wrong candidate lists: do not repair them
   if (short_lists && rows.size() > 64) {
-    // repair row by row, or search again with the long lists?  A fallback row streams the data k times (measured: ~5 TB/s);
+    // repair row by row, or search again with the long lists?  A fallback row streams the data once (measured: ~5 TB/s);
     // the repeat costs about four tile-kernel times (fp32-input filter, longer lists)
     float ms_first = 0;
     GLX_HIP(hipEventElapsedTime(&ms_first, b.e0, b.e1));
-    const double ms_rows = (double)rows.size() * k * ((double)n * d * 8.0 / 5e9);
+    const double ms_rows = (double)rows.size() * ((double)n * d * 8.0 / 5e9);        // (one pass per row: knn_fallback_collect_kernel)
     if (ms_rows > 4.0 * ms_first) {
       g_knn_stats[2] = (double)rows.size();
       return KNN_ESCALATE;
