@@ -618,11 +618,14 @@ class poisson_mbo(ssl):
             if self._cache is not None:
                 self._cache[2].close()
                 self._cache[1].close()
+            order = getattr(W, '_glx_order', None) if (dtype == np.float64 or n < (1 << 17)) else None   # (as in poisson._operators)
+            if order is not None and len(order) != n:
+                order = None
             W = W - sparse.spdiags(W.diagonal(), 0, n, n)       # reference ssl.py:789-791
             G = graph_mod.graph(W)
             dt = 1 / np.max(G.degree_vector())                  # reference ssl.py:801
             P = sparse.identity(n) - dt * G.laplacian()         # reference ssl.py:804
-            dev = _hip.DeviceGraph(P, dtype=dtype, device=self.device)
+            dev = _hip.DeviceGraph(P, dtype=dtype, device=self.device, order=order)     # the search's cell order instead of a pass over the graph
             heat = _hip.Sweep(dev, k, min_iter=0, max_iter=0, use_hipgraph=True)
             self._cache = (key, dev, heat, dt)
         _, dev, heat, dt = self._cache
