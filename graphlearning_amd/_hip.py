@@ -744,9 +744,10 @@ def auto_cells(n, d):
 
 
 def auto_order_cells(n, d):
-    """Below the size of the clustered search: how many cells the all-pairs search works out an ORDER for on the side (the
-    operators on the graph take it instead of their own pass over the graph: 3.7 ms at 70 000 vertices, and the sweep is a
-    per cent faster on it).  GLX_KNN_ORDER=0 turns it off."""
+    """Below the size of the cell-PRUNED search: how many chained cells the rows are reordered by before the all-pairs search
+    (coherent wavefronts: 10-14 % of the search on clustered data, nothing lost elsewhere), whose order the operators on the
+    graph then take instead of their own pass over the graph (3.7 ms at 70 000 vertices).  GLX_KNN_ORDER=0 turns it off;
+    GLX_KNN_REORDER=0 keeps the caller's order in the search and works the cell order out on the side."""
     if os.environ.get('GLX_KNN_ORDER', '1') == '0' or n < 4096 or n >= (1 << 17) or d > 128:
         return 0
     return int(min(128, n // 64))     # (measured at 70 000 x 20: 128 cells = the library's order to 0.5 %, 64 and 32 cells 0.5-1 % behind)

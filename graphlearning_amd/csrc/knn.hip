@@ -1927,11 +1927,14 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   // glx_knn_clustered: form auto_cells cells (nearest of that many sample rows), reorder the rows by cell ON THE DEVICE and
   // search with the cell pruning of glx_knn_cells_range; the re-rank ranks by and returns the caller's indices
   std::vector<int64_t> own_starts;
-  // (auto_cells < 0: only the ORDER of -auto_cells chained cells is worked out and left for glx_knn_last_order -- below 2^17 rows the
-  // all-pairs search is the faster one, but the cell order still saves the operators on the graph their pass over it.  Nothing
-  // of that waits for the device: the cell ids travel back behind the search and the host part runs after its last synchronisation.)
-  const bool order_only = auto_cells < -1;
-  if (order_only) auto_cells = -auto_cells;
+  // auto_cells < -1, since the end of round 3: the rows ARE reordered by -auto_cells chained cells and then searched all pairs.  The
+  // 32 queries of a wavefront then come from one corner of feature space, a ref tile holds candidates for many of them or for none,
+  // and fewer wave-tiles leave the tile kernel's fast path: config 2 2.06 -> 1.83 ms of search wall time, config 3's shape
+  // 3.06 -> 2.63 ms, data without clusters unchanged (profiles/r03_knn_cells_midsize.txt).  GLX_KNN_REORDER=0: the order alone,
+  // worked out on a side stream behind an all-pairs search in the caller's order (what was there before).
+  const bool order_only = auto_cells < -1 && getenv("GLX_KNN_REORDER") && atoi(getenv("GLX_KNN_REORDER")) == 0;
+  const bool reorder_only = auto_cells < -1 && !order_only;
+  if (auto_cells < -1) auto_cells = -auto_cells;
   int oc_m = 0;
   // the cells in a chain of nearest centres (greedy, from the centre farthest from the centres' mean): neighbouring cells of
   // feature space end up next to each other in the row order, which then serves as a locality order for the graph's operators
@@ -2010,6 +2013,10 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     b.cen = nullptr;
     cell_starts = own_starts.data();
     ncells = m;
+    if (reorder_only) {          // the rows in cell order, then all pairs: no pre-pass, no pruning
+      cell_starts = nullptr;
+      ncells = 0;
+    }
     stamp("rows reordered by cell");
     }
   }

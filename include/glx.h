@@ -327,8 +327,9 @@ int glx_knn_cells_range(const double* X, int64_t n, int d, int k, const int64_t*
 /* all n rows in the caller's order, the cells formed by the library: ncells (<= 4096; 0 / 1 = plain all-pairs search) evenly
  * spaced rows serve as centres, every row joins the nearest, the rows are reordered by cell on the device and searched with the
  * pruning of glx_knn_cells_range.  Indices and output rows are the caller's, equal distances go to the lower caller index: the
- * lists of glx_knn_bruteforce bit for bit.  ncells < -1: the all-pairs search, and the ORDER of -ncells chained cells worked out on
- * the side (behind the search, no extra synchronisation) for glx_knn_last_order. */
+ * lists of glx_knn_bruteforce bit for bit.  ncells < -1: the rows reordered by -ncells chained cells on the device, then ALL PAIRS
+ * (no pruning: a wavefront's queries share a corner of feature space, which is worth 10-14 % of the search on clustered data
+ * below the size where pruning pays, and nothing elsewhere); the order is left for glx_knn_last_order. */
 int glx_knn_clustered(const double* X, int64_t n, int d, int k, int ncells, int64_t* ind_out, double* dist_out, int device);
 /* perm_out[position] = caller's row in the cell order of the last glx_knn_clustered search over n rows (GLX_EINVAL: none of that
  * size on record): contiguous cells of feature space, neighbouring cells chained -- a locality order of the vertices for
