@@ -2021,7 +2021,8 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     GLX_POOL(glx_pool_alloc((void**)&b.X, (size_t)n * d * 8));
     hipLaunchKernelGGL(knn_gather_rows_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, st, (const double*)b.Xraw, (const int*)b.orig, n, d, b.X);
     GLX_HIP(hipGetLastError());
-    GLX_HIP(hipStreamSynchronize(st));            // (`perm` is read by the copy above)
+    // (no synchronisation: `perm` = oc_perm outlives the stream's work -- it is declared in front of `b`, whose destructor drains the
+    // stream -- and the kernels that read b.cen finished before the synchronisation in front of finish_order)
     glx_pool_free(b.cen);                          // the cell pass allocates its own
     b.cen = nullptr;
     cell_starts = own_starts.data();
