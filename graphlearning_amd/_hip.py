@@ -753,12 +753,16 @@ def auto_order_cells(n, d):
     return int(min(128, n // 64))     # (measured at 70 000 x 20: 128 cells = the library's order to 0.5 %, 64 and 32 cells 0.5-1 % behind)
 
 
-def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, cell_starts=None, clustered=None, retain=False):
+def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, cell_starts=None, clustered=None, retain=False,
+                   want_order=False):
     """Exact kNN (incl. self) on the GPU.  'angular' = euclidean on row-normalised data, formed
     with the reference's own expression (weightmatrix.py:344-345).  cell_starts: the rows come in a coarse geometric
     order with cell c = rows [cell_starts[c], cell_starts[c+1]); the search skips the cells that cannot hold a
     neighbour (glx_knn_cells_range: the same lists, a fraction of the tiles on clustered data).  clustered: number of cells
     the library forms itself (glx_knn_clustered; None = auto_cells(n, d), 0 = all pairs).
+    want_order (below the size of the pruned search): the rows are put into the order of chained cells first, which knn_last_order
+    then hands to the operators on the graph (weightmatrix.knn asks for it; a plain knnsearch does not pay for an order nobody reads:
+    0.1 ms at d = 20, 0.7 ms at d = 128 for 50 000 rows).
     retain (full searches only): the indices stay on the device for the knn_to_csr(None, ...) that follows and None is returned in
     their place (glx_knn_retain_next: weightmatrix.knn's own flow)."""
     X = np.asarray(X, dtype=np.float64)
@@ -775,7 +779,7 @@ def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, 
     if retain:
         load().glx_knn_retain_next(1)
         try:
-            return _knn_search_full(X, n, d, k, clustered, ind, dist, device)
+            return _knn_search_full(X, n, d, k, clustered, ind, dist, device, want_order)
         except BaseException:
             load().glx_knn_retain_next(0)
             raise
@@ -785,15 +789,15 @@ def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, 
               'glx_knn_cells_range')
         return ind, dist
     if query_range is None:
-        return _knn_search_full(X, n, d, k, clustered, ind, dist, device)
+        return _knn_search_full(X, n, d, k, clustered, ind, dist, device, want_order)
     check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
           'glx_knn_bruteforce')
     return ind, dist
 
 
-def _knn_search_full(X, n, d, k, clustered, ind, dist, device):
+def _knn_search_full(X, n, d, k, clustered, ind, dist, device, want_order=False):
     m = auto_cells(n, d) if clustered is None else int(clustered)
-    if m <= 1 and clustered is None and auto_order_cells(n, d) > 1:
+    if m <= 1 and clustered is None and want_order and auto_order_cells(n, d) > 1:
         m = -auto_order_cells(n, d)     # all pairs; the order of that many chained cells is left for knn_last_order
     if m > 1 or m < -1:       # cells formed by the library (same lists; a fraction of the tiles when the data has clusters)
         check(load().glx_knn_clustered(_ptr(X), n, d, k, m, _ptr(ind), _ptr(dist), _dev(device)), 'glx_knn_clustered')

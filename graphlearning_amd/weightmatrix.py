@@ -48,9 +48,12 @@ def _knn(data, k, kernel, eta, symmetrize, metric, similarity, knn_data, device)
         X = np.asarray(data, dtype=np.float64)
         if similarity not in ['angular', 'euclidean']:
             sys.exit('Invalid choice of similarity ' + similarity)
-        knn_ind, knn_dist = _hip.knn_bruteforce(X, int(k), similarity=similarity, device=device, retain=True)
+        knn_ind, knn_dist = _hip.knn_bruteforce(X, int(k), similarity=similarity, device=device, retain=True, want_order=True)
     else:
-        knn_ind, knn_dist = knnsearch(data, k, similarity=similarity)
+        if similarity not in ['angular', 'euclidean']:
+            sys.exit('Invalid choice of similarity ' + similarity)
+        # (want_order: the graph's operators take the search's cell order; knnsearch proper does not work one out)
+        knn_ind, knn_dist = _hip.knn_bruteforce(np.asarray(data, dtype=np.float64), int(k), similarity=similarity, device=device, want_order=True)
     n = knn_dist.shape[0]
     k = int(np.minimum(knn_dist.shape[1], k))      # clamp to the columns available (reference :135)
     if eta is None and kernel not in ['uniform', 'gaussian', 'symgaussian', 'distance', 'singular']:

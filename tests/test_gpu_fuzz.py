@@ -277,6 +277,10 @@ def test_random_knn_searches_match_ckdtree(gl, orc, seed):
         X = rng.normal(size=(n, d)) * np.exp(rng.normal(size=(1, d)) * 2.0)   # features of very different scale
     sim = 'angular' if rng.random() < 0.2 and d > 1 else 'euclidean'
     J, D = gl.weightmatrix.knnsearch(X, k, similarity=sim)
+    # the search weightmatrix.knn runs (rows put into the order of chained cells first, where the size calls for it): the same lists
+    from graphlearning_amd import _hip
+    J2, D2 = _hip.knn_bruteforce(X, k, similarity=sim, want_order=True)
+    assert np.array_equal(J2, J) and np.array_equal(D2, D), 'seed %d: the reordered search differs' % seed
     Jo, Do = orc.knnsearch(X, k, similarity=sim)
     Jo, Do = Jo.reshape(n, -1), Do.reshape(n, -1)          # (cKDTree drops the axis for k = 1)
     tag = 'seed %d: n=%d d=%d k=%d style=%d %s' % (seed, n, d, k, style, sim)
