@@ -931,6 +931,61 @@ __global__ __launch_bounds__(256) void knn_gather_rows_kernel(const double* __re
 
 // cell[i] = the nearest of m centres (lowest index on ties); centres in batches of 8 through LDS, one walk over a point's
 // features per batch
+// Rows into the order of their cells on the device (stable: ascending caller index inside a cell) -- three small kernels instead of a
+// trip to the host: key = the cell's place in the chain, a histogram per block of 256 rows, one block scanning the (block, key) table,
+// and a scatter that ranks a row among the earlier rows of its block with the same key.  The permutation equals the host's
+// counting sort (finish_order); the search never waits for it.
+__global__ __launch_bounds__(256) void knn_cellrank_hist_kernel(int* __restrict__ cell, const int* __restrict__ place, int64_t n, int m, int* __restrict__ bh) {
+  extern __shared__ int h_[];
+  for (int c = threadIdx.x; c < m; c += 256) h_[c] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int key = place[cell[i]];
+    cell[i] = key;
+    atomicAdd(&h_[key], 1);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < m; c += 256) bh[(int64_t)blockIdx.x * m + c] = h_[c];
+}
+
+__global__ __launch_bounds__(256) void knn_cellrank_scan_kernel(int* __restrict__ bh, int nb, int m) {
+  extern __shared__ int tot_[];
+  for (int c = threadIdx.x; c < m; c += 256) {
+    int run = 0;
+    for (int b = 0; b < nb; ++b) {
+      const int t = bh[(int64_t)b * m + c];
+      bh[(int64_t)b * m + c] = run;
+      run += t;
+    }
+    tot_[c] = run;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int c = 0; c < m; ++c) { const int t = tot_[c]; tot_[c] = run; run += t; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < m; c += 256) {
+    const int base = tot_[c];
+    for (int b = 0; b < nb; ++b) bh[(int64_t)b * m + c] += base;
+  }
+}
+
+__global__ __launch_bounds__(256) void knn_cellrank_scatter_kernel(const int* __restrict__ key, int64_t n, int m, const int* __restrict__ bh,
+                                                                   int* __restrict__ perm) {
+  __shared__ int k_[256];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int kk = i < n ? key[i] : -1;
+  k_[threadIdx.x] = kk;
+  __syncthreads();
+  if (i < n) {
+    int r = 0;
+    for (int j = 0; j < (int)threadIdx.x; ++j) r += (k_[j] == kk) ? 1 : 0;
+    perm[bh[(int64_t)blockIdx.x * m + kk] + r] = (int)i;
+  }
+}
+
 __global__ __launch_bounds__(256) void knn_assign_kernel(const double* __restrict__ X, int d, int64_t n, const double* __restrict__ cen, int m,
                                                          int* __restrict__ cell, int fs) {
   // fs: feature stride -- beyond 32 features every fs-th one decides the cell (ds = ceil(d / fs) <= 32 of them).  The cells only
@@ -1615,7 +1670,7 @@ struct KnnBufs {
   int *cand_i = nullptr, *flags = nullptr, *rows = nullptr, *fb_pi = nullptr, *gtau = nullptr;
   double* fb_pd = nullptr;
   double *dk2 = nullptr, *fb_bd = nullptr;   // exact k-th candidate distance^2 of flagged rows; the one-pass fallback's buffers
-  int *fb_cnt = nullptr, *fb_bi = nullptr, *nbad = nullptr;
+  int *fb_cnt = nullptr, *fb_bi = nullptr, *nbad = nullptr, *place = nullptr, *bh = nullptr;
   int64_t* ind = nullptr;
   glx_work* work = nullptr;           // the device's cached stream + events
   hipStream_t stream = nullptr;
@@ -1626,7 +1681,7 @@ struct KnnBufs {
     glx_pool_free(Xb); glx_pool_free(Xq); glx_pool_free(Xf); glx_pool_free(nrm); glx_pool_free(part); glx_pool_free(rmax);
     glx_pool_free(X); glx_pool_free(mean); glx_pool_free(dist); glx_pool_free(Rf); glx_pool_free(Qf); glx_pool_free(qnorm); glx_pool_free(cand_d);
     glx_pool_free(runs); glx_pool_free(nruns); glx_pool_free(cell_starts); glx_pool_free(cen); glx_pool_free(rad); glx_pool_free(ub2); glx_pool_free(cpart); glx_pool_free(mask); glx_pool_free(visited); glx_pool_free(Xraw); glx_pool_free(orig); glx_pool_free(cell_id);
-    glx_pool_free(pre_d); glx_pool_free(pre_i); glx_pool_free(gtau); glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_pi); glx_pool_free(fb_pd); glx_pool_free(dk2); glx_pool_free(fb_bd); glx_pool_free(fb_cnt); glx_pool_free(fb_bi); glx_pool_free(nbad);
+    glx_pool_free(pre_d); glx_pool_free(pre_i); glx_pool_free(gtau); glx_pool_free(cand_i); glx_pool_free(flags); glx_pool_free(rows); glx_pool_free(ind); glx_pool_free(fb_pi); glx_pool_free(fb_pd); glx_pool_free(dk2); glx_pool_free(fb_bd); glx_pool_free(fb_cnt); glx_pool_free(fb_bi); glx_pool_free(nbad); glx_pool_free(place); glx_pool_free(bh);
     glx_work_release(work);
   }
 };
@@ -1927,6 +1982,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   // (host buffers of the cell-order by-product: declared in front of `b`, whose destructor drains the stream they are filled through)
   std::vector<int> oc_sample, oc_cid, oc_perm;
   std::vector<double> oc_cen;
+  std::vector<int> oc_place;
   KnnBufs b;
   {
     int rcw = glx_work_acquire(device, &b.work);
@@ -1956,14 +2012,12 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   // feature space end up next to each other in the row order, which then serves as a locality order for the graph's operators
   // too (one XCD's share of the rows = a few whole clusters; with the cells in arbitrary order the sweep at 10^6 rows ran 20 % slower);
   // then the rows by cell (counting sort, ascending caller index inside a cell).  Host work on oc_cid / oc_cen.
-  auto finish_order = [&]() {
-    const int m = oc_m;
-    std::vector<double>& cen = oc_cen;
-    std::vector<int>& cid = oc_cid;
+  auto chain_places = [&](const std::vector<double>& cen, int m) -> std::vector<int> {
     std::vector<double> mean(d, 0.0);
     for (int c = 0; c < m; ++c)
       for (int f = 0; f < d; ++f) mean[f] += cen[(size_t)c * d + f] / m;
-    auto dist2 = [&](const double* a, const double* bb) { double t = 0; for (int f = 0; f < d; ++f) { const double q = a[f] - bb[f]; t += q * q; } return t; };
+    const int cfs = (d + 31) / 32;       // (every cfs-th feature, as in the assignment: m^2 d flops on one host thread otherwise)
+    auto dist2 = [&](const double* a, const double* bb) { double t = 0; for (int f = 0; f < d; f += cfs) { const double q = a[f] - bb[f]; t += q * q; } return t; };
     int cur = 0;
     double far = -1.0;
     for (int c = 0; c < m; ++c) { const double t = dist2(&cen[(size_t)c * d], mean.data()); if (t > far) { far = t; cur = c; } }
@@ -1977,6 +2031,12 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
       if (nxt < 0) break;
       cur = nxt;
     }
+    return place;
+  };
+  auto finish_order = [&]() {
+    const int m = oc_m;
+    std::vector<int>& cid = oc_cid;
+    const std::vector<int> place = chain_places(oc_cen, m);
     for (int64_t i = 0; i < n; ++i) cid[i] = place[cid[i]];
     own_starts.assign(m, 0);
     std::vector<int64_t> fill(m + 1, 0);
@@ -1988,7 +2048,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     std::lock_guard<std::mutex> lk(g_knn_order_mu);
     g_knn_last_order.assign(oc_perm.begin(), oc_perm.end());
   };
-  bool order_pending = false;
+  bool order_pending = false, perm_pending = false;
   if (auto_cells > 1 && q0 == 0 && q1 == n && !long_lists && d <= 128 && n >= 4 * (int64_t)auto_cells) {
     const int m = oc_m = auto_cells;
     oc_sample.resize(m);
@@ -2007,6 +2067,29 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     hipLaunchKernelGGL(knn_assign_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), (size_t)16 * d * 8, so, (const double*)b.X, d, n, (const double*)b.cen, m,
                        b.cell_id, (d + 31) / 32);
     GLX_HIP(hipGetLastError());
+    if (reorder_only && !getenv("GLX_KNN_REORDER_HOST")) {
+      // the chain of the cells from the caller's copy of the sample rows (the same doubles the device gathered), the rows into cell
+      // order by the three knn_cellrank kernels: nothing here waits for the device (the host sort cost 0.2 - 0.4 ms of waiting --
+      // for the upload's tail, the cell ids, the permutation's way back)
+      oc_cen.resize((size_t)m * d);
+      for (int c = 0; c < m; ++c) memcpy(&oc_cen[(size_t)c * d], X + (size_t)oc_sample[c] * d, (size_t)d * 8);
+      oc_place = chain_places(oc_cen, m);
+      const int nb = (int)((n + 255) / 256);
+      GLX_POOL(glx_pool_alloc((void**)&b.place, (size_t)m * 4));
+      GLX_POOL(glx_pool_alloc((void**)&b.bh, (size_t)nb * m * 4));
+      GLX_POOL(glx_pool_alloc((void**)&b.orig, (size_t)n * 4));
+      GLX_HIP(hipMemcpyAsync(b.place, oc_place.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(knn_cellrank_hist_kernel, dim3((unsigned)nb), dim3(256), (size_t)m * 4, st, b.cell_id, (const int*)b.place, n, m, b.bh);
+      hipLaunchKernelGGL(knn_cellrank_scan_kernel, dim3(1), dim3(256), (size_t)m * 4, st, b.bh, nb, m);
+      hipLaunchKernelGGL(knn_cellrank_scatter_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const int*)b.cell_id, n, m, (const int*)b.bh, b.orig);
+      b.Xraw = b.X;
+      b.X = nullptr;
+      GLX_POOL(glx_pool_alloc((void**)&b.X, (size_t)n * d * 8));
+      hipLaunchKernelGGL(knn_gather_rows_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, st, (const double*)b.Xraw, (const int*)b.orig, n, d, b.X);
+      GLX_HIP(hipGetLastError());
+      perm_pending = true;                             // the permutation comes back with the results (glx_knn_last_order)
+      stamp("rows reordered by cell (on the device)");
+    } else {
     oc_cid.resize(n);
     oc_cen.resize((size_t)m * d);
     GLX_HIP(hipMemcpyAsync(oc_cid.data(), b.cell_id, (size_t)n * 4, hipMemcpyDeviceToHost, so));
@@ -2035,6 +2118,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
       ncells = 0;
     }
     stamp("rows reordered by cell");
+    }
     }
   }
   // centring in fp64 (distances are translation invariant; small norms keep the filter sharp), all of it on the device
@@ -2275,6 +2359,12 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     GLX_HIP(hipStreamSynchronize(b.work->side));
     finish_order();
     stamp("cell order worked out");
+  }
+  if (perm_pending) {
+    oc_perm.resize(n);
+    GLX_HIP(hipMemcpy(oc_perm.data(), b.orig, (size_t)n * 4, hipMemcpyDeviceToHost));
+    std::lock_guard<std::mutex> lk(g_knn_order_mu);
+    g_knn_last_order.assign(oc_perm.begin(), oc_perm.end());
   }
   if (keep_ind) {        // (everything that writes b.ind has finished: the stream was synchronised above)
     if (g_knn_kept.ind) glx_pool_free(g_knn_kept.ind);
