@@ -2067,7 +2067,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     hipLaunchKernelGGL(knn_assign_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), (size_t)16 * d * 8, so, (const double*)b.X, d, n, (const double*)b.cen, m,
                        b.cell_id, (d + 31) / 32);
     GLX_HIP(hipGetLastError());
-    if (reorder_only && !getenv("GLX_KNN_REORDER_HOST")) {
+    if (reorder_only && !getenv("GLX_KNN_REORDER_HOST")) {     // (GLX_KNN_REORDER_HOST: the host's counting sort, for A/B runs)
       // the chain of the cells from the caller's copy of the sample rows (the same doubles the device gathered), the rows into cell
       // order by the three knn_cellrank kernels: nothing here waits for the device (the host sort cost 0.2 - 0.4 ms of waiting --
       // for the upload's tail, the cell ids, the permutation's way back)
