@@ -45,6 +45,15 @@ def make_features(labels):
     return centers[labels] + rng.normal(size=(len(labels), D_FEAT))
 
 
+def config3_data():
+    """SURVEY.md 8d config 3 (BASELINE configs[2]): CIFAR label vector (60000), synthetic d = 32 blobs standing in for the absent
+    simclr features (same generator as tests/golden/make_golden.py g4_large)."""
+    lab = np.load(os.path.join(ROOT, 'tests', 'golden', 'cifar_labels.npz'))['labels'][:60000].astype(np.int64)
+    rng = np.random.default_rng(1)
+    centers = rng.normal(size=(10, 32)) * 1.2
+    return lab, centers[lab] + rng.normal(size=(60000, 32))
+
+
 def algorithmic_bytes(n, nnz, C, s_v, s_u):
     """Per-sweep algorithmic HBM bytes: CSR values + 4-byte indices, row pointer,
     read u + read Db + write u, and the fused fp64 stop column read + write."""

@@ -534,7 +534,14 @@ struct CgBufs {
   double* pw_vals = nullptr;
   int32_t *mask_rows = nullptr, *mask_ptr = nullptr;
   double *part_dot = nullptr, *part_rs = nullptr, *scal = nullptr, *err_hist = nullptr, *h_err = nullptr;
-  hipStream_t stream = nullptr;
+  // tolerance mode (cg_fused.hip): partial sums, counters, Dirichlet-row masks, the captured launch sequence of a chunk
+  double *f_part1 = nullptr, *f_part1g = nullptr, *f_part2 = nullptr;
+  unsigned *f_tick = nullptr, *f_rowmask = nullptr;
+  int* f_it = nullptr;
+  hipGraphExec_t f_exec = nullptr;
+  std::vector<unsigned long long> f_key;
+  hipEvent_t f_ev[3] = {nullptr, nullptr, nullptr};
+  hipStream_t stream = nullptr, side = nullptr;
   std::map<void**, size_t> cap;
   int64_t pw_n = -1;   // rows the pairwise-summation plan was built for
   PwPlan pw;
@@ -565,6 +572,10 @@ struct CgBufs {
     hipFree(x); hipFree(r); hipFree(p); hipFree(ap); hipFree(dense); hipFree(part_dot); hipFree(part_rs);
     hipFree(scal); hipFree(err_hist); hipFree(prod);
     hipFree(pw_off); hipFree(pw_len); hipFree(pw_l); hipFree(pw_r); hipFree(pw_ls); hipFree(pw_vals); hipFree(mask_rows); hipFree(mask_ptr);
+    hipFree(f_part1); hipFree(f_part1g); hipFree(f_part2); hipFree(f_tick); hipFree(f_rowmask); hipFree(f_it);
+    if (f_exec) hipGraphExecDestroy(f_exec);
+    for (int q = 0; q < 3; ++q) if (f_ev[q]) hipEventDestroy(f_ev[q]);
+    if (side) hipStreamDestroy(side);
     if (h_err) hipHostFree(h_err);
     if (stream) hipStreamDestroy(stream);
   }
@@ -596,7 +607,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   GLX_CHECK(256 / (L.ld / 4) >= 1, GLX_EUNSUPPORTED, "glx_cg_multi: record too wide");
   const int64_t nb_spmm = std::max<int64_t>(glx_spmm_blocks(plan), 1);
   const int64_t nb_upd = std::max<int64_t>((n + UPD_ROWS_PER_BLOCK - 1) / UPD_ROWS_PER_BLOCK, 1);
-  const int64_t hist_cap = max_iter + 2;
+  const int64_t hist_cap = max_iter + 2 + 2 * CG_CHUNK;   // (the tolerance mode copies whole chunks of rows, one chunk ahead)
   GLX_CHECK(max_iter < (1ll << 24), GLX_EUNSUPPORTED, "glx_cg_multi: max_iter %lld exceeds the supported 2^24-1", (long long)max_iter);
   GLX_CHECK(n < (1ll << 27) || !exact, GLX_EUNSUPPORTED, "glx_cg_multi: %lld rows exceed the reference-order reducer's 32-bit offsets", (long long)n);
 
@@ -656,7 +667,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     pw = b.pw;
     pw_grid = b.pw_grid;
   }
-  { int rc_ = b.need_host(&b.h_err, (size_t)(CG_CHUNK + 1) * stride * 8); if (rc_) return rc_; }
+  { int rc_ = b.need_host(&b.h_err, (size_t)2 * (CG_CHUNK + 1) * stride * 8); if (rc_) return rc_; }
   CgScalars sc;
   sc.rsold = b.scal;
   sc.alpha = b.scal + ncols;
@@ -737,12 +748,151 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   }
   const unsigned pgrid = (unsigned)std::max<int64_t>(((int64_t)n * (L.ld / 4) + 255) / 256, 1);
 
-  int64_t it = 0;                               // iterations launched
   std::vector<int64_t> iters(ngroups, 0);       // iterations that ran, per group (utils.py:522 `i`)
   std::vector<double> err(ngroups, 1.0);        // utils.py:519
   std::vector<char> done(ngroups, !(1.0 > tol));
   int running = 0;
   for (int g = 0; g < ngroups; ++g) running += !done[g];
+  // rows [it0 + 1, it0 + cnt] of the residual history have arrived in `h`: which systems stopped where
+  auto read_history = [&](const double* h, int64_t it0, int64_t cnt) {
+    for (int64_t q = 0; q < cnt && running > 0; ++q) {
+      // iteration it0+q+1 ran for every group whose previous err was > tol; its err decides the next one
+      for (int g = 0; g < ngroups; ++g) {
+        if (done[g]) continue;
+        iters[g] = it0 + q + 1;
+        err[g] = h[(size_t)q * stride + g];
+        if (!(err[g] > tol)) { done[g] = 1; --running; }
+      }
+    }
+  };
+  if (!exact) {
+    // ---- tolerance mode: two launches per iteration (cg_fused.hip), a chunk of iterations captured once and replayed ----
+    GLX_CHECK(!mask_grid || ngroups <= 32, GLX_EUNSUPPORTED, "glx_cg_groups_masked: at most 32 systems with Dirichlet rows per tolerance-mode solve (got %d)", ngroups);
+    int rpb = 0;
+    const int nb2 = glx_cg_fused_update_blocks(n, &rpb);
+    // groups of SpMM workgroups: small enough that a group's last arriver adds its rows in one round of loads, few enough that
+    // every workgroup of the update kernel can add the groups for itself
+    const int grp = (int)std::max<int64_t>(32, (nb_spmm + 63) / 64);
+    const int64_t ngrp = (nb_spmm + grp - 1) / grp;
+    const int nq = 3 * ncols;
+    CG_NEED(b.f_part1, (size_t)nb_spmm * nq * 8);
+    CG_NEED(b.f_part1g, (size_t)ngrp * nq * 8);
+    CG_NEED(b.f_part2, (size_t)nb2 * ncols * 8);
+    CG_NEED(b.f_tick, (size_t)(ngrp + 1) * 4);
+    CG_NEED(b.f_it, 64);
+    GLX_HIP(hipMemsetAsync(b.f_tick, 0, (size_t)(ngrp + 1) * 4, st));   // (a launch behind the last iteration may leave arrivals behind)
+    const unsigned* rowmask = nullptr;
+    if (mask_grid) {
+      std::vector<unsigned> hm((size_t)n, 0u);
+      for (int g = 0; g < ngroups; ++g)
+        for (int q = mask_ptr[g]; q < mask_ptr[g + 1]; ++q) {
+          const int32_t rec = A->order_ready && !A->h_inv.empty() ? A->h_inv[mask_rows[q]] : mask_rows[q];
+          hm[rec] |= 1u << g;
+        }
+      CG_NEED(b.f_rowmask, (size_t)n * 4);
+      GLX_HIP(hipMemcpyAsync(b.f_rowmask, hm.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+      GLX_HIP(hipStreamSynchronize(st));   // hm leaves scope
+      rowmask = b.f_rowmask;
+    }
+    for (int q = 0; q < 3; ++q)
+      if (!b.f_ev[q]) GLX_HIP(hipEventCreateWithFlags(&b.f_ev[q], hipEventDisableTiming));
+    if (!b.side) GLX_HIP(hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking));
+    CgDev cd;
+    memset(&cd, 0, sizeof(cd));
+    cd.rsold = sc.rsold;
+    cd.err_hist = b.err_hist;
+    cd.stride = stride;
+    cd.ngroups = ngroups;
+    cd.Cg = Cg;
+    cd.C = C;
+    cd.max_iter = (int)max_iter;
+    cd.it_a = b.f_it;
+    cd.it_b = b.f_it + 4;
+    cd.closed = b.f_it + 8;
+    cd.r = (const char*)b.r;
+    cd.part1 = b.f_part1;
+    cd.part1g = b.f_part1g;
+    cd.tick1 = b.f_tick;
+    cd.grp = grp;
+    cd.ngrp = (int)ngrp;
+    cd.part2 = b.f_part2;
+    cd.nb2 = nb2;
+    a.cg = &cd;
+    a.dot_partial = nullptr;
+    a.prod_out = nullptr;
+    a.exit_err = nullptr;
+    a.act_row = nullptr;
+    a.rowmask = rowmask;
+    GLX_HIP(hipMemsetD32Async((hipDeviceptr_t)b.f_it, 1, 8, st));          // it_a = it_b = 1
+    GLX_HIP(hipMemsetD32Async((hipDeviceptr_t)(b.f_it + 8), 0, 8, st));    // closed = 0
+    auto enqueue_chunk = [&]() -> int {
+      for (int q = 0; q < CG_CHUNK; ++q) {
+        int rc2 = glx_launch_spmm(a, st);                                                      // Ap = A@p, dots, alpha, beta
+        if (rc2) return rc2;
+        rc2 = glx_cg_fused_update(dtype, b.x, b.r, b.p, b.ap, n, L, cd, tol, st);              // alpha, beta, x, r, p, r.r
+        if (rc2) return rc2;
+      }
+      return glx_cg_fused_close(cd, tol, st);                                                  // the chunk's last err
+    };
+    // everything the captured kernels were given: a replay is only valid for the same arguments
+    std::vector<unsigned long long> key = {(unsigned long long)(uintptr_t)plan, (unsigned long long)(uintptr_t)plan->d_col,
+                                           (unsigned long long)(uintptr_t)b.x, (unsigned long long)(uintptr_t)b.r,
+                                           (unsigned long long)(uintptr_t)b.p, (unsigned long long)(uintptr_t)b.ap,
+                                           (unsigned long long)(uintptr_t)b.scal, (unsigned long long)(uintptr_t)b.err_hist,
+                                           (unsigned long long)(uintptr_t)b.f_part1, (unsigned long long)(uintptr_t)b.f_part1g,
+                                           (unsigned long long)grp, (unsigned long long)(uintptr_t)b.f_part2,
+                                           (unsigned long long)(uintptr_t)b.f_tick, (unsigned long long)(uintptr_t)b.f_it,
+                                           (unsigned long long)(uintptr_t)rowmask, (unsigned long long)C, (unsigned long long)Cg,
+                                           (unsigned long long)max_iter, (unsigned long long)n, (unsigned long long)dtype, 0ull};
+    memcpy(&key.back(), &tol, 8);
+    if (!b.f_exec || b.f_key != key) {
+      if (b.f_exec) { hipGraphExecDestroy(b.f_exec); b.f_exec = nullptr; }
+      hipGraph_t graph;
+      GLX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      rc = enqueue_chunk();
+      hipError_t e = hipStreamEndCapture(st, &graph);
+      if (rc) return rc;
+      GLX_HIP(e);
+      GLX_HIP(hipGraphInstantiate(&b.f_exec, graph, nullptr, nullptr, 0));
+      GLX_HIP(hipGraphDestroy(graph));
+      b.f_key = key;
+    }
+    // the GPU never waits for the host: chunk c+1 is launched before the history of chunk c is looked at (kernels of iterations
+    // past convergence exit at once)
+    int64_t launched = 0;     // iterations launched
+    int64_t looked = 0;       // iterations whose history the host has read
+    int slot = 0;
+    auto launch_chunk = [&]() -> int {
+      GLX_HIP(hipGraphLaunch(b.f_exec, st));
+      // the history leaves on a second stream: a copy in `st` would sit between this chunk and the next (19 us measured)
+      GLX_HIP(hipEventRecord(b.f_ev[2], st));
+      GLX_HIP(hipStreamWaitEvent(b.side, b.f_ev[2], 0));
+      GLX_HIP(hipMemcpyAsync(b.h_err + (size_t)slot * (CG_CHUNK + 1) * stride, b.err_hist + (size_t)(launched + 1) * stride,
+                             (size_t)CG_CHUNK * stride * 8, hipMemcpyDeviceToHost, b.side));
+      GLX_HIP(hipEventRecord(b.f_ev[slot], b.side));
+      launched += CG_CHUNK;
+      slot ^= 1;
+      return GLX_OK;
+    };
+    if (running > 0 && max_iter > 0) {
+      rc = launch_chunk();
+      if (rc) return rc;
+      while (running > 0 && looked < max_iter) {
+        const bool more = launched < max_iter;
+        if (more) {
+          rc = launch_chunk();
+          if (rc) return rc;
+        }
+        const int rs = more ? slot : slot ^ 1;          // the slot of the oldest chunk not yet read
+        GLX_HIP(hipEventSynchronize(b.f_ev[rs]));
+        const int64_t cnt = std::min<int64_t>(CG_CHUNK, max_iter - looked);
+        read_history(b.h_err + (size_t)rs * (CG_CHUNK + 1) * stride, looked, cnt);
+        looked += CG_CHUNK;
+      }
+      GLX_HIP(hipStreamSynchronize(b.side));   // a chunk launched ahead may still be copying into h_err
+    }
+  } else {
+  int64_t it = 0;                               // iterations launched
   while (running > 0 && it < max_iter) {
     const int64_t end = std::min<int64_t>(max_iter, it + CG_CHUNK);
     const int64_t it0 = it;
@@ -789,15 +939,8 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     const int64_t cnt = end - it0;
     GLX_HIP(hipMemcpyAsync(b.h_err, b.err_hist + (size_t)(it0 + 1) * stride, (size_t)cnt * stride * 8, hipMemcpyDeviceToHost, st));
     GLX_HIP(hipStreamSynchronize(st));
-    for (int64_t q = 0; q < cnt && running > 0; ++q) {
-      // iteration it0+q+1 ran for every group whose previous err was > tol; its err decides the next one
-      for (int g = 0; g < ngroups; ++g) {
-        if (done[g]) continue;
-        iters[g] = it0 + q + 1;
-        err[g] = b.h_err[(size_t)q * stride + g];
-        if (!(err[g] > tol)) { done[g] = 1; --running; }
-      }
-    }
+    read_history(b.h_err, it0, cnt);
+  }
   }
   rc = glx_unpack_records(b.x, b.dense, n, L, dtype, st, A->d_perm);
   if (rc) return rc;

@@ -113,6 +113,152 @@ void glx_work_release(glx_work* w);
 int glx_graph_plan(glx_graph* g, int G, SellPlan** out);
 int glx_graph_ensure_order(glx_graph* g);
 
+// ---- tolerance-mode CG (cg_fused.hip): two launches per iteration ----------------------------------------------------
+// Device-resident scalars, counters and partial sums of one solve.  The iteration number lives on the device (it_a read by the
+// SpMM kernel, it_b by the update kernel: neither is written by a kernel whose own late workgroups still read it), so one
+// captured launch sequence serves every iteration.  Who reduces what (every sum in a fixed order, no float atomics):
+//   update kernel (it-1)  writes part2[workgroup][ncols] = partial r.r;
+//   SpMM kernel (it)      one extra workgroup closes iteration it-1 BESIDE the product: rsold = sum part2, err_hist[it-1];
+//                         the others write part1[workgroup][3 ncols] (p.Ap, r.Ap, Ap.Ap); the last arriver of every group of
+//                         `grp` workgroups adds its group's rows into part1g[group];
+//   update kernel (it)    every workgroup adds the (few) rows of part1g and forms alpha, beta for itself.
+// Nothing but the last group's sum sits between the end of a kernel's real work and the next launch.
+struct CgDev {
+  double* rsold;      // [ncols] r.r of the current residual
+  double* err_hist;   // [max_iter + 2 + slack][stride]: per system, then the maximum over the systems still running; row 0 = 1 (utils.py:519)
+  int stride, ngroups, Cg, C;
+  int max_iter;
+  int* it_a;          // iteration about to run (SpMM kernel reads, update kernel writes)
+  int* it_b;          // the same, handed from the SpMM kernel to the update kernel
+  int* closed;        // highest iteration whose err_hist row is complete
+  const char* r;      // residual records (the SpMM kernel forms r.Ap beside p.Ap and Ap.Ap)
+  double* part1;      // [nblocks][3 ncols]
+  double* part1g;     // [ngrp][3 ncols]
+  unsigned* tick1;    // [ngrp] arrival counters (back at zero after every launch that ran)
+  int grp, ngrp;      // workgroups per group, groups
+  double* part2;      // [nb2][ncols]
+  int nb2;
+  double* host_hist;  // page-locked mirror of err_hist the host polls (null: none)
+};
+
+// Cross-workgroup hand-off inside one launch (MI355X: per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed
+// by another CU's stores): the payload leaves with agent-scope (write-through) stores, the writer drains them before it draws its
+// ticket, the reader uses agent-scope loads -- the "8-byte agent atomics on both sides" form of the hardware guide.
+__device__ __forceinline__ void glx_agent_store(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool AGENT> __device__ __forceinline__ double glx_load_part(const double* p) {
+  if constexpr (AGENT)
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else
+    return *p;
+}
+// every thread of the workgroup calls it after its agent-scope stores; true (in all threads) for the workgroup that arrives last
+// of `count`.  The counter is back at zero when it returns true.  `s_flag`: any LDS word the caller can spare around the call.
+__device__ __forceinline__ bool glx_arrive_last(unsigned* ticket, unsigned count, double* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = t == count - 1;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *(volatile unsigned*)s_flag = last ? 1u : 0u;
+  }
+  __syncthreads();
+  const bool last = *(volatile unsigned*)s_flag != 0;
+  __syncthreads();   // s_flag is free again
+  return last;
+}
+// column sums of part[nrows][nq] in a fixed order: the workgroup's threads split the rows into parts, eight independent
+// accumulators per thread keep eight loads in flight, the parts are added in order.  consume(q, total) is called by exactly one
+// thread per column.  s_tmp: blockDim.x doubles of LDS.  AGENT: the rows were written by other workgroups of THIS launch
+// (glx_agent_store); plain loads serve rows a previous launch wrote.
+template <bool AGENT, class F>
+__device__ __forceinline__ void glx_reduce_rows(const double* part, int64_t nrows, int nq, double* s_tmp, F&& consume) {
+#pragma clang fp contract(off)
+  const int nt = (int)blockDim.x;
+  for (int q0 = 0; q0 < nq; q0 += nt) {
+    const int nqc = nq - q0 < nt ? nq - q0 : nt;
+    const int parts = nt / nqc;
+    const int q = (int)threadIdx.x % nqc, part_id = (int)threadIdx.x / nqc;
+    double s = 0.0;
+    if (part_id < parts) {
+      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int64_t r = part_id;
+      for (; r + 7 * (int64_t)parts < nrows; r += 8 * (int64_t)parts) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += glx_load_part<AGENT>(part + (size_t)(r + j * (int64_t)parts) * nq + q0 + q);
+      }
+      for (int j = 0; r < nrows; r += parts, ++j) a[j] += glx_load_part<AGENT>(part + (size_t)r * nq + q0 + q);
+      s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    s_tmp[threadIdx.x] = s;
+    __syncthreads();
+    if ((int)threadIdx.x < nqc) {
+      double tot = s_tmp[threadIdx.x];
+      for (int pp = 1; pp < parts; ++pp) tot += s_tmp[pp * nqc + threadIdx.x];
+      consume(q0 + (int)threadIdx.x, tot);
+    }
+    __syncthreads();
+  }
+}
+
+// Close iteration `j = it - 1` (one workgroup of 256 threads; idempotent): rsold = r.r summed over part2 for the systems that ran it
+// (utils.py:527, 530), err_j = np.sqrt(np.sum(rsnew)) per system (utils.py:528; np.sum over a contiguous 1-D float64 array is
+// numpy's pairwise_sum: 8 strided accumulators below 128 elements, a plain loop below 8), then the maximum over the systems still
+// running.  A NaN error stops its own system (`nan > tol` is false) and must not keep the others alive.
+__device__ __forceinline__ void glx_cg_close_iteration(const CgDev& cg, int it, double tol, double* s_tmp /* [256] */) {
+#pragma clang fp contract(off)
+  const int j = it - 1;
+  if (j < 1 || *cg.closed >= j) return;
+  const double* ran = cg.err_hist + (size_t)(j - 1) * cg.stride;      // system g ran iteration j iff ran[g] > tol
+  const int ncols = ((cg.C + 3) / 4) * 4;
+  glx_reduce_rows<false>(cg.part2, (int64_t)cg.nb2, ncols, s_tmp, [&](int q, double tot) {
+    if (q >= cg.C || ran[q / cg.Cg] > tol) cg.rsold[q] = tot;
+  });
+  __threadfence_block();
+  __syncthreads();
+  double mine = 0.0;
+  const int g = threadIdx.x;
+  double* row = cg.err_hist + (size_t)j * cg.stride;
+  if (g < cg.ngroups && ran[g] > tol) {
+    const double* v = cg.rsold + (size_t)g * cg.Cg;
+    const int C = cg.Cg;
+    double e;
+    if (C < 8) {
+      e = 0.0;
+      for (int q = 0; q < C; ++q) e = e + v[q];
+    } else {
+      double r8[8];
+      for (int q = 0; q < 8; ++q) r8[q] = v[q];
+      int i = 8;
+      for (; i < C - (C % 8); i += 8)
+        for (int q = 0; q < 8; ++q) r8[q] = r8[q] + v[i + q];
+      e = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+      for (; i < C; ++i) e = e + v[i];
+    }
+    mine = sqrt(e);
+    row[g] = mine;
+  }
+  s_tmp[threadIdx.x] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = 0.0;
+    for (int q = 0; q < cg.ngroups && q < 256; ++q)
+      if (s_tmp[q] > m) m = s_tmp[q];
+    row[cg.ngroups] = m;
+    __threadfence();
+    *cg.closed = j;
+  }
+  __syncthreads();
+}
+
+struct RecLayout;
+int glx_cg_fused_update_blocks(int64_t n, int* rows_per_block);
+int glx_cg_fused_update(int dtype, void* x, void* r, void* p, const void* ap, int64_t n, const RecLayout& L, const CgDev& cg,
+                        double tol, hipStream_t st);
+int glx_cg_fused_close(const CgDev& cg, double tol, hipStream_t st);
+
 // kernels' launch wrappers (sweep.hip)
 struct SweepArgs {
   const SellPlan* plan;
@@ -144,6 +290,9 @@ struct SweepArgs {
   const int32_t* dup_ptr;
   const int32_t* dup_pos;
   void* dup_out;
+  // CG: Dirichlet rows (bit g of rowmask[record]: A p held at zero there for system g); tolerance-mode state (cg_fused.hip)
+  const unsigned* rowmask;
+  const CgDev* cg;
 };
 int glx_launch_spmm(const SweepArgs& a, hipStream_t stream);
 int64_t glx_spmm_blocks(const SellPlan* plan);

@@ -12,38 +12,13 @@
 // stop-test max and the CG column dots.
 #include "glx_internal.h"
 #include <stdlib.h>
-#ifndef GLX_PIPE_DEPTH
-#define GLX_PIPE_DEPTH 1
-#endif
-#ifndef GLX_NT_STREAM
-#define GLX_NT_STREAM 0   // measured: nontemporal operator loads 15.5 vs 13.4 us (the image is re-read from the Infinity Cache every sweep)
-#endif
-#ifndef GLX_NT_STORE
-#define GLX_NT_STORE 0
-#endif
-#ifndef GLX_LOOP_FORM
-#define GLX_LOOP_FORM 1   // 1: branch-free chunk prefetch issued BEHIND the chunk's gathers (see the chunk loop); 0: the round-1 order
-#endif
-#ifndef GLX_FULL_CHUNKS
-#define GLX_FULL_CHUNKS 1   // chunks in which every slot of the slice has four real entries are gathered without predicates
-#endif
-#ifndef GLX_OFF32
-#define GLX_OFF32 0   // experiment: 32-bit record offsets from a uniform base (state < 4 GB) instead of 64-bit address arithmetic
-#endif
-#ifndef GLX_PERSIST_DEFAULT
-#define GLX_PERSIST_DEFAULT 1   // blocks per workgroup of the sweep kernel (see the persistent form in spmm_sell_kernel)
-#endif
-
+#include <string.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { typedef f32x4 type; };
 template <> struct VecOf<double> { typedef f64x4 type; };
-
-// 256 bytes of zeros: what the lanes of an entry past the end of its row gather in the branch-free loop forms (0 * 0 = 0 exactly,
-// whatever the state holds -- a product with a real record could be 0 * inf)
-__device__ double g_zero_rec[32];
 
 struct SpmmParams {
   const int32_t* slot_row;
@@ -77,11 +52,12 @@ struct SpmmParams {
   int prod_sc;              // prod_out is blocked by prod_sc columns: (row, col) at ((col/sc)*n + row)*sc + col%sc
   const int32_t* perm;      // record -> caller row (null: identity)
   int64_t n_rows;
-  int nt;                   // bit 0: nontemporal operator-stream loads, bit 1: nontemporal stores (GLX_NT / large operators)
   const int32_t* dup_ptr;   // HAS_DUP (boundary rows of a vertex-partitioned sweep): row r is ALSO stored at records dup_pos[dup_ptr[r] .. dup_ptr[r+1]) of dup_out
   const int32_t* dup_pos;   //   -- the send buffer of the halo exchange, so no pack kernel sits between the SpMM and the transport
   char* dup_out;
-  int ablate;               // developer probe (GLX_ABLATE): 1 no chunk loop, 2 gathers hit one hot record, 4 no stores, 8 no XCD remap
+  const unsigned* rowmask;  // CG, Dirichlet rows: bit g of rowmask[record] set = A p is held at zero there for system g (null: none)
+  int fused;                // tolerance-mode CG: three dots + in-kernel reduction to alpha / beta (cg_fused.hip)
+  CgDev cg;
 };
 
 // ---- cross-lane helpers -------------------------------------------------------------
@@ -114,6 +90,11 @@ template <typename V> __device__ __forceinline__ V row_ror4(V v) {
   for (int i = 0; i < NW; ++i) b.w[i] = row_ror4_i(a.w[i]);
   return b.v;
 }
+template <int CTRL> __device__ __forceinline__ double row_ror(double v) {      // CTRL = 0x120 + lanes
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 template <typename V> __device__ __forceinline__ V wave_ror4(V v, int lane) {
   constexpr int NW = sizeof(V) / 4;
   union { V v; int w[NW]; } a, b;
@@ -144,13 +125,6 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   const unsigned mh = wave_max_u32(hi);
   const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
   return ((unsigned long long)mh << 32) | ml;
-}
-
-// XCD-aware block -> slice-group map: the dispatcher places block b on XCD b % 8; hand
-// each XCD a contiguous range of slices so rows that share neighbours share an L2.
-// (the plan pads every range to nb/8 blocks, so the map is a plain transpose)
-__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nb) {
-  return (b % 8) * (nb / 8) + b / 8;
 }
 
 // acc += v * x for one entry.  Entries past the end of a row carry val = 0 and an unloaded
@@ -203,22 +177,28 @@ __device__ __forceinline__ void add_product(typename VecOf<T>::type& acc, double
 // wave shuffle), each adding its products in entry order -- long rows stop being a latency
 // chain of len/4 dependent memory round trips while the rounding sequence stays that of a
 // sequential row sum.
-#ifndef GLX_FORCE_OCC6
-#define GLX_FORCE_OCC6 0
+// (Closed experiments -- other loop forms, a two-chunk pipeline, 32-bit offsets, nontemporal loads / stores, a persistent
+//  grid -- live as patches under scripts/probes/; EXPERIMENTS.md has their numbers.)
+#ifdef GLX_WAVE_PROBE
+__device__ unsigned long long g_wave_probe[1 << 20];
+extern "C" int glx_debug_wave_probe(unsigned long long* out, int64_t n) {
+  GLX_HIP(hipDeviceSynchronize());
+  GLX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_probe), (size_t)n * 8));
+  return GLX_OK;
+}
 #endif
-#if GLX_FORCE_OCC6
-#define GLX_SPMM_OCC __attribute__((amdgpu_waves_per_eu((G == 4 && !PERSIST && !HAS_DOT && sizeof(T) == 8) ? 6 : 1)))
-#else
-#define GLX_SPMM_OCC
-#endif
-template <typename T, int G, bool HAS_W, bool HAS_DOT, bool HAS_DUP = false, bool PERSIST = false>
-__global__ __launch_bounds__(64 * GLX_WPB) GLX_SPMM_OCC void spmm_sell_kernel(const SpmmParams p) {
+template <typename T, int G, bool HAS_W, bool HAS_DOT, bool HAS_DUP = false>
+__global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParams p) {
 #pragma clang fp contract(off)
+#ifdef GLX_WAVE_PROBE
+  const unsigned long long probe_t0 = wall_clock64();
+#endif
   typedef typename VecOf<T>::type V4;
   constexpr int R = 64 / G;
+  constexpr int NRED = GLX_WPB * (G == 4 ? 16 : G) * 12 > 256 ? GLX_WPB * (G == 4 ? 16 : G) * 12 : 256;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  __shared__ double s_red[HAS_DOT ? GLX_WPB * 64 * 4 : 4];
+  __shared__ double s_red[HAS_DOT ? NRED : 4];
 
   // the stop values of the previous sweep: the load is issued HERE, the test comes behind the first slice's loads (below), so that
   // the two round trips overlap instead of following each other in front of every wavefront's work
@@ -226,26 +206,40 @@ __global__ __launch_bounds__(64 * GLX_WPB) GLX_SPMM_OCC void spmm_sell_kernel(co
   if constexpr (HAS_W) {
     if (p.err_prev) stop_v = p.err_prev[lane];
   }
+  const double* act_row = nullptr;
   if constexpr (HAS_DOT) {
-    if (p.exit_err && !(*p.exit_err > p.exit_tol)) return;
+    if (p.fused) {
+      // tolerance-mode CG (cg_fused.hip): the iteration number lives on the device, so that one captured launch sequence serves
+      // every iteration; this kernel reads it_a and hands it to the update kernel through it_b
+      const int it = *p.cg.it_a;
+      if (blockIdx.x == 0 && threadIdx.x == 0) *p.cg.it_b = it;
+      if ((int64_t)blockIdx.x == p.nblocks) {   // the extra workgroup: closes iteration it - 1 beside the product
+        glx_cg_close_iteration(p.cg, it, p.exit_tol, s_red);
+        return;
+      }
+      if (it > p.cg.max_iter) return;
+      // already known to have stopped (a replay behind the last iteration): nothing to do.  A workgroup that does not see the
+      // record yet computes a product nobody reads -- the update kernel decides after the launch boundary
+      if (it >= 2 && *p.cg.closed >= it - 1 && !(p.cg.err_hist[(size_t)(it - 1) * p.cg.stride + p.cg.ngroups] > p.exit_tol)) return;
+      // systems known to have converged neither gather nor store (the record of iteration it - 2: conservative by one iteration)
+      act_row = (p.cg.ngroups > 1 && it >= 2) ? p.cg.err_hist + (size_t)(it - 2) * p.cg.stride : nullptr;
+    } else {
+      if (p.exit_err && !(*p.exit_err > p.exit_tol)) return;
+      act_row = p.act_row;
+    }
   }
-  // Persistent form (GLX_PERSIST = k: grid = nblocks / k workgroups): a workgroup walks the blocks j, j + gridDim/8, ... of ITS
-  // XCD's range, so the header / first-chunk loads of its next block travel while the current one gathers, and the waves of a
-  // CU are in different phases (one stores while another gathers) instead of all starting and all finishing together.
-  // gridDim.x == nblocks is the one-block-per-workgroup form.
-  const int64_t bpx = p.nblocks / 8, gpx = gridDim.x / 8;
-  const bool flat = (p.ablate & 8) != 0;
+  const int64_t bpx = p.nblocks / 8;
   const int g = lane / G, c = lane % G;
   bool lane_on = c < p.nlanes;
   if constexpr (HAS_DOT) {
     // column groups (CG on several systems): lanes whose 4 columns all belong to converged
     // systems neither gather nor store
-    if (p.act_row && lane_on) {
+    if (act_row && lane_on) {
       bool any = false;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int col = c * 4 + e;
-        if (col < p.act_c) any = any || (p.act_row[col / p.act_cg] > p.exit_tol);
+        if (col < p.act_c) any = any || (act_row[col / p.act_cg] > p.exit_tol);
       }
       lane_on = any;
     }
@@ -253,39 +247,27 @@ __global__ __launch_bounds__(64 * GLX_WPB) GLX_SPMM_OCC void spmm_sell_kernel(co
   const bool is_w = HAS_W && (c == p.nvec);
   const T* __restrict__ valp = (const T*)p.val;
   const size_t lane_off = (size_t)c * 4 * sizeof(T);
-  unsigned long long err_run = 0;     // running max of this lane's stop values over the blocks it serves (bit patterns)
 
-  // header + chunk 0 of one slice (chunk 0 sits at a slice-indexed address: its load is issued together with the header loads)
-  struct SliceIn { int col0; T val0; int row, len, nchunks, S, full; int64_t base; };
-  auto load_slice = [&](int64_t slice) -> SliceIn {
-    SliceIn in;
-    in.col0 = 0; in.val0 = 0; in.row = -1; in.len = 0; in.nchunks = 0; in.S = 1; in.full = 0; in.base = 0;
-    if (slice < p.nslices) {
-      if (p.nt & 1) {
-        in.col0 = __builtin_nontemporal_load(&p.col[slice * 64 + lane]);
-        in.val0 = __builtin_nontemporal_load(&valp[slice * 64 + lane]);
-      } else {
-        in.col0 = p.col[slice * 64 + lane];
-        in.val0 = valp[slice * 64 + lane];
-      }
-      const int64_t slot = slice * R + g;
-      in.row = p.slot_row[slot];
-      in.len = p.slot_len[slot];
-      const SliceHdr hd = p.slice_hdr[slice];
-      in.base = p.head + hd.ptr - 64;   // chunk k >= 1 at base + k*64
-      in.nchunks = (p.ablate & 1) ? 0 : hd.nchunks;
-      in.S = hd.S & 0xff;
-      in.full = hd.S >> 8;
-    }
-    return in;
-  };
-  auto vb_of = [&](int64_t it) -> int64_t {     // it-th block of this workgroup, or -1
-    if (flat) { const int64_t v = (int64_t)blockIdx.x + it * gridDim.x; return v < p.nblocks ? v : -1; }
-    const int64_t j = (int64_t)(blockIdx.x / 8) + it * gpx;
-    return j < bpx ? (int64_t)(blockIdx.x % 8) * bpx + j : -1;
-  };
-  int64_t vb = vb_of(0);
-  SliceIn nxt = load_slice(vb >= 0 ? vb * GLX_WPB + wave : p.nslices);
+  // XCD-aware block -> slice-group map: the dispatcher places block b on XCD b % 8; each XCD is handed a contiguous range of
+  // slices so rows that share neighbours share an L2 (the plan pads every range to nblocks / 8 blocks: a plain transpose)
+  const int64_t vb = (int64_t)(blockIdx.x % 8) * bpx + blockIdx.x / 8;
+  const int64_t slice = vb * GLX_WPB + wave;
+  // header + chunk 0 of the slice (chunk 0 sits at a slice-indexed address: its load is issued together with the header loads)
+  int col0 = 0, row = -1, len = 0, nchunks = 0, S = 1, full = 0;
+  T val0 = 0;
+  int64_t base = 0;
+  if (slice < p.nslices) {
+    col0 = p.col[slice * 64 + lane];
+    val0 = valp[slice * 64 + lane];
+    const int64_t slot = slice * R + g;
+    row = p.slot_row[slot];
+    len = p.slot_len[slot];
+    const SliceHdr hd = p.slice_hdr[slice];
+    base = p.head + hd.ptr - 64;   // chunk k >= 1 at base + k*64
+    nchunks = hd.nchunks;
+    S = hd.S & 0xff;
+    full = hd.S >> 8;
+  }
   if constexpr (HAS_W) {
     if (p.err_prev) {   // stop test of ssl.py:667, decided identically by every wavefront
       // (`while ... np.max(np.absolute(v-vinf)) > 1/n`: a NaN maximum compares False and ends the loop too;
@@ -294,53 +276,17 @@ __global__ __launch_bounds__(64 * GLX_WPB) GLX_SPMM_OCC void spmm_sell_kernel(co
       if (m <= p.thresh_bits || m > 0x7ff0000000000000ull) return;
     }
   }
-  for (int64_t it = 0; vb >= 0; ++it) {
-  const int64_t slice = vb * GLX_WPB + wave;
-  SliceIn cur;
-  int64_t vb_next = -1;
-  if constexpr (PERSIST) {
-    cur = nxt;
-    vb_next = vb_of(it + 1);
-    if (vb_next >= 0) nxt = load_slice(vb_next * GLX_WPB + wave);    // in flight during this block's chunk loop
-  } else {
-    cur = it == 0 ? nxt : load_slice(slice);                           // one block per workgroup: nothing to look ahead to
-  }
-  const int col0 = cur.col0;
-  const T val0 = cur.val0;
-  const int row = cur.row, len = cur.len, nchunks = cur.nchunks, S = cur.S;
   // chunks [0, full): every lane of every slot has a real entry (plan) and every lane of a row is in use -> no predicates
-  const int full = (p.nlanes == G && !(HAS_DOT && p.act_row)) ? (cur.full < nchunks ? cur.full : nchunks) : 0;
-  const int64_t base = cur.base;
+  full = (p.nlanes == G && !(HAS_DOT && act_row)) ? (full < nchunks ? full : nchunks) : 0;
   const int seg = g & (S - 1);            // S is a power of two
   V4 acc = {0, 0, 0, 0};
   double accw = 0.0;
 
   if constexpr (G == 4) {
-    // Software pipeline: index/value chunks travel 3 chunks ahead of their use, the
-    // neighbour gathers of chunk k+1 are in flight while chunk k is being added up.
+    // Software pipeline: the index / value chunk k+1 travels while the neighbour gathers of chunk k do.
     struct CV { int col; T val; };
-    // unconditional (index clamped to the slice's last chunk): a conditional load would make the
-    // compiler wait for it at the branch join, i.e. before this chunk's gathers are even issued
-    auto load_cv = [&](int k) -> CV {
-      CV r;
-      const int kc = k < nchunks ? k : nchunks - 1;
-      if (kc <= 0) {          // (also the clamp target of a 1-chunk slice)
-        r.col = col0;
-        r.val = val0;
-      } else if (p.nt & 1) {
-        r.col = __builtin_nontemporal_load(&p.col[base + (int64_t)kc * 64 + lane]);
-        r.val = __builtin_nontemporal_load(&valp[base + (int64_t)kc * 64 + lane]);
-      } else {
-        r.col = p.col[base + (int64_t)kc * 64 + lane];
-        r.val = valp[base + (int64_t)kc * 64 + lane];
-      }
-      return r;
-    };
     auto issue = [&](const CV& cv, int k, V4 (&x)[4], T (&v)[4]) {
-      int c0 = quad_bcast_i<0>(cv.col), c1 = quad_bcast_i<1>(cv.col), c2 = quad_bcast_i<2>(cv.col), c3 = quad_bcast_i<3>(cv.col);
-#ifdef GLX_ABLATE_BUILD      // developer probe (gathers hit 16 hot records): compile-time only, a branch here splits the chunk loop's blocks
-      if (p.ablate & 2) { c0 &= 15; c1 &= 15; c2 &= 15; c3 &= 15; }
-#endif
+      const int c0 = quad_bcast_i<0>(cv.col), c1 = quad_bcast_i<1>(cv.col), c2 = quad_bcast_i<2>(cv.col), c3 = quad_bcast_i<3>(cv.col);
       v[0] = quad_bcast<0>(cv.val);
       v[1] = quad_bcast<1>(cv.val);
       v[2] = quad_bcast<2>(cv.val);
@@ -350,18 +296,10 @@ __global__ __launch_bounds__(64 * GLX_WPB) GLX_SPMM_OCC void spmm_sell_kernel(co
       x[1] = V4{0, 0, 0, 0};
       x[2] = V4{0, 0, 0, 0};
       x[3] = V4{0, 0, 0, 0};
-#if GLX_OFF32
-      const unsigned lo32 = (unsigned)lane_off, rb = (unsigned)p.rec_bytes;
-      if (lane_on && j0 + 0 < len) x[0] = *(const V4*)(p.xin + ((unsigned)c0 * rb + lo32));
-      if (lane_on && j0 + 1 < len) x[1] = *(const V4*)(p.xin + ((unsigned)c1 * rb + lo32));
-      if (lane_on && j0 + 2 < len) x[2] = *(const V4*)(p.xin + ((unsigned)c2 * rb + lo32));
-      if (lane_on && j0 + 3 < len) x[3] = *(const V4*)(p.xin + ((unsigned)c3 * rb + lo32));
-#else
       if (lane_on && j0 + 0 < len) x[0] = *(const V4*)(p.xin + (size_t)c0 * p.rec_bytes + lane_off);
       if (lane_on && j0 + 1 < len) x[1] = *(const V4*)(p.xin + (size_t)c1 * p.rec_bytes + lane_off);
       if (lane_on && j0 + 2 < len) x[2] = *(const V4*)(p.xin + (size_t)c2 * p.rec_bytes + lane_off);
       if (lane_on && j0 + 3 < len) x[3] = *(const V4*)(p.xin + (size_t)c3 * p.rec_bytes + lane_off);
-#endif
     };
     auto consume = [&](int k, const V4 (&x)[4], const T (&v)[4]) {
       if (S == 1) {
@@ -390,98 +328,14 @@ __global__ __launch_bounds__(64 * GLX_WPB) GLX_SPMM_OCC void spmm_sell_kernel(co
         }
       }
     };
-#if GLX_PIPE_DEPTH >= 2
-    V4 xA[4], xB[4];
-    T vA[4], vB[4];
-    CV q0, q1, q2, q3;
-    q0.col = q1.col = q2.col = q3.col = 0;
-    q0.val = q1.val = q2.val = q3.val = 0;
-    if (nchunks > 0) { q0 = load_cv(0); q1 = load_cv(1); q2 = load_cv(2); issue(q0, 0, xA, vA); }
-    int k = 0;
-    while (k < nchunks) {
-      q3 = load_cv(k + 3); issue(q1, k + 1, xB, vB); consume(k, xA, vA); if (++k >= nchunks) break;
-      q0 = load_cv(k + 3); issue(q2, k + 1, xA, vA); consume(k, xB, vB); if (++k >= nchunks) break;
-      q1 = load_cv(k + 3); issue(q3, k + 1, xB, vB); consume(k, xA, vA); if (++k >= nchunks) break;
-      q2 = load_cv(k + 3); issue(q0, k + 1, xA, vA); consume(k, xB, vB); ++k;
-    }
-#else
     V4 xA[4];
     T vA[4];
-#if GLX_LOOP_FORM == 2 || GLX_LOOP_FORM == 3
-    // Experimental (2: two chunks of gathers in flight; 3: one, like form 1, but without exec-mask branches).  Every load of the loop is unconditional -- lanes whose entry lies past the end
-    // of the row gather the zero record instead of being masked off -- so that the compiler's wait-counter pass can count the
-    // loads behind the ones it waits for (a load under an exec-mask branch makes it fall back to "all but the unconditional ones").
-    auto load_cv2 = [&](int k) -> CV {
-      const int kc = k < nchunks ? k : nchunks - 1;
-      const int64_t off = (kc <= 0 ? slice * 64 : base + (int64_t)kc * 64) + lane;
-      CV r;
-      r.col = p.col[off];
-      r.val = valp[off];
-      return r;
-    };
-    const char* zrec = (const char*)g_zero_rec + lane_off;
-    auto issue_u = [&](const CV& cv, int k, V4 (&x)[4], T (&v)[4]) {
-      const int c0 = quad_bcast_i<0>(cv.col), c1 = quad_bcast_i<1>(cv.col), c2 = quad_bcast_i<2>(cv.col), c3 = quad_bcast_i<3>(cv.col);
-      v[0] = quad_bcast<0>(cv.val);
-      v[1] = quad_bcast<1>(cv.val);
-      v[2] = quad_bcast<2>(cv.val);
-      v[3] = quad_bcast<3>(cv.val);
-      const int j0 = (k * S + seg) * 4;
-      const char* a0 = (lane_on && j0 + 0 < len) ? p.xin + (size_t)c0 * p.rec_bytes + lane_off : zrec;
-      const char* a1 = (lane_on && j0 + 1 < len) ? p.xin + (size_t)c1 * p.rec_bytes + lane_off : zrec;
-      const char* a2 = (lane_on && j0 + 2 < len) ? p.xin + (size_t)c2 * p.rec_bytes + lane_off : zrec;
-      const char* a3 = (lane_on && j0 + 3 < len) ? p.xin + (size_t)c3 * p.rec_bytes + lane_off : zrec;
-      x[0] = *(const V4*)a0;
-      x[1] = *(const V4*)a1;
-      x[2] = *(const V4*)a2;
-      x[3] = *(const V4*)a3;
-    };
-#if GLX_LOOP_FORM == 3
-    {
-      CV qn;
-      qn.col = col0;
-      qn.val = val0;
-      for (int k = 0; k < nchunks; ++k) {
-        const CV qc = qn;
-        issue_u(qc, k, xA, vA);
-        qn = load_cv2(k + 1);
-        consume(k, xA, vA);
-      }
-    }
-#else
-    V4 xB[4];
-    T vB[4];
-    if (nchunks > 0) {
-      CV c0v;
-      c0v.col = col0;
-      c0v.val = val0;
-      CV c1v = load_cv2(1);            // older than the gathers of chunk 0: it arrives first
-      CV c2v;
-      issue_u(c0v, 0, xA, vA);
-      int k = 0;
-      while (true) {
-        if (k + 1 >= nchunks) { consume(k, xA, vA); break; }
-        c2v = load_cv2(k + 2);
-        issue_u(c1v, k + 1, xB, vB);
-        consume(k, xA, vA);
-        ++k;
-        if (k + 1 >= nchunks) { consume(k, xB, vB); break; }
-        c1v = load_cv2(k + 2);
-        issue_u(c2v, k + 1, xA, vA);
-        consume(k, xB, vB);
-        ++k;
-      }
-    }
-#endif
-#elif GLX_LOOP_FORM
-    // Round 3.  The round-1 order issued the next chunk's index / value load FIRST and the gathers behind it; the load sat in a
-    // branch (chunk 0 comes from registers, later chunks from memory), and the compiler's wait-counter pass answers a load in a
-    // branch with `s_waitcnt vmcnt(0)` at the join -- so every chunk waited for the NEXT chunk's indices before its own gathers
-    // were even issued: two memory round trips per chunk instead of one (read off the ISA).  Now the address is selected, not the
-    // value (chunk 0 is re-read from its slice-indexed place), the load is unconditional and it is issued BEHIND the gathers: the
-    // wait in front of the adds is `vmcnt(2)` -- the gathers, not the two youngest loads -- and the next chunk's indices have the
-    // whole gather round trip to arrive.
-    auto load_cv2 = [&](int k) -> CV {
+    // The next chunk's index / value load is unconditional (the ADDRESS is selected, not the value: chunk 0 is re-read from its
+    // slice-indexed place) and it is issued BEHIND the gathers: the wait in front of the adds is `vmcnt(2)` -- the gathers, not the
+    // two youngest loads -- and the next chunk's indices have the whole gather round trip to arrive.  (A conditional load, or one
+    // issued in front of the gathers, makes the compiler's wait-counter pass drain everything at the join: two memory round trips
+    // per chunk instead of one -- read off the ISA in round 3.)
+    auto load_cv = [&](int k) -> CV {
       const int kc = k < nchunks ? k : nchunks - 1;
       const int64_t off = (kc <= 0 ? slice * 64 : base + (int64_t)kc * 64) + lane;
       CV r;
@@ -496,60 +350,28 @@ __global__ __launch_bounds__(64 * GLX_WPB) GLX_SPMM_OCC void spmm_sell_kernel(co
       v[1] = quad_bcast<1>(cv.val);
       v[2] = quad_bcast<2>(cv.val);
       v[3] = quad_bcast<3>(cv.val);
-#if GLX_OFF32
-      const unsigned lo32 = (unsigned)lane_off, rb = (unsigned)p.rec_bytes;
-      x[0] = *(const V4*)(p.xin + ((unsigned)c0 * rb + lo32));
-      x[1] = *(const V4*)(p.xin + ((unsigned)c1 * rb + lo32));
-      x[2] = *(const V4*)(p.xin + ((unsigned)c2 * rb + lo32));
-      x[3] = *(const V4*)(p.xin + ((unsigned)c3 * rb + lo32));
-#else
       x[0] = *(const V4*)(p.xin + (size_t)c0 * p.rec_bytes + lane_off);
       x[1] = *(const V4*)(p.xin + (size_t)c1 * p.rec_bytes + lane_off);
       x[2] = *(const V4*)(p.xin + (size_t)c2 * p.rec_bytes + lane_off);
       x[3] = *(const V4*)(p.xin + (size_t)c3 * p.rec_bytes + lane_off);
-#endif
     };
     CV qn;
     qn.col = col0;
     qn.val = val0;
     int k = 0;
-#if GLX_FULL_CHUNKS == 2
-    for (; k < nchunks; ++k) {          // one loop, the gather form picked per chunk (uniform branch)
-      const CV qc = qn;
-      if (k < full) issue_full(qc, xA, vA); else issue(qc, k, xA, vA);
-      qn = load_cv2(k + 1);
-      consume(k, xA, vA);
-    }
-#else
-#if GLX_FULL_CHUNKS
-    if (sizeof(T) == 4 || GLX_FULL_CHUNKS == 3)     // fp64: the second loop costs 4 registers and with them a wavefront per SIMD (measured: slower)
+    if (sizeof(T) == 4)     // fp64: the second loop costs 4 registers and with them a wavefront per SIMD (measured: slower)
       for (; k < full; ++k) {
         const CV qc = qn;
         issue_full(qc, xA, vA);
-        qn = load_cv2(k + 1);
+        qn = load_cv(k + 1);
         consume(k, xA, vA);
       }
-#endif
     for (; k < nchunks; ++k) {
       const CV qc = qn;
       issue(qc, k, xA, vA);
-      qn = load_cv2(k + 1);
+      qn = load_cv(k + 1);
       consume(k, xA, vA);
     }
-#endif
-#else
-    CV qn;
-    qn.col = 0;
-    qn.val = 0;
-    if (nchunks > 0) qn = load_cv(0);
-    for (int k = 0; k < nchunks; ++k) {
-      const CV qc = qn;
-      qn = load_cv(k + 1);      // next chunk's indices/values travel while this chunk's gathers do
-      issue(qc, k, xA, vA);
-      consume(k, xA, vA);
-    }
-#endif
-#endif
   } else {
     const int gbase = lane & ~(G - 1);
     for (int k = 0; k < nchunks; ++k) {
@@ -575,6 +397,13 @@ __global__ __launch_bounds__(64 * GLX_WPB) GLX_SPMM_OCC void spmm_sell_kernel(co
     }
   }
 
+#ifdef GLX_WAVE_PROBE
+  if (lane == 0 && slice * 4 + 3 < (1 << 20)) {
+    g_wave_probe[slice * 4 + 0] = probe_t0;
+    g_wave_probe[slice * 4 + 1] = wall_clock64();
+    g_wave_probe[slice * 4 + 2] = ((unsigned long long)nchunks << 32) | (unsigned)S;
+  }
+#endif
   // epilogue: u_out[row] = Db[row] + acc   (ssl.py:668: `Db + P*u`; addition commutes bitwise)
   V4 outv = acc;
   const bool store_on = lane_on && row >= 0 && seg == 0;
@@ -593,12 +422,21 @@ __global__ __launch_bounds__(64 * GLX_WPB) GLX_SPMM_OCC void spmm_sell_kernel(co
         outv[3] = 0;
       }
     }
-    if (!(p.ablate & 4)) {
-      if (p.nt & 2)
-        __builtin_nontemporal_store(outv, (V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off));
-      else
-        *(V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off) = outv;
+    if constexpr (HAS_DOT) {
+      // Dirichlet rows (ssl.laplace, ssl.py:1232-1241): A p is held at zero on the labelled rows of each system (bit g of the row's
+      // mask), so x, r and p stay zero there and the solve is the one on the sub-matrix (cg.hip)
+      if (p.rowmask) {
+        const unsigned m = p.rowmask[row];
+        if (m) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int col = c * 4 + e;
+            if (col < p.act_c && ((m >> (col / p.act_cg)) & 1u)) outv[e] = 0;
+          }
+        }
+      }
     }
+    *(V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off) = outv;
     if constexpr (HAS_DUP) {
       // a boundary row leaves for its peers straight from the registers: one more store per destination
       for (int q = p.dup_ptr[row], q1 = p.dup_ptr[row + 1]; q < q1; ++q)
@@ -615,54 +453,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) GLX_SPMM_OCC void spmm_sell_kernel(co
         e = fabs(p.deg[row] * wnew - p.vinf[row]);
         if (e != e) e = __longlong_as_double(0x7ff8000000000000ll);   // canonical NaN: orders above +inf as a bit pattern (np.max propagates NaN)
       }
-      const unsigned long long eb = (unsigned long long)__double_as_longlong(e);
-      err_run = eb > err_run ? eb : err_run;
-    }
-  }
-
-  if constexpr (HAS_DOT) {
-    // column dots sum_rows xin[row,c] * xout[row,c] (utils.py:524 `np.sum(p*Ap,axis=0)`):
-    // fixed-order tree inside the block, one partial row per block, reduced by the consumer.
-    double d[4] = {0, 0, 0, 0};
-    if (store_on) {
-      const V4 own = *(const V4*)(p.xin + (size_t)row * p.rec_bytes + lane_off);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d[e] = (double)own[e] * (double)outv[e];
-      if (p.prod_out && c < p.nvec) {   // elementwise p*Ap in the array dtype, row-major (dot_ld columns) in the caller's row order
-        const V4 pr = own * outv;
-        const int64_t orow = p.perm ? p.perm[row] : row;
-        f64x4 pd;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pd[e] = (double)pr[e];
-        *(f64x4*)(p.prod_out + ((size_t)((c * 4) / p.prod_sc) * p.n_rows + orow) * p.prod_sc + (c * 4) % p.prod_sc) = pd;
-      }
-    }
-#pragma unroll
-    for (int off = 32; off >= G; off >>= 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d[e] += shfl_d(d[e], lane ^ off);
-    }
-    if (lane < G) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s_red[(wave * 64 + lane) * 4 + e] = d[e];
-    }
-    __syncthreads();
-    if (threadIdx.x < G && threadIdx.x < p.nvec) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        double s = s_red[(0 * 64 + threadIdx.x) * 4 + e];
-        for (int w = 1; w < GLX_WPB; ++w) s += s_red[(w * 64 + threadIdx.x) * 4 + e];
-        p.dot_partial[(size_t)vb * p.dot_ld + threadIdx.x * 4 + e] = s;
-      }
-    }
-    __syncthreads();   // s_red is reused by the workgroup's next block
-  }
-  vb = vb_next;
-  }   // blocks of this workgroup
-
-  if constexpr (HAS_W) {
-    if (p.err_next) {
-      const unsigned long long m = wave_max_u64(err_run);
+      const unsigned long long m = wave_max_u64((unsigned long long)__double_as_longlong(e));
       __shared__ unsigned long long s_err[GLX_WPB];
       if (lane == 0) s_err[wave] = m;
       __syncthreads();
@@ -673,29 +464,115 @@ __global__ __launch_bounds__(64 * GLX_WPB) GLX_SPMM_OCC void spmm_sell_kernel(co
       }
     }
   }
+
+#ifdef GLX_WAVE_PROBE
+  if (lane == 0 && slice * 4 + 3 < (1 << 20)) g_wave_probe[slice * 4 + 3] = wall_clock64();
+#endif
+  if constexpr (HAS_DOT) {
+    // column dots over the rows (utils.py:524 `np.sum(p*Ap,axis=0)`): fixed-order tree inside the block, one partial row per
+    // block, reduced by the consumer.  ND = 1: p.Ap;  tolerance-mode CG, ND = 3: p.Ap, r.Ap, Ap.Ap (cg_fused.hip)
+    double d[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (store_on) {
+      const V4 own = *(const V4*)(p.xin + (size_t)row * p.rec_bytes + lane_off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = (double)own[e] * (double)outv[e];
+      if (p.fused) {
+        const V4 rv = *(const V4*)(p.cg.r + (size_t)row * p.rec_bytes + lane_off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          d[4 + e] = (double)rv[e] * (double)outv[e];
+          d[8 + e] = (double)outv[e] * (double)outv[e];
+        }
+      }
+      if (p.prod_out && c < p.nvec) {   // elementwise p*Ap in the array dtype, row-major (dot_ld columns) in the caller's row order
+        const V4 pr = own * outv;
+        const int64_t orow = p.perm ? p.perm[row] : row;
+        f64x4 pd;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pd[e] = (double)pr[e];
+        *(f64x4*)(p.prod_out + ((size_t)((c * 4) / p.prod_sc) * p.n_rows + orow) * p.prod_sc + (c * 4) % p.prod_sc) = pd;
+      }
+    }
+    if (!p.fused) {
+#pragma unroll
+      for (int off = 32; off >= G; off >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] += shfl_d(d[e], lane ^ off);
+      }
+      if (lane < G) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_red[(wave * G + lane) * 4 + e] = d[e];
+      }
+      __syncthreads();
+      if (threadIdx.x < G && threadIdx.x < p.nvec) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          double s = s_red[(0 * G + threadIdx.x) * 4 + e];
+          for (int w = 1; w < GLX_WPB; ++w) s += s_red[(w * G + threadIdx.x) * 4 + e];
+          p.dot_partial[(size_t)vb * p.dot_ld + threadIdx.x * 4 + e] = s;
+        }
+      }
+    } else {
+      // rows of the wavefront: two DPP row rotations add the four slots of every 16-lane row (G = 4), the rest goes through LDS
+      constexpr int NSUB = G == 4 ? 4 : 1;      // sub-sums per wavefront handed to LDS
+      if constexpr (G == 4) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+          d[e] += row_ror<0x124>(d[e]);
+          d[e] += row_ror<0x128>(d[e]);
+        }
+        if ((lane & 15) < 4) {
+#pragma unroll
+          for (int e = 0; e < 12; ++e) s_red[((wave * 4 + (lane >> 4)) * 4 + (lane & 3)) * 12 + e] = d[e];
+        }
+      } else {
+#pragma unroll
+        for (int off = 32; off >= G; off >>= 1) {
+#pragma unroll
+          for (int e = 0; e < 12; ++e) d[e] += shfl_d(d[e], lane ^ off);
+        }
+        if (lane < G) {
+#pragma unroll
+          for (int e = 0; e < 12; ++e) s_red[(wave * G + lane) * 12 + e] = d[e];
+        }
+      }
+      __syncthreads();
+      // the workgroup's sums leave with agent-scope stores; the last arriver of a group of p.cg.grp workgroups adds the group's
+      // rows (fixed order: deterministic) -- the update kernel adds the groups (cg_fused.hip)
+      const int ncols = p.dot_ld, nq = 3 * ncols;
+      for (int q = threadIdx.x; q < nq; q += 64 * GLX_WPB) {
+        const int dot = q / ncols, col = q % ncols, cc = col / 4, e = col % 4;
+        double s = 0.0;
+        if (cc < p.nvec) {
+          for (int w = 0; w < GLX_WPB * NSUB; ++w) s += s_red[(w * G + cc) * 12 + dot * 4 + e];
+        }
+        glx_agent_store(p.cg.part1 + (size_t)vb * nq + q, s);
+      }
+      const int64_t grp = vb / p.cg.grp;
+      const int64_t g0 = grp * p.cg.grp, g1 = g0 + p.cg.grp < p.nblocks ? g0 + p.cg.grp : p.nblocks;
+      if (!glx_arrive_last(p.cg.tick1 + grp, (unsigned)(g1 - g0), s_red)) return;
+      glx_reduce_rows<true>(p.cg.part1 + (size_t)g0 * nq, g1 - g0, nq, s_red, [&](int q, double tot) {
+        p.cg.part1g[(size_t)grp * nq + q] = tot;
+      });
+    }
+  }
 }
 
 int64_t glx_spmm_blocks(const SellPlan* plan) { return (plan->nslices + GLX_WPB - 1) / GLX_WPB; }
 
 template <typename T, int G>
 static int launch_g(const SweepArgs& a, const SpmmParams& p, hipStream_t stream) {
-  // GLX_PERSIST = k > 1: k blocks per workgroup (persistent form, sweeps only: the CG form writes per-block partials)
-  static const int persist = getenv("GLX_PERSIST") ? atoi(getenv("GLX_PERSIST")) : GLX_PERSIST_DEFAULT;
-  int64_t nwg = p.nblocks;
-  if (persist > 1 && !a.dot_partial && p.nblocks >= 8 * (int64_t)persist) nwg = ((p.nblocks / 8 + persist - 1) / persist) * 8;
-  const dim3 grid((unsigned)nwg), block(64 * GLX_WPB);
-  const bool persistent = nwg != p.nblocks;
-  if (a.dot_partial) {
+  const dim3 grid((unsigned)p.nblocks), block(64 * GLX_WPB);
+  if (a.cg) {      // one workgroup more: it closes the previous iteration beside the product (cg_fused.hip)
+    hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, true>), dim3((unsigned)p.nblocks + 1), block, 0, stream, p);
+  } else if (a.dot_partial) {
     hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, true>), grid, block, 0, stream, p);
   } else if (a.has_w && a.dup_ptr) {
-    if (persistent) hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false, true, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false, true>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false, true>), grid, block, 0, stream, p);
   } else if (a.has_w) {
-    if (persistent) hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false, false, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false>), grid, block, 0, stream, p);
   } else {
-    if (persistent) hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, false, false, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, false>), grid, block, 0, stream, p);
   }
   GLX_HIP(hipGetLastError());
   return GLX_OK;
@@ -715,11 +592,12 @@ static int launch_t(const SweepArgs& a, const SpmmParams& p, hipStream_t stream)
 }
 
 int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
-  GLX_CHECK(!(a.dot_partial && a.has_w), GLX_EINVAL, "spmm: dot and stop column are exclusive");
+  GLX_CHECK(!((a.dot_partial || a.cg) && a.has_w), GLX_EINVAL, "spmm: dot and stop column are exclusive");
   GLX_CHECK(!a.dup_ptr || (a.has_w && a.dup_pos && a.dup_out), GLX_EINVAL, "spmm: the send-buffer scatter needs the stop column form and all three arrays");
   GLX_CHECK(a.plan->G == a.L.G, GLX_EINVAL, "spmm: plan G=%d but layout G=%d", a.plan->G, a.L.G);
   if (a.plan->nslices == 0) return GLX_OK;
   SpmmParams p;
+  memset(&p, 0, sizeof(p));
   p.slot_row = a.plan->d_slot_row;
   p.slot_len = a.plan->d_slot_len;
   p.slice_hdr = a.plan->d_slice_hdr;
@@ -756,10 +634,9 @@ int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
   p.dup_ptr = a.dup_ptr;
   p.dup_pos = a.dup_pos;
   p.dup_out = (char*)a.dup_out;
-  static const int ablate = getenv("GLX_ABLATE") ? atoi(getenv("GLX_ABLATE")) : 0;
-  p.ablate = ablate;
-  static const int nt_env = getenv("GLX_NT") ? atoi(getenv("GLX_NT")) : -1;
-  p.nt = nt_env >= 0 ? nt_env : 0;
+  p.rowmask = a.rowmask;
+  p.fused = a.cg ? 1 : 0;
+  if (a.cg) p.cg = *a.cg;
   return a.dtype == GLX_F32 ? launch_t<float>(a, p, stream) : launch_t<double>(a, p, stream);
 }
 

@@ -290,6 +290,14 @@ class ssl:
         raise NotImplementedError('Must override _fit')
 
 
+def _free_order(W, n):
+    """The vertex order that came with the graph for free: the cell order of the search that built W (weightmatrix.knn stamps it
+    on its result).  Operators that are used for a handful of CG solves take it when it is there and keep the caller's order
+    when it is not -- the library's own pass over the graph (O(nnz) on the host) would cost more than such a solve gains."""
+    order = getattr(W, '_glx_order', None)
+    return order if (order is not None and len(order) == n) else None
+
+
 # relative half-width around 1/n inside which a fused stop value is re-derived with the reference's recurrence
 # (poisson._settle_stop); the fused and the reference values differ by <= 1e-13 relative
 STOP_BAND = 1e-9
@@ -383,9 +391,10 @@ class poisson(ssl):
         if self.solver == 'conjugate_gradient':
             L = G.laplacian(normalization='normalized')
             aux['D'] = G.degree_matrix(p=-0.5)
-            # one-shot CG solves spend their time in the reference-order reductions, not in the SpMM:
-            # the locality renumbering (an O(nnz) host pass) would not pay for itself
-            dev = _hip.DeviceGraph(L, dtype=self._dtype(), device=self.device, keep_order=True)
+            # one-shot CG solves spend their time in the reference-order reductions, not in the SpMM: the library's locality
+            # renumbering (an O(nnz) host pass) would not pay for itself -- the search's cell order, when W carries it, is free
+            order = _free_order(self.graph.weight_matrix, n)
+            dev = _hip.DeviceGraph(L, dtype=self._dtype(), device=self.device, keep_order=order is None, order=order)
         elif fast:
             P, deg, dinv = _poisson_operator_symmetric(W)
             aux['D'] = sparse.spdiags(dinv, 0, n, n).tocsr()
@@ -740,7 +749,8 @@ class laplace(ssl):
         L = sparse.csr_matrix(self._laplacian(self.graph))
         Mv = 1 / np.sqrt(L.diagonal() + 1e-10)
         M = sparse.spdiags(Mv, 0, n, n).tocsr()
-        dev = _hip.DeviceGraph(M * L * M, dtype=self.dtype, device=self.device, keep_order=True)
+        order = _free_order(self.graph.weight_matrix, n)
+        dev = _hip.DeviceGraph(M * L * M, dtype=self.dtype, device=self.device, keep_order=order is None, order=order)
         self._cache = (key, L, Mv, dev)
         return L, Mv, dev
 
@@ -856,7 +866,8 @@ class randomwalk(ssl):
         m = L.shape[0]
         M = L.diagonal()
         M = sparse.spdiags(1 / np.sqrt(M + 1e-10), 0, m, m).tocsr()
-        dev = _hip.DeviceGraph(M * L * M, dtype=np.float64, device=self.device, keep_order=True)
+        order = _free_order(self.graph.weight_matrix, n)
+        dev = _hip.DeviceGraph(M * L * M, dtype=np.float64, device=self.device, keep_order=order is None, order=order)
         self._cache = (key, M, dev)
         return M, dev
 
