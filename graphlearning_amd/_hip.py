@@ -118,6 +118,9 @@ _SIGNATURES = {
     'glx_affine_iterate': [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int64), _f64p],
     'glx_cg_groups': [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_cg_groups_masked': [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
+    'glx_cg_groups_rows': [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_int64, C.c_int,
+                           C.POINTER(C.c_int), _f64p],
+    'glx_host_fingerprint': [_vp, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)],
     'glx_argmax_project': [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
     'glx_argmax_project_t': [_vp, C.c_int, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
     'glx_knn_bruteforce': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
@@ -399,6 +402,29 @@ class DeviceGraph:
                                           errs.ctypes.data_as(_f64p)), 'glx_cg_groups_masked')
         return X, its, errs
 
+    def cg_groups_rows(self, rows, vals, group_cols, masks, out_scale=None, tol=1e-10, max_iter=100000, reduce='exact'):
+        """cg_groups for a right-hand side given by its nonzero rows (`rows` distinct, `vals` (len(rows), C); every other row
+        zero -- and zero on the Dirichlet rows, which the caller guarantees), the result optionally scaled row by row on the
+        device (glx_cg_groups_rows).  Returns (X, iterations per group, err per group); X is page-locked memory."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32).ravel()
+        vals = np.ascontiguousarray(vals, dtype=self.dtype)
+        Cc = vals.shape[1]
+        ng = Cc // group_cols
+        if len(masks) != ng:
+            raise GlxError('cg_groups_rows: %d masks for %d systems' % (len(masks), ng))
+        mrows = [np.ascontiguousarray(m, dtype=np.int32).ravel() for m in masks]
+        ptr = np.zeros(ng + 1, dtype=np.int32)
+        ptr[1:] = np.cumsum([len(r) for r in mrows])
+        allrows = np.ascontiguousarray(np.concatenate(mrows) if mrows else np.zeros(0, np.int32), dtype=np.int32)
+        scale = None if out_scale is None else _dense(out_scale, np.float64, (self.shape[0],), 'out_scale')
+        X = pinned_empty((self.shape[0], Cc), self.dtype)
+        its = np.zeros(ng, dtype=np.int32)
+        errs = np.zeros(ng, dtype=np.float64)
+        check(load().glx_cg_groups_rows(self._h, len(rows), _ptr(rows), _ptr(vals), _ptr(scale), _ptr(X), Cc, int(group_cols),
+                                        _ptr(allrows), _ptr(ptr), float(tol), int(max_iter), _reduce_flag(reduce),
+                                        its.ctypes.data_as(C.POINTER(C.c_int)), errs.ctypes.data_as(_f64p)), 'glx_cg_groups_rows')
+        return X, its, errs
+
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
             lib = load(required=False)
@@ -411,6 +437,20 @@ class DeviceGraph:
             self.close()
         except Exception:
             pass
+
+
+def host_fingerprint(arrays):
+    """128-bit content fingerprint of a list of contiguous numpy arrays (glx_host_fingerprint: threaded, in the library), or
+    None when the library is not there."""
+    lib = load(required=False)
+    if lib is None:
+        return None
+    out = (C.c_uint64 * 2)()
+    acc = 0
+    for a in arrays:
+        check(lib.glx_host_fingerprint(_ptr(a), a.nbytes, acc & 0xffffffffffffffff, out), 'glx_host_fingerprint')
+        acc = out[0] ^ ((out[1] * 0x9e3779b97f4a7c15) & 0xffffffffffffffff)
+    return (int(out[0]), int(out[1]))
 
 
 def _reduce_flag(reduce):

@@ -532,7 +532,8 @@ struct CgBufs {
   int64_t* pw_off = nullptr;
   int32_t *pw_len = nullptr, *pw_l = nullptr, *pw_r = nullptr, *pw_ls = nullptr;
   double* pw_vals = nullptr;
-  int32_t *mask_rows = nullptr, *mask_ptr = nullptr;
+  int32_t *mask_rows = nullptr, *mask_ptr = nullptr, *rhs_rows = nullptr;
+  double* out_scale = nullptr;
   double *part_dot = nullptr, *part_rs = nullptr, *scal = nullptr, *err_hist = nullptr, *h_err = nullptr;
   // tolerance mode (cg_fused.hip): partial sums, counters, Dirichlet-row masks, the captured launch sequence of a chunk
   double *f_part1 = nullptr, *f_part1g = nullptr, *f_part2 = nullptr;
@@ -572,6 +573,7 @@ struct CgBufs {
     hipFree(x); hipFree(r); hipFree(p); hipFree(ap); hipFree(dense); hipFree(part_dot); hipFree(part_rs);
     hipFree(scal); hipFree(err_hist); hipFree(prod);
     hipFree(pw_off); hipFree(pw_len); hipFree(pw_l); hipFree(pw_r); hipFree(pw_ls); hipFree(pw_vals); hipFree(mask_rows); hipFree(mask_ptr);
+    hipFree(rhs_rows); hipFree(out_scale);
     hipFree(f_part1); hipFree(f_part1g); hipFree(f_part2); hipFree(f_tick); hipFree(f_rowmask); hipFree(f_it);
     if (f_exec) hipGraphExecDestroy(f_exec);
     for (int q = 0; q < 3; ++q) if (f_ev[q]) hipEventDestroy(f_ev[q]);
@@ -583,12 +585,42 @@ struct CgBufs {
 
 void glx_cg_ws_destroy(void* ws) { delete (CgBufs*)ws; }
 
+// right-hand side rows given one by one (all other rows zero): r[rec(b_rows[q])][:] = b_vals[q][:]
+template <typename T>
+__global__ __launch_bounds__(256) void cg_scatter_rows_kernel(T* __restrict__ rec, int ld, int C, const int32_t* __restrict__ rows,
+                                                              const T* __restrict__ vals, int64_t nb, const int32_t* __restrict__ inv) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nb * C) return;
+  const int64_t q = i / C;
+  const int c = (int)(i % C);
+  const int32_t row = rows[q];
+  rec[(size_t)(inv ? inv[row] : row) * ld + c] = vals[i];
+}
+
+// records -> dense (n, C) in the caller's row order, every row times its scale (ssl.laplace: `v = M*v`, ssl.py:1250)
+template <typename T>
+__global__ __launch_bounds__(256) void cg_unpack_scaled_kernel(const T* __restrict__ rec, T* __restrict__ dense, int64_t n, int C, int ld,
+                                                               const int32_t* __restrict__ perm, const double* __restrict__ scale) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * C) return;
+  const int64_t row = i / C;
+  const int c = (int)(i % C);
+  const int64_t orow = perm ? (int64_t)perm[row] : row;
+  dense[orow * C + c] = (T)((T)scale[orow] * rec[row * ld + c]);
+}
+
+struct CgRhsRows {            // optional forms of the right-hand side and of the result (glx_cg_groups_rows)
+  int64_t nb = 0;
+  const int32_t* rows = nullptr;
+  const void* vals = nullptr;
+  const double* out_scale = nullptr;
+};
+
 template <typename T>
 static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double tol, int64_t max_iter, int* iters_out,
-                  double* err_out, int flags, const int32_t* mask_rows, const int32_t* mask_ptr) {
-  // GLX_CG_REDUCE=tree selects block-tree reductions (faster, deterministic, not bit-identical to numpy)
-  const char* red_env = getenv("GLX_CG_REDUCE");
-  const bool exact = !((red_env && strcmp(red_env, "tree") == 0) || (flags & GLX_CG_TREE));
+                  double* err_out, int flags, const int32_t* mask_rows, const int32_t* mask_ptr, const CgRhsRows& rr) {
+  const bool exact = !(flags & GLX_CG_TREE);   // tolerance mode: cg_fused.hip (deterministic, not bit-identical to numpy's chains)
   const bool np1d = exact && (flags & 1) && C == 1;   // caller passed a 1-D right-hand side: numpy's pairwise reductions
   const int ngroups = C / Cg;
   const int stride = ngroups + 1;
@@ -598,7 +630,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   int rc = glx_make_layout(C, dtype, false, &L);
   if (rc) return rc;
   SellPlan* plan = nullptr;
-  rc = glx_graph_plan(A, L.G, &plan);
+  rc = glx_graph_plan(A, L.G, &plan, !exact);
   if (rc) return rc;
   const size_t es = L.esize;
   const int ncols = L.nvec * 4;
@@ -696,9 +728,25 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   GLX_HIP(hipMemsetAsync(b.ap, 0, recb, st));
   GLX_HIP(hipMemsetAsync(b.part_dot, 0, nb_spmm * ncols * 8, st));
   GLX_HIP(hipMemsetAsync(b.scal, 0, 3 * ncols * 8, st));
-  GLX_HIP(hipMemcpyAsync(b.dense, B, (size_t)n * C * es, hipMemcpyHostToDevice, st));
-  rc = glx_pack_records(b.dense, b.r, n, L, dtype, nullptr, st, A->d_perm);   // r = b - A@0 = b (utils.py:514)
-  if (rc) return rc;
+  if (rr.rows) {            // the nonzero rows only (ssl.laplace: the neighbours of the labelled vertices)
+    GLX_HIP(hipMemsetAsync(b.r, 0, recb, st));
+    if (rr.nb > 0) {
+      CG_NEED(b.rhs_rows, (size_t)rr.nb * 4);
+      GLX_HIP(hipMemcpyAsync(b.rhs_rows, rr.rows, (size_t)rr.nb * 4, hipMemcpyHostToDevice, st));
+      GLX_HIP(hipMemcpyAsync(b.dense, rr.vals, (size_t)rr.nb * C * es, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL((cg_scatter_rows_kernel<T>), dim3((unsigned)((rr.nb * C + 255) / 256)), dim3(256), 0, st, (T*)b.r, L.ld, C,
+                         (const int32_t*)b.rhs_rows, (const T*)b.dense, rr.nb, (const int32_t*)A->d_inv);
+      GLX_HIP(hipGetLastError());
+    }
+  } else {
+    GLX_HIP(hipMemcpyAsync(b.dense, B, (size_t)n * C * es, hipMemcpyHostToDevice, st));
+    rc = glx_pack_records(b.dense, b.r, n, L, dtype, nullptr, st, A->d_perm);   // r = b - A@0 = b (utils.py:514)
+    if (rc) return rc;
+  }
+  if (rr.out_scale) {
+    CG_NEED(b.out_scale, (size_t)n * 8);
+    GLX_HIP(hipMemcpyAsync(b.out_scale, rr.out_scale, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  }
   GLX_HIP(hipMemcpyAsync(b.p, b.r, recb, hipMemcpyDeviceToDevice, st));   // p = r.copy() (utils.py:516)
   hipLaunchKernelGGL((cg_update_kernel<T, 1>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
                      (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, sc, 1, tol, b.prod, prod_sc, (const int32_t*)A->d_perm);
@@ -942,8 +990,14 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     read_history(b.h_err, it0, cnt);
   }
   }
-  rc = glx_unpack_records(b.x, b.dense, n, L, dtype, st, A->d_perm);
-  if (rc) return rc;
+  if (rr.out_scale) {
+    hipLaunchKernelGGL((cg_unpack_scaled_kernel<T>), dim3((unsigned)std::max<int64_t>((n * C + 255) / 256, 1)), dim3(256), 0, st,
+                       (const T*)b.x, (T*)b.dense, n, C, L.ld, (const int32_t*)A->d_perm, (const double*)b.out_scale);
+    GLX_HIP(hipGetLastError());
+  } else {
+    rc = glx_unpack_records(b.x, b.dense, n, L, dtype, st, A->d_perm);
+    if (rc) return rc;
+  }
   GLX_HIP(hipMemcpyAsync(X, b.dense, (size_t)n * C * es, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
   for (int g = 0; g < ngroups; ++g) {
@@ -953,10 +1007,9 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   return GLX_OK;
 }
 
-extern "C" int glx_cg_groups_masked(glx_graph* A, const void* B, void* X, int C, int group_cols, const int32_t* mask_rows,
-                                    const int32_t* mask_ptr, double tol, int64_t max_iter, int flags, int* iters_out,
-                                    double* err_out) {
-  GLX_CHECK(A && B && X, GLX_EINVAL, "glx_cg_multi: null argument");
+static int cg_entry(glx_graph* A, const void* B, void* X, int C, int group_cols, const int32_t* mask_rows, const int32_t* mask_ptr,
+                    double tol, int64_t max_iter, int flags, int* iters_out, double* err_out, const CgRhsRows& rr) {
+  GLX_CHECK(A && (B || rr.rows) && X, GLX_EINVAL, "glx_cg_multi: null argument");
   GLX_CHECK(A->n_rows == A->n_cols, GLX_EINVAL, "glx_cg_multi: operator must be square");
   GLX_CHECK(max_iter >= 0, GLX_EINVAL, "glx_cg_multi: negative max_iter");
   GLX_CHECK(C >= 1 && group_cols >= 1 && C % group_cols == 0, GLX_EINVAL,
@@ -965,8 +1018,32 @@ extern "C" int glx_cg_groups_masked(glx_graph* A, const void* B, void* X, int C,
             "glx_cg_groups_masked: mask_rows and mask_ptr go together");
   std::lock_guard<std::mutex> one_solve(A->solve_mu);   // the operator's work buffers are shared by its solves (include/glx.h: threading)
   GLX_HIP(hipSetDevice(A->device));
-  return A->dtype == GLX_F32 ? cg_run<float>(A, B, X, C, group_cols, tol, max_iter, iters_out, err_out, flags, mask_rows, mask_ptr)
-                             : cg_run<double>(A, B, X, C, group_cols, tol, max_iter, iters_out, err_out, flags, mask_rows, mask_ptr);
+  return A->dtype == GLX_F32 ? cg_run<float>(A, B, X, C, group_cols, tol, max_iter, iters_out, err_out, flags, mask_rows, mask_ptr, rr)
+                             : cg_run<double>(A, B, X, C, group_cols, tol, max_iter, iters_out, err_out, flags, mask_rows, mask_ptr, rr);
+}
+
+extern "C" int glx_cg_groups_masked(glx_graph* A, const void* B, void* X, int C, int group_cols, const int32_t* mask_rows,
+                                    const int32_t* mask_ptr, double tol, int64_t max_iter, int flags, int* iters_out,
+                                    double* err_out) {
+  return cg_entry(A, B, X, C, group_cols, mask_rows, mask_ptr, tol, max_iter, flags, iters_out, err_out, CgRhsRows());
+}
+
+extern "C" int glx_cg_groups_rows(glx_graph* A, int64_t nb, const int32_t* b_rows, const void* b_vals, const double* out_scale, void* X,
+                                  int C, int group_cols, const int32_t* mask_rows, const int32_t* mask_ptr, double tol, int64_t max_iter,
+                                  int flags, int* iters_out, double* err_out) {
+  GLX_CHECK(nb >= 0 && b_rows && (nb == 0 || b_vals), GLX_EINVAL, "glx_cg_groups_rows: null right-hand side");
+  GLX_CHECK(!(flags & (GLX_CG_X0 | GLX_CG_NP1D)), GLX_EINVAL, "glx_cg_groups_rows: flags X0 / NP1D need the dense form");
+  if (A) {
+    GLX_CHECK(nb <= A->n_rows, GLX_EINVAL, "glx_cg_groups_rows: %lld rows given, the operator has %lld", (long long)nb, (long long)A->n_rows);
+    for (int64_t q = 0; q < nb; ++q)
+      GLX_CHECK(b_rows[q] >= 0 && b_rows[q] < A->n_rows, GLX_EINVAL, "glx_cg_groups_rows: row %d out of range", b_rows[q]);
+  }
+  CgRhsRows rr;
+  rr.nb = nb;
+  rr.rows = b_rows;
+  rr.vals = b_vals;
+  rr.out_scale = out_scale;
+  return cg_entry(A, nullptr, X, C, group_cols, mask_rows, mask_ptr, tol, max_iter, flags, iters_out, err_out, rr);
 }
 
 extern "C" int glx_cg_groups(glx_graph* A, const void* B, void* X, int C, int group_cols, double tol, int64_t max_iter, int flags,

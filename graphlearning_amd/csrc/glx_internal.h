@@ -60,6 +60,7 @@ struct SliceHdr {
 
 struct SellPlan {
   int G = 0, R = 0;
+  bool relaxed = false;        // built for kernels that add a row's entries in any fixed order (tolerance-mode CG): see glx_graph_plan
   int64_t nslices = 0;
   int64_t stored = 0;          // stored entries incl. padding
   int64_t head = 0;            // first `head` entries: chunk 0 of every slice (slice s at s*64), addressable
@@ -110,7 +111,7 @@ struct glx_work {
 int glx_work_acquire(int device, glx_work** out);
 void glx_work_release(glx_work* w);
 
-int glx_graph_plan(glx_graph* g, int G, SellPlan** out);
+int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed = false);
 int glx_graph_ensure_order(glx_graph* g);
 
 // ---- tolerance-mode CG (cg_fused.hip): two launches per iteration ----------------------------------------------------

@@ -7,6 +7,7 @@
 #include <numeric>
 #include <chrono>
 #include <thread>
+#include <string.h>
 #include <stdlib.h>
 
 static thread_local std::string g_err;
@@ -178,6 +179,56 @@ void glx_pool_free(void* p) {
     }
   }
   hipFree(p);
+}
+
+// 128-bit content fingerprint (host): 4 MiB chunks hashed independently by a few threads -- two 64-bit multiply-mix lanes per
+// chunk over 16-byte blocks -- and the chunk digests folded in order.  Not cryptographic: it tells an edited matrix from an
+// unedited one (utils.matrix_fingerprint), 25 MB in ~0.2 ms instead of ~1 ms on one core.
+static inline uint64_t fp_mix(uint64_t a, uint64_t b) {
+  const __uint128_t m = (__uint128_t)(a ^ 0x9e3779b97f4a7c15ull) * (b ^ 0xc2b2ae3d27d4eb4full);
+  return (uint64_t)m ^ (uint64_t)(m >> 64);
+}
+static void fp_chunk(const unsigned char* p, size_t len, uint64_t seed, uint64_t out[2]) {
+  uint64_t h0 = seed ^ 0x243f6a8885a308d3ull ^ len, h1 = seed ^ 0x13198a2e03707344ull;
+  size_t i = 0;
+  for (; i + 32 <= len; i += 32) {
+    uint64_t w[4];
+    memcpy(w, p + i, 32);
+    h0 = fp_mix(h0 ^ w[0], w[1]) + (h0 << 1);
+    h1 = fp_mix(h1 ^ w[2], w[3]) + (h1 << 1);
+  }
+  uint64_t tail[4] = {0, 0, 0, 0};
+  memcpy(tail, p + i, len - i);
+  h0 = fp_mix(h0 ^ tail[0], tail[1] + 0x5851f42d4c957f2dull);
+  h1 = fp_mix(h1 ^ tail[2], tail[3] + 0x14057b7ef767814full);
+  out[0] = fp_mix(h0, h1 + len);
+  out[1] = fp_mix(h1, h0 ^ (len * 0x9fb21c651e98df25ull));
+}
+extern "C" int glx_host_fingerprint(const void* data, size_t bytes, uint64_t seed, uint64_t out[2]) {
+  GLX_CHECK(out && (data || bytes == 0), GLX_EINVAL, "glx_host_fingerprint: null argument");
+  const size_t CH = (size_t)4 << 20;
+  const size_t nch = std::max<size_t>(1, (bytes + CH - 1) / CH);
+  std::vector<uint64_t> dig(2 * nch);
+  const unsigned char* p = (const unsigned char*)data;
+  auto work = [&](size_t c0, size_t c1) {
+    for (size_t c = c0; c < c1; ++c) fp_chunk(p + c * CH, std::min(CH, bytes - std::min(bytes, c * CH)), seed + c, &dig[2 * c]);
+  };
+  const int nt = (int)std::min<size_t>(8, nch);
+  if (nt <= 1) {
+    work(0, nch);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, nch * t / nt, nch * (t + 1) / nt);
+    for (auto& x : th) x.join();
+  }
+  uint64_t a = seed ^ bytes, b = ~seed;
+  for (size_t c = 0; c < nch; ++c) {
+    a = fp_mix(a ^ dig[2 * c], b + dig[2 * c + 1]);
+    b = fp_mix(b ^ dig[2 * c + 1], a);
+  }
+  out[0] = a;
+  out[1] = b;
+  return GLX_OK;
 }
 
 extern "C" int glx_host_alloc(size_t bytes, void** out) {
@@ -568,9 +619,10 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(const int32_t* __restric
 // over S = 4 slots and rows longer than L4 over S = 16 slots (GLX_SELL_L1/L4).  Every range
 // is padded with empty slices to the same number of 4-slice blocks, so block b serves range
 // b % 8 -- the XCD the dispatcher is observed to place it on.
-int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
+int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
+  if (G != 4) relaxed = false;      // (segments exist in G = 4 plans only)
   for (auto& p : g->plans)
-    if (p.G == G) {
+    if (p.G == G && p.relaxed == relaxed) {
       *out = &p;
       return GLX_OK;
     }
@@ -591,6 +643,11 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   // four quarter-filled slots) and less padding: n = 1e6 (d = 64): 277.1 us with 24/96, 258.5 with 40/160, 248.6 with 64/256
   // (-10 %), 250.9 with 96/384; n = 1e7: 4020 -> 3887 us; at 70 000 vertices 64/256 costs 18.1 us against 13.1
   // (profiles/r03_slot_thresholds.txt).
+  // Relaxed plans (tolerance-mode CG: a row's entries may be added in any fixed order, its segments sum independently and are
+  // combined once behind the chunk loop): what counts is the number of wavefronts, every one of which pays its header loads, its
+  // epilogue and its share of the column dots -- fewer, longer slices win.  Config 3 (60 000 vertices, rows of 21..660 entries),
+  // SpMM + dots per launch: 8/64 37.6 us, 24/96 32.2, 32/128 27.3, 64/256 26.5, 96/384 32.6 (profiles/r04_cg_slot_thresholds.txt)
+  if (relaxed) { L1 = 64; L4 = 256; }
   if ((double)g->n_cols * G * 4.0 * (g->dtype == GLX_F64 ? 8.0 : 4.0) >= 64.0 * 1024 * 1024) { L1 = 64; L4 = 256; }
   if (const char* e = getenv("GLX_SELL_L1")) L1 = std::max(4, atoi(e));
   if (const char* e = getenv("GLX_SELL_L4")) L4 = std::max(L1, atoi(e));
@@ -662,6 +719,31 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
       if (G == 4) h.S = S | ((narrow / (4 * S)) << 8);
       ghdr[x].push_back(h);
     }
+    // longest-running slices first (the launch ends when the last wavefront does): a slice's time is its gather rounds times the
+    // cost of a round in its class -- measured per chunk at config 3: 1.25 / 2.5 / 3.6 us for S = 1 / 4 / 16 when the running sum
+    // hops between segments, one price for all when it does not (relaxed)
+    {
+      const size_t ns = ghdr[x].size();
+      std::vector<int32_t> idx(ns);
+      for (size_t q = 0; q < ns; ++q) idx[q] = (int32_t)q;
+      auto cost = [&](const SliceHdr& h) {
+        const int S = h.S & 0xff;
+        return (int64_t)h.nchunks * (relaxed ? 4 : (S == 1 ? 4 : (S == 4 ? 8 : 12)));
+      };
+      std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return cost(ghdr[x][a]) > cost(ghdr[x][b]); });
+      std::vector<SliceHdr> h2(ns);
+      std::vector<int32_t> r2(ns * R), l2(ns * R);
+      for (size_t q = 0; q < ns; ++q) {
+        h2[q] = ghdr[x][idx[q]];
+        for (int r = 0; r < R; ++r) {
+          r2[q * R + r] = grow[x][(size_t)idx[q] * R + r];
+          l2[q * R + r] = glen[x][(size_t)idx[q] * R + r];
+        }
+      }
+      ghdr[x].swap(h2);
+      grow[x].swap(r2);
+      glen[x].swap(l2);
+    }
   }
   lap("slices formed");
   int64_t bpx = 0;   // blocks (GLX_WPB slices) per XCD range
@@ -693,6 +775,7 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out) {
   SellPlan p;
   p.G = G;
   p.R = R;
+  p.relaxed = relaxed;
   p.nslices = nslices;
   p.stored = head + stored;
   p.head = head;

@@ -56,7 +56,6 @@ struct SpmmParams {
   const int32_t* dup_pos;   //   -- the send buffer of the halo exchange, so no pack kernel sits between the SpMM and the transport
   char* dup_out;
   const unsigned* rowmask;  // CG, Dirichlet rows: bit g of rowmask[record] set = A p is held at zero there for system g (null: none)
-  int fused;                // tolerance-mode CG: three dots + in-kernel reduction to alpha / beta (cg_fused.hip)
   CgDev cg;
 };
 
@@ -187,9 +186,11 @@ extern "C" int glx_debug_wave_probe(unsigned long long* out, int64_t n) {
   return GLX_OK;
 }
 #endif
-template <typename T, int G, bool HAS_W, bool HAS_DOT, bool HAS_DUP = false>
+// DOT: 0 none; 1 the column dots p.Ap of the exact CG (cg.hip); 2 the tolerance-mode CG's form (cg_fused.hip)
+template <typename T, int G, bool HAS_W, int DOT, bool HAS_DUP = false>
 __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParams p) {
 #pragma clang fp contract(off)
+  constexpr bool HAS_DOT = DOT != 0, FUSED = DOT == 2;
 #ifdef GLX_WAVE_PROBE
   const unsigned long long probe_t0 = wall_clock64();
 #endif
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
   }
   const double* act_row = nullptr;
   if constexpr (HAS_DOT) {
-    if (p.fused) {
+    if constexpr (FUSED) {
       // tolerance-mode CG (cg_fused.hip): the iteration number lives on the device, so that one captured launch sequence serves
       // every iteration; this kernel reads it_a and hands it to the update kernel through it_b
       const int it = *p.cg.it_a;
@@ -276,6 +277,9 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       if (m <= p.thresh_bits || m > 0x7ff0000000000000ull) return;
     }
   }
+  // tolerance-mode CG: the entries of a long row need not be added in stored order -- its S segments sum their own entries and
+  // a fixed tree combines them at the end, instead of the running sum hopping from segment to segment in every chunk
+  constexpr bool relaxed = FUSED;
   // chunks [0, full): every lane of every slot has a real entry (plan) and every lane of a row is in use -> no predicates
   full = (p.nlanes == G && !(HAS_DOT && act_row)) ? (full < nchunks ? full : nchunks) : 0;
   const int seg = g & (S - 1);            // S is a power of two
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       if (lane_on && j0 + 3 < len) x[3] = *(const V4*)(p.xin + (size_t)c3 * p.rec_bytes + lane_off);
     };
     auto consume = [&](int k, const V4 (&x)[4], const T (&v)[4]) {
-      if (S == 1) {
+      if (relaxed || S == 1) {   // relaxed: every segment keeps its own partial sum, added up once behind the loop
         accum4<T, HAS_W>(acc, accw, v[0], x[0], is_w);
         accum4<T, HAS_W>(acc, accw, v[1], x[1], is_w);
         accum4<T, HAS_W>(acc, accw, v[2], x[2], is_w);
@@ -404,6 +408,21 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
     g_wave_probe[slice * 4 + 2] = ((unsigned long long)nchunks << 32) | (unsigned)S;
   }
 #endif
+  if constexpr (FUSED && G == 4) {
+    if (S > 1) {      // the segments' partial sums: two DPP rotations inside the 16-lane row, two exchanges across rows
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double a = (double)acc[e];
+        a += row_ror<0x124>(a);
+        a += row_ror<0x128>(a);
+        if (S == 16) {
+          a += shfl_d(a, lane ^ 16);
+          a += shfl_d(a, lane ^ 32);
+        }
+        acc[e] = (T)a;
+      }
+    }
+  }
   // epilogue: u_out[row] = Db[row] + acc   (ssl.py:668: `Db + P*u`; addition commutes bitwise)
   V4 outv = acc;
   const bool store_on = lane_on && row >= 0 && seg == 0;
@@ -476,7 +495,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       const V4 own = *(const V4*)(p.xin + (size_t)row * p.rec_bytes + lane_off);
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = (double)own[e] * (double)outv[e];
-      if (p.fused) {
+      if constexpr (FUSED) {
         const V4 rv = *(const V4*)(p.cg.r + (size_t)row * p.rec_bytes + lane_off);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -493,7 +512,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
         *(f64x4*)(p.prod_out + ((size_t)((c * 4) / p.prod_sc) * p.n_rows + orow) * p.prod_sc + (c * 4) % p.prod_sc) = pd;
       }
     }
-    if (!p.fused) {
+    if constexpr (!FUSED) {
 #pragma unroll
       for (int off = 32; off >= G; off >>= 1) {
 #pragma unroll
@@ -564,15 +583,15 @@ template <typename T, int G>
 static int launch_g(const SweepArgs& a, const SpmmParams& p, hipStream_t stream) {
   const dim3 grid((unsigned)p.nblocks), block(64 * GLX_WPB);
   if (a.cg) {      // one workgroup more: it closes the previous iteration beside the product (cg_fused.hip)
-    hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, true>), dim3((unsigned)p.nblocks + 1), block, 0, stream, p);
+    hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, 2>), dim3((unsigned)p.nblocks + 1), block, 0, stream, p);
   } else if (a.dot_partial) {
-    hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, true>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, 1>), grid, block, 0, stream, p);
   } else if (a.has_w && a.dup_ptr) {
-    hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false, true>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, 0, true>), grid, block, 0, stream, p);
   } else if (a.has_w) {
-    hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, 0>), grid, block, 0, stream, p);
   } else {
-    hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, 0>), grid, block, 0, stream, p);
   }
   GLX_HIP(hipGetLastError());
   return GLX_OK;
@@ -635,7 +654,6 @@ int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
   p.dup_pos = a.dup_pos;
   p.dup_out = (char*)a.dup_out;
   p.rowmask = a.rowmask;
-  p.fused = a.cg ? 1 : 0;
   if (a.cg) p.cg = *a.cg;
   return a.dtype == GLX_F32 ? launch_t<float>(a, p, stream) : launch_t<double>(a, p, stream);
 }

@@ -11,7 +11,7 @@ class graph:
     def __init__(self, W, labels=None, features=None, label_names=None, node_names=None):
         self.weight_matrix = sparse.csr_matrix(W)
         if getattr(W, '_glx_sym', None) is not None:
-            self.weight_matrix._glx_sym = W._glx_sym      # valid only while the wrapper shares W's arrays: utils.known_symmetric compares addresses
+            self.weight_matrix._glx_sym = W._glx_sym      # a CONTENT fingerprint: utils.known_symmetric re-hashes the arrays, so an edited copy is simply unknown
         if getattr(W, '_glx_order', None) is not None:
             self.weight_matrix._glx_order = W._glx_order    # (a vertex order stays valid whatever happens to the values)
         self.labels = labels

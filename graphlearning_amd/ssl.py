@@ -680,6 +680,40 @@ def _neg_columns_times(L, Lcsc, cols, F):
     return out
 
 
+def _neg_columns_times_rows(L, Lcsc, cols, F):
+    """The nonzero rows of `-L[:, cols] * F` (see _neg_columns_times) as (row numbers ascending, values): a row's terms
+    (-l_ij) * F[pos(j), :] are added in ascending j starting from 0, exactly as there, but only the rows some selected column
+    reaches are ever touched.  Returns None when the preconditions of the column-wise form do not hold."""
+    cols = np.asarray(cols)
+    if not (L.has_sorted_indices and L.has_canonical_format and len(np.unique(cols)) == len(cols)) or len(cols) == 0:
+        return None
+    indptr, indices, data = Lcsc.indptr, Lcsc.indices, Lcsc.data
+    pos = np.argsort(cols, kind='stable')                    # selected columns in ascending j
+    cs = cols[pos]
+    lo = indptr[cs].astype(np.int64)
+    lens = indptr[cs + 1].astype(np.int64) - lo
+    total = int(lens.sum())
+    if total == 0:
+        return np.zeros(0, dtype=np.int32), np.zeros((0, F.shape[1]))
+    starts = np.cumsum(lens) - lens
+    idx = np.repeat(lo - starts, lens) + np.arange(total, dtype=np.int64)      # entries of the selected columns, column after column
+    rows = indices[idx]
+    fpos = np.repeat(pos, lens)
+    order = np.argsort(rows, kind='stable')                  # by row; inside a row the ascending-j order survives
+    rows_s = rows[order]
+    contrib = (-data[idx[order]])[:, None] * F[fpos[order], :]
+    first = np.ones(total, dtype=bool)
+    first[1:] = rows_s[1:] != rows_s[:-1]
+    seg = np.cumsum(first) - 1                               # which output row an entry belongs to
+    seg_start = np.flatnonzero(first)
+    rank = np.arange(total) - seg_start[seg]                 # its place in that row's sum
+    out = np.zeros((len(seg_start), F.shape[1]))
+    for r in range(int(rank.max()) + 1):                     # sequential per row: at most one entry per row and pass
+        sel = rank == r
+        out[seg[sel], :] += contrib[sel, :]
+    return rows_s[seg_start].astype(np.int32), out
+
+
 class laplace(ssl):
     def __init__(self, W=None, class_priors=None, X=None, reweighting='none', normalization='combinatorial', tau=0,
                  order=1, mean_shift=False, tol=1e-5, alpha=2, zeta=1e7, r=0.1, reduce='exact'):
@@ -780,6 +814,22 @@ class laplace(ssl):
         if self.reweighting == 'none':
             L, Mv, dev = self._full_system()
             train_ind = np.asarray(train_ind)
+            k = len(np.unique(train_labels))
+            F = utils.labels_to_onehot(train_labels, k)
+            sp = _neg_columns_times_rows(L, self._full_csc(L), train_ind, F)
+            if sp is not None and (len(train_ind) == 0 or (train_ind.min() >= 0 and train_ind.max() < L.shape[0])):
+                # b = -L[:,train_ind]*F (ssl.py:1236) lives on the neighbours of the labelled vertices: only those rows go up,
+                # M*b (ssl.py:1249) row by row; `v = M*v` (ssl.py:1250) is applied on the device on the way out
+                rows, b = sp
+                keep = ~np.isin(rows, train_ind)                 # the labelled rows themselves are not part of the system
+                rows, b = rows[keep], b[keep]
+                u, its, _ = dev.cg_groups_rows(rows, Mv[rows, None] * b, k, masks=[train_ind], out_scale=Mv, tol=self.tol,
+                                               reduce=self.reduce)
+                self.num_iter = int(its[0])
+                u[train_ind, :] = F                              # reference ssl.py:1253-1255
+                if self.mean_shift:
+                    u -= np.mean(u, axis=0)
+                return u
             F, B, k = self._rhs(L, Mv, train_ind, train_labels)
             x, its, _ = dev.cg_groups(B, k, tol=self.tol, masks=[train_ind], reduce=self.reduce)
             self.num_iter = int(its[0])

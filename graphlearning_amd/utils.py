@@ -72,20 +72,16 @@ def _boundary_handling(bdy_set, bdy_val):
 
 
 def matrix_fingerprint(W):
-    """Content fingerprint of a scipy sparse matrix: shape, nnz and a 128-bit hash of its three arrays (xxh3: 0.8 ms for
-    the 14 MB of the 70 000-vertex graph).  The device-resident operators of the learners are keyed by it, so a matrix
-    whose values were edited IN PLACE between two fits is seen as a new graph -- the reference rebuilds its operator on
-    every fit (ssl.py:615-644), an `id(W)` key would silently reuse the stale one."""
+    """Content fingerprint of a scipy sparse matrix: shape, nnz and a 128-bit hash of its three arrays (the library's threaded
+    host hash: ~0.2 ms for the 25 MB of the config-3 graph; hashlib's blake2b when the library is not built).  The
+    device-resident operators of the learners are keyed by it, so a matrix whose values were edited IN PLACE between two fits
+    is seen as a new graph -- the reference rebuilds its operator on every fit (ssl.py:615-644), an `id(W)` key would silently
+    reuse the stale one."""
     arrays = [np.ascontiguousarray(getattr(W, name)) for name in ('data', 'indices', 'indptr') if hasattr(W, name)]
     if not arrays:                                          # a dense matrix or another sparse format
         arrays = [np.ascontiguousarray(sparse.csr_matrix(W).data)]
-    try:
-        import xxhash
-        h = xxhash.xxh3_128()
-        for a in arrays:
-            h.update(memoryview(a).cast('B'))
-        digest = h.intdigest()
-    except ImportError:                                     # slower, same role
+    digest = _hip.host_fingerprint(arrays)
+    if digest is None:                                      # slower, same role
         import hashlib
         h = hashlib.blake2b(digest_size=16)
         for a in arrays:

@@ -71,6 +71,9 @@ int glx_host_permute_rows(int64_t n, const int32_t* rowptr, const int32_t* col, 
 
 /* page-locked host memory for result arrays (a D2H copy into pageable memory is staged and several times slower;
  * the Python boundary recycles these blocks as the backing store of the numpy arrays it returns) */
+/* 128-bit content fingerprint of `bytes` bytes (chunks hashed on a few host threads, then combined): what the learners key
+ * their device-resident operators by, so that a weight matrix edited in place between two fits is seen as a new graph. */
+int glx_host_fingerprint(const void* data, size_t bytes, uint64_t seed, uint64_t out[2]);
 int glx_host_alloc(size_t bytes, void** out);
 int glx_host_free(void* p);
 
@@ -282,6 +285,15 @@ int glx_cg_groups(glx_graph* A, const void* B, void* X, int C, int group_cols, d
 int glx_cg_groups_masked(glx_graph* A, const void* B, void* X, int C, int group_cols, const int32_t* mask_rows,
                          const int32_t* mask_ptr, double tol, int64_t max_iter, int flags, int* iters_out,
                          double* err_out);
+
+/* the same with the right-hand side given by its nonzero rows and the result scaled row by row on the way out -- what
+ * ssl.laplace._fit needs per training set (ssl.py:1236-1250): b = -L[:,train]*F is nonzero only on the neighbours of the
+ * labelled vertices, and `v = M*v` multiplies row i of the solution by M_ii.  b_rows (nb,) distinct rows, b_vals (nb, C) of the
+ * operator's dtype; rows not listed are zero.  out_scale (n,) fp64 or NULL: X[i,:] = out_scale[i] * x[i,:] (one rounding, the
+ * product numpy forms).  Saves the (n, C) upload and two host passes per fit; results identical to the dense form. */
+int glx_cg_groups_rows(glx_graph* A, int64_t nb, const int32_t* b_rows, const void* b_vals, const double* out_scale, void* X,
+                       int C, int group_cols, const int32_t* mask_rows, const int32_t* mask_ptr, double tol, int64_t max_iter,
+                       int flags, int* iters_out, double* err_out);
 
 /* ---- predict / volume-constrained projection --------------------------------------
  * ssl.predict (ssl.py:230-266) and ssl.volume_label_projection (ssl.py:172-209) on
