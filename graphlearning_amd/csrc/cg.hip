@@ -1,11 +1,12 @@
 // Multi right-hand-side conjugate gradient on device: utils.conjgrad of the reference
-// (graphlearning/utils.py:483-532) with x0 = 0.  Used by ssl.poisson (default solver,
-// ssl.py:624-629) and ssl.laplace (ssl.py:1249).  Per iteration: one sliced-ELL SpMM with
-// fused column dots, one fused x/r update with fused ||r||^2 partials, one p update, and
-// two single-block fixed-order reductions.  All reductions are deterministic (no float
-// atomics).  The host reads the residual history in chunks; kernels of iterations past
-// convergence exit at once (same trick as the sweep's stop column).
-#include "glx_internal.h"
+// (graphlearning/utils.py:483-532).  Used by ssl.poisson (default solver, ssl.py:624-629) and
+// ssl.laplace (ssl.py:1249).  This file: the REFERENCE-ORDER solve -- every reduction adds in numpy's
+// order, so iterates and iteration counts are bit-identical to the reference.  Per iteration: one
+// sliced-ELL SpMM that also writes the products p*Ap, one fused x/r update that writes r*r, one p
+// update, and two reduction chains (one wavefront per four columns).  The host reads the residual
+// history in chunks; kernels of iterations past convergence exit at once (same trick as the sweep's
+// stop column).  The tolerance mode (GLX_CG_TREE) lives in cg_fused.hip.
+#include "cg_internal.h"
 #include <map>
 #include <string.h>
 #include <algorithm>
@@ -151,54 +152,6 @@ __global__ __launch_bounds__(256) void cg_pupdate_kernel(const T* __restrict__ r
 #pragma unroll
   for (int e = 0; e < 4; ++e) pn[e] = cg_col_active(sc, it, tol, cv * 4 + e) ? pn[e] : pv[e];
   *(V4*)(p + o) = pn;
-}
-
-// single-block fixed-order column reduction of partial[nb][ncols]
-// MODE 0: alpha = rsold / sum (utils.py:524)
-// MODE 1: rsnew = sum; beta = rsnew/rsold; rsold = rsnew (utils.py:527-530; err: cg_group_err_kernel)
-// MODE 2: rsold = sum (utils.py:517)
-template <int MODE>
-__global__ __launch_bounds__(256) void cg_reduce_kernel(const double* __restrict__ partial, int64_t nb, int ncols, int C,
-                                                        CgScalars sc, int it, double tol) {
-#pragma clang fp contract(off)
-  if (MODE != 2 && !cg_any_active(sc, it, tol)) return;
-  __shared__ double s_sum[256];
-  int cp = 1;
-  while (cp < ncols) cp *= 2;
-  const int nparts = 256 / cp;
-  const int c = threadIdx.x % cp, part = threadIdx.x / cp;
-  double s = 0.0;
-  if (c < ncols && part < nparts) {
-    // eight partial sums per thread, combined in a fixed order: the loads of a run of eight do not wait for one another (one
-    // dependent load + add per block result was 30 us for 1528 blocks -- a third of a tolerance-mode iteration at 70 000 rows)
-    const int64_t per = (nb + nparts - 1) / nparts;
-    const int64_t b0 = part * per, b1 = min(nb, b0 + per);
-    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t b = b0;
-    for (; b + 8 <= b1; b += 8) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) a[q] += partial[(size_t)(b + q) * ncols + c];
-    }
-    for (int q = 0; b < b1; ++b, ++q) a[q] += partial[(size_t)b * ncols + c];
-    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-  }
-  s_sum[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x < ncols) {
-    double tot = 0.0;
-    for (int q = 0; q < nparts; ++q) tot += s_sum[q * cp + threadIdx.x];
-    const int cc = threadIdx.x;
-    const bool live = MODE == 2 || cc >= C || cg_col_active(sc, it, tol, cc);
-    if (!live) {
-    } else if (MODE == 0) {
-      sc.alpha[cc] = cc < C ? sc.rsold[cc] / tot : 0.0;
-    } else if (MODE == 1) {
-      sc.beta[cc] = cc < C ? tot / sc.rsold[cc] : 0.0;
-      sc.rsold[cc] = tot;
-    } else {
-      sc.rsold[cc] = tot;
-    }
-  }
 }
 
 // err_g = np.sqrt(np.sum(rsnew_g)) for every group still running (utils.py:528), then the
@@ -392,16 +345,6 @@ __device__ __forceinline__ double np_leaf_sum(const double* __restrict__ a, int6
   return res;
 }
 
-struct PwPlan {          // device arrays; value index space: leaves [0, nleaves), internal nodes after them by height
-  const int64_t* leaf_off;
-  const int32_t* leaf_len;
-  const int32_t* node_l;     // [ninternal] children of internal node q (value indices)
-  const int32_t* node_r;
-  const int32_t* level_start;   // [nlevels + 1] ranges of internal nodes (0-based among internals) per height
-  double* vals;              // [nleaves + ninternal]
-  int nleaves, ninternal, nlevels;
-};
-
 __global__ __launch_bounds__(256) void cg_pw_leaf_kernel(const double* __restrict__ prod, int st, PwPlan pw, CgScalars sc, int it,
                                                          double tol, int mode) {
   if (mode != 2 && !cg_any_active(sc, it, tol)) return;
@@ -524,65 +467,6 @@ __global__ __launch_bounds__(256) void cg_zero_rows_kernel(T* __restrict__ ap, i
   ap[(size_t)row * ld + g * Cg + idx % Cg] = (T)0;
 }
 
-// Work buffers of a solve.  They live with the operator (glx_graph::cg_ws) and are reused by later solves on it:
-// a dozen hipMalloc / hipFree pairs per call cost milliseconds -- as much as a whole tolerance-mode solve at 60k.
-struct CgBufs {
-  void *x = nullptr, *r = nullptr, *p = nullptr, *ap = nullptr, *dense = nullptr;
-  double* prod = nullptr;
-  int64_t* pw_off = nullptr;
-  int32_t *pw_len = nullptr, *pw_l = nullptr, *pw_r = nullptr, *pw_ls = nullptr;
-  double* pw_vals = nullptr;
-  int32_t *mask_rows = nullptr, *mask_ptr = nullptr, *rhs_rows = nullptr;
-  double* out_scale = nullptr;
-  double *part_dot = nullptr, *part_rs = nullptr, *scal = nullptr, *err_hist = nullptr, *h_err = nullptr;
-  // tolerance mode (cg_fused.hip): partial sums, counters, Dirichlet-row masks, the captured launch sequence of a chunk
-  double *f_part1 = nullptr, *f_part1g = nullptr, *f_part2 = nullptr;
-  unsigned *f_tick = nullptr, *f_rowmask = nullptr;
-  int* f_it = nullptr;
-  hipGraphExec_t f_exec = nullptr;
-  std::vector<unsigned long long> f_key;
-  hipEvent_t f_ev[3] = {nullptr, nullptr, nullptr};
-  hipStream_t stream = nullptr, side = nullptr;
-  std::map<void**, size_t> cap;
-  int64_t pw_n = -1;   // rows the pairwise-summation plan was built for
-  PwPlan pw;
-  unsigned pw_grid = 1;
-  // device buffer of at least `bytes` (contents undefined after growth)
-  int need(void** ptr, size_t bytes) {
-    bytes = std::max<size_t>(bytes, 64);
-    auto it = cap.find(ptr);
-    if (it != cap.end() && it->second >= bytes && *ptr) return GLX_OK;
-    hipFree(*ptr);
-    *ptr = nullptr;
-    cap[ptr] = 0;
-    GLX_HIP(hipMalloc(ptr, bytes));
-    cap[ptr] = bytes;
-    return GLX_OK;
-  }
-  int need_host(double** ptr, size_t bytes) {
-    auto it = cap.find((void**)ptr);
-    if (it != cap.end() && it->second >= bytes && *ptr) return GLX_OK;
-    if (*ptr) hipHostFree(*ptr);
-    *ptr = nullptr;
-    cap[(void**)ptr] = 0;
-    GLX_HIP(hipHostMalloc((void**)ptr, bytes, hipHostMallocDefault));
-    cap[(void**)ptr] = bytes;
-    return GLX_OK;
-  }
-  ~CgBufs() {
-    hipFree(x); hipFree(r); hipFree(p); hipFree(ap); hipFree(dense); hipFree(part_dot); hipFree(part_rs);
-    hipFree(scal); hipFree(err_hist); hipFree(prod);
-    hipFree(pw_off); hipFree(pw_len); hipFree(pw_l); hipFree(pw_r); hipFree(pw_ls); hipFree(pw_vals); hipFree(mask_rows); hipFree(mask_ptr);
-    hipFree(rhs_rows); hipFree(out_scale);
-    hipFree(f_part1); hipFree(f_part1g); hipFree(f_part2); hipFree(f_tick); hipFree(f_rowmask); hipFree(f_it);
-    if (f_exec) hipGraphExecDestroy(f_exec);
-    for (int q = 0; q < 3; ++q) if (f_ev[q]) hipEventDestroy(f_ev[q]);
-    if (side) hipStreamDestroy(side);
-    if (h_err) hipHostFree(h_err);
-    if (stream) hipStreamDestroy(stream);
-  }
-};
-
 void glx_cg_ws_destroy(void* ws) { delete (CgBufs*)ws; }
 
 // right-hand side rows given one by one (all other rows zero): r[rec(b_rows[q])][:] = b_vals[q][:]
@@ -597,31 +481,12 @@ __global__ __launch_bounds__(256) void cg_scatter_rows_kernel(T* __restrict__ re
   rec[(size_t)(inv ? inv[row] : row) * ld + c] = vals[i];
 }
 
-// records -> dense (n, C) in the caller's row order, every row times its scale (ssl.laplace: `v = M*v`, ssl.py:1250)
-template <typename T>
-__global__ __launch_bounds__(256) void cg_unpack_scaled_kernel(const T* __restrict__ rec, T* __restrict__ dense, int64_t n, int C, int ld,
-                                                               const int32_t* __restrict__ perm, const double* __restrict__ scale) {
-#pragma clang fp contract(off)
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n * C) return;
-  const int64_t row = i / C;
-  const int c = (int)(i % C);
-  const int64_t orow = perm ? (int64_t)perm[row] : row;
-  dense[orow * C + c] = (T)((T)scale[orow] * rec[row * ld + c]);
-}
-
-struct CgRhsRows {            // optional forms of the right-hand side and of the result (glx_cg_groups_rows)
-  int64_t nb = 0;
-  const int32_t* rows = nullptr;
-  const void* vals = nullptr;
-  const double* out_scale = nullptr;
-};
-
 template <typename T>
 static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double tol, int64_t max_iter, int* iters_out,
                   double* err_out, int flags, const int32_t* mask_rows, const int32_t* mask_ptr, const CgRhsRows& rr) {
-  const bool exact = !(flags & GLX_CG_TREE);   // tolerance mode: cg_fused.hip (deterministic, not bit-identical to numpy's chains)
-  const bool np1d = exact && (flags & 1) && C == 1;   // caller passed a 1-D right-hand side: numpy's pairwise reductions
+  if (flags & GLX_CG_TREE)     // tolerance mode: cg_fused.hip (deterministic, not bit-identical to numpy's chains)
+    return glx_cg_run_fused(A, B, X, C, Cg, tol, max_iter, iters_out, err_out, flags, mask_rows, mask_ptr, rr);
+  const bool np1d = (flags & 1) && C == 1;   // caller passed a 1-D right-hand side: numpy's pairwise reductions
   const int ngroups = C / Cg;
   const int stride = ngroups + 1;
   const int64_t n = A->n_rows;
@@ -630,18 +495,18 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   int rc = glx_make_layout(C, dtype, false, &L);
   if (rc) return rc;
   SellPlan* plan = nullptr;
-  rc = glx_graph_plan(A, L.G, &plan, !exact);
+  rc = glx_graph_plan(A, L.G, &plan);
   if (rc) return rc;
   const size_t es = L.esize;
   const int ncols = L.nvec * 4;
   GLX_CHECK(ncols <= 256, GLX_EUNSUPPORTED, "glx_cg_multi: C=%d too wide for the column reducer", C);
-  GLX_CHECK(Cg <= 128 || !exact, GLX_EUNSUPPORTED, "glx_cg_multi: %d columns per system too wide for the reference-order reducer", Cg);
+  GLX_CHECK(Cg <= 128, GLX_EUNSUPPORTED, "glx_cg_multi: %d columns per system too wide for the reference-order reducer", Cg);
   GLX_CHECK(256 / (L.ld / 4) >= 1, GLX_EUNSUPPORTED, "glx_cg_multi: record too wide");
   const int64_t nb_spmm = std::max<int64_t>(glx_spmm_blocks(plan), 1);
   const int64_t nb_upd = std::max<int64_t>((n + UPD_ROWS_PER_BLOCK - 1) / UPD_ROWS_PER_BLOCK, 1);
-  const int64_t hist_cap = max_iter + 2 + 2 * CG_CHUNK;   // (the tolerance mode copies whole chunks of rows, one chunk ahead)
+  const int64_t hist_cap = max_iter + 2;
   GLX_CHECK(max_iter < (1ll << 24), GLX_EUNSUPPORTED, "glx_cg_multi: max_iter %lld exceeds the supported 2^24-1", (long long)max_iter);
-  GLX_CHECK(n < (1ll << 27) || !exact, GLX_EUNSUPPORTED, "glx_cg_multi: %lld rows exceed the reference-order reducer's 32-bit offsets", (long long)n);
+  GLX_CHECK(n < (1ll << 27), GLX_EUNSUPPORTED, "glx_cg_multi: %lld rows exceed the reference-order reducer's 32-bit offsets", (long long)n);
 
   // reference-order reducer: one wavefront per 4 columns; the product array is blocked the same way
   const int prod_sc = 4;
@@ -650,7 +515,6 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   CgBufs& b = *(CgBufs*)A->cg_ws;
   const size_t recb = std::max<size_t>((size_t)n * L.ld * es, 64);
   if (!b.stream) GLX_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
-#define CG_NEED(ptr, bytes) do { int rc_ = b.need((void**)&(ptr), (bytes)); if (rc_) return rc_; } while (0)
   CG_NEED(b.x, recb);
   CG_NEED(b.r, recb);
   CG_NEED(b.p, recb);
@@ -661,7 +525,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   CG_NEED(b.scal, (size_t)3 * ncols * 8);
   // the residual history is read in chunks: capped, the loop below wraps nothing (max_iter entries are needed only if they run)
   CG_NEED(b.err_hist, (size_t)hist_cap * stride * 8);
-  if (exact) CG_NEED(b.prod, (size_t)ncols * n * 8);
+  CG_NEED(b.prod, (size_t)ncols * n * 8);
   PwPlan pw;
   memset(&pw, 0, sizeof(pw));
   unsigned pw_grid = 1;
@@ -699,7 +563,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     pw = b.pw;
     pw_grid = b.pw_grid;
   }
-  { int rc_ = b.need_host(&b.h_err, (size_t)2 * (CG_CHUNK + 1) * stride * 8); if (rc_) return rc_; }
+  { int rc_ = b.need_host(&b.h_err, (size_t)(CG_CHUNK + 1) * stride * 8); if (rc_) return rc_; }
   CgScalars sc;
   sc.rsold = b.scal;
   sc.alpha = b.scal + ncols;
@@ -756,10 +620,8 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, 0, tol, 2);
       hipLaunchKernelGGL(cg_pw_tree_kernel<2>, dim3(1), dim3(256), 0, st, pw, sc, 0, tol);
     }
-  else if (exact)
-    hipLaunchKernelGGL(cg_seqsum_dpp_kernel<2>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, 0, tol);
   else
-    hipLaunchKernelGGL(cg_reduce_kernel<2>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, 0, tol);
+    hipLaunchKernelGGL(cg_seqsum_dpp_kernel<2>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, 0, tol);
   GLX_HIP(hipGetLastError());
 
   SweepArgs a;
@@ -813,133 +675,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       }
     }
   };
-  if (!exact) {
-    // ---- tolerance mode: two launches per iteration (cg_fused.hip), a chunk of iterations captured once and replayed ----
-    GLX_CHECK(!mask_grid || ngroups <= 32, GLX_EUNSUPPORTED, "glx_cg_groups_masked: at most 32 systems with Dirichlet rows per tolerance-mode solve (got %d)", ngroups);
-    int rpb = 0;
-    const int nb2 = glx_cg_fused_update_blocks(n, &rpb);
-    // groups of SpMM workgroups: small enough that a group's last arriver adds its rows in one round of loads, few enough that
-    // every workgroup of the update kernel can add the groups for itself
-    const int grp = (int)std::max<int64_t>(32, (nb_spmm + 63) / 64);
-    const int64_t ngrp = (nb_spmm + grp - 1) / grp;
-    const int nq = 3 * ncols;
-    CG_NEED(b.f_part1, (size_t)nb_spmm * nq * 8);
-    CG_NEED(b.f_part1g, (size_t)ngrp * nq * 8);
-    CG_NEED(b.f_part2, (size_t)nb2 * ncols * 8);
-    CG_NEED(b.f_tick, (size_t)(ngrp + 1) * 4);
-    CG_NEED(b.f_it, 64);
-    GLX_HIP(hipMemsetAsync(b.f_tick, 0, (size_t)(ngrp + 1) * 4, st));   // (a launch behind the last iteration may leave arrivals behind)
-    const unsigned* rowmask = nullptr;
-    if (mask_grid) {
-      std::vector<unsigned> hm((size_t)n, 0u);
-      for (int g = 0; g < ngroups; ++g)
-        for (int q = mask_ptr[g]; q < mask_ptr[g + 1]; ++q) {
-          const int32_t rec = A->order_ready && !A->h_inv.empty() ? A->h_inv[mask_rows[q]] : mask_rows[q];
-          hm[rec] |= 1u << g;
-        }
-      CG_NEED(b.f_rowmask, (size_t)n * 4);
-      GLX_HIP(hipMemcpyAsync(b.f_rowmask, hm.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-      GLX_HIP(hipStreamSynchronize(st));   // hm leaves scope
-      rowmask = b.f_rowmask;
-    }
-    for (int q = 0; q < 3; ++q)
-      if (!b.f_ev[q]) GLX_HIP(hipEventCreateWithFlags(&b.f_ev[q], hipEventDisableTiming));
-    if (!b.side) GLX_HIP(hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking));
-    CgDev cd;
-    memset(&cd, 0, sizeof(cd));
-    cd.rsold = sc.rsold;
-    cd.err_hist = b.err_hist;
-    cd.stride = stride;
-    cd.ngroups = ngroups;
-    cd.Cg = Cg;
-    cd.C = C;
-    cd.max_iter = (int)max_iter;
-    cd.it_a = b.f_it;
-    cd.it_b = b.f_it + 4;
-    cd.closed = b.f_it + 8;
-    cd.r = (const char*)b.r;
-    cd.part1 = b.f_part1;
-    cd.part1g = b.f_part1g;
-    cd.tick1 = b.f_tick;
-    cd.grp = grp;
-    cd.ngrp = (int)ngrp;
-    cd.part2 = b.f_part2;
-    cd.nb2 = nb2;
-    a.cg = &cd;
-    a.dot_partial = nullptr;
-    a.prod_out = nullptr;
-    a.exit_err = nullptr;
-    a.act_row = nullptr;
-    a.rowmask = rowmask;
-    GLX_HIP(hipMemsetD32Async((hipDeviceptr_t)b.f_it, 1, 8, st));          // it_a = it_b = 1
-    GLX_HIP(hipMemsetD32Async((hipDeviceptr_t)(b.f_it + 8), 0, 8, st));    // closed = 0
-    auto enqueue_chunk = [&]() -> int {
-      for (int q = 0; q < CG_CHUNK; ++q) {
-        int rc2 = glx_launch_spmm(a, st);                                                      // Ap = A@p, dots, alpha, beta
-        if (rc2) return rc2;
-        rc2 = glx_cg_fused_update(dtype, b.x, b.r, b.p, b.ap, n, L, cd, tol, st);              // alpha, beta, x, r, p, r.r
-        if (rc2) return rc2;
-      }
-      return glx_cg_fused_close(cd, tol, st);                                                  // the chunk's last err
-    };
-    // everything the captured kernels were given: a replay is only valid for the same arguments
-    std::vector<unsigned long long> key = {(unsigned long long)(uintptr_t)plan, (unsigned long long)(uintptr_t)plan->d_col,
-                                           (unsigned long long)(uintptr_t)b.x, (unsigned long long)(uintptr_t)b.r,
-                                           (unsigned long long)(uintptr_t)b.p, (unsigned long long)(uintptr_t)b.ap,
-                                           (unsigned long long)(uintptr_t)b.scal, (unsigned long long)(uintptr_t)b.err_hist,
-                                           (unsigned long long)(uintptr_t)b.f_part1, (unsigned long long)(uintptr_t)b.f_part1g,
-                                           (unsigned long long)grp, (unsigned long long)(uintptr_t)b.f_part2,
-                                           (unsigned long long)(uintptr_t)b.f_tick, (unsigned long long)(uintptr_t)b.f_it,
-                                           (unsigned long long)(uintptr_t)rowmask, (unsigned long long)C, (unsigned long long)Cg,
-                                           (unsigned long long)max_iter, (unsigned long long)n, (unsigned long long)dtype, 0ull};
-    memcpy(&key.back(), &tol, 8);
-    if (!b.f_exec || b.f_key != key) {
-      if (b.f_exec) { hipGraphExecDestroy(b.f_exec); b.f_exec = nullptr; }
-      hipGraph_t graph;
-      GLX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      rc = enqueue_chunk();
-      hipError_t e = hipStreamEndCapture(st, &graph);
-      if (rc) return rc;
-      GLX_HIP(e);
-      GLX_HIP(hipGraphInstantiate(&b.f_exec, graph, nullptr, nullptr, 0));
-      GLX_HIP(hipGraphDestroy(graph));
-      b.f_key = key;
-    }
-    // the GPU never waits for the host: chunk c+1 is launched before the history of chunk c is looked at (kernels of iterations
-    // past convergence exit at once)
-    int64_t launched = 0;     // iterations launched
-    int64_t looked = 0;       // iterations whose history the host has read
-    int slot = 0;
-    auto launch_chunk = [&]() -> int {
-      GLX_HIP(hipGraphLaunch(b.f_exec, st));
-      // the history leaves on a second stream: a copy in `st` would sit between this chunk and the next (19 us measured)
-      GLX_HIP(hipEventRecord(b.f_ev[2], st));
-      GLX_HIP(hipStreamWaitEvent(b.side, b.f_ev[2], 0));
-      GLX_HIP(hipMemcpyAsync(b.h_err + (size_t)slot * (CG_CHUNK + 1) * stride, b.err_hist + (size_t)(launched + 1) * stride,
-                             (size_t)CG_CHUNK * stride * 8, hipMemcpyDeviceToHost, b.side));
-      GLX_HIP(hipEventRecord(b.f_ev[slot], b.side));
-      launched += CG_CHUNK;
-      slot ^= 1;
-      return GLX_OK;
-    };
-    if (running > 0 && max_iter > 0) {
-      rc = launch_chunk();
-      if (rc) return rc;
-      while (running > 0 && looked < max_iter) {
-        const bool more = launched < max_iter;
-        if (more) {
-          rc = launch_chunk();
-          if (rc) return rc;
-        }
-        const int rs = more ? slot : slot ^ 1;          // the slot of the oldest chunk not yet read
-        GLX_HIP(hipEventSynchronize(b.f_ev[rs]));
-        const int64_t cnt = std::min<int64_t>(CG_CHUNK, max_iter - looked);
-        read_history(b.h_err + (size_t)rs * (CG_CHUNK + 1) * stride, looked, cnt);
-        looked += CG_CHUNK;
-      }
-      GLX_HIP(hipStreamSynchronize(b.side));   // a chunk launched ahead may still be copying into h_err
-    }
-  } else {
+  {
   int64_t it = 0;                               // iterations launched
   while (running > 0 && it < max_iter) {
     const int64_t end = std::min<int64_t>(max_iter, it + CG_CHUNK);
@@ -960,10 +696,8 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, i, tol, 0);
       hipLaunchKernelGGL(cg_pw_tree_kernel<0>, dim3(1), dim3(256), 0, st, pw, sc, i, tol);
     }
-      else if (exact)
-        hipLaunchKernelGGL(cg_seqsum_dpp_kernel<0>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       else
-        hipLaunchKernelGGL(cg_reduce_kernel<0>, dim3(1), blk, 0, st, (const double*)b.part_dot, nb_spmm, ncols, C, sc, i, tol);
+        hipLaunchKernelGGL(cg_seqsum_dpp_kernel<0>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
       hipLaunchKernelGGL((cg_update_kernel<T, 0>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
                          (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, sc, i, tol, b.prod, prod_sc, (const int32_t*)A->d_perm);
@@ -973,10 +707,8 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, i, tol, 1);
       hipLaunchKernelGGL(cg_pw_tree_kernel<1>, dim3(1), dim3(256), 0, st, pw, sc, i, tol);
     }
-      else if (exact)
-        hipLaunchKernelGGL(cg_seqsum_dpp_kernel<1>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       else
-        hipLaunchKernelGGL(cg_reduce_kernel<1>, dim3(1), blk, 0, st, (const double*)b.part_rs, nb_upd, ncols, C, sc, i, tol);
+        hipLaunchKernelGGL(cg_seqsum_dpp_kernel<1>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
       hipLaunchKernelGGL(cg_group_err_kernel, dim3(1), blk, 0, st, sc, i, tol);
       GLX_HIP(hipGetLastError());
@@ -991,9 +723,8 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   }
   }
   if (rr.out_scale) {
-    hipLaunchKernelGGL((cg_unpack_scaled_kernel<T>), dim3((unsigned)std::max<int64_t>((n * C + 255) / 256, 1)), dim3(256), 0, st,
-                       (const T*)b.x, (T*)b.dense, n, C, L.ld, (const int32_t*)A->d_perm, (const double*)b.out_scale);
-    GLX_HIP(hipGetLastError());
+    rc = glx_cg_unpack_scaled(dtype, b.x, b.dense, n, L, A->d_perm, b.out_scale, st);
+    if (rc) return rc;
   } else {
     rc = glx_unpack_records(b.x, b.dense, n, L, dtype, st, A->d_perm);
     if (rc) return rc;

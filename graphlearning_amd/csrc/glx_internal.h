@@ -211,43 +211,50 @@ __device__ __forceinline__ void glx_reduce_rows(const double* part, int64_t nrow
 __device__ __forceinline__ void glx_cg_close_iteration(const CgDev& cg, int it, double tol, double* s_tmp /* [256] */) {
 #pragma clang fp contract(off)
   const int j = it - 1;
-  if (j < 1 || *cg.closed >= j) return;
-  const double* ran = cg.err_hist + (size_t)(j - 1) * cg.stride;      // system g ran iteration j iff ran[g] > tol
+  if (j < 0 || *cg.closed >= j) return;
+  // system g ran iteration j iff the row before says so; "iteration 0" is the set-up: rsold = r.r of the right-hand side (utils.py:517)
+  const double* ran = j >= 1 ? cg.err_hist + (size_t)(j - 1) * cg.stride : nullptr;
   const int ncols = ((cg.C + 3) / 4) * 4;
   glx_reduce_rows<false>(cg.part2, (int64_t)cg.nb2, ncols, s_tmp, [&](int q, double tot) {
-    if (q >= cg.C || ran[q / cg.Cg] > tol) cg.rsold[q] = tot;
+    if (!ran || q >= cg.C || ran[q / cg.Cg] > tol) cg.rsold[q] = tot;
   });
   __threadfence_block();
   __syncthreads();
-  double mine = 0.0;
-  const int g = threadIdx.x;
-  double* row = cg.err_hist + (size_t)j * cg.stride;
-  if (g < cg.ngroups && ran[g] > tol) {
-    const double* v = cg.rsold + (size_t)g * cg.Cg;
-    const int C = cg.Cg;
-    double e;
-    if (C < 8) {
-      e = 0.0;
-      for (int q = 0; q < C; ++q) e = e + v[q];
-    } else {
-      double r8[8];
-      for (int q = 0; q < 8; ++q) r8[q] = v[q];
-      int i = 8;
-      for (; i < C - (C % 8); i += 8)
-        for (int q = 0; q < 8; ++q) r8[q] = r8[q] + v[i + q];
-      e = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-      for (; i < C; ++i) e = e + v[i];
+  if (j >= 1) {
+    double mine = 0.0;
+    const int g = threadIdx.x;
+    double* row = cg.err_hist + (size_t)j * cg.stride;
+    if (g < cg.ngroups) {
+      if (ran[g] > tol) {
+        const double* v = cg.rsold + (size_t)g * cg.Cg;
+        const int C = cg.Cg;
+        double e;
+        if (C < 8) {
+          e = 0.0;
+          for (int q = 0; q < C; ++q) e = e + v[q];
+        } else {
+          double r8[8];
+          for (int q = 0; q < 8; ++q) r8[q] = v[q];
+          int i = 8;
+          for (; i < C - (C % 8); i += 8)
+            for (int q = 0; q < 8; ++q) r8[q] = r8[q] + v[i + q];
+          e = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+          for (; i < C; ++i) e = e + v[i];
+        }
+        mine = sqrt(e);
+      }
+      row[g] = mine;        // 0 = stopped: every row of the history is written in full, so nothing needs clearing between solves
     }
-    mine = sqrt(e);
-    row[g] = mine;
+    s_tmp[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double m = 0.0;
+      for (int q = 0; q < cg.ngroups && q < 256; ++q)
+        if (s_tmp[q] > m) m = s_tmp[q];
+      row[cg.ngroups] = m;
+    }
   }
-  s_tmp[threadIdx.x] = mine;
-  __syncthreads();
   if (threadIdx.x == 0) {
-    double m = 0.0;
-    for (int q = 0; q < cg.ngroups && q < 256; ++q)
-      if (s_tmp[q] > m) m = s_tmp[q];
-    row[cg.ngroups] = m;
     __threadfence();
     *cg.closed = j;
   }

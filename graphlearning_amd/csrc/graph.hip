@@ -181,6 +181,71 @@ void glx_pool_free(void* p) {
   hipFree(p);
 }
 
+// A few host worker threads that stay around (spawning eight std::threads costs ~0.3 ms: as much as hashing 25 MB).  parallel_for
+// runs fn(t) for t in [0, nt) on the workers and the caller, and returns when all are done.  One job at a time; a process forked
+// from one that had workers starts its own (threads do not survive fork).
+#include <condition_variable>
+#include <functional>
+#include <unistd.h>
+namespace {
+struct HostPool {
+  std::mutex mu, job_mu;
+  std::condition_variable cv, done;
+  std::vector<std::thread>* workers = nullptr;
+  const std::function<void(int)>* fn = nullptr;
+  int next = 0, total = 0, pending = 0;
+  unsigned long gen = 0;
+  pid_t pid = 0;
+  void loop() {
+    unsigned long seen = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&] { return gen != seen; });
+      seen = gen;
+      while (next < total) {
+        const int t = next++;
+        lk.unlock();
+        (*fn)(t);
+        lk.lock();
+        if (--pending == 0) done.notify_all();
+      }
+    }
+  }
+  void run(int nt, const std::function<void(int)>& f) {
+    std::lock_guard<std::mutex> one(job_mu);
+    if (nt <= 1) { for (int t = 0; t < nt; ++t) f(t); return; }
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      if (pid != getpid()) {            // first use, or a forked child: the parent's workers are not here (their handles are left alone)
+        workers = new std::vector<std::thread>();
+        pid = getpid();
+      }
+      const int want = std::min(7, nt - 1);
+      while ((int)workers->size() < want) workers->emplace_back([this] { loop(); });
+      fn = &f;
+      next = 0;
+      total = nt;
+      pending = nt;
+      ++gen;
+    }
+    cv.notify_all();
+    std::unique_lock<std::mutex> lk(mu);
+    while (next < total) {               // the caller works too
+      const int t = next++;
+      lk.unlock();
+      f(t);
+      lk.lock();
+      --pending;
+    }
+    done.wait(lk, [&] { return pending == 0; });
+  }
+};
+HostPool& host_pool() {
+  static HostPool* p = new HostPool();   // never destroyed: its workers may outlive static destruction
+  return *p;
+}
+}  // namespace
+
 // 128-bit content fingerprint (host): 4 MiB chunks hashed independently by a few threads -- two 64-bit multiply-mix lanes per
 // chunk over 16-byte blocks -- and the chunk digests folded in order.  Not cryptographic: it tells an edited matrix from an
 // unedited one (utils.matrix_fingerprint), 25 MB in ~0.2 ms instead of ~1 ms on one core.
@@ -206,7 +271,7 @@ static void fp_chunk(const unsigned char* p, size_t len, uint64_t seed, uint64_t
 }
 extern "C" int glx_host_fingerprint(const void* data, size_t bytes, uint64_t seed, uint64_t out[2]) {
   GLX_CHECK(out && (data || bytes == 0), GLX_EINVAL, "glx_host_fingerprint: null argument");
-  const size_t CH = (size_t)4 << 20;
+  const size_t CH = (size_t)1 << 20;
   const size_t nch = std::max<size_t>(1, (bytes + CH - 1) / CH);
   std::vector<uint64_t> dig(2 * nch);
   const unsigned char* p = (const unsigned char*)data;
@@ -214,13 +279,7 @@ extern "C" int glx_host_fingerprint(const void* data, size_t bytes, uint64_t see
     for (size_t c = c0; c < c1; ++c) fp_chunk(p + c * CH, std::min(CH, bytes - std::min(bytes, c * CH)), seed + c, &dig[2 * c]);
   };
   const int nt = (int)std::min<size_t>(8, nch);
-  if (nt <= 1) {
-    work(0, nch);
-  } else {
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t) th.emplace_back(work, nch * t / nt, nch * (t + 1) / nt);
-    for (auto& x : th) x.join();
-  }
+  host_pool().run(nt, [&](int t) { work(nch * t / nt, nch * (t + 1) / nt); });
   uint64_t a = seed ^ bytes, b = ~seed;
   for (size_t c = 0; c < nch; ++c) {
     a = fp_mix(a ^ dig[2 * c], b + dig[2 * c + 1]);
