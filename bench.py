@@ -179,6 +179,177 @@ def scale_shard_line(steps=4, T=50):
     return out
 
 
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def _median_ms(f, device_sync, min_reps=5, min_s=0.25, max_reps=200):
+    """Median wall time of f() in ms: every repetition bracketed by device synchronisation, repeated until `min_s` seconds have been
+    timed (at least `min_reps` times) -- the headline's rule for the other configurations."""
+    ts, total = [], 0.0
+    while (total < min_s or len(ts) < min_reps) and len(ts) < max_reps:
+        device_sync()
+        t0 = time.perf_counter()
+        f()
+        device_sync()
+        ts.append(time.perf_counter() - t0)
+        total += ts[-1]
+    ts.sort()
+    return ts[len(ts) // 2] * 1e3, ts[0] * 1e3, ts[-1] * 1e3, len(ts)
+
+
+def cg_algorithmic_bytes(n, nnz, C, s_v=8, s_u=8):
+    """SURVEY.md 8d, CG iteration: SpMM bytes (operator values + 4-byte indices, row pointer, read p, write Ap) plus
+    n*C*s_u*(2 [dots: p, Ap] + 3*2 [x, r, p read + write])."""
+    return nnz * (s_v + 4) + 4 * (n + 1) + 2 * n * C * s_u + n * C * s_u * 8
+
+
+def other_configs(W2, labels2, ti2, device_sync, knn_stats2, X2):
+    """BASELINE configs[2], configs[4], the default Poisson solver and weightmatrix.knn, each timed like the headline (median of
+    synchronised repetitions), each checked against the oracle and / or the digests of the reference's own run
+    (tests/golden/g4_large_meta.json, written by tests/golden/make_golden.py from the reference), each with a scipy CPU figure."""
+    import graphlearning_amd as gl
+    from graphlearning_amd import _hip
+    from oracle import gl_oracle as orc          # the checker and the CPU baseline only (after the timed regions)
+    from scipy import sparse
+    meta = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g4_large_meta.json')))
+    out = {}
+    Cc = N_CLASSES
+
+    # ---- config 3: ssl.laplace (Jacobi-scaled CG on the Dirichlet system), 60 000 vertices, k = 20 --------------------------
+    lab3, X3 = config3_data()
+    m3 = meta['config3']
+    build_ms = _median_ms(lambda: gl.weightmatrix.knn(X3, 20), device_sync, min_reps=3, min_s=0.05)
+    W3 = gl.weightmatrix.knn(X3, 20)
+    st3 = _hip.knn_stats()
+    ti3 = gl.trainsets.generate(lab3, rate=10, seed=0)
+    n3 = W3.shape[0]
+    nnzA = int(W3.nnz + n3)                           # the Laplacian: W's pattern plus the diagonal
+    cgb = cg_algorithmic_bytes(n3, nnzA, Cc)
+    c3 = {'workload': 'configs[2]: CIFAR-shaped k=20 kNN graph (n=60000, d=32 synthetic blobs, nnz=%d), ssl.laplace defaults '
+                      '(tol=1e-5), trainsets.generate(rate=10, seed=0)' % W3.nnz,
+          'graph': {'weightmatrix_knn_ms': build_ms[0], 'knn_tile_ms': st3['tile_ms'], 'nnz': int(W3.nnz),
+                    'W_indices_match_reference': _sha(W3.indices.astype(np.int32)) == m3['W_indices_sha']},
+          'algorithmic_bytes_per_iteration': cgb}
+    # the oracle's solve = the CPU baseline (scipy csr_matvecs inside utils.conjgrad's loop, one core) and the checker
+    MAM, Mb, M, idx, F, k = orc.laplace_system(W3, ti3, lab3[ti3])
+    t0 = time.perf_counter()
+    v_ref, it_ref, _ = orc.conjgrad(MAM, Mb, tol=1e-5, return_iters=True)
+    t_cpu = time.perf_counter() - t0
+    u_ref = np.zeros((n3, k))
+    u_ref[idx, :] = M * v_ref
+    u_ref[ti3, :] = F
+    for mode in ('exact', 'tree'):
+        model = gl.ssl.laplace(W3, reduce=mode)
+        u = model.fit(ti3, lab3[ti3])
+        ms = _median_ms(lambda: model.fit(ti3, lab3[ti3]), device_sync)
+        its = int(model.num_iter)
+        per_it = ms[0] * 1e-3 / its
+        c3[mode] = {'fit_ms': ms[0], 'fit_ms_min': ms[1], 'fit_ms_max': ms[2], 'reps': ms[3], 'cg_iterations': its,
+                    'cg_iterations_per_s': its / (ms[0] * 1e-3), 'edges_classes_per_s': nnzA * Cc * its / (ms[0] * 1e-3),
+                    'us_per_iteration_of_fit_wall_time': per_it * 1e6,
+                    'roofline': {'bound': 'hbm', 'achieved': cgb / per_it / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                 'frac': cgb / per_it / 1e9 / HBM_PEAK_GBS,
+                                 'note': 'whole fit (host set-up, uploads, result download included) divided by its iterations'},
+                    'parity': {'iterations_equal_oracle': its == int(it_ref),
+                               'bit_identical_to_oracle': bool(np.array_equal(u, u_ref)),
+                               'max_abs_diff_to_oracle': float(np.max(np.abs(u - u_ref))),
+                               'within_1e-5': bool(np.max(np.abs(u - u_ref)) <= 1e-5),
+                               'labels_match_reference_run': _sha(model.predict().astype(np.int64)) == m3['pred_sha']}}
+    c3['cpu_baseline'] = {'value': it_ref / t_cpu, 'unit': 'CG iterations/s', 'cores': 1, 'kind': 'port',
+                          'sample': 'the whole solve: %d iterations of the oracle\'s conjgrad (scipy csr_matvecs) in %.2f s' % (it_ref, t_cpu)}
+    out['config3_laplace'] = c3
+
+    # ---- config 2, the DEFAULT Poisson solver (conjugate gradient on the singular normalised system) --------------------------
+    m2 = meta['config2']
+    model = gl.ssl.poisson(W2)
+    u = model.fit(ti2, labels2[ti2])
+    ms = _median_ms(lambda: model.fit(ti2, labels2[ti2]), device_sync)
+    its = int(model.num_iter)
+    n2 = W2.shape[0]
+    nnzL = int(W2.nnz + n2)
+    cgb2 = cg_algorithmic_bytes(n2, nnzL, Cc)
+    t0 = time.perf_counter()
+    u_ref2, it_ref2 = orc.poisson_cg(W2, ti2, labels2[ti2], return_iters=True)
+    t_cpu2 = time.perf_counter() - t0
+    per_it = ms[0] * 1e-3 / its
+    out['config2_poisson_cg'] = {
+        'workload': 'configs[1] graph, ssl.poisson(W) with its default solver (conjugate_gradient, tol=1e-3): reference-order reductions, '
+                    'because the system is singular and the iteration count is part of the contract',
+        'fit_ms': ms[0], 'fit_ms_min': ms[1], 'fit_ms_max': ms[2], 'reps': ms[3], 'cg_iterations': its,
+        'cg_iterations_per_s': its / (ms[0] * 1e-3), 'edges_classes_per_s': nnzL * Cc * its / (ms[0] * 1e-3),
+        'algorithmic_bytes_per_iteration': cgb2,
+        'roofline': {'bound': 'hbm', 'achieved': cgb2 / per_it / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': cgb2 / per_it / 1e9 / HBM_PEAK_GBS,
+                     'note': 'two 70 000-long dependent fp64 add chains per iteration (numpy\'s reduction order) bound this mode, not memory'},
+        'parity': {'iterations_equal_oracle': its == int(it_ref2), 'bit_identical_to_oracle': bool(np.array_equal(u, u_ref2)),
+                   'iterations_match_reference_run': its == m2['cg_iters'],
+                   'labels_match_reference_run': _sha(model.predict().astype(np.int64)) == m2['cg_pred_sha']},
+        'cpu_baseline': {'value': it_ref2 / t_cpu2, 'unit': 'CG iterations/s', 'cores': 1, 'kind': 'port',
+                         'sample': 'the whole fit of the oracle (operator set-up + %d scipy conjgrad iterations) in %.2f s' % (it_ref2, t_cpu2)}}
+
+    # ---- config 5: PoissonMBO on the config-2 graph ---------------------------------------------------------------------------
+    m5 = meta['config5']
+    priors = gl.utils.class_priors(labels2)
+    mbo = gl.ssl.poisson_mbo(W2, priors, solver='gradient_descent', Ns=40, mu=1, T=20)
+    prob = mbo.fit(ti2, labels2[ti2])
+    ms = _median_ms(lambda: mbo.fit(ti2, labels2[ti2]), device_sync)
+    sweeps = int(mbo.poisson_model.num_iter) + 20 * 40
+    # CPU: the heat sweeps `u = P*u + Db` are what the reference's 13 s consist of -- a bounded sample of them on this host
+    dt = 1 / np.max(orc.degree_vector(W2))
+    P = sparse.csr_matrix(sparse.identity(n2) - dt * orc.laplacian(W2))
+    ucpu = orc.labels_to_onehot(labels2, Cc).astype(np.float64)
+    Db = np.zeros((n2, Cc))
+    t0 = time.perf_counter()
+    ncpu = 0
+    while time.perf_counter() - t0 < 4.0:
+        for _ in range(10):
+            ucpu = P * ucpu + Db
+        ncpu += 10
+    t_cpu5 = time.perf_counter() - t0
+    out['config5_poisson_mbo'] = {
+        'workload': 'configs[4]: poisson_mbo(W, class_priors, solver=gradient_descent, Ns=40, mu=1, T=20) on the config-2 graph',
+        'fit_ms': ms[0], 'fit_ms_min': ms[1], 'fit_ms_max': ms[2], 'reps': ms[3], 'sweeps_per_fit': sweeps,
+        'sweeps_per_s': sweeps / (ms[0] * 1e-3), 'volume_projections_per_fit': 21,
+        'parity': {'labels_match_reference_run': _sha(mbo.predict().astype(np.int64)) == m5['pred_sha'],
+                   'prob_matches_reference_run': _sha(np.ascontiguousarray(prob, dtype=np.float64)) == m5['prob_sha']},
+        'cpu_baseline': {'value': ncpu / t_cpu5, 'unit': 'heat sweeps/s', 'cores': 1, 'kind': 'port',
+                         'sample': '%d scipy sweeps u = P*u + Db of the same operator in %.1f s (the reference\'s fit is 851 of them plus 21 '
+                                   'projections)' % (ncpu, t_cpu5)}}
+
+    # ---- weightmatrix.knn at config 2 ------------------------------------------------------------------------------------------
+    ms = _median_ms(lambda: gl.weightmatrix.knn(X2, K_NN), device_sync, min_reps=5, min_s=0.1)
+    st = _hip.knn_stats()
+    pairs = float(n2) * n2 * (st['visited_share'] if st['cells'] else 1.0)
+    # matrix-pipe utilisation by TIME: v_mfma_f32_32x32x16_bf16 occupies a SIMD's matrix pipe for 32 cycles (8 passes of 4);
+    # the bf16x3 filter issues three per 32x32x16 product block (two in its concatenated-operand form); 1024 SIMDs at 2.4 GHz
+    n_mfma = pairs / (32.0 * 32.0) * (st['dpa'] / 16.0) * ((2.0 if st['concatenated'] else 3.0) if st['filter'] == 'bf16x3' else 1.0)
+    util = 32.0 * n_mfma / (1024.0 * st['tile_ms'] * 1e-3 * 2.4e9) if st['filter'] == 'bf16x3' else None
+    from scipy.spatial import cKDTree
+    t0 = time.perf_counter()
+    tree = cKDTree(X2)
+    t_tree = time.perf_counter() - t0
+    nq = 2000
+    t0 = time.perf_counter()
+    dq, jq = tree.query(X2[:nq], k=K_NN + 1)
+    t_q = time.perf_counter() - t0
+    J_gpu, D_gpu = gl.weightmatrix.knnsearch(X2, K_NN + 1)
+    out['weightmatrix_knn'] = {
+        'workload': 'weightmatrix.knn(X, 10): n=70000, d=20 -> scipy CSR (search, Gaussian weights, symmetrisation)',
+        'ms': ms[0], 'ms_min': ms[1], 'ms_max': ms[2], 'reps': ms[3], 'knn_tile_ms': st['tile_ms'], 'knn_total_kernels_ms': st['total_ms'],
+        'filter': st['filter'], 'visited_share_of_pairs': (st['visited_share'] if st['cells'] else 1.0),
+        'mfma_instructions_estimated': n_mfma, 'matrix_pipe_utilisation_by_time': util,
+        'useful_tflops_fp32_equivalent': 2.0 * pairs * st['dpa'] / (st['tile_ms'] * 1e-3) / 1e12,
+        'parity': {'first_%d_rows_equal_ckdtree' % nq: bool(np.array_equal(J_gpu[:nq], jq) and np.array_equal(D_gpu[:nq], dq)),
+                   'neighbour_lists_match_reference_run': _sha(J_gpu.astype(np.int64)) == m2['J_sha'],
+                   'W_indices_match_reference_run': _sha(W2.indices.astype(np.int32)) == m2['W_indices_sha']},
+        'cpu_baseline': {'value': nq / t_q, 'unit': 'queries/s', 'cores': 1, 'kind': 'port',
+                         'sample': 'cKDTree.query of the first %d of the 70000 points against the full tree (k=11) in %.2f s, tree built in '
+                                   '%.2f s; the GPU search answers all 70000 in the `ms` above' % (nq, t_q, t_tree),
+                         'gpu_queries_per_s': n2 / (ms[0] * 1e-3)}}
+    return out
+
+
 def measure_traffic(timeout_s=240):
     """HBM-side bytes per launch of the dominant kernel, MEASURED for this build: two child passes of this script
     under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need separate passes, MI355X_MICROARCH.md), per-dispatch means
@@ -342,6 +513,8 @@ def run_single(args):
                         'knn_total_ms': knn_stats['total_ms'], 'fallback_rows': knn_stats['fallback_rows'],
                         'sell': r64['info']},
     }
+    if not args.no_configs:
+        line['configs'] = other_configs(W, labels, train_ind, device_sync, knn_stats, X)
     if not args.no_scale:
         line['scale_shard_1e6'] = scale_shard_line()
     print(json.dumps(line))
@@ -404,6 +577,7 @@ def main():
     ap.add_argument('--n', type=float, default=1e7, help='vertices of --config 4 (default 10^7; kNN alone is ~110 s on one GPU at that size)')
     ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 counter passes (roofline.traffic = null)')
     ap.add_argument('--no-scale', action='store_true', help='skip the n = 10^6 shard-size line')
+    ap.add_argument('--no-configs', action='store_true', help='skip the configs block (configs 3 and 5, Poisson CG, weightmatrix.knn)')
     ap.add_argument('--min-timed-s', type=float, default=0.5,
                     help='batches of --steps steps are repeated until this many seconds have been timed (at least 5 batches).  Profiling runs '
                          'pass 0: rocprofv3 of ROCm 7.2 segfaults after 16 384 dispatches launched from device graphs (profiles/README.md)')
