@@ -121,6 +121,12 @@ _SIGNATURES = {
     'glx_cg_groups_rows': [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_int64, C.c_int,
                            C.POINTER(C.c_int), _f64p],
     'glx_host_fingerprint': [_vp, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)],
+    'glx_knn_search': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)],
+    'glx_knn_result_lists': [_vp, _vp, _vp],
+    'glx_knn_result_order': [_vp, _vp],
+    'glx_knn_result_to_csr': [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp, _vp, C.POINTER(C.c_int64)],
+    'glx_knn_result_destroy': [_vp],
+    'glx_exp_cr': [_vp, _vp, C.c_int64, C.c_int],
     'glx_argmax_project': [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
     'glx_argmax_project_t': [_vp, C.c_int, C.c_int64, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
     'glx_knn_bruteforce': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
@@ -849,6 +855,76 @@ def _knn_search_full(X, n, d, k, clustered, ind, dist, device, want_order=False)
 
 _PINNED_CSR_MAX = 512 << 20      # above this the weight matrix comes back through ordinary memory
 _KERNEL_ID = {'given': 0, 'uniform': 1, 'gaussian': 2, 'symgaussian': 3, 'distance': 4, 'singular': 5}
+
+
+class KnnResult:
+    """A finished full search whose lists live on the device (glx_knn_search): `to_csr` builds the weight matrix from them
+    without a host round trip, `lists()` copies them out, `order()` is the cell order the search worked out (or None)."""
+
+    def __init__(self, X, k, similarity='euclidean', device=None, clustered=None, want_order=False):
+        X = np.asarray(X, dtype=np.float64)
+        if similarity == 'angular':
+            X = X / np.linalg.norm(X, axis=1)[:, None]
+        elif similarity != 'euclidean':
+            raise GlxError('similarity %r not supported (euclidean, angular)' % (similarity,))
+        X = np.ascontiguousarray(X)
+        n, d = X.shape
+        m = auto_cells(n, d) if clustered is None else int(clustered)
+        if m <= 1 and clustered is None and want_order and auto_order_cells(n, d) > 1:
+            m = -auto_order_cells(n, d)     # all pairs on rows reordered by that many chained cells; the order comes with the result
+        self.n, self.k, self.device = n, int(k), _dev(device)
+        self._h = _vp()
+        check(load().glx_knn_search(_ptr(X), n, d, int(k), m if (m > 1 or m < -1) else 0, self.device, C.byref(self._h)), 'glx_knn_search')
+
+    def lists(self):
+        ind = pinned_empty((self.n, self.k), np.int64)
+        dist = pinned_empty((self.n, self.k), np.float64)
+        check(load().glx_knn_result_lists(self._h, _ptr(ind), _ptr(dist)), 'glx_knn_result_lists')
+        return ind, dist
+
+    def order(self):
+        perm = np.empty(self.n, dtype=np.int32)
+        if load().glx_knn_result_order(self._h, _ptr(perm)) != 0:
+            return None
+        return perm
+
+    def to_csr(self, k, kernel='gaussian', sym=1, weights=None):
+        from scipy import sparse
+        n = self.n
+        w = None if weights is None else _dense(weights, np.float64, (n, k), 'weights')
+        cap = n * int(k) * (2 if sym else 1)
+        pinned = cap * 12 <= _PINNED_CSR_MAX
+        indptr = pinned_empty((n + 1,), np.int32) if pinned else np.empty(n + 1, np.int32)
+        col_buf = pinned_empty((cap,), np.int32) if pinned else np.empty(cap, np.int32)
+        val_buf = pinned_empty((cap,), np.float64) if pinned else np.empty(cap, np.float64)
+        nnz = C.c_int64(0)
+        check(load().glx_knn_result_to_csr(self._h, int(k), _KERNEL_ID[kernel], int(sym), _ptr(w), cap, _ptr(indptr), _ptr(col_buf),
+                                           _ptr(val_buf), C.byref(nnz)), 'glx_knn_result_to_csr')
+        W = sparse.csr_matrix((val_buf[:nnz.value], col_buf[:nnz.value], indptr), shape=(n, n))
+        W.has_sorted_indices = True
+        W.has_canonical_format = True
+        return W
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            lib = load(required=False)
+            if lib is not None:
+                lib.glx_knn_result_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def exp_cr(x, device=None):
+    """exp(x), correctly rounded, evaluated on the device (glx_exp_cr)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    check(load().glx_exp_cr(_ptr(x), _ptr(out), x.size, _dev(device)), 'glx_exp_cr')
+    return out
 
 
 def knn_to_csr(knn_ind, knn_dist, k, kernel='gaussian', sym=1, weights=None, device=None):

@@ -7,6 +7,7 @@
 // symmetrisation rule per column; a hub vertex (more entries than one wavefront's LDS share holds)
 // gets a whole workgroup that sorts in a global scratch.  Output: canonical CSR (sorted, no duplicates, no zeros).
 #include "glx_internal.h"
+#include "exp_cr.h"
 #define GLX_POOL(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 #include <algorithm>
 #include <vector>
@@ -17,7 +18,8 @@ static const int ROW_CAP = 1024;   // forward + reverse entries one wavefront ca
 enum { K_GIVEN = 0, K_UNIFORM = 1, K_GAUSSIAN = 2, K_SYMGAUSSIAN = 3, K_DISTANCE = 4, K_SINGULAR = 5 };
 enum { SYM_NONE = 0, SYM_MEAN = 1, SYM_MAX = 2, SYM_SYMGAUSS = 3 };
 
-// weights exactly as numpy forms them, operation by operation (weightmatrix.py:140-156)
+// weights exactly as numpy forms them, operation by operation (weightmatrix.py:140-156); the exponential is the correctly
+// rounded one of exp_cr.h (numpy's is the host libm's or its own SIMD kernel: within an ulp of this, host by host)
 __global__ void knn_weights_kernel(const int64_t* __restrict__ ind, const double* __restrict__ dist, int64_t n, int kk, int k,
                                    int kernel, const double* __restrict__ given, double* __restrict__ w) {
 #pragma clang fp contract(off)
@@ -33,14 +35,14 @@ __global__ void knn_weights_kernel(const int64_t* __restrict__ ind, const double
     const double dk = dist[i * kk + k - 1];
     const double D = d * d, eps = dk * dk;
     const double a = -4.0 * D;
-    v = exp(a / eps);
+    v = exp_cr(a / eps);
   } else if (kernel == K_SYMGAUSSIAN) {
     const double ei = dist[i * kk + k - 1];
     const double ej = dist[ind[i * kk + t] * kk + k - 1];
     const double a = -4.0 * d;
     const double b = a * d;
     const double c = b / ei;
-    v = exp(c / ej);
+    v = exp_cr(c / ej);
   } else if (kernel == K_DISTANCE) {
     v = d;
   } else if (kernel == K_SINGULAR) {
@@ -378,8 +380,10 @@ struct AsmBufs {
   double* tval = nullptr;
   glx_work* work = nullptr;      // the device's cached stream
   hipStream_t stream = nullptr;
+  bool borrowed = false;         // ind / dist belong to a glx_knn_result
   ~AsmBufs() {
     if (stream) hipStreamSynchronize(stream);   // pooled blocks are reused at once
+    if (borrowed) { ind = nullptr; dist = nullptr; }
     glx_pool_free(ind); glx_pool_free(roff); glx_pool_free(rowptr); glx_pool_free(dist); glx_pool_free(given); glx_pool_free(w); glx_pool_free(rw); glx_pool_free(val);
     glx_pool_free(rcnt); glx_pool_free(cursor); glx_pool_free(rsrc); glx_pool_free(rowcnt); glx_pool_free(col); glx_pool_free(flag);
     glx_pool_free(hub_row); glx_pool_free(hub_off); glx_pool_free(skey); glx_pool_free(sval); glx_pool_free(hub_cnt); glx_pool_free(rpos);
@@ -391,14 +395,16 @@ struct AsmBufs {
 // cap < 0: the CSR arrays are allocated here (malloc; glx_free releases them); cap >= 0: *rowptr_out / *col_out / *val_out
 // are the caller's buffers with room for n + 1 row pointers and cap entries
 static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double* weights, int64_t n, int kk, int k, int kernel,
-                           int sym, int64_t cap, int32_t** rowptr_out, int32_t** col_out, double** val_out, int64_t* nnz_out, int device) {
+                           int sym, int64_t cap, int32_t** rowptr_out, int32_t** col_out, double** val_out, int64_t* nnz_out, int device,
+                           const glx_knn_result* res = nullptr) {
+  // res: the lists are the device-resident ones of a search result (borrowed: glx_knn_result_to_csr); otherwise
   // ind = NULL: the indices the last search retained on the device (glx_knn_retain_next) -- they never visited the host
   GLX_CHECK(rowptr_out && col_out && val_out && nnz_out, GLX_EINVAL, "glx_knn_to_csr: null argument");
-  GLX_CHECK(ind || kk == k, GLX_EINVAL, "glx_knn_to_csr: retained indices have exactly k columns (columns=%d k=%d)", kk, k);
+  GLX_CHECK(ind || kk == k || res, GLX_EINVAL, "glx_knn_to_csr: retained indices have exactly k columns (columns=%d k=%d)", kk, k);
   GLX_CHECK(n >= 1 && k >= 1 && kk >= k, GLX_EINVAL, "glx_knn_to_csr: need n >= 1 and 1 <= k <= columns (n=%lld k=%d columns=%d)", (long long)n, k, kk);
   GLX_CHECK(kernel >= K_GIVEN && kernel <= K_SINGULAR, GLX_EINVAL, "glx_knn_to_csr: bad kernel id %d", kernel);
   GLX_CHECK(sym >= SYM_NONE && sym <= SYM_SYMGAUSS, GLX_EINVAL, "glx_knn_to_csr: bad symmetrisation id %d", sym);
-  GLX_CHECK(kernel == K_GIVEN ? weights != nullptr : (kernel == K_UNIFORM || dist != nullptr), GLX_EINVAL, "glx_knn_to_csr: missing weights / distances");
+  GLX_CHECK(kernel == K_GIVEN ? weights != nullptr : (kernel == K_UNIFORM || dist != nullptr || res), GLX_EINVAL, "glx_knn_to_csr: missing weights / distances");
   GLX_CHECK(n < (1ll << 31) && n * k < (1ll << 31), GLX_EUNSUPPORTED, "glx_knn_to_csr: n*k must fit int32");
   GLX_CHECK(k <= 65535, GLX_EUNSUPPORTED, "glx_knn_to_csr: at most 65535 neighbours per row (k=%d)", k);
   if (cap < 0) { *rowptr_out = nullptr; *col_out = nullptr; *val_out = nullptr; }
@@ -412,14 +418,18 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
   b.stream = b.work->stream;
   hipStream_t st = b.stream;
   const int64_t ne = n * k;
-  if (ind) {
+  if (res) {
+    b.ind = res->ind;
+    b.dist = res->dist;
+    b.borrowed = true;
+  } else if (ind) {
     GLX_POOL(glx_pool_alloc((void**)&b.ind, (size_t)n * kk * 8));
     GLX_HIP(hipMemcpyAsync(b.ind, ind, (size_t)n * kk * 8, hipMemcpyHostToDevice, st));
   } else {
     int rct = glx_knn_take_retained(n, k, device, &b.ind);
     if (rct) return rct;
   }
-  if (dist) {
+  if (dist && !res) {
     GLX_POOL(glx_pool_alloc((void**)&b.dist, (size_t)n * kk * 8));
     GLX_HIP(hipMemcpyAsync(b.dist, dist, (size_t)n * kk * 8, hipMemcpyHostToDevice, st));
   }
@@ -765,4 +775,16 @@ extern "C" int glx_knn_to_csr_into(const int64_t* ind, const double* dist, const
                                    int sym, int64_t cap, int32_t* rowptr, int32_t* col, double* val, int64_t* nnz_out, int device) {
   GLX_CHECK(cap >= 0 && rowptr && col && val, GLX_EINVAL, "glx_knn_to_csr_into: null buffer or negative capacity");
   return knn_to_csr_impl(ind, dist, weights, n, kk, k, kernel, sym, cap, &rowptr, &col, &val, nnz_out, device);
+}
+
+// the weight matrix of a search result (glx_knn_search): the lists never leave the device.  k <= the result's columns; weights
+// (n, k) only for kernel = given.  Caller's buffers as in glx_knn_to_csr_into.
+extern "C" int glx_knn_result_to_csr(const glx_knn_result* res, int k, int kernel, int sym, const double* weights, int64_t cap,
+                                     int32_t* rowptr, int32_t* col, double* val, int64_t* nnz_out) {
+  GLX_CHECK(res && res->ind && res->dist, GLX_EINVAL, "glx_knn_result_to_csr: empty result");
+  GLX_CHECK(rowptr && col && val && cap >= 0, GLX_EINVAL, "glx_knn_result_to_csr: null buffer");
+  int32_t* rp = rowptr;
+  int32_t* ci = col;
+  double* va = val;
+  return knn_to_csr_impl(nullptr, nullptr, weights, res->n, res->k, k, kernel, sym, cap, &rp, &ci, &va, nnz_out, res->device, res);
 }

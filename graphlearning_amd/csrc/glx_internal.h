@@ -99,6 +99,15 @@ void glx_pool_free(void* p);
 // handed over to the caller (who frees it with glx_pool_free), or GLX_EINVAL when nothing of that shape is retained (knn.hip)
 int glx_knn_take_retained(int64_t n, int k, int device, int64_t** ind_dev);
 
+// a finished full search: its lists on the device (pooled blocks, [n][k]) and the cell order it worked out (empty: none)
+struct glx_knn_result {
+  int64_t n = 0;
+  int k = 0, device = 0;
+  int64_t* ind = nullptr;
+  double* dist = nullptr;
+  std::vector<int32_t> order;
+};
+
 // a non-blocking stream and four events, handed out from a per-device list of idle sets and returned to it (graph.hip):
 // creating and destroying them costs milliseconds -- as much as the kNN search of 70 000 points itself
 struct glx_work {

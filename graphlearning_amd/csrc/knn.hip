@@ -1894,6 +1894,9 @@ static const int KNN_ESCALATE = 1;    // knn_pass: too many rows failed the acce
 // (per calling thread: request, search and assembly are three calls of ONE thread -- another thread's search must neither take the
 // request nor replace what is retained)
 static thread_local int g_knn_keep_next = 0;
+// glx_knn_search: the search in progress on this thread hands its device-resident lists (and its cell order) to this result
+// instead of freeing them -- set and cleared inside that one call
+static thread_local glx_knn_result* g_knn_capture = nullptr;
 static thread_local struct { int64_t* ind; int64_t n; int k; int device; } g_knn_kept = {nullptr, 0, 0, 0};
 
 extern "C" int glx_knn_retain_next(int on) {
@@ -1918,8 +1921,9 @@ int glx_knn_take_retained(int64_t n, int k, int device, int64_t** ind_dev) {
 
 static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_t q1, int64_t* ind_out, double* dist_out, int device,
                     bool long_lists, const int64_t* cell_starts = nullptr, int ncells = 0, int auto_cells = 0) {
-  const bool keep_ind = g_knn_keep_next && q0 == 0 && q1 == n;
-  GLX_CHECK(X && (ind_out || keep_ind) && dist_out, GLX_EINVAL, "glx_knn_bruteforce: null argument");
+  glx_knn_result* capture = (q0 == 0 && q1 == n) ? g_knn_capture : nullptr;
+  const bool keep_ind = !capture && g_knn_keep_next && q0 == 0 && q1 == n;
+  GLX_CHECK(X && ((ind_out && dist_out) || (keep_ind && dist_out) || capture), GLX_EINVAL, "glx_knn_bruteforce: null argument");
   GLX_CHECK(n >= 1 && d >= 1 && k >= 1, GLX_EINVAL, "glx_knn_bruteforce: need n, d, k >= 1 (n=%lld d=%d k=%d)", (long long)n, d, k);
   GLX_CHECK(k <= n, GLX_EINVAL, "glx_knn_bruteforce: k=%d exceeds the number of points %lld", k, (long long)n);
   GLX_CHECK(n < (1ll << 31) - BR_MAX, GLX_EINVAL, "glx_knn_bruteforce: n must fit int32");
@@ -2352,7 +2356,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   }
   GLX_HIP(hipEventRecord(b.e3, st));
   if (ind_out) GLX_HIP(hipMemcpyAsync(ind_out, b.ind, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
-  GLX_HIP(hipMemcpyAsync(dist_out, b.dist, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+  if (dist_out) GLX_HIP(hipMemcpyAsync(dist_out, b.dist, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
   stamp("results on the host");
   if (order_pending) {
@@ -2365,6 +2369,19 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     GLX_HIP(hipMemcpy(oc_perm.data(), b.orig, (size_t)n * 4, hipMemcpyDeviceToHost));
     std::lock_guard<std::mutex> lk(g_knn_order_mu);
     g_knn_last_order.assign(oc_perm.begin(), oc_perm.end());
+  }
+  if (capture) {         // the lists stay on the device with the caller's result object (everything that writes them has finished)
+    glx_pool_free(capture->ind);
+    glx_pool_free(capture->dist);
+    capture->ind = b.ind;
+    capture->dist = b.dist;
+    capture->n = n;
+    capture->k = k;
+    capture->device = device;
+    b.ind = nullptr;
+    b.dist = nullptr;
+    std::lock_guard<std::mutex> lk(g_knn_order_mu);
+    capture->order = g_knn_last_order;
   }
   if (keep_ind) {        // (everything that writes b.ind has finished: the stream was synchronised above)
     if (g_knn_kept.ind) glx_pool_free(g_knn_kept.ind);
@@ -2452,5 +2469,51 @@ extern "C" int glx_knn_last_order(int64_t n, int32_t* perm_out) {
   std::lock_guard<std::mutex> lk(g_knn_order_mu);
   GLX_CHECK((int64_t)g_knn_last_order.size() == n && n > 0, GLX_EINVAL, "glx_knn_last_order: no clustered search over %lld rows on record", (long long)n);
   memcpy(perm_out, g_knn_last_order.data(), (size_t)n * 4);
+  return GLX_OK;
+}
+
+// ---- search results as objects -------------------------------------------------------------------------------------------------
+// glx_knn_search runs the full search (every row a query) and leaves the lists ON THE DEVICE in a result object the caller owns:
+// glx_knn_result_to_csr (assemble.hip) builds the weight matrix from them without a host round trip, glx_knn_result_lists copies
+// them out, glx_knn_result_order returns the cell order the search worked out (if it did), glx_knn_result_destroy releases
+// everything.  Nothing is handed from one call to the next through hidden state.
+extern "C" int glx_knn_search(const double* X, int64_t n, int d, int k, int ncells, int device, glx_knn_result** out) {
+  GLX_CHECK(out, GLX_EINVAL, "glx_knn_search: null output");
+  *out = nullptr;
+  GLX_CHECK(ncells >= -4096 && ncells <= 4096, GLX_EINVAL, "glx_knn_search: ncells=%d outside [-4096, 4096]", ncells);
+  glx_knn_result* res = new glx_knn_result();
+  g_knn_capture = res;
+  const int rc = knn_run(X, n, d, k, 0, n, nullptr, nullptr, device, nullptr, 0, (ncells > 1 || ncells < -1) ? ncells : 0);
+  g_knn_capture = nullptr;
+  if (rc || !res->ind) {
+    glx_knn_result_destroy(res);
+    if (!rc) glx_set_error("glx_knn_search: the search left no lists behind");
+    return rc ? rc : GLX_EINVAL;
+  }
+  *out = res;
+  return GLX_OK;
+}
+
+extern "C" int glx_knn_result_lists(const glx_knn_result* res, int64_t* ind_out, double* dist_out) {
+  GLX_CHECK(res && res->ind && res->dist, GLX_EINVAL, "glx_knn_result_lists: empty result");
+  GLX_HIP(hipSetDevice(res->device));
+  const size_t bytes = (size_t)res->n * res->k * 8;
+  if (ind_out) GLX_HIP(hipMemcpy(ind_out, res->ind, bytes, hipMemcpyDeviceToHost));
+  if (dist_out) GLX_HIP(hipMemcpy(dist_out, res->dist, bytes, hipMemcpyDeviceToHost));
+  return GLX_OK;
+}
+
+extern "C" int glx_knn_result_order(const glx_knn_result* res, int32_t* perm_out) {
+  GLX_CHECK(res && perm_out, GLX_EINVAL, "glx_knn_result_order: null argument");
+  GLX_CHECK((int64_t)res->order.size() == res->n && res->n > 0, GLX_EINVAL, "glx_knn_result_order: this search worked out no cell order");
+  memcpy(perm_out, res->order.data(), (size_t)res->n * 4);
+  return GLX_OK;
+}
+
+extern "C" int glx_knn_result_destroy(glx_knn_result* res) {
+  if (!res) return GLX_OK;
+  glx_pool_free(res->ind);
+  glx_pool_free(res->dist);
+  delete res;
   return GLX_OK;
 }

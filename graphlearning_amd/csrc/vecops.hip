@@ -144,3 +144,29 @@ extern "C" int glx_rec_xpby_dev(void* p, const void* r, const double* beta, int6
   GLX_HIP(hipGetLastError());
   return GLX_OK;
 }
+
+// ---- exp_cr on an array (what the Gaussian weights of assemble.hip are made of; the tests check it against a 60-digit exp) ----
+#include "exp_cr.h"
+__global__ void exp_cr_kernel(const double* __restrict__ x, double* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = exp_cr(x[i]);
+}
+extern "C" int glx_exp_cr(const double* x, double* out, int64_t n, int device) {
+  GLX_CHECK((x && out) || n == 0, GLX_EINVAL, "glx_exp_cr: null argument");
+  if (n <= 0) return GLX_OK;
+  GLX_HIP(hipSetDevice(device));
+  double *dx = nullptr, *dy = nullptr;
+  int rc = glx_pool_alloc((void**)&dx, (size_t)n * 8);
+  if (!rc) rc = glx_pool_alloc((void**)&dy, (size_t)n * 8);
+  if (!rc) {
+    hipError_t e = hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(exp_cr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const double*)dx, dy, n);
+      e = hipMemcpy(out, dy, (size_t)n * 8, hipMemcpyDeviceToHost);
+    }
+    if (e != hipSuccess) { glx_set_error("glx_exp_cr: %s", hipGetErrorString(e)); rc = GLX_EHIP; }
+  }
+  glx_pool_free(dx);
+  glx_pool_free(dy);
+  return rc;
+}

@@ -352,7 +352,28 @@ int glx_knn_last_order(int64_t n, int32_t* perm_out);
  * called with ind_out = NULL: inside weightmatrix.knn (graphlearning/weightmatrix.py:119-187) the lists are only ever consumed by
  * the assembly and need not cross PCIe twice.  One search; on = 0 withdraws the request and drops what is retained.  Request,
  * search and assembly belong to the calling thread: other threads' searches neither see the request nor touch what is retained. */
-int glx_knn_retain_next(int on);
+int glx_knn_retain_next(int on);     /* DEPRECATED (kept for one round): use glx_knn_search, which hands the lists over as an object */
+
+/* ---- search results as objects (what weightmatrix.knn uses) ---------------------------------------------------------------------
+ * glx_knn_search runs the full search (every row a query, self included; ncells as in glx_knn_clustered: 0 / 1 all pairs,
+ * > 1 pruned by library-formed cells, < -1 all pairs on rows reordered by -ncells chained cells) and leaves the lists ON THE DEVICE
+ * in a result object.  OWNERSHIP: the caller owns *out and releases it with glx_knn_result_destroy; the other calls borrow it.
+ * The object may be used from any thread, by one thread at a time.  Replaces the hidden hand-offs glx_knn_retain_next /
+ * glx_knn_last_order (caller owns all buffers: the convention of the reference's c_code/cextensions.cpp:19-60). */
+typedef struct glx_knn_result glx_knn_result;
+int glx_knn_search(const double* X, int64_t n, int d, int k, int ncells, int device, glx_knn_result** out);
+/* copies of the lists for the host: ind_out / dist_out (n, k), either may be NULL */
+int glx_knn_result_lists(const glx_knn_result* res, int64_t* ind_out, double* dist_out);
+/* perm_out[position] = caller's row in the cell order the search worked out (GLX_EINVAL: it formed no cells) */
+int glx_knn_result_order(const glx_knn_result* res, int32_t* perm_out);
+/* the weight matrix of the result (reference weightmatrix.py:134-187), k <= the result's columns, arguments otherwise as
+ * glx_knn_to_csr_into; the Gaussian kernels evaluate a correctly rounded exp on the device (csrc/exp_cr.h) */
+int glx_knn_result_to_csr(const glx_knn_result* res, int k, int kernel, int sym, const double* weights, int64_t cap,
+                          int32_t* rowptr, int32_t* col, double* val, int64_t* nnz_out);
+int glx_knn_result_destroy(glx_knn_result* res);
+/* out[i] = exp(x[i]) correctly rounded (csrc/exp_cr.h: the exponential of the Gaussian weights), host arrays; a test hook */
+int glx_exp_cr(const double* x, double* out, int64_t n, int device);
+
 int glx_knn_stats(double stats[16]);  /* of the last search: [0] tile-kernel ms, [1] re-rank ms, [2] fallback rows, [3] total device ms,
                                         [4] fallback ms, [5] padded feature count, [6] ref ranges, [7] list length (negative: bf16 filter),
                                         [8] rows the short lists could not accept when the search was repeated with long ones (else 0);
