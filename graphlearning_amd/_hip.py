@@ -133,8 +133,7 @@ _SIGNATURES = {
     'glx_knn_bruteforce_range': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
     'glx_knn_cells_range': [_vp, C.c_int64, C.c_int, C.c_int, _vp, C.c_int, C.c_int64, C.c_int64, _vp, _vp, C.c_int],
     'glx_knn_clustered': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int],
-    'glx_knn_last_order': [C.c_int64, _vp],
-    'glx_knn_retain_next': [C.c_int],
+    'glx_knn_set_options': [_vp],
     'glx_knn_stats': [_f64p],
     'glx_knn_to_csr': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp),
                        C.POINTER(_vp), _i64p, C.c_int],
@@ -625,12 +624,16 @@ class Comm:
             pass
 
 
+# glx_dist_sweep_create's form flags (include/glx.h): what the library picks by itself, and the forms tests force
+DIST_FORMS = {'auto': 0, 'split': 2, 'split_pack': 2 | 8, 'split_inline': 2 | 16, 'fused': 4, 'selftest': 128, 'eager': 64, 'captured': 32}
+
+
 class DistSweep:
     """One rank's share of the vertex-partitioned Poisson sweep (glx_dist_sweep): local operator (boundary rows first,
     columns [owned | halo]), exchange lists, device state; every sweep and every collective is enqueued by libglx."""
 
     def __init__(self, comm, P_local, n_boundary, send_counts, send_idx, recv_counts, n_global, Cc, dtype=np.float64,
-                 force_exchange=False, use_hipgraph=True):
+                 force_exchange=False, use_hipgraph=True, form='auto'):
         from scipy import sparse
         A = sparse.csr_matrix(P_local)
         self.comm = comm
@@ -649,7 +652,7 @@ class DistSweep:
         self._h = _vp()
         check(load().glx_dist_sweep_create(comm._h, self.n_own, self.n_halo, int(n_boundary), _ptr(rowptr), _ptr(col), _ptr(val),
                                            _dt(self.dtype), self.C, _ptr(sc), _ptr(si), _ptr(rcnt), int(n_global),
-                                           1 if force_exchange else 0, 1 if use_hipgraph else 0, C.byref(self._h)),
+                                           1 if force_exchange else 0, (1 if use_hipgraph else 0) | DIST_FORMS[form], C.byref(self._h)),
               'glx_dist_sweep_create')
         _live_dist_objects.add(self)
 
@@ -792,63 +795,75 @@ def auto_cells(n, d):
 def auto_order_cells(n, d):
     """Below the size of the cell-PRUNED search: how many chained cells the rows are reordered by before the all-pairs search
     (coherent wavefronts: 10-14 % of the search on clustered data, nothing lost elsewhere), whose order the operators on the
-    graph then take instead of their own pass over the graph (3.7 ms at 70 000 vertices).  GLX_KNN_ORDER=0 turns it off;
-    GLX_KNN_REORDER=0 keeps the caller's order in the search and works the cell order out on the side."""
+    graph then take instead of their own pass over the graph (3.7 ms at 70 000 vertices).  GLX_KNN_ORDER=0 turns it off."""
     if os.environ.get('GLX_KNN_ORDER', '1') == '0' or n < 4096 or n >= (1 << 17) or d > 128:
         return 0
     return int(min(128, n // 64))     # (measured at 70 000 x 20: 128 cells = the library's order to 0.5 %, 64 and 32 cells 0.5-1 % behind)
 
 
-def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, cell_starts=None, clustered=None, retain=False,
-                   want_order=False):
-    """Exact kNN (incl. self) on the GPU.  'angular' = euclidean on row-normalised data, formed
-    with the reference's own expression (weightmatrix.py:344-345).  cell_starts: the rows come in a coarse geometric
-    order with cell c = rows [cell_starts[c], cell_starts[c+1]); the search skips the cells that cannot hold a
-    neighbour (glx_knn_cells_range: the same lists, a fraction of the tiles on clustered data).  clustered: number of cells
-    the library forms itself (glx_knn_clustered; None = auto_cells(n, d), 0 = all pairs).
-    want_order (below the size of the pruned search): the rows are put into the order of chained cells first, which knn_last_order
-    then hands to the operators on the graph (weightmatrix.knn asks for it; a plain knnsearch does not pay for an order nobody reads:
-    0.1 ms at d = 20, 0.7 ms at d = 128 for 50 000 rows).
-    retain (full searches only): the indices stay on the device for the knn_to_csr(None, ...) that follows and None is returned in
-    their place (glx_knn_retain_next: weightmatrix.knn's own flow)."""
+class _KnnOptions(C.Structure):
+    _fields_ = [('filter', C.c_int), ('lists', C.c_int), ('nsplit', C.c_int), ('concat', C.c_int)]
+
+
+class knn_options:
+    """Context manager: plan overrides for the calling thread's kNN searches (glx_knn_set_options) -- which candidate filter
+    ('bf16' | 'f32'), list length ('short' | 'long'), ref ranges per query block (1..8), operand form of the bf16 filter at
+    d <= 21 (concat 0 | 1 | 2).  Every plan returns the same exact lists; tests and A/B measurements use this."""
+
+    def __init__(self, filter=None, lists=None, nsplit=None, concat=None):
+        self.opt = _KnnOptions({None: 0, 'bf16': 1, 'f32': 2}[filter], {None: 0, 'short': 1, 'long': 2}[lists],
+                                int(nsplit or 0), -1 if concat is None else int(concat))
+
+    def __enter__(self):
+        check(load().glx_knn_set_options(C.byref(self.opt)), 'glx_knn_set_options')
+        return self
+
+    def __exit__(self, *exc):
+        load().glx_knn_set_options(None)
+        return False
+
+
+def _knn_input(X, similarity):
     X = np.asarray(X, dtype=np.float64)
     if similarity == 'angular':
         X = X / np.linalg.norm(X, axis=1)[:, None]
     elif similarity != 'euclidean':
         raise GlxError('similarity %r not supported (euclidean, angular)' % (similarity,))
-    X = np.ascontiguousarray(X)
+    return np.ascontiguousarray(X)
+
+
+def _knn_cells(n, d, clustered, want_order):
+    """The `ncells` argument of glx_knn_clustered / glx_knn_search for a full search."""
+    m = auto_cells(n, d) if clustered is None else int(clustered)
+    if m <= 1 and clustered is None and want_order and auto_order_cells(n, d) > 1:
+        m = -auto_order_cells(n, d)     # all pairs on rows reordered by that many chained cells
+    return m if (m > 1 or m < -1) else 0
+
+
+def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, cell_starts=None, clustered=None, want_order=False):
+    """Exact kNN (incl. self) on the GPU.  'angular' = euclidean on row-normalised data, formed
+    with the reference's own expression (weightmatrix.py:344-345).  cell_starts: the rows come in a coarse geometric
+    order with cell c = rows [cell_starts[c], cell_starts[c+1]); the search skips the cells that cannot hold a
+    neighbour (glx_knn_cells_range: the same lists, a fraction of the tiles on clustered data).  clustered: number of cells
+    the library forms itself (glx_knn_clustered; None = auto_cells(n, d), 0 = all pairs).
+    want_order (below the size of the pruned search): the rows are put into the order of chained cells before the search
+    (coherent wavefronts; a plain knnsearch does not ask: 0.1 ms at d = 20, 0.7 ms at d = 128 for 50 000 rows) -- KnnResult
+    hands that order out as well."""
+    X = _knn_input(X, similarity)
     n, d = X.shape
     q0, q1 = (0, n) if query_range is None else query_range
-    retain = bool(retain) and query_range is None and cell_starts is None
-    ind = None if retain else pinned_empty((q1 - q0, k), np.int64)       # page-locked result arrays: the copy back runs at PCIe speed
+    ind = pinned_empty((q1 - q0, k), np.int64)       # page-locked result arrays: the copy back runs at PCIe speed
     dist = pinned_empty((q1 - q0, k), np.float64)
-    if retain:
-        load().glx_knn_retain_next(1)
-        try:
-            return _knn_search_full(X, n, d, k, clustered, ind, dist, device, want_order)
-        except BaseException:
-            load().glx_knn_retain_next(0)
-            raise
     if cell_starts is not None:
         cs = np.ascontiguousarray(cell_starts, dtype=np.int64)
         check(load().glx_knn_cells_range(_ptr(X), n, d, k, _ptr(cs), len(cs), q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
               'glx_knn_cells_range')
         return ind, dist
-    if query_range is None:
-        return _knn_search_full(X, n, d, k, clustered, ind, dist, device, want_order)
-    check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
-          'glx_knn_bruteforce')
-    return ind, dist
-
-
-def _knn_search_full(X, n, d, k, clustered, ind, dist, device, want_order=False):
-    m = auto_cells(n, d) if clustered is None else int(clustered)
-    if m <= 1 and clustered is None and want_order and auto_order_cells(n, d) > 1:
-        m = -auto_order_cells(n, d)     # all pairs; the order of that many chained cells is left for knn_last_order
-    if m > 1 or m < -1:       # cells formed by the library (same lists; a fraction of the tiles when the data has clusters)
+    m = _knn_cells(n, d, clustered, want_order) if query_range is None else 0
+    if m:       # cells formed by the library (same lists; a fraction of the tiles when the data has clusters)
         check(load().glx_knn_clustered(_ptr(X), n, d, k, m, _ptr(ind), _ptr(dist), _dev(device)), 'glx_knn_clustered')
         return ind, dist
-    check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, 0, n, _ptr(ind), _ptr(dist), _dev(device)),
+    check(load().glx_knn_bruteforce_range(_ptr(X), n, d, k, q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
           'glx_knn_bruteforce')
     return ind, dist
 
@@ -862,19 +877,12 @@ class KnnResult:
     without a host round trip, `lists()` copies them out, `order()` is the cell order the search worked out (or None)."""
 
     def __init__(self, X, k, similarity='euclidean', device=None, clustered=None, want_order=False):
-        X = np.asarray(X, dtype=np.float64)
-        if similarity == 'angular':
-            X = X / np.linalg.norm(X, axis=1)[:, None]
-        elif similarity != 'euclidean':
-            raise GlxError('similarity %r not supported (euclidean, angular)' % (similarity,))
-        X = np.ascontiguousarray(X)
+        X = _knn_input(X, similarity)
         n, d = X.shape
-        m = auto_cells(n, d) if clustered is None else int(clustered)
-        if m <= 1 and clustered is None and want_order and auto_order_cells(n, d) > 1:
-            m = -auto_order_cells(n, d)     # all pairs on rows reordered by that many chained cells; the order comes with the result
         self.n, self.k, self.device = n, int(k), _dev(device)
         self._h = _vp()
-        check(load().glx_knn_search(_ptr(X), n, d, int(k), m if (m > 1 or m < -1) else 0, self.device, C.byref(self._h)), 'glx_knn_search')
+        check(load().glx_knn_search(_ptr(X), n, d, int(k), _knn_cells(n, d, clustered, want_order), self.device, C.byref(self._h)),
+              'glx_knn_search')
 
     def lists(self):
         ind = pinned_empty((self.n, self.k), np.int64)
@@ -930,14 +938,8 @@ def exp_cr(x, device=None):
 def knn_to_csr(knn_ind, knn_dist, k, kernel='gaussian', sym=1, weights=None, device=None):
     """kNN data -> scipy CSR weight matrix, assembled on the GPU (glx_knn_to_csr)."""
     from scipy import sparse
-    if knn_ind is None:      # the indices the search left on the device (knn_bruteforce(retain=True))
-        ind = None
-        n, kk = np.shape(knn_dist if weights is None else weights)
-        if kk != int(k):
-            raise GlxError('knn_to_csr: retained indices need k = the number of columns')
-    else:
-        ind = np.ascontiguousarray(knn_ind, dtype=np.int64)
-        n, kk = ind.shape
+    ind = np.ascontiguousarray(knn_ind, dtype=np.int64)
+    n, kk = ind.shape
     # distances are only read by the kernels that compute weights from them: with given weights they need not travel
     dist = None if (knn_dist is None or kernel == 'given') else _dense(knn_dist, np.float64, (n, kk), 'knn_dist')
     w = None if weights is None else _dense(weights, np.float64, (n, k), 'weights')
@@ -1019,14 +1021,6 @@ def host_permute_rows(A, perm):
     out = sparse.csr_matrix((dv, ix, ip), shape=A.shape)
     out.has_sorted_indices = A.has_sorted_indices
     return out
-
-
-def knn_last_order(n):
-    """perm[position] = row in the cell order of the last clustered search over n rows, or None."""
-    perm = np.empty(int(n), dtype=np.int32)
-    if load().glx_knn_last_order(int(n), _ptr(perm)) != 0:
-        return None
-    return perm
 
 
 def knn_stats():

@@ -397,10 +397,9 @@ struct AsmBufs {
 static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double* weights, int64_t n, int kk, int k, int kernel,
                            int sym, int64_t cap, int32_t** rowptr_out, int32_t** col_out, double** val_out, int64_t* nnz_out, int device,
                            const glx_knn_result* res = nullptr) {
-  // res: the lists are the device-resident ones of a search result (borrowed: glx_knn_result_to_csr); otherwise
-  // ind = NULL: the indices the last search retained on the device (glx_knn_retain_next) -- they never visited the host
+  // res: the lists are the device-resident ones of a search result (borrowed: glx_knn_result_to_csr)
   GLX_CHECK(rowptr_out && col_out && val_out && nnz_out, GLX_EINVAL, "glx_knn_to_csr: null argument");
-  GLX_CHECK(ind || kk == k || res, GLX_EINVAL, "glx_knn_to_csr: retained indices have exactly k columns (columns=%d k=%d)", kk, k);
+  GLX_CHECK(ind || res, GLX_EINVAL, "glx_knn_to_csr: null neighbour indices");
   GLX_CHECK(n >= 1 && k >= 1 && kk >= k, GLX_EINVAL, "glx_knn_to_csr: need n >= 1 and 1 <= k <= columns (n=%lld k=%d columns=%d)", (long long)n, k, kk);
   GLX_CHECK(kernel >= K_GIVEN && kernel <= K_SINGULAR, GLX_EINVAL, "glx_knn_to_csr: bad kernel id %d", kernel);
   GLX_CHECK(sym >= SYM_NONE && sym <= SYM_SYMGAUSS, GLX_EINVAL, "glx_knn_to_csr: bad symmetrisation id %d", sym);
@@ -422,12 +421,9 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
     b.ind = res->ind;
     b.dist = res->dist;
     b.borrowed = true;
-  } else if (ind) {
+  } else {
     GLX_POOL(glx_pool_alloc((void**)&b.ind, (size_t)n * kk * 8));
     GLX_HIP(hipMemcpyAsync(b.ind, ind, (size_t)n * kk * 8, hipMemcpyHostToDevice, st));
-  } else {
-    int rct = glx_knn_take_retained(n, k, device, &b.ind);
-    if (rct) return rct;
   }
   if (dist && !res) {
     GLX_POOL(glx_pool_alloc((void**)&b.dist, (size_t)n * kk * 8));

@@ -270,7 +270,7 @@ extern "C" int glx_dist_sweep_destroy(glx_dist_sweep* s) {
 extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_halo, int64_t n_boundary, const int32_t* rowptr,
                                      const int32_t* col, const double* val, int state_dtype, int C, const int64_t* send_counts,
                                      const int32_t* send_idx, const int64_t* recv_counts, int64_t n_global, int force_exchange,
-                                     int use_hipgraph, glx_dist_sweep** out) {
+                                     int flags, glx_dist_sweep** out) {
   GLX_CHECK(comm && out && rowptr, GLX_EINVAL, "glx_dist_sweep_create: null argument");
   *out = nullptr;
   GLX_CHECK(n_own >= 0 && n_halo >= 0 && n_boundary >= 0 && n_boundary <= n_own, GLX_EINVAL, "glx_dist_sweep_create: bad sizes");
@@ -297,7 +297,7 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
   s->nb = n_boundary;
   s->n_loc = n_own + n_halo;
   s->n_global = n_global;
-  s->use_graph = use_hipgraph != 0;
+  s->use_graph = (flags & GLX_DIST_CAPTURE) != 0;
   {
     // HIP runtimes before 7.2 (e.g. the 7.0 copy bundled with torch, which wins when torch is imported first) recurse
     // without end in hipStreamEndCapture when a second stream forks from and joins back into the capturing stream:
@@ -305,24 +305,26 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
     int rt = 0;
     hipRuntimeGetVersion(&rt);
     s->overlap = !(s->use_graph && rt < 70200000);
-    if (const char* e = getenv("GLX_DIST_OVERLAP")) s->overlap = atoi(e) != 0;
+    const bool inline_exchange = (flags & GLX_DIST_INLINE) != 0;      // the exchange on the sweep's own stream, whatever the form
+    if (inline_exchange) s->overlap = false;
     // Grouped ncclSend/ncclRecv inside a stream capture has been exercised on ONE rank only (self exchange, RCCL 2.26.6 and
-    // 2.27.7); with real peers the exchanging sweeps are enqueued eagerly -- plain RCCL usage -- unless asked otherwise.
+    // 2.27.7); with real peers the first run decides by a self-test (three captured exchanging sweeps, replayed, against three
+    // eager ones: bit for bit, on every rank, with a deadline); GLX_DIST_EXCHANGE_CAPTURED / _EAGER / _SELFTEST settle it up front.
     // Sweeps without an exchange (no halo anywhere) are captured either way.
-    // Round 3: with real peers the first run decides by a self-test (three captured exchanging sweeps, replayed, against three
-    // eager ones: bit for bit, on every rank, with a deadline); GLX_DIST_CAPTURE_EXCHANGE=0/1 skips the test.
     s->capture_exchange = comm->nranks == 1 ? 1 : -1;
-    if (const char* e = getenv("GLX_DIST_CAPTURE_EXCHANGE")) s->capture_exchange = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
+    if (flags & GLX_DIST_EXCHANGE_CAPTURED) s->capture_exchange = 1;
+    if (flags & GLX_DIST_EXCHANGE_EAGER) s->capture_exchange = 0;
+    if (flags & GLX_DIST_EXCHANGE_SELFTEST) s->capture_exchange = -1;
     if (!s->use_graph) s->capture_exchange = 0;
-    if (s->capture_exchange == 0 && !getenv("GLX_DIST_OVERLAP")) s->overlap = true;   // eager: two streams are safe on every runtime
-    if (const char* e = getenv("GLX_DIST_PACK")) s->scatter = atoi(e) == 0;             // 1: the round-2 pack kernel between SpMM and transport
+    if (s->capture_exchange == 0 && !inline_exchange) s->overlap = true;   // eager: two streams are safe on every runtime
+    if (flags & GLX_DIST_PACK_KERNEL) s->scatter = false;                  // the round-2 pack kernel between SpMM and transport
     // Form of a sweep.  SPLIT: [boundary rows | exchange on a second stream beside the interior rows] hides min(interior, exchange)
     // but pays for a second launch (~9 us at 70 000 rows: a short launch is a chain of dependent memory round trips) and for the
     // cross-stream edges of the captured graph (~14 us measured: 35.0 vs 29.4 us per sweep with the exchange in line).  FUSED: ONE
     // launch for all rows, the exchange in line behind it: 22.9 us per sweep for the same 10 000-record halo (profiles/r03_dist_probe.txt).
     // The split form wins only when BOTH the interior rows and the exchange take longer than those fixed costs (~23 us): estimated
     // from the interior's stored entries (13 ps per entry) and the largest per-peer message (8 us + bytes / 50 GB/s).
-    // GLX_DIST_FUSE=0/1 forces a form.
+    // GLX_DIST_FORM_SPLIT / GLX_DIST_FORM_FUSED force a form.
     double interior_us = 0.0, exchange_us = 0.0;
     {
       const double nnz_int = (double)(rowptr[n_own] - rowptr[n_boundary]);
@@ -334,8 +336,9 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
         exchange_us = peer_max > 0 ? 8.0 + (double)peer_max * L0.ld * L0.esize / 50e3 : 0.0;
     }
     s->fused = n_own > 0 && std::min(interior_us, exchange_us) < 23.0;
-    if (const char* e = getenv("GLX_DIST_FUSE")) s->fused = n_own > 0 && atoi(e) != 0;
-    if (s->fused && !getenv("GLX_DIST_OVERLAP")) s->overlap = false;   // nothing to run beside the exchange
+    if (flags & GLX_DIST_FORM_SPLIT) s->fused = false;
+    if (flags & GLX_DIST_FORM_FUSED) s->fused = n_own > 0;
+    if (s->fused) s->overlap = false;   // nothing to run beside the exchange
   }
   s->thresh = 1.0 / (double)n_global;   // `> 1/n`, ssl.py:667, n = ALL vertices
   int rc = glx_make_layout(C, state_dtype, true, &s->L);

@@ -95,9 +95,6 @@ void glx_cg_ws_destroy(void* ws);
 // device work-buffer pool (graph.hip): size-class free lists in front of hipMalloc / hipFree
 int glx_pool_alloc(void** out, size_t bytes);
 void glx_pool_free(void* p);
-// the neighbour indices the last full search left on the device after glx_knn_retain_next(1) ([n][k] int64, a pooled block):
-// handed over to the caller (who frees it with glx_pool_free), or GLX_EINVAL when nothing of that shape is retained (knn.hip)
-int glx_knn_take_retained(int64_t n, int k, int device, int64_t** ind_dev);
 
 // a finished full search: its lists on the device (pooled blocks, [n][k]) and the cell order it worked out (empty: none)
 struct glx_knn_result {

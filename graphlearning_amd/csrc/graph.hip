@@ -316,7 +316,6 @@ int glx_make_layout(int C, int dtype, bool has_w, RecLayout* L) {
   int rb = 32;
   while (rb < bytes && rb < 128) rb *= 2;      // 32 / 64 / 128-byte records stay line-aligned
   if (rb < bytes) rb = (bytes + 63) / 64 * 64; // larger records: multiple of 64 bytes
-  if (getenv("GLX_REC_NOPAD") && atoi(getenv("GLX_REC_NOPAD"))) rb = bytes;   // developer probe: unpadded records
   L->C = C;
   L->nvec = nvec;
   L->ld = rb / es;
@@ -492,11 +491,9 @@ int glx_graph_ensure_order(glx_graph* g) {
   if (g->order_ready) return GLX_OK;
   g->order_ready = true;
   const int64_t n = g->n_rows;
-  const char* e = getenv("GLX_REORDER");
-  const bool want = !(e && atoi(e) == 0);
-  if (!want || g->keep_order || g->n_rows != g->n_cols || n < 4096) return GLX_OK;
+  if (g->keep_order || g->n_rows != g->n_cols || n < 4096) return GLX_OK;
   const auto t_rcm0 = std::chrono::steady_clock::now();
-  rcm_order(g, g->h_perm, !(e && atoi(e) == 2));   // GLX_REORDER=2: breadth-first order without the degree sort of the children
+  rcm_order(g, g->h_perm, true);
   if (getenv("GLX_TIMING")) fprintf(stderr, "[glx] locality order of %lld vertices: %.1f ms\n", (long long)n,
                                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rcm0).count());
   g->h_inv.assign(n, 0);
@@ -675,7 +672,7 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(const int32_t* __restric
 // into 8 contiguous id ranges, one per XCD; inside a range rows are handed to wavefront slices
 // in order of decreasing length (longest first: LPT balance, little padding inside a slice);
 // the ENTRY order inside a row is untouched.  G = 4 plans split rows longer than L1 entries
-// over S = 4 slots and rows longer than L4 over S = 16 slots (GLX_SELL_L1/L4).  Every range
+// over S = 4 slots and rows longer than L4 over S = 16 slots.  Every range
 // is padded with empty slices to the same number of 4-slice blocks, so block b serves range
 // b % 8 -- the XCD the dispatcher is observed to place it on.
 int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
@@ -708,8 +705,6 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
   // SpMM + dots per launch: 8/64 37.6 us, 24/96 32.2, 32/128 27.3, 64/256 26.5, 96/384 32.6 (profiles/r04_cg_slot_thresholds.txt)
   if (relaxed) { L1 = 64; L4 = 256; }
   if ((double)g->n_cols * G * 4.0 * (g->dtype == GLX_F64 ? 8.0 : 4.0) >= 64.0 * 1024 * 1024) { L1 = 64; L4 = 256; }
-  if (const char* e = getenv("GLX_SELL_L1")) L1 = std::max(4, atoi(e));
-  if (const char* e = getenv("GLX_SELL_L4")) L4 = std::max(L1, atoi(e));
   if (G != 4) { L1 = 1 << 30; L4 = 1 << 30; }
   auto old_of = [&](int64_t nid) -> int64_t { return renum ? g->h_perm[nid] : nid; };
   auto rowlen = [&](int64_t nid) { const int64_t o = old_of(nid); return g->h_rowptr[o + 1] - g->h_rowptr[o]; };
@@ -718,13 +713,12 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
   const int NX = 8;
   std::vector<std::vector<SliceHdr>> ghdr(NX);
   std::vector<std::vector<int32_t>> grow(NX), glen(NX);
-  // the eight id ranges carry equal WORK, not equal row counts (GLX_XCD_BALANCE=0: equal rows, the round-2 rule): the launch ends
+  // the eight id ranges carry equal WORK, not equal row counts (equal rows, the round-2 rule: 13.69 -> 13.10 us per sweep at config 2, profiles/r03_xcd_balance.txt): the launch ends
   // when the slowest XCD does, and under a locality order the rows' lengths drift along the order (a cluster's dense core
   // first, its fringe last).  Work of a row = its entries + XCD_ROW_COST (header, epilogue, store).
   std::vector<int64_t> xb(NX + 1, 0);
   {
-    const char* e = getenv("GLX_XCD_BALANCE");
-    const bool by_work = !(e && atoi(e) == 0) && n >= NX;
+    const bool by_work = n >= NX;
     const int64_t row_cost = 3;
     int64_t total = 0;
     if (by_work) for (int64_t i = 0; i < n; ++i) total += rowlen(i) + row_cost;
@@ -743,9 +737,8 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
     std::vector<int32_t> order(m);
     // sort by decreasing length inside windows of `sigma` consecutive ids (SELL-C-sigma): small
     // windows keep rows that share neighbours in the same wavefronts/CUs (L1 reuse), large ones
-    // minimise padding.  GLX_SELL_SIGMA, default: the whole XCD range.
+    // minimise padding.  The whole XCD range is one window.
     int64_t sigma = m;
-    if (const char* e = getenv("GLX_SELL_SIGMA")) sigma = std::max<int64_t>(R, atoll(e));
     for (int64_t w0 = 0; w0 < m; w0 += sigma) {
       const int64_t w1 = std::min(m, w0 + sigma);
       std::vector<int64_t> cnt(g->max_row + 2, 0);

@@ -178,22 +178,11 @@ __device__ __forceinline__ void add_product(typename VecOf<T>::type& acc, double
 // sequential row sum.
 // (Closed experiments -- other loop forms, a two-chunk pipeline, 32-bit offsets, nontemporal loads / stores, a persistent
 //  grid -- live as patches under scripts/probes/; EXPERIMENTS.md has their numbers.)
-#ifdef GLX_WAVE_PROBE
-__device__ unsigned long long g_wave_probe[1 << 20];
-extern "C" int glx_debug_wave_probe(unsigned long long* out, int64_t n) {
-  GLX_HIP(hipDeviceSynchronize());
-  GLX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_probe), (size_t)n * 8));
-  return GLX_OK;
-}
-#endif
 // DOT: 0 none; 1 the column dots p.Ap of the exact CG (cg.hip); 2 the tolerance-mode CG's form (cg_fused.hip)
 template <typename T, int G, bool HAS_W, int DOT, bool HAS_DUP = false>
 __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParams p) {
 #pragma clang fp contract(off)
   constexpr bool HAS_DOT = DOT != 0, FUSED = DOT == 2;
-#ifdef GLX_WAVE_PROBE
-  const unsigned long long probe_t0 = wall_clock64();
-#endif
   typedef typename VecOf<T>::type V4;
   constexpr int R = 64 / G;
   constexpr int NRED = GLX_WPB * (G == 4 ? 16 : G) * 12 > 256 ? GLX_WPB * (G == 4 ? 16 : G) * 12 : 256;
@@ -401,13 +390,6 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
     }
   }
 
-#ifdef GLX_WAVE_PROBE
-  if (lane == 0 && slice * 4 + 3 < (1 << 20)) {
-    g_wave_probe[slice * 4 + 0] = probe_t0;
-    g_wave_probe[slice * 4 + 1] = wall_clock64();
-    g_wave_probe[slice * 4 + 2] = ((unsigned long long)nchunks << 32) | (unsigned)S;
-  }
-#endif
   if constexpr (FUSED && G == 4) {
     if (S > 1) {      // the segments' partial sums: two DPP rotations inside the 16-lane row, two exchanges across rows
 #pragma unroll
@@ -484,9 +466,6 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
     }
   }
 
-#ifdef GLX_WAVE_PROBE
-  if (lane == 0 && slice * 4 + 3 < (1 << 20)) g_wave_probe[slice * 4 + 3] = wall_clock64();
-#endif
   if constexpr (HAS_DOT) {
     // column dots over the rows (utils.py:524 `np.sum(p*Ap,axis=0)`): fixed-order tree inside the block, one partial row per
     // block, reduced by the consumer.  ND = 1: p.Ap;  tolerance-mode CG, ND = 3: p.Ap, r.Ap, Ap.Ap (cg_fused.hip)

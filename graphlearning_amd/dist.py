@@ -533,14 +533,14 @@ def _force_collectives():
     return os.environ.get('GLX_DIST_FORCE_COLLECTIVES') == '1'
 
 
-def glx_dist_sweep(comm, plan, C, dtype=np.float64, force_exchange=False, use_hipgraph=True):
+def glx_dist_sweep(comm, plan, C, dtype=np.float64, force_exchange=False, use_hipgraph=True, form='auto'):
     """The rank's glx_dist_sweep for a RankPlan (or ShardPlan).  If ANY rank imports a halo, every rank takes part in the
     per-sweep exchange (with nothing to send or receive where it has no halo): the collective calls around it -- the capture
     self-test's verdict, the stop test's all-reduce -- must be issued by all ranks alike."""
     from . import _hip
     any_halo = int(getattr(plan, 'global_halo', 0)) > 0 and int(getattr(plan, 'world', 1)) > 1
     return _hip.DistSweep(comm, plan.P_local, plan.n_boundary, plan.send_counts, plan.send_idx, plan.recv_counts, plan.n_global, C,
-                          dtype=dtype, force_exchange=bool(force_exchange or any_halo), use_hipgraph=use_hipgraph)
+                          dtype=dtype, force_exchange=bool(force_exchange or any_halo), use_hipgraph=use_hipgraph, form=form)
 
 
 def run_stepwise(ds, plan, dist, min_iter, max_iter, err0=None, group=None):

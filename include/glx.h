@@ -192,11 +192,23 @@ int glx_dist_destroy(glx_comm* c);
  * grouped by destination rank.  n_global: vertices of the whole graph (the stop threshold is 1/n_global).
  * force_exchange: issue the exchange even when this rank has nothing to send or receive.  Set it on EVERY rank as soon as ANY
  * rank has a halo: the collective calls around the exchange (the capture self-test's verdict, the stop test's all-reduce) must be
- * issued by all ranks alike (dist.glx_dist_sweep does; also used by 1-rank tests). */
+ * issued by all ranks alike (dist.glx_dist_sweep does; also used by 1-rank tests).
+ * flags: GLX_DIST_CAPTURE alone is the default (the library picks the form of a sweep from the sizes of the interior and of the
+ * exchange); the others force a form -- every one yields the same iterates, tests/test_gpu_dist.py runs them all. */
+enum {
+  GLX_DIST_CAPTURE = 1,             /* sweeps run as captured device graphs (else every launch is enqueued eagerly) */
+  GLX_DIST_FORM_SPLIT = 2,          /* [boundary rows | exchange beside the interior rows]: two launches per sweep */
+  GLX_DIST_FORM_FUSED = 4,          /* one launch for all rows, the exchange in line behind it */
+  GLX_DIST_PACK_KERNEL = 8,         /* a pack kernel between SpMM and transport instead of the SpMM scattering into the send buffer */
+  GLX_DIST_INLINE = 16,             /* the exchange on the sweep's own stream (no second stream) */
+  GLX_DIST_EXCHANGE_CAPTURED = 32,  /* exchanging sweeps are captured without the self-test */
+  GLX_DIST_EXCHANGE_EAGER = 64,     /* exchanging sweeps are enqueued eagerly */
+  GLX_DIST_EXCHANGE_SELFTEST = 128  /* the first run decides by the self-test (default with real peers) */
+};
 int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_halo, int64_t n_boundary, const int32_t* rowptr,
                           const int32_t* col, const double* val, int state_dtype, int C, const int64_t* send_counts,
                           const int32_t* send_idx, const int64_t* recv_counts, int64_t n_global, int force_exchange,
-                          int use_hipgraph, glx_dist_sweep** out);
+                          int flags, glx_dist_sweep** out);
 /* rank-local rows (local order) of Db (n_own, C; may be NULL), w0 = v0/deg, deg, vinf */
 int glx_dist_sweep_set_problem(glx_dist_sweep* s, const void* Db_own, const double* w0_own, const double* deg_own,
                                const double* vinf_own);
@@ -341,25 +353,21 @@ int glx_knn_cells_range(const double* X, int64_t n, int d, int k, const int64_t*
  * pruning of glx_knn_cells_range.  Indices and output rows are the caller's, equal distances go to the lower caller index: the
  * lists of glx_knn_bruteforce bit for bit.  ncells < -1: the rows reordered by -ncells chained cells on the device, then ALL PAIRS
  * (no pruning: a wavefront's queries share a corner of feature space, which is worth 10-14 % of the search on clustered data
- * below the size where pruning pays, and nothing elsewhere); the order is left for glx_knn_last_order. */
+ * below the size where pruning pays, and nothing elsewhere).  glx_knn_search hands that order out with its result. */
 int glx_knn_clustered(const double* X, int64_t n, int d, int k, int ncells, int64_t* ind_out, double* dist_out, int device);
-/* perm_out[position] = caller's row in the cell order of the last glx_knn_clustered search over n rows (GLX_EINVAL: none of that
- * size on record): contiguous cells of feature space, neighbouring cells chained -- a locality order of the vertices for
- * glx_graph_set_order that costs nothing. */
-int glx_knn_last_order(int64_t n, int32_t* perm_out);
-/* on != 0: the NEXT full search (glx_knn_bruteforce / glx_knn_clustered: all rows as queries) keeps its (n,k) neighbour indices
- * on the device for the assembly that follows it -- glx_knn_to_csr[_into] with ind = NULL and kk = k adopts them -- and may be
- * called with ind_out = NULL: inside weightmatrix.knn (graphlearning/weightmatrix.py:119-187) the lists are only ever consumed by
- * the assembly and need not cross PCIe twice.  One search; on = 0 withdraws the request and drops what is retained.  Request,
- * search and assembly belong to the calling thread: other threads' searches neither see the request nor touch what is retained. */
-int glx_knn_retain_next(int on);     /* DEPRECATED (kept for one round): use glx_knn_search, which hands the lists over as an object */
+/* Plan overrides of the calling thread's searches (tests and A/B measurements; NULL or all-default values = the library decides):
+ * filter 0 auto | 1 split-bf16 | 2 fp32 operands; lists 0 auto | 1 short | 2 long (one list holds all k neighbours of a query);
+ * nsplit 0 auto | 1..8 ref ranges per query block; concat -1 auto | 0 blocks of 16 features | 1 concatenated split operands
+ * (d <= 21) | 2 with the norm folded in (d <= 20).  Every plan returns the same exact lists. */
+typedef struct { int filter, lists, nsplit, concat; } glx_knn_options;
+int glx_knn_set_options(const glx_knn_options* opt);
 
 /* ---- search results as objects (what weightmatrix.knn uses) ---------------------------------------------------------------------
  * glx_knn_search runs the full search (every row a query, self included; ncells as in glx_knn_clustered: 0 / 1 all pairs,
  * > 1 pruned by library-formed cells, < -1 all pairs on rows reordered by -ncells chained cells) and leaves the lists ON THE DEVICE
  * in a result object.  OWNERSHIP: the caller owns *out and releases it with glx_knn_result_destroy; the other calls borrow it.
- * The object may be used from any thread, by one thread at a time.  Replaces the hidden hand-offs glx_knn_retain_next /
- * glx_knn_last_order (caller owns all buffers: the convention of the reference's c_code/cextensions.cpp:19-60). */
+ * The object may be used from any thread, by one thread at a time; nothing is handed from one call to the next through hidden
+ * state (caller owns all buffers: the convention of the reference's c_code/cextensions.cpp:19-60). */
 typedef struct glx_knn_result glx_knn_result;
 int glx_knn_search(const double* X, int64_t n, int d, int k, int ncells, int device, glx_knn_result** out);
 /* copies of the lists for the host: ind_out / dist_out (n, k), either may be NULL */
@@ -374,7 +382,7 @@ int glx_knn_result_destroy(glx_knn_result* res);
 /* out[i] = exp(x[i]) correctly rounded (csrc/exp_cr.h: the exponential of the Gaussian weights), host arrays; a test hook */
 int glx_exp_cr(const double* x, double* out, int64_t n, int device);
 
-int glx_knn_stats(double stats[16]);  /* of the last search: [0] tile-kernel ms, [1] re-rank ms, [2] fallback rows, [3] total device ms,
+int glx_knn_stats(double stats[16]);  /* of the calling thread's last search: [0] tile-kernel ms, [1] re-rank ms, [2] fallback rows, [3] total device ms,
                                         [4] fallback ms, [5] padded feature count, [6] ref ranges, [7] list length (negative: bf16 filter),
                                         [8] rows the short lists could not accept when the search was repeated with long ones (else 0);
                                         [9] concatenated operands (d <= 21): 0 no, 1 yes, 2 with the norm folded in (d <= 20),
@@ -385,7 +393,7 @@ int glx_knn_stats(double stats[16]);  /* of the last search: [0] tile-kernel ms,
 /* weightmatrix.knn given knn data (graphlearning/weightmatrix.py:134-187) on the device: kernel
  * weights, COO->CSR with duplicates summed, symmetrisation, zero diagonal, zeros dropped.
  * ind (n,kk) int64 and dist (n,kk) fp64 host arrays of which the first k columns are used
- * (k counts the self point); ind = NULL (kk = k): the indices retained by the last search, see glx_knn_retain_next.  kernel: 0 = `weights` (n,k) given (user eta), 1 uniform,
+ * (k counts the self point).  kernel: 0 = `weights` (n,k) given (user eta), 1 uniform,
  * 2 gaussian, 3 symgaussian, 4 distance, 5 singular.  sym: 0 none, 1 (W+W^T)/2, 2 element-wise
  * max (utils.sparse_max), 3 the symgaussian rule.  Outputs are allocated by the library
  * (release with glx_free): canonical CSR, int32 indices like scipy's. */

@@ -23,9 +23,9 @@ if len(sys.argv) > 1:
 for name, X, k in cases:
     res = {}
     for flt in (('bf16',) if os.environ.get('PROBE_ONLY_D64') else ('bf16', 'f32')):
-        os.environ['GLX_KNN_FILTER'] = flt
-        _hip.knn_bruteforce(X, k)
-        t0 = time.perf_counter(); J, D = _hip.knn_bruteforce(X, k); wall = time.perf_counter() - t0
+        with _hip.knn_options(filter=flt):
+            _hip.knn_bruteforce(X, k)
+            t0 = time.perf_counter(); J, D = _hip.knn_bruteforce(X, k); wall = time.perf_counter() - t0
         st = _hip.knn_stats()
         res[flt] = (J, D)
         n, d = X.shape

@@ -217,29 +217,15 @@ def test_glx_dist_one_rank_forced_halo(golden, transport):
 
 
 @pytest.mark.parametrize('mode', ['auto', 'split', 'split_pack', 'split_inline', 'fused', 'selftest', 'eager'])
-def test_glx_dist_exchange_forms(golden, mode, monkeypatch):
+def test_glx_dist_exchange_forms(golden, mode):
     """Round-3 forms of the exchanging sweep on ONE rank with a forced self-halo through a 1-rank RCCL communicator, all
     bit-identical to the golden iterates: the form the library picks by itself (a halo this small: ONE launch per sweep, the
     exchange in line), the split form [boundary rows | exchange beside the interior rows] with the boundary SpMM scattering
-    its rows into the send buffer, with the round-2 pack kernel (GLX_DIST_PACK=1) and with the exchange in line, the fused
-    form forced, the capture decided by the self-test (GLX_DIST_CAPTURE_EXCHANGE=-1: three eager sweeps against three
+    its rows into the send buffer, with the round-2 pack kernel and with the exchange in line, the fused
+    form forced, the capture decided by the self-test (three eager sweeps against three
     captured + replayed ones), and eager sweeps."""
     from graphlearning_amd import dist as gdist, _hip
     _hip.require_device()
-    for k in ('GLX_DIST_PACK', 'GLX_DIST_FUSE', 'GLX_DIST_CAPTURE_EXCHANGE', 'GLX_DIST_OVERLAP'):
-        monkeypatch.delenv(k, raising=False)
-    if mode.startswith('split'):
-        monkeypatch.setenv('GLX_DIST_FUSE', '0')
-    if mode == 'split_pack':
-        monkeypatch.setenv('GLX_DIST_PACK', '1')
-    elif mode == 'split_inline':
-        monkeypatch.setenv('GLX_DIST_OVERLAP', '0')
-    elif mode == 'fused':
-        monkeypatch.setenv('GLX_DIST_FUSE', '1')
-    elif mode == 'selftest':
-        monkeypatch.setenv('GLX_DIST_CAPTURE_EXCHANGE', '-1')
-    elif mode == 'eager':
-        monkeypatch.setenv('GLX_DIST_CAPTURE_EXCHANGE', '0')
     g = golden('g3_blobs5000.npz')
     W = csr_from(g, 'W')
     ti, lab = g['train_ind'], g['labels']
@@ -249,7 +235,7 @@ def test_glx_dist_exchange_forms(golden, mode, monkeypatch):
     ds = None
     try:
         assert comm.info() == dict(rank=0, nranks=1, device=0, rccl=True)
-        ds = gdist.glx_dist_sweep(comm, plan, prob['k'], force_exchange=True)
+        ds = gdist.glx_dist_sweep(comm, plan, prob['k'], force_exchange=True, form=mode)
         _check_exchange_form(ds, plan, prob, g, mode)
     finally:
         if ds is not None:

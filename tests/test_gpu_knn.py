@@ -20,18 +20,15 @@ def gl():
 @pytest.mark.parametrize('tag', ['d20', 'd64', 'd3'])
 def test_knnsearch_golden(gl, golden, tag, flt, monkeypatch):
     """The candidate filters -- split-bf16 operands on the bf16 matrix cores (default for d <= 128; for 17 <= d <= 21 as ONE
-    contraction over concatenated operands [rh|rh|rl].[qh|ql|qh], for d <= 20 with |r|^2 folded into it as well; GLX_KNN_CAT=1
-    without the fold, =0 in blocks of 16 features) and the fp32-input MFMA kernel -- end in the same exact answer: the cKDTree
+    contraction over concatenated operands [rh|rh|rl].[qh|ql|qh], for d <= 20 with |r|^2 folded into it as well; knn_options(concat=1)
+    without the fold, concat=0 in blocks of 16 features) and the fp32-input MFMA kernel -- end in the same exact answer: the cKDTree
     lists of the reference."""
     from graphlearning_amd import _hip
-    monkeypatch.setenv('GLX_KNN_FILTER', 'f32' if flt == 'f32' else 'bf16')
-    if flt == 'bf16x3':
-        monkeypatch.delenv('GLX_KNN_CAT', raising=False)
-    else:
-        monkeypatch.setenv('GLX_KNN_CAT', '0' if flt == 'bf16x3_blocks' else '1')
     g = golden('g2_knn.npz')
     X, J, D = g['X_' + tag], g['J_' + tag], g['D_' + tag]
-    ind, dist = gl.weightmatrix.knnsearch(X, 11)
+    concat = {'bf16x3': None, 'bf16x3_cat': 1, 'bf16x3_blocks': 0, 'f32': None}[flt]
+    with _hip.knn_options(filter='f32' if flt == 'f32' else 'bf16', concat=concat):
+        ind, dist = gl.weightmatrix.knnsearch(X, 11)
     st = _hip.knn_stats()
     assert st['filter'] == flt.split('_')[0] and st['fallback_rows'] <= 20
     assert st['concatenated'] == (2 if flt == 'bf16x3' else 1 if flt == 'bf16x3_cat' else 0) * (tag == 'd20')
@@ -217,11 +214,8 @@ def test_knn_filter_soundness_on_near_duplicates_and_offsets(gl):
     X = np.repeat(centres, 10, axis=0) + rng.normal(size=(3000, 24)) * 1e-6 + 1e3
     J_ref, D_ref = orc.knnsearch(X, 11)
     for flt in ('bf16', 'f32'):
-        os.environ['GLX_KNN_FILTER'] = flt
-        try:
+        with _hip.knn_options(filter=flt):
             J, D = gl.weightmatrix.knnsearch(X, 11)
-        finally:
-            del os.environ['GLX_KNN_FILTER']
         st = _hip.knn_stats()
         # the 10 members of a cluster are each other's nearest neighbours; ties are broken by index like cKDTree's sort
         assert np.array_equal(np.sort(J[:, :10], axis=1), np.sort(J_ref[:, :10], axis=1)), flt
@@ -397,16 +391,15 @@ def test_clustered_search_hands_its_cell_order_to_the_operator(gl, monkeypatch):
 def test_rerank_every_candidate_width(gl, monkeypatch, k, nsplit, short):
     """The re-rank ranks a query's candidates in registers (one to eight per lane: 64 .. 512 candidates) or, beyond that, in LDS
     (1024: 16 lists of 64): every width against cKDTree's lists -- ties by (distance, index) included, the data has duplicates.
-    GLX_KNN_NSPLIT / GLX_KNN_SHORT pick the number and the length of the lists (reference weightmatrix.py:297-429)."""
+    knn_options(nsplit, lists) pick the number and the length of the lists (reference weightmatrix.py:297-429)."""
     from graphlearning_amd import _hip
     from oracle import gl_oracle as orc
-    monkeypatch.setenv('GLX_KNN_NSPLIT', str(nsplit))
-    monkeypatch.setenv('GLX_KNN_SHORT', short)
     rng = np.random.default_rng(900 + k)
     n, d = 5000, 24
     X = rng.normal(size=(8, d))[rng.integers(0, 8, size=n)] * 2.0 + rng.normal(size=(n, d))
     X[n - 200:] = X[:200]                                     # exact duplicates: ties at distance 0 and beyond
-    J, D = gl.weightmatrix.knnsearch(X, k)
+    with _hip.knn_options(nsplit=nsplit, lists='short' if short == '1' else 'long'):
+        J, D = gl.weightmatrix.knnsearch(X, k)
     st = _hip.knn_stats()
     Jo, Do = orc.knnsearch(X, k)
     Jo, Do = Jo.reshape(n, -1), Do.reshape(n, -1)
@@ -425,31 +418,36 @@ def test_rerank_every_candidate_width(gl, monkeypatch, k, nsplit, short):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('kernel', ['gaussian', 'uniform', 'distance'])
-def test_retained_indices_give_the_same_matrix(gl, monkeypatch, kernel):
-    """weightmatrix.knn keeps the neighbour lists of its own search on the device for the assembly (glx_knn_retain_next; the
-    indices never visit the host): the matrix equals the one built from the lists that did (reference weightmatrix.py:119-187)."""
+def test_result_objects_give_the_same_matrix(gl, kernel, device_exp):
+    """weightmatrix.knn keeps the neighbour lists of its own search on the device in a result object (glx_knn_search /
+    glx_knn_result_to_csr; the lists never visit the host): the matrix equals the one built from lists that did, and the object
+    can be consumed repeatedly and released (reference weightmatrix.py:119-187)."""
     from graphlearning_amd import _hip
     rng = np.random.default_rng(77)
     X = rng.normal(size=(6, 12))[rng.integers(0, 6, size=9000)] * 2.0 + rng.normal(size=(9000, 12))
     W1 = gl.weightmatrix.knn(X, 12, kernel=kernel)
-    monkeypatch.setenv('GLX_KNN_RETAIN', '0')
-    W0 = gl.weightmatrix.knn(X, 12, kernel=kernel)
+    J, D = gl.weightmatrix.knnsearch(X, 13)
+    W0 = gl.weightmatrix.knn(X, 12, kernel=kernel, knn_data=(J, D))
     assert np.array_equal(W1.indptr, W0.indptr) and np.array_equal(W1.indices, W0.indices) and np.array_equal(W1.data, W0.data)
-    # nothing is left behind, and an assembly without indices and without a retained search is refused
+    res = _hip.KnnResult(X, 13, want_order=True)
+    J2, D2 = res.lists()
+    assert np.array_equal(J2, J) and np.array_equal(D2, D)
+    order = res.order()
+    assert order is not None and np.array_equal(np.sort(order), np.arange(9000))
+    sym = 2 if kernel in ('uniform', 'distance') else 1
+    for _ in range(2):          # the object is borrowed by the assembly, not consumed
+        W2 = res.to_csr(13, kernel=kernel, sym=sym)
+        assert np.array_equal(W2.indptr, W1.indptr) and np.array_equal(W2.indices, W1.indices) and np.array_equal(W2.data, W1.data)
+    res.close()
+    res.close()                 # idempotent
     with pytest.raises(_hip.GlxError):
-        _hip.knn_to_csr(None, np.ones((9000, 13)), 13, kernel='uniform', sym=2)
-    # a retained result is dropped by a withdrawn request
-    J, D = _hip.knn_bruteforce(X, 13, retain=True)
-    assert J is None and D.shape == (9000, 13)
-    _hip.load().glx_knn_retain_next(0)
-    with pytest.raises(_hip.GlxError):
-        _hip.knn_to_csr(None, D, 13, kernel='uniform', sym=2)
+        _hip.KnnResult(np.full((10, 3), np.nan), 3)      # non-finite input: refused, no object is left behind
 
 
 @pytest.mark.gpu
-def test_retained_indices_are_per_thread(gl):
-    """Two threads building different graphs at once: each assembly adopts the lists of ITS thread's search (the request and what
-    is retained are thread-local in the library), the matrices equal the ones built one after the other."""
+def test_result_objects_are_independent_across_threads(gl):
+    """Two threads building different graphs at once: each assembly reads the result object of ITS search (no state is shared
+    between searches), the matrices equal the ones built one after the other."""
     import threading
     rng = np.random.default_rng(78)
     Xs = [rng.normal(size=(5, 10))[rng.integers(0, 5, size=n)] * 2.0 + rng.normal(size=(n, 10)) for n in (8000, 8000, 9000)]
