@@ -575,6 +575,13 @@ def main():
     ap.add_argument('--config', type=int, default=2, choices=[2, 4],
                     help='2 (default): BASELINE configs[1], weak scaling over --gpus; 4: configs[3] (blobs d=64), strong scaling of --n vertices')
     ap.add_argument('--n', type=float, default=1e7, help='vertices of --config 4 (default 10^7; kNN alone is ~110 s on one GPU at that size)')
+    ap.add_argument('--partition', default='cut', choices=['cut', 'even', 'cells'],
+                    help='multi-GPU runs: contiguous blocks cut between the pieces of the graph (default), equal blocks, or the cells of the '
+                         'search assigned to ranks by a balanced partition of their quotient graph')
+    ap.add_argument('--knn', default='cells', choices=['cells', 'allpairs'], help='--config 4: cell-pruned search (default) or every tile')
+    ap.add_argument('--workload', default='blobs', choices=['blobs', 'connected'],
+                    help='multi-GPU config 2: the headline features (10 separate clusters) or the same with centre scale 0.8 '
+                         '(one connected component: the halo exchange carries real rows)')
     ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 counter passes (roofline.traffic = null)')
     ap.add_argument('--no-scale', action='store_true', help='skip the n = 10^6 shard-size line')
     ap.add_argument('--no-configs', action='store_true', help='skip the configs block (configs 3 and 5, Poisson CG, weightmatrix.knn)')

@@ -573,8 +573,6 @@ _live_dist_objects = weakref.WeakSet()
 
 
 def _abandon_dist_objects():
-    if os.environ.get('GLX_NO_ATEXIT_ABANDON') == '1':
-        return
     for obj in list(_live_dist_objects):
         try:
             obj._h = _vp()

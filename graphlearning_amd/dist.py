@@ -410,9 +410,7 @@ class DistSweep:
         self.cur = 0
         self._graph = None
         self._graph_err = None
-        import os
-        self._graph_ok = (bool(getattr(ops, 'supports_graph', False)) and not self._stage_host
-                          and os.environ.get('GLX_DIST_GRAPH', '1') != '0')
+        self._graph_ok = bool(getattr(ops, 'supports_graph', False)) and not self._stage_host
 
     def close(self):
         """Release the captured device graph and the rank-local state while the process group is

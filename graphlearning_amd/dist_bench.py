@@ -345,8 +345,8 @@ def main_config4(args):
     lo, hi = int(even[rank]), int(even[rank + 1])
     t0 = time.perf_counter()
     # the cells of the coarse order double as the search's pruning structure (glx_knn_cells_range: the same lists as the all-pairs
-    # search, only the cells that can hold a neighbour are visited; GLX_CONFIG4_KNN=allpairs for the search over every tile)
-    knn_cells = None if os.environ.get('GLX_CONFIG4_KNN', 'cells') == 'allpairs' else cell_starts
+    # search, only the cells that can hold a neighbour are visited; --knn allpairs for the search over every tile)
+    knn_cells = None if getattr(args, 'knn', 'cells') == 'allpairs' else cell_starts
     J, D = _hip.knn_bruteforce(X, K + 1, device=local_rank, query_range=(lo, hi), cell_starts=knn_cells)
     st = _hip.knn_stats()
     t_knn = time.perf_counter() - t0
@@ -355,9 +355,9 @@ def main_config4(args):
         'all pairs' if knn_cells is None else '%d cells, sample stride %d' % (st['cells'], st['seed_sample'])))
     del X
     # the sweep's blocks follow the graph: boundaries at the cell starts that cross the fewest list entries (between clusters: none),
-    # the lists move to their new owners (GLX_CONFIG4_PARTITION=even keeps the equal blocks)
+    # the lists move to their new owners (--partition even keeps the equal blocks)
     t0 = time.perf_counter()
-    partition = os.environ.get('GLX_CONFIG4_PARTITION', 'cut')
+    partition = getattr(args, 'partition', 'cut')
     bounds = even
     if partition == 'cut' and world > 1:
         bounds = dist_build.graph_cut_bounds(dist, n, np.asarray(J), lo, cell_starts, device=dev)
@@ -366,9 +366,9 @@ def main_config4(args):
     t_cut = time.perf_counter() - t0
     progress('block boundaries %s' % [int(b) for b in bounds])
     t0 = time.perf_counter()
-    # (GLX_CONFIG4_LOCAL_ORDER=rcm: a rank's rows in the library's breadth-first order of their links among themselves.  Measured: no
-    # gain over the chained cells of the coarse order -- 253 us per sweep at 10^6 rows either way -- for 3 s more set-up at 10^7)
-    local_order = os.environ.get('GLX_CONFIG4_LOCAL_ORDER', 'block')
+    # (a rank's rows keep the chained cells of the coarse order: the library's breadth-first order of their links among themselves
+    # gained nothing -- 253 us per sweep at 10^6 rows either way -- for 3 s more set-up at 10^7)
+    local_order = 'block'
     sg = dist_build.ShardedGraph(dist, n, J, D, K, device=dev, bounds=bounds, local_order=local_order)
     del J, D
     train_ind = gl.trainsets.generate(labels, rate=5, seed=0)

@@ -49,11 +49,13 @@ def test_hipops_rank_local_sweeps_match_scipy(golden):
             ops.close()
 
 
-@pytest.mark.parametrize('force_coll', ['0', '1'])
-def test_distributed_bench_entry_one_rank(tmp_path, force_coll):
-    # force_coll=1: the all_to_all / all_reduce calls are issued even with one rank (eagerly: collectives are never
-    # captured into a device graph, see DistSweep.run)
-    env = dict(os.environ, GLX_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', GLX_DIST_FORCE_COLLECTIVES=force_coll)
+@pytest.mark.parametrize('force_coll,engine', [('0', 'glx'), ('1', 'glx'), ('1', 'torch')])
+def test_distributed_bench_entry_one_rank(tmp_path, force_coll, engine):
+    # force_coll=1 (GLX_DIST_FORCE_COLLECTIVES): the all_to_all / all_reduce calls are issued even with one rank (eagerly:
+    # collectives are never captured into a device graph, see DistSweep.run); GLX_DIST_ENGINE=torch: the torch.distributed engine
+    # the bench falls back to when the library's own communicator cannot be set up
+    env = dict(os.environ, GLX_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', GLX_DIST_FORCE_COLLECTIVES=force_coll,
+               GLX_DIST_ENGINE=engine, GLX_DIST_SELFTEST_TIMEOUT='20')
     import socket
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -68,6 +70,7 @@ def test_distributed_bench_entry_one_rank(tmp_path, force_coll):
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     j = json.loads(line)
     assert j['n_gpus'] == 1 and j['value'] > 0 and j['config']['sweeps_per_step'] == 50
+    assert j.get('engine', engine) == engine, line[:600]
     print(line[:400])
 
 
