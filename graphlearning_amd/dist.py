@@ -139,6 +139,205 @@ def choose_cuts(xc, cand, n, world, slack_levels=(0.0, 0.1, 0.25, 0.45, 0.65, 0.
     return np.array([0] + list(chosen[1]) + [n], dtype=np.int64)
 
 
+def partition_cost(P, order, bounds):
+    """What a partition costs, rank by rank, without building the plans: stored entries and rows owned, distinct halo rows
+    imported, the largest message from one peer.  Plus a coarse estimate of the time of one fused sweep (the constants of
+    glx_dist_sweep_create's own choice between its forms: 2.5 us + 7.7 ps per stored entry for the rows, 6.6 us + 128-byte records
+    at 50 GB/s for the largest per-peer message as soon as ANY rank imports a halo) -- enough to rank partitions against each
+    other; scripts/scale_model.py measures the kernels."""
+    A = sparse.csr_matrix(P)
+    n = A.shape[0]
+    world = len(bounds) - 1
+    pos = np.empty(n, dtype=np.int64)
+    pos[order] = np.arange(n)
+    owner_of = (np.searchsorted(bounds, pos, side='right') - 1).astype(np.int64)        # owner of every vertex
+    rowlen = np.diff(A.indptr)
+    row_owner = np.repeat(owner_of, rowlen)
+    col_owner = owner_of[A.indices]
+    entries = np.bincount(owner_of, weights=rowlen, minlength=world).astype(np.int64)
+    rows = np.bincount(owner_of, minlength=world).astype(np.int64)
+    remote = row_owner != col_owner
+    # distinct (importing rank, imported row) pairs, then per (importer, owner)
+    key = np.unique(row_owner[remote] * n + A.indices[remote])
+    imp, col = key // n, key % n
+    halo = np.bincount(imp, minlength=world).astype(np.int64)
+    pair = np.bincount(imp * world + owner_of[col], minlength=world * world).reshape(world, world)
+    peer_max = np.maximum(pair.max(axis=1), pair.max(axis=0))           # largest message a rank receives or sends
+    any_halo = int(halo.sum()) > 0
+    t = 2.5 + 7.7e-6 * entries + (6.6 + peer_max * 128.0 / 50e3 if any_halo else 0.0)
+    return dict(entries=entries, rows=rows, halo_rows=halo, peer_max=peer_max, est_us=float(np.max(t)),
+                imbalance=float(entries.max() / max(1.0, entries.mean())), crossing=int(remote.sum()))
+
+
+def quotient_partition(P, order, world, segments=None, eps_levels=(0.03, 0.08, 0.15, 0.3, 0.6), seed=0):
+    """A third way to give the vertices to `world` ranks, beside contiguous cuts of `order` (cut_bounds) and equal blocks: cut
+    `order` into a few hundred SEGMENTS at its least-crossed positions (on a kNN graph of clustered data: cells of feature space),
+    form the quotient graph of the segments (node weight = the work of a segment's rows, edge weight = stored entries between two
+    segments) and distribute the NODES over the ranks -- any subset, not only runs of consecutive ones -- under a balance bound,
+    by greedy growth from spread-out seeds followed by Kernighan-Lin / Fiduccia-Mattheyses style refinement (single moves and
+    pair swaps of best gain).  For a growing balance allowance the assignment of least predicted sweep time (partition_cost)
+    wins.  Ten clusters over eight ranks: contiguous cuts must hand two whole clusters to two ranks (imbalance 1.6); this can
+    split clusters into cells and deal the cells out.
+    Returns (order2, bounds, info): `order2` lists every rank's segments one after another (in the order of `order`, so the
+    locality inside a rank is kept), `bounds` the rank boundaries in it -- the (order, bounds) pair RankPlan takes.  Iterates do
+    not depend on the assignment: a row's entries keep their order whoever owns the row."""
+    A = sparse.csr_matrix(P)
+    n = A.shape[0]
+    order = np.asarray(order, dtype=np.int64)
+    if world <= 1:
+        return order, np.array([0, n], dtype=np.int64), dict(segments=1, eps=0.0)
+    S = int(segments) if segments else int(min(256, max(8 * world, 32)))
+    S = max(world, min(S, n))
+    cross = crossing_counts(A, order)
+    edges = np.linspace(0, n, S + 1).astype(np.int64)
+    cuts = [0]
+    for a, b in zip(edges[1:-1], edges[2:]):            # one boundary per window: its least-crossed position
+        lo = int((edges[np.searchsorted(edges, a) - 1] + a) // 2) if a > 0 else 0
+        lo = max(lo, cuts[-1] + 1)
+        hi = int((a + b) // 2)
+        if hi <= lo:
+            continue
+        cuts.append(lo + int(np.argmin(cross[lo:hi])))
+    segb = np.array(sorted(set(cuts)) + [n], dtype=np.int64)
+    S = len(segb) - 1
+    pos = np.empty(n, dtype=np.int64)
+    pos[order] = np.arange(n)
+    seg_of = (np.searchsorted(segb, pos, side='right') - 1).astype(np.int64)
+    rowlen = np.diff(A.indptr)
+    wnode = np.bincount(seg_of, weights=rowlen + 3.0, minlength=S)
+    rs, cs = np.repeat(seg_of, rowlen), seg_of[A.indices]
+    Q = np.bincount(rs * S + cs, minlength=S * S).reshape(S, S).astype(np.float64)
+    Q = Q + Q.T
+    np.fill_diagonal(Q, 0.0)
+    total = float(wnode.sum())
+    rng = np.random.default_rng(seed)
+
+    def refine(part, cap):
+        load = np.bincount(part, weights=wnode, minlength=world)
+        conn = np.zeros((S, world))
+        for r in range(world):
+            conn[:, r] = Q[:, part == r].sum(axis=1)
+        for _ in range(8 * S):
+            own = conn[np.arange(S), part]
+            gain = conn - own[:, None]                                    # gain[v, r]: cut removed by moving v to r
+            feas = (load[None, :] + wnode[:, None] <= cap)
+            feas[np.arange(S), part] = False
+            g = np.where(feas, gain, -np.inf)
+            v, r = np.unravel_index(int(np.argmax(g)), g.shape)
+            best_move = g[v, r]
+            # pair swaps of the most promising candidates (keeps the loads nearly unchanged)
+            best_swap, sw = 0.0, None
+            cand = np.argsort(-(gain.max(axis=1)))[:24]
+            for a in cand:
+                for b in cand:
+                    if part[a] == part[b]:
+                        continue
+                    ga = gain[a, part[b]] + gain[b, part[a]] - 2.0 * Q[a, b]
+                    if ga > best_swap + 1e-9:
+                        la = load[part[a]] - wnode[a] + wnode[b]
+                        lb = load[part[b]] - wnode[b] + wnode[a]
+                        if la <= cap and lb <= cap:
+                            best_swap, sw = ga, (a, b)
+            if best_move <= 1e-9 and sw is None:
+                break
+
+            def move(v, r):
+                o = part[v]
+                conn[:, o] -= Q[:, v]
+                conn[:, r] += Q[:, v]
+                load[o] -= wnode[v]
+                load[r] += wnode[v]
+                part[v] = r
+            if sw is not None and best_swap > best_move:
+                a, b = sw
+                pa, pb = part[a], part[b]
+                move(a, pb)
+                move(b, pa)
+            else:
+                move(int(v), int(r))
+        return part
+
+    def grow(cap):
+        # seeds: the heaviest node, then repeatedly the node least connected to the seeds so far; the parts take turns (lightest
+        # first) adopting the unassigned node they are most connected to
+        part = np.full(S, -1, dtype=np.int64)
+        seeds = [int(np.argmax(wnode))]
+        while len(seeds) < world:
+            c = Q[:, seeds].sum(axis=1) - 1e-3 * wnode / total
+            c[seeds] = np.inf
+            seeds.append(int(np.argmin(c)))
+        load = np.zeros(world)
+        for r, v in enumerate(seeds):
+            part[v] = r
+            load[r] = wnode[v]
+        conn = np.stack([Q[:, s] for s in seeds], axis=1)
+        left = S - world
+        while left > 0:
+            r = int(np.argmin(load))
+            free = part < 0
+            score = np.where(free, conn[:, r] + 1e-9 * rng.random(S), -np.inf)
+            v = int(np.argmax(score))
+            if conn[v, r] <= 0:                       # nothing adjacent left: the free node nearest in the order to the part's nodes
+                mine = np.flatnonzero(part == r)
+                fr = np.flatnonzero(free)
+                v = int(fr[np.argmin(np.min(np.abs(fr[:, None] - mine[None, :]), axis=1))])
+            part[v] = r
+            load[r] += wnode[v]
+            conn[:, r] += Q[:, v]
+            left -= 1
+        return part
+
+    def contiguous(cap):
+        # consecutive runs of segments, filled up to the mean load: the starting point that already is a cut_bounds-like answer
+        part = np.zeros(S, dtype=np.int64)
+        acc, r = 0.0, 0
+        for v in range(S):
+            if acc + 0.5 * wnode[v] > total / world * (r + 1) and r < world - 1:
+                r += 1
+            part[v] = r
+            acc += wnode[v]
+        return part
+
+    best = None
+    for eps in eps_levels:
+        cap = (1.0 + eps) * total / world
+        if cap < wnode.max():
+            continue
+        for start in (grow, contiguous):
+            part = refine(start(cap).copy(), cap)
+            if np.bincount(part, weights=wnode, minlength=world).max() > cap * (1 + 1e-9) or len(np.unique(part)) < world:
+                continue
+            seg_order = np.argsort(part, kind='stable')                       # by rank, segments ascending inside a rank
+            order2 = np.concatenate([order[segb[v]:segb[v + 1]] for v in seg_order])
+            sizes = np.bincount(part, weights=np.diff(segb), minlength=world).astype(np.int64)
+            bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            cost = partition_cost(A, order2, bounds)
+            if best is None or cost['est_us'] < best[0] - 1e-9:
+                best = (cost['est_us'], order2, bounds, dict(segments=S, eps=float(eps), start=start.__name__, cut_entries=cost['crossing'],
+                                                              est_us=cost['est_us'], imbalance=cost['imbalance']))
+    if best is None:
+        b = block_bounds(n, world)
+        return order, b, dict(segments=S, eps=None, start='equal blocks', est_us=partition_cost(A, order, b)['est_us'])
+    return best[1], best[2], best[3]
+
+
+def plan_partition(P, order, world, how='auto'):
+    """(order, bounds, info) for `how` in 'cut' (contiguous blocks between the graph's pieces), 'even' (equal blocks), 'cells'
+    (quotient_partition) or 'auto' (the one of cut / cells with the smaller estimated sweep time)."""
+    n = sparse.csr_matrix(P).shape[0]
+    if how == 'even':
+        b = block_bounds(n, world)
+        return order, b, dict(partition='even', **{k: v for k, v in partition_cost(P, order, b).items() if k in ('est_us', 'imbalance')})
+    cut = cut_bounds(P, order, world)
+    c_cut = partition_cost(P, order, cut)
+    if how == 'cut' or world <= 1:
+        return order, cut, dict(partition='cut', est_us=c_cut['est_us'], imbalance=c_cut['imbalance'])
+    o2, b2, info = quotient_partition(P, order, world)
+    if how == 'cells' or info['est_us'] < c_cut['est_us']:
+        return o2, b2, dict(partition='cells', **info)
+    return order, cut, dict(partition='cut', est_us=c_cut['est_us'], imbalance=c_cut['imbalance'], cells_est_us=info['est_us'])
+
+
 class RankPlan:
     """What rank `rank` needs: its rows of P with columns renumbered [owned | halo] and the
     send / receive lists of the per-sweep exchange."""
@@ -589,7 +788,7 @@ def poisson_fit_glx(W, train_ind, train_labels, dist, comm=None, device=None, mi
     n = P.shape[0]
     if order is None:
         order = locality_order(P)
-    bounds = cut_bounds(P, order, world) if partition == 'cut' else block_bounds(n, world)
+    order, bounds, _ = plan_partition(P, order, world, partition)
     plan = RankPlan(P, order, bounds, rank)
     own_comm = comm is None and not stepwise
     if stepwise and comm is None:
@@ -691,7 +890,7 @@ def poisson_fit_distributed(W, train_ind, train_labels, dist, ops_factory, min_i
     n = P.shape[0]
     if order is None:
         order = locality_order(P)
-    bounds = cut_bounds(P, order, world) if partition == 'cut' else block_bounds(n, world)
+    order, bounds, _ = plan_partition(P, order, world, partition)
     plan = RankPlan(P, order, bounds, rank)
     ops = ops_factory(plan, prob['k'])
     sweep = DistSweep(plan, ops, dist, group)
@@ -851,7 +1050,7 @@ def cg_distributed(A, B, dist, ops_factory, tol=1e-10, max_iter=100000, order=No
     C = B.shape[1]
     if order is None:
         order = locality_order(A)
-    bounds = cut_bounds(A, order, world) if partition == 'cut' else block_bounds(n, world)
+    order, bounds, _ = plan_partition(A, order, world, partition)
     plan = RankPlan(A, order, bounds, rank)
     ops = ops_factory(plan, C)
     xch = DistSweep(plan, ops, dist, group)          # its exchange(): boundary records of p[0:n_own] -> the peers' halo regions p[n_own:]

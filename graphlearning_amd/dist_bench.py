@@ -97,7 +97,8 @@ def main(args):
 
     n = bench.N_PER_RANK * world
     labels = bench.load_labels(n)
-    X = bench.make_features(labels)
+    connected = getattr(args, 'workload', 'blobs') == 'connected'
+    X = bench.make_features(labels, scale=0.8 if connected else 2.0)
     t0 = time.perf_counter()
     ind, dst = gdist.knnsearch_distributed(X, bench.K_NN + 1, dist, local_rank)   # queries sharded by rank
     W = gl.weightmatrix.knn(None, bench.K_NN, knn_data=(ind, dst))
@@ -135,8 +136,8 @@ def main(args):
         comm = None                                         # (a communicator some ranks did get is left alone)
 
     def measure(partition):
-        bounds = gdist.cut_bounds(P, order, world) if partition == 'cut' else gdist.block_bounds(P.shape[0], world)
-        plan = gdist.RankPlan(P, order, bounds, rank)
+        order_p, bounds, pinfo = gdist.plan_partition(P, order, world, partition)      # (deterministic: every rank arrives at the same plan)
+        plan = gdist.RankPlan(P, order_p, bounds, rank)
         own = plan.own
         if engine == 'glx':
             ds = gdist.glx_dist_sweep(comm, plan, prob['k'], force_exchange=gdist._force_collectives())
@@ -174,7 +175,7 @@ def main(args):
         how = info()
         close()
         return dict(T=T, wall=float(dt.item()), halo_rows=[int(h[0]) for h in halos], owned=[int(h[1]) for h in halos],
-                    global_halo=int(plan.global_halo), how=how)
+                    global_halo=int(plan.global_halo), how=how, planner={k: (v if not hasattr(v, 'item') else v.item()) for k, v in pinfo.items()})
 
     def measure_or_fall_back(partition):
         # an error every rank sees alike (an RCCL call refused, a capture the runtime rejects) must not cost the measurement:
@@ -197,8 +198,16 @@ def main(args):
             print('falling back to the torch.distributed engine', file=sys.stderr)
         return measure(partition)
 
-    res = measure_or_fall_back('cut')
-    even = measure_or_fall_back('even') if world > 1 else None      # equal blocks: a non-zero halo, i.e. the RCCL exchange in every sweep
+    # the headline partition: --partition (default `cut`: contiguous blocks between the graph's pieces; `cells`: the quotient-graph
+    # assignment; `auto`: the one of the two with the smaller estimated sweep time); the others are measured beside it
+    headline = getattr(args, 'partition', 'cut')
+    res = measure_or_fall_back(headline)
+    even = measure_or_fall_back('even') if (world > 1 and headline != 'even') else None      # equal blocks: the RCCL exchange in every sweep
+    others = {}
+    if world > 1:
+        for alt in ('cut', 'cells'):
+            if alt != headline and res['planner'].get('partition') != alt:
+                others[alt] = measure_or_fall_back(alt)
     if rank == 0:
         C = prob['k']
         nnz = int(P.nnz)
@@ -210,9 +219,9 @@ def main(args):
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['wall'] / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'configs[1] scaled weakly: %d x 70000 = %d vertices, k=10 kNN graph, nnz=%d, C=%d, '
-                                   'vertex-partitioned over %d GPUs (RCM order, block boundaries in the gaps between the '
-                                   'graph\'s pieces), %s; value = sweeps/s of the whole graph x %d'
-                                   % (world, n, nnz, C, world,
+                                   'vertex-partitioned over %d GPUs (RCM order, partition `%s`%s), %s; value = sweeps/s of the whole graph x %d'
+                                   % (world, n, nnz, C, world, res['planner'].get('partition', headline),
+                                      ', workload `connected` (centre scale 0.8: one component)' if connected else '',
                                       'one RCCL all-to-all-v halo exchange per sweep' if res['global_halo'] > 0 else
                                       'no halo (every rank owns whole pieces): no per-sweep exchange, one RCCL all-reduce for the stop test',
                                       world),
@@ -239,6 +248,12 @@ def main(args):
         if int(line['rccl_ranks']) != int(args.gpus):
             print('bench.py: the communicator has %d ranks, --gpus is %d' % (line['rccl_ranks'], args.gpus), file=sys.stderr)
             sys.exit(3)
+        line['partition'] = res['planner']
+        for alt, r_alt in others.items():
+            it_a = args.steps * r_alt['T'] / r_alt['wall']
+            line['partition_' + alt] = {'value': it_a * world, 'global_sweeps_per_sec': it_a, 'ms_per_step': r_alt['wall'] / args.steps * 1e3,
+                                        'halo_rows_per_rank': r_alt['halo_rows'], 'owned_per_rank': r_alt['owned'], 'planner': r_alt['planner'],
+                                        'exchange': r_alt['how']['exchange']}
         if even is not None:
             it_e = args.steps * even['T'] / even['wall']
             line['partition_even'] = {'value': it_e * world, 'global_sweeps_per_sec': it_e, 'ms_per_step': even['wall'] / args.steps * 1e3,

@@ -16,11 +16,12 @@ here on a 1-rank communicator: sweep with a 10 000-record self-exchange minus th
 inside one GPU).  Link rate: 7 xGMI links x ~153 GB/s bidirectional per GPU (task statement) -> 76 GB/s per direction peak; 50 GB/s
 per direction is assumed for RCCL point-to-point (ASSUMPTION, not measured: no second GPU).
 
-  weak   config 2 (BASELINE configs[1]): N x 70000 vertices, k = 10, d = 20 -- partitions `cut` (bench.py's headline) and `even`
+  weak   config 2 (BASELINE configs[1]): N x 70000 vertices, k = 10, d = 20 -- partitions `cut`, `even` and `cells` (dist.plan_partition);
+         --scale 0.8: the connected workload (bench.py --workload connected)
   strong config 4 shape (configs[3]): n vertices (default 2e6; 1e7 needs ~15 min of host planning), d = 64, k = 10, blocks of the coarse
          geometric order -- `cut` (boundaries where the fewest entries cross) and `even` --, T = 200 fixed
 
-Writes profiles/r03_scale_model.json (or --out).  Usage: python scripts/scale_model.py [--n4 2e6] [--worlds 2,4,8] [--skip4]
+Writes profiles/r04_scale_model.json (or --out).  Usage: python scripts/scale_model.py [--n4 2e6] [--worlds 2,4,8] [--skip4]
 """
 import os
 import sys
@@ -55,11 +56,10 @@ def rank_measurements(P, order, bounds, prob_rows, C, reps):
         t_plan = time.perf_counter() - t0
         own = plan.own
         tp = {}
-        for form, env in (('split', '0'), ('fused', '1')):
-            os.environ['GLX_DIST_FUSE'] = env
+        for form in ('split', 'fused'):
             # a comm of one rank with the plan of rank r of `world`: counts per peer are folded into one pseudo-peer for the object
             ds = _hip.DistSweep(comm, plan.P_local, plan.n_boundary, [plan.send_idx.size], plan.send_idx, [plan.n_halo], plan.n_global, C,
-                                force_exchange=False, use_hipgraph=False)
+                                force_exchange=False, use_hipgraph=False, form=form)
             ds.set_problem(prob_rows['Db'][own], prob_rows['w0'][own], prob_rows['deg'][own], prob_rows['vinf'][own])
             t = ds.time_parts(reps)
             if form == 'split':
@@ -68,7 +68,6 @@ def rank_measurements(P, order, bounds, prob_rows, C, reps):
                 tp['fused_us'] = t['boundary_us']
             rec = ds.lay['rec_bytes']
             ds.close()
-        os.environ.pop('GLX_DIST_FUSE', None)
         out.append(dict(rank=r, n_own=int(plan.n_own), n_boundary=int(plan.n_boundary), n_halo=int(plan.n_halo), nnz=int(plan.P_local.nnz),
                         recv_per_peer=[int(c) for c in plan.recv_counts], send_per_peer=[int(c) for c in plan.send_counts],
                         rec_bytes=int(rec), plan_s=t_plan, **tp))
@@ -122,7 +121,6 @@ def rccl_latency_us(P70k, order, prob, C):
     plan = _self_halo_plan(Pr, 7)
     plan.own = order[plan.own]
     res = {}
-    os.environ['GLX_DIST_FUSE'] = '1'           # one launch + the exchange in line: sweep - launch = the exchange itself
     for name, uid in (('copy', None), ('rccl', 'rccl')):
         try:
             comm = _hip.Comm(1, 0, _hip.Comm.unique_id() if uid else None, 0)
@@ -131,7 +129,7 @@ def rccl_latency_us(P70k, order, prob, C):
             res['error'] = str(exc)
             continue
         ds = _hip.DistSweep(comm, plan.P_local, plan.n_boundary, plan.send_counts, plan.send_idx, plan.recv_counts, plan.n_global, C,
-                            force_exchange=True)
+                            force_exchange=True, form='fused')      # one launch + the exchange in line: sweep - launch = the exchange itself
         own = plan.own
         ds.set_problem(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
         ds.run(50, 50, CHECK_EVERY, 0.0)
@@ -143,7 +141,6 @@ def rccl_latency_us(P70k, order, prob, C):
         res['halo_bytes'] = int(plan.n_halo) * ds.lay['rec_bytes']
         ds.close()
         comm.close()
-    os.environ.pop('GLX_DIST_FUSE', None)
     if res.get('rccl'):
         # what one grouped ncclSend/ncclRecv exchange of `halo_bytes` costs in line; the part that is not bandwidth is the latency
         res['exchange_us'] = max(0.0, res['rccl'] - res['rccl_launch_alone_us'])
@@ -159,7 +156,9 @@ def main():
     ap.add_argument('--reps', type=int, default=40)
     ap.add_argument('--skip4', action='store_true')
     ap.add_argument('--skip2', action='store_true')
-    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r03_scale_model.json'))
+    ap.add_argument('--scale', type=float, default=2.0, help='centre scale of the config-2 features: 2.0 = the headline blobs (10 separate clusters), '
+                                                              '0.8 = bench.py --workload connected (one component)')
+    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r04_scale_model.json'))
     args = ap.parse_args()
     worlds = [int(w) for w in args.worlds.split(',')]
     _hip.require_device()
@@ -194,21 +193,24 @@ def main():
         for world in worlds:
             n = bench.N_PER_RANK * world
             labels = bench.load_labels(n)
-            W = gl.weightmatrix.knn(bench.make_features(labels), bench.K_NN)
+            W = gl.weightmatrix.knn(bench.make_features(labels, scale=args.scale), bench.K_NN)
             ti = gl.trainsets.generate(labels, rate=1, seed=0)
             prob = gdist.poisson_problem(W, ti, labels[ti])
             P = prob['P']
             order = gdist.locality_order(P)
             entry = dict(n=n, nnz=int(P.nnz))
-            for part in ('even', 'cut'):
-                bounds = gdist.block_bounds(n, world) if part == 'even' else gdist.cut_bounds(P, order, world)
-                ranks = rank_measurements(P, order, bounds, prob, prob['k'], args.reps)
+            for part in ('even', 'cut', 'cells'):
+                t_part = time.perf_counter()
+                order_p, bounds, pinfo = gdist.plan_partition(P, order, world, part)
+                t_part = time.perf_counter() - t_part
+                ranks = rank_measurements(P, order_p, bounds, prob, prob['k'], args.reps)
                 pr = {name: predict(ranks, lat_us, gbs) for name, lat_us, gbs in
                       (('bw_peak', 0.0, LINK_GBS_PEAK), ('bw_rccl', 0.0, LINK_GBS_RCCL), ('rccl', L, LINK_GBS_RCCL))}
                 for v in pr.values():
                     v['weak_efficiency'] = t1 / v['sweep_us']
                     v['iters_per_s_70k_equivalents'] = world * 1e6 / v['sweep_us']
-                entry[part] = dict(ranks=ranks, predicted=pr, imbalance=max(m['n_own'] for m in ranks) * world / n)
+                entry[part] = dict(ranks=ranks, predicted=pr, imbalance=max(m['n_own'] for m in ranks) * world / n,
+                                   work_imbalance=max(m['nnz'] for m in ranks) * world / float(P.nnz), planner=pinfo, planner_s=t_part)
                 log('config 2 weak, N=%d, %s: halo/rank %s, predicted sweep bw %.1f us, rccl %.1f us (eff %.2f / %.2f)'
                     % (world, part, [m['n_halo'] for m in ranks], pr['bw_rccl']['sweep_us'], pr['rccl']['sweep_us'],
                        pr['bw_rccl']['weak_efficiency'], pr['rccl']['weak_efficiency']))

@@ -107,6 +107,10 @@ def main():
         X, lab = blobs(1500, 8, 4, 21, 2.5)
         W = orc.knn(X, 8)
         ti = orc.trainsets_generate(lab, rate=3, seed=2); tl = lab[ti]
+    elif case == 'connected':
+        X, lab = blobs(1800, 8, 4, 23, 0.9)          # overlapping blobs: one component, no cut without a halo
+        W = orc.knn(X, 8)
+        ti = orc.trainsets_generate(lab, rate=3, seed=2); tl = lab[ti]
     else:
         raise SystemExit('unknown case')
     factory = (lambda plan, k: gdist.HipOps(plan, k, 0)) if use_hip else (lambda plan, k: ScipyOps(plan, k))
@@ -118,7 +122,7 @@ def main():
     # partition bookkeeping invariants
     P = gdist.poisson_problem(W, ti, tl)['P']
     order = gdist.locality_order(P)
-    bounds = gdist.cut_bounds(P, order, world) if partition == 'cut' else gdist.block_bounds(P.shape[0], world)
+    order, bounds, _ = gdist.plan_partition(P, order, world, partition)
     plan = gdist.RankPlan(P, order, bounds, rank)
     counts = [None] * world
     dist.all_gather_object(counts, (plan.send_counts, plan.recv_counts, plan.n_own, plan.n_halo))

@@ -94,6 +94,53 @@ def test_distributed_sweep_graph_following_partition(case, world, tmp_path):
     assert len({r['global_halo'] for r in res}) == 1            # every rank derives the same global halo size
 
 
+@pytest.mark.parametrize('case,world', [('twomoons', 2), ('blobs', 3), ('connected', 2), ('connected', 3)])
+def test_distributed_sweep_cell_partition(case, world, tmp_path):
+    """partition='cells' (dist.quotient_partition: the segments of the locality order dealt to the ranks by a balanced partition of
+    their quotient graph -- ownership is NOT contiguous in the order any more) and the `connected` workload (overlapping blobs: one
+    component, every rank imports a real halo): iterates and T bit-identical to the single-process oracle
+    (reference ssl.py:631-677)."""
+    res = _run(case, world, tmp_path, partition='cells')
+    for r in res:
+        assert r['T'] == r['T_ref'] and r['equal'], r          # bit-identical to the single-rank reference iterates
+        assert r['ok_counts'] and r['sorted_perm']
+    if case == 'connected':
+        assert all(r['global_halo'] > 0 and r['n_halo'] > 0 for r in res)
+        even = _run(case, world, tmp_path, partition='even')
+        assert all(r['T'] == r['T_ref'] and r['equal'] for r in even)
+
+
+def test_quotient_partition_balances_what_contiguous_cuts_cannot():
+    """Five equal clusters over four ranks: contiguous cuts between clusters leave one rank with two clusters (imbalance 1.6);
+    the quotient partition may split a cluster into cells and deal them out -- a better balance at the price of a halo --, returns
+    a valid (order, bounds) pair, and its estimate never loses against equal blocks."""
+    from conftest import blobs
+    from oracle import gl_oracle as orc
+    from graphlearning_amd import dist as gdist
+    X, lab = blobs(2500, 6, 5, 33, 6.0)
+    W = orc.knn(X, 8)
+    ti = orc.trainsets_generate(lab, rate=3, seed=2)
+    P = gdist.poisson_problem(W, ti, lab[ti])['P']
+    order = gdist.locality_order(P)
+    n = P.shape[0]
+    for world in (2, 3, 4, 8):
+        o2, b2, info = gdist.quotient_partition(P, order, world)
+        assert np.array_equal(np.sort(o2), np.arange(n)) and b2[0] == 0 and b2[-1] == n and np.all(np.diff(b2) > 0) and len(b2) == world + 1
+        c_q = gdist.partition_cost(P, o2, b2)
+        c_e = gdist.partition_cost(P, order, gdist.block_bounds(n, world))
+        c_c = gdist.partition_cost(P, order, gdist.cut_bounds(P, order, world))
+        assert c_q['est_us'] <= c_e['est_us'] + 1e-9, (world, c_q['est_us'], c_e['est_us'])
+        assert c_q['entries'].sum() == P.nnz and c_q['rows'].sum() == n
+        o3, b3, pinfo = gdist.plan_partition(P, order, world, 'auto')
+        assert pinfo['partition'] in ('cut', 'cells') and pinfo['est_us'] <= min(c_q['est_us'], c_c['est_us']) + 1e-9
+        # the plans of all ranks agree on who sends what
+        plans = [gdist.RankPlan(P, o2, b2, r) for r in range(world)]
+        for a in range(world):
+            for b in range(world):
+                assert plans[a].send_counts[b] == plans[b].recv_counts[a]
+        assert sum(p.n_own for p in plans) == n
+
+
 def test_cut_bounds_follow_the_pieces():
     """Five disconnected random pieces of unequal size, 2/3/4 ranks: zero crossings, every block within
     the allowed imbalance; a graph without structure keeps equal blocks."""
