@@ -64,6 +64,8 @@ _SIGNATURES = {
     'glx_host_alloc': [C.c_size_t, C.POINTER(_vp)],
     'glx_host_free': [_vp],
     'glx_graph_create': [C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)],
+    'glx_graph_create_resident': [C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)],
+    'glx_graph_set_row_transform': [_vp, _vp, C.c_int],
     'glx_graph_destroy': [_vp],
     'glx_graph_keep_order': [_vp],
     'glx_graph_info': [_vp, _i64p],
@@ -279,6 +281,31 @@ def pinned_empty(shape, dtype):
     return _pinned.empty(shape, dtype)
 
 
+def pinned_reserve(specs):
+    """Make sure the pool holds an idle block for every (shape, dtype) of `specs`, allocating the missing ones on a helper thread
+    (page-locking 19 MB of fresh memory takes 3.4 ms: weightmatrix.knn starts it beside its search, whose result arrays these
+    are).  Returns the thread to join, or None when nothing had to be allocated (the steady state)."""
+    need = []
+    for shape, dtype in specs:
+        nbytes = max(int(np.prod(shape)) * np.dtype(dtype).itemsize, 1)
+        if nbytes >= (1 << 16) and not _pinned.idle.get(nbytes) and _pinned.total + nbytes <= _pinned.budget:
+            need.append(nbytes)
+    if not need:
+        return None
+    lib = load()
+
+    def work():
+        for nbytes in need:
+            p = _vp()
+            if lib.glx_host_alloc(nbytes, C.byref(p)) == 0:
+                _pinned.total += nbytes
+                _pinned.idle.setdefault(nbytes, []).append(p.value)
+    import threading
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    return th
+
+
 class DeviceGraph:
     """A sparse operator resident in HBM (glx_graph).  `A` is any scipy sparse matrix;
     the CSR entry order is preserved (see include/glx.h)."""
@@ -297,6 +324,10 @@ class DeviceGraph:
         lib = load()
         check(lib.glx_graph_create(self.shape[0], self.shape[1], self.nnz, _ptr(rowptr), _ptr(col), _ptr(val),
                                    _dt(self.dtype), device, C.byref(self._h)), 'glx_graph_create')
+        self._set_order(order, keep_order)
+
+    def _set_order(self, order, keep_order):
+        lib = load()
         if order is not None:       # the caller's locality order (perm[new] = old) instead of the library's pass over the graph
             perm = np.ascontiguousarray(order, dtype=np.int32)
             if perm.shape != (self.shape[0],):
@@ -304,6 +335,30 @@ class DeviceGraph:
             check(lib.glx_graph_set_order(self._h, _ptr(perm)), 'glx_graph_set_order')
         elif keep_order:
             check(lib.glx_graph_keep_order(self._h), 'glx_graph_keep_order')
+
+    @classmethod
+    def resident(cls, A, dtype=np.float64, device=None, keep_order=False, order=None, want_row_sums=False):
+        """The operator of CSR matrix `A` with the arrays kept on the device only (glx_graph_create_resident); with
+        want_row_sums also `A * ones` (scipy's csr_matvec order) computed there: returns (graph, row_sums or None).
+        `set_row_transform` then turns the rows into what the operator really is (P = D^-1 W^T: reversed rows times 1 / degree)."""
+        self = cls.__new__(cls)
+        self.dtype = np.dtype(dtype)
+        self.shape = A.shape
+        self.nnz = int(A.nnz)
+        self.device = device = _dev(device)
+        rowptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        col = np.ascontiguousarray(A.indices, dtype=np.int32)
+        val = np.ascontiguousarray(A.data, dtype=np.float64)
+        sums = np.empty(self.shape[0], dtype=np.float64) if want_row_sums else None
+        self._h = _vp()
+        check(load().glx_graph_create_resident(self.shape[0], self.shape[1], self.nnz, _ptr(rowptr), _ptr(col), _ptr(val),
+                                               _dt(self.dtype), device, _ptr(sums), C.byref(self._h)), 'glx_graph_create_resident')
+        self._set_order(order, keep_order)
+        return self, sums
+
+    def set_row_transform(self, row_scale=None, reverse_rows=False):
+        sc = None if row_scale is None else _dense(row_scale, np.float64, (self.shape[0],), 'row_scale')
+        check(load().glx_graph_set_row_transform(self._h, _ptr(sc), 1 if reverse_rows else 0), 'glx_graph_set_row_transform')
 
     def info(self):
         out = (C.c_int64 * 8)()
@@ -889,7 +944,7 @@ class KnnResult:
         return ind, dist
 
     def order(self):
-        perm = np.empty(self.n, dtype=np.int32)
+        perm = pinned_empty((self.n,), np.int32)         # (a device-to-host copy into fresh pageable memory takes milliseconds the first time)
         if load().glx_knn_result_order(self._h, _ptr(perm)) != 0:
             return None
         return perm

@@ -452,9 +452,13 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
   GLX_HIP(hipGetLastError());
   hipLaunchKernelGGL(count_reverse_kernel, dim3(ge), dim3(256), 0, st, (const int64_t*)b.ind, n, kk, k, b.rcnt, b.flag);
   GLX_HIP(hipGetLastError());
-  std::vector<int> rcnt(n);
+  // the per-row counts the host scans land in the work set's page-locked staging area: [n] reverse counts | [n] kept entries
+  int* stage = nullptr;
+  GLX_POOL(glx_work_stage(b.work, (size_t)n * 8 + 64, (void**)&stage));
+  int* rcnt = stage;
+  int* rowcnt = stage + n;
   int flags[2] = {0, 0};
-  GLX_HIP(hipMemcpyAsync(rcnt.data(), b.rcnt, n * 4, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipMemcpyAsync(rcnt, b.rcnt, n * 4, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipMemcpyAsync(flags, b.flag, 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
   GLX_CHECK(!flags[0], GLX_EINVAL, "glx_knn_to_csr: neighbour index out of range");
@@ -493,8 +497,7 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
     }
   }
   GLX_HIP(hipGetLastError());
-  std::vector<int> rowcnt(n);
-  GLX_HIP(hipMemcpyAsync(rowcnt.data(), b.rowcnt, n * 4, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipMemcpyAsync(rowcnt, b.rowcnt, n * 4, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipMemcpyAsync(flags, b.flag, 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
   // hub vertices: a workgroup each, sorted in a global scratch (merge_hub_kernel)
@@ -532,18 +535,6 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
   const int64_t nnz = rp[n];
   GLX_CHECK(nnz < (1ll << 31), GLX_EUNSUPPORTED, "glx_knn_to_csr: nnz %lld does not fit the int32 CSR of the reference", (long long)nnz);
   GLX_HIP(hipMemcpyAsync(b.rowptr, rp.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
-  GLX_POOL(glx_pool_alloc((void**)&b.col, std::max<size_t>(nnz * 4, 4)));
-  GLX_POOL(glx_pool_alloc((void**)&b.val, std::max<size_t>(nnz * 8, 8)));
-  hipLaunchKernelGGL(compact_rows_kernel, dim3(gr), dim3(256), 0, st, (const int*)b.rowcnt, (const int64_t*)b.roff, n, k, sym, (const int64_t*)b.rowptr,
-                     (const int*)b.tcol, (const double*)b.tval, b.col, b.val);
-  GLX_HIP(hipGetLastError());
-  if (nh) {
-    hipLaunchKernelGGL(merge_hub_kernel, dim3((unsigned)nh), dim3(1024), 0, st, (const int64_t*)b.ind, (const double*)b.w, kk, k,
-                       (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 1,
-                       (const int64_t*)b.hub_row, (const int64_t*)b.hub_off, b.skey, b.sval, b.hub_cnt, (const int64_t*)b.rowptr,
-                       b.col, b.val);
-    GLX_HIP(hipGetLastError());
-  }
   const bool own = cap < 0;
   GLX_CHECK(own || nnz <= cap, GLX_EINVAL, "glx_knn_to_csr_into: %lld entries, room for %lld", (long long)nnz, (long long)cap);
   int32_t* h_rp = own ? (int32_t*)malloc((n + 1) * 4) : *rowptr_out;
@@ -554,11 +545,38 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
     glx_set_error("glx_knn_to_csr: host allocation failed");
     return GLX_ENOMEM;
   }
+  // Page-locked destinations (the arrays _hip hands in) are written by the compaction kernels themselves through their device
+  // view: no device copy of the result, no copy-engine transfer behind it (whose first use after fresh allocations cost 8 ms).
+  void *v_col = nullptr, *v_val = nullptr;
+  const bool direct = !own && nnz > 0 && hipHostGetDevicePointer(&v_col, h_col, 0) == hipSuccess && v_col &&
+                      hipHostGetDevicePointer(&v_val, h_val, 0) == hipSuccess && v_val;
+  (void)hipGetLastError();
+  int32_t* out_col = (int32_t*)v_col;
+  double* out_val = (double*)v_val;
+  if (!direct) {
+    GLX_POOL(glx_pool_alloc((void**)&b.col, std::max<size_t>(nnz * 4, 4)));
+    GLX_POOL(glx_pool_alloc((void**)&b.val, std::max<size_t>(nnz * 8, 8)));
+    out_col = b.col;
+    out_val = b.val;
+  }
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(gr), dim3(256), 0, st, (const int*)b.rowcnt, (const int64_t*)b.roff, n, k, sym, (const int64_t*)b.rowptr,
+                     (const int*)b.tcol, (const double*)b.tval, out_col, out_val);
+  hipError_t e0 = hipGetLastError();
+  if (e0 == hipSuccess && nh) {
+    hipLaunchKernelGGL(merge_hub_kernel, dim3((unsigned)nh), dim3(1024), 0, st, (const int64_t*)b.ind, (const double*)b.w, kk, k,
+                       (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 1,
+                       (const int64_t*)b.hub_row, (const int64_t*)b.hub_off, b.skey, b.sval, b.hub_cnt, (const int64_t*)b.rowptr,
+                       out_col, out_val);
+    e0 = hipGetLastError();
+  }
   for (int64_t i = 0; i <= n; ++i) h_rp[i] = (int32_t)rp[i];
-  hipError_t e1 = hipMemcpyAsync(h_col, b.col, nnz * 4, hipMemcpyDeviceToHost, st);
-  hipError_t e2 = hipMemcpyAsync(h_val, b.val, nnz * 8, hipMemcpyDeviceToHost, st);
+  hipError_t e1 = hipSuccess, e2 = hipSuccess;
+  if (!direct) {
+    e1 = hipMemcpyAsync(h_col, b.col, nnz * 4, hipMemcpyDeviceToHost, st);
+    e2 = hipMemcpyAsync(h_val, b.val, nnz * 8, hipMemcpyDeviceToHost, st);
+  }
   hipError_t e3 = hipStreamSynchronize(st);
-  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+  if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
     if (own) { free(h_rp); free(h_col); free(h_val); }
     glx_set_error("glx_knn_to_csr: download failed");
     return GLX_EHIP;
@@ -657,9 +675,12 @@ extern "C" int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, 
     hipLaunchKernelGGL(check_cols_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, (const int64_t*)d_rsrc64, nr, n_cols, b.flag);
   }
   GLX_HIP(hipGetLastError());
-  std::vector<int> rcnt(m);
+  int* stage = nullptr;
+  GLX_POOL(glx_work_stage(b.work, (size_t)m * 8 + 64, (void**)&stage));
+  int* rcnt = stage;
+  int* rowcnt = stage + m;
   int flags[2] = {0, 0};
-  GLX_HIP(hipMemcpyAsync(rcnt.data(), b.rcnt, m * 4, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipMemcpyAsync(rcnt, b.rcnt, m * 4, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipMemcpyAsync(flags, b.flag, 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
   GLX_CHECK(!flags[0], GLX_EINVAL, "glx_knn_rows_to_csr: index out of range (a neighbour id, or a reverse entry outside the block)");
@@ -700,8 +721,7 @@ extern "C" int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, 
     }
   }
   GLX_HIP(hipGetLastError());
-  std::vector<int> rowcnt(m);
-  GLX_HIP(hipMemcpyAsync(rowcnt.data(), b.rowcnt, m * 4, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipMemcpyAsync(rowcnt, b.rowcnt, m * 4, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipMemcpyAsync(flags, b.flag, 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
   int64_t nh = 0;

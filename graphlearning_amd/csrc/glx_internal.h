@@ -86,6 +86,14 @@ struct glx_graph {
   std::vector<int32_t> h_perm, h_inv;
   int32_t* d_perm = nullptr;
   int32_t* d_inv = nullptr;
+  // resident source (glx_graph_create_resident): the CSR arrays live on the DEVICE -- the host keeps the row pointers only (h_col /
+  // h_val stay empty unless something asks for the pattern) -- and the operator's row i is row i of the source, optionally with
+  // its entries in reverse order and scaled by row_scale[i] (glx_graph_set_row_transform: P = D^-1 W^T of a symmetric W)
+  int32_t* d_src_rowptr = nullptr;
+  int32_t* d_src_col = nullptr;
+  double* d_src_val = nullptr;
+  double* d_row_scale = nullptr;
+  bool reverse_rows = false;
   void* cg_ws = nullptr;   // work buffers of the conjugate-gradient solves on this operator (cg.hip), reused between calls
   std::mutex solve_mu;     // one solve at a time per operator: the work buffers, their stream and the plans are shared (ctypes
                            // releases the GIL, so two Python threads can reach the same operator)
@@ -102,7 +110,8 @@ struct glx_knn_result {
   int k = 0, device = 0;
   int64_t* ind = nullptr;
   double* dist = nullptr;
-  std::vector<int32_t> order;
+  std::vector<int32_t> order;       // the cell order worked out on the host (cell-pruned search) ...
+  int32_t* order_dev = nullptr;     // ... or left on the device (rows reordered by the cellrank kernels): a pooled block of n entries
 };
 
 // a non-blocking stream and four events, handed out from a per-device list of idle sets and returned to it (graph.hip):
@@ -113,9 +122,15 @@ struct glx_work {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_side = nullptr;
   int device = 0;
+  void* stage = nullptr;          // page-locked host staging area of the set (glx_work_stage), kept with it
+  size_t stage_bytes = 0;
 };
 int glx_work_acquire(int device, glx_work** out);
 void glx_work_release(glx_work* w);
+// `bytes` of page-locked host memory that stays with the work set (grown on demand, contents not preserved across a growth): where
+// device-to-host copies of counters and lists land that the host then reads.  A copy into FRESH pageable memory makes the runtime
+// pin the destination on the fly -- 8 ms for a 280 KB std::vector the first time a graph of a new size is built.
+int glx_work_stage(glx_work* w, size_t bytes, void** out);
 
 int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed = false);
 int glx_graph_ensure_order(glx_graph* g);

@@ -80,9 +80,24 @@ void work_destroy(glx_work* w) {
   if (w->ev_side) hipEventDestroy(w->ev_side);
   if (w->side) hipStreamDestroy(w->side);
   if (w->stream) hipStreamDestroy(w->stream);
+  if (w->stage) hipHostFree(w->stage);
   delete w;
 }
 }  // namespace
+
+int glx_work_stage(glx_work* w, size_t bytes, void** out) {
+  if (bytes > w->stage_bytes) {
+    size_t want = (size_t)1 << 16;
+    while (want < bytes) want <<= 1;
+    if (w->stage) hipHostFree(w->stage);
+    w->stage = nullptr;
+    w->stage_bytes = 0;
+    GLX_HIP(hipHostMalloc(&w->stage, want, hipHostMallocDefault));
+    w->stage_bytes = want;
+  }
+  *out = w->stage;
+  return GLX_OK;
+}
 
 int glx_work_acquire(int device, glx_work** out) {
   WorkCache& wc = work_cache();
@@ -105,6 +120,33 @@ int glx_work_acquire(int device, glx_work** out) {
     glx_set_error("glx_work_acquire: %s", hipGetErrorString(e));
     work_destroy(w);
     return GLX_EHIP;
+  }
+  // The FIRST work set of a device starts the copy engines: the runtime creates a copy queue the first time an engine is picked
+  // (7.7 ms each, measured with rocprofv3 --hip-trace: the first host-to-device copy, the first device-to-host copy, and one more
+  // device-to-host copy when a second engine is drawn), which otherwise lands in the middle of the first graph builds.  Two
+  // transfers per direction in flight at once, through page-locked memory, draw them now -- next to the 150 ms of runtime start-up.
+  {
+    static std::mutex mu;
+    static std::vector<int> warmed;
+    std::lock_guard<std::mutex> lk(mu);
+    if (std::find(warmed.begin(), warmed.end(), device) == warmed.end()) {
+      warmed.push_back(device);
+      const size_t half = (size_t)1 << 20;
+      void *d = nullptr, *h = nullptr;
+      if (hipMalloc(&d, 4 * half) == hipSuccess && hipHostMalloc(&h, 4 * half, hipHostMallocDefault) == hipSuccess) {
+        for (int rep = 0; rep < 2; ++rep) {
+          hipMemcpyAsync((char*)h, (char*)d, half, hipMemcpyDeviceToHost, w->stream);
+          hipMemcpyAsync((char*)h + half, (char*)d + half, half, hipMemcpyDeviceToHost, w->side);
+          hipMemcpyAsync((char*)d + 2 * half, (char*)h + 2 * half, half, hipMemcpyHostToDevice, w->stream);
+          hipMemcpyAsync((char*)d + 3 * half, (char*)h + 3 * half, half, hipMemcpyHostToDevice, w->side);
+        }
+        hipStreamSynchronize(w->stream);
+        hipStreamSynchronize(w->side);
+      }
+      if (h) hipHostFree(h);
+      if (d) hipFree(d);
+      (void)hipGetLastError();
+    }
   }
   *out = w;
   return GLX_OK;
@@ -369,6 +411,117 @@ extern "C" int glx_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, con
   return GLX_OK;
 }
 
+// The same operator object from CSR arrays that stay on the DEVICE: nothing but the row pointers is kept on the host, plans are
+// filled straight from the resident arrays.  rowsum_out (may be NULL): the row sums `A * ones` as scipy's csr_matvec forms them
+// (sequentially, in stored order) -- the degree vector of reference graph.py:108-122 -- computed on the device.  What a fresh
+// ssl.poisson fit does with weightmatrix.knn's matrix (1.3 ms of host passes and two copies of the 14 MB operator otherwise).
+__global__ __launch_bounds__(256) void csr_check_rowsum_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                               const double* __restrict__ val, int64_t n_rows, int64_t n_cols,
+                                                               double* __restrict__ rowsum, int* __restrict__ bad) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows) return;
+  double s = 0.0;
+  int b = 0;
+  for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+    const int32_t c = col[e];
+    if (c < 0 || c >= n_cols) b = 1;
+    s = s + val[e] * 1.0;
+  }
+  if (rowsum) rowsum[i] = s;
+  if (b) *bad = 1;
+}
+
+extern "C" int glx_graph_create_resident(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                                         const double* val, int state_dtype, int device, double* rowsum_out, glx_graph** out) {
+  GLX_CHECK(out != nullptr, GLX_EINVAL, "glx_graph_create_resident: null output");
+  *out = nullptr;
+  GLX_CHECK(n_rows >= 0 && n_cols >= 0 && nnz >= 0, GLX_EINVAL, "glx_graph_create_resident: negative size");
+  GLX_CHECK(n_rows < (1ll << 31) && n_cols < (1ll << 31), GLX_EINVAL, "glx_graph_create_resident: n must fit int32");
+  GLX_CHECK(rowptr && (nnz == 0 || (col && val)), GLX_EINVAL, "glx_graph_create_resident: null CSR array");
+  GLX_CHECK(state_dtype == GLX_F32 || state_dtype == GLX_F64, GLX_EINVAL, "glx_graph_create_resident: bad dtype %d", state_dtype);
+  GLX_CHECK(rowptr[0] == 0 && rowptr[n_rows] == nnz, GLX_EINVAL, "glx_graph_create_resident: rowptr[0]=%d rowptr[n]=%d nnz=%lld",
+            rowptr[0], rowptr[n_rows], (long long)nnz);
+  int ndev = 0;
+  GLX_HIP(hipGetDeviceCount(&ndev));
+  GLX_CHECK(device >= 0 && device < ndev, GLX_EINVAL, "glx_graph_create_resident: device %d of %d", device, ndev);
+  int max_row = 0;
+  for (int64_t i = 0; i < n_rows; ++i) {
+    const int len = rowptr[i + 1] - rowptr[i];
+    GLX_CHECK(len >= 0, GLX_EINVAL, "glx_graph_create_resident: rowptr not monotone at row %lld", (long long)i);
+    max_row = std::max(max_row, len);
+  }
+  GLX_HIP(hipSetDevice(device));
+  glx_graph* g = new glx_graph();
+  g->n_rows = n_rows;
+  g->n_cols = n_cols;
+  g->nnz = nnz;
+  g->dtype = state_dtype;
+  g->device = device;
+  g->max_row = max_row;
+  g->h_rowptr.assign(rowptr, rowptr + n_rows + 1);
+  g->plans.reserve(8);
+  struct Guard { glx_graph* g; ~Guard() { if (g) glx_graph_destroy(g); } } guard{g};
+  glx_work* w = nullptr;
+  int rc = glx_work_acquire(device, &w);
+  if (rc) return rc;
+  struct WorkGuard { glx_work* w; ~WorkGuard() { hipStreamSynchronize(w->stream); glx_work_release(w); } } wguard{w};
+  hipStream_t st = w->stream;
+  GLX_HIP(hipMalloc(&g->d_src_rowptr, (size_t)(n_rows + 1) * 4));
+  GLX_HIP(hipMalloc(&g->d_src_col, std::max<size_t>((size_t)nnz * 4, 4)));
+  GLX_HIP(hipMalloc(&g->d_src_val, std::max<size_t>((size_t)nnz * 8, 8)));
+  GLX_HIP(hipMemcpyAsync(g->d_src_rowptr, rowptr, (size_t)(n_rows + 1) * 4, hipMemcpyHostToDevice, st));
+  if (nnz > 0) {
+    GLX_HIP(hipMemcpyAsync(g->d_src_col, col, (size_t)nnz * 4, hipMemcpyHostToDevice, st));
+    GLX_HIP(hipMemcpyAsync(g->d_src_val, val, (size_t)nnz * 8, hipMemcpyHostToDevice, st));
+  }
+  // column range check (+ the row sums) on the device; results through the work set's page-locked staging area
+  char* stage = nullptr;
+  rc = glx_work_stage(w, (size_t)n_rows * 8 + 64, (void**)&stage);
+  if (rc) return rc;
+  double* d_sum = nullptr;
+  int* d_bad = nullptr;
+  struct Tmp { void *a = nullptr, *b = nullptr; ~Tmp() { glx_pool_free(a); glx_pool_free(b); } } tmp;
+  rc = glx_pool_alloc(&tmp.a, std::max<size_t>((size_t)n_rows * 8, 8));
+  if (!rc) rc = glx_pool_alloc(&tmp.b, 64);
+  if (rc) return rc;
+  d_sum = (double*)tmp.a;
+  d_bad = (int*)tmp.b;
+  GLX_HIP(hipMemsetAsync(d_bad, 0, 4, st));
+  if (n_rows > 0) {
+    hipLaunchKernelGGL(csr_check_rowsum_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, (const int32_t*)g->d_src_rowptr,
+                       (const int32_t*)g->d_src_col, (const double*)g->d_src_val, n_rows, n_cols, rowsum_out ? d_sum : nullptr, d_bad);
+    GLX_HIP(hipGetLastError());
+  }
+  int* h_bad = (int*)(stage + (size_t)n_rows * 8);
+  GLX_HIP(hipMemcpyAsync(h_bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+  if (rowsum_out && n_rows > 0) GLX_HIP(hipMemcpyAsync(stage, d_sum, (size_t)n_rows * 8, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipStreamSynchronize(st));
+  GLX_CHECK(*h_bad == 0, GLX_EINVAL, "glx_graph_create_resident: column index out of range");
+  if (rowsum_out && n_rows > 0) memcpy(rowsum_out, stage, (size_t)n_rows * 8);
+  guard.g = nullptr;
+  *out = g;
+  return GLX_OK;
+}
+
+// Row i of the operator = row i of the resident source with its entries in reverse order (reverse_rows != 0) and multiplied by
+// row_scale[i] (NULL: as they are).  Before the operator is first used.  reverse + D^-1: P = D^-1 W^T of a symmetric W exactly as
+// scipy writes it down (`D * W.transpose()`: csr_matmat emits every row in reverse, reference ssl.py:634-635).
+extern "C" int glx_graph_set_row_transform(glx_graph* g, const double* row_scale, int reverse_rows) {
+  GLX_CHECK(g, GLX_EINVAL, "glx_graph_set_row_transform: null graph");
+  GLX_CHECK(g->d_src_col != nullptr, GLX_EINVAL, "glx_graph_set_row_transform: not a resident graph (glx_graph_create_resident)");
+  GLX_CHECK(g->plans.empty(), GLX_EINVAL, "glx_graph_set_row_transform: call before the operator is first used");
+  GLX_HIP(hipSetDevice(g->device));
+  g->reverse_rows = reverse_rows != 0;
+  hipFree(g->d_row_scale);
+  g->d_row_scale = nullptr;
+  if (row_scale && g->n_rows > 0) {
+    GLX_HIP(hipMalloc(&g->d_row_scale, (size_t)g->n_rows * 8));
+    GLX_HIP(hipMemcpy(g->d_row_scale, row_scale, (size_t)g->n_rows * 8, hipMemcpyHostToDevice));
+  }
+  return GLX_OK;
+}
+
 static void free_plan(SellPlan& p) {
   hipFree(p.d_slot_row);
   hipFree(p.d_slot_len);
@@ -385,6 +538,10 @@ extern "C" int glx_graph_destroy(glx_graph* g) {
   if (g->cg_ws) glx_cg_ws_destroy(g->cg_ws);
   hipFree(g->d_perm);
   hipFree(g->d_inv);
+  hipFree(g->d_src_rowptr);
+  hipFree(g->d_src_col);
+  hipFree(g->d_src_val);
+  hipFree(g->d_row_scale);
   delete g;
   return GLX_OK;
 }
@@ -410,7 +567,7 @@ extern "C" int glx_graph_info(const glx_graph* g, int64_t info[8]) {
 static void rcm_order_arrays(int64_t n, const int32_t* h_rowptr, const int32_t* h_col, std::vector<int32_t>& perm, bool sort_children);
 
 static void rcm_order(const glx_graph* g, std::vector<int32_t>& perm, bool sort_children = true) {
-  rcm_order_arrays(g->n_rows, g->h_rowptr.data(), g->h_col.data(), perm, sort_children);
+  rcm_order_arrays(g->n_rows, g->h_rowptr.data(), g->h_col.data(), perm, sort_children);   // (resident sources: glx_graph_ensure_order fetched the pattern)
 }
 
 static void rcm_order_arrays(int64_t n, const int32_t* h_rowptr, const int32_t* h_col, std::vector<int32_t>& perm, bool sort_children) {
@@ -492,6 +649,11 @@ int glx_graph_ensure_order(glx_graph* g) {
   g->order_ready = true;
   const int64_t n = g->n_rows;
   if (g->keep_order || g->n_rows != g->n_cols || n < 4096) return GLX_OK;
+  if (g->d_src_col && g->h_col.empty() && g->nnz > 0) {      // a resident source: the pass below reads the pattern on the host
+    g->h_col.resize(g->nnz);
+    GLX_HIP(hipSetDevice(g->device));
+    GLX_HIP(hipMemcpy(g->h_col.data(), g->d_src_col, (size_t)g->nnz * 4, hipMemcpyDeviceToHost));
+  }
   const auto t_rcm0 = std::chrono::steady_clock::now();
   rcm_order(g, g->h_perm, true);
   if (getenv("GLX_TIMING")) fprintf(stderr, "[glx] locality order of %lld vertices: %.1f ms\n", (long long)n,
@@ -642,7 +804,11 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(const int32_t* __restric
                                                         const double* __restrict__ cval, const int32_t* __restrict__ perm,
                                                         const int32_t* __restrict__ inv, const int32_t* __restrict__ slot_row,
                                                         const int32_t* __restrict__ slot_len, const SliceHdr* __restrict__ hdr,
-                                                        int64_t nslices, int64_t head, int G, int32_t* __restrict__ col, T* __restrict__ val) {
+                                                        int64_t nslices, int64_t head, int G, int32_t* __restrict__ col, T* __restrict__ val,
+                                                        const double* __restrict__ row_scale, int reverse) {
+#pragma clang fp contract(off)
+  // row_scale / reverse (resident sources, glx_graph_set_row_transform): entry jj of the operator's row is entry len - 1 - jj of
+  // the source row, times row_scale[row] -- one rounding, the host expression `scale[i] * w` of the reference's D^-1 W^T
   const int lane = threadIdx.x & 63;
   const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= nslices) return;
@@ -652,15 +818,19 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(const int32_t* __restric
   const int32_t row = slot_row[s * R + slot];
   const int len = slot_len[s * R + slot];
   const int seg = slot & (S - 1);
-  const int64_t b = row >= 0 ? rowptr[perm ? perm[row] : row] : 0;
+  const int32_t orow = row >= 0 ? (perm ? perm[row] : row) : 0;
+  const int64_t b = row >= 0 ? rowptr[orow] : 0;
+  const double sc = (row >= 0 && row_scale) ? row_scale[orow] : 1.0;
   for (int k = 0; k < h.nchunks || k == 0; ++k) {          // chunk 0 always exists (the dense head region)
     const int jj = G == 4 ? (k * S + seg) * 4 + t : k * G + t;
     int32_t c = 0;
     double v = 0.0;
     if (row >= 0 && jj < len) {
-      c = ccol[b + jj];
+      const int64_t src = reverse ? b + (len - 1 - jj) : b + jj;
+      c = ccol[src];
       if (inv) c = inv[c];
-      v = cval[b + jj];
+      v = cval[src];
+      if (row_scale) v = sc * v;
     }
     const int64_t idx = k == 0 ? s * 64 + lane : head + h.ptr + (int64_t)(k - 1) * 64 + lane;
     col[idx] = c;
@@ -841,29 +1011,34 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
   GLX_HIP(hipMemcpy(p.d_slot_len, slot_len.data(), slot_len.size() * 4, hipMemcpyHostToDevice));
   GLX_HIP(hipMemcpy(p.d_slice_hdr, hdr.data(), hdr.size() * sizeof(SliceHdr), hipMemcpyHostToDevice));
   if (nslices > 0) {
-    // the CSR arrays as they are (work buffers from the pool, released after the fill)
-    int32_t *d_rp = nullptr, *d_cc = nullptr;
-    double* d_cv = nullptr;
+    // the CSR arrays as they are: resident on the device already (glx_graph_create_resident), or uploaded into work buffers from
+    // the pool that are released after the fill
+    int32_t *d_rp = g->d_src_rowptr, *d_cc = g->d_src_col;
+    double* d_cv = g->d_src_val;
     struct Tmp { void *a = nullptr, *b = nullptr, *c = nullptr; ~Tmp() { glx_pool_free(a); glx_pool_free(b); glx_pool_free(c); } } tmp;
-    int rc2 = glx_pool_alloc(&tmp.a, (size_t)(n + 1) * 4);
-    if (!rc2) rc2 = glx_pool_alloc(&tmp.b, std::max<size_t>((size_t)g->nnz * 4, 4));
-    if (!rc2) rc2 = glx_pool_alloc(&tmp.c, std::max<size_t>((size_t)g->nnz * 8, 8));
-    if (rc2) return rc2;
-    d_rp = (int32_t*)tmp.a; d_cc = (int32_t*)tmp.b; d_cv = (double*)tmp.c;
-    GLX_HIP(hipMemcpy(d_rp, g->h_rowptr.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
-    if (g->nnz > 0) {
-      GLX_HIP(hipMemcpy(d_cc, g->h_col.data(), (size_t)g->nnz * 4, hipMemcpyHostToDevice));
-      GLX_HIP(hipMemcpy(d_cv, g->h_val.data(), (size_t)g->nnz * 8, hipMemcpyHostToDevice));
+    if (!d_cc) {
+      int rc2 = glx_pool_alloc(&tmp.a, (size_t)(n + 1) * 4);
+      if (!rc2) rc2 = glx_pool_alloc(&tmp.b, std::max<size_t>((size_t)g->nnz * 4, 4));
+      if (!rc2) rc2 = glx_pool_alloc(&tmp.c, std::max<size_t>((size_t)g->nnz * 8, 8));
+      if (rc2) return rc2;
+      d_rp = (int32_t*)tmp.a; d_cc = (int32_t*)tmp.b; d_cv = (double*)tmp.c;
+      GLX_HIP(hipMemcpy(d_rp, g->h_rowptr.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+      if (g->nnz > 0) {
+        GLX_HIP(hipMemcpy(d_cc, g->h_col.data(), (size_t)g->nnz * 4, hipMemcpyHostToDevice));
+        GLX_HIP(hipMemcpy(d_cv, g->h_val.data(), (size_t)g->nnz * 8, hipMemcpyHostToDevice));
+      }
     }
     const unsigned grid = (unsigned)((nslices + 3) / 4);
     if (g->dtype == GLX_F64)
       hipLaunchKernelGGL(sell_fill_kernel<double>, dim3(grid), dim3(256), 0, 0, (const int32_t*)d_rp, (const int32_t*)d_cc, (const double*)d_cv,
                          (const int32_t*)(renum ? g->d_perm : nullptr), (const int32_t*)(renum ? g->d_inv : nullptr), (const int32_t*)p.d_slot_row,
-                         (const int32_t*)p.d_slot_len, (const SliceHdr*)p.d_slice_hdr, nslices, head, G, p.d_col, (double*)p.d_val);
+                         (const int32_t*)p.d_slot_len, (const SliceHdr*)p.d_slice_hdr, nslices, head, G, p.d_col, (double*)p.d_val,
+                         (const double*)g->d_row_scale, g->reverse_rows ? 1 : 0);
     else
       hipLaunchKernelGGL(sell_fill_kernel<float>, dim3(grid), dim3(256), 0, 0, (const int32_t*)d_rp, (const int32_t*)d_cc, (const double*)d_cv,
                          (const int32_t*)(renum ? g->d_perm : nullptr), (const int32_t*)(renum ? g->d_inv : nullptr), (const int32_t*)p.d_slot_row,
-                         (const int32_t*)p.d_slot_len, (const SliceHdr*)p.d_slice_hdr, nslices, head, G, p.d_col, (float*)p.d_val);
+                         (const int32_t*)p.d_slot_len, (const SliceHdr*)p.d_slice_hdr, nslices, head, G, p.d_col, (float*)p.d_val,
+                         (const double*)g->d_row_scale, g->reverse_rows ? 1 : 0);
     GLX_HIP(hipGetLastError());
     GLX_HIP(hipDeviceSynchronize());          // the pooled CSR copies go back before anybody else may draw them
   }

@@ -372,9 +372,10 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   if (dist_out) GLX_HIP(hipMemcpyAsync(dist_out, b.dist, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
   stamp("results on the host");
-  if (perm_pending) {
-    capture->order.resize(n);
-    GLX_HIP(hipMemcpy(capture->order.data(), b.orig, (size_t)n * 4, hipMemcpyDeviceToHost));
+  if (perm_pending) {    // the permutation stays on the device with the result (glx_knn_result_order copies it into the caller's --
+    glx_pool_free(capture->order_dev);      // page-locked -- array: a synchronous copy into fresh pageable memory cost 8 ms here)
+    capture->order_dev = b.orig;
+    b.orig = nullptr;
   }
   if (capture) {         // the lists stay on the device with the caller's result object (everything that writes them has finished)
     glx_pool_free(capture->ind);
@@ -410,7 +411,7 @@ static int knn_run(const double* X, int64_t n, int d, int k, int64_t q0, int64_t
   if (rc != KNN_ESCALATE) return rc;
   const double flagged = g_knn_stats[2];
   g_knn_stats[10] = g_knn_stats[11] = g_knn_stats[12] = 0.0;
-  if (capture) capture->order.clear();
+  if (capture) { capture->order.clear(); glx_pool_free(capture->order_dev); capture->order_dev = nullptr; }
   rc = knn_pass(X, n, d, k, q0, q1, ind_out, dist_out, device, true, capture);     // (long lists: the fp32-input kernel, all refs)
   g_knn_stats[8] = flagged;            // rows the first (short-list) pass could not accept
   return rc;
@@ -465,7 +466,11 @@ extern "C" int glx_knn_search(const double* X, int64_t n, int d, int k, int ncel
   *out = nullptr;
   GLX_CHECK(ncells >= -4096 && ncells <= 4096, GLX_EINVAL, "glx_knn_search: ncells=%d outside [-4096, 4096]", ncells);
   glx_knn_result* res = new glx_knn_result();
+  const auto t_call = std::chrono::steady_clock::now();
   const int rc = knn_run(X, n, d, k, 0, n, nullptr, nullptr, device, res, nullptr, 0, (ncells > 1 || ncells < -1) ? ncells : 0);
+  if (getenv("GLX_TIMING"))
+    fprintf(stderr, "[glx] knn: search returns after %.2f ms (work buffers released)\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
   if (rc || !res->ind) {
     glx_knn_result_destroy(res);
     if (!rc) glx_set_error("glx_knn_search: the search left no lists behind");
@@ -484,8 +489,36 @@ extern "C" int glx_knn_result_lists(const glx_knn_result* res, int64_t* ind_out,
   return GLX_OK;
 }
 
+__global__ __launch_bounds__(256) void knn_copy_i32_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 extern "C" int glx_knn_result_order(const glx_knn_result* res, int32_t* perm_out) {
   GLX_CHECK(res && perm_out, GLX_EINVAL, "glx_knn_result_order: null argument");
+  if (res->order_dev) {
+    GLX_HIP(hipSetDevice(res->device));
+    // Page-locked destinations (what _hip.KnnResult.order passes) are written by a kernel: the first copy-engine transfer after the
+    // search's allocations took 8 ms (measured: hipMemcpy and hipMemcpyAsync alike, 0.02 ms on every later call), a kernel's
+    // stores into mapped host memory 0.03 ms.
+    glx_work* w = nullptr;
+    int rcw = glx_work_acquire(res->device, &w);
+    if (rcw) return rcw;
+    void* dev_view = nullptr;
+    hipError_t e;
+    if (hipHostGetDevicePointer(&dev_view, perm_out, 0) == hipSuccess && dev_view) {
+      hipLaunchKernelGGL(knn_copy_i32_kernel, dim3((unsigned)((res->n + 255) / 256)), dim3(256), 0, w->stream, (const int32_t*)res->order_dev,
+                         (int32_t*)dev_view, res->n);
+      e = hipGetLastError();
+    } else {
+      (void)hipGetLastError();
+      e = hipMemcpyAsync(perm_out, res->order_dev, (size_t)res->n * 4, hipMemcpyDeviceToHost, w->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+    glx_work_release(w);
+    GLX_HIP(e);
+    return GLX_OK;
+  }
   GLX_CHECK((int64_t)res->order.size() == res->n && res->n > 0, GLX_EINVAL, "glx_knn_result_order: this search worked out no cell order");
   memcpy(perm_out, res->order.data(), (size_t)res->n * 4);
   return GLX_OK;
@@ -495,6 +528,7 @@ extern "C" int glx_knn_result_destroy(glx_knn_result* res) {
   if (!res) return GLX_OK;
   glx_pool_free(res->ind);
   glx_pool_free(res->dist);
+  glx_pool_free(res->order_dev);
   delete res;
   return GLX_OK;
 }

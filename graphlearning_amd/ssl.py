@@ -396,7 +396,20 @@ class poisson(ssl):
             order = _free_order(self.graph.weight_matrix, n)
             dev = _hip.DeviceGraph(L, dtype=self._dtype(), device=self.device, keep_order=order is None, order=order)
         elif fast:
-            P, deg, dinv = _poisson_operator_symmetric(W)
+            order = getattr(W, '_glx_order', None) if (self._dtype() == np.float64 or n < (1 << 17)) else None
+            if order is not None and len(order) != n:
+                order = None
+            plain = (W.indptr.dtype == np.int32 and W.indices.dtype == np.int32 and W.data.dtype == np.float64)
+            if plain:
+                # W goes up as it is (its arrays are page-locked when weightmatrix.knn made them) and stays on the device; degrees
+                # there; P = D^-1 W^T is formed while the sliced-ELL image is filled (reversed rows times 1 / degree, the entries
+                # scipy's `D * W.transpose()` writes down: _poisson_operator_symmetric is the host form of the same arrays)
+                dev, deg = _hip.DeviceGraph.resident(W, dtype=self._dtype(), device=self.device, order=order, want_row_sums=True)
+                dinv = deg ** (-1)
+                dev.set_row_transform(dinv, reverse_rows=True)
+            else:
+                P, deg, dinv = _poisson_operator_symmetric(W)
+                dev = None
             aux['D'] = sparse.spdiags(dinv, 0, n, n).tocsr()
             aux['dinv'] = dinv
             aux['zero_degree'] = bool(np.any(~np.isfinite(aux['dinv'])))
@@ -405,10 +418,8 @@ class poisson(ssl):
             # the cell order of the search that built W, if it was a clustered one: for the fp64 sweep as good as the library's own
             # pass over the graph (251 vs 250 us at 10^6 vertices; 12.45 vs 12.59 us at 70 000) and free (0.13 s / 3.7 ms); the fp32
             # sweep at 10^6 vertices is 4 % faster on the library's order (201 vs 209 us), so that mode keeps paying for it there
-            order = getattr(W, '_glx_order', None) if (self._dtype() == np.float64 or n < (1 << 17)) else None
-            if order is not None and len(order) != n:
-                order = None
-            dev = _hip.DeviceGraph(P, dtype=self._dtype(), device=self.device, order=order)
+            if dev is None:
+                dev = _hip.DeviceGraph(P, dtype=self._dtype(), device=self.device, order=order)
         else:
             D = G.degree_matrix(p=-1)
             P = D * W.transpose()

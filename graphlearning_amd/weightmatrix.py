@@ -50,7 +50,15 @@ def knn(data, k, kernel='gaussian', eta=None, symmetrize=True, metric='raw', sim
         elif type(data) is str:
             knn_ind, knn_dist = load_knn_data(data, metric=metric)
         else:
-            res = _hip.KnnResult(data, int(k), similarity=similarity, device=device, want_order=True)
+            # (the result arrays of the assembly are page-locked beside the search when the pool has none of their size yet)
+            n_rows = int(np.shape(data)[0])
+            cap = n_rows * int(k) * (2 if sym else 1)
+            reserve = _hip.pinned_reserve([((n_rows + 1,), np.int32), ((cap,), np.int32), ((cap,), np.float64)]) if cap * 12 <= _hip._PINNED_CSR_MAX else None
+            try:
+                res = _hip.KnnResult(data, int(k), similarity=similarity, device=device, want_order=True)
+            finally:
+                if reserve is not None:
+                    reserve.join()
             order = res.order()
             knn_ind, knn_dist = (res.lists() if (host_exp or eta is not None) else (None, None))
         if res is not None:

@@ -88,6 +88,15 @@ int glx_host_free(void* p);
 int glx_graph_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr,
                      const int32_t* col, const double* val, int state_dtype, int device,
                      glx_graph** out);
+/* The same operator from CSR arrays that are kept on the DEVICE (the host keeps the row pointers only; a fresh ssl.poisson fit on
+ * weightmatrix.knn's matrix: no host copy of the 14 MB operator, reference ssl.py:615-617, 634-635).  rowsum_out (n_rows fp64, may be
+ * NULL): `A * ones` as scipy's csr_matvec forms it -- the degree vector of graph.py:108-122 -- computed on the device.
+ * glx_graph_set_row_transform (before the first use): row i of the OPERATOR is row i of these arrays with its entries in reverse
+ * order (reverse_rows != 0) and multiplied by row_scale[i] (NULL: unscaled): with row_scale = 1/degree and reverse_rows = 1 the
+ * operator is P = D^-1 W^T of a symmetric W entry for entry as scipy's `D * W.transpose()` writes it. */
+int glx_graph_create_resident(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                              const double* val, int state_dtype, int device, double* rowsum_out, glx_graph** out);
+int glx_graph_set_row_transform(glx_graph* g, const double* row_scale, int reverse_rows);
 int glx_graph_destroy(glx_graph* g);
 /* Square operators are renumbered internally for cache locality (reverse Cuthill-McKee; dense
  * operands passed as HOST arrays are translated on the way in and out, results do not change).

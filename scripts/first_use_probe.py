@@ -76,3 +76,14 @@ if len(sys.argv) > 1 and sys.argv[1] == 'phases':
         pred = m.fit_predict(ti, labels[ti])
         tot = (time.perf_counter() - t) * 1e3
         print('fresh fit_predict %.2f ms: ' % tot + ' | '.join('%s %.2f' % kv for kv in acc.items()) + ' | other %.2f' % (tot - sum(v for k, v in acc.items() if k != 'known_symmetric' or True)), flush=True)
+    # where the rest of a fresh fit_predict goes (cProfile, cumulative)
+    import cProfile, pstats, io
+    Wf = gl.weightmatrix.knn(X, 10)
+    pr = cProfile.Profile()
+    pr.enable()
+    m = gl.ssl.poisson(Wf, solver='gradient_descent')
+    pred = m.fit_predict(ti, labels[ti])
+    pr.disable()
+    out = io.StringIO()
+    pstats.Stats(pr, stream=out).sort_stats('cumulative').print_stats(45)
+    print(out.getvalue()[:9000])
