@@ -15,6 +15,10 @@
 // All reductions are deterministic: per-workgroup partial sums combined in a fixed order (no float atomics), see CgDev.
 #include "cg_internal.h"
 #include <string.h>
+#include <atomic>
+#include <limits>
+#include <thread>
+#include <stdlib.h>
 #include <math.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -262,7 +266,12 @@ int glx_cg_unpack_scaled(int dtype, const void* rec, void* dense, int64_t n, con
 }
 
 // ---- the solve ---------------------------------------------------------------------------------------------------------------
-static const int CG_LONG = 8, CG_SHORT = 2;     // iterations per captured chunk
+// Iterations per captured chunk.  Every hand-over from one launched graph to the next costs ~37 us of idle device (kernel trace:
+// profiles/r04_cg_tree_chunks.txt) whether or not the next one was enqueued in time, an iteration past convergence ~9 us (its two
+// kernels exit at once): long chunks while the end is far, short ones near it.
+static const int CG_NLEN = 3;
+static const int CG_LEN[CG_NLEN] = {32, 16, 4};
+static const int CG_LONG = 32;                 // (the longest: sizes the history buffers)
 
 int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double tol, int64_t max_iter, int* iters_out, double* err_out,
                      int flags, const int32_t* mask_rows, const int32_t* mask_ptr, const CgRhsRows& rr) {
@@ -317,7 +326,20 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
   CG_NEED(b.f_tick, (size_t)(ngrp + 1) * 4);
   CG_NEED(b.f_it, 64);
   if (nmask) CG_NEED(b.f_rowmask, (size_t)n * 4);
-  { int rc_ = b.need_host(&b.h_err, (size_t)2 * (CG_LONG + 1) * stride * 8); if (rc_) return rc_; }
+  {
+    // the host's mirror of the residual history: the maximum slot of every row a solve may write holds NaN = "not yet written"
+    const bool fresh = !b.h_hist || b.h_hist_rows < hist_cap * stride;
+    int rc_ = b.need_host(&b.h_hist, (size_t)hist_cap * stride * 8);
+    if (rc_) return rc_;
+    const double not_yet = std::numeric_limits<double>::quiet_NaN();
+    if (fresh) {
+      b.h_hist_rows = hist_cap * stride;
+      for (int64_t j = 0; j < hist_cap; ++j) b.h_hist[(size_t)j * stride + ngroups] = not_yet;
+    } else {
+      for (int64_t j = 0; j <= std::min<int64_t>(b.h_hist_dirty, hist_cap - 1); ++j) b.h_hist[(size_t)j * stride + ngroups] = not_yet;
+    }
+    b.h_hist_dirty = 0;
+  }
 
   // one upload: [right-hand side rows | Dirichlet rows | their systems | values | output scale]
   const size_t o_rows = 0, o_mrows = o_rows + (size_t)rr.nb * 4, o_mgrp = o_mrows + (size_t)nmask * 4;
@@ -386,6 +408,11 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
   cd.ngrp = (int)ngrp;
   cd.part2 = b.f_part2;
   cd.nb2 = nb2;
+  {
+    void* view = nullptr;
+    GLX_HIP(hipHostGetDevicePointer(&view, b.h_hist, 0));
+    cd.host_hist = (double*)view;
+  }
   if (dtype == GLX_F32)
     hipLaunchKernelGGL(cg_fused_init_kernel<float>, dim3((unsigned)nb2), dim3(256), 0, st, (float*)b.x, (const float*)b.r, (float*)b.p, n, L.ld,
                        L.nvec, cd, rpb, keep_x ? 1 : 0);
@@ -424,16 +451,15 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
                                          (unsigned long long)(uintptr_t)b.f_part1, (unsigned long long)(uintptr_t)b.f_part1g,
                                          (unsigned long long)grp, (unsigned long long)(uintptr_t)b.f_part2,
                                          (unsigned long long)(uintptr_t)b.f_tick, (unsigned long long)(uintptr_t)b.f_it,
-                                         (unsigned long long)(uintptr_t)a.rowmask, (unsigned long long)C, (unsigned long long)Cg,
+                                         (unsigned long long)(uintptr_t)a.rowmask, (unsigned long long)(uintptr_t)cd.host_hist, (unsigned long long)C, (unsigned long long)Cg,
                                          (unsigned long long)max_iter, (unsigned long long)n, (unsigned long long)dtype, 0ull};
   memcpy(&key.back(), &tol, 8);
   if (!b.f_exec[0] || b.f_key != key) {
-    const int lens[2] = {CG_LONG, CG_SHORT};
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < CG_NLEN; ++v) {
       if (b.f_exec[v]) { hipGraphExecDestroy(b.f_exec[v]); b.f_exec[v] = nullptr; }
       hipGraph_t graph;
       GLX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      rc = enqueue_chunk(lens[v]);
+      rc = enqueue_chunk(CG_LEN[v]);
       hipError_t e = hipStreamEndCapture(st, &graph);
       if (rc) return rc;
       GLX_HIP(e);
@@ -463,21 +489,18 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
     }
   };
   // The GPU never waits for the host: the next chunk is launched before the history of the previous one is looked at (kernels of
-  // iterations past convergence exit at once, ~3 us each).  To keep that waste small the chunks get short once the residuals the host
-  // has seen say the end is near (CG's error falls roughly geometrically: the last ratio predicts the iterations still needed).
+  // iterations past convergence exit at once).  The first chunk has 16 iterations and the one launched blind behind it 4; from then
+  // on the residuals the host has seen choose -- CG's error falls roughly geometrically, the last ratio predicts the iterations still
+  // needed, and the longest chunk that does not overshoot them by more than two is launched.
   struct Flight { int slot; int64_t it0; int cnt; };
   Flight fl[2];
   int nfl = 0, slot = 0;
   int64_t launched = 0, looked = 0;
   auto launch_chunk = [&](int v) -> int {
-    const int len = v == 0 ? CG_LONG : CG_SHORT;
+    const int len = CG_LEN[v];
     GLX_HIP(hipGraphLaunch(b.f_exec[v], st));
-    // the history leaves on a second stream: a copy in `st` would sit between this chunk and the next (19 us measured)
-    GLX_HIP(hipEventRecord(b.f_ev[2], st));
-    GLX_HIP(hipStreamWaitEvent(b.side, b.f_ev[2], 0));
-    GLX_HIP(hipMemcpyAsync(b.h_err + (size_t)slot * (CG_LONG + 1) * stride, b.err_hist + (size_t)(launched + 1) * stride,
-                           (size_t)len * stride * 8, hipMemcpyDeviceToHost, b.side));
-    GLX_HIP(hipEventRecord(b.f_ev[slot], b.side));
+    // (nothing else goes into the stream between two chunks: the closing kernels write the history into the host's page-locked
+    // mirror themselves -- an event record + copy here cost a ~37 us bubble per chunk, profiles/r04_cg_tree_chunks.txt)
     fl[nfl].slot = slot;
     fl[nfl].it0 = launched;
     fl[nfl].cnt = len;
@@ -487,27 +510,49 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
     return GLX_OK;
   };
   auto next_kind = [&]() -> int {
-    if (looked < 4 || !(e_last > tol) || !(e_last < e_prev)) return 0;
+    if (looked < 4) return CG_NLEN - 1;                           // nothing seen yet: the short chunk behind the first one
+    if (!(e_last > tol) || !(e_last < e_prev)) return 1;
     const double rate = e_last / e_prev;
     const double need = log(tol / e_last) / log(rate);           // iterations still needed after `looked`
-    return (need - (double)(launched - looked) < (double)CG_LONG + 2.0) ? 1 : 0;
+    const double open = need - (double)(launched - looked);      // ... of which not yet launched
+    for (int v = 0; v < CG_NLEN - 1; ++v)
+      if ((double)CG_LEN[v] <= open + 2.0) return v;
+    return CG_NLEN - 1;
   };
   if (running > 0 && max_iter > 0) {
-    rc = launch_chunk(0);
+    rc = launch_chunk(1);
     if (rc) return rc;
     while (running > 0 && looked < max_iter) {
       if (launched < max_iter && nfl < 2) {
         rc = launch_chunk(next_kind());
         if (rc) return rc;
       }
-      GLX_HIP(hipEventSynchronize(b.f_ev[fl[0].slot]));
       const int64_t cnt = std::min<int64_t>(fl[0].cnt, max_iter - fl[0].it0);
-      read_history(b.h_err + (size_t)fl[0].slot * (CG_LONG + 1) * stride, fl[0].it0, cnt);
+      for (int64_t q = 0; q < cnt && running > 0; ++q) {
+        // row it0+q+1 is written by the kernels of the chunk in flight: iteration it0+q+1 runs because the row before said so
+        const volatile double* slot_max = b.h_hist + (size_t)(fl[0].it0 + q + 1) * stride + ngroups;
+        int spins = 0;
+        bool idle_seen = false;
+        while (*slot_max != *slot_max) {
+          if (++spins < 64) continue;
+          spins = 0;
+          std::this_thread::yield();
+          const hipError_t qe = hipStreamQuery(st);
+          if (qe == hipSuccess) {                    // everything launched has finished: the row must be there by now
+            if (idle_seen) { glx_set_error("glx_cg: residual history row %lld was never written", (long long)(fl[0].it0 + q + 1)); return GLX_EHIP; }
+            idle_seen = true;
+          } else if (qe != hipErrorNotReady) {
+            GLX_HIP(qe);
+          }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        read_history((const double*)b.h_hist + (size_t)(fl[0].it0 + q + 1) * stride, fl[0].it0 + q, 1);
+      }
       looked = fl[0].it0 + fl[0].cnt;
       fl[0] = fl[1];
       --nfl;
     }
-    GLX_HIP(hipStreamSynchronize(b.side));   // a chunk launched ahead may still be copying into h_err
+    b.h_hist_dirty = launched + 1;
   }
   if (rr.out_scale) {
     rc = glx_cg_unpack_scaled(dtype, b.x, b.dense, n, L, A->d_perm, (const double*)(b.f_stage + o_scale), st);

@@ -32,7 +32,9 @@ struct CgBufs {
   unsigned *f_tick = nullptr, *f_rowmask = nullptr;
   int* f_it = nullptr;
   char *f_stage = nullptr, *h_stage = nullptr;          // one upload per solve: rows, Dirichlet rows, values, output scale
-  hipGraphExec_t f_exec[2] = {nullptr, nullptr};        // a long and a short chunk of iterations
+  double* h_hist = nullptr;                              // page-locked mirror of err_hist, written by the closing kernels, polled by the host
+  int64_t h_hist_rows = 0, h_hist_dirty = 0;             // rows allocated / rows a solve may have written (reset to 'not yet' before the next)
+  hipGraphExec_t f_exec[3] = {nullptr, nullptr, nullptr};        // captured chunks of 32, 16 and 4 iterations
   std::vector<unsigned long long> f_key;
   hipEvent_t f_ev[3] = {nullptr, nullptr, nullptr};
   hipStream_t stream = nullptr, side = nullptr;
@@ -70,7 +72,8 @@ struct CgBufs {
     hipFree(f_part1); hipFree(f_part1g); hipFree(f_part2); hipFree(f_tick); hipFree(f_rowmask); hipFree(f_it);
     hipFree(f_stage);
     if (h_stage) hipHostFree(h_stage);
-    for (int q = 0; q < 2; ++q) if (f_exec[q]) hipGraphExecDestroy(f_exec[q]);
+    if (h_hist) hipHostFree(h_hist);
+    for (int q = 0; q < 3; ++q) if (f_exec[q]) hipGraphExecDestroy(f_exec[q]);
     for (int q = 0; q < 3; ++q) if (f_ev[q]) hipEventDestroy(f_ev[q]);
     if (side) hipStreamDestroy(side);
     if (h_err) hipHostFree(h_err);

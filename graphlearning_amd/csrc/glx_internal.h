@@ -245,6 +245,9 @@ __device__ __forceinline__ void glx_cg_close_iteration(const CgDev& cg, int it, 
     double mine = 0.0;
     const int g = threadIdx.x;
     double* row = cg.err_hist + (size_t)j * cg.stride;
+    // the host's copy of the row (page-locked, mapped): per-system values first, the row's maximum LAST -- the host polls that slot
+    // (it holds NaN until then; the maximum itself is never NaN) and needs no event or copy in the solve's stream
+    double* hrow = cg.host_hist ? cg.host_hist + (size_t)j * cg.stride : nullptr;
     if (g < cg.ngroups) {
       if (ran[g] > tol) {
         const double* v = cg.rsold + (size_t)g * cg.Cg;
@@ -265,6 +268,7 @@ __device__ __forceinline__ void glx_cg_close_iteration(const CgDev& cg, int it, 
         mine = sqrt(e);
       }
       row[g] = mine;        // 0 = stopped: every row of the history is written in full, so nothing needs clearing between solves
+      if (hrow) __hip_atomic_store((unsigned long long*)&hrow[g], (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     s_tmp[threadIdx.x] = mine;
     __syncthreads();
@@ -273,6 +277,10 @@ __device__ __forceinline__ void glx_cg_close_iteration(const CgDev& cg, int it, 
       for (int q = 0; q < cg.ngroups && q < 256; ++q)
         if (s_tmp[q] > m) m = s_tmp[q];
       row[cg.ngroups] = m;
+      if (hrow) {
+        __threadfence_system();        // (the per-system values above were stored before the barrier in front of this block)
+        __hip_atomic_store((unsigned long long*)&hrow[cg.ngroups], (unsigned long long)__double_as_longlong(m), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
   if (threadIdx.x == 0) {
