@@ -58,3 +58,28 @@ def blobs(n, d, C, seed, scale, labels=None):
         labels = rng.integers(0, C, size=n)
     X = centers[labels] + rng.normal(size=(n, d))
     return X, labels.astype(np.int64)
+
+
+def free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def run_ranks(cmd, retries=3, **kw):
+    """subprocess.run for a `python -m torch.distributed.run ... --master-port P ...` job: the port was free when it was picked,
+    but another process may take it before the rendezvous binds it -- on EADDRINUSE the job is started again on a new port."""
+    import subprocess
+    r = None
+    for _ in range(retries):
+        r = subprocess.run(cmd, **kw)
+        text = (r.stderr or '') + (r.stdout or '') if kw.get('capture_output') or kw.get('stderr') is not None else ''
+        if r.returncode != 0 and '--master-port' in cmd and ('EADDRINUSE' in text or 'address already in use' in text.lower()):
+            cmd = list(cmd)
+            cmd[cmd.index('--master-port') + 1] = str(free_port())
+            continue
+        return r
+    return r

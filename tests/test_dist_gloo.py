@@ -8,7 +8,7 @@ import sys
 import socket
 import numpy as np
 import pytest
-from conftest import ROOT, csr_from
+from conftest import ROOT, csr_from, run_ranks
 
 
 def _free_port():
@@ -25,7 +25,7 @@ def _run(case, world, tmp_path, partition='even'):
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
            os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out, 'scipy', partition]
     env = dict(os.environ, OMP_NUM_THREADS='1')
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return [json.load(open(out + '.%d' % k)) for k in range(world)]
 
@@ -177,7 +177,7 @@ def test_ssl_trials_shared_over_ranks(tmp_path):
     out = str(tmp_path / 'trials')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=3', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'trials_worker.py'), out]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = [json.load(open(out + '.%d' % k)) for k in range(3)]
     assert len(res[0]['rows']) == 12
@@ -197,7 +197,7 @@ def test_sharded_build_matches_oracle(case, world, tmp_path):
     out = str(tmp_path / ('shard_' + case))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'shard_worker.py'), case, out]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = [json.load(open(out + '.%d' % k)) for k in range(world)]
     for q in res:
@@ -214,7 +214,7 @@ def test_sharded_build_with_graph_cuts(case, world, tmp_path):
     out = str(tmp_path / ('shardcut_' + case))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'shard_worker.py'), case, out, 'ops', 'cut']
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = [json.load(open(out + '.%d' % k)) for k in range(world)]
     for q in res:
@@ -239,7 +239,7 @@ def test_sharded_build_with_local_row_order(case, world, partition, tmp_path):
     out = str(tmp_path / ('shardrcm_' + case))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'shard_worker.py'), case, out, 'ops', partition, 'rcm']
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = [json.load(open(out + '.%d' % k)) for k in range(world)]
     for q in res:
@@ -383,7 +383,7 @@ def test_config4_features_are_sharded(world, n, tmp_path):
     out = str(tmp_path / 'feat')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'feat_worker.py'), out, str(n)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS='1'))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for k in range(world):
         q = json.load(open(out + '.%d' % k))
@@ -399,7 +399,7 @@ def test_distributed_cg_laplace_randomwalk(case, world, partition, tmp_path):
     out = str(tmp_path / ('cg_' + case))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'cg_worker.py'), case, out, 'scipy', partition]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = [json.load(open(out + '.%d' % k)) for k in range(world)]
     for q in res:

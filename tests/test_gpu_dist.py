@@ -7,7 +7,7 @@ import subprocess
 import sys
 import numpy as np
 import pytest
-from conftest import ROOT, csr_from
+from conftest import ROOT, csr_from, run_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +63,7 @@ def test_distributed_bench_entry_one_rank(tmp_path, force_coll, engine):
     s.close()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1']
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'capture unavailable' not in r.stderr, r.stderr[-2000:]
     assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1, r.stdout[-1500:]     # ONE JSON line on stdout (RCCL's banner goes to stderr)
@@ -90,7 +90,7 @@ def test_multi_rank_hip_sweeps_over_gloo(case, world, partition, engine, tmp_pat
     out = str(tmp_path / ('res_' + case + '_' + partition))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out, engine, partition]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS='1'), cwd=ROOT)
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS='1'), cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for k in range(world):
         res = json.load(open(out + '.%d' % k))
@@ -365,7 +365,7 @@ def test_sharded_build_multi_rank_hip_over_gloo(case, world, tmp_path):
     out = str(tmp_path / ('shard_gpu_' + case))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'tests', 'shard_worker.py'), case, out, 'glxstep']
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS='1'), cwd=ROOT)
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS='1'), cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for k in range(world):
         q = json.load(open(out + '.%d' % k))
@@ -385,7 +385,7 @@ def test_distributed_cg_multi_rank_hip_over_gloo(case, world, tmp_path):
     out = str(tmp_path / ('cg_gpu_' + case))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'tests', 'cg_worker.py'), case, out, 'hip', 'even']
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for k in range(world):
         q = json.load(open(out + '.%d' % k))
