@@ -294,16 +294,23 @@ def pinned_reserve(specs):
         return None
     lib = load()
 
-    def work():
-        for nbytes in need:
-            p = _vp()
-            if lib.glx_host_alloc(nbytes, C.byref(p)) == 0:
+    def work(nbytes):
+        p = _vp()
+        if lib.glx_host_alloc(nbytes, C.byref(p)) == 0:
+            with lock:
                 _pinned.total += nbytes
                 _pinned.idle.setdefault(nbytes, []).append(p.value)
     import threading
-    th = threading.Thread(target=work, daemon=True)
-    th.start()
-    return th
+    lock = threading.Lock()
+    ths = [threading.Thread(target=work, args=(nb,), daemon=True) for nb in sorted(need, reverse=True)]   # (one per block: page-locking runs in parallel)
+    for th in ths:
+        th.start()
+
+    class _Join:
+        def join(self):
+            for th in ths:
+                th.join()
+    return _Join()
 
 
 class DeviceGraph:

@@ -150,7 +150,9 @@ int glx_sweep_launches(const glx_sweep* s, int64_t* sweep_kernel_launches);
 int glx_sweep_destroy(glx_sweep* s);
 
 /* Heat/MBO inner loop, ssl.py:826-827: u <- P u + Db, `iters` times, u resident on
- * device between calls (glx_sweep created with min_iter = max_iter = 0 has no stop column). */
+ * device between calls (glx_sweep created with min_iter = max_iter = 0 has no stop column).  glx_sweep_iterate ENQUEUES the sweeps and
+ * returns: every call that reads or replaces the state (glx_sweep_project, glx_sweep_fetch, glx_sweep_set_state, another
+ * glx_sweep_iterate) is ordered behind them in the sweep's own stream. */
 int glx_sweep_set_state(glx_sweep* s, const void* u0, const void* Db);
 int glx_sweep_iterate(glx_sweep* s, int iters);
 
