@@ -230,6 +230,11 @@ class ssl:
                 multi = False
             if multi:
                 from . import dist as gdist
+                # (a collective call: every rank of the job must reach it -- said out loud on every rank, because the reference's
+                # num_cores means joblib workers of ONE process and a ported script may call this on rank 0 only)
+                print('ssl_trials(num_cores=%d): sharing the trials over the %d ranks of the torch.distributed job (rank %d); '
+                      'every rank must call ssl_trials -- pass num_cores=1 to run them all here'
+                      % (num_cores, tdist.get_world_size(), tdist.get_rank()), file=sys.stderr, flush=True)
                 gdist.ssl_trials_distributed(self, trainsets, labels, tdist, tag=tag, save_results=save_results, overwrite=overwrite,
                                              num_trials=num_trials)
                 return
