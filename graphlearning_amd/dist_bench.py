@@ -204,7 +204,7 @@ def main(args):
     res = measure_or_fall_back(headline)
     even = measure_or_fall_back('even') if (world > 1 and headline != 'even') else None      # equal blocks: the RCCL exchange in every sweep
     others = {}
-    if world > 1:
+    if world > 1 and headline != 'cut':          # (the default run measures `cut` and `even` only, as in rounds 1-3)
         for alt in ('cut', 'cells'):
             if alt != headline and res['planner'].get('partition') != alt:
                 others[alt] = measure_or_fall_back(alt)
