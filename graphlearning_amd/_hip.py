@@ -232,10 +232,12 @@ class _PinnedPool:
     beyond it arrays come from ordinary memory, and idle blocks are released first when a request would not fit."""
 
     def __init__(self, keep=4):
+        import threading
         self.keep = keep
         self.idle = {}
         self.total = 0                                   # bytes of page-locked memory this pool currently owns
         self.budget = int(float(os.environ.get('GLX_PINNED_MAX_MB', '4096')) * (1 << 20))
+        self.lock = threading.RLock()                    # graphs are built from several Python threads (and by pinned_reserve's helpers)
 
     def _trim(self):
         for nbytes, lst in list(self.idle.items()):
@@ -250,28 +252,35 @@ class _PinnedPool:
         nbytes = max(int(np.prod(shape)) * dtype.itemsize, 1)
         if nbytes < (1 << 16):
             return np.empty(shape, dtype=dtype)
-        lst = self.idle.get(nbytes)
-        if lst:
-            ptr = lst.pop()
-        else:
-            if self.total + nbytes > self.budget:
-                self._trim()
-            if self.total + nbytes > self.budget:
-                return np.empty(shape, dtype=dtype)      # over the budget: ordinary (pageable) memory
+        with self.lock:
+            lst = self.idle.get(nbytes)
+            ptr = lst.pop() if lst else None
+            if ptr is None:
+                if self.total + nbytes > self.budget:
+                    self._trim()
+                if self.total + nbytes > self.budget:
+                    return np.empty(shape, dtype=dtype)      # over the budget: ordinary (pageable) memory
+                self.total += nbytes                          # (reserved before the allocation: the budget holds across threads)
+        if ptr is None:
             p = _vp()
-            check(load().glx_host_alloc(nbytes, C.byref(p)), 'glx_host_alloc')
+            try:
+                check(load().glx_host_alloc(nbytes, C.byref(p)), 'glx_host_alloc')
+            except BaseException:
+                with self.lock:
+                    self.total -= nbytes
+                raise
             ptr = p.value
-            self.total += nbytes
         return np.asarray(_PinnedBlock(self, ptr, nbytes, shape, dtype))
 
     def _release(self, ptr, nbytes):
-        lst = self.idle.setdefault(nbytes, [])
-        if len(lst) < self.keep:
-            lst.append(ptr)
-        else:
+        with self.lock:
+            lst = self.idle.setdefault(nbytes, [])
+            if len(lst) < self.keep:
+                lst.append(ptr)
+                return
             self.total -= nbytes
-            if _lib is not None:
-                _lib.glx_host_free(_vp(ptr))
+        if _lib is not None:
+            _lib.glx_host_free(_vp(ptr))
 
 
 _pinned = _PinnedPool()
@@ -288,20 +297,23 @@ def pinned_reserve(specs):
     need = []
     for shape, dtype in specs:
         nbytes = max(int(np.prod(shape)) * np.dtype(dtype).itemsize, 1)
-        if nbytes >= (1 << 16) and not _pinned.idle.get(nbytes) and _pinned.total + nbytes <= _pinned.budget:
-            need.append(nbytes)
+        with _pinned.lock:
+            if nbytes >= (1 << 16) and not _pinned.idle.get(nbytes) and _pinned.total + nbytes <= _pinned.budget:
+                _pinned.total += nbytes              # reserved now, handed to the idle list by the helper
+                need.append(nbytes)
     if not need:
         return None
     lib = load()
 
     def work(nbytes):
         p = _vp()
-        if lib.glx_host_alloc(nbytes, C.byref(p)) == 0:
-            with lock:
-                _pinned.total += nbytes
+        ok = lib.glx_host_alloc(nbytes, C.byref(p)) == 0
+        with _pinned.lock:
+            if ok:
                 _pinned.idle.setdefault(nbytes, []).append(p.value)
+            else:
+                _pinned.total -= nbytes
     import threading
-    lock = threading.Lock()
     ths = [threading.Thread(target=work, args=(nb,), daemon=True) for nb in sorted(need, reverse=True)]   # (one per block: page-locking runs in parallel)
     for th in ths:
         th.start()

@@ -176,11 +176,12 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
       oc_place = chain_places(oc_cen, m);
       const int nb = (int)((n + 255) / 256);
       GLX_POOL(glx_pool_alloc((void**)&b.place, (size_t)m * 4));
-      GLX_POOL(glx_pool_alloc((void**)&b.bh, (size_t)nb * m * 4));
+      GLX_POOL(glx_pool_alloc((void**)&b.bh, (size_t)(nb + 1) * m * 4));     // (+ one row: the keys' totals / starting positions)
       GLX_HIP(hipMemcpyAsync(b.place, oc_place.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(knn_cellrank_hist_kernel, dim3((unsigned)nb), dim3(256), (size_t)m * 4, st, b.cell_id, (const int*)b.place, n, m, b.bh);
-      hipLaunchKernelGGL(knn_cellrank_scan_kernel, dim3(1), dim3(256), (size_t)m * 4, st, b.bh, nb, m);
-      hipLaunchKernelGGL(knn_cellrank_scatter_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const int*)b.cell_id, n, m, (const int*)b.bh, b.orig);
+      hipLaunchKernelGGL(knn_cellrank_scan_kernel, dim3((unsigned)m), dim3(256), 0, st, b.bh, nb, m);
+      hipLaunchKernelGGL(knn_cellrank_base_kernel, dim3(1), dim3(256), 0, st, b.bh, nb, m);
+      hipLaunchKernelGGL(knn_cellrank_scatter_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const int*)b.cell_id, n, m, (const int*)b.bh, nb, b.orig);
       perm_pending = capture != nullptr;               // the permutation comes back with the results (glx_knn_result_order)
     } else {
       // the pruned search needs the cells' extents on the host: cell ids and centres come back, the rows are counted into chained

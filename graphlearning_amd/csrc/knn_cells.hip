@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void knn_gather_rows_kernel(const double* __re
 // cell[i] = the nearest of m centres (lowest index on ties); centres in batches of 8 through LDS, one walk over a point's
 // features per batch
 // Rows into the order of their cells on the device (stable: ascending caller index inside a cell) -- three small kernels instead of a
-// trip to the host: key = the cell's place in the chain, a histogram per block of 256 rows, one block scanning the (block, key) table,
+// trip to the host: key = the cell's place in the chain, a histogram per block of 256 rows, a scan of the (block, key) table per key,
 // and a scatter that ranks a row among the earlier rows of its block with the same key.  The permutation equals the host's
 // counting sort (finish_order); the search never waits for it.
 __global__ __launch_bounds__(256) void knn_cellrank_hist_kernel(int* __restrict__ cell, const int* __restrict__ place, int64_t n, int m, int* __restrict__ bh) {
@@ -38,30 +38,58 @@ __global__ __launch_bounds__(256) void knn_cellrank_hist_kernel(int* __restrict_
   for (int c = threadIdx.x; c < m; c += 256) bh[(int64_t)blockIdx.x * m + c] = h_[c];
 }
 
+// exclusive prefix sums of 256 values, one per thread (wave scans + the four wave totals through LDS); returns the block's total
+__device__ __forceinline__ int block_excl_scan256(int v, int* s_w, int& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  __syncthreads();                       // (s_w may still be read by the previous call)
+  if (lane == 63) s_w[w] = incl;
+  __syncthreads();
+  int before = 0;
+  for (int q = 0; q < w; ++q) before += s_w[q];
+  total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  return before + incl - v;
+}
+
+// The (block, key) table of the histogram pass -> where every (block, key) group of rows starts inside its key's run: one workgroup
+// per KEY scans that key's column of the table over the blocks (256 at a time) and leaves the key's total in row `nb` of the table;
+// knn_cellrank_base_kernel turns the totals into the keys' starting positions.  (Round 3's form -- ONE workgroup walking every
+// key's column with a dependent load per block -- took 90 us at 70 000 rows: a tenth of the search.)
 __global__ __launch_bounds__(256) void knn_cellrank_scan_kernel(int* __restrict__ bh, int nb, int m) {
-  extern __shared__ int tot_[];
-  for (int c = threadIdx.x; c < m; c += 256) {
-    int run = 0;
-    for (int b = 0; b < nb; ++b) {
-      const int t = bh[(int64_t)b * m + c];
-      bh[(int64_t)b * m + c] = run;
-      run += t;
-    }
-    tot_[c] = run;
+  __shared__ int s_w[4];
+  const int c = blockIdx.x;
+  int carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += 256) {
+    const int b = b0 + (int)threadIdx.x;
+    const int v = b < nb ? bh[(int64_t)b * m + c] : 0;
+    int total;
+    const int ex = block_excl_scan256(v, s_w, total);
+    if (b < nb) bh[(int64_t)b * m + c] = carry + ex;
+    carry += total;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int c = 0; c < m; ++c) { const int t = tot_[c]; tot_[c] = run; run += t; }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < m; c += 256) {
-    const int base = tot_[c];
-    for (int b = 0; b < nb; ++b) bh[(int64_t)b * m + c] += base;
+  if (threadIdx.x == 0) bh[(int64_t)nb * m + c] = carry;
+}
+
+__global__ __launch_bounds__(256) void knn_cellrank_base_kernel(int* __restrict__ bh, int nb, int m) {
+  __shared__ int s_w[4];
+  int* tot = bh + (int64_t)nb * m;         // [m] totals in, starting positions out
+  int carry = 0;
+  for (int c0 = 0; c0 < m; c0 += 256) {
+    const int c = c0 + (int)threadIdx.x;
+    const int v = c < m ? tot[c] : 0;
+    int total;
+    const int ex = block_excl_scan256(v, s_w, total);
+    if (c < m) tot[c] = carry + ex;
+    carry += total;
   }
 }
 
-__global__ __launch_bounds__(256) void knn_cellrank_scatter_kernel(const int* __restrict__ key, int64_t n, int m, const int* __restrict__ bh,
+__global__ __launch_bounds__(256) void knn_cellrank_scatter_kernel(const int* __restrict__ key, int64_t n, int m, const int* __restrict__ bh, int nb,
                                                                    int* __restrict__ perm) {
   __shared__ int k_[256];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -71,7 +99,7 @@ __global__ __launch_bounds__(256) void knn_cellrank_scatter_kernel(const int* __
   if (i < n) {
     int r = 0;
     for (int j = 0; j < (int)threadIdx.x; ++j) r += (k_[j] == kk) ? 1 : 0;
-    perm[bh[(int64_t)blockIdx.x * m + kk] + r] = (int)i;
+    perm[bh[(int64_t)nb * m + kk] + bh[(int64_t)blockIdx.x * m + kk] + r] = (int)i;
   }
 }
 

@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void knn_gather_rows_kernel(const double* __re
                                                               double* __restrict__ out);
 __global__ __launch_bounds__(256) void knn_cellrank_hist_kernel(int* __restrict__ cell, const int* __restrict__ place, int64_t n, int m, int* __restrict__ bh);
 __global__ __launch_bounds__(256) void knn_cellrank_scan_kernel(int* __restrict__ bh, int nb, int m);
-__global__ __launch_bounds__(256) void knn_cellrank_scatter_kernel(const int* __restrict__ key, int64_t n, int m, const int* __restrict__ bh,
+__global__ __launch_bounds__(256) void knn_cellrank_base_kernel(int* __restrict__ bh, int nb, int m);
+__global__ __launch_bounds__(256) void knn_cellrank_scatter_kernel(const int* __restrict__ key, int64_t n, int m, const int* __restrict__ bh, int nb,
                                                                    int* __restrict__ perm);
 __global__ __launch_bounds__(256) void knn_assign_kernel(const double* __restrict__ X, int d, int64_t n, const double* __restrict__ cen, int m,
                                                          int* __restrict__ cell, int fs);
