@@ -346,5 +346,7 @@ int glx_project_device(glx_projector** pp, const void* dense_dev, int dtype, int
                        double* weights_inout, double* err_out, int* steps_out, int max_steps, int similarity, hipStream_t st,
                        const long long** d_labels_out);
 int glx_onehot_device(const long long* d_labels, void* dense_dev, int dtype, int64_t n, int C, hipStream_t st);
+int glx_project_scores(glx_projector** pp, int64_t n, int C, double** scores_out);
+int glx_onehot_records(const long long* d_labels, void* rec, int dtype, int64_t n, const RecLayout& L, const int32_t* perm, hipStream_t st);
 void glx_projector_destroy(glx_projector* p);
 

@@ -3,6 +3,7 @@
 // off and integer class counts, so labels and weights are bit-identical to numpy's.
 #include "glx_internal.h"
 #include <algorithm>
+#include <string.h>
 #include <map>
 #include <mutex>
 
@@ -27,9 +28,10 @@ __device__ __forceinline__ double wave_max_d(double v) {
   return v;
 }
 
-// stage 1: per-block min / max of prob; stage 2 (one block) reduces the block results
+// min / max of prob: per-block partial results, and the block that finishes last reduces them into mm[0..1] (one launch; minimum and
+// maximum with NaN propagation do not depend on the order).  ticket: a zeroed counter, back at zero afterwards.
 __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ a, int64_t total, double* __restrict__ bmin,
-                                                     double* __restrict__ bmax) {
+                                                     double* __restrict__ bmax, unsigned* __restrict__ ticket, double* __restrict__ mm) {
   double mn = __longlong_as_double(0x7ff0000000000000ll), mx = -mn;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const double v = a[i];
@@ -46,8 +48,28 @@ __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ 
       mn = (s_mn[w] < mn || s_mn[w] != s_mn[w]) ? s_mn[w] : mn;
       mx = (s_mx[w] > mx || s_mx[w] != s_mx[w]) ? s_mx[w] : mx;
     }
-    bmin[blockIdx.x] = mn;
-    bmax[blockIdx.x] = mx;
+    glx_agent_store(&bmin[blockIdx.x], mn);
+    glx_agent_store(&bmax[blockIdx.x], mx);
+  }
+  if (!glx_arrive_last(ticket, gridDim.x, s_mn)) return;
+  mn = __longlong_as_double(0x7ff0000000000000ll);
+  mx = -mn;
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) {
+    const double lo = glx_load_part<true>(&bmin[b]), hi = glx_load_part<true>(&bmax[b]);
+    mn = (lo < mn || lo != lo) ? lo : mn;
+    mx = (hi > mx || hi != hi) ? hi : mx;
+  }
+  mn = wave_min_d(mn);
+  mx = wave_max_d(mx);
+  if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      mn = (s_mn[w] < mn || s_mn[w] != s_mn[w]) ? s_mn[w] : mn;
+      mx = (s_mx[w] > mx || s_mx[w] != s_mx[w]) ? s_mx[w] : mx;
+    }
+    mm[0] = mn;
+    mm[1] = mx;
   }
 }
 
@@ -149,38 +171,33 @@ __device__ void proj_update_step(ProjState st, int64_t n, int C, double dt, int 
   if (!(err > 1e-3) || *st.steps >= max_steps) *st.done = 1;
 }
 
-// (one wavefront: minimum / maximum with NaN propagation do not depend on the order; the single-thread loop this replaces took 108 us
-// for 1024 block results, a third of a resident fit_predict's decision step)
-__global__ __launch_bounds__(64) void minmax_final_kernel(const double* bmin, const double* bmax, int nb, double* mm) {
-  double mn = __longlong_as_double(0x7ff0000000000000ll), mx = -mn;
-  for (int b = threadIdx.x; b < nb; b += 64) {
-    const double lo = bmin[b], hi = bmax[b];
-    mn = (lo < mn || lo != lo) ? lo : mn;
-    mx = (hi > mx || hi != hi) ? hi : mx;
-  }
-  mn = wave_min_d(mn);
-  mx = wave_max_d(mx);
-  if (threadIdx.x == 0) {
-    mm[0] = mn;
-    mm[1] = mx;
-  }
-}
-
+// Device state of one decision in ONE block of 8-byte words, so that one upload sets it up and one download reads it back:
+//   [0, C) class weights w | [C] err | [C+1] steps | [C+2] done, hist ticket (2 ints) | [C+3] min/max ticket | [C+4, 2C+4) priors |
+//   [2C+4, 3C+4) class counts | [3C+4, 3C+6) min, max of prob
 struct ProjBufs {
-  double *scores = nullptr, *bmin = nullptr, *bmax = nullptr, *mm = nullptr, *w = nullptr, *priors = nullptr, *err = nullptr;
-  long long *counts = nullptr, *labels = nullptr;
-  int *steps = nullptr, *done = nullptr;
+  double *scores = nullptr, *bmin = nullptr, *bmax = nullptr, *state = nullptr;
+  long long* labels = nullptr;
+  double* h_image = nullptr;      // page-locked: the state's initial image going up / [w | err | steps | done] coming back
   float* stage32 = nullptr;       // float32 input of the one-shot entry point, before widening
   size_t stage_cap = 0;
   hipStream_t stream = nullptr;   // owned only by the one-shot entry point
   int64_t cap_n = 0;
   int cap_C = 0;
+  double* w() const { return state; }
+  double* err() const { return state + cap_C; }
+  int* steps() const { return (int*)(state + cap_C + 1); }
+  int* done() const { return (int*)(state + cap_C + 2); }
+  unsigned* mm_ticket() const { return (unsigned*)(state + cap_C + 3); }
+  double* priors() const { return state + cap_C + 4; }
+  long long* counts() const { return (long long*)(state + 2 * cap_C + 4); }
+  double* mm() const { return state + 3 * cap_C + 4; }
+  size_t image_words() const { return (size_t)3 * cap_C + 4; }
   void release() {
-    hipFree(scores); hipFree(bmin); hipFree(bmax); hipFree(mm); hipFree(w); hipFree(priors); hipFree(err);
-    hipFree(counts); hipFree(labels); hipFree(steps); hipFree(done);
-    scores = bmin = bmax = mm = w = priors = err = nullptr;
-    counts = labels = nullptr;
-    steps = done = nullptr;
+    hipFree(scores); hipFree(bmin); hipFree(bmax); hipFree(state); hipFree(labels);
+    if (h_image) hipHostFree(h_image);
+    scores = bmin = bmax = state = nullptr;
+    labels = nullptr;
+    h_image = nullptr;
     cap_n = 0;
     cap_C = 0;
   }
@@ -194,22 +211,18 @@ struct ProjBufs {
 static int proj_blocks(int64_t total) { return (int)std::min<int64_t>((total + 255) / 256, 1024); }
 
 static int proj_alloc(ProjBufs& b, int64_t n, int C) {
-  if (b.cap_n >= n && b.cap_C >= C && b.scores) return GLX_OK;
+  if (b.cap_n >= n && b.cap_C == C && b.scores) return GLX_OK;      // (the state block's layout depends on C)
+  const int64_t keep_n = std::max<int64_t>(n, b.cap_n);
   b.release();
-  const int64_t total = n * C;
+  const int64_t total = keep_n * C;
   const int nb = proj_blocks(total);
   GLX_HIP(hipMalloc(&b.scores, total * 8));
   GLX_HIP(hipMalloc(&b.bmin, nb * 8));
   GLX_HIP(hipMalloc(&b.bmax, nb * 8));
-  GLX_HIP(hipMalloc(&b.mm, 16));
-  GLX_HIP(hipMalloc(&b.w, C * 8));
-  GLX_HIP(hipMalloc(&b.priors, C * 8));
-  GLX_HIP(hipMalloc(&b.err, 8));
-  GLX_HIP(hipMalloc(&b.counts, C * 8));
-  GLX_HIP(hipMalloc(&b.labels, n * 8));
-  GLX_HIP(hipMalloc(&b.steps, 4));
-  GLX_HIP(hipMalloc(&b.done, 8));      // [0] done, [1] the ticket counter of argmax_hist_kernel's last-block step
-  b.cap_n = n;
+  GLX_HIP(hipMalloc(&b.state, ((size_t)3 * C + 6) * 8));
+  GLX_HIP(hipMalloc(&b.labels, keep_n * 8));
+  GLX_HIP(hipHostMalloc(&b.h_image, ((size_t)3 * C + 6) * 8, hipHostMallocDefault));
+  b.cap_n = keep_n;
   b.cap_C = C;
   return GLX_OK;
 }
@@ -221,32 +234,31 @@ static int proj_core(ProjBufs& b, hipStream_t st, int64_t n, int C, const double
   const int64_t total = n * C;
   const int nb = proj_blocks(total);
   const int nbr = (int)std::min<int64_t>((n + 255) / 256, 2048);
-  GLX_HIP(hipMemcpyAsync(b.w, weights_inout, C * 8, hipMemcpyHostToDevice, st));
-  if (priors) GLX_HIP(hipMemcpyAsync(b.priors, priors, C * 8, hipMemcpyHostToDevice, st));
-  GLX_HIP(hipMemsetAsync(b.counts, 0, C * 8, st));
-  GLX_HIP(hipMemsetAsync(b.steps, 0, 4, st));
-  GLX_HIP(hipMemsetAsync(b.done, 0, 8, st));
-  GLX_HIP(hipMemsetAsync(b.err, 0, 8, st));
-  hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, st, (const double*)b.scores, total, b.bmin, b.bmax);
-  GLX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, st, (const double*)b.bmin, (const double*)b.bmax, nb, b.mm);
+  // one upload sets the whole state: weights, priors, zeroed err / steps / done / tickets / class counts
+  memset(b.h_image, 0, b.image_words() * 8);
+  memcpy(b.h_image, weights_inout, (size_t)C * 8);
+  if (priors) memcpy(b.h_image + C + 4, priors, (size_t)C * 8);
+  GLX_HIP(hipMemcpyAsync(b.state, b.h_image, b.image_words() * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, st, (const double*)b.scores, total, b.bmin, b.bmax, b.mm_ticket(), b.mm());
   GLX_HIP(hipGetLastError());
   if (f32)
-    hipLaunchKernelGGL(scores_kernel<true>, dim3(nb), dim3(256), 0, st, b.scores, total, (const double*)b.mm);
+    hipLaunchKernelGGL(scores_kernel<true>, dim3(nb), dim3(256), 0, st, b.scores, total, (const double*)b.mm());
   else
-    hipLaunchKernelGGL(scores_kernel<false>, dim3(nb), dim3(256), 0, st, b.scores, total, (const double*)b.mm);
+    hipLaunchKernelGGL(scores_kernel<false>, dim3(nb), dim3(256), 0, st, b.scores, total, (const double*)b.mm());
   GLX_HIP(hipGetLastError());
   ProjState ps;
-  ps.w = b.w;
-  ps.priors = b.priors;
-  ps.counts = b.counts;
-  ps.err = b.err;
-  ps.steps = b.steps;
-  ps.done = b.done;
+  ps.w = b.w();
+  ps.priors = b.priors();
+  ps.counts = b.counts();
+  ps.err = b.err();
+  ps.steps = b.steps();
+  ps.done = b.done();
   const double dt = similarity ? -0.1 : 0.1;   // ssl.py:195-197
   const size_t shm = (size_t)C * 8;
   int steps = 0;
   double err = 1.0;   // ssl.py:201
+  // what comes back lands in the page-locked image (behind the words that went up: the upload has long finished by then)
+  double* h_back = b.h_image;
   if (max_steps > 0) {
     int done = 0;
     // steps per host look: 2, 4, 8 ... PROJ_CHUNK.  Most decisions need one or two steps (class sizes that already match the
@@ -258,18 +270,22 @@ static int proj_core(ProjBufs& b, hipStream_t st, int64_t n, int C, const double
         hipLaunchKernelGGL(argmax_hist_kernel, dim3(nbr), dim3(256), shm, st, (const double*)b.scores, n, C, ps, b.labels, similarity, 1, 2, dt, max_steps);
         GLX_HIP(hipGetLastError());
       }
-      GLX_HIP(hipMemcpyAsync(&done, b.done, 4, hipMemcpyDeviceToHost, st));
+      GLX_HIP(hipMemcpyAsync(h_back + C + 2, b.done(), 4, hipMemcpyDeviceToHost, st));
       GLX_HIP(hipStreamSynchronize(st));
+      done = *(const int*)(h_back + C + 2);
       chunk = std::min(PROJ_CHUNK, chunk * 2);
     }
-    GLX_HIP(hipMemcpyAsync(&steps, b.steps, 4, hipMemcpyDeviceToHost, st));
-    GLX_HIP(hipMemcpyAsync(&err, b.err, 8, hipMemcpyDeviceToHost, st));
   }
   // final predict with the (updated) weights                                 (ssl.py:209)
   hipLaunchKernelGGL(argmax_hist_kernel, dim3(nbr), dim3(256), shm, st, (const double*)b.scores, n, C, ps, b.labels, similarity, 0, 0, dt, max_steps);
   GLX_HIP(hipGetLastError());
-  GLX_HIP(hipMemcpyAsync(weights_inout, b.w, C * 8, hipMemcpyDeviceToHost, st));
+  GLX_HIP(hipMemcpyAsync(h_back, b.state, (size_t)(C + 2) * 8, hipMemcpyDeviceToHost, st));      // [w | err | steps]
   GLX_HIP(hipStreamSynchronize(st));
+  memcpy(weights_inout, h_back, (size_t)C * 8);
+  if (max_steps > 0) {
+    err = h_back[C];
+    steps = *(const int*)(h_back + C + 1);
+  }
   if (err_out) *err_out = err;
   if (steps_out) *steps_out = steps;
   return GLX_OK;
@@ -355,6 +371,18 @@ __global__ __launch_bounds__(256) void onehot_kernel(const long long* __restrict
   dense[i] = (labels[i / C] == (long long)(i % C)) ? (T)1 : (T)0;
 }
 
+// the projector's own fp64 (n, C) input array: a caller whose state is fp64 writes its prob straight into it and passes it as
+// `dense_dev` (no copy); anything else is widened / copied into it
+int glx_project_scores(glx_projector** pp, int64_t n, int C, double** scores_out) {
+  GLX_CHECK(pp && scores_out, GLX_EINVAL, "glx_project_scores: null argument");
+  GLX_CHECK(C <= 4096, GLX_EUNSUPPORTED, "glx_sweep_project: C=%d too large", C);
+  if (!*pp) *pp = new glx_projector();
+  int rc = proj_alloc((*pp)->b, n, C);
+  if (rc) return rc;
+  *scores_out = (*pp)->b.scores;
+  return GLX_OK;
+}
+
 int glx_project_device(glx_projector** pp, const void* dense_dev, int dtype, int64_t n, int C, const double* priors,
                        double* weights_inout, double* err_out, int* steps_out, int max_steps, int similarity, hipStream_t st,
                        const long long** d_labels_out) {
@@ -369,7 +397,7 @@ int glx_project_device(glx_projector** pp, const void* dense_dev, int dtype, int
   const unsigned grid = (unsigned)((total + 255) / 256);
   if (dtype == GLX_F32)
     hipLaunchKernelGGL(to_f64_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dense_dev, b.scores, total);
-  else
+  else if ((const void*)b.scores != dense_dev)
     hipLaunchKernelGGL(to_f64_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)dense_dev, b.scores, total);
   GLX_HIP(hipGetLastError());
   rc = proj_core(b, st, n, C, priors, weights_inout, err_out, steps_out, max_steps, similarity, dtype == GLX_F32);
@@ -384,6 +412,29 @@ int glx_onehot_device(const long long* d_labels, void* dense_dev, int dtype, int
     hipLaunchKernelGGL(onehot_kernel<float>, dim3(grid), dim3(256), 0, st, d_labels, (float*)dense_dev, n, C);
   else
     hipLaunchKernelGGL(onehot_kernel<double>, dim3(grid), dim3(256), 0, st, d_labels, (double*)dense_dev, n, C);
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}
+
+// vertex records of onehot(labels): record i holds vertex perm[i] (null: i), columns 0..C-1 = (label == column), padding zero --
+// the state PoissonMBO's heat sweeps continue from (ssl.py:832), written without the detour through a dense (n, C) array
+template <typename T>
+__global__ __launch_bounds__(256) void onehot_records_kernel(const long long* __restrict__ labels, T* __restrict__ rec, int64_t n, int C, int ld,
+                                                             const int32_t* __restrict__ perm) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * ld) return;
+  const int64_t row = i / ld;
+  const int c = (int)(i % ld);
+  rec[i] = (c < C && labels[perm ? (int64_t)perm[row] : row] == (long long)c) ? (T)1 : (T)0;
+}
+
+int glx_onehot_records(const long long* d_labels, void* rec, int dtype, int64_t n, const RecLayout& L, const int32_t* perm, hipStream_t st) {
+  const unsigned grid = (unsigned)((n * L.ld + 255) / 256);
+  if (n == 0) return GLX_OK;
+  if (dtype == GLX_F32)
+    hipLaunchKernelGGL(onehot_records_kernel<float>, dim3(grid), dim3(256), 0, st, d_labels, (float*)rec, n, L.C, L.ld, perm);
+  else
+    hipLaunchKernelGGL(onehot_records_kernel<double>, dim3(grid), dim3(256), 0, st, d_labels, (double*)rec, n, L.C, L.ld, perm);
   GLX_HIP(hipGetLastError());
   return GLX_OK;
 }

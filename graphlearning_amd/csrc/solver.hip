@@ -540,17 +540,24 @@ extern "C" int glx_sweep_project(glx_sweep* s, const double* priors, double* wei
   GLX_CHECK(!s->has_w || !to_onehot, GLX_EINVAL, "glx_sweep_project: to_onehot needs a sweep created with max_iter = 0");
   GLX_HIP(hipSetDevice(s->device));
   const int dtype = s->P->dtype;
-  int rc = glx_unpack_records(s->buf[s->cur], s->dense, s->n_rows, s->L, dtype, s->stream, s->P->d_perm);
+  // an fp64 state is unpacked straight into the projector's own (n, C) array; a float32 one goes through `dense` and is widened
+  void* prob = s->dense;
+  int rc;
+  if (dtype == GLX_F64) {
+    double* scores = nullptr;
+    rc = glx_project_scores(&s->proj, s->n_rows, s->C, &scores);
+    if (rc) return rc;
+    prob = scores;
+  }
+  rc = glx_unpack_records(s->buf[s->cur], prob, s->n_rows, s->L, dtype, s->stream, s->P->d_perm);
   if (rc) return rc;
   const long long* d_labels = nullptr;
-  rc = glx_project_device(&s->proj, s->dense, dtype, s->n_rows, s->C, priors, weights_inout, err_out, steps_out, max_steps,
+  rc = glx_project_device(&s->proj, prob, dtype, s->n_rows, s->C, priors, weights_inout, err_out, steps_out, max_steps,
                           similarity, s->stream, &d_labels);
   if (rc) return rc;
   if (labels_out) GLX_HIP(hipMemcpyAsync(labels_out, d_labels, (size_t)s->n_rows * 8, hipMemcpyDeviceToHost, s->stream));
   if (to_onehot) {
-    rc = glx_onehot_device(d_labels, s->dense, dtype, s->n_rows, s->C, s->stream);
-    if (rc) return rc;
-    rc = glx_pack_records(s->dense, s->buf[s->cur], s->n_cols, s->L, dtype, nullptr, s->stream, s->P->d_perm);
+    rc = glx_onehot_records(d_labels, s->buf[s->cur], dtype, s->n_cols, s->L, s->P->d_perm, s->stream);
     if (rc) return rc;
   }
   GLX_HIP(hipStreamSynchronize(s->stream));
