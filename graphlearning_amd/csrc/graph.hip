@@ -332,15 +332,70 @@ extern "C" int glx_host_fingerprint(const void* data, size_t bytes, uint64_t see
   return GLX_OK;
 }
 
+// Page-locked, device-visible host memory for result arrays.  From 1 MiB on: anonymous memory aligned to 2 MiB with transparent huge
+// pages asked for, faulted in by a few threads, then registered with the runtime -- 1.1 ms for 19 MB (one huge-page fault zeroes
+// 2 MiB at memory speed) where hipHostMalloc takes 2.7-3.2 ms (1.7 ms with any explicit flag; scripts/probes/pin_probe.hip): fresh
+// result arrays were most of what the first graph build of a new size paid.  Smaller blocks: hipHostMalloc.
+#include <sys/mman.h>
+namespace {
+struct HostBlocks {
+  std::mutex mu;
+  std::map<void*, std::pair<void*, size_t>> mapped;      // user pointer -> (mmap base, mmap length)
+};
+HostBlocks& host_blocks() {
+  static HostBlocks* h = new HostBlocks();
+  return *h;
+}
+}  // namespace
+
 extern "C" int glx_host_alloc(size_t bytes, void** out) {
   GLX_CHECK(out, GLX_EINVAL, "glx_host_alloc: null output");
   *out = nullptr;
-  GLX_HIP(hipHostMalloc(out, bytes > 0 ? bytes : 1, hipHostMallocDefault));
+  const size_t HUGE = (size_t)2 << 20;
+  if (bytes >= ((size_t)1 << 20)) {
+    const size_t len = (bytes + HUGE - 1) / HUGE * HUGE;
+    void* base = mmap(nullptr, len + HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (base != MAP_FAILED) {
+      char* a = (char*)(((uintptr_t)base + HUGE - 1) & ~(uintptr_t)(HUGE - 1));
+      madvise(a, len, MADV_HUGEPAGE);
+      const int64_t npages = (int64_t)(len / HUGE);
+      const int nt = (int)std::min<int64_t>(4, npages);
+      host_pool().run(nt, [&](int t) {               // one store per 4 KiB: faults the range in whether or not huge pages are granted
+        for (size_t off = (size_t)(npages * t / nt) * HUGE, end = (size_t)(npages * (t + 1) / nt) * HUGE; off < end; off += 4096)
+          *(volatile char*)(a + off) = 0;
+      });
+      if (hipHostRegister(a, len, hipHostRegisterDefault) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(host_blocks().mu);
+        host_blocks().mapped[a] = {base, len + HUGE};
+        *out = a;
+        return GLX_OK;
+      }
+      (void)hipGetLastError();
+      munmap(base, len + HUGE);
+    }
+  }
+  GLX_HIP(hipHostMalloc(out, bytes > 0 ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped));
   return GLX_OK;
 }
 
 extern "C" int glx_host_free(void* p) {
-  if (p) GLX_HIP(hipHostFree(p));
+  if (!p) return GLX_OK;
+  std::pair<void*, size_t> m{nullptr, 0};
+  {
+    std::lock_guard<std::mutex> lk(host_blocks().mu);
+    auto it = host_blocks().mapped.find(p);
+    if (it != host_blocks().mapped.end()) {
+      m = it->second;
+      host_blocks().mapped.erase(it);
+    }
+  }
+  if (m.first) {
+    hipError_t e = hipHostUnregister(p);
+    munmap(m.first, m.second);
+    GLX_HIP(e);
+    return GLX_OK;
+  }
+  GLX_HIP(hipHostFree(p));
   return GLX_OK;
 }
 
