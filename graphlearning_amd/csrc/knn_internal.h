@@ -49,7 +49,7 @@ constexpr int tile_nsub(int DH, int KP) {
 constexpr int bf16_nsub(int NKB, int KP) { return (NKB >= 4 || KP >= 32) ? 1 : 2; }
 // 8-entry lists in registers where that buys a fourth workgroup per CU (d = 49 .. 64: 122 registers, 34 KB of LDS; measured
 // +4 % at n = 3e5 .. 1e6; at fewer feature blocks the registers spill, at more the kernel is register-bound anyway)
-constexpr bool bf16_reglists(int NKB, int KP, int CAT) { return KP == 8 && (NKB == 4 || (NKB == 2 && CAT == 2)); }
+constexpr bool bf16_reglists(int NKB, int KP) { return KP == 8 && NKB == 4; }
 
 // device buffers of one pass of the search (pooled blocks; the destructor drains the stream first)
 struct KnnBufs {

@@ -18,7 +18,7 @@
 // (cheap, even when only a few lanes have one) and merged by the whole wavefront in lockstep when any lane's slots run low.
 // CAT (NKB = 2 only): the rows are the concatenated operands of knn_prep_bf16_cat_kernel, refs from Xb, queries from Xq.
 template <int NKB, int KP, int NSUB, int CAT = 0, bool RUNS = false>   // CAT: 1 concatenated operands, 2 also the norm folded into them
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(bf16_reglists(NKB, KP, CAT) ? 4 : 1, 4)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(bf16_reglists(NKB, KP) ? 4 : 1, 4)))
 void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned short* __restrict__ Xq, const float* __restrict__ nrm, int64_t n,
                           int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d, int* __restrict__ cand_i,
                           int* __restrict__ gtau, const int* __restrict__ runs, const int* __restrict__ nruns, int maxruns) {
@@ -35,7 +35,7 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
   extern __shared__ __attribute__((aligned(16))) char smem_b[];
   char* tile = smem_b;                                  // [2][BR][ROWB]
   float* rn = (float*)(smem_b + 2 * BR * ROWB);         // [2][BR]
-  constexpr bool REGL = bf16_reglists(NKB, KP, CAT);         // the lists in registers: LDS then holds tile + append slots only
+  constexpr bool REGL = bf16_reglists(NKB, KP);         // the lists in registers: LDS then holds tile + append slots only
   constexpr int LROWS = REGL ? KBUF : KP + KBUF;
   float* ld = rn + 2 * BR - (REGL ? KP * 256 : 0);      // [KP + KBUF][256] (rows [0, KP) do not exist with register lists)
   int* li = (int*)(rn + 2 * BR + LROWS * 256) - (REGL ? KP * 256 : 0);
@@ -334,7 +334,7 @@ static int launch_tile_bf16(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1,
   constexpr int NSUB = bf16_nsub(NKB, KP);
   constexpr int BR = 32 * NSUB;
   constexpr int ROWB = 4 * 16 * NKB + 16;
-  const size_t shm = (size_t)2 * BR * ROWB + (size_t)2 * BR * 4 + (size_t)(bf16_reglists(NKB, KP, CAT) ? KBUF : KP + KBUF) * 256 * 8;
+  const size_t shm = (size_t)2 * BR * ROWB + (size_t)2 * BR * 4 + (size_t)(bf16_reglists(NKB, KP) ? KBUF : KP + KBUF) * 256 * 8;
   GLX_CHECK(shm <= 160 * 1024, GLX_EUNSUPPORTED, "glx_knn_bruteforce: bf16 filter needs %zu bytes of LDS", shm);
   const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)(seed ? 1 : nsplit));
   if (b.runs) {
