@@ -24,7 +24,10 @@ def shapes():
     yield 'blobs 200000x64 k=11', rng.normal(size=(10, 64))[lab4] * 4.0 + rng.normal(size=(200000, 64)), 11
 
 
+only = sys.argv[2] if len(sys.argv) > 2 else ''
 for name, X, k in shapes():
+    if only and not name.startswith(only):
+        continue
     best = None
     for r in range(reps):
         res = _hip.KnnResult(X, k, want_order=True)
