@@ -917,8 +917,9 @@ def poisson_fit_distributed(W, train_ind, train_labels, dist, ops_factory, min_i
 # iteration exchanges the boundary rows of p (the same all-to-all-v as the sweep), multiplies the rank's rows, and adds the
 # ranks' column sums of p*Ap and r*r with one all-reduce each.  The summation order then depends on the
 # partition, so this is the tolerance mode (iterates within 1e-5 of the reference, identical labels: `reduce='tree'` on one
-# GPU makes the same trade).  Poisson's default CG solve stays on one GPU: its system is singular, and its 140+ iterations
-# amplify a reordered reduction into another iteration count and iterates that differ by far more than 1e-5.
+# GPU makes the same trade).  Poisson's default CG solve is singular and its 140+ iterations amplify a reordered reduction into
+# another iteration count and iterates that differ by far more than 1e-5: poisson_cg_fit_distributed runs it across
+# ranks under a residual contract only (same stop, labels agree away from ties); the bit-identical form stays on one GPU.
 class CgScipyOps:
     """Rank-local pieces of the distributed CG on numpy arrays (CPU tests over gloo)."""
     supports_graph = False
@@ -1128,6 +1129,31 @@ def laplace_fit_distributed(W, train_ind, train_labels, dist, ops_factory, norma
     if mean_shift:
         u -= np.mean(u, axis=0)
     return u, it
+
+
+def poisson_cg_fit_distributed(W, train_ind, train_labels, dist, ops_factory, tol=1e-3, order=None, partition='even', group=None):
+    """ssl.poisson(W) -- the DEFAULT solver, conjugate gradient -- .fit across the ranks of `dist` (reference ssl.py:608-629): the
+    singular system L_normalized x = D^-1/2 source of the graph without its diagonal, by cg_distributed, u = D^-1/2 x.  The contract
+    is weaker than the other distributed solvers' and said so: the stop is the reference's (sqrt of the summed squared residuals
+    <= tol, default 1e-3), but 100+ iterations on a singular system turn a reordered reduction into iterates that differ from the
+    one-GPU, reference-order solve by up to the order of tol and into an iteration count a few steps off -- both runs are solutions
+    to the same residual bound, the labels agree except on vertices whose two largest scores are closer than that.  (On a graph with
+    several components the reference's own system is inconsistent -- the source need not sum to zero per component -- and neither
+    solve means anything: tests/cg_worker.py uses connected graphs.)  Use
+    ssl.poisson on one GPU where the reference's exact iterates matter.  Returns (u (n, C), CG iterations)."""
+    from . import graph as graph_mod
+    from . import ssl as ssl_mod
+    n = W.shape[0]
+    W = sparse.csr_matrix(W)
+    W = sparse.csr_matrix(W - sparse.spdiags(W.diagonal(), 0, n, n))          # ssl.py:615-617
+    G = graph_mod.graph(W)
+    source, _ = ssl_mod._poisson_source(n, np.asarray(train_ind), np.asarray(train_labels))
+    L = sparse.csr_matrix(G.laplacian(normalization='normalized'))
+    D = G.degree_matrix(p=-0.5)
+    if order is None:
+        order = locality_order(L)
+    x, it, _ = cg_distributed(L, D * source, dist, ops_factory, tol=tol, order=order, partition=partition, group=group)
+    return D * x, it
 
 
 def randomwalk_fit_distributed(W, train_ind, train_labels, dist, ops_factory, alpha=0.95, order=None, partition='even', group=None):

@@ -45,10 +45,32 @@ def main():
         ti = orc.trainsets_generate(lab, rate=4, seed=1); tl = lab[ti]
         u, it = gdist.randomwalk_fit_distributed(W, ti, tl, dist, factory, partition=partition)
         u_ref, it_ref = orc.randomwalk_fit(W, ti, tl, return_iters=True)
+    elif case.startswith('poisson_cg'):
+        # the default solver of ssl.poisson: residual contract (see dist.poisson_cg_fit_distributed)
+        if case == 'poisson_cg_twomoons':
+            W = csr_from(g, 'W_gaussian'); ti = g['train_ind']; tl = g['labels'][ti]
+        else:                            # (one connected graph: on a disconnected one the reference's own system is inconsistent)
+            X, lab = blobs(1500, 8, 4, 21, 1.5)
+            W = orc.knn(X, 8)
+            ti = orc.trainsets_generate(lab, rate=3, seed=2); tl = lab[ti]
+        u, it = gdist.poisson_cg_fit_distributed(W, ti, tl, dist, factory, partition=partition)
+        u_ref, it_ref = orc.poisson_cg(W, ti, tl, return_iters=True)
+        # the residual of the distributed solution in the reference's own system
+        from scipy import sparse
+        n = W.shape[0]
+        W0 = sparse.csr_matrix(W - sparse.spdiags(W.diagonal(), 0, n, n))
+        src, _ = orc.poisson_source(n, ti, tl)
+        Dm = orc.degree_matrix(W0, p=-0.5)
+        L = orc.laplacian(W0, 'normalized')
+        deg = np.asarray(W0.sum(axis=1)).ravel()
+        x = np.sqrt(deg)[:, None] * u
+        kw = dict(residual=float(np.sqrt(np.sum((Dm * src - L * x) ** 2))),
+                  label_agreement=float(np.mean(orc.predict(u) == orc.predict(u_ref))))
     else:
         raise SystemExit('unknown case')
+    extra = kw if case.startswith('poisson_cg') else {}
     res = dict(rank=rank, world=world, it=int(it), it_ref=int(it_ref), max_abs_diff=float(np.max(np.abs(u - u_ref))),
-               labels_equal=bool(np.array_equal(orc.predict(u), orc.predict(u_ref))), scale=float(np.max(np.abs(u_ref))))
+               labels_equal=bool(np.array_equal(orc.predict(u), orc.predict(u_ref))), scale=float(np.max(np.abs(u_ref))), **extra)
     with open(out_path + '.%d' % rank, 'w') as f:
         json.dump(res, f)
     dist.barrier()

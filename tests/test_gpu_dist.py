@@ -392,6 +392,26 @@ def test_distributed_cg_multi_rank_hip_over_gloo(case, world, tmp_path):
         assert q['labels_equal'] and q['max_abs_diff'] <= 1e-5 * max(1.0, q['scale']) and abs(q['it'] - q['it_ref']) <= 1, q
 
 
+def test_distributed_poisson_cg_multi_rank_hip_over_gloo(tmp_path):
+    """ssl.poisson's default solver across 2 ranks with the rank-local SpMM / vector kernels on the GPU (dist.CgHipOps): the residual
+    contract of dist.poisson_cg_fit_distributed -- the reference's stop met in the reference's own system, labels identical on this
+    connected graph, a comparable iteration count."""
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    out = str(tmp_path / 'pcg_gpu')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'cg_worker.py'), 'poisson_cg_twomoons', out, 'hip', 'even']
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for k in range(2):
+        q = json.load(open(out + '.%d' % k))
+        assert q['residual'] <= 1e-3 * (1 + 1e-9) and q['label_agreement'] == 1.0, q
+        assert abs(q['it'] - q['it_ref']) <= max(3, q['it_ref'] // 20) and q['max_abs_diff'] <= 1e-2 * max(1.0, q['scale']), q
+
+
 @pytest.mark.parametrize('kernel', ['gaussian', 'uniform', 'singular'])
 def test_block_assembly_on_device_matches_scipy(golden, kernel):
     """dist_build's symmetrisation of ONE rank's rows on the GPU (glx_knn_rows_to_csr: own lists + the reverse entries the other
