@@ -205,25 +205,43 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
       tau = fminf(tau, __int_as_float(best));
     }
   };
-  if (t0 < t1) { stage_load(t0); stage_store(0); }
+  // The staging pipeline is two tiles deep: at the top of the iteration of tile t the registers hold tile t+1 (loaded during the
+  // iteration of t-1, a whole tile of matrix work ago) and go to the other LDS buffer at once -- everyone left it at the barrier
+  // that ended t-1 --, then the loads of tile t+2 are issued.  (One tile deep -- load at the top, store at the bottom -- the store
+  // waited for its loads and the barrier for the store: 190 + 210 of ~1500 cycles per tile, profiles/r04_knn_tile_pmc.txt.)
+  int t = t0;
+  int tn;
+  bool has_next;
+  if constexpr (RUNS) {
+    if (t0 < t1) { stage_load(t0); stage_store(0); }
+    tn = t0 < t1 ? next_tile(t0) : t1;
+    has_next = tn < t1;
+  } else {
+    if (left > 0) { stage_load(t0); stage_store(0); }
+    tn = t0 + nsplit;
+    if (tn >= t1) tn = (int)sp;
+    has_next = left > 1;
+  }
+  if (has_next) stage_load(tn);
   __syncthreads();
   int buf = 0;
   int it = 0;
-  int t = t0;
   while (RUNS ? t < t1 : left > 0) {
-    int tn;
-    bool has_next;
+    int tnn;
+    bool has_nn;
     if constexpr (RUNS) {
-      tn = next_tile(t);
-      has_next = tn < t1;
+      tnn = has_next ? next_tile(tn) : t1;
+      has_nn = tnn < t1;
     } else {
-      tn = t + nsplit;
-      if (tn >= t1) tn = (int)sp;
-      has_next = --left > 0;
+      tnn = tn + nsplit;
+      if (tnn >= t1) tnn = (int)sp;
+      has_nn = left > 2;
+      --left;
     }
+    if (has_next) stage_store(buf ^ 1);
+    if (has_nn) stage_load(tnn);
     // (every lane reads -- rows past q_end their clamped query's --: a scalar branch, no exec-mask bookkeeping per tile)
     if ((it & 15) == 15) tau = fminf(tau, gtau_read(qc));
-    if (has_next) stage_load(tn);
     const char* tl = tile + buf * BR * ROWB;
     const float* rnb = rn + buf * BR;
     f32x16 acc[NSUB];
@@ -306,10 +324,11 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
         }
       }
     }
-    if (has_next) stage_store(buf ^ 1);
     __syncthreads();
     buf ^= 1;
-    t = tn;
+    t = RUNS ? (has_next ? tn : t1) : tn;
+    tn = tnn;
+    has_next = has_nn;
     ++it;
   }
   compact();
