@@ -443,12 +443,14 @@ class ShardedGraph:
         own = self.plan.own
         Db = np.zeros((len(own), k))
         w0 = np.zeros(len(own))
-        pos_of = {int(g): p for p, g in enumerate(own)} if len(train_ind) < 4096 else None
         vval = 1.0 / float(len(train_ind))
-        for q, t in enumerate(train_ind):
-            t = int(t)
-            if self.lo <= t < self.hi:
-                p = pos_of[t] if pos_of is not None else int(np.flatnonzero(own == t)[0])
+        mine = np.flatnonzero((train_ind >= self.lo) & (train_ind < self.hi))
+        if len(mine):
+            pos = np.empty(self.hi - self.lo, dtype=np.int64)      # local position of every owned vertex (two vector passes, no dict of 10^7 keys)
+            pos[own - self.lo] = np.arange(len(own), dtype=np.int64)
+            for q in mine:
+                t = int(train_ind[q])
+                p = int(pos[t - self.lo])
                 Db[p] = (deg_all[t] ** (-1)) * rows_src[q]      # row of D*source: one product per entry
                 w0[p] = vval / deg_all[t]
         return dict(Db=Db, w0=w0, deg=deg_all[own], vinf=vinf_all[own], k=k, deg_all=deg_all, vinf_all=vinf_all)
