@@ -83,6 +83,7 @@ _SIGNATURES = {
     'glx_sweep_stop_values': [_vp, C.c_int64, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     'glx_sweep_destroy': [_vp],
     'glx_sweep_set_state': [_vp, _vp, _vp],
+    'glx_sweep_set_state_labels': [_vp, _vp, C.c_int64, _vp, _vp],
     'glx_sweep_iterate': [_vp, C.c_int],
     'glx_record_layout': [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)],
     'glx_graph_slots': [_vp, C.c_int, C.c_int, _i64p],
@@ -593,6 +594,15 @@ class Sweep:
         u0 = None if u0 is None else _dense(u0, self.graph.dtype, (n, self.C), 'u0')
         Db = None if Db is None else _dense(Db, self.graph.dtype, (n, self.C), 'Db')
         check(load().glx_sweep_set_state(self._h, _ptr(u0), _ptr(Db)), 'glx_sweep_set_state')
+        self.generation = getattr(self, 'generation', 0) + 1
+
+    def set_state_labels(self, labels, rows, Db_rows):
+        """u = onehot(labels), bias = its m nonzero rows (distinct `rows`): n labels and m rows go up instead of two dense arrays."""
+        n = self.graph.shape[0]
+        labels = _dense(labels, np.int64, (n,), 'labels')
+        rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
+        Db_rows = _dense(Db_rows, self.graph.dtype, (len(rows), self.C), 'Db_rows')
+        check(load().glx_sweep_set_state_labels(self._h, _ptr(labels), len(rows), _ptr(rows), _ptr(Db_rows)), 'glx_sweep_set_state_labels')
         self.generation = getattr(self, 'generation', 0) + 1
 
     def iterate(self, iters):

@@ -589,6 +589,67 @@ extern "C" int glx_sweep_set_state(glx_sweep* s, const void* u0, const void* Db)
   return GLX_OK;
 }
 
+// rows of a bias given one by one (heat sweeps: no stop column, no flags per row needed beyond bias_flags_kernel's pass)
+template <typename T>
+__global__ void scatter_bias_rows_kernel(char* __restrict__ bias, int rec_bytes, const int64_t* __restrict__ rows, const int32_t* __restrict__ inv,
+                                         const T* __restrict__ Db_rows, int64_t m, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * C) return;
+  const int64_t row = rows[i / C];
+  const int32_t rec = inv ? inv[row] : (int32_t)row;
+  ((T*)(bias + (size_t)rec * rec_bytes))[i % C] = Db_rows[i];
+}
+
+extern "C" int glx_sweep_set_state_labels(glx_sweep* s, const int64_t* labels, int64_t m, const int64_t* rows, const void* Db_rows) {
+  GLX_CHECK(s && labels, GLX_EINVAL, "glx_sweep_set_state_labels: null argument");
+  GLX_CHECK(!s->has_w, GLX_EINVAL, "glx_sweep_set_state_labels: only for sweeps created with max_iter = 0");
+  GLX_CHECK(s->n_rows == s->n_cols, GLX_EINVAL, "glx_sweep_set_state_labels: operator must be square");
+  GLX_CHECK(m >= 0 && (m == 0 || (rows && Db_rows)), GLX_EINVAL, "glx_sweep_set_state_labels: null array");
+  for (int64_t q = 0; q < m; ++q)
+    GLX_CHECK(rows[q] >= 0 && rows[q] < s->n_rows, GLX_EINVAL, "glx_sweep_set_state_labels: row %lld out of range", (long long)rows[q]);
+  GLX_HIP(hipSetDevice(s->P->device));
+  const int64_t nslots = s->plan->nslices * s->plan->R;
+  const int rb = s->L.ld * s->L.esize;
+  const size_t es = s->L.esize;
+  const size_t b_lab = (size_t)s->n_rows * 8, b_rows = (size_t)m * 8, b_db = ((size_t)m * s->C * es + 7) / 8 * 8;
+  if (s->rows_stage_cap < b_lab + b_rows + b_db) {
+    GLX_HIP(hipStreamSynchronize(s->stream));
+    hipFree(s->rows_stage);
+    s->rows_stage = nullptr;
+    s->rows_stage_cap = 0;
+    GLX_HIP(hipMalloc(&s->rows_stage, b_lab + 2 * (b_rows + b_db) + 64));
+    s->rows_stage_cap = b_lab + 2 * (b_rows + b_db) + 64;
+  }
+  char* st = (char*)s->rows_stage;
+  drop_graphs_if_bias_changes(s, m > 0);
+  GLX_HIP(hipMemcpyAsync(st, labels, b_lab, hipMemcpyHostToDevice, s->stream));
+  int rc = glx_onehot_records((const long long*)st, s->buf[0], s->P->dtype, s->n_rows, s->L, s->P->d_perm, s->stream);   // u = onehot(labels)
+  if (rc) return rc;
+  GLX_HIP(hipMemsetAsync(s->bias, 0, rec_bytes(s, s->n_rows), s->stream));
+  GLX_HIP(hipMemsetAsync(s->slot_has_bias, 0, std::max<int64_t>(nslots, 1), s->stream));
+  if (m > 0) {
+    GLX_HIP(hipMemcpyAsync(st + b_lab, rows, b_rows, hipMemcpyHostToDevice, s->stream));
+    GLX_HIP(hipMemcpyAsync(st + b_lab + b_rows, Db_rows, (size_t)m * s->C * es, hipMemcpyHostToDevice, s->stream));
+    const int64_t tot = m * s->C;
+    if (s->P->dtype == GLX_F32)
+      hipLaunchKernelGGL(scatter_bias_rows_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (char*)s->bias, rb,
+                         (const int64_t*)(st + b_lab), (const int32_t*)s->P->d_inv, (const float*)(st + b_lab + b_rows), m, s->C);
+    else
+      hipLaunchKernelGGL(scatter_bias_rows_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (char*)s->bias, rb,
+                         (const int64_t*)(st + b_lab), (const int32_t*)s->P->d_inv, (const double*)(st + b_lab + b_rows), m, s->C);
+    GLX_HIP(hipGetLastError());
+    if (nslots > 0) {
+      hipLaunchKernelGGL(bias_flags_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s->stream,
+                         s->plan->d_slot_row, s->slot_has_bias, nslots, (const char*)s->bias, rb);
+      GLX_HIP(hipGetLastError());
+    }
+  }
+  s->bias_set = m > 0;
+  s->cur = 0;
+  GLX_HIP(hipStreamSynchronize(s->stream));   // the host arrays may go
+  return GLX_OK;
+}
+
 extern "C" int glx_sweep_iterate(glx_sweep* s, int iters) {
   GLX_CHECK(s && iters >= 0, GLX_EINVAL, "glx_sweep_iterate: bad argument");
   GLX_CHECK(!s->has_w, GLX_EINVAL, "glx_sweep_iterate: only for sweeps created with max_iter = 0");

@@ -688,7 +688,6 @@ class poisson_mbo(ssl):
         source, k = _poisson_source(n, train_ind, train_labels)
         # initialise with Poisson learning (plain argmax: the inner model has no priors)
         labels = self.poisson_model.fit_predict(train_ind, train_labels, all_labels=all_labels)
-        u = utils.labels_to_onehot(labels, k)
         # heat operator P = I - dt L and its device image depend on the graph only: kept across fits
         key = (self._graph_key(), dtype, k)
         if self._cache is None or self._cache[0] != key:
@@ -706,13 +705,18 @@ class poisson_mbo(ssl):
             heat = _hip.Sweep(dev, k, min_iter=0, max_iter=0, use_hipgraph=True)
             self._cache = (key, dev, heat, dt)
         _, dev, heat, dt = self._cache
-        Db = mu * dt * source                                   # reference ssl.py:805
         if self.class_priors is None:   # the reference fails in volume_label_projection (None arithmetic, ssl.py:199)
             raise TypeError('poisson_mbo needs class_priors for its volume-constrained thresholding')
         # the state never leaves the device between the heat sweeps and the thresholding: the
         # volume-constrained decision runs on the sweep's buffer and writes onehot(labels) back
         # into it (glx_sweep_project); per outer step only the class weights come back
-        heat.set_state(u, Db)
+        rows = np.asarray(train_ind).reshape(-1)
+        if len(np.unique(rows)) == len(rows) and labels.min() >= 0 and labels.max() < k:
+            # u = onehot(labels) is formed on the device from the labels, Db = mu * dt * source from its labelled rows (every other
+            # row of the reference's dense product is a zero): n labels + m rows go up, not two dense (n, k) arrays
+            heat.set_state_labels(labels, rows, mu * dt * source[rows])
+        else:
+            heat.set_state(utils.labels_to_onehot(labels, k), mu * dt * source)    # reference ssl.py:798, 805
         for i in range(T):
             heat.iterate(Ns)                                # Ns x `u = P*u + Db`, reference ssl.py:826-827
             w = np.ones((k,)) if type(self.weights) == int else self.weights

@@ -154,6 +154,10 @@ int glx_sweep_destroy(glx_sweep* s);
  * returns: every call that reads or replaces the state (glx_sweep_project, glx_sweep_fetch, glx_sweep_set_state, another
  * glx_sweep_iterate) is ordered behind them in the sweep's own stream. */
 int glx_sweep_set_state(glx_sweep* s, const void* u0, const void* Db);
+/* The same with the state given as labels -- u = onehot(labels), labels (n,) int64 in the caller's row order -- and the bias by its m
+ * nonzero rows (rows distinct; Db_rows (m, C) in the graph's dtype): PoissonMBO's start (ssl.py:797-805) moves n labels and m rows
+ * instead of two dense (n, C) arrays. */
+int glx_sweep_set_state_labels(glx_sweep* s, const int64_t* labels, int64_t m, const int64_t* rows, const void* Db_rows);
 int glx_sweep_iterate(glx_sweep* s, int iters);
 
 /* ---- device-pointer entry points: rank-local sweeps of the vertex-partitioned solver -------

@@ -4,7 +4,7 @@ the device -- degrees there, P = D^-1 W^T formed while the sliced-ELL image is f
 import numpy as np
 import pytest
 from scipy import sparse
-from conftest import csr_from
+from conftest import csr_from, blobs
 
 pytestmark = pytest.mark.gpu
 
@@ -83,3 +83,51 @@ def test_fresh_fit_through_the_resident_path_matches_the_goldens(golden):
     assert m.num_iter == int(g['poisson_gd_T']) and np.array_equal(u, g['poisson_gd_prob'])
     m2 = gl.ssl.poisson(csr_from(g, 'W'), solver='gradient_descent')
     assert np.array_equal(m2.fit(ti, lab[ti]), u) and m2.num_iter == m.num_iter
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_heat_state_from_labels_equals_the_dense_form(dtype):
+    """glx_sweep_set_state_labels (PoissonMBO's start: u = onehot(labels) formed on the device, the bias from its m nonzero rows)
+    against glx_sweep_set_state with the two dense arrays the reference builds (ssl.py:798, 805): the same state after 0, 1 and 7
+    sweeps, bit for bit; duplicate rows and out-of-range rows are the caller's to avoid / are refused."""
+    from graphlearning_amd import _hip
+    rng = np.random.default_rng(5)
+    n, k = 3000, 4
+    X, lab = blobs(n, 6, k, 3, 2.0)
+    from oracle import gl_oracle as orc
+    W = orc.knn(X, 8)
+    deg = np.asarray(W.sum(axis=1)).ravel()
+    dt = 1.0 / deg.max()
+    from scipy import sparse
+    P = sparse.csr_matrix(sparse.identity(n) - dt * (sparse.spdiags(deg, 0, n, n) - W))
+    labels = rng.integers(0, k, size=n).astype(np.int64)
+    rows = rng.choice(n, size=37, replace=False).astype(np.int64)
+    Db_rows = rng.normal(size=(37, k)).astype(dtype)
+    Db = np.zeros((n, k), dtype=dtype)
+    Db[rows] = Db_rows
+    u0 = np.zeros((n, k), dtype=dtype)
+    u0[np.arange(n), labels] = 1
+    dev = _hip.DeviceGraph(P, dtype=dtype)
+    a = _hip.Sweep(dev, k, min_iter=0, max_iter=0, use_hipgraph=True)
+    b = _hip.Sweep(dev, k, min_iter=0, max_iter=0, use_hipgraph=True)
+    a.set_state(u0, Db)
+    b.set_state_labels(labels, rows, Db_rows)
+    assert np.array_equal(a.fetch(), b.fetch())
+    for iters in (1, 7):
+        a.iterate(iters); b.iterate(iters)
+        ua, ub = a.fetch(), b.fetch()
+        assert np.array_equal(ua, ub) and np.isfinite(ua).all()
+    # a second problem on the same object: the previous bias rows must be gone
+    rows2 = rows[:5]
+    b.set_state_labels(labels, rows2, Db_rows[:5])
+    Db2 = np.zeros((n, k), dtype=dtype); Db2[rows2] = Db_rows[:5]
+    a.set_state(u0, Db2)
+    a.iterate(3); b.iterate(3)
+    assert np.array_equal(a.fetch(), b.fetch())
+    # no bias at all
+    b.set_state_labels(labels, rows[:0], Db_rows[:0]); a.set_state(u0, None)
+    a.iterate(2); b.iterate(2)
+    assert np.array_equal(a.fetch(), b.fetch())
+    with pytest.raises(_hip.GlxError):
+        b.set_state_labels(labels, np.array([n]), Db_rows[:1])
+    a.close(); b.close(); dev.close()
