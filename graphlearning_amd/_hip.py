@@ -145,6 +145,7 @@ _SIGNATURES = {
     'glx_host_locality_order': [C.c_int64, _vp, _vp, C.c_int64, _vp],
     'glx_host_permute_rows': [C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'glx_host_row_sums': [C.c_int64, _vp, _vp, _vp],
+    'glx_host_neg_columns_rows': [C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_int, _vp, C.c_int64, _vp, _vp, _i64p],
     'glx_host_reverse_scale_rows': [C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp],
     'glx_knn_to_csr_into': [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, _i64p, C.c_int],
 }
@@ -851,6 +852,30 @@ def host_row_sums(W):
     out = np.empty(W.shape[0], dtype=np.float64)
     check(load().glx_host_row_sums(W.shape[0], _ptr(W.indptr), _ptr(W.data), _ptr(out)), 'glx_host_row_sums')
     return out
+
+
+def host_neg_columns_rows(Lcsc, cols, F, row_scale=None):
+    """(rows ascending int32, values (len(rows), k)) of -L[:, cols] * F without the rows in `cols`, each row times row_scale[row]
+    (glx_host_neg_columns_rows: csr_matvecs' order of a row's terms); None when the preconditions do not hold (the caller then
+    takes the literal expression)."""
+    n = Lcsc.shape[0]
+    cols = np.ascontiguousarray(cols, dtype=np.int64).reshape(-1)
+    F = np.ascontiguousarray(F, dtype=np.float64)
+    if Lcsc.indptr.dtype != np.int32 or Lcsc.indices.dtype != np.int32 or Lcsc.data.dtype != np.float64 or F.ndim != 2 or len(F) != len(cols):
+        return None
+    if len(cols) and (cols.min() < 0 or cols.max() >= n):
+        return None
+    k = F.shape[1]
+    cap = int(Lcsc.indptr[cols + 1].astype(np.int64).sum() - Lcsc.indptr[cols].astype(np.int64).sum()) if len(cols) else 0
+    rows = np.empty(max(cap, 1), dtype=np.int32)
+    vals = np.empty((max(cap, 1), k), dtype=np.float64)
+    cnt = C.c_int64(0)
+    scale = None if row_scale is None else np.ascontiguousarray(row_scale, dtype=np.float64)
+    check(load().glx_host_neg_columns_rows(n, _ptr(Lcsc.indptr), _ptr(Lcsc.indices), _ptr(Lcsc.data), len(cols), _ptr(cols), _ptr(F), k,
+                                           _ptr(scale), cap, _ptr(rows), _ptr(vals), C.byref(cnt)), 'glx_host_neg_columns_rows')
+    if cnt.value < 0:
+        return None
+    return rows[:cnt.value], vals[:cnt.value]
 
 
 def host_reverse_scale_rows(W, scale):

@@ -738,6 +738,67 @@ extern "C" int glx_host_row_sums(int64_t n, const int32_t* rowptr, const double*
   return GLX_OK;
 }
 
+// The nonzero rows of -L[:, cols] * F (ssl.laplace's right-hand side, reference ssl.py:1236) from the CSC image of L: scipy forms the
+// CSR matrix -L[:, cols] and csr_matvecs adds a row's products one after another from 0, i.e. for canonical L and distinct cols the
+// terms (-l_ij) * F[pos(j), :] in ascending j.  Rows listed in `cols` themselves are left out (they are not part of the Dirichlet
+// system), every other row comes out times row_scale[row] (M*b, ssl.py:1249).  *count_out = -1: duplicate columns, the caller falls
+// back to the literal expression.
+extern "C" int glx_host_neg_columns_rows(int64_t n, const int32_t* cptr, const int32_t* crow, const double* cval, int64_t m, const int64_t* cols,
+                                         const double* F, int k, const double* row_scale, int64_t cap, int32_t* rows_out, double* vals_out,
+                                         int64_t* count_out) {
+#pragma clang fp contract(off)
+  GLX_CHECK(cptr && crow && cval && F && rows_out && vals_out && count_out && (cols || m == 0), GLX_EINVAL, "glx_host_neg_columns_rows: null argument");
+  GLX_CHECK(n >= 0 && m >= 0 && k > 0, GLX_EINVAL, "glx_host_neg_columns_rows: bad size");
+  for (int64_t q = 0; q < m; ++q) GLX_CHECK(cols[q] >= 0 && cols[q] < n, GLX_EINVAL, "glx_host_neg_columns_rows: column %lld out of range", (long long)cols[q]);
+  std::vector<int64_t> pos((size_t)m);
+  for (int64_t q = 0; q < m; ++q) pos[q] = q;
+  std::stable_sort(pos.begin(), pos.end(), [&](int64_t a, int64_t b) { return cols[a] < cols[b]; });
+  for (int64_t q = 1; q < m; ++q)
+    if (cols[pos[q]] == cols[pos[q - 1]]) { *count_out = -1; return GLX_OK; }
+  static thread_local std::vector<int32_t> slot;       // row -> slot of this call, -1 elsewhere (only touched entries are reset)
+  if ((int64_t)slot.size() < n) slot.assign((size_t)n, -1);
+  std::vector<int32_t> touched;
+  std::vector<double> acc;
+  for (int64_t q = 0; q < m; ++q) {
+    const int64_t j = cols[pos[q]];
+    const double* f = F + (size_t)pos[q] * k;
+    for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
+      const int32_t row = crow[e];
+      int32_t sl = slot[row];
+      if (sl < 0) {
+        sl = (int32_t)touched.size();
+        slot[row] = sl;
+        touched.push_back(row);
+        acc.resize(acc.size() + (size_t)k, 0.0);
+      }
+      const double nv = -cval[e];
+      double* a = acc.data() + (size_t)sl * k;
+      for (int c = 0; c < k; ++c) a[c] = a[c] + nv * f[c];
+    }
+  }
+  std::vector<int32_t> ord(touched);
+  std::sort(ord.begin(), ord.end());
+  for (int64_t q = 0; q < m; ++q) {                    // the labelled rows themselves are not part of the system
+    const int32_t sl = slot[cols[q]];
+    if (sl >= 0) slot[cols[q]] = -2 - sl;
+  }
+  int64_t cnt = 0;
+  int rc = GLX_OK;
+  for (int32_t row : ord) {
+    const int32_t sl = slot[row];
+    if (sl < 0) continue;
+    if (cnt >= cap) { rc = GLX_EINVAL; glx_set_error("glx_host_neg_columns_rows: more than %lld rows", (long long)cap); break; }
+    const double sc = row_scale ? row_scale[row] : 1.0;
+    const double* a = acc.data() + (size_t)sl * k;
+    rows_out[cnt] = row;
+    for (int c = 0; c < k; ++c) vals_out[(size_t)cnt * k + c] = row_scale ? sc * a[c] : a[c];
+    ++cnt;
+  }
+  for (int32_t row : touched) slot[row] = -1;
+  *count_out = cnt;
+  return rc;
+}
+
 extern "C" int glx_host_reverse_scale_rows(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val, const double* scale,
                                            int32_t* col_out, double* val_out) {
 #pragma clang fp contract(off)

@@ -888,15 +888,16 @@ class laplace(ssl):
             train_ind = np.asarray(train_ind)
             k = len(np.unique(train_labels))
             F = utils.labels_to_onehot(train_labels, k)
-            sp = _neg_columns_times_rows(L, self._full_csc(L), train_ind, F)
-            if sp is not None and (len(train_ind) == 0 or (train_ind.min() >= 0 and train_ind.max() < L.shape[0])):
-                # b = -L[:,train_ind]*F (ssl.py:1236) lives on the neighbours of the labelled vertices: only those rows go up,
-                # M*b (ssl.py:1249) row by row; `v = M*v` (ssl.py:1250) is applied on the device on the way out
-                rows, b = sp
-                keep = ~np.isin(rows, train_ind)                 # the labelled rows themselves are not part of the system
-                rows, b = rows[keep], b[keep]
-                u, its, _ = dev.cg_groups_rows(rows, Mv[rows, None] * b, k, masks=[train_ind], out_scale=Mv, tol=self.tol,
-                                               reduce=self.reduce)
+            sp = None
+            if L.has_sorted_indices and L.has_canonical_format and len(train_ind):
+                # b = -L[:,train_ind]*F (ssl.py:1236) lives on the neighbours of the labelled vertices: only those rows go up, the
+                # labelled rows themselves left out, M*b (ssl.py:1249) row by row -- one pass of the library's host loop over the
+                # selected columns (the numpy form of the same sums, _neg_columns_times_rows, took 0.35 ms of a 3.1 ms fit)
+                sp = _hip.host_neg_columns_rows(self._full_csc(L), train_ind, F, row_scale=Mv)
+            if sp is not None:
+                # `v = M*v` (ssl.py:1250) is applied on the device on the way out
+                rows, Mb = sp
+                u, its, _ = dev.cg_groups_rows(rows, Mb, k, masks=[train_ind], out_scale=Mv, tol=self.tol, reduce=self.reduce)
                 self.num_iter = int(its[0])
                 u[train_ind, :] = F                              # reference ssl.py:1253-1255
                 if self.mean_shift:

@@ -61,6 +61,13 @@ void glx_free(void* p);
 int glx_host_row_sums(int64_t n, const int32_t* rowptr, const double* val, double* sum_out);
 int glx_host_reverse_scale_rows(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val,
                                 const double* scale, int32_t* col_out, double* val_out);
+/* Host: the nonzero rows of -L[:, cols] * F from the CSC image (cptr, crow, cval) of a canonical L -- ssl.laplace's right-hand side,
+ * reference ssl.py:1236, a row's terms added in ascending column order from 0 as scipy's csr_matvecs does --, without the rows listed
+ * in cols, every row times row_scale[row] when given (M*b, ssl.py:1249).  rows_out ascending, vals_out (count, k); cap = room in both.
+ * *count_out = -1 (and GLX_OK): cols has duplicates, use the literal expression. */
+int glx_host_neg_columns_rows(int64_t n, const int32_t* cptr, const int32_t* crow, const double* cval, int64_t m, const int64_t* cols,
+                              const double* F, int k, const double* row_scale, int64_t cap, int32_t* rows_out, double* vals_out,
+                              int64_t* count_out);
 
 /* host helpers of the sharded build: the library's locality order (perm_out[new] = old, the breadth-first pass glx_graph uses for
  * square operators) of an n-row pattern restricted to the columns [col_lo, col_lo + n) -- a rank orders its own rows by their links

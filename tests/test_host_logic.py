@@ -162,6 +162,39 @@ def test_laplace_rhs_fast_path_equals_scipy_expression():
     assert np.array_equal(glssl._neg_columns_times(L2, L2.tocsc(), cols, F), -L2[:, cols] * F)
 
 
+def test_laplace_rhs_rows_of_the_library_equal_the_scipy_expression():
+    """_hip.host_neg_columns_rows (glx_host_neg_columns_rows, what ssl.laplace.fit sends up) == the rows of `M * (-L[:, cols] * F)`
+    (reference ssl.py:1236, 1249) bit for bit: rows ascending, the labelled rows left out, every other row of the product zero; the
+    numpy form of the same sums (ssl._neg_columns_times_rows) agrees; duplicate columns are handed back (None)."""
+    from graphlearning_amd import ssl as glssl
+    rng = np.random.default_rng(1)
+    for n, dens, m, k in [(300, 0.08, 60, 3), (1000, 0.02, 200, 10), (50, 0.5, 30, 2), (400, 0.01, 1, 4)]:
+        A = sparse.random(n, n, density=dens, random_state=int(rng.integers(1 << 30)), format='csr')
+        L = sparse.csr_matrix(sparse.diags(np.asarray(A.sum(axis=1)).ravel() + 0.5) - A - A.T)
+        L.sum_duplicates()
+        L.sort_indices()
+        cols = rng.permutation(n)[:m]
+        F = np.eye(k)[rng.integers(0, k, m)] + (rng.normal(size=(m, k)) if n == 50 else 0.0)
+        Mv = 1 / np.sqrt(L.diagonal() + 1e-10)
+        ref = Mv[:, None] * (-L[:, cols] * F)
+        rows, vals = _hip.host_neg_columns_rows(L.tocsc(), cols, F, row_scale=Mv)
+        assert rows.dtype == np.int32 and np.all(np.diff(rows) > 0) and not np.isin(rows, cols).any()
+        assert np.array_equal(vals, ref[rows])
+        rest = np.ones(n, dtype=bool)
+        rest[rows] = False
+        rest[cols] = False
+        assert not ref[rest].any()
+        r2, b2 = glssl._neg_columns_times_rows(L, L.tocsc(), cols, F)
+        keep = ~np.isin(r2, cols)
+        assert np.array_equal(r2[keep], rows) and np.array_equal(Mv[r2[keep], None] * b2[keep], vals)
+        r3, v3 = _hip.host_neg_columns_rows(L.tocsc(), cols, F)          # no scaling
+        assert np.array_equal(r3, rows) and np.array_equal(v3, (-L[:, cols] * F)[rows])
+    assert _hip.host_neg_columns_rows(L.tocsc(), np.array([3, 5, 3]), np.eye(4)[[0, 1, 2]]) is None
+    with pytest.raises(_hip.GlxError):
+        _hip.load().glx_host_neg_columns_rows  # the symbol exists ...
+        _hip.check(_hip.load().glx_host_neg_columns_rows(n, None, None, None, 0, None, None, 1, None, 0, None, None, None), 'null arguments')
+
+
 def test_load_knn_data_reads_the_reference_cache_file(golden, monkeypatch):
     """./knn_data/<dataset>_<metric>.npz with keys J, D (reference weightmatrix.py:416-427, 451-465).
     tests/golden/knn_data/glxtoy_raw.npz was written by the reference's own knnsearch(dataset='GlxToy')."""
