@@ -131,18 +131,26 @@ int glx_work_acquire(int device, glx_work** out) {
     std::lock_guard<std::mutex> lk(mu);
     if (std::find(warmed.begin(), warmed.end(), device) == warmed.end()) {
       warmed.push_back(device);
+      // (two more streams than the set owns: a solver object's own stream is the third or fourth the process creates, and its first
+      // device-to-host copy drew one more engine -- 10 ms inside the first fit of a process, scripts/first_fit_probe.py)
       const size_t half = (size_t)1 << 20;
       void *d = nullptr, *h = nullptr;
-      if (hipMalloc(&d, 4 * half) == hipSuccess && hipHostMalloc(&h, 4 * half, hipHostMallocDefault) == hipSuccess) {
-        for (int rep = 0; rep < 2; ++rep) {
-          hipMemcpyAsync((char*)h, (char*)d, half, hipMemcpyDeviceToHost, w->stream);
-          hipMemcpyAsync((char*)h + half, (char*)d + half, half, hipMemcpyDeviceToHost, w->side);
-          hipMemcpyAsync((char*)d + 2 * half, (char*)h + 2 * half, half, hipMemcpyHostToDevice, w->stream);
-          hipMemcpyAsync((char*)d + 3 * half, (char*)h + 3 * half, half, hipMemcpyHostToDevice, w->side);
-        }
-        hipStreamSynchronize(w->stream);
-        hipStreamSynchronize(w->side);
+      hipStream_t extra[2] = {nullptr, nullptr};
+      for (int q = 0; q < 2; ++q)
+        if (hipStreamCreateWithFlags(&extra[q], hipStreamNonBlocking) != hipSuccess) extra[q] = nullptr;
+      if (hipMalloc(&d, 8 * half) == hipSuccess && hipHostMalloc(&h, 8 * half, hipHostMallocDefault) == hipSuccess) {
+        hipStream_t sts[4] = {w->stream, w->side, extra[0], extra[1]};
+        for (int rep = 0; rep < 2; ++rep)
+          for (int q = 0; q < 4; ++q) {
+            if (!sts[q]) continue;
+            hipMemcpyAsync((char*)h + (2 * q) * half, (char*)d + (2 * q) * half, half, hipMemcpyDeviceToHost, sts[q]);
+            hipMemcpyAsync((char*)d + (2 * q + 1) * half, (char*)h + (2 * q + 1) * half, half, hipMemcpyHostToDevice, sts[q]);
+          }
+        for (int q = 0; q < 4; ++q)
+          if (sts[q]) hipStreamSynchronize(sts[q]);
       }
+      for (int q = 0; q < 2; ++q)
+        if (extra[q]) hipStreamDestroy(extra[q]);
       if (h) hipHostFree(h);
       if (d) hipFree(d);
       (void)hipGetLastError();
@@ -572,7 +580,12 @@ extern "C" int glx_graph_set_row_transform(glx_graph* g, const double* row_scale
   g->d_row_scale = nullptr;
   if (row_scale && g->n_rows > 0) {
     GLX_HIP(hipMalloc(&g->d_row_scale, (size_t)g->n_rows * 8));
-    GLX_HIP(hipMemcpy(g->d_row_scale, row_scale, (size_t)g->n_rows * 8, hipMemcpyHostToDevice));
+    glx_work* w = nullptr;             // (a work set's stream, not a blocking copy on the NULL stream: see glx_graph_set_order)
+    int rc = glx_work_acquire(g->device, &w);
+    if (rc) return rc;
+    struct WorkGuard { glx_work* w; ~WorkGuard() { hipStreamSynchronize(w->stream); glx_work_release(w); } } wguard{w};
+    GLX_HIP(hipMemcpyAsync(g->d_row_scale, row_scale, (size_t)g->n_rows * 8, hipMemcpyHostToDevice, w->stream));
+    GLX_HIP(hipStreamSynchronize(w->stream));
   }
   return GLX_OK;
 }
@@ -896,8 +909,15 @@ extern "C" int glx_graph_set_order(glx_graph* g, const int32_t* perm) {
   GLX_HIP(hipSetDevice(g->device));
   GLX_HIP(hipMalloc(&g->d_perm, std::max<size_t>(n * 4, 4)));
   GLX_HIP(hipMalloc(&g->d_inv, std::max<size_t>(n * 4, 4)));
-  GLX_HIP(hipMemcpy(g->d_perm, g->h_perm.data(), n * 4, hipMemcpyHostToDevice));
-  GLX_HIP(hipMemcpy(g->d_inv, g->h_inv.data(), n * 4, hipMemcpyHostToDevice));
+  // through a work set's stream and its page-locked staging: a blocking hipMemcpy runs on the NULL stream, whose copy queue the first
+  // such call of a process creates (9 ms of a fresh model's first fit_predict)
+  glx_work* w = nullptr;
+  int rc = glx_work_acquire(g->device, &w);
+  if (rc) return rc;
+  struct WorkGuard { glx_work* w; ~WorkGuard() { hipStreamSynchronize(w->stream); glx_work_release(w); } } wguard{w};
+  GLX_HIP(hipMemcpyAsync(g->d_perm, g->h_perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, w->stream));
+  GLX_HIP(hipMemcpyAsync(g->d_inv, g->h_inv.data(), (size_t)n * 4, hipMemcpyHostToDevice, w->stream));
+  GLX_HIP(hipStreamSynchronize(w->stream));
   return GLX_OK;
 }
 
@@ -1123,9 +1143,16 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
   GLX_HIP(hipMalloc(&p.d_slice_hdr, std::max<size_t>(16, hdr.size() * sizeof(SliceHdr))));
   GLX_HIP(hipMalloc(&p.d_col, std::max<size_t>(4, (head + stored) * 4)));
   GLX_HIP(hipMalloc(&p.d_val, std::max<size_t>(8, (head + stored) * es)));
-  GLX_HIP(hipMemcpy(p.d_slot_row, slot_row.data(), slot_row.size() * 4, hipMemcpyHostToDevice));
-  GLX_HIP(hipMemcpy(p.d_slot_len, slot_len.data(), slot_len.size() * 4, hipMemcpyHostToDevice));
-  GLX_HIP(hipMemcpy(p.d_slice_hdr, hdr.data(), hdr.size() * sizeof(SliceHdr), hipMemcpyHostToDevice));
+  glx_work* pw = nullptr;              // uploads and the fill run in a work set's stream (no blocking copies on the NULL stream)
+  {
+    int rcw = glx_work_acquire(g->device, &pw);
+    if (rcw) return rcw;
+  }
+  struct WorkGuard { glx_work* w; ~WorkGuard() { hipStreamSynchronize(w->stream); glx_work_release(w); } } pwguard{pw};
+  hipStream_t pst = pw->stream;
+  GLX_HIP(hipMemcpyAsync(p.d_slot_row, slot_row.data(), slot_row.size() * 4, hipMemcpyHostToDevice, pst));
+  GLX_HIP(hipMemcpyAsync(p.d_slot_len, slot_len.data(), slot_len.size() * 4, hipMemcpyHostToDevice, pst));
+  GLX_HIP(hipMemcpyAsync(p.d_slice_hdr, hdr.data(), hdr.size() * sizeof(SliceHdr), hipMemcpyHostToDevice, pst));
   if (nslices > 0) {
     // the CSR arrays as they are: resident on the device already (glx_graph_create_resident), or uploaded into work buffers from
     // the pool that are released after the fill
@@ -1138,26 +1165,27 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
       if (!rc2) rc2 = glx_pool_alloc(&tmp.c, std::max<size_t>((size_t)g->nnz * 8, 8));
       if (rc2) return rc2;
       d_rp = (int32_t*)tmp.a; d_cc = (int32_t*)tmp.b; d_cv = (double*)tmp.c;
-      GLX_HIP(hipMemcpy(d_rp, g->h_rowptr.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+      GLX_HIP(hipMemcpyAsync(d_rp, g->h_rowptr.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, pst));
       if (g->nnz > 0) {
-        GLX_HIP(hipMemcpy(d_cc, g->h_col.data(), (size_t)g->nnz * 4, hipMemcpyHostToDevice));
-        GLX_HIP(hipMemcpy(d_cv, g->h_val.data(), (size_t)g->nnz * 8, hipMemcpyHostToDevice));
+        GLX_HIP(hipMemcpyAsync(d_cc, g->h_col.data(), (size_t)g->nnz * 4, hipMemcpyHostToDevice, pst));
+        GLX_HIP(hipMemcpyAsync(d_cv, g->h_val.data(), (size_t)g->nnz * 8, hipMemcpyHostToDevice, pst));
       }
     }
     const unsigned grid = (unsigned)((nslices + 3) / 4);
     if (g->dtype == GLX_F64)
-      hipLaunchKernelGGL(sell_fill_kernel<double>, dim3(grid), dim3(256), 0, 0, (const int32_t*)d_rp, (const int32_t*)d_cc, (const double*)d_cv,
+      hipLaunchKernelGGL(sell_fill_kernel<double>, dim3(grid), dim3(256), 0, pst, (const int32_t*)d_rp, (const int32_t*)d_cc, (const double*)d_cv,
                          (const int32_t*)(renum ? g->d_perm : nullptr), (const int32_t*)(renum ? g->d_inv : nullptr), (const int32_t*)p.d_slot_row,
                          (const int32_t*)p.d_slot_len, (const SliceHdr*)p.d_slice_hdr, nslices, head, G, p.d_col, (double*)p.d_val,
                          (const double*)g->d_row_scale, g->reverse_rows ? 1 : 0);
     else
-      hipLaunchKernelGGL(sell_fill_kernel<float>, dim3(grid), dim3(256), 0, 0, (const int32_t*)d_rp, (const int32_t*)d_cc, (const double*)d_cv,
+      hipLaunchKernelGGL(sell_fill_kernel<float>, dim3(grid), dim3(256), 0, pst, (const int32_t*)d_rp, (const int32_t*)d_cc, (const double*)d_cv,
                          (const int32_t*)(renum ? g->d_perm : nullptr), (const int32_t*)(renum ? g->d_inv : nullptr), (const int32_t*)p.d_slot_row,
                          (const int32_t*)p.d_slot_len, (const SliceHdr*)p.d_slice_hdr, nslices, head, G, p.d_col, (float*)p.d_val,
                          (const double*)g->d_row_scale, g->reverse_rows ? 1 : 0);
     GLX_HIP(hipGetLastError());
-    GLX_HIP(hipDeviceSynchronize());          // the pooled CSR copies go back before anybody else may draw them
+    GLX_HIP(hipStreamSynchronize(pst));       // the pooled CSR copies go back before anybody else may draw them
   }
+  GLX_HIP(hipStreamSynchronize(pst));         // the host vectors of the plan may go
   lap("uploaded");
   g->plans.push_back(p);
   *out = &g->plans.back();

@@ -1,20 +1,28 @@
-import os, sys, time
+"""The first fit_predict of a fresh ssl.poisson(gradient_descent) model in a process (bench.py: graph_build.fresh_fit_predict_all_ms[0])
+against the following ones: cProfile of the first and of the third call.  Usage: GLX_TIMING=1 python scripts/first_fit_probe.py"""
+import cProfile, pstats, io, os, sys, time
 import numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import graphlearning_amd as gl
 from graphlearning_amd import _hip
-labels = bench.load_labels(70000); X = bench.make_features(labels)
+_hip.require_device()
+labels = bench.load_labels(70000)
+X = bench.make_features(labels)
+gl.weightmatrix.knn(X[:4096], 10)
 W = gl.weightmatrix.knn(X, 10)
 ti = gl.trainsets.generate(labels, rate=1, seed=0)
-m0 = gl.ssl.poisson(W, solver='gradient_descent'); m0.fit_predict(ti, labels[ti])   # process warm-up (code objects)
 for rep in range(3):
-    W2 = gl.weightmatrix.knn(X, 10)
-    m = gl.ssl.poisson(W2, solver='gradient_descent')
-    t0 = time.perf_counter(); dev, aux = m._operators(); t1 = time.perf_counter()
-    sw = _hip.Sweep(dev, 10, 50, 1000, True); t2 = time.perf_counter()
-    sw.set_vectors(aux['deg'], aux['vinf']); t3 = time.perf_counter()
-    sw.close()
-    p = m.fit_predict(ti, labels[ti]); t4 = time.perf_counter()
-    p = m.fit_predict(ti, labels[ti]); t5 = time.perf_counter()
-    print('operators %.1f ms | Sweep create %.1f | set_vectors %.1f | first fit_predict %.1f | second %.2f' % ((t1-t0)*1e3, (t2-t1)*1e3, (t3-t2)*1e3, (t4-t3)*1e3, (t5-t4)*1e3))
+    W = gl.weightmatrix.knn(X, 10)
+    pr = cProfile.Profile()
+    t0 = time.perf_counter()
+    pr.enable()
+    m = gl.ssl.poisson(W, solver='gradient_descent')
+    pred = m.fit_predict(ti, labels[ti])
+    pr.disable()
+    dt = (time.perf_counter() - t0) * 1e3
+    print('--- fresh model %d: %.2f ms' % (rep, dt), flush=True)
+    if rep in (0, 2):
+        s = io.StringIO()
+        pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(12)
+        print('\n'.join(l[:160] for l in s.getvalue().split('\n')[4:26]), flush=True)
