@@ -116,6 +116,7 @@ _SIGNATURES = {
     'glx_cg_multi': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), _f64p],
     'glx_cg_solve': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_sweep_project': [_vp, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
+    'glx_sweep_project_iterate': [_vp, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int],
     'glx_lp_iterate': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_int64, C.c_double, C.c_int64, C.c_int64, C.c_int64,
                        C.POINTER(C.c_int64), C.c_int],
     'glx_affine_iterate': [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int64), _f64p],
@@ -615,18 +616,21 @@ class Sweep:
         check(load().glx_sweep_fetch(self._h, _ptr(out)), 'glx_sweep_fetch')
         return out
 
-    def project(self, priors=None, weights=None, max_steps=0, similarity=True, to_onehot=False, want_labels=True):
+    def project(self, priors=None, weights=None, max_steps=0, similarity=True, to_onehot=False, want_labels=True, then_iterate=0):
         """ssl.predict / ssl.volume_label_projection on the device-resident state; with to_onehot the
-        state becomes onehot(labels).  Returns (labels int64 or None, weights, err, steps)."""
+        state becomes onehot(labels), and then_iterate sweeps are enqueued behind it at once (not awaited).
+        Returns (labels int64 or None, weights, err, steps)."""
         n = self.graph.shape[0]
         w = np.ones(self.C) if weights is None else np.array(weights, dtype=np.float64).reshape(self.C).copy()
         pri = np.zeros(self.C) if priors is None else _dense(priors, np.float64, (self.C,), 'priors')
         labels = pinned_empty((n,), np.int64) if want_labels else None
         err = C.c_double(0)
         steps = C.c_int(0)
-        check(load().glx_sweep_project(self._h, _ptr(pri), _ptr(w), _ptr(labels) if want_labels else None, C.byref(err),
-                                       C.byref(steps), int(max_steps), 1 if similarity else 0, 1 if to_onehot else 0),
-              'glx_sweep_project')
+        check(load().glx_sweep_project_iterate(self._h, _ptr(pri), _ptr(w), _ptr(labels) if want_labels else None, C.byref(err),
+                                               C.byref(steps), int(max_steps), 1 if similarity else 0, 1 if to_onehot else 0,
+                                               int(then_iterate)), 'glx_sweep_project')
+        if to_onehot or then_iterate:
+            self.generation = getattr(self, 'generation', 0) + 1
         return labels, w, err.value, steps.value
 
     def launches(self):

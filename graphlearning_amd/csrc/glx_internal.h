@@ -1,5 +1,6 @@
 // Internal declarations shared by the libglx translation units (gfx950 only).
 #pragma once
+#include <functional>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -344,7 +345,7 @@ int glx_unpack_records(const void* rec, void* dense, int64_t n, const RecLayout&
 struct glx_projector;
 int glx_project_device(glx_projector** pp, const void* dense_dev, int dtype, int64_t n, int C, const double* priors,
                        double* weights_inout, double* err_out, int* steps_out, int max_steps, int similarity, hipStream_t st,
-                       const long long** d_labels_out);
+                       const long long** d_labels_out, const std::function<int(bool)>* hook = nullptr);
 int glx_onehot_device(const long long* d_labels, void* dense_dev, int dtype, int64_t n, int C, hipStream_t st);
 int glx_project_scores(glx_projector** pp, int64_t n, int C, double** scores_out);
 int glx_onehot_records(const long long* d_labels, void* rec, int dtype, int64_t n, const RecLayout& L, const int32_t* perm, hipStream_t st);

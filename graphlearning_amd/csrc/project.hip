@@ -2,6 +2,7 @@
 // (ssl.py:172-209) on device.  All arithmetic is elementwise IEEE fp64 with contraction
 // off and integer class counts, so labels and weights are bit-identical to numpy's.
 #include "glx_internal.h"
+#include <functional>
 #include <algorithm>
 #include <string.h>
 #include <map>
@@ -101,6 +102,7 @@ struct ProjState {
   double* w;        // [C]
   double* priors;   // [C]
   long long* counts;  // [C]
+  long long* cnt_part;   // [blocks][C] per-workgroup class counts of the current step
   double* err;      // [1]
   int* steps;       // [1]
   int* done;        // [1]
@@ -132,21 +134,25 @@ __global__ __launch_bounds__(256) void argmax_hist_kernel(const double* __restri
     if (do_hist) atomicAdd((unsigned long long*)&s_cnt[bi], 1ull);
   }
   if (do_hist) {
+    // The workgroup's class counts leave as one row of plain (agent-scope) stores and the workgroup that arrives last adds the rows:
+    // C atomics per workgroup on the same C addresses cost 22 of this kernel's 26 us at 274 workgroups (profiles/r04_mbo_step.txt) --
+    // same-address atomics from eight XCDs serialise at ~7 ns apiece.
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256)
-      if (s_cnt[c]) atomicAdd((unsigned long long*)&st.counts[c], (unsigned long long)s_cnt[c]);
-  }
-  if (do_hist == 2) {
-    __shared__ int s_last;
-    __threadfence();
+      __hip_atomic_store((unsigned long long*)&st.cnt_part[(size_t)blockIdx.x * C + c], (unsigned long long)s_cnt[c], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    if (!glx_arrive_last((unsigned*)(st.done + 1), gridDim.x, (double*)s_cnt)) return;
+    for (int c = threadIdx.x; c < C; c += 256) s_cnt[c] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd((unsigned int*)(st.done + 1), 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (s_last && threadIdx.x == 0) {
-      __threadfence();
-      st.done[1] = 0;
-      proj_update_step(st, n, C, dt, max_steps);
+    for (int64_t q = threadIdx.x; q < (int64_t)gridDim.x * C; q += 256) {
+      const unsigned long long v = __hip_atomic_load((const unsigned long long*)&st.cnt_part[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v) atomicAdd((unsigned long long*)&s_cnt[q % C], v);
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+      __hip_atomic_store((unsigned long long*)&st.counts[c], (unsigned long long)s_cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (do_hist == 2 && threadIdx.x == 0) proj_update_step(st, n, C, dt, max_steps);
   }
 }
 
@@ -177,6 +183,8 @@ __device__ void proj_update_step(ProjState st, int64_t n, int C, double dt, int 
 struct ProjBufs {
   double *scores = nullptr, *bmin = nullptr, *bmax = nullptr, *state = nullptr;
   long long* labels = nullptr;
+  long long* cnt_part = nullptr;  // [PROJ_ROW_BLOCKS][C]
+  hipEvent_t ev = nullptr;        // behind the copy a host look waits for (work enqueued after it does not hold the look up)
   double* h_image = nullptr;      // page-locked: the state's initial image going up / [w | err | steps | done] coming back
   float* stage32 = nullptr;       // float32 input of the one-shot entry point, before widening
   size_t stage_cap = 0;
@@ -193,7 +201,10 @@ struct ProjBufs {
   double* mm() const { return state + 3 * cap_C + 4; }
   size_t image_words() const { return (size_t)3 * cap_C + 4; }
   void release() {
-    hipFree(scores); hipFree(bmin); hipFree(bmax); hipFree(state); hipFree(labels);
+    hipFree(scores); hipFree(bmin); hipFree(bmax); hipFree(state); hipFree(labels); hipFree(cnt_part);
+    cnt_part = nullptr;
+    if (ev) hipEventDestroy(ev);
+    ev = nullptr;
     if (h_image) hipHostFree(h_image);
     scores = bmin = bmax = state = nullptr;
     labels = nullptr;
@@ -208,7 +219,9 @@ struct ProjBufs {
   }
 };
 
-static int proj_blocks(int64_t total) { return (int)std::min<int64_t>((total + 255) / 256, 1024); }
+// (256 workgroups: every one draws a ticket on ONE address at the end -- 1024 of them were most of the min / max kernel's 17 us)
+static int proj_blocks(int64_t total) { return (int)std::min<int64_t>((total + 255) / 256, 256); }
+static const int PROJ_ROW_BLOCKS = 2048;   // most workgroups of an argmax pass (sizes cnt_part)
 
 static int proj_alloc(ProjBufs& b, int64_t n, int C) {
   if (b.cap_n >= n && b.cap_C == C && b.scores) return GLX_OK;      // (the state block's layout depends on C)
@@ -221,6 +234,8 @@ static int proj_alloc(ProjBufs& b, int64_t n, int C) {
   GLX_HIP(hipMalloc(&b.bmax, nb * 8));
   GLX_HIP(hipMalloc(&b.state, ((size_t)3 * C + 6) * 8));
   GLX_HIP(hipMalloc(&b.labels, keep_n * 8));
+  GLX_HIP(hipMalloc(&b.cnt_part, (size_t)PROJ_ROW_BLOCKS * C * 8));
+  GLX_HIP(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
   GLX_HIP(hipHostMalloc(&b.h_image, ((size_t)3 * C + 6) * 8, hipHostMallocDefault));
   b.cap_n = keep_n;
   b.cap_C = C;
@@ -229,11 +244,15 @@ static int proj_alloc(ProjBufs& b, int64_t n, int C) {
 
 // the decision itself: b.scores holds prob (n, C) fp64 on the device (overwritten by the scores);
 // on return b.labels holds the labels and weights_inout the updated class weights
+// `hook` (optional) is called behind every launch of the FINAL decision: hook(false) enqueues what the caller wants back with the
+// decision (it is waited for), hook(true) what merely follows it (enqueued behind the event the host look waits on, so it runs on
+// while the host goes on: PoissonMBO's one-hot state and its next chunk of heat sweeps).  A decision taken speculatively in the
+// first look and found unfinished is taken again later -- the hook runs again and must be idempotent in that sense.
 static int proj_core(ProjBufs& b, hipStream_t st, int64_t n, int C, const double* priors, double* weights_inout, double* err_out,
-                     int* steps_out, int max_steps, int similarity, bool f32 = false) {
+                     int* steps_out, int max_steps, int similarity, bool f32 = false, const std::function<int(bool)>* hook = nullptr) {
   const int64_t total = n * C;
   const int nb = proj_blocks(total);
-  const int nbr = (int)std::min<int64_t>((n + 255) / 256, 2048);
+  const int nbr = (int)std::min<int64_t>((n + 255) / 256, PROJ_ROW_BLOCKS);
   // one upload sets the whole state: weights, priors, zeroed err / steps / done / tickets / class counts
   memset(b.h_image, 0, b.image_words() * 8);
   memcpy(b.h_image, weights_inout, (size_t)C * 8);
@@ -250,6 +269,7 @@ static int proj_core(ProjBufs& b, hipStream_t st, int64_t n, int C, const double
   ps.w = b.w();
   ps.priors = b.priors();
   ps.counts = b.counts();
+  ps.cnt_part = b.cnt_part;
   ps.err = b.err();
   ps.steps = b.steps();
   ps.done = b.done();
@@ -259,28 +279,49 @@ static int proj_core(ProjBufs& b, hipStream_t st, int64_t n, int C, const double
   double err = 1.0;   // ssl.py:201
   // what comes back lands in the page-locked image (behind the words that went up: the upload has long finished by then)
   double* h_back = b.h_image;
+  bool decided = false;          // b.labels and h_back hold the final decision and state
   if (max_steps > 0) {
     int done = 0;
     // steps per host look: 2, 4, 8 ... PROJ_CHUNK.  Most decisions need one or two steps (class sizes that already match the
     // priors: every thresholding of PoissonMBO at config 5), and every launch past the stopping step still costs its ~4 us:
-    // 32 per look made a one-step projection 0.22 ms; the 10^4-step projections reach the full chunk after four looks
+    // 32 per look made a one-step projection 0.22 ms; the 10^4-step projections reach the full chunk after four looks.
+    // The FIRST look also carries the final decision and the whole state: a projection that stops within two steps is one host
+    // round trip (it was two: ~20 us of idle device each, 21 times per PoissonMBO fit).
     int chunk = 2;
+    bool first = true;
     while (!done) {
       for (int q = 0; q < chunk; ++q) {
         hipLaunchKernelGGL(argmax_hist_kernel, dim3(nbr), dim3(256), shm, st, (const double*)b.scores, n, C, ps, b.labels, similarity, 1, 2, dt, max_steps);
         GLX_HIP(hipGetLastError());
       }
-      GLX_HIP(hipMemcpyAsync(h_back + C + 2, b.done(), 4, hipMemcpyDeviceToHost, st));
-      GLX_HIP(hipStreamSynchronize(st));
+      if (first) {
+        hipLaunchKernelGGL(argmax_hist_kernel, dim3(nbr), dim3(256), shm, st, (const double*)b.scores, n, C, ps, b.labels, similarity, 0, 0, dt, max_steps);
+        GLX_HIP(hipGetLastError());
+        GLX_HIP(hipMemcpyAsync(h_back, b.state, (size_t)(C + 3) * 8, hipMemcpyDeviceToHost, st));      // [w | err | steps | done]
+        if (hook) { int rh = (*hook)(false); if (rh) return rh; }
+        GLX_HIP(hipEventRecord(b.ev, st));
+        if (hook) { int rh = (*hook)(true); if (rh) return rh; }
+        GLX_HIP(hipEventSynchronize(b.ev));
+      } else {
+        GLX_HIP(hipMemcpyAsync(h_back + C + 2, b.done(), 4, hipMemcpyDeviceToHost, st));
+        GLX_HIP(hipStreamSynchronize(st));
+      }
       done = *(const int*)(h_back + C + 2);
+      decided = first && done;
+      first = false;
       chunk = std::min(PROJ_CHUNK, chunk * 2);
     }
   }
-  // final predict with the (updated) weights                                 (ssl.py:209)
-  hipLaunchKernelGGL(argmax_hist_kernel, dim3(nbr), dim3(256), shm, st, (const double*)b.scores, n, C, ps, b.labels, similarity, 0, 0, dt, max_steps);
-  GLX_HIP(hipGetLastError());
-  GLX_HIP(hipMemcpyAsync(h_back, b.state, (size_t)(C + 2) * 8, hipMemcpyDeviceToHost, st));      // [w | err | steps]
-  GLX_HIP(hipStreamSynchronize(st));
+  if (!decided) {
+    // final predict with the (updated) weights                                 (ssl.py:209)
+    hipLaunchKernelGGL(argmax_hist_kernel, dim3(nbr), dim3(256), shm, st, (const double*)b.scores, n, C, ps, b.labels, similarity, 0, 0, dt, max_steps);
+    GLX_HIP(hipGetLastError());
+    GLX_HIP(hipMemcpyAsync(h_back, b.state, (size_t)(C + 2) * 8, hipMemcpyDeviceToHost, st));      // [w | err | steps]
+    if (hook) { int rh = (*hook)(false); if (rh) return rh; }
+    GLX_HIP(hipEventRecord(b.ev, st));
+    if (hook) { int rh = (*hook)(true); if (rh) return rh; }
+    GLX_HIP(hipEventSynchronize(b.ev));
+  }
   memcpy(weights_inout, h_back, (size_t)C * 8);
   if (max_steps > 0) {
     err = h_back[C];
@@ -385,7 +426,7 @@ int glx_project_scores(glx_projector** pp, int64_t n, int C, double** scores_out
 
 int glx_project_device(glx_projector** pp, const void* dense_dev, int dtype, int64_t n, int C, const double* priors,
                        double* weights_inout, double* err_out, int* steps_out, int max_steps, int similarity, hipStream_t st,
-                       const long long** d_labels_out) {
+                       const long long** d_labels_out, const std::function<int(bool)>* hook) {
   GLX_CHECK(pp && dense_dev && weights_inout, GLX_EINVAL, "glx_project_device: null argument");
   GLX_CHECK(max_steps == 0 || priors, GLX_EINVAL, "glx_sweep_project: projection needs priors");
   GLX_CHECK(C <= 4096, GLX_EUNSUPPORTED, "glx_sweep_project: C=%d too large", C);
@@ -400,9 +441,9 @@ int glx_project_device(glx_projector** pp, const void* dense_dev, int dtype, int
   else if ((const void*)b.scores != dense_dev)
     hipLaunchKernelGGL(to_f64_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)dense_dev, b.scores, total);
   GLX_HIP(hipGetLastError());
-  rc = proj_core(b, st, n, C, priors, weights_inout, err_out, steps_out, max_steps, similarity, dtype == GLX_F32);
+  if (d_labels_out) *d_labels_out = b.labels;      // (known before the decision: the hook uses it)
+  rc = proj_core(b, st, n, C, priors, weights_inout, err_out, steps_out, max_steps, similarity, dtype == GLX_F32, hook);
   if (rc) return rc;
-  if (d_labels_out) *d_labels_out = b.labels;
   return GLX_OK;
 }
 

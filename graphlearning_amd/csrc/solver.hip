@@ -364,6 +364,8 @@ extern "C" int glx_sweep_set_problem_rows(glx_sweep* s, int64_t m, const int64_t
   return GLX_OK;
 }
 
+static int enqueue_iterate(glx_sweep* s, int iters);
+
 static int launch_sweep(glx_sweep* s, int t, bool with_stop) {
   SweepArgs a;
   memset(&a, 0, sizeof(a));
@@ -534,10 +536,15 @@ extern "C" int glx_sweep_fetch(glx_sweep* s, void* u_out) {
 // ssl.predict / ssl.volume_label_projection (ssl.py:230-266, 172-209) on the sweep's current state
 // without a host round trip; with to_onehot the state is then replaced by onehot(labels), which is
 // the hand-over between the heat sweeps and the thresholding of PoissonMBO (ssl.py:826-832).
-extern "C" int glx_sweep_project(glx_sweep* s, const double* priors, double* weights_inout, int64_t* labels_out, double* err_out,
-                                 int* steps_out, int max_steps, int similarity, int to_onehot) {
+// then_iterate > 0 (needs to_onehot): that many sweeps are enqueued behind the one-hot state before the host has even seen the
+// decision -- PoissonMBO's next heat chunk (ssl.py:826-832) starts where the thresholding ends instead of two host round trips later
+// (~75 us of idle device per outer step at config 5, profiles/r04_mbo_step.txt).
+extern "C" int glx_sweep_project_iterate(glx_sweep* s, const double* priors, double* weights_inout, int64_t* labels_out, double* err_out,
+                                         int* steps_out, int max_steps, int similarity, int to_onehot, int then_iterate) {
   GLX_CHECK(s && weights_inout, GLX_EINVAL, "glx_sweep_project: null argument");
   GLX_CHECK(!s->has_w || !to_onehot, GLX_EINVAL, "glx_sweep_project: to_onehot needs a sweep created with max_iter = 0");
+  GLX_CHECK(then_iterate >= 0 && (then_iterate == 0 || (to_onehot && s->n_rows == s->n_cols)), GLX_EINVAL,
+            "glx_sweep_project: then_iterate needs to_onehot and a square operator");
   GLX_HIP(hipSetDevice(s->device));
   const int dtype = s->P->dtype;
   // an fp64 state is unpacked straight into the projector's own (n, C) array; a float32 one goes through `dense` and is widened
@@ -552,16 +559,26 @@ extern "C" int glx_sweep_project(glx_sweep* s, const double* priors, double* wei
   rc = glx_unpack_records(s->buf[s->cur], prob, s->n_rows, s->L, dtype, s->stream, s->P->d_perm);
   if (rc) return rc;
   const long long* d_labels = nullptr;
-  rc = glx_project_device(&s->proj, prob, dtype, s->n_rows, s->C, priors, weights_inout, err_out, steps_out, max_steps,
-                          similarity, s->stream, &d_labels);
-  if (rc) return rc;
-  if (labels_out) GLX_HIP(hipMemcpyAsync(labels_out, d_labels, (size_t)s->n_rows * 8, hipMemcpyDeviceToHost, s->stream));
-  if (to_onehot) {
-    rc = glx_onehot_records(d_labels, s->buf[s->cur], dtype, s->n_cols, s->L, s->P->d_perm, s->stream);
-    if (rc) return rc;
-  }
-  GLX_HIP(hipStreamSynchronize(s->stream));
-  return GLX_OK;
+  // what goes with the decision (the labels, waited for) and what follows it (the one-hot state, the next sweeps: enqueued, not
+  // awaited -- the next call on this sweep is ordered behind them in its stream)
+  const std::function<int(bool)> hook = [&](bool after) -> int {
+    if (!after) {
+      if (labels_out) GLX_HIP(hipMemcpyAsync(labels_out, d_labels, (size_t)s->n_rows * 8, hipMemcpyDeviceToHost, s->stream));
+      return GLX_OK;
+    }
+    if (to_onehot) {
+      int rh = glx_onehot_records(d_labels, s->buf[s->cur], dtype, s->n_cols, s->L, s->P->d_perm, s->stream);
+      if (rh) return rh;
+    }
+    return then_iterate > 0 ? enqueue_iterate(s, then_iterate) : GLX_OK;
+  };
+  return glx_project_device(&s->proj, prob, dtype, s->n_rows, s->C, priors, weights_inout, err_out, steps_out, max_steps, similarity,
+                            s->stream, &d_labels, &hook);
+}
+
+extern "C" int glx_sweep_project(glx_sweep* s, const double* priors, double* weights_inout, int64_t* labels_out, double* err_out,
+                                 int* steps_out, int max_steps, int similarity, int to_onehot) {
+  return glx_sweep_project_iterate(s, priors, weights_inout, labels_out, err_out, steps_out, max_steps, similarity, to_onehot, 0);
 }
 
 extern "C" int glx_sweep_launches(const glx_sweep* s, int64_t* n) {
@@ -650,11 +667,7 @@ extern "C" int glx_sweep_set_state_labels(glx_sweep* s, const int64_t* labels, i
   return GLX_OK;
 }
 
-extern "C" int glx_sweep_iterate(glx_sweep* s, int iters) {
-  GLX_CHECK(s && iters >= 0, GLX_EINVAL, "glx_sweep_iterate: bad argument");
-  GLX_CHECK(!s->has_w, GLX_EINVAL, "glx_sweep_iterate: only for sweeps created with max_iter = 0");
-  GLX_CHECK(s->n_rows == s->n_cols, GLX_EINVAL, "glx_sweep_iterate: operator must be square");
-  GLX_HIP(hipSetDevice(s->P->device));
+static int enqueue_iterate(glx_sweep* s, int iters) {
   int rc;
   if (s->use_graph && iters > 1) {
     const long key = (long)iters * 4 + s->cur * 2 + (s->bias_set ? 1 : 0);
@@ -685,9 +698,17 @@ extern "C" int glx_sweep_iterate(glx_sweep* s, int iters) {
       if (rc) return rc;
     }
   }
+  return GLX_OK;
+}
+
+extern "C" int glx_sweep_iterate(glx_sweep* s, int iters) {
+  GLX_CHECK(s && iters >= 0, GLX_EINVAL, "glx_sweep_iterate: bad argument");
+  GLX_CHECK(!s->has_w, GLX_EINVAL, "glx_sweep_iterate: only for sweeps created with max_iter = 0");
+  GLX_CHECK(s->n_rows == s->n_cols, GLX_EINVAL, "glx_sweep_iterate: operator must be square");
+  GLX_HIP(hipSetDevice(s->P->device));
   // (enqueued, not awaited: whatever reads the state next -- glx_sweep_project, glx_sweep_fetch, another glx_sweep_iterate -- runs
   // in this sweep's stream behind it; PoissonMBO's 20 outer steps each saved a host round trip)
-  return GLX_OK;
+  return enqueue_iterate(s, iters);
 }
 
 extern "C" int glx_spmm_bias(glx_graph* A, const void* Db, const void* u_in, void* u_out, int C, int iters) {

@@ -717,11 +717,14 @@ class poisson_mbo(ssl):
             heat.set_state_labels(labels, rows, mu * dt * source[rows])
         else:
             heat.set_state(utils.labels_to_onehot(labels, k), mu * dt * source)    # reference ssl.py:798, 805
-        for i in range(T):
+        if T > 0:
             heat.iterate(Ns)                                # Ns x `u = P*u + Db`, reference ssl.py:826-827
+        for i in range(T):
             w = np.ones((k,)) if type(self.weights) == int else self.weights
-            labels, w, err, _ = heat.project(self.class_priors, w, max_steps=10000, similarity=self.similarity,
-                                             to_onehot=True, want_labels=all_labels is not None)   # reference ssl.py:830-832
+            # the thresholding (reference ssl.py:830-832) hands the next outer step's Ns sweeps to the device together with the
+            # one-hot state it writes: no host round trip between the two
+            labels, w, err, _ = heat.project(self.class_priors, w, max_steps=10000, similarity=self.similarity, to_onehot=True,
+                                             want_labels=all_labels is not None, then_iterate=Ns if i + 1 < T else 0)
             self.weights = w
             self.class_priors_error = err
             if all_labels is not None:

@@ -347,6 +347,11 @@ int glx_argmax_project_t(const void* prob, int prob_dtype, int64_t n, int C, con
  * the volume-constrained thresholding of ssl.poisson_mbo._fit (graphlearning/ssl.py:826-832). */
 int glx_sweep_project(glx_sweep* s, const double* priors, double* weights_inout, int64_t* labels_out,
                       double* err_out, int* steps_out, int max_steps, int similarity, int to_onehot);
+/* The same, and -- then_iterate > 0, needs to_onehot -- that many sweeps enqueued behind the one-hot state before the call returns
+ * (not awaited: the next call on this sweep is ordered behind them): PoissonMBO's thresholding and its next chunk of heat sweeps
+ * (ssl.py:826-832) without a host round trip between them. */
+int glx_sweep_project_iterate(glx_sweep* s, const double* priors, double* weights_inout, int64_t* labels_out, double* err_out,
+                              int* steps_out, int max_steps, int similarity, int to_onehot, int then_iterate);
 
 
 /* ---- kNN graph construction --------------------------------------------------------
