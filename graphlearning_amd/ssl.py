@@ -789,6 +789,22 @@ def _neg_columns_times_rows(L, Lcsc, cols, F):
     return rows_s[seg_start].astype(np.int32), out
 
 
+AUTO_TREE_MAX_ITER = 200
+
+
+def _solve(run, reduce):
+    """run(mode) -> (x, iterations, err).  reduce='auto': the tolerance mode ('tree'), handed back to the reference-order reductions
+    ('exact') when its answer is not one the 1e-5 contract covers -- a solve of more than AUTO_TREE_MAX_ITER iterations (hundreds of
+    iterations amplify the reordered sums: one 647-iteration solve of profiles/r04_tree_vs_exact.txt stopped an iteration apart) or a
+    non-finite iterate (a singular system breaks down with another NaN pattern)."""
+    if reduce != 'auto':
+        return run(reduce)
+    out = run('tree')
+    if int(np.max(out[1])) > AUTO_TREE_MAX_ITER or not np.isfinite(np.asarray(out[0])).all():
+        out = run('exact')
+    return out
+
+
 class laplace(ssl):
     def __init__(self, W=None, class_priors=None, X=None, reweighting='none', normalization='combinatorial', tau=0,
                  order=1, mean_shift=False, tol=1e-5, alpha=2, zeta=1e7, r=0.1, reduce='exact'):
@@ -796,7 +812,8 @@ class laplace(ssl):
         Jacobi-scaled multi-RHS conjugate gradient on the GPU.  Reweightings 'poisson' and 'wnll'
         (graph.reweight, reference graph.py:368-466) are supported; 'properly' is not.
 
-        reduce (not in the reference): 'exact' (default) keeps numpy's reduction order, so iterates and
+        reduce (not in the reference): 'auto' = 'tree' unless the solve runs long or breaks down (see _solve);
+        'exact' (default) keeps numpy's reduction order, so iterates and
         iteration counts are bit-identical to the reference; 'tree' is the tolerance mode for this SPD
         system -- block-tree reductions, about 3x faster per fit, same labels, iterates within 1e-5
         (the solve converges to tol=1e-5 either way; include/glx.h GLX_CG_TREE)."""
@@ -900,14 +917,15 @@ class laplace(ssl):
             if sp is not None:
                 # `v = M*v` (ssl.py:1250) is applied on the device on the way out
                 rows, Mb = sp
-                u, its, _ = dev.cg_groups_rows(rows, Mb, k, masks=[train_ind], out_scale=Mv, tol=self.tol, reduce=self.reduce)
+                u, its, _ = _solve(lambda mode: dev.cg_groups_rows(rows, Mb, k, masks=[train_ind], out_scale=Mv, tol=self.tol, reduce=mode),
+                                   self.reduce)
                 self.num_iter = int(its[0])
                 u[train_ind, :] = F                              # reference ssl.py:1253-1255
                 if self.mean_shift:
                     u -= np.mean(u, axis=0)
                 return u
             F, B, k = self._rhs(L, Mv, train_ind, train_labels)
-            x, its, _ = dev.cg_groups(B, k, tol=self.tol, masks=[train_ind], reduce=self.reduce)
+            x, its, _ = _solve(lambda mode: dev.cg_groups(B, k, tol=self.tol, masks=[train_ind], reduce=mode), self.reduce)
             self.num_iter = int(its[0])
             return self._assemble(x, Mv, train_ind, F)
         # reweighted graphs depend on the training set: per-fit sub-matrix, reference ssl.py:1211-1250 line by line
@@ -928,7 +946,8 @@ class laplace(ssl):
         M = sparse.spdiags(1 / np.sqrt(M + 1e-10), 0, m, m).tocsr()   # reference ssl.py:1244-1246
         dev = _hip.DeviceGraph(M * A * M, dtype=self.dtype, device=self.device, keep_order=True)
         try:
-            v, it, _ = dev.cg(np.ascontiguousarray(M * b, dtype=self.dtype), tol=self.tol, reduce=self.reduce)   # reference ssl.py:1249
+            rhs = np.ascontiguousarray(M * b, dtype=self.dtype)
+            v, it, _ = _solve(lambda mode: dev.cg(rhs, tol=self.tol, reduce=mode), self.reduce)   # reference ssl.py:1249
         finally:
             dev.close()
         self.num_iter = it
@@ -956,8 +975,8 @@ class laplace(ssl):
         k = parts[0][2]
         if any(p[2] != k for p in parts):
             return None
-        x, its, _ = dev.cg_groups(np.hstack([p[1] for p in parts]), k, tol=self.tol, masks=[np.asarray(ti) for ti, _ in trials],
-                                  reduce=self.reduce)
+        Bs, masks = np.hstack([p[1] for p in parts]), [np.asarray(ti) for ti, _ in trials]
+        x, its, _ = _solve(lambda mode: dev.cg_groups(Bs, k, tol=self.tol, masks=masks, reduce=mode), self.reduce)
         self.num_iter = [int(i) for i in its]
         return [self._assemble(np.ascontiguousarray(x[:, j * k:(j + 1) * k]), Mv, np.asarray(trials[j][0]), parts[j][0])
                 for j in range(len(trials))]
@@ -1007,7 +1026,8 @@ class randomwalk(ssl):
 
     def _fit(self, train_ind, train_labels, all_labels=None):
         M, dev = self._operator()
-        u, it, _ = dev.cg(np.ascontiguousarray(M * self._rhs(train_ind, train_labels)), tol=1e-6, reduce=self.reduce)   # reference ssl.py:1790
+        rhs = np.ascontiguousarray(M * self._rhs(train_ind, train_labels))
+        u, it, _ = _solve(lambda mode: dev.cg(rhs, tol=1e-6, reduce=mode), self.reduce)   # reference ssl.py:1790
         self.num_iter = it
         return M * u
 
@@ -1022,7 +1042,8 @@ class randomwalk(ssl):
         k = Ys[0].shape[1]
         if any(Y.shape[1] != k for Y in Ys):
             return None
-        x, its, _ = dev.cg_groups(np.hstack(Ys), k, tol=1e-6, reduce=self.reduce)
+        Bs = np.hstack(Ys)
+        x, its, _ = _solve(lambda mode: dev.cg_groups(Bs, k, tol=1e-6, reduce=mode), self.reduce)
         self.num_iter = [int(i) for i in its]
         return [M * np.ascontiguousarray(x[:, j * k:(j + 1) * k]) for j in range(len(trials))]
 

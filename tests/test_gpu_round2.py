@@ -441,3 +441,36 @@ def test_operator_cache_follows_in_place_edits_of_W(golden):
 def sparse_csr(W):
     from scipy import sparse
     return sparse.csr_matrix(W)
+
+
+def test_reduce_auto_is_the_tolerance_mode_until_a_solve_runs_long(gl, golden, monkeypatch):
+    """reduce='auto' (ssl._solve): the tolerance mode's answer while the solve stays short, the reference-order answer -- bit for bit --
+    once it takes more than AUTO_TREE_MAX_ITER iterations (there the reordered sums may move the stopping iteration) or produces a
+    non-finite iterate."""
+    from graphlearning_amd import ssl as glssl
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    ti, lab = g['train_ind'], g['labels']
+    exact, tree, auto = gl.ssl.laplace(W), gl.ssl.laplace(W, reduce='tree'), gl.ssl.laplace(W, reduce='auto')
+    ue, ut, ua = exact.fit(ti, lab[ti]), tree.fit(ti, lab[ti]), auto.fit(ti, lab[ti])
+    assert exact.num_iter <= glssl.AUTO_TREE_MAX_ITER
+    assert np.array_equal(ua, ut) and auto.num_iter == tree.num_iter and np.max(np.abs(ua - ue)) <= 1e-5
+    # the same solve with the bound below its iteration count: handed back to the exact mode
+    monkeypatch.setattr(glssl, 'AUTO_TREE_MAX_ITER', max(1, exact.num_iter // 2))
+    ub = auto.fit(ti, lab[ti])
+    assert np.array_equal(ub, ue) and auto.num_iter == exact.num_iter
+    rw_e, rw_a = gl.ssl.randomwalk(W), gl.ssl.randomwalk(W, reduce='auto')
+    assert np.array_equal(rw_a.fit(ti, lab[ti]), rw_e.fit(ti, lab[ti]))          # (bound still lowered: the exact answer)
+    monkeypatch.setattr(glssl, 'AUTO_TREE_MAX_ITER', 200)
+    assert np.max(np.abs(rw_a.fit(ti, lab[ti]) - rw_e.fit(ti, lab[ti]))) <= 1e-5
+    # a non-finite tolerance-mode result goes back as well (simulated: the runner poisons the tolerance-mode answer)
+    calls = []
+
+    def run(mode):
+        calls.append(mode)
+        x = np.ones((3, 2))
+        if mode == 'tree':
+            x[1, 1] = np.nan
+        return x, np.array([5]), np.array([0.0])
+    out = glssl._solve(run, 'auto')
+    assert calls == ['tree', 'exact'] and np.isfinite(out[0]).all()
