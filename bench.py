@@ -351,7 +351,7 @@ def other_configs(W2, labels2, ti2, device_sync, knn_stats2, X2):
     return out
 
 
-def measure_traffic(timeout_s=240):
+def measure_traffic(timeout_s=120):
     """HBM-side bytes per launch of the dominant kernel, MEASURED for this build: two child passes of this script
     under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need separate passes, MI355X_MICROARCH.md), per-dispatch means
     over the sweep kernel's dispatches.  gfx950 correction from the same guide: FETCH_SIZE counts 128-byte requests as
@@ -369,8 +369,16 @@ def measure_traffic(timeout_s=240):
         cmd = ['rocprofv3', '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'run', '--',
                sys.executable, os.path.abspath(__file__), '--traffic-child']
         try:
-            subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                           timeout=timeout_s)
+            # (its own process group: a pass that outlives the limit is ended together with the profiled child, by that group's id)
+            proc = subprocess.Popen(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL,
+                                    stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None, '%s pass exceeded %d s' % (ctr, timeout_s)
             fs = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
             tot, cnt = 0.0, 0
             for f in fs:
