@@ -318,6 +318,9 @@ def other_configs(W2, labels2, ti2, device_sync, knn_stats2, X2):
                          'sample': '%d scipy sweeps u = P*u + Db of the same operator in %.1f s (the reference\'s fit is 851 of them plus 21 '
                                    'projections)' % (ncpu, t_cpu5)}}
 
+    # ---- stacked gradient-descent trials on the config-2 graph (ssl.ssl_trials: B training sets as column groups of ONE sweep) ----
+    out['trials_gd'] = trials_gd_block(W2, labels2, ti2, device_sync)
+
     # ---- weightmatrix.knn at config 2 ------------------------------------------------------------------------------------------
     ms = _median_ms(lambda: gl.weightmatrix.knn(X2, K_NN), device_sync, min_reps=5, min_s=0.1)
     st = _hip.knn_stats()
@@ -349,6 +352,70 @@ def other_configs(W2, labels2, ti2, device_sync, knn_stats2, X2):
                                    '%.2f s; the GPU search answers all 70000 in the `ms` above' % (nq, t_q, t_tree),
                          'gpu_queries_per_s': n2 / (ms[0] * 1e-3)}}
     return out
+
+
+def grouped_algorithmic_bytes(n, nnz, C, B, s_v=8, s_u=8):
+    """SURVEY.md 8d's per-sweep bytes for B training sets as C B columns of one sweep: the operator's values + 4-byte indices and the
+    row pointer ONCE, read u + read Db + write u for C B columns, B fp64 stop columns read + written."""
+    return nnz * (s_v + 4) + 4 * (n + 1) + 3 * n * C * B * s_u + 2 * n * 8 * B
+
+
+def trials_gd_block(W, labels, ti0, device_sync, B_head=8):
+    """ssl.poisson(solver='gradient_descent') over B training sets at once (glx_sweep_groups; reference ssl.py:292-396 runs them one
+    `_fit` at a time): the config-2 training set and published MNIST permutation sets / generated ones as column groups of ONE sweep.
+    Timed like the headline: T sweeps per step inside the prepared launch graph, HIP events on the library's stream for the
+    per-launch time, median of synchronised repetitions for the wall time; every trial checked against the oracle."""
+    import graphlearning_amd as gl
+    from graphlearning_amd import ssl as glssl
+    from oracle import gl_oracle as orc
+    n, nnz, C = W.shape[0], int(W.nnz), N_CLASSES
+    g6 = np.load(os.path.join(ROOT, 'tests', 'golden', 'g6_helpers.npz'))
+    pool = [ti0] + [g6['mnist_perm_%d' % i] for i in range(10) if ('mnist_perm_%d' % i) in g6.files]
+    pool += [gl.trainsets.generate(labels, rate=1 + s % 3, seed=100 + s) for s in range(24)]
+    block = {'workload': 'configs[1] graph, ssl.poisson(solver=gradient_descent) over B training sets as C B = %d B columns of one sweep '
+                         '(the config-2 set, the published MNIST permutation sets of tests/golden/g6_helpers.npz, generated sets)' % C,
+             'scan': []}
+    old = glssl.GD_TRIAL_BATCH
+    try:
+        for B in (2, 4, B_head, 12, 16):
+            if not glssl._gd_fits(C, B, np.float64):
+                continue
+            glssl.GD_TRIAL_BATCH = B
+            model = gl.ssl.poisson(W, solver='gradient_descent')
+            trials = [(t, labels[t]) for t in pool[:B]]
+            res = model._fit_batch_device(trials)
+            Ts = list(model.num_iter)
+            groups = model._operators()[1]['groups']
+            for _ in range(3):
+                groups.run(used=B)
+            l0, dev_ms, reps = groups.launches(), 0.0, 0
+            while reps < 10 or dev_ms < 100.0:
+                dev_ms += groups.run(used=B)[1]
+                reps += 1
+            launches = groups.launches() - l0
+            per = dev_ms * 1e-3 / max(launches, 1)
+            wall = _median_ms(lambda: groups.run(used=B), device_sync, min_reps=5, min_s=0.1)
+            ab = grouped_algorithmic_bytes(n, nnz, C, B)
+            sweeps = max(Ts)
+            entry = {'B': B, 'T': Ts, 'avg_launch_us': per * 1e6, 'step_ms_wall': wall[0], 'sweeps_per_step': sweeps,
+                     'trial_sweeps_per_s': B * sweeps / (wall[0] * 1e-3), 'edges_classes_per_s': float(nnz) * C * B * sweeps / (wall[0] * 1e-3),
+                     'algorithmic_bytes_per_launch': ab,
+                     'roofline': {'bound': 'hbm', 'achieved': ab / per / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ab / per / 1e9 / HBM_PEAK_GBS}}
+            if B == B_head:
+                ok = True
+                for j, (t, tl) in enumerate(trials):
+                    u_ref, T_ref = orc.poisson_gd(W, t, tl, return_T=True)
+                    # (res was produced by the FIRST run; the timing runs above repeat the same solve into the same state)
+                    ok = ok and Ts[j] == T_ref and bool(np.array_equal(np.asarray(groups.fetch(j)), u_ref))
+                entry['parity'] = {'every_trial_bit_identical_to_oracle_and_T_equal': bool(ok), 'trials_checked': len(trials)}
+                block.update({k: v for k, v in entry.items() if k != 'B'})
+                block['B'] = B
+            block['scan'].append(entry)
+            model._cache[2]['groups'].close()
+            model._cache[1].close()
+    finally:
+        glssl.GD_TRIAL_BATCH = old
+    return block
 
 
 def measure_traffic(timeout_s=120):
@@ -543,6 +610,10 @@ def run_single(args):
 
 def run_distributed(args):
     from graphlearning_amd import dist_bench
+    if args.force_collectives:
+        import torch  # noqa: F401  (first: libglx must bind to torch's HIP runtime, see graphlearning_amd/dist.py)
+        from graphlearning_amd import dist as gdist
+        gdist.FORCE_COLLECTIVES = True
     if args.dist_dry_run:
         dist_bench.main_dry_run(args)
     elif args.config == 4:
@@ -569,8 +640,8 @@ def spawn_ranks(args, argv):
     import subprocess
     n = int(args.gpus)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
-    env = dict(os.environ, GLX_BENCH_SPAWNED='1')
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv) + ['--spawned']
+    env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs between processes on this driver
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(n, 1))))
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -609,6 +680,11 @@ def main():
     ap.add_argument('--min-timed-s', type=float, default=0.5,
                     help='batches of --steps steps are repeated until this many seconds have been timed (at least 5 batches).  Profiling runs '
                          'pass 0: rocprofv3 of ROCm 7.2 segfaults after 16 384 dispatches launched from device graphs (profiles/README.md)')
+    ap.add_argument('--engine', default='glx', choices=['glx', 'torch'],
+                    help='multi-GPU runs: the library-owned RCCL communicator with captured sweeps (default) or the torch.distributed engine')
+    ap.add_argument('--force-dist', action='store_true', help='take the distributed path with one rank (tests)')
+    ap.add_argument('--force-collectives', action='store_true', help='distributed path: issue the collectives even with one rank (tests)')
+    ap.add_argument('--spawned', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--dist-dry-run', action='store_true',
                     help='start the ranks, rendezvous over gloo, count them, print one line and stop: checks the launch path without a GPU')
@@ -620,7 +696,7 @@ def main():
     if args.gpus > 1 and not launched:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
     if (args.gpus > 1 or args.config == 4 or args.dist_dry_run or int(os.environ.get('WORLD_SIZE', '1')) > 1
-            or os.environ.get('GLX_BENCH_FORCE_DIST') == '1'):
+            or args.force_dist):
         run_distributed(args)
     else:
         run_single(args)

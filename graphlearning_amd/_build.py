@@ -25,7 +25,7 @@ def sources():
 
 
 def headers():
-    return glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(HERE, '..', 'include', 'glx.h')]
+    return glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(HERE, '..', 'include', h) for h in ('glx.h', 'glx_experimental.h')]
 
 
 def _hipcc():

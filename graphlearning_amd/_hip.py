@@ -59,7 +59,6 @@ _vp = C.c_void_p
 _SIGNATURES = {
     'glx_version': [],
     'glx_device_count': [C.POINTER(C.c_int)],
-    'glx_set_device': [C.c_int],
     'glx_device_synchronize': [],
     'glx_host_alloc': [C.c_size_t, C.POINTER(_vp)],
     'glx_host_free': [_vp],
@@ -67,7 +66,6 @@ _SIGNATURES = {
     'glx_graph_create_resident': [C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)],
     'glx_graph_set_row_transform': [_vp, _vp, C.c_int],
     'glx_graph_destroy': [_vp],
-    'glx_graph_keep_order': [_vp],
     'glx_graph_info': [_vp, _i64p],
     'glx_graph_order': [_vp, _vp],
     'glx_graph_set_order': [_vp, _vp],
@@ -85,6 +83,15 @@ _SIGNATURES = {
     'glx_sweep_set_state': [_vp, _vp, _vp],
     'glx_sweep_set_state_labels': [_vp, _vp, C.c_int64, _vp, _vp],
     'glx_sweep_iterate': [_vp, C.c_int],
+    'glx_sweep_groups_create': [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)],
+    'glx_sweep_groups_set_vectors': [_vp, _vp, _vp],
+    'glx_sweep_groups_set_problem_rows': [_vp, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_double],
+    'glx_sweep_groups_run': [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)],
+    'glx_sweep_groups_stop_values': [_vp, C.c_int, C.c_int64, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    'glx_sweep_groups_fetch': [_vp, C.c_int, _vp],
+    'glx_sweep_groups_project': [_vp, C.c_int, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int],
+    'glx_sweep_groups_launches': [_vp, _i64p],
+    'glx_sweep_groups_destroy': [_vp],
     'glx_record_layout': [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)],
     'glx_graph_slots': [_vp, C.c_int, C.c_int, _i64p],
     'glx_bias_flags_dev': [_vp, C.c_int, C.c_int, _vp, _vp, _vp],
@@ -115,12 +122,10 @@ _SIGNATURES = {
     'glx_dist_sweep_interior': [_vp, C.c_int, _f64p],
     'glx_cg_multi': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), _f64p],
     'glx_cg_solve': [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
-    'glx_sweep_project': [_vp, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int],
     'glx_sweep_project_iterate': [_vp, _vp, _vp, _vp, _f64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int],
     'glx_lp_iterate': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_int64, C.c_double, C.c_int64, C.c_int64, C.c_int64,
                        C.POINTER(C.c_int64), C.c_int],
     'glx_affine_iterate': [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int64), _f64p],
-    'glx_cg_groups': [_vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_cg_groups_masked': [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_cg_groups_rows': [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_int64, C.c_int,
                            C.POINTER(C.c_int), _f64p],
@@ -356,7 +361,7 @@ class DeviceGraph:
                 raise GlxError('order must be a permutation of the %d rows' % self.shape[0])
             check(lib.glx_graph_set_order(self._h, _ptr(perm)), 'glx_graph_set_order')
         elif keep_order:
-            check(lib.glx_graph_keep_order(self._h), 'glx_graph_keep_order')
+            check(lib.glx_graph_set_order(self._h, None), 'glx_graph_set_order')
 
     @classmethod
     def resident(cls, A, dtype=np.float64, device=None, keep_order=False, order=None, want_row_sums=False):
@@ -468,8 +473,8 @@ class DeviceGraph:
         its = np.zeros(ng, dtype=np.int32)
         errs = np.zeros(ng, dtype=np.float64)
         if masks is None:
-            check(load().glx_cg_groups(self._h, _ptr(B), _ptr(X), B.shape[1], int(group_cols), float(tol), int(max_iter), flags,
-                                       its.ctypes.data_as(C.POINTER(C.c_int)), errs.ctypes.data_as(_f64p)), 'glx_cg_groups')
+            check(load().glx_cg_groups_masked(self._h, _ptr(B), _ptr(X), B.shape[1], int(group_cols), None, None, float(tol), int(max_iter),
+                                              flags, its.ctypes.data_as(C.POINTER(C.c_int)), errs.ctypes.data_as(_f64p)), 'glx_cg_groups_masked')
             return X, its, errs
         if len(masks) != ng:
             raise GlxError('cg_groups: %d masks for %d systems' % (len(masks), ng))
@@ -650,6 +655,110 @@ class Sweep:
             self.close()
         except Exception:
             pass
+
+
+class SweepGroups:
+    """Several training sets as column groups of ONE prepared Poisson sweep (glx_sweep_groups): trial b owns columns
+    b C .. b C + C - 1, its own stop value and its own stop test; every trial's iterate and T are those of its own fit."""
+
+    def __init__(self, graph, Cc, B, min_iter=50, max_iter=1000):
+        self.graph = graph
+        self.C = Cc
+        self.B = B
+        self.generation = 0
+        self._h = _vp()
+        check(load().glx_sweep_groups_create(graph._h, Cc, B, min_iter, max_iter, C.byref(self._h)), 'glx_sweep_groups_create')
+
+    def set_vectors(self, deg, vinf):
+        n = self.graph.shape[0]
+        check(load().glx_sweep_groups_set_vectors(self._h, _ptr(_dense(deg, np.float64, (n,))), _ptr(_dense(vinf, np.float64, (n,)))),
+              'glx_sweep_groups_set_vectors')
+
+    def set_problem_rows(self, b, rows, Db_rows, w0_rows, err0):
+        rows = np.ascontiguousarray(rows, dtype=np.int64).ravel()
+        m = len(rows)
+        Db_rows = _dense(Db_rows, self.graph.dtype, (m, self.C), 'Db_rows')
+        w0_rows = _dense(w0_rows, np.float64, (m,), 'w0_rows')
+        check(load().glx_sweep_groups_set_problem_rows(self._h, int(b), m, _ptr(rows), _ptr(Db_rows), _ptr(w0_rows), float(err0)),
+              'glx_sweep_groups_set_problem_rows')
+
+    def run(self, used=None):
+        """Returns (T per group in use, device ms)."""
+        used = self.B if used is None else int(used)
+        T = (C.c_int * self.B)()
+        ms = C.c_float(0)
+        check(load().glx_sweep_groups_run(self._h, used, T, C.byref(ms)), 'glx_sweep_groups_run')
+        self.generation += 1
+        return [int(T[b]) for b in range(used)], ms.value
+
+    def stop_values(self, b):
+        first, count = C.c_int(0), C.c_int(0)
+        check(load().glx_sweep_groups_stop_values(self._h, int(b), 0, None, C.byref(first), C.byref(count)), 'glx_sweep_groups_stop_values')
+        vals = np.empty(count.value, dtype=np.float64)
+        check(load().glx_sweep_groups_stop_values(self._h, int(b), len(vals), _ptr(vals), C.byref(first), C.byref(count)),
+              'glx_sweep_groups_stop_values')
+        return first.value, vals
+
+    def fetch(self, b):
+        out = pinned_empty((self.graph.shape[0], self.C), self.graph.dtype)
+        check(load().glx_sweep_groups_fetch(self._h, int(b), _ptr(out)), 'glx_sweep_groups_fetch')
+        return out
+
+    def project(self, b, priors=None, weights=None, max_steps=0, similarity=True, want_labels=True):
+        n = self.graph.shape[0]
+        w = np.ones(self.C) if weights is None else np.array(weights, dtype=np.float64).reshape(self.C).copy()
+        pri = np.zeros(self.C) if priors is None else _dense(priors, np.float64, (self.C,), 'priors')
+        labels = pinned_empty((n,), np.int64) if want_labels else None
+        err = C.c_double(0)
+        steps = C.c_int(0)
+        check(load().glx_sweep_groups_project(self._h, int(b), _ptr(pri), _ptr(w), _ptr(labels) if want_labels else None, C.byref(err),
+                                              C.byref(steps), int(max_steps), 1 if similarity else 0), 'glx_sweep_groups_project')
+        return labels, w, err.value, steps.value
+
+    def launches(self):
+        n = C.c_int64(0)
+        check(load().glx_sweep_groups_launches(self._h, C.byref(n)), 'glx_sweep_groups_launches')
+        return n.value
+
+    def view(self, b):
+        return GroupView(self, b)
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            lib = load(required=False)
+            if lib is not None:
+                lib.glx_sweep_groups_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GroupView:
+    """Group b of a SweepGroups with the face of a Sweep (C, fetch, project, generation, _h): what ssl._DeviceState needs to leave a
+    trial's result on the device until somebody looks at it."""
+
+    def __init__(self, groups, b):
+        self.groups, self.b, self.C = groups, int(b), groups.C
+
+    @property
+    def _h(self):
+        return self.groups._h
+
+    @property
+    def generation(self):
+        return self.groups.generation
+
+    def fetch(self):
+        return self.groups.fetch(self.b)
+
+    def project(self, priors=None, weights=None, max_steps=0, similarity=True, to_onehot=False, want_labels=True, then_iterate=0):
+        if to_onehot or then_iterate:
+            raise GlxError('a stacked trial has no heat loop of its own')
+        return self.groups.project(self.b, priors, weights, max_steps=max_steps, similarity=similarity, want_labels=want_labels)
 
 
 # Communicators and distributed sweeps that are still open when the interpreter shuts down are ABANDONED, not destroyed:

@@ -38,7 +38,10 @@ __global__ void knn_weights_kernel(const int64_t* __restrict__ ind, const double
     v = exp_cr(a / eps);
   } else if (kernel == K_SYMGAUSSIAN) {
     const double ei = dist[i * kk + k - 1];
-    const double ej = dist[ind[i * kk + t] * kk + k - 1];
+    // (an index outside [0, n) is reported by count_reverse_kernel, which runs behind this kernel: here it must not become an
+    // out-of-bounds read -- user-supplied knn_data reaches this kernel unchecked)
+    const int64_t jn = ind[i * kk + t];
+    const double ej = dist[(jn >= 0 && jn < n ? jn : i) * kk + k - 1];
     const double a = -4.0 * d;
     const double b = a * d;
     const double c = b / ei;

@@ -777,14 +777,9 @@ extern "C" int glx_cg_groups_rows(glx_graph* A, int64_t nb, const int32_t* b_row
   return cg_entry(A, nullptr, X, C, group_cols, mask_rows, mask_ptr, tol, max_iter, flags, iters_out, err_out, rr);
 }
 
-extern "C" int glx_cg_groups(glx_graph* A, const void* B, void* X, int C, int group_cols, double tol, int64_t max_iter, int flags,
-                             int* iters_out, double* err_out) {
-  return glx_cg_groups_masked(A, B, X, C, group_cols, nullptr, nullptr, tol, max_iter, flags, iters_out, err_out);
-}
-
 extern "C" int glx_cg_solve(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int flags,
                             int* iters_out, double* err_out) {
-  return glx_cg_groups(A, B, X, C, C, tol, max_iter, flags, iters_out, err_out);
+  return glx_cg_groups_masked(A, B, X, C, C, nullptr, nullptr, tol, max_iter, flags, iters_out, err_out);
 }
 
 extern "C" int glx_cg_multi(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int* iters_out,

@@ -328,13 +328,19 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
   if (nmask) CG_NEED(b.f_rowmask, (size_t)n * 4);
   {
     // the host's mirror of the residual history: the maximum slot of every row a solve may write holds NaN = "not yet written"
-    const bool fresh = !b.h_hist || b.h_hist_rows < hist_cap * stride;
+    // A marker is only where the LAYOUT of the solve that armed it put it: another number of systems (ssl_trials' stacked solve
+    // followed by a single fit on the same operator) or a longer history moves the marker slots onto words that hold an earlier
+    // solve's residuals, which the poll below would take for rows already written.  So the markers are re-armed row by row only
+    // while the layout stays the same; any change (or a new buffer) fills the whole mirror.
+    const bool fresh = !b.h_hist || b.h_hist_rows < hist_cap * stride || b.h_hist_stride != stride;
     int rc_ = b.need_host(&b.h_hist, (size_t)hist_cap * stride * 8);
     if (rc_) return rc_;
     const double not_yet = std::numeric_limits<double>::quiet_NaN();
     if (fresh) {
-      b.h_hist_rows = hist_cap * stride;
-      for (int64_t j = 0; j < hist_cap; ++j) b.h_hist[(size_t)j * stride + ngroups] = not_yet;
+      const int64_t words = (int64_t)(b.cap[(void**)&b.h_hist] / 8);
+      for (int64_t j = 0; j < words; ++j) b.h_hist[j] = not_yet;
+      b.h_hist_rows = words;
+      b.h_hist_stride = stride;
     } else {
       for (int64_t j = 0; j <= std::min<int64_t>(b.h_hist_dirty, hist_cap - 1); ++j) b.h_hist[(size_t)j * stride + ngroups] = not_yet;
     }

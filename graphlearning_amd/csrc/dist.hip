@@ -354,7 +354,7 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
     const int64_t nnz = rp.back();
     rc = glx_graph_create(hi[q] - lo[q], s->n_loc, nnz, rp.data(), col + rowptr[lo[q]], val + rowptr[lo[q]], state_dtype, comm->device, &s->part[q]);
     if (rc) DS_FAIL(rc);
-    glx_graph_keep_order(s->part[q]);
+    glx_graph_set_order(s->part[q], nullptr);      // (the caller's order: rank-local operators are rectangular and never renumbered)
     rc = glx_graph_plan(s->part[q], s->L.G, &s->plan[q]);
     if (rc) DS_FAIL(rc);
     DS_HIP(hipMalloc(&s->flags[q], std::max<size_t>((size_t)s->plan[q]->nslices * s->plan[q]->R, 64)));

@@ -7,7 +7,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
-#include "../../include/glx.h"
+#include "../../include/glx_experimental.h"   // (includes glx.h)
 
 // wavefronts (= slices) per workgroup of the SpMM kernel
 #ifndef GLX_WPB
@@ -44,8 +44,14 @@ struct RecLayout {
   int woff;   // byte offset of the fp64 stop value inside the record (-1: none)
   int G;      // lanes cooperating on one row (power of two, >= nvec + has_w)
   int esize;  // sizeof(T)
+  int ngroups = 1;  // column groups (stacked training sets, groups.hip): C = ngroups * (columns per group)
+  int nstop = 0;    // lanes behind the column vectors that hold fp64 stop values (one value per group, group b at byte woff + 8 b)
 };
 int glx_make_layout(int C, int dtype, bool has_w, RecLayout* L);
+// `B` groups of `C` columns with one fp64 stop value each (B = 1: the layout of glx_make_layout(C, dtype, true))
+int glx_make_layout_groups(int C, int B, int dtype, RecLayout* L);
+// stop-test maxima of a grouped sweep: per iteration [ngroups][GLX_GRP_SHARDS] values (sharded atomic maxima, sweep.hip)
+#define GLX_GRP_SHARDS 16
 
 // Sliced-ELL view of a sparse operator.  A slice is the R = 64/G rows one wavefront
 // processes; entries are stored in chunks of 64: chunk k of a slice holds, for row
@@ -331,6 +337,9 @@ struct SweepArgs {
   // CG: Dirichlet rows (bit g of rowmask[record]: A p held at zero there for system g); tolerance-mode state (cg_fused.hip)
   const unsigned* rowmask;
   const CgDev* cg;
+  // column groups (stacked training sets): ngroups > 1 selects the grouped kernel; err_prev / err_next are then [ngroups][GLX_GRP_SHARDS]
+  int ngroups;
+  unsigned used_mask;
 };
 int glx_launch_spmm(const SweepArgs& a, hipStream_t stream);
 int64_t glx_spmm_blocks(const SellPlan* plan);

@@ -30,11 +30,6 @@ extern "C" int glx_device_count(int* n) {
   return GLX_OK;
 }
 
-extern "C" int glx_set_device(int device) {
-  GLX_HIP(hipSetDevice(device));
-  return GLX_OK;
-}
-
 extern "C" int glx_device_synchronize(void) {
   GLX_HIP(hipDeviceSynchronize());
   return GLX_OK;
@@ -427,12 +422,37 @@ int glx_make_layout(int C, int dtype, bool has_w, RecLayout* L) {
   L->woff = has_w ? nvec * 4 * es : -1;
   L->G = G;
   L->esize = es;
+  L->ngroups = 1;
+  L->nstop = has_w ? 1 : 0;
   return GLX_OK;
 }
 
-extern "C" int glx_graph_keep_order(glx_graph* g) {
-  GLX_CHECK(g, GLX_EINVAL, "glx_graph_keep_order: null graph");
-  GLX_CHECK(g->plans.empty() && !g->order_ready, GLX_EINVAL, "glx_graph_keep_order: call before the operator is first used");
+int glx_make_layout_groups(int C, int B, int dtype, RecLayout* L) {
+  GLX_CHECK(C >= 1 && B >= 1 && B <= 32, GLX_EINVAL, "layout: %d groups of %d columns (1 .. 32 groups)", B, C);
+  GLX_CHECK(dtype == GLX_F32 || dtype == GLX_F64, GLX_EINVAL, "layout: bad dtype %d", dtype);
+  if (B == 1) return glx_make_layout(C, dtype, true, L);
+  const int es = dtype == GLX_F32 ? 4 : 8;
+  const int nvec = (C * B + 3) / 4;
+  const int nstop = (B * 8 + 4 * es - 1) / (4 * es);     // fp64 stop values packed behind the columns: 4 (fp64 state) / 2 (fp32) per lane
+  const int lanes = nvec + nstop;
+  GLX_CHECK(lanes <= 64, GLX_EUNSUPPORTED, "layout: %d groups of %d columns need %d lanes per row (max 64)", B, C, lanes);
+  int G = 8;
+  while (G < lanes) G *= 2;
+  const int bytes = lanes * 4 * es;
+  const int rb = (bytes + 127) / 128 * 128;              // whole 128-byte lines: a gather never shares a line with another record
+  L->C = C * B;
+  L->nvec = nvec;
+  L->ld = rb / es;
+  L->woff = nvec * 4 * es;
+  L->G = G;
+  L->esize = es;
+  L->ngroups = B;
+  L->nstop = nstop;
+  return GLX_OK;
+}
+
+static int graph_keep_order(glx_graph* g) {
+  GLX_CHECK(g->plans.empty() && !g->order_ready, GLX_EINVAL, "glx_graph_set_order: call before the operator is first used");
   g->keep_order = true;
   return GLX_OK;
 }
@@ -894,7 +914,8 @@ extern "C" int glx_host_permute_rows(int64_t n, const int32_t* rowptr, const int
 // may know a better one -- weightmatrix.knn has the FEATURES in hand, and an order by a tree over feature space keeps
 // neighbours close without looking at the graph at all.  Before the operator is first used.
 extern "C" int glx_graph_set_order(glx_graph* g, const int32_t* perm) {
-  GLX_CHECK(g && perm, GLX_EINVAL, "glx_graph_set_order: null argument");
+  GLX_CHECK(g, GLX_EINVAL, "glx_graph_set_order: null graph");
+  if (!perm) return graph_keep_order(g);      // the caller's order as it is: no renumbering at all
   GLX_CHECK(g->plans.empty() && !g->order_ready, GLX_EINVAL, "glx_graph_set_order: call before the operator is first used");
   GLX_CHECK(g->n_rows == g->n_cols, GLX_EINVAL, "glx_graph_set_order: operator must be square");
   const int64_t n = g->n_rows;

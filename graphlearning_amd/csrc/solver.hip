@@ -576,11 +576,6 @@ extern "C" int glx_sweep_project_iterate(glx_sweep* s, const double* priors, dou
                             s->stream, &d_labels, &hook);
 }
 
-extern "C" int glx_sweep_project(glx_sweep* s, const double* priors, double* weights_inout, int64_t* labels_out, double* err_out,
-                                 int* steps_out, int max_steps, int similarity, int to_onehot) {
-  return glx_sweep_project_iterate(s, priors, weights_inout, labels_out, err_out, steps_out, max_steps, similarity, to_onehot, 0);
-}
-
 extern "C" int glx_sweep_launches(const glx_sweep* s, int64_t* n) {
   GLX_CHECK(s && n, GLX_EINVAL, "glx_sweep_launches: null argument");
   *n = s->launches;
@@ -835,7 +830,7 @@ extern "C" int glx_record_layout(int C, int dtype, int has_w, int32_t out[6]) {
 static int require_caller_order(glx_graph* P, const char* who) {
   int rc = glx_graph_ensure_order(P);
   if (rc) return rc;
-  GLX_CHECK(P->h_perm.empty(), GLX_EINVAL, "%s: the operator was renumbered internally; create it with glx_graph_keep_order() "
+  GLX_CHECK(P->h_perm.empty(), GLX_EINVAL, "%s: the operator was renumbered internally; create it with glx_graph_set_order(g, NULL) "
             "to use caller-ordered device records", who);
   return GLX_OK;
 }

@@ -57,6 +57,11 @@ struct SpmmParams {
   char* dup_out;
   const unsigned* rowmask;  // CG, Dirichlet rows: bit g of rowmask[record] set = A p is held at zero there for system g (null: none)
   CgDev cg;
+  // GRP (stacked trials, groups.hip): the columns are `ngroups` groups of `grp_cols`, each group with its own fp64 stop value (group b
+  // at byte woff + 8 b of the record, i.e. in the lanes nvec .. nvec + nstop - 1) and its own stop test: err_prev / err_next are rows
+  // of [ngroups][GLX_GRP_SHARDS] maxima; groups outside used_mask never run
+  int ngroups, grp_cols, nstop;
+  unsigned used_mask;
 };
 
 // ---- cross-lane helpers -------------------------------------------------------------
@@ -126,6 +131,26 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return ((unsigned long long)mh << 32) | ml;
 }
 
+// the maximum of every row of 16 lanes, in all of its lanes (the first four steps of wave_max_u32)
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+  unsigned o;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false); v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false); v = o > v ? o : v;
+  return v;
+}
+__device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long v) {
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)(v & 0xffffffffull);
+  const unsigned mh = row16_max_u32(hi);
+  const unsigned ml = row16_max_u32(hi == mh ? lo : 0u);
+  return ((unsigned long long)mh << 32) | ml;
+}
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int off) {
+  const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(v & 0xffffffffull), off), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 // acc += v * x for one entry.  Entries past the end of a row carry val = 0 and an unloaded
 // x = 0, i.e. a product of exactly 0, and acc (which starts at +0 and therefore can never be
 // -0) satisfies acc + 0 == acc bit for bit: no predicate is needed.
@@ -179,9 +204,11 @@ __device__ __forceinline__ void add_product(typename VecOf<T>::type& acc, double
 // (Closed experiments -- other loop forms, a two-chunk pipeline, 32-bit offsets, nontemporal loads / stores, a persistent
 //  grid -- live as patches under scripts/probes/; EXPERIMENTS.md has their numbers.)
 // DOT: 0 none; 1 the column dots p.Ap of the exact CG (cg.hip); 2 the tolerance-mode CG's form (cg_fused.hip)
-template <typename T, int G, bool HAS_W, int DOT, bool HAS_DUP = false>
+// GRP (needs HAS_W, G >= 8): column groups with a stop test each -- several training sets of ssl.poisson as ONE sweep (groups.hip)
+template <typename T, int G, bool HAS_W, int DOT, bool HAS_DUP = false, bool GRP = false>
 __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParams p) {
 #pragma clang fp contract(off)
+  static_assert(!GRP || (HAS_W && DOT == 0 && !HAS_DUP && G >= 8), "column groups: the stop-column form without extras");
   constexpr bool HAS_DOT = DOT != 0, FUSED = DOT == 2;
   typedef typename VecOf<T>::type V4;
   constexpr int R = 64 / G;
@@ -193,7 +220,24 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
   // the stop values of the previous sweep: the load is issued HERE, the test comes behind the first slice's loads (below), so that
   // the two round trips overlap instead of following each other in front of every wavefront's work
   unsigned long long stop_v = 0;
-  if constexpr (HAS_W) {
+  unsigned amask = 0;      // GRP: the groups that still run in this sweep
+  if constexpr (GRP) {
+    // group b runs iff the previous sweep's maximum of its stop value is above 1/n and not NaN (ssl.py:667, per training set): 16
+    // shards per group, four groups per load, a row-of-16 maximum and a ballot turn them into a wave-uniform bit mask
+    amask = p.used_mask;
+    if (p.err_prev) {
+      unsigned m = 0;
+      for (int i = 0; i * 4 < p.ngroups; ++i) {
+        const int grp = i * 4 + (lane >> 4);
+        unsigned long long v = grp < p.ngroups ? p.err_prev[grp * GLX_GRP_SHARDS + (lane & 15)] : 0ull;
+        v = row16_max_u64(v);
+        const unsigned long long bal = __ballot(v > p.thresh_bits && v <= 0x7ff0000000000000ull);
+        m |= (unsigned)(((bal & 1ull) | ((bal >> 15) & 2ull) | ((bal >> 30) & 4ull) | ((bal >> 45) & 8ull)) << (i * 4));
+      }
+      amask &= m;
+    }
+    if (amask == 0) return;      // every training set has stopped: nothing to do (decided identically by every wavefront)
+  } else if constexpr (HAS_W) {
     if (p.err_prev) stop_v = p.err_prev[lane];
   }
   const double* act_row = nullptr;
@@ -234,7 +278,23 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       lane_on = any;
     }
   }
-  const bool is_w = HAS_W && (c == p.nvec);
+  bool is_w = HAS_W && (c == p.nvec);
+  bool ea[4] = {true, true, true, true};     // GRP: which of the lane's four elements belong to a running group
+  if constexpr (GRP) {
+    is_w = c >= p.nvec && c < p.nlanes;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int grp;
+      if (c < p.nvec) {
+        const int col = c * 4 + e;
+        grp = col < p.ngroups * p.grp_cols ? col / p.grp_cols : 32;
+      } else {
+        grp = sizeof(T) == 8 ? (c - p.nvec) * 4 + e : (c - p.nvec) * 2 + (e >> 1);
+      }
+      ea[e] = c < p.nlanes && grp < p.ngroups && ((amask >> grp) & 1u);
+    }
+    lane_on = ea[0] || ea[1] || ea[2] || ea[3];
+  }
   const T* __restrict__ valp = (const T*)p.val;
   const size_t lane_off = (size_t)c * 4 * sizeof(T);
 
@@ -258,7 +318,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
     S = hd.S & 0xff;
     full = hd.S >> 8;
   }
-  if constexpr (HAS_W) {
+  if constexpr (HAS_W && !GRP) {
     if (p.err_prev) {   // stop test of ssl.py:667, decided identically by every wavefront
       // (`while ... np.max(np.absolute(v-vinf)) > 1/n`: a NaN maximum compares False and ends the loop too;
       //  NaN errors are recorded as a bit pattern above +inf, so they dominate the max like numpy's)
@@ -274,6 +334,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
   const int seg = g & (S - 1);            // S is a power of two
   V4 acc = {0, 0, 0, 0};
   double accw = 0.0;
+  double accw1 = 0.0;      // GRP, fp32 state: a stop lane carries two fp64 stop values (elements 0..1 and 2..3)
 
   if constexpr (G == 4) {
     // Software pipeline: the index / value chunk k+1 travels while the neighbour gathers of chunk k do.
@@ -385,7 +446,14 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
           if (aj[t]) xj[t] = *(const V4*)(p.xin + (size_t)cj[t] * p.rec_bytes + lane_off);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) accum4<T, HAS_W>(acc, accw, vj[t], xj[t], is_w);
+        for (int t = 0; t < 4; ++t) {
+          accum4<T, HAS_W>(acc, accw, vj[t], xj[t], is_w);
+          if constexpr (GRP && sizeof(T) == 4) {
+            const double xw = __hiloint2double(__float_as_int(xj[t][3]), __float_as_int(xj[t][2]));
+            const double pw = (double)vj[t] * xw;
+            accw1 = accw1 + pw;
+          }
+        }
       }
     }
   }
@@ -407,7 +475,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
   }
   // epilogue: u_out[row] = Db[row] + acc   (ssl.py:668: `Db + P*u`; addition commutes bitwise)
   V4 outv = acc;
-  const bool store_on = lane_on && row >= 0 && seg == 0;
+  const bool store_on = (GRP ? c < p.nlanes : lane_on) && row >= 0 && seg == 0;
   if (store_on) {
     bool hb = p.bias != nullptr;
     if (hb && p.slot_has_bias) hb = p.slot_has_bias[slice * R + g] != 0;
@@ -421,6 +489,19 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
         outv[1] = __int_as_float(__double2hiint(accw));
         outv[2] = 0;
         outv[3] = 0;
+        if constexpr (GRP) {
+          outv[2] = __int_as_float(__double2loint(accw1));
+          outv[3] = __int_as_float(__double2hiint(accw1));
+        }
+      }
+    }
+    if constexpr (GRP) {
+      // a training set that has stopped keeps its iterate: its elements are copied forward from the row's own record, so that
+      // both buffers hold u_T of that set from its last sweep on, whatever the other sets still do
+      if (!(ea[0] && ea[1] && ea[2] && ea[3])) {
+        const V4 own = *(const V4*)(p.xin + (size_t)row * p.rec_bytes + lane_off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) outv[e] = ea[e] ? outv[e] : own[e];
       }
     }
     if constexpr (HAS_DOT) {
@@ -445,7 +526,48 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
     }
   }
 
-  if constexpr (HAS_W) {
+  if constexpr (GRP) {
+    if (p.err_next) {   // per training set: max_i |v_i - vinf_i| with v = deg * w  (ssl.py:667), the sets that still run only
+      unsigned long long ev[4] = {0ull, 0ull, 0ull, 0ull};
+      if (store_on && is_w) {
+        const double dg = p.deg[row], vi = p.vinf[row];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (sizeof(T) == 4 && (e & 1)) continue;
+          if (!ea[e]) continue;
+          double wnew;
+          if constexpr (sizeof(T) == 4) wnew = e == 0 ? accw : accw1; else wnew = (double)outv[e];
+          double er = fabs(dg * wnew - vi);
+          if (er != er) er = __longlong_as_double(0x7ff8000000000000ll);
+          ev[e] = (unsigned long long)__double_as_longlong(er);
+        }
+      }
+      // the rows of the wavefront (lanes with the same c), then the wavefronts of the workgroup through LDS, one atomic per group
+#pragma unroll
+      for (int off = 32; off >= G; off >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned long long o = shfl_xor_u64(ev[e], off);
+          ev[e] = o > ev[e] ? o : ev[e];
+        }
+      }
+      __shared__ unsigned long long s_eg[GLX_WPB][32];
+      if (g == 0 && is_w) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (sizeof(T) == 4 && (e & 1)) continue;
+          const int grp = sizeof(T) == 8 ? (c - p.nvec) * 4 + e : (c - p.nvec) * 2 + (e >> 1);
+          if (grp < p.ngroups) s_eg[wave][grp] = ev[e];
+        }
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < p.ngroups) {
+        unsigned long long mm = s_eg[0][threadIdx.x];
+        for (int w = 1; w < GLX_WPB; ++w) mm = s_eg[w][threadIdx.x] > mm ? s_eg[w][threadIdx.x] : mm;
+        if (mm != 0) atomicMax(&p.err_next[threadIdx.x * GLX_GRP_SHARDS + (blockIdx.x & (GLX_GRP_SHARDS - 1))], mm);
+      }
+    }
+  } else if constexpr (HAS_W) {
     if (p.err_next) {   // max_i |v_i - vinf_i| with v = deg * w  (ssl.py:667)
       double e = 0.0;
       if (store_on && is_w) {
@@ -561,7 +683,9 @@ int64_t glx_spmm_blocks(const SellPlan* plan) { return (plan->nslices + GLX_WPB 
 template <typename T, int G>
 static int launch_g(const SweepArgs& a, const SpmmParams& p, hipStream_t stream) {
   const dim3 grid((unsigned)p.nblocks), block(64 * GLX_WPB);
-  if (a.cg) {      // one workgroup more: it closes the previous iteration beside the product (cg_fused.hip)
+  if (a.ngroups > 1) {
+    if constexpr (G >= 8) hipLaunchKernelGGL((spmm_sell_kernel<T, G, true, 0, false, true>), grid, block, 0, stream, p);
+  } else if (a.cg) {      // one workgroup more: it closes the previous iteration beside the product (cg_fused.hip)
     hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, 2>), dim3((unsigned)p.nblocks + 1), block, 0, stream, p);
   } else if (a.dot_partial) {
     hipLaunchKernelGGL((spmm_sell_kernel<T, G, false, 1>), grid, block, 0, stream, p);
@@ -611,6 +735,15 @@ int glx_launch_spmm(const SweepArgs& a, hipStream_t stream) {
   p.rec_bytes = a.L.ld * a.L.esize;
   p.nvec = a.L.nvec;
   p.nlanes = a.L.nvec + (a.has_w ? 1 : 0);
+  if (a.ngroups > 1) {
+    GLX_CHECK(a.has_w && !a.dot_partial && !a.cg && !a.dup_ptr && a.L.G >= 8 && a.ngroups <= 32 && a.L.ngroups == a.ngroups, GLX_EINVAL,
+              "spmm: column groups need the stop-column form, a grouped layout and at most 32 groups");
+    p.nlanes = a.L.nvec + a.L.nstop;
+    p.ngroups = a.ngroups;
+    p.grp_cols = a.L.C / a.ngroups;
+    p.nstop = a.L.nstop;
+    p.used_mask = a.used_mask;
+  }
   p.deg = a.deg;
   p.vinf = a.vinf;
   p.err_prev = a.err_prev;

@@ -321,9 +321,41 @@ def quotient_partition(P, order, world, segments=None, eps_levels=(0.03, 0.08, 0
     return best[1], best[2], best[3]
 
 
-def plan_partition(P, order, world, how='auto'):
+PARTITIONS = ('auto', 'cut', 'even', 'cells')
+
+
+def plan_partition(P, order, world, how='auto', dist=None, group=None):
     """(order, bounds, info) for `how` in 'cut' (contiguous blocks between the graph's pieces), 'even' (equal blocks), 'cells'
-    (quotient_partition) or 'auto' (the one of cut / cells with the smaller estimated sweep time)."""
+    (quotient_partition) or 'auto' (the one of cut / cells with the smaller estimated sweep time).  Every rank plans for itself from
+    the same inputs; with `dist` (an initialised torch.distributed) the ranks then compare a digest of what they arrived at and
+    ALL raise if they differ -- 'cells' / 'auto' go through floating-point gains and argsort ties, and two ranks on different
+    numpy builds exchanging rows by different plans would hang the collectives or corrupt the halo silently."""
+    if how not in PARTITIONS:
+        raise ValueError('partition must be one of %s, got %r' % (', '.join(repr(p) for p in PARTITIONS), how))
+    out = _plan_partition(P, order, world, how)
+    if dist is not None and world > 1:
+        _agree(dist, group, [np.asarray(out[0], dtype=np.int64), np.asarray(out[1], dtype=np.int64)], 'vertex partition (%s)' % how)
+    return out
+
+
+def _agree(dist, group, arrays, what):
+    """Collective: raises RuntimeError on every rank unless all ranks hold the same arrays."""
+    import hashlib
+    import torch
+    h = hashlib.blake2b(digest_size=7)
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    v = int.from_bytes(h.digest(), 'little')                  # < 2^56: exact in int64, and in its negation
+    dev = 'cuda' if str(dist.get_backend(group)) == 'nccl' else 'cpu'
+    t = torch.tensor([v, -v], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(t[0].item()), -int(t[1].item())
+    if hi != lo:
+        raise RuntimeError('the ranks of the job computed different %s plans (digest %x on this rank, %x .. %x over the job): '
+                           'the exchange lists would not match' % (what, v, lo, hi))
+
+
+def _plan_partition(P, order, world, how):
     n = sparse.csr_matrix(P).shape[0]
     if how == 'even':
         b = block_bounds(n, world)
@@ -553,8 +585,7 @@ class DistSweep:
         self.exchanges = 0
         # a backend without device collectives (gloo) with device-resident records: stage through the host
         self._stage_host = bool(getattr(ops, 'supports_graph', False)) and dist.get_backend(group) == 'gloo'
-        import os
-        self._force_coll = os.environ.get('GLX_DIST_FORCE_COLLECTIVES') == '1'   # test hook: collectives at world 1
+        self._force_coll = _force_collectives()   # test hook: collectives at world 1
 
     def exchange(self, x, async_op=False):
         """Boundary records of x[0:n_own] -> the peers' halo regions x[n_own:].  With async_op the
@@ -725,9 +756,7 @@ def init_comm(dist, device=None, group=None):
     return _hip.Comm(world, rank, uid[0], device)
 
 
-def _force_collectives():
-    import os
-    return os.environ.get('GLX_DIST_FORCE_COLLECTIVES') == '1'
+XX
 
 
 def glx_dist_sweep(comm, plan, C, dtype=np.float64, force_exchange=False, use_hipgraph=True, form='auto'):
@@ -788,7 +817,7 @@ def poisson_fit_glx(W, train_ind, train_labels, dist, comm=None, device=None, mi
     n = P.shape[0]
     if order is None:
         order = locality_order(P)
-    order, bounds, _ = plan_partition(P, order, world, partition)
+    order, bounds, _ = plan_partition(P, order, world, partition, dist, group)
     plan = RankPlan(P, order, bounds, rank)
     own_comm = comm is None and not stepwise
     if stepwise and comm is None:
@@ -890,7 +919,7 @@ def poisson_fit_distributed(W, train_ind, train_labels, dist, ops_factory, min_i
     n = P.shape[0]
     if order is None:
         order = locality_order(P)
-    order, bounds, _ = plan_partition(P, order, world, partition)
+    order, bounds, _ = plan_partition(P, order, world, partition, dist, group)
     plan = RankPlan(P, order, bounds, rank)
     ops = ops_factory(plan, prob['k'])
     sweep = DistSweep(plan, ops, dist, group)
@@ -1051,7 +1080,7 @@ def cg_distributed(A, B, dist, ops_factory, tol=1e-10, max_iter=100000, order=No
     C = B.shape[1]
     if order is None:
         order = locality_order(A)
-    order, bounds, _ = plan_partition(A, order, world, partition)
+    order, bounds, _ = plan_partition(A, order, world, partition, dist, group)
     plan = RankPlan(A, order, bounds, rank)
     ops = ops_factory(plan, C)
     xch = DistSweep(plan, ops, dist, group)          # its exchange(): boundary records of p[0:n_own] -> the peers' halo regions p[n_own:]

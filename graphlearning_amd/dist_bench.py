@@ -64,7 +64,7 @@ def main_dry_run(args):
     if rank == 0:
         emit(json.dumps({'dry_run': True, 'n_gpus': world, 'ranks_seen': int(seen.item()), 'gpus_asked': int(args.gpus),
                          'ranks': [list(t) for t in ids],
-                         'spawned_by_bench': os.environ.get('GLX_BENCH_SPAWNED') == '1'}))
+                         'spawned_by_bench': bool(getattr(args, 'spawned', False))}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -83,7 +83,7 @@ def main(args):
     import torch                       # first: libglx must bind to torch's HIP runtime (see dist.py)
     import torch.distributed as dist
     rank, world, local_rank = check_world(args, torch.cuda.device_count())
-    if 'MASTER_ADDR' not in os.environ:         # GLX_BENCH_FORCE_DIST=1 python bench.py --gpus 1: a one-rank job without a launcher
+    if 'MASTER_ADDR' not in os.environ:         # python bench.py --gpus 1 --force-dist: a one-rank job without a launcher
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     torch.cuda.set_device(local_rank)
     # a stuck collective ends the job after 5 minutes (watchdog abort) instead of holding the GPUs
@@ -108,7 +108,8 @@ def main(args):
     P = prob['P']
     order = gdist.locality_order(P)
     min_iter, max_iter = 50, 1000
-    engine = os.environ.get('GLX_DIST_ENGINE', 'glx')     # 'glx': library-owned RCCL communicator + captured sweeps; 'torch': round-1 path
+    engine = getattr(args, 'engine', 'glx')     # 'glx': library-owned RCCL communicator + captured sweeps; 'torch': round-1 path
+    gdist.FORCE_COLLECTIVES = bool(getattr(args, 'force_collectives', False))
     comm = None
     if engine == 'glx':
         # the library's own RCCL communicator; an error OR a rendezvous that does not come back within two minutes must not
@@ -136,7 +137,7 @@ def main(args):
         comm = None                                         # (a communicator some ranks did get is left alone)
 
     def measure(partition):
-        order_p, bounds, pinfo = gdist.plan_partition(P, order, world, partition)      # (deterministic: every rank arrives at the same plan)
+        order_p, bounds, pinfo = gdist.plan_partition(P, order, world, partition, dist)      # (every rank plans for itself; the ranks compare digests)
         plan = gdist.RankPlan(P, order_p, bounds, rank)
         own = plan.own
         if engine == 'glx':

@@ -130,6 +130,26 @@ class ssl:
         self._trusted_key = (W, last[1])
         return (W, last[1], fut)
 
+    _MUTABLE = ('weights', 'class_priors_error', 'num_iter', 'stop_settled')
+
+    def _mutable_state(self):
+        """What a `_fit` may change in the model besides its result (and in the inner Poisson model of PoissonMBO)."""
+        def snap(obj):
+            return {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in
+                    ((k, getattr(obj, k)) for k in self._MUTABLE if hasattr(obj, k))}
+        inner = getattr(self, 'poisson_model', None)
+        return snap(self), (snap(inner) if inner is not None else None)
+
+    def _restore_state(self, saved):
+        if saved is None:
+            return
+        for k, v in saved[0].items():
+            setattr(self, k, v)
+        inner = getattr(self, 'poisson_model', None)
+        if inner is not None and saved[1] is not None:
+            for k, v in saved[1].items():
+                setattr(inner, k, v)
+
     def _confirm_key(self, pending):
         W, assumed, fut = pending
         self._trusted_key = None
@@ -201,13 +221,25 @@ class ssl:
                 self.prob[:, i] = self._fit(train_ind, train_labels == l)
         else:
             pending = self._speculate_key()
+            # a speculative fit runs on operators cached for the matrix's PREVIOUS content: whatever it changes in the model
+            # (PoissonMBO's volume weights, iteration counts) is put back before the fit is repeated on the edited matrix, and an
+            # exception it raises only counts if the content really was unchanged
+            saved = self._mutable_state() if pending is not None else None
             try:
                 res = self._fit(train_ind, train_labels, all_labels=all_labels)
-            except BaseException:
-                if pending is not None:
+            except BaseException as exc:
+                if pending is None:
+                    raise
+                if not isinstance(exc, Exception):
                     self._trusted_key = None
-                raise
+                    raise
+                if self._confirm_key(pending):      # the content was what the cached operators were built from: a real failure
+                    raise
+                res, pending = None, None
+                self._restore_state(saved)
+                res = self._fit(train_ind, train_labels, all_labels=all_labels)
             if pending is not None and not self._confirm_key(pending):
+                self._restore_state(saved)
                 res = self._fit(train_ind, train_labels, all_labels=all_labels)     # the matrix was edited in place: operators from its new content
             self._set_result(res)
         if self.class_priors is not None:
@@ -283,13 +315,13 @@ class ssl:
             group = trainsets[pos:pos + batch]
             # trials that share the graph are stacked as extra right-hand-side columns of ONE device
             # solve where the learner supports it (column for column the same result as one by one)
-            probs = self._fit_batch([(t, labels[t]) for t in group]) if len(group) > 1 else None
+            probs = self._fit_batch_device([(t, labels[t]) for t in group]) if len(group) > 1 else None
             for j, train_ind in enumerate(group):
                 if probs is None:
                     pred = self.fit_predict(train_ind, labels[train_ind])
                 else:
                     self.fitted = True
-                    self.prob = probs[j]
+                    self._set_result(probs[j])
                     if self.class_priors is not None:
                         self.volume_label_projection()
                     pred = self.predict()
@@ -308,6 +340,11 @@ class ssl:
         """Fit several (train_ind, train_labels) pairs on the same graph in one device call and
         return their (n, C) results, or None when the learner has no batched path."""
         return None
+
+    def _fit_batch_device(self, trials):
+        """_fit_batch whose results may stay on the device (_DeviceState entries, valid until the learner's next solve):
+        what ssl_trials consumes -- it only needs the label decision of every trial."""
+        return self._fit_batch(trials)
 
     def trials_statistics(self, tag=''):
         """Mean / standard deviation of the accuracies recorded by ssl_trials, per label rate
@@ -336,6 +373,23 @@ def _free_order(W, n):
 # relative half-width around 1/n inside which a fused stop value is re-derived with the reference's recurrence
 # (poisson._settle_stop); the fused and the reference values differ by <= 1e-13 relative
 STOP_BAND = 1e-9
+
+
+# Training sets per stacked gradient-descent sweep (poisson._fit_batch_gd): whole 128-byte lines per gather and the operator's
+# index / value stream amortised, while the stacked state of a 70 000-vertex graph still lives in the L2s / the Infinity Cache
+GD_TRIAL_BATCH = 8
+
+
+def _gd_fits(k, B, dtype):
+    lanes = (B * k + 3) // 4 + ((B + 3) // 4 if np.dtype(dtype) == np.float64 else (B + 1) // 2)
+    return 2 <= B <= 32 and lanes <= 64
+
+
+def _gd_batch(k, dtype):
+    B = GD_TRIAL_BATCH
+    while B > 1 and not _gd_fits(k, B, dtype):
+        B -= 1
+    return max(B, 1)
 
 
 _HASH_POOL = None
@@ -490,6 +544,8 @@ class poisson(ssl):
         if self._cache is not None:
             if self._cache[2].get('sweep') is not None:
                 self._cache[2]['sweep'].close()
+            if self._cache[2].get('groups') is not None:
+                self._cache[2]['groups'].close()
             self._cache[1].close()
         self._cache = (key, dev, aux)
         return dev, aux
@@ -636,16 +692,87 @@ class poisson(ssl):
         return T
 
     def _trial_batch_size(self, labels):
+        k = max(1, len(np.unique(labels)))
+        if self.solver == 'gradient_descent':
+            return _gd_batch(k, self._dtype())
         if self.solver != 'conjugate_gradient':
             return 1
-        k = max(1, len(np.unique(labels)))
         return max(1, min(24, 240 // k))
+
+    def _fit_batch_device(self, trials):
+        if self.solver == 'gradient_descent':
+            return self._fit_batch_gd(trials)
+        return self._fit_batch(trials)
+
+    def _fit_batch_gd(self, trials):
+        """Gradient descent (reference ssl.py:631-670) for several training sets as column groups of ONE sweep (glx_sweep_groups):
+        trial b owns C columns and its own stop value, runs exactly the T sweeps its own fit would and keeps its iterate from then
+        on.  Returns per trial a _DeviceState (the iterate stays in the stacked state until the next solve), or None when the
+        trials cannot be stacked (different class counts, repeated labelled rows, vertices of degree 0: the single fit's dense
+        branch handles those)."""
+        if self.max_iter <= 0 or len(trials) < 2:
+            return None
+        n = self.graph.num_nodes
+        trials = [(np.asarray(ti), np.asarray(tl)) for ti, tl in trials]
+        ks = [len(np.unique(tl)) for _, tl in trials]
+        k = ks[0]
+        if any(kk != k for kk in ks):
+            return None
+        dev, aux = self._operators()
+        if aux['zero_degree']:
+            return None
+        for ti, _ in trials:
+            if not (len(ti) > 0 and len(np.unique(ti)) == len(ti) and ti.min() >= 0 and ti.max() < n):
+                return None
+        cap = max(len(trials), _gd_batch(k, self._dtype()))
+        if cap < 2 or not _gd_fits(k, cap, self._dtype()):
+            return None
+        key = (k, self.min_iter, self.max_iter, cap)
+        if aux.get('groups_key') != key:
+            if aux.get('groups') is not None:
+                aux['groups'].close()
+            aux['groups'] = _hip.SweepGroups(dev, k, cap, min_iter=self.min_iter, max_iter=self.max_iter)
+            aux['groups'].set_vectors(aux['deg'], aux['vinf'])
+            aux['groups_key'] = key
+        groups = aux['groups']
+        for b, (ti, tl) in enumerate(trials):
+            onehot = utils.labels_to_onehot(tl, k)
+            Db_rows = aux['dinv'][ti, None] * (onehot - np.mean(onehot, axis=0))      # as in _fit: rows of D*source
+            vval = 1.0 / float(len(ti))
+            w0_rows = vval / aux['deg'][ti]
+            err0 = 0.0
+            if self.min_iter == 0:
+                v = np.zeros(n)
+                v[ti] = vval
+                err0 = np.max(np.absolute(v - aux['vinf']))
+            groups.set_problem_rows(b, ti, Db_rows, w0_rows, err0)
+        T, _ = groups.run(used=len(trials))
+        res = [_DeviceState(groups.view(b)) for b in range(len(trials))]
+        settled = []
+        for b, (ti, tl) in enumerate(trials):
+            # the one case in which the fused stop value and the reference's recurrence could decide differently (_settle_stop):
+            # that trial is fitted alone, by the path that settles it
+            _, vals = groups.stop_values(b)
+            if np.any(np.absolute(vals - 1.0 / n) <= STOP_BAND * (1.0 / n)):
+                u = self._fit(ti, tl)
+                res[b] = np.array(u.fetch()) if isinstance(u, _DeviceState) else u
+                T[b] = self.num_iter
+                settled.append(b)
+        self.num_iter = [int(t) for t in T]
+        self.stop_settled = settled or None
+        return res
 
     def _fit_batch(self, trials):
         """Poisson CG for several training sets at once: the trials' right-hand sides become column
         groups of one multi-RHS solve (glx_cg_groups), each group with the stop test and iteration
         count utils.conjgrad would give it alone (reference: one conjgrad call per trial,
-        ssl.py:624-629 under ssl.py:292-396)."""
+        ssl.py:624-629 under ssl.py:292-396).  solver='gradient_descent': the trials as column groups of one sweep
+        (_fit_batch_gd), results read back."""
+        if self.solver == 'gradient_descent':
+            res = self._fit_batch_gd(trials)
+            if res is None:
+                return None
+            return [np.array(r.fetch()) if isinstance(r, _DeviceState) else r for r in res]
         if self.solver != 'conjugate_gradient':
             return None
         n = self.graph.num_nodes
@@ -807,16 +934,17 @@ def _solve(run, reduce):
 
 class laplace(ssl):
     def __init__(self, W=None, class_priors=None, X=None, reweighting='none', normalization='combinatorial', tau=0,
-                 order=1, mean_shift=False, tol=1e-5, alpha=2, zeta=1e7, r=0.1, reduce='exact'):
+                 order=1, mean_shift=False, tol=1e-5, alpha=2, zeta=1e7, r=0.1, reduce='auto'):
         """Laplace learning, reference ssl.py:1106-1261: Dirichlet sub-system solved by a
         Jacobi-scaled multi-RHS conjugate gradient on the GPU.  Reweightings 'poisson' and 'wnll'
         (graph.reweight, reference graph.py:368-466) are supported; 'properly' is not.
 
-        reduce (not in the reference): 'auto' = 'tree' unless the solve runs long or breaks down (see _solve);
-        'exact' (default) keeps numpy's reduction order, so iterates and
-        iteration counts are bit-identical to the reference; 'tree' is the tolerance mode for this SPD
-        system -- block-tree reductions, about 3x faster per fit, same labels, iterates within 1e-5
-        (the solve converges to tol=1e-5 either way; include/glx.h GLX_CG_TREE)."""
+        reduce (not in the reference): 'auto' (default) = the tolerance mode 'tree' -- block-tree reductions, about 7x faster per
+        fit at config 3, the same labels and iteration counts, iterates within the north star's 1e-5 of the reference's (this SPD
+        system converges to tol=1e-5 either way; include/glx.h GLX_CG_TREE) -- handed back to 'exact' when a solve runs beyond
+        ssl.AUTO_TREE_MAX_ITER iterations or produces a non-finite iterate (see _solve: the two ways the modes were found to
+        part, profiles/r04_tree_vs_exact.txt, tests/test_gpu_auto.py); 'exact' keeps numpy's reduction order: iterates and
+        iteration counts bit-identical to the reference."""
         super().__init__(W, class_priors)
         self.reduce = reduce
         self.reweighting = reweighting
@@ -983,10 +1111,10 @@ class laplace(ssl):
 
 
 class randomwalk(ssl):
-    def __init__(self, W=None, class_priors=None, alpha=0.95, reduce='exact'):
+    def __init__(self, W=None, class_priors=None, alpha=0.95, reduce='auto'):
         """Lazy random walk classification (reference ssl.py:1731-1793): one Jacobi-scaled
-        multi-RHS conjugate-gradient solve, on the GPU.  reduce='tree' (not in the reference): tolerance
-        mode of the reductions for this SPD system, see ssl.laplace."""
+        multi-RHS conjugate-gradient solve, on the GPU.  reduce (not in the reference): 'auto' (default) / 'tree' / 'exact', the
+        modes of the reductions for this SPD system, see ssl.laplace."""
         super().__init__(W, class_priors)
         self.alpha = alpha
         self.reduce = reduce

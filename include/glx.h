@@ -45,42 +45,17 @@ extern "C" {
 
 typedef struct glx_graph glx_graph;   /* a sparse operator resident in HBM (sliced-ELL + CSR) */
 typedef struct glx_sweep glx_sweep;   /* a prepared Poisson / heat sweep: device state + launch plan */
+typedef struct glx_sweep_groups glx_sweep_groups;   /* several training sets as column groups of ONE prepared Poisson sweep */
 typedef struct glx_cg glx_cg;         /* a prepared multi-RHS conjugate-gradient solve */
 typedef struct glx_comm glx_comm;     /* one rank's RCCL communicator, owned by the library */
 typedef struct glx_dist_sweep glx_dist_sweep;   /* one rank's share of the vertex-partitioned Poisson sweep */
 
 const char* glx_last_error(void);
-int glx_version(void);
 int glx_device_count(int* n);
-int glx_set_device(int device);
-int glx_device_synchronize(void);
 void glx_free(void* p);
-/* Host helpers of ssl.poisson's operator set-up (graphlearning/ssl.py:634-635, 642) for a W that is symmetric bit for bit:
- * row sums in stored order (= scipy's W * ones), and the rows of P = D^-1 W^T written down without a transpose -- row i of W
- * scaled by scale[i] with its entries in reverse order, the arrays scipy's `D * W.transpose()` yields.  No device involved. */
-int glx_host_row_sums(int64_t n, const int32_t* rowptr, const double* val, double* sum_out);
-int glx_host_reverse_scale_rows(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val,
-                                const double* scale, int32_t* col_out, double* val_out);
-/* Host: the nonzero rows of -L[:, cols] * F from the CSC image (cptr, crow, cval) of a canonical L -- ssl.laplace's right-hand side,
- * reference ssl.py:1236, a row's terms added in ascending column order from 0 as scipy's csr_matvecs does --, without the rows listed
- * in cols, every row times row_scale[row] when given (M*b, ssl.py:1249).  rows_out ascending, vals_out (count, k); cap = room in both.
- * *count_out = -1 (and GLX_OK): cols has duplicates, use the literal expression. */
-int glx_host_neg_columns_rows(int64_t n, const int32_t* cptr, const int32_t* crow, const double* cval, int64_t m, const int64_t* cols,
-                              const double* F, int k, const double* row_scale, int64_t cap, int32_t* rows_out, double* vals_out,
-                              int64_t* count_out);
-
-/* host helpers of the sharded build: the library's locality order (perm_out[new] = old, the breadth-first pass glx_graph uses for
- * square operators) of an n-row pattern restricted to the columns [col_lo, col_lo + n) -- a rank orders its own rows by their links
- * among themselves --, and the rows of a CSR matrix in another order (row i of the result = row perm[i], entry order kept). */
-int glx_host_locality_order(int64_t n, const int32_t* rowptr, const int32_t* col, int64_t col_lo, int32_t* perm_out);
-int glx_host_permute_rows(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val, const int64_t* perm,
-                          int32_t* rowptr_out, int32_t* col_out, double* val_out);
 
 /* page-locked host memory for result arrays (a D2H copy into pageable memory is staged and several times slower;
  * the Python boundary recycles these blocks as the backing store of the numpy arrays it returns) */
-/* 128-bit content fingerprint of `bytes` bytes (chunks hashed on a few host threads, then combined): what the learners key
- * their device-resident operators by, so that a weight matrix edited in place between two fits is seen as a new graph. */
-int glx_host_fingerprint(const void* data, size_t bytes, uint64_t seed, uint64_t out[2]);
 int glx_host_alloc(size_t bytes, void** out);
 int glx_host_free(void* p);
 
@@ -105,19 +80,11 @@ int glx_graph_create_resident(int64_t n_rows, int64_t n_cols, int64_t nnz, const
                               const double* val, int state_dtype, int device, double* rowsum_out, glx_graph** out);
 int glx_graph_set_row_transform(glx_graph* g, const double* row_scale, int reverse_rows);
 int glx_graph_destroy(glx_graph* g);
-/* Square operators are renumbered internally for cache locality (reverse Cuthill-McKee; dense
- * operands passed as HOST arrays are translated on the way in and out, results do not change).
- * Call this right after creation to keep the caller's vertex order -- required for the
- * device-pointer (_dev) entry points, whose records are in the caller's order. */
-int glx_graph_keep_order(glx_graph* g);
-/* info[0]=n_rows,[1]=n_cols,[2]=nnz,[3]=stored entries incl. padding,[4]=slices,[5]=rows per slice,[6]=max row nnz,[7]=1 if renumbered */
-int glx_graph_info(const glx_graph* g, int64_t info[8]);
-/* the internal vertex order: perm_out[new] = caller's row (n_rows entries; the identity when the operator
- * was not renumbered).  Forces the order to be computed if it has not been yet. */
-int glx_graph_order(glx_graph* g, int32_t* perm_out);
-/* the caller's own locality order instead of the library's pass over the graph: perm[new] = caller's row, a permutation of
- * 0..n-1 (square operators, before first use).  weightmatrix.knn has the features in hand: an order by a tree over
- * feature space needs no look at the graph.  Results do not depend on the order (a row's entries keep their order). */
+/* Square operators are renumbered internally for cache locality (a breadth-first pass; dense operands passed as HOST arrays
+ * are translated on the way in and out, results do not change -- a row's entries keep their order).  glx_graph_set_order, right
+ * after creation, replaces that pass: perm[new] = caller's row, a permutation of 0..n-1 -- weightmatrix.knn has the features in
+ * hand, and the cell order of its search needs no look at the graph --, or perm = NULL: the caller's order as it is (required for
+ * the device-pointer (_dev) entry points of glx_experimental.h, whose records are in the caller's order). */
 int glx_graph_set_order(glx_graph* g, const int32_t* perm);
 
 /* u_out = Db + A u_in, applied `iters` times (u fed back).  Db may be NULL (no bias).
@@ -153,7 +120,6 @@ int glx_sweep_run(glx_sweep* s, int* T_out, float* device_ms_out);   /* all iter
  * in that case (graphlearning_amd/ssl.py: _exact_stop_iteration). */
 int glx_sweep_stop_values(const glx_sweep* s, int64_t cap, double* vals, int* first, int* count);
 int glx_sweep_fetch(glx_sweep* s, void* u_out);
-int glx_sweep_launches(const glx_sweep* s, int64_t* sweep_kernel_launches);
 int glx_sweep_destroy(glx_sweep* s);
 
 /* Heat/MBO inner loop, ssl.py:826-827: u <- P u + Db, `iters` times, u resident on
@@ -167,33 +133,27 @@ int glx_sweep_set_state(glx_sweep* s, const void* u0, const void* Db);
 int glx_sweep_set_state_labels(glx_sweep* s, const int64_t* labels, int64_t m, const int64_t* rows, const void* Db_rows);
 int glx_sweep_iterate(glx_sweep* s, int iters);
 
-/* ---- device-pointer entry points: rank-local sweeps of the vertex-partitioned solver -------
- * Buffers are DEVICE memory in the vertex-record layout (torch tensors' data_ptr()); `stream`
- * is a hipStream_t; nothing synchronises.  Record layout: `ld` elements per vertex, columns
- * 0..C-1, zero padding to a multiple of 4, then (has_w) the fp64 stop value at byte `woff`.
- * out = {ld, woff, record bytes, lanes per row, 4-wide column vectors, element size}. */
-int glx_record_layout(int C, int dtype, int has_w, int32_t out[6]);
-int glx_graph_slots(glx_graph* P, int C, int has_w, int64_t* nslots);
-/* flags[slot] = 1 where the slot's row has a nonzero bias record (sparse Db: ssl.py:620-622) */
-int glx_bias_flags_dev(glx_graph* P, int C, int has_w, const void* bias_rec, uint8_t* flags, void* stream);
-/* one sweep xout[0:n_rows] = bias + P xin[0:n_cols]; err_next (64 x uint64, caller-zeroed) receives
- * max |deg*w - vinf| as fp64 bit patterns when non-NULL (the rank-local part of ssl.py:667) */
-int glx_sweep_step_dev(glx_graph* P, int C, int has_w, const void* xin, void* xout, const void* bias_rec,
-                       const uint8_t* slot_flags, const double* deg, const double* vinf, void* err_next,
-                       void* stream);
-int glx_pack_records_dev(const void* dense, void* rec, int64_t n, int C, int dtype, int has_w, const double* w,
-                         void* stream);
-int glx_unpack_records_dev(const void* rec, void* dense, int64_t n, int C, int dtype, int has_w, void* stream);
+/* ---- stacked training sets: B fits of ssl.poisson(solver='gradient_descent') as ONE sweep ----
+ * What ssl.ssl_trials does one `_fit` at a time (reference ssl.py:292-396 over ssl.py:631-670).  Trial b owns the columns
+ * b C .. b C + C - 1 of the vertex record and an fp64 stop value of its own; group b runs sweep t iff t < min_iter or its
+ * max|deg w_b - vinf| > 1/n held after sweep t - 1 (ssl.py:667); a group that has stopped neither gathers nor changes.  Every
+ * trial's iterate and sweep count T are those of its own glx_sweep fit, bit for bit (fp64 state).  2 <= B <= 32 and
+ * ceil(B C / 4) + ceil(B / 4) <= 64 (fp32 state: ceil(B / 2)).  Call order: create, set_vectors (the graph's deg and vinf, once),
+ * then per batch of trials set_problem_rows for the groups in use, run(used), fetch / project per group. */
+int glx_sweep_groups_create(glx_graph* P, int C, int B, int min_iter, int max_iter, glx_sweep_groups** out);
+int glx_sweep_groups_set_vectors(glx_sweep_groups* s, const double* deg, const double* vinf);
+/* training set of group b: m distinct labelled rows, their rows of Db = D^-1 b ((m, C), the graph's dtype) and of w0 = v_0 / deg,
+ * err0 = max|v_0 - vinf| (the test in front of the first sweep when min_iter = 0); replaces the group's previous training set */
+int glx_sweep_groups_set_problem_rows(glx_sweep_groups* s, int b, int64_t m, const int64_t* rows, const void* Db_rows,
+                                      const double* w0_rows, double err0);
+/* groups 0 .. used - 1 run from u = 0; T_out[B]: the sweeps of every group (0 for the idle ones) */
+int glx_sweep_groups_run(glx_sweep_groups* s, int used, int* T_out, float* device_ms_out);
+int glx_sweep_groups_stop_values(const glx_sweep_groups* s, int b, int64_t cap, double* vals, int* first, int* count);
+int glx_sweep_groups_fetch(glx_sweep_groups* s, int b, void* u_out);              /* (n, C) of group b, caller order */
+int glx_sweep_groups_project(glx_sweep_groups* s, int b, const double* priors, double* weights_inout, int64_t* labels_out,
+                             double* err_out, int* steps_out, int max_steps, int similarity);   /* as glx_sweep_project, on group b */
+int glx_sweep_groups_destroy(glx_sweep_groups* s);
 
-/* Dense vector kernels of utils.conjgrad (graphlearning/utils.py:483-532) on device records, for the vertex-partitioned
- * conjugate-gradient solve (dist.py: cg_distributed): out[c] = sum_i a[i,c] b[i,c] in fp64 with a fixed order inside the
- * rank (partial: device scratch of glx_rec_dots_scratch(n, C) doubles); x += alpha p, r -= alpha Ap; p = r + beta p --
- * alpha, beta: device fp64[C].  The ranks add their column sums with one all-reduce each (tolerance mode). */
-int64_t glx_rec_dots_scratch(int64_t n, int C);
-int glx_rec_dots_dev(const void* a, const void* b, int64_t n, int C, int dtype, int has_w, double* partial, double* out, void* stream);
-int glx_rec_axpy2_dev(void* x, void* r, const void* p, const void* Ap, const double* alpha, int64_t n, int C, int dtype, int has_w,
-                      void* stream);
-int glx_rec_xpby_dev(void* p, const void* r, const double* beta, int64_t n, int C, int dtype, int has_w, void* stream);
 
 /* ---- vertex-partitioned sweep over RCCL (the reference has no distributed code) -------------
  * One process per GPU: rank 0 calls glx_dist_unique_id, ships the 128 bytes to the other ranks by any means (the
@@ -204,7 +164,6 @@ int glx_rec_xpby_dev(void* p, const void* r, const double* beta, int64_t n, int 
 int glx_dist_unique_id(char id_out[128]);
 int glx_dist_init_rank(int nranks, int rank, const char id[128], int device, glx_comm** out);
 int glx_dist_init(int nranks, const int* devices, glx_comm** out);
-int glx_dist_comm_info(const glx_comm* c, int32_t info[4]);   /* rank, nranks, device, 1 if it has an RCCL communicator */
 int glx_dist_destroy(glx_comm* c);
 /* This rank's share.  rowptr / col / val: its n_own rows of P in local order -- the n_boundary rows some peer
  * gathers FIRST -- with columns renumbered [0, n_own) owned and [n_own, n_own + n_halo) halo, the halo ordered as
@@ -245,23 +204,7 @@ int glx_dist_sweep_set_problem(glx_dist_sweep* s, const void* Db_own, const doub
 int glx_poisson_sweep_dist(glx_dist_sweep* s, int min_iter, int max_iter, int check_every, double err0, int* T_out,
                            float* device_ms_out);
 int glx_dist_sweep_fetch(glx_dist_sweep* s, void* u_own_out);           /* (n_own, C) host, local row order */
-int glx_dist_sweep_stats(const glx_dist_sweep* s, int64_t out[4]);      /* sweeps run, exchanges enqueued, graphs, 1 if it exchanges */
-/* what the object decided: out[0] 1 if it exchanges, [1] exchanging sweeps captured (1) / eager (0) / undecided (-1),
- * [2] self-test 0 not run / 1 passed / 2 failed, [3] exchange on a second stream beside the interior rows, [4] one
- * launch per sweep (GLX_DIST_FUSE), [5] boundary rows scattered into the send buffer by the SpMM (no pack kernel),
- * [6] records sent per sweep, [7] halo records */
-int glx_dist_sweep_info(const glx_dist_sweep* s, int64_t out[8]);
-/* device microseconds of the rank-local pieces of a sweep, each timed alone over `reps` launches: [0] boundary rows
- * (incl. the scatter), [1] interior rows, [2] the stand-alone pack kernel, [3] boundary + interior back to back */
-int glx_dist_sweep_time_parts(glx_dist_sweep* s, int reps, float us_out[4]);
 int glx_dist_sweep_destroy(glx_dist_sweep* s);
-/* the same pieces one at a time with the transport left to the caller (eager, synchronous): multi-rank tests on one
- * GPU move the packed records between ranks through a host-side backend */
-int glx_dist_sweep_begin(glx_dist_sweep* s);                                    /* state <- initial records; packs them */
-int glx_dist_sweep_boundary(glx_dist_sweep* s, int want_err);                   /* boundary rows of the next iterate; packs them */
-int glx_dist_sweep_get_send(glx_dist_sweep* s, void* host_out);                 /* the packed records (sum of send_counts) */
-int glx_dist_sweep_put_halo(glx_dist_sweep* s, const void* host_in, int next);  /* received records -> halo of the current / next iterate */
-int glx_dist_sweep_interior(glx_dist_sweep* s, int want_err, double* err_local_out);   /* interior rows; next becomes current */
 
 /* ---- affine fixed-point iteration with a sup-norm stop --------------------------------
  * u <- A u + b (b may be NULL) from u0 until max|u_new - u_old| <= tol or max_iter sweeps: the power
@@ -307,10 +250,8 @@ int glx_cg_solve(glx_graph* A, const void* B, void* X, int C, double tol, int64_
  * of group_cols columns each -- the trials of ssl.ssl_trials (graphlearning/ssl.py:292-396, one
  * utils.conjgrad call per trial there).  Every system keeps its own residual norm, stop test and
  * iteration count and is frozen once it converges, so column for column the result is identical
- * to solving it alone.  iters_out / err_out: C/group_cols entries.  C <= 252. */
-int glx_cg_groups(glx_graph* A, const void* B, void* X, int C, int group_cols, double tol, int64_t max_iter,
-                  int flags, int* iters_out, double* err_out);
-/* the same with Dirichlet rows per system: the solve on the sub-matrix of the unlabelled vertices that
+ * to solving it alone.  iters_out / err_out: C/group_cols entries.  C <= 252.
+ * Dirichlet rows per system (mask_rows / mask_ptr; both NULL: none): the solve on the sub-matrix of the unlabelled vertices that
  * ssl.laplace._fit builds for every training set (graphlearning/ssl.py:1232-1250) is carried out on
  * the FULL operator by holding x, r, p at zero on the labelled rows (B must be zero there): their
  * columns then contribute exact zeros to every row sum and reduction, so the unlabelled rows of X and
@@ -345,9 +286,7 @@ int glx_argmax_project_t(const void* prob, int prob_dtype, int64_t n, int C, con
 /* the same decision on a sweep's device-resident state (no host round trip).  labels_out may be NULL.
  * to_onehot != 0 then replaces the state by onehot(labels): the hand-over between the heat sweeps and
  * the volume-constrained thresholding of ssl.poisson_mbo._fit (graphlearning/ssl.py:826-832). */
-int glx_sweep_project(glx_sweep* s, const double* priors, double* weights_inout, int64_t* labels_out,
-                      double* err_out, int* steps_out, int max_steps, int similarity, int to_onehot);
-/* The same, and -- then_iterate > 0, needs to_onehot -- that many sweeps enqueued behind the one-hot state before the call returns
+/* then_iterate > 0 (needs to_onehot): that many sweeps are enqueued behind the one-hot state before the call returns
  * (not awaited: the next call on this sweep is ordered behind them): PoissonMBO's thresholding and its next chunk of heat sweeps
  * (ssl.py:826-832) without a host round trip between them. */
 int glx_sweep_project_iterate(glx_sweep* s, const double* priors, double* weights_inout, int64_t* labels_out, double* err_out,
@@ -375,19 +314,6 @@ int glx_knn_bruteforce_range(const double* X, int64_t n, int d, int k, int64_t q
  * neighbour.  The role of the tree in the reference's search (cKDTree / annoy, graphlearning/weightmatrix.py:297-429). */
 int glx_knn_cells_range(const double* X, int64_t n, int d, int k, const int64_t* cell_starts, int ncells, int64_t q_begin,
                         int64_t q_end, int64_t* ind_out, double* dist_out, int device);
-/* all n rows in the caller's order, the cells formed by the library: ncells (<= 4096; 0 / 1 = plain all-pairs search) evenly
- * spaced rows serve as centres, every row joins the nearest, the rows are reordered by cell on the device and searched with the
- * pruning of glx_knn_cells_range.  Indices and output rows are the caller's, equal distances go to the lower caller index: the
- * lists of glx_knn_bruteforce bit for bit.  ncells < -1: the rows reordered by -ncells chained cells on the device, then ALL PAIRS
- * (no pruning: a wavefront's queries share a corner of feature space, which is worth 10-14 % of the search on clustered data
- * below the size where pruning pays, and nothing elsewhere).  glx_knn_search hands that order out with its result. */
-int glx_knn_clustered(const double* X, int64_t n, int d, int k, int ncells, int64_t* ind_out, double* dist_out, int device);
-/* Plan overrides of the calling thread's searches (tests and A/B measurements; NULL or all-default values = the library decides):
- * filter 0 auto | 1 split-bf16 | 2 fp32 operands; lists 0 auto | 1 short | 2 long (one list holds all k neighbours of a query);
- * nsplit 0 auto | 1..8 ref ranges per query block; concat -1 auto | 0 blocks of 16 features | 1 concatenated split operands
- * (d <= 21) | 2 with the norm folded in (d <= 20).  Every plan returns the same exact lists. */
-typedef struct { int filter, lists, nsplit, concat; } glx_knn_options;
-int glx_knn_set_options(const glx_knn_options* opt);
 
 /* ---- search results as objects (what weightmatrix.knn uses) ---------------------------------------------------------------------
  * glx_knn_search runs the full search (every row a query, self included; ncells as in glx_knn_clustered: 0 / 1 all pairs,
@@ -406,16 +332,6 @@ int glx_knn_result_order(const glx_knn_result* res, int32_t* perm_out);
 int glx_knn_result_to_csr(const glx_knn_result* res, int k, int kernel, int sym, const double* weights, int64_t cap,
                           int32_t* rowptr, int32_t* col, double* val, int64_t* nnz_out);
 int glx_knn_result_destroy(glx_knn_result* res);
-/* out[i] = exp(x[i]) correctly rounded (csrc/exp_cr.h: the exponential of the Gaussian weights), host arrays; a test hook */
-int glx_exp_cr(const double* x, double* out, int64_t n, int device);
-
-int glx_knn_stats(double stats[16]);  /* of the calling thread's last search: [0] tile-kernel ms, [1] re-rank ms, [2] fallback rows, [3] total device ms,
-                                        [4] fallback ms, [5] padded feature count, [6] ref ranges, [7] list length (negative: bf16 filter),
-                                        [8] rows the short lists could not accept when the search was repeated with long ones (else 0);
-                                        [9] concatenated operands (d <= 21): 0 no, 1 yes, 2 with the norm folded in (d <= 20),
-                                        [10] tile stride of the sample the seeding pre-pass looked at (0: no pre-pass; tile-kernel ms
-                                        include it and the cell passes), [11] share of the (query block, ref tile) pairs visited and
-                                        [12] number of cells of a cell-pruned search (0: all pairs); [13..15] reserved */
 
 /* weightmatrix.knn given knn data (graphlearning/weightmatrix.py:134-187) on the device: kernel
  * weights, COO->CSR with duplicates summed, symmetrisation, zero diagonal, zeros dropped.
@@ -445,4 +361,7 @@ int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, int64_t m, 
 #ifdef __cplusplus
 }
 #endif
+/* Laboratory and auxiliary entry points -- host helpers of the Python boundary, plan overrides and statistics for A/B runs, the
+ * device-pointer calls of the torch fallback engine, the stepwise form of the distributed sweep for one-GPU multi-rank tests -- are
+ * exported by the same library and declared in glx_experimental.h: no stability promise, not needed to use the path. */
 #endif

@@ -1,0 +1,31 @@
+#!/bin/bash
+# A soak of the randomised parity suite with breadcrumbs: scripts/soak.sh TAG SCALE WORKERS [INSTANCES] [extra pytest args]
+#   INSTANCES independent pytest-xdist sessions of WORKERS workers each run side by side on the one GPU (more processes sharing the
+#   device than one session has: the condition the round-4 flake appeared under, and N soaks for the wall time of one).
+# Output: gpurun_out/TAG/inst<i>/{pytest.log,crumbs/*.log}; the last lines of every session are echoed; exit status = number of
+# sessions that did not pass.
+tag=$1; scale=$2; workers=$3; inst=${4:-1}; shift 4 2>/dev/null || shift $#
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$root"
+export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
+pids=()
+for i in $(seq 1 $inst); do
+  out=$root/gpurun_out/$tag/inst$i
+  mkdir -p "$out/crumbs"
+  GLX_CRUMBS=$out/crumbs GLX_FUZZ_SCALE=$scale timeout ${GLX_SOAK_TIMEOUT:-3000} \
+    python -m pytest tests/test_gpu_fuzz.py -q -x -n $workers --tb=long -rf -p no:cacheprovider "$@" > "$out/pytest.log" 2>&1 &
+  pids+=($!)
+done
+bad=0
+for i in $(seq 1 $inst); do
+  wait ${pids[$((i-1))]}; rc=$?
+  echo "== [$tag/inst$i] exit $rc"
+  tail -n 4 "$root/gpurun_out/$tag/inst$i/pytest.log" | cut -c1-300
+  [ $rc -ne 0 ] && bad=$((bad+1))
+done
+# what every process was doing last (a crash or a hang leaves a START without an outcome)
+for f in "$root"/gpurun_out/$tag/inst*/crumbs/*.log; do
+  last=$(grep -a -E ' (START|PASSED|FAILED|SKIPPED) ' "$f" | tail -n 1)
+  case "$last" in *" START "*|*" FAILED "*) echo "   $(basename $(dirname $(dirname $f)))/$(basename $f): $last" | cut -c1-300;; esac
+done
+exit $bad

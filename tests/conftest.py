@@ -28,6 +28,36 @@ def pytest_configure(config):
             pass
 
 
+# ---- breadcrumbs (soak runs) ----------------------------------------------------------------------------------------
+# GLX_CRUMBS=<directory>: every worker process appends one line per test to <directory>/crumbs.<pid>.log BEFORE the test
+# runs (test id, wall time) and one line with the outcome behind it, flushed and fsync'ed -- so that a failure, a crash of a
+# worker or a hang inside a soak of thousands of cases names its case, and the sequence of cases the same process ran
+# before it (what a failure that depends on the process's history needs: scripts/soak.sh, scripts/replay_crumbs.py).
+_CRUMBS = os.environ.get('GLX_CRUMBS')
+
+
+def _crumb(text):
+    if not _CRUMBS:
+        return
+    import time
+    os.makedirs(_CRUMBS, exist_ok=True)
+    with open(os.path.join(_CRUMBS, 'crumbs.%d.log' % os.getpid()), 'a') as f:
+        f.write('%.3f %s\n' % (time.time(), text))
+        f.flush()
+        os.fsync(f.fileno())
+
+
+def pytest_runtest_logstart(nodeid, location):
+    _crumb('START %s' % nodeid)
+
+
+def pytest_runtest_logreport(report):
+    if _CRUMBS and (report.when == 'call' or report.outcome != 'passed'):
+        _crumb('%s %s %s %.3fs' % (report.outcome.upper(), report.when, report.nodeid, report.duration))
+        if report.outcome == 'failed':
+            _crumb('TRACEBACK %s\n%s' % (report.nodeid, report.longreprtext))
+
+
 @pytest.fixture
 def device_exp():
     """weightmatrix.knn in its default mode inside the test."""

@@ -127,7 +127,14 @@ def main():
     counts = [None] * world
     dist.all_gather_object(counts, (plan.send_counts, plan.recv_counts, plan.n_own, plan.n_halo))
     ok_counts = all(counts[a][0][b] == counts[b][1][a] for a in range(world) for b in range(world))
-    res = dict(rank=rank, world=world, T=int(T), T_ref=int(T_ref), equal=bool(np.array_equal(u, u_ref)),
+    # the ranks' digest comparison of a plan (collective): silent on agreement, an error on EVERY rank when one rank differs
+    gdist._agree(dist, None, [np.arange(7), bounds], 'test')
+    try:
+        gdist._agree(dist, None, [np.arange(7) + (1 if rank == world - 1 else 0)], 'test')
+        caught = False
+    except RuntimeError:
+        caught = True
+    res = dict(rank=rank, world=world, T=int(T), T_ref=int(T_ref), equal=bool(np.array_equal(u, u_ref)), disagree_caught=caught,
                ok_counts=bool(ok_counts), n_own=int(plan.n_own), n_halo=int(plan.n_halo), global_halo=int(plan.global_halo),
                sorted_perm=bool(np.array_equal(np.sort(order), np.arange(P.shape[0]))))
     with open(out_path + '.%d' % rank, 'w') as f:

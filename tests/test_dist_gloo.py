@@ -38,10 +38,23 @@ def test_distributed_sweep_matches_oracle(case, world, tmp_path):
         assert r['T'] == r['T_ref'], r
         assert r['equal'], r                 # bit-identical to the single-rank reference iterates
         assert r['ok_counts'] and r['sorted_perm']
+        assert r['disagree_caught'], r       # a rank with another plan is noticed by every rank (dist._agree)
     assert sum(r['n_own'] for r in res) in (500, 1500)
     if case == 'twomoons':
         assert res[0]['T'] == 409            # the stop test fired at the reference's iteration
         assert all(r['n_halo'] > 0 for r in res)
+
+
+def test_unknown_partition_name_is_rejected():
+    from scipy import sparse
+    from graphlearning_amd import dist as gdist
+    P = sparse.identity(8, format='csr')
+    for bad in ('Even', 'blocks', '', None):
+        with pytest.raises(ValueError):
+            gdist.plan_partition(P, np.arange(8), 2, bad)
+    for ok in gdist.PARTITIONS:
+        order, bounds, info = gdist.plan_partition(P, np.arange(8), 2, ok)
+        assert bounds[0] == 0 and bounds[-1] == 8
 
 
 def test_rank_plan_properties(golden):

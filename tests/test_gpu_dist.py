@@ -51,18 +51,19 @@ def test_hipops_rank_local_sweeps_match_scipy(golden):
 
 @pytest.mark.parametrize('force_coll,engine', [('0', 'glx'), ('1', 'glx'), ('1', 'torch')])
 def test_distributed_bench_entry_one_rank(tmp_path, force_coll, engine):
-    # force_coll=1 (GLX_DIST_FORCE_COLLECTIVES): the all_to_all / all_reduce calls are issued even with one rank (eagerly:
-    # collectives are never captured into a device graph, see DistSweep.run); GLX_DIST_ENGINE=torch: the torch.distributed engine
-    # the bench falls back to when the library's own communicator cannot be set up
-    env = dict(os.environ, GLX_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0', GLX_DIST_FORCE_COLLECTIVES=force_coll,
-               GLX_DIST_ENGINE=engine, GLX_DIST_SELFTEST_TIMEOUT='20')
+    # --force-collectives: the all_to_all / all_reduce calls are issued even with one rank (eagerly: collectives are never captured
+    # into a device graph, see DistSweep.run); --engine torch: the torch.distributed engine the bench falls back to when the
+    # library's own communicator cannot be set up
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GLX_DIST_SELFTEST_TIMEOUT='20')
     import socket
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1']
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--force-dist', '--engine', engine]
+    if force_coll == '1':
+        cmd.append('--force-collectives')
     r = run_ranks(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'capture unavailable' not in r.stderr, r.stderr[-2000:]

@@ -34,7 +34,7 @@ m = gl.ssl.poisson(W, solver='gradient_descent')
 u = m.fit(ti, lab[ti])
 assert m.num_iter == int(g1['poisson_gd_T']) and np.array_equal(u, g1['poisson_gd_prob'])
 assert np.array_equal(gl.ssl.poisson(W).fit(ti, lab[ti]), g1['poisson_cg_prob'])
-assert np.array_equal(gl.ssl.laplace(W).fit(ti, lab[ti]), g1['laplace_combinatorial_prob'])
+assert np.array_equal(gl.ssl.laplace(W, reduce='exact').fit(ti, lab[ti]), g1['laplace_combinatorial_prob'])
 # a graph above the sizes at which the search forms cells / the operators take the search's order
 rng = np.random.default_rng(5)
 X = rng.normal(size=(8, 16))[rng.integers(0, 8, size=6000)] * 2.0 + rng.normal(size=(6000, 16))

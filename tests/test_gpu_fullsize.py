@@ -26,20 +26,45 @@ def gl():
     return gl
 
 
+# Both modes of weightmatrix.knn's Gaussian weights (see tests/test_gpu_fuzz.py): 'host_exp' = this host's numpy exp, the bits of the
+# reference's recorded runs; 'device_exp' = the product's default (correctly rounded exp on the device).  In the default mode the
+# recorded checksums of the reference's runs are held to the north star's contract (structure identical, T / Laplace iteration
+# counts / labels equal, sampled iterates within 1e-5), and the stages whose reference answer hangs on rounding noise -- the
+# singular Poisson CG system, PoissonMBO's thresholding -- are held bit for bit against the oracle run on the SAME matrix instead.
+@pytest.fixture(scope='module', params=['host_exp', 'device_exp'])
+def mode(request):
+    old = os.environ.get('GLX_HOST_EXP')
+    if request.param == 'host_exp':
+        os.environ['GLX_HOST_EXP'] = '1'
+    else:
+        os.environ.pop('GLX_HOST_EXP', None)
+    yield request.param
+    if old is None:
+        os.environ.pop('GLX_HOST_EXP', None)
+    else:
+        os.environ['GLX_HOST_EXP'] = old
+
+
+def _record(line):
+    os.makedirs(os.path.join(os.path.dirname(GOLDEN), '..', 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(os.path.dirname(GOLDEN), '..', 'gpurun_out', 'default_mode_deviations.txt'), 'a') as f:
+        f.write(line + '\n')
+
+
 @pytest.fixture(scope='module')
 def meta():
     return json.load(open(os.path.join(GOLDEN, 'g4_large_meta.json')))
 
 
 @pytest.fixture(scope='module')
-def config2(gl):
+def config2(gl, mode):
     labels = np.load(os.path.join(GOLDEN, 'MNIST_labels.npz'))['labels'].astype(np.int64)
     rng = np.random.default_rng(0)
     centers = rng.normal(size=(10, 20)) * 2.0
     X = centers[labels] + rng.normal(size=(70000, 20))
     J, D = gl.weightmatrix.knnsearch(X, 11)
     W = gl.weightmatrix.knn(None, 10, knn_data=(J, D))
-    return dict(labels=labels, X=X, J=J, D=D, W=W, train_ind=gl.trainsets.generate(labels, rate=1, seed=0))
+    return dict(labels=labels, X=X, J=J, D=D, W=W, train_ind=gl.trainsets.generate(labels, rate=1, seed=0), mode=mode)
 
 
 def test_config2_graph(gl, meta, config2):
@@ -94,19 +119,40 @@ def test_config2_poisson_cg(gl, meta, config2):
     t0 = time.perf_counter()
     u = model.fit(ti, labels[ti])
     print('poisson CG 70k: %d iterations, %.3f s' % (model.num_iter, time.perf_counter() - t0))
+    if config2['mode'] == 'device_exp':
+        # the singular system stopped at 1e-3: one-ulp weights move the iteration count (tests/test_gpu_weights.py) -- bit for bit
+        # against the oracle on the SAME matrix; the distance to the reference's recorded run is recorded, not asserted
+        from oracle import gl_oracle as orc
+        u_ref, it_ref = orc.poisson_cg(W, ti, labels[ti], return_iters=True)
+        assert model.num_iter == it_ref and np.array_equal(u, u_ref)
+        _record('config 2 Poisson CG, default mode: %d iterations (the reference on its own W: %d), labels equal to the reference run: %s, '
+                'sampled |du| %.3e' % (it_ref, m['cg_iters'], sha(model.predict().astype(np.int64)) == m['cg_pred_sha'], _sample_err(u, m['cg_u_samples'])))
+        return
     assert model.num_iter == m['cg_iters'] == 140
     assert sha(model.predict().astype(np.int64)) == m['cg_pred_sha']
     assert abs(np.abs(u).sum() - m['cg_prob_abs_sum']) <= 1e-9 * m['cg_prob_abs_sum']
     assert _sample_err(u, m['cg_u_samples']) <= 1e-5               # 140 iterations of a singular system, element-wise
 
 
-def _check_config5(gl, m, W, labels, ti):
+def _check_config5(gl, m, W, labels, ti, mode='host_exp'):
     pri = gl.utils.class_priors(labels)
     model = gl.ssl.poisson_mbo(W, pri, solver='gradient_descent', Ns=40, mu=1, T=20)
     t0 = time.perf_counter()
     prob = model.fit(ti, labels[ti])
     pred = model.predict()
     print('poisson_mbo 70k: %.3f s, accuracy %.2f' % (time.perf_counter() - t0, gl.ssl.ssl_accuracy(pred, labels, ti)))
+    if mode == 'device_exp':
+        # thresholding is discontinuous in the weights: bit for bit against the oracle's run on the SAME matrix (the reference's
+        # loop, ~13 s on the host); the distance to the reference's recorded run is recorded
+        from oracle import gl_oracle as orc
+        u_ref, lab_ref, w_ref = orc.poisson_mbo_fit(W, ti, labels[ti], pri, solver='gradient_descent', Ns=40, mu=1, T=20)
+        assert np.array_equal(prob, u_ref) and np.array_equal(pred, lab_ref)
+        assert np.array_equal(np.asarray(model.weights), np.asarray(w_ref))
+        _record('config 5 (%d labelled), default mode: class sizes %s (the reference on its own W: %s), accuracy %.4f (%.4f), labels hash equal: %s'
+                % (len(ti), [int(c) for c in np.bincount(pred, minlength=10)], m['class_sizes'], gl.ssl.ssl_accuracy(pred, labels, ti), m['accuracy'],
+                   sha(pred.astype(np.int64)) == m['pred_sha']))
+        assert abs(gl.ssl.ssl_accuracy(pred, labels, ti) - m['accuracy']) <= 0.05
+        return
     # pinned to the reference's run in the build container (tests/golden/make_golden.py g4_config5)
     assert sha(pred.astype(np.int64)) == m['pred_sha']
     assert sha(np.ascontiguousarray(prob, dtype=np.float64)) == m['prob_sha'] and np.abs(prob).sum() == m['prob_abs_sum']
@@ -122,10 +168,10 @@ def _check_config5(gl, m, W, labels, ti):
 def test_config5_poisson_mbo_pinned(gl, meta, config2):
     """Config 5 (ssl.poisson_mbo on the config-2 graph, reference ssl.py:774-839): labels, one-hot state, volume
     weights and class-priors error equal the reference's."""
-    _check_config5(gl, meta['config5'], config2['W'], config2['labels'], config2['train_ind'])
+    _check_config5(gl, meta['config5'], config2['W'], config2['labels'], config2['train_ind'], config2['mode'])
 
 
-def test_config5_hard_overlapping_blobs_pinned(gl, meta):
+def test_config5_hard_overlapping_blobs_pinned(gl, meta, mode):
     """The same pipeline on overlapping blobs (accuracy 92 %): the volume-constrained projection moves the class
     weights away from 1 over many steps inside every one of the 21 projections -- all pinned to the reference."""
     m = meta['config5_hard']
@@ -139,10 +185,10 @@ def test_config5_hard_overlapping_blobs_pinned(gl, meta):
     assert W.nnz == m['nnz'] and sha(W.indices.astype(np.int32)) == m['W_indices_sha']
     ti = gl.trainsets.generate(labels, rate=2, seed=3)
     assert any(abs(w - 1.0) > 1e-3 for w in m['weights'])
-    _check_config5(gl, m, W, labels, ti)
+    _check_config5(gl, m, W, labels, ti, mode)
 
 
-def test_config3_laplace(gl, meta):
+def test_config3_laplace(gl, meta, mode):
     m = meta['config3']
     labels = np.load(os.path.join(GOLDEN, 'cifar_labels.npz'))['labels'].astype(np.int64)
     rng = np.random.default_rng(1)
@@ -154,7 +200,7 @@ def test_config3_laplace(gl, meta):
     assert W.nnz == m['nnz'] and np.diff(W.indptr).max() == m['row_nnz_max'] == 660
     assert sha(W.indices.astype(np.int32)) == m['W_indices_sha']
     ti = gl.trainsets.generate(labels, rate=10, seed=0)
-    model = gl.ssl.laplace(W)
+    model = gl.ssl.laplace(W, reduce='exact')
     t0 = time.perf_counter()
     u = model.fit(ti, labels[ti])
     print('laplace CG 60k: %d iterations, %.3f s' % (model.num_iter, time.perf_counter() - t0))

@@ -26,6 +26,88 @@ def orc():
     return gl_oracle
 
 
+# The two modes of weightmatrix.knn's Gaussian weights: 'host_exp' (GLX_HOST_EXP=1: numpy's exp on this host -- the bits of the
+# reference run here, what the golden vectors hold) and 'device_exp' (the PRODUCT'S DEFAULT: the correctly rounded exp on the
+# device).  In the default mode W differs from this host's reference by at most one ulp per exponential, so the contract has two
+# halves: (1) every solver stage is bit-identical to the oracle applied to the SAME W (nothing but the exp differs from the
+# reference's arithmetic), (2) against the reference's own W the north star's contract -- structure identical, weights within an
+# ulp (two for a symmetrised sum), T equal, labels equal, iterates within 1e-5 -- with every deviation RECORDED with its margin
+# (gpurun_out/default_mode_deviations.txt) and allowed only where the reference's own answer hangs on a rounding: a stop value or a
+# residual within 1e-9 of its threshold, a label whose two best scores tie to 1e-9.  ssl.poisson's default CG solves a SINGULAR
+# system to 1e-3: its iteration count is decided by rounding noise (tests/test_gpu_weights.py: 140 vs 462 at config 2 for one-ulp
+# weights) -- for that stage only half (1) is asserted and the difference to the reference's run is recorded.
+@pytest.fixture(params=['host_exp', 'device_exp'])
+def mode(request):
+    import os
+    old = os.environ.get('GLX_HOST_EXP')
+    if request.param == 'host_exp':
+        os.environ['GLX_HOST_EXP'] = '1'
+    else:
+        os.environ.pop('GLX_HOST_EXP', None)
+    yield request.param
+    if old is None:
+        os.environ.pop('GLX_HOST_EXP', None)
+    else:
+        os.environ['GLX_HOST_EXP'] = old
+
+
+def _ulps(a, b):
+    return np.abs(np.ascontiguousarray(a, dtype=np.float64).view(np.int64) - np.ascontiguousarray(b, dtype=np.float64).view(np.int64))
+
+
+def _record(line):
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(root, 'gpurun_out', 'default_mode_deviations.txt'), 'a') as f:
+        f.write(line + '\n')
+
+
+def _north_star(tag, what, u, u_ref, pred=None, pred_ref=None, count=None, count_ref=None, near=None, strict_count=True):
+    """Half (2) of the default-mode contract against the run on the reference's own W.  `near`: how close (relative) the
+    reference's run came to the threshold that decides `count` -- a deviation of the count is allowed (and recorded) only
+    when the decision hung on a rounding."""
+    scale = max(1.0, float(np.nanmax(np.abs(u_ref)))) if np.size(u_ref) else 1.0
+    du = float(np.nanmax(np.abs(np.asarray(u, dtype=np.float64) - u_ref))) if np.size(u_ref) else 0.0
+    if count is not None and count != count_ref:
+        _record('%s | %s: count %s vs the reference-W run %s (reference run within %.3e of its threshold), max |du| %.3e'
+                % (tag, what, count, count_ref, -1.0 if near is None else near, du))
+        if strict_count:
+            assert near is not None and near <= 1e-9, (tag, what, count, count_ref, near)
+        return
+    assert du <= 1e-5 * scale, (tag, what, du)
+    if pred is not None and not np.array_equal(pred, pred_ref):
+        rows = np.flatnonzero(np.asarray(pred) != np.asarray(pred_ref))
+        srt = np.sort(np.asarray(u_ref, dtype=np.float64)[rows], axis=1)
+        gap = float(np.max(srt[:, -1] - srt[:, -2]))
+        _record('%s | %s: %d labels differ from the reference-W run; largest gap between their two best scores %.3e (max |u| %.3e)'
+                % (tag, what, len(rows), gap, scale))
+        assert gap <= 1e-9 * scale, (tag, what, len(rows), gap)
+
+
+def _gd_stop_margin(orc, W, train_ind, min_iter=50, max_iter=1000):
+    """How close (relative to 1/n) the reference's stop values max|v_t - vinf| (ssl.py:667) come to the threshold 1/n."""
+    n = W.shape[0]
+    W = sparse.csr_matrix(W - sparse.spdiags(W.diagonal(), 0, n, n))
+    D = orc.degree_matrix(W, p=-1)
+    deg = orc.degree_vector(W)
+    v = np.zeros(n)
+    v[train_ind] = 1
+    v = v / np.sum(v)
+    vinf = deg / np.sum(deg)
+    RW = W.transpose() * D
+    T, best = 0, np.inf
+    while T < max_iter:
+        e = np.max(np.absolute(v - vinf))
+        if T >= min_iter:
+            best = min(best, abs(e * n - 1.0))
+            if not (e > 1 / n):
+                break
+        v = RW * v
+        T += 1
+    return float(best)
+
+
 def _case(seed):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.integers(40, 1500))
@@ -45,10 +127,10 @@ def _case(seed):
 
 
 @pytest.mark.parametrize('seed', range(24 * _SCALE))
-def test_random_pipeline_matches_the_oracle(gl, orc, seed):
+def test_random_pipeline_matches_the_oracle(gl, orc, seed, mode):
     c = _case(seed)
     X, lab, ti, k = c['X'], c['lab'], c['ti'], c['k']
-    tag = 'seed %d: n=%d d=%d C=%d k=%d %s sym=%s' % (seed, c['n'], c['d'], c['C'], k, c['kernel'], c['symmetrize'])
+    tag = '%s seed %d: n=%d d=%d C=%d k=%d %s sym=%s' % (mode, seed, c['n'], c['d'], c['C'], k, c['kernel'], c['symmetrize'])
     # a-1: the search (k + 1 columns incl. self), cKDTree's lists
     J, D = gl.weightmatrix.knnsearch(X, k + 1)
     Jo, Do = orc.knnsearch(X, k + 1)
@@ -57,47 +139,80 @@ def test_random_pipeline_matches_the_oracle(gl, orc, seed):
     # a-2: the weight matrix from the SAME kNN data
     W = gl.weightmatrix.knn(None, k, kernel=c['kernel'], symmetrize=c['symmetrize'], knn_data=(Jo, Do.copy()))
     Wo = orc.knn_weights(Jo, Do.copy(), k, kernel=c['kernel'], symmetrize=c['symmetrize'])
-    assert np.array_equal(W.indptr, Wo.indptr) and np.array_equal(W.indices, Wo.indices) and np.array_equal(W.data, Wo.data), tag
-    if not c['symmetrize'] or c['kernel'] in ('distance', 'singular'):
+    assert np.array_equal(W.indptr, Wo.indptr) and np.array_equal(W.indices, Wo.indices), tag
+    device = mode == 'device_exp' and c['kernel'] in ('gaussian', 'symgaussian')
+    if not device:
+        assert np.array_equal(W.data, Wo.data), tag
+    else:
+        # one ulp per exponential; (a + b) / 2 of two of them at most two; symgaussian's rule subtracts (fl(fl(a+b)-a)): a few ulps
+        # of the smaller entry (tests/test_gpu_weights.py)
+        most = 1 if not c['symmetrize'] else (2 if c['kernel'] == 'gaussian' else 8)
+        assert int(_ulps(W.data, Wo.data).max(initial=0)) <= most, (tag, int(_ulps(W.data, Wo.data).max()))
+    if (not c['symmetrize'] or c['kernel'] in ('distance', 'singular')) and not device:
         # directed graphs / unbounded weights: the sweep is the part of the path defined for them
         W = Wo
+    Wsame = sparse.csr_matrix(W) if device else Wo              # the matrix the oracle is handed for half (1)
     with np.errstate(all='ignore'):
         # a-3: gradient descent incl. the stop test
-        u_ref, T_ref = orc.poisson_gd(Wo, ti, lab[ti], return_T=True)
+        u_ref, T_ref = orc.poisson_gd(Wsame, ti, lab[ti], return_T=True)
         m = gl.ssl.poisson(W, solver='gradient_descent')
         u = m.fit(ti, lab[ti])
         assert m.num_iter == T_ref, tag
         assert np.array_equal(u, u_ref, equal_nan=True), tag
-        assert np.array_equal(m.predict(), orc.predict(u_ref)), tag
+        pred = m.predict()
+        assert np.array_equal(pred, orc.predict(u_ref)), tag
+        if device:
+            uo, To = orc.poisson_gd(Wo, ti, lab[ti], return_T=True)
+            near = _gd_stop_margin(orc, Wo, ti) if To != T_ref else None
+            _north_star(tag, 'poisson GD', u, uo, pred, orc.predict(uo), T_ref, To, near)
         if not c['symmetrize'] or c['kernel'] in ('distance', 'singular'):
             return
         # a-4: conjugate gradient on the singular system
-        u_ref, it_ref = orc.poisson_cg(Wo, ti, lab[ti], return_iters=True)
+        u_ref, it_ref = orc.poisson_cg(Wsame, ti, lab[ti], return_iters=True)
         m = gl.ssl.poisson(W)
         u = m.fit(ti, lab[ti])
         assert m.num_iter == it_ref, tag
         assert np.array_equal(u, u_ref, equal_nan=True), tag
+        if device:
+            uo, ito = orc.poisson_cg(Wo, ti, lab[ti], return_iters=True)
+            _north_star(tag, 'poisson CG (singular system: the count hangs on rounding noise)', u, uo, None, None, it_ref, ito, None,
+                        strict_count=False)
         # a-5: Laplace, a random normalisation / tau / mean shift
         norm = str(c['rng'].choice(['combinatorial', 'randomwalk', 'normalized']))
         tau = float(c['rng'].choice([0.0, 0.0, 0.01]))
         shift = bool(c['rng'].random() < 0.3)
-        u_ref, it_ref = orc.laplace_fit(Wo, ti, lab[ti], normalization=norm, tau=tau, mean_shift=shift, return_iters=True)
-        m = gl.ssl.laplace(W, normalization=norm, tau=tau, mean_shift=shift)
+        u_ref, it_ref = orc.laplace_fit(Wsame, ti, lab[ti], normalization=norm, tau=tau, mean_shift=shift, return_iters=True)
+        m = gl.ssl.laplace(W, normalization=norm, tau=tau, mean_shift=shift, reduce='exact')
         u = m.fit(ti, lab[ti])
         assert m.num_iter == it_ref, (tag, norm, tau, shift)
         assert np.array_equal(u, u_ref, equal_nan=True), (tag, norm, tau, shift)
+        if device:
+            uo, ito = orc.laplace_fit(Wo, ti, lab[ti], normalization=norm, tau=tau, mean_shift=shift, return_iters=True)
+            # (an SPD system stopped at 1e-5: a one-ulp weight may move the stop by an iteration; the iterates then differ by ~tol)
+            if abs(it_ref - ito) <= 1 and it_ref != ito:
+                _record('%s | laplace %s: %d iterations vs the reference-W run %d, max |du| %.3e' % (tag, norm, it_ref, ito, float(np.nanmax(np.abs(u - uo)))))
+                assert np.nanmax(np.abs(u - uo)) <= 1e-4 * max(1.0, np.nanmax(np.abs(uo))), (tag, norm)
+            else:
+                _north_star(tag, 'laplace ' + norm, u, uo, m.predict(), orc.predict(uo), it_ref, ito, None)
         # a-6 / a-7: PoissonMBO with the volume constraint (short schedule)
         priors = orc.class_priors(lab)
-        u_ref, lab_ref, w_ref = orc.poisson_mbo_fit(Wo, ti, lab[ti], priors, solver='gradient_descent', Ns=12, T=4)
+        u_ref, lab_ref, w_ref = orc.poisson_mbo_fit(Wsame, ti, lab[ti], priors, solver='gradient_descent', Ns=12, T=4)
         m = gl.ssl.poisson_mbo(W, priors, solver='gradient_descent', Ns=12, T=4)
         pred = m.fit_predict(ti, lab[ti])
         assert np.array_equal(m.prob, u_ref), tag
         assert np.array_equal(pred, lab_ref), tag
         assert np.array_equal(np.asarray(m.weights), np.asarray(w_ref)), tag
+        if device:
+            # (thresholding is discontinuous: the comparison with the reference-W run is a count of labels, recorded when not zero)
+            _, lab_o, _ = orc.poisson_mbo_fit(Wo, ti, lab[ti], priors, solver='gradient_descent', Ns=12, T=4)
+            nd = int(np.sum(np.asarray(pred) != np.asarray(lab_o)))
+            if nd:
+                _record('%s | poisson_mbo: %d of %d labels differ from the reference-W run' % (tag, nd, c['n']))
+            assert nd <= max(2, c['n'] // 100), (tag, nd)
 
 
 @pytest.mark.parametrize('seed', range(12 * _SCALE))
-def test_random_trials_and_comparison_methods_match_the_oracle(gl, orc, seed):
+def test_random_trials_and_comparison_methods_match_the_oracle(gl, orc, seed, mode):
     """Stacked trials (several training sets as column groups of one solve), the float32 branch, and the comparison
     methods of SURVEY 8 f-3 on random symmetric graphs."""
     c = _case(100 + seed)
@@ -108,8 +223,14 @@ def test_random_trials_and_comparison_methods_match_the_oracle(gl, orc, seed):
     W = gl.weightmatrix.knn(X, k)
     assert np.array_equal(W.indices, Wo.indices) and np.max(np.abs(W.data - Wo.data)) <= 1e-12
     W = gl.weightmatrix.knn(None, k, knn_data=(Jo, Do.copy()))
-    assert np.array_equal(W.data, Wo.data)
-    tag = 'seed %d: n=%d d=%d C=%d k=%d' % (seed, c['n'], c['d'], C, k)
+    if mode == 'host_exp':
+        assert np.array_equal(W.data, Wo.data)
+    else:
+        # the product's default: weights within two ulps of this host's reference ((a + b) / 2 of two exponentials); every solver
+        # below is then held against the oracle on the SAME matrix
+        assert np.array_equal(W.indices, Wo.indices) and int(_ulps(W.data, Wo.data).max(initial=0)) <= 2
+        Wo = sparse.csr_matrix(W)
+    tag = '%s seed %d: n=%d d=%d C=%d k=%d' % (mode, seed, c['n'], c['d'], C, k)
     sets = []
     for _ in range(int(rng.integers(2, 6))):
         per_class = int(rng.integers(1, 4))
@@ -125,7 +246,7 @@ def test_random_trials_and_comparison_methods_match_the_oracle(gl, orc, seed):
             assert np.array_equal(probs[j], u_ref, equal_nan=True), (tag, j)
         same_size = [t for t in sets if len(t) == len(sets[0])]
         if len(same_size) > 1:
-            m = gl.ssl.laplace(W)
+            m = gl.ssl.laplace(W, reduce='exact')
             probs = m._fit_batch([(t, lab[t]) for t in same_size])
             if probs is not None:
                 for j, t in enumerate(same_size):
@@ -139,12 +260,12 @@ def test_random_trials_and_comparison_methods_match_the_oracle(gl, orc, seed):
         assert np.max(np.abs(u - u_ref)) <= 1e-5 * max(1.0, np.max(np.abs(u_ref))), tag     # T sweeps of float32 rounding scale with |u|
         # f-3: random walk, reweighted Laplace, page rank
         u_ref, it_ref = orc.randomwalk_fit(Wo, ti, lab[ti], return_iters=True)
-        m = gl.ssl.randomwalk(W)
+        m = gl.ssl.randomwalk(W, reduce='exact')
         u = m.fit(ti, lab[ti])
         assert m.num_iter == it_ref and np.array_equal(u, u_ref), tag
         for rw in ('poisson', 'wnll'):
             u_ref = orc.laplace_reweighted_fit(Wo, ti, lab[ti], rw)
-            u = gl.ssl.laplace(W, reweighting=rw).fit(ti, lab[ti])
+            u = gl.ssl.laplace(W, reweighting=rw, reduce='exact').fit(ti, lab[ti])
             assert np.array_equal(u, u_ref, equal_nan=True), (tag, rw)
         G = gl.graph(W)
         pr_ref, it_ref = orc.page_rank(Wo, return_iters=True)

@@ -470,3 +470,21 @@ def test_result_objects_are_independent_across_threads(gl):
     for (t, rep, j), W in out.items():
         S = serial[j]
         assert np.array_equal(W.indptr, S.indptr) and np.array_equal(W.indices, S.indices) and np.array_equal(W.data, S.data), (t, rep, j)
+
+
+@pytest.mark.parametrize('kernel', ['gaussian', 'symgaussian', 'uniform'])
+def test_out_of_range_neighbour_index_is_an_error_not_a_fault(gl, kernel, device_exp):
+    """User-supplied knn_data with a neighbour index outside [0, n): GlxError('... out of range'), for every kernel -- the
+    symgaussian weights read the neighbour's k-th distance and must not do so out of bounds first.  In the
+    product's default mode (device exp: the `device_exp` fixture)."""
+    from graphlearning_amd import _hip
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(300, 4))
+    J, D = gl.weightmatrix.knnsearch(X, 8)
+    for bad in (10**9, -5, 300):
+        J2 = J.copy()
+        J2[17, 3] = bad
+        with pytest.raises(_hip.GlxError, match='out of range'):
+            gl.weightmatrix.knn(None, 7, kernel=kernel, knn_data=(J2, D.copy()))
+    W = gl.weightmatrix.knn(None, 7, kernel=kernel, knn_data=(J, D.copy()))      # the device is still fine afterwards
+    assert W.shape == (300, 300)

@@ -121,7 +121,7 @@ def test_twomoons_poisson_cg_golden(gl, golden):
 def test_twomoons_laplace_golden(gl, golden, norm):
     g = golden('g1_twomoons.npz')
     W = csr_from(g, 'W_gaussian')
-    m = gl.ssl.laplace(W, normalization=norm)
+    m = gl.ssl.laplace(W, normalization=norm, reduce='exact')
     u = m.fit(g['train_ind'], g['labels'][g['train_ind']])
     assert m.num_iter == int(g['laplace_%s_iters' % norm])
     assert np.array_equal(u, g['laplace_%s_prob' % norm])
@@ -131,7 +131,7 @@ def test_twomoons_laplace_golden(gl, golden, norm):
 def test_twomoons_laplace_tau_meanshift(gl, golden):
     g = golden('g1_twomoons.npz')
     W = csr_from(g, 'W_gaussian')
-    m = gl.ssl.laplace(W, tau=0.01, mean_shift=True)
+    m = gl.ssl.laplace(W, tau=0.01, mean_shift=True, reduce='exact')
     u = m.fit(g['train_ind'], g['labels'][g['train_ind']])
     assert np.array_equal(u, g['laplace_tau_ms_prob'])
 
@@ -176,7 +176,7 @@ def test_blobs5000_golden(gl, golden):
     assert m.num_iter == int(g['poisson_cg_iters'])
     assert np.array_equal(u, g['poisson_cg_prob'])
     assert np.array_equal(m.predict(), g['poisson_cg_pred'])
-    m = gl.ssl.laplace(W)
+    m = gl.ssl.laplace(W, reduce='exact')
     u = m.fit(ti, lab[ti])
     assert m.num_iter == int(g['laplace_iters'])
     assert np.array_equal(u, g['laplace_prob'])
@@ -326,11 +326,11 @@ def test_next_rows_reweight_randomwalk_golden(gl, golden):
         Wr = sparse.csr_matrix(G.reweight(ti, method=method, normalization=norm))
         Wg = csr_from(g, 'Wr_' + tag)
         assert np.array_equal(Wr.indices, Wg.indices) and np.array_equal(Wr.data, Wg.data), tag
-        m = gl.ssl.laplace(W, reweighting=method, normalization=norm)
+        m = gl.ssl.laplace(W, reweighting=method, normalization=norm, reduce='exact')
         u = m.fit(ti, lab[ti])
         assert np.array_equal(u, g['laplace_' + tag + '_prob']), tag
         assert np.array_equal(m.predict(), g['laplace_' + tag + '_pred'])
-    m = gl.ssl.randomwalk(W)
+    m = gl.ssl.randomwalk(W, reduce='exact')
     u = m.fit(ti, lab[ti])
     assert m.num_iter == int(g['randomwalk_iters'])
     assert np.array_equal(u, g['randomwalk_prob']) and np.array_equal(m.predict(), g['randomwalk_pred'])

@@ -157,7 +157,7 @@ def test_tree_reductions_blobs5000_and_randomwalk(gl, golden, orc):
     g = golden('g3_blobs5000.npz')
     W = csr_from(g, 'W')
     ti, lab = g['train_ind'], g['labels']
-    exact = gl.ssl.laplace(W)
+    exact = gl.ssl.laplace(W, reduce='exact')
     ue = exact.fit(ti, lab[ti])
     tree = gl.ssl.laplace(W, reduce='tree')
     ut = tree.fit(ti, lab[ti])
@@ -169,13 +169,13 @@ def test_tree_reductions_blobs5000_and_randomwalk(gl, golden, orc):
     outs = tree._fit_batch([(t, lab[t]) for t in sets])
     for t, o in zip(sets, outs):
         assert np.max(np.abs(o - exact.fit(t, lab[t]))) <= 1e-5
-    rw_e = gl.ssl.randomwalk(W)
+    rw_e = gl.ssl.randomwalk(W, reduce='exact')
     rw_t = gl.ssl.randomwalk(W, reduce='tree')
     a, b = rw_e.fit(ti, lab[ti]), rw_t.fit(ti, lab[ti])
     assert np.max(np.abs(a - b)) <= 1e-5 and np.array_equal(rw_e.predict(), rw_t.predict())
     # a reweighted Laplace fit: graph.reweight('poisson') (singular system) keeps the reference-order reductions, the
     # Dirichlet solve on the reweighted graph (SPD) takes the tolerance mode
-    le = gl.ssl.laplace(W, reweighting='poisson')
+    le = gl.ssl.laplace(W, reweighting='poisson', reduce='exact')
     lt = gl.ssl.laplace(W, reweighting='poisson', reduce='tree')
     a, b = le.fit(ti, lab[ti]), lt.fit(ti, lab[ti])
     assert np.max(np.abs(a - b)) <= 1e-5 and np.array_equal(le.predict(), lt.predict())
@@ -393,8 +393,8 @@ def test_no_device_memory_growth_over_repeated_builds_and_fits(gl):
         X = centres[lab] + rng.normal(size=(8000, 12))
         W = gl.weightmatrix.knn(X, 9)
         ti = gl.trainsets.generate(lab, rate=2, seed=r)
-        for model in (gl.ssl.poisson(W, solver='gradient_descent'), gl.ssl.poisson(W), gl.ssl.laplace(W),
-                      gl.ssl.poisson_mbo(W, gl.utils.class_priors(lab), solver='gradient_descent', T=2), gl.ssl.randomwalk(W)):
+        for model in (gl.ssl.poisson(W, solver='gradient_descent'), gl.ssl.poisson(W), gl.ssl.laplace(W, reduce='exact'),
+                      gl.ssl.poisson_mbo(W, gl.utils.class_priors(lab), solver='gradient_descent', T=2), gl.ssl.randomwalk(W, reduce='exact')):
             model.fit_predict(ti, lab[ti])
         del model, W
         gc.collect()
@@ -413,8 +413,8 @@ def test_operator_cache_follows_in_place_edits_of_W(golden):
     _hip.require_device()
     g = golden('g1_twomoons.npz')
     ti, lab = g['train_ind'], g['labels']
-    makers = [lambda W: gl.ssl.poisson(W, solver='gradient_descent'), lambda W: gl.ssl.poisson(W), lambda W: gl.ssl.laplace(W),
-              lambda W: gl.ssl.randomwalk(W)]
+    makers = [lambda W: gl.ssl.poisson(W, solver='gradient_descent'), lambda W: gl.ssl.poisson(W), lambda W: gl.ssl.laplace(W, reduce='exact'),
+              lambda W: gl.ssl.randomwalk(W, reduce='exact')]
     for mk in makers:
         W = sparse_csr(csr_from(g, 'W_gaussian'))
         model = mk(W)
@@ -443,6 +443,34 @@ def sparse_csr(W):
     return sparse.csr_matrix(W)
 
 
+def test_speculative_fit_leaves_no_trace_when_the_matrix_was_edited(golden, monkeypatch):
+    """a fit on the matrix OBJECT of the previous fit starts on the cached operators while the content is hashed
+    again; when the hash says the matrix was edited in place the fit is repeated -- from the model state the first attempt
+    found (PoissonMBO carries its volume weights from fit to fit, like the reference), not from what the discarded run left."""
+    import graphlearning_amd as gl
+    from graphlearning_amd import _hip
+    from conftest import csr_from
+    _hip.require_device()
+    g = golden('g1_twomoons.npz')
+    ti, lab = g['train_ind'], g['labels']
+    pri = g['class_priors']
+
+    def sequence(speculate):
+        W = sparse_csr(csr_from(g, 'W_gaussian'))
+        model = gl.ssl.poisson_mbo(W, pri, solver='gradient_descent', Ns=12, T=4)
+        if not speculate:
+            monkeypatch.setattr(model, '_speculate_key', lambda: None)
+            monkeypatch.setattr(model.poisson_model, '_speculate_key', lambda: None)
+        out = [np.array(model.fit(ti, lab[ti])), np.array(model.weights, dtype=np.float64)]
+        idx = np.flatnonzero((np.repeat(np.arange(W.shape[0]), np.diff(W.indptr)) < 40) | (W.indices < 40))
+        W.data[idx] *= 0.05                                    # symmetric in-place edit
+        out += [np.array(model.fit(ti, lab[ti])), np.array(model.weights, dtype=np.float64), float(model.class_priors_error)]
+        return out
+    a, b = sequence(True), sequence(False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
 def test_reduce_auto_is_the_tolerance_mode_until_a_solve_runs_long(gl, golden, monkeypatch):
     """reduce='auto' (ssl._solve): the tolerance mode's answer while the solve stays short, the reference-order answer -- bit for bit --
     once it takes more than AUTO_TREE_MAX_ITER iterations (there the reordered sums may move the stopping iteration) or produces a
@@ -451,7 +479,7 @@ def test_reduce_auto_is_the_tolerance_mode_until_a_solve_runs_long(gl, golden, m
     g = golden('g3_blobs5000.npz')
     W = csr_from(g, 'W')
     ti, lab = g['train_ind'], g['labels']
-    exact, tree, auto = gl.ssl.laplace(W), gl.ssl.laplace(W, reduce='tree'), gl.ssl.laplace(W, reduce='auto')
+    exact, tree, auto = gl.ssl.laplace(W, reduce='exact'), gl.ssl.laplace(W, reduce='tree'), gl.ssl.laplace(W, reduce='auto')
     ue, ut, ua = exact.fit(ti, lab[ti]), tree.fit(ti, lab[ti]), auto.fit(ti, lab[ti])
     assert exact.num_iter <= glssl.AUTO_TREE_MAX_ITER
     assert np.array_equal(ua, ut) and auto.num_iter == tree.num_iter and np.max(np.abs(ua - ue)) <= 1e-5
@@ -459,7 +487,7 @@ def test_reduce_auto_is_the_tolerance_mode_until_a_solve_runs_long(gl, golden, m
     monkeypatch.setattr(glssl, 'AUTO_TREE_MAX_ITER', max(1, exact.num_iter // 2))
     ub = auto.fit(ti, lab[ti])
     assert np.array_equal(ub, ue) and auto.num_iter == exact.num_iter
-    rw_e, rw_a = gl.ssl.randomwalk(W), gl.ssl.randomwalk(W, reduce='auto')
+    rw_e, rw_a = gl.ssl.randomwalk(W, reduce='exact'), gl.ssl.randomwalk(W, reduce='auto')
     assert np.array_equal(rw_a.fit(ti, lab[ti]), rw_e.fit(ti, lab[ti]))          # (bound still lowered: the exact answer)
     monkeypatch.setattr(glssl, 'AUTO_TREE_MAX_ITER', 200)
     assert np.max(np.abs(rw_a.fit(ti, lab[ti]) - rw_e.fit(ti, lab[ti]))) <= 1e-5

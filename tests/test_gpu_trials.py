@@ -83,7 +83,7 @@ def test_laplace_trials_on_the_full_operator(gl, golden, norm):
     g = golden('g1_twomoons.npz')
     W = csr_from(g, 'W_gaussian')
     labels = g['labels']
-    model = gl.ssl.laplace(W, normalization=norm)
+    model = gl.ssl.laplace(W, normalization=norm, reduce='exact')
     trials = [g['train_ind']] + [gl.trainsets.generate(labels, rate=r, seed=s) for r, s in ((2, 1), (7, 2), (3, 3))]
     together = model._fit_batch([(ti, labels[ti]) for ti in trials])
     iters = list(model.num_iter)
@@ -101,7 +101,7 @@ def test_laplace_full_operator_equals_submatrix_solve(gl):
     from graphlearning_amd import _hip
     from scipy import sparse
     W, labels = _blob_graph(gl, 4000, 10, 12)
-    model = gl.ssl.laplace(W, tau=0.01)
+    model = gl.ssl.laplace(W, tau=0.01, reduce='exact')
     for seed in (0, 1):
         ti = gl.trainsets.generate(labels, rate=2, seed=seed)
         u = model.fit(ti, labels[ti])
@@ -127,7 +127,7 @@ def test_randomwalk_trials_stacked_equal_single(gl, golden):
     g = golden('g7_next_rows.npz')
     W = csr_from(g, 'W')
     labels = g['labels']
-    model = gl.ssl.randomwalk(W)
+    model = gl.ssl.randomwalk(W, reduce='exact')
     trials = [g['train_ind']] + [gl.trainsets.generate(labels, rate=r, seed=s) for r, s in ((1, 4), (6, 5))]
     together = model._fit_batch([(ti, labels[ti]) for ti in trials])
     iters = list(model.num_iter)
@@ -135,3 +135,50 @@ def test_randomwalk_trials_stacked_equal_single(gl, golden):
     for j, ti in enumerate(trials):
         alone = model.fit(ti, labels[ti])
         assert model.num_iter == iters[j] and np.array_equal(alone, together[j])
+
+
+def test_tree_mode_history_mirror_survives_a_change_of_layout(gl):
+    """The tolerance-mode CG polls a page-locked mirror of the residual history whose rows carry a 'not yet written' marker in
+    their last slot.  The slot's position depends on the number of stacked systems: a stacked solve (4 systems) followed by a
+    single one (and by a longer history) on the SAME operator must not read the earlier solve's residuals as rows already
+    written (early stop, wrong iteration count).  Iteration counts and iterates against reduce='exact'."""
+    from graphlearning_amd import _hip
+    X, labels = blobs(3000, 10, 4, 31, 1.5)
+    W = gl.weightmatrix.knn(X, 9)
+    model = gl.ssl.laplace(W, reduce='tree')
+    exact = gl.ssl.laplace(W, reduce='exact')
+    sets = [gl.trainsets.generate(labels, rate=2, seed=s) for s in range(4)]
+    for rep in range(3):
+        together = model._fit_batch([(t, labels[t]) for t in sets])                      # 4 systems: stride 5
+        its4 = list(model.num_iter)
+        ref4 = exact._fit_batch([(t, labels[t]) for t in sets])
+        assert its4 == list(exact.num_iter)
+        for a, b in zip(together, ref4):
+            assert np.max(np.abs(a - b)) <= 1e-9
+        for t in sets[:2]:                                                               # 1 system on the same operator: stride 2
+            u = model.fit(t, labels[t])
+            it1 = model.num_iter
+            ue = exact.fit(t, labels[t])
+            assert it1 == exact.num_iter, (rep, it1, exact.num_iter)
+            assert np.max(np.abs(u - ue)) <= 1e-9
+        two = model._fit_batch([(t, labels[t]) for t in sets[:2]])                       # stride 3
+        assert list(model.num_iter) == list(exact._fit_batch([(t, labels[t]) for t in sets[:2]]) and exact.num_iter)
+    # the solver object directly, with max_iter changing between solves on one DeviceGraph
+    A = sparse_spd(400, 7)
+    G = _hip.DeviceGraph(A, keep_order=True)
+    rng = np.random.default_rng(0)
+    B4 = rng.normal(size=(400, 8))
+    for max_iter, cols in ((500, 8), (40, 2), (500, 2), (7, 8), (500, 4)):
+        xt, it_t, _ = G.cg_groups(np.ascontiguousarray(B4[:, :cols]), 2, tol=1e-9, max_iter=max_iter, reduce='tree')
+        xe, it_e, _ = G.cg_groups(np.ascontiguousarray(B4[:, :cols]), 2, tol=1e-9, max_iter=max_iter, reduce='exact')
+        assert list(it_t) == list(it_e), (max_iter, cols, it_t, it_e)
+        assert np.max(np.abs(xt - xe)) <= 1e-7 * max(1.0, np.max(np.abs(xe)))
+    G.close()
+
+
+def sparse_spd(n, seed):
+    from scipy import sparse
+    rng = np.random.default_rng(seed)
+    A = sparse.random(n, n, density=0.02, random_state=rng, format='csr')
+    A = A + A.T
+    return sparse.csr_matrix(A + sparse.identity(n) * (np.abs(A).sum(axis=1).max() + 1.0))
