@@ -360,7 +360,7 @@ def grouped_algorithmic_bytes(n, nnz, C, B, s_v=8, s_u=8):
     return nnz * (s_v + 4) + 4 * (n + 1) + 3 * n * C * B * s_u + 2 * n * 8 * B
 
 
-def trials_gd_block(W, labels, ti0, device_sync, B_head=8):
+def trials_gd_block(W, labels, ti0, device_sync, B_head=None, scan_B=(2, 4, 8, 16)):
     """ssl.poisson(solver='gradient_descent') over B training sets at once (glx_sweep_groups; reference ssl.py:292-396 runs them one
     `_fit` at a time): the config-2 training set and published MNIST permutation sets / generated ones as column groups of ONE sweep.
     Timed like the headline: T sweeps per step inside the prepared launch graph, HIP events on the library's stream for the
@@ -369,6 +369,7 @@ def trials_gd_block(W, labels, ti0, device_sync, B_head=8):
     from graphlearning_amd import ssl as glssl
     from oracle import gl_oracle as orc
     n, nnz, C = W.shape[0], int(W.nnz), N_CLASSES
+    B_head = int(B_head or glssl.GD_TRIAL_BATCH)          # the batch ssl_trials uses
     g6 = np.load(os.path.join(ROOT, 'tests', 'golden', 'g6_helpers.npz'))
     pool = [ti0] + [g6['mnist_perm_%d' % i] for i in range(10) if ('mnist_perm_%d' % i) in g6.files]
     pool += [gl.trainsets.generate(labels, rate=1 + s % 3, seed=100 + s) for s in range(24)]
@@ -377,7 +378,7 @@ def trials_gd_block(W, labels, ti0, device_sync, B_head=8):
              'scan': []}
     old = glssl.GD_TRIAL_BATCH
     try:
-        for B in (2, 4, B_head, 12, 16):
+        for B in sorted(set(tuple(scan_B) + (B_head,))):
             if not glssl._gd_fits(C, B, np.float64):
                 continue
             glssl.GD_TRIAL_BATCH = B

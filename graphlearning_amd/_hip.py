@@ -129,6 +129,7 @@ _SIGNATURES = {
     'glx_cg_groups_masked': [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int), _f64p],
     'glx_cg_groups_rows': [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_int64, C.c_int,
                            C.POINTER(C.c_int), _f64p],
+    'glx_cg_last_stop_margin': [_vp, _f64p],
     'glx_host_fingerprint': [_vp, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)],
     'glx_knn_search': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)],
     'glx_knn_result_lists': [_vp, _vp, _vp],
@@ -512,6 +513,13 @@ class DeviceGraph:
                                         its.ctypes.data_as(C.POINTER(C.c_int)), errs.ctypes.data_as(_f64p)), 'glx_cg_groups_rows')
         return X, its, errs
 
+    def last_stop_margin(self):
+        """How close the stop decisions of the last tolerance-mode solve on this operator came to going the other way (relative to
+        tol; inf: no such solve)."""
+        m = C.c_double(0)
+        check(load().glx_cg_last_stop_margin(self._h, C.byref(m)), 'glx_cg_last_stop_margin')
+        return m.value
+
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
             lib = load(required=False)
@@ -822,6 +830,7 @@ class Comm:
 
 # glx_dist_sweep_create's form flags (include/glx.h): what the library picks by itself, and the forms tests force
 DIST_FORMS = {'auto': 0, 'split': 2, 'split_pack': 2 | 8, 'split_inline': 2 | 16, 'fused': 4, 'selftest': 128, 'eager': 64, 'captured': 32}
+DIST_GATHER = 256        # GLX_DIST_FORM_GATHER: the exchange is one in-place all-gather of the ranks' blocks (dist.GatherPlan)
 
 
 class DistSweep:
@@ -829,12 +838,15 @@ class DistSweep:
     columns [owned | halo]), exchange lists, device state; every sweep and every collective is enqueued by libglx."""
 
     def __init__(self, comm, P_local, n_boundary, send_counts, send_idx, recv_counts, n_global, Cc, dtype=np.float64,
-                 force_exchange=False, use_hipgraph=True, form='auto'):
+                 force_exchange=False, use_hipgraph=True, form='auto', gather_cap=None):
+        """gather_cap (dist.GatherPlan): the all-gather form -- P_local's columns are numbered owner * cap + (row within the owner's
+        block), shape (n_own, world * cap); the exchange lists are not used."""
         from scipy import sparse
         A = sparse.csr_matrix(P_local)
         self.comm = comm
         self.n_own, n_loc = A.shape
-        self.n_halo = n_loc - self.n_own
+        self.gather_cap = None if gather_cap is None else int(gather_cap)
+        self.n_halo = n_loc - (self.n_own if gather_cap is None else self.gather_cap)
         self.C = int(Cc)
         self.dtype = np.dtype(dtype)
         self.lay = record_layout(Cc, dtype, True)
@@ -844,11 +856,12 @@ class DistSweep:
         sc = np.ascontiguousarray(send_counts, dtype=np.int64)
         rcnt = np.ascontiguousarray(recv_counts, dtype=np.int64)
         si = np.ascontiguousarray(send_idx, dtype=np.int32)
-        self.n_send = int(sc.sum())
+        self.n_send = int(sc.sum()) if gather_cap is None else self.gather_cap
         self._h = _vp()
+        flags = (1 if use_hipgraph else 0) | DIST_FORMS[form] | (DIST_GATHER if gather_cap is not None else 0)
         check(load().glx_dist_sweep_create(comm._h, self.n_own, self.n_halo, int(n_boundary), _ptr(rowptr), _ptr(col), _ptr(val),
                                            _dt(self.dtype), self.C, _ptr(sc), _ptr(si), _ptr(rcnt), int(n_global),
-                                           1 if force_exchange else 0, (1 if use_hipgraph else 0) | DIST_FORMS[form], C.byref(self._h)),
+                                           1 if force_exchange else 0, flags, C.byref(self._h)),
               'glx_dist_sweep_create')
         _live_dist_objects.add(self)
 

@@ -477,6 +477,7 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
 
   std::vector<int64_t> iters(ngroups, 0);       // iterations that ran, per system (utils.py:522 `i`)
   std::vector<double> err(ngroups, 1.0);        // utils.py:519
+  std::vector<double> err_before(ngroups, 1.0); // the residual norm one iteration before the last one looked at, per system
   std::vector<char> done(ngroups, !(1.0 > tol));
   int running = 0;
   for (int g = 0; g < ngroups; ++g) running += !done[g];
@@ -487,6 +488,7 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
       for (int g = 0; g < ngroups; ++g) {
         if (done[g]) continue;
         iters[g] = it0 + q + 1;
+        err_before[g] = err[g];
         err[g] = h[(size_t)q * stride + g];
         if (!(err[g] > tol)) { done[g] = 1; --running; }
       }
@@ -568,9 +570,32 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
   if (rc) return rc;
   GLX_HIP(hipMemcpyAsync(X, b.dense, (size_t)n * C * es, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
+  // How close the stop decisions of this solve came to going the other way (glx_cg_last_stop_margin): per system that stopped on
+  // the test, the relative distance from `tol` of the residual norm that passed the test and of the last one that failed it.  The
+  // reordered reductions of this mode move a residual norm by a relative 1e-13 .. 1e-8 (more after hundreds of iterations); a
+  // decision with a margin below that could have gone the other way with the reference's order of additions.
+  {
+    double margin = INFINITY;
+    for (int g = 0; g < ngroups; ++g) {
+      if (!done[g] || iters[g] == 0 || !(tol > 0)) continue;
+      const double passed = (tol - err[g]) / tol, failed = (err_before[g] - tol) / tol;
+      if (passed == passed) margin = std::min(margin, fabs(passed));
+      if (iters[g] >= 1 && failed == failed) margin = std::min(margin, fabs(failed));
+    }
+    b.last_stop_margin = margin;
+  }
   for (int g = 0; g < ngroups; ++g) {
     if (iters_out) iters_out[g] = (int)iters[g];
     if (err_out) err_out[g] = err[g];
   }
+  return GLX_OK;
+}
+
+// The smallest relative distance from `tol` of the residual norms that decided the stops of the LAST tolerance-mode solve on this
+// operator (+inf: no such solve yet, or none of its systems stopped on the test).  What ssl._solve(reduce='auto') reads: a solve whose
+// stop hung on less than AUTO_STOP_BAND is handed back to the reference-order reductions.
+extern "C" int glx_cg_last_stop_margin(glx_graph* A, double* margin_out) {
+  GLX_CHECK(A && margin_out, GLX_EINVAL, "glx_cg_last_stop_margin: null argument");
+  *margin_out = A->cg_ws ? ((CgBufs*)A->cg_ws)->last_stop_margin : INFINITY;
   return GLX_OK;
 }

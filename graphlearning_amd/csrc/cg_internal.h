@@ -34,6 +34,7 @@ struct CgBufs {
   char *f_stage = nullptr, *h_stage = nullptr;          // one upload per solve: rows, Dirichlet rows, values, output scale
   double* h_hist = nullptr;                              // page-locked mirror of err_hist, written by the closing kernels, polled by the host
   int64_t h_hist_rows = 0, h_hist_dirty = 0;             // doubles laid out / rows a solve may have written (reset to 'not yet' before the next)
+  double last_stop_margin = INFINITY;                    // of the last tolerance-mode solve (glx_cg_last_stop_margin)
   int h_hist_stride = 0;                                 // the row stride (systems + 1) the mirror's 'not yet' markers were last laid out for
   hipGraphExec_t f_exec[3] = {nullptr, nullptr, nullptr};        // captured chunks of 32, 16 and 4 iterations
   std::vector<unsigned long long> f_key;

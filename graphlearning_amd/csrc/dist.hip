@@ -41,6 +41,7 @@ struct RcclApi {
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -59,7 +60,7 @@ static RcclApi* rccl_api() {
     if (!api.handle) return;
 #define BIND(f) *(void**)(&api.f) = dlsym(api.handle, "nccl" #f); if (!api.f) return;
     BIND(GetUniqueId) BIND(CommInitRank) BIND(CommInitAll) BIND(CommDestroy) BIND(GroupStart) BIND(GroupEnd)
-    BIND(Send) BIND(Recv) BIND(AllReduce) BIND(GetErrorString)
+    BIND(Send) BIND(Recv) BIND(AllReduce) BIND(AllGather) BIND(GetErrorString)
 #undef BIND
     ok = true;
   });
@@ -205,6 +206,12 @@ struct glx_dist_sweep {
   int32_t *dup_ptr = nullptr, *dup_pos = nullptr;   // [rows of part 0 + 1], [n_send]: send-buffer positions of every row
   void* st_ref = nullptr;                    // self-test: the eager result
   unsigned int* st_diff = nullptr;           // self-test: mismatch counter (device) -- made global with an all-reduce
+  // GATHER form (GLX_DIST_FORM_GATHER; SURVEY 8e's fallback when the halo is about all rows): the state is nranks blocks of `cap`
+  // records in rank order, this rank's rows in block `rank` (own_off = rank * cap); the exchange is ONE in-place ncclAllGather of the
+  // blocks -- no send lists, no pack, no send buffer
+  bool gather = false;
+  bool gather_next = false;                  // stepwise form: glx_dist_sweep_boundary has written the NEXT iterate's block (what get_send hands out)
+  int64_t cap = 0, own_off = 0;
   bool problem_set = false;
   int cur = 0;                               // ring index of the current iterate
   int64_t sweeps_run = 0, exchanges = 0;
@@ -274,15 +281,30 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
   GLX_CHECK(comm && out && rowptr, GLX_EINVAL, "glx_dist_sweep_create: null argument");
   *out = nullptr;
   GLX_CHECK(n_own >= 0 && n_halo >= 0 && n_boundary >= 0 && n_boundary <= n_own, GLX_EINVAL, "glx_dist_sweep_create: bad sizes");
-  GLX_CHECK(send_counts && recv_counts, GLX_EINVAL, "glx_dist_sweep_create: null exchange lists");
   const int nr = comm->nranks;
+  const bool gather = (flags & GLX_DIST_FORM_GATHER) != 0;
+  int64_t gcap = n_own;
+  if (gather) {
+    // columns are numbered owner * cap + (row within the owner's block); n_halo = (nranks - 1) * cap; every row is a boundary row
+    GLX_CHECK(nr == 1 ? n_halo == 0 : n_halo % (nr - 1) == 0, GLX_EINVAL, "glx_dist_sweep_create: gather form: n_halo must be (nranks - 1) * cap");
+    gcap = nr == 1 ? n_own : n_halo / (nr - 1);
+    GLX_CHECK(n_own <= gcap && n_boundary == n_own, GLX_EINVAL, "glx_dist_sweep_create: gather form: n_own <= cap and n_boundary = n_own");
+  }
+  static const int64_t zero_counts[1024] = {0};
+  if (gather) {
+    GLX_CHECK(nr <= 1024, GLX_EUNSUPPORTED, "glx_dist_sweep_create: more than 1024 ranks");
+    send_counts = zero_counts;
+    recv_counts = zero_counts;
+    send_idx = nullptr;
+  }
+  GLX_CHECK(send_counts && recv_counts, GLX_EINVAL, "glx_dist_sweep_create: null exchange lists");
   int64_t ns = 0, nrcv = 0;
   for (int r = 0; r < nr; ++r) {
     GLX_CHECK(send_counts[r] >= 0 && recv_counts[r] >= 0, GLX_EINVAL, "glx_dist_sweep_create: negative count");
     ns += send_counts[r];
     nrcv += recv_counts[r];
   }
-  GLX_CHECK(nrcv == n_halo, GLX_EINVAL, "glx_dist_sweep_create: receive counts sum to %lld, halo is %lld", (long long)nrcv, (long long)n_halo);
+  GLX_CHECK(gather || nrcv == n_halo, GLX_EINVAL, "glx_dist_sweep_create: receive counts sum to %lld, halo is %lld", (long long)nrcv, (long long)n_halo);
   GLX_CHECK(ns == 0 || send_idx, GLX_EINVAL, "glx_dist_sweep_create: null send list");
   for (int64_t q = 0; q < ns; ++q)
     GLX_CHECK(send_idx[q] >= 0 && send_idx[q] < n_boundary, GLX_EINVAL, "glx_dist_sweep_create: send row %d is not a boundary row", send_idx[q]);
@@ -295,7 +317,10 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
   s->n_own = n_own;
   s->n_halo = n_halo;
   s->nb = n_boundary;
-  s->n_loc = n_own + n_halo;
+  s->n_loc = gather ? gcap * nr : n_own + n_halo;
+  s->gather = gather;
+  s->cap = gcap;
+  s->own_off = gather ? gcap * comm->rank : 0;
   s->n_global = n_global;
   s->use_graph = (flags & GLX_DIST_CAPTURE) != 0;
   {
@@ -338,6 +363,7 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
     s->fused = n_own > 0 && std::min(interior_us, exchange_us) < 23.0;
     if (flags & GLX_DIST_FORM_SPLIT) s->fused = false;
     if (flags & GLX_DIST_FORM_FUSED) s->fused = n_own > 0;
+    if (gather) s->fused = n_own > 0;   // every row is gathered by the peers: one launch, then the all-gather
     if (s->fused) s->overlap = false;   // nothing to run beside the exchange
   }
   s->thresh = 1.0 / (double)n_global;   // `> 1/n`, ssl.py:667, n = ALL vertices
@@ -387,6 +413,7 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
   }
   s->n_send = ns;
   s->exchange = force_exchange != 0 || ns > 0 || n_halo > 0;   // the planner passes force_exchange = "some rank has a halo"
+  if (gather) s->scatter = false;                              // (nothing to scatter: the rows are where the all-gather reads them)
   DS_HIP(hipMalloc(&s->send_idx, std::max<size_t>((size_t)ns * 4, 64)));
   if (ns > 0) DS_HIP(hipMemcpy(s->send_idx, send_idx, (size_t)ns * 4, hipMemcpyHostToDevice));
   DS_HIP(hipMalloc(&s->sendbuf, recb(s, ns)));
@@ -470,7 +497,7 @@ static int launch_part(glx_dist_sweep* s, int q, const void* xin, void* xout, un
   a.L = s->L;
   a.dtype = s->dtype;
   a.xin = xin;
-  a.xout = rec_at(xout, s, lo);
+  a.xout = rec_at(xout, s, s->own_off + lo);
   a.bias = rec_at(s->bias, s, lo);
   a.slot_has_bias = s->flags[q];
   a.has_w = true;
@@ -501,6 +528,16 @@ static int enqueue_pack(glx_dist_sweep* s, const void* x) {
 // stream behind the pack; the caller joins with wait_exchange().
 static int enqueue_exchange(glx_dist_sweep* s, void* x, bool packed = false) {
   if (!s->exchange) return GLX_OK;
+  if (s->gather) {
+    // every rank's block straight into every rank's state: in place, the send part is the rank's own block
+    if (s->comm->comm) {
+      RcclApi* a = rccl_api();
+      const size_t bytes = (size_t)s->cap * s->L.ld * s->L.esize;
+      GLX_NCCL(a->AllGather(rec_at(x, s, s->own_off), x, bytes, ncclUint8, s->comm->comm, s->stream));
+    }
+    s->exchanges++;
+    return GLX_OK;
+  }
   int rc = packed ? GLX_OK : enqueue_pack(s, x);   // packed: the boundary SpMM has already filled the send buffer
   if (rc) return rc;
   hipStream_t xs = s->overlap ? s->xstream : s->stream;
@@ -546,7 +583,7 @@ static int enqueue_sweep(glx_dist_sweep* s, const void* xin, void* xout, unsigne
 
 // state <- initial records, halo filled by one exchange
 static int enqueue_reset(glx_dist_sweep* s, void* x) {
-  GLX_HIP(hipMemcpyAsync(x, s->init_rec, (size_t)s->n_own * s->L.ld * s->L.esize, hipMemcpyDeviceToDevice, s->stream));
+  GLX_HIP(hipMemcpyAsync(rec_at(x, s, s->own_off), s->init_rec, (size_t)s->n_own * s->L.ld * s->L.esize, hipMemcpyDeviceToDevice, s->stream));
   int rc = enqueue_exchange(s, x);
   if (rc) return rc;
   return wait_exchange(s);
@@ -770,7 +807,7 @@ extern "C" int glx_poisson_sweep_dist(glx_dist_sweep* s, int min_iter, int max_i
 extern "C" int glx_dist_sweep_fetch(glx_dist_sweep* s, void* u_own_out) {
   GLX_CHECK(s && u_own_out, GLX_EINVAL, "glx_dist_sweep_fetch: null argument");
   GLX_HIP(hipSetDevice(s->device));
-  int rc = glx_unpack_records(s->ring[s->cur], s->dense, s->n_own, s->L, s->dtype, s->stream);
+  int rc = glx_unpack_records(rec_at(s->ring[s->cur], s, s->own_off), s->dense, s->n_own, s->L, s->dtype, s->stream);
   if (rc) return rc;
   GLX_HIP(hipMemcpyAsync(u_own_out, s->dense, (size_t)s->n_own * s->C * s->L.esize, hipMemcpyDeviceToHost, s->stream));
   GLX_HIP(hipStreamSynchronize(s->stream));
@@ -798,8 +835,9 @@ extern "C" int glx_dist_sweep_info(const glx_dist_sweep* s, int64_t out[8]) {
   out[3] = s->overlap ? 1 : 0;
   out[4] = s->fused ? 1 : 0;
   out[5] = s->scatter ? 1 : 0;
-  out[6] = s->n_send;
+  out[6] = s->gather ? s->cap : s->n_send;
   out[7] = s->n_halo;
+  if (s->gather) out[5] = 2;      // (2: no send buffer at all -- the all-gather reads the rank's own block)
   return GLX_OK;
 }
 
@@ -844,9 +882,10 @@ extern "C" int glx_dist_sweep_time_parts(glx_dist_sweep* s, int reps, float us_o
 extern "C" int glx_dist_sweep_begin(glx_dist_sweep* s) {
   GLX_CHECK(s && s->problem_set, GLX_EINVAL, "glx_dist_sweep_begin: set the problem first");
   GLX_HIP(hipSetDevice(s->device));
-  GLX_HIP(hipMemcpyAsync(s->ring[0], s->init_rec, (size_t)s->n_own * s->L.ld * s->L.esize, hipMemcpyDeviceToDevice, s->stream));
+  GLX_HIP(hipMemcpyAsync(rec_at(s->ring[0], s, s->own_off), s->init_rec, (size_t)s->n_own * s->L.ld * s->L.esize, hipMemcpyDeviceToDevice, s->stream));
   s->cur = 0;
-  int rc = enqueue_pack(s, s->ring[0]);
+  s->gather_next = false;
+  int rc = s->gather ? GLX_OK : enqueue_pack(s, s->ring[0]);
   if (rc) return rc;
   GLX_HIP(hipStreamSynchronize(s->stream));
   return GLX_OK;
@@ -860,7 +899,8 @@ extern "C" int glx_dist_sweep_boundary(glx_dist_sweep* s, int want_err) {
   void* xout = s->ring[s->cur ^ 1];
   int rc = launch_part(s, 0, s->ring[s->cur], xout, want_err ? s->err : nullptr);
   if (rc) return rc;
-  if (!s->scatter) rc = enqueue_pack(s, xout);           // (scatter: the SpMM has filled the send buffer)
+  if (!s->scatter && !s->gather) rc = enqueue_pack(s, xout);           // (scatter: the SpMM has filled the send buffer)
+  s->gather_next = true;                                               // (gather form: get_send hands out the block just written)
   if (rc) return rc;
   GLX_HIP(hipStreamSynchronize(s->stream));
   return GLX_OK;
@@ -869,6 +909,12 @@ extern "C" int glx_dist_sweep_boundary(glx_dist_sweep* s, int want_err) {
 extern "C" int glx_dist_sweep_get_send(glx_dist_sweep* s, void* host_out) {
   GLX_CHECK(s && (host_out || s->n_send == 0), GLX_EINVAL, "glx_dist_sweep_get_send: null argument");
   GLX_HIP(hipSetDevice(s->device));
+  if (s->gather) {       // the rank's block (cap records) of the iterate being exchanged: the newest one written
+    GLX_CHECK(host_out, GLX_EINVAL, "glx_dist_sweep_get_send: null argument");
+    GLX_HIP(hipMemcpy(host_out, rec_at(s->ring[s->gather_next ? (s->cur ^ 1) : s->cur], s, s->own_off),
+                      (size_t)s->cap * s->L.ld * s->L.esize, hipMemcpyDeviceToHost));
+    return GLX_OK;
+  }
   if (s->n_send > 0) GLX_HIP(hipMemcpy(host_out, s->sendbuf, (size_t)s->n_send * s->L.ld * s->L.esize, hipMemcpyDeviceToHost));
   return GLX_OK;
 }
@@ -878,6 +924,17 @@ extern "C" int glx_dist_sweep_put_halo(glx_dist_sweep* s, const void* host_in, i
   GLX_CHECK(s && (host_in || s->n_halo == 0), GLX_EINVAL, "glx_dist_sweep_put_halo: null argument");
   GLX_HIP(hipSetDevice(s->device));
   void* x = s->ring[next ? (s->cur ^ 1) : s->cur];
+  if (s->gather) {       // host_in: the other ranks' blocks in rank order, cap records each
+    const size_t bb = (size_t)s->cap * s->L.ld * s->L.esize;
+    int k = 0;
+    for (int r = 0; r < s->comm->nranks; ++r) {
+      if (r == s->comm->rank) continue;
+      GLX_HIP(hipMemcpy(rec_at(x, s, (int64_t)r * s->cap), (const char*)host_in + (size_t)k * bb, bb, hipMemcpyHostToDevice));
+      ++k;
+    }
+    s->gather_next = false;
+    return GLX_OK;
+  }
   if (s->n_halo > 0) GLX_HIP(hipMemcpy(rec_at(x, s, s->n_own), host_in, (size_t)s->n_halo * s->L.ld * s->L.esize, hipMemcpyHostToDevice));
   return GLX_OK;
 }
@@ -896,6 +953,7 @@ extern "C" int glx_dist_sweep_interior(glx_dist_sweep* s, int want_err, double* 
     GLX_HIP(hipStreamSynchronize(s->stream));
   }
   s->cur ^= 1;
+  s->gather_next = false;
   s->sweeps_run++;
   return GLX_OK;
 }

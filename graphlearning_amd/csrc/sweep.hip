@@ -427,26 +427,41 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       consume(k, xA, vA);
     }
   } else {
+    // Wide records (G >= 8 lanes per row: many columns, or several training sets stacked -- groups.hip).  A chunk holds G entries of
+    // each of the wavefront's 64 / G rows; its index / value pair arrives with ONE coalesced load (the first chunk's together with
+    // the slice header above, the next chunk's while the current one is consumed), entry j of a row goes to the row's G lanes by a
+    // cross-lane read, and the gathers are issued NB at a time before the first of them is consumed: a row of 16 entries is two
+    // memory round trips behind the header's, not one per four entries.  The loop over a chunk's entries ends at the longest row of
+    // the wavefront (rows are sorted by length: the rows of a slice are about equally long).
+    constexpr int NB = 8;
     const int gbase = lane & ~(G - 1);
-    for (int k = 0; k < nchunks; ++k) {
-      const int colv = k == 0 ? col0 : p.col[base + (int64_t)k * 64 + lane];
-      const T valv = k == 0 ? val0 : valp[base + (int64_t)k * 64 + lane];
-      const int j0 = k * G;
-      for (int tb = 0; tb < G; tb += 4) {
-        int cj[4];
-        T vj[4];
-        bool aj[4];
-        V4 xj[4];
+    int mlen = len;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+    for (int off = 32; off >= G; off >>= 1) {
+      const int o = __shfl_xor(mlen, off);
+      mlen = o > mlen ? o : mlen;
+    }
+    int colv = col0;
+    T valv = val0;
+    for (int k = 0; k < nchunks; ++k) {
+      const int j0 = k * G;
+      // (unconditional: past the last chunk the first one is read again, cf. load_cv of the G = 4 loop)
+      const int64_t noff = (k + 1 < nchunks ? base + (int64_t)(k + 1) * 64 : slice * 64) + lane;
+      const int coln = p.col[noff];
+      const T valn = valp[noff];
+      for (int tb = 0; tb < G && j0 + tb < mlen; tb += NB) {
+        int cj[NB];
+        T vj[NB];
+        V4 xj[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
           cj[t] = __shfl(colv, gbase + tb + t);
           vj[t] = shfl_t(valv, gbase + tb + t);
-          aj[t] = lane_on && (j0 + tb + t < len);
           xj[t] = V4{0, 0, 0, 0};
-          if (aj[t]) xj[t] = *(const V4*)(p.xin + (size_t)cj[t] * p.rec_bytes + lane_off);
+          if (lane_on && (j0 + tb + t < len)) xj[t] = *(const V4*)(p.xin + (size_t)cj[t] * p.rec_bytes + lane_off);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < NB; ++t) {
           accum4<T, HAS_W>(acc, accw, vj[t], xj[t], is_w);
           if constexpr (GRP && sizeof(T) == 4) {
             const double xw = __hiloint2double(__float_as_int(xj[t][3]), __float_as_int(xj[t][2]));
@@ -455,6 +470,8 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
           }
         }
       }
+      colv = coln;
+      valv = valn;
     }
   }
 
@@ -518,6 +535,8 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
         }
       }
     }
+    // (stacked state, measured: non-temporal stores of the new iterate -- meant to keep the records being gathered in the L2 -- change
+    // nothing, 35.3 vs 35.3 us at 4 trials per record, 76.0 vs 76.1 at 8, three alternating runs on one box: profiles/r05_trials_gd.txt)
     *(V4*)(p.xout + (size_t)row * p.rec_bytes + lane_off) = outv;
     if constexpr (HAS_DUP) {
       // a boundary row leaves for its peers straight from the registers: one more store per destination

@@ -438,6 +438,70 @@ class RankPlan:
         self.P_local.has_sorted_indices = False              # keep scipy from reordering the entries
 
 
+class GatherPlan:
+    """The plan of the ALL-GATHER form of the exchange (SURVEY 8e's fallback; glx.h GLX_DIST_FORM_GATHER): when a rank's halo is
+    about all the rows it does not own -- the kNN graph of data without cluster structure is an expander -- there is nothing to
+    select: every rank's whole block goes to every rank.  The state of a rank is `world` blocks of `cap` records in rank order
+    (cap = the largest block; shorter blocks end in zero records), its own rows in block `rank`; the local operator's columns are
+    numbered owner * cap + (position in the owner's block); the exchange is one in-place ncclAllGather -- no send lists, no pack
+    kernel, no send buffer.  The entry order inside a row is untouched: iterates stay bit-identical."""
+    gather = True
+
+    def __init__(self, P, order, bounds, rank):
+        P = sparse.csr_matrix(P)
+        n = P.shape[0]
+        world = len(bounds) - 1
+        self.rank, self.world, self.n_global = rank, world, n
+        sizes = np.diff(np.asarray(bounds, dtype=np.int64))
+        self.cap = int(sizes.max()) if world else 0
+        self.own = np.asarray(order[bounds[rank]:bounds[rank + 1]])
+        self.n_own = len(self.own)
+        self.n_boundary = self.n_own                         # every row is read by the peers
+        self.own_off = rank * self.cap
+        self.n_halo = (world - 1) * self.cap
+        self.global_halo = world * self.n_halo
+        slot = np.empty(n, dtype=np.int64)                   # global id -> its record in every rank's state
+        for r in range(world):
+            ids = order[bounds[r]:bounds[r + 1]]
+            slot[ids] = r * self.cap + np.arange(len(ids))
+        sub = sparse.csr_matrix(P[self.own, :])              # row slicing keeps the entry order of each row
+        self.P_local = sparse.csr_matrix((sub.data, slot[sub.indices].astype(np.int32), sub.indptr), shape=(self.n_own, world * self.cap))
+        self.P_local.has_sorted_indices = False
+        self.send_counts = [0] * world
+        self.recv_counts = [0] * world
+        self.send_idx = np.zeros(0, dtype=np.int64)
+
+
+def halo_share(P, order, bounds):
+    """Sum over the ranks of the rows they import, as a share of the rows they do not own: 1 = every rank needs everybody's rows."""
+    P = sparse.csr_matrix(P)
+    n = P.shape[0]
+    world = len(bounds) - 1
+    if world <= 1:
+        return 0.0
+    pos = np.empty(n, dtype=np.int64)
+    pos[order] = np.arange(n)
+    halo = 0
+    for r in range(world):
+        rows = order[bounds[r]:bounds[r + 1]]
+        cpos = pos[np.unique(P[rows, :].indices)] if len(rows) else np.zeros(0, dtype=np.int64)
+        halo += int(np.sum((cpos < bounds[r]) | (cpos >= bounds[r + 1])))
+    return halo / float((world - 1) * n)
+
+
+GATHER_SHARE = 0.5       # from this share of imported rows on, the exchange is the all-gather of whole blocks
+
+
+def make_plan(P, order, bounds, rank, exchange='auto'):
+    """RankPlan (selected halo rows, all-to-all-v) or GatherPlan (whole blocks, all-gather) -- `exchange` in 'halo', 'gather',
+    'auto' (the all-gather from GATHER_SHARE of the foreign rows imported on: same on every rank, it only depends on the plan)."""
+    if exchange not in ('auto', 'halo', 'gather'):
+        raise ValueError("exchange must be 'auto', 'halo' or 'gather', got %r" % (exchange,))
+    if exchange == 'gather' or (exchange == 'auto' and len(bounds) > 2 and halo_share(P, order, bounds) >= GATHER_SHARE):
+        return GatherPlan(P, order, bounds, rank)
+    return RankPlan(P, order, bounds, rank)
+
+
 class HipOps:
     """Rank-local sweep through libglx on torch CUDA tensors (device-pointer C-ABI)."""
     supports_graph = True
@@ -578,7 +642,8 @@ class DistSweep:
         import torch
         self.torch = torch
         self.plan, self.ops, self.dist, self.group = plan, ops, dist, group
-        self.n_loc = plan.n_own + plan.n_halo
+        self.n_loc = plan.n_own + plan.n_halo if not getattr(plan, 'gather', False) else plan.world * plan.cap
+        self.own_off = int(getattr(plan, 'own_off', 0))     # GatherPlan: the rank's rows sit in block `rank` of the state
         self.send_idx = ops.to_device(plan.send_idx.astype(np.int64))
         self.in_splits = list(plan.send_counts)
         self.out_splits = list(plan.recv_counts)
@@ -592,6 +657,20 @@ class DistSweep:
         collective is only enqueued; the returned handle's wait() orders later work behind it."""
         p = self.plan
         if (p.world == 1 or p.global_halo == 0) and not self._force_coll:
+            return None
+        if getattr(p, 'gather', False):
+            # whole blocks to everybody (GatherPlan): an all-gather straight into the blocks of the state (the scipy stand-in of the
+            # tests and host-staged records; the library's own engine does it in place on the device, csrc/dist.hip)
+            self.exchanges += 1
+            mine = x[self.own_off:self.own_off + p.cap].clone()
+            blocks = [x[r * p.cap:(r + 1) * p.cap] for r in range(p.world)]
+            if self._stage_host:
+                host = [self.torch.empty(b.shape, dtype=b.dtype) for b in blocks]
+                self.dist.all_gather(host, mine.cpu(), group=self.group)
+                for b, h in zip(blocks, host):
+                    b.copy_(h)
+            else:
+                self.dist.all_gather(blocks, mine, group=self.group)
             return None
         send = self.ops.index_rows(x, self.send_idx)
         recv = x[p.n_own:]
@@ -660,7 +739,7 @@ class DistSweep:
         the exchange's send buffer; without an exchange it can be stream-captured."""
         p = self.plan
         self.xa.zero_()
-        self.xa[:p.n_own].copy_(self.init_rec)
+        self.xa[self.own_off:self.own_off + p.n_own].copy_(self.init_rec)
         self.exchange(self.xa)
         self.cur = 0
 
@@ -740,7 +819,8 @@ class DistSweep:
         return T
 
     def result_own(self):
-        return self.ops.unpack([self.xa, self.xb][self.cur], self.plan.n_own)
+        x = [self.xa, self.xb][self.cur]
+        return self.ops.unpack(x[self.own_off:self.own_off + self.plan.n_own], self.plan.n_own)
 
 
 # ---- libglx-owned communicator and sweep (include/glx.h: glx_dist_*) ----------------------------------------------
@@ -756,7 +836,13 @@ def init_comm(dist, device=None, group=None):
     return _hip.Comm(world, rank, uid[0], device)
 
 
-XX
+# Test hook (bench.py --force-collectives, tests/test_gpu_dist.py): the collectives of the exchange and of the stop test are issued
+# even by a one-rank job, so that the code path of a real multi-rank run executes on the one GPU a test box has.
+FORCE_COLLECTIVES = False
+
+
+def _force_collectives():
+    return bool(FORCE_COLLECTIVES)
 
 
 def glx_dist_sweep(comm, plan, C, dtype=np.float64, force_exchange=False, use_hipgraph=True, form='auto'):
@@ -766,7 +852,8 @@ def glx_dist_sweep(comm, plan, C, dtype=np.float64, force_exchange=False, use_hi
     from . import _hip
     any_halo = int(getattr(plan, 'global_halo', 0)) > 0 and int(getattr(plan, 'world', 1)) > 1
     return _hip.DistSweep(comm, plan.P_local, plan.n_boundary, plan.send_counts, plan.send_idx, plan.recv_counts, plan.n_global, C,
-                          dtype=dtype, force_exchange=bool(force_exchange or any_halo), use_hipgraph=use_hipgraph, form=form)
+                          dtype=dtype, force_exchange=bool(force_exchange or any_halo), use_hipgraph=use_hipgraph, form=form,
+                          gather_cap=plan.cap if getattr(plan, 'gather', False) else None)
 
 
 def run_stepwise(ds, plan, dist, min_iter, max_iter, err0=None, group=None):
@@ -778,6 +865,13 @@ def run_stepwise(ds, plan, dist, min_iter, max_iter, err0=None, group=None):
 
     def exchange(next_iterate):
         if plan.global_halo == 0:
+            return
+        if getattr(plan, 'gather', False):       # whole blocks: the all-gather of the library's form, here through `dist`
+            mine = torch.from_numpy(np.ascontiguousarray(ds.get_send()))
+            blocks = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(blocks, mine, group=group)
+            rank = dist.get_rank(group)
+            ds.put_halo(np.concatenate([b.numpy() for r, b in enumerate(blocks) if r != rank], axis=0), next_iterate)
             return
         send = torch.from_numpy(np.ascontiguousarray(ds.get_send()))
         recv = torch.empty((plan.n_halo, ds.lay['ld']), dtype=send.dtype)
@@ -806,7 +900,7 @@ def run_stepwise(ds, plan, dist, min_iter, max_iter, err0=None, group=None):
 
 
 def poisson_fit_glx(W, train_ind, train_labels, dist, comm=None, device=None, min_iter=50, max_iter=1000, order=None, group=None,
-                    gather=True, partition='cut', dtype=np.float64, check_every=8, stepwise=False, force_exchange=False):
+                    gather=True, partition='cut', dtype=np.float64, check_every=8, stepwise=False, force_exchange=False, exchange='auto'):
     """ssl.poisson(solver='gradient_descent').fit across the ranks of `dist` with the library-owned sweep: planner on
     the host, then ONE collective call (glx_poisson_sweep_dist) runs every sweep, exchange and stop test on the
     device (stepwise=True: the same object with `dist` as the transport, see run_stepwise).  Returns (u, T) as
@@ -818,7 +912,7 @@ def poisson_fit_glx(W, train_ind, train_labels, dist, comm=None, device=None, mi
     if order is None:
         order = locality_order(P)
     order, bounds, _ = plan_partition(P, order, world, partition, dist, group)
-    plan = RankPlan(P, order, bounds, rank)
+    plan = make_plan(P, order, bounds, rank, exchange)     # selected halo rows (all-to-all-v) or whole blocks (all-gather)
     own_comm = comm is None and not stepwise
     if stepwise and comm is None:
         from . import _hip
@@ -907,7 +1001,7 @@ def poisson_problem(W, train_ind, train_labels):
 
 
 def poisson_fit_distributed(W, train_ind, train_labels, dist, ops_factory, min_iter=50, max_iter=1000, order=None,
-                            group=None, gather=True, partition='cut'):
+                            group=None, gather=True, partition='cut', exchange='halo'):
     """ssl.poisson(solver='gradient_descent').fit across the ranks of `dist`.
     Every rank holds the whole (host) graph and calls this collectively.  Returns (u, T) with
     u the full (n,C) matrix on every rank (gather=True) or this rank's rows.  partition: 'cut' =
@@ -920,7 +1014,7 @@ def poisson_fit_distributed(W, train_ind, train_labels, dist, ops_factory, min_i
     if order is None:
         order = locality_order(P)
     order, bounds, _ = plan_partition(P, order, world, partition, dist, group)
-    plan = RankPlan(P, order, bounds, rank)
+    plan = make_plan(P, order, bounds, rank, exchange)
     ops = ops_factory(plan, prob['k'])
     sweep = DistSweep(plan, ops, dist, group)
     own = plan.own

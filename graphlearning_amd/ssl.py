@@ -375,9 +375,12 @@ def _free_order(W, n):
 STOP_BAND = 1e-9
 
 
-# Training sets per stacked gradient-descent sweep (poisson._fit_batch_gd): whole 128-byte lines per gather and the operator's
-# index / value stream amortised, while the stacked state of a 70 000-vertex graph still lives in the L2s / the Infinity Cache
-GD_TRIAL_BATCH = 8
+# Training sets per stacked gradient-descent sweep (poisson._fit_batch_gd): whole 128-byte lines per gather (ten fp64 columns alone
+# fill 80 of a line's 128 bytes) and the operator's index / value stream, launch and prologue paid once per batch.  Measured at
+# config 2 (70 000 vertices, 10 classes; profiles/r05_trials_gd.txt): 8.9 us per trial and sweep at 4 trials per record (35.3 us per
+# launch), 9.5 at 8, 11.6 at 2, 12.4 for a single fit's sweep -- an XCD's share of the stacked state outgrows its 4 MB L2 from 4
+# trials on (L2 hit rate 71 % at 4, 53 % at 8), and what the lines gain the misses take back.
+GD_TRIAL_BATCH = 4
 
 
 def _gd_fits(k, B, dtype):
@@ -916,18 +919,27 @@ def _neg_columns_times_rows(L, Lcsc, cols, F):
     return rows_s[seg_start].astype(np.int32), out
 
 
-AUTO_TREE_MAX_ITER = 200
+AUTO_TREE_MAX_ITER = 80
+# relative half-width around `tol` inside which a stop decision of the tolerance mode is not trusted to be the reference's: within
+# a few dozen iterations the two orders of additions move a residual norm by 1e-13 .. 1e-9 relative.  (Beyond ~90 iterations they
+# drift apart by per cent -- conjugate gradients amplify a rounding difference with every iteration: 6 of 863 random systems of
+# scripts/auto_margin_probe.py stopped one or two iterations apart, all between 95 and 187 iterations with margins of 0.4 .. 3 % --
+# which no band catches at a bearable price; those solves are what AUTO_TREE_MAX_ITER hands back.  profiles/r05_auto_margins.txt)
+AUTO_STOP_BAND = 1e-3
 
 
-def _solve(run, reduce):
+def _solve(run, reduce, dev=None):
     """run(mode) -> (x, iterations, err).  reduce='auto': the tolerance mode ('tree'), handed back to the reference-order reductions
-    ('exact') when its answer is not one the 1e-5 contract covers -- a solve of more than AUTO_TREE_MAX_ITER iterations (hundreds of
-    iterations amplify the reordered sums: one 647-iteration solve of profiles/r04_tree_vs_exact.txt stopped an iteration apart) or a
-    non-finite iterate (a singular system breaks down with another NaN pattern)."""
+    ('exact') when its answer is not one the contract (labels, iteration count, 1e-5) covers -- a solve of more than
+    AUTO_TREE_MAX_ITER iterations (every iteration amplifies the difference of the reordered sums: beyond ~90 iterations one solve
+    in a hundred stops an iteration apart, profiles/r05_auto_margins.txt), a non-finite iterate (a singular system breaks down with another NaN
+    pattern), or a stop decision that hung on less than AUTO_STOP_BAND of tol (`dev`: the operator, asked for the margin of its last
+    tolerance-mode solve).  Well-conditioned systems (config 3: 54 iterations) never go back: they are the 7x faster mode."""
     if reduce != 'auto':
         return run(reduce)
     out = run('tree')
-    if int(np.max(out[1])) > AUTO_TREE_MAX_ITER or not np.isfinite(np.asarray(out[0])).all():
+    close = dev is not None and dev.last_stop_margin() < AUTO_STOP_BAND
+    if close or int(np.max(out[1])) > AUTO_TREE_MAX_ITER or not np.isfinite(np.asarray(out[0])).all():
         out = run('exact')
     return out
 
@@ -942,8 +954,8 @@ class laplace(ssl):
         reduce (not in the reference): 'auto' (default) = the tolerance mode 'tree' -- block-tree reductions, about 7x faster per
         fit at config 3, the same labels and iteration counts, iterates within the north star's 1e-5 of the reference's (this SPD
         system converges to tol=1e-5 either way; include/glx.h GLX_CG_TREE) -- handed back to 'exact' when a solve runs beyond
-        ssl.AUTO_TREE_MAX_ITER iterations or produces a non-finite iterate (see _solve: the two ways the modes were found to
-        part, profiles/r04_tree_vs_exact.txt, tests/test_gpu_auto.py); 'exact' keeps numpy's reduction order: iterates and
+        ssl.AUTO_TREE_MAX_ITER iterations, produces a non-finite iterate or stops on a margin below ssl.AUTO_STOP_BAND (see
+        _solve: the ways the modes were found to part, profiles/r05_auto_margins.txt, tests/test_gpu_auto.py); 'exact' keeps numpy's reduction order: iterates and
         iteration counts bit-identical to the reference."""
         super().__init__(W, class_priors)
         self.reduce = reduce
@@ -1046,14 +1058,14 @@ class laplace(ssl):
                 # `v = M*v` (ssl.py:1250) is applied on the device on the way out
                 rows, Mb = sp
                 u, its, _ = _solve(lambda mode: dev.cg_groups_rows(rows, Mb, k, masks=[train_ind], out_scale=Mv, tol=self.tol, reduce=mode),
-                                   self.reduce)
+                                   self.reduce, dev)
                 self.num_iter = int(its[0])
                 u[train_ind, :] = F                              # reference ssl.py:1253-1255
                 if self.mean_shift:
                     u -= np.mean(u, axis=0)
                 return u
             F, B, k = self._rhs(L, Mv, train_ind, train_labels)
-            x, its, _ = _solve(lambda mode: dev.cg_groups(B, k, tol=self.tol, masks=[train_ind], reduce=mode), self.reduce)
+            x, its, _ = _solve(lambda mode: dev.cg_groups(B, k, tol=self.tol, masks=[train_ind], reduce=mode), self.reduce, dev)
             self.num_iter = int(its[0])
             return self._assemble(x, Mv, train_ind, F)
         # reweighted graphs depend on the training set: per-fit sub-matrix, reference ssl.py:1211-1250 line by line
@@ -1075,7 +1087,7 @@ class laplace(ssl):
         dev = _hip.DeviceGraph(M * A * M, dtype=self.dtype, device=self.device, keep_order=True)
         try:
             rhs = np.ascontiguousarray(M * b, dtype=self.dtype)
-            v, it, _ = _solve(lambda mode: dev.cg(rhs, tol=self.tol, reduce=mode), self.reduce)   # reference ssl.py:1249
+            v, it, _ = _solve(lambda mode: dev.cg(rhs, tol=self.tol, reduce=mode), self.reduce, dev)   # reference ssl.py:1249
         finally:
             dev.close()
         self.num_iter = it
@@ -1104,7 +1116,7 @@ class laplace(ssl):
         if any(p[2] != k for p in parts):
             return None
         Bs, masks = np.hstack([p[1] for p in parts]), [np.asarray(ti) for ti, _ in trials]
-        x, its, _ = _solve(lambda mode: dev.cg_groups(Bs, k, tol=self.tol, masks=masks, reduce=mode), self.reduce)
+        x, its, _ = _solve(lambda mode: dev.cg_groups(Bs, k, tol=self.tol, masks=masks, reduce=mode), self.reduce, dev)
         self.num_iter = [int(i) for i in its]
         return [self._assemble(np.ascontiguousarray(x[:, j * k:(j + 1) * k]), Mv, np.asarray(trials[j][0]), parts[j][0])
                 for j in range(len(trials))]
@@ -1155,7 +1167,7 @@ class randomwalk(ssl):
     def _fit(self, train_ind, train_labels, all_labels=None):
         M, dev = self._operator()
         rhs = np.ascontiguousarray(M * self._rhs(train_ind, train_labels))
-        u, it, _ = _solve(lambda mode: dev.cg(rhs, tol=1e-6, reduce=mode), self.reduce)   # reference ssl.py:1790
+        u, it, _ = _solve(lambda mode: dev.cg(rhs, tol=1e-6, reduce=mode), self.reduce, dev)   # reference ssl.py:1790
         self.num_iter = it
         return M * u
 
@@ -1171,7 +1183,7 @@ class randomwalk(ssl):
         if any(Y.shape[1] != k for Y in Ys):
             return None
         Bs = np.hstack(Ys)
-        x, its, _ = _solve(lambda mode: dev.cg_groups(Bs, k, tol=1e-6, reduce=mode), self.reduce)
+        x, its, _ = _solve(lambda mode: dev.cg_groups(Bs, k, tol=1e-6, reduce=mode), self.reduce, dev)
         self.num_iter = [int(i) for i in its]
         return [M * np.ascontiguousarray(x[:, j * k:(j + 1) * k]) for j in range(len(trials))]
 

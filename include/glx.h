@@ -184,7 +184,12 @@ enum {
   GLX_DIST_INLINE = 16,             /* the exchange on the sweep's own stream (no second stream) */
   GLX_DIST_EXCHANGE_CAPTURED = 32,  /* exchanging sweeps are captured without the self-test */
   GLX_DIST_EXCHANGE_EAGER = 64,     /* exchanging sweeps are enqueued eagerly */
-  GLX_DIST_EXCHANGE_SELFTEST = 128  /* the first run decides by the self-test (default with real peers) */
+  GLX_DIST_EXCHANGE_SELFTEST = 128, /* the first run decides by the self-test (default with real peers) */
+  GLX_DIST_FORM_GATHER = 256        /* the exchange is ONE in-place ncclAllGather of the ranks' whole blocks (SURVEY 8e's fallback when a
+                                       rank's halo is about all rows: an expander graph).  Another contract for the arguments: columns are
+                                       numbered owner * cap + (row within the owner's block), n_halo = (nranks - 1) * cap with
+                                       cap >= every rank's n_own, n_boundary = n_own; send / receive lists are ignored (may be NULL).
+                                       No send lists, no pack, no send buffer; iterates bit-identical as ever. */
 };
 int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_halo, int64_t n_boundary, const int32_t* rowptr,
                           const int32_t* col, const double* val, int state_dtype, int C, const int64_t* send_counts,

@@ -119,6 +119,11 @@ int glx_knn_stats(double stats[16]);  /* of the calling thread's last search: [0
                                         include it and the cell passes), [11] share of the (query block, ref tile) pairs visited and
                                         [12] number of cells of a cell-pruned search (0: all pairs); [13..15] reserved */
 
+/* the smallest relative distance from `tol` of the residual norms that decided the stops of the last tolerance-mode (GLX_CG_TREE)
+ * solve on this operator; +inf when there was none.  ssl.laplace / ssl.randomwalk (reduce='auto') hand a solve whose stop hung on less
+ * than ssl.AUTO_STOP_BAND back to the reference-order reductions. */
+int glx_cg_last_stop_margin(glx_graph* A, double* margin_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ class ScipyOps:
         lay = _hip.record_layout(C, np.float64, True)       # pure host call into libglx
         self.ld, self.wcol = lay['ld'], lay['woff'] // 8
         self.P = plan.P_local
+        self.off = int(getattr(plan, 'own_off', 0))          # GatherPlan: the rank's rows are block `rank` of the state
 
     def new_state(self, rows):
         return torch.zeros((rows, self.ld), dtype=torch.float64)
@@ -59,7 +60,7 @@ class ScipyOps:
         u = np.ascontiguousarray(x[:, :C])
         w = np.ascontiguousarray(x[:, self.wcol])
         Ps = self.P[lo:hi, :]
-        out = xout.numpy()
+        out = xout.numpy()[self.off:]
         out[lo:hi, :C] = self.bias[lo:hi, :C] + Ps * u
         wn = Ps * w
         out[lo:hi, self.wcol] = wn
@@ -72,7 +73,7 @@ class ScipyOps:
         x = xin.numpy()
         u = np.ascontiguousarray(x[:, :C])
         w = np.ascontiguousarray(x[:, self.wcol])
-        out = xout.numpy()
+        out = xout.numpy()[self.off:]
         out[:n_own, :C] = self.bias[:, :C] + self.P * u
         wn = self.P * w
         out[:n_own, self.wcol] = wn
@@ -91,6 +92,7 @@ def main():
     use_hip = len(sys.argv) > 3 and sys.argv[3] == 'hip'     # rank-local sweeps on the GPU (all ranks share cuda:0)
     glxstep = len(sys.argv) > 3 and sys.argv[3] == 'glxstep'  # the C-ABI sweep object (glx_dist_sweep), gloo as the transport
     partition = sys.argv[4] if len(sys.argv) > 4 else 'even'  # 'even': equal blocks (halo exchange every sweep); 'cut': graph-following blocks
+    exchange = sys.argv[5] if len(sys.argv) > 5 else 'halo'   # 'halo': selected rows, all-to-all-v; 'gather': whole blocks, all-gather; 'auto'
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     from conftest import csr_from, blobs
@@ -115,15 +117,19 @@ def main():
         raise SystemExit('unknown case')
     factory = (lambda plan, k: gdist.HipOps(plan, k, 0)) if use_hip else (lambda plan, k: ScipyOps(plan, k))
     if glxstep:
-        u, T = gdist.poisson_fit_glx(W, ti, tl, dist, device=0, min_iter=min_iter, max_iter=max_iter, partition=partition, stepwise=True)
+        u, T = gdist.poisson_fit_glx(W, ti, tl, dist, device=0, min_iter=min_iter, max_iter=max_iter, partition=partition, stepwise=True,
+                                     exchange=exchange)
     else:
-        u, T = gdist.poisson_fit_distributed(W, ti, tl, dist, factory, min_iter=min_iter, max_iter=max_iter, partition=partition)
+        u, T = gdist.poisson_fit_distributed(W, ti, tl, dist, factory, min_iter=min_iter, max_iter=max_iter, partition=partition,
+                                             exchange=exchange)
     u_ref, T_ref = orc.poisson_gd(W, ti, tl, min_iter=min_iter, max_iter=max_iter, return_T=True)
     # partition bookkeeping invariants
     P = gdist.poisson_problem(W, ti, tl)['P']
     order = gdist.locality_order(P)
     order, bounds, _ = gdist.plan_partition(P, order, world, partition)
     plan = gdist.RankPlan(P, order, bounds, rank)
+    chosen = type(gdist.make_plan(P, order, bounds, rank, exchange)).__name__
+    share = gdist.halo_share(P, order, bounds)
     counts = [None] * world
     dist.all_gather_object(counts, (plan.send_counts, plan.recv_counts, plan.n_own, plan.n_halo))
     ok_counts = all(counts[a][0][b] == counts[b][1][a] for a in range(world) for b in range(world))
@@ -134,7 +140,7 @@ def main():
         caught = False
     except RuntimeError:
         caught = True
-    res = dict(rank=rank, world=world, T=int(T), T_ref=int(T_ref), equal=bool(np.array_equal(u, u_ref)), disagree_caught=caught,
+    res = dict(rank=rank, world=world, T=int(T), T_ref=int(T_ref), equal=bool(np.array_equal(u, u_ref)), disagree_caught=caught, plan=chosen, halo_share=float(share),
                ok_counts=bool(ok_counts), n_own=int(plan.n_own), n_halo=int(plan.n_halo), global_halo=int(plan.global_halo),
                sorted_perm=bool(np.array_equal(np.sort(order), np.arange(P.shape[0]))))
     with open(out_path + '.%d' % rank, 'w') as f:

@@ -19,11 +19,11 @@ def _free_port():
     return p
 
 
-def _run(case, world, tmp_path, partition='even'):
-    out = str(tmp_path / ('res_' + case + '_' + partition))
+def _run(case, world, tmp_path, partition='even', exchange='halo'):
+    out = str(tmp_path / ('res_' + case + '_' + partition + '_' + exchange))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
-           os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out, 'scipy', partition]
+           os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out, 'scipy', partition, exchange]
     env = dict(os.environ, OMP_NUM_THREADS='1')
     r = run_ranks(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -43,6 +43,49 @@ def test_distributed_sweep_matches_oracle(case, world, tmp_path):
     if case == 'twomoons':
         assert res[0]['T'] == 409            # the stop test fired at the reference's iteration
         assert all(r['n_halo'] > 0 for r in res)
+
+
+@pytest.mark.parametrize('case,world,exchange', [('twomoons', 2, 'gather'), ('connected', 3, 'gather'), ('directed', 2, 'gather'),
+                                                 ('miniter0', 3, 'gather'), ('connected', 3, 'auto'), ('blobs', 3, 'auto')])
+def test_gather_form_of_the_exchange_matches_oracle(case, world, exchange, tmp_path):
+    """SURVEY 8e's fallback: whole blocks to every rank by ONE all-gather straight into the state
+    (dist.GatherPlan) instead of selected halo rows by all-to-all-v: the same iterates and T, bit for bit; 'auto' takes it when
+    the ranks import half of the foreign rows or more (one connected expander-like component) and keeps the halo lists otherwise."""
+    res = _run(case, world, tmp_path, exchange=exchange)
+    for r in res:
+        assert r['T'] == r['T_ref'] and r['equal'], r
+        if exchange == 'gather':
+            assert r['plan'] == 'GatherPlan', r
+        else:
+            assert r['plan'] == ('GatherPlan' if r['halo_share'] >= 0.5 else 'RankPlan'), r
+    print(case, world, exchange, res[0]['plan'], 'halo share %.2f' % res[0]['halo_share'])
+
+
+def test_gather_plan_properties(golden):
+    """GatherPlan: every vertex has ONE record position in every rank's state (owner * cap + position in the owner's block), the
+    local operator is the rank's rows with their entries in the stored order."""
+    from graphlearning_amd import dist as gdist
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    P = gdist.poisson_problem(W, g['train_ind'], g['labels'][g['train_ind']])['P']
+    order = gdist.locality_order(P)
+    n = P.shape[0]
+    bounds = np.array([0, 1000, 2700, 2700, n])          # unequal blocks, one of them empty
+    plans = [gdist.GatherPlan(P, order, bounds, r) for r in range(4)]
+    cap = plans[0].cap
+    assert cap == 2300 and all(p.cap == cap and p.P_local.shape == (p.n_own, 4 * cap) for p in plans)
+    slot = np.empty(n, dtype=np.int64)
+    for r, p in enumerate(plans):
+        assert p.own_off == r * cap and p.n_boundary == p.n_own
+        slot[p.own] = p.own_off + np.arange(p.n_own)
+    for p in plans:
+        sub = P[p.own, :]
+        assert np.array_equal(p.P_local.indptr, sub.indptr) and np.array_equal(p.P_local.data, sub.data)
+        assert np.array_equal(p.P_local.indices, slot[sub.indices])
+    with pytest.raises(ValueError):
+        gdist.make_plan(P, order, bounds, 0, 'broadcast')
+    assert isinstance(gdist.make_plan(P, order, bounds, 0, 'halo'), gdist.RankPlan)
+    assert 0.0 <= gdist.halo_share(P, order, bounds) <= 1.0
 
 
 def test_unknown_partition_name_is_rejected():

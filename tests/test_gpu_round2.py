@@ -372,6 +372,7 @@ def test_disagreeing_stop_iteration_reruns_exactly_that_many_sweeps(gl, golden, 
 
 
 # ---- repeated builds and fits release what they take -----------------------------------------------------------------
+@pytest.mark.skipif('PYTEST_XDIST_WORKER' in os.environ, reason='reads the DEVICE-wide memory in use: other xdist workers on the same GPU move it')
 def test_no_device_memory_growth_over_repeated_builds_and_fits(gl):
     """New graph, new models, every learner, a dozen rounds: what the pools cache after the first rounds is all that stays
     on the device (work-buffer pool, page-locked result pool, the per-device list of idle streams)."""
@@ -479,9 +480,10 @@ def test_reduce_auto_is_the_tolerance_mode_until_a_solve_runs_long(gl, golden, m
     g = golden('g3_blobs5000.npz')
     W = csr_from(g, 'W')
     ti, lab = g['train_ind'], g['labels']
+    monkeypatch.setattr(glssl, 'AUTO_TREE_MAX_ITER', 10 ** 6)        # the mechanism, whatever the thresholds of the day
+    monkeypatch.setattr(glssl, 'AUTO_STOP_BAND', 0.0)
     exact, tree, auto = gl.ssl.laplace(W, reduce='exact'), gl.ssl.laplace(W, reduce='tree'), gl.ssl.laplace(W, reduce='auto')
     ue, ut, ua = exact.fit(ti, lab[ti]), tree.fit(ti, lab[ti]), auto.fit(ti, lab[ti])
-    assert exact.num_iter <= glssl.AUTO_TREE_MAX_ITER
     assert np.array_equal(ua, ut) and auto.num_iter == tree.num_iter and np.max(np.abs(ua - ue)) <= 1e-5
     # the same solve with the bound below its iteration count: handed back to the exact mode
     monkeypatch.setattr(glssl, 'AUTO_TREE_MAX_ITER', max(1, exact.num_iter // 2))
@@ -489,8 +491,13 @@ def test_reduce_auto_is_the_tolerance_mode_until_a_solve_runs_long(gl, golden, m
     assert np.array_equal(ub, ue) and auto.num_iter == exact.num_iter
     rw_e, rw_a = gl.ssl.randomwalk(W, reduce='exact'), gl.ssl.randomwalk(W, reduce='auto')
     assert np.array_equal(rw_a.fit(ti, lab[ti]), rw_e.fit(ti, lab[ti]))          # (bound still lowered: the exact answer)
-    monkeypatch.setattr(glssl, 'AUTO_TREE_MAX_ITER', 200)
+    monkeypatch.setattr(glssl, 'AUTO_TREE_MAX_ITER', 10 ** 6)
     assert np.max(np.abs(rw_a.fit(ti, lab[ti]) - rw_e.fit(ti, lab[ti]))) <= 1e-5
+    # a stop decision inside the band goes back too (here: a band so wide that every decision is inside it)
+    monkeypatch.setattr(glssl, 'AUTO_STOP_BAND', 10.0)
+    ub = auto.fit(ti, lab[ti])
+    assert np.array_equal(ub, ue) and auto.num_iter == exact.num_iter
+    monkeypatch.setattr(glssl, 'AUTO_STOP_BAND', 0.0)
     # a non-finite tolerance-mode result goes back as well (simulated: the runner poisons the tolerance-mode answer)
     calls = []
 
