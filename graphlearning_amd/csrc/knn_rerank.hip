@@ -54,9 +54,9 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
   const int64_t q = q_begin + ql;
   const int ncand = lists * KP;
   const double* xq = X + q * d;
-  // Exact distances only where they can matter: with v_k the k-th smallest FILTER value of the candidates, the exact k-th
-  // distance^2 is at most v_k + eps, and a candidate with a filter value above v_k + 2 eps is at least v_k + eps away -- farther
-  // than the k-th.  Of 128 candidates a dozen or two remain; the others' rows (d doubles each, scattered over X) are never
+  // Exact distances only where they can matter: with v_k the k-th smallest FILTER value of the candidates and E the filter's true
+  // error (E < 2 eps always, knn.hip), the exact k-th distance^2 is at most v_k + E, and a candidate with a filter value above
+  // v_k + 2 E is more than v_k + E away -- farther than the k-th: everything above v_k + 4 eps is left out.  Of 128 candidates a dozen or two remain; the others' rows (d doubles each, scattered over X) are never
   // fetched, which is what this kernel's time was (64 KB of gathers per query at d = 64).
   float* sv = (float*)(si + M);      // [M] filter values (the kernel's dynamic LDS is M * 16 bytes)
   const double rq0 = (double)qnorm[q] + (double)rmax_p[0];
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64) void knn_rerank_kernel(const double* __restrict
     if (before == k - 1) s_vk = v;               // exactly one candidate has this rank
   }
   __syncthreads();
-  const double keep = prefilter ? (double)s_vk + 2.0 * eps0 + 1e-6 * fabs((double)s_vk) : INFINITY;
+  const double keep = prefilter ? (double)s_vk + 4.0 * eps0 + 1e-6 * fabs((double)s_vk) : INFINITY;
   auto exact_of = [&](int c, double& dd, int& idx) {
     dd = INFINITY;
     idx = 0x7fffffff;

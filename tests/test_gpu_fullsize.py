@@ -254,3 +254,34 @@ def test_config2_batched_cg_trials_equal_single_fits(gl, golden, meta, config2):
         alone = model.fit(trials[j], labels[trials[j]])
         assert model.num_iter == iters[j]
         assert np.array_equal(alone, together[j]), j
+
+
+def test_config2_stacked_gd_trials_equal_single_fits_and_oracle(gl, golden, config2):
+    """SURVEY 8 f-1 for the sweep at n = 70000: six published MNIST train sets (label rates 1..5) as column
+    groups of stacked sweeps (glx_sweep_groups; ssl.ssl_trials' batches): every trial's iterate, its sweep count T and its labels
+    equal the fit on its own and the oracle's run of the reference loop, bit for bit."""
+    from oracle import gl_oracle as orc
+    g = golden('g6_helpers.npz')
+    W, labels = config2['W'], config2['labels']
+    trials = [g['mnist_perm_%d' % i] for i in (0, 2, 4, 6, 8, 9)]
+    model = gl.ssl.poisson(W, solver='gradient_descent')
+    B = model._trial_batch_size(labels)
+    assert B >= 2
+    single = gl.ssl.poisson(W, solver='gradient_descent')
+    t0 = time.perf_counter()
+    for pos in range(0, len(trials), B):
+        group = trials[pos:pos + B]
+        res = model._fit_batch_device([(ti, labels[ti]) for ti in group])
+        assert res is not None and len(res) == len(group)
+        Ts = list(model.num_iter)
+        for j, ti in enumerate(group):
+            model._set_result(res[j])
+            model.fitted = True
+            pred = model.predict()                                  # decided on the stacked device state
+            u = np.array(res[j].fetch())
+            u_ref, T_ref = orc.poisson_gd(W, ti, labels[ti], return_T=True)
+            assert Ts[j] == T_ref and np.array_equal(u, u_ref), (pos, j)
+            assert np.array_equal(pred, orc.predict(u_ref)), (pos, j)
+            u1 = single.fit(ti, labels[ti])
+            assert single.num_iter == T_ref and np.array_equal(u1, u), (pos, j)
+    print('6 stacked GD trials at 70k in batches of %d (incl. the oracle runs): %.2f s' % (B, time.perf_counter() - t0))
