@@ -128,7 +128,7 @@ def cpu_baseline_omp(W, train_ind, train_labels, budget_s=4.0):
                 bit_identical_to_scipy=bool(np.array_equal(u6, ref)))
 
 
-def scale_shard_line(steps=4, T=50):
+def scale_shard_line(steps=4, T=50, traffic=True):
     """One GPU's share of config 4 (BASELINE.json configs[3]: blobs d=64, k=10, C=10; n = 10^6 vertices per GPU): the
     same sweep kernel at a size where the state (128 MB of records) and the operator (253 MB) no longer sit in the
     L2s, so its rate is an HBM / Infinity-Cache-true one.  Fixed T sweeps per step (min_iter = max_iter)."""
@@ -175,8 +175,23 @@ def scale_shard_line(steps=4, T=50):
         ab = algorithmic_bytes(n, W.nnz, N_CLASSES, es, es)
         out[dt] = {'avg_launch_us': per * 1e6, 'algorithmic_bytes_per_launch': ab, 'achieved_GBs': ab / per / 1e9,
                    'frac': ab / per / 1e9 / HBM_PEAK_GBS, 'gather_edges_per_s': W.nnz / per}
+        if dt == 'f64':
+            # what a perfect per-XCD L2 would fetch: every distinct neighbour record once per XCD range and sweep (+ the operator's
+            # index / value stream, the row's own bias / stop data, the store of the new iterate), against the counters
+            perm = dev.order()
+            recs, rec_bytes = distinct_line_bound(W, perm, 128)
+            bound = rec_bytes + W.nnz * 12 + 4 * (n + 1) + n * 128 + 2 * n * 8
+            out[dt]['distinct_records_over_xcd_ranges'] = recs
+            out[dt]['distinct_line_bound_bytes'] = bound
         sweep.close()
         model._cache[1].close()
+    if traffic:
+        tr, src = measure_traffic(timeout_s=240, child_flag='--traffic-child-scale')
+        out['f64']['traffic'] = tr
+        out['f64']['traffic_source'] = src
+        if tr:
+            out['f64']['traffic_over_algorithmic'] = tr / out['f64']['algorithmic_bytes_per_launch']
+            out['f64']['traffic_over_distinct_line_bound'] = tr / out['f64']['distinct_line_bound_bytes']
     return out
 
 
@@ -419,7 +434,35 @@ def trials_gd_block(W, labels, ti0, device_sync, B_head=None, scan_B=(2, 4, 8, 1
     return block
 
 
-def measure_traffic(timeout_s=120):
+def distinct_line_bound(W, perm, rec_bytes=128, nx=8):
+    """What a PERFECT per-XCD L2 would have to fetch per sweep, computed on the host: the rows of the operator are cut into the eight
+    contiguous ranges of equal work the plan hands to the XCDs (graph.hip: work of a row = its entries + 3) in the vertex order `perm`
+    (perm[new] = caller's row; None = the caller's order); every range must bring in each DISTINCT neighbour record it gathers once.
+    Returns (distinct records summed over the ranges, bytes = that many records)."""
+    n = W.shape[0]
+    lens = np.diff(W.indptr).astype(np.int64)
+    if perm is None:
+        perm = np.arange(n, dtype=np.int64)
+    perm = np.asarray(perm, dtype=np.int64)
+    work = np.cumsum(lens[perm] + 3)
+    cuts = [0] + [int(np.searchsorted(work, work[-1] * x / nx, side='left')) for x in range(1, nx)] + [n]
+    total = 0
+    seen = np.zeros(n, dtype=bool)
+    for x in range(nx):
+        rows = perm[cuts[x]:cuts[x + 1]]
+        if len(rows) == 0:
+            continue
+        seen[:] = False
+        # (P = D^-1 W^T of a symmetric W has W's pattern: the rows' neighbour lists are W's)
+        rowsel = np.zeros(n, dtype=bool)
+        rowsel[rows] = True
+        idx = W.indices[np.repeat(rowsel, lens)]
+        seen[idx] = True
+        total += int(seen.sum())
+    return total, total * rec_bytes
+
+
+def measure_traffic(timeout_s=120, child_flag='--traffic-child', kernel='spmm_sell_kernel<double'):
     """HBM-side bytes per launch of the dominant kernel, MEASURED for this build: two child passes of this script
     under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need separate passes, MI355X_MICROARCH.md), per-dispatch means
     over the sweep kernel's dispatches.  gfx950 correction from the same guide: FETCH_SIZE counts 128-byte requests as
@@ -435,7 +478,7 @@ def measure_traffic(timeout_s=120):
     for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
         d = tempfile.mkdtemp(prefix='glx_pmc_', dir='/tmp')
         cmd = ['rocprofv3', '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'run', '--',
-               sys.executable, os.path.abspath(__file__), '--traffic-child']
+               sys.executable, os.path.abspath(__file__), child_flag]
         try:
             # (its own process group: a pass that outlives the limit is ended together with the profiled child, by that group's id)
             proc = subprocess.Popen(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL,
@@ -451,7 +494,7 @@ def measure_traffic(timeout_s=120):
             tot, cnt = 0.0, 0
             for f in fs:
                 for r in csv.DictReader(open(f)):
-                    if r['Counter_Name'] == ctr and 'spmm_sell_kernel<double' in r['Kernel_Name']:
+                    if r['Counter_Name'] == ctr and kernel in r['Kernel_Name']:
                         tot += float(r['Counter_Value'])
                         cnt += 1
             if cnt == 0:
@@ -464,6 +507,27 @@ def measure_traffic(timeout_s=120):
     traffic = (2.0 * vals['FETCH_SIZE'][0] + vals['WRITE_SIZE'][0]) * 1024.0
     return traffic, ('measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes, means over %d / %d dispatches of '
                      'spmm_sell_kernel<double,4,true,false>; (2 x FETCH_SIZE + WRITE_SIZE) KiB' % (vals['FETCH_SIZE'][1], vals['WRITE_SIZE'][1]))
+
+
+def scale_graph(n=1000000):
+    """One GPU's share of config 4 (blobs d = 64, k = 10, 10 classes, default_rng(2))."""
+    import graphlearning_amd as gl
+    rng = np.random.default_rng(2)
+    labels = rng.integers(0, 10, size=n)
+    centers = rng.normal(size=(10, 64)) * 4
+    X = centers[labels] + rng.normal(size=(n, 64))
+    return gl.weightmatrix.knn(X, K_NN), labels
+
+
+def traffic_child_scale(n=1000000, T=20):
+    """Workload of the counter passes at the shard size: T fp64 sweeps of the n = 10^6 graph, three times."""
+    import graphlearning_amd as gl
+    from graphlearning_amd import _hip
+    W, labels = scale_graph(n)
+    train_ind = gl.trainsets.generate(labels, rate=5, seed=0)
+    model = gl.ssl.poisson(W, solver='gradient_descent', min_iter=T, max_iter=T)
+    for _ in range(3):
+        model.fit(train_ind, labels[train_ind])
 
 
 def traffic_child():
@@ -605,7 +669,7 @@ def run_single(args):
     if not args.no_configs:
         line['configs'] = other_configs(W, labels, train_ind, device_sync, knn_stats, X)
     if not args.no_scale:
-        line['scale_shard_1e6'] = scale_shard_line()
+        line['scale_shard_1e6'] = scale_shard_line(traffic=not args.no_traffic)
     print(json.dumps(line))
 
 
@@ -687,11 +751,15 @@ def main():
     ap.add_argument('--force-collectives', action='store_true', help='distributed path: issue the collectives even with one rank (tests)')
     ap.add_argument('--spawned', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--traffic-child-scale', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--dist-dry-run', action='store_true',
                     help='start the ranks, rendezvous over gloo, count them, print one line and stop: checks the launch path without a GPU')
     args = ap.parse_args()
     if args.traffic_child:
         traffic_child()
+        return
+    if args.traffic_child_scale:
+        traffic_child_scale()
         return
     launched = 'WORLD_SIZE' in os.environ            # torch.distributed.run (the driver's form for N > 1) or our own spawn
     if args.gpus > 1 and not launched:

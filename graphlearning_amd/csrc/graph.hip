@@ -1031,7 +1031,10 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
   // epilogue and its share of the column dots -- fewer, longer slices win.  Config 3 (60 000 vertices, rows of 21..660 entries),
   // SpMM + dots per launch: 8/64 37.6 us, 24/96 32.2, 32/128 27.3, 64/256 26.5, 96/384 32.6 (profiles/r04_cg_slot_thresholds.txt)
   if (relaxed) { L1 = 64; L4 = 256; }
-  if ((double)g->n_cols * G * 4.0 * (g->dtype == GLX_F64 ? 8.0 : 4.0) >= 64.0 * 1024 * 1024) { L1 = 64; L4 = 256; }
+  const bool big_state = (double)g->n_cols * G * 4.0 * (g->dtype == GLX_F64 ? 8.0 : 4.0) >= 64.0 * 1024 * 1024;
+  if (big_state) { L1 = 64; L4 = 256; }
+  const int64_t sigma_big = 32768;      // measured at n = 10^6 (fp64, us per sweep): whole range 255, 8192: 255, 16384: 252, 32768: 229, 65536: 239, 131072: 253
+  bool windowed = false;
   if (G != 4) { L1 = 1 << 30; L4 = 1 << 30; }
   auto old_of = [&](int64_t nid) -> int64_t { return renum ? g->h_perm[nid] : nid; };
   // (row lengths in the new numbering, looked up ~6 times per row below: one pass through the permutation instead of six)
@@ -1071,7 +1074,15 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
     // sort by decreasing length inside windows of `sigma` consecutive ids (SELL-C-sigma): small
     // windows keep rows that share neighbours in the same wavefronts/CUs (L1 reuse), large ones
     // minimise padding.  The whole XCD range is one window.
-    int64_t sigma = m;
+    // Round 5: once the records no longer fit the L2s the window must be SMALL.  The wavefronts resident on an XCD at one time cover
+    // ~10^4 consecutive rows of the slice order; sorted by length over the whole range those rows come from all over the XCD's share
+    // of the vertex order (16 MB of records at 10^6 vertices against a 4 MB L2) and their gathers miss -- counters at n = 10^6:
+    // 1.82 GB per sweep against 0.57 GB for the distinct records of the eight ranges (profiles/r05_scale_1e6_pmc.txt).  Sorted inside
+    // windows of `sigma` consecutive rows the resident wavefronts work on one stretch of the locality order at a time: -10 % at 32768
+    // rows per window.  (Smaller windows gain nothing: inside a cluster of the blob data the kNN graph is an expander -- a window's
+    // neighbours are spread over its whole cluster, 13 MB of records, whatever the window's size.)
+    int64_t sigma = big_state ? sigma_big : m;
+    if (sigma < m) windowed = true;
     for (int64_t w0 = 0; w0 < m; w0 += sigma) {
       const int64_t w1 = std::min(m, w0 + sigma);
       std::vector<int64_t> cnt(g->max_row + 2, 0);
@@ -1106,8 +1117,9 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
     }
     // longest-running slices first (the launch ends when the last wavefront does): a slice's time is its gather rounds times the
     // cost of a round in its class -- measured per chunk at config 3: 1.25 / 2.5 / 3.6 us for S = 1 / 4 / 16 when the running sum
-    // hops between segments, one price for all when it does not (relaxed)
-    {
+    // hops between segments, one price for all when it does not (relaxed).  Not with windows: the order of the windows IS the point
+    // (and with thousands of slices per XCD the tail of a launch does not matter).
+    if (!windowed) {
       const size_t ns = ghdr[x].size();
       std::vector<int32_t> idx(ns);
       for (size_t q = 0; q < ns; ++q) idx[q] = (int32_t)q;

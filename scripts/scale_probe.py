@@ -21,6 +21,7 @@ ap.add_argument('--diag', action='store_true')
 ap.add_argument('--dtype', default='f64')
 ap.add_argument('--T', type=int, default=50)
 ap.add_argument('--reps', type=int, default=5)
+ap.add_argument('--bound', action='store_true', help='the distinct-line lower bound of the sweep\'s memory traffic (bench.distinct_line_bound)')
 args = ap.parse_args()
 n = args.n
 
@@ -71,6 +72,11 @@ for dt in (['f64', 'f32'] if args.dtype == 'both' else [args.dtype]):
     ab = bench.algorithmic_bytes(n, W.nnz, 10, es, es)
     print('sweep %s: %.1f us/launch, algorithmic %.1f MB -> %.2f TB/s = %.1f%% of 8 TB/s; %.1f Gedge/s; %s' % (
         dt, us, ab / 1e6, ab / us / 1e6, ab / us / 1e6 / 8 * 100, W.nnz / us / 1e3, dev.info()))
+    if args.bound and dt == 'f64':
+        recs, rb = bench.distinct_line_bound(W, dev.order(), 128)
+        bound = rb + W.nnz * 12 + 4 * (n + 1) + n * 128 + 2 * n * 8
+        print('traffic bounds per sweep (fp64): algorithmic %.1f MB | distinct-line bound %.1f MB (%d distinct neighbour records over the 8 XCD ranges = %.2f per vertex, '
+              '%.2f of the stored entries) | counters: see the rocprofv3 passes' % (ab / 1e6, bound / 1e6, recs, recs / n, recs / W.nnz))
     u = sw.fetch()
     pred = np.argmax(u, axis=1)
     print('accuracy %.2f%%' % gl.ssl.ssl_accuracy(pred, labels, train_ind))
