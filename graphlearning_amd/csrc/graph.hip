@@ -1031,8 +1031,12 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
   // epilogue and its share of the column dots -- fewer, longer slices win.  Config 3 (60 000 vertices, rows of 21..660 entries),
   // SpMM + dots per launch: 8/64 37.6 us, 24/96 32.2, 32/128 27.3, 64/256 26.5, 96/384 32.6 (profiles/r04_cg_slot_thresholds.txt)
   if (relaxed) { L1 = 64; L4 = 256; }
-  const bool big_state = (double)g->n_cols * G * 4.0 * (g->dtype == GLX_F64 ? 8.0 : 4.0) >= 64.0 * 1024 * 1024;
+#ifndef GLX_SELL_WINDOW_MIN_MB
+#define GLX_SELL_WINDOW_MIN_MB 32      // records beyond the eight L2s (32 MB)
+#endif
+  const bool big_state = (double)g->n_cols * G * 4.0 * (g->dtype == GLX_F64 ? 8.0 : 4.0) >= (double)GLX_SELL_WINDOW_MIN_MB * 1024 * 1024;
   if (big_state) { L1 = 64; L4 = 256; }
+  const bool window_state = big_state;
   const int64_t sigma_big = 32768;      // measured at n = 10^6 (fp64, us per sweep): whole range 255, 8192: 255, 16384: 252, 32768: 229, 65536: 239, 131072: 253
   bool windowed = false;
   if (G != 4) { L1 = 1 << 30; L4 = 1 << 30; }
@@ -1081,14 +1085,28 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
     // windows of `sigma` consecutive rows the resident wavefronts work on one stretch of the locality order at a time: -10 % at 32768
     // rows per window.  (Smaller windows gain nothing: inside a cluster of the blob data the kNN graph is an expander -- a window's
     // neighbours are spread over its whole cluster, 13 MB of records, whatever the window's size.)
-    int64_t sigma = big_state ? sigma_big : m;
+    int64_t sigma = window_state ? sigma_big : m;
     if (sigma < m) windowed = true;
-    for (int64_t w0 = 0; w0 < m; w0 += sigma) {
-      const int64_t w1 = std::min(m, w0 + sigma);
+    // With windows the LONG rows (those split over 4 or 16 slots: chains of dependent round trips) still come first, longest first,
+    // whatever their window: they are few and they are what a launch's tail consists of (without this the windows cost 20 % at
+    // 3 x 10^5 vertices, where an XCD's range is hardly more than one window).
+    int64_t nlong = 0;
+    std::vector<int32_t> rest;
+    if (sigma < m) {
+      std::vector<int32_t> lng;
+      rest.reserve(m);
+      for (int64_t i = 0; i < m; ++i) (klass(rowlen(b0 + i)) > 1 ? lng : rest).push_back((int32_t)(b0 + i));
+      std::stable_sort(lng.begin(), lng.end(), [&](int32_t a, int32_t b) { return rowlen(a) > rowlen(b); });
+      nlong = (int64_t)lng.size();
+      std::copy(lng.begin(), lng.end(), order.begin());
+    }
+    for (int64_t w0 = 0; w0 < m - nlong; w0 += sigma) {
+      const int64_t w1 = std::min(m - nlong, w0 + sigma);
+      auto rowat = [&](int64_t i) -> int64_t { return nlong || sigma < m ? (int64_t)rest[i] : b0 + i; };
       std::vector<int64_t> cnt(g->max_row + 2, 0);
-      for (int64_t i = w0; i < w1; ++i) cnt[g->max_row - rowlen(b0 + i) + 1]++;
+      for (int64_t i = w0; i < w1; ++i) cnt[g->max_row - rowlen(rowat(i)) + 1]++;
       for (size_t b = 1; b < cnt.size(); ++b) cnt[b] += cnt[b - 1];
-      for (int64_t i = w0; i < w1; ++i) order[w0 + cnt[g->max_row - rowlen(b0 + i)]++] = (int32_t)(b0 + i);
+      for (int64_t i = w0; i < w1; ++i) order[nlong + w0 + cnt[g->max_row - rowlen(rowat(i))]++] = (int32_t)rowat(i);
     }
     int64_t pos = 0;
     while (pos < m) {
