@@ -1082,15 +1082,26 @@ def knn_bruteforce(X, k, similarity='euclidean', device=None, query_range=None, 
     want_order (below the size of the pruned search): the rows are put into the order of chained cells before the search
     (coherent wavefronts; a plain knnsearch does not ask: 0.1 ms at d = 20, 0.7 ms at d = 128 for 50 000 rows) -- KnnResult
     hands that order out as well."""
-    X = _knn_input(X, similarity)
-    n, d = X.shape
+    dev_ptr = None
+    if hasattr(X, 'data_ptr') and getattr(X, 'is_cuda', False):
+        # a torch CUDA tensor (float64, contiguous, euclidean): the search reads it where it is (range / cells forms only)
+        if similarity != 'euclidean' or str(X.dtype) != 'torch.float64' or not X.is_contiguous() or (query_range is None and cell_starts is None):
+            raise GlxError('a device-resident X must be a contiguous float64 tensor, euclidean, searched by range or by cells')
+        n, d = int(X.shape[0]), int(X.shape[1])
+        dev_ptr = _vp(X.data_ptr())
+    else:
+        X = _knn_input(X, similarity)
+        n, d = X.shape
     q0, q1 = (0, n) if query_range is None else query_range
     ind = pinned_empty((q1 - q0, k), np.int64)       # page-locked result arrays: the copy back runs at PCIe speed
     dist = pinned_empty((q1 - q0, k), np.float64)
     if cell_starts is not None:
         cs = np.ascontiguousarray(cell_starts, dtype=np.int64)
-        check(load().glx_knn_cells_range(_ptr(X), n, d, k, _ptr(cs), len(cs), q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
+        check(load().glx_knn_cells_range(dev_ptr or _ptr(X), n, d, k, _ptr(cs), len(cs), q0, q1, _ptr(ind), _ptr(dist), _dev(device)),
               'glx_knn_cells_range')
+        return ind, dist
+    if dev_ptr is not None:
+        check(load().glx_knn_bruteforce_range(dev_ptr, n, d, k, q0, q1, _ptr(ind), _ptr(dist), _dev(device)), 'glx_knn_bruteforce')
         return ind, dist
     m = _knn_cells(n, d, clustered, want_order) if query_range is None else 0
     if m:       # cells formed by the library (same lists; a fraction of the tiles when the data has clusters)

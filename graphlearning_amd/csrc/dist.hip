@@ -378,7 +378,9 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
     std::vector<int32_t> rp(hi[q] - lo[q] + 1);
     for (int64_t i = lo[q]; i <= hi[q]; ++i) rp[i - lo[q]] = rowptr[i] - rowptr[lo[q]];
     const int64_t nnz = rp.back();
-    rc = glx_graph_create(hi[q] - lo[q], s->n_loc, nnz, rp.data(), col + rowptr[lo[q]], val + rowptr[lo[q]], state_dtype, comm->device, &s->part[q]);
+    // (resident: the arrays go to the device as they are and the plan is filled there -- no host copy of the rank's 10^8 entries)
+    rc = glx_graph_create_resident(hi[q] - lo[q], s->n_loc, nnz, rp.data(), col + rowptr[lo[q]], val + rowptr[lo[q]], state_dtype, comm->device, nullptr,
+                                   &s->part[q]);
     if (rc) DS_FAIL(rc);
     glx_graph_set_order(s->part[q], nullptr);      // (the caller's order: rank-local operators are rectangular and never renumbered)
     rc = glx_graph_plan(s->part[q], s->L.G, &s->plan[q]);

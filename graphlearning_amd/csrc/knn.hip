@@ -118,7 +118,9 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   GLX_POOL(glx_pool_alloc((void**)&b.X, (size_t)n * d * 8));
   GLX_POOL(glx_pool_alloc((void**)&b.mean, d * 8));
   stamp("stream, events, buffers");
-  GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyHostToDevice, st));
+  // (hipMemcpyDefault: X may also be a DEVICE pointer -- glx_knn_bruteforce_range / glx_knn_cells_range of the sharded build, whose
+  // features are generated, ordered and kept on the GPU; the library-formed cells below read sample rows on the host and need a host X)
+  GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyDefault, st));
   stamp("X enqueued");
   // Cells formed by the library (auto_cells).  > 1: that many cells (nearest of evenly spaced sample rows), the rows reordered by
   // cell and searched with the cell pruning of glx_knn_cells_range; the re-rank ranks by and returns the caller's indices.

@@ -309,7 +309,8 @@ int glx_sweep_project_iterate(glx_sweep* s, const double* priors, double* weight
 int glx_knn_bruteforce(const double* X, int64_t n, int d, int k, int similarity,
                        int64_t* ind_out, double* dist_out, int device);
 /* same search restricted to the query rows [q_begin, q_end) (rank-local share when the queries are
- * sharded across GPUs; every rank holds all of X).  ind_out/dist_out: (q_end - q_begin, k). */
+ * sharded across GPUs; every rank holds all of X).  ind_out/dist_out: (q_end - q_begin, k).  For this entry point and for
+ * glx_knn_cells_range X may be a DEVICE pointer (features generated and ordered on the GPU: no trip through the host). */
 int glx_knn_bruteforce_range(const double* X, int64_t n, int d, int k, int64_t q_begin, int64_t q_end,
                              int64_t* ind_out, double* dist_out, int device);
 /* the same search -- the same lists, bit for bit -- for rows that come in a coarse geometric order: cell c = the rows
