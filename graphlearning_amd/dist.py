@@ -489,7 +489,11 @@ def halo_share(P, order, bounds):
     return halo / float((world - 1) * n)
 
 
-GATHER_SHARE = 0.5       # from this share of imported rows on, the exchange is the all-gather of whole blocks
+# From this share of the foreign rows imported on, the exchange is the all-gather of whole blocks.  In the bandwidth model of
+# scripts/scale_model.py (one block per link against the largest per-peer message of the halo lists) whole blocks only win when the
+# ranks import nearly everything; below that the lists move fewer bytes (profiles/r05_scale_model_connected.json: share 0.5-0.7 at
+# N = 2 .. 8 on the connected workload, lists 150-210 us per sweep, whole blocks 200-310 us).
+GATHER_SHARE = 0.9
 
 
 def make_plan(P, order, bounds, rank, exchange='auto'):

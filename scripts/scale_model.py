@@ -75,6 +75,34 @@ def rank_measurements(P, order, bounds, prob_rows, C, reps):
     return out
 
 
+def gather_measurements(P, order, bounds, prob_rows, C, reps):
+    """The all-gather form (dist.GatherPlan, GLX_DIST_FORM_GATHER): every rank's one launch over a state of `world` blocks of `cap`
+    records, timed per virtual rank (a rank identity without a transport)."""
+    world = len(bounds) - 1
+    out = []
+    for r in range(world):
+        plan = gdist.GatherPlan(P, order, bounds, r)
+        comm = _hip.Comm(world, r, None, 0)
+        ds = gdist.glx_dist_sweep(comm, plan, C, use_hipgraph=False)
+        own = plan.own
+        ds.set_problem(prob_rows['Db'][own], prob_rows['w0'][own], prob_rows['deg'][own], prob_rows['vinf'][own])
+        t = ds.time_parts(reps)
+        out.append(dict(rank=r, n_own=int(plan.n_own), cap=int(plan.cap), fused_us=t['boundary_us'], rec_bytes=int(ds.lay['rec_bytes'])))
+        ds.close()
+        comm.close()
+    return out
+
+
+def predict_gather(granks, latency_us, link_gbs, T=50, min_iter=50):
+    """sweep(N) of the all-gather form: one launch, then every rank's block to every peer -- on a fully connected xGMI node each of the
+    N - 1 links of a GPU carries ONE block per direction: X = L + cap * record bytes / link rate (the same L as the grouped send/recv:
+    an ASSUMPTION; RCCL's all-gather may well differ)."""
+    x = [latency_us + m['cap'] * m['rec_bytes'] / (link_gbs * 1e3) for m in granks]
+    per_rank = [m['fused_us'] + xi for m, xi in zip(granks, x)]
+    n_allreduce = 1 + max(0, -(-(T - min_iter) // CHECK_EVERY))
+    return dict(sweep_us=max(per_rank) + ALLREDUCE_US * n_allreduce / max(T, 1), per_rank_us=per_rank, exchange_us=max(x))
+
+
 def predict(ranks, latency_us, link_gbs, T=50, min_iter=50):
     """sweep(N) and its parts from the per-rank measurements.  Every rank runs the cheaper of its two forms:
     fused  = one launch for all rows, exchange in line:           fused_r + X_r
@@ -209,8 +237,18 @@ def main():
                 for v in pr.values():
                     v['weak_efficiency'] = t1 / v['sweep_us']
                     v['iters_per_s_70k_equivalents'] = world * 1e6 / v['sweep_us']
+                share = gdist.halo_share(P, order_p, bounds)
+                granks = gather_measurements(P, order_p, bounds, prob, prob['k'], args.reps)
+                pg = {name: predict_gather(granks, lat_us, gbs) for name, lat_us, gbs in
+                      (('bw_peak', 0.0, LINK_GBS_PEAK), ('bw_rccl', 0.0, LINK_GBS_RCCL), ('rccl', L, LINK_GBS_RCCL))}
+                for v in pg.values():
+                    v['weak_efficiency'] = t1 / v['sweep_us']
                 entry[part] = dict(ranks=ranks, predicted=pr, imbalance=max(m['n_own'] for m in ranks) * world / n,
-                                   work_imbalance=max(m['nnz'] for m in ranks) * world / float(P.nnz), planner=pinfo, planner_s=t_part)
+                                   work_imbalance=max(m['nnz'] for m in ranks) * world / float(P.nnz), planner=pinfo, planner_s=t_part,
+                                   halo_share=share, gather_form=dict(ranks=granks, predicted=pg),
+                                   auto_takes='gather' if (share >= gdist.GATHER_SHARE and world > 1) else 'halo')
+                log('    halo share %.2f; all-gather form: predicted sweep bw %.1f us, rccl %.1f us (eff %.2f / %.2f)'
+                    % (share, pg['bw_rccl']['sweep_us'], pg['rccl']['sweep_us'], pg['bw_rccl']['weak_efficiency'], pg['rccl']['weak_efficiency']))
                 log('config 2 weak, N=%d, %s: halo/rank %s, predicted sweep bw %.1f us, rccl %.1f us (eff %.2f / %.2f)'
                     % (world, part, [m['n_halo'] for m in ranks], pr['bw_rccl']['sweep_us'], pr['rccl']['sweep_us'],
                        pr['bw_rccl']['weak_efficiency'], pr['rccl']['weak_efficiency']))

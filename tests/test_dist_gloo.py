@@ -50,14 +50,15 @@ def test_distributed_sweep_matches_oracle(case, world, tmp_path):
 def test_gather_form_of_the_exchange_matches_oracle(case, world, exchange, tmp_path):
     """SURVEY 8e's fallback: whole blocks to every rank by ONE all-gather straight into the state
     (dist.GatherPlan) instead of selected halo rows by all-to-all-v: the same iterates and T, bit for bit; 'auto' takes it when
-    the ranks import half of the foreign rows or more (one connected expander-like component) and keeps the halo lists otherwise."""
+    the ranks import nearly all foreign rows (dist.GATHER_SHARE) and keeps the halo lists otherwise."""
     res = _run(case, world, tmp_path, exchange=exchange)
     for r in res:
         assert r['T'] == r['T_ref'] and r['equal'], r
         if exchange == 'gather':
             assert r['plan'] == 'GatherPlan', r
         else:
-            assert r['plan'] == ('GatherPlan' if r['halo_share'] >= 0.5 else 'RankPlan'), r
+            from graphlearning_amd import dist as gdist
+            assert r['plan'] == ('GatherPlan' if r['halo_share'] >= gdist.GATHER_SHARE else 'RankPlan'), r
     print(case, world, exchange, res[0]['plan'], 'halo share %.2f' % res[0]['halo_share'])
 
 
