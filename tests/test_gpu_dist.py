@@ -247,6 +247,59 @@ def test_glx_dist_exchange_forms(golden, mode):
         comm.close()
 
 
+@pytest.mark.parametrize('transport', ['none', 'rccl'])
+def test_glx_dist_gather_form_one_rank(golden, transport):
+    """GLX_DIST_FORM_GATHER on ONE rank: the state is the rank's own block, the exchange an in-place ncclAllGather on a 1-rank RCCL
+    communicator -- issued inside the captured device graphs like the grouped send / recv of the list form -- or nothing at all without
+    a communicator.  Golden iterates, replay included."""
+    from graphlearning_amd import dist as gdist, _hip
+    _hip.require_device()
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    ti, lab = g['train_ind'], g['labels']
+    prob = gdist.poisson_problem(W, ti, lab[ti])
+    P = prob['P']
+    n = P.shape[0]
+    order = gdist.locality_order(P)
+    plan = gdist.make_plan(P, order, gdist.block_bounds(n, 1), 0, 'gather')
+    assert type(plan).__name__ == 'GatherPlan' and plan.cap == n and plan.n_halo == 0
+    comm = _hip.Comm(1, 0, _hip.Comm.unique_id() if transport == 'rccl' else None, 0)
+    ds = gdist.glx_dist_sweep(comm, plan, prob['k'], force_exchange=True)
+    try:
+        own = plan.own
+        ds.set_problem(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
+        for _ in range(2):
+            T, ms = ds.run(50, 1000, 8, 0.0)
+            full = np.zeros_like(g['poisson_gd_prob'])
+            full[own] = ds.fetch()
+            assert T == int(g['poisson_gd_T']) and np.array_equal(full, g['poisson_gd_prob'])
+        info = ds.info()
+        assert info['fused'] and info['send_records'] == n and ds.stats()['exchanges'] >= 50
+        print('gather form, one rank (%s): %.1f us per sweep; %s' % (transport, ms * 1e3 / max(T, 1), info))
+    finally:
+        ds.close()
+        comm.close()
+
+
+@pytest.mark.parametrize('case,world', [('twomoons', 2), ('connected', 3)])
+def test_multi_rank_gather_form_over_gloo(case, world, tmp_path):
+    """Several ranks sharing cuda:0, the C-ABI sweep object in its all-gather form (every row a boundary row, the state = world blocks),
+    gloo moving the blocks: bit-identical to the single-rank oracle."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / ('res_gather_' + case))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out, 'glxstep', 'even', 'gather']
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS='1'), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for k in range(world):
+        res = json.load(open(out + '.%d' % k))
+        assert res['T'] == res['T_ref'] and res['equal'] and res['plan'] == 'GatherPlan', res
+
+
 def _check_exchange_form(ds, plan, prob, g, mode):
     own = plan.own
     ds.set_problem(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])

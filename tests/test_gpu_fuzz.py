@@ -298,13 +298,13 @@ def test_random_plaplace_jacobi_matches_the_oracle(gl, orc, seed):
     assert np.array_equal(u, uo, equal_nan=True), (seed, n, p, tol, T)      # (p < 3 can send the reference iteration to NaN: same NaNs)
 
 
-def _virtual_ranks_sweep(gdist, _hip, prob, order, bounds, min_iter, max_iter, dtype=np.float64):
+def _virtual_ranks_sweep(gdist, _hip, prob, order, bounds, min_iter, max_iter, dtype=np.float64, gather=False):
     """Every rank's glx_dist_sweep object in ONE process, the packed boundary records moved between them by numpy (the
     all-to-all-v of the real transport): the stepwise protocol of graphlearning_amd.dist.run_stepwise."""
     P, C = prob['P'], prob['k']
     n = P.shape[0]
     world = len(bounds) - 1
-    plans = [gdist.RankPlan(P, order, bounds, r) for r in range(world)]
+    plans = [(gdist.GatherPlan if gather else gdist.RankPlan)(P, order, bounds, r) for r in range(world)]
     comms = [_hip.Comm(world, r, None) for r in range(world)]
     dss = [gdist.glx_dist_sweep(comms[r], plans[r], C, dtype=dtype) for r in range(world)]
     try:
@@ -314,6 +314,11 @@ def _virtual_ranks_sweep(gdist, _hip, prob, order, bounds, min_iter, max_iter, d
 
         def exchange(next_iterate):
             if plans[0].global_halo == 0:
+                return
+            if gather:       # the all-gather form: every rank's whole block (cap records) to every other rank, in rank order
+                blocks = [ds.get_send() for ds in dss]
+                for r, ds in enumerate(dss):
+                    ds.put_halo(np.concatenate([b for q, b in enumerate(blocks) if q != r], axis=0), next_iterate)
                 return
             sends = [ds.get_send() for ds in dss]
             offs = [np.concatenate([[0], np.cumsum(plans[s].send_counts)]) for s in range(world)]
@@ -376,7 +381,10 @@ def test_random_vertex_partitions_match_the_oracle(gl, orc, seed):
         tag = 'seed %d: n=%d k=%d sym=%s world=%d %s iters=(%d,%d) halo rows %d' % (seed, n, k, sym, world, how, min_iter, max_iter, halo)
         assert T == T_ref, tag
         assert np.array_equal(u, u_ref, equal_nan=True), tag
-        u32, T32, _ = _virtual_ranks_sweep(gdist, _hip, prob, order, bounds, min_iter, max_iter, dtype=np.float32)
+        if seed % 2 == 0:      # the all-gather form of the exchange (GLX_DIST_FORM_GATHER): the same iterates
+            ug, Tg, _ = _virtual_ranks_sweep(gdist, _hip, prob, order, bounds, min_iter, max_iter, gather=True)
+            assert Tg == T_ref and np.array_equal(ug, u_ref, equal_nan=True), tag + ' (all-gather form)'
+        u32, T32, _ = _virtual_ranks_sweep(gdist, _hip, prob, order, bounds, min_iter, max_iter, dtype=np.float32, gather=(seed % 4 == 1))
         assert T32 == T_ref and u32.dtype == np.float32, tag
         assert np.nanmax(np.abs(u32 - u_ref)) <= 1e-5 * max(1.0, np.nanmax(np.abs(u_ref))), tag
 
