@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 GLX_F32, GLX_F64 = 0, 1
-GLX_CG_NP1D, GLX_CG_TREE, GLX_CG_X0 = 1, 2, 4     # flags of glx_cg_solve / glx_cg_groups (include/glx.h)
+GLX_CG_NP1D, GLX_CG_TREE, GLX_CG_X0 = 1, 2, 4     # flags of glx_cg_solve / glx_cg_groups_masked (include/glx.h)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libglx.so')
 _lib = None
@@ -641,7 +641,7 @@ class Sweep:
         steps = C.c_int(0)
         check(load().glx_sweep_project_iterate(self._h, _ptr(pri), _ptr(w), _ptr(labels) if want_labels else None, C.byref(err),
                                                C.byref(steps), int(max_steps), 1 if similarity else 0, 1 if to_onehot else 0,
-                                               int(then_iterate)), 'glx_sweep_project')
+                                               int(then_iterate)), 'glx_sweep_project_iterate')
         if to_onehot or then_iterate:
             self.generation = getattr(self, 'generation', 0) + 1
         return labels, w, err.value, steps.value

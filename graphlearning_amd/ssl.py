@@ -767,7 +767,7 @@ class poisson(ssl):
 
     def _fit_batch(self, trials):
         """Poisson CG for several training sets at once: the trials' right-hand sides become column
-        groups of one multi-RHS solve (glx_cg_groups), each group with the stop test and iteration
+        groups of one multi-RHS solve (glx_cg_groups_masked), each group with the stop test and iteration
         count utils.conjgrad would give it alone (reference: one conjgrad call per trial,
         ssl.py:624-629 under ssl.py:292-396).  solver='gradient_descent': the trials as column groups of one sweep
         (_fit_batch_gd), results read back."""
@@ -839,7 +839,7 @@ class poisson_mbo(ssl):
             raise TypeError('poisson_mbo needs class_priors for its volume-constrained thresholding')
         # the state never leaves the device between the heat sweeps and the thresholding: the
         # volume-constrained decision runs on the sweep's buffer and writes onehot(labels) back
-        # into it (glx_sweep_project); per outer step only the class weights come back
+        # into it (glx_sweep_project_iterate); per outer step only the class weights come back
         rows = np.asarray(train_ind).reshape(-1)
         if len(np.unique(rows)) == len(rows) and labels.min() >= 0 and labels.max() < k:
             # u = onehot(labels) is formed on the device from the labels, Db = mu * dt * source from its labelled rows (every other
@@ -1176,7 +1176,7 @@ class randomwalk(ssl):
         return max(1, min(24, 240 // k))
 
     def _fit_batch(self, trials):
-        """Several training sets as column groups of one solve (glx_cg_groups), like ssl.poisson."""
+        """Several training sets as column groups of one solve (glx_cg_groups_masked), like ssl.poisson."""
         M, dev = self._operator()
         Ys = [M * self._rhs(np.asarray(ti), np.asarray(tl)) for ti, tl in trials]
         k = Ys[0].shape[1]

@@ -124,7 +124,7 @@ int glx_sweep_destroy(glx_sweep* s);
 
 /* Heat/MBO inner loop, ssl.py:826-827: u <- P u + Db, `iters` times, u resident on
  * device between calls (glx_sweep created with min_iter = max_iter = 0 has no stop column).  glx_sweep_iterate ENQUEUES the sweeps and
- * returns: every call that reads or replaces the state (glx_sweep_project, glx_sweep_fetch, glx_sweep_set_state, another
+ * returns: every call that reads or replaces the state (glx_sweep_project_iterate, glx_sweep_fetch, glx_sweep_set_state, another
  * glx_sweep_iterate) is ordered behind them in the sweep's own stream. */
 int glx_sweep_set_state(glx_sweep* s, const void* u0, const void* Db);
 /* The same with the state given as labels -- u = onehot(labels), labels (n,) int64 in the caller's row order -- and the bias by its m
@@ -151,7 +151,7 @@ int glx_sweep_groups_run(glx_sweep_groups* s, int used, int* T_out, float* devic
 int glx_sweep_groups_stop_values(const glx_sweep_groups* s, int b, int64_t cap, double* vals, int* first, int* count);
 int glx_sweep_groups_fetch(glx_sweep_groups* s, int b, void* u_out);              /* (n, C) of group b, caller order */
 int glx_sweep_groups_project(glx_sweep_groups* s, int b, const double* priors, double* weights_inout, int64_t* labels_out,
-                             double* err_out, int* steps_out, int max_steps, int similarity);   /* as glx_sweep_project, on group b */
+                             double* err_out, int* steps_out, int max_steps, int similarity);   /* as glx_sweep_project_iterate with iters = 0, on group b */
 int glx_sweep_groups_destroy(glx_sweep_groups* s);
 
 

@@ -400,7 +400,7 @@ def test_page_rank_midsize_vs_oracle(gl, orc):
 
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
 def test_sweep_project_equals_host_projection(gl, dtype):
-    """glx_sweep_project (decision on the device-resident sweep state) against glx_argmax_project on the
+    """glx_sweep_project_iterate with iters = 0 (decision on the device-resident sweep state) against glx_argmax_project on the
     fetched array (which the g5 golden pins to the reference): labels, weights, error, step count; then
     the state has become onehot(labels)."""
     from graphlearning_amd import _hip
