@@ -7,7 +7,7 @@ mkdir -p $out
 cd /tmp
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum"; do
   name=$(echo $grp | tr ' ' '_')
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/$name -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 > $out/$name.log 2>&1
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/$name -o run -- python $GRAFT_REPO_ROOT/bench.py --no-traffic --no-scale --steps 4 --warmup 1 --min-timed-s 0 "$@" > $out/$name.log 2>&1
   f=$(find $out/$name -name "*counter_collection.csv" | head -1)
   echo "== $grp  ($f)"
   python3 - "$f" <<'PY'
