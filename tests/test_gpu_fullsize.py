@@ -126,7 +126,10 @@ def test_config2_poisson_cg(gl, meta, config2):
         u_ref, it_ref = orc.poisson_cg(W, ti, labels[ti], return_iters=True)
         assert model.num_iter == it_ref and np.array_equal(u, u_ref)
         _record('config 2 Poisson CG, default mode: %d iterations (the reference on its own W: %d), labels equal to the reference run: %s, '
-                'sampled |du| %.3e' % (it_ref, m['cg_iters'], sha(model.predict().astype(np.int64)) == m['cg_pred_sha'], _sample_err(u, m['cg_u_samples'])))
+                'sampled |du| %.3e of max |u| %.3e (the ten clusters are separate components: the singular system\'s per-component null-space '
+                'part grows to 1e13 in the reference\'s own run and hangs on the last bits of W; it is constant per component and column pattern, labels do not see it)'
+                % (it_ref, m['cg_iters'], sha(model.predict().astype(np.int64)) == m['cg_pred_sha'], _sample_err(u, m['cg_u_samples']),
+                   float(np.max(np.abs(m['cg_u_samples']['values'])))))
         return
     assert model.num_iter == m['cg_iters'] == 140
     assert sha(model.predict().astype(np.int64)) == m['cg_pred_sha']
