@@ -192,6 +192,10 @@ def scale_shard_line(steps=4, T=50, traffic=True):
         if tr:
             out['f64']['traffic_over_algorithmic'] = tr / out['f64']['algorithmic_bytes_per_launch']
             out['f64']['traffic_over_distinct_line_bound'] = tr / out['f64']['distinct_line_bound_bytes']
+            # what the memory side behind the L2s actually delivers while this kernel runs (counter bytes, not algorithmic ones): the
+            # Infinity Cache sits in that path, so this is "beyond-L2" traffic against the HBM peak, an upper estimate of the HBM share
+            out['f64']['traffic_GBs'] = tr / (out['f64']['avg_launch_us'] * 1e-6) / 1e9
+            out['f64']['traffic_frac_of_hbm_peak'] = out['f64']['traffic_GBs'] / HBM_PEAK_GBS
     return out
 
 

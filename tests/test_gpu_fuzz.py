@@ -192,8 +192,16 @@ def test_random_pipeline_matches_the_oracle(gl, orc, seed, mode):
         assert np.array_equal(u, u_ref, equal_nan=True), (tag, norm, tau, shift)
         if device:
             uo, ito = orc.laplace_fit(Wo, ti, lab[ti], normalization=norm, tau=tau, mean_shift=shift, return_iters=True)
+            if not np.all(np.isfinite(uo)):
+                # the reference's own solve BROKE DOWN on its W: a column whose residual is exactly zero makes utils.conjgrad divide
+                # 0 / 0 (utils.py:524), the NaN column never satisfies the stop and the other columns iterate on rounding noise for
+                # thousands of steps (seed 214 at 9 x the seeds: six separate components, mean shift -- 3752 iterations on the
+                # reference's W, 4522 on the device's).  Half (1) above held bit for bit, NaN column included; a count decided by noise
+                # is recorded, not asserted -- the rule of the singular Poisson system
+                _record('%s | laplace %s: the reference-W run broke down (non-finite iterate, %d iterations); %d iterations here, finite columns within %.3e'
+                        % (tag, norm, ito, it_ref, float(np.nanmax(np.abs(u - uo))) if np.any(np.isfinite(u - uo)) else float('nan')))
             # (an SPD system stopped at 1e-5: a one-ulp weight may move the stop by an iteration; the iterates then differ by ~tol)
-            if abs(it_ref - ito) <= 1 and it_ref != ito:
+            elif abs(it_ref - ito) <= 1 and it_ref != ito:
                 _record('%s | laplace %s: %d iterations vs the reference-W run %d, max |du| %.3e' % (tag, norm, it_ref, ito, float(np.nanmax(np.abs(u - uo)))))
                 assert np.nanmax(np.abs(u - uo)) <= 1e-4 * max(1.0, np.nanmax(np.abs(uo))), (tag, norm)
             else:
