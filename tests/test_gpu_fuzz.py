@@ -5,6 +5,7 @@ against the oracle bit for bit.  The goldens pin a few shapes; this walks many (
 import numpy as np
 import pytest
 from scipy import sparse
+from scipy.sparse import csgraph
 
 pytestmark = pytest.mark.gpu
 
@@ -192,14 +193,23 @@ def test_random_pipeline_matches_the_oracle(gl, orc, seed, mode):
         assert np.array_equal(u, u_ref, equal_nan=True), (tag, norm, tau, shift)
         if device:
             uo, ito = orc.laplace_fit(Wo, ti, lab[ti], normalization=norm, tau=tau, mean_shift=shift, return_iters=True)
+            # The system is DEFINITE iff tau > 0 or every connected component of W holds a labelled vertex; otherwise the harmonic extension
+            # is not unique on the unlabelled components, CG's answer there is whatever rounding leaves (seed 458 at 20 x the seeds: k = 3
+            # in two dimensions, five of six components without a label -- same count, the unlabelled components 2e-3 apart) and the
+            # reference's own result hangs on the last bits of W: the rule of the singular Poisson system, recorded, not asserted.
+            ncomp, comp = csgraph.connected_components(Wo, directed=False)
+            definite = tau > 0 or len(np.unique(comp[ti])) == ncomp
             if not np.all(np.isfinite(uo)):
                 # the reference's own solve BROKE DOWN on its W: a column whose residual is exactly zero makes utils.conjgrad divide
                 # 0 / 0 (utils.py:524), the NaN column never satisfies the stop and the other columns iterate on rounding noise for
                 # thousands of steps (seed 214 at 9 x the seeds: six separate components, mean shift -- 3752 iterations on the
                 # reference's W, 4522 on the device's).  Half (1) above held bit for bit, NaN column included; a count decided by noise
-                # is recorded, not asserted -- the rule of the singular Poisson system
+                # is recorded, not asserted
                 _record('%s | laplace %s: the reference-W run broke down (non-finite iterate, %d iterations); %d iterations here, finite columns within %.3e'
                         % (tag, norm, ito, it_ref, float(np.nanmax(np.abs(u - uo))) if np.any(np.isfinite(u - uo)) else float('nan')))
+            elif not definite:
+                _north_star(tag, 'laplace %s (singular: %d of %d components without a label)' % (norm, ncomp - len(np.unique(comp[ti])), ncomp),
+                            u, uo, None, None, it_ref, ito, None, strict_count=False, assert_du=False)
             # (an SPD system stopped at 1e-5: a one-ulp weight may move the stop by an iteration; the iterates then differ by ~tol)
             elif abs(it_ref - ito) <= 1 and it_ref != ito:
                 _record('%s | laplace %s: %d iterations vs the reference-W run %d, max |du| %.3e' % (tag, norm, it_ref, ito, float(np.nanmax(np.abs(u - uo)))))
