@@ -10,7 +10,10 @@ import ctypes as C
 import numpy as np
 
 GLX_F32, GLX_F64 = 0, 1
-GLX_CG_NP1D, GLX_CG_TREE, GLX_CG_X0 = 1, 2, 4     # flags of glx_cg_solve / glx_cg_groups_masked (include/glx.h)
+GLX_CG_NP1D, GLX_CG_TREE, GLX_CG_X0, GLX_CG_BLOCKS, GLX_CG_CHAIN = 1, 2, 4, 8, 16     # flags of glx_cg_solve / glx_cg_groups_masked (include/glx.h)
+# how reduce='exact' walks numpy's reduction chains: None = the library's choice (block form from 8192 rows on), 'blocks' / 'chain'
+# force one form (same bits; tests and measurements)
+CG_EXACT_FORM = None
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libglx.so')
 _lib = None
@@ -130,6 +133,7 @@ _SIGNATURES = {
     'glx_cg_groups_rows': [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_int64, C.c_int,
                            C.POINTER(C.c_int), _f64p],
     'glx_cg_last_stop_margin': [_vp, _f64p],
+    'glx_cg_last_block_stats': [_vp, C.POINTER(C.c_int)],
     'glx_host_fingerprint': [_vp, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)],
     'glx_knn_search': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)],
     'glx_knn_result_lists': [_vp, _vp, _vp],
@@ -513,6 +517,12 @@ class DeviceGraph:
                                         its.ctypes.data_as(C.POINTER(C.c_int)), errs.ctypes.data_as(_f64p)), 'glx_cg_groups_rows')
         return X, its, errs
 
+    def last_block_stats(self):
+        """(plain, by record, row by row) block counts of the last reference-order solve's reduction chains; (-1, -1, -1): chain form."""
+        out = (C.c_int * 3)()
+        check(load().glx_cg_last_block_stats(self._h, out), 'glx_cg_last_block_stats')
+        return tuple(out)
+
     def last_stop_margin(self):
         """How close the stop decisions of the last tolerance-mode solve on this operator came to going the other way (relative to
         tol; inf: no such solve)."""
@@ -550,7 +560,9 @@ def host_fingerprint(arrays):
 
 def _reduce_flag(reduce):
     if reduce == 'exact':
-        return 0
+        if CG_EXACT_FORM not in (None, 'blocks', 'chain'):
+            raise GlxError("CG_EXACT_FORM must be None, 'blocks' or 'chain', got %r" % (CG_EXACT_FORM,))
+        return {None: 0, 'blocks': GLX_CG_BLOCKS, 'chain': GLX_CG_CHAIN}[CG_EXACT_FORM]
     if reduce == 'tree':
         return GLX_CG_TREE
     raise GlxError("reduce must be 'exact' (reference-order reductions) or 'tree' (tolerance mode), got %r" % (reduce,))

@@ -22,30 +22,6 @@ template <> struct V4Of<double> { typedef f64x4 type; };
 static const int CG_CHUNK = 8;
 static const int UPD_ROWS_PER_BLOCK = 256;
 
-// The C columns may hold several independent systems side by side ("groups" of Cg columns: the
-// trials of ssl.ssl_trials, ssl.py:292-396, stacked on one operator).  Every group has its own
-// residual norm, stop test and iteration count, exactly as if it had been solved alone; a group
-// that has converged is frozen (no further updates of its columns) while the others run on.
-struct CgScalars {
-  double* rsold;     // [ncols]
-  double* alpha;     // [ncols]
-  double* beta;      // [ncols]
-  double* err_hist;  // [max_hist+1][stride]: per group, then the maximum over the groups still running;
-                     // row 0 = 1 (utils.py:519), unwritten rows = 0 (= stopped)
-  int stride;        // ngroups + 1
-  int ngroups;
-  int Cg;            // columns per group
-  int C;             // ngroups * Cg
-};
-
-// `while (err > tol)`, utils.py:521 (NaN stops the loop too): does iteration `it` run for ...
-__device__ __forceinline__ bool cg_any_active(const CgScalars& sc, int it, double tol) {   // ... any group
-  return sc.err_hist[(size_t)(it - 1) * sc.stride + sc.ngroups] > tol;
-}
-__device__ __forceinline__ bool cg_col_active(const CgScalars& sc, int it, double tol, int col) {   // ... this column's group
-  return col < sc.C && sc.err_hist[(size_t)(it - 1) * sc.stride + col / sc.Cg] > tol;
-}
-
 // x += alpha p ; r -= alpha Ap ; partial[b][c] = sum_rows r^2           (utils.py:525-527)
 // MODE 0: that update.  MODE 1 (init): r = p = b given in r; partial = sum r^2 (utils.py:514-517)
 template <typename T, int MODE>
@@ -526,6 +502,25 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   // the residual history is read in chunks: capped, the loop below wraps nothing (max_iter entries are needed only if they run)
   CG_NEED(b.err_hist, (size_t)hist_cap * stride * 8);
   CG_NEED(b.prod, (size_t)ncols * n * 8);
+  // the two reference-order chains per iteration: walked row by row (cg_seqsum_dpp_kernel, 2.4 ns per row) or in block form
+  // (cg_seqsum.hip: integer block sums confirmed by the exact state; same bits) -- the block form from 8192 rows on
+  SsWork ssw;
+  memset(&ssw, 0, sizeof(ssw));
+  ssw.nchunks = glx_seqsum_chunks(n);
+  const bool ss_blocks = !np1d && !(flags & GLX_CG_CHAIN) && ssw.nchunks <= glx_seqsum_max_chunks() && n >= 1 &&
+                         ((flags & GLX_CG_BLOCKS) || n >= 8192);
+  if (ss_blocks) {
+    CG_NEED(b.ss_bsum, (size_t)(ncols / 4) * ssw.nchunks * 64 * 4 * 8);
+    CG_NEED(b.ss_csum, (size_t)(ncols / 4) * ssw.nchunks * 4 * 8);
+    CG_NEED(b.ss_rec, glx_seqsum_rec_bytes(ncols, ssw.nchunks));
+    CG_NEED(b.ss_mask, (size_t)ncols * ssw.nchunks * 8);
+    CG_NEED(b.ss_stats, 64);
+    ssw.rec = b.ss_rec;
+    ssw.bsum = b.ss_bsum;
+    ssw.csum = b.ss_csum;
+    ssw.mask = b.ss_mask;
+    ssw.stats = b.ss_stats;
+  }
   PwPlan pw;
   memset(&pw, 0, sizeof(pw));
   unsigned pw_grid = 1;
@@ -620,7 +615,11 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, 0, tol, 2);
       hipLaunchKernelGGL(cg_pw_tree_kernel<2>, dim3(1), dim3(256), 0, st, pw, sc, 0, tol);
     }
-  else
+  else if (ss_blocks) {
+    GLX_HIP(hipMemsetAsync(b.ss_stats, 0, 64, st));
+    rc = glx_seqsum_run(2, b.prod, n, ncols, C, sc, 0, tol, ssw, st);
+    if (rc) return rc;
+  } else
     hipLaunchKernelGGL(cg_seqsum_dpp_kernel<2>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, 0, tol);
   GLX_HIP(hipGetLastError());
 
@@ -696,7 +695,10 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, i, tol, 0);
       hipLaunchKernelGGL(cg_pw_tree_kernel<0>, dim3(1), dim3(256), 0, st, pw, sc, i, tol);
     }
-      else
+      else if (ss_blocks) {
+        rc = glx_seqsum_run(0, b.prod, n, ncols, C, sc, i, tol, ssw, st);
+        if (rc) return rc;
+      } else
         hipLaunchKernelGGL(cg_seqsum_dpp_kernel<0>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
       hipLaunchKernelGGL((cg_update_kernel<T, 0>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
@@ -707,7 +709,10 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, i, tol, 1);
       hipLaunchKernelGGL(cg_pw_tree_kernel<1>, dim3(1), dim3(256), 0, st, pw, sc, i, tol);
     }
-      else
+      else if (ss_blocks) {
+        rc = glx_seqsum_run(1, b.prod, n, ncols, C, sc, i, tol, ssw, st);
+        if (rc) return rc;
+      } else
         hipLaunchKernelGGL(cg_seqsum_dpp_kernel<1>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
       GLX_HIP(hipGetLastError());
       hipLaunchKernelGGL(cg_group_err_kernel, dim3(1), blk, 0, st, sc, i, tol);
@@ -730,7 +735,10 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     if (rc) return rc;
   }
   GLX_HIP(hipMemcpyAsync(X, b.dense, (size_t)n * C * es, hipMemcpyDeviceToHost, st));
+  if (ss_blocks) GLX_HIP(hipMemcpyAsync(b.h_err, b.ss_stats, 12, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
+  b.ss_last[0] = b.ss_last[1] = b.ss_last[2] = ss_blocks ? 0 : -1;
+  if (ss_blocks) memcpy(b.ss_last, b.h_err, 12);
   for (int g = 0; g < ngroups; ++g) {
     if (iters_out) iters_out[g] = (int)iters[g];
     if (err_out) err_out[g] = err[g];
@@ -775,6 +783,14 @@ extern "C" int glx_cg_groups_rows(glx_graph* A, int64_t nb, const int32_t* b_row
   rr.vals = b_vals;
   rr.out_scale = out_scale;
   return cg_entry(A, nullptr, X, C, group_cols, mask_rows, mask_ptr, tol, max_iter, flags, iters_out, err_out, rr);
+}
+
+// How the LAST reference-order solve on this operator took its reduction chains: blocks applied as plain integer sums / through
+// their record (splits) / row by row; -1, -1, -1: the chain form (one dependent addition per row) or no solve yet.
+extern "C" int glx_cg_last_block_stats(glx_graph* A, int* out3) {
+  GLX_CHECK(A && out3, GLX_EINVAL, "glx_cg_last_block_stats: null argument");
+  for (int q = 0; q < 3; ++q) out3[q] = A->cg_ws ? ((CgBufs*)A->cg_ws)->ss_last[q] : -1;
+  return GLX_OK;
 }
 
 extern "C" int glx_cg_solve(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int flags,

@@ -27,6 +27,12 @@ struct CgBufs {
   int32_t *mask_rows = nullptr, *mask_ptr = nullptr, *rhs_rows = nullptr;
   double* out_scale = nullptr;
   double *part_dot = nullptr, *part_rs = nullptr, *scal = nullptr, *err_hist = nullptr, *h_err = nullptr;
+  // block form of the reference-order reductions (cg_seqsum.hip): block / chunk sums, block records, row-by-row flags, counters
+  double *ss_bsum = nullptr, *ss_csum = nullptr;
+  char* ss_rec = nullptr;
+  unsigned long long* ss_mask = nullptr;
+  int* ss_stats = nullptr;
+  int ss_last[3] = {-1, -1, -1};       // of the last reference-order solve: blocks taken plain / by record / row by row (-1: chain form)
   // tolerance mode (cg_fused.hip): partial sums, counters, Dirichlet-row masks, staging, the captured launch sequences
   double *f_part1 = nullptr, *f_part1g = nullptr, *f_part2 = nullptr;
   unsigned *f_tick = nullptr, *f_rowmask = nullptr;
@@ -73,6 +79,7 @@ struct CgBufs {
     hipFree(rhs_rows); hipFree(out_scale);
     hipFree(f_part1); hipFree(f_part1g); hipFree(f_part2); hipFree(f_tick); hipFree(f_rowmask); hipFree(f_it);
     hipFree(f_stage);
+    hipFree(ss_bsum); hipFree(ss_csum); hipFree(ss_rec); hipFree(ss_mask); hipFree(ss_stats);
     if (h_stage) hipHostFree(h_stage);
     if (h_hist) hipHostFree(h_hist);
     for (int q = 0; q < 3; ++q) if (f_exec[q]) hipGraphExecDestroy(f_exec[q]);
@@ -84,6 +91,31 @@ struct CgBufs {
 };
 
 
+// The C columns may hold several independent systems side by side ("groups" of Cg columns: the
+// trials of ssl.ssl_trials, ssl.py:292-396, stacked on one operator).  Every group has its own
+// residual norm, stop test and iteration count, exactly as if it had been solved alone; a group
+// that has converged is frozen (no further updates of its columns) while the others run on.
+struct CgScalars {
+  double* rsold;     // [ncols]
+  double* alpha;     // [ncols]
+  double* beta;      // [ncols]
+  double* err_hist;  // [max_hist+1][stride]: per group, then the maximum over the groups still running;
+                     // row 0 = 1 (utils.py:519), unwritten rows = 0 (= stopped)
+  int stride;        // ngroups + 1
+  int ngroups;
+  int Cg;            // columns per group
+  int C;             // ngroups * Cg
+};
+
+// `while (err > tol)`, utils.py:521 (NaN stops the loop too): does iteration `it` run for ...
+__device__ __forceinline__ bool cg_any_active(const CgScalars& sc, int it, double tol) {   // ... any group
+  return sc.err_hist[(size_t)(it - 1) * sc.stride + sc.ngroups] > tol;
+}
+__device__ __forceinline__ bool cg_col_active(const CgScalars& sc, int it, double tol, int col) {   // ... this column's group
+  return col < sc.C && sc.err_hist[(size_t)(it - 1) * sc.stride + col / sc.Cg] > tol;
+}
+
+
 struct CgRhsRows {            // optional forms of the right-hand side and of the result (glx_cg_groups_rows)
   int64_t nb = 0;
   const int32_t* rows = nullptr;
@@ -91,6 +123,21 @@ struct CgRhsRows {            // optional forms of the right-hand side and of th
   const double* out_scale = nullptr;
 };
 
+
+// the reference-order column reductions in block form (cg_seqsum.hip; arithmetic in seqsum_exact.h).  mode 0: alpha = rsold / sum p*Ap;
+// 1: beta = sum r*r / rsold, rsold = sum r*r; 2: rsold = sum r*r -- the results of cg.hip's cg_seqsum_dpp_kernel, bit for bit.
+struct SsWork {
+  char* rec;
+  double *bsum, *csum;
+  unsigned long long* mask;
+  int* stats;                 // [3] blocks taken as plain integers / through their record / row by row (may be null)
+  int nchunks;
+};
+int glx_seqsum_chunks(int64_t n);
+int glx_seqsum_max_chunks();
+size_t glx_seqsum_rec_bytes(int ncols, int nchunks);
+int glx_seqsum_run(int mode, const double* prod, int64_t n, int ncols_all, int C, const CgScalars& sc, int it, double tol, const SsWork& w,
+                   hipStream_t st);
 
 // the tolerance-mode solve (cg_fused.hip); arguments as cg.hip's cg_run
 int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double tol, int64_t max_iter, int* iters_out, double* err_out,

@@ -1,0 +1,308 @@
+// The reference-order column reductions of utils.conjgrad (graphlearning/utils.py:524,527: `np.sum(p * Ap, axis=0)`,
+// `np.sum(r ** 2, axis=0)`), bit for bit, without walking the n dependent additions one by one: seqsum_exact.h has the
+// arithmetic (a running sum inside one binade advances by integer steps; blocks of rows are summed as integers from a guessed
+// exponent and accepted only when the exact state confirms the guess).  Three launches per reduction:
+//   ss_sum_kernel    plain sums of blocks of SS_BLOCK rows and of chunks of 64 blocks           (the approximate prefix)
+//   ss_quant_kernel  per block: the guess from that prefix, the integer record, the chunk-local prefix of the block totals
+//   ss_walk_kernel   one wavefront per column walks the chunks with the exact state: 64 blocks are checked at once, the first
+//                    one that is not a plain same-binade block is taken through its record (splits = single fp64 additions) or,
+//                    if the record does not fit the exact state, row by row; then alpha / beta / rsold as cg.hip's first reducer.
+// The product array is the one cg.hip's producers write: [column block of 4][row in the caller's order][4].
+#define GLX_HD __host__ __device__ static inline
+#include "cg_internal.h"
+#include "seqsum_exact.h"
+
+#define SS_MAX_CHUNKS 2048       // flags of one column in LDS: n <= 2048 * 64 * SS_BLOCK rows (cg.hip falls back to the chain above)
+static const int SS_PF = 6;     // blocks the walk may have to add row by row whose rows are fetched one chunk ahead
+
+struct SsSoA {                  // [field][column][chunk][64 blocks]
+  int32_t* E[SS_MAXSPLIT + 1];
+  int32_t* nsplit;
+  int64_t *R[SS_MAXSPLIT + 1], *lo[SS_MAXSPLIT + 1], *hi[SS_MAXSPLIT + 1];
+  double* xs[SS_MAXSPLIT];
+  unsigned long long* excl;     // sum of R[0] over the plain blocks in front of this one in its chunk (wrapping arithmetic)
+};
+
+size_t glx_seqsum_rec_bytes(int ncols, int nchunks) {
+  const size_t N = (size_t)ncols * nchunks * 64;
+  return N * (4 * (SS_MAXSPLIT + 2) + 8 * (3 * (SS_MAXSPLIT + 1) + SS_MAXSPLIT + 1));
+}
+
+static SsSoA ss_carve(char* base, int ncols, int nchunks) {
+  const size_t N = (size_t)ncols * nchunks * 64;
+  SsSoA s;
+  char* p = base;
+  for (int j = 0; j <= SS_MAXSPLIT; ++j) { s.R[j] = (int64_t*)p; p += N * 8; }
+  for (int j = 0; j <= SS_MAXSPLIT; ++j) { s.lo[j] = (int64_t*)p; p += N * 8; }
+  for (int j = 0; j <= SS_MAXSPLIT; ++j) { s.hi[j] = (int64_t*)p; p += N * 8; }
+  for (int j = 0; j < SS_MAXSPLIT; ++j) { s.xs[j] = (double*)p; p += N * 8; }
+  s.excl = (unsigned long long*)p; p += N * 8;
+  for (int j = 0; j <= SS_MAXSPLIT; ++j) { s.E[j] = (int32_t*)p; p += N * 4; }
+  s.nsplit = (int32_t*)p;
+  return s;
+}
+
+// does this launch have work for column block cb?  (the gates of cg.hip's first reducer)
+template <int MODE>
+__device__ __forceinline__ bool ss_block_live(const CgScalars& sc, int it, double tol, int cb) {
+  if (MODE == 2) return true;
+  if (!cg_any_active(sc, it, tol)) return false;
+  bool any = false;
+  for (int c = cb * 4; c < cb * 4 + 4; ++c) any = any || cg_col_active(sc, it, tol, c);
+  return any;
+}
+
+// thread (bl, cc): block chunk*64+bl of column cb*4+cc
+template <int MODE>
+__global__ __launch_bounds__(256) void ss_sum_kernel(const double* __restrict__ prod, int64_t n, int nchunks, CgScalars sc, int it,
+                                                     double tol, double* __restrict__ bsum, double* __restrict__ csum) {
+  const int cb = blockIdx.y, chunk = blockIdx.x;
+  if (!ss_block_live<MODE>(sc, it, tol, cb)) return;
+  const int bl = threadIdx.x >> 2, cc = threadIdx.x & 3;
+  const double* __restrict__ src = prod + (size_t)cb * n * 4 + cc;
+  const int64_t r0 = ((int64_t)chunk * 64 + bl) * SS_BLOCK;
+  double t = 0.0;
+#pragma unroll 8
+  for (int i = 0; i < SS_BLOCK; ++i) {
+    const int64_t row = r0 + i;
+    t += row < n ? src[row * 4] : 0.0;
+  }
+  bsum[(((size_t)cb * nchunks + chunk) * 64 + bl) * 4 + cc] = t;
+  __shared__ double sh[256];
+  sh[threadIdx.x] = t;
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double c = 0.0;
+    for (int q = 0; q < 64; ++q) c += sh[q * 4 + threadIdx.x];
+    csum[((size_t)cb * nchunks + chunk) * 4 + threadIdx.x] = c;
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void ss_quant_kernel(const double* __restrict__ prod, int64_t n, int nchunks, CgScalars sc, int it,
+                                                       double tol, const double* __restrict__ bsum, const double* __restrict__ csum,
+                                                       SsSoA soa, unsigned long long* __restrict__ badmask) {
+#pragma clang fp contract(off)
+  const int cb = blockIdx.y, chunk = blockIdx.x;
+  if (!ss_block_live<MODE>(sc, it, tol, cb)) return;
+  const int bl = threadIdx.x >> 2, cc = threadIdx.x & 3;
+  __shared__ double sh[256];
+  __shared__ unsigned long long shr[256];
+  __shared__ unsigned shm[8];
+  // the approximate state in front of this chunk, then in front of this block
+  double part = 0.0;
+  for (int c2 = bl; c2 < chunk; c2 += 64) part += csum[((size_t)cb * nchunks + c2) * 4 + cc];
+  sh[threadIdx.x] = part;
+  if (threadIdx.x < 8) shm[threadIdx.x] = 0u;
+  __syncthreads();
+  double pre = 0.0;
+  for (int q = 0; q < 64; ++q) pre += sh[q * 4 + cc];
+  __syncthreads();
+  sh[threadIdx.x] = bsum[(((size_t)cb * nchunks + chunk) * 64 + bl) * 4 + cc];
+  __syncthreads();
+  for (int q = 0; q < bl; ++q) pre += sh[q * 4 + cc];
+  const int64_t r0 = ((int64_t)chunk * 64 + bl) * SS_BLOCK;
+  const int64_t left = n - r0;
+  const int len = left <= 0 ? 0 : (left < SS_BLOCK ? (int)left : SS_BLOCK);
+  SsRec rec;
+  ss_block_record(prod + (size_t)cb * n * 4 + cc + (size_t)(len ? r0 : 0) * 4, 4, len, pre, &rec);
+  const bool plain = rec.nsplit == 0 && rec.E[0] >= 0;
+  shr[threadIdx.x] = plain ? (unsigned long long)rec.R[0] : 0ull;
+  if (rec.E[0] == SS_E_BAD) atomicOr(&shm[cc * 2 + (bl >> 5)], 1u << (bl & 31));
+  __syncthreads();
+  unsigned long long ex = 0ull;
+  for (int q = 0; q < bl; ++q) ex += shr[q * 4 + cc];
+  const int col = cb * 4 + cc;
+  const size_t o = ((size_t)col * nchunks + chunk) * 64 + bl;
+#pragma unroll
+  for (int j = 0; j <= SS_MAXSPLIT; ++j) {
+    soa.E[j][o] = rec.E[j];
+    soa.R[j][o] = rec.R[j];
+    soa.lo[j][o] = rec.lo[j];
+    soa.hi[j][o] = rec.hi[j];
+  }
+#pragma unroll
+  for (int j = 0; j < SS_MAXSPLIT; ++j) soa.xs[j][o] = rec.xs[j];
+  soa.nsplit[o] = rec.nsplit;
+  soa.excl[o] = ex;
+  if (bl == 0) badmask[(size_t)col * nchunks + chunk] = (unsigned long long)shm[cc * 2] | ((unsigned long long)shm[cc * 2 + 1] << 32);
+}
+
+struct SsLane {                 // one block's record, one lane
+  int32_t E[SS_MAXSPLIT + 1], nsplit;
+  int64_t R[SS_MAXSPLIT + 1], lo[SS_MAXSPLIT + 1], hi[SS_MAXSPLIT + 1];
+  double xs[SS_MAXSPLIT];
+  unsigned long long excl;
+};
+
+__device__ __forceinline__ SsLane ss_load_lane(const SsSoA& soa, size_t o) {
+  SsLane L;
+#pragma unroll
+  for (int j = 0; j <= SS_MAXSPLIT; ++j) {
+    L.E[j] = soa.E[j][o];
+    L.R[j] = soa.R[j][o];
+    L.lo[j] = soa.lo[j][o];
+    L.hi[j] = soa.hi[j][o];
+  }
+#pragma unroll
+  for (int j = 0; j < SS_MAXSPLIT; ++j) L.xs[j] = soa.xs[j][o];
+  L.nsplit = soa.nsplit[o];
+  L.excl = soa.excl[o];
+  return L;
+}
+
+__device__ __forceinline__ int ss_rl32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ long long ss_rl64(long long v, int lane) {
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffLL), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
+  return ((long long)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ double ss_rlf(double v, int lane) { return __longlong_as_double(ss_rl64(__double_as_longlong(v), lane)); }
+
+// s += the SS_BLOCK values the first lanes hold, row after row (rows past n were loaded as +0)
+__device__ __forceinline__ double ss_add_rows(double s, double x) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int j = 0; j < SS_BLOCK; ++j) s = s + ss_rlf(x, j);
+  return s;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void ss_walk_kernel(const double* __restrict__ prod, int64_t n, int nchunks, int ncols_all, int C,
+                                                     CgScalars sc, int it, double tol, SsSoA soa,
+                                                     const unsigned long long* __restrict__ badmask, int* __restrict__ stats) {
+#pragma clang fp contract(off)
+  if (MODE != 2 && !cg_any_active(sc, it, tol)) return;
+  const int col = blockIdx.x, lane = threadIdx.x;
+  const bool live = col < ncols_all && (MODE == 2 || col >= C || cg_col_active(sc, it, tol, col));
+  if (!live) return;
+  const double* __restrict__ src = prod + (size_t)(col >> 2) * n * 4 + (col & 3);
+  auto load_rows = [&](int64_t blk) -> double {
+    const int64_t row = blk * SS_BLOCK + lane;
+    return lane < SS_BLOCK && row < n ? src[row * 4] : 0.0;
+  };
+  // which blocks of a chunk the quantising pass flagged "row by row": the whole column's flags, in LDS
+  __shared__ unsigned long long shmask[SS_MAX_CHUNKS];
+  for (int c = lane; c < nchunks; c += 64) shmask[c] = badmask[(size_t)col * nchunks + c];
+  __syncthreads();
+  // their rows, in flagged order, for the first SS_PF of them
+  auto prefetch = [&](int chunk, double* pf) {
+    unsigned long long m = chunk < nchunks ? shmask[chunk] : 0ull;
+#pragma unroll
+    for (int q = 0; q < SS_PF; ++q) {
+      pf[q] = 0.0;
+      if (m) {
+        const int f = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        pf[q] = load_rows((int64_t)chunk * 64 + f);
+      }
+    }
+  };
+  const size_t obase = (size_t)col * nchunks * 64;
+  double s = 0.0;                          // the exact state, the same in every lane
+  int n_plain = 0, n_rec = 0, n_rows = 0;  // blocks taken as plain integers / through their record / row by row
+  SsLane nxt = ss_load_lane(soa, obase + lane);
+  double pf_nxt[SS_PF];
+  prefetch(0, pf_nxt);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const SsLane cur = nxt;
+    double pf[SS_PF];
+#pragma unroll
+    for (int q = 0; q < SS_PF; ++q) pf[q] = pf_nxt[q];
+    if (chunk + 1 < nchunks) nxt = ss_load_lane(soa, obase + (size_t)(chunk + 1) * 64 + lane);
+    prefetch(chunk + 1, pf_nxt);
+    const unsigned long long bad = shmask[chunk];
+    const bool plain = cur.nsplit == 0 && cur.E[0] >= 0;
+    const unsigned long long total = (unsigned long long)ss_rl64((long long)cur.excl, 63) +
+                                     (unsigned long long)ss_rl64(plain ? cur.R[0] : 0ll, 63);
+    int start = 0;
+    while (start < 64) {
+      const bool valid = ss_valid(s);
+      const int E = ss_expo(s);
+      const int64_t K = ss_mant(s);
+      const unsigned long long ex0 = (unsigned long long)ss_rl64((long long)cur.excl, start);
+      const int64_t Kl = (int64_t)((unsigned long long)K + (cur.excl - ex0));      // the state in front of this lane's block
+      bool ok = lane < start || cur.E[0] == SS_E_ANY || (plain && valid && cur.E[0] == E && ss_range_ok(Kl, cur.lo[0], cur.hi[0]));
+      const unsigned long long fm = __ballot(!ok);
+      const int f = fm ? __ffsll((long long)fm) - 1 : 64;
+      if (f > start) {         // blocks start .. f-1 are plain (or empty): one integer addition
+        const unsigned long long upto = f < 64 ? (unsigned long long)ss_rl64((long long)cur.excl, f) : total;
+        const unsigned long long d = upto - ex0;
+        if (valid && d) s = ss_compose(E, (int64_t)((unsigned long long)K + d));
+        n_plain += f - start;
+      }
+      if (f == 64) break;
+      // block f: through its record, else row by row
+      SsRec rec;
+#pragma unroll
+      for (int j = 0; j <= SS_MAXSPLIT; ++j) {
+        rec.E[j] = ss_rl32(cur.E[j], f);
+        rec.R[j] = ss_rl64(cur.R[j], f);
+        rec.lo[j] = ss_rl64(cur.lo[j], f);
+        rec.hi[j] = ss_rl64(cur.hi[j], f);
+      }
+#pragma unroll
+      for (int j = 0; j < SS_MAXSPLIT; ++j) rec.xs[j] = ss_rlf(cur.xs[j], f);
+      rec.nsplit = ss_rl32(cur.nsplit, f);
+      if (rec.E[0] != SS_E_BAD && ss_apply_record(&s, &rec)) {
+        ++n_rec;
+      } else {
+        double x;
+        const int slot = rec.E[0] == SS_E_BAD ? __popcll(bad & ((1ull << f) - 1ull)) : SS_PF;   // its place among the flagged ones
+        if (slot < SS_PF) {
+          x = pf[0];
+#pragma unroll
+          for (int q = 1; q < SS_PF; ++q) x = slot == q ? pf[q] : x;
+        } else {
+          x = load_rows((int64_t)chunk * 64 + f);
+        }
+        s = ss_add_rows(s, x);
+        ++n_rows;
+      }
+      start = f + 1;
+    }
+  }
+  const double tot = s;
+  if (lane == 0) {
+    if (stats) {
+      atomicAdd(&stats[0], n_plain);
+      atomicAdd(&stats[1], n_rec);
+      atomicAdd(&stats[2], n_rows);
+    }
+    const int gc = col;
+    if (MODE == 0) {
+      sc.alpha[gc] = gc < C ? sc.rsold[gc] / tot : 0.0;
+    } else if (MODE == 1) {
+      sc.beta[gc] = gc < C ? tot / sc.rsold[gc] : 0.0;
+      sc.rsold[gc] = tot;
+    } else {
+      sc.rsold[gc] = tot;
+    }
+  }
+}
+
+template <int MODE>
+static int ss_launch(const double* prod, int64_t n, int ncols_all, int C, const CgScalars& sc, int it, double tol, const SsWork& w,
+                     hipStream_t st) {
+  const SsSoA soa = ss_carve(w.rec, ncols_all, w.nchunks);
+  const dim3 grid((unsigned)w.nchunks, (unsigned)(ncols_all / 4));
+  hipLaunchKernelGGL(ss_sum_kernel<MODE>, grid, dim3(256), 0, st, prod, n, w.nchunks, sc, it, tol, w.bsum, w.csum);
+  GLX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(ss_quant_kernel<MODE>, grid, dim3(256), 0, st, prod, n, w.nchunks, sc, it, tol, (const double*)w.bsum,
+                     (const double*)w.csum, soa, w.mask);
+  GLX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(ss_walk_kernel<MODE>, dim3((unsigned)ncols_all), dim3(64), 0, st, prod, n, w.nchunks, ncols_all, C, sc, it, tol, soa,
+                     (const unsigned long long*)w.mask, w.stats);
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}
+
+int glx_seqsum_run(int mode, const double* prod, int64_t n, int ncols_all, int C, const CgScalars& sc, int it, double tol, const SsWork& w,
+                   hipStream_t st) {
+  return mode == 0 ? ss_launch<0>(prod, n, ncols_all, C, sc, it, tol, w, st)
+       : mode == 1 ? ss_launch<1>(prod, n, ncols_all, C, sc, it, tol, w, st)
+                   : ss_launch<2>(prod, n, ncols_all, C, sc, it, tol, w, st);
+}
+
+int glx_seqsum_max_chunks() { return SS_MAX_CHUNKS; }
+int glx_seqsum_chunks(int64_t n) { return (int)((n + (int64_t)SS_BLOCK * 64 - 1) / ((int64_t)SS_BLOCK * 64)); }

@@ -245,10 +245,15 @@ int glx_cg_multi(glx_graph* A, const void* B, void* X, int C, double tol, int64_
  *                ssl.randomwalk / graph.reweight, not for the singular Poisson system);
  *   GLX_CG_X0    X holds the initial iterate x0 on entry and B the caller's r0 = b - A@x0
  *                (utils.py:510-514: `x = x0.copy(); r = b - A@x`); x then accumulates from x0 like the
- *                reference's `x += alpha * p`. */
+ *                reference's `x += alpha * p`;
+ *   GLX_CG_BLOCKS / GLX_CG_CHAIN  how the reference-order mode walks numpy's row-after-row reduction chains: in block form
+ *                (integer block sums confirmed by the exact running sum, csrc/seqsum_exact.h) or one dependent addition per row.
+ *                Same bits either way; the default takes the block form from 8192 rows on.  For tests and measurements. */
 #define GLX_CG_NP1D 1
 #define GLX_CG_TREE 2
 #define GLX_CG_X0 4
+#define GLX_CG_BLOCKS 8
+#define GLX_CG_CHAIN 16
 int glx_cg_solve(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int flags,
                  int* iters_out, double* err_out);
 /* several independent systems on one operator, side by side: the C columns are C/group_cols systems

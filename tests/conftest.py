@@ -16,8 +16,17 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 os.environ.setdefault('GLX_HOST_EXP', '1')
 
 
+def pytest_addoption(parser):
+    # --cg-form blocks|chain: every reference-order conjugate-gradient solve of the session walks numpy's reduction chains in that form
+    # (graphlearning_amd._hip.CG_EXACT_FORM; same bits either way -- the whole parity suite can be run under either)
+    parser.addoption('--cg-form', action='store', default=None, choices=['blocks', 'chain'])
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    if config.getoption('--cg-form'):
+        from graphlearning_amd import _hip
+        _hip.CG_EXACT_FORM = config.getoption('--cg-form')
     # the multi-GPU tests need torch's HIP runtime to be the first one loaded in the process (graphlearning_amd.dist checks it):
     # whichever GPU test runs first, torch is already there
     mark = config.getoption('-m') or ''
