@@ -436,7 +436,8 @@ class DeviceGraph:
         squeeze = B.ndim == 1
         if squeeze:
             B = B[:, None]
-        flags = (GLX_CG_NP1D if squeeze else 0) | _reduce_flag(reduce)
+        # (a single column, 1-D or (n,1): numpy's axis-0 reduction of it is one contiguous run, summed pairwise)
+        flags = (GLX_CG_NP1D if B.shape[1] == 1 else 0) | _reduce_flag(reduce)
         if x0 is None:
             X = np.empty_like(B)
         else:

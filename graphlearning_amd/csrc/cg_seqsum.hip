@@ -61,12 +61,12 @@ __global__ __launch_bounds__(256) void ss_sum_kernel(const double* __restrict__ 
   const int bl = threadIdx.x >> 2, cc = threadIdx.x & 3;
   const double* __restrict__ src = prod + (size_t)cb * n * 4 + cc;
   const int64_t r0 = ((int64_t)chunk * 64 + bl) * SS_BLOCK;
+  double xv[SS_BLOCK];                     // every load issued before the first is used
+#pragma unroll
+  for (int i = 0; i < SS_BLOCK; ++i) xv[i] = r0 + i < n ? src[(r0 + i) * 4] : 0.0;
   double t = 0.0;
-#pragma unroll 8
-  for (int i = 0; i < SS_BLOCK; ++i) {
-    const int64_t row = r0 + i;
-    t += row < n ? src[row * 4] : 0.0;
-  }
+#pragma unroll
+  for (int i = 0; i < SS_BLOCK; ++i) t += xv[i];
   bsum[(((size_t)cb * nchunks + chunk) * 64 + bl) * 4 + cc] = t;
   __shared__ double sh[256];
   sh[threadIdx.x] = t;
@@ -89,6 +89,13 @@ __global__ __launch_bounds__(256) void ss_quant_kernel(const double* __restrict_
   __shared__ double sh[256];
   __shared__ unsigned long long shr[256];
   __shared__ unsigned shm[8];
+  const int64_t r0 = ((int64_t)chunk * 64 + bl) * SS_BLOCK;
+  double xv[SS_BLOCK];                     // the block's rows: every load issued here, consumed from registers below
+  {
+    const double* __restrict__ src = prod + (size_t)cb * n * 4 + cc;
+#pragma unroll
+    for (int i = 0; i < SS_BLOCK; ++i) xv[i] = r0 + i < n ? src[(r0 + i) * 4] : 0.0;
+  }
   // the approximate state in front of this chunk, then in front of this block
   double part = 0.0;
   for (int c2 = bl; c2 < chunk; c2 += 64) part += csum[((size_t)cb * nchunks + c2) * 4 + cc];
@@ -101,11 +108,10 @@ __global__ __launch_bounds__(256) void ss_quant_kernel(const double* __restrict_
   sh[threadIdx.x] = bsum[(((size_t)cb * nchunks + chunk) * 64 + bl) * 4 + cc];
   __syncthreads();
   for (int q = 0; q < bl; ++q) pre += sh[q * 4 + cc];
-  const int64_t r0 = ((int64_t)chunk * 64 + bl) * SS_BLOCK;
   const int64_t left = n - r0;
   const int len = left <= 0 ? 0 : (left < SS_BLOCK ? (int)left : SS_BLOCK);
   SsRec rec;
-  ss_block_record(prod + (size_t)cb * n * 4 + cc + (size_t)(len ? r0 : 0) * 4, 4, len, pre, &rec);
+  ss_block_record_v(xv, len, pre, &rec);
   const bool plain = rec.nsplit == 0 && rec.E[0] >= 0;
   shr[threadIdx.x] = plain ? (unsigned long long)rec.R[0] : 0ull;
   if (rec.E[0] == SS_E_BAD) atomicOr(&shm[cc * 2 + (bl >> 5)], 1u << (bl & 31));
@@ -158,13 +164,46 @@ __device__ __forceinline__ long long ss_rl64(long long v, int lane) {
   return ((long long)hi << 32) | (unsigned)lo;
 }
 __device__ __forceinline__ double ss_rlf(double v, int lane) { return __longlong_as_double(ss_rl64(__double_as_longlong(v), lane)); }
+// a value every lane holds, moved to scalar registers: what follows from it is scalar arithmetic (one wavefront alone on its
+// SIMD pays 4-16 cycles per dependent vector instruction; the walk below is a long dependent chain of integer steps)
+__device__ __forceinline__ long long ss_uni(long long v) {
+  const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((long long)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ double ss_unif(double v) { return __longlong_as_double(ss_uni(__double_as_longlong(v))); }
 
 // s += the SS_BLOCK values the first lanes hold, row after row (rows past n were loaded as +0)
 __device__ __forceinline__ double ss_add_rows(double s, double x) {
 #pragma clang fp contract(off)
 #pragma unroll
   for (int j = 0; j < SS_BLOCK; ++j) s = s + ss_rlf(x, j);
-  return s;
+  return ss_unif(s);
+}
+
+// ss_apply_record (seqsum_exact.h) on the record lane f holds, its fields fetched as they are needed
+__device__ __forceinline__ bool ss_apply_lane(double* s, const SsLane& cur, int f) {
+#pragma clang fp contract(off)
+  const int E0 = ss_rl32(cur.E[0], f);
+  if (E0 == SS_E_ANY) return true;
+  if (E0 == SS_E_BAD || !ss_valid(*s)) return false;
+  int E = ss_expo(*s);
+  int64_t K = ss_mant(*s);
+  const int nsplit = ss_rl32(cur.nsplit, f);
+#pragma unroll
+  for (int j = 0; j <= SS_MAXSPLIT; ++j) {
+    if (j > nsplit) break;
+    if (ss_rl32(cur.E[j], f) != E || !ss_range_ok(K, ss_rl64(cur.lo[j], f), ss_rl64(cur.hi[j], f))) return false;
+    K += ss_rl64(cur.R[j], f);
+    if (j < SS_MAXSPLIT && j < nsplit) {
+      const double sn = ss_unif(ss_compose(E, K) + ss_rlf(cur.xs[j < SS_MAXSPLIT ? j : 0], f));
+      if (!ss_valid(sn)) return false;
+      E = ss_expo(sn);
+      K = ss_mant(sn);
+    }
+  }
+  *s = ss_compose(E, K);
+  return true;
 }
 
 template <int MODE>
@@ -187,7 +226,7 @@ __global__ __launch_bounds__(64) void ss_walk_kernel(const double* __restrict__ 
   __syncthreads();
   // their rows, in flagged order, for the first SS_PF of them
   auto prefetch = [&](int chunk, double* pf) {
-    unsigned long long m = chunk < nchunks ? shmask[chunk] : 0ull;
+    unsigned long long m = chunk < nchunks ? (unsigned long long)ss_uni((long long)shmask[chunk]) : 0ull;
 #pragma unroll
     for (int q = 0; q < SS_PF; ++q) {
       pf[q] = 0.0;
@@ -199,7 +238,7 @@ __global__ __launch_bounds__(64) void ss_walk_kernel(const double* __restrict__ 
     }
   };
   const size_t obase = (size_t)col * nchunks * 64;
-  double s = 0.0;                          // the exact state, the same in every lane
+  double s = 0.0;                          // the exact state: the same in every lane, kept in scalar registers
   int n_plain = 0, n_rec = 0, n_rows = 0;  // blocks taken as plain integers / through their record / row by row
   SsLane nxt = ss_load_lane(soa, obase + lane);
   double pf_nxt[SS_PF];
@@ -211,10 +250,12 @@ __global__ __launch_bounds__(64) void ss_walk_kernel(const double* __restrict__ 
     for (int q = 0; q < SS_PF; ++q) pf[q] = pf_nxt[q];
     if (chunk + 1 < nchunks) nxt = ss_load_lane(soa, obase + (size_t)(chunk + 1) * 64 + lane);
     prefetch(chunk + 1, pf_nxt);
-    const unsigned long long bad = shmask[chunk];
+    const unsigned long long bad = (unsigned long long)ss_uni((long long)shmask[chunk]);
     const bool plain = cur.nsplit == 0 && cur.E[0] >= 0;
     const unsigned long long total = (unsigned long long)ss_rl64((long long)cur.excl, 63) +
                                      (unsigned long long)ss_rl64(plain ? cur.R[0] : 0ll, 63);
+    // what a round can decide without the state: is this lane's block one the integer form may take at all
+    const bool any = cur.E[0] == SS_E_ANY;
     int start = 0;
     while (start < 64) {
       const bool valid = ss_valid(s);
@@ -222,7 +263,7 @@ __global__ __launch_bounds__(64) void ss_walk_kernel(const double* __restrict__ 
       const int64_t K = ss_mant(s);
       const unsigned long long ex0 = (unsigned long long)ss_rl64((long long)cur.excl, start);
       const int64_t Kl = (int64_t)((unsigned long long)K + (cur.excl - ex0));      // the state in front of this lane's block
-      bool ok = lane < start || cur.E[0] == SS_E_ANY || (plain && valid && cur.E[0] == E && ss_range_ok(Kl, cur.lo[0], cur.hi[0]));
+      const bool ok = lane < start || any || (plain && valid && cur.E[0] == E && ss_range_ok(Kl, cur.lo[0], cur.hi[0]));
       const unsigned long long fm = __ballot(!ok);
       const int f = fm ? __ffsll((long long)fm) - 1 : 64;
       if (f > start) {         // blocks start .. f-1 are plain (or empty): one integer addition
@@ -233,22 +274,12 @@ __global__ __launch_bounds__(64) void ss_walk_kernel(const double* __restrict__ 
       }
       if (f == 64) break;
       // block f: through its record, else row by row
-      SsRec rec;
-#pragma unroll
-      for (int j = 0; j <= SS_MAXSPLIT; ++j) {
-        rec.E[j] = ss_rl32(cur.E[j], f);
-        rec.R[j] = ss_rl64(cur.R[j], f);
-        rec.lo[j] = ss_rl64(cur.lo[j], f);
-        rec.hi[j] = ss_rl64(cur.hi[j], f);
-      }
-#pragma unroll
-      for (int j = 0; j < SS_MAXSPLIT; ++j) rec.xs[j] = ss_rlf(cur.xs[j], f);
-      rec.nsplit = ss_rl32(cur.nsplit, f);
-      if (rec.E[0] != SS_E_BAD && ss_apply_record(&s, &rec)) {
+      if (ss_apply_lane(&s, cur, f)) {
         ++n_rec;
       } else {
         double x;
-        const int slot = rec.E[0] == SS_E_BAD ? __popcll(bad & ((1ull << f) - 1ull)) : SS_PF;   // its place among the flagged ones
+        const bool flagged = ss_rl32(cur.E[0], f) == SS_E_BAD;
+        const int slot = flagged ? __popcll(bad & ((1ull << f) - 1ull)) : SS_PF;   // its place among the flagged ones
         if (slot < SS_PF) {
           x = pf[0];
 #pragma unroll

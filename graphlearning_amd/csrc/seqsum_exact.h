@@ -96,8 +96,9 @@ GLX_HD void ss_store_seg(SsRec* rec, int seg, int E, int64_t R, int64_t lo, int6
     if (j == seg) { rec->E[j] = E; rec->R[j] = R; rec->lo[j] = lo; rec->hi[j] = hi; }
 }
 
-// One block of `len` rows (x[i * stride]) prepared from the approximate state s_apx at its first row.
-GLX_HD void ss_block_record(const double* x, int64_t stride, int len, double s_apx, SsRec* rec) {
+// One block prepared from the approximate state s_apx at its first row: rows xv[0 .. len) (the caller has loaded them; on the
+// device the loops unroll and xv lives in registers -- a row-by-row loop over memory would wait for every load in turn).
+GLX_HD void ss_block_record_v(const double* xv, int len, double s_apx, SsRec* rec) {
   SS_NOFMA
 #pragma unroll
   for (int j = 0; j <= SS_MAXSPLIT; ++j) { rec->E[j] = SS_E_ANY; rec->R[j] = rec->lo[j] = rec->hi[j] = 0; }
@@ -106,7 +107,8 @@ GLX_HD void ss_block_record(const double* x, int64_t stride, int len, double s_a
   rec->nsplit = 0;
   {   // rows that are all +-0 change no state (+0 + -0 = +0, and the chain never holds -0): Dirichlet rows, leading zeros
     bool allzero = true;
-    for (int i = 0; i < len; ++i) allzero = allzero && x[(int64_t)i * stride] == 0.0;
+#pragma unroll
+    for (int i = 0; i < SS_BLOCK; ++i) allzero = allzero && (i >= len || xv[i] == 0.0);
     if (allzero) return;
   }
   rec->E[0] = SS_E_BAD;
@@ -116,32 +118,47 @@ GLX_HD void ss_block_record(const double* x, int64_t stride, int len, double s_a
   int64_t Kt = ss_mant(s_apx);          // predicted state: decides where to split, never what the sum is
   int64_t R = 0, lo = 0, hi = 0;
   int seg = 0;
-  for (int i = 0; i < len; ++i) {
-    const double xi = x[(int64_t)i * stride];
-    int64_t r = 0;
-    const bool q = ss_quant(xi, scale, &r);
-    if (q && ss_range_ok(Kt, R + r, R + r)) {
-      R += r;
-      lo = R < lo ? R : lo;
-      hi = R > hi ? R : hi;
-      continue;
-    }
-    // this row is to be added exactly
-    if (seg == SS_MAXSPLIT) { rec->E[0] = SS_E_BAD; return; }        // one too many: the block goes row by row
-    ss_store_seg(rec, seg, E, R, lo, hi);
+  bool dead = false;                    // more rows to add exactly than the record holds, or a state the integer form cannot carry
 #pragma unroll
-    for (int j = 0; j < SS_MAXSPLIT; ++j)
-      if (j == seg) rec->xs[j] = xi;
-    const double sn = ss_compose(E, Kt + R) + xi;
-    if (!ss_valid(sn)) { rec->E[0] = SS_E_BAD; return; }
-    E = ss_expo(sn);
-    scale = ss_scale(E);
-    Kt = ss_mant(sn);
-    R = 0; lo = 0; hi = 0;
-    ++seg;
+  for (int i = 0; i < SS_BLOCK; ++i) {  // (no early exits: the loop unrolls completely and xv stays in registers)
+    if (i < len && !dead) {
+      const double xi = xv[i];
+      int64_t r = 0;
+      const bool q = ss_quant(xi, scale, &r);
+      if (q && ss_range_ok(Kt, R + r, R + r)) {
+        R += r;
+        lo = R < lo ? R : lo;
+        hi = R > hi ? R : hi;
+      } else if (seg == SS_MAXSPLIT) {
+        dead = true;                    // one too many: the block goes row by row
+      } else {                          // this row is to be added exactly
+        ss_store_seg(rec, seg, E, R, lo, hi);
+#pragma unroll
+        for (int j = 0; j < SS_MAXSPLIT; ++j)
+          if (j == seg) rec->xs[j] = xi;
+        const double sn = ss_compose(E, Kt + R) + xi;
+        if (!ss_valid(sn)) {
+          dead = true;
+        } else {
+          E = ss_expo(sn);
+          scale = ss_scale(E);
+          Kt = ss_mant(sn);
+          R = 0; lo = 0; hi = 0;
+          ++seg;
+        }
+      }
+    }
   }
+  if (dead) { rec->E[0] = SS_E_BAD; return; }
   ss_store_seg(rec, seg, E, R, lo, hi);
   rec->nsplit = seg;
+}
+// the same from memory (x[i * stride])
+GLX_HD void ss_block_record(const double* x, int64_t stride, int len, double s_apx, SsRec* rec) {
+  double xv[SS_BLOCK];
+#pragma unroll
+  for (int i = 0; i < SS_BLOCK; ++i) xv[i] = i < len ? x[(int64_t)i * stride] : 0.0;
+  ss_block_record_v(xv, len, s_apx, rec);
 }
 
 // Apply a prepared block to the exact state.  false: the guess did not hold (state untouched) -- add the rows one by one.

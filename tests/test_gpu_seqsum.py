@@ -43,7 +43,7 @@ def _same(a, b):
     return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
 
-@pytest.mark.parametrize('n,C', [(40, 1), (65, 3), (500, 4), (1500, 7), (3000, 10), (4097, 13), (12000, 5)])
+@pytest.mark.parametrize('n,C', [(40, 2), (65, 3), (500, 4), (1500, 7), (3000, 10), (4097, 13), (12000, 5)])
 def test_block_form_equals_chain_and_oracle(gl, orc, form, n, C):
     from graphlearning_amd import _hip
     rng = np.random.default_rng(n + C)
@@ -65,6 +65,20 @@ def test_block_form_equals_chain_and_oracle(gl, orc, form, n, C):
         assert it == it_ref, (name, it, it_ref)
         assert err == err_ref, (name, err, err_ref)
         assert np.array_equal(x, x_ref), name
+
+
+def test_single_column_2d_right_hand_side_reduces_pairwise(gl, orc):
+    """an (n,1) right-hand side: numpy's `np.sum(..., axis=0)` of one column is a contiguous run, summed pairwise like the 1-D case"""
+    from graphlearning_amd import _hip
+    rng = np.random.default_rng(3)
+    for n in (40, 700, 9000):
+        A = _spd(n, n + 1)
+        b = rng.normal(size=(n, 1))
+        x_ref, it_ref, err_ref = orc.conjgrad(A, b, tol=1e-9, return_iters=True)
+        G = _hip.DeviceGraph(A)
+        x, it, err = G.cg(b, tol=1e-9)
+        G.close()
+        assert it == it_ref and err == err_ref and np.array_equal(x, x_ref), n
 
 
 def test_goldens_in_block_form(gl, golden, form):
