@@ -280,6 +280,7 @@ def other_configs(W2, labels2, ti2, device_sync, knn_stats2, X2):
                                'within_1e-5': bool(np.max(np.abs(u - u_ref)) <= 1e-5),
                                'labels_match_reference_run': _sha(model.predict().astype(np.int64)) == m3['pred_sha']}}
     blk3 = model._cache[3].last_block_stats()            # of the 'exact' fit (the loop's last model)
+    forms3 = model._cache[3].last_block_forms()
     _hip.CG_EXACT_FORM = 'chain'
     try:
         u_chain3 = model.fit(ti3, lab3[ti3])
@@ -287,6 +288,7 @@ def other_configs(W2, labels2, ti2, device_sync, knn_stats2, X2):
     finally:
         _hip.CG_EXACT_FORM = None
     c3['exact']['reduction_chains'] = {'form': 'blocks of 32 rows', 'blocks_plain_by_record_row_by_row': list(blk3),
+                                       'kinds_in_block_form_at_the_end': {'p.Ap': bool(forms3 & 1), 'r.r': bool(forms3 & 2)},
                                        'chain_form_fit_ms': ms_chain3[0], 'speedup_over_chain_form': ms_chain3[0] / c3['exact']['fit_ms'],
                                        'bit_identical_to_chain_form': bool(np.array_equal(u, u_chain3))}
     c3['headline'] = 'default'
@@ -310,6 +312,7 @@ def other_configs(W2, labels2, ti2, device_sync, knn_stats2, X2):
     per_it = ms[0] * 1e-3 / its
     # the same fit with the reduction chains walked one dependent addition per row (the form of rounds 1-5; same bits)
     blk2 = model._cache[1].last_block_stats()
+    forms2 = model._cache[1].last_block_forms()
     _hip.CG_EXACT_FORM = 'chain'
     try:
         u_chain = model.fit(ti2, labels2[ti2])
@@ -325,7 +328,8 @@ def other_configs(W2, labels2, ti2, device_sync, knn_stats2, X2):
         'roofline': {'bound': 'hbm', 'achieved': cgb2 / per_it / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': cgb2 / per_it / 1e9 / HBM_PEAK_GBS,
                      'note': 'numpy\'s two row-after-row reduction chains per iteration, walked in block form (csrc/seqsum_exact.h: integer '
                              'block sums confirmed by the exact running sum; same bits as the chain)'},
-        'reduction_chains': {'form': 'blocks of 32 rows', 'blocks_plain_by_record_row_by_row': list(blk2),
+        'reduction_chains': {'form': 'blocks of 32 rows, re-decided per kind of reduction during the solve (products that cancel go row by row)',
+                             'blocks_plain_by_record_row_by_row': list(blk2), 'kinds_in_block_form_at_the_end': {'p.Ap': bool(forms2 & 1), 'r.r': bool(forms2 & 2)},
                              'chain_form_fit_ms': ms_chain[0], 'chain_form_us_per_iteration': ms_chain[0] * 1e3 / its,
                              'speedup_over_chain_form': ms_chain[0] / ms[0],
                              'bit_identical_to_chain_form': bool(np.array_equal(u, u_chain))},

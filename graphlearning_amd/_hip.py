@@ -519,8 +519,15 @@ class DeviceGraph:
         return X, its, errs
 
     def last_block_stats(self):
-        """(plain, by record, row by row) block counts of the last reference-order solve's reduction chains; (-1, -1, -1): chain form."""
-        out = (C.c_int * 3)()
+        """(plain, by record, row by row) block counts of the last reference-order solve's reduction chains; (-1, -1, -1): chain form.
+        `last_block_forms()`: which kinds of reduction ended the solve in block form (bit 0: p.Ap, bit 1: r.r)."""
+        return self._block_stats()[:3]
+
+    def last_block_forms(self):
+        return self._block_stats()[3]
+
+    def _block_stats(self):
+        out = (C.c_int * 4)()
         check(load().glx_cg_last_block_stats(self._h, out), 'glx_cg_last_block_stats')
         return tuple(out)
 

@@ -520,7 +520,16 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     ssw.csum = b.ss_csum;
     ssw.mask = b.ss_mask;
     ssw.stats = b.ss_stats;
+    { int rc_ = b.need_host(&b.h_ss, 64); if (rc_) return rc_; }
+    memset(b.h_ss, 0, 64);
   }
+  // Per kind of reduction (0: p.Ap, 1: r.r) the form is re-decided whenever the host looks at the residual history: the block
+  // form costs about a microsecond per block that is not a plain same-binade one (a lone wavefront issues an instruction every
+  // four cycles), the chain 2.4 ns per row -- products that cancel (the singular Poisson system on separate clusters: p.Ap
+  // changes sign from row to row) are cheaper row by row.  Same bits either way, so switching in mid-solve changes nothing but time.
+  bool blocks_now[2] = {ss_blocks, ss_blocks};
+  const bool blocks_forced = (flags & GLX_CG_BLOCKS) != 0;
+  int ss_seen[2][3] = {{0, 0, 0}, {0, 0, 0}};
   PwPlan pw;
   memset(&pw, 0, sizeof(pw));
   unsigned pw_grid = 1;
@@ -695,7 +704,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, i, tol, 0);
       hipLaunchKernelGGL(cg_pw_tree_kernel<0>, dim3(1), dim3(256), 0, st, pw, sc, i, tol);
     }
-      else if (ss_blocks) {
+      else if (blocks_now[0]) {
         rc = glx_seqsum_run(0, b.prod, n, ncols, C, sc, i, tol, ssw, st);
         if (rc) return rc;
       } else
@@ -709,7 +718,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, i, tol, 1);
       hipLaunchKernelGGL(cg_pw_tree_kernel<1>, dim3(1), dim3(256), 0, st, pw, sc, i, tol);
     }
-      else if (ss_blocks) {
+      else if (blocks_now[1]) {
         rc = glx_seqsum_run(1, b.prod, n, ncols, C, sc, i, tol, ssw, st);
         if (rc) return rc;
       } else
@@ -723,8 +732,20 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     }
     const int64_t cnt = end - it0;
     GLX_HIP(hipMemcpyAsync(b.h_err, b.err_hist + (size_t)(it0 + 1) * stride, (size_t)cnt * stride * 8, hipMemcpyDeviceToHost, st));
+    if (ss_blocks) GLX_HIP(hipMemcpyAsync(b.h_ss, b.ss_stats, 64, hipMemcpyDeviceToHost, st));
     GLX_HIP(hipStreamSynchronize(st));
     read_history(b.h_err, it0, cnt);
+    if (ss_blocks && !blocks_forced) {
+      for (int m = 0; m < 2; ++m) {
+        if (!blocks_now[m]) continue;
+        const double rounds = (double)(b.h_ss[4 * m + 1] - ss_seen[m][1]) + (double)(b.h_ss[4 * m + 2] - ss_seen[m][2]);
+        for (int q = 0; q < 3; ++q) ss_seen[m][q] = b.h_ss[4 * m + q];
+        const double chains = (double)cnt * ncols;
+        const double blocks_us = rounds / chains * 1.0 + ssw.nchunks * 0.3 + 14.0;      // measured: about 1 us per round, 14 for the two passes in front
+        const double chain_us = (double)n * 0.0024;
+        if (blocks_us > chain_us) blocks_now[m] = false;
+      }
+    }
   }
   }
   if (rr.out_scale) {
@@ -735,10 +756,10 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     if (rc) return rc;
   }
   GLX_HIP(hipMemcpyAsync(X, b.dense, (size_t)n * C * es, hipMemcpyDeviceToHost, st));
-  if (ss_blocks) GLX_HIP(hipMemcpyAsync(b.h_err, b.ss_stats, 12, hipMemcpyDeviceToHost, st));
+  if (ss_blocks) GLX_HIP(hipMemcpyAsync(b.h_ss, b.ss_stats, 64, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
-  b.ss_last[0] = b.ss_last[1] = b.ss_last[2] = ss_blocks ? 0 : -1;
-  if (ss_blocks) memcpy(b.ss_last, b.h_err, 12);
+  for (int q = 0; q < 3; ++q) b.ss_last[q] = ss_blocks ? b.h_ss[q] + b.h_ss[4 + q] + b.h_ss[8 + q] : -1;
+  b.ss_last[3] = ss_blocks ? (blocks_now[0] ? 1 : 0) + (blocks_now[1] ? 2 : 0) : -1;
   for (int g = 0; g < ngroups; ++g) {
     if (iters_out) iters_out[g] = (int)iters[g];
     if (err_out) err_out[g] = err[g];
@@ -786,10 +807,11 @@ extern "C" int glx_cg_groups_rows(glx_graph* A, int64_t nb, const int32_t* b_row
 }
 
 // How the LAST reference-order solve on this operator took its reduction chains: blocks applied as plain integer sums / through
-// their record (splits) / row by row; -1, -1, -1: the chain form (one dependent addition per row) or no solve yet.
+// their record (splits) / row by row, and which kinds of reduction were still in block form at its end (bit 0: p.Ap, bit 1: r.r);
+// all -1: the chain form (one dependent addition per row) or no solve yet.
 extern "C" int glx_cg_last_block_stats(glx_graph* A, int* out3) {
   GLX_CHECK(A && out3, GLX_EINVAL, "glx_cg_last_block_stats: null argument");
-  for (int q = 0; q < 3; ++q) out3[q] = A->cg_ws ? ((CgBufs*)A->cg_ws)->ss_last[q] : -1;
+  for (int q = 0; q < 4; ++q) out3[q] = A->cg_ws ? ((CgBufs*)A->cg_ws)->ss_last[q] : -1;
   return GLX_OK;
 }
 

@@ -31,8 +31,10 @@ struct CgBufs {
   double *ss_bsum = nullptr, *ss_csum = nullptr;
   char* ss_rec = nullptr;
   unsigned long long* ss_mask = nullptr;
-  int* ss_stats = nullptr;
-  int ss_last[3] = {-1, -1, -1};       // of the last reference-order solve: blocks taken plain / by record / row by row (-1: chain form)
+  int* ss_stats = nullptr;             // [3 modes][4]: blocks taken plain / by record / row by row, per kind of reduction
+  int* h_ss = nullptr;                 // page-locked copy of them
+  int ss_last[4] = {-1, -1, -1, -1};   // of the last reference-order solve: blocks taken plain / by record / row by row, kinds of reduction
+                                       // still in block form at its end (bit 0: p.Ap, bit 1: r.r); -1: chain form
   // tolerance mode (cg_fused.hip): partial sums, counters, Dirichlet-row masks, staging, the captured launch sequences
   double *f_part1 = nullptr, *f_part1g = nullptr, *f_part2 = nullptr;
   unsigned *f_tick = nullptr, *f_rowmask = nullptr;
@@ -86,6 +88,7 @@ struct CgBufs {
     for (int q = 0; q < 3; ++q) if (f_ev[q]) hipEventDestroy(f_ev[q]);
     if (side) hipStreamDestroy(side);
     if (h_err) hipHostFree(h_err);
+    if (h_ss) hipHostFree(h_ss);
     if (stream) hipStreamDestroy(stream);
   }
 };
@@ -130,7 +133,7 @@ struct SsWork {
   char* rec;
   double *bsum, *csum;
   unsigned long long* mask;
-  int* stats;                 // [3] blocks taken as plain integers / through their record / row by row (may be null)
+  int* stats;                 // [3 modes][4]: blocks taken as plain integers / through their record / row by row (may be null)
   int nchunks;
 };
 int glx_seqsum_chunks(int64_t n);

@@ -4,15 +4,16 @@
 // exponent and accepted only when the exact state confirms the guess).  Three launches per reduction:
 //   ss_sum_kernel    plain sums of blocks of SS_BLOCK rows and of chunks of 64 blocks           (the approximate prefix)
 //   ss_quant_kernel  per block: the guess from that prefix, the integer record, the chunk-local prefix of the block totals
-//   ss_walk_kernel   one wavefront per column walks the chunks with the exact state: 64 blocks are checked at once, the first
-//                    one that is not a plain same-binade block is taken through its record (splits = single fp64 additions) or,
-//                    if the record does not fit the exact state, row by row; then alpha / beta / rsold as cg.hip's first reducer.
+//   ss_walk_kernel   per column one wavefront walks the chunks with the exact state (three more fetch records ahead into LDS): 64
+//                    blocks are checked at once, the first one that is not a plain same-binade block is taken through its record
+//                    (splits = single fp64 additions) or, if the record does not fit the exact state, row by row; then
+//                    alpha / beta / rsold as cg.hip's first reducer.
 // The product array is the one cg.hip's producers write: [column block of 4][row in the caller's order][4].
 #define GLX_HD __host__ __device__ static inline
 #include "cg_internal.h"
 #include "seqsum_exact.h"
 
-#define SS_MAX_CHUNKS 2048       // flags of one column in LDS: n <= 2048 * 64 * SS_BLOCK rows (cg.hip falls back to the chain above)
+#define SS_MAX_CHUNKS 2048       // flags of one column in LDS (16 KB): n <= 2048 * 64 * SS_BLOCK rows (cg.hip falls back to the chain above)
 static const int SS_PF = 6;     // blocks the walk may have to add row by row whose rows are fetched one chunk ahead
 
 struct SsSoA {                  // [field][column][chunk][64 blocks]
@@ -102,12 +103,14 @@ __global__ __launch_bounds__(256) void ss_quant_kernel(const double* __restrict_
   sh[threadIdx.x] = part;
   if (threadIdx.x < 8) shm[threadIdx.x] = 0u;
   __syncthreads();
-  double pre = 0.0;
+  double pre = 0.0;                        // (fixed trip counts: the LDS reads of a loop are issued together, not one per latency)
+#pragma unroll 16
   for (int q = 0; q < 64; ++q) pre += sh[q * 4 + cc];
   __syncthreads();
   sh[threadIdx.x] = bsum[(((size_t)cb * nchunks + chunk) * 64 + bl) * 4 + cc];
   __syncthreads();
-  for (int q = 0; q < bl; ++q) pre += sh[q * 4 + cc];
+#pragma unroll 16
+  for (int q = 0; q < 64; ++q) pre += q < bl ? sh[q * 4 + cc] : 0.0;
   const int64_t left = n - r0;
   const int len = left <= 0 ? 0 : (left < SS_BLOCK ? (int)left : SS_BLOCK);
   SsRec rec;
@@ -117,7 +120,8 @@ __global__ __launch_bounds__(256) void ss_quant_kernel(const double* __restrict_
   if (rec.E[0] == SS_E_BAD) atomicOr(&shm[cc * 2 + (bl >> 5)], 1u << (bl & 31));
   __syncthreads();
   unsigned long long ex = 0ull;
-  for (int q = 0; q < bl; ++q) ex += shr[q * 4 + cc];
+#pragma unroll 16
+  for (int q = 0; q < 64; ++q) ex += q < bl ? shr[q * 4 + cc] : 0ull;
   const int col = cb * 4 + cc;
   const size_t o = ((size_t)col * nchunks + chunk) * 64 + bl;
 #pragma unroll
@@ -206,25 +210,72 @@ __device__ __forceinline__ bool ss_apply_lane(double* s, const SsLane& cur, int 
   return true;
 }
 
+// LDS of the walk: two halves of four chunk slots of records ([field][64 lanes]) and the column's row-by-row flags
+#define SS_RING64 (3 * (SS_MAXSPLIT + 1) + SS_MAXSPLIT + 1)       // R, lo, hi per segment, xs per split, excl
+#define SS_RING32 (SS_MAXSPLIT + 2)                                // E per segment, nsplit
+static size_t ss_walk_lds_bytes(int nchunks) {
+  return (size_t)2 * 4 * 64 * (SS_RING64 * 8 + SS_RING32 * 4) + (size_t)nchunks * 8;
+}
+
+__device__ __forceinline__ void ss_ring_store(unsigned long long* r64, int* r32, int lane, const SsLane& L) {
+  int k = 0;
+#pragma unroll
+  for (int j = 0; j <= SS_MAXSPLIT; ++j) {
+    r64[(k++) * 64 + lane] = (unsigned long long)L.R[j];
+    r64[(k++) * 64 + lane] = (unsigned long long)L.lo[j];
+    r64[(k++) * 64 + lane] = (unsigned long long)L.hi[j];
+    r32[j * 64 + lane] = L.E[j];
+  }
+#pragma unroll
+  for (int j = 0; j < SS_MAXSPLIT; ++j) r64[(k++) * 64 + lane] = (unsigned long long)__double_as_longlong(L.xs[j]);
+  r64[k * 64 + lane] = L.excl;
+  r32[(SS_MAXSPLIT + 1) * 64 + lane] = L.nsplit;
+}
+__device__ __forceinline__ SsLane ss_ring_fetch(const unsigned long long* r64, const int* r32, int lane) {
+  SsLane L;
+  int k = 0;
+#pragma unroll
+  for (int j = 0; j <= SS_MAXSPLIT; ++j) {
+    L.R[j] = (int64_t)r64[(k++) * 64 + lane];
+    L.lo[j] = (int64_t)r64[(k++) * 64 + lane];
+    L.hi[j] = (int64_t)r64[(k++) * 64 + lane];
+    L.E[j] = r32[j * 64 + lane];
+  }
+#pragma unroll
+  for (int j = 0; j < SS_MAXSPLIT; ++j) L.xs[j] = __longlong_as_double((long long)r64[(k++) * 64 + lane]);
+  L.excl = r64[k * 64 + lane];
+  L.nsplit = r32[(SS_MAXSPLIT + 1) * 64 + lane];
+  return L;
+}
+
+// One workgroup of four wavefronts per column.  All four fetch block records (wavefront w the chunks 4 j + w) one PHASE of four
+// chunks ahead into the other half of the LDS ring -- a lone wavefront that fetched its own next chunk waited a full memory
+// round trip per chunk (1.3 us, measured) --; wavefront 0 walks the four chunks of the current phase from LDS with the exact state.
 template <int MODE>
-__global__ __launch_bounds__(64) void ss_walk_kernel(const double* __restrict__ prod, int64_t n, int nchunks, int ncols_all, int C,
-                                                     CgScalars sc, int it, double tol, SsSoA soa,
-                                                     const unsigned long long* __restrict__ badmask, int* __restrict__ stats) {
+__global__ __launch_bounds__(256) void ss_walk_kernel(const double* __restrict__ prod, int64_t n, int nchunks, int ncols_all, int C,
+                                                      CgScalars sc, int it, double tol, SsSoA soa,
+                                                      const unsigned long long* __restrict__ badmask, int* __restrict__ stats) {
 #pragma clang fp contract(off)
+  extern __shared__ unsigned long long ss_lds[];
   if (MODE != 2 && !cg_any_active(sc, it, tol)) return;
-  const int col = blockIdx.x, lane = threadIdx.x;
+  const int col = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool live = col < ncols_all && (MODE == 2 || col >= C || cg_col_active(sc, it, tol, col));
   if (!live) return;
+  unsigned long long* ring64 = ss_lds;                                            // [2][4][SS_RING64][64]
+  int* ring32 = (int*)(ss_lds + (size_t)2 * 4 * SS_RING64 * 64);                  // [2][4][SS_RING32][64]
+  unsigned long long* shmask = (unsigned long long*)(ring32 + (size_t)2 * 4 * SS_RING32 * 64);   // [nchunks]
+  auto r64_of = [&](int half, int slot) { return ring64 + (size_t)(half * 4 + slot) * SS_RING64 * 64; };
+  auto r32_of = [&](int half, int slot) { return ring32 + (size_t)(half * 4 + slot) * SS_RING32 * 64; };
   const double* __restrict__ src = prod + (size_t)(col >> 2) * n * 4 + (col & 3);
   auto load_rows = [&](int64_t blk) -> double {
     const int64_t row = blk * SS_BLOCK + lane;
     return lane < SS_BLOCK && row < n ? src[row * 4] : 0.0;
   };
-  // which blocks of a chunk the quantising pass flagged "row by row": the whole column's flags, in LDS
-  __shared__ unsigned long long shmask[SS_MAX_CHUNKS];
-  for (int c = lane; c < nchunks; c += 64) shmask[c] = badmask[(size_t)col * nchunks + c];
+  const size_t obase = (size_t)col * nchunks * 64;
+  for (int c = threadIdx.x; c < nchunks; c += 256) shmask[c] = badmask[(size_t)col * nchunks + c];
+  if (wave < nchunks) ss_ring_store(r64_of(0, wave), r32_of(0, wave), lane, ss_load_lane(soa, obase + (size_t)wave * 64 + lane));
   __syncthreads();
-  // their rows, in flagged order, for the first SS_PF of them
+  // rows of the blocks of a chunk flagged "row by row", in flagged order, for the first SS_PF of them
   auto prefetch = [&](int chunk, double* pf) {
     unsigned long long m = chunk < nchunks ? (unsigned long long)ss_uni((long long)shmask[chunk]) : 0ull;
 #pragma unroll
@@ -237,64 +288,73 @@ __global__ __launch_bounds__(64) void ss_walk_kernel(const double* __restrict__ 
       }
     }
   };
-  const size_t obase = (size_t)col * nchunks * 64;
   double s = 0.0;                          // the exact state: the same in every lane, kept in scalar registers
   int n_plain = 0, n_rec = 0, n_rows = 0;  // blocks taken as plain integers / through their record / row by row
-  SsLane nxt = ss_load_lane(soa, obase + lane);
   double pf_nxt[SS_PF];
-  prefetch(0, pf_nxt);
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const SsLane cur = nxt;
-    double pf[SS_PF];
+  if (wave == 0) prefetch(0, pf_nxt);
+  const int nphases = (nchunks + 3) / 4;
+  for (int phase = 0; phase < nphases; ++phase) {
+    const int half = phase & 1;
+    const int mine = (phase + 1) * 4 + wave;             // the chunk this wavefront fetches for the next phase
+    SsLane Lnext;
+    if (mine < nchunks) Lnext = ss_load_lane(soa, obase + (size_t)mine * 64 + lane);
+    if (wave == 0) {
+      for (int slot = 0; slot < 4; ++slot) {
+        const int chunk = phase * 4 + slot;
+        if (chunk >= nchunks) break;
+        const SsLane cur = ss_ring_fetch(r64_of(half, slot), r32_of(half, slot), lane);
+        double pf[SS_PF];
 #pragma unroll
-    for (int q = 0; q < SS_PF; ++q) pf[q] = pf_nxt[q];
-    if (chunk + 1 < nchunks) nxt = ss_load_lane(soa, obase + (size_t)(chunk + 1) * 64 + lane);
-    prefetch(chunk + 1, pf_nxt);
-    const unsigned long long bad = (unsigned long long)ss_uni((long long)shmask[chunk]);
-    const bool plain = cur.nsplit == 0 && cur.E[0] >= 0;
-    const unsigned long long total = (unsigned long long)ss_rl64((long long)cur.excl, 63) +
-                                     (unsigned long long)ss_rl64(plain ? cur.R[0] : 0ll, 63);
-    // what a round can decide without the state: is this lane's block one the integer form may take at all
-    const bool any = cur.E[0] == SS_E_ANY;
-    int start = 0;
-    while (start < 64) {
-      const bool valid = ss_valid(s);
-      const int E = ss_expo(s);
-      const int64_t K = ss_mant(s);
-      const unsigned long long ex0 = (unsigned long long)ss_rl64((long long)cur.excl, start);
-      const int64_t Kl = (int64_t)((unsigned long long)K + (cur.excl - ex0));      // the state in front of this lane's block
-      const bool ok = lane < start || any || (plain && valid && cur.E[0] == E && ss_range_ok(Kl, cur.lo[0], cur.hi[0]));
-      const unsigned long long fm = __ballot(!ok);
-      const int f = fm ? __ffsll((long long)fm) - 1 : 64;
-      if (f > start) {         // blocks start .. f-1 are plain (or empty): one integer addition
-        const unsigned long long upto = f < 64 ? (unsigned long long)ss_rl64((long long)cur.excl, f) : total;
-        const unsigned long long d = upto - ex0;
-        if (valid && d) s = ss_compose(E, (int64_t)((unsigned long long)K + d));
-        n_plain += f - start;
-      }
-      if (f == 64) break;
-      // block f: through its record, else row by row
-      if (ss_apply_lane(&s, cur, f)) {
-        ++n_rec;
-      } else {
-        double x;
-        const bool flagged = ss_rl32(cur.E[0], f) == SS_E_BAD;
-        const int slot = flagged ? __popcll(bad & ((1ull << f) - 1ull)) : SS_PF;   // its place among the flagged ones
-        if (slot < SS_PF) {
-          x = pf[0];
+        for (int q = 0; q < SS_PF; ++q) pf[q] = pf_nxt[q];
+        prefetch(chunk + 1, pf_nxt);
+        const unsigned long long bad = (unsigned long long)ss_uni((long long)shmask[chunk]);
+        const bool plain = cur.nsplit == 0 && cur.E[0] >= 0;
+        const unsigned long long total = (unsigned long long)ss_rl64((long long)cur.excl, 63) +
+                                         (unsigned long long)ss_rl64(plain ? cur.R[0] : 0ll, 63);
+        const bool any = cur.E[0] == SS_E_ANY;
+        int start = 0;
+        while (start < 64) {
+          const bool valid = ss_valid(s);
+          const int E = ss_expo(s);
+          const int64_t K = ss_mant(s);
+          const unsigned long long ex0 = (unsigned long long)ss_rl64((long long)cur.excl, start);
+          const int64_t Kl = (int64_t)((unsigned long long)K + (cur.excl - ex0));      // the state in front of this lane's block
+          const bool ok = lane < start || any || (plain && valid && cur.E[0] == E && ss_range_ok(Kl, cur.lo[0], cur.hi[0]));
+          const unsigned long long fm = __ballot(!ok);
+          const int f = fm ? __ffsll((long long)fm) - 1 : 64;
+          if (f > start) {         // blocks start .. f-1 are plain (or empty): one integer addition
+            const unsigned long long upto = f < 64 ? (unsigned long long)ss_rl64((long long)cur.excl, f) : total;
+            const unsigned long long d = upto - ex0;
+            if (valid && d) s = ss_compose(E, (int64_t)((unsigned long long)K + d));
+            n_plain += f - start;
+          }
+          if (f == 64) break;
+          // block f: through its record, else row by row
+          if (ss_apply_lane(&s, cur, f)) {
+            ++n_rec;
+          } else {
+            double x;
+            const bool flagged = ss_rl32(cur.E[0], f) == SS_E_BAD;
+            const int slot_pf = flagged ? __popcll(bad & ((1ull << f) - 1ull)) : SS_PF;   // its place among the flagged ones
+            if (slot_pf < SS_PF) {
+              x = pf[0];
 #pragma unroll
-          for (int q = 1; q < SS_PF; ++q) x = slot == q ? pf[q] : x;
-        } else {
-          x = load_rows((int64_t)chunk * 64 + f);
+              for (int q = 1; q < SS_PF; ++q) x = slot_pf == q ? pf[q] : x;
+            } else {
+              x = load_rows((int64_t)chunk * 64 + f);
+            }
+            s = ss_add_rows(s, x);
+            ++n_rows;
+          }
+          start = f + 1;
         }
-        s = ss_add_rows(s, x);
-        ++n_rows;
       }
-      start = f + 1;
     }
+    if (mine < nchunks) ss_ring_store(r64_of(half ^ 1, wave), r32_of(half ^ 1, wave), lane, Lnext);
+    __syncthreads();
   }
   const double tot = s;
-  if (lane == 0) {
+  if (threadIdx.x == 0) {
     if (stats) {
       atomicAdd(&stats[0], n_plain);
       atomicAdd(&stats[1], n_rec);
@@ -322,8 +382,10 @@ static int ss_launch(const double* prod, int64_t n, int ncols_all, int C, const 
   hipLaunchKernelGGL(ss_quant_kernel<MODE>, grid, dim3(256), 0, st, prod, n, w.nchunks, sc, it, tol, (const double*)w.bsum,
                      (const double*)w.csum, soa, w.mask);
   GLX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(ss_walk_kernel<MODE>, dim3((unsigned)ncols_all), dim3(64), 0, st, prod, n, w.nchunks, ncols_all, C, sc, it, tol, soa,
-                     (const unsigned long long*)w.mask, w.stats);
+  const size_t lds = ss_walk_lds_bytes(w.nchunks);
+  GLX_HIP(hipFuncSetAttribute((const void*)ss_walk_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(ss_walk_kernel<MODE>, dim3((unsigned)ncols_all), dim3(256), lds, st, prod, n, w.nchunks, ncols_all, C, sc, it, tol, soa,
+                     (const unsigned long long*)w.mask, w.stats ? w.stats + 4 * MODE : nullptr);
   GLX_HIP(hipGetLastError());
   return GLX_OK;
 }

@@ -123,10 +123,12 @@ int glx_knn_stats(double stats[16]);  /* of the calling thread's last search: [0
  * solve on this operator; +inf when there was none.  ssl.laplace / ssl.randomwalk (reduce='auto') hand a solve whose stop hung on less
  * than ssl.AUTO_STOP_BAND back to the reference-order reductions. */
 int glx_cg_last_stop_margin(glx_graph* A, double* margin_out);
-/* how the last reference-order solve on this operator walked numpy's reduction chains (csrc/seqsum_exact.h): out3 = blocks of 32 rows
+/* how the last reference-order solve on this operator walked numpy's reduction chains (csrc/seqsum_exact.h): out4 = blocks of 32 rows
  * applied as plain integer sums, through their record (rows added exactly between integer segments), row by row -- summed over
- * the solve's reductions; -1, -1, -1: the chain form (GLX_CG_CHAIN, fewer than 8192 rows, a 1-D right-hand side) or no solve yet. */
-int glx_cg_last_block_stats(glx_graph* A, int* out3);
+ * the solve's reductions --, and which kinds of reduction were still in block form at its end (bit 0: p.Ap, bit 1: r.r; the solve
+ * moves a kind whose products cancel to the chain form, see GLX_CG_BLOCKS); all -1: the chain form throughout (GLX_CG_CHAIN, fewer
+ * than 8192 rows, a 1-D right-hand side) or no solve yet. */
+int glx_cg_last_block_stats(glx_graph* A, int* out4);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 """A/B of the two forms of the reference-order reduction chains (GLX_CG_CHAIN / GLX_CG_BLOCKS, include/glx.h) on the bench's
 configurations: ssl.poisson's default CG on config 2 (singular system, cancelling products) and ssl.laplace(reduce='exact') on
 config 3.  Prints fit times, per-iteration times, block statistics and whether the iterates are the same bits.
-    python scripts/cg_forms.py [reps]"""
+    python scripts/cg_forms.py [reps] [forms, e.g. blocks or chain,blocks]"""
 import os
 import sys
 import time
@@ -14,28 +14,29 @@ import graphlearning_amd as gl  # noqa: E402
 from graphlearning_amd import _hip  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+forms = tuple(sys.argv[2].split(',')) if len(sys.argv) > 2 else ('chain', 'auto', 'blocks', 'chain', 'auto')
 
 
 def timed(model, ti, lab, dev_of):
     out = {}
-    for form in ('chain', 'blocks', 'chain', 'blocks'):
-        _hip.CG_EXACT_FORM = form
+    for form in forms:
+        _hip.CG_EXACT_FORM = None if form == 'auto' else form      # 'auto': the library's choice, re-decided per kind of reduction during the solve
         u = model.fit(ti, lab).copy()
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
             model.fit(ti, lab)
             ts.append(time.perf_counter() - t0)
-        out.setdefault(form, []).append((float(np.median(ts)) * 1e3, int(model.num_iter), dev_of(model).last_block_stats(), u))
+        out.setdefault(form, []).append((float(np.median(ts)) * 1e3, int(model.num_iter), dev_of(model).last_block_stats() + (dev_of(model).last_block_forms(),), u))
     _hip.CG_EXACT_FORM = None
     return out
 
 
 def report(name, res):
-    uc = res['chain'][0][3]
-    for form in ('chain', 'blocks'):
+    uc = res[forms[0]][0][3]
+    for form in dict.fromkeys(forms):
         for ms, its, st, u in res[form]:
-            print('%s | %-6s: fit %.2f ms, %d iterations, %.1f us per iteration, blocks (plain, by record, row by row) %s, same bits as chain: %s'
+            print('%s | %-6s: fit %.2f ms, %d iterations, %.1f us per iteration, blocks (plain, by record, row by row, kinds still in block form at the end) %s, same bits as chain: %s'
                   % (name, form, ms, its, ms * 1e3 / its, st, np.array_equal(u, uc, equal_nan=True)), flush=True)
 
 
