@@ -279,12 +279,15 @@ __global__ __launch_bounds__(256) void ss_walk_kernel(const double* __restrict__
   auto prefetch = [&](int chunk, double* pf) {
     unsigned long long m = chunk < nchunks ? (unsigned long long)ss_uni((long long)shmask[chunk]) : 0ull;
 #pragma unroll
-    for (int q = 0; q < SS_PF; ++q) {
-      pf[q] = 0.0;
-      if (m) {
-        const int f = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        pf[q] = load_rows((int64_t)chunk * 64 + f);
+    for (int q = 0; q < SS_PF; ++q) pf[q] = 0.0;
+    if (m) {                               // (most chunks have none)
+#pragma unroll
+      for (int q = 0; q < SS_PF; ++q) {
+        if (m) {
+          const int f = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          pf[q] = load_rows((int64_t)chunk * 64 + f);
+        }
       }
     }
   };

@@ -65,18 +65,21 @@ GLX_HD double ss_scale(int E) { return ss_from_bits((int64_t)(1023 + 1075 - E) <
 GLX_HD bool ss_quant(double x, double scale, int64_t* r) {
   SS_NOFMA
   const double X = x * scale;                 // exact (a power of two) unless it underflows, and then |X| < 2^-1000: rnd = 0, no tie
-  if (!(fabs(X) < 4503599627370496.0)) return false;
   const double Rd = rint(X);                  // round half to even (the default mode; v_rndne_f64 on the device)
-  if (fabs(X - Rd) == 0.5) return false;      // X - Rd is exact; a tie's direction depends on the parity of K
-  *r = (int64_t)Rd;
-  return true;
+  // the integer in Rd, for |Rd| <= 2^51: Rd + 1.5 * 2^52 is exact and lies in [2^52, 2^53), where consecutive doubles are
+  // consecutive bit patterns (a float -> int64 conversion is a dozen instructions on the device; this is two)
+  *r = ss_bits(Rd + 6755399441055744.0) - 0x4338000000000000LL;
+  // X - Rd is exact; a tie's direction depends on the parity of K.  (nan and inf fail the first test)
+  return fabs(X) < 2251799813685248.0 && fabs(X - Rd) != 0.5;
+}
+// is a (a state in units of K's grid) strictly inside K's binade, on K's side of zero
+GLX_HD bool ss_inside(int64_t K, int64_t a) {
+  const int64_t m = K > 0 ? a : (int64_t)(0 - (uint64_t)a);
+  return (uint64_t)m - (uint64_t)(SS_TWO52 + 1) < (uint64_t)(SS_TWO52 - 1);      // 2^52 < m < 2^53, one unsigned comparison
 }
 // may a segment with partial sums in [lo, hi] be applied to K?  (every intermediate strictly inside the binade, sign kept)
 GLX_HD int64_t ss_wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }   // wrapping (a walk may test lanes it will not use)
-GLX_HD bool ss_range_ok(int64_t K, int64_t lo, int64_t hi) {
-  const int64_t a = ss_wadd(K, lo), b = ss_wadd(K, hi);
-  return K > 0 ? (a > SS_TWO52 && b < SS_TWO53) : (b < -SS_TWO52 && a > -SS_TWO53);
-}
+GLX_HD bool ss_range_ok(int64_t K, int64_t lo, int64_t hi) { return ss_inside(K, ss_wadd(K, lo)) && ss_inside(K, ss_wadd(K, hi)); }
 
 // What the quantising pass leaves per block: up to SS_MAXSPLIT + 1 integer segments with one row added exactly between each two.
 #ifndef SS_MAXSPLIT
@@ -125,8 +128,9 @@ GLX_HD void ss_block_record_v(const double* xv, int len, double s_apx, SsRec* re
       const double xi = xv[i];
       int64_t r = 0;
       const bool q = ss_quant(xi, scale, &r);
-      if (q && ss_range_ok(Kt, R + r, R + r)) {
-        R += r;
+      const int64_t Rn = ss_wadd(R, r);
+      if (q & ss_inside(Kt, ss_wadd(Kt, Rn))) {        // (&: both sides are cheap and branch-free)
+        R = Rn;
         lo = R < lo ? R : lo;
         hi = R > hi ? R : hi;
       } else if (seg == SS_MAXSPLIT) {
