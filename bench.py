@@ -287,7 +287,7 @@ def other_configs(W2, labels2, ti2, device_sync, knn_stats2, X2):
         ms_chain3 = _median_ms(lambda: model.fit(ti3, lab3[ti3]), device_sync)
     finally:
         _hip.CG_EXACT_FORM = None
-    c3['exact']['reduction_chains'] = {'form': 'blocks of 32 rows', 'blocks_plain_by_record_row_by_row': list(blk3),
+    c3['exact']['reduction_chains'] = {'form': 'blocks of 256 rows', 'blocks_plain_by_record_row_by_row': list(blk3),
                                        'kinds_in_block_form_at_the_end': {'p.Ap': bool(forms3 & 1), 'r.r': bool(forms3 & 2)},
                                        'chain_form_fit_ms': ms_chain3[0], 'speedup_over_chain_form': ms_chain3[0] / c3['exact']['fit_ms'],
                                        'bit_identical_to_chain_form': bool(np.array_equal(u, u_chain3))}
@@ -328,7 +328,7 @@ def other_configs(W2, labels2, ti2, device_sync, knn_stats2, X2):
         'roofline': {'bound': 'hbm', 'achieved': cgb2 / per_it / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': cgb2 / per_it / 1e9 / HBM_PEAK_GBS,
                      'note': 'numpy\'s two row-after-row reduction chains per iteration, walked in block form (csrc/seqsum_exact.h: integer '
                              'block sums confirmed by the exact running sum; same bits as the chain)'},
-        'reduction_chains': {'form': 'blocks of 32 rows, re-decided per kind of reduction during the solve (products that cancel go row by row)',
+        'reduction_chains': {'form': 'blocks of 256 rows, re-decided per kind of reduction during the solve (products that cancel go row by row)',
                              'blocks_plain_by_record_row_by_row': list(blk2), 'kinds_in_block_form_at_the_end': {'p.Ap': bool(forms2 & 1), 'r.r': bool(forms2 & 2)},
                              'chain_form_fit_ms': ms_chain[0], 'chain_form_us_per_iteration': ms_chain[0] * 1e3 / its,
                              'speedup_over_chain_form': ms_chain[0] / ms[0],

@@ -510,8 +510,8 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   const bool ss_blocks = !np1d && !(flags & GLX_CG_CHAIN) && ssw.nchunks <= glx_seqsum_max_chunks() && n >= 1 &&
                          ((flags & GLX_CG_BLOCKS) || n >= 8192);
   if (ss_blocks) {
-    CG_NEED(b.ss_bsum, (size_t)(ncols / 4) * ssw.nchunks * 64 * 4 * 8);
-    CG_NEED(b.ss_csum, (size_t)(ncols / 4) * ssw.nchunks * 4 * 8);
+    CG_NEED(b.ss_bsum, glx_seqsum_sum_doubles(ncols, ssw.nchunks, 0) * 8);
+    CG_NEED(b.ss_csum, glx_seqsum_sum_doubles(ncols, ssw.nchunks, 1) * 8);
     CG_NEED(b.ss_rec, glx_seqsum_rec_bytes(ncols, ssw.nchunks));
     CG_NEED(b.ss_mask, (size_t)ncols * ssw.nchunks * 8);
     CG_NEED(b.ss_stats, 64);
@@ -741,7 +741,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
         const double rounds = (double)(b.h_ss[4 * m + 1] - ss_seen[m][1]) + (double)(b.h_ss[4 * m + 2] - ss_seen[m][2]);
         for (int q = 0; q < 3; ++q) ss_seen[m][q] = b.h_ss[4 * m + q];
         const double chains = (double)cnt * ncols;
-        const double blocks_us = rounds / chains * 1.0 + ssw.nchunks * 0.3 + 14.0;      // measured: about 1 us per round, 14 for the two passes in front
+        const double blocks_us = rounds / chains * 1.2 + ssw.nchunks * 0.6 + 12.0;      // about a microsecond per block that is not plain, 12 for the passes in front
         const double chain_us = (double)n * 0.0024;
         if (blocks_us > chain_us) blocks_now[m] = false;
       }

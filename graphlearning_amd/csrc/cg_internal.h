@@ -139,6 +139,7 @@ struct SsWork {
 int glx_seqsum_chunks(int64_t n);
 int glx_seqsum_max_chunks();
 size_t glx_seqsum_rec_bytes(int ncols, int nchunks);
+size_t glx_seqsum_sum_doubles(int ncols, int nchunks, int which);
 int glx_seqsum_run(int mode, const double* prod, int64_t n, int ncols_all, int C, const CgScalars& sc, int it, double tol, const SsWork& w,
                    hipStream_t st);
 

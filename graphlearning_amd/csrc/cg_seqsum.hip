@@ -2,8 +2,9 @@
 // `np.sum(r ** 2, axis=0)`), bit for bit, without walking the n dependent additions one by one: seqsum_exact.h has the
 // arithmetic (a running sum inside one binade advances by integer steps; blocks of rows are summed as integers from a guessed
 // exponent and accepted only when the exact state confirms the guess).  Three launches per reduction:
-//   ss_sum_kernel    plain sums of blocks of SS_BLOCK rows and of chunks of 64 blocks           (the approximate prefix)
-//   ss_quant_kernel  per block: the guess from that prefix, the integer record, the chunk-local prefix of the block totals
+//   ss_sum_kernel    plain sums of runs of 16 rows and of groups of 16 blocks (a block = 256 rows)     (the approximate prefix)
+//   ss_quant_kernel  per run of 16 rows: the guess from that prefix and the integer record; the 16 records of a block merged in a
+//                    tree inside one wavefront; the group-local prefix of the block totals
 //   ss_walk_kernel   per column one wavefront walks the chunks with the exact state (three more fetch records ahead into LDS): 64
 //                    blocks are checked at once, the first one that is not a plain same-binade block is taken through its record
 //                    (splits = single fp64 additions) or, if the record does not fit the exact state, row by row; then
@@ -14,7 +15,7 @@
 #include "seqsum_exact.h"
 
 #define SS_MAX_CHUNKS 2048       // flags of one column in LDS (16 KB): n <= 2048 * 64 * SS_BLOCK rows (cg.hip falls back to the chain above)
-static const int SS_PF = 6;     // blocks the walk may have to add row by row whose rows are fetched one chunk ahead
+static const int SS_PF = 3;     // blocks the walk may have to add row by row whose rows are fetched one chunk ahead
 
 struct SsSoA {                  // [field][column][chunk][64 blocks]
   int32_t* E[SS_MAXSPLIT + 1];
@@ -53,89 +54,134 @@ __device__ __forceinline__ bool ss_block_live(const CgScalars& sc, int it, doubl
   return any;
 }
 
-// thread (bl, cc): block chunk*64+bl of column cb*4+cc
-template <int MODE>
-__global__ __launch_bounds__(256) void ss_sum_kernel(const double* __restrict__ prod, int64_t n, int nchunks, CgScalars sc, int it,
-                                                     double tol, double* __restrict__ bsum, double* __restrict__ csum) {
-  const int cb = blockIdx.y, chunk = blockIdx.x;
-  if (!ss_block_live<MODE>(sc, it, tol, cb)) return;
-  const int bl = threadIdx.x >> 2, cc = threadIdx.x & 3;
-  const double* __restrict__ src = prod + (size_t)cb * n * 4 + cc;
-  const int64_t r0 = ((int64_t)chunk * 64 + bl) * SS_BLOCK;
-  double xv[SS_BLOCK];                     // every load issued before the first is used
-#pragma unroll
-  for (int i = 0; i < SS_BLOCK; ++i) xv[i] = r0 + i < n ? src[(r0 + i) * 4] : 0.0;
-  double t = 0.0;
-#pragma unroll
-  for (int i = 0; i < SS_BLOCK; ++i) t += xv[i];
-  bsum[(((size_t)cb * nchunks + chunk) * 64 + bl) * 4 + cc] = t;
-  __shared__ double sh[256];
-  sh[threadIdx.x] = t;
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    double c = 0.0;
-    for (int q = 0; q < 64; ++q) c += sh[q * 4 + threadIdx.x];
-    csum[((size_t)cb * nchunks + chunk) * 4 + threadIdx.x] = c;
-  }
+// Geometry of the two passes in front of the walk: a workgroup of 1024 threads = a GROUP of 16 blocks (a quarter of a walk chunk)
+// of one column block; wavefront w = block 16 g + w; lane = (run of SS_SUB rows `subw` of that block, column cc) = subw * 4 + cc.
+static_assert(SS_SUB == 16 && SS_Q == 16, "the kernels below lay one block out over one wavefront: 16 runs of 16 rows x 4 columns");
+
+__device__ __forceinline__ double ss_col_sum(double v) {        // sum over the 16 runs of a wavefront, per column (lanes 4 apart)
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void ss_quant_kernel(const double* __restrict__ prod, int64_t n, int nchunks, CgScalars sc, int it,
-                                                       double tol, const double* __restrict__ bsum, const double* __restrict__ csum,
-                                                       SsSoA soa, unsigned long long* __restrict__ badmask) {
-#pragma clang fp contract(off)
-  const int cb = blockIdx.y, chunk = blockIdx.x;
+__global__ __launch_bounds__(1024) void ss_sum_kernel(const double* __restrict__ prod, int64_t n, int ngroups, CgScalars sc, int it,
+                                                      double tol, double* __restrict__ ssum, double* __restrict__ gsum) {
+  const int cb = blockIdx.y, g = blockIdx.x;
   if (!ss_block_live<MODE>(sc, it, tol, cb)) return;
-  const int bl = threadIdx.x >> 2, cc = threadIdx.x & 3;
-  __shared__ double sh[256];
-  __shared__ unsigned long long shr[256];
-  __shared__ unsigned shm[8];
-  const int64_t r0 = ((int64_t)chunk * 64 + bl) * SS_BLOCK;
-  double xv[SS_BLOCK];                     // the block's rows: every load issued here, consumed from registers below
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, subw = lane >> 2, cc = lane & 3;
+  const double* __restrict__ src = prod + (size_t)cb * n * 4 + cc;
+  const int64_t r0 = (((int64_t)g * 16 + wave) * SS_Q + subw) * SS_SUB;
+  double xv[SS_SUB];                       // every load issued before the first is used
+#pragma unroll
+  for (int i = 0; i < SS_SUB; ++i) xv[i] = r0 + i < n ? src[(r0 + i) * 4] : 0.0;
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < SS_SUB; ++i) t += xv[i];
+  ssum[(((size_t)cb * ngroups + g) * 256 + wave * 16 + subw) * 4 + cc] = t;
+  const double w = ss_col_sum(t);
+  __shared__ double sh[16 * 4];
+  if (lane < 4) sh[wave * 4 + lane] = w;
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double c = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) c += sh[q * 4 + threadIdx.x];
+    gsum[((size_t)cb * ngroups + g) * 4 + threadIdx.x] = c;
+  }
+}
+
+__device__ __forceinline__ SsRec ss_shfl_down_rec(const SsRec& r, int delta) {
+  SsRec o;
+#pragma unroll
+  for (int j = 0; j <= SS_MAXSPLIT; ++j) {
+    o.E[j] = __shfl_down(r.E[j], delta);
+    o.R[j] = __shfl_down((long long)r.R[j], delta);
+    o.lo[j] = __shfl_down((long long)r.lo[j], delta);
+    o.hi[j] = __shfl_down((long long)r.hi[j], delta);
+  }
+#pragma unroll
+  for (int j = 0; j < SS_MAXSPLIT; ++j) o.xs[j] = __shfl_down(r.xs[j], delta);
+  o.nsplit = __shfl_down(r.nsplit, delta);
+  return o;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void ss_quant_kernel(const double* __restrict__ prod, int64_t n, int nchunks, CgScalars sc, int it,
+                                                        double tol, const double* __restrict__ ssum, const double* __restrict__ gsum,
+                                                        SsSoA soa, unsigned long long* __restrict__ badmask) {
+#pragma clang fp contract(off)
+  const int cb = blockIdx.y, g = blockIdx.x, ngroups = nchunks * 4;
+  if (!ss_block_live<MODE>(sc, it, tol, cb)) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, subw = lane >> 2, cc = lane & 3;
+  __shared__ double sh[16 * 4], sh2[16 * 4];
+  __shared__ unsigned long long shc[16 * 4];
+  __shared__ unsigned shm[4];
+  const int64_t r0 = (((int64_t)g * 16 + wave) * SS_Q + subw) * SS_SUB;
+  double xv[SS_SUB];                       // this thread's rows: every load issued here, consumed from registers below
   {
     const double* __restrict__ src = prod + (size_t)cb * n * 4 + cc;
 #pragma unroll
-    for (int i = 0; i < SS_BLOCK; ++i) xv[i] = r0 + i < n ? src[(r0 + i) * 4] : 0.0;
+    for (int i = 0; i < SS_SUB; ++i) xv[i] = r0 + i < n ? src[(r0 + i) * 4] : 0.0;
   }
-  // the approximate state in front of this chunk, then in front of this block
+  // the approximate state in front of this group (sums of the groups before it) ...
   double part = 0.0;
-  for (int c2 = bl; c2 < chunk; c2 += 64) part += csum[((size_t)cb * nchunks + c2) * 4 + cc];
-  sh[threadIdx.x] = part;
-  if (threadIdx.x < 8) shm[threadIdx.x] = 0u;
-  __syncthreads();
-  double pre = 0.0;                        // (fixed trip counts: the LDS reads of a loop are issued together, not one per latency)
-#pragma unroll 16
-  for (int q = 0; q < 64; ++q) pre += sh[q * 4 + cc];
-  __syncthreads();
-  sh[threadIdx.x] = bsum[(((size_t)cb * nchunks + chunk) * 64 + bl) * 4 + cc];
-  __syncthreads();
-#pragma unroll 16
-  for (int q = 0; q < 64; ++q) pre += q < bl ? sh[q * 4 + cc] : 0.0;
-  const int64_t left = n - r0;
-  const int len = left <= 0 ? 0 : (left < SS_BLOCK ? (int)left : SS_BLOCK);
-  SsRec rec;
-  ss_block_record_v(xv, len, pre, &rec);
-  const bool plain = rec.nsplit == 0 && rec.E[0] >= 0;
-  shr[threadIdx.x] = plain ? (unsigned long long)rec.R[0] : 0ull;
-  if (rec.E[0] == SS_E_BAD) atomicOr(&shm[cc * 2 + (bl >> 5)], 1u << (bl & 31));
-  __syncthreads();
-  unsigned long long ex = 0ull;
-#pragma unroll 16
-  for (int q = 0; q < 64; ++q) ex += q < bl ? shr[q * 4 + cc] : 0ull;
-  const int col = cb * 4 + cc;
-  const size_t o = ((size_t)col * nchunks + chunk) * 64 + bl;
+  for (int g2 = wave * 16 + subw; g2 < g; g2 += 256) part += gsum[((size_t)cb * ngroups + g2) * 4 + cc];
+  part = ss_col_sum(part);
+  // ... and in front of this thread's rows inside it (inclusive scan over the 16 runs of the wavefront, wavefront totals in LDS)
+  const double mine = ssum[(((size_t)cb * ngroups + g) * 256 + wave * 16 + subw) * 4 + cc];
+  double incl = mine;
 #pragma unroll
-  for (int j = 0; j <= SS_MAXSPLIT; ++j) {
-    soa.E[j][o] = rec.E[j];
-    soa.R[j][o] = rec.R[j];
-    soa.lo[j][o] = rec.lo[j];
-    soa.hi[j][o] = rec.hi[j];
+  for (int d = 1; d < 16; d *= 2) {
+    const double v = __shfl_up(incl, 4 * d);
+    if (subw >= d) incl += v;
   }
+  if (lane < 4) sh[wave * 4 + lane] = part;
+  if (lane >= 60) sh2[wave * 4 + cc] = incl;          // run 15: the wavefront's total
+  if (threadIdx.x < 4) shm[threadIdx.x] = 0u;
+  __syncthreads();
+  double pre = incl - mine;
 #pragma unroll
-  for (int j = 0; j < SS_MAXSPLIT; ++j) soa.xs[j][o] = rec.xs[j];
-  soa.nsplit[o] = rec.nsplit;
-  soa.excl[o] = ex;
-  if (bl == 0) badmask[(size_t)col * nchunks + chunk] = (unsigned long long)shm[cc * 2] | ((unsigned long long)shm[cc * 2 + 1] << 32);
+  for (int q = 0; q < 16; ++q) pre += sh[q * 4 + cc] + (q < wave ? sh2[q * 4 + cc] : 0.0);
+  const int64_t left = n - r0;
+  const int len = left <= 0 ? 0 : (left < SS_SUB ? (int)left : SS_SUB);
+  SsRec rec;
+  ss_sub_record(xv, len, pre, &rec);
+  // the 16 records of the block, merged in a tree: run q takes in run q + d
+#pragma unroll
+  for (int d = 1; d < 16; d *= 2) {
+    const SsRec other = ss_shfl_down_rec(rec, 4 * d);
+    if ((subw & (2 * d - 1)) == 0) ss_merge_record(&rec, &other);
+  }
+  // lanes 0..3 hold the block's record for the four columns
+  const bool plain = rec.nsplit == 0 && rec.E[0] >= 0;
+  if (lane < 4) {
+    shc[wave * 4 + lane] = plain ? (unsigned long long)rec.R[0] : 0ull;
+    if (rec.E[0] == SS_E_BAD) atomicOr(&shm[lane], 1u << wave);
+  }
+  __syncthreads();
+  if (lane < 4) {
+    unsigned long long ex = 0ull;                      // group-local: the walk adds the totals of the groups in front (same chunk)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ex += q < wave ? shc[q * 4 + lane] : 0ull;
+    const int col = cb * 4 + lane;
+    const size_t o = ((size_t)col * nchunks + (g >> 2)) * 64 + (g & 3) * 16 + wave;
+#pragma unroll
+    for (int j = 0; j <= SS_MAXSPLIT; ++j) {
+      soa.E[j][o] = rec.E[j];
+      soa.R[j][o] = rec.R[j];
+      soa.lo[j][o] = rec.lo[j];
+      soa.hi[j][o] = rec.hi[j];
+    }
+#pragma unroll
+    for (int j = 0; j < SS_MAXSPLIT; ++j) soa.xs[j][o] = rec.xs[j];
+    soa.nsplit[o] = rec.nsplit;
+    soa.excl[o] = ex;
+    // 16 flags per group: four groups make the chunk's 64-bit word
+    if (wave == 0) ((unsigned short*)badmask)[((size_t)col * nchunks + (g >> 2)) * 4 + (g & 3)] = (unsigned short)shm[lane];
+  }
 }
 
 struct SsLane {                 // one block's record, one lane
@@ -177,11 +223,16 @@ __device__ __forceinline__ long long ss_uni(long long v) {
 }
 __device__ __forceinline__ double ss_unif(double v) { return __longlong_as_double(ss_uni(__double_as_longlong(v))); }
 
-// s += the SS_BLOCK values the first lanes hold, row after row (rows past n were loaded as +0)
-__device__ __forceinline__ double ss_add_rows(double s, double x) {
+#define SS_RPL (SS_BLOCK / 64)    // rows of one block per lane: row 64 q + lane in register q
+struct SsRows { double v[SS_RPL]; };
+// s += the rows of a block, row after row (rows past n were loaded as +0)
+__device__ __forceinline__ double ss_add_rows(double s, const SsRows& x) {
 #pragma clang fp contract(off)
 #pragma unroll
-  for (int j = 0; j < SS_BLOCK; ++j) s = s + ss_rlf(x, j);
+  for (int q = 0; q < SS_RPL; ++q) {
+#pragma unroll
+    for (int j = 0; j < 64; ++j) s = s + ss_rlf(x.v[q], j);
+  }
   return ss_unif(s);
 }
 
@@ -267,19 +318,27 @@ __global__ __launch_bounds__(256) void ss_walk_kernel(const double* __restrict__
   auto r64_of = [&](int half, int slot) { return ring64 + (size_t)(half * 4 + slot) * SS_RING64 * 64; };
   auto r32_of = [&](int half, int slot) { return ring32 + (size_t)(half * 4 + slot) * SS_RING32 * 64; };
   const double* __restrict__ src = prod + (size_t)(col >> 2) * n * 4 + (col & 3);
-  auto load_rows = [&](int64_t blk) -> double {
-    const int64_t row = blk * SS_BLOCK + lane;
-    return lane < SS_BLOCK && row < n ? src[row * 4] : 0.0;
+  auto load_rows = [&](int64_t blk) -> SsRows {
+    SsRows x;
+#pragma unroll
+    for (int q = 0; q < SS_RPL; ++q) {
+      const int64_t row = blk * SS_BLOCK + q * 64 + lane;
+      x.v[q] = row < n ? src[row * 4] : 0.0;
+    }
+    return x;
   };
   const size_t obase = (size_t)col * nchunks * 64;
   for (int c = threadIdx.x; c < nchunks; c += 256) shmask[c] = badmask[(size_t)col * nchunks + c];
   if (wave < nchunks) ss_ring_store(r64_of(0, wave), r32_of(0, wave), lane, ss_load_lane(soa, obase + (size_t)wave * 64 + lane));
   __syncthreads();
   // rows of the blocks of a chunk flagged "row by row", in flagged order, for the first SS_PF of them
-  auto prefetch = [&](int chunk, double* pf) {
+  auto prefetch = [&](int chunk, SsRows* pf) {
     unsigned long long m = chunk < nchunks ? (unsigned long long)ss_uni((long long)shmask[chunk]) : 0ull;
 #pragma unroll
-    for (int q = 0; q < SS_PF; ++q) pf[q] = 0.0;
+    for (int q = 0; q < SS_PF; ++q) {
+#pragma unroll
+      for (int k = 0; k < SS_RPL; ++k) pf[q].v[k] = 0.0;
+    }
     if (m) {                               // (most chunks have none)
 #pragma unroll
       for (int q = 0; q < SS_PF; ++q) {
@@ -293,7 +352,7 @@ __global__ __launch_bounds__(256) void ss_walk_kernel(const double* __restrict__
   };
   double s = 0.0;                          // the exact state: the same in every lane, kept in scalar registers
   int n_plain = 0, n_rec = 0, n_rows = 0;  // blocks taken as plain integers / through their record / row by row
-  double pf_nxt[SS_PF];
+  SsRows pf_nxt[SS_PF];
   if (wave == 0) prefetch(0, pf_nxt);
   const int nphases = (nchunks + 3) / 4;
   for (int phase = 0; phase < nphases; ++phase) {
@@ -305,15 +364,23 @@ __global__ __launch_bounds__(256) void ss_walk_kernel(const double* __restrict__
       for (int slot = 0; slot < 4; ++slot) {
         const int chunk = phase * 4 + slot;
         if (chunk >= nchunks) break;
-        const SsLane cur = ss_ring_fetch(r64_of(half, slot), r32_of(half, slot), lane);
-        double pf[SS_PF];
+        SsLane cur = ss_ring_fetch(r64_of(half, slot), r32_of(half, slot), lane);
+        SsRows pf[SS_PF];
 #pragma unroll
         for (int q = 0; q < SS_PF; ++q) pf[q] = pf_nxt[q];
         prefetch(chunk + 1, pf_nxt);
         const unsigned long long bad = (unsigned long long)ss_uni((long long)shmask[chunk]);
         const bool plain = cur.nsplit == 0 && cur.E[0] >= 0;
-        const unsigned long long total = (unsigned long long)ss_rl64((long long)cur.excl, 63) +
-                                         (unsigned long long)ss_rl64(plain ? cur.R[0] : 0ll, 63);
+        // the quantising pass left prefixes local to its groups of 16 blocks: add the totals of the groups in front
+        unsigned long long total;
+        {
+          const unsigned long long incl = cur.excl + (plain ? (unsigned long long)cur.R[0] : 0ull);
+          const unsigned long long t0 = (unsigned long long)ss_rl64((long long)incl, 15), t1 = (unsigned long long)ss_rl64((long long)incl, 31),
+                                   t2 = (unsigned long long)ss_rl64((long long)incl, 47), t3 = (unsigned long long)ss_rl64((long long)incl, 63);
+          const int gq = lane >> 4;
+          cur.excl += gq == 0 ? 0ull : gq == 1 ? t0 : gq == 2 ? t0 + t1 : t0 + t1 + t2;
+          total = t0 + t1 + t2 + t3;
+        }
         const bool any = cur.E[0] == SS_E_ANY;
         int start = 0;
         while (start < 64) {
@@ -336,13 +403,16 @@ __global__ __launch_bounds__(256) void ss_walk_kernel(const double* __restrict__
           if (ss_apply_lane(&s, cur, f)) {
             ++n_rec;
           } else {
-            double x;
+            SsRows x;
             const bool flagged = ss_rl32(cur.E[0], f) == SS_E_BAD;
             const int slot_pf = flagged ? __popcll(bad & ((1ull << f) - 1ull)) : SS_PF;   // its place among the flagged ones
             if (slot_pf < SS_PF) {
               x = pf[0];
 #pragma unroll
-              for (int q = 1; q < SS_PF; ++q) x = slot_pf == q ? pf[q] : x;
+              for (int q = 1; q < SS_PF; ++q) {
+#pragma unroll
+                for (int k = 0; k < SS_RPL; ++k) x.v[k] = slot_pf == q ? pf[q].v[k] : x.v[k];
+              }
             } else {
               x = load_rows((int64_t)chunk * 64 + f);
             }
@@ -379,10 +449,10 @@ template <int MODE>
 static int ss_launch(const double* prod, int64_t n, int ncols_all, int C, const CgScalars& sc, int it, double tol, const SsWork& w,
                      hipStream_t st) {
   const SsSoA soa = ss_carve(w.rec, ncols_all, w.nchunks);
-  const dim3 grid((unsigned)w.nchunks, (unsigned)(ncols_all / 4));
-  hipLaunchKernelGGL(ss_sum_kernel<MODE>, grid, dim3(256), 0, st, prod, n, w.nchunks, sc, it, tol, w.bsum, w.csum);
+  const dim3 grid((unsigned)w.nchunks * 4, (unsigned)(ncols_all / 4));       // groups of 16 blocks x column blocks
+  hipLaunchKernelGGL(ss_sum_kernel<MODE>, grid, dim3(1024), 0, st, prod, n, w.nchunks * 4, sc, it, tol, w.bsum, w.csum);
   GLX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(ss_quant_kernel<MODE>, grid, dim3(256), 0, st, prod, n, w.nchunks, sc, it, tol, (const double*)w.bsum,
+  hipLaunchKernelGGL(ss_quant_kernel<MODE>, grid, dim3(1024), 0, st, prod, n, w.nchunks, sc, it, tol, (const double*)w.bsum,
                      (const double*)w.csum, soa, w.mask);
   GLX_HIP(hipGetLastError());
   const size_t lds = ss_walk_lds_bytes(w.nchunks);
@@ -401,4 +471,7 @@ int glx_seqsum_run(int mode, const double* prod, int64_t n, int ncols_all, int C
 }
 
 int glx_seqsum_max_chunks() { return SS_MAX_CHUNKS; }
+size_t glx_seqsum_sum_doubles(int ncols, int nchunks, int which) {      // which 0: sums of the runs of 16 rows, 1: of the groups
+  return which == 0 ? (size_t)(ncols / 4) * nchunks * 4 * 256 * 4 : (size_t)(ncols / 4) * nchunks * 4 * 4;
+}
 int glx_seqsum_chunks(int64_t n) { return (int)((n + (int64_t)SS_BLOCK * 64 - 1) / ((int64_t)SS_BLOCK * 64)); }

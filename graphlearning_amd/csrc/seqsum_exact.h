@@ -34,9 +34,13 @@
 #define SS_NOFMA
 #endif
 
-#ifndef SS_BLOCK
-#define SS_BLOCK 32             // rows per block
+#ifndef SS_SUB
+#define SS_SUB 16               // rows one thread turns into a record ...
 #endif
+#ifndef SS_Q
+#define SS_Q 16                 // ... and records of consecutive rows merged into the record of one BLOCK (a power of two: the device merges in a tree)
+#endif
+#define SS_BLOCK (SS_SUB * SS_Q)   // rows per block: what the walk takes in one integer step when nothing special happens inside
 #define SS_E_BAD (-1)           // a block the quantising pass could not prepare: always taken row by row
 #define SS_E_ANY (-2)           // matches any exponent (blocks beyond the last row: nothing to add)
 #define SS_EMIN 64              // states below 2^(64-1023) (and zero, subnormals, inf, nan) are not handled in integer form
@@ -99,9 +103,9 @@ GLX_HD void ss_store_seg(SsRec* rec, int seg, int E, int64_t R, int64_t lo, int6
     if (j == seg) { rec->E[j] = E; rec->R[j] = R; rec->lo[j] = lo; rec->hi[j] = hi; }
 }
 
-// One block prepared from the approximate state s_apx at its first row: rows xv[0 .. len) (the caller has loaded them; on the
+// SS_SUB rows prepared from the approximate state s_apx at the first of them: rows xv[0 .. len) (the caller has loaded them; on the
 // device the loops unroll and xv lives in registers -- a row-by-row loop over memory would wait for every load in turn).
-GLX_HD void ss_block_record_v(const double* xv, int len, double s_apx, SsRec* rec) {
+GLX_HD void ss_sub_record(const double* xv, int len, double s_apx, SsRec* rec) {
   SS_NOFMA
 #pragma unroll
   for (int j = 0; j <= SS_MAXSPLIT; ++j) { rec->E[j] = SS_E_ANY; rec->R[j] = rec->lo[j] = rec->hi[j] = 0; }
@@ -111,7 +115,7 @@ GLX_HD void ss_block_record_v(const double* xv, int len, double s_apx, SsRec* re
   {   // rows that are all +-0 change no state (+0 + -0 = +0, and the chain never holds -0): Dirichlet rows, leading zeros
     bool allzero = true;
 #pragma unroll
-    for (int i = 0; i < SS_BLOCK; ++i) allzero = allzero && (i >= len || xv[i] == 0.0);
+    for (int i = 0; i < SS_SUB; ++i) allzero = allzero && (i >= len || xv[i] == 0.0);
     if (allzero) return;
   }
   rec->E[0] = SS_E_BAD;
@@ -123,7 +127,7 @@ GLX_HD void ss_block_record_v(const double* xv, int len, double s_apx, SsRec* re
   int seg = 0;
   bool dead = false;                    // more rows to add exactly than the record holds, or a state the integer form cannot carry
 #pragma unroll
-  for (int i = 0; i < SS_BLOCK; ++i) {  // (no early exits: the loop unrolls completely and xv stays in registers)
+  for (int i = 0; i < SS_SUB; ++i) {  // (no early exits: the loop unrolls completely and xv stays in registers)
     if (i < len && !dead) {
       const double xi = xv[i];
       int64_t r = 0;
@@ -157,12 +161,48 @@ GLX_HD void ss_block_record_v(const double* xv, int len, double s_apx, SsRec* re
   ss_store_seg(rec, seg, E, R, lo, hi);
   rec->nsplit = seg;
 }
-// the same from memory (x[i * stride])
-GLX_HD void ss_block_record(const double* x, int64_t stride, int len, double s_apx, SsRec* rec) {
-  double xv[SS_BLOCK];
+// Record r (rows that follow M's) appended to M: the last segment of M continues with segment 0 of r when both were quantised
+// for the same exponent; r's further segments follow.  Whatever does not fit (exponents that disagree, more splits than a record
+// holds) leaves M "row by row".  A record is only ever a PROPOSAL -- ss_apply_record checks every segment against the exact state --
+// so any way of merging is safe; this one keeps the partial-sum extremes exact.
+GLX_HD void ss_merge_record(SsRec* M, const SsRec* r) {
+  if (M->E[0] == SS_E_BAD || r->E[0] == SS_E_ANY) return;
+  if (r->E[0] == SS_E_BAD) { M->E[0] = SS_E_BAD; return; }
+  if (M->E[0] == SS_E_ANY) { *M = *r; return; }
+  const int m = M->nsplit;
+  int El = 0;
+  int64_t Rl = 0, lol = 0, hil = 0;
 #pragma unroll
-  for (int i = 0; i < SS_BLOCK; ++i) xv[i] = i < len ? x[(int64_t)i * stride] : 0.0;
-  ss_block_record_v(xv, len, s_apx, rec);
+  for (int j = 0; j <= SS_MAXSPLIT; ++j)
+    if (j == m) { El = M->E[j]; Rl = M->R[j]; lol = M->lo[j]; hil = M->hi[j]; }
+  if (El != r->E[0] || m + r->nsplit > SS_MAXSPLIT) { M->E[0] = SS_E_BAD; return; }
+  const int64_t a = ss_wadd(Rl, r->lo[0]), b = ss_wadd(Rl, r->hi[0]);
+  ss_store_seg(M, m, El, ss_wadd(Rl, r->R[0]), a < lol ? a : lol, b > hil ? b : hil);
+#pragma unroll
+  for (int j = 1; j <= SS_MAXSPLIT; ++j) {
+    if (j <= r->nsplit) {
+      ss_store_seg(M, m + j, r->E[j], r->R[j], r->lo[j], r->hi[j]);
+#pragma unroll
+      for (int k = 0; k < SS_MAXSPLIT; ++k)
+        if (k == m + j - 1) M->xs[k] = r->xs[j - 1];
+    }
+  }
+  M->nsplit = m + r->nsplit;
+}
+
+// One block from memory (x[i * stride], `len` rows, s_apx[q] = the approximate state in front of its q-th run of SS_SUB rows),
+// merged in the tree order of the device (host tests)
+GLX_HD void ss_block_record(const double* x, int64_t stride, int len, const double* s_apx, SsRec* rec) {
+  SsRec sub[SS_Q];
+  for (int q = 0; q < SS_Q; ++q) {
+    double xv[SS_SUB];
+    const int l = len - q * SS_SUB < 0 ? 0 : (len - q * SS_SUB > SS_SUB ? SS_SUB : len - q * SS_SUB);
+    for (int i = 0; i < SS_SUB; ++i) xv[i] = i < l ? x[(int64_t)(q * SS_SUB + i) * stride] : 0.0;
+    ss_sub_record(xv, l, s_apx[q], &sub[q]);
+  }
+  for (int d = 1; d < SS_Q; d *= 2)
+    for (int q = 0; q + d < SS_Q; q += 2 * d) ss_merge_record(&sub[q], &sub[q + d]);
+  *rec = sub[0];
 }
 
 // Apply a prepared block to the exact state.  false: the guess did not hold (state untouched) -- add the rows one by one.

@@ -123,7 +123,7 @@ int glx_knn_stats(double stats[16]);  /* of the calling thread's last search: [0
  * solve on this operator; +inf when there was none.  ssl.laplace / ssl.randomwalk (reduce='auto') hand a solve whose stop hung on less
  * than ssl.AUTO_STOP_BAND back to the reference-order reductions. */
 int glx_cg_last_stop_margin(glx_graph* A, double* margin_out);
-/* how the last reference-order solve on this operator walked numpy's reduction chains (csrc/seqsum_exact.h): out4 = blocks of 32 rows
+/* how the last reference-order solve on this operator walked numpy's reduction chains (csrc/seqsum_exact.h): out4 = blocks of 256 rows
  * applied as plain integer sums, through their record (rows added exactly between integer segments), row by row -- summed over
  * the solve's reductions --, and which kinds of reduction were still in block form at its end (bit 0: p.Ap, bit 1: r.r; the solve
  * moves a kind whose products cancel to the chain form, see GLX_CG_BLOCKS); all -1: the chain form throughout (GLX_CG_CHAIN, fewer

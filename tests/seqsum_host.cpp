@@ -9,21 +9,31 @@ extern "C" double ss_host_chain(const double* x, int64_t n) {
   return s;
 }
 
-// stats: [0] blocks applied in integer form, [1] blocks taken row by row, [2] blocks with a split
+// records of nb blocks: plain sums of the runs of SS_SUB rows, their plain prefix (perturbed by `noise`, relative), one record per
+// run, merged per block in the device's tree order
+static void host_records(const double* x, int64_t n, int64_t nb, double noise, std::vector<SsRec>& rec) {
+  const int64_t nsub = nb * SS_Q;
+  std::vector<double> apx(nsub + 1, 0.0);
+  for (int64_t q = 0; q < nsub; ++q) {
+    double t = 0.0;
+    for (int64_t i = q * SS_SUB; i < n && i < (q + 1) * SS_SUB; ++i) t += x[i];
+    apx[q + 1] = apx[q] + t;
+  }
+  for (int64_t q = 0; q < nsub; ++q) apx[q] *= 1.0 + noise * ((q * 2654435761u) % 1000 / 500.0 - 1.0);
+  rec.resize(nb);
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t left = n - b * SS_BLOCK;
+    const int len = left <= 0 ? 0 : (left < SS_BLOCK ? (int)left : SS_BLOCK);
+    ss_block_record(x + (len ? b * SS_BLOCK : 0), 1, len, &apx[b * SS_Q], &rec[b]);
+  }
+}
+
+// stats: [0] blocks applied in integer form, [1] blocks taken row by row, [2] rows added exactly inside applied blocks
 extern "C" double ss_host_blocks(const double* x, int64_t n, double noise, int64_t* stats) {
   const int64_t nb = (n + SS_BLOCK - 1) / SS_BLOCK;
-  std::vector<double> apx(nb + 1, 0.0);
-  for (int64_t b = 0; b < nb; ++b) {                 // pass 1: plain block sums, plain prefix
-    double t = 0.0;
-    for (int64_t i = b * SS_BLOCK; i < n && i < (b + 1) * SS_BLOCK; ++i) t += x[i];
-    apx[b + 1] = apx[b] + t;
-  }
-  std::vector<SsRec> rec(nb);
-  for (int64_t b = 0; b < nb; ++b) {                 // pass 2: records from the guess
-    const int len = (int)((n - b * SS_BLOCK) < SS_BLOCK ? (n - b * SS_BLOCK) : SS_BLOCK);
-    ss_block_record(x + b * SS_BLOCK, 1, len, apx[b] * (1.0 + noise * ((b * 2654435761u) % 1000 / 500.0 - 1.0)), &rec[b]);
-  }
-  double s = 0.0;                                    // pass 3: the walk with the exact state
+  std::vector<SsRec> rec;
+  host_records(x, n, nb, noise, rec);
+  double s = 0.0;
   stats[0] = stats[1] = stats[2] = 0;
   for (int64_t b = 0; b < nb; ++b) {
     if (ss_apply_record(&s, &rec[b])) { stats[0]++; stats[2] += rec[b].nsplit; continue; }
@@ -39,20 +49,9 @@ extern "C" double ss_host_blocks(const double* x, int64_t n, double noise, int64
 extern "C" double ss_host_walk(const double* x, int64_t n, double noise, int64_t* stats) {
   const int64_t nchunks = (n + (int64_t)SS_BLOCK * 64 - 1) / ((int64_t)SS_BLOCK * 64);
   const int64_t nb = nchunks * 64;
-  std::vector<double> bsum(nb, 0.0), apx(nb + 1, 0.0);
-  for (int64_t b = 0; b < nb; ++b) {
-    double t = 0.0;
-    for (int64_t i = b * SS_BLOCK; i < n && i < (b + 1) * SS_BLOCK; ++i) t += x[i];
-    bsum[b] = t;
-    apx[b + 1] = apx[b] + t;
-  }
-  std::vector<SsRec> rec(nb);
+  std::vector<SsRec> rec;
+  host_records(x, n, nb, noise, rec);
   std::vector<uint64_t> excl(nb, 0);
-  for (int64_t b = 0; b < nb; ++b) {
-    const int64_t left = n - b * SS_BLOCK;
-    const int len = left <= 0 ? 0 : (left < SS_BLOCK ? (int)left : SS_BLOCK);
-    ss_block_record(x + (len ? b * SS_BLOCK : 0), 1, len, apx[b] * (1.0 + noise * ((b * 2654435761u) % 1000 / 500.0 - 1.0)), &rec[b]);
-  }
   for (int64_t c = 0; c < nchunks; ++c) {
     uint64_t e = 0;
     for (int l = 0; l < 64; ++l) {
