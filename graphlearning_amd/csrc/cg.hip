@@ -513,7 +513,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     CG_NEED(b.ss_bsum, glx_seqsum_sum_doubles(ncols, ssw.nchunks, 0) * 8);
     CG_NEED(b.ss_csum, glx_seqsum_sum_doubles(ncols, ssw.nchunks, 1) * 8);
     CG_NEED(b.ss_rec, glx_seqsum_rec_bytes(ncols, ssw.nchunks));
-    CG_NEED(b.ss_mask, (size_t)ncols * ssw.nchunks * 8);
+    CG_NEED(b.ss_mask, (size_t)ncols * ssw.nchunks * 16);      // a byte per group of 4 blocks
     CG_NEED(b.ss_stats, 64);
     ssw.rec = b.ss_rec;
     ssw.bsum = b.ss_bsum;

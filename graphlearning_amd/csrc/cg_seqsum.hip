@@ -4,7 +4,7 @@
 // exponent and accepted only when the exact state confirms the guess).  Three launches per reduction:
 //   ss_sum_kernel    plain sums of runs of 16 rows and of groups of 16 blocks (a block = 256 rows)     (the approximate prefix)
 //   ss_quant_kernel  per run of 16 rows: the guess from that prefix and the integer record; the 16 records of a block merged in a
-//                    tree inside one wavefront; the group-local prefix of the block totals
+//                    tree inside one wavefront
 //   ss_walk_kernel   per column one wavefront walks the chunks with the exact state (three more fetch records ahead into LDS): 64
 //                    blocks are checked at once, the first one that is not a plain same-binade block is taken through its record
 //                    (splits = single fp64 additions) or, if the record does not fit the exact state, row by row; then
@@ -22,12 +22,11 @@ struct SsSoA {                  // [field][column][chunk][64 blocks]
   int32_t* nsplit;
   int64_t *R[SS_MAXSPLIT + 1], *lo[SS_MAXSPLIT + 1], *hi[SS_MAXSPLIT + 1];
   double* xs[SS_MAXSPLIT];
-  unsigned long long* excl;     // sum of R[0] over the plain blocks in front of this one in its chunk (wrapping arithmetic)
 };
 
 size_t glx_seqsum_rec_bytes(int ncols, int nchunks) {
   const size_t N = (size_t)ncols * nchunks * 64;
-  return N * (4 * (SS_MAXSPLIT + 2) + 8 * (3 * (SS_MAXSPLIT + 1) + SS_MAXSPLIT + 1));
+  return N * (4 * (SS_MAXSPLIT + 2) + 8 * (3 * (SS_MAXSPLIT + 1) + SS_MAXSPLIT));
 }
 
 static SsSoA ss_carve(char* base, int ncols, int nchunks) {
@@ -38,7 +37,6 @@ static SsSoA ss_carve(char* base, int ncols, int nchunks) {
   for (int j = 0; j <= SS_MAXSPLIT; ++j) { s.lo[j] = (int64_t*)p; p += N * 8; }
   for (int j = 0; j <= SS_MAXSPLIT; ++j) { s.hi[j] = (int64_t*)p; p += N * 8; }
   for (int j = 0; j < SS_MAXSPLIT; ++j) { s.xs[j] = (double*)p; p += N * 8; }
-  s.excl = (unsigned long long*)p; p += N * 8;
   for (int j = 0; j <= SS_MAXSPLIT; ++j) { s.E[j] = (int32_t*)p; p += N * 4; }
   s.nsplit = (int32_t*)p;
   return s;
@@ -54,9 +52,11 @@ __device__ __forceinline__ bool ss_block_live(const CgScalars& sc, int it, doubl
   return any;
 }
 
-// Geometry of the two passes in front of the walk: a workgroup of 1024 threads = a GROUP of 16 blocks (a quarter of a walk chunk)
-// of one column block; wavefront w = block 16 g + w; lane = (run of SS_SUB rows `subw` of that block, column cc) = subw * 4 + cc.
+// Geometry of the two passes in front of the walk: a workgroup of 256 threads = a GROUP of 4 blocks of one column block, one
+// wavefront per SIMD (the passes are instruction-bound: four wavefronts on one SIMD take turns); wavefront w = block 4 g + w;
+// lane = (run of SS_SUB rows `subw` of that block, column cc) = subw * 4 + cc.  16 groups make a chunk of the walk.
 static_assert(SS_SUB == 16 && SS_Q == 16, "the kernels below lay one block out over one wavefront: 16 runs of 16 rows x 4 columns");
+#define SS_GB 4                  // blocks (wavefronts) per group
 
 __device__ __forceinline__ double ss_col_sum(double v) {        // sum over the 16 runs of a wavefront, per column (lanes 4 apart)
   v += __shfl_xor(v, 4);
@@ -67,28 +67,28 @@ __device__ __forceinline__ double ss_col_sum(double v) {        // sum over the 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(1024) void ss_sum_kernel(const double* __restrict__ prod, int64_t n, int ngroups, CgScalars sc, int it,
-                                                      double tol, double* __restrict__ ssum, double* __restrict__ gsum) {
+__global__ __launch_bounds__(64 * SS_GB) void ss_sum_kernel(const double* __restrict__ prod, int64_t n, int ngroups, CgScalars sc, int it,
+                                                            double tol, double* __restrict__ ssum, double* __restrict__ gsum) {
   const int cb = blockIdx.y, g = blockIdx.x;
   if (!ss_block_live<MODE>(sc, it, tol, cb)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, subw = lane >> 2, cc = lane & 3;
   const double* __restrict__ src = prod + (size_t)cb * n * 4 + cc;
-  const int64_t r0 = (((int64_t)g * 16 + wave) * SS_Q + subw) * SS_SUB;
+  const int64_t r0 = (((int64_t)g * SS_GB + wave) * SS_Q + subw) * SS_SUB;
   double xv[SS_SUB];                       // every load issued before the first is used
 #pragma unroll
   for (int i = 0; i < SS_SUB; ++i) xv[i] = r0 + i < n ? src[(r0 + i) * 4] : 0.0;
   double t = 0.0;
 #pragma unroll
   for (int i = 0; i < SS_SUB; ++i) t += xv[i];
-  ssum[(((size_t)cb * ngroups + g) * 256 + wave * 16 + subw) * 4 + cc] = t;
+  ssum[(((size_t)cb * ngroups + g) * (SS_GB * 16) + wave * 16 + subw) * 4 + cc] = t;
   const double w = ss_col_sum(t);
-  __shared__ double sh[16 * 4];
+  __shared__ double sh[SS_GB * 4];
   if (lane < 4) sh[wave * 4 + lane] = w;
   __syncthreads();
   if (threadIdx.x < 4) {
     double c = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) c += sh[q * 4 + threadIdx.x];
+    for (int q = 0; q < SS_GB; ++q) c += sh[q * 4 + threadIdx.x];
     gsum[((size_t)cb * ngroups + g) * 4 + threadIdx.x] = c;
   }
 }
@@ -108,18 +108,18 @@ __device__ __forceinline__ SsRec ss_shfl_down_rec(const SsRec& r, int delta) {
   return o;
 }
 
+// badmask: one byte per group (bit w: block 4 g + w goes row by row); the walk packs the 16 bytes of a chunk into its 64-bit word
 template <int MODE>
-__global__ __launch_bounds__(1024) void ss_quant_kernel(const double* __restrict__ prod, int64_t n, int nchunks, CgScalars sc, int it,
-                                                        double tol, const double* __restrict__ ssum, const double* __restrict__ gsum,
-                                                        SsSoA soa, unsigned long long* __restrict__ badmask) {
+__global__ __launch_bounds__(64 * SS_GB) void ss_quant_kernel(const double* __restrict__ prod, int64_t n, int nchunks, CgScalars sc, int it,
+                                                              double tol, const double* __restrict__ ssum, const double* __restrict__ gsum,
+                                                              SsSoA soa, unsigned char* __restrict__ badmask) {
 #pragma clang fp contract(off)
-  const int cb = blockIdx.y, g = blockIdx.x, ngroups = nchunks * 4;
+  const int cb = blockIdx.y, g = blockIdx.x, ngroups = nchunks * (64 / SS_GB);
   if (!ss_block_live<MODE>(sc, it, tol, cb)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, subw = lane >> 2, cc = lane & 3;
-  __shared__ double sh[16 * 4], sh2[16 * 4];
-  __shared__ unsigned long long shc[16 * 4];
+  __shared__ double sh[SS_GB * 4], sh2[SS_GB * 4];
   __shared__ unsigned shm[4];
-  const int64_t r0 = (((int64_t)g * 16 + wave) * SS_Q + subw) * SS_SUB;
+  const int64_t r0 = (((int64_t)g * SS_GB + wave) * SS_Q + subw) * SS_SUB;
   double xv[SS_SUB];                       // this thread's rows: every load issued here, consumed from registers below
   {
     const double* __restrict__ src = prod + (size_t)cb * n * 4 + cc;
@@ -128,10 +128,10 @@ __global__ __launch_bounds__(1024) void ss_quant_kernel(const double* __restrict
   }
   // the approximate state in front of this group (sums of the groups before it) ...
   double part = 0.0;
-  for (int g2 = wave * 16 + subw; g2 < g; g2 += 256) part += gsum[((size_t)cb * ngroups + g2) * 4 + cc];
+  for (int g2 = wave * 16 + subw; g2 < g; g2 += SS_GB * 16) part += gsum[((size_t)cb * ngroups + g2) * 4 + cc];
   part = ss_col_sum(part);
   // ... and in front of this thread's rows inside it (inclusive scan over the 16 runs of the wavefront, wavefront totals in LDS)
-  const double mine = ssum[(((size_t)cb * ngroups + g) * 256 + wave * 16 + subw) * 4 + cc];
+  const double mine = ssum[(((size_t)cb * ngroups + g) * (SS_GB * 16) + wave * 16 + subw) * 4 + cc];
   double incl = mine;
 #pragma unroll
   for (int d = 1; d < 16; d *= 2) {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(1024) void ss_quant_kernel(const double* __restrict
   __syncthreads();
   double pre = incl - mine;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) pre += sh[q * 4 + cc] + (q < wave ? sh2[q * 4 + cc] : 0.0);
+  for (int q = 0; q < SS_GB; ++q) pre += sh[q * 4 + cc] + (q < wave ? sh2[q * 4 + cc] : 0.0);
   const int64_t left = n - r0;
   const int len = left <= 0 ? 0 : (left < SS_SUB ? (int)left : SS_SUB);
   SsRec rec;
@@ -156,18 +156,11 @@ __global__ __launch_bounds__(1024) void ss_quant_kernel(const double* __restrict
     if ((subw & (2 * d - 1)) == 0) ss_merge_record(&rec, &other);
   }
   // lanes 0..3 hold the block's record for the four columns
-  const bool plain = rec.nsplit == 0 && rec.E[0] >= 0;
-  if (lane < 4) {
-    shc[wave * 4 + lane] = plain ? (unsigned long long)rec.R[0] : 0ull;
-    if (rec.E[0] == SS_E_BAD) atomicOr(&shm[lane], 1u << wave);
-  }
+  if (lane < 4 && rec.E[0] == SS_E_BAD) atomicOr(&shm[lane], 1u << wave);
   __syncthreads();
   if (lane < 4) {
-    unsigned long long ex = 0ull;                      // group-local: the walk adds the totals of the groups in front (same chunk)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) ex += q < wave ? shc[q * 4 + lane] : 0ull;
     const int col = cb * 4 + lane;
-    const size_t o = ((size_t)col * nchunks + (g >> 2)) * 64 + (g & 3) * 16 + wave;
+    const size_t o = ((size_t)col * nchunks + g / (64 / SS_GB)) * 64 + (g % (64 / SS_GB)) * SS_GB + wave;
 #pragma unroll
     for (int j = 0; j <= SS_MAXSPLIT; ++j) {
       soa.E[j][o] = rec.E[j];
@@ -178,9 +171,7 @@ __global__ __launch_bounds__(1024) void ss_quant_kernel(const double* __restrict
 #pragma unroll
     for (int j = 0; j < SS_MAXSPLIT; ++j) soa.xs[j][o] = rec.xs[j];
     soa.nsplit[o] = rec.nsplit;
-    soa.excl[o] = ex;
-    // 16 flags per group: four groups make the chunk's 64-bit word
-    if (wave == 0) ((unsigned short*)badmask)[((size_t)col * nchunks + (g >> 2)) * 4 + (g & 3)] = (unsigned short)shm[lane];
+    if (wave == 0) badmask[(size_t)col * ngroups + g] = (unsigned char)shm[lane];
   }
 }
 
@@ -188,7 +179,7 @@ struct SsLane {                 // one block's record, one lane
   int32_t E[SS_MAXSPLIT + 1], nsplit;
   int64_t R[SS_MAXSPLIT + 1], lo[SS_MAXSPLIT + 1], hi[SS_MAXSPLIT + 1];
   double xs[SS_MAXSPLIT];
-  unsigned long long excl;
+  unsigned long long excl;      // sum of R[0] over the plain blocks in front of this one in its chunk (wrapping arithmetic): the walk's own scan
 };
 
 __device__ __forceinline__ SsLane ss_load_lane(const SsSoA& soa, size_t o) {
@@ -203,7 +194,7 @@ __device__ __forceinline__ SsLane ss_load_lane(const SsSoA& soa, size_t o) {
 #pragma unroll
   for (int j = 0; j < SS_MAXSPLIT; ++j) L.xs[j] = soa.xs[j][o];
   L.nsplit = soa.nsplit[o];
-  L.excl = soa.excl[o];
+  L.excl = 0ull;
   return L;
 }
 
@@ -262,7 +253,7 @@ __device__ __forceinline__ bool ss_apply_lane(double* s, const SsLane& cur, int 
 }
 
 // LDS of the walk: two halves of four chunk slots of records ([field][64 lanes]) and the column's row-by-row flags
-#define SS_RING64 (3 * (SS_MAXSPLIT + 1) + SS_MAXSPLIT + 1)       // R, lo, hi per segment, xs per split, excl
+#define SS_RING64 (3 * (SS_MAXSPLIT + 1) + SS_MAXSPLIT)           // R, lo, hi per segment, xs per split
 #define SS_RING32 (SS_MAXSPLIT + 2)                                // E per segment, nsplit
 static size_t ss_walk_lds_bytes(int nchunks) {
   return (size_t)2 * 4 * 64 * (SS_RING64 * 8 + SS_RING32 * 4) + (size_t)nchunks * 8;
@@ -279,7 +270,6 @@ __device__ __forceinline__ void ss_ring_store(unsigned long long* r64, int* r32,
   }
 #pragma unroll
   for (int j = 0; j < SS_MAXSPLIT; ++j) r64[(k++) * 64 + lane] = (unsigned long long)__double_as_longlong(L.xs[j]);
-  r64[k * 64 + lane] = L.excl;
   r32[(SS_MAXSPLIT + 1) * 64 + lane] = L.nsplit;
 }
 __device__ __forceinline__ SsLane ss_ring_fetch(const unsigned long long* r64, const int* r32, int lane) {
@@ -294,7 +284,7 @@ __device__ __forceinline__ SsLane ss_ring_fetch(const unsigned long long* r64, c
   }
 #pragma unroll
   for (int j = 0; j < SS_MAXSPLIT; ++j) L.xs[j] = __longlong_as_double((long long)r64[(k++) * 64 + lane]);
-  L.excl = r64[k * 64 + lane];
+  L.excl = 0ull;
   L.nsplit = r32[(SS_MAXSPLIT + 1) * 64 + lane];
   return L;
 }
@@ -328,7 +318,13 @@ __global__ __launch_bounds__(256) void ss_walk_kernel(const double* __restrict__
     return x;
   };
   const size_t obase = (size_t)col * nchunks * 64;
-  for (int c = threadIdx.x; c < nchunks; c += 256) shmask[c] = badmask[(size_t)col * nchunks + c];
+  for (int c = threadIdx.x; c < nchunks; c += 256) {       // a byte per group of 4 blocks -> the chunk's 64 flags
+    const unsigned char* bm = (const unsigned char*)badmask + ((size_t)col * nchunks + c) * 16;
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) m |= (unsigned long long)(bm[q] & 0xfu) << (4 * q);
+    shmask[c] = m;
+  }
   if (wave < nchunks) ss_ring_store(r64_of(0, wave), r32_of(0, wave), lane, ss_load_lane(soa, obase + (size_t)wave * 64 + lane));
   __syncthreads();
   // rows of the blocks of a chunk flagged "row by row", in flagged order, for the first SS_PF of them
@@ -371,15 +367,18 @@ __global__ __launch_bounds__(256) void ss_walk_kernel(const double* __restrict__
         prefetch(chunk + 1, pf_nxt);
         const unsigned long long bad = (unsigned long long)ss_uni((long long)shmask[chunk]);
         const bool plain = cur.nsplit == 0 && cur.E[0] >= 0;
-        // the quantising pass left prefixes local to its groups of 16 blocks: add the totals of the groups in front
+        // the chunk-local exclusive prefix of the plain blocks' totals (wrapping arithmetic)
         unsigned long long total;
         {
-          const unsigned long long incl = cur.excl + (plain ? (unsigned long long)cur.R[0] : 0ull);
-          const unsigned long long t0 = (unsigned long long)ss_rl64((long long)incl, 15), t1 = (unsigned long long)ss_rl64((long long)incl, 31),
-                                   t2 = (unsigned long long)ss_rl64((long long)incl, 47), t3 = (unsigned long long)ss_rl64((long long)incl, 63);
-          const int gq = lane >> 4;
-          cur.excl += gq == 0 ? 0ull : gq == 1 ? t0 : gq == 2 ? t0 + t1 : t0 + t1 + t2;
-          total = t0 + t1 + t2 + t3;
+          const unsigned long long contrib = plain ? (unsigned long long)cur.R[0] : 0ull;
+          unsigned long long v = contrib;
+#pragma unroll
+          for (int d = 1; d < 64; d *= 2) {
+            const unsigned long long t = (unsigned long long)__shfl_up((long long)v, d);
+            if (lane >= d) v += t;
+          }
+          cur.excl = v - contrib;
+          total = (unsigned long long)ss_rl64((long long)v, 63);
         }
         const bool any = cur.E[0] == SS_E_ANY;
         int start = 0;
@@ -449,11 +448,12 @@ template <int MODE>
 static int ss_launch(const double* prod, int64_t n, int ncols_all, int C, const CgScalars& sc, int it, double tol, const SsWork& w,
                      hipStream_t st) {
   const SsSoA soa = ss_carve(w.rec, ncols_all, w.nchunks);
-  const dim3 grid((unsigned)w.nchunks * 4, (unsigned)(ncols_all / 4));       // groups of 16 blocks x column blocks
-  hipLaunchKernelGGL(ss_sum_kernel<MODE>, grid, dim3(1024), 0, st, prod, n, w.nchunks * 4, sc, it, tol, w.bsum, w.csum);
+  const int ngroups = w.nchunks * (64 / SS_GB);
+  const dim3 grid((unsigned)ngroups, (unsigned)(ncols_all / 4));             // groups of 4 blocks x column blocks
+  hipLaunchKernelGGL(ss_sum_kernel<MODE>, grid, dim3(64 * SS_GB), 0, st, prod, n, ngroups, sc, it, tol, w.bsum, w.csum);
   GLX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(ss_quant_kernel<MODE>, grid, dim3(1024), 0, st, prod, n, w.nchunks, sc, it, tol, (const double*)w.bsum,
-                     (const double*)w.csum, soa, w.mask);
+  hipLaunchKernelGGL(ss_quant_kernel<MODE>, grid, dim3(64 * SS_GB), 0, st, prod, n, w.nchunks, sc, it, tol, (const double*)w.bsum,
+                     (const double*)w.csum, soa, (unsigned char*)w.mask);
   GLX_HIP(hipGetLastError());
   const size_t lds = ss_walk_lds_bytes(w.nchunks);
   GLX_HIP(hipFuncSetAttribute((const void*)ss_walk_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -472,6 +472,6 @@ int glx_seqsum_run(int mode, const double* prod, int64_t n, int ncols_all, int C
 
 int glx_seqsum_max_chunks() { return SS_MAX_CHUNKS; }
 size_t glx_seqsum_sum_doubles(int ncols, int nchunks, int which) {      // which 0: sums of the runs of 16 rows, 1: of the groups
-  return which == 0 ? (size_t)(ncols / 4) * nchunks * 4 * 256 * 4 : (size_t)(ncols / 4) * nchunks * 4 * 4;
+  return which == 0 ? (size_t)(ncols / 4) * nchunks * 64 * SS_Q * 4 : (size_t)(ncols / 4) * nchunks * (64 / SS_GB) * 4;
 }
 int glx_seqsum_chunks(int64_t n) { return (int)((n + (int64_t)SS_BLOCK * 64 - 1) / ((int64_t)SS_BLOCK * 64)); }
