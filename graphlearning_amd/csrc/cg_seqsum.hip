@@ -14,7 +14,7 @@
 #include "cg_internal.h"
 #include "seqsum_exact.h"
 
-#define SS_MAX_CHUNKS 2048       // flags of one column in LDS (16 KB): n <= 2048 * 64 * SS_BLOCK rows (cg.hip falls back to the chain above)
+#define SS_MAX_CHUNKS 1024       // flags of one column in LDS (8 KB): n <= 1024 * 64 * SS_BLOCK = 16.7 M rows (cg.hip falls back to the chain above)
 static const int SS_PF = 3;     // blocks the walk may have to add row by row whose rows are fetched one chunk ahead
 
 struct SsSoA {                  // [field][column][chunk][64 blocks]
@@ -456,7 +456,8 @@ static int ss_launch(const double* prod, int64_t n, int ncols_all, int C, const 
                      (const double*)w.csum, soa, (unsigned char*)w.mask);
   GLX_HIP(hipGetLastError());
   const size_t lds = ss_walk_lds_bytes(w.nchunks);
-  GLX_HIP(hipFuncSetAttribute((const void*)ss_walk_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // (the same bound whatever the solve: concurrent solves on other operators set it too, and none may lower it under a launch in flight)
+  GLX_HIP(hipFuncSetAttribute((const void*)ss_walk_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_walk_lds_bytes(SS_MAX_CHUNKS)));
   hipLaunchKernelGGL(ss_walk_kernel<MODE>, dim3((unsigned)ncols_all), dim3(256), lds, st, prod, n, w.nchunks, ncols_all, C, sc, it, tol, soa,
                      (const unsigned long long*)w.mask, w.stats ? w.stats + 4 * MODE : nullptr);
   GLX_HIP(hipGetLastError());
