@@ -508,6 +508,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   memset(&ssw, 0, sizeof(ssw));
   ssw.nchunks = glx_seqsum_chunks(n);
   const bool ss_blocks = !np1d && !(flags & GLX_CG_CHAIN) && ssw.nchunks <= glx_seqsum_max_chunks() && n >= 1 &&
+                         glx_seqsum_rec_bytes(ncols, ssw.nchunks) <= ((size_t)1 << 30) &&      // (hundreds of columns x millions of rows: the chain)
                          ((flags & GLX_CG_BLOCKS) || n >= 8192);
   if (ss_blocks) {
     CG_NEED(b.ss_bsum, glx_seqsum_sum_doubles(ncols, ssw.nchunks, 0) * 8);

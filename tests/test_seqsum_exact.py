@@ -104,3 +104,22 @@ def test_squares_are_almost_all_plain_blocks(lib, request):
     rng = np.random.default_rng(2)
     plain, by_record, by_rows = _check(lib, rng.normal(size=70000) ** 2)[1]
     assert by_rows <= 6 and by_record <= 30, (plain, by_record, by_rows)
+
+
+def test_property_any_finite_or_not_doubles(lib):
+    """hypothesis: arbitrary doubles (all exponents, signed zeros, subnormals, inf, nan), arbitrary lengths -- the chain's bits"""
+    hyp = pytest.importorskip('hypothesis')
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    import hypothesis.extra.numpy as hnp
+
+    elems = st.one_of(st.floats(allow_nan=True, allow_infinity=True, width=64),
+                      st.floats(min_value=-1e3, max_value=1e3, width=64),
+                      st.sampled_from([0.0, -0.0, 0.5, 1.0, 2.0 ** -52, 2.0 ** -53, 1.0 + 2.0 ** -52, 2.0 ** 52, 2.0 ** 53, -2.0 ** 53]))
+
+    @settings(max_examples=300, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(hnp.arrays(np.float64, st.integers(0, 700), elements=elems), st.sampled_from([0.0, 1e-12, 0.3]))
+    def run(x, noise):
+        with np.errstate(all='ignore'):
+            _check(lib, x, noise)
+
+    run()
