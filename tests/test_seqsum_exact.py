@@ -34,7 +34,8 @@ def _check(L, x, noise=0.0):
     p = x.ctypes.data_as(ctypes.c_void_p)
     n = ctypes.c_int64(x.size)
     want = L.ss_host_chain(p, n)
-    assert _bits(want) == _bits(np.cumsum(x)[-1] if x.size else 0.0) or np.isnan(want)     # np.cumsum is the same chain
+    # np.cumsum is the same chain; it starts from +0 here as in the device reducers (a column of nothing but -0 sums to +0: cg.hip)
+    assert _bits(want) == _bits(np.cumsum(np.concatenate([[0.0], x]))[-1]) or np.isnan(want)
     out = []
     for f in (L.ss_host_blocks, L.ss_host_walk):
         st = (ctypes.c_int64 * 3)()
@@ -116,7 +117,7 @@ def test_property_any_finite_or_not_doubles(lib):
                       st.floats(min_value=-1e3, max_value=1e3, width=64),
                       st.sampled_from([0.0, -0.0, 0.5, 1.0, 2.0 ** -52, 2.0 ** -53, 1.0 + 2.0 ** -52, 2.0 ** 52, 2.0 ** 53, -2.0 ** 53]))
 
-    @settings(max_examples=300, deadline=None, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=300, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
     @given(hnp.arrays(np.float64, st.integers(0, 700), elements=elems), st.sampled_from([0.0, 1e-12, 0.3]))
     def run(x, noise):
         with np.errstate(all='ignore'):
