@@ -124,3 +124,50 @@ def test_property_any_finite_or_not_doubles(lib):
             _check(lib, x, noise)
 
     run()
+
+
+def test_block_form_equals_numpys_own_axis0_sum_on_the_reference_cg(lib, golden):
+    """the chain being replaced IS numpy's: `np.sum(p * Ap, axis=0)` and `np.sum(r ** 2, axis=0)` of utils.conjgrad
+    (graphlearning/utils.py:524,527), evaluated by numpy on the products of the Poisson CG solve of the n = 5000 golden graph
+    (reference inputs: tests/golden/g3_blobs5000.npz) -- every column of every iteration through the block form, bit for bit"""
+    from conftest import csr_from
+    from oracle import gl_oracle as orc
+    g = golden('g3_blobs5000.npz')
+    W = csr_from(g, 'W')
+    n = W.shape[0]
+    ti = g['train_ind']
+    src, _ = orc.poisson_source(n, ti, g['labels'][ti])
+    L = orc.laplacian(W, 'normalized')
+    D = orc.degree_matrix(W, p=-0.5)
+    b = D * src
+    x = np.zeros_like(b)
+    r = b.copy()
+    p = r.copy()
+    rsold = np.sum(r ** 2, axis=0)
+    err, it, checked = 1.0, 0, 0
+
+    def through_blocks(prod, want):
+        nonlocal checked
+        for c in range(prod.shape[1]):
+            col = np.ascontiguousarray(prod[:, c])
+            for f in (lib.ss_host_blocks, lib.ss_host_walk):
+                st = (ctypes.c_int64 * 3)()
+                got = f(col.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(n), ctypes.c_double(0.0), st)
+                assert _bits(got) == _bits(want[c]), (it, c, got, want[c])
+            checked += 1
+
+    while err > 1e-3 and it < 400:                      # utils.conjgrad, utils.py:521-530
+        it += 1
+        Ap = L @ p
+        pAp = np.sum(p * Ap, axis=0)
+        through_blocks(p * Ap, pAp)
+        alpha = rsold / pAp
+        x += alpha * p
+        r -= alpha * Ap
+        rsnew = np.sum(r ** 2, axis=0)
+        through_blocks(r ** 2, rsnew)
+        err = np.sqrt(np.sum(rsnew))
+        p = r + (rsnew / rsold) * p
+        rsold = rsnew
+    assert it == int(g['poisson_cg_iters'])             # the loop above is the reference's solve
+    assert checked == 2 * it * b.shape[1]
