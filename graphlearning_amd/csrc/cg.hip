@@ -739,10 +739,13 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     if (ss_blocks && !blocks_forced) {
       for (int m = 0; m < 2; ++m) {
         if (!blocks_now[m]) continue;
-        const double rounds = (double)(b.h_ss[4 * m + 1] - ss_seen[m][1]) + (double)(b.h_ss[4 * m + 2] - ss_seen[m][2]);
+        const double by_rec = (double)(b.h_ss[4 * m + 1] - ss_seen[m][1]), by_rows = (double)(b.h_ss[4 * m + 2] - ss_seen[m][2]);
         for (int q = 0; q < 3; ++q) ss_seen[m][q] = b.h_ss[4 * m + q];
         const double chains = (double)cnt * ncols;
-        const double blocks_us = rounds / chains * 1.2 + ssw.nchunks * 0.6 + 12.0;      // about a microsecond per block that is not plain, 12 for the passes in front
+        // measured on one MI355X (profiles/r05_cg_forms.txt, r05_cg_blocks_kernel_stats.csv): 0.7 us per block taken through its record,
+        // 3.5 per 256-row block taken row by row (1.7 of additions, the rest its rows arriving: three are fetched ahead per chunk),
+        // 0.6 per chunk of the walk, 14.5 for the two passes in front; the chain 2.4 ns per row
+        const double blocks_us = (by_rec * 0.7 + by_rows * 3.5) / chains + ssw.nchunks * 0.6 + 14.5;
         const double chain_us = (double)n * 0.0024;
         if (blocks_us > chain_us) blocks_now[m] = false;
       }
