@@ -2,7 +2,7 @@
 // `np.sum(r ** 2, axis=0)`), bit for bit, without walking the n dependent additions one by one: seqsum_exact.h has the
 // arithmetic (a running sum inside one binade advances by integer steps; blocks of rows are summed as integers from a guessed
 // exponent and accepted only when the exact state confirms the guess).  Three launches per reduction:
-//   ss_sum_kernel    plain sums of runs of 16 rows and of groups of 16 blocks (a block = 256 rows)     (the approximate prefix)
+//   ss_sum_kernel    plain sums of runs of 16 rows and of groups of 4 blocks (a block = 256 rows)      (the approximate prefix)
 //   ss_quant_kernel  per run of 16 rows: the guess from that prefix and the integer record; the 16 records of a block merged in a
 //                    tree inside one wavefront
 //   ss_walk_kernel   per column one wavefront walks the chunks with the exact state (three more fetch records ahead into LDS): 64
