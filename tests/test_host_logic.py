@@ -326,3 +326,22 @@ def test_order_cells_policy(monkeypatch):
     assert _hip.auto_order_cells(1 << 17, 20) == 0 and _hip.auto_order_cells(70000, 200) == 0
     monkeypatch.setenv('GLX_KNN_ORDER', '0')
     assert _hip.auto_order_cells(70000, 20) == 0
+
+
+def test_exact_mode_form_switch_maps_to_the_cabi_flags(monkeypatch):
+    """_hip.CG_EXACT_FORM (tests / measurements: pytest --cg-form) -> the GLX_CG_BLOCKS / GLX_CG_CHAIN bits of include/glx.h; the
+    tolerance mode ignores it; anything else is refused"""
+    import re
+    from graphlearning_amd import _hip
+    hdr = open(os.path.join(ROOT, 'include', 'glx.h')).read()
+    flag = {m.group(1): int(m.group(2)) for m in re.finditer(r'#define (GLX_CG_[A-Z0-9]+) (\d+)', hdr)}
+    assert (flag['GLX_CG_NP1D'], flag['GLX_CG_TREE'], flag['GLX_CG_X0'], flag['GLX_CG_BLOCKS'], flag['GLX_CG_CHAIN']) == \
+        (_hip.GLX_CG_NP1D, _hip.GLX_CG_TREE, _hip.GLX_CG_X0, _hip.GLX_CG_BLOCKS, _hip.GLX_CG_CHAIN)
+    assert len(set(flag.values())) == len(flag) and all(v & (v - 1) == 0 for v in flag.values())      # distinct single bits
+    for form, want in ((None, 0), ('blocks', flag['GLX_CG_BLOCKS']), ('chain', flag['GLX_CG_CHAIN'])):
+        monkeypatch.setattr(_hip, 'CG_EXACT_FORM', form)
+        assert _hip._reduce_flag('exact') == want
+        assert _hip._reduce_flag('tree') == flag['GLX_CG_TREE']
+    monkeypatch.setattr(_hip, 'CG_EXACT_FORM', 'fast')
+    with pytest.raises(_hip.GlxError):
+        _hip._reduce_flag('exact')
