@@ -737,6 +737,88 @@ def _free_port():
     return port
 
 
+def supervise_rank(args, argv):
+    """What a rank launched by torch.distributed.run does for a multi-GPU line: it is a SUPERVISOR that never touches its GPU.  The
+    measurement itself runs in a child process per rank (`bench.py <same arguments> --child`, the ranks' children rendezvous on their own
+    port), so that a hang -- a collective that never completes leaves kernels on the device that no later call in the same process
+    survives -- costs one ATTEMPT, not the line: the supervisors watch their children in lockstep (one gloo all_reduce of the status
+    codes per second), and when any child fails or the attempt's time limit passes, every supervisor kills its child (the device is
+    clean again) and the next attempt starts: first the library's own RCCL communicator with captured exchanging sweeps, then the
+    torch.distributed engine (eager all_to_all_single).  Supervisor rank 0 relays its child's ONE JSON line to stdout, with the attempts
+    that came before it recorded under `attempts`."""
+    import signal
+    import subprocess
+    import datetime
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    if world != int(args.gpus):
+        from graphlearning_amd import dist_bench
+        dist_bench.check_world(args)            # exits with status 2 and the message
+    dist.init_process_group('gloo', timeout=datetime.timedelta(minutes=30))
+    engines = [args.engine] + (['torch'] if args.engine == 'glx' else [])
+    limit = float(os.environ.get('GLX_BENCH_ATTEMPT_S', '600'))
+    attempts = []
+    final_rc, final_line = 1, None
+    for k, engine in enumerate(engines):
+        port = [_free_port() if rank == 0 else None]
+        dist.broadcast_object_list(port, src=0)
+        env = dict(os.environ, MASTER_PORT=str(port[0]), GLX_BENCH_ATTEMPT=str(k), GLX_BENCH_SPAWNED='1' if args.spawned else '0')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # (under torch.distributed.run the ranks are CLIENTS of the launcher's store; the children rendezvous on their own port, where
+        # child rank 0 must host the store itself)
+        env['TORCHELASTIC_USE_AGENT_STORE'] = 'False'
+        cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != '--spawned'] + ['--child', '--engine', engine]
+        t0 = time.perf_counter()
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        verdict = None
+        while verdict is None:
+            time.sleep(1.0)
+            rc = child.poll()
+            code = 0 if rc is None else (1 if rc == 0 else 2)               # running | finished | failed
+            late = 1 if time.perf_counter() - t0 > limit else 0
+            st = torch.tensor([code, -code, late], dtype=torch.int64)
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            worst, best, late = int(st[0]), -int(st[1]), int(st[2])
+            if worst == 2:
+                verdict = 'a rank failed'
+            elif best == 1 and worst == 1:
+                verdict = 'ok'
+            elif late:
+                verdict = 'no line within %.0f s' % limit
+        if verdict != 'ok' and child.poll() is None:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        out = child.communicate()[0] or ''
+        lines = [ln for ln in out.splitlines() if ln.startswith('{') and ('"metric"' in ln or '"dry_run"' in ln)]
+        if rank == 0:
+            ok = verdict == 'ok' and bool(lines)
+            attempts.append({'engine': engine, 'outcome': verdict if (verdict != 'ok' or lines) else 'no JSON line', 'seconds': time.perf_counter() - t0})
+            if ok:
+                final_line = json.loads(lines[-1])
+                final_rc = 0
+            elif k + 1 < len(engines):
+                print('bench.py: attempt %d (engine %s): %s; the children are gone, trying engine %s' % (k, engine, attempts[-1]['outcome'], engines[k + 1]),
+                      file=sys.stderr)
+        done = [final_rc == 0 if rank == 0 else None]
+        dist.broadcast_object_list(done, src=0)
+        if done[0]:
+            final_rc = 0
+            break
+    if rank == 0:
+        if final_line is not None:
+            final_line['attempts'] = attempts
+            final_line['supervised'] = True
+            print(json.dumps(final_line), flush=True)
+        else:
+            print('bench.py: no attempt produced a line: %s' % attempts, file=sys.stderr)
+    dist.barrier()
+    dist.destroy_process_group()
+    return final_rc
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks here --
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same
@@ -773,9 +855,13 @@ def main():
     ap.add_argument('--config', type=int, default=2, choices=[2, 4],
                     help='2 (default): BASELINE configs[1], weak scaling over --gpus; 4: configs[3] (blobs d=64), strong scaling of --n vertices')
     ap.add_argument('--n', type=float, default=1e7, help='vertices of --config 4 (default 10^7; kNN alone is ~110 s on one GPU at that size)')
-    ap.add_argument('--partition', default='cut', choices=['cut', 'even', 'cells', 'auto'],
-                    help='multi-GPU runs: contiguous blocks cut between the pieces of the graph (default), equal blocks, or the cells of the '
-                         'search assigned to ranks by a balanced partition of their quotient graph')
+    ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'],
+                    help='multi-GPU config 2: strong (default; the stated metric): the ONE 70000-vertex graph over N GPUs; weak: N x 70000 vertices')
+    ap.add_argument('--partition', default=None, choices=['cut', 'even', 'cells', 'auto'],
+                    help='multi-GPU runs: equal blocks of the locality order (`even`: the default of the strong-scaling line -- every sweep carries '
+                         'the halo exchange), contiguous blocks cut between the pieces of the graph (`cut`: the default of --scaling weak and --config 4), '
+                         'or the cells of the search assigned to ranks by a balanced partition of their quotient graph')
+    ap.add_argument('--no-sides', action='store_true', help='multi-GPU config 2: skip the measurements beside the headline (other partition, `connected` workload)')
     ap.add_argument('--knn', default='cells', choices=['cells', 'allpairs'], help='--config 4: cell-pruned search (default) or every tile')
     ap.add_argument('--workload', default='blobs', choices=['blobs', 'connected'],
                     help='multi-GPU config 2: the headline features (10 separate clusters) or the same with centre scale 0.8 '
@@ -791,6 +877,9 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help='take the distributed path with one rank (tests)')
     ap.add_argument('--force-collectives', action='store_true', help='distributed path: issue the collectives even with one rank (tests)')
     ap.add_argument('--spawned', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--child', action='store_true', help=argparse.SUPPRESS)           # a rank's measuring process under its supervisor
+    ap.add_argument('--test-ops', default=None, help=argparse.SUPPRESS)               # tests: module.py:Class of a CPU stand-in for the rank-local sweep
+    ap.add_argument('--test-graph', default=None, help=argparse.SUPPRESS)             # tests: npz with the graph the stand-in sweeps
     ap.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--traffic-child-scale', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--dist-dry-run', action='store_true',
@@ -805,6 +894,8 @@ def main():
     launched = 'WORLD_SIZE' in os.environ            # torch.distributed.run (the driver's form for N > 1) or our own spawn
     if args.gpus > 1 and not launched:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
+    if launched and not args.child and os.environ.get('GLX_BENCH_SUPERVISE', '1') != '0':
+        sys.exit(supervise_rank(args, sys.argv[1:]))     # every launched rank supervises a measuring child (hangs cost an attempt, not the line)
     if (args.gpus > 1 or args.config == 4 or args.dist_dry_run or int(os.environ.get('WORLD_SIZE', '1')) > 1
             or args.force_dist):
         run_distributed(args)

@@ -477,19 +477,21 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
 
   std::vector<int64_t> iters(ngroups, 0);       // iterations that ran, per system (utils.py:522 `i`)
   std::vector<double> err(ngroups, 1.0);        // utils.py:519
-  std::vector<double> err_before(ngroups, 1.0); // the residual norm one iteration before the last one looked at, per system
   std::vector<char> done(ngroups, !(1.0 > tol));
   int running = 0;
   for (int g = 0; g < ngroups; ++g) running += !done[g];
   double e_prev = 1.0, e_last = 1.0;            // the two latest maxima over the running systems the host has seen
+  double margin_seen = INFINITY;                // min over every decision taken of |err - tol| / tol (glx_cg_last_stop_margin)
   auto read_history = [&](const double* h, int64_t it0, int64_t cnt) {
     for (int64_t q = 0; q < cnt && running > 0; ++q) {
       // iteration it0+q+1 ran for every system whose previous err was > tol; its err decides the next one
       for (int g = 0; g < ngroups; ++g) {
         if (done[g]) continue;
         iters[g] = it0 + q + 1;
-        err_before[g] = err[g];
         err[g] = h[(size_t)q * stride + g];
+        // EVERY residual norm a running system shows is a stop decision (CG's residual norms are not monotone: one that came within
+        // the band of tol on the far side iterations ago could have stopped the reference's order of additions there)
+        if (tol > 0 && err[g] == err[g]) margin_seen = std::min(margin_seen, fabs(err[g] - tol) / tol);
         if (!(err[g] > tol)) { done[g] = 1; --running; }
       }
       e_prev = e_last;
@@ -570,20 +572,12 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
   if (rc) return rc;
   GLX_HIP(hipMemcpyAsync(X, b.dense, (size_t)n * C * es, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
-  // How close the stop decisions of this solve came to going the other way (glx_cg_last_stop_margin): per system that stopped on
-  // the test, the relative distance from `tol` of the residual norm that passed the test and of the last one that failed it.  The
-  // reordered reductions of this mode move a residual norm by a relative 1e-13 .. 1e-8 (more after hundreds of iterations); a
-  // decision with a margin below that could have gone the other way with the reference's order of additions.
-  {
-    double margin = INFINITY;
-    for (int g = 0; g < ngroups; ++g) {
-      if (!done[g] || iters[g] == 0 || !(tol > 0)) continue;
-      const double passed = (tol - err[g]) / tol, failed = (err_before[g] - tol) / tol;
-      if (passed == passed) margin = std::min(margin, fabs(passed));
-      if (iters[g] >= 1 && failed == failed) margin = std::min(margin, fabs(failed));
-    }
-    b.last_stop_margin = margin;
-  }
+  // How close the stop decisions of this solve came to going the other way (glx_cg_last_stop_margin): the smallest relative distance
+  // from `tol` of ANY residual norm a running system showed -- the one that passed the test, the last one that failed it, and every
+  // earlier one (residual norms of CG are not monotone).  The reordered reductions of this mode move a residual norm by a relative
+  // 1e-13 .. 1e-8 (more after hundreds of iterations); a decision with a margin below that could have gone the other way with the
+  // reference's order of additions.
+  b.last_stop_margin = margin_seen;
   for (int g = 0; g < ngroups; ++g) {
     if (iters_out) iters_out[g] = (int)iters[g];
     if (err_out) err_out[g] = err[g];
@@ -591,8 +585,8 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
   return GLX_OK;
 }
 
-// The smallest relative distance from `tol` of the residual norms that decided the stops of the LAST tolerance-mode solve on this
-// operator (+inf: no such solve yet, or none of its systems stopped on the test).  What ssl._solve(reduce='auto') reads: a solve whose
+// The smallest relative distance from `tol` of the residual norms the LAST tolerance-mode solve on this operator compared with it --
+// every iteration of every system, not only the deciding ones (+inf: no such solve yet, or no iteration ran).  What ssl._solve(reduce='auto') reads: a solve whose
 // stop hung on less than AUTO_STOP_BAND is handed back to the reference-order reductions.
 extern "C" int glx_cg_last_stop_margin(glx_graph* A, double* margin_out) {
   GLX_CHECK(A && margin_out, GLX_EINVAL, "glx_cg_last_stop_margin: null argument");

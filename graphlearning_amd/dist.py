@@ -539,6 +539,9 @@ class HipOps:
                                    err=torch.zeros(64, dtype=torch.int64, device=self.device)))
         self.rec_bytes = self.lay['rec_bytes']
         self.plan = plan
+        # GatherPlan: the state is `world` blocks of `cap` records and the rank's rows are block `rank` of it -- a sweep WRITES there
+        # (bias, degrees, stop values stay indexed by local row); RankPlan: the own rows lead the state, offset 0
+        self.own_off = int(getattr(plan, 'own_off', 0))
 
     def _stream(self):
         return self._hip._vp(self.torch.cuda.current_stream(self.device).cuda_stream)
@@ -592,7 +595,7 @@ class HipOps:
         if want_err:
             part['err'].zero_()
         self._hip.check(self._hip.load().glx_sweep_step_dev(
-            part['graph']._h, self.C, 1, xin.data_ptr(), xout.data_ptr() + lo * self.rec_bytes,
+            part['graph']._h, self.C, 1, xin.data_ptr(), xout.data_ptr() + (self.own_off + lo) * self.rec_bytes,
             self.bias.data_ptr() + lo * self.rec_bytes, part['flags'].data_ptr(), self.deg.data_ptr() + lo * 8,
             self.vinf.data_ptr() + lo * 8, part['err'].data_ptr() if want_err else None, self._stream()), 'glx_sweep_step_dev')
         if want_err:   # fp64 bit patterns of non-negative values order like the values
@@ -1100,6 +1103,8 @@ class CgHipOps:
         import torch
         from . import _hip
         self.torch, self._hip, self.plan, self.C = torch, _hip, plan, C
+        if getattr(plan, 'gather', False):
+            raise ValueError('CgHipOps works on a RankPlan ([owned | halo] columns); the all-gather form (GatherPlan) is a form of the sweep only')
         self.dtype = np.dtype(dtype)
         self.tdtype = torch.float64 if self.dtype == np.float64 else torch.float32
         device = _hip.default_device() if device is None else int(device)

@@ -1,11 +1,12 @@
-"""bench.py --gpus N (N > 1): weak-scaling run of the vertex-partitioned Poisson sweep.
+"""bench.py --gpus N (N > 1): the vertex-partitioned Poisson sweep on N GPUs -- by default STRONG scaling of the
+70 000-vertex configs[1] graph (BASELINE.json's metric: "MNIST k=10 graph @1/2/4/8 GPU").
 
 Launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: one
-rank per GPU, torch.distributed backend "nccl" (= RCCL over xGMI).  The global graph has
-N * 70000 vertices (MNIST label vector tiled, same blob generator, k = 10): every rank builds
-it identically (exact kNN with the queries sharded over the ranks and all_gathered, deterministic assembly), owns one contiguous
-block of the RCM-ordered vertices (boundaries placed in the gaps between the graph's pieces, dist.cut_bounds)
-and exchanges boundary vertex records once per sweep -- or nothing at all when no block has a halo.
+rank per GPU, torch.distributed backend "nccl" (= RCCL over xGMI).  Every rank builds the graph
+identically (exact kNN with the queries sharded over the ranks and all_gathered, deterministic assembly), owns one contiguous
+block of the RCM-ordered vertices -- equal blocks (`even`, the headline: every block has a halo) or blocks placed in the gaps
+between the graph's pieces (`cut`, measured beside it) -- and exchanges boundary vertex records once per sweep.
+--scaling weak: N * 70000 vertices (MNIST label vector tiled, same blob generator), 70 000 per rank.
 """
 import os
 import sys
@@ -56,6 +57,13 @@ def main_dry_run(args):
     rank, world, local_rank = check_world(args)
     if 'MASTER_ADDR' not in os.environ:         # --gpus 1 without a launcher
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    # failure injection for the supervisor's tests (bench.supervise_rank): GLX_BENCH_TEST_FAIL = "<attempt>:<exit|hang>" makes the LAST
+    # rank of that attempt die or hang before the rendezvous
+    inject = os.environ.get('GLX_BENCH_TEST_FAIL', '')
+    if inject and rank == world - 1 and inject.split(':')[0] == os.environ.get('GLX_BENCH_ATTEMPT', '0'):
+        if inject.endswith('exit'):
+            sys.exit(7)
+        time.sleep(3600)
     dist.init_process_group('gloo', timeout=datetime.timedelta(minutes=2))
     seen = torch.ones(1, dtype=torch.int64)
     dist.all_reduce(seen)
@@ -63,8 +71,8 @@ def main_dry_run(args):
     dist.all_gather_object(ids, (rank, local_rank, os.getpid()))
     if rank == 0:
         emit(json.dumps({'dry_run': True, 'n_gpus': world, 'ranks_seen': int(seen.item()), 'gpus_asked': int(args.gpus),
-                         'ranks': [list(t) for t in ids],
-                         'spawned_by_bench': bool(getattr(args, 'spawned', False))}))
+                         'ranks': [list(t) for t in ids], 'engine': getattr(args, 'engine', None),
+                         'spawned_by_bench': bool(getattr(args, 'spawned', False) or os.environ.get('GLX_BENCH_SPAWNED') == '1')}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,37 +86,72 @@ def _free_port():
     return port
 
 
+def _load_test_ops(spec):
+    """--test-ops path/to/module.py:Class (hidden; tests/test_dist_gloo.py): the rank-local sweep stand-in of the CPU tests, so that the
+    launch path, the planner, the exchange and the line's schema run on a machine without a GPU.  Never a product path."""
+    import importlib.util
+    path, cls = spec.rsplit(':', 1)
+    sp = importlib.util.spec_from_file_location('glx_bench_test_ops', path)
+    mod = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(mod)
+    return getattr(mod, cls)
+
+
 def main(args):
+    """bench.py --gpus N: the STATED multi-GPU metric (BASELINE.json: "Poisson iters/sec ..., MNIST k=10 graph @1/2/4/8 GPU") --
+    STRONG scaling of the 70 000-vertex configs[1] graph: the same graph as the N = 1 line, vertex-partitioned into N equal blocks of a
+    locality order (`even`: every block cuts through clusters, so every sweep carries the halo exchange), value = sweeps per second of THAT
+    graph.  Beside it: the `cut` partition (blocks between the graph's pieces; may need no exchange at all) and the `connected` workload
+    (one component).  --scaling weak: every rank owns 70 000 vertices of an N x 70 000 graph (the line of rounds 1-5)."""
     emit = _claim_stdout()
+    test_ops = getattr(args, 'test_ops', None)
     import torch                       # first: libglx must bind to torch's HIP runtime (see dist.py)
     import torch.distributed as dist
-    rank, world, local_rank = check_world(args, torch.cuda.device_count())
+    rank, world, local_rank = check_world(args, None if test_ops else torch.cuda.device_count())
     if 'MASTER_ADDR' not in os.environ:         # python bench.py --gpus 1 --force-dist: a one-rank job without a launcher
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
-    torch.cuda.set_device(local_rank)
-    # a stuck collective ends the job after 5 minutes (watchdog abort) instead of holding the GPUs
     import datetime
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=datetime.timedelta(minutes=5))
     import bench
-    import graphlearning_amd as gl
-    from graphlearning_amd import _hip, dist as gdist
-    _hip.set_default_device(local_rank)        # every libglx call of this process uses this rank's GPU
-    dev = torch.device('cuda', local_rank)
-
-    n = bench.N_PER_RANK * world
-    labels = bench.load_labels(n)
-    connected = getattr(args, 'workload', 'blobs') == 'connected'
-    X = bench.make_features(labels, scale=0.8 if connected else 2.0)
-    t0 = time.perf_counter()
-    ind, dst = gdist.knnsearch_distributed(X, bench.K_NN + 1, dist, local_rank)   # queries sharded by rank
-    W = gl.weightmatrix.knn(None, bench.K_NN, knn_data=(ind, dst))
-    t_graph = time.perf_counter() - t0
-    train_ind = gl.trainsets.generate(labels, rate=1, seed=0)
-    prob = gdist.poisson_problem(W, train_ind, labels[train_ind])
-    P = prob['P']
-    order = gdist.locality_order(P)
+    from graphlearning_amd import dist as gdist
+    if test_ops:
+        dist.init_process_group('gloo', timeout=datetime.timedelta(minutes=5))
+        dev = torch.device('cpu')
+        sync = lambda: None
+        gl = _hip = None
+    else:
+        torch.cuda.set_device(local_rank)
+        # a stuck collective ends the job after 5 minutes (watchdog abort) instead of holding the GPUs
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=datetime.timedelta(minutes=5))
+        import graphlearning_amd as gl
+        from graphlearning_amd import _hip
+        _hip.set_default_device(local_rank)        # every libglx call of this process uses this rank's GPU
+        dev = torch.device('cuda', local_rank)
+        sync = torch.cuda.synchronize
+    strong = getattr(args, 'scaling', 'strong') == 'strong'
     min_iter, max_iter = 50, 1000
-    engine = getattr(args, 'engine', 'glx')     # 'glx': library-owned RCCL communicator + captured sweeps; 'torch': round-1 path
+
+    def build(workload):
+        """The graph of one workload, built identically on every rank (exact kNN with the queries sharded over the ranks and
+        all-gathered, deterministic device assembly), its Poisson problem and a locality order of the vertices."""
+        t0 = time.perf_counter()
+        if test_ops:                   # (CPU tests hand the graph in: building one needs the GPU)
+            g = np.load(args.test_graph)
+            from scipy import sparse
+            W = sparse.csr_matrix((g['data'], g['indices'], g['indptr']), shape=(len(g['indptr']) - 1,) * 2)
+            labels, train_ind = g['labels'], g['train_ind']
+        else:
+            n = bench.N_PER_RANK * (1 if strong else world)
+            labels = bench.load_labels(n)
+            X = bench.make_features(labels, scale=0.8 if workload == 'connected' else 2.0)
+            ind, dst = gdist.knnsearch_distributed(X, bench.K_NN + 1, dist, local_rank)   # queries sharded by rank
+            W = gl.weightmatrix.knn(None, bench.K_NN, knn_data=(ind, dst))
+            train_ind = gl.trainsets.generate(labels, rate=1, seed=0)
+        prob = gdist.poisson_problem(W, train_ind, labels[train_ind])
+        order = gdist.locality_order(prob['P'])
+        return dict(W=W, labels=labels, train_ind=train_ind, prob=prob, P=prob['P'], order=order, workload=workload,
+                    n=W.shape[0], nnz=int(prob['P'].nnz), graph_build_s=time.perf_counter() - t0)
+
+    engine = 'test' if test_ops else getattr(args, 'engine', 'glx')   # 'glx': library-owned RCCL communicator + captured sweeps; 'torch': torch.distributed collectives
     gdist.FORCE_COLLECTIVES = bool(getattr(args, 'force_collectives', False))
     comm = None
     if engine == 'glx':
@@ -130,63 +173,91 @@ def main(args):
             print('rank %d: glx communicator unavailable (%s); using the torch.distributed engine'
                   % (rank, box.get('err', 'no answer from ncclCommInitRank after 120 s')), file=sys.stderr)
             engine = 'torch'
-    flag = torch.tensor([1 if engine == 'glx' else 0], dtype=torch.int64, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 0:
-        engine = 'torch'
-        comm = None                                         # (a communicator some ranks did get is left alone)
+    if not test_ops:
+        flag = torch.tensor([1 if engine == 'glx' else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            engine = 'torch'
+            comm = None                                         # (a communicator some ranks did get is left alone)
+    N_BATCHES = 5
 
-    def measure(partition):
-        order_p, bounds, pinfo = gdist.plan_partition(P, order, world, partition, dist)      # (every rank plans for itself; the ranks compare digests)
+    def measure(G, partition, want_u=False):
+        P, prob = G['P'], G['prob']
+        order_p, bounds, pinfo = gdist.plan_partition(P, G['order'], world, partition, dist)      # (every rank plans for itself; the ranks compare digests)
         plan = gdist.RankPlan(P, order_p, bounds, rank)
         own = plan.own
+        parts = None
         if engine == 'glx':
             ds = gdist.glx_dist_sweep(comm, plan, prob['k'], force_exchange=gdist._force_collectives())
             ds.set_problem(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
             run = lambda: ds.run(min_iter, max_iter, 8, 0.0)[0]
             close = ds.close
             info = ds.info
+            fetch = ds.fetch
         else:
-            info = lambda: dict(exchange='eager' if (world > 1 and plan.global_halo > 0) else 'none', selftest='not run',
-                                overlap=True, fused=False, scatter=False)
-            ops = gdist.HipOps(plan, prob['k'], local_rank)
+            info = lambda: dict(exchange='eager' if ((world > 1 and plan.global_halo > 0) or gdist._force_collectives()) else 'none',
+                                selftest='not run', overlap=True, fused=False, scatter=False)
+            ops = _load_test_ops(test_ops)(plan, prob['k']) if test_ops else gdist.HipOps(plan, prob['k'], local_rank)
             sweep = gdist.DistSweep(plan, ops, dist)
             sweep.setup(prob['Db'][own], prob['w0'][own], prob['deg'][own], prob['vinf'][own])
             run = lambda: sweep.run(min_iter, max_iter)
+            fetch = sweep.result_own
 
             def close():
-                torch.cuda.synchronize()
+                sync()
                 sweep.close()
-                ops.close()
+                if hasattr(ops, 'close'):
+                    ops.close()
         T = 0
         for _ in range(args.warmup):
             T = run()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            T = run()
-        torch.cuda.synchronize()
-        dist.barrier()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        halo = torch.tensor([plan.n_halo, plan.n_own, int(plan.P_local.nnz)], dtype=torch.int64, device=dev)
+        # batches of EXACTLY --steps steps, each bracketed by a barrier + device synchronisation on both sides, the time of a batch = the
+        # MAX over the ranks; the reported batch is the median one (the rule of the N = 1 line)
+        walls = []
+        for _ in range(N_BATCHES):
+            dist.barrier()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                T = run()
+            sync()
+            dist.barrier()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            walls.append(float(dt.item()))
+        walls.sort()
+        halo = torch.tensor([plan.n_halo, plan.n_own, int(plan.P_local.nnz), plan.n_boundary], dtype=torch.int64, device=dev)
         halos = [torch.zeros_like(halo) for _ in range(world)]
         dist.all_gather(halos, halo)
         how = info()
+        if engine == 'glx':
+            try:
+                parts = ds.time_parts(20)          # this rank's pieces of one sweep, each timed alone (microseconds)
+            except Exception:                      # noqa: BLE001
+                parts = None
+        u = None
+        if want_u:                                 # the iterate of the last step, every rank's rows, for the parity check on rank 0
+            got = [None] * world
+            dist.all_gather_object(got, (own, fetch()))
+            if rank == 0:
+                u = np.zeros((G['n'], prob['k']), dtype=got[0][1].dtype)
+                for ids, block in got:
+                    u[ids] = block
         close()
-        return dict(T=T, wall=float(dt.item()), halo_rows=[int(h[0]) for h in halos], owned=[int(h[1]) for h in halos],
-                    global_halo=int(plan.global_halo), how=how, planner={k: (v if not hasattr(v, 'item') else v.item()) for k, v in pinfo.items()})
+        return dict(T=T, wall=walls[len(walls) // 2], wall_min=walls[0], wall_max=walls[-1], halo_rows=[int(h[0]) for h in halos],
+                    owned=[int(h[1]) for h in halos], boundary=[int(h[3]) for h in halos], global_halo=int(plan.global_halo), how=how,
+                    parts_rank0=parts, u=u,
+                    planner={k: (v if not hasattr(v, 'item') else v.item()) for k, v in pinfo.items()})
 
-    def measure_or_fall_back(partition):
+    def measure_or_fall_back(G, partition, want_u=False):
         # an error every rank sees alike (an RCCL call refused, a capture the runtime rejects) must not cost the measurement:
         # the ranks agree on it and repeat the run with the torch.distributed engine
         nonlocal engine
         if engine != 'glx':
-            return measure(partition)
+            return measure(G, partition, want_u)
         out, ok = None, 1
         try:
-            out = measure(partition)
+            out = measure(G, partition, want_u)
         except Exception as exc:                                # noqa: BLE001
             ok = 0
             print('rank %d: libglx distributed sweep failed (%s)' % (rank, exc), file=sys.stderr)
@@ -197,51 +268,87 @@ def main(args):
         engine = 'torch'
         if rank == 0:
             print('falling back to the torch.distributed engine', file=sys.stderr)
-        return measure(partition)
+        return measure(G, partition, want_u)
 
-    # the headline partition: --partition (default `cut`: contiguous blocks between the graph's pieces; `cells`: the quotient-graph
-    # assignment; `auto`: the one of the two with the smaller estimated sweep time); the others are measured beside it
-    headline = getattr(args, 'partition', 'cut')
-    res = measure_or_fall_back(headline)
-    even = measure_or_fall_back('even') if (world > 1 and headline != 'even') else None      # equal blocks: the RCCL exchange in every sweep
-    others = {}
-    if world > 1 and headline != 'cut':          # (the default run measures `cut` and `even` only, as in rounds 1-3)
-        for alt in ('cut', 'cells'):
+    def side(G, partition):
+        """A measurement BESIDE the headline: whatever goes wrong in it (on every rank alike) is recorded in its entry, the line is
+        printed all the same."""
+        ok, out = 1, None
+        try:
+            out = measure_or_fall_back(G, partition)
+        except Exception as exc:                                # noqa: BLE001
+            ok, out = 0, dict(error=repr(exc))
+        agreed = torch.tensor([ok], dtype=torch.int64, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        return out if int(agreed.item()) == 1 else dict(error=(out or {}).get('error', 'failed on another rank'))
+
+    workload = getattr(args, 'workload', 'blobs')
+    G = build(workload)
+    # the headline partition.  strong scaling (default): `even` -- equal blocks of the locality order; they cut through clusters, so every rank
+    # imports a halo and EVERY sweep carries the exchange (asserted below).  --partition cut / cells / auto are measured beside it.
+    headline = getattr(args, 'partition', None) or ('even' if strong else 'cut')
+    res = measure_or_fall_back(G, headline, want_u=True)
+    exchanges_per_sweep = 1 if (res['global_halo'] > 0 and world > 1) or (gdist._force_collectives() and res['how']['exchange'] != 'none') else 0
+    if strong and world > 1 and exchanges_per_sweep < 1:
+        print('bench.py: the headline partition `%s` has no halo on %d ranks: the stated metric is a sweep WITH its halo exchange' % (headline, world),
+              file=sys.stderr)
+        sys.exit(4)
+    sides = {}
+    if world > 1 and not getattr(args, 'no_sides', False):
+        for alt in ('cut', 'even'):
             if alt != headline and res['planner'].get('partition') != alt:
-                others[alt] = measure_or_fall_back(alt)
+                sides['partition_' + alt] = (G, side(G, alt))
+        if workload != 'connected' and not test_ops:
+            Gc = build('connected')
+            sides['workload_connected'] = (Gc, side(Gc, 'even'))
     if rank == 0:
+        prob, n, nnz, W = G['prob'], G['n'], G['nnz'], G['W']
         C = prob['k']
-        nnz = int(P.nnz)
         T = res['T']
         iters = args.steps * T / res['wall']
         abytes = bench.algorithmic_bytes(n, nnz, C, 8, 8)
+        have_rccl = comm is not None and comm.has_transport()
+        what = ('configs[1]: MNIST-shaped k=10 kNN graph, n=%d, nnz=%d, C=%d, ssl.poisson gradient_descent (T=%d sweeps per step, stop test '
+                'included)' % (n, nnz, C, T)) if strong else (
+                'configs[1] scaled weakly: %d x 70000 = %d vertices, k=10 kNN graph, nnz=%d, C=%d' % (world, n, nnz, C))
+        how = ('STRONG scaling: the one graph vertex-partitioned over %d GPUs (%s blocks of a locality order)' % (world, res['planner'].get('partition', headline))
+               if strong else 'vertex-partitioned over %d GPUs (partition `%s`); value = sweeps/s of the whole graph x %d' % (world, res['planner'].get('partition', headline), world))
+        xch = ('one halo exchange of boundary vertex records per sweep (RCCL all-to-all-v: grouped ncclSend/ncclRecv)' if res['global_halo'] > 0 and world > 1
+               else ('one rank: no peers' if world == 1 else 'no halo (every rank owns whole pieces): no per-sweep exchange'))
+        if test_ops:
+            cpu, parity, T_ref = None, None, None
+        else:
+            cpu, parity, T_ref = bench.cpu_baseline(W, G['train_ind'], G['labels'][G['train_ind']], res['u'], T)
+        value = iters if strong else iters * world
         line = {
-            'metric': 'Poisson iters/sec', 'value': iters * world, 'unit': 'iters/s (70000-vertex-graph equivalents)',
+            'metric': 'Poisson iters/sec', 'value': value, 'unit': 'iters/s' if strong else 'iters/s (70000-vertex-graph equivalents)',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['wall'] / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'configs[1] scaled weakly: %d x 70000 = %d vertices, k=10 kNN graph, nnz=%d, C=%d, '
-                                   'vertex-partitioned over %d GPUs (RCM order, partition `%s`%s), %s; value = sweeps/s of the whole graph x %d'
-                                   % (world, n, nnz, C, world, res['planner'].get('partition', headline),
-                                      ', workload `connected` (centre scale 0.8: one component)' if connected else '',
-                                      'one RCCL all-to-all-v halo exchange per sweep' if res['global_halo'] > 0 else
-                                      'no halo (every rank owns whole pieces): no per-sweep exchange, one RCCL all-reduce for the stop test',
-                                      world),
+            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '%s; %s; %s%s' % (what, how, xch, '; workload `connected` (centre scale 0.8: one component)' if workload == 'connected' else ''),
                        'n': n, 'nnz': nnz, 'classes': C, 'sweeps_per_step': T, 'parallelism': 'vertex-partition x%d' % world,
-                       'engine': ('libglx communicator (grouped ncclSend/ncclRecv + captured device graphs)' if engine == 'glx'
-                                  else 'torch.distributed all_to_all_single (eager)')},
+                       'engine': {'glx': 'libglx communicator (grouped ncclSend/ncclRecv + captured device graphs)',
+                                  'torch': 'torch.distributed all_to_all_single (eager)', 'test': 'CPU stand-in of the tests (gloo)'}[engine]},
+            'timing': {'batches': N_BATCHES, 'steps_per_batch': args.steps, 'reported': 'median batch (each batch: barrier + synchronize on both sides, max over ranks)',
+                       'ms_per_step_min': res['wall_min'] / args.steps * 1e3, 'ms_per_step_max': res['wall_max'] / args.steps * 1e3},
             'global_sweeps_per_sec': iters,
             'edges_classes_per_sec': iters * nnz * C,
             'roofline': {'bound': 'hbm', 'achieved': abytes * iters / 1e9, 'peak': bench.HBM_PEAK_GBS * world, 'unit': 'GB/s',
                          'frac': abytes * iters / 1e9 / (bench.HBM_PEAK_GBS * world), 'traffic': None,
-                         'note': 'whole-job algorithmic bytes per sweep / wall time incl. halo exchange'},
-            'cpu_baseline': None,
-            'halo': {'rows_per_rank': res['halo_rows'], 'owned_per_rank': res['owned'],
-                     'exchanges_per_sweep': 1 if res['global_halo'] > 0 else 0, 'global_halo_rows': res['global_halo']},
-            'graph_build_s': t_graph,
+                         'algorithmic_bytes_per_sweep': abytes, 'us_per_sweep': res['wall'] / (args.steps * T) * 1e6,
+                         'note': 'whole-job algorithmic bytes per sweep / wall time per sweep incl. the halo exchange, against N x 8 TB/s; the '
+                                 'one-GPU sweep of this graph takes 12 us, so at N > 1 the per-sweep exchange latency is the bound, not HBM'},
+            'cpu_baseline': cpu,
+            'speedup_vs_cpu_baseline': (value / cpu['value']) if cpu else None,
+            'parity': None if test_ops else {'bit_identical_to_oracle': parity, 'T': T, 'T_oracle': T_ref,
+                                             'note': 'the iterate of the last timed step, every rank\'s rows gathered, against the one-process scipy oracle'},
+            'halo': {'rows_per_rank': res['halo_rows'], 'owned_per_rank': res['owned'], 'boundary_rows_per_rank': res['boundary'],
+                     'exchanges_per_sweep': exchanges_per_sweep, 'global_halo_rows': res['global_halo']},
+            'sweep_parts_rank0_us': res['parts_rank0'],
+            'graph_build_s': G['graph_build_s'],
             # what really ran: ranks of the RCCL communicator the sweeps used (the library's own, or torch's), the engine, and
             # whether sweeps that carry the halo exchange were replayed from captured device graphs or enqueued eagerly
-            'rccl_ranks': (comm.info()['nranks'] if (comm is not None and comm.has_transport()) else int(dist.get_world_size())),
-            'rccl_owner': 'libglx' if (comm is not None and comm.has_transport()) else 'torch.distributed (nccl backend)',
+            'rccl_ranks': (comm.info()['nranks'] if have_rccl else int(dist.get_world_size())),
+            'rccl_owner': 'libglx' if have_rccl else ('torch.distributed (%s backend)' % dist.get_backend()),
             'engine': engine,
             'exchange': res['how']['exchange'],
             'exchange_selftest': res['how']['selftest'],
@@ -250,23 +357,21 @@ def main(args):
             print('bench.py: the communicator has %d ranks, --gpus is %d' % (line['rccl_ranks'], args.gpus), file=sys.stderr)
             sys.exit(3)
         line['partition'] = res['planner']
-        for alt, r_alt in others.items():
+        for key, (Gs, r_alt) in sides.items():
+            if 'error' in r_alt:
+                line[key] = r_alt
+                continue
             it_a = args.steps * r_alt['T'] / r_alt['wall']
-            line['partition_' + alt] = {'value': it_a * world, 'global_sweeps_per_sec': it_a, 'ms_per_step': r_alt['wall'] / args.steps * 1e3,
-                                        'halo_rows_per_rank': r_alt['halo_rows'], 'owned_per_rank': r_alt['owned'], 'planner': r_alt['planner'],
-                                        'exchange': r_alt['how']['exchange']}
-        if even is not None:
-            it_e = args.steps * even['T'] / even['wall']
-            line['partition_even'] = {'value': it_e * world, 'global_sweeps_per_sec': it_e, 'ms_per_step': even['wall'] / args.steps * 1e3,
-                                      'halo_rows_per_rank': even['halo_rows'], 'owned_per_rank': even['owned'],
-                                      'exchange': even['how']['exchange'], 'exchange_selftest': even['how']['selftest'],
-                                      'note': 'equal blocks of the same order: every rank imports a halo, so every sweep carries the '
-                                              'RCCL exchange (the headline partition above places the cuts between the graph\'s pieces)'}
+            line[key] = {'value': it_a if strong else it_a * world, 'global_sweeps_per_sec': it_a, 'ms_per_step': r_alt['wall'] / args.steps * 1e3,
+                         'sweeps_per_step': r_alt['T'], 'n': Gs['n'], 'nnz': Gs['nnz'],
+                         'halo_rows_per_rank': r_alt['halo_rows'], 'owned_per_rank': r_alt['owned'], 'planner': r_alt['planner'],
+                         'exchanges_per_sweep': 1 if r_alt['global_halo'] > 0 else 0,
+                         'exchange': r_alt['how']['exchange'], 'exchange_selftest': r_alt['how']['selftest']}
         emit(json.dumps(line))
     if comm is not None:
         comm.close()
     # orderly teardown: sweeps and communicator are closed above, then the group
-    torch.cuda.synchronize()
+    sync()
     dist.barrier()
     dist.destroy_process_group()
     sys.stdout.flush()
@@ -388,7 +493,7 @@ def main_config4(args):
     # the sweep's blocks follow the graph: boundaries at the cell starts that cross the fewest list entries (between clusters: none),
     # the lists move to their new owners (--partition even keeps the equal blocks)
     t0 = time.perf_counter()
-    partition = getattr(args, 'partition', 'cut')
+    partition = getattr(args, 'partition', None) or 'cut'
     bounds = even
     if partition == 'cut' and world > 1:
         bounds = dist_build.graph_cut_bounds(dist, n, np.asarray(J), lo, cell_starts, device=dev)

@@ -933,8 +933,8 @@ def _solve(run, reduce, dev=None):
     ('exact') when its answer is not one the contract (labels, iteration count, 1e-5) covers -- a solve of more than
     AUTO_TREE_MAX_ITER iterations (every iteration amplifies the difference of the reordered sums: beyond ~90 iterations one solve
     in a hundred stops an iteration apart, profiles/r05_auto_margins.txt), a non-finite iterate (a singular system breaks down with another NaN
-    pattern), or a stop decision that hung on less than AUTO_STOP_BAND of tol (`dev`: the operator, asked for the margin of its last
-    tolerance-mode solve).  Well-conditioned systems (config 3: 54 iterations) never go back: they are the 7x faster mode."""
+    pattern), or ANY comparison of a residual norm with tol -- at every iteration, not only the deciding one: CG's residual norms are not
+    monotone -- that hung on less than AUTO_STOP_BAND of tol (`dev`: the operator, asked for the margin of its last tolerance-mode solve).  Well-conditioned systems (config 3: 54 iterations) never go back: they are the 7x faster mode."""
     if reduce != 'auto':
         return run(reduce)
     out = run('tree')

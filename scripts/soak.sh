@@ -2,6 +2,7 @@
 # A soak of the randomised parity suite with breadcrumbs: scripts/soak.sh TAG SCALE WORKERS [INSTANCES] [extra pytest args]
 #   INSTANCES independent pytest-xdist sessions of WORKERS workers each run side by side on the one GPU (more processes sharing the
 #   device than one session has: the condition the round-4 flake appeared under, and N soaks for the wall time of one).
+#   Session i walks the seeds from GLX_SOAK_BASE + (i-1)*10^5 on (different cases in every session).
 #   GLX_SOAK_X= (empty) runs every case instead of stopping at the first failure (-x is the default).
 # Output: gpurun_out/TAG/inst<i>/{pytest.log,crumbs/*.log}; the last lines of every session are echoed; exit status = number of
 # sessions that did not pass.
@@ -13,7 +14,7 @@ pids=()
 for i in $(seq 1 $inst); do
   out=$root/gpurun_out/$tag/inst$i
   mkdir -p "$out/crumbs"
-  GLX_CRUMBS=$out/crumbs GLX_FUZZ_SCALE=$scale timeout ${GLX_SOAK_TIMEOUT:-3000} \
+  GLX_CRUMBS=$out/crumbs GLX_FUZZ_SCALE=$scale GLX_FUZZ_BASE=$(( ${GLX_SOAK_BASE:-0} + (i-1)*100000 )) timeout ${GLX_SOAK_TIMEOUT:-3000} \
     python -m pytest tests/test_gpu_fuzz.py -q ${GLX_SOAK_X--x} -n $workers --tb=long -rf -p no:cacheprovider "$@" > "$out/pytest.log" 2>&1 &
   pids+=($!)
 done

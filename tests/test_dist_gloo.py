@@ -424,6 +424,58 @@ def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
     assert sorted(t[0] for t in line['ranks']) == [0, 1] and len({t[2] for t in line['ranks']}) == 2     # two processes
 
 
+@pytest.mark.parametrize('inject,limit', [('0:exit', '600'), ('0:hang', '8')])
+def test_bench_supervisor_survives_a_failed_or_hung_attempt(inject, limit):
+    """bench.supervise_rank: every launched rank supervises a measuring child.  A child that dies (or hangs past the attempt's limit)
+    costs the ATTEMPT: all children are killed and the next engine is tried; the line is printed all the same and records what happened."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(GLX_BENCH_TEST_FAIL=inject, GLX_BENCH_ATTEMPT_S=limit)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dist-dry-run'], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['supervised'] and line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['engine'] == 'torch'
+    assert [a['engine'] for a in line['attempts']] == ['glx', 'torch'] and line['attempts'][1]['outcome'] == 'ok'
+    assert line['attempts'][0]['outcome'] == ('a rank failed' if inject.endswith('exit') else 'no line within 8 s')
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_bench_strong_scaling_line_schema(world, tmp_path):
+    """`bench.py --gpus N` reports the STATED metric -- strong scaling of ONE graph (value = sweeps/s of that graph,
+    `scaling: strong`), a halo exchange in every sweep of the headline partition (asserted by the bench itself: exit status 4 otherwise),
+    `roofline` against N x 8 TB/s, the communicator's rank count = N -- through the whole launch path (torch.distributed.run ->
+    supervising ranks -> measuring children).  No GPU here: the rank-local sweep is the scipy stand-in of these tests (--test-ops), the
+    graph is handed in (--test-graph); planner, exchange lists, collectives (gloo) and the line are the product's."""
+    from conftest import blobs
+    from oracle import gl_oracle as orc
+    X, lab = blobs(1600, 8, 4, 31, 2.5)
+    W = orc.knn(X, 8)
+    ti = orc.trainsets_generate(lab, rate=2, seed=1)
+    gpath = str(tmp_path / 'graph.npz')
+    np.savez(gpath, data=W.data, indices=W.indices, indptr=W.indptr, labels=lab, train_ind=ti)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', '2', '--warmup', '1',
+           '--test-ops', os.path.join(ROOT, 'tests', 'dist_worker.py') + ':ScipyOps', '--test-graph', gpath]
+    r = run_ranks(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    u_ref, T_ref = orc.poisson_gd(W, ti, lab[ti], return_T=True)
+    assert j['metric'] == 'Poisson iters/sec' and j['unit'] == 'iters/s' and j['scaling'] == 'strong' and j['higher_is_better'] is True
+    assert j['n_gpus'] == world and j['rccl_ranks'] == world and j['steps'] == 2 and j['warmup'] == 1
+    assert j['config']['n'] == 1600 and j['config']['sweeps_per_step'] == T_ref           # ONE graph, not N of them
+    assert j['value'] == pytest.approx(2 * T_ref / (j['ms_per_step'] * 2e-3), rel=1e-9)   # value = sweeps/s of that graph
+    assert j['halo']['exchanges_per_sweep'] >= 1 and min(j['halo']['rows_per_rank']) > 0 and j['partition']['partition'] == 'even'
+    assert sum(j['halo']['owned_per_rank']) == 1600 and len(j['halo']['owned_per_rank']) == world
+    roof = j['roofline']
+    assert roof['bound'] == 'hbm' and roof['peak'] == 8000.0 * world and roof['frac'] == pytest.approx(roof['achieved'] / roof['peak'])
+    assert 'cpu_baseline' in j and j['supervised'] and j['attempts'][-1]['outcome'] == 'ok'
+    assert 'partition_cut' in j and ('error' in j['partition_cut'] or j['partition_cut']['sweeps_per_step'] == T_ref)
+
+
 def test_bench_refuses_a_world_that_is_not_gpus():
     """A job whose WORLD_SIZE differs from --gpus exits non-zero instead of reporting the wrong n_gpus."""
     env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))

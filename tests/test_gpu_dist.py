@@ -281,10 +281,12 @@ def test_glx_dist_gather_form_one_rank(golden, transport):
         comm.close()
 
 
+@pytest.mark.parametrize('engine', ['glxstep', 'hip'])
 @pytest.mark.parametrize('case,world', [('twomoons', 2), ('connected', 3)])
-def test_multi_rank_gather_form_over_gloo(case, world, tmp_path):
-    """Several ranks sharing cuda:0, the C-ABI sweep object in its all-gather form (every row a boundary row, the state = world blocks),
-    gloo moving the blocks: bit-identical to the single-rank oracle."""
+def test_multi_rank_gather_form_over_gloo(case, world, engine, tmp_path):
+    """Several ranks sharing cuda:0 in the all-gather form (every row a boundary row, the state = world blocks), gloo moving the blocks:
+    bit-identical to the single-rank oracle.  engine 'glxstep': the C-ABI sweep object; 'hip': the torch-tensor plumbing (dist.HipOps),
+    whose sweeps must land in block `rank` of the state (ranks > 0 wrote into block 0)."""
     import socket
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -292,7 +294,7 @@ def test_multi_rank_gather_form_over_gloo(case, world, tmp_path):
     s.close()
     out = str(tmp_path / ('res_gather_' + case))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out, 'glxstep', 'even', 'gather']
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'dist_worker.py'), case, out, engine, 'even', 'gather']
     r = run_ranks(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS='1'), cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for k in range(world):

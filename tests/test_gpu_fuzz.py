@@ -11,6 +11,12 @@ pytestmark = pytest.mark.gpu
 
 # GLX_FUZZ_SCALE=10 runs ten times as many random cases of every kind (a soak run; the default is what CI runs)
 _SCALE = int(__import__('os').environ.get('GLX_FUZZ_SCALE', '1'))
+# GLX_FUZZ_BASE=b shifts every seed range by b: concurrent soak sessions walk DIFFERENT cases (scripts/soak.sh gives session i base i * 10^5)
+_BASE = int(__import__('os').environ.get('GLX_FUZZ_BASE', '0'))
+
+
+def _seeds(k):
+    return range(_BASE, _BASE + k * _SCALE)
 
 
 @pytest.fixture(scope='module')
@@ -131,7 +137,7 @@ def _case(seed):
     return dict(n=n, d=d, C=C, k=k, X=X, lab=lab.astype(np.int64), kernel=kernel, symmetrize=symmetrize, ti=ti, rng=rng)
 
 
-@pytest.mark.parametrize('seed', range(24 * _SCALE))
+@pytest.mark.parametrize('seed', _seeds(24))
 def test_random_pipeline_matches_the_oracle(gl, orc, seed, mode):
     c = _case(seed)
     X, lab, ti, k = c['X'], c['lab'], c['ti'], c['k']
@@ -233,7 +239,7 @@ def test_random_pipeline_matches_the_oracle(gl, orc, seed, mode):
             assert nd <= max(2, c['n'] // 100), (tag, nd)
 
 
-@pytest.mark.parametrize('seed', range(12 * _SCALE))
+@pytest.mark.parametrize('seed', _seeds(12))
 def test_random_trials_and_comparison_methods_match_the_oracle(gl, orc, seed, mode):
     """Stacked trials (several training sets as column groups of one solve), the float32 branch, and the comparison
     methods of SURVEY 8 f-3 on random symmetric graphs."""
@@ -295,7 +301,7 @@ def test_random_trials_and_comparison_methods_match_the_oracle(gl, orc, seed, mo
         assert G.page_rank_iters == it_ref and np.array_equal(pr, pr_ref), tag
 
 
-@pytest.mark.parametrize('seed', range(8 * _SCALE))
+@pytest.mark.parametrize('seed', _seeds(8))
 def test_random_plaplace_jacobi_matches_the_oracle(gl, orc, seed):
     """graph.plaplace(fast=False) on random graphs, boundary sets, exponents and iteration caps: iterates and the
     stopping iteration equal to the C restatement of lp_iterate_main."""
@@ -374,7 +380,7 @@ def _virtual_ranks_sweep(gdist, _hip, prob, order, bounds, min_iter, max_iter, d
     return u, T, halo
 
 
-@pytest.mark.parametrize('seed', range(14 * _SCALE))
+@pytest.mark.parametrize('seed', _seeds(14))
 def test_random_vertex_partitions_match_the_oracle(gl, orc, seed):
     """The rank-local pieces of the sharded sweep (boundary rows | pack | halo | interior rows, per-rank maxima of the stop
     column) on random graphs -- symmetric and directed -- cut into 2..6 vertex blocks in three ways (the library's locality
@@ -407,7 +413,7 @@ def test_random_vertex_partitions_match_the_oracle(gl, orc, seed):
         assert np.nanmax(np.abs(u32 - u_ref)) <= 1e-5 * max(1.0, np.nanmax(np.abs(u_ref))), tag
 
 
-@pytest.mark.parametrize('seed', range(30 * _SCALE))
+@pytest.mark.parametrize('seed', _seeds(30))
 def test_random_knn_searches_match_ckdtree(gl, orc, seed):
     """The exact search over a wide range of shapes -- n = 2 .. 6000, d = 1 .. 300 (every feature-block count of the bf16
     filter and the blocked fp32 kernel beyond d = 128), k = 1 .. 60 (every list length), clustered / isotropic / offset /
@@ -448,7 +454,7 @@ def test_random_knn_searches_match_ckdtree(gl, orc, seed):
         assert len(bad) <= max(1, n // 1000), (tag, len(bad))
 
 
-@pytest.mark.parametrize('seed', range(16 * _SCALE))
+@pytest.mark.parametrize('seed', _seeds(16))
 def test_random_clustered_searches_match_all_pairs(gl, seed):
     """glx_knn_clustered / glx_knn_cells_range over random shapes -- n = 300 .. 40 000, d = 1 .. 128, k = 1 .. 60, 2 .. 300 cells,
     clustered / isotropic / offset / duplicated data, whole set or a query sub-range with the caller's cells -- against the all-pairs
