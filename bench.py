@@ -345,6 +345,52 @@ def other_configs(W2, labels2, ti2, device_sync, knn_stats2, X2):
         'cpu_baseline': {'value': it_ref2 / t_cpu2, 'unit': 'CG iterations/s', 'cores': 1, 'kind': 'port',
                          'sample': 'the whole fit of the oracle (operator set-up + %d scipy conjgrad iterations) in %.2f s' % (it_ref2, t_cpu2)}}
 
+    # ---- the default Poisson solver on a CONSISTENT system: the `connected` workload (centre scale 0.8: one component) ---------------
+    # config 2's blob graph is ten separate components: its normalised system is singular ten times over and inconsistent in rounding,
+    # the reference's own iterate reaches 1e13 along the null space (tests/golden/g4_large_meta.json).  The same solve on a graph that is
+    # ONE component (the multi-GPU runs' `connected` workload) is the number for a well-posed Poisson CG; beside it the tolerance-mode
+    # reductions (`tree`), which ssl.poisson does not use by default: iterations and max |du| against the reference-order solve.
+    try:
+        Xc = make_features(labels2, scale=0.8)
+        Wc = gl.weightmatrix.knn(Xc, K_NN)
+        ncomp = int(sparse.csgraph.connected_components(Wc, directed=False)[0])
+        model_c = gl.ssl.poisson(Wc)
+        uc = model_c.fit(ti2, labels2[ti2])
+        ms_c = _median_ms(lambda: model_c.fit(ti2, labels2[ti2]), device_sync)
+        its_c = int(model_c.num_iter)
+        nnzLc = int(Wc.nnz + n2)
+        cgbc = cg_algorithmic_bytes(n2, nnzLc, Cc)
+        t0 = time.perf_counter()
+        uc_ref, itc_ref = orc.poisson_cg(Wc, ti2, labels2[ti2], return_iters=True)
+        t_cpuc = time.perf_counter() - t0
+        per_c = ms_c[0] * 1e-3 / max(its_c, 1)
+        dev_c, aux_c = model_c._operators()
+        src_c, _k = gl.ssl._poisson_source(n2, ti2, labels2[ti2])
+        rhs_c = np.ascontiguousarray(aux_c['D'] * src_c)
+        xt, it_t, _e = dev_c.cg(rhs_c, tol=model_c.tol, reduce='tree')
+        ms_t = _median_ms(lambda: dev_c.cg(rhs_c, tol=model_c.tol, reduce='tree'), device_sync)
+        ut = aux_c['D'] * xt
+        blk_c = model_c._cache[1].last_block_stats()
+        out['poisson_cg_connected'] = {
+            'workload': 'the configs[1] generator with centre scale 0.8 (n=70000, nnz=%d, %d connected component%s), ssl.poisson(W) with its '
+                        'default solver (conjugate_gradient, tol=1e-3), trainsets.generate(rate=1, seed=0)' % (Wc.nnz, ncomp, '' if ncomp == 1 else 's'),
+            'fit_ms': ms_c[0], 'fit_ms_min': ms_c[1], 'fit_ms_max': ms_c[2], 'reps': ms_c[3], 'cg_iterations': its_c,
+            'us_per_iteration_of_fit_wall_time': per_c * 1e6, 'cg_iterations_per_s': its_c / (ms_c[0] * 1e-3),
+            'algorithmic_bytes_per_iteration': cgbc,
+            'roofline': {'bound': 'hbm', 'achieved': cgbc / per_c / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': cgbc / per_c / 1e9 / HBM_PEAK_GBS},
+            'blocks_plain_by_record_row_by_row': list(blk_c),
+            'parity': {'iterations_equal_oracle': its_c == int(itc_ref), 'bit_identical_to_oracle': bool(np.array_equal(uc, uc_ref)),
+                       'accuracy_percent': float(gl.ssl.ssl_accuracy(model_c.predict(), labels2, ti2))},
+            'tolerance_mode_reductions': {'fit_ms': ms_t[0], 'cg_iterations': int(np.max(it_t)), 'max_abs_du_vs_reference_order': float(np.max(np.abs(ut - uc))),
+                                          'scale_of_u': float(np.max(np.abs(uc))),
+                                          'labels_equal': bool(np.array_equal(np.argmax(ut, axis=1), np.argmax(uc, axis=1))),
+                                          'note': 'not what ssl.poisson runs: its contract is the reference\'s iterates bit for bit'},
+            'cpu_baseline': {'value': itc_ref / t_cpuc, 'unit': 'CG iterations/s', 'cores': 1, 'kind': 'port',
+                             'sample': 'the whole fit of the oracle (operator set-up + %d scipy conjgrad iterations) in %.2f s' % (itc_ref, t_cpuc)}}
+        del model_c, Wc, Xc
+    except Exception as e:          # a measurement beside the line, never the reason there is no line
+        out['poisson_cg_connected'] = {'error': repr(e)}
+
     # ---- config 5: PoissonMBO on the config-2 graph ---------------------------------------------------------------------------
     m5 = meta['config5']
     priors = gl.utils.class_priors(labels2)
@@ -399,7 +445,8 @@ def other_configs(W2, labels2, ti2, device_sync, knn_stats2, X2):
         'ms': ms[0], 'ms_min': ms[1], 'ms_max': ms[2], 'reps': ms[3], 'knn_tile_ms': st['tile_ms'], 'knn_total_kernels_ms': st['total_ms'],
         'filter': st['filter'], 'visited_share_of_pairs': (st['visited_share'] if st['cells'] else 1.0),
         'mfma_instructions_estimated': n_mfma, 'matrix_pipe_utilisation_by_time': util,
-        'useful_tflops_fp32_equivalent': 2.0 * pairs * st['dpa'] / (st['tile_ms'] * 1e-3) / 1e12,
+        'issued_mfma_tflops': 2.0 * 32 * 32 * 16 * n_mfma / (st['tile_ms'] * 1e-3) / 1e12,
+        'issued_mfma_frac_of_bf16_peak': (2.0 * 32 * 32 * 16 * n_mfma / (st['tile_ms'] * 1e-3) / 1e12 / 2500.0) if st['filter'] == 'bf16x3' else None,
         'parity': {'first_%d_rows_equal_ckdtree' % nq: bool(np.array_equal(J_gpu[:nq], jq) and np.array_equal(D_gpu[:nq], dq)),
                    'neighbour_lists_match_reference_run': _sha(J_gpu.astype(np.int64)) == m2['J_sha'],
                    'W_indices_match_reference_run': _sha(W2.indices.astype(np.int32)) == m2['W_indices_sha']},
@@ -862,6 +909,8 @@ def main():
                          'the halo exchange), contiguous blocks cut between the pieces of the graph (`cut`: the default of --scaling weak and --config 4), '
                          'or the cells of the search assigned to ranks by a balanced partition of their quotient graph')
     ap.add_argument('--no-sides', action='store_true', help='multi-GPU config 2: skip the measurements beside the headline (other partition, `connected` workload)')
+    ap.add_argument('--check', action='store_true', help='--config 4: property checks beside the line (counting argument of the search on sampled rows, '
+                         'W symmetric / zero diagonal, degree-weighted sums conserved)')
     ap.add_argument('--knn', default='cells', choices=['cells', 'allpairs'], help='--config 4: cell-pruned search (default) or every tile')
     ap.add_argument('--workload', default='blobs', choices=['blobs', 'connected'],
                     help='multi-GPU config 2: the headline features (10 separate clusters) or the same with centre scale 0.8 '

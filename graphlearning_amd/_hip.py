@@ -10,10 +10,11 @@ import ctypes as C
 import numpy as np
 
 GLX_F32, GLX_F64 = 0, 1
-GLX_CG_NP1D, GLX_CG_TREE, GLX_CG_X0, GLX_CG_BLOCKS, GLX_CG_CHAIN = 1, 2, 4, 8, 16     # flags of glx_cg_solve / glx_cg_groups_masked (include/glx.h)
+GLX_CG_NP1D, GLX_CG_TREE, GLX_CG_X0, GLX_CG_BLOCKS, GLX_CG_CHAIN, GLX_CG_EAGER = 1, 2, 4, 8, 16, 32     # flags of glx_cg_solve / glx_cg_groups_masked (include/glx.h)
 # how reduce='exact' walks numpy's reduction chains: None = the library's choice (block form from 8192 rows on), 'blocks' / 'chain'
 # force one form (same bits; tests and measurements)
 CG_EXACT_FORM = None
+CG_EXACT_EAGER = False          # True: the exact-mode CG enqueues its iterations launch by launch (GLX_CG_EAGER) instead of replaying captured chunks
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libglx.so')
 _lib = None
@@ -133,6 +134,8 @@ _SIGNATURES = {
     'glx_cg_groups_rows': [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_int64, C.c_int,
                            C.POINTER(C.c_int), _f64p],
     'glx_cg_last_stop_margin': [_vp, _f64p],
+    'glx_pool_set_enabled': [C.c_int],
+    'glx_nearest_dist': [_vp, C.c_int64, C.c_int, _vp, C.c_int64, _vp, C.c_int],
     'glx_cg_last_block_stats': [_vp, C.POINTER(C.c_int)],
     'glx_host_fingerprint': [_vp, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)],
     'glx_knn_search': [_vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)],
@@ -298,8 +301,20 @@ class _PinnedPool:
 
 _pinned = _PinnedPool()
 
+# Off switches of the two buffer pools (results are identical either way: tests/test_gpu_switches.py; the randomised soak runs with
+# each off as an ablation -- a result that moves with a switch names the subsystem):
+#   PINNED_RESULTS = False   result arrays come from np.empty (ordinary memory), no page-locked block is recycled
+#   pool_set_enabled(False)  device work buffers and work sets come straight from / go straight back to the HIP runtime
+PINNED_RESULTS = True
+
+
+def pool_set_enabled(enabled):
+    check(load().glx_pool_set_enabled(1 if enabled else 0), 'glx_pool_set_enabled')
+
 
 def pinned_empty(shape, dtype):
+    if not PINNED_RESULTS:
+        return np.empty(shape, dtype=np.dtype(dtype))
     return _pinned.empty(shape, dtype)
 
 
@@ -308,7 +323,7 @@ def pinned_reserve(specs):
     (page-locking 19 MB of fresh memory takes 3.4 ms: weightmatrix.knn starts it beside its search, whose result arrays these
     are).  Returns the thread to join, or None when nothing had to be allocated (the steady state)."""
     need = []
-    for shape, dtype in specs:
+    for shape, dtype in specs if PINNED_RESULTS else ():
         nbytes = max(int(np.prod(shape)) * np.dtype(dtype).itemsize, 1)
         with _pinned.lock:
             if nbytes >= (1 << 16) and not _pinned.idle.get(nbytes) and _pinned.total + nbytes <= _pinned.budget:
@@ -570,7 +585,7 @@ def _reduce_flag(reduce):
     if reduce == 'exact':
         if CG_EXACT_FORM not in (None, 'blocks', 'chain'):
             raise GlxError("CG_EXACT_FORM must be None, 'blocks' or 'chain', got %r" % (CG_EXACT_FORM,))
-        return {None: 0, 'blocks': GLX_CG_BLOCKS, 'chain': GLX_CG_CHAIN}[CG_EXACT_FORM]
+        return {None: 0, 'blocks': GLX_CG_BLOCKS, 'chain': GLX_CG_CHAIN}[CG_EXACT_FORM] | (GLX_CG_EAGER if CG_EXACT_EAGER else 0)
     if reduce == 'tree':
         return GLX_CG_TREE
     raise GlxError("reduce must be 'exact' (reference-order reductions) or 'tree' (tolerance mode), got %r" % (reduce,))
@@ -956,6 +971,17 @@ class DistSweep:
             self.close()
         except Exception:
             pass
+
+
+def nearest_dist(X, idx, device=None):
+    """Distance from every row of X to the nearest of its rows `idx` (glx_nearest_dist: cKDTree(X[idx]).query(X)[0], bit for bit)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    if X.ndim != 2:
+        raise GlxError('nearest_dist: X must be (n, d)')
+    idx = np.ascontiguousarray(np.asarray(idx).reshape(-1), dtype=np.int64)
+    out = np.empty(X.shape[0], dtype=np.float64)
+    check(load().glx_nearest_dist(_ptr(X), X.shape[0], X.shape[1], _ptr(idx), len(idx), _ptr(out), _dev(device)), 'glx_nearest_dist')
+    return out
 
 
 def record_layout(Cc, dtype=np.float64, has_w=True):

@@ -136,11 +136,13 @@ __global__ __launch_bounds__(256) void cg_pupdate_kernel(const T* __restrict__ r
 // loop below 8 (Cg <= 128 here).  One thread per group.
 __global__ __launch_bounds__(256) void cg_group_err_kernel(CgScalars sc, int it, double tol) {
 #pragma clang fp contract(off)
-  if (!cg_any_active(sc, it, tol)) return;
+  // (the rows of the residual history are a ring of CG_CHUNK + 1 entries reused chunk after chunk: an iteration that does not run
+  // writes the zeros -- "stopped" -- that a fresh buffer would hold, so that everything behind it stays off as well)
+  const bool any = cg_any_active(sc, it, tol);
   __shared__ double s_e[256];
   const int g = threadIdx.x;
   double mine = 0.0;
-  if (g < sc.ngroups && cg_col_active(sc, it, tol, g * sc.Cg)) {
+  if (any && g < sc.ngroups && cg_col_active(sc, it, tol, g * sc.Cg)) {
     const double* a = sc.rsold + (size_t)g * sc.Cg;
     const int C = sc.Cg;
     double e;
@@ -157,8 +159,9 @@ __global__ __launch_bounds__(256) void cg_group_err_kernel(CgScalars sc, int it,
       for (; i < C; ++i) e = e + a[i];
     }
     mine = sqrt(e);
-    sc.err_hist[(size_t)it * sc.stride + g] = mine;
   }
+  __syncthreads();        // (every thread has read row it - 1 before row `it` is written: with a one-row ring they could be the same)
+  if (g < sc.ngroups) sc.err_hist[(size_t)it * sc.stride + g] = mine;
   s_e[threadIdx.x] = mine;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -168,6 +171,21 @@ __global__ __launch_bounds__(256) void cg_group_err_kernel(CgScalars sc, int it,
       if (s_e[q] > m) m = s_e[q];
     sc.err_hist[(size_t)it * sc.stride + sc.ngroups] = m;
   }
+}
+
+// the ring of the residual history turns: row 0 (what iteration 1 of a chunk tests) <- row `from` (what the previous chunk's last iteration left)
+__global__ void cg_roll_hist_kernel(double* err_hist, int stride, int from) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < stride) err_hist[i] = err_hist[(size_t)from * stride + i];
+}
+
+// Dirichlet rows of every system as bits of rowmask[record] (zeroed before): the SpMM holds A p at zero there (sweep.hip)
+__global__ __launch_bounds__(256) void cg_rowmask_kernel(unsigned* __restrict__ rowmask, const int32_t* __restrict__ mask_rows,
+                                                         const int32_t* __restrict__ mask_ptr) {
+  const int g = blockIdx.y;
+  const int cnt = mask_ptr[g + 1] - mask_ptr[g];
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < cnt) atomicOr(&rowmask[mask_rows[mask_ptr[g] + idx]], 1u << g);
 }
 
 // ---- reference-order reductions ---------------------------------------------------------
@@ -420,9 +438,11 @@ struct PwHost {
   }
 };
 
-__global__ void cg_set_err0(double* err_hist, int64_t n, int stride) {
+// the ring of CG_CHUNK + 1 history rows: row 0 and the last row = 1 (utils.py:519: err = 1 in front of the loop; every chunk starts by
+// copying the last row to row 0), the others 0 (= stopped)
+__global__ void cg_set_err0(double* err_hist, int64_t n, int stride, int last_row) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) err_hist[i] = i < stride ? 1.0 : 0.0;
+  if (i < n) err_hist[i] = (i < stride || i / stride == last_row) ? 1.0 : 0.0;
 }
 
 // Dirichlet rows (ssl.laplace._fit, ssl.py:1232-1241, solves on the sub-matrix of the unlabelled
@@ -480,7 +500,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   GLX_CHECK(256 / (L.ld / 4) >= 1, GLX_EUNSUPPORTED, "glx_cg_multi: record too wide");
   const int64_t nb_spmm = std::max<int64_t>(glx_spmm_blocks(plan), 1);
   const int64_t nb_upd = std::max<int64_t>((n + UPD_ROWS_PER_BLOCK - 1) / UPD_ROWS_PER_BLOCK, 1);
-  const int64_t hist_cap = max_iter + 2;
+  const int64_t hist_cap = CG_CHUNK + 1;       // a ring: row 0 = what the chunk's first iteration tests, rows 1 .. CG_CHUNK = what its iterations leave
   GLX_CHECK(max_iter < (1ll << 24), GLX_EUNSUPPORTED, "glx_cg_multi: max_iter %lld exceeds the supported 2^24-1", (long long)max_iter);
   GLX_CHECK(n < (1ll << 27), GLX_EUNSUPPORTED, "glx_cg_multi: %lld rows exceed the reference-order reducer's 32-bit offsets", (long long)n);
 
@@ -499,7 +519,6 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   CG_NEED(b.part_dot, (size_t)nb_spmm * ncols * 8);
   CG_NEED(b.part_rs, (size_t)nb_upd * ncols * 8);
   CG_NEED(b.scal, (size_t)3 * ncols * 8);
-  // the residual history is read in chunks: capped, the loop below wraps nothing (max_iter entries are needed only if they run)
   CG_NEED(b.err_hist, (size_t)hist_cap * stride * 8);
   CG_NEED(b.prod, (size_t)ncols * n * 8);
   // the two reference-order chains per iteration: walked row by row (cg_seqsum_dpp_kernel, 2.4 ns per row) or in block form
@@ -511,18 +530,20 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
                          glx_seqsum_rec_bytes(ncols, ssw.nchunks) <= ((size_t)1 << 30) &&      // (hundreds of columns x millions of rows: the chain)
                          ((flags & GLX_CG_BLOCKS) || n >= 8192);
   if (ss_blocks) {
+    rc = glx_seqsum_prepare();
+    if (rc) return rc;
     CG_NEED(b.ss_bsum, glx_seqsum_sum_doubles(ncols, ssw.nchunks, 0) * 8);
     CG_NEED(b.ss_csum, glx_seqsum_sum_doubles(ncols, ssw.nchunks, 1) * 8);
     CG_NEED(b.ss_rec, glx_seqsum_rec_bytes(ncols, ssw.nchunks));
     CG_NEED(b.ss_mask, (size_t)ncols * ssw.nchunks * 16);      // a byte per group of 4 blocks
-    CG_NEED(b.ss_stats, 64);
+    CG_NEED(b.ss_stats, 128);
     ssw.rec = b.ss_rec;
     ssw.bsum = b.ss_bsum;
     ssw.csum = b.ss_csum;
     ssw.mask = b.ss_mask;
     ssw.stats = b.ss_stats;
-    { int rc_ = b.need_host(&b.h_ss, 64); if (rc_) return rc_; }
-    memset(b.h_ss, 0, 64);
+    { int rc_ = b.need_host(&b.h_ss, 256); if (rc_) return rc_; }
+    memset(b.h_ss, 0, 256);
   }
   // Per kind of reduction (0: p.Ap, 1: r.r) the form is re-decided whenever the host looks at the residual history: the block
   // form costs about a microsecond per block that is not a plain same-binade one (a lone wavefront issues an instruction every
@@ -530,7 +551,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   // changes sign from row to row) are cheaper row by row.  Same bits either way, so switching in mid-solve changes nothing but time.
   bool blocks_now[2] = {ss_blocks, ss_blocks};
   const bool blocks_forced = (flags & GLX_CG_BLOCKS) != 0;
-  int ss_seen[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  unsigned long long ss_seen[2][3] = {{0, 0, 0}, {0, 0, 0}};
   PwPlan pw;
   memset(&pw, 0, sizeof(pw));
   unsigned pw_grid = 1;
@@ -568,7 +589,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     pw = b.pw;
     pw_grid = b.pw_grid;
   }
-  { int rc_ = b.need_host(&b.h_err, (size_t)(CG_CHUNK + 1) * stride * 8); if (rc_) return rc_; }
+  { int rc_ = b.need_host(&b.h_err, (size_t)2 * (CG_CHUNK + 1) * stride * 8); if (rc_) return rc_; }      // two chunks in flight
   CgScalars sc;
   sc.rsold = b.scal;
   sc.alpha = b.scal + ncols;
@@ -585,7 +606,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   T* p = (T*)b.p;
   T* ap = (T*)b.ap;
 
-  hipLaunchKernelGGL(cg_set_err0, dim3((unsigned)((hist_cap * stride + 255) / 256)), blk, 0, st, b.err_hist, hist_cap * stride, stride);
+  hipLaunchKernelGGL(cg_set_err0, dim3((unsigned)((hist_cap * stride + 255) / 256)), blk, 0, st, b.err_hist, hist_cap * stride, stride, CG_CHUNK);
   GLX_HIP(hipGetLastError());
   if (flags & GLX_CG_X0) {   // X holds x0 on entry; B is the caller's r0 = b - A@x0 (utils.py:510-514)
     GLX_HIP(hipMemcpyAsync(b.dense, X, (size_t)n * C * es, hipMemcpyHostToDevice, st));
@@ -626,7 +647,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       hipLaunchKernelGGL(cg_pw_tree_kernel<2>, dim3(1), dim3(256), 0, st, pw, sc, 0, tol);
     }
   else if (ss_blocks) {
-    GLX_HIP(hipMemsetAsync(b.ss_stats, 0, 64, st));
+    GLX_HIP(hipMemsetAsync(b.ss_stats, 0, 128, st));
     rc = glx_seqsum_run(2, b.prod, n, ncols, C, sc, 0, tol, ssw, st);
     if (rc) return rc;
   } else
@@ -664,6 +685,17 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     GLX_HIP(hipMemcpy(b.mask_rows, rec.data(), (size_t)total * 4, hipMemcpyHostToDevice));
     GLX_HIP(hipMemcpy(b.mask_ptr, mask_ptr, (size_t)(ngroups + 1) * 4, hipMemcpyHostToDevice));
     mask_grid = (unsigned)(((int64_t)most * Cg + 255) / 256);
+    if (ngroups <= 32) {
+      // the SpMM itself holds A p at zero on these rows (a bit per system in rowmask[record]): no kernel behind it.  (The products
+      // p * Ap of such a row are 0 * 0 = +0 instead of 0 * (A p) = +-0: a zero of either sign leaves every running sum as it is.)
+      CG_NEED(b.e_rowmask, (size_t)n * 4);
+      GLX_HIP(hipMemsetAsync(b.e_rowmask, 0, (size_t)n * 4, st));
+      hipLaunchKernelGGL(cg_rowmask_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)ngroups), blk, 0, st, b.e_rowmask,
+                         (const int32_t*)b.mask_rows, (const int32_t*)b.mask_ptr);
+      GLX_HIP(hipGetLastError());
+      a.rowmask = b.e_rowmask;
+      mask_grid = 0;
+    }
   }
   const unsigned pgrid = (unsigned)std::max<int64_t>(((int64_t)n * (L.ld / 4) + 255) / 256, 1);
 
@@ -684,68 +716,137 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       }
     }
   };
-  {
-  int64_t it = 0;                               // iterations launched
-  while (running > 0 && it < max_iter) {
-    const int64_t end = std::min<int64_t>(max_iter, it + CG_CHUNK);
-    const int64_t it0 = it;
-    for (; it < end; ++it) {
-      const int i = (int)it + 1;
-      a.exit_err = b.err_hist + (size_t)(i - 1) * stride + ngroups;   // all groups converged: exit at once
-      a.act_row = ngroups > 1 ? b.err_hist + (size_t)(i - 1) * stride : nullptr;
-      rc = glx_launch_spmm(a, st);                                                   // Ap = A@p, p.Ap partials
-      if (rc) return rc;
-      if (mask_grid) {
-        hipLaunchKernelGGL((cg_zero_rows_kernel<T>), dim3(mask_grid, (unsigned)ngroups), blk, 0, st, ap, L.ld, (const int32_t*)b.mask_rows,
-                           (const int32_t*)b.mask_ptr, Cg, sc, i, tol);
-        GLX_HIP(hipGetLastError());
-      }
-      if (np1d)
-        {
+  // One iteration of utils.conjgrad's loop (utils.py:521-530) as it is enqueued: `i` = its row in the ring of the residual history
+  // (1 .. CG_CHUNK; the kernels test row i - 1 and leave row i), `bl0` / `bl1` = the form of its two reduction chains.
+  auto enqueue_iteration = [&](int i, bool bl0, bool bl1) -> int {
+    a.exit_err = b.err_hist + (size_t)(i - 1) * stride + ngroups;   // all groups converged: exit at once
+    a.act_row = ngroups > 1 ? b.err_hist + (size_t)(i - 1) * stride : nullptr;
+    int rc2 = glx_launch_spmm(a, st);                                               // Ap = A@p, p.Ap partials
+    if (rc2) return rc2;
+    if (mask_grid) {
+      hipLaunchKernelGGL((cg_zero_rows_kernel<T>), dim3(mask_grid, (unsigned)ngroups), blk, 0, st, ap, L.ld, (const int32_t*)b.mask_rows,
+                         (const int32_t*)b.mask_ptr, Cg, sc, i, tol);
+      GLX_HIP(hipGetLastError());
+    }
+    if (np1d) {
       hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, i, tol, 0);
       hipLaunchKernelGGL(cg_pw_tree_kernel<0>, dim3(1), dim3(256), 0, st, pw, sc, i, tol);
+    } else if (bl0) {
+      rc2 = glx_seqsum_run(0, b.prod, n, ncols, C, sc, i, tol, ssw, st);
+      if (rc2) return rc2;
+    } else {
+      hipLaunchKernelGGL(cg_seqsum_dpp_kernel<0>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
     }
-      else if (blocks_now[0]) {
-        rc = glx_seqsum_run(0, b.prod, n, ncols, C, sc, i, tol, ssw, st);
-        if (rc) return rc;
-      } else
-        hipLaunchKernelGGL(cg_seqsum_dpp_kernel<0>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
-      GLX_HIP(hipGetLastError());
-      hipLaunchKernelGGL((cg_update_kernel<T, 0>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
-                         (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, sc, i, tol, b.prod, prod_sc, (const int32_t*)A->d_perm);
-      GLX_HIP(hipGetLastError());
-      if (np1d)
-        {
+    GLX_HIP(hipGetLastError());
+    hipLaunchKernelGGL((cg_update_kernel<T, 0>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
+                       (const double*)sc.alpha, b.part_rs, n, L.ld, L.nvec, sc, i, tol, b.prod, prod_sc, (const int32_t*)A->d_perm);
+    GLX_HIP(hipGetLastError());
+    if (np1d) {
       hipLaunchKernelGGL(cg_pw_leaf_kernel, dim3(pw_grid), dim3(256), 0, st, (const double*)b.prod, prod_sc, pw, sc, i, tol, 1);
       hipLaunchKernelGGL(cg_pw_tree_kernel<1>, dim3(1), dim3(256), 0, st, pw, sc, i, tol);
+    } else if (bl1) {
+      rc2 = glx_seqsum_run(1, b.prod, n, ncols, C, sc, i, tol, ssw, st);
+      if (rc2) return rc2;
+    } else {
+      hipLaunchKernelGGL(cg_seqsum_dpp_kernel<1>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
     }
-      else if (blocks_now[1]) {
-        rc = glx_seqsum_run(1, b.prod, n, ncols, C, sc, i, tol, ssw, st);
-        if (rc) return rc;
-      } else
-        hipLaunchKernelGGL(cg_seqsum_dpp_kernel<1>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
-      GLX_HIP(hipGetLastError());
-      hipLaunchKernelGGL(cg_group_err_kernel, dim3(1), blk, 0, st, sc, i, tol);
-      GLX_HIP(hipGetLastError());
-      hipLaunchKernelGGL((cg_pupdate_kernel<T>), dim3(pgrid), blk, 0, st, (const T*)r, p, (const double*)sc.beta, n, L.ld, L.nvec,
-                         sc, i, tol, 1);
-      GLX_HIP(hipGetLastError());
+    GLX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(cg_group_err_kernel, dim3(1), blk, 0, st, sc, i, tol);
+    GLX_HIP(hipGetLastError());
+    hipLaunchKernelGGL((cg_pupdate_kernel<T>), dim3(pgrid), blk, 0, st, (const T*)r, p, (const double*)sc.beta, n, L.ld, L.nvec,
+                       sc, i, tol, 1);
+    GLX_HIP(hipGetLastError());
+    return GLX_OK;
+  };
+  // a chunk: the ring turns (row 0 <- the last row), then `cnt` iterations
+  auto enqueue_chunk = [&](int cnt, bool bl0, bool bl1) -> int {
+    hipLaunchKernelGGL(cg_roll_hist_kernel, dim3((unsigned)((stride + 255) / 256)), blk, 0, st, b.err_hist, stride, CG_CHUNK);
+    GLX_HIP(hipGetLastError());
+    for (int i = 1; i <= cnt; ++i) {
+      int rc2 = enqueue_iteration(i, bl0, bl1);
+      if (rc2) return rc2;
     }
-    const int64_t cnt = end - it0;
-    GLX_HIP(hipMemcpyAsync(b.h_err, b.err_hist + (size_t)(it0 + 1) * stride, (size_t)cnt * stride * 8, hipMemcpyDeviceToHost, st));
-    if (ss_blocks) GLX_HIP(hipMemcpyAsync(b.h_ss, b.ss_stats, 64, hipMemcpyDeviceToHost, st));
-    GLX_HIP(hipStreamSynchronize(st));
-    read_history(b.h_err, it0, cnt);
+    return GLX_OK;
+  };
+  // Full chunks are replayed from a captured launch sequence (one per combination of reduction forms): the same thirteen-odd launches
+  // per iteration, without the host between them.  The sequences belong to the solve parameters they were captured for.
+  const bool use_graphs = !(flags & GLX_CG_EAGER);
+  if (use_graphs) {
+    const std::vector<unsigned long long> key = {
+        (unsigned long long)n, (unsigned long long)C, (unsigned long long)Cg, (unsigned long long)__builtin_bit_cast(unsigned long long, tol),
+        (unsigned long long)dtype, (unsigned long long)flags, (unsigned long long)(uintptr_t)plan, (unsigned long long)(uintptr_t)b.x,
+        (unsigned long long)(uintptr_t)b.r, (unsigned long long)(uintptr_t)b.p, (unsigned long long)(uintptr_t)b.ap,
+        (unsigned long long)(uintptr_t)b.prod, (unsigned long long)(uintptr_t)b.part_dot, (unsigned long long)(uintptr_t)b.part_rs,
+        (unsigned long long)(uintptr_t)b.scal, (unsigned long long)(uintptr_t)b.err_hist, (unsigned long long)(uintptr_t)b.ss_bsum,
+        (unsigned long long)(uintptr_t)b.ss_csum, (unsigned long long)(uintptr_t)b.ss_rec, (unsigned long long)(uintptr_t)b.ss_mask,
+        (unsigned long long)(uintptr_t)b.ss_stats, (unsigned long long)(uintptr_t)b.mask_rows, (unsigned long long)(uintptr_t)b.mask_ptr,
+        (unsigned long long)(uintptr_t)a.rowmask, (unsigned long long)mask_grid, (unsigned long long)(uintptr_t)A->d_perm,
+        (unsigned long long)(uintptr_t)b.pw_vals, (unsigned long long)b.pw_n, (unsigned long long)(uintptr_t)st};
+    if (key != b.e_key) {
+      for (int q = 0; q < 4; ++q)
+        if (b.e_exec[q]) { hipGraphExecDestroy(b.e_exec[q]); b.e_exec[q] = nullptr; }
+      b.e_key = key;
+    }
+    for (int q = 0; q < 2; ++q)
+      if (!b.e_ev[q]) GLX_HIP(hipEventCreateWithFlags(&b.e_ev[q], hipEventDisableTiming));
+  }
+  auto launch_chunk = [&](int cnt, bool bl0, bool bl1) -> int {
+    if (!use_graphs || cnt < CG_CHUNK) return enqueue_chunk(cnt, bl0, bl1);
+    const int v = (bl0 ? 1 : 0) + (bl1 ? 2 : 0);
+    if (!b.e_exec[v]) {
+      hipGraph_t graph = nullptr;
+      GLX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      const int rc2 = enqueue_chunk(CG_CHUNK, bl0, bl1);
+      const hipError_t e = hipStreamEndCapture(st, &graph);
+      if (rc2) { if (graph) hipGraphDestroy(graph); return rc2; }
+      GLX_HIP(e);
+      const hipError_t e2 = hipGraphInstantiate(&b.e_exec[v], graph, nullptr, nullptr, 0);
+      hipGraphDestroy(graph);
+      GLX_HIP(e2);
+    }
+    GLX_HIP(hipGraphLaunch(b.e_exec[v], st));
+    return GLX_OK;
+  };
+  {
+  // The GPU does not wait for the host: chunk k + 1 is launched before the history of chunk k is looked at (the kernels of iterations
+  // past convergence exit at once and leave "stopped" behind them); two chunks in flight, each with its own page-locked slot.
+  struct Flight { int64_t it0; int cnt; int slot; };
+  Flight fl[2];
+  int nfl = 0, slot = 0;
+  int64_t it = 0;                               // iterations launched
+  const size_t slot_doubles = (size_t)(CG_CHUNK + 1) * stride;
+  while (running > 0 && (it < max_iter || nfl > 0)) {
+    if (it < max_iter && nfl < 2) {
+      const int cnt = (int)std::min<int64_t>(CG_CHUNK, max_iter - it);
+      rc = launch_chunk(cnt, blocks_now[0], blocks_now[1]);
+      if (rc) return rc;
+      GLX_HIP(hipMemcpyAsync(b.h_err + slot * slot_doubles, b.err_hist + stride, (size_t)cnt * stride * 8, hipMemcpyDeviceToHost, st));
+      if (ss_blocks) GLX_HIP(hipMemcpyAsync(b.h_ss + slot * 16, b.ss_stats, 128, hipMemcpyDeviceToHost, st));
+      GLX_HIP(hipEventRecord(b.e_ev[slot], st));
+      fl[nfl].it0 = it;
+      fl[nfl].cnt = cnt;
+      fl[nfl].slot = slot;
+      ++nfl;
+      it += cnt;
+      slot ^= 1;
+      if (nfl < 2 && it < max_iter) continue;
+    }
+    const Flight f = fl[0];
+    fl[0] = fl[1];
+    --nfl;
+    GLX_HIP(hipEventSynchronize(b.e_ev[f.slot]));
+    read_history(b.h_err + f.slot * slot_doubles, f.it0, f.cnt);
     if (ss_blocks && !blocks_forced) {
+      const unsigned long long* hs = b.h_ss + f.slot * 16;
       for (int m = 0; m < 2; ++m) {
         if (!blocks_now[m]) continue;
-        const double by_rec = (double)(b.h_ss[4 * m + 1] - ss_seen[m][1]), by_rows = (double)(b.h_ss[4 * m + 2] - ss_seen[m][2]);
-        for (int q = 0; q < 3; ++q) ss_seen[m][q] = b.h_ss[4 * m + q];
-        const double chains = (double)cnt * ncols;
-        // measured on one MI355X (profiles/r05_cg_forms.txt, r05_cg_blocks_kernel_stats.csv): 0.7 us per block taken through its record,
-        // 3.5 per 256-row block taken row by row (1.7 of additions, the rest its rows arriving: three are fetched ahead per chunk),
-        // 0.6 per chunk of the walk, 14.5 for the two passes in front; the chain 2.4 ns per row
-        const double blocks_us = (by_rec * 0.7 + by_rows * 3.5) / chains + ssw.nchunks * 0.6 + 14.5;
+        const double by_rec = (double)(hs[4 * m + 1] - ss_seen[m][1]), by_rows = (double)(hs[4 * m + 2] - ss_seen[m][2]);
+        for (int q = 0; q < 3; ++q) ss_seen[m][q] = hs[4 * m + q];
+        const double chains = (double)f.cnt * ncols;
+        // measured on one MI355X (profiles/r06_cg_blocks_kernel_stats.csv): 0.7 us per block taken through its record, 1.2 per 256-row
+        // block taken row by row (0.65 of additions -- the chain's 2.4 ns per row --, the rest its rows arriving: three are fetched
+        // ahead per chunk), 0.6 per chunk of the walk, 14.5 for the two passes in front; the chain 2.4 ns per row
+        const double blocks_us = (by_rec * 0.7 + by_rows * 1.2) / chains + ssw.nchunks * 0.6 + 14.5;
         const double chain_us = (double)n * 0.0024;
         if (blocks_us > chain_us) blocks_now[m] = false;
       }
@@ -760,9 +861,10 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     if (rc) return rc;
   }
   GLX_HIP(hipMemcpyAsync(X, b.dense, (size_t)n * C * es, hipMemcpyDeviceToHost, st));
-  if (ss_blocks) GLX_HIP(hipMemcpyAsync(b.h_ss, b.ss_stats, 64, hipMemcpyDeviceToHost, st));
+  if (ss_blocks) GLX_HIP(hipMemcpyAsync(b.h_ss, b.ss_stats, 128, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
-  for (int q = 0; q < 3; ++q) b.ss_last[q] = ss_blocks ? b.h_ss[q] + b.h_ss[4 + q] + b.h_ss[8 + q] : -1;
+  for (int q = 0; q < 3; ++q)     // (the entry point hands out ints: clamped, never negative -- -1 is the chain form's mark)
+    b.ss_last[q] = ss_blocks ? (int)std::min<unsigned long long>(b.h_ss[q] + b.h_ss[4 + q] + b.h_ss[8 + q], 0x7fffffffull) : -1;
   b.ss_last[3] = ss_blocks ? (blocks_now[0] ? 1 : 0) + (blocks_now[1] ? 2 : 0) : -1;
   for (int g = 0; g < ngroups; ++g) {
     if (iters_out) iters_out[g] = (int)iters[g];

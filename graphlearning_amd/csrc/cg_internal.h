@@ -31,8 +31,8 @@ struct CgBufs {
   double *ss_bsum = nullptr, *ss_csum = nullptr;
   char* ss_rec = nullptr;
   unsigned long long* ss_mask = nullptr;
-  int* ss_stats = nullptr;             // [3 modes][4]: blocks taken plain / by record / row by row, per kind of reduction
-  int* h_ss = nullptr;                 // page-locked copy of them
+  unsigned long long* ss_stats = nullptr;   // [3 modes][4]: blocks taken plain / by record / row by row, per kind of reduction (64-bit: 1.6e7 per iteration at the largest sizes)
+  unsigned long long* h_ss = nullptr;       // page-locked copies of them: one per chunk in flight
   int ss_last[4] = {-1, -1, -1, -1};   // of the last reference-order solve: blocks taken plain / by record / row by row, kinds of reduction
                                        // still in block form at its end (bit 0: p.Ap, bit 1: r.r); -1: chain form
   // tolerance mode (cg_fused.hip): partial sums, counters, Dirichlet-row masks, staging, the captured launch sequences
@@ -45,6 +45,12 @@ struct CgBufs {
   double last_stop_margin = INFINITY;                    // of the last tolerance-mode solve (glx_cg_last_stop_margin)
   int h_hist_stride = 0;                                 // the row stride (systems + 1) the mirror's 'not yet' markers were last laid out for
   hipGraphExec_t f_exec[3] = {nullptr, nullptr, nullptr};        // captured chunks of 32, 16 and 4 iterations
+  // reference-order mode (cg.hip): a chunk of CG_CHUNK iterations as ONE captured launch sequence per combination of reduction forms
+  // (bit 0: p.Ap in block form, bit 1: r.r), valid for the solve parameters in e_key; events of the two chunks in flight
+  hipGraphExec_t e_exec[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<unsigned long long> e_key;
+  hipEvent_t e_ev[2] = {nullptr, nullptr};
+  unsigned* e_rowmask = nullptr;                         // Dirichlet rows of every system as bits (the SpMM holds A p at zero there)
   std::vector<unsigned long long> f_key;
   hipEvent_t f_ev[3] = {nullptr, nullptr, nullptr};
   hipStream_t stream = nullptr, side = nullptr;
@@ -81,7 +87,9 @@ struct CgBufs {
     hipFree(rhs_rows); hipFree(out_scale);
     hipFree(f_part1); hipFree(f_part1g); hipFree(f_part2); hipFree(f_tick); hipFree(f_rowmask); hipFree(f_it);
     hipFree(f_stage);
-    hipFree(ss_bsum); hipFree(ss_csum); hipFree(ss_rec); hipFree(ss_mask); hipFree(ss_stats);
+    hipFree(ss_bsum); hipFree(ss_csum); hipFree(ss_rec); hipFree(ss_mask); hipFree(ss_stats); hipFree(e_rowmask);
+    for (int q = 0; q < 4; ++q) if (e_exec[q]) hipGraphExecDestroy(e_exec[q]);
+    for (int q = 0; q < 2; ++q) if (e_ev[q]) hipEventDestroy(e_ev[q]);
     if (h_stage) hipHostFree(h_stage);
     if (h_hist) hipHostFree(h_hist);
     for (int q = 0; q < 3; ++q) if (f_exec[q]) hipGraphExecDestroy(f_exec[q]);
@@ -133,10 +141,11 @@ struct SsWork {
   char* rec;
   double *bsum, *csum;
   unsigned long long* mask;
-  int* stats;                 // [3 modes][4]: blocks taken as plain integers / through their record / row by row (may be null)
+  unsigned long long* stats;  // [3 modes][4]: blocks taken as plain integers / through their record / row by row (may be null)
   int nchunks;
 };
 int glx_seqsum_chunks(int64_t n);
+int glx_seqsum_prepare();
 int glx_seqsum_max_chunks();
 size_t glx_seqsum_rec_bytes(int ncols, int nchunks);
 size_t glx_seqsum_sum_doubles(int ncols, int nchunks, int which);

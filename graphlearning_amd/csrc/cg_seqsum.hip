@@ -13,6 +13,7 @@
 #define GLX_HD __host__ __device__ static inline
 #include "cg_internal.h"
 #include "seqsum_exact.h"
+#include <mutex>
 
 #define SS_MAX_CHUNKS 1024       // flags of one column in LDS (8 KB): n <= 1024 * 64 * SS_BLOCK = 16.7 M rows (cg.hip falls back to the chain above)
 static const int SS_PF = 3;     // blocks the walk may have to add row by row whose rows are fetched one chunk ahead
@@ -216,15 +217,33 @@ __device__ __forceinline__ double ss_unif(double v) { return __longlong_as_doubl
 
 #define SS_RPL (SS_BLOCK / 64)    // rows of one block per lane: row 64 q + lane in register q
 struct SsRows { double v[SS_RPL]; };
-// s += the rows of a block, row after row (rows past n were loaded as +0)
+// s += the rows of a block, row after row (rows past n were loaded as +0): the chain of cg.hip's first reducer.  Register q of lane l
+// holds row 64 q + l; `v_fmac_f64_dpp tot, x, 1.0 row_newbcast:k` adds the value lane k of a DPP row of 16 lanes holds to every lane of
+// that row (x * 1 + tot, fused = the correctly rounded sum), so the 16 rows 64 q + 16 r .. + 15 are first replicated into all four
+// DPP rows (two ds_bpermute per run of 16, independent of the chain and issued ahead of it) and then added by 16 dependent
+// instructions with no cross-lane move in between: 2.4 ns per row like the chain kernel, instead of the 6.7 of a readlane pair + add
+// per row (rounds 5: 1.7 us per block).  Every lane ends with the same sum.
+#define SS_DPP_L(K) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
 __device__ __forceinline__ double ss_add_rows(double s, const SsRows& x) {
-#pragma clang fp contract(off)
+  const int lane = (int)(threadIdx.x & 63);
+  double rep[SS_RPL * 4];
 #pragma unroll
   for (int q = 0; q < SS_RPL; ++q) {
 #pragma unroll
-    for (int j = 0; j < 64; ++j) s = s + ss_rlf(x.v[q], j);
+    for (int r = 0; r < 4; ++r) rep[q * 4 + r] = __shfl(x.v[q], 16 * r + (lane & 15));
   }
-  return ss_unif(s);
+  double tot = s;
+  const double one = 1.0;
+#pragma unroll
+  for (int g = 0; g < SS_RPL * 4; ++g) {
+    // (s_nop 1: a VALU write of the DPP source right in front of the block needs two wait states before a DPP read; the assembler block
+    // is opaque to the hazard recogniser)
+    asm volatile("s_nop 1\n\t" SS_DPP_L(0) SS_DPP_L(1) SS_DPP_L(2) SS_DPP_L(3) SS_DPP_L(4) SS_DPP_L(5) SS_DPP_L(6) SS_DPP_L(7) SS_DPP_L(8)
+                     SS_DPP_L(9) SS_DPP_L(10) SS_DPP_L(11) SS_DPP_L(12) SS_DPP_L(13) SS_DPP_L(14) SS_DPP_L(15)
+                 : "+v"(tot)
+                 : "v"(rep[g]), "v"(one));
+  }
+  return ss_unif(tot);
 }
 
 // ss_apply_record (seqsum_exact.h) on the record lane f holds, its fields fetched as they are needed
@@ -295,12 +314,20 @@ __device__ __forceinline__ SsLane ss_ring_fetch(const unsigned long long* r64, c
 template <int MODE>
 __global__ __launch_bounds__(256) void ss_walk_kernel(const double* __restrict__ prod, int64_t n, int nchunks, int ncols_all, int C,
                                                       CgScalars sc, int it, double tol, SsSoA soa,
-                                                      const unsigned long long* __restrict__ badmask, int* __restrict__ stats) {
+                                                      const unsigned long long* __restrict__ badmask, unsigned long long* __restrict__ stats) {
 #pragma clang fp contract(off)
   extern __shared__ unsigned long long ss_lds[];
   if (MODE != 2 && !cg_any_active(sc, it, tol)) return;
   const int col = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool live = col < ncols_all && (MODE == 2 || col >= C || cg_col_active(sc, it, tol, col));
+  if (col >= C) {                          // a padding column of the last column block: its products are zeros
+    if (col < ncols_all && threadIdx.x == 0) {
+      if (MODE == 0) sc.alpha[col] = 0.0;
+      if (MODE == 1) sc.beta[col] = 0.0;
+      if (MODE != 0) sc.rsold[col] = 0.0;
+    }
+    return;
+  }
+  const bool live = MODE == 2 || cg_col_active(sc, it, tol, col);
   if (!live) return;
   unsigned long long* ring64 = ss_lds;                                            // [2][4][SS_RING64][64]
   int* ring32 = (int*)(ss_lds + (size_t)2 * 4 * SS_RING64 * 64);                  // [2][4][SS_RING32][64]
@@ -428,9 +455,9 @@ __global__ __launch_bounds__(256) void ss_walk_kernel(const double* __restrict__
   const double tot = s;
   if (threadIdx.x == 0) {
     if (stats) {
-      atomicAdd(&stats[0], n_plain);
-      atomicAdd(&stats[1], n_rec);
-      atomicAdd(&stats[2], n_rows);
+      atomicAdd(&stats[0], (unsigned long long)n_plain);
+      atomicAdd(&stats[1], (unsigned long long)n_rec);
+      atomicAdd(&stats[2], (unsigned long long)n_rows);
     }
     const int gc = col;
     if (MODE == 0) {
@@ -456,8 +483,6 @@ static int ss_launch(const double* prod, int64_t n, int ncols_all, int C, const 
                      (const double*)w.csum, soa, (unsigned char*)w.mask);
   GLX_HIP(hipGetLastError());
   const size_t lds = ss_walk_lds_bytes(w.nchunks);
-  // (the same bound whatever the solve: concurrent solves on other operators set it too, and none may lower it under a launch in flight)
-  GLX_HIP(hipFuncSetAttribute((const void*)ss_walk_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_walk_lds_bytes(SS_MAX_CHUNKS)));
   hipLaunchKernelGGL(ss_walk_kernel<MODE>, dim3((unsigned)ncols_all), dim3(256), lds, st, prod, n, w.nchunks, ncols_all, C, sc, it, tol, soa,
                      (const unsigned long long*)w.mask, w.stats ? w.stats + 4 * MODE : nullptr);
   GLX_HIP(hipGetLastError());
@@ -469,6 +494,23 @@ int glx_seqsum_run(int mode, const double* prod, int64_t n, int ncols_all, int C
   return mode == 0 ? ss_launch<0>(prod, n, ncols_all, C, sc, it, tol, w, st)
        : mode == 1 ? ss_launch<1>(prod, n, ncols_all, C, sc, it, tol, w, st)
                    : ss_launch<2>(prod, n, ncols_all, C, sc, it, tol, w, st);
+}
+
+// The walk's dynamic LDS bound: the same whatever the solve (concurrent solves on other operators set it too, and none may lower it under
+// a launch in flight), set once per process and device -- before any launch sequence is captured (cg.hip), not inside one.
+int glx_seqsum_prepare() {
+  static std::mutex mu;
+  static std::vector<int> done;
+  int dev = 0;
+  GLX_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  if (std::find(done.begin(), done.end(), dev) != done.end()) return GLX_OK;
+  const int lds = (int)ss_walk_lds_bytes(SS_MAX_CHUNKS);
+  GLX_HIP(hipFuncSetAttribute((const void*)ss_walk_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  GLX_HIP(hipFuncSetAttribute((const void*)ss_walk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  GLX_HIP(hipFuncSetAttribute((const void*)ss_walk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  done.push_back(dev);
+  return GLX_OK;
 }
 
 int glx_seqsum_max_chunks() { return SS_MAX_CHUNKS; }

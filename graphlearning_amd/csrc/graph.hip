@@ -52,6 +52,9 @@ struct PoolState {
   size_t cached = 0;
 };
 static PoolState& pool() { static PoolState* p = new PoolState(); return *p; }   // never destroyed: outlives the HIP runtime's teardown
+// glx_pool_set_enabled(0): every block straight from / back to the runtime and no idle work sets -- the ablation switch of the
+// randomised soak (a result that changes with it names a buffer handed on while still in use) and of tests/test_gpu_switches.py
+static bool g_pool_enabled = true;
 
 static size_t pool_class(size_t bytes) {
   size_t c = 4096;
@@ -162,12 +165,35 @@ void glx_work_release(glx_work* w) {
   {
     std::lock_guard<std::mutex> lk(wc.mu);
     auto& v = wc.idle[w->device];
-    if (v.size() < 8) {
+    if (g_pool_enabled && v.size() < 8) {
       v.push_back(w);
       return;
     }
   }
   work_destroy(w);
+}
+
+extern "C" int glx_pool_set_enabled(int enabled) {
+  g_pool_enabled = enabled != 0;
+  if (!g_pool_enabled) {             // what is idle now goes back to the runtime (blocks in use follow when they are released)
+    std::vector<void*> idle;
+    std::vector<glx_work*> sets;
+    {
+      PoolState& ps = pool();
+      std::lock_guard<std::mutex> lk(ps.mu);
+      for (auto& kv : ps.idle) idle.push_back(kv.second);
+      ps.idle.clear();
+      ps.cached = 0;
+    }
+    {
+      WorkCache& wc = work_cache();
+      std::lock_guard<std::mutex> lk(wc.mu);
+      for (auto& kv : wc.idle) { sets.insert(sets.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
+    }
+    for (void* p : idle) hipFree(p);
+    for (glx_work* w : sets) work_destroy(w);
+  }
+  return GLX_OK;
 }
 
 int glx_pool_alloc(void** out, size_t bytes) {
@@ -217,7 +243,7 @@ void glx_pool_free(void* p) {
     if (it == ps.live.end()) { hipFree(p); return; }
     key = it->second;
     ps.live.erase(it);
-    if (key.second <= POOL_BLOCK_MAX && ps.cached + key.second <= POOL_CAP) {
+    if (g_pool_enabled && key.second <= POOL_BLOCK_MAX && ps.cached + key.second <= POOL_CAP) {
       ps.idle.insert({key, p});
       ps.cached += key.second;
       return;

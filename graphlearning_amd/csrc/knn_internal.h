@@ -46,22 +46,10 @@ constexpr int tile_nsub(int DH, int KP) {
 
 // bf16 filter: refs per tile = 32 * NSUB.  Measured (one box): 16-32 features: NSUB 2 (config 2: 1.88 vs 2.12 ms, config 3: 2.74 vs
 // 3.09 ms); 64 features: NSUB 1 -- a 17 KB tile lets three workgroups share a CU (n = 1e6: 376 vs 401 ms)
-#ifndef GLX_KNN_NSUB_LOW
-#define GLX_KNN_NSUB_LOW 2      // (build-time knobs of the A/B runs in profiles/r05_knn_tile_pmc.txt)
-#endif
-#ifndef GLX_KNN_REGL_LOW
-#define GLX_KNN_REGL_LOW 0
-#endif
-#ifndef GLX_KNN_TWO_SETS
-#define GLX_KNN_TWO_SETS 0      // two query sets per wavefront (knn_tile_bf16.h, NQ = 2): measured 18-25 % SLOWER, kept as a build option
-#endif
-#ifndef GLX_KNN_REGL_WAVES
-#define GLX_KNN_REGL_WAVES 4
-#endif
-constexpr int bf16_nsub(int NKB, int KP) { return (NKB >= 4 || KP >= 32) ? 1 : GLX_KNN_NSUB_LOW; }
+constexpr int bf16_nsub(int NKB, int KP) { return (NKB >= 4 || KP >= 32) ? 1 : 2; }
 // 8-entry lists in registers where that buys a fourth workgroup per CU (d = 49 .. 64: 122 registers, 34 KB of LDS; measured
 // +4 % at n = 3e5 .. 1e6; at fewer feature blocks the registers spill, at more the kernel is register-bound anyway)
-constexpr bool bf16_reglists(int NKB, int KP) { return KP == 8 && (NKB == 4 || GLX_KNN_REGL_LOW != 0); }
+constexpr bool bf16_reglists(int NKB, int KP) { return KP == 8 && NKB == 4; }
 
 // device buffers of one pass of the search (pooled blocks; the destructor drains the stream first)
 struct KnnBufs {

@@ -477,3 +477,56 @@ int knn_launch_fallback(const KnnBufs& b, int64_t n, int d, int k, int64_t q0, s
   GLX_HIP(hipGetLastError());
   return GLX_OK;
 }
+
+
+// ---- distance to the nearest of a few reference rows (graph.reweight(method='properly'), reference graph.py:455-457) ----------------
+// `Xtree = cKDTree(X[idx]); D, J = Xtree.query(X)`: for every row of X the euclidean distance to the nearest labelled row -- m labelled
+// rows against n, all pairs, with cKDTree's accumulation pattern and its final square root, so D is the reference's bit for bit.
+// One thread per query row, the reference rows staged through LDS in pieces.
+__global__ __launch_bounds__(256) void knn_nearest_dist_kernel(const double* __restrict__ X, int64_t n, int d, const double* __restrict__ R, int64_t m,
+                                                               int piece, double* __restrict__ out) {
+  extern __shared__ double s_ref[];       // [piece][d]
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const double* xq = X + (q < n ? q : n - 1) * d;
+  double best = INFINITY;
+  for (int64_t j0 = 0; j0 < m; j0 += piece) {
+    const int cnt = (int)(m - j0 < piece ? m - j0 : piece);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt * d; i += 256) s_ref[i] = R[j0 * d + i];
+    __syncthreads();
+    for (int j = 0; j < cnt; ++j) {
+      const double dd = sqdist_exact(xq, s_ref + (size_t)j * d, d);
+      best = dd < best ? dd : best;
+    }
+  }
+  if (q < n) out[q] = sqrt(best);
+}
+
+extern "C" int glx_nearest_dist(const double* X, int64_t n, int d, const int64_t* idx, int64_t m, double* dist_out, int device) {
+  GLX_CHECK(X && idx && dist_out && n >= 1 && d >= 1 && m >= 1, GLX_EINVAL, "glx_nearest_dist: bad argument");
+  GLX_CHECK((size_t)d * 8 <= 48 * 1024, GLX_EUNSUPPORTED, "glx_nearest_dist: %d features exceed one row of the LDS stage", d);
+  for (int64_t j = 0; j < m; ++j) GLX_CHECK(idx[j] >= 0 && idx[j] < n, GLX_EINVAL, "glx_nearest_dist: row %lld out of range", (long long)idx[j]);
+  GLX_HIP(hipSetDevice(device));
+  std::vector<double> R((size_t)m * d);
+  for (int64_t j = 0; j < m; ++j) memcpy(R.data() + (size_t)j * d, X + (size_t)idx[j] * d, (size_t)d * 8);
+  double *dX = nullptr, *dR = nullptr, *dO = nullptr;
+  int rc = glx_pool_alloc((void**)&dX, (size_t)n * d * 8);
+  if (!rc) rc = glx_pool_alloc((void**)&dR, R.size() * 8);
+  if (!rc) rc = glx_pool_alloc((void**)&dO, (size_t)n * 8);
+  if (!rc) {
+    const int piece = (int)std::max<int64_t>(1, std::min<int64_t>(m, (48 * 1024 / 8) / d));
+    hipError_t e = hipMemcpy(dX, X, (size_t)n * d * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dR, R.data(), R.size() * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(knn_nearest_dist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)piece * d * 8, 0, (const double*)dX, n, d,
+                         (const double*)dR, m, piece, dO);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(dist_out, dO, (size_t)n * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { glx_set_error("glx_nearest_dist: %s", hipGetErrorString(e)); rc = GLX_EHIP; }
+  }
+  glx_pool_free(dX);
+  glx_pool_free(dR);
+  glx_pool_free(dO);
+  return rc;
+}

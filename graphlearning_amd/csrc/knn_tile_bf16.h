@@ -20,16 +20,11 @@
 // an unsorted list with the maximum tracked; candidates below the lane's threshold are APPENDED to the lane's LDS slots
 // (cheap, even when only a few lanes have one) and merged by the whole wavefront in lockstep when any lane's slots run low.
 // CAT (NKB = 2 only): the rows are the concatenated operands of knn_prep_bf16_cat_kernel, refs from Xb, queries from Xq.
-// NQ = 2 (-DGLX_KNN_TWO_SETS=1; all-pairs search, 8-entry lists): every wavefront serves TWO sets of 32 queries -- the structural change
-// DESIGN section 9 named at the end of round 4.  A ref fragment read from LDS feeds two MFMAs, a staged tile and its barrier are paid
-// once per 16 instead of 8 MFMAs of a wavefront, the two accumulator sets are independent chains; the lists of both sets live in
-// registers (223 VGPRs, no spills, two waves per SIMD).  MEASURED (round 5, profiles/r05_knn_tile_pmc.txt): identical lists, and 18-25 %
-// SLOWER than one set (config 2: 0.968 vs 0.777 ms; 120 000 x 20: 3.03 vs 2.57 ms): the selection behind the contraction doubles per
-// wavefront while half as many wavefronts are there to hide it.  Neither was occupancy the bound -- lists in registers with three
-// (-2 %) or four (+11 %, 32-ref tiles) resident waves instead of 2.6 --, nor the barrier count alone (a barrier per 32 refs: +8 %).
-// Off by default; kept as a build option so that the experiment can be repeated.
-template <int NKB, int KP, int NSUB, int CAT = 0, bool RUNS = false, int NQ = 1>   // CAT: 1 concatenated operands, 2 also the norm folded into them
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ == 2 ? 2 : (bf16_reglists(NKB, KP) ? (NKB == 4 ? 4 : GLX_KNN_REGL_WAVES) : 1), 4)))
+// (Round 5 measured a variant with TWO sets of 32 queries per wavefront -- one ref-fragment read feeding two MFMAs, 16 MFMAs per barrier,
+// both sets' lists in registers: identical lists, 18-25 % SLOWER, profiles/r05_knn_tile_pmc.txt.  The experiment is closed; the variant
+// is kept as scripts/probes/knn_two_sets_experiment.patch.)
+template <int NKB, int KP, int NSUB, int CAT = 0, bool RUNS = false>   // CAT: 1 concatenated operands, 2 also the norm folded into them
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(bf16_reglists(NKB, KP) ? 4 : 1, 4)))
 void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned short* __restrict__ Xq, const float* __restrict__ nrm, int64_t n,
                           int64_t q_begin, int64_t q_end, int nsplit, float* __restrict__ cand_d, int* __restrict__ cand_i,
                           int* __restrict__ gtau, const int* __restrict__ runs, const int* __restrict__ nruns, int maxruns) {
@@ -37,7 +32,6 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
   // [runs[2 r], runs[2 r + 1]), r < nruns[block] (ascending, disjoint; knn_runs_kernel), not all of them
   // nsplit = the tile stride of a ref range; the number of ranges is the grid's y extent (equal in the search proper; the
   // seeding pre-pass runs ONE range with a larger stride: every 8th tile, say -- a sample of the refs)
-  static_assert(NQ == 1 || (NQ == 2 && KP == 8 && !RUNS), "two query sets per wavefront: the all-pairs search with 8-entry lists");
   constexpr int KPAD = 16 * NKB;
   constexpr int BR = 32 * NSUB;
   constexpr int ROWB = 4 * KPAD + 16;                  // bytes per ref row in LDS: hi | lo, +16 so that 16 rows cover all 64 banks
@@ -47,47 +41,44 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
   extern __shared__ __attribute__((aligned(16))) char smem_b[];
   char* tile = smem_b;                                  // [2][BR][ROWB]
   float* rn = (float*)(smem_b + 2 * BR * ROWB);         // [2][BR]
-  constexpr bool REGL = bf16_reglists(NKB, KP) || NQ == 2;         // the lists in registers: LDS then holds tile + append slots only
+  constexpr bool REGL = bf16_reglists(NKB, KP);       // the lists in registers: LDS then holds tile + append slots only
   constexpr int LROWS = REGL ? KBUF : KP + KBUF;
-  // slot a of set s: ld[s][(KP + a) * 256 + tid] (rows [0, KP) do not exist with register lists)
-  float* ld_base = rn + 2 * BR - (REGL ? KP * 256 : 0);
-  int* li_base = (int*)(rn + 2 * BR + NQ * LROWS * 256) - (REGL ? KP * 256 : 0);
-  float lv[NQ][REGL ? 8 : 1];
-  int lx[NQ][REGL ? 8 : 1];
+  // slot a: ld[(KP + a) * 256 + tid] (rows [0, KP) do not exist with register lists)
+  float* ld = rn + 2 * BR - (REGL ? KP * 256 : 0);
+  int* li = (int*)(rn + 2 * BR + LROWS * 256) - (REGL ? KP * 256 : 0);
+  float lv[REGL ? 8 : 1];
+  int lx[REGL ? 8 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
   const int64_t qb = blockIdx.x, sp = blockIdx.y;
-  int64_t q[NQ], qc[NQ];
+  int64_t q, qc;
   // query fragments: B[k][j], lane holds k = 8h .. 8h+7 of every block, hi and lo
-  bf16x8 bh[NQ][NKB], bl[NQ][NKB];
-  float qn[NQ];
-#pragma unroll
-  for (int s = 0; s < NQ; ++s) {
-    q[s] = q_begin + qb * (BQ * NQ) + (wave * NQ + s) * 32 + j;
-    qc[s] = q[s] < q_end ? q[s] : q_end - 1;
-    const uint4* qrow = (const uint4*)((CAT ? Xq : Xb) + qc[s] * 2 * KPAD);
+  bf16x8 bh[NKB], bl[NKB];
+  float qn;
+  {
+    q = q_begin + qb * BQ + wave * 32 + j;
+    qc = q < q_end ? q : q_end - 1;
+    const uint4* qrow = (const uint4*)((CAT ? Xq : Xb) + qc * 2 * KPAD);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      bh[s][kb] = __builtin_bit_cast(bf16x8, qrow[kb * 2 + h]);
-      bl[s][kb] = __builtin_bit_cast(bf16x8, qrow[KPAD / 8 + kb * 2 + h]);
+      bh[kb] = __builtin_bit_cast(bf16x8, qrow[kb * 2 + h]);
+      bl[kb] = __builtin_bit_cast(bf16x8, qrow[KPAD / 8 + kb * 2 + h]);
     }
     // a use in front of the loop: the compiler waits for these loads HERE.  Left pending into the loop they make its
     // wait-counter pass put decreasing vmcnt waits in front of the MFMAs of EVERY tile, which drain the tile's own staging
     // loads (issued just before) instead of letting them travel under the matrix work
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      const uint4 a = __builtin_bit_cast(uint4, bh[s][kb]), c = __builtin_bit_cast(uint4, bl[s][kb]);
+      const uint4 a = __builtin_bit_cast(uint4, bh[kb]), c = __builtin_bit_cast(uint4, bl[kb]);
       asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w));
     }
-    qn[s] = nrm[qc[s]];
-    asm volatile("" ::"v"(qn[s]));
+    qn = nrm[qc];
+    asm volatile("" ::"v"(qn));
   }
 #pragma unroll
-  for (int s = 0; s < NQ; ++s)
-#pragma unroll
     for (int p = 0; p < KP; ++p) {
-      if constexpr (REGL) { lv[s][p] = INFINITY; lx[s][p] = -1; }
-      else { ld_base[p * 256 + tid] = INFINITY; li_base[p * 256 + tid] = -1; }
+      if constexpr (REGL) { lv[p] = INFINITY; lx[p] = -1; }
+      else { ld[p * 256 + tid] = INFINITY; li[p * 256 + tid] = -1; }
     }
   // thresholds are kept WITHOUT the query's norm: values are |r|^2 - 2 q.r.  gtau[query]: the smallest threshold any of the
   // query's lists has published (an ordered-int image of the float) -- at the start the seed of the pre-pass (knn_seed_kernel),
@@ -97,12 +88,8 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
     best ^= (best >> 31) & 0x7fffffff;
     return __int_as_float(best);
   };
-  float tau[NQ];
-#pragma unroll
-  for (int s = 0; s < NQ; ++s) {
-    tau[s] = INFINITY;
-    if (q[s] < q_end) tau[s] = gtau_read(q[s]);
-  }
+  float tau = INFINITY;
+  if (q < q_end) tau = gtau_read(q);
 
   const int64_t ntiles = (n + BR - 1) / BR;
   // ref range `sp` = the tiles sp, sp + nsplit, sp + 2 nsplit, ...: INTERLEAVED, not a contiguous block of refs.  Data often comes
@@ -140,7 +127,7 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
     t0 = next_tile(-nsplit);
   } else {
     left = t1 > (int)sp ? (t1 - (int)sp + nsplit - 1) / nsplit : 0;
-    const int own = (int)((q_begin + qb * (BQ * NQ) + (BQ * NQ) / 2 - BQ / 2) / BR);          // the tile in the middle of the block's rows
+    const int own = (int)((q_begin + qb * BQ) / BR);          // the tile in the middle of the block's rows
     int j0 = own > (int)sp ? (own - (int)sp + nsplit - 1) / nsplit : 0;
     if (j0 >= left) j0 = 0;
     t0 = (int)sp + j0 * nsplit;
@@ -172,19 +159,14 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
     }
     if (CAT != 2 && tid < BR) rn[buf * BR + tid] = pre_rn;
   };
-  int cnt[NQ];
-  float tau_own[NQ];
+  int cnt = 0;
+  float tau_own = INFINITY;
   int pmax = 0;
-#pragma unroll
-  for (int s = 0; s < NQ; ++s) { cnt[s] = 0; tau_own[s] = INFINITY; }
-  auto compact = [&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    float* ld = ld_base + s * LROWS * 256;
-    int* li = li_base + s * LROWS * 256;
-    for (int a = 0; __any(a < cnt[s]); ++a) {      // (a ballot per step instead of a cross-lane maximum up front: 6 ds_bpermute round trips)
-      if (a < cnt[s]) {
+  auto compact = [&]() {
+    for (int a = 0; __any(a < cnt); ++a) {      // (a ballot per step instead of a cross-lane maximum up front: 6 ds_bpermute round trips)
+      if (a < cnt) {
         const float v = ld[(KP + a) * 256 + tid];
-        if (v < tau_own[s]) {
+        if (v < tau_own) {
           if constexpr (REGL) {
             // the candidate replaces the (first) largest entry; select chains instead of indexed LDS accesses
             const int vi = li[(KP + a) * 256 + tid];
@@ -192,13 +174,13 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
             float m2 = -INFINITY;
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-              const bool hit = !placed && lv[s][p] == tau_own[s];
-              lv[s][p] = hit ? v : lv[s][p];
-              lx[s][p] = hit ? vi : lx[s][p];
+              const bool hit = !placed && lv[p] == tau_own;
+              lv[p] = hit ? v : lv[p];
+              lx[p] = hit ? vi : lx[p];
               placed = placed || hit;
-              m2 = fmaxf(m2, lv[s][p]);
+              m2 = fmaxf(m2, lv[p]);
             }
-            tau_own[s] = m2;
+            tau_own = m2;
           } else {
             ld[pmax * 256 + tid] = v;
             li[pmax * 256 + tid] = li[(KP + a) * 256 + tid];
@@ -209,27 +191,27 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
               const float x = ld[p * 256 + tid];
               if (x > m2) { m2 = x; pm = p; }
             }
-            tau_own[s] = m2;
+            tau_own = m2;
             pmax = pm;
           }
         }
       }
     }
-    cnt[s] = 0;
+    cnt = 0;
     // lanes l and l^32 serve the same query (same |q|^2 offset); never above what is already known (the seed, published thresholds)
-    const float tau_was = tau[s];
-    tau[s] = fminf(tau[s], fminf(tau_own[s], __shfl_xor(tau_own[s], 32)));
+    const float tau_was = tau;
+    tau = fminf(tau, fminf(tau_own, __shfl_xor(tau_own, 32)));
     // the query's lists of the OTHER ref ranges run in other workgroups: the smallest threshold any of them has reached is
     // published per query (atomicMin on the ordered-int image) and adopted here.  Sound for the same reason the pair's
     // minimum is: whatever a list rejects lies above the smallest FINAL threshold of the query's lists, which is what the
     // acceptance test of the re-rank compares with the exact k-th distance.
-    if (tau[s] < tau_was && q[s] < q_end) {       // (only a threshold that moved: the atomic's round trip is a stall of the whole wavefront)
-      int key = __float_as_int(tau[s]);
+    if (tau < tau_was && q < q_end) {       // (only a threshold that moved: the atomic's round trip is a stall of the whole wavefront)
+      int key = __float_as_int(tau);
       key ^= (key >> 31) & 0x7fffffff;
-      const int old = atomicMin(&gtau[q[s] - q_begin], key);
+      const int old = atomicMin(&gtau[q - q_begin], key);
       int best = min(old, key);
       best ^= (best >> 31) & 0x7fffffff;
-      tau[s] = fminf(tau[s], __int_as_float(best));
+      tau = fminf(tau, __int_as_float(best));
     }
   };
   // The staging pipeline is two tiles deep: at the top of the iteration of tile t the registers hold tile t+1 (loaded during the
@@ -269,18 +251,15 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
     if (has_nn) stage_load(tnn);
     // (every lane reads -- rows past q_end their clamped query's --: a scalar branch, no exec-mask bookkeeping per tile)
     if ((it & 15) == 15) {
-#pragma unroll
-      for (int s = 0; s < NQ; ++s) tau[s] = fminf(tau[s], gtau_read(qc[s]));
+      tau = fminf(tau, gtau_read(qc));
     }
     const char* tl = tile + buf * BR * ROWB;
     const float* rnb = rn + buf * BR;
-    f32x16 acc[NQ][NSUB];
+    f32x16 acc[NSUB];
 #pragma unroll
-    for (int s = 0; s < NQ; ++s)
+    for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[s][sub][e] = 0.f;     // (the first MFMA of a chain takes the constant 0 as its C operand)
+      for (int e = 0; e < 16; ++e) acc[sub][e] = 0.f;     // (the first MFMA of a chain takes the constant 0 as its C operand)
     // the tile's norms, read IN FRONT of the contraction: behind it (where they are used) every one of the 4 NSUB reads was a
     // round trip of its own -- ds_read_b128, s_waitcnt lgkmcnt(0), four fmas, next read -- with the matrix pipe idle
     float4 r4s[CAT != 2 ? NSUB : 1][4];
@@ -298,15 +277,14 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
         const char* rowp = tl + (sub * 32 + j) * ROWB + (kb * 16 + 8 * h) * 2;
         const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)rowp);
         const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(rowp + 2 * KPAD));
-#pragma unroll
-        for (int s = 0; s < NQ; ++s) {       // (one fragment read, NQ independent accumulator chains)
+        {
           if constexpr (CAT) {     // fragments kb and 2 + kb of the one concatenated contraction
-            acc[s][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s][kb], acc[s][sub], 0, 0, 0);
-            acc[s][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl[s][kb], acc[s][sub], 0, 0, 0);
+            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kb], acc[sub], 0, 0, 0);
+            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl[kb], acc[sub], 0, 0, 0);
           } else {
-            acc[s][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s][kb], acc[s][sub], 0, 0, 0);
-            acc[s][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s][kb], acc[s][sub], 0, 0, 0);
-            acc[s][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s][kb], acc[s][sub], 0, 0, 0);
+            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kb], acc[sub], 0, 0, 0);
+            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kb], acc[sub], 0, 0, 0);
+            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[kb], acc[sub], 0, 0, 0);
           }
         }
       }
@@ -314,10 +292,7 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
     // selection on value = |r|^2 - 2 q.r (element e of sub-tile `sub` is ref sub*32 + (e&3) + 8*(e>>2) + 4h, query j): per group
     // of 4 elements an extremum first, so that groups without a candidate in any lane cost one compare (with 64 lanes per
     // wavefront SOME lane has a candidate in almost every tile)
-    auto select = [&](auto sc) {
-      constexpr int s = decltype(sc)::value;
-      float* ld = ld_base + s * LROWS * 256;
-      int* li = li_base + s * LROWS * 256;
+    auto select = [&]() {
       float m4[NSUB][4];
       float m = INFINITY;
 #pragma unroll
@@ -328,14 +303,14 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
             // (written as ONE chain ending in +inf: two v_min3_f32 on the raw accumulators.  A two-input minimum of raw MFMA results
             // costs a v_max_f32 x, x per input first -- the compiler quiets possible signalling NaNs for v_min_f32, not for
             // v_min3_f32: 37 -> 20 vector instructions per wave-tile for this reduction)
-            m4[sub][eg] = fminf(fminf(fminf(fminf(acc[s][sub][eg * 4 + 0], acc[s][sub][eg * 4 + 1]), acc[s][sub][eg * 4 + 2]), acc[s][sub][eg * 4 + 3]), INFINITY);
+            m4[sub][eg] = fminf(fminf(fminf(fminf(acc[sub][eg * 4 + 0], acc[sub][eg * 4 + 1]), acc[sub][eg * 4 + 2]), acc[sub][eg * 4 + 3]), INFINITY);
           } else {
             const float4 r4 = r4s[sub][eg];
-            acc[s][sub][eg * 4 + 0] = fmaf(-2.f, acc[s][sub][eg * 4 + 0], r4.x);
-            acc[s][sub][eg * 4 + 1] = fmaf(-2.f, acc[s][sub][eg * 4 + 1], r4.y);
-            acc[s][sub][eg * 4 + 2] = fmaf(-2.f, acc[s][sub][eg * 4 + 2], r4.z);
-            acc[s][sub][eg * 4 + 3] = fmaf(-2.f, acc[s][sub][eg * 4 + 3], r4.w);
-            m4[sub][eg] = fminf(fminf(acc[s][sub][eg * 4 + 0], acc[s][sub][eg * 4 + 1]), fminf(acc[s][sub][eg * 4 + 2], acc[s][sub][eg * 4 + 3]));
+            acc[sub][eg * 4 + 0] = fmaf(-2.f, acc[sub][eg * 4 + 0], r4.x);
+            acc[sub][eg * 4 + 1] = fmaf(-2.f, acc[sub][eg * 4 + 1], r4.y);
+            acc[sub][eg * 4 + 2] = fmaf(-2.f, acc[sub][eg * 4 + 2], r4.z);
+            acc[sub][eg * 4 + 3] = fmaf(-2.f, acc[sub][eg * 4 + 3], r4.w);
+            m4[sub][eg] = fminf(fminf(acc[sub][eg * 4 + 0], acc[sub][eg * 4 + 1]), fminf(acc[sub][eg * 4 + 2], acc[sub][eg * 4 + 3]));
             m = fminf(m, m4[sub][eg]);
           }
         }
@@ -343,29 +318,28 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) m = fminf(fminf(fminf(fminf(m, m4[sub][0]), m4[sub][1]), m4[sub][2]), m4[sub][3]);
       }
-      if (__any(m < tau[s])) {
+      if (__any(m < tau)) {
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
           for (int eg = 0; eg < 4; ++eg) {
-            if (__any(m4[sub][eg] < tau[s])) {       // (the guard per group of four: 438 -> 394 ms at n = 1e6)
+            if (__any(m4[sub][eg] < tau)) {       // (the guard per group of four: 438 -> 394 ms at n = 1e6)
 #pragma unroll
               for (int e = eg * 4; e < eg * 4 + 4; ++e) {
-                const float v = acc[s][sub][e];
-                if (v < tau[s]) {
-                  ld[(KP + cnt[s]) * 256 + tid] = v;
-                  li[(KP + cnt[s]) * 256 + tid] = t * BR + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                  ++cnt[s];
+                const float v = acc[sub][e];
+                if (v < tau) {
+                  ld[(KP + cnt) * 256 + tid] = v;
+                  li[(KP + cnt) * 256 + tid] = t * BR + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                  ++cnt;
                 }
               }
-              if (__any(cnt[s] > KBUF - 4)) compact(sc);
+              if (__any(cnt > KBUF - 4)) compact();
             }
           }
         }
       }
     };
-    select(std::integral_constant<int, 0>{});
-    if constexpr (NQ == 2) select(std::integral_constant<int, 1>{});
+    select();
     __syncthreads();
     buf ^= 1;
     t = RUNS ? (has_next ? tn : t1) : tn;
@@ -373,22 +347,18 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
     has_next = has_nn;
     ++it;
   }
-  compact(std::integral_constant<int, 0>{});
-  if constexpr (NQ == 2) compact(std::integral_constant<int, 1>{});
-#pragma unroll
-  for (int s = 0; s < NQ; ++s) {
-    if (q[s] < q_end) {
+  compact();
+  {
+    if (q < q_end) {
       const int64_t lists = (int64_t)gridDim.y * 2;
-      const int64_t base = ((q[s] - q_begin) * lists + sp * 2 + h) * KP;
-      const float* ld = ld_base + s * LROWS * 256;
-      const int* li = li_base + s * LROWS * 256;
+      const int64_t base = ((q - q_begin) * lists + sp * 2 + h) * KP;
 #pragma unroll
       for (int p = 0; p < KP; ++p) {
         if constexpr (REGL) {
-          cand_d[base + p] = lv[s][p] + qn[s];                 // back to squared distances (inf stays inf)
-          cand_i[base + p] = lx[s][p];
+          cand_d[base + p] = lv[p] + qn;                 // back to squared distances (inf stays inf)
+          cand_i[base + p] = lx[p];
         } else {
-          cand_d[base + p] = ld[p * 256 + tid] + qn[s];
+          cand_d[base + p] = ld[p * 256 + tid] + qn;
           cand_i[base + p] = li[p * 256 + tid];
         }
       }
@@ -396,27 +366,11 @@ void knn_tile_bf16_kernel(const unsigned short* __restrict__ Xb, const unsigned 
   }
 }
 
-// two query sets per wavefront: the all-pairs search with 8-entry lists and operands of at most 32 features (more features, longer
-// lists: the registers of a second set are not there; the cell-pruned search: its runs are per 128-query block)
-constexpr bool bf16_two_sets(int NKB, int KP) { return GLX_KNN_TWO_SETS != 0 && KP == 8 && NKB <= 2; }
-
 template <int NKB, int KP, int CAT = 0>
 static int launch_tile_bf16(const KnnBufs& b, int64_t n, int64_t q0, int64_t q1, int nsplit, hipStream_t st, bool seed) {
   constexpr int NSUB = bf16_nsub(NKB, KP);
   constexpr int BR = 32 * NSUB;
   constexpr int ROWB = 4 * 16 * NKB + 16;
-  if constexpr (bf16_two_sets(NKB, KP)) {
-    if (!b.runs && !seed) {
-      const size_t shm2 = (size_t)2 * BR * ROWB + (size_t)2 * BR * 4 + (size_t)2 * KBUF * 256 * 8;
-      const dim3 grid2((unsigned)((q1 - q0 + 2 * BQ - 1) / (2 * BQ)), (unsigned)nsplit);
-      GLX_HIP(hipFuncSetAttribute((const void*)knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
-      hipLaunchKernelGGL((knn_tile_bf16_kernel<NKB, KP, NSUB, CAT, false, 2>), grid2, dim3(256), shm2, st, (const unsigned short*)b.Xb,
-                         (const unsigned short*)(CAT ? b.Xq : b.Xb), (const float*)b.nrm, n, q0, q1, nsplit, b.cand_d, b.cand_i, b.gtau,
-                         (const int*)nullptr, (const int*)nullptr, 0);
-      GLX_HIP(hipGetLastError());
-      return GLX_OK;
-    }
-  }
   const size_t shm = (size_t)2 * BR * ROWB + (size_t)2 * BR * 4 + (size_t)(bf16_reglists(NKB, KP) ? KBUF : KP + KBUF) * 256 * 8;
   GLX_CHECK(shm <= 160 * 1024, GLX_EUNSUPPORTED, "glx_knn_bruteforce: bf16 filter needs %zu bytes of LDS", shm);
   const dim3 grid((unsigned)((q1 - q0 + BQ - 1) / BQ), (unsigned)(seed ? 1 : nsplit));

@@ -436,6 +436,55 @@ def config4_features_sharded(n, dist, dev, rank, world, world_shards=64, seed=2,
     return X, labels
 
 
+def _knn_counting_check(torch, X, J, D, lo, K, nsample=512, seed=0):
+    """The counting argument of an exact search, on `nsample` of this rank's query rows: with r the reported distance of the last list
+    entry (the K-th neighbour; the lists hold the row itself first), no more than K points lie strictly within r of the row, and at
+    least K + 1 within r -- computed from the features with torch (differences squared and added in fp64), no part of the search."""
+    rng = np.random.default_rng(seed)
+    rows = np.sort(rng.choice(len(J), size=min(nsample, len(J)), replace=False))
+    n = X.shape[0]
+    rk2 = torch.tensor(D[rows, -1] ** 2, dtype=torch.float64, device=X.device)
+    inside = torch.zeros(len(rows), dtype=torch.int64, device=X.device)
+    within = torch.zeros(len(rows), dtype=torch.int64, device=X.device)
+    idx = torch.tensor(lo + rows, dtype=torch.int64, device=X.device)
+    for a in range(0, len(rows), 32):
+        q = X[idx[a:a + 32]].to(torch.float64)                       # (b, d)
+        for c0 in range(0, n, 131072):
+            blk = X[c0:c0 + 131072].to(torch.float64)
+            d2 = ((blk[:, None, :] - q[None, :, :]) ** 2).sum(dim=2)  # (rows of the block, b)
+            inside[a:a + 32] += (d2 < rk2[None, a:a + 32] * (1 - 1e-9)).sum(dim=0)
+            within[a:a + 32] += (d2 <= rk2[None, a:a + 32] * (1 + 1e-9)).sum(dim=0)
+    inside, within = inside.cpu().numpy(), within.cpu().numpy()
+    self_first = bool(np.array_equal(J[rows, 0], lo + rows))
+    return {'rows': int(len(rows)), 'max_points_strictly_inside': int(inside.max()), 'min_points_within': int(within.min()), 'k_plus_self': K + 1,
+            'row_itself_first': self_first, 'ok': bool(inside.max() <= K and within.min() >= K + 1 and self_first)}
+
+
+def _operator_checks(sg, world, nsample=1000000, seed=1):
+    """This rank's rows of W: no stored diagonal entry, no stored zero, sorted columns; and (one rank: the whole matrix is here) symmetry on
+    `nsample` sampled entries, each looked up transposed by a binary search over the row-major keys."""
+    W = sg.W_own
+    rows_global = sg.plan.own if hasattr(sg.plan, 'own') else np.arange(W.shape[0])
+    nrow = W.shape[0]
+    rid = np.repeat(np.arange(nrow, dtype=np.int64), np.diff(W.indptr))
+    out = {'rows': int(nrow), 'nnz': int(W.nnz),
+           'zero_diagonal': bool(not np.any(W.indices == np.asarray(sg.lo + rid, dtype=W.indices.dtype))) if hasattr(sg, 'lo') else None,
+           'no_stored_zeros': bool(np.all(W.data != 0)), 'positive_weights': bool(np.all(W.data > 0))}
+    if world == 1:
+        n = W.shape[1]
+        keys = rid * n + W.indices                                        # ascending: rows ascending, columns sorted inside a row
+        out['sorted_columns'] = bool(np.all(np.diff(keys) > 0))
+        rng = np.random.default_rng(seed)
+        pick = rng.integers(0, W.nnz, size=min(nsample, W.nnz))
+        tkeys = W.indices[pick].astype(np.int64) * n + rid[pick]
+        pos = np.searchsorted(keys, tkeys)
+        pos[pos >= len(keys)] = len(keys) - 1
+        out['symmetric_on_sample'] = bool(np.all(keys[pos] == tkeys) and np.array_equal(W.data[pos], W.data[pick]))
+        out['symmetry_sample'] = int(len(pick))
+    out['ok'] = all(v for k, v in out.items() if isinstance(v, bool))
+    return out
+
+
 def main_config4(args):
     """bench.py --gpus N --config 4: STRONG scaling of config 4 (BASELINE.json configs[3]): n vertices in total (default
     10^7), d = 64, k = 10, C = 10, Poisson gradient descent with a fixed T = 200 sweeps per step, the graph built sharded
@@ -489,6 +538,10 @@ def main_config4(args):
     progress('kNN lists of %d query rows (tile kernel %.1f s, %d fallback rows, %s)' % (
         hi - lo, st['tile_ms'] / 1e3, st['fallback_rows'],
         'all pairs' if knn_cells is None else '%d cells, sample stride %d' % (st['cells'], st['seed_sample'])))
+    checks = None
+    if getattr(args, 'check', False):
+        checks = {'knn_counting_argument': _knn_counting_check(torch, X, np.asarray(J), np.asarray(D), lo, K)}
+        progress('check: counting argument on %d sampled query rows' % checks['knn_counting_argument']['rows'])
     del X
     # the sweep's blocks follow the graph: boundaries at the cell starts that cross the fewest list entries (between clusters: none),
     # the lists move to their new owners (--partition even keeps the equal blocks)
@@ -537,6 +590,17 @@ def main_config4(args):
     dist.all_gather(allst, stats)
     u_own = ds.fetch()
     how = ds.info()
+    if checks is not None:
+        checks.update(_operator_checks(sg, world))
+        # the sweep conserves sum_i deg_i u_i per class: u <- D^-1 (b + W^T u) with symmetric W gives sum deg u' = sum b + sum deg u, and the
+        # columns of b = onehot - mean(onehot) add up to zero; u starts at 0
+        du = torch.tensor(np.concatenate([prob['deg'] @ u_own, prob['deg'] @ np.abs(u_own)]), dtype=torch.float64, device=dev)   # (both in the rank's local row order)
+        dist.all_reduce(du)
+        du = du.cpu().numpy()
+        Cc = u_own.shape[1]
+        checks['degree_weighted_sum_conserved'] = {'max_abs_sum_deg_u': float(np.max(np.abs(du[:Cc]))), 'sum_deg_abs_u': float(np.min(du[Cc:])),
+                                                   'ok': bool(np.all(np.abs(du[:Cc]) <= 1e-8 * du[Cc:]))}
+        progress('check: operator symmetric / zero diagonal, degree-weighted sums conserved')
     pred = np.argmax(u_own, axis=1)
     hit = torch.tensor([int(np.sum(pred == labels[sg.plan.own])), len(pred)], dtype=torch.int64, device=dev)
     dist.all_reduce(hit)
@@ -569,6 +633,7 @@ def main_config4(args):
                       'local_order': local_order, 'knn_search': 'all pairs' if knn_cells is None else 'cell-pruned (%d cells)' % st['cells'], 'knn_tile_s': st['tile_ms'] / 1e3,
                       'symmetrise_plan_s': t_build},
             'accuracy_percent': 100.0 * int(hit[0]) / max(int(hit[1]), 1),
+            'checks': checks,
             'rccl_ranks': comm.info()['nranks'], 'rccl_owner': 'libglx' if comm.has_transport() else 'none (one rank)', 'engine': 'glx',
             'exchange': how['exchange'], 'exchange_selftest': how['selftest'],
         }

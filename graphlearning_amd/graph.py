@@ -48,8 +48,8 @@ class graph:
         """Reweight the graph more heavily near the labelled nodes `idx` (reference
         graph.py:368-466).  'poisson' solves one Poisson problem with the GPU conjugate-gradient
         solver (1-D right-hand side: numpy's pairwise-summed reductions are reproduced);
-        'wnll' is a diagonal scaling.  'properly' (a kd-tree range query on the features) is
-        outside this package's scope.  (The 'poisson' system is the singular graph Laplacian: its
+        'wnll' is a diagonal scaling; 'properly' scales by the distance to the nearest labelled point (all pairs on
+        the GPU, glx_nearest_dist: cKDTree's distances bit for bit).  (The 'poisson' system is the singular graph Laplacian: its
         conjugate-gradient iterates amplify rounding, so the solve always uses the reference-order
         reductions -- the tolerance mode of ssl.laplace / ssl.randomwalk does not apply here.)"""
         from . import utils
@@ -78,8 +78,17 @@ class graph:
             a[idx] = n / m
             D = sparse.spdiags(a, 0, n, n).tocsr()
             return D * self.weight_matrix + self.weight_matrix * D
-        elif method == 'properly':
-            raise NotImplementedError("graph.reweight(method='properly') is outside the GPU hot path this package covers")
+        elif method == 'properly':     # reference graph.py:448-462
+            if X is None:
+                sys.exit('Must provide data features X for properly weighted graph Laplacian.')
+            from . import _hip
+            rzeta = r / (zeta - 1) ** (1 / alpha)
+            # `D, J = cKDTree(X[idx, :]).query(X)`: the distance to the nearest labelled point, all pairs on the GPU (the reference's bits)
+            D = _hip.nearest_dist(X, idx)
+            D[D < rzeta] = rzeta
+            gamma = 1 + (r / D) ** alpha
+            D = sparse.spdiags(gamma, 0, n, n).tocsr()
+            return D * self.weight_matrix + self.weight_matrix * D
         else:
             sys.exit('Invalid reweighting method ' + method + '.')
 

@@ -124,7 +124,7 @@ class ssl:
         matrix, so an in-place edit between two fits is honoured exactly as before.  Returns the pending check or None."""
         last = getattr(self, '_last_key', None)
         W = self.graph.weight_matrix
-        if last is None or last[0] is not W or getattr(self, '_trusted_key', None) is not None:
+        if not SPECULATIVE_FITS or last is None or last[0] is not W or getattr(self, '_trusted_key', None) is not None:
             return None
         fut = _hash_pool().submit(utils.matrix_fingerprint, W)
         self._trusted_key = (W, last[1])
@@ -396,6 +396,9 @@ def _gd_batch(k, dtype):
 
 
 _HASH_POOL = None
+# False: a fit on a matrix object the previous fit saw hashes the matrix FIRST and starts afterwards (the fit never runs on a guess).
+# Results are identical either way (tests/test_gpu_switches.py); the switch is the off position of the speculation for ablation runs.
+SPECULATIVE_FITS = True
 
 
 def _hash_pool():
@@ -949,7 +952,7 @@ class laplace(ssl):
                  order=1, mean_shift=False, tol=1e-5, alpha=2, zeta=1e7, r=0.1, reduce='auto'):
         """Laplace learning, reference ssl.py:1106-1261: Dirichlet sub-system solved by a
         Jacobi-scaled multi-RHS conjugate gradient on the GPU.  Reweightings 'poisson' and 'wnll'
-        (graph.reweight, reference graph.py:368-466) are supported; 'properly' is not.
+        (graph.reweight, reference graph.py:368-466) and 'properly' (needs the features `X`) are supported.
 
         reduce (not in the reference): 'auto' (default) = the tolerance mode 'tree' -- block-tree reductions, about 7x faster per
         fit at config 3, the same labels and iteration counts, iterates within the north star's 1e-5 of the reference's (this SPD

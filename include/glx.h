@@ -248,12 +248,15 @@ int glx_cg_multi(glx_graph* A, const void* B, void* X, int C, double tol, int64_
  *                reference's `x += alpha * p`;
  *   GLX_CG_BLOCKS / GLX_CG_CHAIN  how the reference-order mode walks numpy's row-after-row reduction chains: in block form
  *                (integer block sums confirmed by the exact running sum, csrc/seqsum_exact.h) or one dependent addition per row.
- *                Same bits either way; the default takes the block form from 8192 rows on.  For tests and measurements. */
+ *                Same bits either way; the default takes the block form from 8192 rows on.  For tests and measurements.
+ *   GLX_CG_EAGER the reference-order mode enqueues every iteration launch by launch instead of replaying chunks of 8 iterations from
+ *                captured launch sequences (the default).  Same bits either way.  For tests and measurements. */
 #define GLX_CG_NP1D 1
 #define GLX_CG_TREE 2
 #define GLX_CG_X0 4
 #define GLX_CG_BLOCKS 8
 #define GLX_CG_CHAIN 16
+#define GLX_CG_EAGER 32
 int glx_cg_solve(glx_graph* A, const void* B, void* X, int C, double tol, int64_t max_iter, int flags,
                  int* iters_out, double* err_out);
 /* several independent systems on one operator, side by side: the C columns are C/group_cols systems
@@ -313,6 +316,11 @@ int glx_sweep_project_iterate(glx_sweep* s, const double* priors, double* weight
  * d > 34) the candidate filter blocks the feature dimension instead of keeping the query in registers. */
 int glx_knn_bruteforce(const double* X, int64_t n, int d, int k, int similarity,
                        int64_t* ind_out, double* dist_out, int device);
+/* dist_out[i] = euclidean distance from row i of X (n, d) to the nearest of its rows idx[0 .. m): `cKDTree(X[idx]).query(X)[0]` of
+ * graph.reweight(method='properly') (graphlearning/graph.py:455-457), all pairs with cKDTree's accumulation pattern -- the reference's
+ * distances bit for bit.  Host arrays. */
+int glx_nearest_dist(const double* X, int64_t n, int d, const int64_t* idx, int64_t m, double* dist_out, int device);
+
 /* same search restricted to the query rows [q_begin, q_end) (rank-local share when the queries are
  * sharded across GPUs; every rank holds all of X).  ind_out/dist_out: (q_end - q_begin, k).  For this entry point and for
  * glx_knn_cells_range X may be a DEVICE pointer (features generated and ordered on the GPU: no trip through the host). */

@@ -108,6 +108,11 @@ int glx_knn_clustered(const double* X, int64_t n, int d, int k, int ncells, int6
 typedef struct { int filter, lists, nsplit, concat; } glx_knn_options;
 int glx_knn_set_options(const glx_knn_options* opt);
 
+/* 0: the device work-buffer pool and the idle work sets (streams, events, staging) are bypassed -- every buffer comes from hipMalloc and
+ * goes back with hipFree; 1 (default): size-class free lists in front of the runtime.  Results are identical either way
+ * (tests/test_gpu_switches.py); the switch exists for ablation runs of the randomised soak. */
+int glx_pool_set_enabled(int enabled);
+
 /* out[i] = exp(x[i]) correctly rounded (csrc/exp_cr.h: the exponential of the Gaussian weights), host arrays; a test hook */
 int glx_exp_cr(const double* x, double* out, int64_t n, int device);
 

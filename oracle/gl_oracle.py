@@ -418,9 +418,9 @@ def laplace_fit(W, train_ind, train_labels, normalization='combinatorial', tau=0
 # ----------------------------------------------------------------------------
 # "next" rows: graph.reweight, laplace reweightings, ssl.randomwalk
 # ----------------------------------------------------------------------------
-def reweight(W, idx, method='poisson', normalization='combinatorial'):
-    """graph.reweight, graphlearning/graph.py:368-466, methods 'poisson' (:413-434) and 'wnll'
-    (:436-446).  Note the 1-D right-hand side: numpy reduces it with pairwise summation."""
+def reweight(W, idx, method='poisson', normalization='combinatorial', X=None, alpha=2, zeta=1e7, r=0.1):
+    """graph.reweight, graphlearning/graph.py:368-466, methods 'poisson' (:413-434), 'wnll'
+    (:436-446) and 'properly' (:448-462).  Note the 1-D right-hand side of 'poisson': numpy reduces it with pairwise summation."""
     W = sparse.csr_matrix(W)
     n = W.shape[0]
     if method == 'poisson':
@@ -447,12 +447,21 @@ def reweight(W, idx, method='poisson', normalization='combinatorial'):
         a[idx] = n / m
         D = sparse.spdiags(a, 0, n, n).tocsr()
         return D * W + W * D
+    if method == 'properly':        # graph.py:448-462: gamma = 1 + (r / dist to the nearest labelled point)^alpha, distances floored at r_zeta
+        from scipy import spatial
+        rzeta = r / (zeta - 1) ** (1 / alpha)
+        Xtree = spatial.cKDTree(X[idx, :])
+        D, J = Xtree.query(X)
+        D[D < rzeta] = rzeta
+        gamma = 1 + (r / D) ** alpha
+        D = sparse.spdiags(gamma, 0, n, n).tocsr()
+        return D * W + W * D
     raise ValueError('Invalid reweighting method ' + method + '.')
 
 
-def laplace_reweighted_fit(W, train_ind, train_labels, reweighting, normalization='combinatorial', tol=1e-5):
+def laplace_reweighted_fit(W, train_ind, train_labels, reweighting, normalization='combinatorial', tol=1e-5, X=None):
     """ssl.laplace._fit with reweighting != 'none', graphlearning/ssl.py:1208-1213."""
-    Wr = reweight(W, train_ind, method=reweighting, normalization=normalization)
+    Wr = reweight(W, train_ind, method=reweighting, normalization=normalization, X=X)
     return laplace_fit(Wr, train_ind, train_labels, normalization=normalization, tol=tol)
 
 

@@ -67,6 +67,32 @@ def pytest_runtest_logreport(report):
             _crumb('TRACEBACK %s\n%s' % (report.nodeid, report.longreprtext))
 
 
+# ---- ablations (soak runs) ------------------------------------------------------------------------------------------
+# GLX_TEST_ABLATE=nopool,nopinned,nospec (any subset): the session runs with the named subsystem switched OFF through the product's
+# own API switches (_hip.pool_set_enabled, _hip.PINNED_RESULTS, ssl.SPECULATIVE_FITS).  A test-harness variable, not a product one: the
+# library never reads it.  scripts/soak.sh passes it through; a failure rate that moves with a switch names the subsystem.
+_ABLATE = [a for a in os.environ.get('GLX_TEST_ABLATE', '').split(',') if a]
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _ablations():
+    if _ABLATE:
+        unknown = set(_ABLATE) - {'nopool', 'nopinned', 'nospec'}
+        assert not unknown, 'GLX_TEST_ABLATE: unknown names %s' % sorted(unknown)
+        from graphlearning_amd import _hip, ssl
+        if 'nospec' in _ABLATE:
+            ssl.SPECULATIVE_FITS = False
+        if 'nopinned' in _ABLATE:
+            _hip.PINNED_RESULTS = False
+        if 'nopool' in _ABLATE and _hip.load(required=False) is not None:
+            try:
+                _hip.pool_set_enabled(False)
+            except Exception:
+                pass
+        _crumb('ABLATE %s' % ','.join(_ABLATE))
+    yield
+
+
 @pytest.fixture
 def device_exp():
     """weightmatrix.knn in its default mode inside the test."""

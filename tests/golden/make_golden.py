@@ -335,6 +335,33 @@ def g10_knn_cache():
     print('g10 done', W.nnz, Wu.nnz)
 
 
+def g11_properly():
+    """graph.reweight(method='properly') (reference graph.py:448-462) and ssl.laplace(reweighting='properly'): blobs in eight dimensions and
+    two-moons, the default parameters and a second set."""
+    out = {}
+    for tag, (X, labels) in (('blobs', blobs(3000, 8, 4, 11, 2.0)), ('moons', skd.make_moons(n_samples=500, noise=0.1, random_state=0))):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        labels = np.asarray(labels, dtype=np.int64)
+        W = gl.weightmatrix.knn(X, 10, knn_data=gl.weightmatrix.knnsearch(X, 11, method='kdtree'))
+        train_ind = gl.trainsets.generate(labels, rate=3, seed=1)
+        out[tag + '_X'] = X
+        out[tag + '_labels'] = labels
+        out[tag + '_train_ind'] = np.asarray(train_ind, dtype=np.int64)
+        out.update(csr_parts(W, tag + '_W'))
+        G = gl.graph(W)
+        for ptag, kw in (('default', {}), ('p2', dict(alpha=3, zeta=1e5, r=0.5))):
+            Wr = sparse.csr_matrix(G.reweight(train_ind, method='properly', X=X, **kw))
+            out.update(csr_parts(Wr, tag + '_Wr_' + ptag))
+            Wo = sparse.csr_matrix(orc.reweight(W, train_ind, method='properly', X=X, **kw))
+            assert np.array_equal(Wr.data, Wo.data) and np.array_equal(Wr.indices, Wo.indices)
+        mdl = gl.ssl.laplace(W, X=X, reweighting='properly')
+        out[tag + '_laplace_prob'] = mdl.fit(train_ind, labels[train_ind])
+        out[tag + '_laplace_pred'] = mdl.predict()
+        assert np.array_equal(orc.laplace_reweighted_fit(W, train_ind, labels[train_ind], 'properly', X=X), out[tag + '_laplace_prob'])
+    np.savez_compressed(os.path.join(HERE, 'g11_properly.npz'), **out)
+    print('g11 done')
+
+
 def g4_large():
     """Config 2 (70k) and config 3 (60k): checksums only; the graphs are
     regenerated from seeds by the oracle on the GPU box."""
@@ -492,5 +519,6 @@ if __name__ == '__main__':
     g8_pagerank()
     g9_plaplace()
     g10_knn_cache()
+    g11_properly()
     if args.large:
         g4_large()

@@ -334,8 +334,34 @@ def test_next_rows_reweight_randomwalk_golden(gl, golden):
     u = m.fit(ti, lab[ti])
     assert m.num_iter == int(g['randomwalk_iters'])
     assert np.array_equal(u, g['randomwalk_prob']) and np.array_equal(m.predict(), g['randomwalk_pred'])
-    with pytest.raises(NotImplementedError):
-        G.reweight(ti, method='properly', X=np.zeros((500, 2)))
+    with pytest.raises(SystemExit):        # reference graph.py:450-451: `properly` needs the features
+        G.reweight(ti, method='properly')
+
+
+def test_reweight_properly_golden(gl, golden):
+    """graph.reweight(method='properly') (reference graph.py:448-462: gamma = 1 + (r / distance to the nearest labelled point)^alpha) and
+    ssl.laplace(reweighting='properly'): the nearest-labelled distances computed all pairs on the GPU are cKDTree's bit for bit, so the
+    reweighted matrix and the fit are the reference's (goldens written by tests/golden/make_golden.py g11_properly)."""
+    from graphlearning_amd import _hip
+    from scipy import spatial
+    g = golden('g11_properly.npz')
+    for tag in ('blobs', 'moons'):
+        X, lab, ti = g[tag + '_X'], g[tag + '_labels'], g[tag + '_train_ind']
+        W = csr_from(g, tag + '_W')
+        D = _hip.nearest_dist(X, ti)
+        assert np.array_equal(D, spatial.cKDTree(X[ti]).query(X)[0]), tag
+        G = gl.graph.graph(W)
+        for ptag, kw in (('default', {}), ('p2', dict(alpha=3, zeta=1e5, r=0.5))):
+            Wr = sparse.csr_matrix(G.reweight(ti, method='properly', X=X, **kw))
+            Wg = csr_from(g, tag + '_Wr_' + ptag)
+            assert np.array_equal(Wr.indptr, Wg.indptr) and np.array_equal(Wr.indices, Wg.indices) and np.array_equal(Wr.data, Wg.data), (tag, ptag)
+        m = gl.ssl.laplace(W, X=X, reweighting='properly', reduce='exact')
+        u = m.fit(ti, lab[ti])
+        assert np.array_equal(u, g[tag + '_laplace_prob']), tag
+        assert np.array_equal(m.predict(), g[tag + '_laplace_pred']), tag
+        m2 = gl.ssl.laplace(W, X=X, reweighting='properly')            # the default mode: within 1e-5, same labels
+        u2 = m2.fit(ti, lab[ti])
+        assert np.max(np.abs(u2 - u)) <= 1e-5 and np.array_equal(m2.predict(), g[tag + '_laplace_pred']), tag
 
 
 def test_prepared_sweep_reuse(gl, golden):

@@ -106,3 +106,29 @@ def test_scale_poisson_sweeps_equal_oracle(gl, orc, data):
     mf.fit(ti, labels[ti])
     print('stop test n=%d: T = %d' % (N, T_full))
     assert mf.num_iter == T_full
+
+
+def test_config4_at_its_stated_size_on_one_gpu():
+    """BASELINE configs[3] at n = 10^7 (d = 64, k = 10, C = 10) through the bench entry on ONE GPU -- 10^7 x 64 features
+    generated, ordered and searched on the device (cell-pruned exact search), 1.6e8-entry W assembled, 200 Poisson sweeps -- with the
+    size-independent properties the domain offers: the counting argument of an exact search on 512 sampled rows (no more than k points
+    strictly inside the k-th distance, the row itself first), W symmetric on 10^6 sampled entries with no diagonal and no stored zero,
+    the degree-weighted class sums of the iterate conserved (= 0), accuracy above 99 % on well-separated blobs."""
+    import json
+    import subprocess
+    import sys
+    import os
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', '4', '--n', '1e7', '--gpus', '1', '--steps', '1', '--warmup', '1', '--check'],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert j['config']['n'] == 10000000 and j['config']['sweeps_per_step'] == 200 and j['n_gpus'] == 1 and j['value'] > 0
+    assert 1.5e8 < j['config']['nnz'] < 1.8e8
+    ch = j['checks']
+    assert ch['knn_counting_argument']['ok'] and ch['knn_counting_argument']['rows'] == 512, ch['knn_counting_argument']
+    assert ch['ok'] and ch['symmetric_on_sample'] and ch['zero_diagonal'] and ch['no_stored_zeros'] and ch['sorted_columns'], ch
+    assert ch['degree_weighted_sum_conserved']['ok'], ch['degree_weighted_sum_conserved']
+    assert j['accuracy_percent'] > 99.0, j['accuracy_percent']
+    print('config 4 at n = 1e7 on one GPU: %.1f sweeps/s (%.2f ms per sweep), frac %.3f, build %s' % (
+        j['value'], 1e3 / j['value'], j['roofline']['frac'], {k: (round(v, 2) if isinstance(v, float) else v) for k, v in j['build'].items() if k.endswith('_s')}))

@@ -67,6 +67,30 @@ def test_block_form_equals_chain_and_oracle(gl, orc, form, n, C):
         assert np.array_equal(x, x_ref), name
 
 
+@pytest.mark.parametrize('n,C,max_iter', [(700, 3, 100000), (9000, 10, 100000), (9000, 4, 13), (9000, 4, 16), (9000, 4, 3), (300, 2, 0)])
+def test_captured_chunks_equal_eager_launches(gl, orc, monkeypatch, n, C, max_iter):
+    """Round 6: the reference-order solve replays chunks of 8 iterations from captured launch sequences and launches chunk k + 1 before
+    it has looked at chunk k (iterations past convergence must leave everything as it is).  Same bits as the launch-by-launch form
+    (GLX_CG_EAGER) and as the oracle: iterates, iteration counts, residual norms -- for solves that converge inside a chunk, that are cut
+    by max_iter inside a chunk (partial chunks run eagerly), at a chunk boundary, and for repeated solves on one operator (the replay of
+    sequences captured by an earlier solve; another tolerance and another right-hand side width re-capture)."""
+    from graphlearning_amd import _hip
+    rng = np.random.default_rng(n + C + max_iter)
+    A = _spd(n, n + 7)
+    G = _hip.DeviceGraph(A)
+    for rep, tol in enumerate((1e-9, 1e-9, 1e-6)):
+        b = rng.normal(size=(n, C)) * np.exp(rng.normal(size=C) * 2)
+        x_ref, it_ref, err_ref = orc.conjgrad(A, b, tol=tol, max_iter=max_iter, return_iters=True)
+        got = {}
+        for eager in (False, True):
+            monkeypatch.setattr(_hip, 'CG_EXACT_EAGER', eager)
+            got[eager] = G.cg(b, tol=tol, max_iter=max_iter)
+        for eager in (False, True):
+            x, it, err = got[eager]
+            assert it == it_ref and err == err_ref and np.array_equal(x, x_ref), (rep, eager, it, it_ref, err, err_ref)
+    G.close()
+
+
 def test_single_column_2d_right_hand_side_reduces_pairwise(gl, orc):
     """an (n,1) right-hand side: numpy's `np.sum(..., axis=0)` of one column is a contiguous run, summed pairwise like the 1-D case"""
     from graphlearning_amd import _hip

@@ -1,0 +1,86 @@
+"""The off switches of the subsystems that sit between a caller and the kernels: the device work-buffer pool
+and idle work sets (_hip.pool_set_enabled), the page-locked result blocks (_hip.PINNED_RESULTS), the speculative fit on the previous
+content fingerprint (ssl.SPECULATIVE_FITS).  With each one off, the whole path -- search, weight matrix, every learner, an in-place
+edit of the matrix between two fits -- returns the same bits as with everything on."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _walk(gl):
+    """A pass over the path that exercises all three subsystems: graphs of several sizes built back to back (pooled work buffers of
+    several size classes, recycled page-locked CSR arrays), fits repeated on the same matrix object (speculation), an in-place edit."""
+    from conftest import blobs
+    out = []
+    for seed, n, k in ((1, 700, 7), (2, 2600, 10), (3, 700, 7), (4, 9000, 12)):
+        X, lab = blobs(n, 12, 4, seed, 1.6)
+        W = gl.weightmatrix.knn(X, k)
+        out += [W.indptr.copy(), W.indices.copy(), W.data.copy()]
+        ti = gl.trainsets.generate(lab, rate=3, seed=seed)
+        for make in (lambda: gl.ssl.poisson(W, solver='gradient_descent'), lambda: gl.ssl.poisson(W), lambda: gl.ssl.laplace(W),
+                     lambda: gl.ssl.laplace(W, reduce='exact'), lambda: gl.ssl.poisson_mbo(W, gl.utils.class_priors(lab), Ns=10, T=4)):
+            m = make()
+            for rep in range(3):                          # the second and third fit find the first one's fingerprint
+                ti_r = gl.trainsets.generate(lab, rate=3, seed=seed + rep)
+                out.append(np.array(m.fit(ti_r, lab[ti_r]), copy=True))
+                out.append(np.array(m.predict(), copy=True))
+                out.append(np.array([getattr(m, 'num_iter', -1)]))
+        m = gl.ssl.poisson(W, solver='gradient_descent')
+        m.fit(ti, lab[ti])
+        W.data *= 0.5                                      # edited in place: the next fit must see the new content
+        W.data[::7] *= 1.25
+        out.append(np.array(m.fit(ti, lab[ti]), copy=True))
+        out.append(np.array([m.num_iter]))
+    return out
+
+
+@pytest.fixture(scope='module')
+def gl():
+    import graphlearning_amd as gl
+    from graphlearning_amd import _hip
+    _hip.require_device()
+    return gl
+
+
+@pytest.fixture(scope='module')
+def everything_on(gl):
+    return _walk(gl)
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x.shape == y.shape and x.dtype == y.dtype and np.array_equal(x, y, equal_nan=True), i
+
+
+def test_identical_with_the_device_pool_bypassed(gl, everything_on):
+    from graphlearning_amd import _hip
+    _hip.pool_set_enabled(False)
+    try:
+        _same(everything_on, _walk(gl))
+    finally:
+        _hip.pool_set_enabled(True)
+    _same(everything_on, _walk(gl))                        # and after switching it back on
+
+
+def test_identical_without_page_locked_result_blocks(gl, everything_on):
+    from graphlearning_amd import _hip
+    old = _hip.PINNED_RESULTS
+    _hip.PINNED_RESULTS = False
+    try:
+        got = _walk(gl)
+    finally:
+        _hip.PINNED_RESULTS = old
+    _same(everything_on, got)
+
+
+def test_identical_without_speculative_fits(gl, everything_on):
+    from graphlearning_amd import ssl
+    old = ssl.SPECULATIVE_FITS
+    ssl.SPECULATIVE_FITS = False
+    try:
+        got = _walk(gl)
+    finally:
+        ssl.SPECULATIVE_FITS = old
+    _same(everything_on, got)

@@ -182,3 +182,18 @@ def test_g9_plaplace(golden):
         u, it, uu, ul = orc.plaplace_jacobi(W, g['bdy'], g['bdy_val'], p, tol=tol, max_num_it=T, return_iters=True, return_bounds=True)
         assert it == int(it_ref)
         assert np.array_equal(uu, g[tag + '_uu']) and np.array_equal(ul, g[tag + '_ul']) and np.array_equal(u, g[tag + '_u'])
+
+
+def test_g11_properly(golden):
+    from scipy import sparse
+    """graph.reweight(method='properly') (graph.py:448-462) and ssl.laplace(reweighting='properly'): the oracle reproduces the reference's
+    reweighted matrices (default parameters and a second set) and the fit, bit for bit."""
+    g = golden('g11_properly.npz')
+    for tag in ('blobs', 'moons'):
+        X, lab, ti = g[tag + '_X'], g[tag + '_labels'], g[tag + '_train_ind']
+        W = csr_from(g, tag + '_W')
+        for ptag, kw in (('default', {}), ('p2', dict(alpha=3, zeta=1e5, r=0.5))):
+            Wr = sparse.csr_matrix(orc.reweight(W, ti, method='properly', X=X, **kw))
+            Wg = csr_from(g, tag + '_Wr_' + ptag)
+            assert np.array_equal(Wr.indices, Wg.indices) and np.array_equal(Wr.data, Wg.data), (tag, ptag)
+        assert np.array_equal(orc.laplace_reweighted_fit(W, ti, lab[ti], 'properly', X=X), g[tag + '_laplace_prob']), tag
