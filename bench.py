@@ -796,11 +796,12 @@ def supervise_rank(args, argv):
     import signal
     import subprocess
     import datetime
+    from graphlearning_amd import dist_bench
+    emit = dist_bench._claim_stdout()           # (gloo announces its connections on stdout: the contract is ONE JSON line there)
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     if world != int(args.gpus):
-        from graphlearning_amd import dist_bench
         dist_bench.check_world(args)            # exits with status 2 and the message
     dist.init_process_group('gloo', timeout=datetime.timedelta(minutes=30))
     engines = [args.engine] + (['torch'] if args.engine == 'glx' else [])
@@ -858,7 +859,7 @@ def supervise_rank(args, argv):
         if final_line is not None:
             final_line['attempts'] = attempts
             final_line['supervised'] = True
-            print(json.dumps(final_line), flush=True)
+            emit(json.dumps(final_line))
         else:
             print('bench.py: no attempt produced a line: %s' % attempts, file=sys.stderr)
     dist.barrier()

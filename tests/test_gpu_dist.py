@@ -72,6 +72,15 @@ def test_distributed_bench_entry_one_rank(tmp_path, force_coll, engine):
     j = json.loads(line)
     assert j['n_gpus'] == 1 and j['value'] > 0 and j['config']['sweeps_per_step'] == 50
     assert j.get('engine', engine) == engine, line[:600]
+    # round 6: the distributed entry reports the STATED metric -- the one 70 000-vertex graph (strong scaling), with the CPU baseline, the
+    # roofline and a parity verdict (the gathered iterate against the one-process oracle) on every N -- from a measuring child under its
+    # supervising rank; with the collectives forced, every sweep carries the exchange
+    assert j['scaling'] == 'strong' and j['config']['n'] == 70000 and j['unit'] == 'iters/s' and j['supervised'] and j['attempts'][-1]['outcome'] == 'ok'
+    assert j['parity']['bit_identical_to_oracle'] and j['parity']['T'] == 50
+    assert j['cpu_baseline']['value'] > 0 and j['cpu_baseline']['cores'] == 1 and j['roofline']['peak'] == 8000.0 and 0 < j['roofline']['frac'] < 1
+    assert j['halo']['exchanges_per_sweep'] == (1 if force_coll == '1' else 0), j['halo']
+    if force_coll == '1':
+        assert j['exchange'] in ('captured', 'eager'), j['exchange']
     print(line[:400])
 
 
