@@ -113,7 +113,7 @@ __device__ __forceinline__ SsRec ss_shfl_down_rec(const SsRec& r, int delta) {
 template <int MODE>
 __global__ __launch_bounds__(64 * SS_GB) void ss_quant_kernel(const double* __restrict__ prod, int64_t n, int nchunks, CgScalars sc, int it,
                                                               double tol, const double* __restrict__ ssum, const double* __restrict__ gsum,
-                                                              SsSoA soa, unsigned char* __restrict__ badmask) {
+                                                              const double* __restrict__ gpre, SsSoA soa, unsigned char* __restrict__ badmask) {
 #pragma clang fp contract(off)
   const int cb = blockIdx.y, g = blockIdx.x, ngroups = nchunks * (64 / SS_GB);
   if (!ss_block_live<MODE>(sc, it, tol, cb)) return;
@@ -128,8 +128,14 @@ __global__ __launch_bounds__(64 * SS_GB) void ss_quant_kernel(const double* __re
     for (int i = 0; i < SS_SUB; ++i) xv[i] = r0 + i < n ? src[(r0 + i) * 4] : 0.0;
   }
   // the approximate state in front of this group (sums of the groups before it) ...
+  // (every workgroup adding the sums of ALL groups in front of it is quadratic in the number of groups -- fine for the 69 groups of
+  // 70 000 rows, 1.3e8 loads per column block at 16.7 M rows: from SS_SCAN_FROM groups on ss_scan_kernel has left the exclusive prefix)
   double part = 0.0;
-  for (int g2 = wave * 16 + subw; g2 < g; g2 += SS_GB * 16) part += gsum[((size_t)cb * ngroups + g2) * 4 + cc];
+  if (gpre) {
+    part = (wave == 0 && subw == 0) ? gpre[((size_t)cb * ngroups + g) * 4 + cc] : 0.0;
+  } else {
+    for (int g2 = wave * 16 + subw; g2 < g; g2 += SS_GB * 16) part += gsum[((size_t)cb * ngroups + g2) * 4 + cc];
+  }
   part = ss_col_sum(part);
   // ... and in front of this thread's rows inside it (inclusive scan over the 16 runs of the wavefront, wavefront totals in LDS)
   const double mine = ssum[(((size_t)cb * ngroups + g) * (SS_GB * 16) + wave * 16 + subw) * 4 + cc];
@@ -173,6 +179,30 @@ __global__ __launch_bounds__(64 * SS_GB) void ss_quant_kernel(const double* __re
     for (int j = 0; j < SS_MAXSPLIT; ++j) soa.xs[j][o] = rec.xs[j];
     soa.nsplit[o] = rec.nsplit;
     if (wave == 0) badmask[(size_t)col * ngroups + g] = (unsigned char)shm[lane];
+  }
+}
+
+// exclusive prefix of the group sums of one column block (one workgroup of 256 threads per column block: 64 threads per column walk
+// strides of the groups, a wavefront scan carries the running total) -- only launched for many groups (SS_SCAN_FROM)
+#define SS_SCAN_FROM 1024
+template <int MODE>
+__global__ __launch_bounds__(256) void ss_scan_kernel(int ngroups, CgScalars sc, int it, double tol, const double* __restrict__ gsum,
+                                                      double* __restrict__ gpre) {
+  const int cb = blockIdx.x;
+  if (!ss_block_live<MODE>(sc, it, tol, cb)) return;
+  const int cc = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double carry = 0.0;
+  for (int g0 = 0; g0 < ngroups; g0 += 64) {
+    const int g = g0 + lane;
+    const double v = g < ngroups ? gsum[((size_t)cb * ngroups + g) * 4 + cc] : 0.0;
+    double incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d *= 2) {
+      const double t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (g < ngroups) gpre[((size_t)cb * ngroups + g) * 4 + cc] = carry + (incl - v);
+    carry += __shfl(incl, 63);
   }
 }
 
@@ -479,8 +509,15 @@ static int ss_launch(const double* prod, int64_t n, int ncols_all, int C, const 
   const dim3 grid((unsigned)ngroups, (unsigned)(ncols_all / 4));             // groups of 4 blocks x column blocks
   hipLaunchKernelGGL(ss_sum_kernel<MODE>, grid, dim3(64 * SS_GB), 0, st, prod, n, ngroups, sc, it, tol, w.bsum, w.csum);
   GLX_HIP(hipGetLastError());
+  const double* gpre = nullptr;
+  if (ngroups >= SS_SCAN_FROM) {            // the prefix lives behind the group sums in the same buffer (glx_seqsum_sum_doubles)
+    double* pre = w.csum + (size_t)(ncols_all / 4) * ngroups * 4;
+    hipLaunchKernelGGL(ss_scan_kernel<MODE>, dim3((unsigned)(ncols_all / 4)), dim3(256), 0, st, ngroups, sc, it, tol, (const double*)w.csum, pre);
+    GLX_HIP(hipGetLastError());
+    gpre = pre;
+  }
   hipLaunchKernelGGL(ss_quant_kernel<MODE>, grid, dim3(64 * SS_GB), 0, st, prod, n, w.nchunks, sc, it, tol, (const double*)w.bsum,
-                     (const double*)w.csum, soa, (unsigned char*)w.mask);
+                     (const double*)w.csum, gpre, soa, (unsigned char*)w.mask);
   GLX_HIP(hipGetLastError());
   const size_t lds = ss_walk_lds_bytes(w.nchunks);
   hipLaunchKernelGGL(ss_walk_kernel<MODE>, dim3((unsigned)ncols_all), dim3(256), lds, st, prod, n, w.nchunks, ncols_all, C, sc, it, tol, soa,
@@ -515,6 +552,6 @@ int glx_seqsum_prepare() {
 
 int glx_seqsum_max_chunks() { return SS_MAX_CHUNKS; }
 size_t glx_seqsum_sum_doubles(int ncols, int nchunks, int which) {      // which 0: sums of the runs of 16 rows, 1: of the groups
-  return which == 0 ? (size_t)(ncols / 4) * nchunks * 64 * SS_Q * 4 : (size_t)(ncols / 4) * nchunks * (64 / SS_GB) * 4;
+  return which == 0 ? (size_t)(ncols / 4) * nchunks * 64 * SS_Q * 4 : (size_t)2 * (ncols / 4) * nchunks * (64 / SS_GB) * 4;   // (1: + their exclusive prefix)
 }
 int glx_seqsum_chunks(int64_t n) { return (int)((n + (int64_t)SS_BLOCK * 64 - 1) / ((int64_t)SS_BLOCK * 64)); }

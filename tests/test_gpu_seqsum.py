@@ -91,6 +91,26 @@ def test_captured_chunks_equal_eager_launches(gl, orc, monkeypatch, n, C, max_it
     G.close()
 
 
+def test_block_form_with_the_prefix_scan_of_many_groups(gl, orc, form):
+    """From 1024 groups of 1024 rows on, the approximate prefix in front of a group comes from a scan pass (ss_scan_kernel) instead of every
+    workgroup adding all group sums in front of it (quadratic in the number of groups).  1.1 M rows, a few iterations: the same
+    bits as the chain form and the oracle."""
+    from graphlearning_amd import _hip
+    n, C = 1100000, 2
+    rng = np.random.default_rng(5)
+    i = np.arange(n)
+    A = sparse.csr_matrix(sparse.diags([np.full(n, 4.0), np.full(n - 1, -1.0), np.full(n - 1, -1.0), np.full(n - 997, 0.5), np.full(n - 997, 0.5)],
+                                       [0, 1, -1, 997, -997]))
+    b = rng.normal(size=(n, C)) * np.array([1.0, 1e-3])
+    x_ref, it_ref, err_ref = orc.conjgrad(A, b, tol=1e-12, max_iter=4, return_iters=True)
+    G = _hip.DeviceGraph(A)
+    for name in ('blocks', 'chain'):
+        form(name)
+        x, it, err = G.cg(b, tol=1e-12, max_iter=4)
+        assert it == it_ref and err == err_ref and np.array_equal(x, x_ref), name
+    G.close()
+
+
 def test_single_column_2d_right_hand_side_reduces_pairwise(gl, orc):
     """an (n,1) right-hand side: numpy's `np.sum(..., axis=0)` of one column is a contiguous run, summed pairwise like the 1-D case"""
     from graphlearning_amd import _hip
