@@ -230,11 +230,6 @@ def main(args):
         halos = [torch.zeros_like(halo) for _ in range(world)]
         dist.all_gather(halos, halo)
         how = info()
-        if engine == 'glx':
-            try:
-                parts = ds.time_parts(20)          # this rank's pieces of one sweep, each timed alone (microseconds)
-            except Exception:                      # noqa: BLE001
-                parts = None
         u = None
         if want_u:                                 # the iterate of the last step, every rank's rows, for the parity check on rank 0
             got = [None] * world
@@ -243,6 +238,11 @@ def main(args):
                 u = np.zeros((G['n'], prob['k']), dtype=got[0][1].dtype)
                 for ids, block in got:
                     u[ids] = block
+        if engine == 'glx':                        # (behind the fetch: the timed pieces run on the sweep's own state buffers)
+            try:
+                parts = ds.time_parts(20)          # this rank's pieces of one sweep, each timed alone (microseconds)
+            except Exception:                      # noqa: BLE001
+                parts = None
         close()
         return dict(T=T, wall=walls[len(walls) // 2], wall_min=walls[0], wall_max=walls[-1], halo_rows=[int(h[0]) for h in halos],
                     owned=[int(h[1]) for h in halos], boundary=[int(h[3]) for h in halos], global_halo=int(plan.global_halo), how=how,

@@ -15,6 +15,7 @@ from graphlearning_amd import _hip  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 forms = tuple(sys.argv[2].split(',')) if len(sys.argv) > 2 else ('chain', 'auto', 'blocks', 'chain', 'auto')
+_hip.CG_EXACT_EAGER = len(sys.argv) > 3 and sys.argv[3] == 'eager'      # third argument `eager`: launch by launch instead of captured chunks
 
 
 def timed(model, ti, lab, dev_of):

@@ -124,7 +124,7 @@ def test_config4_at_its_stated_size_on_one_gpu():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert j['config']['n'] == 10000000 and j['config']['sweeps_per_step'] == 200 and j['n_gpus'] == 1 and j['value'] > 0
-    assert 1.5e8 < j['config']['nnz'] < 1.8e8
+    assert 1.6e8 < j['config']['nnz'] < 2.0e8            # 10^7 rows x (10 .. 20 stored entries after symmetrisation)
     ch = j['checks']
     assert ch['knn_counting_argument']['ok'] and ch['knn_counting_argument']['rows'] == 512, ch['knn_counting_argument']
     assert ch['ok'] and ch['symmetric_on_sample'] and ch['zero_diagonal'] and ch['no_stored_zeros'] and ch['sorted_columns'], ch
