@@ -135,6 +135,7 @@ _SIGNATURES = {
                            C.POINTER(C.c_int), _f64p],
     'glx_cg_last_stop_margin': [_vp, _f64p],
     'glx_pool_set_enabled': [C.c_int],
+    'glx_pool_set_poison': [C.c_int],
     'glx_nearest_dist': [_vp, C.c_int64, C.c_int, _vp, C.c_int64, _vp, C.c_int],
     'glx_cg_last_block_stats': [_vp, C.POINTER(C.c_int)],
     'glx_host_fingerprint': [_vp, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)],
@@ -310,6 +311,11 @@ PINNED_RESULTS = True
 
 def pool_set_enabled(enabled):
     check(load().glx_pool_set_enabled(1 if enabled else 0), 'glx_pool_set_enabled')
+
+
+def pool_set_poison(byte):
+    """Debugging aid: work buffers are filled with `byte` (0 .. 255) when handed out; None / -1 switches it off."""
+    check(load().glx_pool_set_poison(-1 if byte is None else int(byte)), 'glx_pool_set_poison')
 
 
 def pinned_empty(shape, dtype):

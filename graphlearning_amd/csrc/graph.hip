@@ -55,6 +55,9 @@ static PoolState& pool() { static PoolState* p = new PoolState(); return *p; }  
 // glx_pool_set_enabled(0): every block straight from / back to the runtime and no idle work sets -- the ablation switch of the
 // randomised soak (a result that changes with it names a buffer handed on while still in use) and of tests/test_gpu_switches.py
 static bool g_pool_enabled = true;
+// glx_pool_set_poison(b): every block handed out is first filled with the byte b (-1: off, the default) -- a debugging aid: a kernel
+// that reads a work buffer before anything wrote it then computes from the pattern instead of from whatever an earlier call left there
+static int g_pool_poison = -1;
 
 static size_t pool_class(size_t bytes) {
   size_t c = 4096;
@@ -196,7 +199,23 @@ extern "C" int glx_pool_set_enabled(int enabled) {
   return GLX_OK;
 }
 
+extern "C" int glx_pool_set_poison(int byte) {
+  g_pool_poison = byte < 0 ? -1 : (byte & 0xff);
+  return GLX_OK;
+}
+
+static int pool_alloc_raw(void** out, size_t bytes);
 int glx_pool_alloc(void** out, size_t bytes) {
+  const int rc = pool_alloc_raw(out, bytes);
+  if (!rc && g_pool_poison >= 0 && *out) {
+    GLX_HIP(hipDeviceSynchronize());
+    GLX_HIP(hipMemset(*out, g_pool_poison, pool_class(std::max<size_t>(bytes, 1))));
+    GLX_HIP(hipDeviceSynchronize());
+  }
+  return rc;
+}
+
+static int pool_alloc_raw(void** out, size_t bytes) {
   int dev = 0;
   GLX_HIP(hipGetDevice(&dev));
   const size_t c = pool_class(std::max<size_t>(bytes, 1));

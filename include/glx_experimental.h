@@ -112,6 +112,9 @@ int glx_knn_set_options(const glx_knn_options* opt);
  * goes back with hipFree; 1 (default): size-class free lists in front of the runtime.  Results are identical either way
  * (tests/test_gpu_switches.py); the switch exists for ablation runs of the randomised soak. */
 int glx_pool_set_enabled(int enabled);
+/* debugging aid: every work buffer the pool hands out is first filled with `byte` (0 .. 255; -1 = off, the default), so that a kernel reading
+ * a buffer before anything wrote it computes from the pattern instead of from what an earlier call left there */
+int glx_pool_set_poison(int byte);
 
 /* out[i] = exp(x[i]) correctly rounded (csrc/exp_cr.h: the exponential of the Gaussian weights), host arrays; a test hook */
 int glx_exp_cr(const double* x, double* out, int64_t n, int device);

@@ -77,13 +77,16 @@ _ABLATE = [a for a in os.environ.get('GLX_TEST_ABLATE', '').split(',') if a]
 @pytest.fixture(scope='session', autouse=True)
 def _ablations():
     if _ABLATE:
-        unknown = set(_ABLATE) - {'nopool', 'nopinned', 'nospec'}
+        unknown = {a for a in _ABLATE if not a.startswith('poison')} - {'nopool', 'nopinned', 'nospec'}
         assert not unknown, 'GLX_TEST_ABLATE: unknown names %s' % sorted(unknown)
         from graphlearning_amd import _hip, ssl
         if 'nospec' in _ABLATE:
             ssl.SPECULATIVE_FITS = False
         if 'nopinned' in _ABLATE:
             _hip.PINNED_RESULTS = False
+        for a in _ABLATE:                       # poison<byte>: every pooled work buffer is filled with that byte when handed out
+            if a.startswith('poison') and _hip.load(required=False) is not None:
+                _hip.pool_set_poison(int(a[6:] or '255'))
         if 'nopool' in _ABLATE and _hip.load(required=False) is not None:
             try:
                 _hip.pool_set_enabled(False)
