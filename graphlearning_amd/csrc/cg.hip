@@ -783,28 +783,31 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
         (unsigned long long)(uintptr_t)a.rowmask, (unsigned long long)mask_grid, (unsigned long long)(uintptr_t)A->d_perm,
         (unsigned long long)(uintptr_t)b.pw_vals, (unsigned long long)b.pw_n, (unsigned long long)(uintptr_t)st};
     if (key != b.e_key) {
-      for (int q = 0; q < 4; ++q)
-        if (b.e_exec[q]) { hipGraphExecDestroy(b.e_exec[q]); b.e_exec[q] = nullptr; }
+      for (int q = 0; q < 8; ++q)
+        if (b.e_exec[q / 2][q % 2]) { hipGraphExecDestroy(b.e_exec[q / 2][q % 2]); b.e_exec[q / 2][q % 2] = nullptr; }
       b.e_key = key;
     }
-    for (int q = 0; q < 2; ++q)
-      if (!b.e_ev[q]) GLX_HIP(hipEventCreateWithFlags(&b.e_ev[q], hipEventDisableTiming));
   }
-  auto launch_chunk = [&](int cnt, bool bl0, bool bl1) -> int {
+  for (int q = 0; q < 2; ++q)
+    if (!b.e_ev[q]) GLX_HIP(hipEventCreateWithFlags(&b.e_ev[q], hipEventDisableTiming));
+  // `inst`: the chunk's slot (0 / 1).  Two chunks are in flight at a time and each slot has its OWN instance of the captured sequence:
+  // launching an instance that is still running makes the runtime wait for it on the host -- a sleeping wait, ~0.95 ms of idle device per
+  // chunk in the first version of this loop (profiles/r06_cg_blocks_kernel_stats.csv has the trace before and after)
+  auto launch_chunk = [&](int cnt, bool bl0, bool bl1, int inst) -> int {
     if (!use_graphs || cnt < CG_CHUNK) return enqueue_chunk(cnt, bl0, bl1);
     const int v = (bl0 ? 1 : 0) + (bl1 ? 2 : 0);
-    if (!b.e_exec[v]) {
+    if (!b.e_exec[v][inst]) {
       hipGraph_t graph = nullptr;
       GLX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
       const int rc2 = enqueue_chunk(CG_CHUNK, bl0, bl1);
       const hipError_t e = hipStreamEndCapture(st, &graph);
       if (rc2) { if (graph) hipGraphDestroy(graph); return rc2; }
       GLX_HIP(e);
-      const hipError_t e2 = hipGraphInstantiate(&b.e_exec[v], graph, nullptr, nullptr, 0);
+      const hipError_t e2 = hipGraphInstantiate(&b.e_exec[v][inst], graph, nullptr, nullptr, 0);
       hipGraphDestroy(graph);
       GLX_HIP(e2);
     }
-    GLX_HIP(hipGraphLaunch(b.e_exec[v], st));
+    GLX_HIP(hipGraphLaunch(b.e_exec[v][inst], st));
     return GLX_OK;
   };
   {
@@ -818,7 +821,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   while (running > 0 && (it < max_iter || nfl > 0)) {
     if (it < max_iter && nfl < 2) {
       const int cnt = (int)std::min<int64_t>(CG_CHUNK, max_iter - it);
-      rc = launch_chunk(cnt, blocks_now[0], blocks_now[1]);
+      rc = launch_chunk(cnt, blocks_now[0], blocks_now[1], slot);
       if (rc) return rc;
       GLX_HIP(hipMemcpyAsync(b.h_err + slot * slot_doubles, b.err_hist + stride, (size_t)cnt * stride * 8, hipMemcpyDeviceToHost, st));
       if (ss_blocks) GLX_HIP(hipMemcpyAsync(b.h_ss + slot * 16, b.ss_stats, 128, hipMemcpyDeviceToHost, st));
@@ -843,10 +846,11 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
         const double by_rec = (double)(hs[4 * m + 1] - ss_seen[m][1]), by_rows = (double)(hs[4 * m + 2] - ss_seen[m][2]);
         for (int q = 0; q < 3; ++q) ss_seen[m][q] = hs[4 * m + q];
         const double chains = (double)f.cnt * ncols;
-        // measured on one MI355X (profiles/r06_cg_blocks_kernel_stats.csv): 0.7 us per block taken through its record, 1.2 per 256-row
+        // measured on one MI355X (profiles/r06_cg_blocks_kernel_stats.csv): 0.7 us per block taken through its record, 1.5 per 256-row
         // block taken row by row (0.65 of additions -- the chain's 2.4 ns per row --, the rest its rows arriving: three are fetched
-        // ahead per chunk), 0.6 per chunk of the walk, 14.5 for the two passes in front; the chain 2.4 ns per row
-        const double blocks_us = (by_rec * 0.7 + by_rows * 1.2) / chains + ssw.nchunks * 0.6 + 14.5;
+        // ahead per chunk; 399 us for a walk with every one of its 274 blocks row by row), 0.6 per chunk of the walk, 14.5 for the two
+        // passes in front; the chain 2.4 ns per row
+        const double blocks_us = (by_rec * 0.7 + by_rows * 1.5) / chains + ssw.nchunks * 0.6 + 14.5;
         const double chain_us = (double)n * 0.0024;
         if (blocks_us > chain_us) blocks_now[m] = false;
       }

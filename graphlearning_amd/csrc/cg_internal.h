@@ -47,7 +47,7 @@ struct CgBufs {
   hipGraphExec_t f_exec[3] = {nullptr, nullptr, nullptr};        // captured chunks of 32, 16 and 4 iterations
   // reference-order mode (cg.hip): a chunk of CG_CHUNK iterations as ONE captured launch sequence per combination of reduction forms
   // (bit 0: p.Ap in block form, bit 1: r.r), valid for the solve parameters in e_key; events of the two chunks in flight
-  hipGraphExec_t e_exec[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipGraphExec_t e_exec[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // two instances each: the chunks in flight never share one
   std::vector<unsigned long long> e_key;
   hipEvent_t e_ev[2] = {nullptr, nullptr};
   unsigned* e_rowmask = nullptr;                         // Dirichlet rows of every system as bits (the SpMM holds A p at zero there)
@@ -88,7 +88,7 @@ struct CgBufs {
     hipFree(f_part1); hipFree(f_part1g); hipFree(f_part2); hipFree(f_tick); hipFree(f_rowmask); hipFree(f_it);
     hipFree(f_stage);
     hipFree(ss_bsum); hipFree(ss_csum); hipFree(ss_rec); hipFree(ss_mask); hipFree(ss_stats); hipFree(e_rowmask);
-    for (int q = 0; q < 4; ++q) if (e_exec[q]) hipGraphExecDestroy(e_exec[q]);
+    for (int q = 0; q < 8; ++q) if (e_exec[q / 2][q % 2]) hipGraphExecDestroy(e_exec[q / 2][q % 2]);
     for (int q = 0; q < 2; ++q) if (e_ev[q]) hipEventDestroy(e_ev[q]);
     if (h_stage) hipHostFree(h_stage);
     if (h_hist) hipHostFree(h_hist);
