@@ -419,6 +419,33 @@ def test_random_vertex_partitions_match_the_oracle(gl, orc, seed):
         assert np.nanmax(np.abs(u32 - u_ref)) <= 1e-5 * max(1.0, np.nanmax(np.abs(u_ref))), tag
 
 
+def _dump_knn_mismatch(seed, n, d, k, style, sim, J, D, J2, D2, Jo, Do, st1, st2, X, _hip):
+    import json
+    import os
+    rows = np.flatnonzero(np.any(J != J2, axis=1) | np.any(D != D2, axis=1))
+    scale = max(1.0, float(np.max(Do)))
+    rec = {'seed': int(seed), 'pid': os.getpid(), 'n': n, 'd': d, 'k': k, 'style': style, 'sim': sim, 'nrows': int(len(rows)), 'rows': rows[:32].tolist(),
+           'plain_equals_ckdtree': bool(np.array_equal(J, Jo) and np.max(np.abs(D - Do)) <= 1e-12 * scale),
+           'ordered_equals_ckdtree': bool(np.array_equal(J2, Jo) and np.max(np.abs(D2 - Do)) <= 1e-12 * scale),
+           'stats_plain': {a: (b if isinstance(b, str) else float(b)) for a, b in st1.items()},
+           'stats_ordered': {a: (b if isinstance(b, str) else float(b)) for a, b in st2.items()}, 'detail': [], 'again': []}
+    for i in rows[:6]:
+        rec['detail'].append({'row': int(i), 'J_plain': J[i].tolist(), 'J_ordered': J2[i].tolist(), 'J_ckdtree': Jo[i].tolist(),
+                              'D_plain': D[i].tolist(), 'D_ordered': D2[i].tolist(), 'D_ckdtree': Do[i].tolist()})
+    for rep in range(3):       # the same two searches again, at once, in the same process
+        Ja, Da = _hip.knn_bruteforce(X, k, similarity=sim)
+        Jb, Db = _hip.knn_bruteforce(X, k, similarity=sim, want_order=True)
+        rec['again'].append({'plain_equals_ckdtree': bool(np.array_equal(Ja, Jo)), 'ordered_equals_ckdtree': bool(np.array_equal(Jb, Jo)),
+                             'plain_equals_first_plain': bool(np.array_equal(Ja, J) and np.array_equal(Da, D)),
+                             'ordered_equals_first_ordered': bool(np.array_equal(Jb, J2) and np.array_equal(Db, D2))})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(root, 'gpurun_out', 'knn_mismatch.jsonl'), 'a') as f:
+        f.write(json.dumps(rec) + '\n')
+        f.flush()
+        os.fsync(f.fileno())
+
+
 @pytest.mark.parametrize('seed', _seeds(30))
 def test_random_knn_searches_match_ckdtree(gl, orc, seed):
     """The exact search over a wide range of shapes -- n = 2 .. 6000, d = 1 .. 300 (every feature-block count of the bf16
@@ -442,10 +469,16 @@ def test_random_knn_searches_match_ckdtree(gl, orc, seed):
     J, D = gl.weightmatrix.knnsearch(X, k, similarity=sim)
     # the search weightmatrix.knn runs (rows put into the order of chained cells first, where the size calls for it): the same lists
     from graphlearning_amd import _hip
+    st1 = _hip.knn_stats()
     J2, D2 = _hip.knn_bruteforce(X, k, similarity=sim, want_order=True)
-    assert np.array_equal(J2, J) and np.array_equal(D2, D), 'seed %d: the reordered search differs' % seed
+    st2 = _hip.knn_stats()
     Jo, Do = orc.knnsearch(X, k, similarity=sim)
     Jo, Do = Jo.reshape(n, -1), Do.reshape(n, -1)          # (cKDTree drops the axis for k = 1)
+    if not (np.array_equal(J2, J) and np.array_equal(D2, D)):
+        # (what the round-4 flake turned out to be: two searches of the same data that differ once in ~18 000 cases under 12 processes on
+        # one GPU -- the evidence goes to gpurun_out/knn_mismatch.jsonl before the assertion: which rows, which of the two is cKDTree's)
+        _dump_knn_mismatch(seed, n, d, k, style, sim, np.array(J), np.array(D), np.array(J2), np.array(D2), Jo, Do, st1, st2, X, _hip)
+    assert np.array_equal(J2, J) and np.array_equal(D2, D), 'seed %d: the reordered search differs' % seed
     tag = 'seed %d: n=%d d=%d k=%d style=%d %s' % (seed, n, d, k, style, sim)
     assert J.dtype == np.int64 and D.dtype == np.float64 and J.shape == (n, k), tag
     scale = max(1.0, float(np.max(Do)))
