@@ -195,7 +195,14 @@ def scale_shard_line(steps=4, T=50, traffic=True):
             # what the memory side behind the L2s actually delivers while this kernel runs (counter bytes, not algorithmic ones): the
             # Infinity Cache sits in that path, so this is "beyond-L2" traffic against the HBM peak, an upper estimate of the HBM share
             out['f64']['traffic_GBs'] = tr / (out['f64']['avg_launch_us'] * 1e-6) / 1e9
-            out['f64']['traffic_frac_of_hbm_peak'] = out['f64']['traffic_GBs'] / HBM_PEAK_GBS
+            # (FETCH_SIZE / WRITE_SIZE count what leaves the L2s: hits of the 256 MB Infinity Cache are in there -- this is NOT an HBM rate;
+            # 7 TB/s here exceeds what HBM sustains, 6.3 TB/s.  The share of the fabric reads that goes on to HBM comes from one more pass)
+            out['f64']['beyond_l2_traffic_frac_of_hbm_peak'] = out['f64']['traffic_GBs'] / HBM_PEAK_GBS
+            share, note = measure_dram_share()
+            out['f64']['dram_share_of_fabric_reads'] = share
+            out['f64']['dram_share_source'] = note
+            if share is not None:
+                out['f64']['hbm_read_traffic_frac_of_hbm_peak_estimate'] = out['f64']['traffic_GBs'] * share / HBM_PEAK_GBS
     return out
 
 
@@ -593,8 +600,49 @@ def measure_traffic(timeout_s=120, child_flag='--traffic-child', kernel='spmm_se
         finally:
             shutil.rmtree(d, ignore_errors=True)
     traffic = (2.0 * vals['FETCH_SIZE'][0] + vals['WRITE_SIZE'][0]) * 1024.0
+    measure_traffic.last_child = (child_flag, kernel)
     return traffic, ('measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes, means over %d / %d dispatches of '
                      'spmm_sell_kernel<double,4,true,false>; (2 x FETCH_SIZE + WRITE_SIZE) KiB' % (vals['FETCH_SIZE'][1], vals['WRITE_SIZE'][1]))
+
+
+def measure_dram_share(timeout_s=240, child_flag='--traffic-child-scale', kernel='spmm_sell_kernel<double'):
+    """Of the read requests the L2s send to the fabric while the sweep kernel runs, the share that goes on to HBM (the rest are hits of the
+    Infinity Cache, which FETCH_SIZE counts as well: MI355X_MICROARCH.md, HBM section): one more `rocprofv3 --pmc` child pass over
+    TCC_EA0_RDREQ_sum and TCC_EA0_RDREQ_DRAM_sum.  Best effort: (share or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not on PATH'
+    d = tempfile.mkdtemp(prefix='glx_pmc_', dir='/tmp')
+    try:
+        cmd = ['rocprofv3', '--pmc', 'TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_DRAM_sum', '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'run', '--',
+               sys.executable, os.path.abspath(__file__), child_flag]
+        proc = subprocess.Popen(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                start_new_session=True)
+        try:
+            proc.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.wait()
+            return None, 'pass exceeded %d s' % timeout_s
+        tot = {'TCC_EA0_RDREQ_sum': 0.0, 'TCC_EA0_RDREQ_DRAM_sum': 0.0}
+        cnt = 0
+        for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r['Counter_Name'] in tot and kernel in r['Kernel_Name']:
+                    tot[r['Counter_Name']] += float(r['Counter_Value'])
+                    cnt += 1
+        if cnt == 0 or tot['TCC_EA0_RDREQ_sum'] <= 0:
+            return None, 'no samples of TCC_EA0_RDREQ_sum / TCC_EA0_RDREQ_DRAM_sum for the sweep kernel (counters not offered by this rocprofv3?)'
+        return tot['TCC_EA0_RDREQ_DRAM_sum'] / tot['TCC_EA0_RDREQ_sum'], 'TCC_EA0_RDREQ_DRAM_sum / TCC_EA0_RDREQ_sum over %d samples' % (cnt // 2)
+    except Exception as e:      # noqa: BLE001
+        return None, 'pass failed: %s' % e
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def scale_graph(n=1000000):

@@ -818,8 +818,12 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   int nfl = 0, slot = 0;
   int64_t it = 0;                               // iterations launched
   const size_t slot_doubles = (size_t)(CG_CHUNK + 1) * stride;
+  // A chunk launched ahead runs in the forms decided one look earlier.  While a kind of reduction in block form is anywhere near the price
+  // of the chain (products that cancel: its walk can cost twice the chain), a late switch costs more than the bubble of waiting for the
+  // look: one chunk in flight until the block form has shown itself cheap (under half the chain) or is no longer in use.
+  bool ahead = !(ss_blocks && !blocks_forced);
   while (running > 0 && (it < max_iter || nfl > 0)) {
-    if (it < max_iter && nfl < 2) {
+    if (it < max_iter && nfl < (ahead ? 2 : 1)) {
       const int cnt = (int)std::min<int64_t>(CG_CHUNK, max_iter - it);
       rc = launch_chunk(cnt, blocks_now[0], blocks_now[1], slot);
       if (rc) return rc;
@@ -832,7 +836,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       ++nfl;
       it += cnt;
       slot ^= 1;
-      if (nfl < 2 && it < max_iter) continue;
+      if (nfl < (ahead ? 2 : 1) && it < max_iter) continue;
     }
     const Flight f = fl[0];
     fl[0] = fl[1];
@@ -841,6 +845,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     read_history(b.h_err + f.slot * slot_doubles, f.it0, f.cnt);
     if (ss_blocks && !blocks_forced) {
       const unsigned long long* hs = b.h_ss + f.slot * 16;
+      bool cheap = true;
       for (int m = 0; m < 2; ++m) {
         if (!blocks_now[m]) continue;
         const double by_rec = (double)(hs[4 * m + 1] - ss_seen[m][1]), by_rows = (double)(hs[4 * m + 2] - ss_seen[m][2]);
@@ -853,7 +858,9 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
         const double blocks_us = (by_rec * 0.7 + by_rows * 1.5) / chains + ssw.nchunks * 0.6 + 14.5;
         const double chain_us = (double)n * 0.0024;
         if (blocks_us > chain_us) blocks_now[m] = false;
+        else if (blocks_us > 0.5 * chain_us) cheap = false;
       }
+      ahead = cheap;
     }
   }
   }
