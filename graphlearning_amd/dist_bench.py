@@ -368,13 +368,26 @@ def main(args):
                          'exchanges_per_sweep': 1 if r_alt['global_halo'] > 0 else 0,
                          'exchange': r_alt['how']['exchange'], 'exchange_selftest': r_alt['how']['selftest']}
         emit(json.dumps(line))
-    if comm is not None:
-        comm.close()
-    # orderly teardown: sweeps and communicator are closed above, then the group
-    sync()
-    dist.barrier()
-    dist.destroy_process_group()
+
+    def teardown():     # orderly: sweeps are closed above, then the communicator, then the group
+        if comm is not None:
+            comm.close()
+        sync()
+        dist.barrier()
+        dist.destroy_process_group()
+    _finish(teardown)
+
+
+def _finish(teardown, seconds=30.0):
+    """The line is out; what is left is tearing communicators down -- the one thing that can still hang when an exchange went wrong on
+    some rank.  It gets `seconds`, then the process ends regardless (the supervising rank is waiting for this child's exit status)."""
+    import threading
+    th = threading.Thread(target=teardown, daemon=True)
+    th.start()
+    th.join(seconds)
     sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 def config4_features(n, world_shards=64, seed=2, d=64, C=10):
@@ -638,9 +651,11 @@ def main_config4(args):
             'exchange': how['exchange'], 'exchange_selftest': how['selftest'],
         }
         emit(json.dumps(line))
-    ds.close()
-    comm.close()
-    torch.cuda.synchronize()
-    dist.barrier()
-    dist.destroy_process_group()
-    sys.stdout.flush()
+
+    def teardown():
+        ds.close()
+        comm.close()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
+    _finish(teardown)
