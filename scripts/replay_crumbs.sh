@@ -1,0 +1,19 @@
+#!/bin/bash
+# Replay of a soak worker's test sequence (from its crumbs file): scripts/replay_crumbs.sh SEQUENCE_FILE FIRST_N COPIES REPEATS [GLX_FUZZ_BASE]
+#   COPIES processes at once (1 = the history alone, 12 = the history under the contention of the soak), each REPEATS times.
+seq=$1; first=$2; copies=${3:-1}; reps=${4:-1}; base=${5:-100000}
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$root"
+export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp GLX_FUZZ_SCALE=400 GLX_FUZZ_BASE=$base
+ids=$(head -n $first "$seq" | tr '\n' ' ')
+for r in $(seq $reps); do
+  pids=()
+  for c in $(seq $copies); do
+    python -m pytest $ids -q -p no:cacheprovider -x > /tmp/replay_${r}_${c}.log 2>&1 &
+    pids+=($!)
+  done
+  for c in $(seq $copies); do
+    wait ${pids[$((c-1))]}; echo "repeat $r copy $c: exit $? -- $(tail -n 1 /tmp/replay_${r}_${c}.log | cut -c1-200)"
+  done
+done
+cat gpurun_out/knn_mismatch.jsonl 2>/dev/null | cut -c1-4000
