@@ -136,6 +136,8 @@ _SIGNATURES = {
     'glx_cg_last_stop_margin': [_vp, _f64p],
     'glx_pool_set_enabled': [C.c_int],
     'glx_pool_set_poison': [C.c_int],
+    'glx_debug_set': [C.c_int],
+    'glx_debug_counters': [_vp],
     'glx_nearest_dist': [_vp, C.c_int64, C.c_int, _vp, C.c_int64, _vp, C.c_int],
     'glx_cg_last_block_stats': [_vp, C.POINTER(C.c_int)],
     'glx_host_fingerprint': [_vp, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)],
@@ -311,6 +313,16 @@ PINNED_RESULTS = True
 
 def pool_set_enabled(enabled):
     check(load().glx_pool_set_enabled(1 if enabled else 0), 'glx_pool_set_enabled')
+
+
+def debug_set(flags):
+    check(load().glx_debug_set(int(flags)), 'glx_debug_set')
+
+
+def debug_counters():
+    out = (C.c_uint64 * 4)()
+    check(load().glx_debug_counters(out), 'glx_debug_counters')
+    return dict(uploads_checked=int(out[0]), engine_readback_differs=int(out[1]), kernel_readback_differs=int(out[2]), bytes_differing=int(out[3]))
 
 
 def pool_set_poison(byte):

@@ -13,6 +13,8 @@
 #include "knn_internal.h"
 #include <chrono>
 #include <stdlib.h>
+#include <unistd.h>
+#include <vector>
 
 // statistics of the calling thread's last search (glx_knn_stats)
 static thread_local double g_knn_stats[16];
@@ -29,6 +31,55 @@ extern "C" int glx_knn_set_options(const glx_knn_options* opt) {
   GLX_CHECK(opt->filter >= 0 && opt->filter <= 2 && opt->lists >= 0 && opt->lists <= 2 && opt->nsplit >= 0 && opt->nsplit <= 8 &&
             opt->concat >= -1 && opt->concat <= 2, GLX_EINVAL, "glx_knn_set_options: value out of range");
   g_knn_opt = *opt;
+  return GLX_OK;
+}
+
+// ---- debugging aid: is the device copy of X the caller's X? ------------------------------------------------------------------------
+// glx_debug_set(1): after the upload of a search's features the device copy is read back TWICE -- by the copy engine, and through a
+// kernel (i.e. through the L2s) -- and compared with the caller's array; differences are counted (glx_debug_counters) and described
+// on stderr.  Round 6: the one parity failure of the randomised soak that left evidence was a search whose device copy of ONE row of X
+// was not the caller's (EXPERIMENTS.md round 6, section 2).
+static int g_debug_flags = 0;
+static unsigned long long g_debug_counts[4] = {0, 0, 0, 0};   // uploads checked, uploads whose engine read-back differed, whose kernel read-back differed, bytes differing
+extern "C" int glx_debug_set(int flags) { g_debug_flags = flags; return GLX_OK; }
+extern "C" int glx_debug_counters(unsigned long long out[4]) {
+  GLX_CHECK(out, GLX_EINVAL, "glx_debug_counters: null output");
+  for (int q = 0; q < 4; ++q) out[q] = g_debug_counts[q];
+  return GLX_OK;
+}
+__global__ __launch_bounds__(256) void knn_copy_u64_kernel(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+static int knn_verify_upload(const double* X_host, const double* X_dev, int64_t n, int d, hipStream_t st, const char* what) {
+  const size_t bytes = (size_t)n * d * 8;
+  GLX_HIP(hipStreamSynchronize(st));
+  std::vector<unsigned long long> back(bytes / 8);
+  ++g_debug_counts[0];
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 0) {
+      GLX_HIP(hipMemcpy(back.data(), X_dev, bytes, hipMemcpyDeviceToHost));
+    } else {
+      void* tmp = nullptr;
+      GLX_HIP(hipMalloc(&tmp, bytes));                  // (a fresh allocation, not a pooled block)
+      hipLaunchKernelGGL(knn_copy_u64_kernel, dim3(1024), dim3(256), 0, st, (const unsigned long long*)X_dev, (unsigned long long*)tmp, (int64_t)(bytes / 8));
+      hipError_t e = hipStreamSynchronize(st);
+      if (e == hipSuccess) e = hipMemcpy(back.data(), tmp, bytes, hipMemcpyDeviceToHost);
+      hipFree(tmp);
+      GLX_HIP(e);
+    }
+    const unsigned long long* src = (const unsigned long long*)X_host;
+    size_t nbad = 0, first = 0, last = 0;
+    for (size_t i = 0; i < bytes / 8; ++i)
+      if (back[i] != src[i]) { if (!nbad) first = i; last = i; ++nbad; }
+    if (nbad) {
+      ++g_debug_counts[1 + pass];
+      g_debug_counts[3] += nbad * 8;
+      fprintf(stderr, "[glx] knn DEBUG (%s, pid %d): the device copy of X read back by %s differs from the caller's array in %zu of %zu words: words %zu .. %zu "
+                      "(rows %zu .. %zu of %lld, d = %d; byte offsets %zu .. %zu; device address %p)\n", what, (int)getpid(),
+              pass == 0 ? "the copy engine" : "a kernel (through the L2s)", nbad, bytes / 8, first, last, first / d, last / d, (long long)n, d, first * 8, last * 8 + 7,
+              (const void*)X_dev);
+    }
+  }
   return GLX_OK;
 }
 
@@ -122,6 +173,15 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   // features are generated, ordered and kept on the GPU; the library-formed cells below read sample rows on the host and need a host X)
   GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyDefault, st));
   stamp("X enqueued");
+  if (g_debug_flags & 1) {
+    hipPointerAttribute_t at;
+    const bool on_host = hipPointerGetAttributes(&at, X) != hipSuccess || at.type != hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    if (on_host) {
+      const int rcv = knn_verify_upload(X, b.X, n, d, st, "after the upload");
+      if (rcv) return rcv;
+    }
+  }
   // Cells formed by the library (auto_cells).  > 1: that many cells (nearest of evenly spaced sample rows), the rows reordered by
   // cell and searched with the cell pruning of glx_knn_cells_range; the re-rank ranks by and returns the caller's indices.
   // < -1 (below the size where pruning pays): the rows ARE reordered by -auto_cells chained cells on the device and then searched

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Replay of a soak worker's test sequence (from its crumbs file): scripts/replay_crumbs.sh SEQUENCE_FILE FIRST_N COPIES REPEATS [GLX_FUZZ_BASE]
+#   (GLX_TEST_ABLATE / HIP_LAUNCH_BLOCKING are passed through; failures and the library's DEBUG lines are echoed)
 #   COPIES processes at once (1 = the history alone, 12 = the history under the contention of the soak), each REPEATS times.
 seq=$1; first=$2; copies=${3:-1}; reps=${4:-1}; base=${5:-100000}
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -9,11 +10,13 @@ ids=$(head -n $first "$seq" | tr '\n' ' ')
 for r in $(seq $reps); do
   pids=()
   for c in $(seq $copies); do
-    python -m pytest $ids -q -p no:cacheprovider -x > /tmp/replay_${r}_${c}.log 2>&1 &
+    python -m pytest $ids -q -s -p no:cacheprovider -x > /tmp/replay_${r}_${c}.log 2>&1 &
     pids+=($!)
   done
   for c in $(seq $copies); do
-    wait ${pids[$((c-1))]}; echo "repeat $r copy $c: exit $? -- $(tail -n 1 /tmp/replay_${r}_${c}.log | cut -c1-200)"
+    wait ${pids[$((c-1))]}; rc=$?
+    [ $rc -ne 0 ] && echo "repeat $r copy $c: exit $rc -- $(tail -n 1 /tmp/replay_${r}_${c}.log | cut -c1-200)"
+    grep -a "knn DEBUG" /tmp/replay_${r}_${c}.log | head -4 | cut -c1-500
   done
 done
-cat gpurun_out/knn_mismatch.jsonl 2>/dev/null | cut -c1-4000
+echo "replay done: $copies copies x $reps repeats of $first cases (GLX_TEST_ABLATE=$GLX_TEST_ABLATE HIP_LAUNCH_BLOCKING=$HIP_LAUNCH_BLOCKING)"

@@ -428,7 +428,8 @@ def _dump_knn_mismatch(seed, n, d, k, style, sim, J, D, J2, D2, Jo, Do, st1, st2
            'plain_equals_ckdtree': bool(np.array_equal(J, Jo) and np.max(np.abs(D - Do)) <= 1e-12 * scale),
            'ordered_equals_ckdtree': bool(np.array_equal(J2, Jo) and np.max(np.abs(D2 - Do)) <= 1e-12 * scale),
            'stats_plain': {a: (b if isinstance(b, str) else float(b)) for a, b in st1.items()},
-           'stats_ordered': {a: (b if isinstance(b, str) else float(b)) for a, b in st2.items()}, 'detail': [], 'again': []}
+           'stats_ordered': {a: (b if isinstance(b, str) else float(b)) for a, b in st2.items()}, 'detail': [], 'again': [],
+           'ablate': os.environ.get('GLX_TEST_ABLATE', ''), 'launch_blocking': os.environ.get('HIP_LAUNCH_BLOCKING', ''), 'debug_counters': _hip.debug_counters()}
     for i in rows[:6]:
         rec['detail'].append({'row': int(i), 'J_plain': J[i].tolist(), 'J_ordered': J2[i].tolist(), 'J_ckdtree': Jo[i].tolist(),
                               'D_plain': D[i].tolist(), 'D_ordered': D2[i].tolist(), 'D_ckdtree': Do[i].tolist()})
