@@ -75,9 +75,27 @@ static int knn_verify_upload(const double* X_host, const double* X_dev, int64_t 
       ++g_debug_counts[1 + pass];
       g_debug_counts[3] += nbad * 8;
       fprintf(stderr, "[glx] knn DEBUG (%s, pid %d): the device copy of X read back by %s differs from the caller's array in %zu of %zu words: words %zu .. %zu "
-                      "(rows %zu .. %zu of %lld, d = %d; byte offsets %zu .. %zu; device address %p)\n", what, (int)getpid(),
+                      "(rows %zu .. %zu of %lld, d = %d; byte offsets %zu .. %zu; device address %p; source address %p)\n", what, (int)getpid(),
               pass == 0 ? "the copy engine" : "a kernel (through the L2s)", nbad, bytes / 8, first, last, first / d, last / d, (long long)n, d, first * 8, last * 8 + 7,
-              (const void*)X_dev);
+              (const void*)X_dev, (const void*)X_host);
+      if (pass == 0) {
+        // what the wrong words hold: zeros, words of the SAME array from another place (a shifted or repeated piece), or nothing of it
+        size_t zeros = 0, shown = 0;
+        for (size_t i = first; i <= last; ++i) {
+          if (back[i] == src[i]) continue;
+          if (back[i] == 0) { ++zeros; continue; }
+          if (shown < 6) {
+            long long at = -1;
+            for (size_t j = 0; j < bytes / 8; ++j)
+              if (src[j] == back[i]) { at = (long long)j; break; }
+            fprintf(stderr, "[glx] knn DEBUG   word %zu: got %016llx (as a double %.6g), expected %016llx (%.6g); the value got %s%lld\n", i, back[i],
+                    __builtin_bit_cast(double, back[i]), src[i], __builtin_bit_cast(double, src[i]),
+                    at >= 0 ? "is word " : "occurs nowhere in the caller's array ", at);
+            ++shown;
+          }
+        }
+        fprintf(stderr, "[glx] knn DEBUG   %zu of the wrong words are zero\n", zeros);
+      }
     }
   }
   return GLX_OK;
