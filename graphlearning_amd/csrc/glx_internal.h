@@ -131,6 +131,9 @@ struct glx_work {
   int device = 0;
   void* stage = nullptr;          // page-locked host staging area of the set (glx_work_stage), kept with it
   size_t stage_bytes = 0;
+  void* up_stage = nullptr;       // page-locked staging area of glx_upload_staged: two halves that take turns
+  size_t up_bytes = 0;
+  hipEvent_t ev_up[2] = {nullptr, nullptr};
 };
 int glx_work_acquire(int device, glx_work** out);
 void glx_work_release(glx_work* w);
@@ -138,6 +141,11 @@ void glx_work_release(glx_work* w);
 // device-to-host copies of counters and lists land that the host then reads.  A copy into FRESH pageable memory makes the runtime
 // pin the destination on the fly -- 8 ms for a 280 KB std::vector the first time a graph of a new size is built.
 int glx_work_stage(glx_work* w, size_t bytes, void** out);
+// Host (pageable) -> device through the set's OWN page-locked staging area: chunks copied in by host threads, each followed by an
+// asynchronous copy from page-locked memory on `st`; the two halves of the area take turns.  Why not hipMemcpyAsync from the caller's array:
+// round 6 found that copy delivering wrong bytes (a run of < 1 KB) once in ~10 000 uploads of a search's features while a dozen processes
+// shared the GPU -- the one parity failure the randomised soak ever produced (EXPERIMENTS.md round 6, section 2).
+int glx_upload_staged(glx_work* w, void* dst, const void* src, size_t bytes, hipStream_t st);
 
 int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed = false);
 int glx_graph_ensure_order(glx_graph* g);

@@ -82,6 +82,9 @@ void work_destroy(glx_work* w) {
   if (w->side) hipStreamDestroy(w->side);
   if (w->stream) hipStreamDestroy(w->stream);
   if (w->stage) hipHostFree(w->stage);
+  if (w->up_stage) hipHostFree(w->up_stage);
+  for (int i = 0; i < 2; ++i)
+    if (w->ev_up[i]) hipEventDestroy(w->ev_up[i]);
   delete w;
 }
 }  // namespace
@@ -444,6 +447,45 @@ extern "C" int glx_host_free(void* p) {
     return GLX_OK;
   }
   GLX_HIP(hipHostFree(p));
+  return GLX_OK;
+}
+
+int glx_upload_staged(glx_work* w, void* dst, const void* src, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return GLX_OK;
+  const size_t HALF_MAX = (size_t)16 << 20;
+  size_t half = (size_t)1 << 16;
+  while (half < bytes && half < HALF_MAX) half <<= 1;
+  if (w->up_bytes < 2 * half) {
+    if (w->up_stage) {
+      for (int i = 0; i < 2; ++i)
+        if (w->ev_up[i]) GLX_HIP(hipEventSynchronize(w->ev_up[i]));
+      hipHostFree(w->up_stage);
+    }
+    w->up_stage = nullptr;
+    w->up_bytes = 0;
+    GLX_HIP(hipHostMalloc(&w->up_stage, 2 * half, hipHostMallocDefault));
+    w->up_bytes = 2 * half;
+  }
+  const size_t h = w->up_bytes / 2;
+  for (int i = 0; i < 2; ++i)
+    if (!w->ev_up[i]) GLX_HIP(hipEventCreateWithFlags(&w->ev_up[i], hipEventDisableTiming));
+  int turn = 0;
+  for (size_t off = 0; off < bytes; off += h, turn ^= 1) {
+    const size_t len = std::min(h, bytes - off);
+    char* stage = (char*)w->up_stage + (size_t)turn * h;
+    GLX_HIP(hipEventSynchronize(w->ev_up[turn]));          // (the copy that last read this half; an event never recorded is complete)
+    const int nt = (int)std::min<size_t>(4, std::max<size_t>(1, len >> 20));
+    if (nt > 1) {
+      host_pool().run(nt, [&](int t) {
+        const size_t a = len * (size_t)t / nt / 64 * 64, b2 = t + 1 == nt ? len : len * (size_t)(t + 1) / nt / 64 * 64;
+        memcpy(stage + a, (const char*)src + off + a, b2 - a);
+      });
+    } else {
+      memcpy(stage, (const char*)src + off, len);
+    }
+    GLX_HIP(hipMemcpyAsync((char*)dst + off, stage, len, hipMemcpyHostToDevice, st));
+    GLX_HIP(hipEventRecord(w->ev_up[turn], st));
+  }
   return GLX_OK;
 }
 

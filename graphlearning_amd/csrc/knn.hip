@@ -35,7 +35,8 @@ extern "C" int glx_knn_set_options(const glx_knn_options* opt) {
 }
 
 // ---- debugging aid: is the device copy of X the caller's X? ------------------------------------------------------------------------
-// glx_debug_set(1): after the upload of a search's features the device copy is read back TWICE -- by the copy engine, and through a
+// glx_debug_set(flags): bit 1 (2) = the upload of a search's features as rounds 1-5 did it (hipMemcpyAsync from the caller's pageable array;
+// the default since round 6 is the library's own page-locked staging, glx_upload_staged); bit 0 (1) = after the upload of a search's features the device copy is read back TWICE -- by the copy engine, and through a
 // kernel (i.e. through the L2s) -- and compared with the caller's array; differences are counted (glx_debug_counters) and described
 // on stderr.  Round 6: the one parity failure of the randomised soak that left evidence was a search whose device copy of ONE row of X
 // was not the caller's (EXPERIMENTS.md round 6, section 2).
@@ -187,14 +188,24 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   GLX_POOL(glx_pool_alloc((void**)&b.X, (size_t)n * d * 8));
   GLX_POOL(glx_pool_alloc((void**)&b.mean, d * 8));
   stamp("stream, events, buffers");
+  int rc0 = GLX_OK;
   // (hipMemcpyDefault: X may also be a DEVICE pointer -- glx_knn_bruteforce_range / glx_knn_cells_range of the sharded build, whose
   // features are generated, ordered and kept on the GPU; the library-formed cells below read sample rows on the host and need a host X)
-  GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyDefault, st));
+  bool on_host = true;
+  {
+    hipPointerAttribute_t at;
+    on_host = hipPointerGetAttributes(&at, X) != hipSuccess || (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged);
+    (void)hipGetLastError();
+  }
+  if (on_host && !(g_debug_flags & 2)) {
+    // the caller's (pageable) array goes up through the work set's own page-locked staging area (glx_internal.h: why)
+    rc0 = glx_upload_staged(b.work, b.X, X, (size_t)n * d * 8, st);
+    if (rc0) return rc0;
+  } else {
+    GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyDefault, st));
+  }
   stamp("X enqueued");
   if (g_debug_flags & 1) {
-    hipPointerAttribute_t at;
-    const bool on_host = hipPointerGetAttributes(&at, X) != hipSuccess || at.type != hipMemoryTypeDevice;
-    (void)hipGetLastError();
     if (on_host) {
       const int rcv = knn_verify_upload(X, b.X, n, d, st, "after the upload");
       if (rcv) return rcv;

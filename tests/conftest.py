@@ -77,7 +77,7 @@ _ABLATE = [a for a in os.environ.get('GLX_TEST_ABLATE', '').split(',') if a]
 @pytest.fixture(scope='session', autouse=True)
 def _ablations():
     if _ABLATE:
-        unknown = {a for a in _ABLATE if not a.startswith('poison')} - {'nopool', 'nopinned', 'nospec', 'verifyupload'}
+        unknown = {a for a in _ABLATE if not a.startswith('poison')} - {'nopool', 'nopinned', 'nospec', 'verifyupload', 'pageableupload'}
         assert not unknown, 'GLX_TEST_ABLATE: unknown names %s' % sorted(unknown)
         from graphlearning_amd import _hip, ssl
         if 'nospec' in _ABLATE:
@@ -87,8 +87,8 @@ def _ablations():
         for a in _ABLATE:                       # poison<byte>: every pooled work buffer is filled with that byte when handed out
             if a.startswith('poison') and _hip.load(required=False) is not None:
                 _hip.pool_set_poison(int(a[6:] or '255'))
-        if 'verifyupload' in _ABLATE and _hip.load(required=False) is not None:
-            _hip.debug_set(1)                 # every search checks its device copy of X against the caller's array (stderr + counters)
+        if ('verifyupload' in _ABLATE or 'pageableupload' in _ABLATE) and _hip.load(required=False) is not None:
+            _hip.debug_set((1 if 'verifyupload' in _ABLATE else 0) | (2 if 'pageableupload' in _ABLATE else 0))                 # every search checks its device copy of X against the caller's array (stderr + counters)
         if 'nopool' in _ABLATE and _hip.load(required=False) is not None:
             try:
                 _hip.pool_set_enabled(False)
