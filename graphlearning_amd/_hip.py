@@ -138,6 +138,7 @@ _SIGNATURES = {
     'glx_pool_set_poison': [C.c_int],
     'glx_debug_set': [C.c_int],
     'glx_debug_counters': [_vp],
+    'glx_upload_stats': [_vp],
     'glx_nearest_dist': [_vp, C.c_int64, C.c_int, _vp, C.c_int64, _vp, C.c_int],
     'glx_cg_last_block_stats': [_vp, C.POINTER(C.c_int)],
     'glx_host_fingerprint': [_vp, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)],
@@ -323,6 +324,14 @@ def debug_counters():
     out = (C.c_uint64 * 4)()
     check(load().glx_debug_counters(out), 'glx_debug_counters')
     return dict(uploads_checked=int(out[0]), engine_readback_differs=int(out[1]), kernel_readback_differs=int(out[2]), bytes_differing=int(out[3]))
+
+
+def upload_stats():
+    """The checked uploads of this process: how many were checked, how many arrived with a wrong sum, how many of those were repaired by a
+    repeat, how many given up (glx_upload_stats)."""
+    out = (C.c_uint64 * 4)()
+    check(load().glx_upload_stats(out), 'glx_upload_stats')
+    return dict(checked=int(out[0]), wrong_sums=int(out[1]), repaired=int(out[2]), given_up=int(out[3]))
 
 
 def pool_set_poison(byte):

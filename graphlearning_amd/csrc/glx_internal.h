@@ -134,6 +134,8 @@ struct glx_work {
   void* up_stage = nullptr;       // page-locked staging area of glx_upload_staged: two halves that take turns
   size_t up_bytes = 0;
   hipEvent_t ev_up[2] = {nullptr, nullptr};
+  unsigned long long* up_sum = nullptr;      // device word of the upload check (glx_upload_checked)
+  unsigned long long* up_sum_host = nullptr; // its page-locked mirror
 };
 int glx_work_acquire(int device, glx_work** out);
 void glx_work_release(glx_work* w);
@@ -145,7 +147,14 @@ int glx_work_stage(glx_work* w, size_t bytes, void** out);
 // asynchronous copy from page-locked memory on `st`; the two halves of the area take turns.  Why not hipMemcpyAsync from the caller's array:
 // round 6 found that copy delivering wrong bytes (a run of < 1 KB) once in ~10 000 uploads of a search's features while a dozen processes
 // shared the GPU -- the one parity failure the randomised soak ever produced (EXPERIMENTS.md round 6, section 2).
-int glx_upload_staged(glx_work* w, void* dst, const void* src, size_t bytes, hipStream_t st);
+int glx_upload_staged(glx_work* w, void* dst, const void* src, size_t bytes, hipStream_t st, unsigned long long* sum_out = nullptr,
+                      size_t stage_shift = 0);
+// The same, CHECKED: the host threads add the 64-bit words up while they copy them in, a kernel adds up what arrived on the device, and the
+// two sums are compared before the call returns (one stream synchronisation).  A difference is described on stderr (is the staging area
+// what the caller's array holds?  what does the device hold?), counted (glx_upload_stats) and the upload repeated through another part of
+// the staging area, up to three times; GLX_EHIP if none arrives intact.  `bytes` a multiple of 8; below 128 KB the check is skipped (the
+// faulty runs of round 6 all sat 128 KB or more into an upload).
+int glx_upload_checked(glx_work* w, void* dst, const void* src, size_t bytes, hipStream_t st, const char* what);
 
 int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed = false);
 int glx_graph_ensure_order(glx_graph* g);

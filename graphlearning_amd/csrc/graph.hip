@@ -42,6 +42,7 @@ extern "C" void glx_free(void* p) { free(p); }
 // kernels.  Work buffers of the one-shot entry points (knn.hip, assemble.hip) come from size-class free lists instead;
 // at most POOL_CAP bytes stay cached per process, larger blocks go straight back to the runtime.  Callers release a
 // buffer only after the stream that used it has been synchronised.
+#include <atomic>
 #include <map>
 #include <mutex>
 static const size_t POOL_CAP = 1ull << 30, POOL_BLOCK_MAX = 256ull << 20;
@@ -83,6 +84,8 @@ void work_destroy(glx_work* w) {
   if (w->stream) hipStreamDestroy(w->stream);
   if (w->stage) hipHostFree(w->stage);
   if (w->up_stage) hipHostFree(w->up_stage);
+  if (w->up_sum) hipFree(w->up_sum);
+  if (w->up_sum_host) hipHostFree(w->up_sum_host);
   for (int i = 0; i < 2; ++i)
     if (w->ev_up[i]) hipEventDestroy(w->ev_up[i]);
   delete w;
@@ -450,11 +453,29 @@ extern "C" int glx_host_free(void* p) {
   return GLX_OK;
 }
 
-int glx_upload_staged(glx_work* w, void* dst, const void* src, size_t bytes, hipStream_t st) {
+// copy `len` bytes (a multiple of 8 when a sum is asked for) and add the 64-bit words up (wrapping)
+static unsigned long long copy_and_sum(char* dst, const char* src, size_t len, bool want_sum) {
+  if (!want_sum) { memcpy(dst, src, len); return 0ull; }
+  const unsigned long long* s8 = (const unsigned long long*)src;
+  unsigned long long* d8 = (unsigned long long*)dst;
+  unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  const size_t nw = len / 8;
+  size_t i = 0;
+  for (; i + 4 <= nw; i += 4) {
+    const unsigned long long v0 = s8[i], v1 = s8[i + 1], v2 = s8[i + 2], v3 = s8[i + 3];
+    d8[i] = v0; d8[i + 1] = v1; d8[i + 2] = v2; d8[i + 3] = v3;
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; i < nw; ++i) { d8[i] = s8[i]; a0 += s8[i]; }
+  return a0 + a1 + a2 + a3;
+}
+
+int glx_upload_staged(glx_work* w, void* dst, const void* src, size_t bytes, hipStream_t st, unsigned long long* sum_out, size_t stage_shift) {
+  if (sum_out) *sum_out = 0ull;
   if (bytes == 0) return GLX_OK;
   const size_t HALF_MAX = (size_t)16 << 20;
   size_t half = (size_t)1 << 16;
-  while (half < bytes && half < HALF_MAX) half <<= 1;
+  while (half < bytes + stage_shift && half < HALF_MAX) half <<= 1;
   if (w->up_bytes < 2 * half) {
     if (w->up_stage) {
       for (int i = 0; i < 2; ++i)
@@ -467,26 +488,90 @@ int glx_upload_staged(glx_work* w, void* dst, const void* src, size_t bytes, hip
     w->up_bytes = 2 * half;
   }
   const size_t h = w->up_bytes / 2;
+  GLX_CHECK(stage_shift % 64 == 0 && stage_shift < h / 2, GLX_EINVAL, "glx_upload_staged: bad staging shift");
+  const size_t room = h - stage_shift;             // bytes of a half in use
   for (int i = 0; i < 2; ++i)
     if (!w->ev_up[i]) GLX_HIP(hipEventCreateWithFlags(&w->ev_up[i], hipEventDisableTiming));
   int turn = 0;
-  for (size_t off = 0; off < bytes; off += h, turn ^= 1) {
-    const size_t len = std::min(h, bytes - off);
-    char* stage = (char*)w->up_stage + (size_t)turn * h;
+  unsigned long long total = 0;
+  for (size_t off = 0; off < bytes; off += room, turn ^= 1) {
+    const size_t len = std::min(room, bytes - off);
+    char* stage = (char*)w->up_stage + (size_t)turn * h + stage_shift;
     GLX_HIP(hipEventSynchronize(w->ev_up[turn]));          // (the copy that last read this half; an event never recorded is complete)
     const int nt = (int)std::min<size_t>(4, std::max<size_t>(1, len >> 20));
     if (nt > 1) {
+      unsigned long long part[4] = {0, 0, 0, 0};
       host_pool().run(nt, [&](int t) {
         const size_t a = len * (size_t)t / nt / 64 * 64, b2 = t + 1 == nt ? len : len * (size_t)(t + 1) / nt / 64 * 64;
-        memcpy(stage + a, (const char*)src + off + a, b2 - a);
+        part[t] = copy_and_sum(stage + a, (const char*)src + off + a, b2 - a, sum_out != nullptr);
       });
+      total += part[0] + part[1] + part[2] + part[3];
     } else {
-      memcpy(stage, (const char*)src + off, len);
+      total += copy_and_sum(stage, (const char*)src + off, len, sum_out != nullptr);
     }
     GLX_HIP(hipMemcpyAsync((char*)dst + off, stage, len, hipMemcpyHostToDevice, st));
     GLX_HIP(hipEventRecord(w->ev_up[turn], st));
   }
+  if (sum_out) *sum_out = total;
   return GLX_OK;
+}
+
+__global__ __launch_bounds__(256) void upload_sum_kernel(const unsigned long long* __restrict__ p, int64_t nwords, unsigned long long* __restrict__ out) {
+  unsigned long long a = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * 256) a += p[i];
+  for (int off = 32; off >= 1; off >>= 1) a += (unsigned long long)__shfl_xor((long long)a, off);
+  if ((threadIdx.x & 63) == 0 && a) atomicAdd(out, a);
+}
+
+static std::atomic<unsigned long long> g_upload_stats[4];       // uploads checked, sums that differed, uploads repeated successfully, given up
+extern "C" int glx_upload_stats(unsigned long long out[4]) {
+  GLX_CHECK(out, GLX_EINVAL, "glx_upload_stats: null output");
+  for (int q = 0; q < 4; ++q) out[q] = g_upload_stats[q].load();
+  return GLX_OK;
+}
+
+int glx_upload_checked(glx_work* w, void* dst, const void* src, size_t bytes, hipStream_t st, const char* what) {
+  if (bytes < ((size_t)128 << 10) || bytes % 8 != 0) return glx_upload_staged(w, dst, src, bytes, st);
+  if (!w->up_sum) GLX_HIP(hipMalloc((void**)&w->up_sum, 64));
+  if (!w->up_sum_host) GLX_HIP(hipHostMalloc((void**)&w->up_sum_host, 64, hipHostMallocDefault));
+  ++g_upload_stats[0];
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    unsigned long long want = 0;
+    // (a repeat goes through another part of the staging area: the faulty runs of round 6 stayed at ONE offset of the area from upload to upload)
+    int rc = glx_upload_staged(w, dst, src, bytes, st, &want, (size_t)attempt * 12288);
+    if (rc) return rc;
+    GLX_HIP(hipMemsetAsync(w->up_sum, 0, 8, st));
+    const int64_t nw = (int64_t)(bytes / 8);
+    hipLaunchKernelGGL(upload_sum_kernel, dim3((unsigned)std::min<int64_t>(2048, (nw + 255) / 256)), dim3(256), 0, st, (const unsigned long long*)dst, nw, w->up_sum);
+    GLX_HIP(hipGetLastError());
+    GLX_HIP(hipMemcpyAsync(w->up_sum_host, w->up_sum, 8, hipMemcpyDeviceToHost, st));
+    GLX_HIP(hipStreamSynchronize(st));
+    if (*w->up_sum_host == want) {
+      if (attempt) ++g_upload_stats[2];
+      return GLX_OK;
+    }
+    ++g_upload_stats[1];
+    // what went wrong where: the staging area against the caller's array (single-piece uploads: the area still holds the whole array),
+    // and the device copy, read back, against it
+    size_t stage_bad = 0, dev_bad = 0, first = 0, last = 0, zeros = 0;
+    const unsigned long long* s8 = (const unsigned long long*)src;
+    if (bytes + (size_t)attempt * 12288 <= w->up_bytes / 2) {
+      const unsigned long long* g8 = (const unsigned long long*)((const char*)w->up_stage + (size_t)attempt * 12288);
+      for (size_t i = 0; i < bytes / 8; ++i) stage_bad += g8[i] != s8[i];
+    }
+    std::vector<unsigned long long> back(bytes / 8);
+    if (hipMemcpy(back.data(), dst, bytes, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (size_t i = 0; i < bytes / 8; ++i)
+        if (back[i] != s8[i]) { if (!dev_bad) first = i; last = i; ++dev_bad; zeros += back[i] == 0; }
+    }
+    (void)hipGetLastError();
+    fprintf(stderr, "[glx] upload check (%s, pid %d, attempt %d): %zu bytes arrived with sum %016llx instead of %016llx -- the staging area differs from "
+                    "the caller's array in %zu words, the device copy in %zu (bytes %zu .. %zu of the upload, %zu of them zero); repeating the upload\n",
+            what, (int)getpid(), attempt, bytes, *w->up_sum_host, want, stage_bad, dev_bad, first * 8, last * 8 + 7, zeros);
+  }
+  ++g_upload_stats[3];
+  glx_set_error("%s: the upload of %zu bytes did not arrive intact in four attempts", what, bytes);
+  return GLX_EHIP;
 }
 
 int glx_make_layout(int C, int dtype, bool has_w, RecLayout* L) {

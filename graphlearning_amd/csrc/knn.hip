@@ -199,7 +199,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   }
   if (on_host && !(g_debug_flags & 2)) {
     // the caller's (pageable) array goes up through the work set's own page-locked staging area (glx_internal.h: why)
-    rc0 = glx_upload_staged(b.work, b.X, X, (size_t)n * d * 8, st);
+    rc0 = glx_upload_checked(b.work, b.X, X, (size_t)n * d * 8, st, "features of a search");
     if (rc0) return rc0;
   } else {
     GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyDefault, st));

@@ -119,6 +119,9 @@ int glx_pool_set_poison(int byte);
  * (default: through the library's own page-locked staging area); bit 0 = after the upload of a search's features read the device copy back (by the copy engine and through a
  * kernel) and compare it with the caller's array; counters: uploads checked, uploads whose engine / kernel read-back differed, bytes differing */
 int glx_debug_set(int flags);
+/* the checked uploads of this process (csrc/glx_internal.h glx_upload_checked): uploads checked, sums that differed, uploads that arrived intact on
+ * a repeat, uploads given up */
+int glx_upload_stats(unsigned long long out[4]);
 int glx_debug_counters(unsigned long long out[4]);
 
 /* out[i] = exp(x[i]) correctly rounded (csrc/exp_cr.h: the exponential of the Gaussian weights), host arrays; a test hook */

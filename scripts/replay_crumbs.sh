@@ -16,7 +16,7 @@ for r in $(seq $reps); do
   for c in $(seq $copies); do
     wait ${pids[$((c-1))]}; rc=$?
     [ $rc -ne 0 ] && echo "repeat $r copy $c: exit $rc -- $(tail -n 1 /tmp/replay_${r}_${c}.log | cut -c1-200)"
-    grep -a "knn DEBUG" /tmp/replay_${r}_${c}.log | head -12 | cut -c1-600
+    grep -a "knn DEBUG\|upload check" /tmp/replay_${r}_${c}.log | head -12 | cut -c1-700
   done
 done
 echo "replay done: $copies copies x $reps repeats of $first cases (GLX_TEST_ABLATE=$GLX_TEST_ABLATE HIP_LAUNCH_BLOCKING=$HIP_LAUNCH_BLOCKING)"

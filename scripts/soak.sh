@@ -30,4 +30,6 @@ for f in "$root"/gpurun_out/$tag/inst*/crumbs/*.log; do
   last=$(grep -a -E ' (START|PASSED|FAILED|SKIPPED) ' "$f" | tail -n 1)
   case "$last" in *" START "*|*" FAILED "*) echo "   $(basename $(dirname $(dirname $f)))/$(basename $f): $last" | cut -c1-300;; esac
 done
+# the checked uploads of every process (tests/conftest.py writes them at the end of its session)
+grep -a -h ' UPLOADS ' "$root"/gpurun_out/$tag/inst*/crumbs/*.log | awk '{c+=gensub(/.*checked.: ([0-9]+).*/,"\\1",1); w+=gensub(/.*wrong_sums.: ([0-9]+).*/,"\\1",1); r+=gensub(/.*repaired.: ([0-9]+).*/,"\\1",1); g+=gensub(/.*given_up.: ([0-9]+).*/,"\\1",1)} END {printf "uploads checked %d, wrong sums %d, repaired by a repeat %d, given up %d\n", c, w, r, g}'
 exit $bad
