@@ -31,5 +31,12 @@ for f in "$root"/gpurun_out/$tag/inst*/crumbs/*.log; do
   case "$last" in *" START "*|*" FAILED "*) echo "   $(basename $(dirname $(dirname $f)))/$(basename $f): $last" | cut -c1-300;; esac
 done
 # the checked uploads of every process (tests/conftest.py writes them at the end of its session)
-grep -a -h ' UPLOADS ' "$root"/gpurun_out/$tag/inst*/crumbs/*.log | awk '{c+=gensub(/.*checked.: ([0-9]+).*/,"\\1",1); w+=gensub(/.*wrong_sums.: ([0-9]+).*/,"\\1",1); r+=gensub(/.*repaired.: ([0-9]+).*/,"\\1",1); g+=gensub(/.*given_up.: ([0-9]+).*/,"\\1",1)} END {printf "uploads checked %d, wrong sums %d, repaired by a repeat %d, given up %d\n", c, w, r, g}'
+grep -a -h ' UPLOADS ' "$root"/gpurun_out/$tag/inst*/crumbs/*.log | python3 -c "
+import sys, re
+t = [0, 0, 0, 0]
+for ln in sys.stdin:
+    v = re.findall(r': (\\d+)', ln.split('UPLOADS', 1)[1])
+    for q in range(min(4, len(v))): t[q] += int(v[q])
+print('uploads checked %d, wrong sums %d, repaired by a repeat %d, given up %d' % tuple(t))
+"
 exit $bad
