@@ -139,6 +139,7 @@ _SIGNATURES = {
     'glx_debug_set': [C.c_int],
     'glx_debug_counters': [_vp],
     'glx_upload_stats': [_vp],
+    'glx_upload_set_mode': [C.c_int],
     'glx_nearest_dist': [_vp, C.c_int64, C.c_int, _vp, C.c_int64, _vp, C.c_int],
     'glx_cg_last_block_stats': [_vp, C.POINTER(C.c_int)],
     'glx_host_fingerprint': [_vp, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)],
@@ -324,6 +325,11 @@ def debug_counters():
     out = (C.c_uint64 * 4)()
     check(load().glx_debug_counters(out), 'glx_debug_counters')
     return dict(uploads_checked=int(out[0]), engine_readback_differs=int(out[1]), kernel_readback_differs=int(out[2]), bytes_differing=int(out[3]))
+
+
+def upload_set_mode(mode):
+    """0 staged + checked (default), 1 staged, 2 straight from the caller's pageable memory (rounds 1-5)."""
+    check(load().glx_upload_set_mode(int(mode)), 'glx_upload_set_mode')
 
 
 def upload_stats():

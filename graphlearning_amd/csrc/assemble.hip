@@ -426,15 +426,15 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
     b.borrowed = true;
   } else {
     GLX_POOL(glx_pool_alloc((void**)&b.ind, (size_t)n * kk * 8));
-    GLX_HIP(hipMemcpyAsync(b.ind, ind, (size_t)n * kk * 8, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.ind, ind, (size_t)n * kk * 8, st, __func__));
   }
   if (dist && !res) {
     GLX_POOL(glx_pool_alloc((void**)&b.dist, (size_t)n * kk * 8));
-    GLX_HIP(hipMemcpyAsync(b.dist, dist, (size_t)n * kk * 8, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.dist, dist, (size_t)n * kk * 8, st, __func__));
   }
   if (kernel == K_GIVEN) {
     GLX_POOL(glx_pool_alloc((void**)&b.given, ne * 8));
-    GLX_HIP(hipMemcpyAsync(b.given, weights, ne * 8, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.given, weights, ne * 8, st, __func__));
   }
   GLX_POOL(glx_pool_alloc((void**)&b.w, ne * 8));
   GLX_POOL(glx_pool_alloc((void**)&b.rcnt, (n + 1) * 4));
@@ -467,7 +467,7 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
   GLX_CHECK(!flags[0], GLX_EINVAL, "glx_knn_to_csr: neighbour index out of range");
   std::vector<int64_t> roff(n + 1, 0);
   for (int64_t i = 0; i < n; ++i) roff[i + 1] = roff[i] + rcnt[i];
-  GLX_HIP(hipMemcpyAsync(b.roff, roff.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+  GLX_UP(glx_upload(b.roff, roff.data(), (n + 1) * 8, st, __func__));
   hipLaunchKernelGGL(fill_reverse_kernel, dim3(ge), dim3(256), 0, st, (const int64_t*)b.ind, (const double*)b.w, n, kk, k,
                      (const int64_t*)b.roff, b.cursor, b.rsrc, b.rpos, b.rw);
   GLX_HIP(hipGetLastError());
@@ -493,7 +493,7 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
                          b.tcol, b.tval, b.flag + 1, (int64_t)0);
     } else if (!big.empty()) {
       GLX_POOL(glx_pool_alloc((void**)&b.biglist, big.size() * 4));
-      GLX_HIP(hipMemcpyAsync(b.biglist, big.data(), big.size() * 4, hipMemcpyHostToDevice, st));
+      GLX_UP(glx_upload(b.biglist, big.data(), big.size() * 4, st, __func__));
       hipLaunchKernelGGL(merge_rows_kernel, dim3((unsigned)((big.size() + 3) / 4)), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, n, kk, k,
                          (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 2, b.rowcnt, (const int64_t*)nullptr,
                          b.tcol, b.tval, b.flag + 1, (int64_t)0, 64, (const int*)b.biglist, (int)big.size());
@@ -521,8 +521,8 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
     GLX_POOL(glx_pool_alloc((void**)&b.hub_cnt, nh * 4));
     GLX_POOL(glx_pool_alloc((void**)&b.skey, (size_t)hoff.back() * 8));
     GLX_POOL(glx_pool_alloc((void**)&b.sval, (size_t)hoff.back() * 8));
-    GLX_HIP(hipMemcpyAsync(b.hub_row, hrow.data(), nh * 8, hipMemcpyHostToDevice, st));
-    GLX_HIP(hipMemcpyAsync(b.hub_off, hoff.data(), (nh + 1) * 8, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.hub_row, hrow.data(), nh * 8, st, __func__));
+    GLX_UP(glx_upload(b.hub_off, hoff.data(), (nh + 1) * 8, st, __func__));
     hipLaunchKernelGGL(merge_hub_kernel, dim3((unsigned)nh), dim3(1024), 0, st, (const int64_t*)b.ind, (const double*)b.w, kk, k,
                        (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 0,
                        (const int64_t*)b.hub_row, (const int64_t*)b.hub_off, b.skey, b.sval, b.hub_cnt, (const int64_t*)nullptr,
@@ -537,7 +537,7 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
   for (int64_t i = 0; i < n; ++i) rp[i + 1] = rp[i] + rowcnt[i];
   const int64_t nnz = rp[n];
   GLX_CHECK(nnz < (1ll << 31), GLX_EUNSUPPORTED, "glx_knn_to_csr: nnz %lld does not fit the int32 CSR of the reference", (long long)nnz);
-  GLX_HIP(hipMemcpyAsync(b.rowptr, rp.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+  GLX_UP(glx_upload(b.rowptr, rp.data(), (n + 1) * 8, st, __func__));
   const bool own = cap < 0;
   GLX_CHECK(own || nnz <= cap, GLX_EINVAL, "glx_knn_to_csr_into: %lld entries, room for %lld", (long long)nnz, (long long)cap);
   int32_t* h_rp = own ? (int32_t*)malloc((n + 1) * 4) : *rowptr_out;
@@ -648,9 +648,9 @@ extern "C" int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, 
   int64_t *d_rrow = nullptr, *d_rsrc64 = nullptr, *d_rpos64 = nullptr;
   struct Extra { int64_t *a = nullptr, *b = nullptr, *c = nullptr; ~Extra() { glx_pool_free(a); glx_pool_free(b); glx_pool_free(c); } } ex;
   GLX_POOL(glx_pool_alloc((void**)&b.ind, (size_t)ne * 8));
-  GLX_HIP(hipMemcpyAsync(b.ind, ind_own, (size_t)ne * 8, hipMemcpyHostToDevice, st));
+  GLX_UP(glx_upload(b.ind, ind_own, (size_t)ne * 8, st, __func__));
   GLX_POOL(glx_pool_alloc((void**)&b.w, (size_t)ne * 8));
-  GLX_HIP(hipMemcpyAsync(b.w, w_own, (size_t)ne * 8, hipMemcpyHostToDevice, st));
+  GLX_UP(glx_upload(b.w, w_own, (size_t)ne * 8, st, __func__));
   GLX_POOL(glx_pool_alloc((void**)&b.rcnt, (m + 1) * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.cursor, (m + 1) * 4));
   GLX_POOL(glx_pool_alloc((void**)&b.roff, (m + 1) * 8));
@@ -670,10 +670,10 @@ extern "C" int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, 
     GLX_POOL(glx_pool_alloc((void**)&ex.c, (size_t)nr * 8));
     GLX_POOL(glx_pool_alloc((void**)&b.dist, (size_t)nr * 8));
     d_rrow = ex.a; d_rsrc64 = ex.b; d_rpos64 = ex.c;
-    GLX_HIP(hipMemcpyAsync(d_rrow, rev_row, (size_t)nr * 8, hipMemcpyHostToDevice, st));
-    GLX_HIP(hipMemcpyAsync(d_rsrc64, rev_src, (size_t)nr * 8, hipMemcpyHostToDevice, st));
-    GLX_HIP(hipMemcpyAsync(d_rpos64, rev_pos, (size_t)nr * 8, hipMemcpyHostToDevice, st));
-    GLX_HIP(hipMemcpyAsync(b.dist, rev_w, (size_t)nr * 8, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(d_rrow, rev_row, (size_t)nr * 8, st, __func__));
+    GLX_UP(glx_upload(d_rsrc64, rev_src, (size_t)nr * 8, st, __func__));
+    GLX_UP(glx_upload(d_rpos64, rev_pos, (size_t)nr * 8, st, __func__));
+    GLX_UP(glx_upload(b.dist, rev_w, (size_t)nr * 8, st, __func__));
     hipLaunchKernelGGL(count_rev_rows_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, (const int64_t*)d_rrow, nr, row_base, m, b.rcnt, b.flag);
     hipLaunchKernelGGL(check_cols_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, (const int64_t*)d_rsrc64, nr, n_cols, b.flag);
   }
@@ -689,7 +689,7 @@ extern "C" int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, 
   GLX_CHECK(!flags[0], GLX_EINVAL, "glx_knn_rows_to_csr: index out of range (a neighbour id, or a reverse entry outside the block)");
   std::vector<int64_t> roff(m + 1, 0);
   for (int64_t i = 0; i < m; ++i) roff[i + 1] = roff[i] + rcnt[i];
-  GLX_HIP(hipMemcpyAsync(b.roff, roff.data(), (m + 1) * 8, hipMemcpyHostToDevice, st));
+  GLX_UP(glx_upload(b.roff, roff.data(), (m + 1) * 8, st, __func__));
   if (nr > 0) {
     hipLaunchKernelGGL(fill_rev_rows_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, (const int64_t*)d_rrow, (const int64_t*)d_rsrc64,
                        (const int64_t*)d_rpos64, (const double*)b.dist, nr, row_base, (const int64_t*)b.roff, b.cursor, b.rsrc, b.rpos, b.rw);
@@ -717,7 +717,7 @@ extern "C" int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, 
                          b.tcol, b.tval, b.flag + 1, row_base);
     } else if (!big.empty()) {
       GLX_POOL(glx_pool_alloc((void**)&b.biglist, big.size() * 4));
-      GLX_HIP(hipMemcpyAsync(b.biglist, big.data(), big.size() * 4, hipMemcpyHostToDevice, st));
+      GLX_UP(glx_upload(b.biglist, big.data(), big.size() * 4, st, __func__));
       hipLaunchKernelGGL(merge_rows_kernel, dim3((unsigned)((big.size() + 3) / 4)), dim3(256), shm, st, (const int64_t*)b.ind, (const double*)b.w, m, k, k,
                          (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 2, b.rowcnt, (const int64_t*)nullptr,
                          b.tcol, b.tval, b.flag + 1, row_base, 64, (const int*)b.biglist, (int)big.size());
@@ -744,8 +744,8 @@ extern "C" int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, 
     GLX_POOL(glx_pool_alloc((void**)&b.hub_cnt, nh * 4));
     GLX_POOL(glx_pool_alloc((void**)&b.skey, (size_t)hoff.back() * 8));
     GLX_POOL(glx_pool_alloc((void**)&b.sval, (size_t)hoff.back() * 8));
-    GLX_HIP(hipMemcpyAsync(b.hub_row, hrow.data(), nh * 8, hipMemcpyHostToDevice, st));
-    GLX_HIP(hipMemcpyAsync(b.hub_off, hoff.data(), (nh + 1) * 8, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.hub_row, hrow.data(), nh * 8, st, __func__));
+    GLX_UP(glx_upload(b.hub_off, hoff.data(), (nh + 1) * 8, st, __func__));
     hipLaunchKernelGGL(merge_hub_kernel, dim3((unsigned)nh), dim3(1024), 0, st, (const int64_t*)b.ind, (const double*)b.w, k, k,
                        (const int64_t*)b.roff, (const int*)b.rsrc, (const unsigned short*)b.rpos, (const double*)b.rw, sym, 0,
                        (const int64_t*)b.hub_row, (const int64_t*)b.hub_off, b.skey, b.sval, b.hub_cnt, (const int64_t*)nullptr,
@@ -761,7 +761,7 @@ extern "C" int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, 
   const int64_t nnz = rp[m];
   GLX_CHECK(nnz < (1ll << 31), GLX_EUNSUPPORTED, "glx_knn_rows_to_csr: nnz %lld does not fit an int32 CSR", (long long)nnz);
   GLX_CHECK(nnz <= cap, GLX_EINVAL, "glx_knn_rows_to_csr: %lld entries, room for %lld", (long long)nnz, (long long)cap);
-  GLX_HIP(hipMemcpyAsync(b.rowptr, rp.data(), (m + 1) * 8, hipMemcpyHostToDevice, st));
+  GLX_UP(glx_upload(b.rowptr, rp.data(), (m + 1) * 8, st, __func__));
   GLX_POOL(glx_pool_alloc((void**)&b.col, std::max<size_t>(nnz * 4, 4)));
   GLX_POOL(glx_pool_alloc((void**)&b.val, std::max<size_t>(nnz * 8, 8)));
   hipLaunchKernelGGL(compact_rows_kernel, dim3(gr), dim3(256), 0, st, (const int*)b.rowcnt, (const int64_t*)b.roff, m, k, sym, (const int64_t*)b.rowptr,
@@ -775,8 +775,8 @@ extern "C" int glx_knn_rows_to_csr(const int64_t* ind_own, const double* w_own, 
     GLX_HIP(hipGetLastError());
   }
   for (int64_t i = 0; i <= m; ++i) rowptr_out[i] = (int32_t)rp[i];
-  GLX_HIP(hipMemcpyAsync(col_out, b.col, nnz * 4, hipMemcpyDeviceToHost, st));
-  GLX_HIP(hipMemcpyAsync(val_out, b.val, nnz * 8, hipMemcpyDeviceToHost, st));
+  GLX_UP(glx_download(col_out, b.col, nnz * 4, st, __func__));
+  GLX_UP(glx_download(val_out, b.val, nnz * 8, st, __func__));
   GLX_HIP(hipStreamSynchronize(st));
   *nnz_out = nnz;
   return GLX_OK;

@@ -567,13 +567,13 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       CG_NEED(b.pw_r, std::max<size_t>(ni, 1) * 4);
       CG_NEED(b.pw_ls, ph.level_start.size() * 4 + 4);
       CG_NEED(b.pw_vals, (nl + ni) * 8);
-      GLX_HIP(hipMemcpy(b.pw_off, ph.leaf_off.data(), nl * 8, hipMemcpyHostToDevice));
-      GLX_HIP(hipMemcpy(b.pw_len, ph.leaf_len.data(), nl * 4, hipMemcpyHostToDevice));
+      GLX_UP(glx_upload_sync(b.pw_off, ph.leaf_off.data(), nl * 8, __func__));
+      GLX_UP(glx_upload_sync(b.pw_len, ph.leaf_len.data(), nl * 4, __func__));
       if (ni) {
-        GLX_HIP(hipMemcpy(b.pw_l, ph.node_l.data(), ni * 4, hipMemcpyHostToDevice));
-        GLX_HIP(hipMemcpy(b.pw_r, ph.node_r.data(), ni * 4, hipMemcpyHostToDevice));
+        GLX_UP(glx_upload_sync(b.pw_l, ph.node_l.data(), ni * 4, __func__));
+        GLX_UP(glx_upload_sync(b.pw_r, ph.node_r.data(), ni * 4, __func__));
       }
-      if (!ph.level_start.empty()) GLX_HIP(hipMemcpy(b.pw_ls, ph.level_start.data(), ph.level_start.size() * 4, hipMemcpyHostToDevice));
+      if (!ph.level_start.empty()) GLX_UP(glx_upload_sync(b.pw_ls, ph.level_start.data(), ph.level_start.size() * 4, __func__));
       b.pw.leaf_off = b.pw_off;
       b.pw.leaf_len = b.pw_len;
       b.pw.node_l = b.pw_l;
@@ -609,7 +609,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
   hipLaunchKernelGGL(cg_set_err0, dim3((unsigned)((hist_cap * stride + 255) / 256)), blk, 0, st, b.err_hist, hist_cap * stride, stride, CG_CHUNK);
   GLX_HIP(hipGetLastError());
   if (flags & GLX_CG_X0) {   // X holds x0 on entry; B is the caller's r0 = b - A@x0 (utils.py:510-514)
-    GLX_HIP(hipMemcpyAsync(b.dense, X, (size_t)n * C * es, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.dense, X, (size_t)n * C * es, st, __func__));
     rc = glx_pack_records(b.dense, b.x, n, L, dtype, nullptr, st, A->d_perm);
     if (rc) return rc;
   } else {
@@ -622,20 +622,20 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     GLX_HIP(hipMemsetAsync(b.r, 0, recb, st));
     if (rr.nb > 0) {
       CG_NEED(b.rhs_rows, (size_t)rr.nb * 4);
-      GLX_HIP(hipMemcpyAsync(b.rhs_rows, rr.rows, (size_t)rr.nb * 4, hipMemcpyHostToDevice, st));
-      GLX_HIP(hipMemcpyAsync(b.dense, rr.vals, (size_t)rr.nb * C * es, hipMemcpyHostToDevice, st));
+      GLX_UP(glx_upload(b.rhs_rows, rr.rows, (size_t)rr.nb * 4, st, __func__));
+      GLX_UP(glx_upload(b.dense, rr.vals, (size_t)rr.nb * C * es, st, __func__));
       hipLaunchKernelGGL((cg_scatter_rows_kernel<T>), dim3((unsigned)((rr.nb * C + 255) / 256)), dim3(256), 0, st, (T*)b.r, L.ld, C,
                          (const int32_t*)b.rhs_rows, (const T*)b.dense, rr.nb, (const int32_t*)A->d_inv);
       GLX_HIP(hipGetLastError());
     }
   } else {
-    GLX_HIP(hipMemcpyAsync(b.dense, B, (size_t)n * C * es, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.dense, B, (size_t)n * C * es, st, __func__));
     rc = glx_pack_records(b.dense, b.r, n, L, dtype, nullptr, st, A->d_perm);   // r = b - A@0 = b (utils.py:514)
     if (rc) return rc;
   }
   if (rr.out_scale) {
     CG_NEED(b.out_scale, (size_t)n * 8);
-    GLX_HIP(hipMemcpyAsync(b.out_scale, rr.out_scale, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.out_scale, rr.out_scale, (size_t)n * 8, st, __func__));
   }
   GLX_HIP(hipMemcpyAsync(b.p, b.r, recb, hipMemcpyDeviceToDevice, st));   // p = r.copy() (utils.py:516)
   hipLaunchKernelGGL((cg_update_kernel<T, 1>), dim3((unsigned)nb_upd), blk, 0, st, x, r, (const T*)p, (const T*)ap,
@@ -682,8 +682,8 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     }
     CG_NEED(b.mask_rows, (size_t)total * 4);
     CG_NEED(b.mask_ptr, (size_t)(ngroups + 1) * 4);
-    GLX_HIP(hipMemcpy(b.mask_rows, rec.data(), (size_t)total * 4, hipMemcpyHostToDevice));
-    GLX_HIP(hipMemcpy(b.mask_ptr, mask_ptr, (size_t)(ngroups + 1) * 4, hipMemcpyHostToDevice));
+    GLX_UP(glx_upload_sync(b.mask_rows, rec.data(), (size_t)total * 4, __func__));
+    GLX_UP(glx_upload_sync(b.mask_ptr, mask_ptr, (size_t)(ngroups + 1) * 4, __func__));
     mask_grid = (unsigned)(((int64_t)most * Cg + 255) / 256);
     if (ngroups <= 32) {
       // the SpMM itself holds A p at zero on these rows (a bit per system in rowmask[record]): no kernel behind it.  (The products
@@ -871,7 +871,7 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
     rc = glx_unpack_records(b.x, b.dense, n, L, dtype, st, A->d_perm);
     if (rc) return rc;
   }
-  GLX_HIP(hipMemcpyAsync(X, b.dense, (size_t)n * C * es, hipMemcpyDeviceToHost, st));
+  GLX_UP(glx_download(X, b.dense, (size_t)n * C * es, st, __func__));
   if (ss_blocks) GLX_HIP(hipMemcpyAsync(b.h_ss, b.ss_stats, 128, hipMemcpyDeviceToHost, st));
   GLX_HIP(hipStreamSynchronize(st));
   for (int q = 0; q < 3; ++q)     // (the entry point hands out ints: clamped, never negative -- -1 is the chain form's mark)

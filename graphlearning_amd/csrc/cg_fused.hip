@@ -369,14 +369,14 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
   }
   const bool keep_x = (flags & GLX_CG_X0) != 0;
   if (keep_x) {   // X holds x0 on entry; B is the caller's r0 = b - A@x0 (utils.py:510-514)
-    GLX_HIP(hipMemcpyAsync(b.dense, X, (size_t)n * C * es, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.dense, X, (size_t)n * C * es, st, __func__));
     rc = glx_pack_records(b.dense, b.x, n, L, dtype, nullptr, st, A->d_perm);
     if (rc) return rc;
   }
   if (rr.rows) {
     GLX_HIP(hipMemsetAsync(b.r, 0, recb, st));
   } else {
-    GLX_HIP(hipMemcpyAsync(b.dense, B, (size_t)n * C * es, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.dense, B, (size_t)n * C * es, st, __func__));
     rc = glx_pack_records(b.dense, b.r, n, L, dtype, nullptr, st, A->d_perm);   // r = b - A@0 = b (utils.py:514)
     if (rc) return rc;
   }
@@ -570,7 +570,7 @@ int glx_cg_run_fused(glx_graph* A, const void* B, void* X, int C, int Cg, double
     rc = glx_unpack_records(b.x, b.dense, n, L, dtype, st, A->d_perm);
   }
   if (rc) return rc;
-  GLX_HIP(hipMemcpyAsync(X, b.dense, (size_t)n * C * es, hipMemcpyDeviceToHost, st));
+  GLX_UP(glx_download(X, b.dense, (size_t)n * C * es, st, __func__));
   GLX_HIP(hipStreamSynchronize(st));
   // How close the stop decisions of this solve came to going the other way (glx_cg_last_stop_margin): the smallest relative distance
   // from `tol` of ANY residual norm a running system showed -- the one that passed the test, the last one that failed it, and every

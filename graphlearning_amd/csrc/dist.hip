@@ -370,6 +370,7 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
   int rc = glx_make_layout(C, state_dtype, true, &s->L);
   if (rc) { delete s; return rc; }
 #define DS_FAIL(code) do { glx_dist_sweep_destroy(s); return (code); } while (0)
+#define DS_UP(call) do { const int rc_up_ = (call); if (rc_up_) DS_FAIL(rc_up_); } while (0)
 #define DS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { glx_set_error("%s -> %s", #call, hipGetErrorString(e_)); DS_FAIL(GLX_EHIP); } } while (0)
   // the two operators over the same local vector
   const int64_t lo[2] = {0, s->fused ? n_own : n_boundary}, hi[2] = {s->fused ? n_own : n_boundary, n_own};
@@ -417,7 +418,7 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
   s->exchange = force_exchange != 0 || ns > 0 || n_halo > 0;   // the planner passes force_exchange = "some rank has a halo"
   if (gather) s->scatter = false;                              // (nothing to scatter: the rows are where the all-gather reads them)
   DS_HIP(hipMalloc(&s->send_idx, std::max<size_t>((size_t)ns * 4, 64)));
-  if (ns > 0) DS_HIP(hipMemcpy(s->send_idx, send_idx, (size_t)ns * 4, hipMemcpyHostToDevice));
+  if (ns > 0) DS_UP(glx_upload_sync(s->send_idx, send_idx, (size_t)ns * 4, __func__));
   DS_HIP(hipMalloc(&s->sendbuf, recb(s, ns)));
   {
     // rows of part 0 -> their positions in the send buffer (a row needed by several peers has several)
@@ -429,8 +430,8 @@ extern "C" int glx_dist_sweep_create(glx_comm* comm, int64_t n_own, int64_t n_ha
     for (int64_t q = 0; q < ns; ++q) dq[fill[send_idx[q]]++] = (int32_t)q;
     DS_HIP(hipMalloc(&s->dup_ptr, (size_t)(nr0 + 1) * 4));
     DS_HIP(hipMalloc(&s->dup_pos, dq.size() * 4));
-    DS_HIP(hipMemcpy(s->dup_ptr, dp.data(), (size_t)(nr0 + 1) * 4, hipMemcpyHostToDevice));
-    DS_HIP(hipMemcpy(s->dup_pos, dq.data(), dq.size() * 4, hipMemcpyHostToDevice));
+    DS_UP(glx_upload_sync(s->dup_ptr, dp.data(), (size_t)(nr0 + 1) * 4, __func__));
+    DS_UP(glx_upload_sync(s->dup_pos, dq.data(), dq.size() * 4, __func__));
   }
   DS_HIP(hipMalloc(&s->err, (size_t)ERR_SLOTS * ERR_SHARDS * 8));
   DS_HIP(hipMemsetAsync(s->err, 0, (size_t)ERR_SLOTS * ERR_SHARDS * 8, s->stream));
@@ -455,7 +456,7 @@ extern "C" int glx_dist_sweep_set_problem(glx_dist_sweep* s, const void* Db_own,
   const size_t es = s->L.esize;
   int rc;
   if (Db_own) {
-    GLX_HIP(hipMemcpyAsync(s->dense, Db_own, (size_t)s->n_own * s->C * es, hipMemcpyHostToDevice, s->stream));
+    GLX_UP(glx_upload(s->dense, Db_own, (size_t)s->n_own * s->C * es, s->stream, __func__));
     rc = glx_pack_records(s->dense, s->bias, s->n_own, s->L, s->dtype, nullptr, s->stream);
   } else {
     rc = glx_pack_records(nullptr, s->bias, s->n_own, s->L, s->dtype, nullptr, s->stream);
@@ -468,11 +469,11 @@ extern "C" int glx_dist_sweep_set_problem(glx_dist_sweep* s, const void* Db_own,
     if (rc) return rc;
   }
   GLX_HIP(hipStreamSynchronize(s->stream));   // `dense` is reused
-  GLX_HIP(hipMemcpyAsync(s->dense, w0_own, s->n_own * 8, hipMemcpyHostToDevice, s->stream));
+  GLX_UP(glx_upload(s->dense, w0_own, s->n_own * 8, s->stream, __func__));
   rc = glx_pack_records(nullptr, s->init_rec, s->n_own, s->L, s->dtype, (const double*)s->dense, s->stream);   // u = 0, w = w0
   if (rc) return rc;
-  GLX_HIP(hipMemcpyAsync(s->deg, deg_own, s->n_own * 8, hipMemcpyHostToDevice, s->stream));
-  GLX_HIP(hipMemcpyAsync(s->vinf, vinf_own, s->n_own * 8, hipMemcpyHostToDevice, s->stream));
+  GLX_UP(glx_upload(s->deg, deg_own, s->n_own * 8, s->stream, __func__));
+  GLX_UP(glx_upload(s->vinf, vinf_own, s->n_own * 8, s->stream, __func__));
   GLX_HIP(hipStreamSynchronize(s->stream));
   s->problem_set = true;
   return GLX_OK;
@@ -811,7 +812,7 @@ extern "C" int glx_dist_sweep_fetch(glx_dist_sweep* s, void* u_own_out) {
   GLX_HIP(hipSetDevice(s->device));
   int rc = glx_unpack_records(rec_at(s->ring[s->cur], s, s->own_off), s->dense, s->n_own, s->L, s->dtype, s->stream);
   if (rc) return rc;
-  GLX_HIP(hipMemcpyAsync(u_own_out, s->dense, (size_t)s->n_own * s->C * s->L.esize, hipMemcpyDeviceToHost, s->stream));
+  GLX_UP(glx_download(u_own_out, s->dense, (size_t)s->n_own * s->C * s->L.esize, s->stream, __func__));
   GLX_HIP(hipStreamSynchronize(s->stream));
   return GLX_OK;
 }
@@ -913,11 +914,10 @@ extern "C" int glx_dist_sweep_get_send(glx_dist_sweep* s, void* host_out) {
   GLX_HIP(hipSetDevice(s->device));
   if (s->gather) {       // the rank's block (cap records) of the iterate being exchanged: the newest one written
     GLX_CHECK(host_out, GLX_EINVAL, "glx_dist_sweep_get_send: null argument");
-    GLX_HIP(hipMemcpy(host_out, rec_at(s->ring[s->gather_next ? (s->cur ^ 1) : s->cur], s, s->own_off),
-                      (size_t)s->cap * s->L.ld * s->L.esize, hipMemcpyDeviceToHost));
+    GLX_UP(glx_download_sync(host_out, rec_at(s->ring[s->gather_next ? (s->cur ^ 1) : s->cur], s, s->own_off), (size_t)s->cap * s->L.ld * s->L.esize, __func__));
     return GLX_OK;
   }
-  if (s->n_send > 0) GLX_HIP(hipMemcpy(host_out, s->sendbuf, (size_t)s->n_send * s->L.ld * s->L.esize, hipMemcpyDeviceToHost));
+  if (s->n_send > 0) GLX_UP(glx_download_sync(host_out, s->sendbuf, (size_t)s->n_send * s->L.ld * s->L.esize, __func__));
   return GLX_OK;
 }
 
@@ -931,13 +931,13 @@ extern "C" int glx_dist_sweep_put_halo(glx_dist_sweep* s, const void* host_in, i
     int k = 0;
     for (int r = 0; r < s->comm->nranks; ++r) {
       if (r == s->comm->rank) continue;
-      GLX_HIP(hipMemcpy(rec_at(x, s, (int64_t)r * s->cap), (const char*)host_in + (size_t)k * bb, bb, hipMemcpyHostToDevice));
+      GLX_UP(glx_upload_sync(rec_at(x, s, (int64_t)r * s->cap), (const char*)host_in + (size_t)k * bb, bb, __func__));
       ++k;
     }
     s->gather_next = false;
     return GLX_OK;
   }
-  if (s->n_halo > 0) GLX_HIP(hipMemcpy(rec_at(x, s, s->n_own), host_in, (size_t)s->n_halo * s->L.ld * s->L.esize, hipMemcpyHostToDevice));
+  if (s->n_halo > 0) GLX_UP(glx_upload_sync(rec_at(x, s, s->n_own), host_in, (size_t)s->n_halo * s->L.ld * s->L.esize, __func__));
   return GLX_OK;
 }
 

@@ -131,11 +131,6 @@ struct glx_work {
   int device = 0;
   void* stage = nullptr;          // page-locked host staging area of the set (glx_work_stage), kept with it
   size_t stage_bytes = 0;
-  void* up_stage = nullptr;       // page-locked staging area of glx_upload_staged: two halves that take turns
-  size_t up_bytes = 0;
-  hipEvent_t ev_up[2] = {nullptr, nullptr};
-  unsigned long long* up_sum = nullptr;      // device word of the upload check (glx_upload_checked)
-  unsigned long long* up_sum_host = nullptr; // its page-locked mirror
 };
 int glx_work_acquire(int device, glx_work** out);
 void glx_work_release(glx_work* w);
@@ -143,18 +138,25 @@ void glx_work_release(glx_work* w);
 // device-to-host copies of counters and lists land that the host then reads.  A copy into FRESH pageable memory makes the runtime
 // pin the destination on the fly -- 8 ms for a 280 KB std::vector the first time a graph of a new size is built.
 int glx_work_stage(glx_work* w, size_t bytes, void** out);
-// Host (pageable) -> device through the set's OWN page-locked staging area: chunks copied in by host threads, each followed by an
-// asynchronous copy from page-locked memory on `st`; the two halves of the area take turns.  Why not hipMemcpyAsync from the caller's array:
-// round 6 found that copy delivering wrong bytes (a run of < 1 KB) once in ~10 000 uploads of a search's features while a dozen processes
-// shared the GPU -- the one parity failure the randomised soak ever produced (EXPERIMENTS.md round 6, section 2).
-int glx_upload_staged(glx_work* w, void* dst, const void* src, size_t bytes, hipStream_t st, unsigned long long* sum_out = nullptr,
-                      size_t stage_shift = 0);
-// The same, CHECKED: the host threads add the 64-bit words up while they copy them in, a kernel adds up what arrived on the device, and the
-// two sums are compared before the call returns (one stream synchronisation).  A difference is described on stderr (is the staging area
-// what the caller's array holds?  what does the device hold?), counted (glx_upload_stats) and the upload repeated through another part of
-// the staging area, up to three times; GLX_EHIP if none arrives intact.  `bytes` a multiple of 8; below 128 KB the check is skipped (the
-// faulty runs of round 6 all sat 128 KB or more into an upload).
-int glx_upload_checked(glx_work* w, void* dst, const void* src, size_t bytes, hipStream_t st, const char* what);
+// ---- host -> device uploads ------------------------------------------------------------------------------------------------------------
+// Round 6 found the one parity failure the randomised soak ever produced: a copy between PAGEABLE host memory and the device -- hipMemcpyAsync
+// from a numpy array, the runtime staging it internally -- that arrived with a run of 256 zero bytes 128-132 KB into the transfer, about once
+// in 10 000 copies and only while a dozen processes shared the GPU (EXPERIMENTS.md round 6, section 2; scripts/replay_crumbs.sh reproduces
+// it).  Copies from and to page-locked memory never showed it.  So every upload of 128 KB or more goes through page-locked staging memory of
+// the library's own (two halves that take turns, filled by host threads), and is CHECKED: the host threads add the 64-bit words up while
+// they copy them in, a kernel adds up what arrived, the sums are compared before the call returns (one stream synchronisation).  A
+// difference is described on stderr, counted (glx_upload_stats) and the upload repeated through another part of the staging area, up to
+// three times; GLX_EHIP if none arrives intact.  Below 128 KB: hipMemcpyAsync as before (no faulty run ever sat that early in a transfer).
+// The staging area belongs to the calling thread and device; `st` may be any stream (the null stream included).
+int glx_upload(void* dst, const void* src, size_t bytes, hipStream_t st, const char* what);
+int glx_upload_sync(void* dst, const void* src, size_t bytes, const char* what);      // ... on the null stream, complete on return
+// The other direction, for the same reason: a result of 128 KB or more that goes into memory which is NOT page-locked (a caller's plain numpy
+// array) comes down through the staging area piece by piece and is checked the same way (a kernel's sum of the device words against the sum
+// of what the host threads copied out); the call then returns with the copy COMPLETE.  Into page-locked memory (what the Python layer hands
+// in for its results) and below 128 KB: hipMemcpyAsync as before, complete when the caller synchronises `st`.
+int glx_download(void* dst_host, const void* src_dev, size_t bytes, hipStream_t st, const char* what);
+int glx_download_sync(void* dst_host, const void* src_dev, size_t bytes, const char* what);
+#define GLX_UP(call) do { const int rc_up_ = (call); if (rc_up_) return rc_up_; } while (0)
 
 int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed = false);
 int glx_graph_ensure_order(glx_graph* g);

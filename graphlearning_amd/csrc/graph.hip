@@ -83,11 +83,6 @@ void work_destroy(glx_work* w) {
   if (w->side) hipStreamDestroy(w->side);
   if (w->stream) hipStreamDestroy(w->stream);
   if (w->stage) hipHostFree(w->stage);
-  if (w->up_stage) hipHostFree(w->up_stage);
-  if (w->up_sum) hipFree(w->up_sum);
-  if (w->up_sum_host) hipHostFree(w->up_sum_host);
-  for (int i = 0; i < 2; ++i)
-    if (w->ev_up[i]) hipEventDestroy(w->ev_up[i]);
   delete w;
 }
 }  // namespace
@@ -470,55 +465,88 @@ static unsigned long long copy_and_sum(char* dst, const char* src, size_t len, b
   return a0 + a1 + a2 + a3;
 }
 
-int glx_upload_staged(glx_work* w, void* dst, const void* src, size_t bytes, hipStream_t st, unsigned long long* sum_out, size_t stage_shift) {
+namespace {
+struct Uploader {                 // per calling thread and device; never destroyed (HIP objects must not outlive the runtime's teardown)
+  void* stage = nullptr;          // page-locked: two halves that take turns
+  size_t bytes = 0;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  unsigned long long* sum = nullptr;        // device word of the check
+  unsigned long long* sum_host = nullptr;   // its page-locked mirror
+};
+Uploader* my_uploader() {
+  static thread_local std::map<int, Uploader*> per_device;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  Uploader*& u = per_device[dev];
+  if (!u) u = new Uploader();
+  return u;
+}
+}  // namespace
+
+// the staged copy: returns the wrapping sum of the 64-bit words (a zero-padded last word for a length that is no multiple of 8) when asked
+static int upload_staged(Uploader* w, void* dst, const void* src, size_t bytes, hipStream_t st, unsigned long long* sum_out, size_t stage_shift) {
   if (sum_out) *sum_out = 0ull;
   if (bytes == 0) return GLX_OK;
   const size_t HALF_MAX = (size_t)16 << 20;
-  size_t half = (size_t)1 << 16;
+  size_t half = (size_t)1 << 18;
   while (half < bytes + stage_shift && half < HALF_MAX) half <<= 1;
-  if (w->up_bytes < 2 * half) {
-    if (w->up_stage) {
+  if (w->bytes < 2 * half) {
+    if (w->stage) {
       for (int i = 0; i < 2; ++i)
-        if (w->ev_up[i]) GLX_HIP(hipEventSynchronize(w->ev_up[i]));
-      hipHostFree(w->up_stage);
+        if (w->ev[i]) GLX_HIP(hipEventSynchronize(w->ev[i]));
+      hipHostFree(w->stage);
     }
-    w->up_stage = nullptr;
-    w->up_bytes = 0;
-    GLX_HIP(hipHostMalloc(&w->up_stage, 2 * half, hipHostMallocDefault));
-    w->up_bytes = 2 * half;
+    w->stage = nullptr;
+    w->bytes = 0;
+    GLX_HIP(hipHostMalloc(&w->stage, 2 * half, hipHostMallocDefault));
+    w->bytes = 2 * half;
   }
-  const size_t h = w->up_bytes / 2;
-  GLX_CHECK(stage_shift % 64 == 0 && stage_shift < h / 2, GLX_EINVAL, "glx_upload_staged: bad staging shift");
-  const size_t room = h - stage_shift;             // bytes of a half in use
+  const size_t h = w->bytes / 2;
+  GLX_CHECK(stage_shift % 64 == 0 && stage_shift < h / 2, GLX_EINVAL, "glx_upload: bad staging shift");
+  const size_t room = (h - stage_shift) / 64 * 64;             // bytes of a half in use (a multiple of 8: whole words per piece)
   for (int i = 0; i < 2; ++i)
-    if (!w->ev_up[i]) GLX_HIP(hipEventCreateWithFlags(&w->ev_up[i], hipEventDisableTiming));
+    if (!w->ev[i]) GLX_HIP(hipEventCreateWithFlags(&w->ev[i], hipEventDisableTiming));
   int turn = 0;
   unsigned long long total = 0;
   for (size_t off = 0; off < bytes; off += room, turn ^= 1) {
     const size_t len = std::min(room, bytes - off);
-    char* stage = (char*)w->up_stage + (size_t)turn * h + stage_shift;
-    GLX_HIP(hipEventSynchronize(w->ev_up[turn]));          // (the copy that last read this half; an event never recorded is complete)
-    const int nt = (int)std::min<size_t>(4, std::max<size_t>(1, len >> 20));
+    const size_t whole = len / 8 * 8;
+    char* stage = (char*)w->stage + (size_t)turn * h + stage_shift;
+    GLX_HIP(hipEventSynchronize(w->ev[turn]));          // (the copy that last read this half; an event never recorded is complete)
+    const int nt = (int)std::min<size_t>(4, std::max<size_t>(1, whole >> 20));
     if (nt > 1) {
       unsigned long long part[4] = {0, 0, 0, 0};
       host_pool().run(nt, [&](int t) {
-        const size_t a = len * (size_t)t / nt / 64 * 64, b2 = t + 1 == nt ? len : len * (size_t)(t + 1) / nt / 64 * 64;
+        const size_t a = whole * (size_t)t / nt / 64 * 64, b2 = t + 1 == nt ? whole : whole * (size_t)(t + 1) / nt / 64 * 64;
         part[t] = copy_and_sum(stage + a, (const char*)src + off + a, b2 - a, sum_out != nullptr);
       });
       total += part[0] + part[1] + part[2] + part[3];
     } else {
-      total += copy_and_sum(stage, (const char*)src + off, len, sum_out != nullptr);
+      total += copy_and_sum(stage, (const char*)src + off, whole, sum_out != nullptr);
     }
-    GLX_HIP(hipMemcpyAsync((char*)dst + off, stage, len, hipMemcpyHostToDevice, st));
-    GLX_HIP(hipEventRecord(w->ev_up[turn], st));
+    if (len > whole) {                                   // the last bytes of the upload: a word padded with zeros for the sum
+      unsigned long long tail = 0;
+      memcpy(&tail, (const char*)src + off + whole, len - whole);
+      memcpy(stage + whole, (const char*)src + off + whole, len - whole);
+      total += tail;
+    }
+    GLX_UP(glx_upload((char*)dst + off, stage, len, st, __func__));
+    GLX_HIP(hipEventRecord(w->ev[turn], st));
   }
   if (sum_out) *sum_out = total;
   return GLX_OK;
 }
 
-__global__ __launch_bounds__(256) void upload_sum_kernel(const unsigned long long* __restrict__ p, int64_t nwords, unsigned long long* __restrict__ out) {
+__global__ __launch_bounds__(256) void upload_sum_kernel(const unsigned long long* __restrict__ p, int64_t nwords, int tail_bytes,
+                                                         unsigned long long* __restrict__ out) {
   unsigned long long a = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * 256) a += p[i];
+  if (tail_bytes && blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned char* t = (const unsigned char*)(p + nwords);
+    unsigned long long v = 0;
+    for (int q = 0; q < tail_bytes; ++q) v |= (unsigned long long)t[q] << (8 * q);
+    a += v;
+  }
   for (int off = 32; off >= 1; off >>= 1) a += (unsigned long long)__shfl_xor((long long)a, off);
   if ((threadIdx.x & 63) == 0 && a) atomicAdd(out, a);
 }
@@ -529,49 +557,163 @@ extern "C" int glx_upload_stats(unsigned long long out[4]) {
   for (int q = 0; q < 4; ++q) out[q] = g_upload_stats[q].load();
   return GLX_OK;
 }
+static int g_upload_mode = 0;      // glx_upload_set_mode: 0 staged + checked (default), 1 staged, 2 hipMemcpyAsync from the caller's memory (rounds 1-5)
+extern "C" int glx_upload_set_mode(int mode) {
+  GLX_CHECK(mode >= 0 && mode <= 2, GLX_EINVAL, "glx_upload_set_mode: 0 (staged + checked), 1 (staged) or 2 (direct)");
+  g_upload_mode = mode;
+  return GLX_OK;
+}
 
-int glx_upload_checked(glx_work* w, void* dst, const void* src, size_t bytes, hipStream_t st, const char* what) {
-  if (bytes < ((size_t)128 << 10) || bytes % 8 != 0) return glx_upload_staged(w, dst, src, bytes, st);
-  if (!w->up_sum) GLX_HIP(hipMalloc((void**)&w->up_sum, 64));
-  if (!w->up_sum_host) GLX_HIP(hipHostMalloc((void**)&w->up_sum_host, 64, hipHostMallocDefault));
+int glx_upload(void* dst, const void* src, size_t bytes, hipStream_t st, const char* what) {
+  if (bytes == 0) return GLX_OK;
+  GLX_CHECK(dst && src, GLX_EINVAL, "%s: null pointer in an upload of %zu bytes", what, bytes);
+  if (bytes < ((size_t)128 << 10) || g_upload_mode == 2) {
+    GLX_UP(glx_upload(dst, src, bytes, st, __func__));
+    return GLX_OK;
+  }
+  Uploader* w = my_uploader();
+  const bool aligned = ((uintptr_t)dst % 8 == 0) && ((uintptr_t)src % 8 == 0);
+  // (word sums need 8-byte aligned ends; the staging alone is what keeps the transfer off the runtime's pageable path)
+  if (!aligned || g_upload_mode == 1) return upload_staged(w, dst, src, bytes, st, nullptr, 0);
+  if (!w->sum) GLX_HIP(hipMalloc((void**)&w->sum, 64));
+  if (!w->sum_host) GLX_HIP(hipHostMalloc((void**)&w->sum_host, 64, hipHostMallocDefault));
   ++g_upload_stats[0];
   for (int attempt = 0; attempt < 4; ++attempt) {
     unsigned long long want = 0;
-    // (a repeat goes through another part of the staging area: the faulty runs of round 6 stayed at ONE offset of the area from upload to upload)
-    int rc = glx_upload_staged(w, dst, src, bytes, st, &want, (size_t)attempt * 12288);
+    // (a repeat goes through another part of the staging area)
+    int rc = upload_staged(w, dst, src, bytes, st, &want, (size_t)attempt * 12288);
     if (rc) return rc;
-    GLX_HIP(hipMemsetAsync(w->up_sum, 0, 8, st));
+    GLX_HIP(hipMemsetAsync(w->sum, 0, 8, st));
     const int64_t nw = (int64_t)(bytes / 8);
-    hipLaunchKernelGGL(upload_sum_kernel, dim3((unsigned)std::min<int64_t>(2048, (nw + 255) / 256)), dim3(256), 0, st, (const unsigned long long*)dst, nw, w->up_sum);
+    hipLaunchKernelGGL(upload_sum_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (nw + 255) / 256))), dim3(256), 0, st,
+                       (const unsigned long long*)dst, nw, (int)(bytes % 8), w->sum);
     GLX_HIP(hipGetLastError());
-    GLX_HIP(hipMemcpyAsync(w->up_sum_host, w->up_sum, 8, hipMemcpyDeviceToHost, st));
+    GLX_HIP(hipMemcpyAsync(w->sum_host, w->sum, 8, hipMemcpyDeviceToHost, st));
     GLX_HIP(hipStreamSynchronize(st));
-    if (*w->up_sum_host == want) {
+    if (*w->sum_host == want) {
       if (attempt) ++g_upload_stats[2];
       return GLX_OK;
     }
     ++g_upload_stats[1];
-    // what went wrong where: the staging area against the caller's array (single-piece uploads: the area still holds the whole array),
-    // and the device copy, read back, against it
+    // what went wrong where: the staging area against the caller's array (single-piece uploads: the area still holds the whole array), and
+    // the device copy, read back THROUGH PAGE-LOCKED MEMORY (a read-back into pageable memory can show the same holes), against it
     size_t stage_bad = 0, dev_bad = 0, first = 0, last = 0, zeros = 0;
     const unsigned long long* s8 = (const unsigned long long*)src;
-    if (bytes + (size_t)attempt * 12288 <= w->up_bytes / 2) {
-      const unsigned long long* g8 = (const unsigned long long*)((const char*)w->up_stage + (size_t)attempt * 12288);
-      for (size_t i = 0; i < bytes / 8; ++i) stage_bad += g8[i] != s8[i];
+    const size_t nwords = bytes / 8;
+    if (bytes + (size_t)attempt * 12288 <= w->bytes / 2) {
+      const unsigned long long* g8 = (const unsigned long long*)((const char*)w->stage + (size_t)attempt * 12288);
+      for (size_t i = 0; i < nwords; ++i) stage_bad += g8[i] != s8[i];
     }
-    std::vector<unsigned long long> back(bytes / 8);
-    if (hipMemcpy(back.data(), dst, bytes, hipMemcpyDeviceToHost) == hipSuccess) {
-      for (size_t i = 0; i < bytes / 8; ++i)
-        if (back[i] != s8[i]) { if (!dev_bad) first = i; last = i; ++dev_bad; zeros += back[i] == 0; }
+    unsigned long long* back = nullptr;
+    if (hipHostMalloc((void**)&back, std::max<size_t>(bytes, 64), hipHostMallocDefault) == hipSuccess && back) {
+      if (hipMemcpy(back, dst, bytes, hipMemcpyDeviceToHost) == hipSuccess) {
+        for (size_t i = 0; i < nwords; ++i)
+          if (back[i] != s8[i]) { if (!dev_bad) first = i; last = i; ++dev_bad; zeros += back[i] == 0; }
+      }
+      hipHostFree(back);
     }
     (void)hipGetLastError();
     fprintf(stderr, "[glx] upload check (%s, pid %d, attempt %d): %zu bytes arrived with sum %016llx instead of %016llx -- the staging area differs from "
                     "the caller's array in %zu words, the device copy in %zu (bytes %zu .. %zu of the upload, %zu of them zero); repeating the upload\n",
-            what, (int)getpid(), attempt, bytes, *w->up_sum_host, want, stage_bad, dev_bad, first * 8, last * 8 + 7, zeros);
+            what, (int)getpid(), attempt, bytes, *w->sum_host, want, stage_bad, dev_bad, first * 8, last * 8 + 7, zeros);
   }
   ++g_upload_stats[3];
   glx_set_error("%s: the upload of %zu bytes did not arrive intact in four attempts", what, bytes);
   return GLX_EHIP;
+}
+
+int glx_download(void* dst, const void* src, size_t bytes, hipStream_t st, const char* what) {
+  if (bytes == 0) return GLX_OK;
+  GLX_CHECK(dst && src, GLX_EINVAL, "%s: null pointer in a download of %zu bytes", what, bytes);
+  bool direct = bytes < ((size_t)128 << 10) || g_upload_mode == 2;
+  if (!direct) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, dst) == hipSuccess && (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged)) direct = true;   // page-locked
+    (void)hipGetLastError();
+  }
+  if (direct) {
+    GLX_UP(glx_download(dst, src, bytes, st, __func__));
+    return GLX_OK;
+  }
+  Uploader* w = my_uploader();
+  const bool check = g_upload_mode == 0 && ((uintptr_t)dst % 8 == 0) && ((uintptr_t)src % 8 == 0) && bytes % 8 == 0;
+  if (check) {
+    if (!w->sum) GLX_HIP(hipMalloc((void**)&w->sum, 64));
+    if (!w->sum_host) GLX_HIP(hipHostMalloc((void**)&w->sum_host, 64, hipHostMallocDefault));
+    ++g_upload_stats[0];
+  }
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    const size_t shift = (size_t)attempt * 12288;
+    // the staging area is the uploads' own: one half of it is used here, piece by piece
+    const size_t HALF_MAX = (size_t)16 << 20;
+    size_t half = (size_t)1 << 18;
+    while (half < bytes + shift && half < HALF_MAX) half <<= 1;
+    if (w->bytes < 2 * half) {
+      if (w->stage) {
+        for (int i = 0; i < 2; ++i)
+          if (w->ev[i]) GLX_HIP(hipEventSynchronize(w->ev[i]));
+        hipHostFree(w->stage);
+      }
+      w->stage = nullptr;
+      w->bytes = 0;
+      GLX_HIP(hipHostMalloc(&w->stage, 2 * half, hipHostMallocDefault));
+      w->bytes = 2 * half;
+    }
+    for (int i = 0; i < 2; ++i)
+      if (w->ev[i]) GLX_HIP(hipEventSynchronize(w->ev[i]));        // (no upload of this thread still reads the area)
+    const size_t room = (w->bytes / 2 - shift) / 64 * 64;
+    unsigned long long want = 0, got = 0;
+    if (check) {
+      GLX_HIP(hipMemsetAsync(w->sum, 0, 8, st));
+      const int64_t nw = (int64_t)(bytes / 8);
+      hipLaunchKernelGGL(upload_sum_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (nw + 255) / 256))), dim3(256), 0, st,
+                         (const unsigned long long*)src, nw, 0, w->sum);
+      GLX_HIP(hipGetLastError());
+      GLX_HIP(hipMemcpyAsync(w->sum_host, w->sum, 8, hipMemcpyDeviceToHost, st));
+    }
+    char* stage = (char*)w->stage + shift;
+    for (size_t off = 0; off < bytes; off += room) {
+      const size_t len = std::min(room, bytes - off);
+      GLX_HIP(hipMemcpyAsync(stage, (const char*)src + off, len, hipMemcpyDeviceToHost, st));
+      GLX_HIP(hipStreamSynchronize(st));
+      const size_t whole = check ? len : 0;
+      const int nt = (int)std::min<size_t>(4, std::max<size_t>(1, len >> 20));
+      if (nt > 1) {
+        unsigned long long part[4] = {0, 0, 0, 0};
+        host_pool().run(nt, [&](int t) {
+          const size_t a = len * (size_t)t / nt / 64 * 64, b2 = t + 1 == nt ? len : len * (size_t)(t + 1) / nt / 64 * 64;
+          part[t] = copy_and_sum((char*)dst + off + a, stage + a, b2 - a, whole != 0);
+        });
+        got += part[0] + part[1] + part[2] + part[3];
+      } else {
+        got += copy_and_sum((char*)dst + off, stage, len, whole != 0);
+      }
+    }
+    if (!check) return GLX_OK;
+    want = *w->sum_host;
+    if (got == want) {
+      if (attempt) ++g_upload_stats[2];
+      return GLX_OK;
+    }
+    ++g_upload_stats[1];
+    fprintf(stderr, "[glx] download check (%s, pid %d, attempt %d): %zu bytes came down with sum %016llx instead of %016llx; repeating the download\n", what,
+            (int)getpid(), attempt, bytes, got, want);
+  }
+  ++g_upload_stats[3];
+  glx_set_error("%s: the download of %zu bytes did not arrive intact in four attempts", what, bytes);
+  return GLX_EHIP;
+}
+
+int glx_download_sync(void* dst, const void* src, size_t bytes, const char* what) {
+  GLX_UP(glx_download(dst, src, bytes, nullptr, what));
+  GLX_HIP(hipStreamSynchronize(nullptr));
+  return GLX_OK;
+}
+
+int glx_upload_sync(void* dst, const void* src, size_t bytes, const char* what) {
+  GLX_UP(glx_upload(dst, src, bytes, nullptr, what));
+  GLX_HIP(hipStreamSynchronize(nullptr));
+  return GLX_OK;
 }
 
 int glx_make_layout(int C, int dtype, bool has_w, RecLayout* L) {
@@ -725,10 +867,10 @@ extern "C" int glx_graph_create_resident(int64_t n_rows, int64_t n_cols, int64_t
   GLX_HIP(hipMalloc(&g->d_src_rowptr, (size_t)(n_rows + 1) * 4));
   GLX_HIP(hipMalloc(&g->d_src_col, std::max<size_t>((size_t)nnz * 4, 4)));
   GLX_HIP(hipMalloc(&g->d_src_val, std::max<size_t>((size_t)nnz * 8, 8)));
-  GLX_HIP(hipMemcpyAsync(g->d_src_rowptr, rowptr, (size_t)(n_rows + 1) * 4, hipMemcpyHostToDevice, st));
+  GLX_UP(glx_upload(g->d_src_rowptr, rowptr, (size_t)(n_rows + 1) * 4, st, __func__));
   if (nnz > 0) {
-    GLX_HIP(hipMemcpyAsync(g->d_src_col, col, (size_t)nnz * 4, hipMemcpyHostToDevice, st));
-    GLX_HIP(hipMemcpyAsync(g->d_src_val, val, (size_t)nnz * 8, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(g->d_src_col, col, (size_t)nnz * 4, st, __func__));
+    GLX_UP(glx_upload(g->d_src_val, val, (size_t)nnz * 8, st, __func__));
   }
   // column range check (+ the row sums) on the device; results through the work set's page-locked staging area
   char* stage = nullptr;
@@ -776,7 +918,7 @@ extern "C" int glx_graph_set_row_transform(glx_graph* g, const double* row_scale
     int rc = glx_work_acquire(g->device, &w);
     if (rc) return rc;
     struct WorkGuard { glx_work* w; ~WorkGuard() { hipStreamSynchronize(w->stream); glx_work_release(w); } } wguard{w};
-    GLX_HIP(hipMemcpyAsync(g->d_row_scale, row_scale, (size_t)g->n_rows * 8, hipMemcpyHostToDevice, w->stream));
+    GLX_UP(glx_upload(g->d_row_scale, row_scale, (size_t)g->n_rows * 8, w->stream, __func__));
     GLX_HIP(hipStreamSynchronize(w->stream));
   }
   return GLX_OK;
@@ -912,7 +1054,7 @@ int glx_graph_ensure_order(glx_graph* g) {
   if (g->d_src_col && g->h_col.empty() && g->nnz > 0) {      // a resident source: the pass below reads the pattern on the host
     g->h_col.resize(g->nnz);
     GLX_HIP(hipSetDevice(g->device));
-    GLX_HIP(hipMemcpy(g->h_col.data(), g->d_src_col, (size_t)g->nnz * 4, hipMemcpyDeviceToHost));
+    GLX_UP(glx_download_sync(g->h_col.data(), g->d_src_col, (size_t)g->nnz * 4, __func__));
   }
   const auto t_rcm0 = std::chrono::steady_clock::now();
   rcm_order(g, g->h_perm, true);
@@ -923,8 +1065,8 @@ int glx_graph_ensure_order(glx_graph* g) {
   GLX_HIP(hipSetDevice(g->device));
   GLX_HIP(hipMalloc(&g->d_perm, n * 4));
   GLX_HIP(hipMalloc(&g->d_inv, n * 4));
-  GLX_HIP(hipMemcpy(g->d_perm, g->h_perm.data(), n * 4, hipMemcpyHostToDevice));
-  GLX_HIP(hipMemcpy(g->d_inv, g->h_inv.data(), n * 4, hipMemcpyHostToDevice));
+  GLX_UP(glx_upload_sync(g->d_perm, g->h_perm.data(), n * 4, __func__));
+  GLX_UP(glx_upload_sync(g->d_inv, g->h_inv.data(), n * 4, __func__));
   return GLX_OK;
 }
 
@@ -1108,8 +1250,8 @@ extern "C" int glx_graph_set_order(glx_graph* g, const int32_t* perm) {
   int rc = glx_work_acquire(g->device, &w);
   if (rc) return rc;
   struct WorkGuard { glx_work* w; ~WorkGuard() { hipStreamSynchronize(w->stream); glx_work_release(w); } } wguard{w};
-  GLX_HIP(hipMemcpyAsync(g->d_perm, g->h_perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, w->stream));
-  GLX_HIP(hipMemcpyAsync(g->d_inv, g->h_inv.data(), (size_t)n * 4, hipMemcpyHostToDevice, w->stream));
+  GLX_UP(glx_upload(g->d_perm, g->h_perm.data(), (size_t)n * 4, w->stream, __func__));
+  GLX_UP(glx_upload(g->d_inv, g->h_inv.data(), (size_t)n * 4, w->stream, __func__));
   GLX_HIP(hipStreamSynchronize(w->stream));
   return GLX_OK;
 }
@@ -1379,9 +1521,9 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
   }
   struct WorkGuard { glx_work* w; ~WorkGuard() { hipStreamSynchronize(w->stream); glx_work_release(w); } } pwguard{pw};
   hipStream_t pst = pw->stream;
-  GLX_HIP(hipMemcpyAsync(p.d_slot_row, slot_row.data(), slot_row.size() * 4, hipMemcpyHostToDevice, pst));
-  GLX_HIP(hipMemcpyAsync(p.d_slot_len, slot_len.data(), slot_len.size() * 4, hipMemcpyHostToDevice, pst));
-  GLX_HIP(hipMemcpyAsync(p.d_slice_hdr, hdr.data(), hdr.size() * sizeof(SliceHdr), hipMemcpyHostToDevice, pst));
+  GLX_UP(glx_upload(p.d_slot_row, slot_row.data(), slot_row.size() * 4, pst, __func__));
+  GLX_UP(glx_upload(p.d_slot_len, slot_len.data(), slot_len.size() * 4, pst, __func__));
+  GLX_UP(glx_upload(p.d_slice_hdr, hdr.data(), hdr.size() * sizeof(SliceHdr), pst, __func__));
   if (nslices > 0) {
     // the CSR arrays as they are: resident on the device already (glx_graph_create_resident), or uploaded into work buffers from
     // the pool that are released after the fill
@@ -1394,10 +1536,10 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
       if (!rc2) rc2 = glx_pool_alloc(&tmp.c, std::max<size_t>((size_t)g->nnz * 8, 8));
       if (rc2) return rc2;
       d_rp = (int32_t*)tmp.a; d_cc = (int32_t*)tmp.b; d_cv = (double*)tmp.c;
-      GLX_HIP(hipMemcpyAsync(d_rp, g->h_rowptr.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, pst));
+      GLX_UP(glx_upload(d_rp, g->h_rowptr.data(), (size_t)(n + 1) * 4, pst, __func__));
       if (g->nnz > 0) {
-        GLX_HIP(hipMemcpyAsync(d_cc, g->h_col.data(), (size_t)g->nnz * 4, hipMemcpyHostToDevice, pst));
-        GLX_HIP(hipMemcpyAsync(d_cv, g->h_val.data(), (size_t)g->nnz * 8, hipMemcpyHostToDevice, pst));
+        GLX_UP(glx_upload(d_cc, g->h_col.data(), (size_t)g->nnz * 4, pst, __func__));
+        GLX_UP(glx_upload(d_cv, g->h_val.data(), (size_t)g->nnz * 8, pst, __func__));
       }
     }
     const unsigned grid = (unsigned)((nslices + 3) / 4);

@@ -141,8 +141,8 @@ extern "C" int glx_sweep_groups_set_vectors(glx_sweep_groups* s, const double* d
   if (s->n == 0) { s->vectors_set = true; return GLX_OK; }
   double* tmp = (double*)s->dense;      // (n * max(C esize, 16) bytes: room for two fp64 vectors)
   const unsigned grid = (unsigned)((s->n + 255) / 256);
-  GLX_HIP(hipMemcpyAsync(tmp, deg, (size_t)s->n * 8, hipMemcpyHostToDevice, s->stream));
-  GLX_HIP(hipMemcpyAsync(tmp + s->n, vinf, (size_t)s->n * 8, hipMemcpyHostToDevice, s->stream));
+  GLX_UP(glx_upload(tmp, deg, (size_t)s->n * 8, s->stream, __func__));
+  GLX_UP(glx_upload(tmp + s->n, vinf, (size_t)s->n * 8, s->stream, __func__));
   hipLaunchKernelGGL(grp_permute_f64_kernel, dim3(grid), dim3(256), 0, s->stream, (const double*)tmp, s->deg, (const int32_t*)s->P->d_perm, s->n);
   hipLaunchKernelGGL(grp_permute_f64_kernel, dim3(grid), dim3(256), 0, s->stream, (const double*)(tmp + s->n), s->vinf, (const int32_t*)s->P->d_perm, s->n);
   GLX_HIP(hipGetLastError());
@@ -195,7 +195,7 @@ extern "C" int glx_sweep_groups_set_problem_rows(glx_sweep_groups* s, int b, int
   double* w0_b = s->w0 + (size_t)b * s->n;
   const bool f32 = s->P->dtype == GLX_F32;
   if (mp > 0) {      // the previous training set of this group: its bias rows and start values back to zero
-    GLX_HIP(hipMemcpyAsync(st, s->rows[b].data(), b_prev, hipMemcpyHostToDevice, s->stream));
+    GLX_UP(glx_upload(st, s->rows[b].data(), b_prev, s->stream, __func__));
     const int64_t tot = mp * s->C;
     if (f32)
       hipLaunchKernelGGL(grp_set_rows_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (char*)s->bias, rb,
@@ -207,9 +207,9 @@ extern "C" int glx_sweep_groups_set_problem_rows(glx_sweep_groups* s, int b, int
   }
   if (m > 0) {
     char* q0 = st + b_prev;
-    GLX_HIP(hipMemcpyAsync(q0, rows, b_rows, hipMemcpyHostToDevice, s->stream));
-    GLX_HIP(hipMemcpyAsync(q0 + b_rows, Db_rows, (size_t)m * s->C * es, hipMemcpyHostToDevice, s->stream));
-    GLX_HIP(hipMemcpyAsync(q0 + b_rows + b_db, w0_rows, b_w, hipMemcpyHostToDevice, s->stream));
+    GLX_UP(glx_upload(q0, rows, b_rows, s->stream, __func__));
+    GLX_UP(glx_upload(q0 + b_rows, Db_rows, (size_t)m * s->C * es, s->stream, __func__));
+    GLX_UP(glx_upload(q0 + b_rows + b_db, w0_rows, b_w, s->stream, __func__));
     const int64_t tot = m * s->C;
     if (f32)
       hipLaunchKernelGGL(grp_set_rows_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (char*)s->bias, rb,
@@ -442,7 +442,7 @@ extern "C" int glx_sweep_groups_fetch(glx_sweep_groups* s, int b, void* u_out) {
   GLX_HIP(hipSetDevice(s->device));
   int rc = grp_unpack(s, b, s->dense);
   if (rc) return rc;
-  GLX_HIP(hipMemcpyAsync(u_out, s->dense, (size_t)s->n * s->C * s->L.esize, hipMemcpyDeviceToHost, s->stream));
+  GLX_UP(glx_download(u_out, s->dense, (size_t)s->n * s->C * s->L.esize, s->stream, __func__));
   GLX_HIP(hipStreamSynchronize(s->stream));
   return GLX_OK;
 }
@@ -466,7 +466,7 @@ extern "C" int glx_sweep_groups_project(glx_sweep_groups* s, int b, const double
   if (rc) return rc;
   const long long* d_labels = nullptr;
   const std::function<int(bool)> hook = [&](bool after) -> int {
-    if (!after && labels_out) GLX_HIP(hipMemcpyAsync(labels_out, d_labels, (size_t)s->n * 8, hipMemcpyDeviceToHost, s->stream));
+    if (!after && labels_out) GLX_UP(glx_download(labels_out, d_labels, (size_t)s->n * 8, s->stream, __func__));
     return GLX_OK;
   };
   return glx_project_device(&s->proj, prob, dtype, s->n, s->C, priors, weights_inout, err_out, steps_out, max_steps, similarity, s->stream,

@@ -35,8 +35,7 @@ extern "C" int glx_knn_set_options(const glx_knn_options* opt) {
 }
 
 // ---- debugging aid: is the device copy of X the caller's X? ------------------------------------------------------------------------
-// glx_debug_set(flags): bit 1 (2) = the upload of a search's features as rounds 1-5 did it (hipMemcpyAsync from the caller's pageable array;
-// the default since round 6 is the library's own page-locked staging, glx_upload_staged); bit 0 (1) = after the upload of a search's features the device copy is read back TWICE -- by the copy engine, and through a
+// glx_debug_set(flags): bit 0 (1) = after the upload of a search's features the device copy is read back TWICE -- by the copy engine, and through a
 // kernel (i.e. through the L2s) -- and compared with the caller's array; differences are counted (glx_debug_counters) and described
 // on stderr.  Round 6: the one parity failure of the randomised soak that left evidence was a search whose device copy of ONE row of X
 // was not the caller's (EXPERIMENTS.md round 6, section 2).
@@ -54,17 +53,20 @@ __global__ __launch_bounds__(256) void knn_copy_u64_kernel(const unsigned long l
 static int knn_verify_upload(const double* X_host, const double* X_dev, int64_t n, int d, hipStream_t st, const char* what) {
   const size_t bytes = (size_t)n * d * 8;
   GLX_HIP(hipStreamSynchronize(st));
-  std::vector<unsigned long long> back(bytes / 8);
+  // (read back INTO PAGE-LOCKED MEMORY: a copy into pageable memory can show the very holes this check looks for)
+  unsigned long long* back = nullptr;
+  GLX_HIP(hipHostMalloc((void**)&back, std::max<size_t>(bytes, 64), hipHostMallocDefault));
+  struct Free { unsigned long long* p; ~Free() { hipHostFree(p); } } free_back{back};
   ++g_debug_counts[0];
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 0) {
-      GLX_HIP(hipMemcpy(back.data(), X_dev, bytes, hipMemcpyDeviceToHost));
+      GLX_HIP(hipMemcpy(back, X_dev, bytes, hipMemcpyDeviceToHost));
     } else {
       void* tmp = nullptr;
       GLX_HIP(hipMalloc(&tmp, bytes));                  // (a fresh allocation, not a pooled block)
       hipLaunchKernelGGL(knn_copy_u64_kernel, dim3(1024), dim3(256), 0, st, (const unsigned long long*)X_dev, (unsigned long long*)tmp, (int64_t)(bytes / 8));
       hipError_t e = hipStreamSynchronize(st);
-      if (e == hipSuccess) e = hipMemcpy(back.data(), tmp, bytes, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(back, tmp, bytes, hipMemcpyDeviceToHost);
       hipFree(tmp);
       GLX_HIP(e);
     }
@@ -197,9 +199,9 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     on_host = hipPointerGetAttributes(&at, X) != hipSuccess || (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged);
     (void)hipGetLastError();
   }
-  if (on_host && !(g_debug_flags & 2)) {
-    // the caller's (pageable) array goes up through the work set's own page-locked staging area (glx_internal.h: why)
-    rc0 = glx_upload_checked(b.work, b.X, X, (size_t)n * d * 8, st, "features of a search");
+  if (on_host) {
+    // the caller's (pageable) array goes up through the library's page-locked staging area, checked (glx_internal.h: why)
+    rc0 = glx_upload(b.X, X, (size_t)n * d * 8, st, "features of a search");
     if (rc0) return rc0;
   } else {
     GLX_HIP(hipMemcpyAsync(b.X, X, (size_t)n * d * 8, hipMemcpyDefault, st));
@@ -252,7 +254,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     for (int c = 0; c < m; ++c) oc_sample[c] = (int)(((2 * (int64_t)c + 1) * n) / (2 * (int64_t)m));     // evenly spaced rows
     GLX_POOL(glx_pool_alloc((void**)&b.cen, (size_t)m * d * 8));
     GLX_POOL(glx_pool_alloc((void**)&b.cell_id, (size_t)std::max<int64_t>(n, m) * 4));
-    GLX_HIP(hipMemcpyAsync(b.cell_id, oc_sample.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.cell_id, oc_sample.data(), (size_t)m * 4, st, __func__));
     hipLaunchKernelGGL(knn_gather_rows_kernel, dim3((unsigned)(((int64_t)m * d + 255) / 256)), dim3(256), 0, st, (const double*)b.X, (const int*)b.cell_id,
                        (int64_t)m, d, b.cen);
     hipLaunchKernelGGL(knn_assign_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), (size_t)16 * d * 8, st, (const double*)b.X, d, n, (const double*)b.cen, m,
@@ -268,7 +270,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
       const int nb = (int)((n + 255) / 256);
       GLX_POOL(glx_pool_alloc((void**)&b.place, (size_t)m * 4));
       GLX_POOL(glx_pool_alloc((void**)&b.bh, (size_t)(nb + 1) * m * 4));     // (+ one row: the keys' totals / starting positions)
-      GLX_HIP(hipMemcpyAsync(b.place, oc_place.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+      GLX_UP(glx_upload(b.place, oc_place.data(), (size_t)m * 4, st, __func__));
       hipLaunchKernelGGL(knn_cellrank_hist_kernel, dim3((unsigned)nb), dim3(256), (size_t)m * 4, st, b.cell_id, (const int*)b.place, n, m, b.bh);
       hipLaunchKernelGGL(knn_cellrank_scan_kernel, dim3((unsigned)m), dim3(256), 0, st, b.bh, nb, m);
       hipLaunchKernelGGL(knn_cellrank_base_kernel, dim3(1), dim3(256), 0, st, b.bh, nb, m);
@@ -279,8 +281,8 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
       // cells here (stable: ascending caller index inside a cell)
       oc_cid.resize(n);
       oc_cen.resize((size_t)m * d);
-      GLX_HIP(hipMemcpyAsync(oc_cid.data(), b.cell_id, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-      GLX_HIP(hipMemcpyAsync(oc_cen.data(), b.cen, (size_t)m * d * 8, hipMemcpyDeviceToHost, st));
+      GLX_UP(glx_download(oc_cid.data(), b.cell_id, (size_t)n * 4, st, __func__));
+      GLX_UP(glx_download(oc_cen.data(), b.cen, (size_t)m * d * 8, st, __func__));
       GLX_HIP(hipStreamSynchronize(st));
       oc_place = chain_places(oc_cen, m);
       std::vector<int64_t> fill(m + 1, 0);
@@ -290,7 +292,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
       oc_perm.resize(n);
       for (int64_t i = 0; i < n; ++i) oc_perm[fill[oc_cid[i]]++] = (int)i;
       // (no synchronisation behind the upload: oc_perm outlives the stream's work -- see its declaration)
-      GLX_HIP(hipMemcpyAsync(b.orig, oc_perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+      GLX_UP(glx_upload(b.orig, oc_perm.data(), (size_t)n * 4, st, __func__));
       if (capture) capture->order.assign(oc_perm.begin(), oc_perm.end());
       glx_pool_free(b.cen);                          // the cell pass allocates its own
       b.cen = nullptr;
@@ -381,7 +383,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
       GLX_POOL(glx_pool_alloc((void**)&b.nruns, (size_t)nqb * 4));
       b.maxruns = ncells;
       GLX_POOL(glx_pool_alloc((void**)&b.runs, (size_t)nqb * 2 * ncells * 4));   // (from here on the tile launches follow the runs)
-      GLX_HIP(hipMemcpyAsync(b.cell_starts, cell_starts, (size_t)ncells * 8, hipMemcpyHostToDevice, st));
+      GLX_UP(glx_upload(b.cell_starts, cell_starts, (size_t)ncells * 8, st, __func__));
       // centres and radii of the cells
       GLX_POOL(glx_pool_alloc((void**)&b.cpart, (size_t)ncells * CELL_SPLIT * (d + 1) * 8));
       double* prad = b.cpart + (size_t)ncells * CELL_SPLIT * d;
@@ -463,8 +465,8 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     if (rc) return rc;
   }
   GLX_HIP(hipEventRecord(b.e3, st));
-  if (ind_out) GLX_HIP(hipMemcpyAsync(ind_out, b.ind, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
-  if (dist_out) GLX_HIP(hipMemcpyAsync(dist_out, b.dist, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+  if (ind_out) GLX_UP(glx_download(ind_out, b.ind, (size_t)nq * k * 8, st, __func__));
+  if (dist_out) GLX_UP(glx_download(dist_out, b.dist, (size_t)nq * k * 8, st, __func__));
   GLX_HIP(hipStreamSynchronize(st));
   stamp("results on the host");
   if (perm_pending) {    // the permutation stays on the device with the result (glx_knn_result_order copies it into the caller's --
@@ -579,8 +581,8 @@ extern "C" int glx_knn_result_lists(const glx_knn_result* res, int64_t* ind_out,
   GLX_CHECK(res && res->ind && res->dist, GLX_EINVAL, "glx_knn_result_lists: empty result");
   GLX_HIP(hipSetDevice(res->device));
   const size_t bytes = (size_t)res->n * res->k * 8;
-  if (ind_out) GLX_HIP(hipMemcpy(ind_out, res->ind, bytes, hipMemcpyDeviceToHost));
-  if (dist_out) GLX_HIP(hipMemcpy(dist_out, res->dist, bytes, hipMemcpyDeviceToHost));
+  if (ind_out) GLX_UP(glx_download_sync(ind_out, res->ind, bytes, __func__));
+  if (dist_out) GLX_UP(glx_download_sync(dist_out, res->dist, bytes, __func__));
   return GLX_OK;
 }
 

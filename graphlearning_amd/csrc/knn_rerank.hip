@@ -515,15 +515,16 @@ extern "C" int glx_nearest_dist(const double* X, int64_t n, int d, const int64_t
   if (!rc) rc = glx_pool_alloc((void**)&dO, (size_t)n * 8);
   if (!rc) {
     const int piece = (int)std::max<int64_t>(1, std::min<int64_t>(m, (48 * 1024 / 8) / d));
-    hipError_t e = hipMemcpy(dX, X, (size_t)n * d * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dR, R.data(), R.size() * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
+    rc = glx_upload_sync(dX, X, (size_t)n * d * 8, "glx_nearest_dist");
+    if (!rc) rc = glx_upload_sync(dR, R.data(), R.size() * 8, "glx_nearest_dist");
+    hipError_t e = hipSuccess;
+    if (!rc) {
       hipLaunchKernelGGL(knn_nearest_dist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)piece * d * 8, 0, (const double*)dX, n, d,
                          (const double*)dR, m, piece, dO);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(dist_out, dO, (size_t)n * 8, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) { glx_set_error("glx_nearest_dist: %s", hipGetErrorString(e)); rc = GLX_EHIP; }
+    if (!rc && e == hipSuccess) e = hipMemcpy(dist_out, dO, (size_t)n * 8, hipMemcpyDeviceToHost);
+    if (!rc && e != hipSuccess) { glx_set_error("glx_nearest_dist: %s", hipGetErrorString(e)); rc = GLX_EHIP; }
   }
   glx_pool_free(dX);
   glx_pool_free(dR);

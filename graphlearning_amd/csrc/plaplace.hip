@@ -141,16 +141,16 @@ extern "C" int glx_lp_iterate(double* uu, double* ul, const int32_t* nbr, const 
   GLX_HIP(hipMalloc(&b.err, (T + 1) * 8));
   GLX_HIP(hipMalloc(&b.stop, 4));
   GLX_HIP(hipHostMalloc((void**)&b.h_err, LP_CHUNK * 8, hipHostMallocDefault));
-  GLX_HIP(hipMemcpyAsync(b.a, x0.data(), n * 16, hipMemcpyHostToDevice, st));
+  GLX_UP(glx_upload(b.a, x0.data(), n * 16, st, __func__));
   GLX_HIP(hipMemsetAsync(b.b, 0, n * 16, st));
-  GLX_HIP(hipMemcpyAsync(b.start, start.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+  GLX_UP(glx_upload(b.start, start.data(), (n + 1) * 8, st, __func__));
   if (M > 0) {
-    GLX_HIP(hipMemcpyAsync(b.nbr, nbr, M * 4, hipMemcpyHostToDevice, st));
-    GLX_HIP(hipMemcpyAsync(b.w, W, M * 8, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.nbr, nbr, M * 4, st, __func__));
+    GLX_UP(glx_upload(b.w, W, M * 8, st, __func__));
   }
-  GLX_HIP(hipMemcpyAsync(b.invdeg, invdeg.data(), n * 8, hipMemcpyHostToDevice, st));
-  GLX_HIP(hipMemcpyAsync(b.bdy, bdy.data(), n * 4, hipMemcpyHostToDevice, st));
-  if (m > 0) GLX_HIP(hipMemcpyAsync(b.val, val, m * 8, hipMemcpyHostToDevice, st));
+  GLX_UP(glx_upload(b.invdeg, invdeg.data(), n * 8, st, __func__));
+  GLX_UP(glx_upload(b.bdy, bdy.data(), n * 4, st, __func__));
+  if (m > 0) GLX_UP(glx_upload(b.val, val, m * 8, st, __func__));
   GLX_HIP(hipMemsetAsync(b.err, 0, (T + 1) * 8, st));
   GLX_HIP(hipMemsetAsync(b.stop, 0, 4, st));
 
@@ -174,7 +174,7 @@ extern "C" int glx_lp_iterate(double* uu, double* ul, const int32_t* nbr, const 
     }
   }
   // the caller's arrays are buffer `a`: whatever iterate last lived there (see the file header)
-  GLX_HIP(hipMemcpyAsync(x0.data(), b.a, n * 16, hipMemcpyDeviceToHost, st));
+  GLX_UP(glx_download(x0.data(), b.a, n * 16, st, __func__));
   GLX_HIP(hipStreamSynchronize(st));
   for (int64_t i = 0; i < n; ++i) { uu[i] = x0[i].x; ul[i] = x0[i].y; }
   if (iters_out) *iters_out = stopped_at >= 0 ? stopped_at : T;

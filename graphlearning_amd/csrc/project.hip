@@ -381,16 +381,16 @@ static int argmax_project_any(const void* prob, int prob_dtype, int64_t n, int C
       GLX_HIP(hipMalloc(&b.stage32, (size_t)n * C * 4));
       b.stage_cap = (size_t)n * C;
     }
-    GLX_HIP(hipMemcpyAsync(b.stage32, prob, (size_t)n * C * 4, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.stage32, prob, (size_t)n * C * 4, st, __func__));
     hipLaunchKernelGGL(to_f64_kernel<float>, dim3((unsigned)(((size_t)n * C + 255) / 256)), dim3(256), 0, st, (const float*)b.stage32, b.scores,
                        (int64_t)n * C);
     GLX_HIP(hipGetLastError());
   } else {
-    GLX_HIP(hipMemcpyAsync(b.scores, prob, (size_t)n * C * 8, hipMemcpyHostToDevice, st));
+    GLX_UP(glx_upload(b.scores, prob, (size_t)n * C * 8, st, __func__));
   }
   rc = proj_core(b, st, n, C, priors, weights_inout, err_out, steps_out, max_steps, similarity, prob_dtype == GLX_F32);
   if (rc) return rc;
-  GLX_HIP(hipMemcpyAsync(labels_out, b.labels, n * 8, hipMemcpyDeviceToHost, st));
+  GLX_UP(glx_download(labels_out, b.labels, n * 8, st, __func__));
   GLX_HIP(hipStreamSynchronize(st));
   return GLX_OK;
 }

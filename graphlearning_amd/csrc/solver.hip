@@ -159,7 +159,7 @@ static int upload_bias(glx_sweep* s, const void* Db) {
     s->bias_set = false;
     return GLX_OK;
   }
-  GLX_HIP(hipMemcpyAsync(s->dense, Db, (size_t)s->n_rows * s->C * s->L.esize, hipMemcpyHostToDevice, s->stream));
+  GLX_UP(glx_upload(s->dense, Db, (size_t)s->n_rows * s->C * s->L.esize, s->stream, __func__));
   int rc = glx_pack_records(s->dense, s->bias, s->n_rows, s->L, s->P->dtype, nullptr, s->stream, s->P->d_perm);
   if (rc) return rc;
   if (nslots > 0) {
@@ -181,15 +181,15 @@ extern "C" int glx_sweep_set_problem(glx_sweep* s, const void* Db, const double*
   if (rc) return rc;
   if (s->row_slot) { hipFree(s->row_slot); s->row_slot = nullptr; s->prev_m = 0; }   // a later sparse problem starts from scratch
   s->vectors_set = true;
-  GLX_HIP(hipMemcpyAsync(s->w0, w0, s->n_cols * 8, hipMemcpyHostToDevice, s->stream));   // caller order; packed through perm
+  GLX_UP(glx_upload(s->w0, w0, s->n_cols * 8, s->stream, __func__));   // caller order; packed through perm
   std::vector<double> degp, vinfp;
   if (!s->P->h_perm.empty()) {   // the kernel indexes deg / vinf by renumbered row
     degp.resize(s->n_rows);
     vinfp.resize(s->n_rows);
     for (int64_t i = 0; i < s->n_rows; ++i) { degp[i] = deg[s->P->h_perm[i]]; vinfp[i] = vinf[s->P->h_perm[i]]; }
   }
-  GLX_HIP(hipMemcpyAsync(s->deg, degp.empty() ? deg : degp.data(), s->n_rows * 8, hipMemcpyHostToDevice, s->stream));
-  GLX_HIP(hipMemcpyAsync(s->vinf, vinfp.empty() ? vinf : vinfp.data(), s->n_rows * 8, hipMemcpyHostToDevice, s->stream));
+  GLX_UP(glx_upload(s->deg, degp.empty() ? deg : degp.data(), s->n_rows * 8, s->stream, __func__));
+  GLX_UP(glx_upload(s->vinf, vinfp.empty() ? vinf : vinfp.data(), s->n_rows * 8, s->stream, __func__));
   double e0 = 0.0;
   for (int64_t i = 0; i < s->n_rows; ++i) {
     const double e = fabs(deg[i] * w0[i] - vinf[i]);
@@ -220,9 +220,11 @@ extern "C" int glx_sweep_set_vectors(glx_sweep* s, const double* deg, const doub
   void* own = nullptr;
   if ((size_t)s->C * s->L.esize < 16) { GLX_HIP(hipMalloc(&own, (size_t)s->n_rows * 16)); tmp = (double*)own; }
   const unsigned grid = (unsigned)((s->n_rows + 255) / 256);
-  hipError_t e = hipMemcpyAsync(tmp, deg, s->n_rows * 8, hipMemcpyHostToDevice, s->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(tmp + s->n_rows, vinf, s->n_rows * 8, hipMemcpyHostToDevice, s->stream);
-  if (e == hipSuccess && s->n_rows > 0) {
+  int rcu = glx_upload(tmp, deg, s->n_rows * 8, s->stream, __func__);
+  if (!rcu) rcu = glx_upload(tmp + s->n_rows, vinf, s->n_rows * 8, s->stream, __func__);
+  if (rcu) { hipFree(own); return rcu; }
+  hipError_t e = hipSuccess;
+  if (s->n_rows > 0) {
     hipLaunchKernelGGL(permute_f64_kernel, dim3(grid), dim3(256), 0, s->stream, (const double*)tmp, s->deg, (const int32_t*)s->P->d_perm, s->n_rows);
     hipLaunchKernelGGL(permute_f64_kernel, dim3(grid), dim3(256), 0, s->stream, (const double*)(tmp + s->n_rows), s->vinf,
                        (const int32_t*)s->P->d_perm, s->n_rows);
@@ -343,9 +345,9 @@ extern "C" int glx_sweep_set_problem_rows(glx_sweep* s, int64_t m, const int64_t
       s->rows_stage_cap = 2 * (b_rows + b_db + b_w);
     }
     char* st = (char*)s->rows_stage;
-    GLX_HIP(hipMemcpyAsync(st, rows, b_rows, hipMemcpyHostToDevice, s->stream));
-    GLX_HIP(hipMemcpyAsync(st + b_rows, Db_rows, (size_t)m * s->C * es, hipMemcpyHostToDevice, s->stream));
-    GLX_HIP(hipMemcpyAsync(st + b_rows + b_db, w0_rows, b_w, hipMemcpyHostToDevice, s->stream));
+    GLX_UP(glx_upload(st, rows, b_rows, s->stream, __func__));
+    GLX_UP(glx_upload(st + b_rows, Db_rows, (size_t)m * s->C * es, s->stream, __func__));
+    GLX_UP(glx_upload(st + b_rows + b_db, w0_rows, b_w, s->stream, __func__));
     const int64_t tot = m * s->C;
     if (s->P->dtype == GLX_F32)
       hipLaunchKernelGGL(set_rows_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (char*)s->bias, rb, s->slot_has_bias,
@@ -528,7 +530,7 @@ extern "C" int glx_sweep_fetch(glx_sweep* s, void* u_out) {
   GLX_HIP(hipSetDevice(s->P->device));
   int rc = glx_unpack_records(s->buf[s->cur], s->dense, s->n_rows, s->L, s->P->dtype, s->stream, s->P->d_perm);
   if (rc) return rc;
-  GLX_HIP(hipMemcpyAsync(u_out, s->dense, (size_t)s->n_rows * s->C * s->L.esize, hipMemcpyDeviceToHost, s->stream));
+  GLX_UP(glx_download(u_out, s->dense, (size_t)s->n_rows * s->C * s->L.esize, s->stream, __func__));
   GLX_HIP(hipStreamSynchronize(s->stream));
   return GLX_OK;
 }
@@ -563,7 +565,7 @@ extern "C" int glx_sweep_project_iterate(glx_sweep* s, const double* priors, dou
   // awaited -- the next call on this sweep is ordered behind them in its stream)
   const std::function<int(bool)> hook = [&](bool after) -> int {
     if (!after) {
-      if (labels_out) GLX_HIP(hipMemcpyAsync(labels_out, d_labels, (size_t)s->n_rows * 8, hipMemcpyDeviceToHost, s->stream));
+      if (labels_out) GLX_UP(glx_download(labels_out, d_labels, (size_t)s->n_rows * 8, s->stream, __func__));
       return GLX_OK;
     }
     if (to_onehot) {
@@ -590,7 +592,7 @@ extern "C" int glx_sweep_set_state(glx_sweep* s, const void* u0, const void* Db)
   if (rc) return rc;
   GLX_HIP(hipStreamSynchronize(s->stream));   // `dense` staging is reused below
   if (u0) {
-    GLX_HIP(hipMemcpyAsync(s->dense, u0, (size_t)s->n_cols * s->C * s->L.esize, hipMemcpyHostToDevice, s->stream));
+    GLX_UP(glx_upload(s->dense, u0, (size_t)s->n_cols * s->C * s->L.esize, s->stream, __func__));
     rc = glx_pack_records(s->dense, s->buf[0], s->n_cols, s->L, s->P->dtype, nullptr, s->stream, s->P->d_perm);
   } else {
     rc = glx_pack_records(nullptr, s->buf[0], s->n_cols, s->L, s->P->dtype, nullptr, s->stream);
@@ -634,14 +636,14 @@ extern "C" int glx_sweep_set_state_labels(glx_sweep* s, const int64_t* labels, i
   }
   char* st = (char*)s->rows_stage;
   drop_graphs_if_bias_changes(s, m > 0);
-  GLX_HIP(hipMemcpyAsync(st, labels, b_lab, hipMemcpyHostToDevice, s->stream));
+  GLX_UP(glx_upload(st, labels, b_lab, s->stream, __func__));
   int rc = glx_onehot_records((const long long*)st, s->buf[0], s->P->dtype, s->n_rows, s->L, s->P->d_perm, s->stream);   // u = onehot(labels)
   if (rc) return rc;
   GLX_HIP(hipMemsetAsync(s->bias, 0, rec_bytes(s, s->n_rows), s->stream));
   GLX_HIP(hipMemsetAsync(s->slot_has_bias, 0, std::max<int64_t>(nslots, 1), s->stream));
   if (m > 0) {
-    GLX_HIP(hipMemcpyAsync(st + b_lab, rows, b_rows, hipMemcpyHostToDevice, s->stream));
-    GLX_HIP(hipMemcpyAsync(st + b_lab + b_rows, Db_rows, (size_t)m * s->C * es, hipMemcpyHostToDevice, s->stream));
+    GLX_UP(glx_upload(st + b_lab, rows, b_rows, s->stream, __func__));
+    GLX_UP(glx_upload(st + b_lab + b_rows, Db_rows, (size_t)m * s->C * es, s->stream, __func__));
     const int64_t tot = m * s->C;
     if (s->P->dtype == GLX_F32)
       hipLaunchKernelGGL(scatter_bias_rows_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (char*)s->bias, rb,

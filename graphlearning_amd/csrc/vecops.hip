@@ -159,8 +159,9 @@ extern "C" int glx_exp_cr(const double* x, double* out, int64_t n, int device) {
   int rc = glx_pool_alloc((void**)&dx, (size_t)n * 8);
   if (!rc) rc = glx_pool_alloc((void**)&dy, (size_t)n * 8);
   if (!rc) {
-    hipError_t e = hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
+    rc = glx_upload_sync(dx, x, (size_t)n * 8, "glx_exp_cr");
+    hipError_t e = hipSuccess;
+    if (!rc) {
       hipLaunchKernelGGL(exp_cr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const double*)dx, dy, n);
       e = hipMemcpy(out, dy, (size_t)n * 8, hipMemcpyDeviceToHost);
     }

@@ -115,11 +115,14 @@ int glx_pool_set_enabled(int enabled);
 /* debugging aid: every work buffer the pool hands out is first filled with `byte` (0 .. 255; -1 = off, the default), so that a kernel reading
  * a buffer before anything wrote it computes from the pattern instead of from what an earlier call left there */
 int glx_pool_set_poison(int byte);
-/* debugging aid of the search: flags bit 1 (value 2) = upload the features with hipMemcpyAsync from the caller's pageable array as rounds 1-5 did
- * (default: through the library's own page-locked staging area); bit 0 = after the upload of a search's features read the device copy back (by the copy engine and through a
+/* debugging aid of the search: flags bit 0 = after the upload of a search's features read the device copy back (by the copy engine and through a
  * kernel) and compare it with the caller's array; counters: uploads checked, uploads whose engine / kernel read-back differed, bytes differing */
 int glx_debug_set(int flags);
-/* the checked uploads of this process (csrc/glx_internal.h glx_upload_checked): uploads checked, sums that differed, uploads that arrived intact on
+/* how uploads of 128 KB or more travel: 0 (default) through the library's page-locked staging area and CHECKED (word sums of the source and of
+ * what arrived; a difference is described on stderr and the upload repeated), 1 staged without the check, 2 hipMemcpyAsync straight from the caller's
+ * pageable memory as rounds 1-5 did -- the path on which round 6 found holes of 256 zero bytes.  For A/B runs. */
+int glx_upload_set_mode(int mode);
+/* the checked uploads of this process (csrc/glx_internal.h glx_upload): uploads checked, sums that differed, uploads that arrived intact on
  * a repeat, uploads given up */
 int glx_upload_stats(unsigned long long out[4]);
 int glx_debug_counters(unsigned long long out[4]);

@@ -99,7 +99,9 @@ def _ablations():
             if a.startswith('poison') and _hip.load(required=False) is not None:
                 _hip.pool_set_poison(int(a[6:] or '255'))
         if ('verifyupload' in _ABLATE or 'pageableupload' in _ABLATE) and _hip.load(required=False) is not None:
-            _hip.debug_set((1 if 'verifyupload' in _ABLATE else 0) | (2 if 'pageableupload' in _ABLATE else 0))                 # every search checks its device copy of X against the caller's array (stderr + counters)
+            _hip.debug_set(1 if 'verifyupload' in _ABLATE else 0)
+            if 'pageableupload' in _ABLATE:
+                _hip.upload_set_mode(2)                 # every search checks its device copy of X against the caller's array (stderr + counters)
         if 'nopool' in _ABLATE and _hip.load(required=False) is not None:
             try:
                 _hip.pool_set_enabled(False)
