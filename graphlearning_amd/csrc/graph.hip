@@ -530,7 +530,7 @@ static int upload_staged(Uploader* w, void* dst, const void* src, size_t bytes, 
       memcpy(stage + whole, (const char*)src + off + whole, len - whole);
       total += tail;
     }
-    GLX_UP(glx_upload((char*)dst + off, stage, len, st, __func__));
+    GLX_HIP(hipMemcpyAsync((char*)dst + off, stage, len, hipMemcpyHostToDevice, st));
     GLX_HIP(hipEventRecord(w->ev[turn], st));
   }
   if (sum_out) *sum_out = total;
@@ -568,7 +568,7 @@ int glx_upload(void* dst, const void* src, size_t bytes, hipStream_t st, const c
   if (bytes == 0) return GLX_OK;
   GLX_CHECK(dst && src, GLX_EINVAL, "%s: null pointer in an upload of %zu bytes", what, bytes);
   if (bytes < ((size_t)128 << 10) || g_upload_mode == 2) {
-    GLX_UP(glx_upload(dst, src, bytes, st, __func__));
+    GLX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
     return GLX_OK;
   }
   Uploader* w = my_uploader();
@@ -632,7 +632,7 @@ int glx_download(void* dst, const void* src, size_t bytes, hipStream_t st, const
     (void)hipGetLastError();
   }
   if (direct) {
-    GLX_UP(glx_download(dst, src, bytes, st, __func__));
+    GLX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
     return GLX_OK;
   }
   Uploader* w = my_uploader();
