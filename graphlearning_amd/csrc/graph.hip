@@ -503,7 +503,9 @@ static int upload_staged(Uploader* w, void* dst, const void* src, size_t bytes, 
   }
   const size_t h = w->bytes / 2;
   GLX_CHECK(stage_shift % 64 == 0 && stage_shift < h / 2, GLX_EINVAL, "glx_upload: bad staging shift");
-  const size_t room = (h - stage_shift) / 64 * 64;             // bytes of a half in use (a multiple of 8: whole words per piece)
+  // bytes of a half in use per piece (a multiple of 64: whole words); big uploads go in pieces of 4 MB so that the host threads fill one half
+  // while the copy engine empties the other
+  const size_t room = std::min<size_t>((h - stage_shift) / 64 * 64, bytes > ((size_t)6 << 20) ? ((size_t)4 << 20) : (size_t)-1);
   for (int i = 0; i < 2; ++i)
     if (!w->ev[i]) GLX_HIP(hipEventCreateWithFlags(&w->ev[i], hipEventDisableTiming));
   int turn = 0;
@@ -513,14 +515,14 @@ static int upload_staged(Uploader* w, void* dst, const void* src, size_t bytes, 
     const size_t whole = len / 8 * 8;
     char* stage = (char*)w->stage + (size_t)turn * h + stage_shift;
     GLX_HIP(hipEventSynchronize(w->ev[turn]));          // (the copy that last read this half; an event never recorded is complete)
-    const int nt = (int)std::min<size_t>(4, std::max<size_t>(1, whole >> 20));
+    const int nt = (int)std::min<size_t>(8, std::max<size_t>(1, whole >> 19));
     if (nt > 1) {
-      unsigned long long part[4] = {0, 0, 0, 0};
+      unsigned long long part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       host_pool().run(nt, [&](int t) {
         const size_t a = whole * (size_t)t / nt / 64 * 64, b2 = t + 1 == nt ? whole : whole * (size_t)(t + 1) / nt / 64 * 64;
         part[t] = copy_and_sum(stage + a, (const char*)src + off + a, b2 - a, sum_out != nullptr);
       });
-      total += part[0] + part[1] + part[2] + part[3];
+      for (int t = 0; t < 8; ++t) total += part[t];
     } else {
       total += copy_and_sum(stage, (const char*)src + off, whole, sum_out != nullptr);
     }
@@ -600,7 +602,7 @@ int glx_upload(void* dst, const void* src, size_t bytes, hipStream_t st, const c
     size_t stage_bad = 0, dev_bad = 0, first = 0, last = 0, zeros = 0;
     const unsigned long long* s8 = (const unsigned long long*)src;
     const size_t nwords = bytes / 8;
-    if (bytes + (size_t)attempt * 12288 <= w->bytes / 2) {
+    if (bytes <= ((size_t)6 << 20) && bytes + (size_t)attempt * 12288 <= w->bytes / 2) {      // (one piece: the area still holds the whole array)
       const unsigned long long* g8 = (const unsigned long long*)((const char*)w->stage + (size_t)attempt * 12288);
       for (size_t i = 0; i < nwords; ++i) stage_bad += g8[i] != s8[i];
     }

@@ -318,18 +318,9 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
     S = hd.S & 0xff;
     full = hd.S >> 8;
   }
-  // What the epilogue needs from memory is asked for HERE, with the header's answer just in: the row's bias flag, and its degree and stop
-  // target on the stop lane.  Behind the chunk loop (rounds 1-5) they were two or three dependent round trips at the tail of every wavefront:
-  // the phase replays of round 6 (profiles/r06_sweep_phases.txt) put the epilogue alone at 7.1 us over the launch floor and at 1.9 us of the
-  // full kernel, nearly all of it these waits.
-  uint8_t pf_hb = 0;
-  double pf_deg = 0.0, pf_vinf = 0.0;
-  if (row >= 0) {
-    if (p.bias != nullptr && p.slot_has_bias) pf_hb = p.slot_has_bias[slice * R + g];
-    if constexpr (HAS_W && !GRP) {
-      if (is_w && p.err_next) { pf_deg = p.deg[row]; pf_vinf = p.vinf[row]; }
-    }
-  }
+  // (Round 6 tried asking for what the epilogue needs from memory HERE -- the row's bias flag, degree and stop target -- instead of behind
+  // the chunk loop: the phase replays, profiles/r06_sweep_phases.txt, put the epilogue at 1.9 us of the full kernel.  Measured: 12.86 us per
+  // launch against 12.4 -- the three early loads per lane compete with the first gathers; not kept.)
   if constexpr (HAS_W && !GRP) {
     if (p.err_prev) {   // stop test of ssl.py:667, decided identically by every wavefront
       // (`while ... np.max(np.absolute(v-vinf)) > 1/n`: a NaN maximum compares False and ends the loop too;
@@ -507,7 +498,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
   const bool store_on = (GRP ? c < p.nlanes : lane_on) && row >= 0 && seg == 0;
   if (store_on) {
     bool hb = p.bias != nullptr;
-    if (hb && p.slot_has_bias) hb = pf_hb != 0;
+    if (hb && p.slot_has_bias) hb = p.slot_has_bias[slice * R + g] != 0;
     if (hb) {
       const V4 b = *(const V4*)(p.bias + (size_t)row * p.rec_bytes + lane_off);
       outv = b + acc;
@@ -604,7 +595,7 @@ __global__ __launch_bounds__(64 * GLX_WPB) void spmm_sell_kernel(const SpmmParam
       if (store_on && is_w) {
         double wnew;
         if constexpr (sizeof(T) == 4) wnew = accw; else wnew = (double)outv[0];
-        e = fabs(pf_deg * wnew - pf_vinf);
+        e = fabs(p.deg[row] * wnew - p.vinf[row]);
         if (e != e) e = __longlong_as_double(0x7ff8000000000000ll);   // canonical NaN: orders above +inf as a bit pattern (np.max propagates NaN)
       }
       const unsigned long long m = wave_max_u64((unsigned long long)__double_as_longlong(e));
