@@ -84,3 +84,20 @@ def test_identical_without_speculative_fits(gl, everything_on):
     finally:
         ssl.SPECULATIVE_FITS = old
     _same(everything_on, got)
+
+
+@pytest.mark.parametrize('mode', [1, 2])
+def test_identical_however_the_big_transfers_travel(gl, everything_on, mode):
+    """_hip.upload_set_mode: 0 (default) = transfers of 128 KB or more through the library's page-locked staging, checked by word sums;
+    1 = staged, unchecked; 2 = straight from / into the caller's memory as rounds 1-5 did.  Same results -- and in the default mode the
+    walk's transfers were all checked and none differed."""
+    from graphlearning_amd import _hip
+    before = _hip.upload_stats()
+    assert before['checked'] > 0 and before['wrong_sums'] == 0 and before['given_up'] == 0, before      # (the module's `everything_on` walk)
+    _hip.upload_set_mode(mode)
+    try:
+        got = _walk(gl)
+    finally:
+        _hip.upload_set_mode(0)
+    _same(everything_on, got)
+    assert _hip.upload_stats()['checked'] == before['checked']          # nothing was checked in modes 1 / 2
