@@ -574,9 +574,9 @@ static int knn_to_csr_impl(const int64_t* ind, const double* dist, const double*
   }
   for (int64_t i = 0; i <= n; ++i) h_rp[i] = (int32_t)rp[i];
   hipError_t e1 = hipSuccess, e2 = hipSuccess;
-  if (!direct) {
-    e1 = hipMemcpyAsync(h_col, b.col, nnz * 4, hipMemcpyDeviceToHost, st);
-    e2 = hipMemcpyAsync(h_val, b.val, nnz * 8, hipMemcpyDeviceToHost, st);
+  if (!direct) {       // (into memory that may be ordinary: through the checked download)
+    if (glx_download(h_col, b.col, nnz * 4, st, "glx_knn_to_csr")) e1 = hipErrorUnknown;
+    if (e1 == hipSuccess && glx_download(h_val, b.val, nnz * 8, st, "glx_knn_to_csr")) e2 = hipErrorUnknown;
   }
   hipError_t e3 = hipStreamSynchronize(st);
   if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {

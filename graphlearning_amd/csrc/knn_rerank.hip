@@ -523,7 +523,7 @@ extern "C" int glx_nearest_dist(const double* X, int64_t n, int d, const int64_t
                          (const double*)dR, m, piece, dO);
       e = hipGetLastError();
     }
-    if (!rc && e == hipSuccess) e = hipMemcpy(dist_out, dO, (size_t)n * 8, hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess) rc = glx_download_sync(dist_out, dO, (size_t)n * 8, "glx_nearest_dist");
     if (!rc && e != hipSuccess) { glx_set_error("glx_nearest_dist: %s", hipGetErrorString(e)); rc = GLX_EHIP; }
   }
   glx_pool_free(dX);

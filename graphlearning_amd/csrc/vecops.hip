@@ -163,9 +163,10 @@ extern "C" int glx_exp_cr(const double* x, double* out, int64_t n, int device) {
     hipError_t e = hipSuccess;
     if (!rc) {
       hipLaunchKernelGGL(exp_cr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const double*)dx, dy, n);
-      e = hipMemcpy(out, dy, (size_t)n * 8, hipMemcpyDeviceToHost);
+      e = hipGetLastError();
+      if (e == hipSuccess) rc = glx_download_sync(out, dy, (size_t)n * 8, "glx_exp_cr");
     }
-    if (e != hipSuccess) { glx_set_error("glx_exp_cr: %s", hipGetErrorString(e)); rc = GLX_EHIP; }
+    if (!rc && e != hipSuccess) { glx_set_error("glx_exp_cr: %s", hipGetErrorString(e)); rc = GLX_EHIP; }
   }
   glx_pool_free(dx);
   glx_pool_free(dy);

@@ -101,3 +101,22 @@ def test_identical_however_the_big_transfers_travel(gl, everything_on, mode):
         _hip.upload_set_mode(0)
     _same(everything_on, got)
     assert _hip.upload_stats()['checked'] == before['checked']          # nothing was checked in modes 1 / 2
+
+
+def test_big_transfers_in_pieces_round_trip(gl):
+    """glx_upload / glx_download beyond one piece of the staging area (4 MB pieces from 6 MB on, two halves taking turns), with lengths that are
+    not multiples of the piece, through the one entry point that is nothing but upload -> elementwise kernel -> download (glx_exp_cr): a 40 MB
+    array gives the same bits as its slices sent one by one, and every transfer was checked."""
+    from graphlearning_amd import _hip
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=5_000_011) * 3.0
+    before = _hip.upload_stats()
+    big = _hip.exp_cr(x)
+    after = _hip.upload_stats()
+    assert after['checked'] >= before['checked'] + 2 and after['wrong_sums'] == before['wrong_sums'] and after['given_up'] == 0, (before, after)
+    parts = np.concatenate([_hip.exp_cr(x[a:a + 9001]) for a in range(0, 300_000, 9001)])           # (72 KB each: direct copies)
+    assert np.array_equal(big[:len(parts)], parts)
+    tail = _hip.exp_cr(x[-70_001:])                                                                    # 560 KB: one checked piece
+    assert np.array_equal(big[-70_001:], tail)
+    with np.errstate(over='ignore'):
+        assert np.max(np.abs(big - np.exp(x)) / np.exp(x)) < 3e-16
