@@ -756,7 +756,8 @@ extern "C" int glx_poisson_sweep_dist(glx_dist_sweep* s, int min_iter, int max_i
   GLX_HIP(hipEventRecord(s->ev0, s->stream));
   // head: reset + the sweeps the stop test cannot cut short, ping-pong on ring[0] / ring[1]
   rc = run_captured(s, {0L, (long)head, 0L, 0L}, [&]() -> int {
-    GLX_HIP(hipMemsetAsync(s->err, 0, ERR_SHARDS * 8, s->stream));
+    // (a kernel, not a memset node: captured and replayed -- glx_zero_async, glx_internal.h)
+    { int rz = glx_zero_async(s->err, ERR_SHARDS * 8, s->stream); if (rz) return rz; }
     int r2 = enqueue_reset(s, s->ring[0]);
     for (int t = 0; t < head && !r2; ++t)
       r2 = enqueue_sweep(s, s->ring[t & 1], s->ring[(t & 1) ^ 1], (head_err && t + 1 == head) ? s->err : nullptr);
@@ -780,7 +781,7 @@ extern "C" int glx_poisson_sweep_dist(glx_dist_sweep* s, int min_iter, int max_i
       const int cnt = std::min(check_every, max_iter - T);
       const int cur0 = s->cur;
       rc = run_captured(s, {1L, (long)R, (long)cur0, (long)cnt}, [&]() -> int {   // the ring size is part of the buffers a chunk touches
-        GLX_HIP(hipMemsetAsync(s->err + ERR_SHARDS, 0, (size_t)cnt * ERR_SHARDS * 8, s->stream));
+        { int rz = glx_zero_async(s->err + ERR_SHARDS, (size_t)cnt * ERR_SHARDS * 8, s->stream); if (rz) return rz; }
         int r2 = GLX_OK;
         for (int j = 0; j < cnt && !r2; ++j)
           r2 = enqueue_sweep(s, s->ring[(cur0 + j) % R], s->ring[(cur0 + j + 1) % R], s->err + (size_t)(j + 1) * ERR_SHARDS);

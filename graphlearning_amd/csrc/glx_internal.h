@@ -107,9 +107,18 @@ struct glx_graph {
 };
 void glx_cg_ws_destroy(void* ws);
 
+// Zero-fill by a KERNEL, for launch sequences that are captured and replayed: a memset NODE of a captured sequence is not safe on every
+// runtime this library meets -- on the HIP runtime bundled with PyTorch 2.10 + rocm7.0 (7.0.51831: what the library runs on whenever torch was
+// imported first, i.e. in every multi-GPU job) a replayed memset node fills with the value of the process's last eager hipMemset instead
+// of its own (scripts/probes/graph_memset_probe.hip; found in round 6 when a poisoned pool turned a row of stop values into 1.4e306 on
+// the second replay of the stacked trials' head graph).  `p` 8-byte aligned, `bytes` a multiple of 8.
+int glx_zero_async(void* p, size_t bytes, hipStream_t st);
 // device work-buffer pool (graph.hip): size-class free lists in front of hipMalloc / hipFree
 int glx_pool_alloc(void** out, size_t bytes);
 void glx_pool_free(void* p);
+// small page-locked blocks (graph.hip): power-of-two classes in front of hipHostMalloc / hipHostFree (0.25 ms each)
+int glx_pinned_alloc(void** out, size_t bytes);
+void glx_pinned_free(void* p);
 
 // a finished full search: its lists on the device (pooled blocks, [n][k]) and the cell order it worked out (empty: none)
 struct glx_knn_result {

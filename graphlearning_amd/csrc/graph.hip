@@ -45,6 +45,7 @@ extern "C" void glx_free(void* p) { free(p); }
 #include <atomic>
 #include <map>
 #include <mutex>
+#define GLX_POOL(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 static const size_t POOL_CAP = 1ull << 30, POOL_BLOCK_MAX = 256ull << 20;
 struct PoolState {
   std::mutex mu;
@@ -177,6 +178,7 @@ void glx_work_release(glx_work* w) {
   work_destroy(w);
 }
 
+static void pinned_release_idle();
 extern "C" int glx_pool_set_enabled(int enabled) {
   g_pool_enabled = enabled != 0;
   if (!g_pool_enabled) {             // what is idle now goes back to the runtime (blocks in use follow when they are released)
@@ -196,6 +198,7 @@ extern "C" int glx_pool_set_enabled(int enabled) {
     }
     for (void* p : idle) hipFree(p);
     for (glx_work* w : sets) work_destroy(w);
+    pinned_release_idle();
   }
   return GLX_OK;
 }
@@ -270,6 +273,69 @@ void glx_pool_free(void* p) {
     }
   }
   hipFree(p);
+}
+
+// Small page-locked blocks (the stop-value mirrors of a sweep object, the projector's image): hipHostMalloc 0.03-0.13 ms, hipHostFree
+// 0.25 ms each -- two of each per model on a fresh graph.  Power-of-two classes from 4 KiB to 4 MiB, at most 32 MiB idle; follows the
+// pool's switch (glx_pool_set_enabled).  The contract is the device pool's: nothing in flight still writes a block that is handed back.
+namespace {
+struct PinnedPool {
+  std::mutex mu;
+  std::multimap<size_t, void*> idle;
+  std::map<void*, size_t> live;
+  size_t cached = 0;
+};
+PinnedPool& pinned_pool() { static PinnedPool* p = new PinnedPool(); return *p; }
+}  // namespace
+int glx_pinned_alloc(void** out, size_t bytes) {
+  size_t c = 4096;
+  while (c < bytes) c <<= 1;
+  PinnedPool& pp = pinned_pool();
+  if (c <= ((size_t)4 << 20)) {
+    std::lock_guard<std::mutex> lk(pp.mu);
+    auto it = pp.idle.find(c);
+    if (it != pp.idle.end()) {
+      *out = it->second;
+      pp.idle.erase(it);
+      pp.cached -= c;
+      pp.live[*out] = c;
+      return GLX_OK;
+    }
+  }
+  *out = nullptr;
+  GLX_HIP(hipHostMalloc(out, c, hipHostMallocDefault));
+  std::lock_guard<std::mutex> lk(pp.mu);
+  pp.live[*out] = c;
+  return GLX_OK;
+}
+static void pinned_release_idle() {
+  std::vector<void*> idle;
+  {
+    PinnedPool& pp = pinned_pool();
+    std::lock_guard<std::mutex> lk(pp.mu);
+    for (auto& kv : pp.idle) idle.push_back(kv.second);
+    pp.idle.clear();
+    pp.cached = 0;
+  }
+  for (void* p : idle) hipHostFree(p);
+}
+void glx_pinned_free(void* p) {
+  if (!p) return;
+  PinnedPool& pp = pinned_pool();
+  {
+    std::lock_guard<std::mutex> lk(pp.mu);
+    auto it = pp.live.find(p);
+    if (it != pp.live.end()) {
+      const size_t c = it->second;
+      pp.live.erase(it);
+      if (g_pool_enabled && c <= ((size_t)4 << 20) && pp.cached + c <= ((size_t)32 << 20)) {
+        pp.idle.insert({c, p});
+        pp.cached += c;
+        return;
+      }
+    }
+  }
+  hipHostFree(p);
 }
 
 // A few host worker threads that stay around (spawning eight std::threads costs ~0.3 ms: as much as hashing 25 MB).  parallel_for
@@ -491,11 +557,7 @@ static int upload_staged(Uploader* w, void* dst, const void* src, size_t bytes, 
   size_t half = (size_t)1 << 18;
   while (half < bytes + stage_shift && half < HALF_MAX) half <<= 1;
   if (w->bytes < 2 * half) {
-    if (w->stage) {
-      for (int i = 0; i < 2; ++i)
-        if (w->ev[i]) GLX_HIP(hipEventSynchronize(w->ev[i]));
-      hipHostFree(w->stage);
-    }
+    if (w->stage) hipHostFree(w->stage);          // (nothing reads it any more: every call ends behind its last copy, see below)
     w->stage = nullptr;
     w->bytes = 0;
     GLX_HIP(hipHostMalloc(&w->stage, 2 * half, hipHostMallocDefault));
@@ -514,7 +576,12 @@ static int upload_staged(Uploader* w, void* dst, const void* src, size_t bytes, 
     const size_t len = std::min(room, bytes - off);
     const size_t whole = len / 8 * 8;
     char* stage = (char*)w->stage + (size_t)turn * h + stage_shift;
-    GLX_HIP(hipEventSynchronize(w->ev[turn]));          // (the copy that last read this half; an event never recorded is complete)
+    // the copy of THIS call that last read this half.  Never an event of an earlier call: the runtime's hipEventSynchronize looks at the
+    // stream the event was last recorded on, and that stream may be gone by now (a work set's stream destroyed with its set: the pool
+    // switched off) -- "operation not permitted on an event last recorded in a capturing stream" out of freed memory, in the first
+    // upload after such a stream's address was reused (round 6, tests/test_gpu_switches.py).  Every call therefore ends with its
+    // copies complete (the checked path waits for its sum, the unchecked one for the stream) and starts with both halves free.
+    if (off >= 2 * room) GLX_HIP(hipEventSynchronize(w->ev[turn]));
     const int nt = (int)std::min<size_t>(8, std::max<size_t>(1, whole >> 19));
     if (nt > 1) {
       unsigned long long part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -536,13 +603,23 @@ static int upload_staged(Uploader* w, void* dst, const void* src, size_t bytes, 
     GLX_HIP(hipEventRecord(w->ev[turn], st));
   }
   if (sum_out) *sum_out = total;
+  else GLX_HIP(hipStreamSynchronize(st));             // (the checked caller synchronises behind its sum kernel)
   return GLX_OK;
 }
 
+// (one atomic per workgroup and at most UPLOAD_SUM_BLOCKS of them: 8192 wavefronts adding to ONE address took 100 us for 11 MB, the
+// additions themselves 5)
+#define UPLOAD_SUM_BLOCKS 512
 __global__ __launch_bounds__(256) void upload_sum_kernel(const unsigned long long* __restrict__ p, int64_t nwords, int tail_bytes,
                                                          unsigned long long* __restrict__ out) {
   unsigned long long a = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * 256) a += p[i];
+  const int64_t step = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * step < nwords; i += 4 * step) {          // four loads in flight per thread
+    const unsigned long long v0 = p[i], v1 = p[i + step], v2 = p[i + 2 * step], v3 = p[i + 3 * step];
+    a += v0 + v1 + v2 + v3;
+  }
+  for (; i < nwords; i += step) a += p[i];
   if (tail_bytes && blockIdx.x == 0 && threadIdx.x == 0) {
     const unsigned char* t = (const unsigned char*)(p + nwords);
     unsigned long long v = 0;
@@ -550,7 +627,16 @@ __global__ __launch_bounds__(256) void upload_sum_kernel(const unsigned long lon
     a += v;
   }
   for (int off = 32; off >= 1; off >>= 1) a += (unsigned long long)__shfl_xor((long long)a, off);
-  if ((threadIdx.x & 63) == 0 && a) atomicAdd(out, a);
+  __shared__ unsigned long long sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = sh[0] + sh[1] + sh[2] + sh[3];
+    if (t) atomicAdd(out, t);
+  }
+}
+static inline unsigned upload_sum_grid(int64_t nwords) {
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(UPLOAD_SUM_BLOCKS, (nwords + 1023) / 1024));
 }
 
 static std::atomic<unsigned long long> g_upload_stats[4];       // uploads checked, sums that differed, uploads repeated successfully, given up
@@ -587,7 +673,7 @@ int glx_upload(void* dst, const void* src, size_t bytes, hipStream_t st, const c
     if (rc) return rc;
     GLX_HIP(hipMemsetAsync(w->sum, 0, 8, st));
     const int64_t nw = (int64_t)(bytes / 8);
-    hipLaunchKernelGGL(upload_sum_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (nw + 255) / 256))), dim3(256), 0, st,
+    hipLaunchKernelGGL(upload_sum_kernel, dim3(upload_sum_grid(nw)), dim3(256), 0, st,
                        (const unsigned long long*)dst, nw, (int)(bytes % 8), w->sum);
     GLX_HIP(hipGetLastError());
     GLX_HIP(hipMemcpyAsync(w->sum_host, w->sum, 8, hipMemcpyDeviceToHost, st));
@@ -668,7 +754,7 @@ int glx_download(void* dst, const void* src, size_t bytes, hipStream_t st, const
     if (check) {
       GLX_HIP(hipMemsetAsync(w->sum, 0, 8, st));
       const int64_t nw = (int64_t)(bytes / 8);
-      hipLaunchKernelGGL(upload_sum_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (nw + 255) / 256))), dim3(256), 0, st,
+      hipLaunchKernelGGL(upload_sum_kernel, dim3(upload_sum_grid(nw)), dim3(256), 0, st,
                          (const unsigned long long*)src, nw, 0, w->sum);
       GLX_HIP(hipGetLastError());
       GLX_HIP(hipMemcpyAsync(w->sum_host, w->sum, 8, hipMemcpyDeviceToHost, st));
@@ -866,9 +952,9 @@ extern "C" int glx_graph_create_resident(int64_t n_rows, int64_t n_cols, int64_t
   if (rc) return rc;
   struct WorkGuard { glx_work* w; ~WorkGuard() { hipStreamSynchronize(w->stream); glx_work_release(w); } } wguard{w};
   hipStream_t st = w->stream;
-  GLX_HIP(hipMalloc(&g->d_src_rowptr, (size_t)(n_rows + 1) * 4));
-  GLX_HIP(hipMalloc(&g->d_src_col, std::max<size_t>((size_t)nnz * 4, 4)));
-  GLX_HIP(hipMalloc(&g->d_src_val, std::max<size_t>((size_t)nnz * 8, 8)));
+  GLX_POOL(glx_pool_alloc((void**)&g->d_src_rowptr, (size_t)(n_rows + 1) * 4));
+  GLX_POOL(glx_pool_alloc((void**)&g->d_src_col, std::max<size_t>((size_t)nnz * 4, 4)));
+  GLX_POOL(glx_pool_alloc((void**)&g->d_src_val, std::max<size_t>((size_t)nnz * 8, 8)));
   GLX_UP(glx_upload(g->d_src_rowptr, rowptr, (size_t)(n_rows + 1) * 4, st, __func__));
   if (nnz > 0) {
     GLX_UP(glx_upload(g->d_src_col, col, (size_t)nnz * 4, st, __func__));
@@ -912,10 +998,10 @@ extern "C" int glx_graph_set_row_transform(glx_graph* g, const double* row_scale
   GLX_CHECK(g->plans.empty(), GLX_EINVAL, "glx_graph_set_row_transform: call before the operator is first used");
   GLX_HIP(hipSetDevice(g->device));
   g->reverse_rows = reverse_rows != 0;
-  hipFree(g->d_row_scale);
+  glx_pool_free(g->d_row_scale);
   g->d_row_scale = nullptr;
   if (row_scale && g->n_rows > 0) {
-    GLX_HIP(hipMalloc(&g->d_row_scale, (size_t)g->n_rows * 8));
+    GLX_POOL(glx_pool_alloc((void**)&g->d_row_scale, (size_t)g->n_rows * 8));
     glx_work* w = nullptr;             // (a work set's stream, not a blocking copy on the NULL stream: see glx_graph_set_order)
     int rc = glx_work_acquire(g->device, &w);
     if (rc) return rc;
@@ -926,26 +1012,30 @@ extern "C" int glx_graph_set_row_transform(glx_graph* g, const double* row_scale
   return GLX_OK;
 }
 
-static void free_plan(SellPlan& p) {
-  hipFree(p.d_slot_row);
-  hipFree(p.d_slot_len);
-  hipFree(p.d_slice_hdr);
-  hipFree(p.d_col);
-  hipFree(p.d_val);
+static void free_plan(SellPlan& p) {      // (callers: glx_graph_destroy behind its device synchronisation)
+  glx_pool_free(p.d_slot_row);
+  glx_pool_free(p.d_slot_len);
+  glx_pool_free(p.d_slice_hdr);
+  glx_pool_free(p.d_col);
+  glx_pool_free(p.d_val);
   p = SellPlan();
 }
 
 extern "C" int glx_graph_destroy(glx_graph* g) {
   if (!g) return GLX_OK;
   hipSetDevice(g->device);
+  // the operator's buffers go back to the size-class pool (hipFree of a block of megabytes costs 0.23 ms and there were ten of them: a
+  // third of a first fit on a fresh graph, profiles/r06_fresh_path.txt).  hipFree waited for the device; the pool's contract is that nothing
+  // in flight still uses a block that is handed back -- so wait here, once.
+  hipDeviceSynchronize();
   for (auto& p : g->plans) free_plan(p);
   if (g->cg_ws) glx_cg_ws_destroy(g->cg_ws);
-  hipFree(g->d_perm);
-  hipFree(g->d_inv);
-  hipFree(g->d_src_rowptr);
-  hipFree(g->d_src_col);
-  hipFree(g->d_src_val);
-  hipFree(g->d_row_scale);
+  glx_pool_free(g->d_perm);
+  glx_pool_free(g->d_inv);
+  glx_pool_free(g->d_src_rowptr);
+  glx_pool_free(g->d_src_col);
+  glx_pool_free(g->d_src_val);
+  glx_pool_free(g->d_row_scale);
   delete g;
   return GLX_OK;
 }
@@ -1065,8 +1155,8 @@ int glx_graph_ensure_order(glx_graph* g) {
   g->h_inv.assign(n, 0);
   for (int64_t i = 0; i < n; ++i) g->h_inv[g->h_perm[i]] = (int32_t)i;
   GLX_HIP(hipSetDevice(g->device));
-  GLX_HIP(hipMalloc(&g->d_perm, n * 4));
-  GLX_HIP(hipMalloc(&g->d_inv, n * 4));
+  GLX_POOL(glx_pool_alloc((void**)&g->d_perm, n * 4));
+  GLX_POOL(glx_pool_alloc((void**)&g->d_inv, n * 4));
   GLX_UP(glx_upload_sync(g->d_perm, g->h_perm.data(), n * 4, __func__));
   GLX_UP(glx_upload_sync(g->d_inv, g->h_inv.data(), n * 4, __func__));
   return GLX_OK;
@@ -1244,8 +1334,8 @@ extern "C" int glx_graph_set_order(glx_graph* g, const int32_t* perm) {
   g->h_inv.swap(inv);
   g->order_ready = true;
   GLX_HIP(hipSetDevice(g->device));
-  GLX_HIP(hipMalloc(&g->d_perm, std::max<size_t>(n * 4, 4)));
-  GLX_HIP(hipMalloc(&g->d_inv, std::max<size_t>(n * 4, 4)));
+  GLX_POOL(glx_pool_alloc((void**)&g->d_perm, std::max<size_t>(n * 4, 4)));
+  GLX_POOL(glx_pool_alloc((void**)&g->d_inv, std::max<size_t>(n * 4, 4)));
   // through a work set's stream and its page-locked staging: a blocking hipMemcpy runs on the NULL stream, whose copy queue the first
   // such call of a process creates (9 ms of a fresh model's first fit_predict)
   glx_work* w = nullptr;
@@ -1511,11 +1601,11 @@ int glx_graph_plan(glx_graph* g, int G, SellPlan** out, bool relaxed) {
   p.stored = head + stored;
   p.head = head;
   const size_t es = g->dtype == GLX_F64 ? 8 : 4;
-  GLX_HIP(hipMalloc(&p.d_slot_row, std::max<size_t>(4, slot_row.size() * 4)));
-  GLX_HIP(hipMalloc(&p.d_slot_len, std::max<size_t>(4, slot_len.size() * 4)));
-  GLX_HIP(hipMalloc(&p.d_slice_hdr, std::max<size_t>(16, hdr.size() * sizeof(SliceHdr))));
-  GLX_HIP(hipMalloc(&p.d_col, std::max<size_t>(4, (head + stored) * 4)));
-  GLX_HIP(hipMalloc(&p.d_val, std::max<size_t>(8, (head + stored) * es)));
+  GLX_POOL(glx_pool_alloc((void**)&p.d_slot_row, std::max<size_t>(4, slot_row.size() * 4)));
+  GLX_POOL(glx_pool_alloc((void**)&p.d_slot_len, std::max<size_t>(4, slot_len.size() * 4)));
+  GLX_POOL(glx_pool_alloc((void**)&p.d_slice_hdr, std::max<size_t>(16, hdr.size() * sizeof(SliceHdr))));
+  GLX_POOL(glx_pool_alloc((void**)&p.d_col, std::max<size_t>(4, (head + stored) * 4)));
+  GLX_POOL(glx_pool_alloc((void**)&p.d_val, std::max<size_t>(8, (head + stored) * es)));
   glx_work* pw = nullptr;              // uploads and the fill run in a work set's stream (no blocking copies on the NULL stream)
   {
     int rcw = glx_work_acquire(g->device, &pw);

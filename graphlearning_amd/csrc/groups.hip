@@ -282,11 +282,12 @@ static int grp_launch_sweep(glx_sweep_groups* s, int t, unsigned used_mask) {
 static int grp_enqueue_head(glx_sweep_groups* s, unsigned used_mask) {
   const int head = std::min(s->min_iter, s->max_iter);
   const size_t er = grp_err_row(s);
-  GLX_HIP(hipMemsetAsync(s->err + (size_t)head * er, 0, er * 8, s->stream));
+  // (kernels, not memset nodes: this sequence is captured and replayed -- glx_zero_async, glx_internal.h)
+  { int rz = glx_zero_async(s->err + (size_t)head * er, er * 8, s->stream); if (rz) return rz; }
   if (s->min_iter == 0)      // the test in front of the first sweep: err0 of every group, written to the mirror by the caller
     GLX_HIP(hipMemcpyAsync(s->err, s->h_err, er * 8, hipMemcpyHostToDevice, s->stream));
   s->cur = 0;
-  GLX_HIP(hipMemsetAsync(s->buf[0], 0, (size_t)s->n * grp_rec_bytes(s), s->stream));
+  { int rz = glx_zero_async(s->buf[0], (size_t)s->n * grp_rec_bytes(s), s->stream); if (rz) return rz; }
   if (s->n > 0) {
     const int64_t tot = s->n * s->B;
     hipLaunchKernelGGL(grp_init_stop_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, (char*)s->buf[0], (int)grp_rec_bytes(s),

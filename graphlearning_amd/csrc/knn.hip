@@ -345,6 +345,7 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   stamp("centred, norms bounded");
   GLX_HIP(hipEventRecord(b.e0, st));
   int rc;
+  g_knn_stats[9] = 0.0;      // (the fp32 filter has no concatenated form: not the previous search's value)
   if (use_bf16) {
     // 17 <= d <= 21 (two blocks of 16 per half): the three split products as ONE contraction over concatenated operands,
     // 4 MFMAs per 32 x 32 tile instead of 6 (d <= 16 needs 3 either way)

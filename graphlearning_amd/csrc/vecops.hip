@@ -172,3 +172,16 @@ extern "C" int glx_exp_cr(const double* x, double* out, int64_t n, int device) {
   glx_pool_free(dy);
   return rc;
 }
+
+__global__ __launch_bounds__(256) void glx_zero_kernel(unsigned long long* __restrict__ p, int64_t nwords) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * 256) p[i] = 0ull;
+}
+int glx_zero_async(void* p, size_t bytes, hipStream_t st) {
+  GLX_CHECK(((uintptr_t)p % 8 == 0) && bytes % 8 == 0, GLX_EINVAL, "glx_zero_async: 8-byte words only");
+  if (bytes == 0) return GLX_OK;
+  const int64_t nw = (int64_t)(bytes / 8);
+  hipLaunchKernelGGL(glx_zero_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (nw + 255) / 256))), dim3(256), 0, st,
+                     (unsigned long long*)p, nw);
+  GLX_HIP(hipGetLastError());
+  return GLX_OK;
+}

@@ -2,6 +2,8 @@
 and idle work sets (_hip.pool_set_enabled), the page-locked result blocks (_hip.PINNED_RESULTS), the speculative fit on the previous
 content fingerprint (ssl.SPECULATIVE_FITS).  With each one off, the whole path -- search, weight matrix, every learner, an in-place
 edit of the matrix between two fits -- returns the same bits as with everything on."""
+import os
+
 import numpy as np
 import pytest
 
@@ -26,6 +28,11 @@ def _walk(gl):
                 out.append(np.array(m.fit(ti_r, lab[ti_r]), copy=True))
                 out.append(np.array(m.predict(), copy=True))
                 out.append(np.array([getattr(m, 'num_iter', -1)]))
+        # stacked trials with class priors: the head graph of the stacked sweeps is replayed batch after batch, the weights of the volume
+        # projection run through all of them (a stop row that a replay leaves wrong shows as a 51st sweep and other labels: round 6)
+        tsets = gl.trainsets.generate(lab, rate=np.array([[1], [2], [4]]), num_trials=4, seed=seed)
+        mt = gl.ssl.poisson(W, class_priors=gl.utils.class_priors(lab), solver='gradient_descent')
+        out.append(np.array([[float(v) for v in row.split(',')] for row in mt._trial_rows(tsets, lab)]))
         m = gl.ssl.poisson(W, solver='gradient_descent')
         m.fit(ti, lab[ti])
         W.data *= 0.5                                      # edited in place: the next fit must see the new content
@@ -62,6 +69,22 @@ def test_identical_with_the_device_pool_bypassed(gl, everything_on):
     finally:
         _hip.pool_set_enabled(True)
     _same(everything_on, _walk(gl))                        # and after switching it back on
+
+
+@pytest.mark.parametrize('byte', [0x7f, 0xff, 0x00])
+def test_identical_with_a_poisoned_pool(gl, everything_on, byte):
+    """Every pooled block is filled with `byte` when it is handed out (_hip.pool_set_poison): nothing may read a work buffer before writing
+    it -- and, on the HIP runtime that comes with PyTorch (the suite loads torch first: conftest.py), the eager hipMemset of the fill used to
+    change what the memset NODES of replayed launch graphs wrote (scripts/probes/graph_memset_probe.hip): captured sequences zero
+    their rows with a kernel now (glx_zero_async)."""
+    from graphlearning_amd import _hip
+    _hip.pool_set_poison(byte)
+    try:
+        got = _walk(gl)
+    finally:
+        session = [a for a in os.environ.get('GLX_TEST_ABLATE', '').split(',') if a.startswith('poison')]      # (an ablation run's own fill)
+        _hip.pool_set_poison(int(session[0][6:] or '255') if session else -1)
+    _same(everything_on, got)
 
 
 def test_identical_without_page_locked_result_blocks(gl, everything_on):
