@@ -99,47 +99,15 @@ __global__ __launch_bounds__(256) void cg_update_kernel(T* __restrict__ x, T* __
   }
 }
 
-// p = r + beta p                                                          (utils.py:529)
-template <typename T>
-__global__ __launch_bounds__(256) void cg_pupdate_kernel(const T* __restrict__ r, T* __restrict__ p,
-                                                         const double* __restrict__ beta, int64_t n, int ld, int nvec,
-                                                         const CgScalars sc, int it, double tol, int) {
-#pragma clang fp contract(off)
-  typedef typename V4Of<T>::type V4;
-  // this kernel belongs to iteration `it`: it runs iff the iteration ran
-  if (!cg_any_active(sc, it, tol)) return;
-  const int nvq = ld / 4;
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t row = v / nvq;
-  const int cv = (int)(v % nvq);
-  if (row >= n || cv >= nvec) return;
-  bool any = false;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) any = any || cg_col_active(sc, it, tol, cv * 4 + e);
-  if (!any) return;
-  V4 b;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) b[e] = (T)beta[cv * 4 + e];
-  const size_t o = (size_t)row * ld + cv * 4;
-  const V4 rv = *(const V4*)(r + o);
-  const V4 pv = *(const V4*)(p + o);
-  const V4 t = b * pv;
-  V4 pn = rv + t;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) pn[e] = cg_col_active(sc, it, tol, cv * 4 + e) ? pn[e] : pv[e];
-  *(V4*)(p + o) = pn;
-}
-
 // err_g = np.sqrt(np.sum(rsnew_g)) for every group still running (utils.py:528), then the
 // maximum over those groups (what the kernels of the next iteration test).  np.sum over a
 // contiguous 1-D float64 array is numpy's pairwise_sum: 8 accumulators below 128 elements, a plain
 // loop below 8 (Cg <= 128 here).  One thread per group.
-__global__ __launch_bounds__(256) void cg_group_err_kernel(CgScalars sc, int it, double tol) {
+__device__ __forceinline__ void cg_group_err_body(const CgScalars& sc, int it, double tol, double* s_e) {
 #pragma clang fp contract(off)
   // (the rows of the residual history are a ring of CG_CHUNK + 1 entries reused chunk after chunk: an iteration that does not run
   // writes the zeros -- "stopped" -- that a fresh buffer would hold, so that everything behind it stays off as well)
   const bool any = cg_any_active(sc, it, tol);
-  __shared__ double s_e[256];
   const int g = threadIdx.x;
   double mine = 0.0;
   if (any && g < sc.ngroups && cg_col_active(sc, it, tol, g * sc.Cg)) {
@@ -171,6 +139,49 @@ __global__ __launch_bounds__(256) void cg_group_err_kernel(CgScalars sc, int it,
       if (s_e[q] > m) m = s_e[q];
     sc.err_hist[(size_t)it * sc.stride + sc.ngroups] = m;
   }
+}
+__global__ __launch_bounds__(256) void cg_group_err_kernel(CgScalars sc, int it, double tol) {
+  __shared__ double s_e[256];
+  cg_group_err_body(sc, it, tol, s_e);
+}
+
+// p = r + beta p                                                          (utils.py:529)
+template <typename T>
+__global__ __launch_bounds__(256) void cg_pupdate_kernel(const T* __restrict__ r, T* __restrict__ p,
+                                                         const double* __restrict__ beta, int64_t n, int ld, int nvec,
+                                                         const CgScalars sc, int it, double tol, int with_err) {
+#pragma clang fp contract(off)
+  typedef typename V4Of<T>::type V4;
+  // with_err == 2: the launch has one workgroup more than the rows need, and that one forms the iteration's residual norms (the row of
+  // the history the NEXT iteration tests; this kernel tests the previous row like everything else of iteration `it`) -- one launch of a
+  // single workgroup less per iteration of the reference-order solve (4.6 us of its ~140)
+  if (with_err == 2 && blockIdx.x == gridDim.x - 1) {
+    __shared__ double s_e[256];
+    cg_group_err_body(sc, it, tol, s_e);
+    return;
+  }
+  // this kernel belongs to iteration `it`: it runs iff the iteration ran
+  if (!cg_any_active(sc, it, tol)) return;
+  const int nvq = ld / 4;
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = v / nvq;
+  const int cv = (int)(v % nvq);
+  if (row >= n || cv >= nvec) return;
+  bool any = false;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) any = any || cg_col_active(sc, it, tol, cv * 4 + e);
+  if (!any) return;
+  V4 b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b[e] = (T)beta[cv * 4 + e];
+  const size_t o = (size_t)row * ld + cv * 4;
+  const V4 rv = *(const V4*)(r + o);
+  const V4 pv = *(const V4*)(p + o);
+  const V4 t = b * pv;
+  V4 pn = rv + t;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) pn[e] = cg_col_active(sc, it, tol, cv * 4 + e) ? pn[e] : pv[e];
+  *(V4*)(p + o) = pn;
 }
 
 // the ring of the residual history turns: row 0 (what iteration 1 of a chunk tests) <- row `from` (what the previous chunk's last iteration left)
@@ -751,10 +762,8 @@ static int cg_run(glx_graph* A, const void* B, void* X, int C, int Cg, double to
       hipLaunchKernelGGL(cg_seqsum_dpp_kernel<1>, dim3(seq_grid), dim3(64), 0, st, (const double*)b.prod, n, ncols, C, sc, i, tol);
     }
     GLX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(cg_group_err_kernel, dim3(1), blk, 0, st, sc, i, tol);
-    GLX_HIP(hipGetLastError());
-    hipLaunchKernelGGL((cg_pupdate_kernel<T>), dim3(pgrid), blk, 0, st, (const T*)r, p, (const double*)sc.beta, n, L.ld, L.nvec,
-                       sc, i, tol, 1);
+    hipLaunchKernelGGL((cg_pupdate_kernel<T>), dim3(pgrid + 1), blk, 0, st, (const T*)r, p, (const double*)sc.beta, n, L.ld, L.nvec,
+                       sc, i, tol, 2);      // (+ the workgroup of the residual norms: cg_group_err_body)
     GLX_HIP(hipGetLastError());
     return GLX_OK;
   };
