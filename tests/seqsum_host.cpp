@@ -99,3 +99,44 @@ extern "C" double ss_host_walk(const double* x, int64_t n, double noise, int64_t
   }
   return s;
 }
+
+// A census of the blocks of one column (tests/seqsum_census.py): out[0] plain, [1] empty, [2] through a record with splits, [3] record
+// refused by the exact state, [4] prepared as "row by row", [5] plain but refused.  verbose: why the row-by-row blocks are what they are.
+#include <stdio.h>
+// Per column walk: classify blocks. Emulates device prefix: group sums (4 blocks) prefix + in-group run prefix.
+extern "C" void ss_host_census(const double* x, int64_t n, int64_t stride, int64_t* out /*[8]*/, int verbose) {
+  const int64_t nchunks = (n + (int64_t)SS_BLOCK * 64 - 1) / ((int64_t)SS_BLOCK * 64);
+  const int64_t nb = nchunks * 64, nsub = nb * SS_Q;
+  std::vector<double> xs(nb * SS_BLOCK, 0.0);
+  for (int64_t i = 0; i < n; ++i) xs[i] = x[i * stride];
+  std::vector<double> apx(nsub + 1, 0.0);
+  for (int64_t q = 0; q < nsub; ++q) { double t = 0; for (int i = 0; i < SS_SUB; ++i) t += xs[q * SS_SUB + i]; apx[q + 1] = apx[q] + t; }
+  double s = 0.0;
+  // out: 0 plain, 1 any(empty), 2 rec ok, 3 rec failed->rows, 4 BAD->rows, 5 plain-but-mismatch->rows...
+  for (int k = 0; k < 8; ++k) out[k] = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    SsRec rec;
+    const int64_t left = n - b * SS_BLOCK;
+    const int len = left <= 0 ? 0 : (left < SS_BLOCK ? (int)left : SS_BLOCK);
+    ss_block_record(&xs[b * SS_BLOCK], 1, len, &apx[b * SS_Q], &rec);
+    int cls;
+    double s0 = s;
+    if (rec.E[0] == SS_E_ANY) cls = 1;
+    else if (rec.E[0] == SS_E_BAD) cls = 4;
+    else if (ss_apply_record(&s, &rec)) cls = rec.nsplit ? 2 : 0;
+    else cls = rec.nsplit ? 3 : 5;
+    if (cls >= 3) {
+      for (int i = 0; i < SS_BLOCK; ++i) s = s + xs[b * SS_BLOCK + i];
+      if (verbose) {
+        // why BAD: count sub-records bad, splits
+        int nbad = 0, nspl = 0;
+        for (int q = 0; q < SS_Q; ++q) { SsRec r; ss_sub_record(&xs[b * SS_BLOCK + q * SS_SUB], SS_SUB, apx[b * SS_Q + q], &r); if (r.E[0] == SS_E_BAD) nbad++; else if (r.E[0] >= 0) nspl += r.nsplit; }
+        // count binade changes of exact chain inside the block and sign changes
+        double t = s0; int nbin = 0;
+        for (int i = 0; i < SS_BLOCK; ++i) { double u = t + xs[b * SS_BLOCK + i]; if (ss_expo(u) != ss_expo(t) || (u < 0) != (t < 0)) nbin++; t = u; }
+        printf("  blk %lld cls %d s0 %.6e -> %.6e  subBAD %d splits %d binade changes %d  apx %.6e\n", (long long)b, cls, s0, s, nbad, nspl, nbin, apx[b * SS_Q]);
+      }
+    }
+    out[cls]++;
+  }
+}
