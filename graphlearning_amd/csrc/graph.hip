@@ -737,18 +737,14 @@ int glx_download(void* dst, const void* src, size_t bytes, hipStream_t st, const
     size_t half = (size_t)1 << 18;
     while (half < bytes + shift && half < HALF_MAX) half <<= 1;
     if (w->bytes < 2 * half) {
-      if (w->stage) {
-        for (int i = 0; i < 2; ++i)
-          if (w->ev[i]) GLX_HIP(hipEventSynchronize(w->ev[i]));
-        hipHostFree(w->stage);
-      }
+      if (w->stage) hipHostFree(w->stage);      // (every upload of this thread ended with its copies complete: upload_staged)
       w->stage = nullptr;
       w->bytes = 0;
       GLX_HIP(hipHostMalloc(&w->stage, 2 * half, hipHostMallocDefault));
       w->bytes = 2 * half;
     }
-    for (int i = 0; i < 2; ++i)
-      if (w->ev[i]) GLX_HIP(hipEventSynchronize(w->ev[i]));        // (no upload of this thread still reads the area)
+    // (no upload of this thread still reads the area -- and no event of an earlier call is waited for here either: the stream it was
+    // recorded on may be gone, and the runtime's hipEventSynchronize looks at that stream; see upload_staged)
     const size_t room = (w->bytes / 2 - shift) / 64 * 64;
     unsigned long long want = 0, got = 0;
     if (check) {

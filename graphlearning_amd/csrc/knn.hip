@@ -445,8 +445,12 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
   if (short_lists && rows.size() > 64) {
     // repair row by row, or search again with the long lists?  A fallback row streams the data once (measured: ~5 TB/s);
     // the repeat costs about four tile-kernel times (fp32-input filter, longer lists)
-    float ms_first = 0;
-    GLX_HIP(hipEventElapsedTime(&ms_first, b.e0, b.e1));
+    // The first pass is priced by a MODEL, not by its measured time: the choice must not depend on who else uses the GPU (with six
+    // processes sharing it the measured pass came out long enough, once in thirty runs, to send 21 000 rows of
+    // tests/test_gpu_knn.py::test_search_on_data_sorted_by_locality through the row-by-row repair -- the right answer, the slow way).
+    // 1.26e10 (query, ref, 16-feature block) triples per ms: config 2's 0.78 ms for 70 000^2 pairs of two blocks.
+    const double share = b.visited ? std::max(g_knn_stats[11], 0.01) : 1.0;
+    const double ms_first = std::max(0.03, (double)nq * (double)n * share * ((double)dpa / 16.0) / 1.26e10);   // (0.03 ms: launches + the host look of a tiny pass)
     const double ms_rows = (double)rows.size() * ((double)n * d * 8.0 / 5e9);        // (one pass per row: knn_fallback_collect_kernel)
     if (ms_rows > 4.0 * ms_first) {
       g_knn_stats[2] = (double)rows.size();
