@@ -115,6 +115,8 @@ def test_identical_however_the_big_transfers_travel(gl, everything_on, mode):
     1 = staged, unchecked; 2 = straight from / into the caller's memory as rounds 1-5 did.  Same results -- and in the default mode the
     walk's transfers were all checked and none differed."""
     from graphlearning_amd import _hip
+    if 'pageableupload' in os.environ.get('GLX_TEST_ABLATE', ''):
+        pytest.skip('the session runs with direct copies (an ablation run): nothing is checked')
     before = _hip.upload_stats()
     assert before['checked'] > 0 and before['wrong_sums'] == 0 and before['given_up'] == 0, before      # (the module's `everything_on` walk)
     _hip.upload_set_mode(mode)
@@ -131,6 +133,8 @@ def test_big_transfers_in_pieces_round_trip(gl):
     not multiples of the piece, through the one entry point that is nothing but upload -> elementwise kernel -> download (glx_exp_cr): a 40 MB
     array gives the same bits as its slices sent one by one, and every transfer was checked."""
     from graphlearning_amd import _hip
+    if 'pageableupload' in os.environ.get('GLX_TEST_ABLATE', ''):
+        pytest.skip('the session runs with direct copies (an ablation run): nothing is checked')
     rng = np.random.default_rng(0)
     x = rng.normal(size=5_000_011) * 3.0
     before = _hip.upload_stats()
