@@ -301,6 +301,28 @@ def main(args):
         if workload != 'connected' and not test_ops:
             Gc = build('connected')
             sides['workload_connected'] = (Gc, side(Gc, 'even'))
+    # The verdict before the line is built: the gathered iterate against the one-process oracle (rank 0).  A library exchange that gives ANOTHER
+    # iterate -- no RCCL peer has ever existed for it -- must not become the line: the ranks agree on the verdict and the measurement is
+    # repeated with the torch.distributed engine, the line says so (`parity_refit`).  GLX_BENCH_TEST_FAIL=parity (a harness variable of
+    # tests/test_gpu_dist.py) takes the verdict of the first measurement as "differs".
+    cpu = parity = T_ref = None
+    parity_refit = None
+    if not test_ops:
+        if rank == 0:
+            cpu, parity, T_ref = bench.cpu_baseline(G['W'], G['train_ind'], G['labels'][G['train_ind']], res['u'], res['T'])
+        verdict = torch.tensor([0 if (rank == 0 and (not parity or os.environ.get('GLX_BENCH_TEST_FAIL') == 'parity')) else 1], dtype=torch.int64, device=dev)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+        if int(verdict.item()) == 0 and engine == 'glx':
+            engine = 'torch'
+            if rank == 0:
+                print('the library\'s own exchange gave an iterate that differs from the oracle: measuring again with the torch.distributed engine',
+                      file=sys.stderr)
+            first_value = args.steps * res['T'] / res['wall']
+            res = measure(G, headline, want_u=True)
+            if rank == 0:
+                cpu, parity, T_ref = bench.cpu_baseline(G['W'], G['train_ind'], G['labels'][G['train_ind']], res['u'], res['T'])
+                parity_refit = {'reason': 'the iterate of the libglx exchange engine differed from the oracle', 'discarded_sweeps_per_sec': first_value,
+                                'measured_again_with': 'torch.distributed all_to_all_single (eager)'}
     if rank == 0:
         prob, n, nnz, W = G['prob'], G['n'], G['nnz'], G['W']
         C = prob['k']
@@ -315,10 +337,6 @@ def main(args):
                if strong else 'vertex-partitioned over %d GPUs (partition `%s`); value = sweeps/s of the whole graph x %d' % (world, res['planner'].get('partition', headline), world))
         xch = ('one halo exchange of boundary vertex records per sweep (RCCL all-to-all-v: grouped ncclSend/ncclRecv)' if res['global_halo'] > 0 and world > 1
                else ('one rank: no peers' if world == 1 else 'no halo (every rank owns whole pieces): no per-sweep exchange'))
-        if test_ops:
-            cpu, parity, T_ref = None, None, None
-        else:
-            cpu, parity, T_ref = bench.cpu_baseline(W, G['train_ind'], G['labels'][G['train_ind']], res['u'], T)
         value = iters if strong else iters * world
         line = {
             'metric': 'Poisson iters/sec', 'value': value, 'unit': 'iters/s' if strong else 'iters/s (70000-vertex-graph equivalents)',
@@ -341,6 +359,7 @@ def main(args):
             'speedup_vs_cpu_baseline': (value / cpu['value']) if cpu else None,
             'parity': None if test_ops else {'bit_identical_to_oracle': parity, 'T': T, 'T_oracle': T_ref,
                                              'note': 'the iterate of the last timed step, every rank\'s rows gathered, against the one-process scipy oracle'},
+            'parity_refit': parity_refit,
             'halo': {'rows_per_rank': res['halo_rows'], 'owned_per_rank': res['owned'], 'boundary_rows_per_rank': res['boundary'],
                      'exchanges_per_sweep': exchanges_per_sweep, 'global_halo_rows': res['global_halo']},
             'sweep_parts_rank0_us': res['parts_rank0'],
