@@ -780,7 +780,8 @@ def run_single(args):
     line = {
         'metric': 'Poisson iters/sec', 'value': value, 'unit': 'iters/s', 'n_gpus': 1, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': r64['wall'] / args.steps * 1e3, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        # (one GPU: strong and weak coincide; the label follows the family of lines this one starts: --scaling, default strong = the ONE graph over N GPUs)
+        'scaling': getattr(args, 'scaling', 'strong'), 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'configs[1]: MNIST-shaped k=10 kNN graph, n=70000, nnz=%d, C=10, ssl.poisson '
                                'gradient_descent (T=%d sweeps per step, stop test included)' % (nnz, T),
                    'n': n, 'nnz': int(nnz), 'classes': C, 'sweeps_per_step': T},

@@ -140,11 +140,6 @@ __device__ __forceinline__ void cg_group_err_body(const CgScalars& sc, int it, d
     sc.err_hist[(size_t)it * sc.stride + sc.ngroups] = m;
   }
 }
-__global__ __launch_bounds__(256) void cg_group_err_kernel(CgScalars sc, int it, double tol) {
-  __shared__ double s_e[256];
-  cg_group_err_body(sc, it, tol, s_e);
-}
-
 // p = r + beta p                                                          (utils.py:529)
 template <typename T>
 __global__ __launch_bounds__(256) void cg_pupdate_kernel(const T* __restrict__ r, T* __restrict__ p,
