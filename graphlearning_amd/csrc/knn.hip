@@ -450,7 +450,8 @@ static int knn_pass(const double* X, int64_t n, int d, int k, int64_t q0, int64_
     // tests/test_gpu_knn.py::test_search_on_data_sorted_by_locality through the row-by-row repair -- the right answer, the slow way).
     // 1.26e10 (query, ref, 16-feature block) triples per ms: config 2's 0.78 ms for 70 000^2 pairs of two blocks.
     const double share = b.visited ? std::max(g_knn_stats[11], 0.01) : 1.0;
-    const double ms_first = std::max(0.03, (double)nq * (double)n * share * ((double)dpa / 16.0) / 1.26e10);   // (0.03 ms: launches + the host look of a tiny pass)
+    // (the fp32-input filter runs at a quarter of that: profiles/r02_knn_filter_probe.txt, d = 64 / 128; 0.03 ms: launches + the host look of a tiny pass)
+    const double ms_first = std::max(0.03, (double)nq * (double)n * share * ((double)dpa / 16.0) / 1.26e10 * (use_bf16 ? 1.0 : 4.0));
     const double ms_rows = (double)rows.size() * ((double)n * d * 8.0 / 5e9);        // (one pass per row: knn_fallback_collect_kernel)
     if (ms_rows > 4.0 * ms_first) {
       g_knn_stats[2] = (double)rows.size();
