@@ -346,3 +346,52 @@ def test_exact_mode_form_switch_maps_to_the_cabi_flags(monkeypatch):
     monkeypatch.setattr(_hip, 'CG_EXACT_FORM', 'fast')
     with pytest.raises(_hip.GlxError):
         _hip._reduce_flag('exact')
+
+
+def test_captured_launch_sequences_hold_no_memset_node():
+    """Round 6 (profiles/r06_graph_memset_probe.txt): on the HIP runtime bundled with PyTorch a memset NODE of a replayed launch graph writes the
+    value of the process's last eager hipMemset.  Whatever the library enqueues between hipStreamBeginCapture and hipStreamEndCapture therefore
+    clears memory with a kernel (glx_zero_async).  A source check: the functions that are captured contain no hipMemset call."""
+    csrc = os.path.join(ROOT, 'graphlearning_amd', 'csrc')
+
+    def body(fname, start, end):
+        text = open(os.path.join(csrc, fname)).read()
+        i = text.index(start)
+        return text[i:text.index(end, i + len(start))]
+
+    captured = {
+        'solver.hip: enqueue_head': body('solver.hip', 'static int enqueue_head(glx_sweep* s)', 'extern "C" int glx_sweep_run'),
+        'solver.hip: launch_sweep': body('solver.hip', 'static int launch_sweep(', 'static int enqueue_head('),
+        'groups.hip: grp_launch_sweep + grp_enqueue_head': body('groups.hip', 'static int grp_launch_sweep(', 'static double grp_err_value('),
+        'cg.hip: enqueue_iteration + enqueue_chunk': body('cg.hip', 'auto enqueue_iteration = ', '// Full chunks are replayed from a captured launch sequence'),
+        'cg_fused.hip: enqueue_chunk': body('cg_fused.hip', 'auto enqueue_chunk = ', 'hipStreamBeginCapture'),
+        'dist.hip: enqueue_reset .. enqueue_sweep helpers': body('dist.hip', 'static int enqueue_reset(', 'static int ensure_ring('),
+    }
+    for name, text in captured.items():
+        code = '\n'.join(line.split('//')[0] for line in text.splitlines())
+        assert 'hipMemset' not in code, name
+    # the lambdas handed to run_captured (dist.hip): from the call to the closing of the lambda
+    text = open(os.path.join(csrc, 'dist.hip')).read()
+    for m in re.finditer(r'run_captured\(s, \{[^}]*\}, \[&\]\(\) -> int \{', text):
+        lam = text[m.end():text.index('});', m.end())]
+        assert 'hipMemset' not in '\n'.join(line.split('//')[0] for line in lam.splitlines()), lam[:200]
+    assert 'glx_zero_async' in captured['solver.hip: enqueue_head'] and 'glx_zero_async' in captured['groups.hip: grp_launch_sweep + grp_enqueue_head']
+
+
+def test_block_census_agrees_with_the_walk():
+    """tests/seqsum_census.py's classifier (ss_host_census) and the lane-for-lane restatement of the device walk (ss_host_walk) count the same
+    blocks on the same column: plain + empty = the walk's plain, record, row by row."""
+    import ctypes, subprocess, tempfile
+    lib = os.path.join(tempfile.mkdtemp(), 'libss_census.so')
+    subprocess.run(['g++', '-O2', '-ffp-contract=off', '-shared', '-fPIC', '-o', lib, os.path.join(ROOT, 'tests', 'seqsum_host.cpp')], check=True)
+    L = ctypes.CDLL(lib)
+    L.ss_host_walk.restype = ctypes.c_double
+    rng = np.random.default_rng(5)
+    for x in (rng.normal(size=40000) ** 2, rng.normal(size=40000) * rng.normal(size=40000) + 0.05, np.concatenate([np.zeros(3000), rng.random(20000)])):
+        x = np.ascontiguousarray(x)
+        out = (ctypes.c_int64 * 8)()
+        L.ss_host_census(ctypes.c_void_p(x.ctypes.data), ctypes.c_int64(x.size), ctypes.c_int64(1), out, 0)
+        st = (ctypes.c_int64 * 3)()
+        L.ss_host_walk(ctypes.c_void_p(x.ctypes.data), ctypes.c_int64(x.size), ctypes.c_double(0.0), st)
+        c = list(out)
+        assert c[0] + c[1] == st[0] and c[2] == st[1] and c[3] + c[4] + c[5] == st[2], (c, list(st))
