@@ -112,7 +112,10 @@ int glx_sweep_set_problem(glx_sweep* s, const void* Db, const double* w0, const 
 int glx_sweep_set_vectors(glx_sweep* s, const double* deg, const double* vinf);
 int glx_sweep_set_problem_rows(glx_sweep* s, int64_t m, const int64_t* rows, const void* Db_rows,
                                const double* w0_rows, double err0);
-int glx_sweep_run(glx_sweep* s, int* T_out, float* device_ms_out);   /* all iterations on device; HIP-event time */
+int glx_sweep_run(glx_sweep* s, int* T_out, float* device_ms_out);   /* all iterations on device; HIP-event time.  With use_hipgraph the
+                                                                        * FIRST run of the object launches its sweeps one by one and the launch
+                                                                        * graph is captured on the second (a model fitted once never earns the
+                                                                        * capture back); the iterates do not depend on the form. */
 /* The stop values the last glx_sweep_run compared with 1/n (ssl.py:667): vals[i] = max|v_t - v_inf| for t = *first + i,
  * i < *count, the last one being the value that ended the loop (absent when max_iter did).  vals may be NULL to query
  * the counts.  The fused column computes them as deg*(P w), the reference as RW*v (ssl.py:669): equal up to rounding, so
